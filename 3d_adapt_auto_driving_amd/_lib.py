@@ -1,0 +1,84 @@
+"""ctypes binding of libprcnn_hip.so -- the C ABI declared in include/prcnn_hip.h.
+
+There is NO fallback: if the shared library is missing or an entry point fails, an exception is
+raised.  Nothing in this package imports the CPU oracle.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libprcnn_hip.so")
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+
+# name -> argument types (return type is always int except where noted)
+SIGNATURES = {
+    "prcnn_version": [],
+    "prcnn_opt_n_threads": [_I],
+    "prcnn_ball_query": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
+    "prcnn_group_points": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "prcnn_group_points_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "prcnn_gather_points": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "prcnn_gather_points_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "prcnn_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],
+    "prcnn_three_nn": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "prcnn_three_interpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "prcnn_three_interpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "prcnn_query_and_group": [_I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
+    "prcnn_boxes_overlap_bev": [_I, _P, _I, _P, _P, _P],
+    "prcnn_boxes_iou_bev": [_I, _P, _I, _P, _P, _P],
+    "prcnn_nms": [_I, _P, _P, _F, _P],
+    "prcnn_nms_normal": [_I, _P, _P, _F, _P],
+    "prcnn_nms_device": [_I, _I, _P, _P, _F, _I, _I, _P, _P, _P],
+    "prcnn_roipool3d": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "prcnn_rotate_iou_eval": [_I, _I, _P, _P, _P, _I, _P],
+}
+
+_lib = None
+
+
+class PrcnnError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libprcnn_hip.so (once).  Raises if it has not been built: build it with
+    ``python __graft_entry__.py`` or ``make -C 3d_adapt_auto_driving_amd/csrc``."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PrcnnError("%s not found: the HIP extension is not built (no CPU fallback exists)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+            fn.argtypes = argtypes
+            fn.restype = _I
+        lib.prcnn_last_error.restype = C.c_char_p
+        lib.prcnn_last_error.argtypes = []
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().prcnn_last_error().decode("utf-8", "replace")
+
+
+def call(name, *args):
+    """Call an entry point; a negative return code raises PrcnnError with the library's message."""
+    rc = getattr(load(), name)(*args)
+    if rc < 0:
+        raise PrcnnError("%s failed (%d): %s" % (name, rc, last_error()))
+    return rc
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(t):
+    """hipStream_t of torch's current stream on the tensor's device, as an int."""
+    import torch
+    return torch.cuda.current_stream(t.device).cuda_stream

@@ -1,0 +1,286 @@
+// ball_group.hip -- ball query (K1), grouping (K2/K3), gather (K4/K5) and the fused
+// QueryAndGroup path for gfx950.
+//
+// Reference behaviour restated (never copied): pointnet2_lib/pointnet2/src/ball_query_gpu.cu:9-45,
+// group_points_gpu.cu:8-66, sampling_gpu.cu:8-63, pointnet2_utils.py:241-264.
+//
+// Ball query design (wave64, brute force but index-order exact):
+//   * one lane owns one query centre for the whole scan; the cloud point is wave-uniform, so it
+//     is fetched with SCALAR loads (s_load_dwordx4) and used as an SGPR operand of the VALU
+//     distance ops -- no LDS or vector-memory traffic in the inner loop;
+//   * a workgroup = NSEG waves that own the SAME 64 centres but disjoint, contiguous index
+//     segments of the cloud (fills the chip when b*m/64 alone is < #SIMDs);
+//   * each wave appends its hits (already in index order) to an LDS list laid out
+//     [segment][slot][lane] (bank = lane -> conflict free) and stops early once all of its
+//     lanes hold nsample hits;
+//   * after one barrier the segment lists are concatenated in segment order = global index
+//     order, truncated to nsample and back-filled with the first hit, and written with fully
+//     coalesced stores.
+#include "common.hpp"
+
+namespace prcnn {
+
+template <int NSEG>
+__global__ __launch_bounds__(64 * NSEG) void ball_query_kernel(
+    int n, int m, float r2, int nsample, const float *__restrict__ new_xyz,
+    const float *__restrict__ xyz, int *__restrict__ idx, int write_empty)
+{
+    extern __shared__ int lds[];  // [NSEG][nsample][64] hits, then [NSEG][64] counts
+    int *counts = lds + NSEG * nsample * 64;
+
+    const int b = blockIdx.y;
+    const int c0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63;
+    const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = c0 + lane;
+    const bool valid = p < m;
+
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    if (valid) {
+        const float *c = new_xyz + ((long)b * m + p) * 3;
+        cx = c[0]; cy = c[1]; cz = c[2];
+    }
+    const float *__restrict__ cloud = xyz + (long)b * n * 3;
+    const int seg_len = (n + NSEG - 1) / NSEG;
+    const int k0 = seg * seg_len;
+    const int k1 = min(n, k0 + seg_len);
+
+    int cnt = valid ? 0 : nsample;  // lanes past m never record anything
+    int *myhits = lds + seg * nsample * 64 + lane;
+
+    for (int kb = k0; kb < k1; kb += 64) {
+        if (__all(cnt >= nsample)) break;
+        const int ke = min(k1, kb + 64);
+#pragma unroll 4
+        for (int k = kb; k < ke; ++k) {
+            // wave-uniform address -> scalar loads
+            const float x = cloud[3 * k], y = cloud[3 * k + 1], z = cloud[3 * k + 2];
+            const float d2 = sqdist3(cx, cy, cz, x, y, z);
+            if (d2 < r2 && cnt < nsample) {
+                myhits[cnt * 64] = k;
+                ++cnt;
+            }
+        }
+    }
+    counts[seg * 64 + lane] = valid ? cnt : 0;
+    __syncthreads();
+
+    // merge: element e = (centre cl, slot s); consecutive e -> consecutive idx addresses
+    const int total_e = min(64, m - c0) * nsample;
+    int *out = idx + ((long)b * m + c0) * nsample;
+    for (int e = threadIdx.x; e < total_e; e += 64 * NSEG) {
+        const int cl = e / nsample;
+        const int s = e - cl * nsample;
+        int tot = 0;
+#pragma unroll
+        for (int g = 0; g < NSEG; ++g) tot += counts[g * 64 + cl];
+        if (tot == 0) {
+            if (write_empty) out[e] = 0;
+            continue;
+        }
+        int want = s < tot ? s : 0;  // slots past the hit count repeat the first hit
+        int v = 0;
+#pragma unroll
+        for (int g = 0; g < NSEG; ++g) {
+            const int cg = counts[g * 64 + cl];
+            if (want >= 0 && want < cg) v = lds[(g * nsample + want) * 64 + cl];
+            want -= cg;  // becomes negative once consumed
+        }
+        out[e] = v;
+    }
+}
+
+// K2: out[b][c][slot] = points[b][c][idx[b][slot]]
+__global__ __launch_bounds__(256) void group_points_kernel(
+    int c, int n, long slots, const float *__restrict__ points, const int *__restrict__ idx,
+    float *__restrict__ out)
+{
+    const int b = blockIdx.z;
+    const int ci = blockIdx.y;
+    const long s = (long)blockIdx.x * 256 + threadIdx.x;
+    if (s >= slots) return;
+    const int k = idx[(long)b * slots + s];
+    out[((long)b * c + ci) * slots + s] = points[((long)b * c + ci) * n + k];
+}
+
+// K3: grad_points[b][c][idx[b][slot]] += grad_out[b][c][slot]
+__global__ __launch_bounds__(256) void group_points_grad_kernel(
+    int c, int n, long slots, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    float *__restrict__ grad_points)
+{
+    const int b = blockIdx.z;
+    const int ci = blockIdx.y;
+    const long s = (long)blockIdx.x * 256 + threadIdx.x;
+    if (s >= slots) return;
+    const int k = idx[(long)b * slots + s];
+    atomicAdd(grad_points + ((long)b * c + ci) * n + k, grad_out[((long)b * c + ci) * slots + s]);
+}
+
+// Fused grouping for QueryAndGroup: one thread per (centre, sample) slot walks the channels.
+// Channel 0..2 = xyz[idx] - new_xyz (exact f32 subtract), 3.. = features[idx].
+__global__ __launch_bounds__(256) void group_cat_kernel(
+    int n, int m, int c, int nsample, const float *__restrict__ new_xyz,
+    const float *__restrict__ xyz, const float *__restrict__ features,
+    const int *__restrict__ idx, float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const long slots = (long)m * nsample;
+    const long s = (long)blockIdx.x * 256 + threadIdx.x;
+    if (s >= slots) return;
+    const int p = (int)(s / nsample);
+    const int k = idx[(long)b * slots + s];
+    const float *pt = xyz + ((long)b * n + k) * 3;
+    const float *ct = new_xyz + ((long)b * m + p) * 3;
+    float *o = out + (long)b * (3 + c) * slots + s;
+    o[0] = pt[0] - ct[0];
+    o[slots] = pt[1] - ct[1];
+    o[2 * slots] = pt[2] - ct[2];
+    const float *f = features + (long)b * c * n + k;
+    o += 3 * slots;
+    for (int ci = 0; ci < c; ++ci) o[(long)ci * slots] = f[(long)ci * n];
+}
+
+// K4 / K5
+__global__ __launch_bounds__(256) void gather_points_kernel(
+    int c, int n, int m, const float *__restrict__ points, const int *__restrict__ idx,
+    float *__restrict__ out)
+{
+    const int b = blockIdx.z, ci = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= m) return;
+    out[((long)b * c + ci) * m + p] = points[((long)b * c + ci) * n + idx[(long)b * m + p]];
+}
+
+__global__ __launch_bounds__(256) void gather_points_grad_kernel(
+    int c, int n, int m, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    float *__restrict__ grad_points)
+{
+    const int b = blockIdx.z, ci = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= m) return;
+    atomicAdd(grad_points + ((long)b * c + ci) * n + idx[(long)b * m + p],
+              grad_out[((long)b * c + ci) * m + p]);
+}
+
+static int pick_nseg(int b, int n, int m, int nsample)
+{
+    const long groups = (long)b * ceil_div(m, 64);
+    int nseg = 1;
+    // aim for >= 2048 waves (2 per SIMD on 256 CUs), keep segments >= 256 points and the hit
+    // lists within 128 KiB of LDS
+    while (nseg < 8 && groups * nseg < 2048 && n / (nseg * 2) >= 256 &&
+           (long)(nseg * 2) * nsample * 256 + (long)(nseg * 2) * 256 <= 128 * 1024)
+        nseg *= 2;
+    return nseg;
+}
+
+template <int NSEG>
+static int launch_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                             const float *xyz, int *idx, int write_empty, hipStream_t st)
+{
+    const size_t lds = ((size_t)NSEG * nsample * 64 + (size_t)NSEG * 64) * sizeof(int);
+    static size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+        if (hipFuncSetAttribute((const void *)ball_query_kernel<NSEG>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("ball_query: cannot reserve %zu bytes of LDS", lds);
+            return PRCNN_ELAUNCH;
+        }
+        configured = lds;
+    }
+    dim3 grid(ceil_div(m, 64), b);
+    hipLaunchKernelGGL(ball_query_kernel<NSEG>, grid, dim3(64 * NSEG), lds, st, n, m,
+                       radius * radius, nsample, new_xyz, xyz, idx, write_empty);
+    return check_launch("ball_query");
+}
+
+static int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                               const float *xyz, int *idx, int write_empty, hipStream_t st)
+{
+    PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample > 0, "ball_query: bad sizes b=%d n=%d m=%d ns=%d", b, n, m, nsample);
+    PRCNN_REQUIRE(nsample <= 256, "ball_query: nsample=%d > 256 unsupported", nsample);
+    PRCNN_REQUIRE(b <= 65535, "ball_query: batch %d > 65535", b);
+    if (b == 0 || m == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(new_xyz && xyz && idx, "ball_query: null pointer");
+    switch (pick_nseg(b, n, m, nsample)) {
+        case 1: return launch_ball_query<1>(b, n, m, radius, nsample, new_xyz, xyz, idx, write_empty, st);
+        case 2: return launch_ball_query<2>(b, n, m, radius, nsample, new_xyz, xyz, idx, write_empty, st);
+        case 4: return launch_ball_query<4>(b, n, m, radius, nsample, new_xyz, xyz, idx, write_empty, st);
+        default: return launch_ball_query<8>(b, n, m, radius, nsample, new_xyz, xyz, idx, write_empty, st);
+    }
+}
+
+}  // namespace prcnn
+
+using namespace prcnn;
+
+extern "C" int prcnn_ball_query(int b, int n, int m, float radius, int nsample,
+                                const float *new_xyz, const float *xyz, int *idx, void *stream)
+{
+    return ball_query_dispatch(b, n, m, radius, nsample, new_xyz, xyz, idx, 0, (hipStream_t)stream);
+}
+
+extern "C" int prcnn_group_points(int b, int c, int n, int npoints, int nsample,
+                                  const float *points, const int *idx, float *out, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, "group_points: bad sizes");
+    PRCNN_REQUIRE(b <= 65535 && c <= 65535, "group_points: b/c > 65535");
+    const long slots = (long)npoints * nsample;
+    if (b == 0 || c == 0 || slots == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(points && idx && out, "group_points: null pointer");
+    dim3 grid(ceil_div(slots, 256), c, b);
+    hipLaunchKernelGGL(group_points_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, slots, points, idx, out);
+    return check_launch("group_points");
+}
+
+extern "C" int prcnn_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                                       const float *grad_out, const int *idx, float *grad_points, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, "group_points_grad: bad sizes");
+    PRCNN_REQUIRE(b <= 65535 && c <= 65535, "group_points_grad: b/c > 65535");
+    const long slots = (long)npoints * nsample;
+    if (b == 0 || c == 0 || slots == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(grad_out && idx && grad_points, "group_points_grad: null pointer");
+    dim3 grid(ceil_div(slots, 256), c, b);
+    hipLaunchKernelGGL(group_points_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, slots, grad_out, idx, grad_points);
+    return check_launch("group_points_grad");
+}
+
+extern "C" int prcnn_gather_points(int b, int c, int n, int npoints,
+                                   const float *points, const int *idx, float *out, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0, "gather_points: bad sizes");
+    PRCNN_REQUIRE(b <= 65535 && c <= 65535, "gather_points: b/c > 65535");
+    if (b == 0 || c == 0 || npoints == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(points && idx && out, "gather_points: null pointer");
+    dim3 grid(ceil_div(npoints, 256), c, b);
+    hipLaunchKernelGGL(gather_points_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, npoints, points, idx, out);
+    return check_launch("gather_points");
+}
+
+extern "C" int prcnn_gather_points_grad(int b, int c, int n, int npoints,
+                                        const float *grad_out, const int *idx, float *grad_points, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0, "gather_points_grad: bad sizes");
+    PRCNN_REQUIRE(b <= 65535 && c <= 65535, "gather_points_grad: b/c > 65535");
+    if (b == 0 || c == 0 || npoints == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(grad_out && idx && grad_points, "gather_points_grad: null pointer");
+    dim3 grid(ceil_div(npoints, 256), c, b);
+    hipLaunchKernelGGL(gather_points_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, npoints, grad_out, idx, grad_points);
+    return check_launch("gather_points_grad");
+}
+
+extern "C" int prcnn_query_and_group(int b, int n, int m, int c, float radius, int nsample,
+                                     const float *new_xyz, const float *xyz, const float *features,
+                                     int *idx, float *out, void *stream)
+{
+    PRCNN_REQUIRE(c >= 0 && (c == 0 || features), "query_and_group: features missing for c=%d", c);
+    PRCNN_REQUIRE(idx && out, "query_and_group: idx/out must be provided");
+    PRCNN_REQUIRE(n > 0 || m == 0, "query_and_group: empty cloud");
+    int rc = ball_query_dispatch(b, n, m, radius, nsample, new_xyz, xyz, idx, 1, (hipStream_t)stream);
+    if (rc != PRCNN_OK || b == 0 || m == 0) return rc;
+    dim3 grid(ceil_div((long)m * nsample, 256), b);
+    hipLaunchKernelGGL(group_cat_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, m, c, nsample,
+                       new_xyz, xyz, features, idx, out);
+    return check_launch("query_and_group");
+}

@@ -1,0 +1,129 @@
+// interp.hip -- three_nn (K7), three_interpolate (K8) and its gradient (K9) for gfx950.
+//
+// Reference behaviour restated: pointnet2_lib/pointnet2/src/interpolate_gpu.cu:9-52, :77-97,
+// :120-142.  three_nn keeps the three smallest squared distances with strict '<' (lowest index
+// wins ties).  The reference compares an f32 candidate against double bests initialised to
+// 1e40; every stored best is an f32 value, so f32 comparisons against +inf are equivalent and
+// an untouched slot reads back as (float)1e40 = +inf either way.
+//
+// Design: one lane per unknown point; the known point is wave-uniform and comes in through
+// scalar loads, so the inner loop is pure VALU (8 distance ops + the 3-deep insertion).
+#include "common.hpp"
+#include <math.h>
+
+namespace prcnn {
+
+__global__ __launch_bounds__(256) void three_nn_kernel(
+    int n, int m, const float *__restrict__ unknown, const float *__restrict__ known,
+    float *__restrict__ dist2, int *__restrict__ idx)
+{
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = p < n;
+    float ux = 0.f, uy = 0.f, uz = 0.f;
+    if (valid) {
+        const float *u = unknown + ((long)b * n + p) * 3;
+        ux = u[0]; uy = u[1]; uz = u[2];
+    }
+    const float *__restrict__ kn = known + (long)b * m * 3;
+    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+    int i1 = 0, i2 = 0, i3 = 0;
+#pragma unroll 4
+    for (int k = 0; k < m; ++k) {
+        const float d = sqdist3(ux, uy, uz, kn[3 * k], kn[3 * k + 1], kn[3 * k + 2]);
+        if (d < b1) {
+            b3 = b2; i3 = i2;
+            b2 = b1; i2 = i1;
+            b1 = d; i1 = k;
+        } else if (d < b2) {
+            b3 = b2; i3 = i2;
+            b2 = d; i2 = k;
+        } else if (d < b3) {
+            b3 = d; i3 = k;
+        }
+    }
+    if (valid) {
+        float *od = dist2 + ((long)b * n + p) * 3;
+        int *oi = idx + ((long)b * n + p) * 3;
+        od[0] = b1; od[1] = b2; od[2] = b3;
+        oi[0] = i1; oi[1] = i2; oi[2] = i3;
+    }
+}
+
+// out[b][c][p] = w0*f[i0] + w1*f[i1] + w2*f[i2]  (left to right, no fma)
+__global__ __launch_bounds__(256) void three_interpolate_kernel(
+    int c, int m, int n, const float *__restrict__ points, const int *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ out)
+{
+    const int b = blockIdx.z;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int *ix = idx + ((long)b * n + p) * 3;
+    const float *w = weight + ((long)b * n + p) * 3;
+    const int i0 = ix[0], i1 = ix[1], i2 = ix[2];
+    const float w0 = w[0], w1 = w[1], w2 = w[2];
+    // blockIdx.y walks channel groups so that idx/weight are read once per 8 channels
+    const int c0 = blockIdx.y * 8;
+    const int c1 = min(c, c0 + 8);
+    for (int ci = c0; ci < c1; ++ci) {
+        const float *f = points + ((long)b * c + ci) * m;
+        const float v = __fadd_rn(__fadd_rn(__fmul_rn(w0, f[i0]), __fmul_rn(w1, f[i1])), __fmul_rn(w2, f[i2]));
+        out[((long)b * c + ci) * n + p] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
+    int c, int n, int m, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ grad_points)
+{
+    const int b = blockIdx.z, ci = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int *ix = idx + ((long)b * n + p) * 3;
+    const float *w = weight + ((long)b * n + p) * 3;
+    const float g = grad_out[((long)b * c + ci) * n + p];
+    float *dst = grad_points + ((long)b * c + ci) * m;
+    atomicAdd(dst + ix[0], g * w[0]);
+    atomicAdd(dst + ix[1], g * w[1]);
+    atomicAdd(dst + ix[2], g * w[2]);
+}
+
+}  // namespace prcnn
+
+using namespace prcnn;
+
+extern "C" int prcnn_three_nn(int b, int n, int m, const float *unknown, const float *known,
+                              float *dist2, int *idx, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "three_nn: bad sizes");
+    PRCNN_REQUIRE(b <= 65535, "three_nn: batch > 65535");
+    if (b == 0 || n == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(unknown && dist2 && idx && (known || m == 0), "three_nn: null pointer");
+    dim3 grid(ceil_div(n, 256), b);
+    hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, m, unknown, known, dist2, idx);
+    return check_launch("three_nn");
+}
+
+extern "C" int prcnn_three_interpolate(int b, int c, int m, int n, const float *points,
+                                       const int *idx, const float *weight, float *out, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && c >= 0 && n >= 0 && m >= 0, "three_interpolate: bad sizes");
+    PRCNN_REQUIRE(b <= 65535 && c <= 65535 * 8, "three_interpolate: b/c too large");
+    if (b == 0 || c == 0 || n == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(points && idx && weight && out, "three_interpolate: null pointer");
+    dim3 grid(ceil_div(n, 256), ceil_div(c, 8), b);
+    hipLaunchKernelGGL(three_interpolate_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, m, n, points, idx, weight, out);
+    return check_launch("three_interpolate");
+}
+
+extern "C" int prcnn_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                            const int *idx, const float *weight, float *grad_points, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && c >= 0 && n >= 0 && m >= 0, "three_interpolate_grad: bad sizes");
+    PRCNN_REQUIRE(b <= 65535 && c <= 65535, "three_interpolate_grad: b/c too large");
+    if (b == 0 || c == 0 || n == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(grad_out && idx && weight && grad_points, "three_interpolate_grad: null pointer");
+    dim3 grid(ceil_div(n, 256), c, b);
+    hipLaunchKernelGGL(three_interpolate_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points);
+    return check_launch("three_interpolate_grad");
+}

@@ -1,0 +1,408 @@
+// iou3d.hip -- BEV rotated overlap / IoU (K10, K11), rotated and axis-aligned greedy NMS
+// (K12, K13) for gfx950.
+//
+// Reference behaviour restated: lib/utils/iou3d/src/iou3d_kernel.cu:14-348 and the host greedy
+// reduce of iou3d.cpp:73-170.
+//
+// NMS design.  The reference builds the full n x n/64 suppression mask on the device, copies it
+// to the host and reduces it serially there (3 round trips per scene in eval_rcnn).  Here one
+// workgroup per problem walks the score-sorted boxes in blocks of 64 rows and evaluates IoUs
+// LAZILY: for row block r it computes, for every still-alive later column, the 64-bit word
+// "which rows of block r suppress me" (rows staged in LDS, one column per lane), resolves the
+// 64 rows of the block serially against the already-known words (same order as the host loop),
+// then kills the columns suppressed by the rows that were kept.  It stops as soon as
+// `max_keep` boxes are kept -- the proposal layer only ever uses the first 70/30 -- and the
+// kept list is, by construction, the prefix of the reference's list.  No host round trip, no
+// mask in HBM.
+#include "common.hpp"
+#include <math.h>
+#include <stdlib.h>
+
+namespace prcnn {
+
+struct P2 {
+    float x, y;
+};
+
+#define IOU_EPS 1e-8f
+
+__device__ __forceinline__ float cross3(P2 p1, P2 p2, P2 p0)
+{
+    return __fsub_rn(__fmul_rn(p1.x - p0.x, p2.y - p0.y), __fmul_rn(p2.x - p0.x, p1.y - p0.y));
+}
+
+// iou3d_kernel.cu:73-106: (p0,p1) is an edge of a, (q0,q1) an edge of b
+__device__ __forceinline__ bool seg_intersection(P2 p1, P2 p0, P2 q1, P2 q0, P2 &ans)
+{
+    if (!(fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) &&
+          fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) && fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y)))
+        return false;
+    const float s1 = cross3(q0, p1, p0);
+    const float s2 = cross3(p1, q1, p0);
+    const float s3 = cross3(p0, q1, q0);
+    const float s4 = cross3(q1, p1, q0);
+    if (!(__fmul_rn(s1, s2) > 0 && __fmul_rn(s3, s4) > 0)) return false;
+    const float s5 = cross3(q1, p1, p0);
+    if (fabsf(s5 - s1) > IOU_EPS) {
+        ans.x = __fdiv_rn(__fsub_rn(__fmul_rn(s5, q0.x), __fmul_rn(s1, q1.x)), s5 - s1);
+        ans.y = __fdiv_rn(__fsub_rn(__fmul_rn(s5, q0.y), __fmul_rn(s1, q1.y)), s5 - s1);
+    } else {
+        const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = __fsub_rn(__fmul_rn(p0.x, p1.y), __fmul_rn(p1.x, p0.y));
+        const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = __fsub_rn(__fmul_rn(q0.x, q1.y), __fmul_rn(q1.x, q0.y));
+        const float D = __fsub_rn(__fmul_rn(a0, b1), __fmul_rn(a1, b0));
+        ans.x = __fdiv_rn(__fsub_rn(__fmul_rn(b0, c1), __fmul_rn(b1, c0)), D);
+        ans.y = __fdiv_rn(__fsub_rn(__fmul_rn(a1, c0), __fmul_rn(a0, c1)), D);
+    }
+    return true;
+}
+
+// rotate p about c by (cosv, sinv): iou3d_kernel.cu:92-96
+__device__ __forceinline__ P2 rot_about(P2 c, float cosv, float sinv, P2 p)
+{
+    P2 r;
+    r.x = __fadd_rn(__fadd_rn(__fmul_rn(p.x - c.x, cosv), __fmul_rn(p.y - c.y, sinv)), c.x);
+    r.y = __fadd_rn(__fadd_rn(__fmul_rn(-(p.x - c.x), sinv), __fmul_rn(p.y - c.y, cosv)), c.y);
+    return r;
+}
+
+// iou3d_kernel.cu:50-65 with cos(-t) = cos t, sin(-t) = -sin t
+__device__ __forceinline__ bool corner_in_box(const float *box, float cosv, float sinv, P2 p)
+{
+    const float MARGIN = 1e-5f;
+    P2 c = { (box[0] + box[2]) / 2, (box[1] + box[3]) / 2 };
+    const P2 r = rot_about(c, cosv, -sinv, p);
+    return r.x > box[0] - MARGIN && r.x < box[2] + MARGIN && r.y > box[1] - MARGIN && r.y < box[3] + MARGIN;
+}
+
+struct RBox {
+    float v[5];
+    float cosv, sinv;  // of v[4], evaluated once per box
+};
+
+__device__ __forceinline__ RBox make_rbox(const float *p)
+{
+    RBox r;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) r.v[i] = p[i];
+    r.cosv = cos_f32(p[4]);
+    r.sinv = sin_f32(p[4]);
+    return r;
+}
+
+// iou3d_kernel.cu:108-212
+__device__ float rbox_overlap(const RBox &A, const RBox &B)
+{
+    const P2 ca = { (A.v[0] + A.v[2]) / 2, (A.v[1] + A.v[3]) / 2 };
+    const P2 cb = { (B.v[0] + B.v[2]) / 2, (B.v[1] + B.v[3]) / 2 };
+    P2 pa[5], pb[5];
+    pa[0] = rot_about(ca, A.cosv, A.sinv, P2{ A.v[0], A.v[1] });
+    pa[1] = rot_about(ca, A.cosv, A.sinv, P2{ A.v[2], A.v[1] });
+    pa[2] = rot_about(ca, A.cosv, A.sinv, P2{ A.v[2], A.v[3] });
+    pa[3] = rot_about(ca, A.cosv, A.sinv, P2{ A.v[0], A.v[3] });
+    pb[0] = rot_about(cb, B.cosv, B.sinv, P2{ B.v[0], B.v[1] });
+    pb[1] = rot_about(cb, B.cosv, B.sinv, P2{ B.v[2], B.v[1] });
+    pb[2] = rot_about(cb, B.cosv, B.sinv, P2{ B.v[2], B.v[3] });
+    pb[3] = rot_about(cb, B.cosv, B.sinv, P2{ B.v[0], B.v[3] });
+    pa[4] = pa[0];
+    pb[4] = pb[0];
+
+    P2 poly[24];
+    float ang[24];
+    P2 centre = { 0.f, 0.f };
+    int cnt = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            P2 hit;
+            if (seg_intersection(pa[i + 1], pa[i], pb[j + 1], pb[j], hit)) {
+                poly[cnt] = hit;
+                centre.x = centre.x + hit.x;
+                centre.y = centre.y + hit.y;
+                ++cnt;
+            }
+        }
+    for (int k = 0; k < 4; ++k) {
+        if (corner_in_box(A.v, A.cosv, A.sinv, pb[k])) {
+            centre.x = centre.x + pb[k].x; centre.y = centre.y + pb[k].y;
+            poly[cnt++] = pb[k];
+        }
+        if (corner_in_box(B.v, B.cosv, B.sinv, pa[k])) {
+            centre.x = centre.x + pa[k].x; centre.y = centre.y + pa[k].y;
+            poly[cnt++] = pa[k];
+        }
+    }
+    if (cnt < 3) return 0.f;  // fewer than 3 vertices: the shoelace sum below is exactly 0
+    centre.x = __fdiv_rn(centre.x, (float)cnt);
+    centre.y = __fdiv_rn(centre.y, (float)cnt);
+
+    for (int i = 0; i < cnt; ++i) ang[i] = atan2_f32(poly[i].y - centre.y, poly[i].x - centre.x);
+    for (int j = 0; j < cnt - 1; ++j)
+        for (int i = 0; i < cnt - j - 1; ++i)
+            if (ang[i] > ang[i + 1]) {
+                const P2 tp = poly[i]; poly[i] = poly[i + 1]; poly[i + 1] = tp;
+                const float ta = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = ta;
+            }
+    float area = 0.f;
+    for (int k = 0; k < cnt - 1; ++k) {
+        const float ux = poly[k].x - poly[0].x, uy = poly[k].y - poly[0].y;
+        const float vx = poly[k + 1].x - poly[0].x, vy = poly[k + 1].y - poly[0].y;
+        area = __fadd_rn(area, __fsub_rn(__fmul_rn(ux, vy), __fmul_rn(uy, vx)));
+    }
+    return fabsf(area) * 0.5f;
+}
+
+// iou3d_kernel.cu:214-221
+__device__ __forceinline__ float rbox_iou(const RBox &A, const RBox &B)
+{
+    const float sa = __fmul_rn(A.v[2] - A.v[0], A.v[3] - A.v[1]);
+    const float sb = __fmul_rn(B.v[2] - B.v[0], B.v[3] - B.v[1]);
+    const float so = rbox_overlap(A, B);
+    return __fdiv_rn(so, fmaxf(__fsub_rn(__fadd_rn(sa, sb), so), IOU_EPS));
+}
+
+// iou3d_kernel.cu:295-303
+__device__ __forceinline__ float aabox_iou(const float *a, const float *b)
+{
+    const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+    const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+    const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+    const float interS = __fmul_rn(width, height);
+    const float Sa = __fmul_rn(a[2] - a[0], a[3] - a[1]);
+    const float Sb = __fmul_rn(b[2] - b[0], b[3] - b[1]);
+    return __fdiv_rn(interS, fmaxf(__fsub_rn(__fadd_rn(Sa, Sb), interS), IOU_EPS));
+}
+
+template <bool IOU>
+__global__ __launch_bounds__(256) void pair_kernel(int na, const float *__restrict__ a, int nb,
+                                                   const float *__restrict__ b, float *__restrict__ out)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)na * nb) return;
+    const int i = (int)(e / nb), j = (int)(e - (long)i * nb);
+    const RBox A = make_rbox(a + 5 * i), B = make_rbox(b + 5 * j);
+    out[e] = IOU ? rbox_iou(A, B) : rbox_overlap(A, B);
+}
+
+// ---- lazy greedy NMS, one workgroup per problem ----------------------------------------
+constexpr int NMS_THREADS = 512;
+constexpr int NMS_MAX_N = 65536;   // removed-bitmask lives in LDS (8 KiB)
+constexpr int NMS_RCH = 8;         // rows per work item
+
+template <bool ROTATED>
+__device__ __forceinline__ bool suppresses(const float *s_row, int r, const RBox &C, float thresh)
+{
+    if (ROTATED) {
+        RBox R;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) R.v[q] = s_row[r * 7 + q];
+        R.cosv = s_row[r * 7 + 5];
+        R.sinv = s_row[r * 7 + 6];
+        return rbox_iou(R, C) > thresh;  // (row, column) order as nms_kernel :285
+    }
+    return aabox_iou(&s_row[r * 7], C.v) > thresh;
+}
+
+template <bool ROTATED>
+__device__ __forceinline__ RBox load_col(const float *p)
+{
+    if (ROTATED) return make_rbox(p);
+    RBox r;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) r.v[i] = p[i];
+    r.cosv = 1.f; r.sinv = 0.f;
+    return r;
+}
+
+template <bool ROTATED>
+__global__ __launch_bounds__(NMS_THREADS) void nms_lazy_kernel(
+    int n_max, const int *__restrict__ counts, const float *__restrict__ boxes_all, float thresh,
+    int max_keep, int *__restrict__ keep_all, int *__restrict__ num_keep_all)
+{
+    __shared__ float s_row[64 * 7];             // the 64 row boxes of the block (+cos,sin)
+    __shared__ unsigned long long s_diag[64];   // word(c): rows of the block with IoU > thresh, r < c
+    __shared__ unsigned long long s_kept;       // rows of the block that survive
+    __shared__ unsigned int s_removed[NMS_MAX_N / 32];
+    __shared__ int s_nkeep;
+
+    const int prob = blockIdx.x;
+    int n = counts ? counts[prob] : n_max;
+    n = min(max(n, 0), n_max);
+    const float *__restrict__ boxes = boxes_all + (long)prob * n_max * 5;
+    int *__restrict__ keep = keep_all + (long)prob * max_keep;
+    const int t = threadIdx.x;
+
+    for (int i = t; i < (n + 31) / 32; i += NMS_THREADS) s_removed[i] = 0u;
+    for (int i = t; i < max_keep; i += NMS_THREADS) keep[i] = -1;
+    if (t == 0) s_nkeep = 0;
+    __syncthreads();
+
+    const int nblocks = (n + 63) / 64;
+    for (int rb = 0; rb < nblocks; ++rb) {
+        const int r0 = rb * 64;
+        const int rows = min(64, n - r0);
+        // A: stage the row boxes
+        if (t < rows) {
+            const float *p = boxes + (long)(r0 + t) * 5;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) s_row[t * 7 + q] = p[q];
+            if (ROTATED) {
+                s_row[t * 7 + 5] = cos_f32(p[4]);
+                s_row[t * 7 + 6] = sin_f32(p[4]);
+            }
+        }
+        if (t < 64) s_diag[t] = 0ull;
+        __syncthreads();
+
+        // B: the block's own 64 columns; item = (column, chunk of NMS_RCH rows)
+        {
+            const int cl = t & 63, ch = t >> 6;  // 512 threads = 64 columns x 8 chunks
+            if (cl < rows && !((s_removed[(r0 + cl) >> 5] >> ((r0 + cl) & 31)) & 1u)) {
+                const int rlo = ch * NMS_RCH, rhi = min(rlo + NMS_RCH, cl);  // rows before the column
+                if (rlo < rhi) {
+                    const RBox C = load_col<ROTATED>(boxes + (long)(r0 + cl) * 5);
+                    unsigned long long w = 0;
+                    for (int r = rlo; r < rhi; ++r)
+                        if (suppresses<ROTATED>(s_row, r, C, thresh)) w |= 1ull << r;
+                    if (w) atomicOr(&s_diag[cl], w);
+                }
+            }
+        }
+        __syncthreads();
+
+        // C: serial resolve of the 64 rows, exactly the host loop of iou3d.cpp:100-119
+        if (t == 0) {
+            unsigned long long kept = 0;
+            int nk = s_nkeep;
+            for (int cl = 0; cl < rows && nk < max_keep; ++cl) {
+                const int c = r0 + cl;
+                if ((s_removed[c >> 5] >> (c & 31)) & 1u) continue;
+                if (s_diag[cl] & kept) continue;
+                kept |= 1ull << cl;
+                keep[nk++] = c;
+            }
+            s_kept = kept;
+            s_nkeep = nk;
+        }
+        __syncthreads();
+        if (s_nkeep >= max_keep) break;
+
+        // D: kept rows knock out later columns
+        const unsigned long long kept = s_kept;
+        const int c_first = r0 + 64;
+        const long items = (long)max(0, n - c_first) * (64 / NMS_RCH);
+        for (long e = t; e < items; e += NMS_THREADS) {
+            const int c = c_first + (int)(e / (64 / NMS_RCH));
+            const int ch = (int)(e % (64 / NMS_RCH));
+            const unsigned int chunk_bits = (unsigned int)((kept >> (ch * NMS_RCH)) & ((1u << NMS_RCH) - 1u));
+            if (!chunk_bits) continue;
+            if ((s_removed[c >> 5] >> (c & 31)) & 1u) continue;  // monotone flag: a stale 0 only costs work
+            const RBox C = load_col<ROTATED>(boxes + (long)c * 5);
+            for (int q = 0; q < NMS_RCH; ++q) {
+                if (!((chunk_bits >> q) & 1u)) continue;
+                if (suppresses<ROTATED>(s_row, ch * NMS_RCH + q, C, thresh)) {
+                    atomicOr(&s_removed[c >> 5], 1u << (c & 31));
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (t == 0) num_keep_all[prob] = s_nkeep;
+}
+
+// cached device scratch for the blocking API (one per process, grown on demand)
+static int *g_scratch = nullptr;
+static size_t g_scratch_ints = 0;
+
+static int ensure_scratch(size_t ints)
+{
+    if (ints <= g_scratch_ints) return PRCNN_OK;
+    if (g_scratch) (void)hipFree(g_scratch);
+    g_scratch = nullptr;
+    g_scratch_ints = 0;
+    if (hipMalloc((void **)&g_scratch, ints * sizeof(int)) != hipSuccess) {
+        set_error("nms: cannot allocate %zu bytes of scratch", ints * sizeof(int));
+        return PRCNN_ELAUNCH;
+    }
+    g_scratch_ints = ints;
+    return PRCNN_OK;
+}
+
+static int nms_device(int nprob, int n_max, const int *counts, const float *boxes, float thresh,
+                      int rotated, int max_keep, int *keep, int *num_keep, hipStream_t st)
+{
+    PRCNN_REQUIRE(nprob >= 0 && n_max >= 0 && max_keep >= 0, "nms: bad sizes");
+    PRCNN_REQUIRE(n_max <= NMS_MAX_N, "nms: %d boxes > %d unsupported", n_max, NMS_MAX_N);
+    if (nprob == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(num_keep && (keep || max_keep == 0) && (boxes || n_max == 0), "nms: null pointer");
+    if (rotated)
+        hipLaunchKernelGGL(nms_lazy_kernel<true>, dim3(nprob), dim3(NMS_THREADS), 0, st, n_max, counts, boxes, thresh, max_keep, keep, num_keep);
+    else
+        hipLaunchKernelGGL(nms_lazy_kernel<false>, dim3(nprob), dim3(NMS_THREADS), 0, st, n_max, counts, boxes, thresh, max_keep, keep, num_keep);
+    return check_launch("nms");
+}
+
+static int nms_blocking(int n, const float *boxes, long long *keep_host, float thresh, int rotated, hipStream_t st)
+{
+    PRCNN_REQUIRE(n >= 0, "nms: negative box count");
+    if (n == 0) return 0;
+    PRCNN_REQUIRE(boxes && keep_host, "nms: null pointer");
+    int rc = ensure_scratch((size_t)n + 1);
+    if (rc != PRCNN_OK) return rc;
+    rc = nms_device(1, n, nullptr, boxes, thresh, rotated, n, g_scratch + 1, g_scratch, st);
+    if (rc != PRCNN_OK) return rc;
+    int *host = (int *)malloc(sizeof(int) * ((size_t)n + 1));
+    if (!host) { set_error("nms: host allocation failed"); return PRCNN_ELAUNCH; }
+    hipError_t e = hipMemcpyAsync(host, g_scratch, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        free(host);
+        set_error("nms: copy back failed: %s", hipGetErrorString(e));
+        return PRCNN_ELAUNCH;
+    }
+    const int k = host[0];
+    for (int i = 0; i < k; ++i) keep_host[i] = host[1 + i];
+    free(host);
+    return k;
+}
+
+}  // namespace prcnn
+
+using namespace prcnn;
+
+extern "C" int prcnn_boxes_overlap_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
+                                       float *ans_overlap, void *stream)
+{
+    PRCNN_REQUIRE(num_a >= 0 && num_b >= 0, "boxes_overlap_bev: bad sizes");
+    if (num_a == 0 || num_b == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(boxes_a && boxes_b && ans_overlap, "boxes_overlap_bev: null pointer");
+    hipLaunchKernelGGL(pair_kernel<false>, dim3(ceil_div((long)num_a * num_b, 256)), dim3(256), 0,
+                       (hipStream_t)stream, num_a, boxes_a, num_b, boxes_b, ans_overlap);
+    return check_launch("boxes_overlap_bev");
+}
+
+extern "C" int prcnn_boxes_iou_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
+                                   float *ans_iou, void *stream)
+{
+    PRCNN_REQUIRE(num_a >= 0 && num_b >= 0, "boxes_iou_bev: bad sizes");
+    if (num_a == 0 || num_b == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(boxes_a && boxes_b && ans_iou, "boxes_iou_bev: null pointer");
+    hipLaunchKernelGGL(pair_kernel<true>, dim3(ceil_div((long)num_a * num_b, 256)), dim3(256), 0,
+                       (hipStream_t)stream, num_a, boxes_a, num_b, boxes_b, ans_iou);
+    return check_launch("boxes_iou_bev");
+}
+
+extern "C" int prcnn_nms(int boxes_num, const float *boxes, long long *keep_host, float thresh, void *stream)
+{
+    return nms_blocking(boxes_num, boxes, keep_host, thresh, 1, (hipStream_t)stream);
+}
+
+extern "C" int prcnn_nms_normal(int boxes_num, const float *boxes, long long *keep_host, float thresh, void *stream)
+{
+    return nms_blocking(boxes_num, boxes, keep_host, thresh, 0, (hipStream_t)stream);
+}
+
+extern "C" int prcnn_nms_device(int nprob, int n_max, const int *counts, const float *boxes, float thresh,
+                                int rotated, int max_keep, int *keep, int *num_keep, void *stream)
+{
+    return nms_device(nprob, n_max, counts, boxes, thresh, rotated, max_keep, keep, num_keep, (hipStream_t)stream);
+}

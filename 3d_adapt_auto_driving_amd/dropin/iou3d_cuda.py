@@ -1,0 +1,68 @@
+"""Drop-in for the reference's ``iou3d_cuda`` pybind module
+(pointrcnn/lib/utils/iou3d/src/iou3d.cpp:174-179) over libprcnn_hip.so.
+
+boxes are (n,5) [x1,y1,x2,y2,ry] CUDA f32 contiguous (CHECK_INPUT, iou3d.cpp:7-9); ``keep`` of
+the two NMS calls is a CPU int64 tensor and the call blocks, as in the reference.
+"""
+import importlib
+import os
+import sys
+
+import torch
+
+_pkg_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.path.dirname(_pkg_dir) not in sys.path:
+    sys.path.insert(0, os.path.dirname(_pkg_dir))
+_lib = importlib.import_module(os.path.basename(_pkg_dir) + "._lib")
+
+
+def _chk(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError("iou3d_cuda: tensor must be a CUDA tensor")
+        if not t.is_contiguous():
+            raise RuntimeError("iou3d_cuda: tensor must be contiguous")
+        if t.dtype != torch.float32:
+            raise RuntimeError("iou3d_cuda: expected float32")
+
+
+def boxes_overlap_bev_gpu(boxes_a, boxes_b, ans_overlap):
+    _chk(boxes_a, boxes_b, ans_overlap)
+    _lib.call("prcnn_boxes_overlap_bev", boxes_a.size(0), boxes_a.data_ptr(), boxes_b.size(0),
+              boxes_b.data_ptr(), ans_overlap.data_ptr(), _lib.current_stream(boxes_a))
+    return 1
+
+
+def boxes_iou_bev_gpu(boxes_a, boxes_b, ans_iou):
+    _chk(boxes_a, boxes_b, ans_iou)
+    _lib.call("prcnn_boxes_iou_bev", boxes_a.size(0), boxes_a.data_ptr(), boxes_b.size(0),
+              boxes_b.data_ptr(), ans_iou.data_ptr(), _lib.current_stream(boxes_a))
+    return 1
+
+
+def _nms(name, boxes, keep, thresh):
+    _chk(boxes)
+    if keep.is_cuda or keep.dtype != torch.int64 or not keep.is_contiguous():
+        raise RuntimeError("iou3d_cuda: keep must be a contiguous CPU int64 tensor")
+    if keep.numel() < boxes.size(0):
+        raise RuntimeError("iou3d_cuda: keep is shorter than boxes")
+    return _lib.call(name, boxes.size(0), boxes.data_ptr(), keep.data_ptr(), float(thresh),
+                     _lib.current_stream(boxes))
+
+
+def nms_gpu(boxes, keep, nms_overlap_thresh):
+    return _nms("prcnn_nms", boxes, keep, nms_overlap_thresh)
+
+
+def nms_normal_gpu(boxes, keep, nms_overlap_thresh):
+    return _nms("prcnn_nms_normal", boxes, keep, nms_overlap_thresh)
+
+
+# -- extension beyond the reference module: batched, device-resident greedy NMS -------------
+def nms_device(boxes, counts, thresh, rotated, max_keep, keep, num_keep):
+    """boxes (P, n_max, 5) f32, counts (P) i32 or None, keep (P, max_keep) i32, num_keep (P) i32."""
+    _chk(boxes)
+    _lib.call("prcnn_nms_device", boxes.size(0), boxes.size(1), _lib.ptr(counts), boxes.data_ptr(),
+              float(thresh), int(bool(rotated)), int(max_keep), keep.data_ptr(), num_keep.data_ptr(),
+              _lib.current_stream(boxes))
+    return 1

@@ -1,0 +1,99 @@
+"""Drop-in for the reference's ``pointnet2_cuda`` pybind module
+(pointrcnn/pointnet2_lib/pointnet2/src/pointnet2_api.cpp:10-24): same function names, argument
+order and pre-allocated-output convention, bound to libprcnn_hip.so through the C ABI
+(include/prcnn_hip.h).  Put this directory on ``sys.path`` and the reference's
+``pointnet2_utils.py`` (``import pointnet2_cuda as pointnet2``, :7) imports it unmodified.
+
+Like the reference wrappers, kernels go to torch's current stream.  Inputs must be CUDA(HIP),
+contiguous, f32/i32 (ball_query.cpp:10-12 checks only ball_query's inputs; we check all).
+"""
+import importlib
+import os
+import sys
+
+import torch
+
+_pkg_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.path.dirname(_pkg_dir) not in sys.path:
+    sys.path.insert(0, os.path.dirname(_pkg_dir))
+_lib = importlib.import_module(os.path.basename(_pkg_dir) + "._lib")
+
+
+def _chk(dtype, *tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError("pointnet2_cuda: tensor must be a CUDA tensor")
+        if not t.is_contiguous():
+            raise RuntimeError("pointnet2_cuda: tensor must be contiguous")
+        if t.dtype != dtype:
+            raise RuntimeError("pointnet2_cuda: expected %s, got %s" % (dtype, t.dtype))
+
+
+def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+    _chk(torch.float32, new_xyz, xyz); _chk(torch.int32, idx)
+    _lib.call("prcnn_ball_query", b, n, m, radius, nsample, new_xyz.data_ptr(), xyz.data_ptr(),
+              idx.data_ptr(), _lib.current_stream(xyz))
+    return 1
+
+
+def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
+    _chk(torch.float32, points, out); _chk(torch.int32, idx)
+    _lib.call("prcnn_group_points", b, c, n, npoints, nsample, points.data_ptr(), idx.data_ptr(),
+              out.data_ptr(), _lib.current_stream(points))
+    return 1
+
+
+def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
+    _chk(torch.float32, grad_out, grad_points); _chk(torch.int32, idx)
+    _lib.call("prcnn_group_points_grad", b, c, n, npoints, nsample, grad_out.data_ptr(), idx.data_ptr(),
+              grad_points.data_ptr(), _lib.current_stream(grad_out))
+    return 1
+
+
+def gather_points_wrapper(b, c, n, npoints, points, idx, out):
+    _chk(torch.float32, points, out); _chk(torch.int32, idx)
+    _lib.call("prcnn_gather_points", b, c, n, npoints, points.data_ptr(), idx.data_ptr(),
+              out.data_ptr(), _lib.current_stream(points))
+    return 1
+
+
+def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
+    _chk(torch.float32, grad_out, grad_points); _chk(torch.int32, idx)
+    _lib.call("prcnn_gather_points_grad", b, c, n, npoints, grad_out.data_ptr(), idx.data_ptr(),
+              grad_points.data_ptr(), _lib.current_stream(grad_out))
+    return 1
+
+
+def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
+    _chk(torch.float32, points, temp); _chk(torch.int32, idx)
+    _lib.call("prcnn_furthest_point_sampling", b, n, m, points.data_ptr(), temp.data_ptr(),
+              idx.data_ptr(), _lib.current_stream(points))
+    return 1
+
+
+def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+    _chk(torch.float32, unknown, known, dist2); _chk(torch.int32, idx)
+    _lib.call("prcnn_three_nn", b, n, m, unknown.data_ptr(), known.data_ptr(), dist2.data_ptr(),
+              idx.data_ptr(), _lib.current_stream(unknown))
+
+
+def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
+    _chk(torch.float32, points, weight, out); _chk(torch.int32, idx)
+    _lib.call("prcnn_three_interpolate", b, c, m, n, points.data_ptr(), idx.data_ptr(),
+              weight.data_ptr(), out.data_ptr(), _lib.current_stream(points))
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+    _chk(torch.float32, grad_out, weight, grad_points); _chk(torch.int32, idx)
+    _lib.call("prcnn_three_interpolate_grad", b, c, n, m, grad_out.data_ptr(), idx.data_ptr(),
+              weight.data_ptr(), grad_points.data_ptr(), _lib.current_stream(grad_out))
+
+
+# -- extension beyond the reference module: the fused QueryAndGroup path -------------------
+def query_and_group_wrapper(b, n, m, c, radius, nsample, new_xyz, xyz, features, idx, out):
+    _chk(torch.float32, new_xyz, xyz, out); _chk(torch.int32, idx)
+    if features is not None:
+        _chk(torch.float32, features)
+    _lib.call("prcnn_query_and_group", b, n, m, c, radius, nsample, new_xyz.data_ptr(), xyz.data_ptr(),
+              _lib.ptr(features), idx.data_ptr(), out.data_ptr(), _lib.current_stream(xyz))
+    return 1

@@ -1,0 +1,51 @@
+"""Drop-in for the reference's ``roipool3d_cuda`` pybind module
+(pointrcnn/lib/utils/roipool3d/src/roipool3d.cpp:198-203) over libprcnn_hip.so.
+
+``forward`` / ``forward_slow`` are the device path (both map to the same kernel: the "slow"
+overload, roipool3d_kernel.cu:31-94, computes the identical result).  ``pts_in_boxes3d_cpu`` and
+``roipool3d_cpu`` are HOST utilities of the reference used only by its dataset / GT-database
+code (kitti_rcnn_dataset.py:507, generate_gt_database.py:75), which SURVEY.md section 8 puts
+out of scope: they raise NotImplementedError here rather than silently running on the CPU.
+"""
+import importlib
+import os
+import sys
+
+import torch
+
+_pkg_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.path.dirname(_pkg_dir) not in sys.path:
+    sys.path.insert(0, os.path.dirname(_pkg_dir))
+_lib = importlib.import_module(os.path.basename(_pkg_dir) + "._lib")
+
+
+def _chk(dtype, *tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError("roipool3d_cuda: tensor must be a CUDA tensor")
+        if not t.is_contiguous():
+            raise RuntimeError("roipool3d_cuda: tensor must be contiguous")
+        if t.dtype != dtype:
+            raise RuntimeError("roipool3d_cuda: expected %s, got %s" % (dtype, t.dtype))
+
+
+def forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag):
+    _chk(torch.float32, xyz, boxes3d, pts_feature, pooled_features)
+    _chk(torch.int32, pooled_empty_flag)
+    _lib.call("prcnn_roipool3d", xyz.size(0), xyz.size(1), boxes3d.size(1), pts_feature.size(2),
+              pooled_features.size(2), xyz.data_ptr(), boxes3d.data_ptr(), pts_feature.data_ptr(),
+              pooled_features.data_ptr(), pooled_empty_flag.data_ptr(), _lib.current_stream(xyz))
+    return 1
+
+
+forward_slow = forward
+
+
+def pts_in_boxes3d_cpu(pts_flag, pts, boxes3d):
+    raise NotImplementedError("roipool3d_cuda.pts_in_boxes3d_cpu: host-side dataset utility, out of the "
+                              "MI355X hot-path scope (no CPU paths in this build)")
+
+
+def roipool3d_cpu(pts, boxes3d, pts_feature, pooled_pts, pooled_features, pooled_empty_flag):
+    raise NotImplementedError("roipool3d_cuda.roipool3d_cpu: host-side dataset utility, out of the "
+                              "MI355X hot-path scope (no CPU paths in this build)")

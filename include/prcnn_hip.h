@@ -1,0 +1,142 @@
+/*
+ * prcnn_hip.h -- C ABI of libprcnn_hip.so: the MI355X (gfx950) implementation of the
+ * PointRCNN eval_rcnn hot-path operators of cxy1997/3D_adapt_auto_driving.
+ *
+ * This is the drop-in boundary.  Every entry point is what the reference's three pybind
+ * modules bind for this path (reference paths relative to /root/reference/pointrcnn/):
+ *
+ *   pointnet2_cuda  pointnet2_lib/pointnet2/src/pointnet2_api.cpp:10-24
+ *   iou3d_cuda      lib/utils/iou3d/src/iou3d.cpp:174-179
+ *   roipool3d_cuda  lib/utils/roipool3d/src/roipool3d.cpp:198-203
+ *   rotate_iou      ../evaluate/rotate_iou.py:294-329 (numba.cuda kernel :261-291)
+ *
+ * Conventions (same as the reference wrappers):
+ *   - plain device pointers + sizes; f32 / i32, C-contiguous, row-major; the CALLER allocates
+ *     every output; dims are passed as ints.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  The
+ *     reference launches pointnet2 on torch's current stream and iou3d/roipool3d on the default
+ *     stream; here every op takes the stream explicitly and is asynchronous unless stated.
+ *   - return value: 0 on success, a negative PRCNN_E* code on failure (the reference calls
+ *     exit(-1) on a failed launch, ball_query_gpu.cu:63-66; we report instead).
+ *     prcnn_last_error() returns a static description of the last failure on this thread.
+ *   - no allocation inside any call except the blocking prcnn_nms / prcnn_nms_normal, which
+ *     keep one cached device scratch (the reference cudaMalloc/cudaFree's per call,
+ *     iou3d.cpp:87,97).
+ */
+#ifndef PRCNN_HIP_H
+#define PRCNN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRCNN_OK 0
+#define PRCNN_EINVAL (-1)  /* bad argument (null pointer, negative size, unsupported size) */
+#define PRCNN_ELAUNCH (-2) /* HIP launch / runtime error */
+
+int prcnn_version(void);
+const char *prcnn_last_error(void);
+/* opt_n_threads() of cuda_utils.h:10-13: the reference FPS block size for n points. */
+int prcnn_opt_n_threads(int work_size);
+
+/* ---- pointnet2_cuda ------------------------------------------------------------------ */
+
+/* ball_query_wrapper_fast  src/ball_query.cpp:14-25 -> kernel src/ball_query_gpu.cu:9-45.
+ * new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample): first nsample in-radius indices in index
+ * order, first hit back-fills; rows of empty balls are left untouched (caller zero-fills). */
+int prcnn_ball_query(int b, int n, int m, float radius, int nsample,
+                     const float *new_xyz, const float *xyz, int *idx, void *stream);
+
+/* group_points_wrapper_fast  src/group_points.cpp:25-36 -> src/group_points_gpu.cu:47-66.
+ * points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample). */
+int prcnn_group_points(int b, int c, int n, int npoints, int nsample,
+                       const float *points, const int *idx, float *out, void *stream);
+/* group_points_grad_wrapper_fast  src/group_points.cpp:11-22 -> src/group_points_gpu.cu:8-25.
+ * grad_points (b,c,n) must be zero-filled by the caller; atomic scatter-add. */
+int prcnn_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                            const float *grad_out, const int *idx, float *grad_points, void *stream);
+
+/* gather_points_wrapper_fast  src/sampling.cpp:11-20 -> src/sampling_gpu.cu:8-24. */
+int prcnn_gather_points(int b, int c, int n, int npoints,
+                        const float *points, const int *idx, float *out, void *stream);
+/* gather_points_grad_wrapper_fast  src/sampling.cpp:23-33 -> src/sampling_gpu.cu:46-63. */
+int prcnn_gather_points_grad(int b, int c, int n, int npoints,
+                             const float *grad_out, const int *idx, float *grad_points, void *stream);
+
+/* furthest_point_sampling_wrapper  src/sampling.cpp:36-46 -> src/sampling_gpu.cu:93-253.
+ * xyz (b,n,3), temp (b,n) scratch pre-filled by the caller (1e10) -> idx (b,m).  Ties resolve
+ * as in the reference kernel launched with opt_n_threads(n) threads.  On return temp holds the
+ * running minimum distances, as the reference leaves them. */
+int prcnn_furthest_point_sampling(int b, int n, int m,
+                                  const float *xyz, float *temp, int *idx, void *stream);
+
+/* three_nn_wrapper_fast  src/interpolate.cpp:14-23 -> src/interpolate_gpu.cu:9-52.
+ * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) SQUARED distances, idx (b,n,3). */
+int prcnn_three_nn(int b, int n, int m, const float *unknown, const float *known,
+                   float *dist2, int *idx, void *stream);
+/* three_interpolate_wrapper_fast  src/interpolate.cpp:26-39 -> src/interpolate_gpu.cu:77-97.
+ * points (b,c,m), idx/weight (b,n,3) -> out (b,c,n). */
+int prcnn_three_interpolate(int b, int c, int m, int n, const float *points,
+                            const int *idx, const float *weight, float *out, void *stream);
+/* three_interpolate_grad_wrapper_fast  src/interpolate.cpp:42-54 -> interpolate_gpu.cu:120-142. */
+int prcnn_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                 const int *idx, const float *weight, float *grad_points, void *stream);
+
+/* Fused QueryAndGroup.forward (pointnet2_utils.py:241-264 = K1 + K2 x2 + centre subtract + cat):
+ * out (b,3+c,m,nsample) = cat(xyz[idx]-new_xyz, features[idx]); features may be NULL (c = 0).
+ * idx (b,m,nsample) is an OUTPUT here and is fully written (empty balls -> 0, the value the
+ * reference's zero-filled idx holds).  Not part of the reference ABI; it is what the
+ * reference's Python composes from it. */
+int prcnn_query_and_group(int b, int n, int m, int c, float radius, int nsample,
+                          const float *new_xyz, const float *xyz, const float *features,
+                          int *idx, float *out, void *stream);
+
+/* ---- iou3d_cuda ---------------------------------------------------------------------- */
+
+/* boxes_overlap_bev_gpu  src/iou3d.cpp:31-50 -> src/iou3d_kernel.cu:223-234.
+ * boxes_a (na,5), boxes_b (nb,5) [x1,y1,x2,y2,ry] -> ans (na,nb) intersection area. */
+int prcnn_boxes_overlap_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
+                            float *ans_overlap, void *stream);
+/* boxes_iou_bev_gpu  src/iou3d.cpp:52-71 -> src/iou3d_kernel.cu:236-248. */
+int prcnn_boxes_iou_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
+                        float *ans_iou, void *stream);
+/* nms_gpu  src/iou3d.cpp:73-120 -> src/iou3d_kernel.cu:250-292 + host reduce.
+ * boxes (n,5) DEVICE, score-sorted; keep (n) HOST int64.  BLOCKING (as the reference's
+ * cudaMemcpy is).  Returns num_to_keep >= 0, or a negative PRCNN_E* code. */
+int prcnn_nms(int boxes_num, const float *boxes, long long *keep_host, float thresh, void *stream);
+/* nms_normal_gpu  src/iou3d.cpp:123-170 -> src/iou3d_kernel.cu:306-348. */
+int prcnn_nms_normal(int boxes_num, const float *boxes, long long *keep_host, float thresh, void *stream);
+
+/* Device-resident, batched greedy NMS (no host round trip): `nprob` independent problems.
+ * boxes (nprob, n_max, 5) score-sorted per problem; counts (nprob) DEVICE i32 = valid rows of
+ * each problem (NULL -> all n_max).  Writes keep (nprob, max_keep) i32 (row indices, padded
+ * with -1) and num_keep (nprob) i32 = min(#kept, max_keep): exactly the first max_keep
+ * entries the reference's full greedy pass would return.  rotated != 0 -> iou_bev, else
+ * iou_normal.  Asynchronous. */
+int prcnn_nms_device(int nprob, int n_max, const int *counts, const float *boxes, float thresh,
+                     int rotated, int max_keep, int *keep, int *num_keep, void *stream);
+
+/* ---- roipool3d_cuda ------------------------------------------------------------------ */
+
+/* forward  src/roipool3d.cpp:48-79 -> roipool3dLauncher src/roipool3d_kernel.cu:209-237.
+ * xyz (B,N,3), boxes3d (B,M,7) already enlarged, pts_feature (B,N,C) ->
+ * pooled_features (B,M,S,3+C) and pooled_empty_flag (B,M), both zero-filled by the caller;
+ * rows of empty boxes are left untouched. */
+int prcnn_roipool3d(int batch_size, int pts_num, int boxes_num, int feature_in_len,
+                    int sampled_pts_num, const float *xyz, const float *boxes3d,
+                    const float *pts_feature, float *pooled_features, int *pooled_empty_flag,
+                    void *stream);
+
+/* ---- evaluate/rotate_iou.py ---------------------------------------------------------- */
+
+/* rotate_iou_gpu_eval  evaluate/rotate_iou.py:294-329 (kernel :261-291).
+ * boxes (n,5), query_boxes (k,5) [cx,cy,w,h,angle] DEVICE -> iou (n,k);
+ * criterion -1 IoU, 0 /area(query), 1 /area(box), 2 raw intersection (as the kernel passes
+ * (query, box) to the device function, :287-291). */
+int prcnn_rotate_iou_eval(int n, int k, const float *boxes, const float *query_boxes,
+                          float *iou, int criterion, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,253 @@
+"""-m gpu parity tests: every HIP operator, called through the drop-in extension modules (i.e.
+through the C ABI of libprcnn_hip.so), against the CPU oracle on the same seeded inputs.
+Index outputs must be bit-exact; float outputs of pure copies/selects bit-exact as well;
+geometric float outputs within the tolerance stated next to the assert."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import scene, scenes, bev_boxes, boxes3d
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def fps_gpu(ext, xyz, m):
+    b, n, _ = xyz.shape
+    t = T(xyz)
+    temp = torch.full((b, n), 1e10, device=DEV)
+    idx = torch.empty((b, m), dtype=torch.int32, device=DEV)
+    ext.pointnet2.furthest_point_sampling_wrapper(b, n, m, t, temp, idx)
+    return idx.cpu().numpy(), temp.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,m", [(128, 32), (512, 128), (1000, 100), (1024, 256), (4096, 1024), (16384, 4096)])
+def test_fps_matches_oracle(ext, oracle, n, m):
+    xyz = scenes(2, n, seed0=n)
+    got, gtemp = fps_gpu(ext, xyz, m)
+    want, wtemp = oracle.furthest_point_sample(xyz, m, return_temp=True)
+    assert np.array_equal(got, want)
+    assert np.array_equal(gtemp, wtemp)
+
+
+def test_fps_tie_rule_lattice_and_duplicates(ext, oracle):
+    # integer lattice: many exactly equal distances -> the block-size dependent tie rule decides
+    g = np.stack(np.meshgrid(np.arange(16), np.arange(8), np.arange(16), indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(5)
+    lat = g[rng.permutation(len(g))].astype(np.float32)[None]            # (1, 2048, 3)
+    dup = np.repeat(scene(3, 256), 4, axis=0)[None]                     # every point 4 times
+    dup = dup[:, rng.permutation(dup.shape[1])]
+    for xyz, m in ((lat, 512), (dup, 300), (lat[:, :700], 128)):
+        got, _ = fps_gpu(ext, xyz, m)
+        assert np.array_equal(got, oracle.furthest_point_sample(xyz, m))
+
+
+def test_fps_many_small_clouds(ext, oracle):
+    xyz = np.random.default_rng(1).uniform(-1, 1, (300, 512, 3)).astype(np.float32)
+    got, _ = fps_gpu(ext, xyz, 128)
+    assert np.array_equal(got, oracle.furthest_point_sample(xyz, 128))
+
+
+def centres(oracle, xyz, m):
+    idx = oracle.furthest_point_sample(xyz, m).astype(np.int64)
+    return np.take_along_axis(xyz, idx[..., None].repeat(3, -1), 1)
+
+
+@pytest.mark.parametrize("n,m,r,ns", [(16384, 4096, 0.1, 16), (16384, 4096, 0.5, 32), (16384, 4096, 0.4, 64),
+                                      (4096, 1024, 1.0, 32), (1024, 256, 2.0, 32), (256, 64, 4.0, 32),
+                                      (1000, 77, 0.7, 20)])
+def test_ball_query_matches_oracle(ext, oracle, n, m, r, ns):
+    xyz = scenes(2, n, seed0=7)
+    new_xyz = centres(oracle, xyz, m)
+    new_xyz[0, 0] = [500, 500, 500]  # an empty ball
+    idx = torch.full((2, m, ns), -7, dtype=torch.int32, device=DEV)
+    ext.pointnet2.ball_query_wrapper(2, n, m, r, ns, T(new_xyz), T(xyz), idx)
+    want = np.full((2, m, ns), -7, np.int32)
+    oracle.ball_query_into(r, ns, xyz, new_xyz, want)
+    assert np.array_equal(idx.cpu().numpy(), want)
+    assert (want[0, 0] == -7).all()  # empty ball: row untouched
+
+
+def test_ball_query_rcnn_shape(ext, oracle):
+    rng = np.random.default_rng(2)
+    xyz = rng.uniform(-2.5, 2.5, (200, 512, 3)).astype(np.float32)
+    new_xyz = centres(oracle, xyz, 128)
+    idx = torch.zeros((200, 128, 64), dtype=torch.int32, device=DEV)
+    ext.pointnet2.ball_query_wrapper(200, 512, 128, 0.2, 64, T(new_xyz), T(xyz), idx)
+    assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(0.2, 64, xyz, new_xyz))
+
+
+@pytest.mark.parametrize("c", [0, 1, 16, 128])
+def test_query_and_group_fused(ext, oracle, c):
+    n, m, r, ns = 4096, 1024, 0.8, 32
+    xyz = scenes(2, n, seed0=11)
+    new_xyz = centres(oracle, xyz, m)
+    new_xyz[1, 5] = [-500, 0, 0]
+    feats = np.random.default_rng(c).standard_normal((2, c, n)).astype(np.float32) if c else None
+    idx = torch.empty((2, m, ns), dtype=torch.int32, device=DEV)
+    out = torch.empty((2, 3 + c, m, ns), device=DEV)
+    ext.pointnet2.query_and_group_wrapper(2, n, m, c, r, ns, T(new_xyz), T(xyz), T(feats) if c else None, idx, out)
+    want, widx = oracle.query_and_group(r, ns, xyz, new_xyz, feats)
+    assert np.array_equal(idx.cpu().numpy(), widx)
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_group_and_gather(ext, oracle):
+    rng = np.random.default_rng(3)
+    pts = rng.standard_normal((3, 19, 777)).astype(np.float32)
+    idx = rng.integers(0, 777, (3, 50, 9)).astype(np.int32)
+    out = torch.empty((3, 19, 50, 9), device=DEV)
+    ext.pointnet2.group_points_wrapper(3, 19, 777, 50, 9, T(pts), T(idx), out)
+    assert np.array_equal(out.cpu().numpy(), oracle.group_points(pts, idx))
+    gidx = rng.integers(0, 777, (3, 123)).astype(np.int32)
+    gout = torch.empty((3, 19, 123), device=DEV)
+    ext.pointnet2.gather_points_wrapper(3, 19, 777, 123, T(pts), T(gidx), gout)
+    assert np.array_equal(gout.cpu().numpy(), oracle.gather_points(pts, gidx))
+
+
+def test_grad_kernels(ext, oracle):
+    rng = np.random.default_rng(4)
+    idx = rng.integers(0, 200, (2, 40, 8)).astype(np.int32)
+    go = rng.standard_normal((2, 5, 40, 8)).astype(np.float32)
+    g = torch.zeros((2, 5, 200), device=DEV)
+    ext.pointnet2.group_points_grad_wrapper(2, 5, 200, 40, 8, T(go), T(idx), g)
+    np.testing.assert_allclose(g.cpu().numpy(), oracle.group_points_grad(go, idx, 200), rtol=1e-5, atol=1e-5)
+    gidx = rng.integers(0, 200, (2, 60)).astype(np.int32)
+    go2 = rng.standard_normal((2, 5, 60)).astype(np.float32)
+    g2 = torch.zeros((2, 5, 200), device=DEV)
+    ext.pointnet2.gather_points_grad_wrapper(2, 5, 200, 60, T(go2), T(gidx), g2)
+    np.testing.assert_allclose(g2.cpu().numpy(), oracle.gather_points_grad(go2, gidx, 200), rtol=1e-5, atol=1e-5)
+    i3 = rng.integers(0, 50, (2, 70, 3)).astype(np.int32)
+    w3 = rng.uniform(0, 1, (2, 70, 3)).astype(np.float32)
+    go3 = rng.standard_normal((2, 5, 70)).astype(np.float32)
+    g3 = torch.zeros((2, 5, 50), device=DEV)
+    ext.pointnet2.three_interpolate_grad_wrapper(2, 5, 70, 50, T(go3), T(i3), T(w3), g3)
+    np.testing.assert_allclose(g3.cpu().numpy(), oracle.three_interpolate_grad(go3, i3, w3, 50), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,m", [(256, 64), (1024, 256), (4096, 1024), (16384, 4096), (333, 5)])
+def test_three_nn_and_interpolate(ext, oracle, n, m):
+    unknown = scenes(2, n, seed0=21)
+    known = centres(oracle, unknown, m)
+    known[0, 1] = known[0, 0]  # exact tie: lowest index must win
+    d2 = torch.empty((2, n, 3), device=DEV)
+    idx = torch.empty((2, n, 3), dtype=torch.int32, device=DEV)
+    ext.pointnet2.three_nn_wrapper(2, n, m, T(unknown), T(known), d2, idx)
+    wd2, widx = oracle.three_nn(unknown, known)
+    assert np.array_equal(idx.cpu().numpy(), widx)
+    assert np.array_equal(d2.cpu().numpy(), wd2)
+    rng = np.random.default_rng(n)
+    feats = rng.standard_normal((2, 24, m)).astype(np.float32)
+    w = rng.uniform(0, 1, (2, n, 3)).astype(np.float32)
+    out = torch.empty((2, 24, n), device=DEV)
+    ext.pointnet2.three_interpolate_wrapper(2, 24, m, n, T(feats), idx, T(w), out)
+    assert np.array_equal(out.cpu().numpy(), oracle.three_interpolate(feats, widx, w))  # same rounding sequence
+
+
+def test_roipool3d(ext, oracle):
+    rng = np.random.default_rng(8)
+    xyz = scenes(2, 16384, seed0=31)
+    boxes = np.stack([boxes3d(rng, 100), boxes3d(rng, 100)], 0)
+    boxes[0, 3, :3] = [300, 300, 300]            # empty box
+    boxes[1, :10, 0:3] = xyz[1, :10] + [0, 1.0, 0]  # boxes that certainly contain points
+    boxes[:, :, 3:6] += 2.0; boxes[:, :, 1] += 1.0  # enlarged as roipool3d_utils.py:19 does
+    feat = rng.standard_normal((2, 16384, 130)).astype(np.float32)
+    pooled = torch.zeros((2, 100, 512, 133), device=DEV)
+    empty = torch.zeros((2, 100), dtype=torch.int32, device=DEV)
+    ext.roipool3d.forward(T(xyz), T(boxes), T(feat), pooled, empty)
+    wp, we = oracle.roipool3d(xyz, boxes, feat, 512)
+    assert np.array_equal(empty.cpu().numpy(), we)
+    assert np.array_equal(pooled.cpu().numpy(), wp)
+    assert we[0, 3] == 1 and we.sum() < 150
+
+
+def test_roipool3d_full_and_partial_boxes(ext, oracle):
+    rng = np.random.default_rng(9)
+    xyz = rng.uniform([-3, 0, 8], [3, 2, 14], (1, 5000, 3)).astype(np.float32)
+    boxes = np.array([[[0, 2, 11, 2, 5.5, 5.5, 0.3],      # > 512 points inside
+                       [2.5, 2, 13.5, 2, 0.6, 0.6, 1.0],   # a few points: wrap-around fill
+                       [50, 2, 50, 2, 1, 1, 0]]], np.float32)
+    feat = rng.standard_normal((1, 5000, 7)).astype(np.float32)
+    pooled = torch.zeros((1, 3, 512, 10), device=DEV)
+    empty = torch.zeros((1, 3), dtype=torch.int32, device=DEV)
+    ext.roipool3d.forward_slow(T(xyz), T(boxes), T(feat), pooled, empty)
+    wp, we = oracle.roipool3d(xyz, boxes, feat, 512)
+    assert np.array_equal(empty.cpu().numpy(), we) and list(we[0]) == [0, 0, 1]
+    assert np.array_equal(pooled.cpu().numpy(), wp)
+
+
+@pytest.mark.parametrize("n,thresh", [(6300, 0.8), (2700, 0.8), (900, 0.5), (65, 0.3), (1, 0.5)])
+def test_nms_normal(ext, oracle, n, thresh):
+    boxes = bev_boxes(np.random.default_rng(n), n, spread=25.0, rotated=False)
+    keep = torch.zeros(n, dtype=torch.int64)
+    k = ext.iou3d.nms_normal_gpu(T(boxes), keep, thresh)
+    want = oracle.nms_normal(boxes, thresh)
+    assert k == len(want) and np.array_equal(keep[:k].numpy(), want)
+
+
+@pytest.mark.parametrize("n,thresh", [(100, 0.1), (300, 0.3), (64, 0.01), (700, 0.5)])
+def test_nms_rotated(ext, oracle, n, thresh):
+    boxes = bev_boxes(np.random.default_rng(n + 1), n, spread=12.0)
+    keep = torch.zeros(n, dtype=torch.int64)
+    k = ext.iou3d.nms_gpu(T(boxes), keep, thresh)
+    want = oracle.nms(boxes, thresh)
+    assert k == len(want) and np.array_equal(keep[:k].numpy(), want)
+
+
+def test_nms_device_batched_prefix(ext, oracle):
+    rng = np.random.default_rng(12)
+    P, nmax, K = 6, 3000, 70
+    counts = np.array([3000, 2999, 64, 0, 1500, 1], np.int32)
+    boxes = np.stack([bev_boxes(rng, nmax, spread=15.0, rotated=False) for _ in range(P)], 0)
+    keep = torch.empty((P, K), dtype=torch.int32, device=DEV)
+    num = torch.empty((P,), dtype=torch.int32, device=DEV)
+    ext.iou3d.nms_device(T(boxes), T(counts), 0.8, False, K, keep, num)
+    keep, num = keep.cpu().numpy(), num.cpu().numpy()
+    for p in range(P):
+        want = oracle.nms_normal(boxes[p, :counts[p]], 0.8)[:K]
+        assert num[p] == len(want)
+        assert np.array_equal(keep[p, :num[p]], want)
+        assert (keep[p, num[p]:] == -1).all()
+
+
+def test_overlap_and_iou_bev(ext, oracle):
+    rng = np.random.default_rng(13)
+    a, b = bev_boxes(rng, 256, spread=8.0), bev_boxes(rng, 200, spread=8.0)
+    b[:5] = a[:5]  # identical boxes (degenerate polygon case)
+    ov = torch.zeros((256, 200), device=DEV); iou = torch.zeros((256, 200), device=DEV)
+    ext.iou3d.boxes_overlap_bev_gpu(T(a), T(b), ov)
+    ext.iou3d.boxes_iou_bev_gpu(T(a), T(b), iou)
+    # same rounding sequence as the oracle; libm differences (f64 sin/cos/atan2 rounded to f32) may
+    # move a value by an ulp-scale amount -> 1e-5 absolute on areas of O(10)
+    np.testing.assert_allclose(ov.cpu().numpy(), oracle.boxes_overlap_bev(a, b), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(iou.cpu().numpy(), oracle.boxes_iou_bev(a, b), rtol=0, atol=1e-6)
+    assert (oracle.boxes_overlap_bev(a, b) > 0).mean() > 0.02
+
+
+def test_rotate_iou_eval(oracle):
+    import importlib
+    lib = importlib.import_module("3d_adapt_auto_driving_amd._lib")
+    rng = np.random.default_rng(14)
+    def cbox(n):
+        return np.stack([rng.uniform(-6, 6, n), rng.uniform(-6, 6, n), rng.uniform(1.4, 2, n),
+                         rng.uniform(3, 5, n), rng.uniform(-np.pi, np.pi, n)], 1).astype(np.float32)
+    a, q = cbox(150), cbox(90)
+    for crit in (-1, 0, 1, 2):
+        out = torch.zeros((150, 90), device=DEV)
+        ta, tq = T(a), T(q)
+        lib.call("prcnn_rotate_iou_eval", 150, 90, ta.data_ptr(), tq.data_ptr(), out.data_ptr(), crit,
+                 lib.current_stream(out))
+        np.testing.assert_allclose(out.cpu().numpy(), oracle.rotate_iou_eval(a, q, crit), rtol=0, atol=1e-5)
+
+
+def test_bad_arguments_raise(ext):
+    lib = __import__("importlib").import_module("3d_adapt_auto_driving_amd._lib")
+    x = torch.zeros((1, 8, 3), device=DEV)
+    with pytest.raises(RuntimeError):
+        ext.pointnet2.ball_query_wrapper(1, 8, 8, 0.1, 4, x.cpu(), x, torch.zeros((1, 8, 4), dtype=torch.int32, device=DEV))
+    with pytest.raises(lib.PrcnnError):
+        lib.call("prcnn_ball_query", 1, 8, 8, 0.1, 4, None, None, None, None)
