@@ -6,7 +6,8 @@ def scene(seed, n=16384, n_cars=10):
     """KITTI-shaped synthetic cloud: uniform background in PC_AREA_SCOPE, a ground
     plane near y=1.6 and a few car-sized dense boxes."""
     rng = np.random.default_rng(seed)
-    n_car_pts = 200 * n_cars
+    per_car = max(1, min(200, n // (4 * n_cars)))
+    n_car_pts = per_car * n_cars
     n_ground = (n - n_car_pts) // 2
     n_bg = n - n_car_pts - n_ground
     bg = rng.uniform([-40, -1, 0], [40, 3, 70.4], (n_bg, 3))
@@ -16,7 +17,7 @@ def scene(seed, n=16384, n_cars=10):
     for _ in range(n_cars):
         c = np.array([rng.uniform(-20, 20), 0.8, rng.uniform(5, 60)])
         ry = rng.uniform(-np.pi, np.pi)
-        loc = rng.uniform([-1.95, -0.75, -0.8], [1.95, 0.75, 0.8], (200, 3))  # l, h, w
+        loc = rng.uniform([-1.95, -0.75, -0.8], [1.95, 0.75, 0.8], (per_car, 3))  # l, h, w
         x = loc[:, 0] * np.cos(ry) + loc[:, 2] * np.sin(ry)
         z = -loc[:, 0] * np.sin(ry) + loc[:, 2] * np.cos(ry)
         cars.append(np.stack([x, loc[:, 1], z], 1) + c)
