@@ -1,0 +1,233 @@
+"""Joint RPN+RCNN evaluation harness: the counterpart of the hot loop of
+pointrcnn/tools/eval_rcnn.py (eval_one_epoch_joint :466-690, save_kitti_format :76-101,
+checkpoint loading via train_utils.load_checkpoint :78-92) for synthetic KITTI-shaped scenes.
+
+Differences that are deliberate:
+  * the per-scene tail (score threshold -> sort -> rotated NMS -> D2H, :611-635) is batched on
+    the device: one masked sort, one launch of the device-resident NMS for all scenes, ONE D2H
+    copy per batch of fixed-shape (B,M,7)/(B,M)/(B) tensors;
+  * scenes shard across ranks (rank r takes scenes r, r+W, ...) and detections are combined with
+    one all_gather at the end (the reference is single-process);
+  * the reference's dataloader bug (`far_points=` keyword, eval_rcnn.py:862) is not reproduced.
+
+CLI (subset of the reference's flags):  python -m ... --cfg_file X --eval_mode rcnn --ckpt Y
+  --batch_size 8 --output_dir out [--set K V ...] [--scenes 64]
+"""
+import argparse
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import config as config_mod
+from . import kitti_utils
+from . import iou3d_utils
+from . import synth
+from .bbox_transform import decode_bbox_target
+from .net.point_rcnn import PointRCNN
+
+
+def build_model(cfg, device, seed=0):
+    """Random-init PointRCNN in TEST mode (eval_rcnn.py:758), deterministic in ``seed``."""
+    torch.manual_seed(seed)
+    model = PointRCNN(cfg, num_classes=2, use_xyz=True, mode="TEST")
+    return model.to(device).eval()
+
+
+def load_checkpoint(model, filename, logger=None):
+    """Accepts the reference's .pth layout {'model_state','optimizer_state','epoch','it'}
+    (train_utils.py:60-92); also a bare state_dict."""
+    ckpt = torch.load(filename, map_location="cpu")
+    state = ckpt["model_state"] if isinstance(ckpt, dict) and "model_state" in ckpt else ckpt
+    model.load_state_dict(state)
+    return ckpt.get("epoch", -1) if isinstance(ckpt, dict) else -1
+
+
+@torch.no_grad()
+def postprocess(cfg, ret_dict, batch_size):
+    """Final box decoding + score threshold + rotated NMS, batched (eval_rcnn.py:506-530,611-629).
+    Returns boxes (B,M,7), raw scores (B,M) and num (B) i32 on the device; rows >= num are zero."""
+    R = cfg.RCNN
+    rois = ret_dict["rois"]
+    M = rois.shape[1]
+    rcnn_cls = ret_dict["rcnn_cls"].view(batch_size, M, -1)
+    rcnn_reg = ret_dict["rcnn_reg"].view(batch_size, M, -1)
+    anchor = torch.from_numpy(cfg.CLS_MEAN_SIZE[0]).float().to(rois.device)
+    pred = decode_bbox_target(rois.view(-1, 7), rcnn_reg.view(-1, rcnn_reg.shape[-1]), anchor_size=anchor,
+                              loc_scope=R.LOC_SCOPE, loc_bin_size=R.LOC_BIN_SIZE, num_head_bin=R.NUM_HEAD_BIN,
+                              get_xz_fine=True, get_y_by_bin=R.LOC_Y_BY_BIN, loc_y_scope=R.LOC_Y_SCOPE,
+                              loc_y_bin_size=R.LOC_Y_BIN_SIZE, get_ry_fine=True).view(batch_size, M, 7)
+    if rcnn_cls.shape[2] != 1:
+        raise NotImplementedError("multi-class RCNN head")
+    raw = rcnn_cls[:, :, 0]
+    selected = torch.sigmoid(raw) > R.SCORE_THRESH
+    key = torch.where(selected, raw, torch.full_like(raw, float("-inf")))
+    _, order = torch.sort(key, dim=1, descending=True)          # selected boxes first, by raw score
+    counts = selected.sum(dim=1).to(torch.int32)
+    boxes_sorted = torch.gather(pred, 1, order.unsqueeze(-1).expand(-1, -1, 7))
+    scores_sorted = torch.gather(raw, 1, order)
+    bev = kitti_utils.boxes3d_to_bev_torch(boxes_sorted.reshape(-1, 7)).view(batch_size, M, 5)
+    keep, num = iou3d_utils.nms_device_batched(bev, counts, R.NMS_THRESH, True, M)
+    valid = torch.arange(M, device=raw.device).unsqueeze(0) < num.long().unsqueeze(1)
+    rows = keep.long().clamp(min=0)
+    boxes = torch.gather(boxes_sorted, 1, rows.unsqueeze(-1).expand(-1, -1, 7)) * valid.unsqueeze(-1)
+    scores = torch.gather(scores_sorted, 1, rows) * valid
+    return {"boxes": boxes, "scores": scores, "num": num, "pred_boxes3d": pred, "raw_scores": raw}
+
+
+@torch.no_grad()
+def infer_batch(model, cfg, pts_input):
+    """pts_input (B,N,3) device f32 -> detections dict (all device tensors, fixed shapes)."""
+    ret = model({"pts_input": pts_input})
+    det = postprocess(cfg, ret, pts_input.shape[0])
+    det["rois"] = ret["rois"]
+    det["rcnn_reg"] = ret["rcnn_reg"]
+    det["rcnn_cls"] = ret["rcnn_cls"]
+    return det
+
+
+def save_kitti_format(sample_id, calib, bbox3d, kitti_output_dir, scores, img_shape, cls_name="Car"):
+    """16-field KITTI label lines, %.4f (eval_rcnn.py:76-101): boxes projecting wider/taller than
+    80 % of the image are dropped; alpha = -sign(beta)*pi/2 + beta + ry with beta = atan2(z, x)."""
+    path = os.path.join(kitti_output_dir, "%06d.txt" % sample_id)
+    if bbox3d.shape[0] == 0:
+        open(path, "w").close()
+        return 0
+    corners3d = kitti_utils.boxes3d_to_corners3d(bbox3d)
+    img_boxes, _ = calib.corners3d_to_img_boxes(corners3d)
+    img_boxes[:, 0] = np.clip(img_boxes[:, 0], 0, img_shape[1] - 1)
+    img_boxes[:, 1] = np.clip(img_boxes[:, 1], 0, img_shape[0] - 1)
+    img_boxes[:, 2] = np.clip(img_boxes[:, 2], 0, img_shape[1] - 1)
+    img_boxes[:, 3] = np.clip(img_boxes[:, 3], 0, img_shape[0] - 1)
+    bw, bh = img_boxes[:, 2] - img_boxes[:, 0], img_boxes[:, 3] - img_boxes[:, 1]
+    ok = np.logical_and(bw < img_shape[1] * 0.8, bh < img_shape[0] * 0.8)
+    written = 0
+    with open(path, "w") as f:
+        for k in range(bbox3d.shape[0]):
+            if not ok[k]:
+                continue
+            x, z, ry = bbox3d[k, 0], bbox3d[k, 2], bbox3d[k, 6]
+            beta = np.arctan2(z, x)
+            alpha = -np.sign(beta) * np.pi / 2 + beta + ry
+            print("%s -1 -1 %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f" %
+                  (cls_name, alpha, img_boxes[k, 0], img_boxes[k, 1], img_boxes[k, 2], img_boxes[k, 3],
+                   bbox3d[k, 3], bbox3d[k, 4], bbox3d[k, 5], bbox3d[k, 0], bbox3d[k, 1], bbox3d[k, 2],
+                   bbox3d[k, 6], scores[k]), file=f)
+            written += 1
+    return written
+
+
+def shard_scene_ids(num_scenes, rank, world):
+    """Rank r evaluates scenes r, r+world, ... (independent units)."""
+    return list(range(rank, num_scenes, world))
+
+
+def pack_detections(scene_ids, det_batches, max_det):
+    """Host-side table [S, max_det, 9] = 7 box + score + scene id, zero padded, plus counts [S]."""
+    S = len(scene_ids)
+    table = torch.zeros((S, max_det, 9), dtype=torch.float32)
+    counts = torch.zeros((S,), dtype=torch.int32)
+    i = 0
+    for boxes, scores, num in det_batches:
+        b = boxes.shape[0]
+        table[i:i + b, :, 0:7] = boxes
+        table[i:i + b, :, 7] = scores
+        counts[i:i + b] = num
+        i += b
+    table[:, :, 8] = torch.tensor(scene_ids, dtype=torch.float32).view(-1, 1)
+    return table, counts
+
+
+def all_gather_detections(table, counts, device):
+    """The ONE collective of the job: all ranks exchange their padded detection tables
+    (RCCL all_gather over xGMI when the backend is nccl; gloo in the CPU tests).  Tables are
+    padded to the largest per-rank scene count so that all_gather_into_tensor applies."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return table, counts
+    world = dist.get_world_size()
+    n_local = torch.tensor([table.shape[0]], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local)
+    smax = int(max(int(s.item()) for s in sizes))
+    pad_t = torch.zeros((smax,) + tuple(table.shape[1:]), dtype=table.dtype, device=device)
+    pad_c = torch.full((smax,), -1, dtype=torch.int32, device=device)   # -1 marks padding rows
+    pad_t[:table.shape[0]] = table.to(device)
+    pad_c[:counts.shape[0]] = counts.to(device)
+    out_t = torch.empty((world * smax,) + tuple(table.shape[1:]), dtype=table.dtype, device=device)
+    out_c = torch.empty((world * smax,), dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(out_t, pad_t)
+    dist.all_gather_into_tensor(out_c, pad_c)
+    real = out_c >= 0
+    return out_t[real].cpu(), out_c[real].cpu()
+
+
+@torch.no_grad()
+def eval_synthetic(model, cfg, device, scene_ids, batch_size=8, npoints=16384, output_dir=None, raw_points=None):
+    """Evaluate the given synthetic scene ids on this rank.  Returns (table, counts) as
+    pack_detections.  If raw_points is set, scenes are generated with that many points and
+    reduced to ``npoints`` by the reference's near/far sampler (cross-domain config)."""
+    calib = synth.SyntheticCalib()
+    if output_dir:
+        os.makedirs(output_dir, exist_ok=True)
+    M = cfg.TEST.RPN_POST_NMS_TOP_N
+    batches = []
+    for s in range(0, len(scene_ids), batch_size):
+        ids = scene_ids[s:s + batch_size]
+        if raw_points:
+            clouds = [synth.subsample_rpn(synth.dense_scene(i, raw_points), npoints,
+                                          rng=np.random.default_rng(1024 + i)) for i in ids]
+        else:
+            clouds = [synth.scene(i, npoints) for i in ids]
+        pts = torch.from_numpy(np.stack(clouds, 0)).to(device, non_blocking=True)
+        det = infer_batch(model, cfg, pts)
+        boxes, scores, num = det["boxes"].cpu(), det["scores"].cpu(), det["num"].cpu()   # one D2H per batch
+        batches.append((boxes, scores, num))
+        if output_dir:
+            for k, sid in enumerate(ids):
+                n = int(num[k])
+                save_kitti_format(sid, calib, boxes[k, :n].numpy(), output_dir, scores[k, :n].numpy(),
+                                  calib.image_shape, cfg.CLASSES)
+    return pack_detections(scene_ids, batches, M)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="PointRCNN joint evaluation on synthetic KITTI-shaped scenes (MI355X)")
+    ap.add_argument("--cfg_file", type=str, default=None, help="reference-style yaml (tools/cfgs/*.yaml)")
+    ap.add_argument("--eval_mode", type=str, default="rcnn")
+    ap.add_argument("--ckpt", type=str, default=None, help="reference .pth checkpoint (random init if omitted)")
+    ap.add_argument("--batch_size", type=int, default=8)
+    ap.add_argument("--scenes", type=int, default=16)
+    ap.add_argument("--output_dir", type=str, default=None)
+    ap.add_argument("--set", dest="set_cfgs", default=None, nargs=argparse.REMAINDER)
+    args = ap.parse_args(argv)
+
+    cfg = config_mod.make_cfg()
+    config_mod.apply_eval_defaults(cfg, args.eval_mode)
+    if args.cfg_file:
+        config_mod.cfg_from_file(cfg, args.cfg_file)
+        config_mod.apply_eval_defaults(cfg, args.eval_mode) if False else None
+    if args.set_cfgs:
+        config_mod.cfg_from_list(cfg, args.set_cfgs)
+    if not torch.cuda.is_available():
+        raise RuntimeError("eval_rcnn: no GPU visible; this build has no CPU path")
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(device)
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")
+    model = build_model(cfg, device)
+    if args.ckpt:
+        load_checkpoint(model, args.ckpt)
+    out = os.path.join(args.output_dir, "final_result", "data") if args.output_dir else None
+    table, counts = eval_synthetic(model, cfg, device, shard_scene_ids(args.scenes, rank, world),
+                                   args.batch_size, cfg.RPN.NUM_POINTS, out)
+    table, counts = all_gather_detections(table, counts, device)
+    if rank == 0:
+        print("scenes=%d detections=%d" % (table.shape[0], int(counts.sum())))
+
+
+if __name__ == "__main__":
+    main()

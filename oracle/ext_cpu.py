@@ -1,0 +1,140 @@
+"""CPU stand-ins for the three extension modules, backed by the C ORACLE.
+
+TEST INFRASTRUCTURE ONLY: tests (and bench.py's cpu_baseline leg / the in-container fixture
+generator) monkeypatch these objects over ``pointnet2_utils.pointnet2``,
+``iou3d_utils.iou3d_cuda`` and ``roipool3d_utils.roipool3d_cuda`` to run the SAME Python model
+code on CPU tensors with the oracle as the operator backend.  The shipped package never imports
+this file and has no CPU path of its own.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import oracle as O
+
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int)
+_l = C.POINTER(C.c_longlong)
+
+
+def _p(t, ty):
+    assert not t.is_cuda and t.is_contiguous()
+    return C.cast(t.data_ptr(), ty)
+
+
+class pointnet2_cpu:
+    @staticmethod
+    def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+        O.lib().orc_ball_query(b, n, m, C.c_float(radius), nsample, _p(new_xyz, _f), _p(xyz, _f), _p(idx, _i))
+        return 1
+
+    @staticmethod
+    def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
+        O.lib().orc_group_points(b, c, n, npoints, nsample, _p(points, _f), _p(idx, _i), _p(out, _f))
+        return 1
+
+    @staticmethod
+    def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
+        O.lib().orc_group_points_grad(b, c, n, npoints, nsample, _p(grad_out, _f), _p(idx, _i), _p(grad_points, _f))
+        return 1
+
+    @staticmethod
+    def gather_points_wrapper(b, c, n, npoints, points, idx, out):
+        O.lib().orc_gather_points(b, c, n, npoints, _p(points, _f), _p(idx, _i), _p(out, _f))
+        return 1
+
+    @staticmethod
+    def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
+        O.lib().orc_gather_points_grad(b, c, n, npoints, _p(grad_out, _f), _p(idx, _i), _p(grad_points, _f))
+        return 1
+
+    @staticmethod
+    def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
+        O.lib().orc_furthest_point_sampling(b, n, m, _p(points, _f), _p(temp, _f), _p(idx, _i))
+        return 1
+
+    @staticmethod
+    def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+        O.lib().orc_three_nn(b, n, m, _p(unknown, _f), _p(known, _f), _p(dist2, _f), _p(idx, _i))
+
+    @staticmethod
+    def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
+        O.lib().orc_three_interpolate(b, c, m, n, _p(points, _f), _p(idx, _i), _p(weight, _f), _p(out, _f))
+
+    @staticmethod
+    def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+        O.lib().orc_three_interpolate_grad(b, c, n, m, _p(grad_out, _f), _p(idx, _i), _p(weight, _f), _p(grad_points, _f))
+
+    @staticmethod
+    def query_and_group_wrapper(b, n, m, c, radius, nsample, new_xyz, xyz, features, idx, out):
+        O.lib().orc_query_and_group(b, n, m, c, C.c_float(radius), nsample, _p(new_xyz, _f), _p(xyz, _f),
+                                    _p(features, _f) if features is not None else None, _p(idx, _i), _p(out, _f))
+        return 1
+
+
+class iou3d_cpu:
+    @staticmethod
+    def boxes_overlap_bev_gpu(boxes_a, boxes_b, ans):
+        O.lib().orc_boxes_overlap_bev(boxes_a.size(0), _p(boxes_a, _f), boxes_b.size(0), _p(boxes_b, _f), _p(ans, _f))
+        return 1
+
+    @staticmethod
+    def boxes_iou_bev_gpu(boxes_a, boxes_b, ans):
+        O.lib().orc_boxes_iou_bev(boxes_a.size(0), _p(boxes_a, _f), boxes_b.size(0), _p(boxes_b, _f), _p(ans, _f))
+        return 1
+
+    @staticmethod
+    def nms_gpu(boxes, keep, thresh):
+        return O.lib().orc_nms(boxes.size(0), _p(boxes, _f), _p(keep, _l), C.c_float(thresh))
+
+    @staticmethod
+    def nms_normal_gpu(boxes, keep, thresh):
+        return O.lib().orc_nms_normal(boxes.size(0), _p(boxes, _f), _p(keep, _l), C.c_float(thresh))
+
+    @staticmethod
+    def nms_device(boxes, counts, thresh, rotated, max_keep, keep, num_keep):
+        """Reference semantics: full greedy NMS per problem, then the first max_keep entries."""
+        P, nmax, _ = boxes.shape
+        fn = O.lib().orc_nms if rotated else O.lib().orc_nms_normal
+        keep.fill_(-1)
+        for p in range(P):
+            n = nmax if counts is None else int(counts[p])
+            n = max(0, min(n, nmax))
+            buf = torch.zeros(max(n, 1), dtype=torch.int64)
+            k = fn(n, _p(boxes[p].contiguous(), _f), _p(buf, _l), C.c_float(thresh)) if n else 0
+            k = min(k, max_keep)
+            keep[p, :k] = buf[:k].to(torch.int32)
+            num_keep[p] = k
+        return 1
+
+
+class roipool3d_cpu:
+    @staticmethod
+    def forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag):
+        O.lib().orc_roipool3d(xyz.size(0), xyz.size(1), boxes3d.size(1), pts_feature.size(2),
+                              pooled_features.size(2), _p(xyz, _f), _p(boxes3d, _f), _p(pts_feature, _f),
+                              _p(pooled_features, _f), _p(pooled_empty_flag, _i))
+        return 1
+
+    forward_slow = forward
+
+
+def patch_package(pkg_name="3d_adapt_auto_driving_amd"):
+    """Context manager: run the package's Python model code on CPU tensors with the oracle as the
+    operator backend.  Restores the HIP extension modules on exit."""
+    import contextlib
+    import importlib
+
+    @contextlib.contextmanager
+    def _cm():
+        pu = importlib.import_module(pkg_name + ".pointnet2.pointnet2_utils")
+        iu = importlib.import_module(pkg_name + ".iou3d_utils")
+        ru = importlib.import_module(pkg_name + ".roipool3d_utils")
+        saved = (pu.pointnet2, iu.iou3d_cuda, ru.roipool3d_cuda)
+        pu.pointnet2, iu.iou3d_cuda, ru.roipool3d_cuda = pointnet2_cpu, iou3d_cpu, roipool3d_cpu
+        try:
+            yield
+        finally:
+            pu.pointnet2, iu.iou3d_cuda, ru.roipool3d_cuda = saved
+    return _cm()

@@ -1,0 +1,222 @@
+"""Generates the committed golden fixtures under tests/golden/*.npz.
+
+RUN IN THE BUILD CONTAINER ONLY (needs /root/reference, read-only):   python tests/golden/make_golden.py
+The fixtures are DATA (inputs + expected outputs); no reference source is stored.  Sources of truth:
+
+  g5_roipool_ref.npz   outputs of the REFERENCE's own compiled CPU code (oracle/_ref = roipool3d.cpp
+                       built by oracle/Makefile): pts_in_boxes3d_cpu, roipool3d_cpu
+  g7_glue_ref.npz      outputs of the reference's importable Python glue: decode_bbox_target (both
+                       flag sets used on the path), boxes3d_to_bev_torch, enlarge_box3d,
+                       rotate_pc_along_y_torch, boxes3d_to_corners3d, Calibration.corners3d_to_img_boxes
+  g8_e2e_tiny_ref.npz  the reference PointRCNN (imported under tests/golden/ref_harness.py shims, oracle
+                       operator backend) on a tiny config: weights, input, rois, rcnn_cls, rcnn_reg and the
+                       final boxes produced with the reference's own decode + nms_gpu sequence
+                       (eval_rcnn.py:516-530,611-629)
+  g_ops_oracle.npz     oracle outputs for ball query / FPS / three_nn / group / NMS / overlap / rotate_iou
+                       on small seeded inputs with the edge cases of SURVEY.md section 8c (regression pins; the
+                       tests also check them against independent numpy brute force)
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import ref_harness as H  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+import helpers  # noqa: E402
+
+TINY = {  # G8 tiny configuration: same topology as default.yaml, ~60 k parameters
+    "RPN": {"NUM_POINTS": 2048,
+            "SA_CONFIG": {"NPOINTS": [512, 128, 32, 8],
+                          "MLPS": [[[8, 8, 16], [8, 8, 16]], [[16, 16, 32], [16, 16, 32]],
+                                   [[32, 32, 32], [32, 32, 32]], [[32, 32, 64], [32, 32, 64]]]},
+            "FP_MLPS": [[128, 128], [32, 32], [32, 32], [32, 32]],
+            "CLS_FC": [32], "REG_FC": [32]},
+    "RCNN": {"XYZ_UP_LAYER": [128, 128], "NUM_POINTS": 128,
+             "SA_CONFIG": {"NPOINTS": [32, 8, -1], "NSAMPLE": [16, 16, 16],
+                           "MLPS": [[32, 32, 32], [32, 32, 64], [64, 64, 64]]},
+             "CLS_FC": [32, 32], "REG_FC": [32, 32]},
+    "TEST": {"RPN_PRE_NMS_TOP_N": 600, "RPN_POST_NMS_TOP_N": 20},
+}
+
+
+def g5():
+    ref = O.load_reference_roipool()
+    assert ref is not None, "build oracle/_ref first: make -C oracle ref"
+    rng = np.random.default_rng(50)
+    pts = rng.uniform([-12, 0, 18], [12, 3, 42], (4096, 3)).astype(np.float32)   # dense patch
+    boxes = helpers.boxes3d(rng, 16, xz_scope=((-10, 10), (20, 40)))
+    boxes[3, :3] = [300, 300, 300]                     # empty
+    boxes[0] = [0, 2.6, 30, 4, 30, 30, 0.3]            # > 512 points
+    boxes[1, :3] = pts[7] + [0, 0.8, 0]                # a handful of points
+    feat = rng.standard_normal((4096, 9)).astype(np.float32)
+    flag = torch.zeros((16, 4096), dtype=torch.long)
+    ref.pts_in_boxes3d_cpu(flag, torch.from_numpy(pts), torch.from_numpy(boxes))
+    pp, pf, pe = torch.zeros(16, 512, 3), torch.zeros(16, 512, 9), torch.zeros(16, dtype=torch.long)
+    ref.roipool3d_cpu(torch.from_numpy(pts), torch.from_numpy(boxes), torch.from_numpy(feat), pp, pf, pe)
+    np.savez_compressed(os.path.join(HERE, "g5_roipool_ref.npz"), pts=pts, boxes=boxes, feat=feat,
+                        pts_flag=flag.numpy().astype(np.uint8), pooled_pts=pp.numpy(),
+                        pooled_features=pf.numpy(),
+                        pooled_empty_flag=pe.numpy())
+    print("g5: hits per box", flag.sum(1).tolist())
+
+
+def g7():
+    H.install()
+    from lib.utils.bbox_transform import decode_bbox_target
+    import lib.utils.kitti_utils as ku
+    from lib.utils.calibration import Calibration
+    rng = np.random.default_rng(70)
+    anchor = torch.tensor([1.52563191462, 1.62856739989, 3.88311640418])
+    out = {}
+    # RPN flavour (proposal_layer.py:23-30): points (N,3), 76 channels, xz fine, full-circle heading
+    xyz = torch.from_numpy(rng.uniform([-40, -1, 0], [40, 3, 70], (300, 3)).astype(np.float32))
+    reg = torch.from_numpy(rng.standard_normal((300, 76)).astype(np.float32))
+    out["rpn_xyz"], out["rpn_reg"] = xyz.numpy(), reg.numpy()
+    out["rpn_boxes"] = decode_bbox_target(xyz.clone(), reg.clone(), anchor_size=anchor, loc_scope=3.0, loc_bin_size=0.5,
+                                          num_head_bin=12, get_xz_fine=True, get_y_by_bin=False,
+                                          get_ry_fine=False).numpy()
+    # RCNN flavour (eval_rcnn.py:516-523): RoIs (N,7), 46 channels, fine heading
+    rois = torch.from_numpy(helpers.boxes3d(rng, 200))
+    reg2 = torch.from_numpy(rng.standard_normal((200, 46)).astype(np.float32))
+    out["rcnn_rois"], out["rcnn_reg"] = rois.numpy(), reg2.numpy()
+    out["rcnn_boxes"] = decode_bbox_target(rois.clone(), reg2.clone(), anchor_size=anchor, loc_scope=1.5, loc_bin_size=0.5,
+                                           num_head_bin=9, get_xz_fine=True, get_y_by_bin=False, loc_y_scope=0.5,
+                                           loc_y_bin_size=0.25, get_ry_fine=True).numpy()
+    out["bev"] = ku.boxes3d_to_bev_torch(rois).numpy()
+    out["enlarged"] = ku.enlarge_box3d(rois, 1.0).numpy()
+    pc = torch.from_numpy(rng.standard_normal((200, 16, 5)).astype(np.float32))
+    out["rot_pc_in"] = pc.numpy().copy()
+    out["rot_pc_out"] = ku.rotate_pc_along_y_torch(pc.clone(), rois[:, 6]).numpy()
+    corners = ku.boxes3d_to_corners3d(rois.numpy())
+    out["corners3d"] = corners
+    P2 = np.array([[707.05, 0., 604., 45.], [0., 707.05, 180., 0.2], [0., 0., 1., 0.003]], dtype=np.float32)
+    calib = Calibration({"P2": P2, "R0": np.eye(3, dtype=np.float32), "Tr_velo2cam": np.zeros((3, 4), np.float32)})
+    ib, ic = calib.corners3d_to_img_boxes(corners)
+    out["img_boxes"], out["img_corners"] = ib, ic
+    np.savez_compressed(os.path.join(HERE, "g7_glue_ref.npz"), **out)
+    print("g7 done")
+
+
+def g8():
+    model, cfg = H.reference_model(TINY)
+    torch.manual_seed(8)
+    # random-init leaves the heads near zero; spread them so that decisions are not degenerate
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if "reg_layer" in name or "cls_layer" in name:
+                if p.dim() > 1:
+                    p.copy_(torch.randn_like(p) * 0.3)
+                else:
+                    p.copy_(torch.randn_like(p) * 0.5)
+        model.rpn.rpn_cls_layer[-1].conv.bias.zero_()     # ~half of the points become foreground
+        for m in model.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.running_mean.copy_(torch.randn_like(m.running_mean) * 0.1)
+                m.running_var.copy_(torch.rand_like(m.running_var) + 0.5)
+    pts = torch.from_numpy(helpers.scenes(2, 2048, seed0=80))
+    with torch.no_grad():
+        ret = model({"pts_input": pts})
+        # centre the segmentation threshold (sigmoid > 0.3 <=> raw > -0.8473) on the median score so
+        # that roughly half of the points are foreground, then run the pass that is recorded
+        model.rpn.rpn_cls_layer[-1].conv.bias += (-0.8473 - ret["rpn_cls"].median())
+        ret = model({"pts_input": pts})
+    from lib.utils.bbox_transform import decode_bbox_target
+    import lib.utils.kitti_utils as ku
+    import lib.utils.iou3d.iou3d_utils as iu
+    B = 2
+    anchor = torch.from_numpy(cfg.CLS_MEAN_SIZE[0])
+    rcnn_cls = ret["rcnn_cls"].view(B, -1, ret["rcnn_cls"].shape[1])
+    rcnn_reg = ret["rcnn_reg"].view(B, -1, ret["rcnn_reg"].shape[1])
+    pred = decode_bbox_target(ret["rois"].view(-1, 7), rcnn_reg.view(-1, rcnn_reg.shape[-1]), anchor_size=anchor,
+                              loc_scope=cfg.RCNN.LOC_SCOPE, loc_bin_size=cfg.RCNN.LOC_BIN_SIZE,
+                              num_head_bin=cfg.RCNN.NUM_HEAD_BIN, get_xz_fine=True,
+                              get_y_by_bin=cfg.RCNN.LOC_Y_BY_BIN, loc_y_scope=cfg.RCNN.LOC_Y_SCOPE,
+                              loc_y_bin_size=cfg.RCNN.LOC_Y_BIN_SIZE, get_ry_fine=True).view(B, -1, 7)
+    norm = torch.sigmoid(rcnn_cls)
+    inds = norm > cfg.RCNN.SCORE_THRESH
+    M = pred.shape[1]
+    final_boxes = np.zeros((B, M, 7), np.float32); final_scores = np.zeros((B, M), np.float32)
+    final_num = np.zeros((B,), np.int32)
+    for k in range(B):
+        cur = inds[k].view(-1)
+        if cur.sum() == 0:
+            continue
+        sel_boxes, sel_raw = pred[k, cur], rcnn_cls[k, cur]
+        keep = iu.nms_gpu(ku.boxes3d_to_bev_torch(sel_boxes), sel_raw.view(-1), cfg.RCNN.NMS_THRESH).view(-1)
+        n = len(keep)
+        final_boxes[k, :n] = sel_boxes[keep].numpy(); final_scores[k, :n] = sel_raw[keep].view(-1).numpy()
+        final_num[k] = n
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    np.savez_compressed(os.path.join(HERE, "g8_e2e_tiny_ref.npz"), pts=pts.numpy(),
+                        rois=ret["rois"].numpy(), roi_scores_raw=ret["roi_scores_raw"].numpy(),
+                        rpn_cls=ret["rpn_cls"].numpy(), rcnn_cls=ret["rcnn_cls"].numpy(), rcnn_reg=ret["rcnn_reg"].numpy(),
+                        seg_result=ret["seg_result"].numpy(), final_boxes=final_boxes, final_scores=final_scores,
+                        final_num=final_num, state_keys=np.array(list(sd.keys())),
+                        **{"w/" + k: v for k, v in sd.items()})
+    print("g8: params", sum(v.size for v in sd.values()), "final_num", final_num.tolist(),
+          "seg fg", int(ret["seg_result"].sum()), "nonzero rois", int((ret["rois"].abs().sum(-1) > 0).sum()))
+
+
+def g_ops():
+    rng = np.random.default_rng(1)
+    out = {}
+    # G1 ball query: B=2,N=1024,M=256; empty ball, under-full ball, duplicate cloud
+    xyz = helpers.scenes(2, 1024, seed0=100)
+    xyz[1, 512:] = xyz[1, :512]                         # duplicate-point cloud
+    sel = O.furthest_point_sample(xyz, 256).astype(np.int64)
+    new = np.take_along_axis(xyz, sel[..., None].repeat(3, -1), 1)
+    new[0, 0] = [500, 500, 500]
+    out["bq_xyz"], out["bq_new"] = xyz, new
+    for r in (0.1, 0.2, 0.4, 2.0):
+        for ns in (16, 32, 64):
+            out["bq_r%g_ns%d" % (r, ns)] = O.ball_query(r, ns, xyz, new)
+    # G2 FPS incl. lattice + duplicates (tie rule) for several n
+    g = np.stack(np.meshgrid(np.arange(16), np.arange(8), np.arange(16), indexing="ij"), -1).reshape(-1, 3)
+    lat = g[rng.permutation(len(g))].astype(np.float32)
+    for n, m in ((128, 32), (512, 128), (1000, 100), (1024, 256), (2048, 512)):
+        cloud = lat[:n][None].copy()
+        out["fps_lat_in_%d" % n] = cloud
+        out["fps_lat_%d" % n] = O.furthest_point_sample(cloud, m)
+        rnd = helpers.scenes(1, n, seed0=200 + n)
+        out["fps_rnd_in_%d" % n] = rnd
+        out["fps_rnd_%d" % n] = O.furthest_point_sample(rnd, m)
+    # G3 three_nn with ties
+    unk = helpers.scenes(1, 512, seed0=300)
+    kn = unk[:, ::8].copy(); kn[0, 1] = kn[0, 0]
+    d2, i3 = O.three_nn(unk, kn)
+    out["nn_unknown"], out["nn_known"], out["nn_d2"], out["nn_idx"] = unk, kn, d2, i3
+    # G6 NMS + overlap on 256 boxes
+    bx = helpers.bev_boxes(rng, 256, spread=10.0)
+    out["nms_boxes"] = bx
+    out["nms_rot_keep"] = O.nms(bx, 0.1)
+    out["nms_norm_keep"] = O.nms_normal(bx, 0.5)
+    out["overlap"] = O.boxes_overlap_bev(bx[:64], bx[64:128])
+    out["iou_bev"] = O.boxes_iou_bev(bx[:64], bx[64:128])
+    # G9 rotate_iou
+    cb = np.stack([rng.uniform(-6, 6, 80), rng.uniform(-6, 6, 80), rng.uniform(1.4, 2, 80), rng.uniform(3, 5, 80),
+                   rng.uniform(-np.pi, np.pi, 80)], 1).astype(np.float32)
+    out["riou_boxes"] = cb
+    for crit in (-1, 0, 1, 2):
+        out["riou_c%d" % crit] = O.rotate_iou_eval(cb[:50], cb[50:], crit)
+    np.savez_compressed(os.path.join(HERE, "g_ops_oracle.npz"), **out)
+    print("g_ops done")
+
+
+if __name__ == "__main__":
+    assert H.available(), "/root/reference is not mounted: fixtures can only be regenerated in the build container"
+    g5()
+    g7()
+    g_ops()
+    g8()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

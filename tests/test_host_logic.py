@@ -1,0 +1,209 @@
+"""CPU tests of the host-side Python (glue + model) against fixtures produced by the REFERENCE's
+own Python (tests/golden/make_golden.py) and of the C-ABI surface (load + exported symbols)."""
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg, ROOT
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def test_capi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "prcnn_hip.h")).read()
+    declared = set(re.findall(r"\b(prcnn_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    lib = pkg("_lib").load()                       # loads without a GPU; no compute call here
+    for name in declared:
+        assert hasattr(lib, name), "libprcnn_hip.so does not export %s" % name
+    assert declared - {"prcnn_last_error"} == set(pkg("_lib").SIGNATURES)
+    assert lib.prcnn_version() >= 100
+    assert lib.prcnn_opt_n_threads(1000) == 512
+
+
+def test_capi_rejects_bad_arguments_without_gpu():
+    L = pkg("_lib")
+    with pytest.raises(L.PrcnnError, match="null pointer"):
+        L.call("prcnn_ball_query", 1, 8, 8, 0.1, 4, None, None, None, None)
+    with pytest.raises(L.PrcnnError, match="bad sizes"):
+        L.call("prcnn_three_nn", -1, 8, 8, None, None, None, None, None)
+    with pytest.raises(L.PrcnnError):
+        L.call("prcnn_rotate_iou_eval", 2, 2, None, None, None, 7, None)
+
+
+def test_no_cpu_fallback_in_product_ops():
+    pu = pkg("pointnet2.pointnet2_utils")
+    xyz = torch.zeros((1, 16, 3))
+    with pytest.raises(RuntimeError, match="CUDA"):
+        pu.furthest_point_sample(xyz, 4)
+    with pytest.raises(NotImplementedError):
+        pkg("roipool3d_utils").pts_in_boxes3d_cpu(xyz[0], torch.zeros((1, 7)))
+    # nothing under the package imports the oracle
+    pdir = pkg().PACKAGE_DIR
+    for dp, _, files in os.walk(pdir):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
+
+
+def test_glue_matches_reference_python():
+    g = load("g7_glue_ref.npz")
+    bt, ku = pkg("bbox_transform"), pkg("kitti_utils")
+    anchor = torch.tensor([1.52563191462, 1.62856739989, 3.88311640418])
+    rpn = bt.decode_bbox_target(torch.from_numpy(g["rpn_xyz"]), torch.from_numpy(g["rpn_reg"]), anchor_size=anchor,
+                                loc_scope=3.0, loc_bin_size=0.5, num_head_bin=12, get_xz_fine=True,
+                                get_y_by_bin=False, get_ry_fine=False)
+    assert np.array_equal(rpn.numpy(), g["rpn_boxes"])
+    rois = torch.from_numpy(g["rcnn_rois"])
+    rc = bt.decode_bbox_target(rois.clone(), torch.from_numpy(g["rcnn_reg"]), anchor_size=anchor, loc_scope=1.5,
+                               loc_bin_size=0.5, num_head_bin=9, get_xz_fine=True, get_y_by_bin=False,
+                               loc_y_scope=0.5, loc_y_bin_size=0.25, get_ry_fine=True)
+    assert np.array_equal(rc.numpy(), g["rcnn_boxes"])
+    assert np.array_equal(ku.boxes3d_to_bev_torch(rois).numpy(), g["bev"])
+    assert np.array_equal(ku.enlarge_box3d(rois, 1.0).numpy(), g["enlarged"])
+    assert np.array_equal(ku.enlarge_box3d(rois.numpy(), 1.0), g["enlarged"])
+    pc = torch.from_numpy(g["rot_pc_in"].copy())
+    assert np.array_equal(ku.rotate_pc_along_y_torch(pc, rois[:, 6]).numpy(), g["rot_pc_out"])
+    corners = ku.boxes3d_to_corners3d(g["rcnn_rois"])
+    assert np.array_equal(corners, g["corners3d"])
+    ib, ic = pkg("synth").SyntheticCalib().corners3d_to_img_boxes(corners)
+    np.testing.assert_allclose(ib, g["img_boxes"], rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(ic, g["img_corners"], rtol=1e-6, atol=1e-4)
+
+
+def test_state_dict_layout_default_cfg():
+    cfg = pkg("config").default_eval_cfg()
+    model = pkg("eval_rcnn").build_model(cfg, "cpu")
+    sd = model.state_dict()
+    assert len(sd) == 244 and sum(v.numel() for v in sd.values()) == 3901774
+    assert "rpn.backbone_net.SA_modules.0.mlps.0.layer0.bn.bn.running_mean" in sd
+    assert "rpn.rpn_cls_layer.2.conv.bias" in sd and "rpn.rpn_cls_layer.1.conv.bias" not in sd
+    assert "rcnn_net.cls_layer.3.conv.weight" in sd and "rcnn_net.SA_modules.0.mlps.0.layer0.conv.bias" in sd
+    assert sd["rpn.rpn_reg_layer.2.conv.weight"].shape == (76, 128, 1)
+    assert sd["rcnn_net.reg_layer.3.conv.weight"].shape == (46, 256, 1)
+
+
+TINY = {"RPN": {"NUM_POINTS": 2048,
+                "SA_CONFIG": {"NPOINTS": [512, 128, 32, 8],
+                              "MLPS": [[[8, 8, 16], [8, 8, 16]], [[16, 16, 32], [16, 16, 32]],
+                                       [[32, 32, 32], [32, 32, 32]], [[32, 32, 64], [32, 32, 64]]]},
+                "FP_MLPS": [[128, 128], [32, 32], [32, 32], [32, 32]], "CLS_FC": [32], "REG_FC": [32]},
+        "RCNN": {"XYZ_UP_LAYER": [128, 128], "NUM_POINTS": 128,
+                 "SA_CONFIG": {"NPOINTS": [32, 8, -1], "NSAMPLE": [16, 16, 16],
+                               "MLPS": [[32, 32, 32], [32, 32, 64], [64, 64, 64]]},
+                 "CLS_FC": [32, 32], "REG_FC": [32, 32]},
+        "TEST": {"RPN_PRE_NMS_TOP_N": 600, "RPN_POST_NMS_TOP_N": 20}}
+
+
+def tiny_model(device="cpu"):
+    C = pkg("config")
+    cfg = C.default_eval_cfg()
+    C.merge_into(TINY, cfg)
+    model = pkg("eval_rcnn").build_model(cfg, device)
+    g = load("g8_e2e_tiny_ref.npz")
+    sd = {str(k): torch.from_numpy(g["w/" + str(k)]) for k in g["state_keys"]}
+    model.load_state_dict(sd)          # strict: the key tree must equal the reference's
+    return model, cfg, g
+
+
+def test_e2e_tiny_matches_reference_model(oracle):
+    """My model + oracle operator backend on CPU == the reference PointRCNN (run under the shim
+    harness when the fixture was made): same RoIs, same head outputs, same final detections."""
+    from oracle import ext_cpu
+    model, cfg, g = tiny_model()
+    pts = torch.from_numpy(g["pts"])
+    with ext_cpu.patch_package():
+        det = pkg("eval_rcnn").infer_batch(model, cfg, pts)
+    assert np.array_equal(det["rois"].numpy(), g["rois"])
+    np.testing.assert_allclose(det["rcnn_cls"].numpy(), g["rcnn_cls"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(det["rcnn_reg"].numpy(), g["rcnn_reg"], rtol=0, atol=1e-6)
+    assert np.array_equal(det["num"].numpy(), g["final_num"])
+    np.testing.assert_allclose(det["boxes"].numpy(), g["final_boxes"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(det["scores"].numpy(), g["final_scores"], rtol=0, atol=1e-6)
+    assert g["final_num"].min() >= 1 and g["seg_result"].sum() > 100
+
+
+def test_proposal_layer_far_band_fallback(oracle):
+    """No point beyond 40 m: the far band re-uses the next near proposals (proposal_layer.py:92-99).
+    Checked against a literal per-scene restatement with the oracle NMS."""
+    from oracle import ext_cpu
+    C = pkg("config")
+    cfg = C.default_eval_cfg()
+    C.merge_into({"TEST": {"RPN_PRE_NMS_TOP_N": 200, "RPN_POST_NMS_TOP_N": 20}}, cfg)
+    PL = pkg("net.proposal_layer").ProposalLayer(cfg, mode="TEST")
+    rng = np.random.default_rng(4)
+    B, N = 2, 600
+    xyz = torch.from_numpy(rng.uniform([-10, -1, 2], [10, 3, 38], (B, N, 3)).astype(np.float32))
+    xyz[1, :300, 2] += 40.0                                   # scene 1 does have far points
+    reg = torch.from_numpy(rng.standard_normal((B, N, 76)).astype(np.float32) * 0.2)
+    scores = torch.from_numpy(rng.standard_normal((B, N)).astype(np.float32))
+    with ext_cpu.patch_package():
+        rois, rs = PL(scores, reg, xyz)
+        # literal reference order, scene by scene
+        bt, ku, iu = pkg("bbox_transform"), pkg("kitti_utils"), pkg("iou3d_utils")
+        prop = bt.decode_bbox_target(xyz.view(-1, 3), reg.view(-1, 76), anchor_size=PL.MEAN_SIZE, loc_scope=3.0,
+                                     loc_bin_size=0.5, num_head_bin=12, get_xz_fine=True, get_y_by_bin=False,
+                                     get_ry_fine=False)
+        prop[:, 1] += prop[:, 3] / 2
+        prop = prop.view(B, N, 7)
+        for b in range(B):
+            order = torch.sort(scores[b], descending=True)[1]
+            so, po = scores[b][order], prop[b][order]
+            dist = po[:, 2]
+            first = (dist > 0) & (dist <= 40)
+            outs, outb = [], []
+            for i, (lo, hi, pre, post) in enumerate(((0, 40, 140, 14), (40, 80, 60, 6))):
+                m = (dist > lo) & (dist <= hi)
+                if m.sum() != 0:
+                    cs, cp = so[m][:pre], po[m][:pre]
+                else:
+                    assert i == 1
+                    cs, cp = so[first][140:][:pre], po[first][140:][:pre]
+                keep = iu.nms_normal_gpu(ku.boxes3d_to_bev_torch(cp), cs, 0.8)[:post]
+                outs.append(cs[keep]); outb.append(cp[keep])
+            wb, ws = torch.cat(outb), torch.cat(outs)
+            assert torch.equal(rois[b, :len(wb)], wb) and torch.equal(rs[b, :len(ws)], ws)
+            assert (rois[b, len(wb):] == 0).all()
+
+
+def test_kitti_writer_format(tmp_path):
+    E, S = pkg("eval_rcnn"), pkg("synth")
+    boxes = np.array([[1.0, 1.6, 20.0, 1.5, 1.6, 3.9, 0.3], [0.0, 1.6, 1.0, 1.5, 1.6, 3.9, 0.0]], np.float32)
+    n = E.save_kitti_format(7, S.SyntheticCalib(), boxes, str(tmp_path), np.array([1.5, 0.2]), (375, 1242))
+    lines = open(tmp_path / "000007.txt").read().strip().split("\n")
+    assert n == 1 and len(lines) == 1                    # the box at z=1 m fills the image and is dropped
+    f = lines[0].split()
+    assert f[0] == "Car" and len(f) == 16 and f[-1] == "1.5000" and f[11:14] == ["1.0000", "1.6000", "20.0000"]
+    E.save_kitti_format(8, S.SyntheticCalib(), boxes[:0], str(tmp_path), np.zeros(0), (375, 1242))
+    assert open(tmp_path / "000008.txt").read() == ""
+
+
+def test_subsample_rpn_semantics():
+    S = pkg("synth")
+    raw = S.dense_scene(3, 60000)
+    sub = S.subsample_rpn(raw, 16384, 4000, np.random.default_rng(1))
+    assert sub.shape == (16384, 3) and (sub[:, 2] >= 40).sum() == min(4000, (raw[:, 2] >= 40).sum())
+    small = S.subsample_rpn(raw[:5000], 16384)
+    assert small.shape == (16384, 3)
+    assert len(np.unique(small, axis=0)) <= 5000
+
+
+def test_config_merge_and_set():
+    C = pkg("config")
+    cfg = C.default_eval_cfg()
+    assert cfg.TEST.RPN_NMS_THRESH == 0.8 and cfg.RPN.LOC_XZ_FINE and cfg.RCNN.ENABLED and cfg.RPN.FIXED
+    C.cfg_from_list(cfg, ["RCNN.NMS_THRESH", "0.2", "RPN.NUM_POINTS", "32768"])
+    assert cfg.RCNN.NMS_THRESH == 0.2 and cfg.RPN.NUM_POINTS == 32768
+    with pytest.raises(ValueError):
+        C.cfg_from_list(cfg, ["RPN.NUM_POINTS", "'x'"])
+    with pytest.raises(KeyError):
+        C.merge_into({"NOPE": 1}, cfg, strict=True)
