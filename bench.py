@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X PointRCNN eval path.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One STEP = one pass of the joint RPN->RCNN hot path (eval_rcnn-equivalent: backbone SA/FP ops,
+proposal layer with device NMS, RoI pooling, RCNN, final decode + rotated NMS, async D2H of the
+detections) over ONE batch of 8 synthetic KITTI-shaped scenes (16384 points, random-init weights,
+default.yaml shapes) per GPU -- BASELINE.json configs[2]; inputs are resident in HBM before the
+timed region.  Scenes shard one batch per rank (weak scaling); the only collective is the final
+all_gather of the padded detection tables, inside the timed region.
+
+The JSON line also carries
+  roofline      fused ball_query+group (BASELINE.json configs[1]: B=8, N=16384, M=4096, C=128,
+                ns=32, r=0.2) timed with HIP events on the launch stream; achieved = algorithmic
+                bytes (SURVEY.md section 8d formula) / average duration of the launch pair
+  cpu_baseline  the same model code on the host cores with the C oracle as operator backend
+                (kind "port": the reference has no CPU path for this pipeline), rank 0, N=1 only.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "3d_adapt_auto_driving_amd"
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+BATCH = 8
+NPOINTS = 16384
+
+
+def algorithmic_bytes_qg(n, m, c, ns):
+    """read xyz once, centres, features once; write idx and the grouped tensor."""
+    return 12 * n + 12 * m + 4 * c * n + 4 * m * ns + 4 * (3 + c) * m * ns
+
+
+def roofline_query_and_group(dev, reps=20):
+    pkg = importlib.import_module(PKG)
+    if pkg.DROPIN_DIR not in sys.path:
+        sys.path.insert(0, pkg.DROPIN_DIR)
+    import pointnet2_cuda
+    synth = importlib.import_module(PKG + ".synth")
+    B, N, M, C, NS, R = BATCH, NPOINTS, 4096, 128, 32, 0.2
+    xyz = torch.from_numpy(synth.scenes(B, N, seed0=1000)).to(dev)
+    temp = torch.full((B, N), 1e10, device=dev)
+    sel = torch.empty((B, M), dtype=torch.int32, device=dev)
+    pointnet2_cuda.furthest_point_sampling_wrapper(B, N, M, xyz, temp, sel)
+    new_xyz = torch.gather(xyz, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    feats = torch.randn((B, C, N), device=dev)
+    idx = torch.empty((B, M, NS), dtype=torch.int32, device=dev)
+    out = torch.empty((B, 3 + C, M, NS), device=dev)
+    for _ in range(3):
+        pointnet2_cuda.query_and_group_wrapper(B, N, M, C, R, NS, new_xyz, xyz, feats, idx, out)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:   # HIP events recorded on the stream the kernels are launched on (torch's current stream)
+        a.record()
+        pointnet2_cuda.query_and_group_wrapper(B, N, M, C, R, NS, new_xyz, xyz, feats, idx, out)
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    nbytes = B * algorithmic_bytes_qg(N, M, C, NS)
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "ball_query_kernel+group_cat_kernel (prcnn_query_and_group)",
+            "launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": nbytes,
+            "shape": {"B": B, "N": N, "M": M, "C": C, "nsample": NS, "radius": R}}
+
+
+def cpu_baseline(cfg, scenes=2):
+    """Same Python model code on CPU tensors, operator backend = the C oracle (OpenMP), convs =
+    PyTorch CPU.  Bounded sample: `scenes` scenes of the same workload."""
+    from oracle import ext_cpu, oracle as O
+    E = importlib.import_module(PKG + ".eval_rcnn")
+    synth = importlib.import_module(PKG + ".synth")
+    model = E.build_model(cfg, "cpu")
+    pts = torch.from_numpy(synth.scenes(scenes, NPOINTS, seed0=0))
+    with ext_cpu.patch_package():
+        E.infer_batch(model, cfg, pts[:1])          # warm-up (allocator, thread pools)
+        t0 = time.perf_counter()
+        E.infer_batch(model, cfg, pts)
+        dt = time.perf_counter() - t0
+    return {"value": round(scenes / dt, 4), "unit": "scenes/s", "cores": int(max(O.num_threads(), torch.get_num_threads())),
+            "kind": "port", "sample": "%d synthetic scenes x %d points, full RPN+RCNN+postprocess, 1 batch" % (scenes, NPOINTS)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU product path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+
+    C = importlib.import_module(PKG + ".config")
+    E = importlib.import_module(PKG + ".eval_rcnn")
+    synth = importlib.import_module(PKG + ".synth")
+    cfg = C.default_eval_cfg()
+    model = E.build_model(cfg, dev, seed=0)
+    M = cfg.TEST.RPN_POST_NMS_TOP_N
+
+    # distinct synthetic scenes per rank and per step slot, resident in HBM before timing
+    n_slots = 2
+    batches = [torch.from_numpy(synth.scenes(BATCH, NPOINTS, seed0=(rank * n_slots + s) * BATCH)).to(dev)
+               for s in range(n_slots)]
+    total = args.warmup + args.steps
+    host_boxes = torch.empty((total, BATCH, M, 7), pin_memory=True)
+    host_scores = torch.empty((total, BATCH, M), pin_memory=True)
+    host_num = torch.empty((total, BATCH), dtype=torch.int32, pin_memory=True)
+
+    def step(i):
+        det = E.infer_batch(model, cfg, batches[i % n_slots])
+        host_boxes[i].copy_(det["boxes"], non_blocking=True)
+        host_scores[i].copy_(det["scores"], non_blocking=True)
+        host_num[i].copy_(det["num"], non_blocking=True)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        step(i)
+    torch.cuda.synchronize()
+    # the one exchange of the job: padded detection tables of this rank's scenes
+    ids = list(range(rank * args.steps * BATCH, (rank + 1) * args.steps * BATCH))
+    table, counts = E.pack_detections(ids, [(host_boxes[i], host_scores[i], host_num[i])
+                                            for i in range(args.warmup, total)], M)
+    table, counts = E.all_gather_detections(table, counts, dev)
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    scenes_total = world * args.steps * BATCH
+    line = {
+        "metric": "KITTI scenes/s end-to-end eval_rcnn (joint RPN+RCNN, synthetic 16384-pt scenes)",
+        "value": round(scenes_total / elapsed, 3), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[2]: full PointRCNN RPN+RCNN inference, default.yaml shapes, "
+                               "random-init weights, batch=8 synthetic KITTI scenes x 16384 pts per GPU per step",
+                   "scenes_per_step_per_gpu": BATCH, "points_per_scene": NPOINTS, "rois_per_scene": M,
+                   "parallelism": "scene-sharded x%d, one final all_gather of detections" % world,
+                   "detections_gathered": int(counts.sum()) if rank == 0 else None},
+    }
+    if rank == 0:
+        if not args.no_roofline:
+            line["roofline"] = roofline_query_and_group(dev)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

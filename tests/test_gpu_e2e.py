@@ -1,0 +1,145 @@
+"""-m gpu end-to-end parity: the model on the GPU (HIP operators through the C ABI, PyTorch-ROCm
+convolutions) against the same model on the CPU with the oracle operator backend, and against the
+fixture recorded from the REFERENCE model (tests/golden/g8_e2e_tiny_ref.npz).
+
+Tolerance (BASELINE.json north_star): indices bit-exact, box regressions within 1e-4.  The
+convolutions run in different libraries on the two sides (MIOpen/rocBLAS f32 vs MKL f32), so head
+outputs agree to ~1e-5 and an index decision (arg-max bin, sort order, NMS) could flip on a
+near-tie; the fixtures are built so that they do not (make_golden.py spreads the head weights),
+and the full-size test matches boxes one-to-one instead of assuming identical ordering."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from test_host_logic import tiny_model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_tiny_model_gpu_matches_reference_fixture():
+    model, cfg, g = tiny_model(DEV)
+    det = pkg("eval_rcnn").infer_batch(model, cfg, torch.from_numpy(g["pts"]).to(DEV))
+    np.testing.assert_allclose(det["rois"].cpu().numpy(), g["rois"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(det["rcnn_reg"].cpu().numpy(), g["rcnn_reg"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(det["rcnn_cls"].cpu().numpy(), g["rcnn_cls"], rtol=0, atol=1e-4)
+    assert np.array_equal(det["num"].cpu().numpy(), g["final_num"])                    # NMS keep counts
+    np.testing.assert_allclose(det["boxes"].cpu().numpy(), g["final_boxes"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(det["scores"].cpu().numpy(), g["final_scores"], rtol=0, atol=1e-4)
+
+
+def test_backbone_indices_bit_exact_full_size(oracle):
+    """FPS / ball-query indices of all four RPN SA levels on a full 16384-point scene: the xyz chain
+    involves no convolution, so GPU and oracle must agree exactly at every level."""
+    pu = pkg("pointnet2.pointnet2_utils")
+    xyz = pkg("synth").scenes(2, 16384, seed0=40)
+    cur_g, cur_c = torch.from_numpy(xyz).to(DEV), xyz
+    for npoint, radii, ns in ((4096, (0.1, 0.5), (16, 32)), (1024, (0.5, 1.0), (16, 32)),
+                              (256, (1.0, 2.0), (16, 32)), (64, (2.0, 4.0), (16, 32))):
+        sel = pu.furthest_point_sample(cur_g, npoint)
+        want = oracle.furthest_point_sample(cur_c, npoint)
+        assert np.array_equal(sel.cpu().numpy(), want)
+        new_g = pu.gather_operation(cur_g.transpose(1, 2).contiguous(), sel).transpose(1, 2).contiguous()
+        new_c = np.take_along_axis(cur_c, want.astype(np.int64)[..., None].repeat(3, -1), 1)
+        assert np.array_equal(new_g.cpu().numpy(), new_c)
+        for r, s in zip(radii, ns):
+            assert np.array_equal(pu.ball_query(r, s, cur_g, new_g).cpu().numpy(), oracle.ball_query(r, s, cur_c, new_c))
+        cur_g, cur_c = new_g, new_c
+
+
+def match_boxes(a, b):
+    """greedy one-to-one matching of two (n,7) box sets by centre distance -> max abs diff of pairs"""
+    if len(a) == 0 or len(b) == 0:
+        return 0.0, 0
+    d = np.linalg.norm(a[:, None, :3] - b[None, :, :3], axis=2)
+    worst, used, matched = 0.0, set(), 0
+    for i in np.argsort(d.min(1)):
+        j = int(np.argmin(d[i]))
+        if j in used or d[i, j] > 0.05:
+            continue
+        used.add(j); matched += 1
+        worst = max(worst, float(np.abs(a[i] - b[j]).max()))
+    return worst, matched
+
+
+def test_full_size_gpu_vs_cpu_oracle_boxes(oracle):
+    """default.yaml shapes, 1 scene, random init: GPU pipeline vs CPU pipeline with oracle operators."""
+    from oracle import ext_cpu
+    C, E, S = pkg("config"), pkg("eval_rcnn"), pkg("synth")
+    cfg = C.default_eval_cfg()
+    model_c = E.build_model(cfg, "cpu", seed=3)
+    # spread the heads (random init leaves them ~0, which makes every decision a near-tie)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for name, p in model_c.named_parameters():
+            if ("reg_layer" in name or "cls_layer" in name) and p.dim() > 1:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+    model_g = E.build_model(cfg, DEV, seed=3)
+    model_g.load_state_dict(model_c.state_dict())
+    pts = torch.from_numpy(S.scenes(1, 16384, seed0=77))
+    with ext_cpu.patch_package():
+        dc = E.infer_batch(model_c, cfg, pts)
+    dg = E.infer_batch(model_g, cfg, pts.to(DEV))
+    # RPN head outputs: same convolutions up to library rounding
+    rois_c, rois_g = dc["rois"][0].numpy(), dg["rois"][0].cpu().numpy()
+    worst, matched = match_boxes(rois_g, rois_c)
+    assert matched >= 0.9 * len(rois_c), "only %d of %d RoIs matched" % (matched, len(rois_c))
+    assert worst < 1e-3
+    nc, ng = int(dc["num"][0]), int(dg["num"][0])
+    worst, matched = match_boxes(dg["boxes"][0, :ng].cpu().numpy(), dc["boxes"][0, :nc].numpy())
+    assert matched >= 0.8 * max(nc, 1) and worst < 1e-3, (worst, matched, nc, ng)
+
+
+def test_postprocess_batched_equals_per_scene_reference_order():
+    """The batched device tail (masked sort + batched NMS) == the reference's per-scene loop
+    (eval_rcnn.py:611-629) run with the blocking drop-in API on the same device tensors."""
+    C, E, ku, iu = pkg("config"), pkg("eval_rcnn"), pkg("kitti_utils"), pkg("iou3d_utils")
+    cfg = C.default_eval_cfg()
+    rng = np.random.default_rng(6)
+    B, M = 4, 100
+    from helpers import boxes3d
+    rois = torch.from_numpy(np.stack([boxes3d(rng, M, xz_scope=((-8, 8), (8, 24))) for _ in range(B)])).to(DEV)
+    ret = {"rois": rois, "rcnn_cls": torch.from_numpy(rng.standard_normal((B * M, 1)).astype(np.float32) * 2).to(DEV),
+           "rcnn_reg": torch.from_numpy(rng.standard_normal((B * M, 46)).astype(np.float32)).to(DEV)}
+    ret["rcnn_cls"][:M] = -5.0     # scene 0: nothing above the score threshold
+    det = E.postprocess(cfg, ret, B)
+    assert int(det["num"][0]) == 0
+    for k in range(B):
+        raw = det["raw_scores"][k]
+        sel = torch.sigmoid(raw) > cfg.RCNN.SCORE_THRESH
+        if sel.sum() == 0:
+            continue
+        boxes, sc = det["pred_boxes3d"][k][sel], raw[sel]
+        keep = iu.nms_gpu(ku.boxes3d_to_bev_torch(boxes), sc, cfg.RCNN.NMS_THRESH)
+        n = int(det["num"][k])
+        assert n == len(keep)
+        assert torch.equal(det["boxes"][k, :n], boxes[keep]) and torch.equal(det["scores"][k, :n], sc[keep])
+        assert (det["boxes"][k, n:] == 0).all()
+
+
+def test_reference_python_runs_on_dropin_modules():
+    """Drop-in check at the extension boundary: a caller written against the REFERENCE module names
+    and calling conventions (zero-filled idx, transposes, in-place subtract, cat -- the sequence of
+    pointnet2_utils.py:241-264) gets the same tensor as the fused path."""
+    import sys
+    p = pkg()
+    if p.DROPIN_DIR not in sys.path:
+        sys.path.insert(0, p.DROPIN_DIR)
+    import pointnet2_cuda as pointnet2
+    xyz = torch.from_numpy(pkg("synth").scenes(2, 4096, seed0=9)).to(DEV)
+    new_xyz = xyz[:, :512].contiguous()
+    feats = torch.randn((2, 32, 4096), device=DEV)
+    idx = torch.zeros((2, 512, 16), dtype=torch.int32, device=DEV)
+    pointnet2.ball_query_wrapper(2, 4096, 512, 0.6, 16, new_xyz, xyz, idx)
+    xyz_t = xyz.transpose(1, 2).contiguous()
+    gx = torch.empty((2, 3, 512, 16), device=DEV)
+    pointnet2.group_points_wrapper(2, 3, 4096, 512, 16, xyz_t, idx, gx)
+    gx -= new_xyz.transpose(1, 2).unsqueeze(-1)
+    gf = torch.empty((2, 32, 512, 16), device=DEV)
+    pointnet2.group_points_wrapper(2, 32, 4096, 512, 16, feats, idx, gf)
+    composed = torch.cat([gx, gf], dim=1)
+    fused = pkg("pointnet2.pointnet2_utils").QueryAndGroup(0.6, 16)(xyz, new_xyz, feats)
+    assert torch.equal(composed, fused)
