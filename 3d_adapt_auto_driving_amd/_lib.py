@@ -27,6 +27,8 @@ SIGNATURES = {
     "prcnn_three_interpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "prcnn_three_interpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "prcnn_query_and_group": [_I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
+    "prcnn_bias_relu_inplace": [C.c_long, _I, C.c_long, _P, _P, _P],
+    "prcnn_maxpool_bias_relu": [_I, _I, _I, _I, _P, _P, _P, _P],
     "prcnn_boxes_overlap_bev": [_I, _P, _I, _P, _P, _P],
     "prcnn_boxes_iou_bev": [_I, _P, _I, _P, _P, _P],
     "prcnn_nms": [_I, _P, _P, _F, _P],
@@ -50,6 +52,13 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise PrcnnError("%s not found: the HIP extension is not built (no CPU fallback exists)" % LIB_PATH)
+        # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so); the streams and device
+        # pointers we are handed belong to THAT runtime, so it must be the one this library binds
+        # to: import torch first so its copy is already mapped when the loader resolves ours.
+        import torch  # noqa: F401
+        _hip = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(_hip):
+            C.CDLL(_hip, mode=C.RTLD_GLOBAL)
         lib = C.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -97,3 +97,21 @@ def query_and_group_wrapper(b, n, m, c, radius, nsample, new_xyz, xyz, features,
     _lib.call("prcnn_query_and_group", b, n, m, c, radius, nsample, new_xyz.data_ptr(), xyz.data_ptr(),
               _lib.ptr(features), idx.data_ptr(), out.data_ptr(), _lib.current_stream(xyz))
     return 1
+
+
+# -- extension beyond the reference module: shared-MLP epilogues -----------------------------------
+def bias_relu_inplace_wrapper(x, bias):
+    """x (B, C, ...) in place: x = relu(x + bias[c])."""
+    _chk(torch.float32, x, bias)
+    outer, c = x.size(0), x.size(1)
+    inner = x.numel() // max(outer * c, 1)
+    _lib.call("prcnn_bias_relu_inplace", outer, c, inner, bias.data_ptr(), x.data_ptr(), _lib.current_stream(x))
+    return x
+
+
+def maxpool_bias_relu_wrapper(x, bias, out):
+    """x (B, C, npoint, nsample) raw conv output -> out (B, C, npoint) = relu(max_s x + bias[c])."""
+    _chk(torch.float32, x, bias, out)
+    _lib.call("prcnn_maxpool_bias_relu", x.size(0), x.size(1), x.size(2), x.size(3), bias.data_ptr(),
+              x.data_ptr(), out.data_ptr(), _lib.current_stream(x))
+    return out

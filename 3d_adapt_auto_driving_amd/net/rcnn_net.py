@@ -5,6 +5,7 @@ import torch.nn as nn
 
 from ..pointnet2.pointnet2_modules import PointnetSAModule
 from ..pointnet2 import pytorch_utils as pt_utils
+from ..pointnet2 import fused_mlp
 from .. import kitti_utils
 from .. import roipool3d_utils
 from .rpn import _head
@@ -76,9 +77,9 @@ class RCNNNet(nn.Module):
         xyz = pts_input[..., 0:3].contiguous()
         if R.USE_RPN_FEATURES:
             xyz_input = pts_input[..., 0:self.rcnn_input_channel].transpose(1, 2).unsqueeze(dim=3)
-            xyz_feature = self.xyz_up_layer(xyz_input)
+            xyz_feature = fused_mlp.run(self.xyz_up_layer, xyz_input.contiguous(), pool=False)
             rpn_feature = pts_input[..., self.rcnn_input_channel:].transpose(1, 2).unsqueeze(dim=3)
-            merged = self.merge_down_layer(torch.cat((xyz_feature, rpn_feature), dim=1))
+            merged = fused_mlp.run(self.merge_down_layer, torch.cat((xyz_feature, rpn_feature), dim=1), pool=False)
             l_xyz, l_features = [xyz], [merged.squeeze(dim=3).contiguous()]
         else:
             feats = pts_input[..., 3:].transpose(1, 2).contiguous() if pts_input.size(-1) > 3 else None

@@ -10,6 +10,7 @@ import torch.nn.functional as F
 
 from . import pointnet2_utils
 from . import pytorch_utils as pt_utils
+from . import fused_mlp
 
 
 class _PointnetSAModuleBase(nn.Module):
@@ -29,6 +30,10 @@ class _PointnetSAModuleBase(nn.Module):
 
         pooled = []
         for grouper, mlp in zip(self.groupers, self.mlps):
+            if not self.training and self.pool_method == "max_pool":
+                # inference: GEMM + fused epilogues, pooling fused with the last bias/ReLU
+                pooled.append(fused_mlp.run(mlp, grouper(xyz, new_xyz, features), pool=True))
+                continue
             x = mlp(grouper(xyz, new_xyz, features))          # (B, mlp[-1], npoint, nsample)
             if self.pool_method == "max_pool":
                 x = F.max_pool2d(x, kernel_size=[1, x.size(3)])
@@ -85,4 +90,6 @@ class PointnetFPModule(nn.Module):
         else:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         x = interpolated if unknow_feats is None else torch.cat([interpolated, unknow_feats], dim=1)
+        if not self.training:
+            return fused_mlp.run(self.mlp, x.unsqueeze(-1), pool=False).squeeze(-1)
         return self.mlp(x.unsqueeze(-1)).squeeze(-1)

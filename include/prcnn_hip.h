@@ -91,6 +91,19 @@ int prcnn_query_and_group(int b, int n, int m, int c, float radius, int nsample,
                           const float *new_xyz, const float *xyz, const float *features,
                           int *idx, float *out, void *stream);
 
+/* ---- shared-MLP epilogues (fused forms of pytorch_utils.py Conv2d -> BN(eval) -> ReLU and of
+ *      the max over nsample of pointnet2_modules.py:41-44; not in the reference ABI) ------------ */
+
+/* x (outer, c, inner) f32 in place: x = max(x + bias[c], 0).  Replaces the separate bias-add and
+ * ReLU passes after a bias-free 1x1 convolution (pytorch_utils.py:35-101). */
+int prcnn_bias_relu_inplace(long outer, int c, long inner, const float *bias, float *x, void *stream);
+
+/* in (b, c, npoint, nsample) = raw output of the LAST 1x1 convolution of a shared MLP ->
+ * out (b, c, npoint) = relu(max_s in + bias[c]), which equals max_s relu(in + bias[c]) exactly
+ * (F.max_pool2d over nsample, pointnet2_modules.py:41-44). */
+int prcnn_maxpool_bias_relu(int b, int c, int npoint, int nsample, const float *bias,
+                            const float *in, float *out, void *stream);
+
 /* ---- iou3d_cuda ---------------------------------------------------------------------- */
 
 /* boxes_overlap_bev_gpu  src/iou3d.cpp:31-50 -> src/iou3d_kernel.cu:223-234.

@@ -73,6 +73,18 @@ class pointnet2_cpu:
         return 1
 
 
+    # epilogue stand-ins (plain torch on CPU; same formulas as csrc/mlp_epilogue.hip)
+    @staticmethod
+    def bias_relu_inplace_wrapper(x, bias):
+        shape = [1, -1] + [1] * (x.dim() - 2)
+        return x.add_(bias.view(shape)).clamp_(min=0)
+
+    @staticmethod
+    def maxpool_bias_relu_wrapper(x, bias, out):
+        out.copy_((x.amax(dim=3) + bias.view(1, -1, 1)).clamp_(min=0))
+        return out
+
+
 class iou3d_cpu:
     @staticmethod
     def boxes_overlap_bev_gpu(boxes_a, boxes_b, ans):

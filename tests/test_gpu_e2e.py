@@ -90,7 +90,7 @@ def test_full_size_gpu_vs_cpu_oracle_boxes(oracle):
     assert worst < 1e-3
     nc, ng = int(dc["num"][0]), int(dg["num"][0])
     worst, matched = match_boxes(dg["boxes"][0, :ng].cpu().numpy(), dc["boxes"][0, :nc].numpy())
-    assert matched >= 0.8 * max(nc, 1) and worst < 1e-3, (worst, matched, nc, ng)
+    assert nc >= 3 and matched >= 0.8 * nc and worst < 1e-3, (worst, matched, nc, ng)
 
 
 def test_postprocess_batched_equals_per_scene_reference_order():
