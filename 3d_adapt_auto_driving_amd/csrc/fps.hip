@@ -15,14 +15,18 @@
 
 namespace prcnn {
 
-struct Cand {
-    float v;
-    uint32_t key;
-};
-
+// (v, key) beats (bv, bkey): larger value, ties -> smaller key.  Branchless on purpose: the
+// short-circuit form compiles to exec-mask branches inside the hot loop.
 __device__ __forceinline__ bool better(float v, uint32_t key, float bv, uint32_t bkey)
 {
-    return v > bv || (v == bv && key < bkey);
+    return (v > bv) | ((v == bv) & (key < bkey));
+}
+
+__device__ __forceinline__ void take_if_better(float v, uint32_t key, float &bv, uint32_t &bkey)
+{
+    const bool t = better(v, key, bv, bkey);
+    bv = t ? v : bv;
+    bkey = t ? key : bkey;
 }
 
 template <int CTRL>
@@ -36,25 +40,32 @@ __device__ __forceinline__ void step_dpp(float &v, uint32_t &key)
 {
     const float ov = __int_as_float(dpp_mov<CTRL>(__float_as_int(v)));
     const uint32_t ok = (uint32_t)dpp_mov<CTRL>((int)key);
-    if (better(ov, ok, v, key)) { v = ov; key = ok; }
+    take_if_better(ov, ok, v, key);
 }
 
-__device__ __forceinline__ void step_shfl(float &v, uint32_t &key, int mask)
-{
-    const float ov = __shfl_xor(v, mask, 64);
-    const uint32_t ok = (uint32_t)__shfl_xor((int)key, mask, 64);
-    if (better(ov, ok, v, key)) { v = ov; key = ok; }
-}
-
-// all 64 lanes end up with the wave's best (v, key)
-__device__ __forceinline__ void wave_argmax(float &v, uint32_t &key)
+// every lane of each 16-lane row ends up with the row's best (v, key): DPP only, no LDS
+__device__ __forceinline__ void row16_argmax(float &v, uint32_t &key)
 {
     step_dpp<0xB1>(v, key);   // quad_perm [1,0,3,2]  (lane ^ 1)
     step_dpp<0x4E>(v, key);   // quad_perm [2,3,0,1]  (lane ^ 2)
-    step_dpp<0x141>(v, key);  // row_half_mirror: quads of an 8-lane group meet
-    step_dpp<0x140>(v, key);  // row_mirror: 8-lane halves of a 16-lane row meet
-    step_shfl(v, key, 16);
-    step_shfl(v, key, 32);
+    step_dpp<0x141>(v, key);  // row_half_mirror: the two quads of an 8-lane group meet
+    step_dpp<0x140>(v, key);  // row_mirror: the 8-lane halves of a 16-lane row meet
+}
+
+// wave-uniform best of the 64 lanes: rows reduced with DPP, the 4 row results read into SGPRs
+__device__ __forceinline__ void wave_argmax(float &v, uint32_t &key)
+{
+    row16_argmax(v, key);
+    float rv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    uint32_t rk = (uint32_t)__builtin_amdgcn_readlane((int)key, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        const float ov = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), r));
+        const uint32_t ok = (uint32_t)__builtin_amdgcn_readlane((int)key, r);
+        take_if_better(ov, ok, rv, rk);
+    }
+    v = rv;
+    key = rk;
 }
 
 struct KeyCodec {
@@ -75,14 +86,16 @@ struct KeyCodec {
 };
 
 // Register-resident FPS: one block (WAVES waves) per cloud, PPT points per lane.
-template <int WAVES, int PPT>
+// ORDERED: the virtual block size equals the real one (bs == 64*WAVES), so a lane's points
+// k = t + i*T have keys increasing with i and a strict '>' scan already keeps the smallest key.
+template <int WAVES, int PPT, bool ORDERED>
 __global__ __launch_bounds__(64 * WAVES) void fps_reg_kernel(
     int n, int m, KeyCodec kc, const float *__restrict__ xyz, float *__restrict__ temp,
     int *__restrict__ idx)
 {
     constexpr int T = 64 * WAVES;
-    __shared__ float s_v[2][WAVES];
-    __shared__ uint32_t s_k[2][WAVES];
+    __shared__ float s_v[2][16];
+    __shared__ uint32_t s_k[2][16];
 
     const int b = blockIdx.x;
     const float *__restrict__ cloud = xyz + (long)b * n * 3;
@@ -105,6 +118,11 @@ __global__ __launch_bounds__(64 * WAVES) void fps_reg_kernel(
             pk[i] = 0xffffffffu;
         }
     }
+    if (WAVES > 1 && t < 32) {  // unused exchange slots must lose every comparison
+        (&s_v[0][0])[t] = -INFINITY;
+        (&s_k[0][0])[t] = 0xffffffffu;
+    }
+    if (WAVES > 1) __syncthreads();
 
     int old = 0;
     if (t == 0) sel[0] = 0;
@@ -115,21 +133,24 @@ __global__ __launch_bounds__(64 * WAVES) void fps_reg_kernel(
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             const float d = sqdist3(px[i], py[i], pz[i], ox, oy, oz);
-            const float d2 = d < pt[i] ? d : pt[i];
+            const float d2 = fminf(d, pt[i]);  // min(d, temp[k]) of sampling_gpu.cu:134
             pt[i] = d2;
-            if (better(d2, pk[i], bv, bkey)) { bv = d2; bkey = pk[i]; }
+            if (ORDERED) {
+                const bool tk = d2 > bv;
+                bv = tk ? d2 : bv;
+                bkey = tk ? pk[i] : bkey;
+            } else {
+                take_if_better(d2, pk[i], bv, bkey);
+            }
         }
         wave_argmax(bv, bkey);
         if (WAVES > 1) {
             const int buf = j & 1;
             if ((t & 63) == 0) { s_v[buf][t >> 6] = bv; s_k[buf][t >> 6] = bkey; }
             __syncthreads();
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) {
-                const float ov = s_v[buf][w];
-                const uint32_t ok = s_k[buf][w];
-                if (better(ov, ok, bv, bkey)) { bv = ov; bkey = ok; }
-            }
+            bv = s_v[buf][t & 15];
+            bkey = s_k[buf][t & 15];
+            row16_argmax(bv, bkey);
         }
         // no candidate beat the reference's initial (-1, index 0): it would return 0
         old = (bkey == 0xffffffffu) ? 0 : kc.decode(bkey);
@@ -164,22 +185,17 @@ __global__ __launch_bounds__(1024) void fps_generic_kernel(
         uint32_t bkey = 0xffffffffu;
         for (int k = t; k < n; k += 1024) {
             const float d = sqdist3(cloud[3 * k], cloud[3 * k + 1], cloud[3 * k + 2], ox, oy, oz);
-            const float tk = mind[k];
-            const float d2 = d < tk ? d : tk;
+            const float d2 = fminf(d, mind[k]);
             mind[k] = d2;
-            const uint32_t key = kc.encode(k);
-            if (better(d2, key, bv, bkey)) { bv = d2; bkey = key; }
+            take_if_better(d2, kc.encode(k), bv, bkey);
         }
         wave_argmax(bv, bkey);
         const int buf = j & 1;
         if ((t & 63) == 0) { s_v[buf][t >> 6] = bv; s_k[buf][t >> 6] = bkey; }
         __syncthreads();
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            const float ov = s_v[buf][w];
-            const uint32_t ok = s_k[buf][w];
-            if (better(ov, ok, bv, bkey)) { bv = ov; bkey = ok; }
-        }
+        bv = s_v[buf][t & 15];
+        bkey = s_k[buf][t & 15];
+        row16_argmax(bv, bkey);
         old = (bkey == 0xffffffffu) ? 0 : kc.decode(bkey);
         old = __builtin_amdgcn_readfirstlane(old);
         if (t == 0) sel[j] = old;
@@ -199,7 +215,10 @@ static int host_opt_n_threads(int work_size)
 template <int WAVES, int PPT>
 static void launch_reg(int b, int n, int m, KeyCodec kc, const float *xyz, float *temp, int *idx, hipStream_t st)
 {
-    hipLaunchKernelGGL((fps_reg_kernel<WAVES, PPT>), dim3(b), dim3(64 * WAVES), 0, st, n, m, kc, xyz, temp, idx);
+    if ((1 << kc.log2bs) == 64 * WAVES)
+        hipLaunchKernelGGL((fps_reg_kernel<WAVES, PPT, true>), dim3(b), dim3(64 * WAVES), 0, st, n, m, kc, xyz, temp, idx);
+    else
+        hipLaunchKernelGGL((fps_reg_kernel<WAVES, PPT, false>), dim3(b), dim3(64 * WAVES), 0, st, n, m, kc, xyz, temp, idx);
 }
 
 }  // namespace prcnn
