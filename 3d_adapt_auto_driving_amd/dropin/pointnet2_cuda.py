@@ -115,3 +115,32 @@ def maxpool_bias_relu_wrapper(x, bias, out):
     _lib.call("prcnn_maxpool_bias_relu", x.size(0), x.size(1), x.size(2), x.size(3), bias.data_ptr(),
               x.data_ptr(), out.data_ptr(), _lib.current_stream(x))
     return out
+
+
+# -- extension beyond the reference module: point-major (channels-last) forms ----------------------
+def group_cat_pm_wrapper(b, n, m, c, nsample, new_xyz, xyz, features, idx, out):
+    """features (b,n,c) point-major or None -> out (b, m*nsample, round_up(c,4)+4)."""
+    _chk(torch.float32, new_xyz, xyz, out); _chk(torch.int32, idx)
+    if features is not None:
+        _chk(torch.float32, features)
+    _lib.call("prcnn_group_cat_pm", b, n, m, c, nsample, new_xyz.data_ptr(), xyz.data_ptr(), _lib.ptr(features),
+              idx.data_ptr(), out.data_ptr(), _lib.current_stream(xyz))
+    return out
+
+
+def maxpool_pm_wrapper(x, ns, out, out_col):
+    """x (rows*ns, c) -> out (rows, stride)[:, out_col:out_col+c] = max over each run of ns rows."""
+    _chk(torch.float32, x, out)
+    rows = x.size(0) // ns
+    _lib.call("prcnn_maxpool_pm", rows, ns, x.size(1), x.data_ptr(), out.data_ptr(), out.size(-1), out_col,
+              _lib.current_stream(x))
+    return out
+
+
+def three_interpolate_pm_wrapper(features, idx, weight, out, out_col):
+    """features (b,m,c), idx/weight (b,n,3) -> out (b,n,stride)[..., out_col:out_col+c]."""
+    _chk(torch.float32, features, weight, out); _chk(torch.int32, idx)
+    b, m, c = features.shape
+    _lib.call("prcnn_three_interpolate_pm", b, c, m, idx.size(1), features.data_ptr(), idx.data_ptr(),
+              weight.data_ptr(), out.data_ptr(), out.size(-1), out_col, _lib.current_stream(features))
+    return out

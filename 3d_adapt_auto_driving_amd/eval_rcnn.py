@@ -26,6 +26,7 @@ from . import iou3d_utils
 from . import synth
 from .bbox_transform import decode_bbox_target
 from .net.point_rcnn import PointRCNN
+from .net.fast_infer import FastPointRCNN
 
 
 def build_model(cfg, device, seed=0):
@@ -77,14 +78,63 @@ def postprocess(cfg, ret_dict, batch_size):
 
 
 @torch.no_grad()
-def infer_batch(model, cfg, pts_input):
-    """pts_input (B,N,3) device f32 -> detections dict (all device tensors, fixed shapes)."""
-    ret = model({"pts_input": pts_input})
+def infer_batch(model, cfg, pts_input, engine=None, geo=None):
+    """pts_input (B,N,3) device f32 -> detections dict (all device tensors, fixed shapes).
+    ``engine`` = a FastPointRCNN built from ``model`` (point-major fused path); without it the
+    nn.Module graph (reference operation order) runs."""
+    ret = engine(pts_input, geo) if engine is not None else model({"pts_input": pts_input})
     det = postprocess(cfg, ret, pts_input.shape[0])
     det["rois"] = ret["rois"]
     det["rcnn_reg"] = ret["rcnn_reg"]
     det["rcnn_cls"] = ret["rcnn_cls"]
     return det
+
+
+class PipelinedRunner:
+    """Two-stream software pipeline over batches: the xyz-only GEOMETRY of batch i+1 (FPS, ball
+    query, three-NN: latency-bound, FPS keeps only B CUs busy) runs on a side HIP stream while the
+    FEATURE pass of batch i (GEMMs, grouping, RoI pooling, NMS) fills the rest of the chip on the
+    main stream.  Call ``step(cur, nxt)`` once per batch; ``nxt`` may be None at the end."""
+
+    def __init__(self, model, cfg, device):
+        self.model, self.cfg = model, cfg
+        self.engine = FastPointRCNN(model, cfg)
+        self.device = torch.device(device)
+        self.side = torch.cuda.Stream(self.device)
+        self._geo = None          # (tensor identity, geometry dict, ready event)
+
+    def _launch_geometry(self, pts):
+        main = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(main)                   # pts (and the allocator's frees) are ordered before us
+        with torch.cuda.stream(self.side):
+            geo = self.engine.geometry(pts)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        for t in _tensors(geo):                       # consumed on the main stream: tell the caching allocator
+            t.record_stream(main)
+        self._geo = (pts, geo, ev)
+
+    @torch.no_grad()
+    def step(self, cur, nxt=None):
+        if self._geo is None or self._geo[0] is not cur:
+            self._launch_geometry(cur)
+        _, geo, ev = self._geo
+        self._geo = None
+        if nxt is not None:
+            self._launch_geometry(nxt)                # enqueue first: it overlaps the feature pass below
+        torch.cuda.current_stream(self.device).wait_event(ev)
+        return infer_batch(self.model, self.cfg, cur, engine=self.engine, geo=geo)
+
+
+def _tensors(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors(v)
 
 
 def save_kitti_format(sample_id, calib, bbox3d, kitti_output_dir, scores, img_shape, cls_name="Car"):
@@ -173,15 +223,24 @@ def eval_synthetic(model, cfg, device, scene_ids, batch_size=8, npoints=16384, o
         os.makedirs(output_dir, exist_ok=True)
     M = cfg.TEST.RPN_POST_NMS_TOP_N
     batches = []
-    for s in range(0, len(scene_ids), batch_size):
+    runner = PipelinedRunner(model, cfg, device) if torch.device(device).type == "cuda" else None
+
+    def load(s):
         ids = scene_ids[s:s + batch_size]
+        if not ids:
+            return None, ids
         if raw_points:
             clouds = [synth.subsample_rpn(synth.dense_scene(i, raw_points), npoints,
                                           rng=np.random.default_rng(1024 + i)) for i in ids]
         else:
             clouds = [synth.scene(i, npoints) for i in ids]
-        pts = torch.from_numpy(np.stack(clouds, 0)).to(device, non_blocking=True)
-        det = infer_batch(model, cfg, pts)
+        return torch.from_numpy(np.stack(clouds, 0)).to(device, non_blocking=True), ids
+
+    nxt, nxt_ids = load(0)
+    for s in range(0, len(scene_ids), batch_size):
+        pts, ids = nxt, nxt_ids
+        nxt, nxt_ids = load(s + batch_size)
+        det = runner.step(pts, nxt) if runner is not None else infer_batch(model, cfg, pts)
         boxes, scores, num = det["boxes"].cpu(), det["scores"].cpu(), det["num"].cpu()   # one D2H per batch
         batches.append((boxes, scores, num))
         if output_dir:

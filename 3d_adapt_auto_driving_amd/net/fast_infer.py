@@ -1,0 +1,262 @@
+"""MI355X inference engine for PointRCNN: the same network function as ``PointRCNN.forward``
+(pointrcnn/lib/net/point_rcnn.py:26-70 and everything it calls), re-scheduled for the hardware:
+
+  * POINT-MAJOR activations everywhere: features are (B, N, C), a grouped neighbourhood is a
+    (B*M*ns, K) row matrix, so every gather is a contiguous C-vector (16-byte lanes on consecutive
+    addresses), every shared-MLP layer is ONE f32 GEMM  rows x K @ K x Cout  with the bias + ReLU
+    epilogue fused into the GEMM (hipBLASLt), and the max over nsample reduces ns consecutive rows.
+    Nothing is transposed between layers; RoI pooling consumes the RPN features as they are.
+  * BatchNorm (eval) folded into the GEMM weights; first-layer weights permuted/zero-padded to the
+    grouped row layout [features | pad | dx dy dz | 0].
+  * GEOMETRY / FEATURE split: FPS, ball query and three-NN of the whole RPN backbone depend on xyz
+    only.  ``geometry()`` computes them (it is the latency-bound part: FPS is serial per scene and
+    occupies B CUs); ``forward(pts, geo)`` consumes them.  A pipelined caller runs geometry of
+    batch i+1 on a second HIP stream while the GEMMs of batch i fill the other CUs
+    (eval_rcnn.PipelinedRunner).
+
+Values differ from the module path only by f32 rounding of the GEMMs (different kernels and
+summation orders); indices (FPS / ball query / three-NN / NMS keep) are produced by the same
+kernels.  Parity is tested against the reference fixtures with the 1e-4 box tolerance.
+"""
+import torch
+
+from ..pointnet2 import pointnet2_utils as pu
+from ..pointnet2 import fused_mlp
+from .. import kitti_utils
+from .. import roipool3d_utils
+
+
+def _round4(c):
+    return (c + 3) // 4 * 4
+
+
+def gemm_bias_act(a, wt, bias, relu):
+    """a (rows, K) @ wt (K, Cout) + bias, optional ReLU, epilogue fused in the GEMM when the
+    backend offers it (hipBLASLt through torch._addmm_activation)."""
+    if relu:
+        try:
+            return torch._addmm_activation(bias, a, wt)
+        except (AttributeError, RuntimeError):
+            return torch.addmm(bias, a, wt).relu_()
+    return torch.addmm(bias, a, wt)
+
+
+class _Mlp:
+    """Folded weights of one SharedMLP / Conv1d chain in (K, Cout) form."""
+
+    def __init__(self, layers, grouped_c=None):
+        """layers: [(w (Cout,Cin), b (Cout), relu)].  grouped_c: if not None the first layer
+        consumes a grouped row [features(grouped_c) | pad | xyz | 0] whereas the module's weight
+        columns are [xyz(3) | features]."""
+        self.layers = []
+        for i, (w, b, relu) in enumerate(layers):
+            if i == 0 and grouped_c is not None:
+                c, c4 = grouped_c, _round4(grouped_c)
+                wt = w.new_zeros((c4 + 4, w.shape[0]))
+                if c:
+                    wt[:c] = w[:, 3:3 + c].t()
+                wt[c4:c4 + 3] = w[:, 0:3].t()
+            else:
+                k = w.shape[1]
+                wt = w.new_zeros((_round4(k), w.shape[0]))
+                wt[:k] = w.t()
+            self.layers.append((wt.contiguous(), b.contiguous(), relu))
+
+    def __call__(self, a):
+        for wt, b, relu in self.layers:
+            a = gemm_bias_act(a, wt, b, relu)
+        return a
+
+
+def _fold_shared_mlp(mlp):
+    layers = fused_mlp.folded_layers(mlp)
+    if layers is None:
+        raise NotImplementedError("fast path: unsupported SharedMLP structure")
+    return [(w, b, True) for w, b in layers]
+
+
+def _fold_head(seq):
+    """nn.Sequential of pt_utils.Conv1d (+Dropout): -> [(w, b, relu)]"""
+    out = []
+    for block in seq:
+        if isinstance(block, torch.nn.Dropout):
+            continue
+        fb = fused_mlp._fold_block(block)
+        if fb is not None:
+            out.append((fb[0], fb[1], True))
+            continue
+        names = [n for n, _ in block.named_children()]
+        if names != ["conv"]:
+            raise NotImplementedError("fast path: unsupported head block %s" % names)
+        conv = block.conv
+        w = conv.weight.detach().reshape(conv.out_channels, conv.in_channels)
+        b = conv.bias.detach() if conv.bias is not None else w.new_zeros(conv.out_channels)
+        out.append((w, b, False))
+    return out
+
+
+class FastPointRCNN:
+    def __init__(self, model, cfg):
+        assert not model.training, "FastPointRCNN is an inference engine: call model.eval() first"
+        self.model, self.cfg = model, cfg
+        rpn = model.rpn
+        bb = rpn.backbone_net
+        self.sa = []
+        for sa in bb.SA_modules:
+            scales = []
+            for grouper, mlp in zip(sa.groupers, sa.mlps):
+                cin = mlp[0].conv.in_channels - 3
+                scales.append((grouper.radius, grouper.nsample, _Mlp(_fold_shared_mlp(mlp), grouped_c=cin), cin))
+            self.sa.append((sa.npoint, scales))
+        self.fp = [_Mlp(_fold_shared_mlp(fp.mlp)) for fp in bb.FP_modules]
+        self.rpn_cls = _Mlp(_fold_head(rpn.rpn_cls_layer))
+        self.rpn_reg = _Mlp(_fold_head(rpn.rpn_reg_layer))
+        if cfg.RCNN.ENABLED:
+            r = model.rcnn_net
+            self.xyz_up = _Mlp(_fold_shared_mlp(r.xyz_up_layer))
+            self.merge_down = _Mlp(_fold_shared_mlp(r.merge_down_layer))
+            self.rcnn_sa = []
+            for sa in r.SA_modules:
+                mlp = sa.mlps[0]
+                cin = mlp[0].conv.in_channels - 3
+                g = sa.groupers[0]
+                self.rcnn_sa.append((sa.npoint, getattr(g, "radius", None), getattr(g, "nsample", None),
+                                     _Mlp(_fold_shared_mlp(mlp), grouped_c=cin), cin))
+            self.rcnn_cls = _Mlp(_fold_head(r.cls_layer))
+            self.rcnn_reg = _Mlp(_fold_head(r.reg_layer))
+
+    # ------------------------------------------------------------------ geometry (xyz only)
+    @torch.no_grad()
+    def geometry(self, xyz):
+        """FPS / ball-query / three-NN of the RPN backbone for xyz (B,N,3)."""
+        levels, l_xyz = [], [xyz]
+        for npoint, scales in self.sa:
+            cur = l_xyz[-1]
+            sel = pu.furthest_point_sample(cur, npoint)
+            new_xyz = torch.gather(cur, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+            idxs = [pu.ball_query(radius, ns, cur, new_xyz) for radius, ns, _, _ in scales]
+            levels.append({"sel": sel, "new_xyz": new_xyz, "idx": idxs})
+            l_xyz.append(new_xyz)
+        interp = []
+        for k in range(len(self.fp)):      # FP level k: unknown = l_xyz[k], known = l_xyz[k+1]
+            dist, idx = pu.three_nn(l_xyz[k], l_xyz[k + 1])
+            dist_recip = 1.0 / (dist + 1e-8)
+            weight = (dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)).contiguous()
+            interp.append((idx, weight))
+        return {"l_xyz": l_xyz, "sa": levels, "fp": interp}
+
+    # ------------------------------------------------------------------ building blocks
+    @staticmethod
+    def _sa_scale(xyz, new_xyz, feats, idx, mlp, cin, out, out_col):
+        """one (radius, nsample) scale: group -> GEMM chain -> max over nsample into out[..., slice]"""
+        ext = pu.pointnet2
+        B, N, _ = xyz.shape
+        M, ns = idx.shape[1], idx.shape[2]
+        grouped = torch.empty((B, M * ns, _round4(cin) + 4), dtype=torch.float32, device=xyz.device)
+        ext.group_cat_pm_wrapper(B, N, M, cin, ns, new_xyz, xyz, feats, idx, grouped)
+        y = mlp(grouped.view(B * M * ns, -1))
+        ext.maxpool_pm_wrapper(y, ns, out, out_col)
+
+    def _backbone(self, xyz, geo):
+        l_xyz, l_feat = geo["l_xyz"], [None]
+        for (npoint, scales), lev in zip(self.sa, geo["sa"]):
+            cur_xyz, cur_feat = l_xyz[len(l_feat) - 1], l_feat[-1]
+            B = cur_xyz.shape[0]
+            width = sum(s[2].layers[-1][0].shape[1] for s in scales)
+            out = torch.empty((B, npoint, width), dtype=torch.float32, device=xyz.device)
+            col = 0
+            for (radius, ns, mlp, cin), idx in zip(scales, lev["idx"]):
+                self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, idx, mlp, cin, out, col)
+                col += mlp.layers[-1][0].shape[1]
+            l_feat.append(out)
+        ext = pu.pointnet2
+        for i in range(-1, -(len(self.fp) + 1), -1):          # coarse -> fine
+            k = len(self.fp) + i                               # FP module index == fine level
+            known_feat, skip = l_feat[k + 1], l_feat[k]
+            idx, weight = geo["fp"][k]
+            B, n = idx.shape[0], idx.shape[1]
+            c2 = known_feat.shape[2]
+            c1 = 0 if skip is None else skip.shape[2]
+            buf = torch.empty((B, n, c2 + c1), dtype=torch.float32, device=xyz.device)
+            ext.three_interpolate_pm_wrapper(known_feat, idx, weight, buf, 0)
+            if c1:
+                buf[:, :, c2:] = skip
+            l_feat[k] = self.fp[k](buf.view(B * n, c2 + c1)).view(B, n, -1)
+        return l_feat[0]                                       # (B, N, 128) point-major
+
+    # ------------------------------------------------------------------ full forward
+    @torch.no_grad()
+    def forward(self, pts_input, geo=None):
+        """pts_input (B,N,3) -> the dict PointRCNN.forward returns in TEST mode (rpn_cls, rpn_reg,
+        backbone_xyz, rois, roi_scores_raw, seg_result, rcnn_cls, rcnn_reg); backbone features are
+        returned point-major under 'rpn_features' (B,N,C)."""
+        cfg = self.cfg
+        if pts_input.shape[-1] != 3:
+            raise NotImplementedError("fast path: per-point input features (USE_INTENSITY) not supported")
+        xyz = pts_input.contiguous()
+        if geo is None:
+            geo = self.geometry(xyz)
+        B, N, _ = xyz.shape
+        feats = self._backbone(xyz, geo)
+        flat = feats.view(B * N, -1)
+        rpn_cls = self.rpn_cls(flat).view(B, N, -1)
+        rpn_reg = self.rpn_reg(flat).view(B, N, -1)
+        out = {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": xyz, "rpn_features": feats}
+        if not cfg.RCNN.ENABLED:
+            return out
+        rpn_scores_raw = rpn_cls[:, :, 0]
+        seg_mask = (torch.sigmoid(rpn_scores_raw) > cfg.RPN.SCORE_THRESH).float()
+        pts_depth = torch.norm(xyz, p=2, dim=2)
+        rois, roi_scores_raw = self.model.rpn.proposal_layer(rpn_scores_raw, rpn_reg, xyz)
+        out.update({"rois": rois, "roi_scores_raw": roi_scores_raw, "seg_result": seg_mask})
+        out.update(self._rcnn(xyz, feats, seg_mask, pts_depth, rois))
+        return out
+
+    def _rcnn(self, xyz, feats, seg_mask, pts_depth, rois):
+        R = self.cfg.RCNN
+        if not (R.ROI_SAMPLE_JIT and R.USE_RPN_FEATURES and not R.USE_INTENSITY):
+            raise NotImplementedError("fast path covers the default.yaml RCNN input configuration")
+        extra = [seg_mask.unsqueeze(2)]
+        if R.USE_DEPTH:
+            extra.append((pts_depth / 70.0 - 0.5).unsqueeze(2))
+        pts_feature = torch.cat(extra + [feats], dim=2)                       # (B,N,2+128), already point-major
+        pooled, _ = roipool3d_utils.roipool3d_gpu(xyz, pts_feature, rois, R.POOL_EXTRA_WIDTH, sampled_pt_num=R.NUM_POINTS)
+        B, M, P, W = pooled.shape
+        pooled[:, :, :, 0:3] -= rois[:, :, 0:3].unsqueeze(2)
+        flat = pooled.view(B * M, P, W)
+        flat[:, :, 0:3] = kitti_utils.rotate_pc_along_y_torch(flat[:, :, 0:3], rois.reshape(-1, 7)[:, 6])
+
+        nin = self.model.rcnn_net.rcnn_input_channel                           # xyz + mask + depth = 5
+        rows = flat.view(B * M * P, W)
+        a = rows.new_zeros((rows.shape[0], _round4(nin)))
+        a[:, :nin] = rows[:, :nin]
+        xyz_feature = self.xyz_up(a)                                           # (rows, 128)
+        merged = self.merge_down(torch.cat((xyz_feature, rows[:, nin:]), dim=1))
+        l_xyz = [flat[:, :, 0:3].contiguous()]
+        l_feat = [merged.view(B * M, P, -1)]
+        ext = pu.pointnet2
+        for npoint, radius, ns, mlp, cin in self.rcnn_sa:
+            cur_xyz, cur_feat = l_xyz[-1], l_feat[-1]
+            Bc, n = cur_xyz.shape[0], cur_xyz.shape[1]
+            cout = mlp.layers[-1][0].shape[1]
+            if npoint is not None:
+                sel = pu.furthest_point_sample(cur_xyz, npoint)
+                new_xyz = torch.gather(cur_xyz, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+                idx = pu.ball_query(radius, ns, cur_xyz, new_xyz)
+                out = torch.empty((Bc, npoint, cout), dtype=torch.float32, device=cur_xyz.device)
+                self._sa_scale(cur_xyz, new_xyz, cur_feat, idx, mlp, cin, out, 0)
+                l_xyz.append(new_xyz)
+            else:                                                               # GroupAll: one group of n points
+                c4 = _round4(cin)
+                g = cur_feat.new_zeros((Bc, n, c4 + 4))
+                g[:, :, :cin] = cur_feat
+                g[:, :, c4:c4 + 3] = cur_xyz
+                y = mlp(g.view(Bc * n, c4 + 4))
+                out = torch.empty((Bc, 1, cout), dtype=torch.float32, device=cur_xyz.device)
+                ext.maxpool_pm_wrapper(y, n, out, 0)
+                l_xyz.append(None)
+            l_feat.append(out)
+        top = l_feat[-1].view(l_feat[-1].shape[0], -1)                         # (B*M, 512)
+        return {"rcnn_cls": self.rcnn_cls(top), "rcnn_reg": self.rcnn_reg(top)}
+
+    __call__ = forward

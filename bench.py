@@ -4,7 +4,8 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One STEP = one pass of the joint RPN->RCNN hot path (eval_rcnn-equivalent: backbone SA/FP ops,
+One STEP = one pass (software-pipelined over two HIP streams: geometry of the next batch overlaps the
+feature pass of the current one; each step does exactly one of each) of the joint RPN->RCNN hot path (eval_rcnn-equivalent: backbone SA/FP ops,
 proposal layer with device NMS, RoI pooling, RCNN, final decode + rotated NMS, async D2H of the
 detections) over ONE batch of 8 synthetic KITTI-shaped scenes (16384 points, random-init weights,
 default.yaml shapes) per GPU -- BASELINE.json configs[2]; inputs are resident in HBM before the
@@ -132,8 +133,12 @@ def main():
     host_scores = torch.empty((total, BATCH, M), pin_memory=True)
     host_num = torch.empty((total, BATCH), dtype=torch.int32, pin_memory=True)
 
+    runner = E.PipelinedRunner(model, cfg, dev)     # point-major engine + geometry on a side stream
+
     def step(i):
-        det = E.infer_batch(model, cfg, batches[i % n_slots])
+        # features of batch i on the main stream || geometry (FPS / ball query / three-NN) of batch
+        # i+1 on the side stream; every timed step does one geometry and one feature pass
+        det = runner.step(batches[i % n_slots], batches[(i + 1) % n_slots])
         host_boxes[i].copy_(det["boxes"], non_blocking=True)
         host_scores[i].copy_(det["scores"], non_blocking=True)
         host_num[i].copy_(det["num"], non_blocking=True)

@@ -104,6 +104,22 @@ int prcnn_bias_relu_inplace(long outer, int c, long inner, const float *bias, fl
 int prcnn_maxpool_bias_relu(int b, int c, int npoint, int nsample, const float *bias,
                             const float *in, float *out, void *stream);
 
+/* ---- point-major (channels-last) forms used by the MI355X inference path (csrc/pointmajor.hip);
+ *      same values as K2 / the max-pool / K8, features stored (b, n, c) instead of (b, c, n) -------- */
+
+/* Grouping for QueryAndGroup (pointnet2_utils.py:241-264) with point-major features (b,n,c):
+ * out (b, m*nsample, kpad), kpad = round_up(c,4)+4, row = [features[idx] | 0-pad | xyz[idx]-centre | 0]. */
+int prcnn_group_cat_pm(int b, int n, int m, int c, int nsample, const float *new_xyz, const float *xyz,
+                       const float *features, const int *idx, float *out, void *stream);
+/* max over ns consecutive rows: in (rows_out*ns, c) -> out[r][out_col..out_col+c), row stride out_stride
+ * (F.max_pool2d over nsample, pointnet2_modules.py:41-44, on the point-major MLP output). */
+int prcnn_maxpool_pm(long rows_out, int ns, int c, const float *in, float *out, int out_stride,
+                     int out_col, void *stream);
+/* three_interpolate (interpolate_gpu.cu:77-97) on point-major features (b,m,c); result written into a
+ * column slice of out (b, n, out_stride). */
+int prcnn_three_interpolate_pm(int b, int c, int m, int n, const float *features, const int *idx,
+                               const float *weight, float *out, int out_stride, int out_col, void *stream);
+
 /* ---- iou3d_cuda ---------------------------------------------------------------------- */
 
 /* boxes_overlap_bev_gpu  src/iou3d.cpp:31-50 -> src/iou3d_kernel.cu:223-234.

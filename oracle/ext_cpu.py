@@ -85,6 +85,34 @@ class pointnet2_cpu:
         return out
 
 
+    # point-major stand-ins (plain torch on CPU; same values as csrc/pointmajor.hip)
+    @staticmethod
+    def group_cat_pm_wrapper(b, n, m, c, nsample, new_xyz, xyz, features, idx, out):
+        ix = idx.long().view(b, m * nsample)
+        c4 = (c + 3) // 4 * 4
+        out.zero_()
+        if c:
+            out[:, :, :c] = torch.gather(features, 1, ix.unsqueeze(-1).expand(-1, -1, c))
+        g = torch.gather(xyz, 1, ix.unsqueeze(-1).expand(-1, -1, 3)).view(b, m, nsample, 3) - new_xyz.unsqueeze(2)
+        out[:, :, c4:c4 + 3] = g.view(b, m * nsample, 3)
+        return out
+
+    @staticmethod
+    def maxpool_pm_wrapper(x, ns, out, out_col):
+        rows, c = x.size(0) // ns, x.size(1)
+        out.view(rows, -1)[:, out_col:out_col + c] = x.view(rows, ns, c).amax(dim=1)
+        return out
+
+    @staticmethod
+    def three_interpolate_pm_wrapper(features, idx, weight, out, out_col):
+        b, m, c = features.shape
+        n = idx.size(1)
+        f = torch.gather(features, 1, idx.long().view(b, n * 3, 1).expand(-1, -1, c)).view(b, n, 3, c)
+        w = weight.unsqueeze(-1)
+        out[:, :, out_col:out_col + c] = (w[:, :, 0] * f[:, :, 0] + w[:, :, 1] * f[:, :, 1]) + w[:, :, 2] * f[:, :, 2]
+        return out
+
+
 class iou3d_cpu:
     @staticmethod
     def boxes_overlap_bev_gpu(boxes_a, boxes_b, ans):

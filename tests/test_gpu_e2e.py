@@ -31,6 +31,29 @@ def test_tiny_model_gpu_matches_reference_fixture():
     np.testing.assert_allclose(det["scores"].cpu().numpy(), g["final_scores"], rtol=0, atol=1e-4)
 
 
+def test_fast_engine_gpu_matches_reference_fixture_and_pipelining_is_transparent():
+    """Point-major engine on the GPU vs the reference fixture; and the two-stream pipelined runner
+    returns exactly what the same engine returns when called serially."""
+    E, F = pkg("eval_rcnn"), pkg("net.fast_infer")
+    model, cfg, g = tiny_model(DEV)
+    pts = torch.from_numpy(g["pts"]).to(DEV)
+    eng = F.FastPointRCNN(model, cfg)
+    det = E.infer_batch(model, cfg, pts, engine=eng)
+    for key, ref in (("rois", "rois"), ("rcnn_cls", "rcnn_cls"), ("rcnn_reg", "rcnn_reg"),
+                     ("boxes", "final_boxes"), ("scores", "final_scores")):
+        np.testing.assert_allclose(det[key].cpu().numpy(), g[ref], rtol=0, atol=1e-4)
+    assert np.array_equal(det["num"].cpu().numpy(), g["final_num"])
+    runner = E.PipelinedRunner(model, cfg, DEV)
+    other = torch.from_numpy(pkg("synth").scenes(2, 2048, seed0=123)).to(DEV)
+    seq = [pts, other, pts, other, pts]
+    outs = [runner.step(seq[i], seq[i + 1] if i + 1 < len(seq) else None) for i in range(len(seq))]
+    torch.cuda.synchronize()
+    for i in (0, 2, 4):
+        assert torch.equal(outs[i]["boxes"], det["boxes"]) and torch.equal(outs[i]["num"], det["num"])
+    ref_other = E.infer_batch(model, cfg, other, engine=eng)
+    assert torch.equal(outs[1]["boxes"], ref_other["boxes"]) and torch.equal(outs[3]["scores"], ref_other["scores"])
+
+
 def test_backbone_indices_bit_exact_full_size(oracle):
     """FPS / ball-query indices of all four RPN SA levels on a full 16384-point scene: the xyz chain
     involves no convolution, so GPU and oracle must agree exactly at every level."""
