@@ -140,6 +140,105 @@ __global__ __launch_bounds__(256) void group_cat_kernel(
     for (int ci = 0; ci < c; ++ci) o[(long)ci * slots] = f[(long)ci * n];
 }
 
+// Channel-major grouping at HBM speed: the source rows of ROWS output channels of one scene are
+// staged in LDS (ROWS * N floats), so the data-dependent gather is an LDS read (ds_read_b32, a few
+// cycles even with bank conflicts) instead of 64 different cache lines per wave-load; idx is read
+// with 16-byte loads, the (B, 3+C, M, ns) output is written with 16-byte stores on consecutive
+// addresses.  Output channels 0..2 are xyz[idx] - centre, channels 3.. are features[idx]
+// (pointnet2_utils.py:249-257).  grid = (row groups, slot chunks, B); block = 1024 threads.
+template <int ROWS>
+__global__ __launch_bounds__(1024) void group_cat_lds_kernel(
+    int n, int m, int c, int nsample, const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+    const float *__restrict__ features, const int *__restrict__ idx, float *__restrict__ out)
+{
+    extern __shared__ float rows[];  // [ROWS][n]
+    const int b = blockIdx.z;
+    const int ch0 = blockIdx.x * ROWS;
+    const int cout = 3 + c;
+    const long slots = (long)m * nsample;
+    const int t = threadIdx.x;
+
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int ch = ch0 + r;
+        if (ch >= cout) break;
+        float *dst = rows + (long)r * n;
+        if (ch < 3) {
+            const float *src = xyz + (long)b * n * 3 + ch;
+            for (int k = t; k < n; k += 1024) dst[k] = src[3 * (long)k];
+        } else {
+            const float *src = features + ((long)b * c + (ch - 3)) * n;
+            for (int k = t; k < n; k += 1024) dst[k] = src[k];
+        }
+    }
+    __syncthreads();
+
+    // this block's share of the slots, in units of 4 consecutive slots
+    const long quads = slots >> 2;
+    const long per = (quads + gridDim.y - 1) / gridDim.y;
+    const long q0 = (long)blockIdx.y * per;
+    const long q1 = min(quads, q0 + per);
+    const int4 *idx4 = reinterpret_cast<const int4 *>(idx + (long)b * slots);
+    const float *ctr = new_xyz + (long)b * m * 3;
+    for (long q = q0 + t; q < q1; q += 1024) {
+        const int4 k = idx4[q];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int ch = ch0 + r;
+            if (ch >= cout) break;
+            const float *row = rows + (long)r * n;
+            float4 v = make_float4(row[k.x], row[k.y], row[k.z], row[k.w]);
+            if (ch < 3) {
+                const long s0 = q << 2;
+                v.x -= ctr[((s0 + 0) / nsample) * 3 + ch];
+                v.y -= ctr[((s0 + 1) / nsample) * 3 + ch];
+                v.z -= ctr[((s0 + 2) / nsample) * 3 + ch];
+                v.w -= ctr[((s0 + 3) / nsample) * 3 + ch];
+            }
+            reinterpret_cast<float4 *>(out + ((long)b * cout + ch) * slots)[q] = v;
+        }
+    }
+    // tail slots (slots % 4), handled by the last chunk
+    if (blockIdx.y == gridDim.y - 1) {
+        for (long s = (quads << 2) + t; s < slots; s += 1024) {
+            const int k = idx[(long)b * slots + s];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const int ch = ch0 + r;
+                if (ch >= cout) break;
+                float v = rows[(long)r * n + k];
+                if (ch < 3) v -= ctr[(s / nsample) * 3 + ch];
+                out[((long)b * cout + ch) * slots + s] = v;
+            }
+        }
+    }
+}
+
+template <int ROWS>
+static int launch_group_cat_lds(int b, int n, int m, int c, int nsample, const float *new_xyz, const float *xyz,
+                                const float *features, const int *idx, float *out, hipStream_t st)
+{
+    const size_t lds = (size_t)ROWS * n * sizeof(float);
+    static size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+        if (hipFuncSetAttribute((const void *)group_cat_lds_kernel<ROWS>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("group_cat: cannot reserve %zu bytes of LDS", lds);
+            return PRCNN_ELAUNCH;
+        }
+        configured = lds;
+    }
+    const int groups = ceil_div(3 + c, ROWS);
+    // enough blocks to fill 256 CUs a few times over; every chunk re-stages the rows, so keep chunks large
+    int chunks = 1;
+    const long slots = (long)m * nsample;
+    while ((long)b * groups * chunks < 1024 && slots / (chunks * 2) >= 16384) chunks *= 2;
+    dim3 grid(groups, chunks, b);
+    hipLaunchKernelGGL(group_cat_lds_kernel<ROWS>, grid, dim3(1024), lds, st, n, m, c, nsample, new_xyz, xyz,
+                       features, idx, out);
+    return check_launch("query_and_group");
+}
+
 // K4 / K5
 __global__ __launch_bounds__(256) void gather_points_kernel(
     int c, int n, int m, const float *__restrict__ points, const int *__restrict__ idx,
@@ -194,6 +293,11 @@ static int launch_ball_query(int b, int n, int m, float radius, int nsample, con
     return check_launch("ball_query");
 }
 
+int ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                    int *idx, int write_empty, hipStream_t st, int *used);   // ball_grid.hip
+
+static int g_ball_query_mode = 0;   // 0 auto, 1 brute force only, 2 grid whenever it accepts
+
 static int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                                const float *xyz, int *idx, int write_empty, hipStream_t st)
 {
@@ -202,6 +306,11 @@ static int ball_query_dispatch(int b, int n, int m, float radius, int nsample, c
     PRCNN_REQUIRE(b <= 65535, "ball_query: batch %d > 65535", b);
     if (b == 0 || m == 0) return PRCNN_OK;
     PRCNN_REQUIRE(new_xyz && xyz && idx, "ball_query: null pointer");
+    if (g_ball_query_mode != 1) {
+        int used = 0;
+        const int rc = ball_query_grid(b, n, m, radius, nsample, new_xyz, xyz, idx, write_empty, st, &used);
+        if (rc != PRCNN_OK || used) return rc;
+    }
     switch (pick_nseg(b, n, m, nsample)) {
         case 1: return launch_ball_query<1>(b, n, m, radius, nsample, new_xyz, xyz, idx, write_empty, st);
         case 2: return launch_ball_query<2>(b, n, m, radius, nsample, new_xyz, xyz, idx, write_empty, st);
@@ -213,6 +322,14 @@ static int ball_query_dispatch(int b, int n, int m, float radius, int nsample, c
 }  // namespace prcnn
 
 using namespace prcnn;
+
+// 0 = automatic (hashed grid for n >= 4096, brute force otherwise), 1 = brute force only
+extern "C" int prcnn_set_ball_query_mode(int mode)
+{
+    PRCNN_REQUIRE(mode >= 0 && mode <= 1, "set_ball_query_mode: mode %d", mode);
+    g_ball_query_mode = mode;
+    return PRCNN_OK;
+}
 
 extern "C" int prcnn_ball_query(int b, int n, int m, float radius, int nsample,
                                 const float *new_xyz, const float *xyz, int *idx, void *stream)
@@ -279,6 +396,15 @@ extern "C" int prcnn_query_and_group(int b, int n, int m, int c, float radius, i
     PRCNN_REQUIRE(n > 0 || m == 0, "query_and_group: empty cloud");
     int rc = ball_query_dispatch(b, n, m, radius, nsample, new_xyz, xyz, idx, 1, (hipStream_t)stream);
     if (rc != PRCNN_OK || b == 0 || m == 0) return rc;
+    // LDS row staging pays when every staged row is reused by many slots and fits in LDS
+    const long slots = (long)m * nsample;
+    const bool aligned = (((uintptr_t)idx | (uintptr_t)out) & 15) == 0 && (slots & 3) == 0;
+    if (aligned && b <= 65535 && slots >= 4L * n && (long)n * 4 <= 128 * 1024) {
+        hipStream_t st = (hipStream_t)stream;
+        if ((long)n * 4 * 4 <= 128 * 1024) return launch_group_cat_lds<4>(b, n, m, c, nsample, new_xyz, xyz, features, idx, out, st);
+        if ((long)n * 4 * 2 <= 128 * 1024) return launch_group_cat_lds<2>(b, n, m, c, nsample, new_xyz, xyz, features, idx, out, st);
+        return launch_group_cat_lds<1>(b, n, m, c, nsample, new_xyz, xyz, features, idx, out, st);
+    }
     dim3 grid(ceil_div((long)m * nsample, 256), b);
     hipLaunchKernelGGL(group_cat_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, m, c, nsample,
                        new_xyz, xyz, features, idx, out);
