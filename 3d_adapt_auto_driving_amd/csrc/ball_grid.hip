@@ -2,20 +2,21 @@
 // grid, for large clouds.
 //
 // The brute-force kernel (ball_group.hip) tests all M*N pairs: 67 M distance tests per scene at
-// N=16384, which is VALU-bound far above the few MB the op actually has to move.  Here the cloud is
-// binned on (x, z) into cells of edge s = 1.001*r (hashed into H = 2^k >= 2N buckets per scene, so
-// no extent has to be known), with an UNSTABLE counting sort (histogram -> exclusive scan ->
-// atomic scatter).  A centre then only visits the <= 9 buckets of its 3x3 cell neighbourhood.  The
-// reference's result -- the FIRST nsample in-radius indices in index order, first hit back-filled
-// -- does not depend on visiting order: every in-radius index is inserted into a per-lane sorted
-// list (LDS, [slot][lane], keeps the nsample smallest), so the output is bit-identical to the
-// brute-force scan.  The in-radius test itself is the same f32 expression.
+// N=16384, VALU-bound far above the few MB the op actually has to move.  Here the cloud is binned on
+// (x, z) into cells of edge s = 1.001*r, hashed into H = 2^k >= 2N buckets per scene (no extent has to
+// be known).  Buckets are LINKED LISTS built with one atomicExch per point -- no histogram, scan or
+// scatter passes: node[k] = (x, y, z, next) is a single 16-byte record, so walking a bucket is one
+// 16-byte load per candidate.  A centre visits only the <= 9 buckets of its 3x3 cell neighbourhood.
+//
+// The reference's result -- the FIRST nsample in-radius indices in index order, first hit
+// back-filled -- does not depend on visiting order: every in-radius index is inserted into a per-lane
+// sorted list (LDS, [slot][lane], keeps the nsample smallest), so the output is bit-identical to the
+// brute-force scan.  The in-radius test is the same f32 expression.
 //
 // Cell coordinates are computed in f64 and the cell edge carries a 0.1 % margin, so a point with
-// d^2 < r^2 can never fall outside the 3x3 neighbourhood through rounding.  Hash collisions only
-// add candidates; a bucket reached through two neighbour cells is visited once.
+// d^2 < r^2 can never fall outside the 3x3 neighbourhood through rounding.  Hash collisions only add
+// candidates; a bucket reached through two neighbour cells is visited once.
 #include "common.hpp"
-#include <hipcub/hipcub.hpp>
 #include <math.h>
 #include <mutex>
 
@@ -33,50 +34,42 @@ __device__ __forceinline__ int cell_coord(float v, double inv_s)
     return (int)c;
 }
 
-__global__ __launch_bounds__(256) void grid_hist_kernel(int n, unsigned mask, double inv_s,
-                                                        const float *__restrict__ xyz, int *__restrict__ keys,
-                                                        int *__restrict__ counts)
+// head[b][bucket] = index of the most recently inserted point (-1 = empty, set by the memset 0xFF)
+__global__ __launch_bounds__(256) void grid_link_kernel(int n, unsigned mask, double inv_s,
+                                                        const float *__restrict__ xyz, int *__restrict__ head,
+                                                        float4 *__restrict__ node)
 {
     const int b = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
     const float *p = xyz + ((long)b * n + k) * 3;
-    const unsigned key = cell_hash(cell_coord(p[0], inv_s), cell_coord(p[2], inv_s), mask);
-    const long slot = (long)b * (mask + 1) + key;
-    keys[(long)b * n + k] = (int)slot;
-    atomicAdd(counts + slot, 1);
+    const float x = p[0], y = p[1], z = p[2];
+    const unsigned key = cell_hash(cell_coord(x, inv_s), cell_coord(z, inv_s), mask);
+    const int prev = atomicExch(head + (long)b * (mask + 1) + key, k);
+    node[(long)b * n + k] = make_float4(x, y, z, __int_as_float(prev));
 }
 
-__global__ __launch_bounds__(256) void grid_scatter_kernel(int n, const float *__restrict__ xyz,
-                                                           const int *__restrict__ keys, const int *__restrict__ start,
-                                                           int *__restrict__ cursor, float4 *__restrict__ sorted)
-{
-    const int b = blockIdx.y;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n) return;
-    const float *p = xyz + ((long)b * n + k) * 3;
-    const int slot = keys[(long)b * n + k];
-    const int pos = start[slot] + atomicAdd(cursor + slot, 1);
-    sorted[pos] = make_float4(p[0], p[1], p[2], __int_as_float(k));   // pos is global: scenes are contiguous
-}
+constexpr int QT = 64;   // query threads per block (one wave): 512 blocks at b*m = 32768 centres
 
-__global__ __launch_bounds__(256) void grid_query_kernel(
-    int m, unsigned mask, double inv_s, float r2, int nsample, const float *__restrict__ new_xyz,
-    const int *__restrict__ start, const float4 *__restrict__ sorted, int *__restrict__ idx, int write_empty)
+__global__ __launch_bounds__(QT) void grid_query_kernel(
+    int n, int m, unsigned mask, double inv_s, float r2, int nsample, const float *__restrict__ new_xyz,
+    const int *__restrict__ head, const float4 *__restrict__ node, int *__restrict__ idx, int write_empty)
 {
-    extern __shared__ int lst[];  // [nsample][256]: per-lane ascending list of hit indices
+    extern __shared__ int lst[];  // [nsample][QT]: per-lane ascending list of hit indices
     const int b = blockIdx.y;
     const int t = threadIdx.x;
-    const int p = blockIdx.x * 256 + t;
+    const int p = blockIdx.x * QT + t;
     if (p >= m) return;
     const float *c = new_xyz + ((long)b * m + p) * 3;
     const float cx = c[0], cy = c[1], cz = c[2];
     const int ix = cell_coord(cx, inv_s), iz = cell_coord(cz, inv_s);
-    const long base = (long)b * (mask + 1);
+    const int *__restrict__ hd = head + (long)b * (mask + 1);
+    const float4 *__restrict__ nd = node + (long)b * n;
     int *mine = lst + t;
 
+    // all nine bucket heads are fetched up front (independent loads), then the lists are walked
     unsigned seen[9];
-    int cnt = 0;
+    int first[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
         const unsigned key = cell_hash(ix + q / 3 - 1, iz + q % 3 - 1, mask);
@@ -84,19 +77,23 @@ __global__ __launch_bounds__(256) void grid_query_kernel(
         bool dup = false;
 #pragma unroll
         for (int e = 0; e < q; ++e) dup |= (seen[e] == key);
-        if (dup) continue;
-        const int s0 = start[base + key], s1 = start[base + key + 1];
-        for (int j = s0; j < s1; ++j) {
-            const float4 pt = sorted[j];
+        first[q] = dup ? -1 : hd[key];
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        for (int k = first[q]; k >= 0;) {
+            const float4 pt = nd[k];
+            const int cur = k;
+            k = __float_as_int(pt.w);
             if (!(sqdist3(cx, cy, cz, pt.x, pt.y, pt.z) < r2)) continue;
-            const int k = __float_as_int(pt.w);
-            if (cnt == nsample && k > mine[(nsample - 1) * 256]) continue;   // not among the nsample smallest
+            if (cnt == nsample && cur > mine[(nsample - 1) * QT]) continue;   // not among the nsample smallest
             int pos = cnt < nsample ? cnt : nsample - 1;
-            while (pos > 0 && mine[(pos - 1) * 256] > k) {
-                mine[pos * 256] = mine[(pos - 1) * 256];
+            while (pos > 0 && mine[(pos - 1) * QT] > cur) {
+                mine[pos * QT] = mine[(pos - 1) * QT];
                 --pos;
             }
-            mine[pos * 256] = k;
+            mine[pos * QT] = cur;
             if (cnt < nsample) ++cnt;
         }
     }
@@ -106,8 +103,8 @@ __global__ __launch_bounds__(256) void grid_query_kernel(
             for (int l = 0; l < nsample; ++l) out[l] = 0;
         return;
     }
-    const int first = mine[0];
-    for (int l = 0; l < nsample; ++l) out[l] = l < cnt ? mine[l * 256] : first;
+    const int lowest = mine[0];
+    for (int l = 0; l < nsample; ++l) out[l] = l < cnt ? mine[l * QT] : lowest;
 }
 
 // ---- per-stream scratch ---------------------------------------------------------------------
@@ -155,42 +152,23 @@ int ball_query_grid(int b, int n, int m, float radius, int nsample, const float 
     if (!(radius > 0.f) || !isfinite(radius) || n < 4096 || m < 64 || nsample > 128 || b > 65535) return PRCNN_OK;
     unsigned H = 1;
     while (H < 2u * (unsigned)n) H <<= 1;
-    const size_t total_buckets = (size_t)b * H + 1;
-    size_t scan_bytes = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int *)nullptr, (int *)nullptr, (int)total_buckets, st);
-    const size_t o_counts = 0;
-    const size_t o_cursor = o_counts + align_up(total_buckets * sizeof(int));
-    const size_t o_start = o_cursor + align_up(total_buckets * sizeof(int));
-    const size_t o_keys = o_start + align_up(total_buckets * sizeof(int));
-    const size_t o_sorted = o_keys + align_up((size_t)b * n * sizeof(int));
-    const size_t o_scan = o_sorted + align_up((size_t)b * n * sizeof(float4));
-    const size_t need = o_scan + align_up(scan_bytes);
+    const size_t o_head = 0;
+    const size_t o_node = align_up((size_t)b * H * sizeof(int));
+    const size_t need = o_node + align_up((size_t)b * n * sizeof(float4));
     char *base = scratch_for(st, need);
     if (!base) { set_error("ball_query: cannot allocate %zu bytes of grid scratch", need); return PRCNN_ELAUNCH; }
-    int *counts = (int *)(base + o_counts), *cursor = (int *)(base + o_cursor), *start = (int *)(base + o_start);
-    int *keys = (int *)(base + o_keys);
-    float4 *sorted = (float4 *)(base + o_sorted);
+    int *head = (int *)(base + o_head);
+    float4 *node = (float4 *)(base + o_node);
 
     const double inv_s = 1.0 / ((double)radius * 1.001);
-    if (hipMemsetAsync(base, 0, o_start, st) != hipSuccess) { set_error("ball_query: memset failed"); return PRCNN_ELAUNCH; }
-    dim3 pgrid(ceil_div(n, 256), b);
-    hipLaunchKernelGGL(grid_hist_kernel, pgrid, dim3(256), 0, st, n, H - 1, inv_s, xyz, keys, counts);
-    if (hipcub::DeviceScan::ExclusiveSum(base + o_scan, scan_bytes, counts, start, (int)total_buckets, st) != hipSuccess) {
-        set_error("ball_query: scan failed");
+    if (hipMemsetAsync(head, 0xFF, (size_t)b * H * sizeof(int), st) != hipSuccess) {
+        set_error("ball_query: memset failed");
         return PRCNN_ELAUNCH;
     }
-    hipLaunchKernelGGL(grid_scatter_kernel, pgrid, dim3(256), 0, st, n, xyz, keys, start, cursor, sorted);
-    const size_t lds = (size_t)nsample * 256 * sizeof(int);
-    static size_t configured = 0;
-    if (lds > 64 * 1024 && lds > configured) {
-        if (hipFuncSetAttribute((const void *)grid_query_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            set_error("ball_query: cannot reserve %zu bytes of LDS", lds);
-            return PRCNN_ELAUNCH;
-        }
-        configured = lds;
-    }
-    hipLaunchKernelGGL(grid_query_kernel, dim3(ceil_div(m, 256), b), dim3(256), lds, st, m, H - 1, inv_s,
-                       radius * radius, nsample, new_xyz, start, sorted, idx, write_empty);
+    hipLaunchKernelGGL(grid_link_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, st, n, H - 1, inv_s, xyz, head, node);
+    const size_t lds = (size_t)nsample * QT * sizeof(int);
+    hipLaunchKernelGGL(grid_query_kernel, dim3(ceil_div(m, QT), b), dim3(QT), lds, st, n, m, H - 1, inv_s,
+                       radius * radius, nsample, new_xyz, head, node, idx, write_empty);
     *used = 1;
     return check_launch("ball_query(grid)");
 }

@@ -17,6 +17,7 @@
 //     order, truncated to nsample and back-filled with the first hit, and written with fully
 //     coalesced stores.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace prcnn {
 
@@ -180,22 +181,37 @@ __global__ __launch_bounds__(1024) void group_cat_lds_kernel(
     const long q1 = min(quads, q0 + per);
     const int4 *idx4 = reinterpret_cast<const int4 *>(idx + (long)b * slots);
     const float *ctr = new_xyz + (long)b * m * 3;
-    for (long q = q0 + t; q < q1; q += 1024) {
-        const int4 k = idx4[q];
+    constexpr int U = 4;   // quads in flight per thread: idx loads issued first, then gathers, then stores
+    for (long qb = q0; qb < q1; qb += 1024 * U) {
+        int4 k[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long q = qb + t + (long)u * 1024;
+            k[u] = q < q1 ? idx4[q] : make_int4(0, 0, 0, 0);
+        }
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int ch = ch0 + r;
             if (ch >= cout) break;
             const float *row = rows + (long)r * n;
-            float4 v = make_float4(row[k.x], row[k.y], row[k.z], row[k.w]);
-            if (ch < 3) {
-                const long s0 = q << 2;
-                v.x -= ctr[((s0 + 0) / nsample) * 3 + ch];
-                v.y -= ctr[((s0 + 1) / nsample) * 3 + ch];
-                v.z -= ctr[((s0 + 2) / nsample) * 3 + ch];
-                v.w -= ctr[((s0 + 3) / nsample) * 3 + ch];
+            float4 *dst = reinterpret_cast<float4 *>(out + ((long)b * cout + ch) * slots);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long q = qb + t + (long)u * 1024;
+                if (q >= q1) continue;
+                float4 v = make_float4(row[k[u].x], row[k[u].y], row[k[u].z], row[k[u].w]);
+                if (ch < 3) {
+                    const long s0 = q << 2;
+                    v.x -= ctr[((s0 + 0) / nsample) * 3 + ch];
+                    v.y -= ctr[((s0 + 1) / nsample) * 3 + ch];
+                    v.z -= ctr[((s0 + 2) / nsample) * 3 + ch];
+                    v.w -= ctr[((s0 + 3) / nsample) * 3 + ch];
+                }
+                __builtin_nontemporal_store(v.x, &dst[q].x);
+                __builtin_nontemporal_store(v.y, &dst[q].y);
+                __builtin_nontemporal_store(v.z, &dst[q].z);
+                __builtin_nontemporal_store(v.w, &dst[q].w);
             }
-            reinterpret_cast<float4 *>(out + ((long)b * cout + ch) * slots)[q] = v;
         }
     }
     // tail slots (slots % 4), handled by the last chunk
@@ -233,6 +249,7 @@ static int launch_group_cat_lds(int b, int n, int m, int c, int nsample, const f
     int chunks = 1;
     const long slots = (long)m * nsample;
     while ((long)b * groups * chunks < 1024 && slots / (chunks * 2) >= 16384) chunks *= 2;
+    if (const char *e = getenv("PRCNN_GROUP_CHUNKS")) chunks = atoi(e) > 0 ? atoi(e) : chunks;   // tuning knob
     dim3 grid(groups, chunks, b);
     hipLaunchKernelGGL(group_cat_lds_kernel<ROWS>, grid, dim3(1024), lds, st, n, m, c, nsample, new_xyz, xyz,
                        features, idx, out);
@@ -401,8 +418,13 @@ extern "C" int prcnn_query_and_group(int b, int n, int m, int c, float radius, i
     const bool aligned = (((uintptr_t)idx | (uintptr_t)out) & 15) == 0 && (slots & 3) == 0;
     if (aligned && b <= 65535 && slots >= 4L * n && (long)n * 4 <= 128 * 1024) {
         hipStream_t st = (hipStream_t)stream;
-        if ((long)n * 4 * 4 <= 128 * 1024) return launch_group_cat_lds<4>(b, n, m, c, nsample, new_xyz, xyz, features, idx, out, st);
-        if ((long)n * 4 * 2 <= 128 * 1024) return launch_group_cat_lds<2>(b, n, m, c, nsample, new_xyz, xyz, features, idx, out, st);
+        int force = 0;
+        if (const char *e = getenv("PRCNN_GROUP_ROWS")) force = atoi(e);                     // tuning knob
+        if (force == 1) return launch_group_cat_lds<1>(b, n, m, c, nsample, new_xyz, xyz, features, idx, out, st);
+        if (force == 2 && (long)n * 4 * 2 <= 144 * 1024) return launch_group_cat_lds<2>(b, n, m, c, nsample, new_xyz, xyz, features, idx, out, st);
+        // <= 64 KiB of staged rows per block keeps two blocks per CU: one stages while the other streams
+        if ((long)n * 4 * 4 <= 64 * 1024) return launch_group_cat_lds<4>(b, n, m, c, nsample, new_xyz, xyz, features, idx, out, st);
+        if ((long)n * 4 * 2 <= 64 * 1024) return launch_group_cat_lds<2>(b, n, m, c, nsample, new_xyz, xyz, features, idx, out, st);
         return launch_group_cat_lds<1>(b, n, m, c, nsample, new_xyz, xyz, features, idx, out, st);
     }
     dim3 grid(ceil_div((long)m * nsample, 256), b);

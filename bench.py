@@ -73,7 +73,7 @@ def roofline_query_and_group(dev, reps=20):
     achieved = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": "ball_query_kernel+group_cat_kernel (prcnn_query_and_group)",
+            "kernel": "prcnn_query_and_group = grid_link_kernel + grid_query_kernel + group_cat_lds_kernel",
             "launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": nbytes,
             "shape": {"B": B, "N": N, "M": M, "C": C, "nsample": NS, "radius": R}}
 
