@@ -15,8 +15,12 @@ def rotate_pc_along_y_torch(pc, rot_angle):
     cosa = torch.cos(rot_angle).view(-1, 1)
     sina = torch.sin(rot_angle).view(-1, 1)
     R = torch.stack([torch.cat([cosa, -sina], dim=1), torch.cat([sina, cosa], dim=1)], dim=1)  # (N,2,2)
-    xz = pc[:, [0, 2]].unsqueeze(dim=1)  # (N,1,2)
-    pc[:, [0, 2]] = torch.matmul(xz, R.permute(0, 2, 1)).squeeze(dim=1)
+    # same batched 2x2 matmul as the reference; the columns are picked / written back without an
+    # index tensor (a Python-list index uploads a tensor and synchronises the stream)
+    xz = torch.stack((pc[:, 0], pc[:, 2]), dim=1).unsqueeze(dim=1)  # (N,1,2)
+    out = torch.matmul(xz, R.permute(0, 2, 1)).squeeze(dim=1)
+    pc[:, 0] = out[:, 0]
+    pc[:, 2] = out[:, 1]
     return pc
 
 
@@ -63,7 +67,7 @@ def decode_bbox_target(roi_box3d, pred_reg, loc_scope, loc_bin_size, num_head_bi
         angle_per_class = (2 * np.pi) / num_head_bin
         ry_res = ry_res_norm * (angle_per_class / 2)
         ry = (ry_bin.float() * angle_per_class + ry_res) % (2 * np.pi)
-        ry[ry > np.pi] -= 2 * np.pi
+        ry = torch.where(ry > np.pi, ry - 2 * np.pi, ry)          # == ry[ry > pi] -= 2 pi, without a host sync
     cursor += 2 * num_head_bin
 
     assert cursor + 3 == pred_reg.shape[1], "regression width %d != layout %d" % (pred_reg.shape[1], cursor + 3)
@@ -75,5 +79,6 @@ def decode_bbox_target(roi_box3d, pred_reg, loc_scope, loc_bin_size, num_head_bi
         roi_ry = roi_box3d[:, 6]
         ret = rotate_pc_along_y_torch(ret, -roi_ry)
         ret[:, 6] += roi_ry
-    ret[:, [0, 2]] += roi_box3d[:, [0, 2]]
+    ret[:, 0] += roi_box3d[:, 0]
+    ret[:, 2] += roi_box3d[:, 2]
     return ret

@@ -45,6 +45,17 @@ def load_checkpoint(model, filename, logger=None):
     return ckpt.get("epoch", -1) if isinstance(ckpt, dict) else -1
 
 
+_ANCHORS = {}
+
+
+def _anchor_on(cfg, device):
+    """CLS_MEAN_SIZE as a device tensor, uploaded once (a per-call H2D copy synchronises the stream)."""
+    key = (str(device), tuple(float(v) for v in cfg.CLS_MEAN_SIZE[0]))
+    if key not in _ANCHORS:
+        _ANCHORS[key] = torch.tensor(key[1], dtype=torch.float32, device=device)
+    return _ANCHORS[key]
+
+
 @torch.no_grad()
 def postprocess(cfg, ret_dict, batch_size):
     """Final box decoding + score threshold + rotated NMS, batched (eval_rcnn.py:506-530,611-629).
@@ -54,7 +65,7 @@ def postprocess(cfg, ret_dict, batch_size):
     M = rois.shape[1]
     rcnn_cls = ret_dict["rcnn_cls"].view(batch_size, M, -1)
     rcnn_reg = ret_dict["rcnn_reg"].view(batch_size, M, -1)
-    anchor = torch.from_numpy(cfg.CLS_MEAN_SIZE[0]).float().to(rois.device)
+    anchor = _anchor_on(cfg, rois.device)
     pred = decode_bbox_target(rois.view(-1, 7), rcnn_reg.view(-1, rcnn_reg.shape[-1]), anchor_size=anchor,
                               loc_scope=R.LOC_SCOPE, loc_bin_size=R.LOC_BIN_SIZE, num_head_bin=R.NUM_HEAD_BIN,
                               get_xz_fine=True, get_y_by_bin=R.LOC_Y_BY_BIN, loc_y_scope=R.LOC_Y_SCOPE,

@@ -12,7 +12,10 @@ def rotate_pc_along_y_torch(pc, rot_angle):
     cosa = torch.cos(rot_angle).view(-1, 1)
     sina = torch.sin(rot_angle).view(-1, 1)
     R = torch.stack([torch.cat([cosa, -sina], dim=1), torch.cat([sina, cosa], dim=1)], dim=1)  # (N,2,2)
-    pc[:, :, [0, 2]] = torch.matmul(pc[:, :, [0, 2]], R.permute(0, 2, 1))
+    xz = torch.stack((pc[:, :, 0], pc[:, :, 2]), dim=2)              # (N,P,2), no index tensor (no host sync)
+    out = torch.matmul(xz, R.permute(0, 2, 1))
+    pc[:, :, 0] = out[:, :, 0]
+    pc[:, :, 2] = out[:, :, 1]
     return pc
 
 
