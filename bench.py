@@ -71,8 +71,20 @@ def roofline_query_and_group(dev, reps=20):
     ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     nbytes = B * algorithmic_bytes_qg(N, M, C, NS)
     achieved = nbytes / (ms * 1e-3) / 1e9
+    # HBM traffic cannot be measured from inside the process: it comes from the committed rocprofv3
+    # PMC passes of this same function (profiles/r01_pmc_query_and_group.json; FETCH_SIZE doubled as
+    # MI355X_MICROARCH.md prescribes for gfx950), and is reported only if the shape matches.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_query_and_group.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("algorithmic_bytes_per_launch") == nbytes:
+            traffic = pmc["hbm_traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": "profiles/r01_pmc_query_and_group.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
             "kernel": "prcnn_query_and_group = grid_link_kernel + grid_query_kernel + group_cat_lds_kernel",
             "launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": nbytes,
             "shape": {"B": B, "N": N, "M": M, "C": C, "nsample": NS, "radius": R}}
