@@ -51,6 +51,40 @@ __global__ __launch_bounds__(256) void group_cat_pm_kernel(
     }
 }
 
+// First shared-MLP layer without materialising the grouped input.  The layer is linear before its
+// ReLU, so  W1 [f_k ; x_k - c_p] + b1 = (W1f f_k + b1) + W1x (x_k - c_p):  the feature part
+// P = F W1f^T + b1 is ONE GEMM over the N points of the cloud instead of over the M*ns grouped
+// rows (16x fewer rows at M*ns = 8192, N = 512), and this kernel forms the grouped rows of the
+// layer-1 OUTPUT directly:   out[slot][ch] = relu(P[idx[slot]][ch] + wx[ch]*dx + wy[ch]*dy + wz[ch]*dz)
+// (the coordinate part is evaluated on the differences, so nothing cancels).  Thread per 16-byte
+// chunk of the output row; P rows are contiguous C-vectors.
+__global__ __launch_bounds__(256) void gather_affine_relu_pm_kernel(
+    int n, int m, int c4 /* cout/4 */, int nsample, const float *__restrict__ new_xyz,
+    const float *__restrict__ xyz, const float4 *__restrict__ P /* (b,n,cout) */,
+    const float4 *__restrict__ wxyz /* (3, cout) */, const int *__restrict__ idx, float4 *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const long slots = (long)m * nsample;
+    const long total = slots * c4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long s = e / c4;
+        const int j = (int)(e - s * c4);
+        const int k = idx[(long)b * slots + s];
+        const int p = (int)(s / nsample);
+        const float *pt = xyz + ((long)b * n + k) * 3;
+        const float *ct = new_xyz + ((long)b * m + p) * 3;
+        const float dx = pt[0] - ct[0], dy = pt[1] - ct[1], dz = pt[2] - ct[2];
+        const float4 base = P[((long)b * n + k) * c4 + j];
+        const float4 wx = wxyz[j], wy = wxyz[c4 + j], wz = wxyz[2 * c4 + j];
+        float4 v;
+        v.x = fmaxf(base.x + wx.x * dx + wy.x * dy + wz.x * dz, 0.f);
+        v.y = fmaxf(base.y + wx.y * dx + wy.y * dy + wz.y * dz, 0.f);
+        v.z = fmaxf(base.z + wx.z * dx + wy.z * dy + wz.z * dz, 0.f);
+        v.w = fmaxf(base.w + wx.w * dx + wy.w * dy + wz.w * dz, 0.f);
+        out[((long)b * slots) * c4 + e] = v;
+    }
+}
+
 // out[r][ch] = max_s in[(r*ns + s)][ch]; rows of `in` have `c` floats, rows of `out` have
 // `out_stride` floats and the result goes to columns [out_col, out_col + c)
 __global__ __launch_bounds__(256) void maxpool_pm_kernel(long rows_out, int ns, int c4 /* c/4 */,
@@ -122,6 +156,23 @@ extern "C" int prcnn_group_cat_pm(int b, int n, int m, int c, int nsample, const
     hipLaunchKernelGGL(group_cat_pm_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, m, c, nsample, chunks,
                        new_xyz, xyz, features, idx, (float4 *)out);
     return check_launch("group_cat_pm");
+}
+
+// P (b, n, cout) = per-point part of the first layer (bias included), wxyz (3, cout) = its xyz columns
+// -> out (b, m*nsample, cout) = relu(P[idx] + wxyz . (xyz[idx] - centre)); cout % 4 == 0
+extern "C" int prcnn_gather_affine_relu_pm(int b, int n, int m, int cout, int nsample, const float *new_xyz,
+                                           const float *xyz, const float *P, const float *wxyz, const int *idx,
+                                           float *out, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && cout >= 0 && nsample >= 0, "gather_affine_relu_pm: bad sizes");
+    PRCNN_REQUIRE((cout & 3) == 0 && b <= 65535, "gather_affine_relu_pm: cout %% 4 != 0 or batch too large");
+    if (b == 0 || m == 0 || nsample == 0 || cout == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(new_xyz && xyz && P && wxyz && idx && out, "gather_affine_relu_pm: null pointer");
+    PRCNN_REQUIRE((((uintptr_t)P | (uintptr_t)wxyz | (uintptr_t)out) & 15) == 0, "gather_affine_relu_pm: 16-byte alignment required");
+    dim3 grid(grid_cap((long)m * nsample * (cout / 4)), b);
+    hipLaunchKernelGGL(gather_affine_relu_pm_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, m, cout / 4, nsample,
+                       new_xyz, xyz, (const float4 *)P, (const float4 *)wxyz, idx, (float4 *)out);
+    return check_launch("gather_affine_relu_pm");
 }
 
 // in (rows_out*ns, c) -> out[r][out_col .. out_col+c) with row stride out_stride; c % 4 == 0

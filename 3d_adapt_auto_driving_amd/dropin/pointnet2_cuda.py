@@ -144,3 +144,12 @@ def three_interpolate_pm_wrapper(features, idx, weight, out, out_col):
     _lib.call("prcnn_three_interpolate_pm", b, c, m, idx.size(1), features.data_ptr(), idx.data_ptr(),
               weight.data_ptr(), out.data_ptr(), out.size(-1), out_col, _lib.current_stream(features))
     return out
+
+
+def gather_affine_relu_pm_wrapper(new_xyz, xyz, P, wxyz, idx, out):
+    """P (b,n,cout), wxyz (3,cout), idx (b,m,ns) -> out (b, m*ns, cout) = relu(P[idx] + wxyz.(xyz[idx]-centre))."""
+    _chk(torch.float32, new_xyz, xyz, P, wxyz, out); _chk(torch.int32, idx)
+    b, n, cout = P.shape
+    _lib.call("prcnn_gather_affine_relu_pm", b, n, idx.size(1), cout, idx.size(2), new_xyz.data_ptr(), xyz.data_ptr(),
+              P.data_ptr(), wxyz.data_ptr(), idx.data_ptr(), out.data_ptr(), _lib.current_stream(xyz))
+    return out

@@ -62,8 +62,15 @@ class _Mlp:
                 wt[:k] = w.t()
             self.layers.append((wt.contiguous(), b.contiguous(), relu))
 
-    def __call__(self, a):
-        for wt, b, relu in self.layers:
+        # split form of the first layer for the "linear before ReLU" shortcut (see _sa_scale)
+        self.split = None
+        if grouped_c is not None and grouped_c >= 32 and grouped_c % 4 == 0 and self.layers[0][2]:
+            wt, b, _ = self.layers[0]
+            c4 = _round4(grouped_c)
+            self.split = (wt[:grouped_c].contiguous(), wt[c4:c4 + 3].contiguous(), b)   # (C,Cout), (3,Cout), (Cout)
+
+    def __call__(self, a, start=0):
+        for wt, b, relu in self.layers[start:]:
             a = gemm_bias_act(a, wt, b, relu)
         return a
 
@@ -152,9 +159,18 @@ class FastPointRCNN:
         ext = pu.pointnet2
         B, N, _ = xyz.shape
         M, ns = idx.shape[1], idx.shape[2]
-        grouped = torch.empty((B, M * ns, _round4(cin) + 4), dtype=torch.float32, device=xyz.device)
-        ext.group_cat_pm_wrapper(B, N, M, cin, ns, new_xyz, xyz, feats, idx, grouped)
-        y = mlp(grouped.view(B * M * ns, -1))
+        if mlp.split is not None and M * ns > N:
+            # layer 1 is linear before its ReLU: its feature part is one GEMM over the N points,
+            # the grouped rows of the layer-1 OUTPUT are formed by a gather (csrc/pointmajor.hip)
+            wf, wx, b1 = mlp.split
+            P = torch.addmm(b1, feats.view(B * N, cin), wf).view(B, N, -1)
+            y = torch.empty((B, M * ns, wf.shape[1]), dtype=torch.float32, device=xyz.device)
+            ext.gather_affine_relu_pm_wrapper(new_xyz, xyz, P, wx, idx, y)
+            y = mlp(y.view(B * M * ns, -1), start=1)
+        else:
+            grouped = torch.empty((B, M * ns, _round4(cin) + 4), dtype=torch.float32, device=xyz.device)
+            ext.group_cat_pm_wrapper(B, N, M, cin, ns, new_xyz, xyz, feats, idx, grouped)
+            y = mlp(grouped.view(B * M * ns, -1))
         ext.maxpool_pm_wrapper(y, ns, out, out_col)
 
     def _backbone(self, xyz, geo):

@@ -115,6 +115,12 @@ int prcnn_maxpool_bias_relu(int b, int c, int npoint, int nsample, const float *
  * out (b, m*nsample, kpad), kpad = round_up(c,4)+4, row = [features[idx] | 0-pad | xyz[idx]-centre | 0]. */
 int prcnn_group_cat_pm(int b, int n, int m, int c, int nsample, const float *new_xyz, const float *xyz,
                        const float *features, const int *idx, float *out, void *stream);
+/* First shared-MLP layer on grouped points without materialising the grouped input (the layer is
+ * linear before its ReLU): P (b,n,cout) = features @ W1f^T + b1 per point, wxyz (3,cout) = the xyz
+ * columns of W1 -> out (b, m*nsample, cout) = relu(P[idx] + wxyz . (xyz[idx] - new_xyz)). */
+int prcnn_gather_affine_relu_pm(int b, int n, int m, int cout, int nsample, const float *new_xyz,
+                                const float *xyz, const float *P, const float *wxyz, const int *idx,
+                                float *out, void *stream);
 /* max over ns consecutive rows: in (rows_out*ns, c) -> out[r][out_col..out_col+c), row stride out_stride
  * (F.max_pool2d over nsample, pointnet2_modules.py:41-44, on the point-major MLP output). */
 int prcnn_maxpool_pm(long rows_out, int ns, int c, const float *in, float *out, int out_stride,

@@ -98,6 +98,17 @@ class pointnet2_cpu:
         return out
 
     @staticmethod
+    def gather_affine_relu_pm_wrapper(new_xyz, xyz, P, wxyz, idx, out):
+        b, n, cout = P.shape
+        m, ns = idx.size(1), idx.size(2)
+        ix = idx.long().view(b, m * ns)
+        base = torch.gather(P, 1, ix.unsqueeze(-1).expand(-1, -1, cout))
+        d = torch.gather(xyz, 1, ix.unsqueeze(-1).expand(-1, -1, 3)).view(b, m, ns, 3) - new_xyz.unsqueeze(2)
+        d = d.view(b, m * ns, 3)
+        out.copy_((base + wxyz[0] * d[..., 0:1] + wxyz[1] * d[..., 1:2] + wxyz[2] * d[..., 2:3]).clamp_(min=0))
+        return out
+
+    @staticmethod
     def maxpool_pm_wrapper(x, ns, out, out_col):
         rows, c = x.size(0) // ns, x.size(1)
         out.view(rows, -1)[:, out_col:out_col + c] = x.view(rows, ns, c).amax(dim=1)

@@ -300,6 +300,25 @@ def test_point_major_kernels(ext, oracle):
     assert np.array_equal(buf.cpu().numpy()[:, :, 8:32], oracle.three_interpolate(known, i3, w3).transpose(0, 2, 1))
 
 
+def test_gather_affine_relu_pm(ext):
+    """Layer-1 shortcut kernel vs its definition relu(P[idx] + wxyz . (xyz[idx] - centre)) evaluated by
+    torch on the same device (same f32 operation order per element; fma contraction is off)."""
+    from oracle import ext_cpu
+    rng = np.random.default_rng(35)
+    b, n, m, ns, cout = 3, 500, 40, 16, 64
+    xyz = T(rng.standard_normal((b, n, 3)).astype(np.float32))
+    new_xyz = xyz[:, :m].contiguous()
+    P = T(rng.standard_normal((b, n, cout)).astype(np.float32))
+    w = T(rng.standard_normal((3, cout)).astype(np.float32))
+    idx = T(rng.integers(0, n, (b, m, ns)).astype(np.int32))
+    out = torch.empty((b, m * ns, cout), device=DEV)
+    ext.pointnet2.gather_affine_relu_pm_wrapper(new_xyz, xyz, P, w, idx, out)
+    want = torch.empty((b, m * ns, cout))
+    ext_cpu.pointnet2_cpu.gather_affine_relu_pm_wrapper(new_xyz.cpu(), xyz.cpu(), P.cpu(), w.cpu(), idx.cpu(), want)
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=0, atol=2e-6)
+    assert (out == 0).float().mean() > 0.2                      # the ReLU really clips
+
+
 def test_mlp_epilogue_kernels(ext):
     rng = np.random.default_rng(34)
     x = rng.standard_normal((3, 20, 50, 16)).astype(np.float32)
@@ -312,6 +331,98 @@ def test_mlp_epilogue_kernels(ext):
         out = torch.empty((3, 20, 50), device=DEV)
         ext.pointnet2.maxpool_bias_relu_wrapper(T(y), T(b), out)
         assert np.array_equal(out.cpu().numpy(), np.maximum(y + b[None, :, None, None], 0).max(-1))
+
+
+def test_edge_cases_empty_ragged_and_degenerate(ext, oracle):
+    """Empty and degenerate sizes through the C ABI: zero centres / zero boxes are no-ops, fewer than 3
+    known points leave +inf / index 0 in three_nn (interpolate_gpu.cu:31-32), more samples than
+    points repeats FPS picks, a radius covering everything returns indices 0..ns-1, a single-point
+    cloud works, and RoI pooling over an empty cloud flags every box."""
+    E = ext.pointnet2
+    xyz = scenes(1, 777, seed0=3)
+    t = T(xyz)
+    # m = 0 / b = 0: nothing is touched
+    idx = torch.full((1, 0, 8), 5, dtype=torch.int32, device=DEV)
+    E.ball_query_wrapper(1, 777, 0, 0.5, 8, torch.empty((1, 0, 3), device=DEV), t, idx)
+    E.furthest_point_sampling_wrapper(0, 777, 4, torch.empty((0, 777, 3), device=DEV),
+                                      torch.empty((0, 777), device=DEV), torch.empty((0, 4), dtype=torch.int32, device=DEV))
+    # FPS: m == 1, m > n (repeats once everything is taken), n == 1
+    for n, m in ((777, 1), (5, 9), (1, 3)):
+        pts = xyz[:, :n].copy()
+        got, _ = fps_gpu(ext, pts, m)
+        assert np.array_equal(got, oracle.furthest_point_sample(pts, m))
+    # three_nn with 1 and 2 known points
+    for m in (1, 2):
+        d2 = torch.empty((1, 777, 3), device=DEV); i3 = torch.empty((1, 777, 3), dtype=torch.int32, device=DEV)
+        E.three_nn_wrapper(1, 777, m, t, T(xyz[:, :m].copy()), d2, i3)
+        wd, wi = oracle.three_nn(xyz, xyz[:, :m].copy())
+        assert np.array_equal(i3.cpu().numpy(), wi) and np.array_equal(d2.cpu().numpy(), wd)
+        assert np.isinf(wd[0, :, m:]).all()
+    # huge radius: the first nsample indices; nsample larger than the cloud: back-fill with index 0
+    for n, ns in ((777, 16), (5000, 16), (9, 32)):
+        cloud = scenes(1, max(n, 16), seed0=n)[:, :n].copy()
+        new_xyz = cloud[:, :7].copy()
+        idx = torch.zeros((1, 7, ns), dtype=torch.int32, device=DEV)
+        E.ball_query_wrapper(1, n, 7, 1e4, ns, T(new_xyz), T(cloud), idx)
+        want = np.tile(np.where(np.arange(ns) < n, np.arange(ns), 0).astype(np.int32), (1, 7, 1))
+        assert np.array_equal(idx.cpu().numpy(), want) and np.array_equal(want, oracle.ball_query(1e4, ns, cloud, new_xyz))
+    # nsample = 1 grouping, single channel
+    f = np.random.default_rng(0).standard_normal((1, 1, 777)).astype(np.float32)
+    gi = np.random.default_rng(1).integers(0, 777, (1, 33, 1)).astype(np.int32)
+    out = torch.empty((1, 1, 33, 1), device=DEV)
+    E.group_points_wrapper(1, 1, 777, 33, 1, T(f), T(gi), out)
+    assert np.array_equal(out.cpu().numpy(), oracle.group_points(f, gi))
+    # RoI pooling: zero boxes is a no-op; an empty cloud flags all boxes and leaves rows untouched
+    boxes = np.array([[[0, 2, 10, 2, 3, 5, 0.1]] * 3], np.float32)
+    pooled = torch.full((1, 3, 16, 5), 9.0, device=DEV); flag = torch.zeros((1, 3), dtype=torch.int32, device=DEV)
+    ext.roipool3d.forward(torch.empty((1, 0, 3), device=DEV), T(boxes), torch.empty((1, 0, 2), device=DEV), pooled, flag)
+    assert flag.cpu().tolist() == [[1, 1, 1]] and (pooled == 9.0).all()
+    ext.roipool3d.forward(t, torch.empty((1, 0, 7), device=DEV), torch.empty((1, 777, 2), device=DEV),
+                          torch.empty((1, 0, 16, 5), device=DEV), torch.empty((1, 0), dtype=torch.int32, device=DEV))
+    # NMS on zero boxes
+    assert ext.iou3d.nms_gpu(torch.empty((0, 5), device=DEV), torch.zeros(0, dtype=torch.int64), 0.1) == 0
+    assert ext.iou3d.nms_normal_gpu(torch.empty((0, 5), device=DEV), torch.zeros(0, dtype=torch.int64), 0.1) == 0
+    # all boxes identical: only the first survives, for both IoU kinds
+    same = np.tile(np.array([[0, 0, 4, 2, 0.3]], np.float32), (130, 1))
+    keep = torch.zeros(130, dtype=torch.int64)
+    assert ext.iou3d.nms_gpu(T(same), keep, 0.5) == 1 and keep[0] == 0
+    assert ext.iou3d.nms_normal_gpu(T(same), keep, 0.5) == 1 and keep[0] == 0
+    torch.cuda.synchronize()
+
+
+def test_maximum_sizes_properties(ext, oracle):
+    """BASELINE-size and larger inputs checked through size-independent properties (the oracle would
+    take minutes): sortedness / radius / back-fill of ball query rows, FPS picks are distinct and the
+    min-distance sequence is non-increasing, grouping equals a torch gather, dense-cloud sizes
+    (N = 131072: generic FPS kernel, grid ball query with capped buckets) run."""
+    n, m, ns, r = 131072, 2048, 32, 0.3
+    xyz = scenes(1, n, seed0=9)
+    t = T(xyz)
+    sel, temp = fps_gpu(ext, xyz, m)
+    assert len(np.unique(sel[0])) == m and sel[0, 0] == 0
+    picked = xyz[0, sel[0].astype(np.int64)]
+    dmin = [np.min(np.sum((picked[:j] - picked[j]) ** 2, 1)) for j in range(1, 300)]
+    assert all(dmin[j] >= dmin[j + 1] - 1e-3 for j in range(len(dmin) - 1))         # FPS: radii shrink
+    new_xyz = np.ascontiguousarray(picked[None])
+    idx = torch.zeros((1, m, ns), dtype=torch.int32, device=DEV)
+    ext.pointnet2.ball_query_wrapper(1, n, m, r, ns, T(new_xyz), t, idx)
+    ix = idx.cpu().numpy()[0].astype(np.int64)
+    d2 = np.sum((xyz[0][ix] - new_xyz[0][:, None, :]) ** 2, -1)
+    assert (d2 < r * r + 1e-5).all()                                                  # every listed point is inside
+    first_repeat = (ix == ix[:, :1])
+    for row, rep in zip(ix[:64], first_repeat[:64]):
+        cnt = ns if not rep[1:].any() else 1 + int(np.argmax(rep[1:]))
+        assert (np.diff(row[:cnt]) > 0).all() and (row[cnt:] == row[0]).all()         # index order + back-fill
+    # exact check of a few rows against numpy brute force
+    for p in (0, 1, 777, m - 1):
+        dd = xyz[0] - new_xyz[0, p]
+        hits = np.nonzero((dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2] < np.float32(r) * np.float32(r))[0][:ns]
+        want = np.full(ns, hits[0]); want[:len(hits)] = hits
+        assert np.array_equal(ix[p], want)
+    feats = torch.randn((1, 8, n), device=DEV)
+    out = torch.empty((1, 8, m, ns), device=DEV)
+    ext.pointnet2.group_points_wrapper(1, 8, n, m, ns, feats, idx, out)
+    assert torch.equal(out, torch.gather(feats, 2, idx.view(1, 1, -1).long().expand(-1, 8, -1)).view(1, 8, m, ns))
 
 
 def test_bad_arguments_raise(ext):
