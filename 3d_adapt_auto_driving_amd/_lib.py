@@ -32,6 +32,7 @@ SIGNATURES = {
     "prcnn_maxpool_bias_relu": [_I, _I, _I, _I, _P, _P, _P, _P],
     "prcnn_group_cat_pm": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "prcnn_gather_affine_relu_pm": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "prcnn_sa_mlp_fused": [_I] * 7 + [_P] * 10 + [_I, _I, _P],
     "prcnn_maxpool_pm": [C.c_long, _I, _I, _P, _P, _I, _I, _P],
     "prcnn_three_interpolate_pm": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P],
     "prcnn_boxes_overlap_bev": [_I, _P, _I, _P, _P, _P],

@@ -153,3 +153,19 @@ def gather_affine_relu_pm_wrapper(new_xyz, xyz, P, wxyz, idx, out):
     _lib.call("prcnn_gather_affine_relu_pm", b, n, idx.size(1), cout, idx.size(2), new_xyz.data_ptr(), xyz.data_ptr(),
               P.data_ptr(), wxyz.data_ptr(), idx.data_ptr(), out.data_ptr(), _lib.current_stream(xyz))
     return out
+
+
+def sa_mlp_fused_supported(c1, c2, c3, nsample):
+    return c1 == 128 and c2 == 128 and c3 in (128, 256) and nsample == 64
+
+
+def sa_mlp_fused_wrapper(new_xyz, xyz, P, wxyz, idx, w2t, b2, w3t, b3, out, out_col):
+    """gather + 3-layer shared MLP + max over nsample in one MFMA kernel (csrc/sa_mlp_fused.hip).
+    P (b,n,128), wxyz (3,128), idx (b,m,64), w2t (128,128), w3t (128,c3), out (b,m,stride)."""
+    _chk(torch.float32, new_xyz, xyz, P, wxyz, w2t, b2, w3t, b3, out); _chk(torch.int32, idx)
+    b, n, c1 = P.shape
+    _lib.call("prcnn_sa_mlp_fused", b, n, idx.size(1), idx.size(2), c1, w2t.size(1), w3t.size(1),
+              new_xyz.data_ptr(), xyz.data_ptr(), P.data_ptr(), wxyz.data_ptr(), idx.data_ptr(), w2t.data_ptr(),
+              b2.data_ptr(), w3t.data_ptr(), b3.data_ptr(), out.data_ptr(), out.size(-1), out_col,
+              _lib.current_stream(xyz))
+    return out

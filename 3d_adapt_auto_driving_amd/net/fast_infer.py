@@ -159,6 +159,15 @@ class FastPointRCNN:
         ext = pu.pointnet2
         B, N, _ = xyz.shape
         M, ns = idx.shape[1], idx.shape[2]
+        if (mlp.split is not None and len(mlp.layers) == 3 and mlp.layers[1][2] and mlp.layers[2][2] and
+                ext.sa_mlp_fused_supported(mlp.split[0].shape[1], mlp.layers[1][0].shape[1],
+                                           mlp.layers[2][0].shape[1], ns)):
+            # whole scale in ONE hand-written MFMA kernel: gather -> 3 layers -> max, no HBM activations
+            wf, wx, b1 = mlp.split
+            P = torch.addmm(b1, feats.view(B * N, cin), wf).view(B, N, -1)
+            ext.sa_mlp_fused_wrapper(new_xyz, xyz, P, wx, idx, mlp.layers[1][0], mlp.layers[1][1],
+                                     mlp.layers[2][0], mlp.layers[2][1], out, out_col)
+            return
         if mlp.split is not None and M * ns > N:
             # layer 1 is linear before its ReLU: its feature part is one GEMM over the N points,
             # the grouped rows of the layer-1 OUTPUT are formed by a gather (csrc/pointmajor.hip)

@@ -121,6 +121,16 @@ int prcnn_group_cat_pm(int b, int n, int m, int c, int nsample, const float *new
 int prcnn_gather_affine_relu_pm(int b, int n, int m, int cout, int nsample, const float *new_xyz,
                                 const float *xyz, const float *P, const float *wxyz, const int *idx,
                                 float *out, void *stream);
+/* One kernel for a set-abstraction MLP on grouped points (hand-written v_mfma_f32_32x32x2_f32 tiles):
+ * gather -> layer 1 (P[idx] + wxyz.(xyz[idx]-centre), ReLU) -> layer 2 (w2t,b2,ReLU) -> layer 3
+ * (w3t,b3,ReLU) -> max over nsample; nothing of the grouped activations touches HBM
+ * (pointnet2_modules.py:37-53 for one scale).  w2t (c1,c2) / w3t (c2,c3) are stored input-channel-major.
+ * Supported: c1 = c2 = 128, c3 in {128,256}, nsample = 64.  out[(b*m)][out_col..out_col+c3), row stride
+ * out_stride. */
+int prcnn_sa_mlp_fused(int b, int n, int m, int nsample, int c1, int c2, int c3, const float *new_xyz,
+                       const float *xyz, const float *P, const float *wxyz, const int *idx, const float *w2t,
+                       const float *b2, const float *w3t, const float *b3, float *out, int out_stride,
+                       int out_col, void *stream);
 /* max over ns consecutive rows: in (rows_out*ns, c) -> out[r][out_col..out_col+c), row stride out_stride
  * (F.max_pool2d over nsample, pointnet2_modules.py:41-44, on the point-major MLP output). */
 int prcnn_maxpool_pm(long rows_out, int ns, int c, const float *in, float *out, int out_stride,

@@ -109,6 +109,20 @@ class pointnet2_cpu:
         return out
 
     @staticmethod
+    def sa_mlp_fused_supported(c1, c2, c3, nsample):
+        return c1 == 128 and c2 == 128 and c3 in (128, 256) and nsample == 64
+
+    @staticmethod
+    def sa_mlp_fused_wrapper(new_xyz, xyz, P, wxyz, idx, w2t, b2, w3t, b3, out, out_col):
+        b, m, ns = idx.shape
+        y = torch.empty((b, m * ns, P.shape[2]))
+        pointnet2_cpu.gather_affine_relu_pm_wrapper(new_xyz, xyz, P, wxyz, idx, y)
+        y = torch.addmm(b2, y.view(b * m * ns, -1), w2t).clamp_(min=0)
+        y = torch.addmm(b3, y, w3t).clamp_(min=0)
+        out.view(b * m, -1)[:, out_col:out_col + w3t.shape[1]] = y.view(b * m, ns, -1).amax(dim=1)
+        return out
+
+    @staticmethod
     def maxpool_pm_wrapper(x, ns, out, out_col):
         rows, c = x.size(0) // ns, x.size(1)
         out.view(rows, -1)[:, out_col:out_col + c] = x.view(rows, ns, c).amax(dim=1)

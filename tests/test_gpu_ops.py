@@ -319,6 +319,41 @@ def test_gather_affine_relu_pm(ext):
     assert (out == 0).float().mean() > 0.2                      # the ReLU really clips
 
 
+@pytest.mark.parametrize("c3", [128, 256])
+def test_sa_mlp_fused_mfma_kernel(ext, c3):
+    """Hand-written MFMA kernel (gather -> 3 layers -> max) vs the same computation with library f32
+    GEMMs on the same device: identical gathers, GEMM summation order differs -> 2e-5 relative."""
+    from oracle import ext_cpu
+    rng = np.random.default_rng(36 + c3)
+    b, n, m, ns = 5, 512, 37, 64
+    xyz = T(rng.uniform(-2, 2, (b, n, 3)).astype(np.float32))
+    new_xyz = xyz[:, :m].contiguous()
+    P = T(rng.standard_normal((b, n, 128)).astype(np.float32))
+    wx = T((rng.standard_normal((3, 128)) * 0.5).astype(np.float32))
+    idx = T(rng.integers(0, n, (b, m, ns)).astype(np.int32))
+    w2 = T((rng.standard_normal((128, 128)) / 11).astype(np.float32)); b2 = T(rng.standard_normal(128).astype(np.float32) * 0.1)
+    w3 = T((rng.standard_normal((128, c3)) / 11).astype(np.float32)); b3 = T(rng.standard_normal(c3).astype(np.float32) * 0.1)
+    out = torch.full((b, m, c3 + 8), -1.0, device=DEV)
+    ext.pointnet2.sa_mlp_fused_wrapper(new_xyz, xyz, P, wx, idx, w2, b2, w3, b3, out, 8)
+    # reference: same math through torch on the GPU (library GEMMs)
+    y = torch.empty((b, m * ns, 128), device=DEV)
+    ext.pointnet2.gather_affine_relu_pm_wrapper(new_xyz, xyz, P, wx, idx, y)
+    y = torch.addmm(b2, y.view(-1, 128), w2).clamp_(min=0)
+    y = torch.addmm(b3, y, w3).clamp_(min=0)
+    want = y.view(b * m, ns, c3).amax(dim=1).view(b, m, c3)
+    got = out[:, :, 8:]
+    assert (out[:, :, :8] == -1.0).all()
+    err = (got - want).abs().max().item()
+    assert err <= 2e-5 * max(1.0, want.abs().max().item()), err
+    assert (want > 0).float().mean() > 0.5
+    # and against a float64 evaluation on the host (transpose-detecting: weights are not symmetric)
+    yc = torch.empty((b, m * ns, 128))
+    ext_cpu.pointnet2_cpu.gather_affine_relu_pm_wrapper(new_xyz.cpu(), xyz.cpu(), P.cpu(), wx.cpu(), idx.cpu(), yc)
+    y64 = (yc.double().view(-1, 128) @ w2.cpu().double() + b2.cpu().double()).clamp_(min=0)
+    y64 = (y64 @ w3.cpu().double() + b3.cpu().double()).clamp_(min=0).view(b * m, ns, c3).amax(dim=1)
+    assert (got.cpu().double().view(-1, c3) - y64).abs().max().item() < 5e-5
+
+
 def test_mlp_epilogue_kernels(ext):
     rng = np.random.default_rng(34)
     x = rng.standard_normal((3, 20, 50, 16)).astype(np.float32)
