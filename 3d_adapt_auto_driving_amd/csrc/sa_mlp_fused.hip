@@ -42,10 +42,11 @@ __global__ __launch_bounds__(256) void sa_mlp_fused_kernel(
     const float4 *__restrict__ P /* (b,n,128) */, const float4 *__restrict__ wxyz /* (3,128) */,
     const int *__restrict__ idx /* (b,m,64) */, const float *__restrict__ w2t /* (128,128) k-major */,
     const float *__restrict__ b2, const float *__restrict__ w3t /* (128,C3) k-major */,
-    const float *__restrict__ b3, float *__restrict__ out, int out_stride, int out_col)
+    const float *__restrict__ b3, float *__restrict__ out, int out_stride, int out_col,
+    unsigned int *__restrict__ ticket)
 {
     constexpr int NCT = C3 / 128;                 // column tiles of layer 3 per wave
-    __shared__ float lds[2 * SA_NS * SA_LD];      // A1 tile and Y1 tile, 64 x 132 each
+    __shared__ float lds[2 * SA_NS * SA_LD + 4];  // A1 tile and Y1 tile, 64 x 132 each (+ the tile ticket)
     float *A1 = lds, *Y1 = lds + SA_NS * SA_LD;
 
     const int tid = threadIdx.x;
@@ -69,7 +70,15 @@ __global__ __launch_bounds__(256) void sa_mlp_fused_kernel(
     const int chunk = tid & 31;
     const float4 wx = wxyz[chunk], wy = wxyz[32 + chunk], wz = wxyz[64 + chunk];
 
-    for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
+    // Tiles are handed out through a ticket counter, not a static stride: a workgroup that starts late
+    // (e.g. its CU was busy with another stream's kernel) simply takes fewer tiles instead of
+    // stretching the whole launch.
+    unsigned int *slot = reinterpret_cast<unsigned int *>(lds + 2 * SA_NS * SA_LD);
+    for (;;) {
+        if (tid == 0) *slot = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const long t = *slot;
+        if (t >= tiles) break;
         const long b = t / m;
         const float *ct3 = new_xyz + t * 3;
         const float cx = ct3[0], cy = ct3[1], cz = ct3[2];
@@ -150,10 +159,25 @@ __global__ __launch_bounds__(256) void sa_mlp_fused_kernel(
             }
         }
         // the next tile's builder overwrites A1 only; every wave has left layer 2 (barrier above), and
-        // Y1 is rewritten only after the next tile's first barrier, which all waves reach after layer 3
+        // Y1 is rewritten only after the next tile's barriers, which all waves reach after layer 3;
+        // the ticket slot is rewritten by thread 0 after it passed the layer-2 barrier, i.e. after
+        // every thread has read it
     }
 }
 
+}  // namespace prcnn
+
+namespace prcnn {
+// 64 rotating ticket words per process (one launch uses one; zeroed by a memset on the same stream)
+static unsigned int *g_tickets = nullptr;
+static unsigned int g_ticket_next = 0;
+static unsigned int *next_ticket(hipStream_t st)
+{
+    if (!g_tickets && hipMalloc((void **)&g_tickets, 64 * sizeof(unsigned int)) != hipSuccess) return nullptr;
+    unsigned int *t = g_tickets + (g_ticket_next++ & 63);
+    if (hipMemsetAsync(t, 0, sizeof(unsigned int), st) != hipSuccess) return nullptr;
+    return t;
+}
 }  // namespace prcnn
 
 using namespace prcnn;
@@ -176,11 +200,13 @@ extern "C" int prcnn_sa_mlp_fused(int b, int n, int m, int nsample, int c1, int 
     PRCNN_REQUIRE((((uintptr_t)P | (uintptr_t)wxyz) & 15) == 0, "sa_mlp_fused: 16-byte alignment required");
     const long cap = 256L * (c3 == 128 ? 2 : 1);      // persistent: workgroups resident per CU x 256 CUs
     const int grid = (int)(tiles < cap ? tiles : cap);
+    unsigned int *ticket = next_ticket((hipStream_t)stream);
+    if (!ticket) { set_error("sa_mlp_fused: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
     if (c3 == 128)
         hipLaunchKernelGGL(sa_mlp_fused_kernel<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, m, tiles, new_xyz,
-                           xyz, (const float4 *)P, (const float4 *)wxyz, idx, w2t, b2, w3t, b3, out, out_stride, out_col);
+                           xyz, (const float4 *)P, (const float4 *)wxyz, idx, w2t, b2, w3t, b3, out, out_stride, out_col, ticket);
     else
         hipLaunchKernelGGL(sa_mlp_fused_kernel<256>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, m, tiles, new_xyz,
-                           xyz, (const float4 *)P, (const float4 *)wxyz, idx, w2t, b2, w3t, b3, out, out_stride, out_col);
+                           xyz, (const float4 *)P, (const float4 *)wxyz, idx, w2t, b2, w3t, b3, out, out_stride, out_col, ticket);
     return check_launch("sa_mlp_fused");
 }
