@@ -18,7 +18,6 @@
 // candidates; a bucket reached through two neighbour cells is visited once.
 #include "common.hpp"
 #include <math.h>
-#include <mutex>
 
 namespace prcnn {
 
@@ -105,41 +104,6 @@ __global__ __launch_bounds__(QT) void grid_query_kernel(
     }
     const int lowest = mine[0];
     for (int l = 0; l < nsample; ++l) out[l] = l < cnt ? mine[l * QT] : lowest;
-}
-
-// ---- per-stream scratch ---------------------------------------------------------------------
-struct Scratch {
-    hipStream_t stream;
-    char *ptr;
-    size_t bytes;
-};
-static Scratch g_scratch[8];
-static int g_scratch_n = 0;
-static std::mutex g_scratch_mu;
-
-static char *scratch_for(hipStream_t st, size_t bytes)
-{
-    std::lock_guard<std::mutex> lock(g_scratch_mu);
-    Scratch *s = nullptr;
-    for (int i = 0; i < g_scratch_n; ++i)
-        if (g_scratch[i].stream == st) s = &g_scratch[i];
-    if (!s) {
-        if (g_scratch_n == 8) {   // recycle the first slot (its stream must be idle by contract)
-            s = &g_scratch[0];
-            (void)hipStreamSynchronize(s->stream);
-            s->stream = st;
-        } else {
-            s = &g_scratch[g_scratch_n++];
-            s->stream = st; s->ptr = nullptr; s->bytes = 0;
-        }
-    }
-    if (s->bytes < bytes) {
-        if (s->ptr) { (void)hipStreamSynchronize(st); (void)hipFree(s->ptr); }
-        s->ptr = nullptr; s->bytes = 0;
-        if (hipMalloc((void **)&s->ptr, bytes) != hipSuccess) return nullptr;
-        s->bytes = bytes;
-    }
-    return s->ptr;
 }
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }

@@ -21,6 +21,10 @@ int check_launch(const char *what);
         }                                        \
     } while (0)
 
+// cached device scratch, one per stream (grown on demand; hipMalloc only on growth).  `slot` separates
+// independent users (0: ball-query grid, 1: FPS ordering).
+char *scratch_for(hipStream_t st, size_t bytes, int slot = 0);
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // (a-b)^2 summed left to right, one rounding per operation (no fma): the distance form of

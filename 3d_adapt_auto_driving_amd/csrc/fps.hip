@@ -12,6 +12,7 @@
 // one wave each (no barrier at all), which is what the 100*B RoI clouds of the RCNN stage need.
 #include "common.hpp"
 #include <math.h>
+#include <stdlib.h>
 
 namespace prcnn {
 
@@ -164,6 +165,179 @@ __global__ __launch_bounds__(64 * WAVES) void fps_reg_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Spatially pruned FPS (exact).  A new pivot can lower the running minimum of point k only if
+// d(k, pivot)^2 < temp[k] <= V, where V = max_k temp[k] is the value of the pivot just selected.
+// So only points inside the ball of radius sqrt(V) around the pivot need a distance evaluation, and
+// V shrinks as sampling proceeds (about (area / j) after j picks).  The cloud is first ordered along a
+// Morton curve over (x, z) (fps_order_kernel: one workgroup per cloud, LDS counting sort), so that each
+// group of 64 consecutive points -- one register slot across the lanes of a wave, a "tile" -- is
+// spatially compact.  Per iteration lane i < PPT of every wave tests the pivot against the bounding box
+// of tile i (a lower bound of every distance in the tile, with a 1e-5 relative safety margin that
+// covers f32 rounding of both sides); tiles that cannot change are skipped, and a wave none of whose
+// tiles changed re-submits its cached best.  Selected indices, tie rule and running minima are
+// bit-identical to the full scan: skipped points satisfy min(d, temp) == temp.
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ unsigned part1by1(unsigned v)   // spread the low 16 bits to even positions
+{
+    v &= 0xffffu;
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+// perm[b][s] = original index of the s-th point in Morton order of a 64 x 64 grid over the cloud's
+// (x, z) bounding box.  Any permutation is valid for correctness; this one makes tiles compact.
+__global__ __launch_bounds__(1024) void fps_order_kernel(int n, const float *__restrict__ xyz, int *__restrict__ perm)
+{
+    __shared__ int cnt[4096];
+    __shared__ float red[4][16];
+    __shared__ int wsum[16];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float *__restrict__ cloud = xyz + (long)b * n * 3;
+    float x0 = INFINITY, x1 = -INFINITY, z0 = INFINITY, z1 = -INFINITY;
+    for (int k = t; k < n; k += 1024) {
+        const float x = cloud[3 * k], z = cloud[3 * k + 2];
+        x0 = fminf(x0, x); x1 = fmaxf(x1, x); z0 = fminf(z0, z); z1 = fmaxf(z1, z);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, d, 64)); x1 = fmaxf(x1, __shfl_xor(x1, d, 64));
+        z0 = fminf(z0, __shfl_xor(z0, d, 64)); z1 = fmaxf(z1, __shfl_xor(z1, d, 64));
+    }
+    if ((t & 63) == 0) { red[0][t >> 6] = x0; red[1][t >> 6] = x1; red[2][t >> 6] = z0; red[3][t >> 6] = z1; }
+    for (int i = t; i < 4096; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    x0 = red[0][0]; x1 = red[1][0]; z0 = red[2][0]; z1 = red[3][0];
+    for (int w = 1; w < 16; ++w) {
+        x0 = fminf(x0, red[0][w]); x1 = fmaxf(x1, red[1][w]); z0 = fminf(z0, red[2][w]); z1 = fmaxf(z1, red[3][w]);
+    }
+    const float sx = x1 > x0 ? 64.f / (x1 - x0) : 0.f, sz = z1 > z0 ? 64.f / (z1 - z0) : 0.f;
+    auto code_of = [&](int k) {
+        float fx = (cloud[3 * k] - x0) * sx, fz = (cloud[3 * k + 2] - z0) * sz;
+        fx = fx == fx ? fx : 0.f; fz = fz == fz ? fz : 0.f;            // NaN-safe
+        const int cx = min(63, max(0, (int)fx)), cz = min(63, max(0, (int)fz));
+        return (int)(part1by1((unsigned)cx) | (part1by1((unsigned)cz) << 1));
+    };
+    for (int k = t; k < n; k += 1024) atomicAdd(&cnt[code_of(k)], 1);
+    __syncthreads();
+    // exclusive scan of the 4096 counters: 4 per thread
+    int local = 0, c4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { c4[i] = cnt[4 * t + i]; local += c4[i]; }
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if ((t & 63) >= d) incl += o;
+    }
+    if ((t & 63) == 63) wsum[t >> 6] = incl;
+    __syncthreads();
+    int run = incl - local;
+    for (int w = 0; w < (t >> 6); ++w) run += wsum[w];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { cnt[4 * t + i] = run; run += c4[i]; }
+    __syncthreads();
+    for (int k = t; k < n; k += 1024) perm[(long)b * n + atomicAdd(&cnt[code_of(k)], 1)] = k;
+}
+
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_pruned_kernel(
+    int n, int m, KeyCodec kc, const float *__restrict__ xyz, const int *__restrict__ perm,
+    float *__restrict__ temp, int *__restrict__ idx)
+{
+    __shared__ float s_v[2][16];
+    __shared__ uint32_t s_k[2][16];
+    const int b = blockIdx.x;
+    const float *__restrict__ cloud = xyz + (long)b * n * 3;
+    const int *__restrict__ order = perm + (long)b * n;
+    float *__restrict__ mind = temp + (long)b * n;
+    int *__restrict__ sel = idx + (long)b * m;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+
+    float px[PPT], py[PPT], pz[PPT], pt[PPT];
+    uint32_t pk[PPT];
+    int porig[PPT];
+    // lane i < PPT keeps the bounding box of tile i of this wave
+    float bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY, bz0 = INFINITY, bz1 = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int s = w * (64 * PPT) + i * 64 + lane;      // position in Morton order
+        float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY, z0 = INFINITY, z1 = -INFINITY;
+        if (s < n) {
+            const int k = order[s];
+            porig[i] = k;
+            px[i] = cloud[3 * k]; py[i] = cloud[3 * k + 1]; pz[i] = cloud[3 * k + 2];
+            pt[i] = mind[k];
+            pk[i] = kc.encode(k);
+            x0 = x1 = px[i]; y0 = y1 = py[i]; z0 = z1 = pz[i];
+        } else {
+            porig[i] = -1;
+            px[i] = py[i] = pz[i] = 0.f;
+            pt[i] = -INFINITY;
+            pk[i] = 0xffffffffu;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            x0 = fminf(x0, __shfl_xor(x0, d, 64)); x1 = fmaxf(x1, __shfl_xor(x1, d, 64));
+            y0 = fminf(y0, __shfl_xor(y0, d, 64)); y1 = fmaxf(y1, __shfl_xor(y1, d, 64));
+            z0 = fminf(z0, __shfl_xor(z0, d, 64)); z1 = fmaxf(z1, __shfl_xor(z1, d, 64));
+        }
+        if (lane == i) { bx0 = x0; bx1 = x1; by0 = y0; by1 = y1; bz0 = z0; bz1 = z1; }
+    }
+    if (t < 32) {
+        (&s_v[0][0])[t] = -INFINITY;
+        (&s_k[0][0])[t] = 0xffffffffu;
+    }
+    __syncthreads();
+
+    int old = 0;
+    float vmax = INFINITY;                 // value of the pivot just selected: bounds every running minimum
+    float wbv = -1.0f;                     // this wave's cached best
+    uint32_t wkey = 0xffffffffu;
+    if (t == 0) sel[0] = 0;
+    for (int j = 1; j < m; ++j) {
+        const float ox = cloud[3 * old], oy = cloud[3 * old + 1], oz = cloud[3 * old + 2];
+        // distance from the pivot to tile `lane`'s box: a lower bound for every point of the tile
+        const float dx = fmaxf(fmaxf(bx0 - ox, ox - bx1), 0.f);
+        const float dy = fmaxf(fmaxf(by0 - oy, oy - by1), 0.f);
+        const float dz = fmaxf(fmaxf(bz0 - oz, oz - bz1), 0.f);
+        const float lb = dx * dx + dy * dy + dz * dz;
+        const bool touch = (lane < PPT) && !(lb * 0.99999f >= vmax);   // empty boxes give lb = +inf
+        const unsigned long long mask = __ballot(touch);
+        if (mask != 0ull) {                                              // wave-uniform
+#pragma unroll
+            for (int i = 0; i < PPT; ++i)
+                if ((mask >> i) & 1ull) {
+                    const float d = sqdist3(px[i], py[i], pz[i], ox, oy, oz);
+                    pt[i] = fminf(d, pt[i]);
+                }
+            float bv = -1.0f;
+            uint32_t bkey = 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) take_if_better(pt[i], pk[i], bv, bkey);
+            wave_argmax(bv, bkey);
+            wbv = bv; wkey = bkey;
+        }
+        const int buf = j & 1;
+        if (lane == 0) { s_v[buf][w] = wbv; s_k[buf][w] = wkey; }
+        __syncthreads();
+        float bv = s_v[buf][t & 15];
+        uint32_t bkey = s_k[buf][t & 15];
+        row16_argmax(bv, bkey);
+        vmax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bv)));
+        old = (bkey == 0xffffffffu) ? 0 : kc.decode(bkey);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (t == 0) sel[j] = old;
+    }
+#pragma unroll
+    for (int i = 0; i < PPT; ++i)
+        if (porig[i] >= 0) mind[porig[i]] = pt[i];
+}
+
 // Any-n fallback: running minima stay in `temp` (global), one 1024-thread block per cloud.
 __global__ __launch_bounds__(1024) void fps_generic_kernel(
     int n, int m, KeyCodec kc, const float *__restrict__ xyz, float *__restrict__ temp,
@@ -245,6 +419,18 @@ extern "C" int prcnn_furthest_point_sampling(int b, int n, int m, const float *x
     while ((1 << kc.sh) < nq) ++kc.sh;
     PRCNN_REQUIRE(kc.sh + kc.log2bs <= 31, "fps: n=%d too large for the 32-bit tie key", n);
 
+    // large clouds: Morton ordering + pruned scan (exact).  It needs (n ints) of scratch per scene and pays
+    // off when the sample count is large enough for the pruning radius to shrink.
+    static const bool no_prune = getenv("PRCNN_FPS_NO_PRUNE") != nullptr;
+    if (!no_prune && n > 2048 && n <= 16384 && m >= 256) {
+        int *perm = (int *)scratch_for(st, (size_t)b * n * sizeof(int), 1);
+        if (!perm) { set_error("fps: cannot allocate ordering scratch"); return PRCNN_ELAUNCH; }
+        hipLaunchKernelGGL(fps_order_kernel, dim3(b), dim3(1024), 0, st, n, xyz, perm);
+        if (n <= 4096) hipLaunchKernelGGL(fps_pruned_kernel<4>, dim3(b), dim3(1024), 0, st, n, m, kc, xyz, perm, temp, idx);
+        else if (n <= 8192) hipLaunchKernelGGL(fps_pruned_kernel<8>, dim3(b), dim3(1024), 0, st, n, m, kc, xyz, perm, temp, idx);
+        else hipLaunchKernelGGL(fps_pruned_kernel<16>, dim3(b), dim3(1024), 0, st, n, m, kc, xyz, perm, temp, idx);
+        return check_launch("furthest_point_sampling(pruned)");
+    }
     if (n <= 128) launch_reg<1, 2>(b, n, m, kc, xyz, temp, idx, st);
     else if (n <= 256) launch_reg<1, 4>(b, n, m, kc, xyz, temp, idx, st);
     else if (n <= 512) launch_reg<1, 8>(b, n, m, kc, xyz, temp, idx, st);
