@@ -327,8 +327,8 @@ static int ensure_scratch(size_t ints)
     return PRCNN_OK;
 }
 
-static int nms_device(int nprob, int n_max, const int *counts, const float *boxes, float thresh,
-                      int rotated, int max_keep, int *keep, int *num_keep, hipStream_t st)
+int nms_device(int nprob, int n_max, const int *counts, const float *boxes, float thresh,
+               int rotated, int max_keep, int *keep, int *num_keep, hipStream_t st)
 {
     PRCNN_REQUIRE(nprob >= 0 && n_max >= 0 && max_keep >= 0, "nms: bad sizes");
     PRCNN_REQUIRE(n_max <= NMS_MAX_N, "nms: %d boxes > %d unsupported", n_max, NMS_MAX_N);

@@ -1,0 +1,294 @@
+// proposal.hip -- the RPN proposal layer as five launches (counterpart of
+// pointrcnn/lib/rpn/proposal_layer.py:15-119 with decode_bbox_target of lib/utils/bbox_transform.py:24-121).
+//
+// The reference does this per scene in Python: ~25 elementwise torch kernels for the decode, a sort,
+// boolean-mask selections with two device->host syncs, and two NMS calls with host round trips; the
+// batched torch formulation in net/proposal_layer.py still needs ~90 short launches.  Here:
+//   1. rpn_decode_kernel     one lane per point: arg-max of the x / z / heading bins, residuals, box
+//                            (same f32 operation order as the torch expression, no fma)
+//   2. score_sort_kernel     one workgroup per scene: bitonic sort of (score desc, index asc) keys in LDS
+//   3. band_select_kernel    one workgroup per scene: ordered compaction (wave ballot + LDS prefix) of the
+//                            sorted proposals into the (0,40] m and (40,80] m tables, top 70 % / 30 % of
+//                            RPN_PRE_NMS_TOP_N, with the reference's "no far points" fallback
+//   4. nms_lazy_kernel       (iou3d.hip) all 2*B problems in one launch, stops at the post-NMS quota
+//   5. assemble_rois_kernel  near keeps, then far keeps, zero padded -> rois (B, M, 7), scores (B, M)
+// No host synchronisation anywhere.
+#include "common.hpp"
+#include <math.h>
+
+namespace prcnn {
+
+int nms_device(int nprob, int n_max, const int *counts, const float *boxes, float thresh, int rotated,
+               int max_keep, int *keep, int *num_keep, hipStream_t st);   // iou3d.hip
+
+struct DecodeCfg {
+    float loc_scope, loc_bin_size;
+    int nbin;          // per_loc_bin_num = 2 * int(loc_scope / loc_bin_size)
+    int num_head_bin;
+    int xz_fine;
+    float anchor[3];
+    int channels;
+};
+
+__device__ __forceinline__ int argmax_row(const float *p, int n)
+{
+    int best = 0;
+    float bv = p[0];
+    for (int i = 1; i < n; ++i)
+        if (p[i] > bv) { bv = p[i]; best = i; }   // first maximum, as torch.argmax on distinct values
+    return best;
+}
+
+// torch.remainder for f32: fmod, then shifted into the sign of the divisor
+__device__ __forceinline__ float torch_remainder(float a, float b)
+{
+    float m = fmodf(a, b);
+    if (m != 0.f && ((b < 0.f) != (m < 0.f))) m += b;
+    return m;
+}
+
+// decode_bbox_target(xyz (N,3), reg, get_xz_fine, get_y_by_bin=False, get_ry_fine=False), then
+// proposals[:, 1] += proposals[:, 3] / 2 (proposal_layer.py:31)
+__global__ __launch_bounds__(256) void rpn_decode_kernel(long total, DecodeCfg c, const float *__restrict__ xyz,
+                                                         const float *__restrict__ reg, float *__restrict__ boxes)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float *r = reg + i * c.channels;
+    const float *p = xyz + i * 3;
+    const int nb = c.nbin;
+    const int xb = argmax_row(r, nb), zb = argmax_row(r + nb, nb);
+    const float half_bin = c.loc_bin_size / 2;
+    float px = __fsub_rn(__fadd_rn(__fmul_rn((float)xb, c.loc_bin_size), half_bin), c.loc_scope);
+    float pz = __fsub_rn(__fadd_rn(__fmul_rn((float)zb, c.loc_bin_size), half_bin), c.loc_scope);
+    int cur = 2 * nb;
+    if (c.xz_fine) {
+        px = __fadd_rn(px, __fmul_rn(r[2 * nb + xb], c.loc_bin_size));
+        pz = __fadd_rn(pz, __fmul_rn(r[3 * nb + zb], c.loc_bin_size));
+        cur = 4 * nb;
+    }
+    float py = __fadd_rn(p[1], r[cur]);
+    cur += 1;
+    const int rb = argmax_row(r + cur, c.num_head_bin);
+    const float res_norm = r[cur + c.num_head_bin + rb];
+    const float apc = (float)((2.0 * M_PI) / c.num_head_bin);            // python double -> f32 scalar
+    const float apc_half = (float)(((2.0 * M_PI) / c.num_head_bin) / 2.0);
+    const float two_pi = (float)(2.0 * M_PI), pi = (float)M_PI;
+    float ry = torch_remainder(__fadd_rn(__fmul_rn((float)rb, apc), __fmul_rn(res_norm, apc_half)), two_pi);
+    if (ry > pi) ry = __fsub_rn(ry, two_pi);
+    cur += 2 * c.num_head_bin;
+    const float h = __fadd_rn(__fmul_rn(r[cur], c.anchor[0]), c.anchor[0]);
+    const float w = __fadd_rn(__fmul_rn(r[cur + 1], c.anchor[1]), c.anchor[1]);
+    const float l = __fadd_rn(__fmul_rn(r[cur + 2], c.anchor[2]), c.anchor[2]);
+    float *o = boxes + i * 7;
+    o[0] = __fadd_rn(px, p[0]);
+    o[1] = __fadd_rn(py, h / 2);
+    o[2] = __fadd_rn(pz, p[2]);
+    o[3] = h; o[4] = w; o[5] = l; o[6] = ry;
+}
+
+// key: descending score, ties by ascending index
+__device__ __forceinline__ unsigned long long sort_key(float score, unsigned idx)
+{
+    unsigned u = __float_as_uint(score);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-order image of the float
+    return ((unsigned long long)(~u) << 32) | idx;     // inverted: larger score sorts first
+}
+
+// one workgroup per scene; n padded to npad = 2^k <= 16384 with +inf keys; writes order (b, n) i32
+__global__ __launch_bounds__(1024) void score_sort_kernel(int n, int npad, const float *__restrict__ scores,
+                                                          int *__restrict__ order)
+{
+    extern __shared__ unsigned long long keys[];
+    const int b = blockIdx.x, t = threadIdx.x;
+    for (int i = t; i < npad; i += 1024)
+        keys[i] = i < n ? sort_key(scores[(long)b * n + i], (unsigned)i) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1)
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            for (int i = t; i < npad / 2; i += 1024) {
+                const int lo = ((i / j) * 2 * j) + (i % j), hi = lo + j;   // pair (lo, lo + j)
+                const bool up = ((lo & k) == 0);
+                const unsigned long long a = keys[lo], c = keys[hi];
+                if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int i = t; i < n; i += 1024) order[(long)b * n + i] = (int)(keys[i] & 0xffffffffu);
+}
+
+// tables: payload (b, 2, rows, 8) = box7 + score, bev (b, 2, rows, 5), counts (b, 2)
+__global__ __launch_bounds__(1024) void band_select_kernel(
+    int n, int rows, int pre_near, int pre_far, const float *__restrict__ boxes, const float *__restrict__ scores,
+    const int *__restrict__ order, float *__restrict__ payload, float *__restrict__ bev, int *__restrict__ counts)
+{
+    __shared__ int wcnt[2][16];
+    __shared__ int tot[2];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const float *__restrict__ bx = boxes + (long)b * n * 7;
+    const float *__restrict__ sc = scores + (long)b * n;
+    const int *__restrict__ ord = order + (long)b * n;
+    float *__restrict__ pay = payload + (long)b * 2 * rows * 8;
+    float *__restrict__ bv = bev + (long)b * 2 * rows * 5;
+    if (t < 2) tot[t] = 0;
+    __syncthreads();
+
+    auto emit = [&](int band, int slot, int k) {
+        float *o = pay + ((long)band * rows + slot) * 8;
+        const float *q = bx + (long)k * 7;
+#pragma unroll
+        for (int e = 0; e < 7; ++e) o[e] = q[e];
+        o[7] = sc[k];
+        float *v = bv + ((long)band * rows + slot) * 5;
+        const float hl = q[5] / 2, hw = q[4] / 2;               // boxes3d_to_bev_torch (kitti_utils.py:134-147)
+        v[0] = q[0] - hl; v[1] = q[2] - hw; v[2] = q[0] + hl; v[3] = q[2] + hw; v[4] = q[6];
+    };
+
+    // pass 0: near band gets near ranks [0, pre_near), far band far ranks [0, pre_far)
+    // pass 1 (only if the scene has no far point): far band gets near ranks [pre_near, pre_near + pre_far)
+    for (int pass = 0; pass < 2; ++pass) {
+        int near_seen = 0, far_seen = 0;
+        for (int base = 0; base < n; base += 1024) {
+            if (pass == 0 && near_seen >= pre_near && far_seen >= pre_far) break;
+            if (pass == 1 && near_seen >= pre_near + pre_far) break;
+            const int s = base + t;
+            int k = -1;
+            bool is_near = false, is_far = false;
+            if (s < n) {
+                k = ord[s];
+                const float dist = bx[(long)k * 7 + 2];
+                is_near = dist > 0.f && dist <= 40.0f;
+                is_far = dist > 40.0f && dist <= 80.0f;
+            }
+            const unsigned long long mn = __ballot(is_near), mf = __ballot(is_far);
+            if (lane == 0) { wcnt[0][w] = __popcll(mn); wcnt[1][w] = __popcll(mf); }
+            __syncthreads();
+            int nb = near_seen, fb = far_seen, nt = 0, ft = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (q < w) { nb += wcnt[0][q]; fb += wcnt[1][q]; }
+                nt += wcnt[0][q]; ft += wcnt[1][q];
+            }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (is_near) {
+                const int rank = nb + __popcll(mn & below);
+                if (pass == 0 && rank < pre_near) emit(0, rank, k);
+                if (pass == 1 && rank >= pre_near && rank < pre_near + pre_far) emit(1, rank - pre_near, k);
+            }
+            if (is_far && pass == 0) {
+                const int rank = fb + __popcll(mf & below);
+                if (rank < pre_far) emit(1, rank, k);
+            }
+            near_seen += nt; far_seen += ft;
+            __syncthreads();
+        }
+        if (pass == 0) {
+            if (t == 0) { tot[0] = near_seen; tot[1] = far_seen; }
+            __syncthreads();
+            // the scan stops early once both quotas are full, so "no far point" is only known if it ran
+            // to the end; a scene with an empty far band never fills the far quota, hence it did
+            if (tot[1] != 0) {
+                if (t == 0) { counts[b * 2] = min(tot[0], pre_near); counts[b * 2 + 1] = min(tot[1], pre_far); }
+                return;
+            }
+        } else if (t == 0) {
+            counts[b * 2] = min(tot[0], pre_near);
+            counts[b * 2 + 1] = max(0, min(near_seen, pre_near + pre_far) - pre_near);
+        }
+    }
+}
+
+__global__ __launch_bounds__(128) void assemble_rois_kernel(
+    int rows, int keep_stride, int post_near, int post_far, const float *__restrict__ payload,
+    const int *__restrict__ keep, const int *__restrict__ num, float *__restrict__ rois, float *__restrict__ scores)
+{
+    const int b = blockIdx.x, j = threadIdx.x;
+    const int post = post_near + post_far;
+    if (j >= post) return;
+    const int kn = min(num[b * 2], post_near), kf = min(num[b * 2 + 1], post_far);
+    float *o = rois + ((long)b * post + j) * 7;
+    int band = -1, slot = 0;
+    if (j < kn) { band = 0; slot = keep[(b * 2) * keep_stride + j]; }
+    else if (j < kn + kf) { band = 1; slot = keep[(b * 2 + 1) * keep_stride + (j - kn)]; }
+    if (band < 0) {
+#pragma unroll
+        for (int e = 0; e < 7; ++e) o[e] = 0.f;
+        scores[(long)b * post + j] = 0.f;
+        return;
+    }
+    const float *q = payload + (((long)b * 2 + band) * rows + slot) * 8;
+#pragma unroll
+    for (int e = 0; e < 7; ++e) o[e] = q[e];
+    scores[(long)b * post + j] = q[7];
+}
+
+static size_t aligned(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace prcnn
+
+using namespace prcnn;
+
+// xyz (b,n,3), scores (b,n) raw RPN scores, reg (b,n,channels) -> rois (b, post_top_n, 7), roi_scores (b, post_top_n)
+// distance-based proposal (RPN_DISTANCE_BASED_PROPOSE), get_y_by_bin = False, get_ry_fine = False.
+extern "C" int prcnn_rpn_proposals(int b, int n, int channels, float loc_scope, float loc_bin_size,
+                                   int num_head_bin, int xz_fine, const float *anchor_size_host,
+                                   int pre_nms_top_n, int post_nms_top_n, float nms_thresh, int rotated_nms,
+                                   const float *xyz, const float *scores, const float *reg, float *rois,
+                                   float *roi_scores, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && n > 0 && channels > 0 && num_head_bin > 0 && loc_bin_size > 0, "rpn_proposals: bad sizes");
+    PRCNN_REQUIRE(anchor_size_host, "rpn_proposals: anchor size missing");
+    DecodeCfg c;
+    c.loc_scope = loc_scope; c.loc_bin_size = loc_bin_size;
+    c.nbin = (int)(loc_scope / loc_bin_size) * 2;
+    c.num_head_bin = num_head_bin; c.xz_fine = xz_fine ? 1 : 0; c.channels = channels;
+    for (int i = 0; i < 3; ++i) c.anchor[i] = anchor_size_host[i];
+    const int expect = c.nbin * (c.xz_fine ? 4 : 2) + 1 + 2 * num_head_bin + 3;
+    PRCNN_REQUIRE(channels == expect, "rpn_proposals: %d regression channels, layout needs %d", channels, expect);
+    int npad = 1;
+    while (npad < n) npad <<= 1;
+    PRCNN_REQUIRE(npad <= 16384, "rpn_proposals: n=%d > 16384 points per scene unsupported by the fused path", n);
+    const int pre_near = (int)(pre_nms_top_n * 0.7), pre_far = pre_nms_top_n - pre_near;
+    const int post_near = (int)(post_nms_top_n * 0.7), post_far = post_nms_top_n - post_near;
+    PRCNN_REQUIRE(post_nms_top_n <= 128 && post_near >= post_far && pre_near >= pre_far, "rpn_proposals: unsupported quotas");
+    if (b == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(xyz && scores && reg && rois && roi_scores, "rpn_proposals: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = pre_near;
+    const size_t o_boxes = 0;
+    const size_t o_order = o_boxes + aligned((size_t)b * n * 7 * 4);
+    const size_t o_pay = o_order + aligned((size_t)b * n * 4);
+    const size_t o_bev = o_pay + aligned((size_t)b * 2 * rows * 8 * 4);
+    const size_t o_cnt = o_bev + aligned((size_t)b * 2 * rows * 5 * 4);
+    const size_t o_keep = o_cnt + aligned((size_t)b * 2 * 4);
+    const size_t o_num = o_keep + aligned((size_t)b * 2 * post_near * 4);
+    const size_t need = o_num + aligned((size_t)b * 2 * 4);
+    char *base = scratch_for(st, need, 2);
+    if (!base) { set_error("rpn_proposals: cannot allocate %zu bytes of scratch", need); return PRCNN_ELAUNCH; }
+    float *boxes = (float *)(base + o_boxes);
+    int *order = (int *)(base + o_order);
+    float *payload = (float *)(base + o_pay), *bev = (float *)(base + o_bev);
+    int *counts = (int *)(base + o_cnt), *keep = (int *)(base + o_keep), *num = (int *)(base + o_num);
+
+    const long total = (long)b * n;
+    hipLaunchKernelGGL(rpn_decode_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, total, c, xyz, reg, boxes);
+    const size_t lds = (size_t)npad * sizeof(unsigned long long);
+    static size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+        if (hipFuncSetAttribute((const void *)score_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("rpn_proposals: cannot reserve %zu bytes of LDS", lds);
+            return PRCNN_ELAUNCH;
+        }
+        configured = lds;
+    }
+    hipLaunchKernelGGL(score_sort_kernel, dim3(b), dim3(1024), lds, st, n, npad, scores, order);
+    hipLaunchKernelGGL(band_select_kernel, dim3(b), dim3(1024), 0, st, n, rows, pre_near, pre_far, boxes, scores, order,
+                       payload, bev, counts);
+    int rc = check_launch("rpn_proposals");
+    if (rc != PRCNN_OK) return rc;
+    rc = nms_device(2 * b, rows, counts, bev, nms_thresh, rotated_nms, post_near, keep, num, st);
+    if (rc != PRCNN_OK) return rc;
+    hipLaunchKernelGGL(assemble_rois_kernel, dim3(b), dim3(128), 0, st, rows, post_near, post_near, post_far, payload, keep,
+                       num, rois, roi_scores);
+    return check_launch("rpn_proposals");
+}

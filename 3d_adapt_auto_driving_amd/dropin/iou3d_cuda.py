@@ -66,3 +66,17 @@ def nms_device(boxes, counts, thresh, rotated, max_keep, keep, num_keep):
               float(thresh), int(bool(rotated)), int(max_keep), keep.data_ptr(), num_keep.data_ptr(),
               _lib.current_stream(boxes))
     return 1
+
+
+def rpn_proposals(xyz, scores, reg, anchor_size, loc_scope, loc_bin_size, num_head_bin, xz_fine,
+                  pre_nms_top_n, post_nms_top_n, nms_thresh, rotated, rois, roi_scores):
+    """Fused RPN proposal layer (csrc/proposal.hip).  xyz (B,N,3), scores (B,N), reg (B,N,C) ->
+    rois (B,post,7), roi_scores (B,post); anchor_size: 3 python floats (h, w, l)."""
+    import ctypes
+    _chk(xyz, scores, reg, rois, roi_scores)
+    anchor = (ctypes.c_float * 3)(*[float(v) for v in anchor_size])
+    _lib.call("prcnn_rpn_proposals", xyz.size(0), xyz.size(1), reg.size(2), float(loc_scope), float(loc_bin_size),
+              int(num_head_bin), int(bool(xz_fine)), ctypes.cast(anchor, ctypes.c_void_p), int(pre_nms_top_n),
+              int(post_nms_top_n), float(nms_thresh), int(bool(rotated)), xyz.data_ptr(), scores.data_ptr(),
+              reg.data_ptr(), rois.data_ptr(), roi_scores.data_ptr(), _lib.current_stream(xyz))
+    return rois, roi_scores

@@ -22,11 +22,25 @@ class ProposalLayer(nn.Module):
         self.cfg = cfg
         self.mode = mode
         self.register_buffer("MEAN_SIZE", torch.from_numpy(cfg.CLS_MEAN_SIZE[0]).float().clone(), persistent=False)
+        self._anchor = [float(v) for v in torch.from_numpy(cfg.CLS_MEAN_SIZE[0]).float()]   # f32-rounded h, w, l
+        self.fused = True      # use the fused HIP proposal path when the extension offers it
 
     def forward(self, rpn_scores, rpn_reg, xyz):
         """rpn_scores (B,N), rpn_reg (B,N,C), xyz (B,N,3) -> rois (B,M,7), roi_scores_raw (B,M)."""
         cfg = self.cfg
         B, N = rpn_scores.shape
+        ext = iou3d_utils.iou3d_cuda
+        if (self.fused and cfg[self.mode].RPN_DISTANCE_BASED_PROPOSE and N <= 16384 and hasattr(ext, "rpn_proposals")
+                and cfg.RPN.NMS_TYPE in ("normal", "rotate")):
+            # one extension call: decode, sort, band selection, NMS and assembly as HIP kernels
+            M = cfg[self.mode].RPN_POST_NMS_TOP_N
+            rois = torch.empty((B, M, 7), dtype=torch.float32, device=xyz.device)
+            roi_scores = torch.empty((B, M), dtype=torch.float32, device=xyz.device)
+            ext.rpn_proposals(xyz.contiguous(), rpn_scores.contiguous(), rpn_reg.contiguous(), self._anchor,
+                              cfg.RPN.LOC_SCOPE, cfg.RPN.LOC_BIN_SIZE, cfg.RPN.NUM_HEAD_BIN, cfg.RPN.LOC_XZ_FINE,
+                              cfg[self.mode].RPN_PRE_NMS_TOP_N, M, cfg[self.mode].RPN_NMS_THRESH,
+                              cfg.RPN.NMS_TYPE == "rotate", rois, roi_scores)
+            return rois, roi_scores
         proposals = decode_bbox_target(xyz.view(-1, 3), rpn_reg.view(-1, rpn_reg.shape[-1]),
                                        anchor_size=self.MEAN_SIZE, loc_scope=cfg.RPN.LOC_SCOPE,
                                        loc_bin_size=cfg.RPN.LOC_BIN_SIZE, num_head_bin=cfg.RPN.NUM_HEAD_BIN,

@@ -165,6 +165,17 @@ int prcnn_nms_normal(int boxes_num, const float *boxes, long long *keep_host, fl
 int prcnn_nms_device(int nprob, int n_max, const int *counts, const float *boxes, float thresh,
                      int rotated, int max_keep, int *keep, int *num_keep, void *stream);
 
+/* Whole RPN proposal layer (lib/rpn/proposal_layer.py:15-119 + decode_bbox_target of
+ * lib/utils/bbox_transform.py:24-121, distance-based variant) in five launches and no host sync:
+ * decode -> per-scene score sort -> (0,40] / (40,80] m band selection (top 70 % / 30 % of pre_nms_top_n,
+ * with the "no far points" fallback) -> batched NMS -> rois (b, post_nms_top_n, 7) + raw scores, zero padded.
+ * xyz (b,n,3), scores (b,n), reg (b,n,channels); anchor_size_host = 3 floats in HOST memory (h,w,l).
+ * n <= 16384 per scene. */
+int prcnn_rpn_proposals(int b, int n, int channels, float loc_scope, float loc_bin_size, int num_head_bin,
+                        int xz_fine, const float *anchor_size_host, int pre_nms_top_n, int post_nms_top_n,
+                        float nms_thresh, int rotated_nms, const float *xyz, const float *scores,
+                        const float *reg, float *rois, float *roi_scores, void *stream);
+
 /* ---- roipool3d_cuda ------------------------------------------------------------------ */
 
 /* forward  src/roipool3d.cpp:48-79 -> roipool3dLauncher src/roipool3d_kernel.cu:209-237.

@@ -145,6 +145,34 @@ def test_postprocess_batched_equals_per_scene_reference_order():
         assert (det["boxes"][k, n:] == 0).all()
 
 
+def test_fused_proposal_layer_equals_batched_torch_path():
+    """csrc/proposal.hip (decode + LDS sort + band selection + NMS + assembly) vs the batched torch-op
+    formulation of net/proposal_layer.py (itself checked against the reference's per-scene loop in
+    tests/test_host_logic.py), incl. a scene with no far points and one with fewer near points than
+    the quota."""
+    C = pkg("config")
+    cfg = C.default_eval_cfg()
+    PL = pkg("net.proposal_layer").ProposalLayer(cfg, mode="TEST").to(DEV)
+    rng = np.random.default_rng(44)
+    B, N = 4, 16384
+    xyz = rng.uniform([-40, -1, 0.5], [40, 3, 70], (B, N, 3)).astype(np.float32)
+    xyz[1, :, 2] = rng.uniform(0.5, 39.5, N)                 # scene 1: nothing beyond 40 m
+    xyz[2, 3000:, 2] = rng.uniform(41, 70, N - 3000)         # scene 2: only 3000 near points
+    xyz[3, :, 2] = rng.uniform(100, 120, N)                  # scene 3: neither band -> no proposals
+    xyz[3, :50, 2] = rng.uniform(1, 30, 50)                  #          ... except 50 near points
+    xyz = torch.from_numpy(xyz).to(DEV)
+    reg = torch.from_numpy((rng.standard_normal((B, N, 76)) * 0.5).astype(np.float32)).to(DEV)
+    scores = torch.from_numpy(rng.standard_normal((B, N)).astype(np.float32)).to(DEV)
+    PL.fused = True
+    rois_f, sc_f = PL(scores, reg, xyz)
+    PL.fused = False
+    rois_t, sc_t = PL(scores, reg, xyz)
+    torch.cuda.synchronize()
+    assert torch.equal(sc_f, sc_t)
+    assert torch.equal(rois_f, rois_t), float((rois_f - rois_t).abs().max())
+    assert (rois_t[3].abs().sum(-1) > 0).sum() <= 50 and (rois_t[0].abs().sum(-1) > 0).sum() == 100
+
+
 def test_reference_python_runs_on_dropin_modules():
     """Drop-in check at the extension boundary: a caller written against the REFERENCE module names
     and calling conventions (zero-filled idx, transposes, in-place subtract, cat -- the sequence of
