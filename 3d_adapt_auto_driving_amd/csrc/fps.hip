@@ -103,6 +103,7 @@ __global__ __launch_bounds__(64 * WAVES) void fps_reg_kernel(
     float *__restrict__ mind = temp + (long)b * n;
     int *__restrict__ sel = idx + (long)b * m;
     const int t = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);   // latency-bound dependent chain: win issue arbitration (see fps_pruned_kernel)
 
     float px[PPT], py[PPT], pz[PPT], pt[PPT];
     uint32_t pk[PPT];
@@ -257,6 +258,10 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(
     float *__restrict__ mind = temp + (long)b * n;
     int *__restrict__ sel = idx + (long)b * m;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    // FPS is a chain of ~m dependent iterations: when it shares a CU with another stream's waves (the
+    // pipelined runner overlaps it with the feature pass) every lost issue slot is pure latency, so its
+    // waves take the highest arbitration priority; they are few (<= 16 per CU) and mostly wait on barriers.
+    __builtin_amdgcn_s_setprio(3);
 
     float px[PPT], py[PPT], pz[PPT], pt[PPT];
     uint32_t pk[PPT];

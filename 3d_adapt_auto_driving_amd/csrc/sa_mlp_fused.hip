@@ -9,7 +9,8 @@
 // writes and re-reads it once per layer (3.35 GB per layer at the RCNN SA1 size, B = 8).
 //
 // Mapping to CDNA4 (gfx950, wave64):
-//   * tile = one query centre = 64 grouped rows; workgroup = 4 waves, persistent over tiles.
+//   * tile = one query centre = 64 grouped rows; workgroup = 4 waves serving 8 tiles drawn from a ticket
+//     counter, then retiring.
 //   * layers 2 and 3 are dense f32 contractions -> v_mfma_f32_32x32x2_f32 (exact f32: a k-ordered
 //     fma chain).  Wave w owns output columns [32w, 32w+32) (+128 for the second half when C3 = 256)
 //     for BOTH 32-row halves of the tile, so its B operand (the weight columns) never changes:
@@ -35,6 +36,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int SA_C = 128;          // C1 = C2 (layer-1 and layer-2 widths)
 constexpr int SA_NS = 64;          // grouped rows per tile (= nsample)
 constexpr int SA_LD = SA_C + 4;    // LDS row stride in floats
+// A workgroup retires after this many tiles (its 128-256 KiB of weight registers are re-read from L2 by
+// the next one): short-lived workgroups keep CUs turning over, so kernels of other streams (the
+// geometry pass of the next batch) are not locked out for the whole launch as they would be by a
+// persistent grid.
+constexpr int SA_TILES_PER_WG = 8;
 
 template <int C3>
 __global__ __launch_bounds__(256) void sa_mlp_fused_kernel(
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256) void sa_mlp_fused_kernel(
     // (e.g. its CU was busy with another stream's kernel) simply takes fewer tiles instead of
     // stretching the whole launch.
     unsigned int *slot = reinterpret_cast<unsigned int *>(lds + 2 * SA_NS * SA_LD);
-    for (;;) {
+    for (int served = 0; served < SA_TILES_PER_WG; ++served) {
         if (tid == 0) *slot = atomicAdd(ticket, 1u);
         __syncthreads();
         const long t = *slot;
@@ -198,8 +204,7 @@ extern "C" int prcnn_sa_mlp_fused(int b, int n, int m, int nsample, int c1, int 
     if (tiles == 0) return PRCNN_OK;
     PRCNN_REQUIRE(new_xyz && xyz && P && wxyz && idx && w2t && b2 && w3t && b3 && out, "sa_mlp_fused: null pointer");
     PRCNN_REQUIRE((((uintptr_t)P | (uintptr_t)wxyz) & 15) == 0, "sa_mlp_fused: 16-byte alignment required");
-    const long cap = 256L * (c3 == 128 ? 2 : 1);      // persistent: workgroups resident per CU x 256 CUs
-    const int grid = (int)(tiles < cap ? tiles : cap);
+    const int grid = (int)((tiles + SA_TILES_PER_WG - 1) / SA_TILES_PER_WG);
     unsigned int *ticket = next_ticket((hipStream_t)stream);
     if (!ticket) { set_error("sa_mlp_fused: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
     if (c3 == 128)

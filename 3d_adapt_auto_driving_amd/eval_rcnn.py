@@ -111,7 +111,10 @@ class PipelinedRunner:
         self.model, self.cfg = model, cfg
         self.engine = FastPointRCNN(model, cfg)
         self.device = torch.device(device)
-        self.side = torch.cuda.Stream(self.device)
+        # high priority: the geometry kernels are few, short-lived workgroups on a latency-bound chain;
+        # when CU slots free up they should be placed before the feature pass's next workgroups
+        prio = int(os.environ.get("PRCNN_SIDE_PRIORITY", "-1"))
+        self.side = torch.cuda.Stream(self.device, priority=prio)
         self._geo = None          # (tensor identity, geometry dict, ready event)
 
     def _launch_geometry(self, pts):
