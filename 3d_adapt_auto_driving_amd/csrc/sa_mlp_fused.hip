@@ -42,8 +42,10 @@ constexpr int SA_LD = SA_C + 4;    // LDS row stride in floats
 // persistent grid.
 constexpr int SA_TILES_PER_WG = 8;
 
+// C3 = 128: two workgroups per CU (2 waves per SIMD, <= 256 registers each) so that one workgroup's tile
+// builder / epilogues run beside the other's MFMAs; C3 = 256 needs ~440 registers -> one per CU.
 template <int C3>
-__global__ __launch_bounds__(256) void sa_mlp_fused_kernel(
+__global__ __launch_bounds__(256, (C3 == 128 ? 2 : 1)) void sa_mlp_fused_kernel(
     int n, int m, long tiles, const float *__restrict__ new_xyz, const float *__restrict__ xyz,
     const float4 *__restrict__ P /* (b,n,128) */, const float4 *__restrict__ wxyz /* (3,128) */,
     const int *__restrict__ idx /* (b,m,64) */, const float *__restrict__ w2t /* (128,128) k-major */,
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void sa_mlp_fused_kernel(
     unsigned int *__restrict__ ticket)
 {
     constexpr int NCT = C3 / 128;                 // column tiles of layer 3 per wave
-    __shared__ float lds[2 * SA_NS * SA_LD + 4];  // A1 tile and Y1 tile, 64 x 132 each (+ the tile ticket)
+    __shared__ float lds[2 * SA_NS * SA_LD + 4];  // A1 tile and Y1 tile, 64 x 132 each (+ two tile tickets)
     float *A1 = lds, *Y1 = lds + SA_NS * SA_LD;
 
     const int tid = threadIdx.x;
@@ -78,22 +80,28 @@ __global__ __launch_bounds__(256) void sa_mlp_fused_kernel(
 
     // Tiles are handed out through a ticket counter, not a static stride: a workgroup that starts late
     // (e.g. its CU was busy with another stream's kernel) simply takes fewer tiles instead of
-    // stretching the whole launch.
-    unsigned int *slot = reinterpret_cast<unsigned int *>(lds + 2 * SA_NS * SA_LD);
-    for (int served = 0; served < SA_TILES_PER_WG; ++served) {
-        if (tid == 0) *slot = atomicAdd(ticket, 1u);
-        __syncthreads();
-        const long t = *slot;
-        if (t >= tiles) break;
+    // stretching the whole launch.  The ticket and the neighbour indices of the NEXT tile are fetched one
+    // tile ahead, so the builder's only exposed latency is the gather of the P rows themselves.
+    unsigned int *slot = reinterpret_cast<unsigned int *>(lds + 2 * SA_NS * SA_LD);   // [2] double-buffered
+    if (tid == 0) slot[0] = atomicAdd(ticket, 1u);
+    __syncthreads();
+    long t = slot[0];
+    int kidx[8];
+    if (t < tiles) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kidx[i] = idx[t * SA_NS + (tid >> 5) + 8 * i];
+    }
+    for (int served = 0; served < SA_TILES_PER_WG && t < tiles; ++served) {
         const long b = t / m;
         const float *ct3 = new_xyz + t * 3;
         const float cx = ct3[0], cy = ct3[1], cz = ct3[2];
-        const int *ix = idx + t * SA_NS;
+        // draw the next ticket now; it is read after this tile's first barrier
+        if (tid == 0) slot[(served + 1) & 1] = atomicAdd(ticket, 1u);
         // ---- layer 1 into LDS
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = (tid >> 5) + 8 * i;
-            const int k = ix[row];
+            const int k = kidx[i];
             const float *pt = xyz + (b * n + k) * 3;
             const float dx = pt[0] - cx, dy = pt[1] - cy, dz = pt[2] - cz;
             const float4 base = P[(b * n + k) * (SA_C / 4) + chunk];
@@ -105,6 +113,11 @@ __global__ __launch_bounds__(256) void sa_mlp_fused_kernel(
             *reinterpret_cast<float4 *>(A1 + row * SA_LD + 4 * chunk) = v;
         }
         __syncthreads();
+        const long t_next = slot[(served + 1) & 1];
+        if (t_next < tiles && served + 1 < SA_TILES_PER_WG) {     // neighbour indices of the next tile, in flight during the MFMAs
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kidx[i] = idx[t_next * SA_NS + (tid >> 5) + 8 * i];
+        }
 
         // ---- layer 2: Y1[64][32w..32w+32) = relu(A1 @ W2 + b2)
         {
@@ -165,9 +178,10 @@ __global__ __launch_bounds__(256) void sa_mlp_fused_kernel(
             }
         }
         // the next tile's builder overwrites A1 only; every wave has left layer 2 (barrier above), and
-        // Y1 is rewritten only after the next tile's barriers, which all waves reach after layer 3;
-        // the ticket slot is rewritten by thread 0 after it passed the layer-2 barrier, i.e. after
-        // every thread has read it
+        // Y1 is rewritten only after the next tile's barriers, which all waves reach after layer 3.
+        // Ticket slots alternate: slot[(served+1)&1] is written before this tile's first barrier and read
+        // after it; it is rewritten two tiles later, after two more barriers.
+        t = t_next;
     }
 }
 
