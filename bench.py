@@ -16,6 +16,8 @@ The JSON line also carries
   roofline      fused ball_query+group (BASELINE.json configs[1]: B=8, N=16384, M=4096, C=128,
                 ns=32, r=0.2) timed with HIP events on the launch stream; achieved = algorithmic
                 bytes (SURVEY.md section 8d formula) / average duration of the launch pair
+  roofline_mfma the dominant kernel of the step, the hand-written f32 MFMA kernel of the RCNN SA MLP
+                (prcnn_sa_mlp_fused), against the dense f32 MFMA peak
   cpu_baseline  the same model code on the host cores with the C oracle as operator backend
                 (kind "port": the reference has no CPU path for this pipeline), rank 0, N=1 only.
 """
@@ -88,6 +90,45 @@ def roofline_query_and_group(dev, reps=20):
             "kernel": "prcnn_query_and_group = grid_link_kernel + grid_query_kernel + group_cat_lds_kernel",
             "launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": nbytes,
             "shape": {"B": B, "N": N, "M": M, "C": C, "nsample": NS, "radius": R}}
+
+
+def roofline_sa_mlp_fused(dev, reps=10):
+    """The dominant kernel of the step: the hand-written MFMA kernel that runs a whole RCNN
+    set-abstraction MLP (gather -> 3 layers -> max over nsample) at the RCNN SA1 size of one batch
+    (B = 8 scenes x 100 RoIs = 800 clouds of 512 points, 128 centres x 64 samples, 128-128-128).
+    Algorithmic flops = the two dense layers (2 * rows * (128*128 + 128*128)); the gathered layer 1 and
+    the pooling ride along.  Peak = dense f32 MFMA (MI355X_MICROARCH.md: 157.3 TFLOP/s)."""
+    pkg = importlib.import_module(PKG)
+    if pkg.DROPIN_DIR not in sys.path:
+        sys.path.insert(0, pkg.DROPIN_DIR)
+    import pointnet2_cuda
+    b, n, m, ns, c3 = 100 * BATCH, 512, 128, 64, 128
+    g = torch.Generator(device=dev).manual_seed(0)
+    xyz = torch.randn((b, n, 3), device=dev, generator=g)
+    new_xyz = xyz[:, :m].contiguous()
+    P = torch.randn((b, n, 128), device=dev, generator=g)
+    wx = torch.randn((3, 128), device=dev, generator=g)
+    idx = torch.randint(0, n, (b, m, ns), dtype=torch.int32, device=dev, generator=g)
+    w2 = torch.randn((128, 128), device=dev, generator=g) / 11
+    w3 = torch.randn((128, c3), device=dev, generator=g) / 11
+    b2 = torch.randn(128, device=dev, generator=g)
+    b3 = torch.randn(c3, device=dev, generator=g)
+    out = torch.empty((b, m, c3), device=dev)
+    run = lambda: pointnet2_cuda.sa_mlp_fused_wrapper(new_xyz, xyz, P, wx, idx, w2, b2, w3, b3, out, 0)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, e in evs:
+        a.record(); run(); e.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(e) for a, e in evs]))
+    flops = 2.0 * b * m * ns * (128 * 128 + 128 * c3)
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 1), "peak": 157.3, "unit": "TFLOP/s",
+            "frac": round(achieved / 157.3, 4), "traffic": None, "kernel": "sa_mlp_fused_kernel<128> (prcnn_sa_mlp_fused)",
+            "launch_ms": round(ms, 4), "algorithmic_flops_per_launch": flops,
+            "shape": {"clouds": b, "points": n, "centres": m, "nsample": ns, "mlp": [128, 128, c3]}}
 
 
 def cpu_baseline(cfg, scenes=2):
@@ -198,6 +239,7 @@ def main():
     if rank == 0:
         if not args.no_roofline:
             line["roofline"] = roofline_query_and_group(dev)
+            line["roofline_mfma"] = roofline_sa_mlp_fused(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
