@@ -102,40 +102,58 @@ def infer_batch(model, cfg, pts_input, engine=None, geo=None):
 
 
 class PipelinedRunner:
-    """Two-stream software pipeline over batches: the xyz-only GEOMETRY of batch i+1 (FPS, ball
-    query, three-NN: latency-bound, FPS keeps only B CUs busy) runs on a side HIP stream while the
-    FEATURE pass of batch i (GEMMs, grouping, RoI pooling, NMS) fills the rest of the chip on the
-    main stream.  Call ``step(cur, nxt)`` once per batch; ``nxt`` may be None at the end."""
+    """Software pipeline over batches on HIP streams: the xyz-only GEOMETRY of upcoming batches (FPS,
+    ball query, three-NN: a latency-bound chain that keeps only B CUs busy) runs on side streams while
+    the FEATURE pass of the current batch (MFMA kernels, GEMMs, pooling, NMS) fills the rest of the chip
+    on the main stream.  ``depth`` batches of geometry are kept in flight (one side stream each).
+    Call ``step(cur, upcoming)`` once per batch; ``upcoming`` = the next batch, or a list of the next
+    ``depth`` batches, or None at the end."""
 
-    def __init__(self, model, cfg, device):
+    def __init__(self, model, cfg, device, depth=None):
         self.model, self.cfg = model, cfg
         self.engine = FastPointRCNN(model, cfg)
         self.device = torch.device(device)
+        self.depth = int(os.environ.get("PRCNN_GEO_DEPTH", "1")) if depth is None else depth
         # high priority: the geometry kernels are few, short-lived workgroups on a latency-bound chain;
         # when CU slots free up they should be placed before the feature pass's next workgroups
         prio = int(os.environ.get("PRCNN_SIDE_PRIORITY", "-1"))
-        self.side = torch.cuda.Stream(self.device, priority=prio)
-        self._geo = None          # (tensor identity, geometry dict, ready event)
+        self.sides = [torch.cuda.Stream(self.device, priority=prio) for _ in range(max(1, self.depth))]
+        self._next_side = 0
+        self._pending = []        # [(batch tensor, geometry dict, ready event)] in launch order
+
+    @property
+    def side(self):
+        return self.sides[0]
 
     def _launch_geometry(self, pts):
         main = torch.cuda.current_stream(self.device)
-        self.side.wait_stream(main)                   # pts (and the allocator's frees) are ordered before us
-        with torch.cuda.stream(self.side):
+        side = self.sides[self._next_side % len(self.sides)]
+        self._next_side += 1
+        side.wait_stream(main)                        # pts (and the allocator's frees) are ordered before us
+        with torch.cuda.stream(side):
             geo = self.engine.geometry(pts)
             ev = torch.cuda.Event()
-            ev.record(self.side)
+            ev.record(side)
         for t in _tensors(geo):                       # consumed on the main stream: tell the caching allocator
             t.record_stream(main)
-        self._geo = (pts, geo, ev)
+        self._pending.append((pts, geo, ev))
+
+    def _take(self, pts):
+        for i, (p, geo, ev) in enumerate(self._pending):
+            if p is pts:
+                del self._pending[i]
+                return geo, ev
+        self._launch_geometry(pts)
+        return self._take(pts)
 
     @torch.no_grad()
-    def step(self, cur, nxt=None):
-        if self._geo is None or self._geo[0] is not cur:
-            self._launch_geometry(cur)
-        _, geo, ev = self._geo
-        self._geo = None
-        if nxt is not None:
-            self._launch_geometry(nxt)                # enqueue first: it overlaps the feature pass below
+    def step(self, cur, upcoming=None):
+        geo, ev = self._take(cur)
+        if upcoming is not None:
+            todo = list(upcoming) if isinstance(upcoming, (list, tuple)) else [upcoming]
+            for nxt in todo[:max(1, self.depth)]:
+                if nxt is not None and all(p is not nxt for p, _, _ in self._pending):
+                    self._launch_geometry(nxt)        # enqueue first: it overlaps the feature pass below
         torch.cuda.current_stream(self.device).wait_event(ev)
         return infer_batch(self.model, self.cfg, cur, engine=self.engine, geo=geo)
 

@@ -178,7 +178,7 @@ def main():
     M = cfg.TEST.RPN_POST_NMS_TOP_N
 
     # distinct synthetic scenes per rank and per step slot, resident in HBM before timing
-    n_slots = 2
+    n_slots = 4
     batches = [torch.from_numpy(synth.scenes(BATCH, NPOINTS, seed0=(rank * n_slots + s) * BATCH)).to(dev)
                for s in range(n_slots)]
     total = args.warmup + args.steps
@@ -191,7 +191,7 @@ def main():
     def step(i):
         # features of batch i on the main stream || geometry (FPS / ball query / three-NN) of batch
         # i+1 on the side stream; every timed step does one geometry and one feature pass
-        det = runner.step(batches[i % n_slots], batches[(i + 1) % n_slots])
+        det = runner.step(batches[i % n_slots], [batches[(i + d) % n_slots] for d in range(1, runner.depth + 1)])
         host_boxes[i].copy_(det["boxes"], non_blocking=True)
         host_scores[i].copy_(det["scores"], non_blocking=True)
         host_num[i].copy_(det["num"], non_blocking=True)
