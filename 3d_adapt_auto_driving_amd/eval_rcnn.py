@@ -246,11 +246,10 @@ def all_gather_detections(table, counts, device):
 
 
 @torch.no_grad()
-def eval_synthetic(model, cfg, device, scene_ids, batch_size=8, npoints=16384, output_dir=None, raw_points=None):
-    """Evaluate the given synthetic scene ids on this rank.  Returns (table, counts) as
-    pack_detections.  If raw_points is set, scenes are generated with that many points and
-    reduced to ``npoints`` by the reference's near/far sampler (cross-domain config)."""
-    calib = synth.SyntheticCalib()
+def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=None):
+    """Evaluate ``scene_ids`` of a scene source (kitti_io.KittiSource / SyntheticSource) on this rank:
+    the counterpart of the batch loop of eval_one_epoch_joint (eval_rcnn.py:493-649) incl. the KITTI
+    result files.  Returns (table, counts) as pack_detections."""
     if output_dir:
         os.makedirs(output_dir, exist_ok=True)
     M = cfg.TEST.RPN_POST_NMS_TOP_N
@@ -260,27 +259,33 @@ def eval_synthetic(model, cfg, device, scene_ids, batch_size=8, npoints=16384, o
     def load(s):
         ids = scene_ids[s:s + batch_size]
         if not ids:
-            return None, ids
-        if raw_points:
-            clouds = [synth.subsample_rpn(synth.dense_scene(i, raw_points), npoints,
-                                          rng=np.random.default_rng(1024 + i)) for i in ids]
-        else:
-            clouds = [synth.scene(i, npoints) for i in ids]
-        return torch.from_numpy(np.stack(clouds, 0)).to(device, non_blocking=True), ids
+            return None, ids, None
+        loaded = [source.load(i) for i in ids]
+        pts = torch.from_numpy(np.stack([l[0] for l in loaded], 0)).to(device, non_blocking=True)
+        return pts, ids, [(l[1], l[2]) for l in loaded]
 
-    nxt, nxt_ids = load(0)
+    nxt, nxt_ids, nxt_meta = load(0)
     for s in range(0, len(scene_ids), batch_size):
-        pts, ids = nxt, nxt_ids
-        nxt, nxt_ids = load(s + batch_size)
+        pts, ids, meta = nxt, nxt_ids, nxt_meta
+        nxt, nxt_ids, nxt_meta = load(s + batch_size)
         det = runner.step(pts, nxt) if runner is not None else infer_batch(model, cfg, pts)
         boxes, scores, num = det["boxes"].cpu(), det["scores"].cpu(), det["num"].cpu()   # one D2H per batch
         batches.append((boxes, scores, num))
         if output_dir:
             for k, sid in enumerate(ids):
                 n = int(num[k])
-                save_kitti_format(sid, calib, boxes[k, :n].numpy(), output_dir, scores[k, :n].numpy(),
-                                  calib.image_shape, cfg.CLASSES)
+                calib, shape = meta[k]
+                save_kitti_format(sid, calib, boxes[k, :n].numpy(), output_dir, scores[k, :n].numpy(), shape, cfg.CLASSES)
     return pack_detections(scene_ids, batches, M)
+
+
+def eval_synthetic(model, cfg, device, scene_ids, batch_size=8, npoints=16384, output_dir=None, raw_points=None):
+    """eval_scenes over the synthetic generator (seed = scene id); ``raw_points`` generates denser raw
+    clouds that are reduced with the reference's near/far sampler (cross-domain config)."""
+    from . import kitti_io
+    assert npoints == cfg.RPN.NUM_POINTS, "npoints must equal cfg.RPN.NUM_POINTS"
+    src = kitti_io.SyntheticSource(cfg, 0, raw_points=raw_points)
+    return eval_scenes(model, cfg, device, src, scene_ids, batch_size, output_dir)
 
 
 def main(argv=None):
@@ -289,7 +294,9 @@ def main(argv=None):
     ap.add_argument("--eval_mode", type=str, default="rcnn")
     ap.add_argument("--ckpt", type=str, default=None, help="reference .pth checkpoint (random init if omitted)")
     ap.add_argument("--batch_size", type=int, default=8)
-    ap.add_argument("--scenes", type=int, default=16)
+    ap.add_argument("--scenes", type=int, default=16, help="number of synthetic scenes (ignored with --data_root)")
+    ap.add_argument("--data_root", type=str, default=None, help="directory holding KITTI/object/... and KITTI/ImageSets")
+    ap.add_argument("--split", type=str, default=None, help="ImageSets split (default cfg.TEST.SPLIT)")
     ap.add_argument("--output_dir", type=str, default=None)
     ap.add_argument("--set", dest="set_cfgs", default=None, nargs=argparse.REMAINDER)
     args = ap.parse_args(argv)
@@ -298,7 +305,6 @@ def main(argv=None):
     config_mod.apply_eval_defaults(cfg, args.eval_mode)
     if args.cfg_file:
         config_mod.cfg_from_file(cfg, args.cfg_file)
-        config_mod.apply_eval_defaults(cfg, args.eval_mode) if False else None
     if args.set_cfgs:
         config_mod.cfg_from_list(cfg, args.set_cfgs)
     if not torch.cuda.is_available():
@@ -313,8 +319,13 @@ def main(argv=None):
     if args.ckpt:
         load_checkpoint(model, args.ckpt)
     out = os.path.join(args.output_dir, "final_result", "data") if args.output_dir else None
-    table, counts = eval_synthetic(model, cfg, device, shard_scene_ids(args.scenes, rank, world),
-                                   args.batch_size, cfg.RPN.NUM_POINTS, out)
+    from . import kitti_io
+    if args.data_root:
+        source = kitti_io.KittiSource(args.data_root, cfg, args.split or cfg.TEST.SPLIT)
+    else:
+        source = kitti_io.SyntheticSource(cfg, args.scenes)
+    my_ids = [source.ids[i] for i in shard_scene_ids(len(source.ids), rank, world)]
+    table, counts = eval_scenes(model, cfg, device, source, my_ids, args.batch_size, out)
     table, counts = all_gather_detections(table, counts, device)
     if rank == 0:
         print("scenes=%d detections=%d" % (table.shape[0], int(counts.sum())))

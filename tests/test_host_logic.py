@@ -231,6 +231,45 @@ def test_subsample_rpn_semantics():
     assert len(np.unique(small, axis=0)) <= 5000
 
 
+def test_kitti_input_stage(tmp_path):
+    """Fake KITTI tree -> KittiSource: calib parsing, lidar->rect->image projection, validity filter
+    (image bounds, depth >= 0, PC_AREA_SCOPE) and the 16384-point sampler, against plain numpy."""
+    K = pkg("kitti_io")
+    cfg = pkg("config").default_eval_cfg()
+    root = tmp_path
+    d = root / "KITTI" / "object" / "training"
+    for sub in ("velodyne", "calib"):
+        (d / sub).mkdir(parents=True)
+    (root / "KITTI" / "ImageSets").mkdir(parents=True)
+    (root / "KITTI" / "ImageSets" / "val.txt").write_text("000003\n000007\n")
+    rng = np.random.default_rng(0)
+    P2 = np.array([[707.05, 0, 604.08, 45.75], [0, 707.05, 180.5, -0.34], [0, 0, 1, 0.005]], np.float32)
+    R0 = np.eye(3, dtype=np.float32)
+    Tr = np.array([[0, -1, 0, 0.0], [0, 0, -1, -0.08], [1, 0, 0, -0.27]], np.float32)     # velodyne -> camera axes
+    for sid in (3, 7):
+        lidar = np.concatenate([rng.uniform([0, -40, -2.5], [75, 40, 1.0], (30000, 3)), rng.uniform(0, 1, (30000, 1))], 1)
+        lidar.astype(np.float32).tofile(d / "velodyne" / ("%06d.bin" % sid))
+        fmt = lambda name, m: name + ": " + " ".join("%.6e" % v for v in m.reshape(-1)) + "\n"
+        (d / "calib" / ("%06d.txt" % sid)).write_text(fmt("P0", P2) + fmt("P1", P2) + fmt("P2", P2) + fmt("P3", P2) +
+                                                      fmt("R0_rect", R0) + fmt("Tr_velo_to_cam", Tr) + fmt("Tr_imu_to_velo", Tr))
+    src = K.KittiSource(str(root), cfg, "val")
+    assert src.ids == [3, 7]
+    pts, calib, shape = src.load(7)
+    assert pts.shape == (16384, 3) and pts.dtype == np.float32 and shape == (375, 1242, 3)
+    np.testing.assert_allclose(calib.P2, P2, rtol=1e-6)
+    # every sampled point passes the reference's validity test
+    img, depth = calib.rect_to_img(pts)
+    assert (img[:, 0] >= 0).all() and (img[:, 0] < 1242).all() and (img[:, 1] >= 0).all() and (img[:, 1] < 375).all()
+    assert (depth >= 0).all() and (pts[:, 2] >= 0).all() and (pts[:, 2] <= 70.4).all() and (np.abs(pts[:, 0]) <= 40).all()
+    # and they are a subset of the transformed raw cloud
+    lidar = np.fromfile(d / "velodyne" / "000007.bin", dtype=np.float32).reshape(-1, 4)
+    rect = np.hstack([lidar[:, :3], np.ones((len(lidar), 1), np.float32)]) @ (Tr.T @ R0.T)
+    assert len(np.unique(pts, axis=0)) <= len(rect)
+    raw = {tuple(np.round(r, 4)) for r in rect}
+    assert all(tuple(np.round(p, 4)) in raw for p in pts[:200])
+    assert (pts[:, 2] >= 40).sum() <= 4000                       # at most npoints_faraway far points
+
+
 def test_config_merge_and_set():
     C = pkg("config")
     cfg = C.default_eval_cfg()
