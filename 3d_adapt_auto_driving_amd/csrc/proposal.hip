@@ -222,6 +222,130 @@ __global__ __launch_bounds__(128) void assemble_rois_kernel(
     scores[(long)b * post + j] = q[7];
 }
 
+// ---- final stage (eval_rcnn.py:506-530, 611-629): decode the RCNN regression against its RoI, score
+// threshold, order by raw score, BEV boxes for the rotated NMS.  One workgroup (128 lanes) per scene, one
+// lane per RoI; the <= 128 scores are sorted with a bitonic network in LDS.
+struct RcnnCfg {
+    float loc_scope, loc_bin_size, loc_y_scope, loc_y_bin_size, score_thresh;
+    int nbin, nbin_y, num_head_bin, y_by_bin, channels;
+    float anchor[3];
+};
+
+__global__ __launch_bounds__(128) void rcnn_decode_select_kernel(
+    int m, RcnnCfg c, const float *__restrict__ rois, const float *__restrict__ reg, const float *__restrict__ cls,
+    float *__restrict__ pred /* (b,m,7) decoded, RoI order */, float *__restrict__ sorted /* (b,m,8) box7+raw, score order */,
+    float *__restrict__ bev /* (b,m,5) */, int *__restrict__ counts)
+{
+    __shared__ unsigned long long keys[128];
+    __shared__ int nsel;
+    const int b = blockIdx.x, t = threadIdx.x;
+    float box[7] = {0, 0, 0, 0, 0, 0, 0};
+    float raw = 0.f;
+    bool selected = false;
+    if (t == 0) nsel = 0;
+    __syncthreads();
+    if (t < m) {
+        const float *r = reg + ((long)b * m + t) * c.channels;
+        const float *roi = rois + ((long)b * m + t) * 7;
+        const int nb = c.nbin;
+        const int xb = argmax_row(r, nb), zb = argmax_row(r + nb, nb);
+        const float half_bin = c.loc_bin_size / 2;
+        float px = __fsub_rn(__fadd_rn(__fmul_rn((float)xb, c.loc_bin_size), half_bin), c.loc_scope);
+        float pz = __fsub_rn(__fadd_rn(__fmul_rn((float)zb, c.loc_bin_size), half_bin), c.loc_scope);
+        px = __fadd_rn(px, __fmul_rn(r[2 * nb + xb], c.loc_bin_size));      // get_xz_fine = True
+        pz = __fadd_rn(pz, __fmul_rn(r[3 * nb + zb], c.loc_bin_size));
+        int cur = 4 * nb;
+        float py;
+        if (c.y_by_bin) {
+            const int yb = argmax_row(r + cur, c.nbin_y);
+            const float y_res = __fmul_rn(r[cur + c.nbin_y + yb], c.loc_y_bin_size);
+            py = __fadd_rn(__fsub_rn(__fadd_rn(__fmul_rn((float)yb, c.loc_y_bin_size), c.loc_y_bin_size / 2), c.loc_y_scope), y_res);
+            py = __fadd_rn(py, roi[1]);
+            cur += 2 * c.nbin_y;
+        } else {
+            py = __fadd_rn(roi[1], r[cur]);
+            cur += 1;
+        }
+        const int rb = argmax_row(r + cur, c.num_head_bin);
+        const float res_norm = r[cur + c.num_head_bin + rb];
+        // get_ry_fine = True: bins over +-pi/4 around the RoI heading
+        const float apc = (float)((M_PI / 2) / c.num_head_bin);
+        const float apc_half = (float)(((M_PI / 2) / c.num_head_bin) / 2.0);
+        float ry = __fsub_rn(__fadd_rn(__fadd_rn(__fmul_rn((float)rb, apc), apc_half), __fmul_rn(res_norm, apc_half)), (float)(M_PI / 4));
+        cur += 2 * c.num_head_bin;
+        const float h = __fadd_rn(__fmul_rn(r[cur], c.anchor[0]), c.anchor[0]);
+        const float w = __fadd_rn(__fmul_rn(r[cur + 1], c.anchor[1]), c.anchor[1]);
+        const float l = __fadd_rn(__fmul_rn(r[cur + 2], c.anchor[2]), c.anchor[2]);
+        // rotate (px, pz) by -roi_ry back to the scene frame (rotate_pc_along_y_torch with -ry), add the RoI centre
+        const float roi_ry = roi[6];
+        const float cosa = cosf(-roi_ry), sina = sinf(-roi_ry);
+        const float nx = __fadd_rn(__fmul_rn(px, cosa), __fmul_rn(pz, -sina));
+        const float nz = __fadd_rn(__fmul_rn(px, sina), __fmul_rn(pz, cosa));
+        box[0] = __fadd_rn(nx, roi[0]); box[1] = py; box[2] = __fadd_rn(nz, roi[2]);
+        box[3] = h; box[4] = w; box[5] = l; box[6] = __fadd_rn(ry, roi_ry);
+        raw = cls[(long)b * m + t];
+        const float norm = 1.0f / (1.0f + expf(-raw));
+        selected = norm > c.score_thresh;
+        float *o = pred + ((long)b * m + t) * 7;
+#pragma unroll
+        for (int e = 0; e < 7; ++e) o[e] = box[e];
+    }
+    // selected RoIs first, by descending raw score; unselected after them
+    keys[t] = (t < m && selected) ? sort_key(raw, (unsigned)t) : (~0ull - 127 + t);
+    if (t < m && selected) atomicAdd(&nsel, 1);
+    __syncthreads();
+    for (int k = 2; k <= 128; k <<= 1)
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            const int partner = t ^ j;
+            if (partner > t) {
+                const bool up = ((t & k) == 0);
+                const unsigned long long a = keys[t], d = keys[partner];
+                if ((a > d) == up) { keys[t] = d; keys[partner] = a; }
+            }
+            __syncthreads();
+        }
+    // slot t of the sorted table takes the box lane `src` decoded (its global write is ordered by the barriers above)
+    if (t < m) {
+        const unsigned long long kk = keys[t];
+        const bool sel_slot = t < nsel;
+        const int src = sel_slot ? (int)(kk & 0xffffffffu) : -1;
+        float *o = sorted + ((long)b * m + t) * 8;
+        float *v = bev + ((long)b * m + t) * 5;
+        if (src >= 0) {
+            const float *q = pred + ((long)b * m + src) * 7;
+            o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = q[3]; o[4] = q[4]; o[5] = q[5]; o[6] = q[6];
+            o[7] = cls[(long)b * m + src];
+            const float hl = q[5] / 2, hw = q[4] / 2;
+            v[0] = q[0] - hl; v[1] = q[2] - hw; v[2] = q[0] + hl; v[3] = q[2] + hw; v[4] = q[6];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 5; ++e) v[e] = 0.f;
+        }
+    }
+    if (t == 0) counts[b] = nsel;
+}
+
+__global__ __launch_bounds__(128) void rcnn_final_gather_kernel(int m, const float *__restrict__ sorted,
+                                                               const int *__restrict__ keep, const int *__restrict__ num,
+                                                               float *__restrict__ boxes, float *__restrict__ scores)
+{
+    const int b = blockIdx.x, j = threadIdx.x;
+    if (j >= m) return;
+    float *o = boxes + ((long)b * m + j) * 7;
+    if (j < num[b]) {
+        const float *q = sorted + ((long)b * m + keep[(long)b * m + j]) * 8;
+#pragma unroll
+        for (int e = 0; e < 7; ++e) o[e] = q[e];
+        scores[(long)b * m + j] = q[7];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 7; ++e) o[e] = 0.f;
+        scores[(long)b * m + j] = 0.f;
+    }
+}
+
 static size_t aligned(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace prcnn
@@ -291,4 +415,47 @@ extern "C" int prcnn_rpn_proposals(int b, int n, int channels, float loc_scope, 
     hipLaunchKernelGGL(assemble_rois_kernel, dim3(b), dim3(128), 0, st, rows, post_near, post_near, post_far, payload, keep,
                        num, rois, roi_scores);
     return check_launch("rpn_proposals");
+}
+
+
+// rois (b,m,7), rcnn_reg (b,m,channels), rcnn_cls (b,m) raw -> pred_boxes3d (b,m,7) decoded in RoI order,
+// boxes (b,m,7) / scores (b,m) = survivors of score threshold + rotated NMS in descending score order, zero
+// padded, num (b) i32.  get_xz_fine = get_ry_fine = True (eval_rcnn.py:516-523).  m <= 128.
+extern "C" int prcnn_rcnn_postprocess(int b, int m, int channels, float loc_scope, float loc_bin_size,
+                                      int num_head_bin, int y_by_bin, float loc_y_scope, float loc_y_bin_size,
+                                      const float *anchor_size_host, float score_thresh, float nms_thresh,
+                                      const float *rois, const float *rcnn_reg, const float *rcnn_cls,
+                                      float *pred_boxes3d, float *boxes, float *scores, int *num, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && m > 0 && m <= 128 && channels > 0 && num_head_bin > 0, "rcnn_postprocess: bad sizes (m <= 128)");
+    PRCNN_REQUIRE(anchor_size_host, "rcnn_postprocess: anchor size missing");
+    RcnnCfg c;
+    c.loc_scope = loc_scope; c.loc_bin_size = loc_bin_size; c.loc_y_scope = loc_y_scope; c.loc_y_bin_size = loc_y_bin_size;
+    c.score_thresh = score_thresh;
+    c.nbin = (int)(loc_scope / loc_bin_size) * 2;
+    c.nbin_y = (int)(loc_y_scope / loc_y_bin_size) * 2;
+    c.num_head_bin = num_head_bin; c.y_by_bin = y_by_bin ? 1 : 0; c.channels = channels;
+    for (int i = 0; i < 3; ++i) c.anchor[i] = anchor_size_host[i];
+    const int expect = c.nbin * 4 + (c.y_by_bin ? 2 * c.nbin_y : 1) + 2 * num_head_bin + 3;
+    PRCNN_REQUIRE(channels == expect, "rcnn_postprocess: %d regression channels, layout needs %d", channels, expect);
+    if (b == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(rois && rcnn_reg && rcnn_cls && pred_boxes3d && boxes && scores && num, "rcnn_postprocess: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t o_sorted = 0;
+    const size_t o_bev = o_sorted + aligned((size_t)b * m * 8 * 4);
+    const size_t o_cnt = o_bev + aligned((size_t)b * m * 5 * 4);
+    const size_t o_keep = o_cnt + aligned((size_t)b * 4);
+    const size_t need = o_keep + aligned((size_t)b * m * 4);
+    char *base = scratch_for(st, need, 3);
+    if (!base) { set_error("rcnn_postprocess: cannot allocate %zu bytes of scratch", need); return PRCNN_ELAUNCH; }
+    float *sorted = (float *)(base + o_sorted), *bev = (float *)(base + o_bev);
+    int *counts = (int *)(base + o_cnt), *keep = (int *)(base + o_keep);
+    hipLaunchKernelGGL(rcnn_decode_select_kernel, dim3(b), dim3(128), 0, st, m, c, rois, rcnn_reg, rcnn_cls, pred_boxes3d,
+                       sorted, bev, counts);
+    int rc = check_launch("rcnn_postprocess");
+    if (rc != PRCNN_OK) return rc;
+    rc = nms_device(b, m, counts, bev, nms_thresh, 1, m, keep, num, st);
+    if (rc != PRCNN_OK) return rc;
+    hipLaunchKernelGGL(rcnn_final_gather_kernel, dim3(b), dim3(128), 0, st, m, sorted, keep, num, boxes, scores);
+    return check_launch("rcnn_postprocess");
 }

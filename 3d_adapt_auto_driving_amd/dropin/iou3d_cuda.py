@@ -80,3 +80,20 @@ def rpn_proposals(xyz, scores, reg, anchor_size, loc_scope, loc_bin_size, num_he
               int(post_nms_top_n), float(nms_thresh), int(bool(rotated)), xyz.data_ptr(), scores.data_ptr(),
               reg.data_ptr(), rois.data_ptr(), roi_scores.data_ptr(), _lib.current_stream(xyz))
     return rois, roi_scores
+
+
+def rcnn_postprocess(rois, rcnn_reg, rcnn_cls, anchor_size, loc_scope, loc_bin_size, num_head_bin, y_by_bin,
+                     loc_y_scope, loc_y_bin_size, score_thresh, nms_thresh, pred_boxes3d, boxes, scores, num):
+    """Fused final stage (csrc/proposal.hip): decode against the RoIs, score threshold, rotated NMS.
+    rois (B,M,7), rcnn_reg (B,M,C), rcnn_cls (B,M) -> pred_boxes3d (B,M,7), boxes (B,M,7), scores (B,M), num (B) i32."""
+    import ctypes
+    _chk(rois, rcnn_reg, rcnn_cls, pred_boxes3d, boxes, scores)
+    if num.dtype != torch.int32 or not num.is_cuda:
+        raise RuntimeError("iou3d_cuda: num must be a CUDA int32 tensor")
+    anchor = (ctypes.c_float * 3)(*[float(v) for v in anchor_size])
+    _lib.call("prcnn_rcnn_postprocess", rois.size(0), rois.size(1), rcnn_reg.size(2), float(loc_scope),
+              float(loc_bin_size), int(num_head_bin), int(bool(y_by_bin)), float(loc_y_scope), float(loc_y_bin_size),
+              ctypes.cast(anchor, ctypes.c_void_p), float(score_thresh), float(nms_thresh), rois.data_ptr(),
+              rcnn_reg.data_ptr(), rcnn_cls.data_ptr(), pred_boxes3d.data_ptr(), boxes.data_ptr(), scores.data_ptr(),
+              num.data_ptr(), _lib.current_stream(rois))
+    return boxes, scores, num

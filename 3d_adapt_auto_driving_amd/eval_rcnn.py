@@ -46,6 +46,13 @@ def load_checkpoint(model, filename, logger=None):
 
 
 _ANCHORS = {}
+FUSED_POSTPROCESS = True     # final stage through the fused HIP entry when the extension offers it
+
+
+def _anchor_host(cfg):
+    """CLS_MEAN_SIZE rounded to f32, as python floats (h, w, l)."""
+    import numpy as np
+    return [float(v) for v in np.asarray(cfg.CLS_MEAN_SIZE[0], dtype=np.float32)]
 
 
 def _anchor_on(cfg, device):
@@ -65,14 +72,27 @@ def postprocess(cfg, ret_dict, batch_size):
     M = rois.shape[1]
     rcnn_cls = ret_dict["rcnn_cls"].view(batch_size, M, -1)
     rcnn_reg = ret_dict["rcnn_reg"].view(batch_size, M, -1)
+    if rcnn_cls.shape[2] != 1:
+        raise NotImplementedError("multi-class RCNN head")
+    raw = rcnn_cls[:, :, 0]
+    ext = iou3d_utils.iou3d_cuda
+    if FUSED_POSTPROCESS and M <= 128 and hasattr(ext, "rcnn_postprocess"):
+        # one extension call (three launches): decode, threshold, score sort, rotated NMS, assembly
+        dev = rois.device
+        pred = torch.empty((batch_size, M, 7), dtype=torch.float32, device=dev)
+        boxes = torch.empty((batch_size, M, 7), dtype=torch.float32, device=dev)
+        scores = torch.empty((batch_size, M), dtype=torch.float32, device=dev)
+        num = torch.empty((batch_size,), dtype=torch.int32, device=dev)
+        raw = raw.contiguous()
+        ext.rcnn_postprocess(rois.contiguous(), rcnn_reg.contiguous(), raw, _anchor_host(cfg), R.LOC_SCOPE,
+                             R.LOC_BIN_SIZE, R.NUM_HEAD_BIN, R.LOC_Y_BY_BIN, R.LOC_Y_SCOPE, R.LOC_Y_BIN_SIZE,
+                             R.SCORE_THRESH, R.NMS_THRESH, pred, boxes, scores, num)
+        return {"boxes": boxes, "scores": scores, "num": num, "pred_boxes3d": pred, "raw_scores": raw}
     anchor = _anchor_on(cfg, rois.device)
     pred = decode_bbox_target(rois.view(-1, 7), rcnn_reg.view(-1, rcnn_reg.shape[-1]), anchor_size=anchor,
                               loc_scope=R.LOC_SCOPE, loc_bin_size=R.LOC_BIN_SIZE, num_head_bin=R.NUM_HEAD_BIN,
                               get_xz_fine=True, get_y_by_bin=R.LOC_Y_BY_BIN, loc_y_scope=R.LOC_Y_SCOPE,
                               loc_y_bin_size=R.LOC_Y_BIN_SIZE, get_ry_fine=True).view(batch_size, M, 7)
-    if rcnn_cls.shape[2] != 1:
-        raise NotImplementedError("multi-class RCNN head")
-    raw = rcnn_cls[:, :, 0]
     selected = torch.sigmoid(raw) > R.SCORE_THRESH
     key = torch.where(selected, raw, torch.full_like(raw, float("-inf")))
     _, order = torch.sort(key, dim=1, descending=True)          # selected boxes first, by raw score

@@ -176,6 +176,17 @@ int prcnn_rpn_proposals(int b, int n, int channels, float loc_scope, float loc_b
                         float nms_thresh, int rotated_nms, const float *xyz, const float *scores,
                         const float *reg, float *rois, float *roi_scores, void *stream);
 
+/* Final detection stage of eval_rcnn.py (tools/eval_rcnn.py:506-530 decode with get_xz_fine = get_ry_fine
+ * = True, :611-629 score threshold + rotated NMS) in three launches and no host sync.
+ * rois (b,m,7), rcnn_reg (b,m,channels), rcnn_cls (b,m) raw scores, m <= 128.
+ * pred_boxes3d (b,m,7) = every RoI's decoded box (RoI order); boxes (b,m,7) / scores (b,m) raw = survivors of
+ * sigmoid(score) > score_thresh and rotated NMS, descending score, zero padded; num (b) i32. */
+int prcnn_rcnn_postprocess(int b, int m, int channels, float loc_scope, float loc_bin_size, int num_head_bin,
+                           int y_by_bin, float loc_y_scope, float loc_y_bin_size, const float *anchor_size_host,
+                           float score_thresh, float nms_thresh, const float *rois, const float *rcnn_reg,
+                           const float *rcnn_cls, float *pred_boxes3d, float *boxes, float *scores, int *num,
+                           void *stream);
+
 /* ---- roipool3d_cuda ------------------------------------------------------------------ */
 
 /* forward  src/roipool3d.cpp:48-79 -> roipool3dLauncher src/roipool3d_kernel.cu:209-237.

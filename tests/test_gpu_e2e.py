@@ -173,6 +173,47 @@ def test_fused_proposal_layer_equals_batched_torch_path():
     assert (rois_t[3].abs().sum(-1) > 0).sum() <= 50 and (rois_t[0].abs().sum(-1) > 0).sum() == 100
 
 
+def test_fused_final_stage_equals_batched_torch_path():
+    """prcnn_rcnn_postprocess (decode against the RoIs + threshold + LDS score sort + rotated NMS + assembly)
+    vs the batched torch-op formulation of eval_rcnn.postprocess (itself checked against the reference's
+    per-scene order above).  Boxes within 1e-5 (the torch path rotates through a batched matmul whose
+    contraction is the library's), selection identical; both LOC_Y_BY_BIN settings; a scene with nothing
+    above the threshold."""
+    C, E = pkg("config"), pkg("eval_rcnn")
+    rng = np.random.default_rng(46)
+    for y_by_bin in (False, True):
+        cfg = C.default_eval_cfg()
+        cfg.RCNN.LOC_Y_BY_BIN = y_by_bin
+        B, M = 5, 100
+        ch = 4 * 6 + (2 * 4 if y_by_bin else 1) + 2 * 9 + 3
+        rois = np.zeros((B, M, 7), np.float32)
+        centres = rng.uniform([-20, 1, 5], [20, 2, 60], (B, 12, 3))
+        for b in range(B):
+            which = rng.integers(0, 12, M)
+            rois[b, :, :3] = centres[b, which] + rng.normal(0, 0.4, (M, 3))
+            rois[b, :, 3:6] = [1.5, 1.6, 3.9] + rng.normal(0, 0.05, (M, 3))
+            rois[b, :, 6] = rng.uniform(-np.pi, np.pi, M)
+        reg = (rng.standard_normal((B, M, ch)) * 0.3).astype(np.float32)
+        cls = (rng.standard_normal((B, M, 1)) * 2).astype(np.float32)
+        cls[3] = -5.0                                                 # scene 3: nothing passes the threshold
+        cls[4, 10:] = -5.0                                            # scene 4: ten candidates
+        ret = {"rois": torch.from_numpy(rois).to(DEV), "rcnn_reg": torch.from_numpy(reg).to(DEV).view(B * M, ch),
+               "rcnn_cls": torch.from_numpy(cls).to(DEV).view(B * M, 1)}
+        E.FUSED_POSTPROCESS = True
+        f = E.postprocess(cfg, ret, B)
+        E.FUSED_POSTPROCESS = False
+        try:
+            t = E.postprocess(cfg, ret, B)
+        finally:
+            E.FUSED_POSTPROCESS = True
+        torch.cuda.synchronize()
+        assert (f["pred_boxes3d"] - t["pred_boxes3d"]).abs().max().item() < 1e-5
+        assert torch.equal(f["num"], t["num"]), (f["num"], t["num"])
+        assert int(f["num"][3]) == 0 and 0 < int(f["num"][4]) <= 10 and int(f["num"][0]) > 5
+        assert torch.equal(f["scores"], t["scores"])
+        assert (f["boxes"] - t["boxes"]).abs().max().item() < 1e-5
+
+
 def test_eval_scenes_writes_kitti_result_files(tmp_path):
     """Harness loop on the GPU (pipelined runner) over a few synthetic scenes: one KITTI result file per
     scene (empty file when nothing survives), 16 fields per line, and the packed table agrees with them."""
