@@ -10,6 +10,7 @@
 // scalar loads, so the inner loop is pure VALU (8 distance ops + the 3-deep insertion).
 #include "common.hpp"
 #include <math.h>
+#include <stdlib.h>
 
 namespace prcnn {
 
@@ -90,6 +91,10 @@ __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
 
 }  // namespace prcnn
 
+namespace prcnn {
+int three_nn_grid(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                  hipStream_t st, int *used);   // three_nn_grid.hip
+}
 using namespace prcnn;
 
 extern "C" int prcnn_three_nn(int b, int n, int m, const float *unknown, const float *known,
@@ -99,6 +104,12 @@ extern "C" int prcnn_three_nn(int b, int n, int m, const float *unknown, const f
     PRCNN_REQUIRE(b <= 65535, "three_nn: batch > 65535");
     if (b == 0 || n == 0) return PRCNN_OK;
     PRCNN_REQUIRE(unknown && dist2 && idx && (known || m == 0), "three_nn: null pointer");
+    static const bool brute_only = getenv("PRCNN_THREE_NN_BRUTE") != nullptr;
+    if (!brute_only) {
+        int used = 0;
+        const int rc = three_nn_grid(b, n, m, unknown, known, dist2, idx, (hipStream_t)stream, &used);
+        if (rc != PRCNN_OK || used) return rc;
+    }
     dim3 grid(ceil_div(n, 256), b);
     hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, m, unknown, known, dist2, idx);
     return check_launch("three_nn");

@@ -1,0 +1,205 @@
+// three_nn_grid.hip -- exact three_nn (K7 semantics, interpolate_gpu.cu:9-52) through a dense uniform
+// grid over the KNOWN points, for large (n, m).
+//
+// The brute-force kernel (interp.hip) tests all n*m pairs: 67 M distance tests per scene at
+// (16384, 4096), pure VALU that fights the MFMA kernels for issue slots when the two streams co-run.
+// Here the m known points of a scene are binned on (x, z) into a G x G grid over their own bounding
+// rectangle (G ~ sqrt(m/2), out-of-extent coordinates clamp to the border cells) and counting-sorted
+// by cell, all inside ONE workgroup per scene (histogram + scan in LDS).  Cells of one grid row are
+// contiguous in the sorted array, so a row segment of the search square is a single index range.
+//
+// A query walks Chebyshev rings R = 0, 1, 2, ... around its own (clamped) cell.  After ring R every
+// unvisited point lies in a cell at Chebyshev distance >= R+1, hence at distance >= R*s in the (x, z)
+// plane (clamping only moves cells closer than the points really are).  The walk stops as soon as the
+// third-best squared distance is below (R*s)^2 (minus a 1e-5 relative margin for the rounding of the
+// cell assignment), or when the square covers the grid.
+//
+// The reference result -- the three smallest f32 squared distances, lowest index first among equals --
+// does not depend on visiting order once insertion compares (d, index) lexicographically: the strict
+// '<' scan in index order keeps exactly the lowest indices among equal distances.  The distance is the
+// same f32 expression, so dist2 and idx are bit-identical to the brute-force scan.
+#include "common.hpp"
+#include <math.h>
+
+namespace prcnn {
+
+constexpr int TG_MAX = 96;                 // grid edge limit: 9216 cells, 36 KB of LDS histogram
+constexpr int TB = 1024;                   // build workgroup
+
+struct GridParams {                         // one per scene, written by the build kernel
+    double x0, z0, inv_s;
+    float s;
+    int g;
+};
+
+__device__ __forceinline__ int grid_coord(float v, double o, double inv_s, int g)
+{
+    double c = floor(((double)v - o) * inv_s);
+    c = fmin(fmax(c, 0.0), (double)(g - 1));   // NaN -> 0
+    return (int)c;
+}
+
+__global__ __launch_bounds__(TB) void tnn_build_kernel(int m, int g, const float *__restrict__ known,
+                                                       GridParams *__restrict__ params, int *__restrict__ cell_start,
+                                                       float4 *__restrict__ sorted)
+{
+    extern __shared__ int hist[];          // g*g counters, then cursors
+    __shared__ float red[4][TB / 64];
+    __shared__ int wsum[TB / 64];
+    __shared__ GridParams gp;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const float *__restrict__ kn = known + (long)b * m * 3;
+    const int cells = g * g;
+
+    // bounding rectangle of the finite points
+    float xmin = INFINITY, xmax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+    for (int k = t; k < m; k += TB) {
+        const float x = kn[3 * k], z = kn[3 * k + 2];
+        if (isfinite(x)) { xmin = fminf(xmin, x); xmax = fmaxf(xmax, x); }
+        if (isfinite(z)) { zmin = fminf(zmin, z); zmax = fmaxf(zmax, z); }
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        xmin = fminf(xmin, __shfl_xor(xmin, off)); xmax = fmaxf(xmax, __shfl_xor(xmax, off));
+        zmin = fminf(zmin, __shfl_xor(zmin, off)); zmax = fmaxf(zmax, __shfl_xor(zmax, off));
+    }
+    if (lane == 0) { red[0][w] = xmin; red[1][w] = xmax; red[2][w] = zmin; red[3][w] = zmax; }
+    for (int c = t; c < cells; c += TB) hist[c] = 0;
+    __syncthreads();
+    if (t == 0) {
+        for (int i = 1; i < TB / 64; ++i) {
+            xmin = fminf(xmin, red[0][i]); xmax = fmaxf(xmax, red[1][i]);
+            zmin = fminf(zmin, red[2][i]); zmax = fmaxf(zmax, red[3][i]);
+        }
+        if (!(xmin <= xmax)) { xmin = 0.f; xmax = 0.f; }
+        if (!(zmin <= zmax)) { zmin = 0.f; zmax = 0.f; }
+        double ext = fmax((double)xmax - (double)xmin, (double)zmax - (double)zmin);
+        if (!(ext > 1e-6)) ext = 1e-6;
+        const double s = ext / g * (1.0 + 1e-9);
+        gp.x0 = xmin; gp.z0 = zmin; gp.inv_s = 1.0 / s; gp.s = (float)s; gp.g = g;
+        params[b] = gp;
+    }
+    __syncthreads();
+    const double x0 = gp.x0, z0 = gp.z0, inv_s = gp.inv_s;
+
+    for (int k = t; k < m; k += TB) {
+        const int c = grid_coord(kn[3 * k + 2], z0, inv_s, g) * g + grid_coord(kn[3 * k], x0, inv_s, g);
+        atomicAdd(&hist[c], 1);
+    }
+    __syncthreads();
+
+    // exclusive scan of the cell counts: each thread owns a contiguous chunk
+    const int per = (cells + TB - 1) / TB;
+    const int lo = t * per, hi = min(lo + per, cells);
+    int sum = 0;
+    for (int c = lo; c < hi; ++c) sum += hist[c];
+    int incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int i = 0; i < w; ++i) base += wsum[i];
+    int *__restrict__ cs = cell_start + (long)b * (TG_MAX * TG_MAX + 1);
+    for (int c = lo; c < hi; ++c) {
+        const int cnt = hist[c];
+        cs[c] = base;
+        hist[c] = base;                    // becomes the scatter cursor
+        base += cnt;
+    }
+    if (t == TB - 1) cs[cells] = m;
+    __syncthreads();
+
+    float4 *__restrict__ so = sorted + (long)b * m;
+    for (int k = t; k < m; k += TB) {
+        const float x = kn[3 * k], y = kn[3 * k + 1], z = kn[3 * k + 2];
+        const int c = grid_coord(z, z0, inv_s, g) * g + grid_coord(x, x0, inv_s, g);
+        const int pos = atomicAdd(&hist[c], 1);
+        so[pos] = make_float4(x, y, z, __int_as_float(k));
+    }
+}
+
+__global__ __launch_bounds__(256) void tnn_query_kernel(int n, int m, const float *__restrict__ unknown,
+                                                        const GridParams *__restrict__ params,
+                                                        const int *__restrict__ cell_start,
+                                                        const float4 *__restrict__ sorted, float *__restrict__ dist2,
+                                                        int *__restrict__ idx)
+{
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const GridParams gp = params[b];
+    const int g = gp.g;
+    const float *u = unknown + ((long)b * n + p) * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    const int ix = grid_coord(ux, gp.x0, gp.inv_s, g), iz = grid_coord(uz, gp.z0, gp.inv_s, g);
+    const int *__restrict__ cs = cell_start + (long)b * (TG_MAX * TG_MAX + 1);
+    const float4 *__restrict__ so = sorted + (long)b * m;
+
+    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+    int i1 = 0, i2 = 0, i3 = 0;
+    auto scan = [&](int first, int last) {
+        for (int q = first; q < last; ++q) {
+            const float4 pt = so[q];
+            const int k = __float_as_int(pt.w);
+            const float d = sqdist3(ux, uy, uz, pt.x, pt.y, pt.z);
+            if (d < b1 || (d == b1 && k < i1)) {
+                b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k;
+            } else if (d < b2 || (d == b2 && k < i2)) {
+                b3 = b2; i3 = i2; b2 = d; i2 = k;
+            } else if (d < b3 || (d == b3 && k < i3)) {
+                b3 = d; i3 = k;
+            }
+        }
+    };
+    const int reach = max(max(ix, g - 1 - ix), max(iz, g - 1 - iz));   // ring that covers the whole grid
+    for (int r = 0; r <= reach; ++r) {
+        const int xlo = max(ix - r, 0), xhi = min(ix + r, g - 1);
+        for (int dz = -r; dz <= r; ++dz) {
+            const int z = iz + dz;
+            if (z < 0 || z >= g) continue;
+            const int row = z * g;
+            if (dz == -r || dz == r) {
+                scan(cs[row + xlo], cs[row + xhi + 1]);                // a full row segment: one range
+            } else {
+                if (ix - r >= 0) scan(cs[row + ix - r], cs[row + ix - r + 1]);
+                if (ix + r < g) scan(cs[row + ix + r], cs[row + ix + r + 1]);
+            }
+        }
+        const float bound = (float)r * gp.s;
+        if (b3 < bound * bound * 0.99999f) break;
+    }
+    float *od = dist2 + ((long)b * n + p) * 3;
+    int *oi = idx + ((long)b * n + p) * 3;
+    od[0] = b1; od[1] = b2; od[2] = b3;
+    oi[0] = i1; oi[1] = i2; oi[2] = i3;
+}
+
+static size_t align_up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// Returns PRCNN_OK or an error; *used = 0 when the grid path declines (caller runs the brute-force scan).
+int three_nn_grid(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                  hipStream_t st, int *used)
+{
+    *used = 0;
+    if (m < 1024 || n < 1024 || m > (1 << 20)) return PRCNN_OK;
+    int g = (int)ceil(sqrt((double)m / 2.0));
+    if (g > TG_MAX) g = TG_MAX;
+    const size_t o_par = 0;
+    const size_t o_cs = align_up256((size_t)b * sizeof(GridParams));
+    const size_t o_sorted = o_cs + align_up256((size_t)b * (TG_MAX * TG_MAX + 1) * sizeof(int));
+    const size_t need = o_sorted + align_up256((size_t)b * m * sizeof(float4));
+    char *base = scratch_for(st, need, 4);
+    if (!base) { set_error("three_nn: cannot allocate %zu bytes of grid scratch", need); return PRCNN_ELAUNCH; }
+    GridParams *params = (GridParams *)(base + o_par);
+    int *cs = (int *)(base + o_cs);
+    float4 *sorted = (float4 *)(base + o_sorted);
+    hipLaunchKernelGGL(tnn_build_kernel, dim3(b), dim3(TB), (size_t)g * g * sizeof(int), st, m, g, known, params, cs, sorted);
+    hipLaunchKernelGGL(tnn_query_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, st, n, m, unknown, params, cs,
+                       sorted, dist2, idx);
+    *used = 1;
+    return check_launch("three_nn(grid)");
+}
+
+}  // namespace prcnn

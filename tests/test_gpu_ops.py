@@ -173,6 +173,35 @@ def test_three_nn_and_interpolate(ext, oracle, n, m):
     assert np.array_equal(out.cpu().numpy(), oracle.three_interpolate(feats, widx, w))  # same rounding sequence
 
 
+def test_three_nn_grid_edge_cases(ext, oracle):
+    """Grid path of three_nn (m >= 1024): queries far outside the known points' extent, all known points
+    identical (degenerate extent), heavy duplication (distance ties -> lowest indices), a tight cluster plus
+    far outliers (many rings), unrelated clouds.  dist2 and idx bit-exact vs the brute-force oracle."""
+    rng = np.random.default_rng(77)
+    n, m = 2048, 1024
+    cases = []
+    kn = rng.uniform([-40, -1, 0], [40, 3, 70], (m, 3)).astype(np.float32)
+    un = rng.uniform([-200, -5, -150], [200, 5, 300], (n, 3)).astype(np.float32)        # mostly outside
+    cases.append((un, kn))
+    cases.append((rng.standard_normal((n, 3)).astype(np.float32), np.tile(np.float32([[1.5, 0.5, 2.5]]), (m, 1))))
+    base = rng.uniform(-10, 10, (16, 3)).astype(np.float32)
+    cases.append((rng.uniform(-12, 12, (n, 3)).astype(np.float32), base[rng.integers(0, 16, m)]))   # 16 distinct sites
+    kn = (rng.standard_normal((m, 3)) * 0.05).astype(np.float32)
+    kn[:5] = [[500, 0, 500], [-500, 0, 500], [500, 0, -500], [-500, 0, -500], [0, 0, 800]]
+    un = np.concatenate([(rng.standard_normal((n // 2, 3)) * 0.05), rng.uniform(-600, 600, (n // 2, 3))]).astype(np.float32)
+    cases.append((un, kn))
+    un = scenes(1, n, seed0=5)[0]
+    cases.append((un, un[rng.permutation(n)[:m]].copy()))                                 # known = subset of unknown
+    for un, kn in cases:
+        unknown, known = np.stack([un, un[::-1].copy()]), np.stack([kn, kn[::-1].copy()])
+        d2 = torch.empty((2, n, 3), device=DEV)
+        idx = torch.empty((2, n, 3), dtype=torch.int32, device=DEV)
+        ext.pointnet2.three_nn_wrapper(2, n, m, T(unknown), T(known), d2, idx)
+        wd2, widx = oracle.three_nn(unknown, known)
+        assert np.array_equal(idx.cpu().numpy(), widx)
+        assert np.array_equal(d2.cpu().numpy(), wd2)
+
+
 def test_roipool3d(ext, oracle):
     rng = np.random.default_rng(8)
     xyz = scenes(2, 16384, seed0=31)
