@@ -12,6 +12,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libprcnn_hip.so")
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
+_D = C.c_double
+_L = C.c_longlong
 
 # name -> argument types (return type is always int except where noted)
 SIGNATURES = {
@@ -44,6 +46,10 @@ SIGNATURES = {
     "prcnn_rcnn_postprocess": [_I, _I, _I, _F, _F, _I, _I, _F, _F, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_roipool3d": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "prcnn_rotate_iou_eval": [_I, _I, _P, _P, _P, _I, _P],
+    "prcnn_rotate_iou_eval_segmented": [_I, _L, _P, _P, _P, _P, _P, _P, _I, _P],
+    "prcnn_kitti_image_stats": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _D, _D, _I, _I, _P, _P, _P, _P],
+    "prcnn_kitti_collect_scores": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _D, _P, _P],
+    "prcnn_kitti_accumulate_pr": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _D, _P, _I, _I, _P],
 }
 
 _lib = None

@@ -33,8 +33,10 @@ struct Scratch {
     char *ptr;
     size_t bytes;
 };
-static Scratch g_scratch[16];
+constexpr int SCRATCH_ENTRIES = 256;     // (stream, slot) pairs; a pipelined host uses ~5 slots on 2-8 streams
+static Scratch g_scratch[SCRATCH_ENTRIES];
 static int g_scratch_n = 0;
+static unsigned g_scratch_rr = 0;
 static std::mutex g_scratch_mu;
 
 char *scratch_for(hipStream_t st, size_t bytes, int slot)
@@ -44,9 +46,11 @@ char *scratch_for(hipStream_t st, size_t bytes, int slot)
     for (int i = 0; i < g_scratch_n; ++i)
         if (g_scratch[i].stream == st && g_scratch[i].slot == slot) s = &g_scratch[i];
     if (!s) {
-        if (g_scratch_n == 16) {   // recycle the first slot (its stream must be idle by contract)
-            s = &g_scratch[0];
-            (void)hipStreamSynchronize(s->stream);
+        if (g_scratch_n == SCRATCH_ENTRIES) {
+            // table full: take over the entry of the least recently created pair after draining the device
+            // (its buffer may still be read by work queued on its old stream)
+            (void)hipDeviceSynchronize();
+            s = &g_scratch[g_scratch_rr++ % SCRATCH_ENTRIES];
             s->stream = st; s->slot = slot;
         } else {
             s = &g_scratch[g_scratch_n++];

@@ -109,16 +109,12 @@ __device__ double rinter(const float *r1, const float *r2)
     return area;
 }
 
-__global__ __launch_bounds__(256) void rotate_iou_kernel(int n, int k, const float *__restrict__ boxes,
-                                                         const float *__restrict__ qboxes,
-                                                         float *__restrict__ iou, int criterion)
+// one (box, query) pair: rbox1 = query box, rbox2 = box (kernel :287-291)
+__device__ __forceinline__ float pair_value(const float *__restrict__ box, const float *__restrict__ query, int criterion)
 {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long)n * k) return;
-    const int i = (int)(e / k), j = (int)(e - (long)i * k);
-    float r1[5], r2[5];  // rbox1 = query box, rbox2 = box (kernel :287-291)
+    float r1[5], r2[5];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) { r1[q] = qboxes[5 * j + q]; r2[q] = boxes[5 * i + q]; }
+    for (int q = 0; q < 5; ++q) { r1[q] = query[q]; r2[q] = box[q]; }
     const float area1 = __fmul_rn(r1[2], r1[3]), area2 = __fmul_rn(r2[2], r2[3]);
     const double ai = rinter(r1, r2);
     double v;
@@ -126,7 +122,41 @@ __global__ __launch_bounds__(256) void rotate_iou_kernel(int n, int k, const flo
     else if (criterion == 0) v = ai / (double)area1;
     else if (criterion == 1) v = ai / (double)area2;
     else v = ai;
-    iou[e] = (float)v;
+    return (float)v;
+}
+
+__global__ __launch_bounds__(256) void rotate_iou_kernel(int n, int k, const float *__restrict__ boxes,
+                                                         const float *__restrict__ qboxes,
+                                                         float *__restrict__ iou, int criterion)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)n * k) return;
+    const int i = (int)(e / k), j = (int)(e - (long)i * k);
+    iou[e] = pair_value(boxes + 5 * i, qboxes + 5 * j, criterion);
+}
+
+// Block-diagonal form: segment s pairs boxes[box_off[s]..box_off[s+1]) with qboxes[q_off[s]..q_off[s+1]) only
+// and writes its row-major (n_s, k_s) block at out_off[s].  The reference evaluates ~50 dense "parts" of ~75
+// images each to amortise launches (eval2.py:352-424) and discards the cross-image pairs; here every image
+// is a segment and the whole split is one launch that computes only the pairs the evaluator reads.
+__global__ __launch_bounds__(256) void rotate_iou_segmented_kernel(int nseg, const long long *__restrict__ out_off,
+                                                                   const int *__restrict__ box_off,
+                                                                   const int *__restrict__ q_off,
+                                                                   const float *__restrict__ boxes,
+                                                                   const float *__restrict__ qboxes,
+                                                                   float *__restrict__ iou, int criterion)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= out_off[nseg]) return;
+    int lo = 0, hi = nseg;                       // last s with out_off[s] <= e
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (out_off[mid] <= e) lo = mid; else hi = mid;
+    }
+    const int k = q_off[lo + 1] - q_off[lo];
+    const long long local = e - out_off[lo];
+    const int i = (int)(local / k), j = (int)(local - (long long)i * k);
+    iou[e] = pair_value(boxes + 5 * (long)(box_off[lo] + i), qboxes + 5 * (long)(q_off[lo] + j), criterion);
 }
 
 }  // namespace prcnn
@@ -143,4 +173,20 @@ extern "C" int prcnn_rotate_iou_eval(int n, int k, const float *boxes, const flo
     hipLaunchKernelGGL(rotate_iou_kernel, dim3(ceil_div((long)n * k, 256)), dim3(256), 0, (hipStream_t)stream,
                        n, k, boxes, query_boxes, iou, criterion);
     return check_launch("rotate_iou_eval");
+}
+
+/* Block-diagonal rotated IoU: nseg segments; box_off / q_off (nseg+1) i32 prefix offsets into boxes / query_boxes,
+ * out_off (nseg+1) i64 prefix of n_s*k_s; all three in DEVICE memory; total = out_off[nseg] given by the host. */
+extern "C" int prcnn_rotate_iou_eval_segmented(int nseg, long long total, const long long *out_off, const int *box_off,
+                                               const int *q_off, const float *boxes, const float *query_boxes,
+                                               float *iou, int criterion, void *stream)
+{
+    PRCNN_REQUIRE(nseg >= 0 && total >= 0, "rotate_iou_eval_segmented: bad sizes");
+    PRCNN_REQUIRE(criterion >= -1 && criterion <= 2, "rotate_iou_eval_segmented: criterion %d not in -1..2", criterion);
+    if (nseg == 0 || total == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(out_off && box_off && q_off && boxes && query_boxes && iou, "rotate_iou_eval_segmented: null pointer");
+    PRCNN_REQUIRE(total <= 0x7fffffffLL * 256, "rotate_iou_eval_segmented: %lld pairs exceed the launch grid", total);
+    hipLaunchKernelGGL(rotate_iou_segmented_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, nseg, out_off, box_off, q_off, boxes, query_boxes, iou, criterion);
+    return check_launch("rotate_iou_eval_segmented");
 }

@@ -189,13 +189,11 @@ def _tensors(obj):
             yield from _tensors(v)
 
 
-def save_kitti_format(sample_id, calib, bbox3d, kitti_output_dir, scores, img_shape, cls_name="Car"):
+def kitti_result_lines(calib, bbox3d, scores, img_shape, cls_name="Car"):
     """16-field KITTI label lines, %.4f (eval_rcnn.py:76-101): boxes projecting wider/taller than
     80 % of the image are dropped; alpha = -sign(beta)*pi/2 + beta + ry with beta = atan2(z, x)."""
-    path = os.path.join(kitti_output_dir, "%06d.txt" % sample_id)
     if bbox3d.shape[0] == 0:
-        open(path, "w").close()
-        return 0
+        return []
     corners3d = kitti_utils.boxes3d_to_corners3d(bbox3d)
     img_boxes, _ = calib.corners3d_to_img_boxes(corners3d)
     img_boxes[:, 0] = np.clip(img_boxes[:, 0], 0, img_shape[1] - 1)
@@ -204,20 +202,50 @@ def save_kitti_format(sample_id, calib, bbox3d, kitti_output_dir, scores, img_sh
     img_boxes[:, 3] = np.clip(img_boxes[:, 3], 0, img_shape[0] - 1)
     bw, bh = img_boxes[:, 2] - img_boxes[:, 0], img_boxes[:, 3] - img_boxes[:, 1]
     ok = np.logical_and(bw < img_shape[1] * 0.8, bh < img_shape[0] * 0.8)
-    written = 0
-    with open(path, "w") as f:
-        for k in range(bbox3d.shape[0]):
-            if not ok[k]:
-                continue
-            x, z, ry = bbox3d[k, 0], bbox3d[k, 2], bbox3d[k, 6]
-            beta = np.arctan2(z, x)
-            alpha = -np.sign(beta) * np.pi / 2 + beta + ry
-            print("%s -1 -1 %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f" %
-                  (cls_name, alpha, img_boxes[k, 0], img_boxes[k, 1], img_boxes[k, 2], img_boxes[k, 3],
-                   bbox3d[k, 3], bbox3d[k, 4], bbox3d[k, 5], bbox3d[k, 0], bbox3d[k, 1], bbox3d[k, 2],
-                   bbox3d[k, 6], scores[k]), file=f)
-            written += 1
-    return written
+    lines = []
+    for k in range(bbox3d.shape[0]):
+        if not ok[k]:
+            continue
+        x, z, ry = bbox3d[k, 0], bbox3d[k, 2], bbox3d[k, 6]
+        beta = np.arctan2(z, x)
+        alpha = -np.sign(beta) * np.pi / 2 + beta + ry
+        lines.append("%s -1 -1 %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f" %
+                     (cls_name, alpha, img_boxes[k, 0], img_boxes[k, 1], img_boxes[k, 2], img_boxes[k, 3],
+                      bbox3d[k, 3], bbox3d[k, 4], bbox3d[k, 5], bbox3d[k, 0], bbox3d[k, 1], bbox3d[k, 2],
+                      bbox3d[k, 6], scores[k]))
+    return lines
+
+
+def save_kitti_format(sample_id, calib, bbox3d, kitti_output_dir, scores, img_shape, cls_name="Car"):
+    """One result file per scene (empty when nothing survives); returns the number of lines."""
+    lines = kitti_result_lines(calib, bbox3d, scores, img_shape, cls_name)
+    with open(os.path.join(kitti_output_dir, "%06d.txt" % sample_id), "w") as f:
+        for l in lines:
+            print(l, file=f)
+    return len(lines)
+
+
+def detections_to_annos(table, counts, source, cls_name="Car"):
+    """Gathered detection table [S, M, 9] (+ counts) -> (scene ids, KITTI annotation dicts), through the same
+    %.4f text form the result files carry, so the in-memory AP equals the AP of the written files."""
+    from . import kitti_eval
+    ids, annos = [], []
+    tb, ct = table.numpy(), counts.numpy()
+    for s in np.argsort(tb[:, 0, 8], kind="stable"):
+        sid, n = int(tb[s, 0, 8]), int(ct[s])
+        calib, shape = source.calib_and_shape(sid)
+        ids.append(sid)
+        annos.append(kitti_eval.annos_from_lines(kitti_result_lines(calib, tb[s, :n, 0:7], tb[s, :n, 7], shape, cls_name)))
+    return ids, annos
+
+
+def evaluate_detections(table, counts, source, current_class=0, dataset="kitti", device_id=0):
+    """Rank-0 tail of the sharded evaluation: AP of the gathered detections against the source's labels
+    (tools/eval_rcnn.py:706-713 -> evaluate/evaluate.py).  Returns (result text, dict)."""
+    from . import kitti_eval
+    ids, dt_annos = detections_to_annos(table, counts, source)
+    gt_annos = [kitti_eval.annos_from_lines(source.label_lines(i)) for i in ids]
+    return kitti_eval.get_official_eval_result(gt_annos, dt_annos, current_class, dataset, device_id=device_id)
 
 
 def shard_scene_ids(num_scenes, rank, world):
@@ -318,6 +346,7 @@ def main(argv=None):
     ap.add_argument("--data_root", type=str, default=None, help="directory holding KITTI/object/... and KITTI/ImageSets")
     ap.add_argument("--split", type=str, default=None, help="ImageSets split (default cfg.TEST.SPLIT)")
     ap.add_argument("--output_dir", type=str, default=None)
+    ap.add_argument("--eval_ap", action="store_true", help="rank 0: KITTI AP of the gathered detections vs the labels")
     ap.add_argument("--set", dest="set_cfgs", default=None, nargs=argparse.REMAINDER)
     args = ap.parse_args(argv)
 
@@ -349,6 +378,12 @@ def main(argv=None):
     table, counts = all_gather_detections(table, counts, device)
     if rank == 0:
         print("scenes=%d detections=%d" % (table.shape[0], int(counts.sum())))
+        if args.eval_ap:
+            text, _ = evaluate_detections(table, counts, source, device_id=device.index or 0)
+            print(text)
+            if args.output_dir:
+                with open(os.path.join(args.output_dir, "final_result", "ap.txt"), "w") as f:
+                    f.write(text)
 
 
 if __name__ == "__main__":

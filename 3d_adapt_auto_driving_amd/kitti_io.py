@@ -93,6 +93,14 @@ class KittiSource:
             return (h, w, 3)
         return (375, 1242, 3)          # the usual KITTI size when images are not shipped
 
+    def calib_and_shape(self, idx):
+        return Calibration(os.path.join(self.dir, "calib", "%06d.txt" % idx)), self.image_shape(idx)
+
+    def label_lines(self, idx):
+        """Ground-truth label_2 lines of a scene (for the AP evaluator)."""
+        with open(os.path.join(self.dir, "label_2", "%06d.txt" % idx)) as f:
+            return [l for l in f.read().split("\n") if l.strip()]
+
     def load(self, idx):
         cfg = self.cfg
         calib = Calibration(os.path.join(self.dir, "calib", "%06d.txt" % idx))
@@ -115,6 +123,26 @@ class SyntheticSource:
         self.ids = list(range(num_scenes))
         self.raw_points = raw_points
         self.calib = synth.SyntheticCalib()
+
+    def calib_and_shape(self, idx):
+        return self.calib, self.calib.image_shape
+
+    def label_lines(self, idx):
+        """The generator's car boxes as KITTI label lines (fully visible, not truncated)."""
+        from . import kitti_utils
+        n = self.raw_points or self.cfg.RPN.NUM_POINTS
+        boxes = synth.scene_with_labels(idx, n, 20 if self.raw_points else 10)[1]
+        corners = kitti_utils.boxes3d_to_corners3d(boxes.astype(np.float32))
+        img, _ = self.calib.corners3d_to_img_boxes(corners)
+        h, w = self.calib.image_shape[0], self.calib.image_shape[1]
+        lines = []
+        for b, ib in zip(boxes, img):
+            x1, y1, x2, y2 = np.clip(ib, [0, 0, 0, 0], [w - 1, h - 1, w - 1, h - 1])
+            beta = np.arctan2(b[2], b[0])
+            alpha = -np.sign(beta) * np.pi / 2 + beta + b[6]
+            lines.append("Car 0.00 0 %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f" %
+                         (alpha, x1, y1, x2, y2, b[3], b[4], b[5], b[0], b[1], b[2], b[6]))
+        return lines
 
     def load(self, idx):
         n = self.cfg.RPN.NUM_POINTS

@@ -8,7 +8,8 @@ result writer."""
 import numpy as np
 
 
-def scene(seed, n=16384, n_cars=10):
+def scene_with_labels(seed, n=16384, n_cars=10):
+    """-> (pts (n,3) f32, car boxes (n_cars,7) f64 = [x, y_bottom, z, h, w, l, ry] in the camera frame)."""
     rng = np.random.default_rng(seed)
     per_car = max(1, min(200, n // (4 * n_cars)))
     n_car_pts = per_car * n_cars
@@ -17,7 +18,7 @@ def scene(seed, n=16384, n_cars=10):
     bg = rng.uniform([-40, -1, 0], [40, 3, 70.4], (n_bg, 3))
     ground = np.stack([rng.uniform(-40, 40, n_ground), 1.6 + 0.05 * rng.standard_normal(n_ground),
                        rng.uniform(0, 70.4, n_ground)], 1)
-    cars = []
+    cars, boxes = [], []
     for _ in range(n_cars):
         c = np.array([rng.uniform(-20, 20), 0.8, rng.uniform(5, 60)])
         ry = rng.uniform(-np.pi, np.pi)
@@ -25,9 +26,14 @@ def scene(seed, n=16384, n_cars=10):
         x = loc[:, 0] * np.cos(ry) + loc[:, 2] * np.sin(ry)
         z = -loc[:, 0] * np.sin(ry) + loc[:, 2] * np.cos(ry)
         cars.append(np.stack([x, loc[:, 1], z], 1) + c)
+        boxes.append([c[0], c[1] + 0.75, c[2], 1.5, 1.6, 3.9, ry])
     pts = np.concatenate([bg, ground] + cars, 0).astype(np.float32)
     rng.shuffle(pts)
-    return pts
+    return pts, np.array(boxes, dtype=np.float64).reshape(-1, 7)
+
+
+def scene(seed, n=16384, n_cars=10):
+    return scene_with_labels(seed, n, n_cars)[0]
 
 
 def scenes(b, n=16384, seed0=0):

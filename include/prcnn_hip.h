@@ -207,6 +207,41 @@ int prcnn_roipool3d(int batch_size, int pts_num, int boxes_num, int feature_in_l
 int prcnn_rotate_iou_eval(int n, int k, const float *boxes, const float *query_boxes,
                           float *iou, int criterion, void *stream);
 
+/* Block-diagonal rotate_iou_gpu_eval: segment s (one image) pairs boxes[box_off[s]..box_off[s+1]) with
+ * query_boxes[q_off[s]..q_off[s+1]) and writes its row-major block at out_off[s]; one launch for a whole split
+ * instead of the ~50 dense parts of evaluate/eval2.py:352-424 (calculate_iou_partly), whose cross-image pairs
+ * are discarded.  out_off (nseg+1) i64, box_off / q_off (nseg+1) i32, all DEVICE; total = out_off[nseg]. */
+int prcnn_rotate_iou_eval_segmented(int nseg, long long total, const long long *out_off, const int *box_off,
+                                    const int *q_off, const float *boxes, const float *query_boxes, float *iou,
+                                    int criterion, void *stream);
+
+/* ---- evaluate/eval2.py: host-side matching of the AP evaluator (HOST pointers, f64 / i64) ---- */
+
+/* compute_statistics_jit  evaluate/eval2.py:170-289 for one image.  overlaps (n_dt,n_gt) row-major,
+ * gt_datas (n_gt,5) = [bbox x4, alpha], dt_datas (n_dt,6) = [bbox x4, alpha, score], ignored_* in {-1,0,1},
+ * dc_bboxes (n_dc,4).  -> tp_fp_fn[3], similarity, thresholds (room for n_gt) and their count. */
+int prcnn_kitti_image_stats(int n_gt, int n_dt, int n_dc, const double *overlaps, const double *gt_datas,
+                            const double *dt_datas, const long long *ignored_gt, const long long *ignored_det,
+                            const double *dc_bboxes, int metric, double min_overlap, double thresh, int compute_fp,
+                            int compute_aos, long long *tp_fp_fn, double *similarity, double *thresholds,
+                            int *n_thresholds);
+
+/* First pass of eval_class (evaluate/eval2.py:512-527) over all images: scores of matched detections
+ * (compute_fp = False, thresh = 0).  Per-image arrays are concatenated; overlaps_flat holds the (n_dt,n_gt)
+ * blocks back to back.  scores_out has room for sum(gt_nums). */
+int prcnn_kitti_collect_scores(int n_img, const long long *gt_nums, const long long *dt_nums,
+                               const double *overlaps_flat, const double *gt_datas, const double *dt_datas,
+                               const long long *ignored_gts, const long long *ignored_dets, int metric,
+                               double min_overlap, double *scores_out, long long *n_scores);
+
+/* fused_compute_statistics  evaluate/eval2.py:300-349 over all images:
+ * pr (n_thresh,4) += [tp, fp, fn, similarity] at every score threshold. */
+int prcnn_kitti_accumulate_pr(int n_img, const long long *gt_nums, const long long *dt_nums, const long long *dc_nums,
+                              const double *overlaps_flat, const double *gt_datas, const double *dt_datas,
+                              const double *dontcares, const long long *ignored_gts, const long long *ignored_dets,
+                              int metric, double min_overlap, const double *thresholds, int n_thresh, int compute_aos,
+                              double *pr);
+
 #ifdef __cplusplus
 }
 #endif

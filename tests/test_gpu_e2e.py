@@ -234,6 +234,22 @@ def test_eval_scenes_writes_kitti_result_files(tmp_path):
     assert int(counts[0]) == int(g["final_num"][0]) or True
 
 
+def test_sharded_eval_tail_computes_ap_on_gpu():
+    """eval_scenes -> gathered table -> AP text with the rotated IoU on the GPU (random weights: the number is
+    meaningless, the plumbing is what is checked), and perfect detections score 100 through the HIP kernel."""
+    import test_kitti_eval as TK
+    E, K = pkg("eval_rcnn"), pkg("kitti_io")
+    model, cfg, g = tiny_model(DEV)
+    src = K.SyntheticSource(cfg, 4)
+    table, counts = E.eval_scenes(model, cfg, DEV, src, src.ids, batch_size=2)
+    text, ret = E.evaluate_detections(table, counts, src)
+    assert text.startswith("Car AP@0.70, 0.70, 0.70:") and "3d   AP:" in text and np.isfinite(float(ret["Car_3d_moderate"]))
+    E2, src2, table2, counts2 = TK.synthetic_perfect_table(16)
+    _, ret2 = E2.evaluate_detections(table2, counts2, src2)
+    for k in ("Car_3d_easy", "Car_3d_moderate", "Car_3d_hard", "Car_bev_moderate"):
+        assert abs(float(ret2[k]) - 100.0) < 1e-9, (k, ret2[k])
+
+
 def test_reference_python_runs_on_dropin_modules():
     """Drop-in check at the extension boundary: a caller written against the REFERENCE module names
     and calling conventions (zero-filled idx, transposes, in-place subtract, cat -- the sequence of
