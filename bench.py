@@ -162,12 +162,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU product path)")
-    dev = torch.device("cuda", local_rank)
+    # PRCNN_BENCH_SHARE_GPU=1: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share
+    # devices, gloo instead of RCCL, which refuses two ranks on one device).  Never set by the driver.
+    share = os.environ.get("PRCNN_BENCH_SHARE_GPU") == "1"
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count() if share else local_rank)
     torch.cuda.set_device(dev)
+    comm_dev = torch.device("cpu") if share else dev
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
 
     C = importlib.import_module(PKG + ".config")
@@ -214,13 +221,13 @@ def main():
     ids = list(range(rank * args.steps * BATCH, (rank + 1) * args.steps * BATCH))
     table, counts = E.pack_detections(ids, [(host_boxes[i], host_scores[i], host_num[i])
                                             for i in range(args.warmup, total)], M)
-    table, counts = E.all_gather_detections(table, counts, dev)
+    table, counts = E.all_gather_detections(table, counts, comm_dev)
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
