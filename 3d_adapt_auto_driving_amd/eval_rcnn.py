@@ -14,6 +14,7 @@ CLI (subset of the reference's flags):  python -m ... --cfg_file X --eval_mode r
   --batch_size 8 --output_dir out [--set K V ...] [--scenes 64]
 """
 import argparse
+import contextlib
 import os
 
 import numpy as np
@@ -133,7 +134,7 @@ class PipelinedRunner:
         self.model, self.cfg = model, cfg
         self.engine = FastPointRCNN(model, cfg)
         self.device = torch.device(device)
-        self.depth = int(os.environ.get("PRCNN_GEO_DEPTH", "1")) if depth is None else depth
+        self.depth = int(os.environ.get("PRCNN_GEO_DEPTH", "2")) if depth is None else depth
         # high priority: the geometry kernels are few, short-lived workgroups on a latency-bound chain;
         # when CU slots free up they should be placed before the feature pass's next workgroups
         prio = int(os.environ.get("PRCNN_SIDE_PRIORITY", "-1"))
@@ -166,16 +167,83 @@ class PipelinedRunner:
         self._launch_geometry(pts)
         return self._take(pts)
 
-    @torch.no_grad()
-    def step(self, cur, upcoming=None):
-        geo, ev = self._take(cur)
+    def _prefetch_geometry(self, upcoming):
         if upcoming is not None:
             todo = list(upcoming) if isinstance(upcoming, (list, tuple)) else [upcoming]
             for nxt in todo[:max(1, self.depth)]:
                 if nxt is not None and all(p is not nxt for p, _, _ in self._pending):
                     self._launch_geometry(nxt)        # enqueue first: it overlaps the feature pass below
+
+    @torch.no_grad()
+    def step(self, cur, upcoming=None):
+        geo, ev = self._take(cur)
+        self._prefetch_geometry(upcoming)
         torch.cuda.current_stream(self.device).wait_event(ev)
         return infer_batch(self.model, self.cfg, cur, engine=self.engine, geo=geo)
+
+    # ---- three-stream form: the latency-bound tails leave the GEMM stream -------------------------
+    # The proposal layer (per-scene score sort, band selection, NMS: ONE workgroup per scene) and the final
+    # stage (decode + NMS) keep only B CUs busy.  On the feature stream they would stall the chip-filling
+    # kernels behind them, so they run on a third stream and the feature stream is software-pipelined:
+    #     feature stream :  RPN(i)   RCNN(i-1)   RPN(i+1)   RCNN(i)   ...
+    #     tail stream    :        proposals(i)  final(i-1)      proposals(i+1)  final(i) ...
+    #     geometry stream:  geometry(i+1)                geometry(i+2)
+    # Exactly one stream carries library GEMMs (two GEMM streams deadlock).
+    # ``submit`` returns the detections of the PREVIOUS batch (None on the first call), ``flush`` the last one;
+    # the returned tensors are produced on ``self.tail``: read them under that stream or after ``det["ready"]``.
+    @torch.no_grad()
+    def submit(self, cur, upcoming=None):
+        if getattr(self, "tail", None) is None:
+            self.tail = torch.cuda.Stream(self.device)
+            self._inflight = None
+        main = torch.cuda.current_stream(self.device)
+        geo, ev = self._take(cur)
+        self._prefetch_geometry(upcoming)
+        main.wait_event(ev)
+        st = self.engine.rpn_stage(cur, geo)
+        ev_rpn = torch.cuda.Event()
+        ev_rpn.record(main)
+        for t in (st["rpn_scores_raw"], st["rpn_reg"], st["backbone_xyz"]):
+            t.record_stream(self.tail)
+        with torch.cuda.stream(self.tail):
+            self.tail.wait_event(ev_rpn)
+            rois, roi_scores = self.engine.propose(st)
+            ev_prop = torch.cuda.Event()
+            ev_prop.record(self.tail)
+        rois.record_stream(main)
+        done = self._finish_inflight()
+        self._inflight = (cur, st, rois, roi_scores, ev_prop)
+        return done
+
+    def _finish_inflight(self):
+        if self._inflight is None:
+            return None
+        main = torch.cuda.current_stream(self.device)
+        cur, st, rois, roi_scores, ev_prop = self._inflight
+        self._inflight = None
+        main.wait_event(ev_prop)
+        out = self.engine.rcnn_stage(st, rois)
+        ev_rcnn = torch.cuda.Event()
+        ev_rcnn.record(main)
+        for t in (out["rcnn_cls"], out["rcnn_reg"]):
+            t.record_stream(self.tail)
+        with torch.cuda.stream(self.tail):
+            self.tail.wait_event(ev_rcnn)
+            ret = {"rois": rois, "rcnn_cls": out["rcnn_cls"], "rcnn_reg": out["rcnn_reg"]}
+            det = postprocess(self.cfg, ret, cur.shape[0])
+            det.update(ret)
+            ready = torch.cuda.Event()
+            ready.record(self.tail)
+        det["ready"] = ready
+        det["stream"] = self.tail
+        return det
+
+    @torch.no_grad()
+    def flush(self):
+        """Finish the batch still in flight (RCNN + final stage) and return its detections (or None)."""
+        if getattr(self, "tail", None) is None:
+            return None
+        return self._finish_inflight()
 
 
 def _tensors(obj):
@@ -312,18 +380,37 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
         pts = torch.from_numpy(np.stack([l[0] for l in loaded], 0)).to(device, non_blocking=True)
         return pts, ids, [(l[1], l[2]) for l in loaded]
 
-    nxt, nxt_ids, nxt_meta = load(0)
-    for s in range(0, len(scene_ids), batch_size):
-        pts, ids, meta = nxt, nxt_ids, nxt_meta
-        nxt, nxt_ids, nxt_meta = load(s + batch_size)
-        det = runner.step(pts, nxt) if runner is not None else infer_batch(model, cfg, pts)
-        boxes, scores, num = det["boxes"].cpu(), det["scores"].cpu(), det["num"].cpu()   # one D2H per batch
+    def finish(det, ids, meta):
+        # one D2H per batch, issued on the stream that produced the detections
+        with torch.cuda.stream(det["stream"]) if "stream" in det else contextlib.nullcontext():
+            boxes, scores, num = (det[k].to("cpu", non_blocking=True) for k in ("boxes", "scores", "num"))
+        if "stream" in det:
+            det["stream"].synchronize()
         batches.append((boxes, scores, num))
         if output_dir:
             for k, sid in enumerate(ids):
                 n = int(num[k])
                 calib, shape = meta[k]
                 save_kitti_format(sid, calib, boxes[k, :n].numpy(), output_dir, scores[k, :n].numpy(), shape, cfg.CLASSES)
+
+    # software pipeline: while batch i is on the device, batch i+1 is loaded and (three-stream runner) the RCNN +
+    # final stage of batch i-1 complete; results are consumed one batch late
+    prev = None
+    nxt, nxt_ids, nxt_meta = load(0)
+    for s in range(0, len(scene_ids), batch_size):
+        pts, ids, meta = nxt, nxt_ids, nxt_meta
+        nxt, nxt_ids, nxt_meta = load(s + batch_size)
+        if runner is not None:
+            det = runner.submit(pts, nxt)
+            if det is not None:
+                finish(det, *prev)
+            prev = (ids, meta)
+        else:
+            finish(infer_batch(model, cfg, pts), ids, meta)
+    if runner is not None:
+        det = runner.flush()
+        if det is not None:
+            finish(det, *prev)
     return pack_detections(scene_ids, batches, M)
 
 

@@ -211,10 +211,8 @@ class FastPointRCNN:
 
     # ------------------------------------------------------------------ full forward
     @torch.no_grad()
-    def forward(self, pts_input, geo=None):
-        """pts_input (B,N,3) -> the dict PointRCNN.forward returns in TEST mode (rpn_cls, rpn_reg,
-        backbone_xyz, rois, roi_scores_raw, seg_result, rcnn_cls, rcnn_reg); backbone features are
-        returned point-major under 'rpn_features' (B,N,C)."""
+    def rpn_stage(self, pts_input, geo=None):
+        """Backbone + RPN heads: everything up to (not including) the proposal layer."""
         cfg = self.cfg
         if pts_input.shape[-1] != 3:
             raise NotImplementedError("fast path: per-point input features (USE_INTENSITY) not supported")
@@ -227,14 +225,33 @@ class FastPointRCNN:
         rpn_cls = self.rpn_cls(flat).view(B, N, -1)
         rpn_reg = self.rpn_reg(flat).view(B, N, -1)
         out = {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": xyz, "rpn_features": feats}
-        if not cfg.RCNN.ENABLED:
+        if cfg.RCNN.ENABLED:
+            raw = rpn_cls[:, :, 0].contiguous()
+            out["rpn_scores_raw"] = raw
+            out["seg_result"] = (torch.sigmoid(raw) > cfg.RPN.SCORE_THRESH).float()
+            out["pts_depth"] = torch.norm(xyz, p=2, dim=2)
+        return out
+
+    @torch.no_grad()
+    def propose(self, st):
+        """The proposal layer on the RPN stage's outputs -> (rois, roi_scores_raw)."""
+        return self.model.rpn.proposal_layer(st["rpn_scores_raw"], st["rpn_reg"], st["backbone_xyz"])
+
+    @torch.no_grad()
+    def rcnn_stage(self, st, rois):
+        return self._rcnn(st["backbone_xyz"], st["rpn_features"], st["seg_result"], st["pts_depth"], rois)
+
+    @torch.no_grad()
+    def forward(self, pts_input, geo=None):
+        """pts_input (B,N,3) -> the dict PointRCNN.forward returns in TEST mode (rpn_cls, rpn_reg,
+        backbone_xyz, rois, roi_scores_raw, seg_result, rcnn_cls, rcnn_reg); backbone features are
+        returned point-major under 'rpn_features' (B,N,C)."""
+        out = self.rpn_stage(pts_input, geo)
+        if not self.cfg.RCNN.ENABLED:
             return out
-        rpn_scores_raw = rpn_cls[:, :, 0]
-        seg_mask = (torch.sigmoid(rpn_scores_raw) > cfg.RPN.SCORE_THRESH).float()
-        pts_depth = torch.norm(xyz, p=2, dim=2)
-        rois, roi_scores_raw = self.model.rpn.proposal_layer(rpn_scores_raw, rpn_reg, xyz)
-        out.update({"rois": rois, "roi_scores_raw": roi_scores_raw, "seg_result": seg_mask})
-        out.update(self._rcnn(xyz, feats, seg_mask, pts_depth, rois))
+        rois, roi_scores_raw = self.propose(out)
+        out.update({"rois": rois, "roi_scores_raw": roi_scores_raw})
+        out.update(self.rcnn_stage(out, rois))
         return out
 
     def _rcnn(self, xyz, feats, seg_mask, pts_depth, rois):

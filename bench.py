@@ -22,6 +22,7 @@ The JSON line also carries
                 (kind "port": the reference has no CPU path for this pipeline), rank 0, N=1 only.
 """
 import argparse
+import contextlib
 import importlib
 import json
 import os
@@ -151,8 +152,8 @@ def cpu_baseline(cfg, scenes=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -195,13 +196,31 @@ def main():
 
     runner = E.PipelinedRunner(model, cfg, dev)     # point-major engine + geometry on a side stream
 
+    lagged = os.environ.get("PRCNN_TAIL_OVERLAP", "1") != "0"
+
+    def copy_out(det, i):
+        # async D2H of batch i's detections into its pinned slot, on the stream that produced them
+        with torch.cuda.stream(det["stream"]) if "stream" in det else contextlib.nullcontext():
+            host_boxes[i].copy_(det["boxes"], non_blocking=True)
+            host_scores[i].copy_(det["scores"], non_blocking=True)
+            host_num[i].copy_(det["num"], non_blocking=True)
+
     def step(i):
-        # features of batch i on the main stream || geometry (FPS / ball query / three-NN) of batch
-        # i+1 on the side stream; every timed step does one geometry and one feature pass
-        det = runner.step(batches[i % n_slots], [batches[(i + d) % n_slots] for d in range(1, runner.depth + 1)])
-        host_boxes[i].copy_(det["boxes"], non_blocking=True)
-        host_scores[i].copy_(det["scores"], non_blocking=True)
-        host_num[i].copy_(det["num"], non_blocking=True)
+        # every timed step does one geometry pass (batch i+1, side stream), one RPN pass (batch i) and one
+        # RCNN + final pass; in the three-stream form the latter belongs to batch i-1 (software pipeline,
+        # eval_rcnn.PipelinedRunner.submit) and the per-scene tails run beside the GEMM stream
+        nxt = [batches[(i + d) % n_slots] for d in range(1, runner.depth + 1)]
+        if lagged:
+            det = runner.submit(batches[i % n_slots], nxt)
+            if det is not None:
+                copy_out(det, i - 1)
+        else:
+            copy_out(runner.step(batches[i % n_slots], nxt), i)
+
+    def drain(last):
+        det = runner.flush() if lagged else None
+        if det is not None:
+            copy_out(det, last)
 
     def barrier():
         if world > 1:
@@ -210,12 +229,14 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    drain(args.warmup - 1)                 # the pipeline is empty when timing starts ...
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         step(i)
+    drain(total - 1)                       # ... and drained inside the timed region: exactly K full batches
     torch.cuda.synchronize()
     # the one exchange of the job: padded detection tables of this rank's scenes
     ids = list(range(rank * args.steps * BATCH, (rank + 1) * args.steps * BATCH))

@@ -52,6 +52,17 @@ def test_fast_engine_gpu_matches_reference_fixture_and_pipelining_is_transparent
         assert torch.equal(outs[i]["boxes"], det["boxes"]) and torch.equal(outs[i]["num"], det["num"])
     ref_other = E.infer_batch(model, cfg, other, engine=eng)
     assert torch.equal(outs[1]["boxes"], ref_other["boxes"]) and torch.equal(outs[3]["scores"], ref_other["scores"])
+    # three-stream form (tails beside the GEMM stream, RCNN of batch i-1 after RPN of batch i): same results, one
+    # batch later
+    runner3 = E.PipelinedRunner(model, cfg, DEV)
+    lag = [runner3.submit(seq[i], seq[i + 1] if i + 1 < len(seq) else None) for i in range(len(seq))]
+    lag = lag[1:] + [runner3.flush()]
+    assert lag[-1] is not None and runner3.flush() is None
+    for i, d in enumerate(lag):
+        d["ready"].synchronize()
+        want = det if i % 2 == 0 else ref_other
+        for key in ("boxes", "scores", "num", "rois", "rcnn_cls"):
+            assert torch.equal(d[key], want[key]), (i, key)
 
 
 def test_backbone_indices_bit_exact_full_size(oracle):
