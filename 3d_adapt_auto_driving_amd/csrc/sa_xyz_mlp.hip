@@ -1,0 +1,112 @@
+// sa_xyz_mlp.hip -- one whole set-abstraction scale on coordinates only (the first RPN SA level:
+// QueryAndGroup with no input features -> 3-layer shared MLP -> max over nsample;
+// pointnet2_modules.py:37-53 with pointnet2_utils.py:241-264) in ONE kernel.
+//
+// Why its own kernel: with C_in = 3 and widths of 16..64 the level is all activation traffic when it goes
+// through GEMMs -- 1.5 M grouped rows x (32+32+64) floats written and read back (> 1 GB per batch of 8
+// scenes) for 9 GFLOP of arithmetic.  Here a grouped row lives in ONE LANE from the gather to the max:
+//   * lane = one (centre, sample) row; the ns rows of a centre are ns consecutive lanes of a wave;
+//   * weights are wave-uniform: they come in through scalar loads and enter the FMAs as SGPR operands
+//     (v_fmac_f32 v, s, v), so the inner loops are pure VALU with no LDS and no vector loads;
+//   * activations (C1 + C2 + C3 <= 160 values) stay in VGPRs, loops fully unrolled;
+//   * max over nsample = xor-butterfly across the ns lanes of the centre; each lane then stores its share
+//     of the C3 outputs.
+// HBM traffic: idx (4 B/row), the gathered coordinates (L2-resident cloud), C3 floats per centre out.
+// Bound: VALU f32 (2 * rows * (3 C1 + C1 C2 + C2 C3) flop).  The MLP arithmetic decides no index, so FMAs
+// are used (the GEMM libraries it replaces do the same); results agree with the GEMM path to f32 rounding.
+#include "common.hpp"
+
+namespace prcnn {
+
+template <int C1, int C2, int C3, int NS>
+__global__ __launch_bounds__(256) void sa_xyz_mlp_kernel(
+    long rows, int n, int m, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const int *__restrict__ idx, const float *__restrict__ w1, const float *__restrict__ b1,
+    const float *__restrict__ w2, const float *__restrict__ b2, const float *__restrict__ w3,
+    const float *__restrict__ b3, float *__restrict__ out, int out_stride, int out_col)
+{
+    static_assert(C3 % NS == 0, "every lane of a centre stores C3 / NS channels");
+    const long row_raw = (long)blockIdx.x * 256 + threadIdx.x;
+    const long row = row_raw < rows ? row_raw : rows - 1;       // tail lanes recompute the last row, store nothing
+    const long centre = row / NS;
+    const int b = (int)(centre / m);
+    const int k = idx[row];
+    const float *p = xyz + ((long)b * n + k) * 3;
+    const float *c = new_xyz + centre * 3;
+    const float dx = p[0] - c[0], dy = p[1] - c[1], dz = p[2] - c[2];
+
+    float a1[C1];
+#pragma unroll
+    for (int j = 0; j < C1; ++j)
+        a1[j] = fmaxf(fmaf(w1[2 * C1 + j], dz, fmaf(w1[C1 + j], dy, fmaf(w1[j], dx, b1[j]))), 0.f);
+
+    float a2[C2];
+#pragma unroll
+    for (int j = 0; j < C2; ++j) a2[j] = b2[j];
+#pragma unroll
+    for (int q = 0; q < C1; ++q)
+#pragma unroll
+        for (int j = 0; j < C2; ++j) a2[j] = fmaf(w2[q * C2 + j], a1[q], a2[j]);
+#pragma unroll
+    for (int j = 0; j < C2; ++j) a2[j] = fmaxf(a2[j], 0.f);
+
+    float a3[C3];
+#pragma unroll
+    for (int j = 0; j < C3; ++j) a3[j] = b3[j];
+#pragma unroll
+    for (int q = 0; q < C2; ++q)
+#pragma unroll
+        for (int j = 0; j < C3; ++j) a3[j] = fmaf(w3[q * C3 + j], a2[q], a3[j]);
+
+    // ReLU commutes with max; reduce across the NS lanes of this centre
+#pragma unroll
+    for (int off = NS / 2; off >= 1; off >>= 1)
+#pragma unroll
+        for (int j = 0; j < C3; ++j) a3[j] = fmaxf(a3[j], __shfl_xor(a3[j], off));
+
+    if (row_raw < rows) {
+        constexpr int PER = C3 / NS;
+        const int s = (int)(row % NS);
+        float *o = out + centre * out_stride + out_col + s * PER;
+#pragma unroll
+        for (int j = 0; j < C3; ++j)                               // lane s keeps channels [s*PER, (s+1)*PER)
+            if (j / PER == s) o[j - s * PER] = fmaxf(a3[j], 0.f);
+    }
+}
+
+}  // namespace prcnn
+
+using namespace prcnn;
+
+// xyz (b,n,3), new_xyz (b,m,3), idx (b,m,nsample) -> out[(b*m rows)][out_col .. out_col + c3), row stride out_stride.
+// w1 (>=3, c1) rows = x, y, z weights; w2 (c1, c2); w3 (c2, c3): k-major ("row = input channel"), BN folded.
+// Every layer is followed by ReLU.  Supported: (c1,c2,c3,nsample) in {(16,16,32,16), (32,32,64,32)}.
+extern "C" int prcnn_sa_xyz_mlp_supported(int c1, int c2, int c3, int nsample)
+{
+    return (c1 == 16 && c2 == 16 && c3 == 32 && nsample == 16) || (c1 == 32 && c2 == 32 && c3 == 64 && nsample == 32);
+}
+
+extern "C" int prcnn_sa_xyz_mlp(int b, int n, int m, int nsample, int c1, int c2, int c3, const float *new_xyz,
+                                const float *xyz, const int *idx, const float *w1, const float *b1, const float *w2,
+                                const float *b2, const float *w3, const float *b3, float *out, int out_stride,
+                                int out_col, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "sa_xyz_mlp: bad sizes");
+    PRCNN_REQUIRE(prcnn_sa_xyz_mlp_supported(c1, c2, c3, nsample),
+                  "sa_xyz_mlp: unsupported shape c1=%d c2=%d c3=%d nsample=%d", c1, c2, c3, nsample);
+    PRCNN_REQUIRE(out_stride >= out_col + c3 && out_col >= 0, "sa_xyz_mlp: bad output slice");
+    const long rows = (long)b * m * nsample;
+    if (rows == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(n > 0, "sa_xyz_mlp: empty cloud");
+    PRCNN_REQUIRE(new_xyz && xyz && idx && w1 && b1 && w2 && b2 && w3 && b3 && out, "sa_xyz_mlp: null pointer");
+    const long grid = (rows + 255) / 256;
+    PRCNN_REQUIRE(grid <= 0x7fffffffL, "sa_xyz_mlp: too many rows");
+    hipStream_t st = (hipStream_t)stream;
+    if (nsample == 16)
+        hipLaunchKernelGGL((sa_xyz_mlp_kernel<16, 16, 32, 16>), dim3((unsigned)grid), dim3(256), 0, st, rows, n, m, xyz, new_xyz,
+                           idx, w1, b1, w2, b2, w3, b3, out, out_stride, out_col);
+    else
+        hipLaunchKernelGGL((sa_xyz_mlp_kernel<32, 32, 64, 32>), dim3((unsigned)grid), dim3(256), 0, st, rows, n, m, xyz, new_xyz,
+                           idx, w1, b1, w2, b2, w3, b3, out, out_stride, out_col);
+    return check_launch("sa_xyz_mlp");
+}

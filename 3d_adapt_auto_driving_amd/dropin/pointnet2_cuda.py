@@ -169,3 +169,19 @@ def sa_mlp_fused_wrapper(new_xyz, xyz, P, wxyz, idx, w2t, b2, w3t, b3, out, out_
               b2.data_ptr(), w3t.data_ptr(), b3.data_ptr(), out.data_ptr(), out.size(-1), out_col,
               _lib.current_stream(xyz))
     return out
+
+
+def sa_xyz_mlp_supported(c1, c2, c3, nsample):
+    return bool(_lib.load().prcnn_sa_xyz_mlp_supported(int(c1), int(c2), int(c3), int(nsample)))
+
+
+def sa_xyz_mlp_wrapper(new_xyz, xyz, idx, w1, b1, w2, b2, w3, b3, out, out_col):
+    """Coordinates-only SA scale in one VALU kernel (csrc/sa_xyz_mlp.hip): gather -> 3 layers -> max.
+    xyz (b,n,3), new_xyz (b,m,3), idx (b,m,ns), w1 (>=3,c1), w2 (c1,c2), w3 (c2,c3) k-major, out (b,m,stride)."""
+    _chk(torch.float32, new_xyz, xyz, w1, b1, w2, b2, w3, b3, out); _chk(torch.int32, idx)
+    b, n, _ = xyz.shape
+    _lib.call("prcnn_sa_xyz_mlp", b, n, idx.size(1), idx.size(2), w1.size(1), w2.size(1), w3.size(1),
+              new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+              b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), out.data_ptr(), out.size(-1), out_col,
+              _lib.current_stream(xyz))
+    return out

@@ -26,6 +26,9 @@ from .. import kitti_utils
 from .. import roipool3d_utils
 
 
+USE_XYZ_MLP = True      # coordinates-only SA scales through csrc/sa_xyz_mlp.hip (False: grouped GEMM chain)
+
+
 def _round4(c):
     return (c + 3) // 4 * 4
 
@@ -167,6 +170,13 @@ class FastPointRCNN:
             P = torch.addmm(b1, feats.view(B * N, cin), wf).view(B, N, -1)
             ext.sa_mlp_fused_wrapper(new_xyz, xyz, P, wx, idx, mlp.layers[1][0], mlp.layers[1][1],
                                      mlp.layers[2][0], mlp.layers[2][1], out, out_col)
+            return
+        if (cin == 0 and USE_XYZ_MLP and len(mlp.layers) == 3 and all(l[2] for l in mlp.layers) and
+                hasattr(ext, "sa_xyz_mlp_wrapper") and
+                ext.sa_xyz_mlp_supported(mlp.layers[0][0].shape[1], mlp.layers[1][0].shape[1], mlp.layers[2][0].shape[1], ns)):
+            # coordinates-only level (RPN SA1): one VALU kernel, a grouped row never leaves its lane
+            (w1, b1, _), (w2, b2, _), (w3, b3, _) = mlp.layers
+            ext.sa_xyz_mlp_wrapper(new_xyz, xyz, idx, w1, b1, w2, b2, w3, b3, out, out_col)
             return
         if mlp.split is not None and M * ns > N:
             # layer 1 is linear before its ReLU: its feature part is one GEMM over the N points,

@@ -131,6 +131,18 @@ int prcnn_sa_mlp_fused(int b, int n, int m, int nsample, int c1, int c2, int c3,
                        const float *xyz, const float *P, const float *wxyz, const int *idx, const float *w2t,
                        const float *b2, const float *w3t, const float *b3, float *out, int out_stride,
                        int out_col, void *stream);
+
+/* One whole coordinates-only set-abstraction scale (first RPN SA level: QueryAndGroup without input features ->
+ * 3-layer shared MLP + ReLU -> max over nsample; pointnet2_modules.py:37-53, pointnet2_utils.py:241-264) in one
+ * VALU kernel: a grouped row lives in one lane from the gather to the max, weights are scalar operands.
+ * xyz (b,n,3), new_xyz (b,m,3), idx (b,m,nsample); w1 (>=3,c1), w2 (c1,c2), w3 (c2,c3) k-major, BN folded;
+ * out[(b*m rows)][out_col .. out_col+c3), row stride out_stride.
+ * Supported (c1,c2,c3,nsample): (16,16,32,16), (32,32,64,32) -- prcnn_sa_xyz_mlp_supported returns 1 for those. */
+int prcnn_sa_xyz_mlp_supported(int c1, int c2, int c3, int nsample);
+int prcnn_sa_xyz_mlp(int b, int n, int m, int nsample, int c1, int c2, int c3, const float *new_xyz,
+                     const float *xyz, const int *idx, const float *w1, const float *b1, const float *w2,
+                     const float *b2, const float *w3, const float *b3, float *out, int out_stride, int out_col,
+                     void *stream);
 /* max over ns consecutive rows: in (rows_out*ns, c) -> out[r][out_col..out_col+c), row stride out_stride
  * (F.max_pool2d over nsample, pointnet2_modules.py:41-44, on the point-major MLP output). */
 int prcnn_maxpool_pm(long rows_out, int ns, int c, const float *in, float *out, int out_stride,

@@ -65,6 +65,25 @@ def test_fast_engine_gpu_matches_reference_fixture_and_pipelining_is_transparent
             assert torch.equal(d[key], want[key]), (i, key)
 
 
+def test_xyz_level_kernel_equals_gemm_chain_in_engine():
+    """Full-size RPN backbone with the first SA level through csrc/sa_xyz_mlp.hip vs through the grouped GEMM
+    chain: the (B, N, 128) point features agree to f32 rounding."""
+    C, E, F = pkg("config"), pkg("eval_rcnn"), pkg("net.fast_infer")
+    cfg = C.default_eval_cfg()
+    model = E.build_model(cfg, DEV, seed=0)
+    eng = F.FastPointRCNN(model, cfg)
+    pts = torch.from_numpy(pkg("synth").scenes(2, cfg.RPN.NUM_POINTS, seed0=77)).to(DEV)
+    geo = eng.geometry(pts)
+    a = eng._backbone(pts, geo)
+    F.USE_XYZ_MLP = False
+    try:
+        b = eng._backbone(pts, geo)
+    finally:
+        F.USE_XYZ_MLP = True
+    assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+    assert float(a.abs().max()) > 0
+
+
 def test_backbone_indices_bit_exact_full_size(oracle):
     """FPS / ball-query indices of all four RPN SA levels on a full 16384-point scene: the xyz chain
     involves no convolution, so GPU and oracle must agree exactly at every level."""

@@ -529,3 +529,31 @@ def test_bad_arguments_raise(ext):
         ext.pointnet2.ball_query_wrapper(1, 8, 8, 0.1, 4, x.cpu(), x, torch.zeros((1, 8, 4), dtype=torch.int32, device=DEV))
     with pytest.raises(lib.PrcnnError):
         lib.call("prcnn_ball_query", 1, 8, 8, 0.1, 4, None, None, None, None)
+
+
+@pytest.mark.parametrize("c1,c2,c3,ns", [(16, 16, 32, 16), (32, 32, 64, 32)])
+def test_sa_xyz_mlp_fused_level(ext, oracle, c1, c2, c3, ns):
+    """Coordinates-only SA scale in one VALU kernel (csrc/sa_xyz_mlp.hip) vs the same function composed from
+    torch ops in f32 (gather, centre subtraction, three linear+ReLU layers, max over nsample).  Tolerance 1e-5
+    relative: only the summation order / FMA rounding differs.  Row count not a multiple of the block (tail
+    lanes), output written into a column slice of a wider buffer."""
+    rng = np.random.default_rng(c1)
+    B, N, M = 3, 4096, 333
+    xyz = scenes(B, N, seed0=61)
+    new = centres(oracle, xyz, M)
+    idx = oracle.ball_query(0.5 if ns == 32 else 0.1, ns, xyz, new)
+    w1 = (rng.standard_normal((4, c1)) * 0.8).astype(np.float32); w1[3] = 0
+    w2 = (rng.standard_normal((c1, c2)) * 0.3).astype(np.float32)
+    w3 = (rng.standard_normal((c2, c3)) * 0.3).astype(np.float32)
+    b1, b2, b3 = (rng.standard_normal(c).astype(np.float32) * 0.1 for c in (c1, c2, c3))
+    out = torch.full((B, M, c3 + 8), -7.0, device=DEV)
+    ext.pointnet2.sa_xyz_mlp_wrapper(T(new), T(xyz), T(idx), T(w1), T(b1), T(w2), T(b2), T(w3), T(b3), out, 5)
+    txyz, tnew, tidx = T(xyz), T(new), T(idx).long()
+    g = torch.gather(txyz.unsqueeze(1).expand(-1, M, -1, -1), 2, tidx.unsqueeze(-1).expand(-1, -1, -1, 3)) - tnew.unsqueeze(2)
+    y = torch.relu(g @ T(w1)[:3] + T(b1))
+    y = torch.relu(y @ T(w2) + T(b2))
+    y = torch.relu(y @ T(w3) + T(b3)).max(dim=2).values
+    got = out[:, :, 5:5 + c3]
+    assert torch.allclose(got, y, rtol=1e-5, atol=1e-5), float((got - y).abs().max())
+    assert bool((out[:, :, :5] == -7.0).all()) and bool((out[:, :, 5 + c3:] == -7.0).all())   # slice only
+    assert ext.pointnet2.sa_xyz_mlp_supported(c1, c2, c3, ns) and not ext.pointnet2.sa_xyz_mlp_supported(c1, c2, c3, 64)
