@@ -14,32 +14,25 @@
 // temporary allocation, nothing written for empty boxes except their flag.
 #include "common.hpp"
 #include <math.h>
+#include <stdint.h>
 
 namespace prcnn {
 
 constexpr int RP_THREADS = 256;
 constexpr int RP_MAX_S = 2048;
 
-__global__ __launch_bounds__(RP_THREADS) void roipool3d_kernel(
-    int pts_num, int boxes_num, int feat_len, int sampled, const float *__restrict__ xyz,
-    const float *__restrict__ boxes3d, const float *__restrict__ pts_feature,
-    float *__restrict__ pooled, int *__restrict__ empty_flag)
+// Sweep of one (scene, box): first `sampled` in-box point indices in index order -> s_sel; returns min(#hits, sampled).
+// bx = the (already enlarged) box [x, y_bottom, z, h, w, l, ry].
+__device__ __forceinline__ int select_points(int pts_num, int sampled, const float *__restrict__ pts, float bx0, float bx1,
+                                             float bx2, float h, float w, float l, float ry, int *s_sel, int *s_wcnt)
 {
-    __shared__ int s_sel[RP_MAX_S];
-    __shared__ int s_wcnt[RP_THREADS / 64];
-
-    const int box = blockIdx.x, b = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const float *bx = boxes3d + ((long)b * boxes_num + box) * 7;
     // pt_in_box3d :14-28; the trig pair and cy depend on the box only
-    const float cx = bx[0], cz = bx[2], h = bx[3], w = bx[4], l = bx[5];
-    const float cy = (float)((double)bx[1] - (double)h / 2.0);
-    const float cosa = cos_f32(bx[6]), sina = sin_f32(bx[6]);
+    const float cx = bx0, cz = bx2;
+    const float cy = (float)((double)bx1 - (double)h / 2.0);
+    const float cosa = cos_f32(ry), sina = sin_f32(ry);
     const float hh = h * 0.5f, hl = l * 0.5f, hw = w * 0.5f;  // exact halves
-    const float *__restrict__ pts = xyz + (long)b * pts_num * 3;
-
     __syncthreads();
-
     int total = 0;
     for (int base = 0; base < pts_num && total < sampled; base += RP_THREADS) {
         const int k = base + t;
@@ -68,7 +61,22 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_kernel(
         }
         __syncthreads();
     }
-    const int cnt = min(total, sampled);
+    return min(total, sampled);
+}
+
+__global__ __launch_bounds__(RP_THREADS) void roipool3d_kernel(
+    int pts_num, int boxes_num, int feat_len, int sampled, const float *__restrict__ xyz,
+    const float *__restrict__ boxes3d, const float *__restrict__ pts_feature,
+    float *__restrict__ pooled, int *__restrict__ empty_flag)
+{
+    __shared__ int s_sel[RP_MAX_S];
+    __shared__ int s_wcnt[RP_THREADS / 64];
+
+    const int box = blockIdx.x, b = blockIdx.y;
+    const int t = threadIdx.x;
+    const float *bx = boxes3d + ((long)b * boxes_num + box) * 7;
+    const float *__restrict__ pts = xyz + (long)b * pts_num * 3;
+    const int cnt = select_points(pts_num, sampled, pts, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], bx[6], s_sel, s_wcnt);
     if (cnt == 0) {
         if (t == 0) empty_flag[(long)b * boxes_num + box] = 1;
         return;  // rows stay as the caller left them
@@ -84,6 +92,68 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_kernel(
         const int j = (int)(e - (long)s * width);
         const int k = s_sel[s < cnt ? s : s % cnt];  // wrap-around duplication :152-159
         dst[e] = j < 3 ? pts[3 * k + j] : feat[(long)k * feat_len + (j - 3)];
+    }
+}
+
+// RCNN input assembly in the same pass (rcnn_net.py:139-163 with roipool3d_utils.py:7-28 and
+// kitti_utils.py:150-160 enlarge_box3d): the box is enlarged here, the pooled coordinates are moved into the
+// RoI's canonical frame (centre subtracted, rotated by the RoI heading about y), and the row is written in the
+// layout the RCNN point MLPs consume:  [x', y', z', seg mask, depth, 0, 0, 0 | C features]  (C % 4 == 0, every
+// 16-byte chunk aligned).  The caller does not pre-clear: empty boxes are written here too.  Selection is the same code
+// as roipool3d_kernel, hence the same points.
+__global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(
+    int pts_num, int boxes_num, int feat_len, int sampled, float extra, float extra2, const float *__restrict__ xyz,
+    const float *__restrict__ rois, const float *__restrict__ feats, const float *__restrict__ seg_mask,
+    const float *__restrict__ depth, float4 *__restrict__ pooled, int *__restrict__ empty_flag)
+{
+    __shared__ int s_sel[RP_MAX_S];
+    __shared__ int s_wcnt[RP_THREADS / 64];
+
+    const int box = blockIdx.x, b = blockIdx.y;
+    const int t = threadIdx.x;
+    const float *bx = rois + ((long)b * boxes_num + box) * 7;
+    const float rx = bx[0], ry_bottom = bx[1], rz = bx[2], heading = bx[6];
+    const float *__restrict__ pts = xyz + (long)b * pts_num * 3;
+    // enlarge_box3d: h, w, l += 2 * extra_width;  y += extra_width
+    const int cnt = select_points(pts_num, sampled, pts, rx, ry_bottom + extra, rz, bx[3] + extra2, bx[4] + extra2,
+                                  bx[5] + extra2, heading, s_sel, s_wcnt);
+    const int q4 = 2 + feat_len / 4;                                     // float4 chunks per row
+    float4 *__restrict__ dst = pooled + ((long)b * boxes_num + box) * (long)sampled * q4;
+    const long chunks = (long)sampled * q4;
+    const float cosa = cosf(heading), sina = sinf(heading);             // torch.cos / torch.sin of the f32 heading
+    if (cnt == 0) {
+        // the reference leaves zero rows and then applies the canonical transform to ALL rows (rcnn_net.py:147-156):
+        // an empty box holds the image of the origin, zero features
+        if (t == 0) empty_flag[(long)b * boxes_num + box] = 1;
+        const float x = 0.f - rx, y = 0.f - ry_bottom, z = 0.f - rz;
+        const float4 origin = make_float4(fmaf(z, -sina, __fmul_rn(x, cosa)), y, fmaf(z, cosa, __fmul_rn(x, sina)), 0.f);
+        for (long e = t; e < chunks; e += RP_THREADS) dst[e] = (e % q4 == 0) ? origin : make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    if (t == 0) empty_flag[(long)b * boxes_num + box] = 0;
+    const float4 *__restrict__ feat4 = reinterpret_cast<const float4 *>(feats + (long)b * pts_num * feat_len);
+    const float *__restrict__ mk = seg_mask + (long)b * pts_num;
+    const float *__restrict__ dp = depth + (long)b * pts_num;
+    const int f4 = feat_len / 4;
+    for (long e = t; e < chunks; e += RP_THREADS) {
+        const int s = (int)(e / q4);
+        const int q = (int)(e - (long)s * q4);
+        const int k = s_sel[s < cnt ? s : s % cnt];
+        float4 v;
+        if (q >= 2) {
+            v = feat4[(long)k * f4 + (q - 2)];
+        } else if (q == 0) {
+            const float x = pts[3 * k] - rx, y = pts[3 * k + 1] - ry_bottom, z = pts[3 * k + 2] - rz;
+            // rotate_pc_along_y_torch (kitti_utils.py:45-63) is a batched (1x2)@(2x2) matmul: the GEMM library
+            // accumulates k = 0, 1 with fused multiply-adds, i.e. fma(z, r1, x * r0) -- reproduced here
+            v.x = fmaf(z, -sina, __fmul_rn(x, cosa));
+            v.y = y;
+            v.z = fmaf(z, cosa, __fmul_rn(x, sina));
+            v.w = mk[k];
+        } else {
+            v = make_float4(dp[k], 0.f, 0.f, 0.f);
+        }
+        dst[e] = v;
     }
 }
 
@@ -108,4 +178,28 @@ extern "C" int prcnn_roipool3d(int batch_size, int pts_num, int boxes_num, int f
                        feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature, pooled_features,
                        pooled_empty_flag);
     return check_launch("roipool3d");
+}
+
+
+// Fast-path RCNN input assembly (see roipool3d_canonical_kernel).  xyz (b,n,3), rois (b,m,7) NOT enlarged,
+// feats (b,n,c) point-major with c % 4 == 0, seg_mask / depth (b,n) -> pooled (b,m,sampled,8+c), empty (b,m) i32.
+extern "C" int prcnn_roipool3d_canonical(int batch_size, int pts_num, int boxes_num, int feature_len, int sampled_pts_num,
+                                         float pool_extra_width, const float *xyz, const float *rois, const float *feats,
+                                         const float *seg_mask, const float *depth, float *pooled, int *pooled_empty_flag,
+                                         void *stream)
+{
+    PRCNN_REQUIRE(batch_size >= 0 && pts_num >= 0 && boxes_num >= 0 && feature_len >= 0 && sampled_pts_num >= 0,
+                  "roipool3d_canonical: bad sizes");
+    PRCNN_REQUIRE(feature_len % 4 == 0, "roipool3d_canonical: feature length %d is not a multiple of 4", feature_len);
+    PRCNN_REQUIRE(sampled_pts_num <= RP_MAX_S, "roipool3d_canonical: sampled_pts_num=%d > %d unsupported", sampled_pts_num, RP_MAX_S);
+    PRCNN_REQUIRE(batch_size <= 65535, "roipool3d_canonical: batch > 65535");
+    if (batch_size == 0 || boxes_num == 0 || sampled_pts_num == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(rois && pooled && pooled_empty_flag && (pts_num == 0 || (xyz && seg_mask && depth && (feats || feature_len == 0))),
+                  "roipool3d_canonical: null pointer");
+    PRCNN_REQUIRE((((uintptr_t)pooled | (uintptr_t)feats) & 15) == 0, "roipool3d_canonical: 16-byte alignment required");
+    dim3 grid(boxes_num, batch_size);
+    hipLaunchKernelGGL(roipool3d_canonical_kernel, grid, dim3(RP_THREADS), 0, (hipStream_t)stream, pts_num, boxes_num,
+                       feature_len, sampled_pts_num, pool_extra_width, (float)((double)pool_extra_width * 2.0), xyz, rois, feats,
+                       seg_mask, depth, reinterpret_cast<float4 *>(pooled), pooled_empty_flag);
+    return check_launch("roipool3d_canonical");
 }

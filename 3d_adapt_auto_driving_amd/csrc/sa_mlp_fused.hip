@@ -95,8 +95,10 @@ __global__ __launch_bounds__(256, (C3 == 128 ? 2 : 1)) void sa_mlp_fused_kernel(
         const long b = t / m;
         const float *ct3 = new_xyz + t * 3;
         const float cx = ct3[0], cy = ct3[1], cz = ct3[2];
-        // draw the next ticket now; it is read after this tile's first barrier
-        if (tid == 0) slot[(served + 1) & 1] = atomicAdd(ticket, 1u);
+        // draw the next ticket now; it is read after this tile's first barrier.  Not on the last tile this
+        // workgroup serves: a ticket drawn and not served would be a tile nobody computes.
+        const bool more = served + 1 < SA_TILES_PER_WG;
+        if (tid == 0) slot[(served + 1) & 1] = more ? atomicAdd(ticket, 1u) : 0xffffffffu;
         // ---- layer 1 into LDS
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256, (C3 == 128 ? 2 : 1)) void sa_mlp_fused_kernel(
         }
         __syncthreads();
         const long t_next = slot[(served + 1) & 1];
-        if (t_next < tiles && served + 1 < SA_TILES_PER_WG) {     // neighbour indices of the next tile, in flight during the MFMAs
+        if (t_next < tiles) {     // neighbour indices of the next tile, in flight during the MFMAs
 #pragma unroll
             for (int i = 0; i < 8; ++i) kidx[i] = idx[t_next * SA_NS + (tid >> 5) + 8 * i];
         }

@@ -41,6 +41,17 @@ def forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag):
 forward_slow = forward
 
 
+def forward_canonical(xyz, rois, feats, seg_mask, depth, pool_extra_width, pooled, pooled_empty_flag):
+    """Extension beyond the reference ABI (csrc/roipool.hip roipool3d_canonical_kernel): enlarge + pool + canonical
+    transform + RCNN row layout [x',y',z',mask,depth,0,0,0 | C feats] in one pass.  pooled (B,M,S,8+C)."""
+    _chk(torch.float32, xyz, rois, feats, seg_mask, depth, pooled)
+    _chk(torch.int32, pooled_empty_flag)
+    _lib.call("prcnn_roipool3d_canonical", xyz.size(0), xyz.size(1), rois.size(1), feats.size(2), pooled.size(2),
+              float(pool_extra_width), xyz.data_ptr(), rois.data_ptr(), feats.data_ptr(), seg_mask.data_ptr(),
+              depth.data_ptr(), pooled.data_ptr(), pooled_empty_flag.data_ptr(), _lib.current_stream(xyz))
+    return 1
+
+
 def pts_in_boxes3d_cpu(pts_flag, pts, boxes3d):
     raise NotImplementedError("roipool3d_cuda.pts_in_boxes3d_cpu: host-side dataset utility, out of the "
                               "MI355X hot-path scope (no CPU paths in this build)")

@@ -26,6 +26,7 @@ from .. import kitti_utils
 from .. import roipool3d_utils
 
 
+USE_ROIPOOL_CANONICAL = True   # RCNN input assembly through roipool3d_canonical_kernel (False: torch-op sequence)
 USE_XYZ_MLP = True      # coordinates-only SA scales through csrc/sa_xyz_mlp.hip (False: grouped GEMM chain)
 
 
@@ -268,22 +269,37 @@ class FastPointRCNN:
         R = self.cfg.RCNN
         if not (R.ROI_SAMPLE_JIT and R.USE_RPN_FEATURES and not R.USE_INTENSITY):
             raise NotImplementedError("fast path covers the default.yaml RCNN input configuration")
-        extra = [seg_mask.unsqueeze(2)]
-        if R.USE_DEPTH:
-            extra.append((pts_depth / 70.0 - 0.5).unsqueeze(2))
-        pts_feature = torch.cat(extra + [feats], dim=2)                       # (B,N,2+128), already point-major
-        pooled, _ = roipool3d_utils.roipool3d_gpu(xyz, pts_feature, rois, R.POOL_EXTRA_WIDTH, sampled_pt_num=R.NUM_POINTS)
-        B, M, P, W = pooled.shape
-        pooled[:, :, :, 0:3] -= rois[:, :, 0:3].unsqueeze(2)
-        flat = pooled.view(B * M, P, W)
-        flat[:, :, 0:3] = kitti_utils.rotate_pc_along_y_torch(flat[:, :, 0:3], rois.reshape(-1, 7)[:, 6])
-
         nin = self.model.rcnn_net.rcnn_input_channel                           # xyz + mask + depth = 5
-        rows = flat.view(B * M * P, W)
-        a = rows.new_zeros((rows.shape[0], _round4(nin)))
-        a[:, :nin] = rows[:, :nin]
+        rp = roipool3d_utils.roipool3d_cuda
+        C = feats.shape[2]
+        if (USE_ROIPOOL_CANONICAL and hasattr(rp, "forward_canonical") and R.USE_DEPTH and nin == 5 and C % 4 == 0):
+            # enlarge + pool + canonical transform + aligned row layout [x',y',z',mask,depth,0,0,0 | feats] in ONE kernel
+            B, M = rois.shape[0], rois.shape[1]
+            P, W = R.NUM_POINTS, 8 + C
+            pooled = torch.empty((B, M, P, W), dtype=torch.float32, device=xyz.device)
+            empty = torch.empty((B, M), dtype=torch.int32, device=xyz.device)
+            rp.forward_canonical(xyz, rois.contiguous(), feats, seg_mask.contiguous(),
+                                 (pts_depth / 70.0 - 0.5).contiguous(), R.POOL_EXTRA_WIDTH, pooled, empty)
+            flat = pooled.view(B * M, P, W)
+            rows = flat.view(B * M * P, W)
+            a = rows[:, 0:8]                                                   # strided view: columns 5..7 are zero
+            rpn_part = rows[:, 8:]
+        else:
+            extra = [seg_mask.unsqueeze(2)]
+            if R.USE_DEPTH:
+                extra.append((pts_depth / 70.0 - 0.5).unsqueeze(2))
+            pts_feature = torch.cat(extra + [feats], dim=2)                   # (B,N,2+128), already point-major
+            pooled, _ = roipool3d_utils.roipool3d_gpu(xyz, pts_feature, rois, R.POOL_EXTRA_WIDTH, sampled_pt_num=R.NUM_POINTS)
+            B, M, P, W = pooled.shape
+            pooled[:, :, :, 0:3] -= rois[:, :, 0:3].unsqueeze(2)
+            flat = pooled.view(B * M, P, W)
+            flat[:, :, 0:3] = kitti_utils.rotate_pc_along_y_torch(flat[:, :, 0:3], rois.reshape(-1, 7)[:, 6])
+            rows = flat.view(B * M * P, W)
+            a = rows.new_zeros((rows.shape[0], _round4(nin)))
+            a[:, :nin] = rows[:, :nin]
+            rpn_part = rows[:, nin:]
         xyz_feature = self.xyz_up(a)                                           # (rows, 128)
-        merged = self.merge_down(torch.cat((xyz_feature, rows[:, nin:]), dim=1))
+        merged = self.merge_down(torch.cat((xyz_feature, rpn_part), dim=1))
         l_xyz = [flat[:, :, 0:3].contiguous()]
         l_feat = [merged.view(B * M, P, -1)]
         ext = pu.pointnet2

@@ -210,6 +210,16 @@ int prcnn_roipool3d(int batch_size, int pts_num, int boxes_num, int feature_in_l
                     const float *pts_feature, float *pooled_features, int *pooled_empty_flag,
                     void *stream);
 
+/* RCNN input assembly in one pass (lib/net/rcnn_net.py:139-163 + roipool3d_utils.py:7-28 + kitti_utils.py:150-160):
+ * enlarge the RoIs by pool_extra_width, pool the first `sampled` points per box (same selection as prcnn_roipool3d),
+ * move the pooled coordinates into the RoI's canonical frame and write rows
+ * [x', y', z', seg mask, depth, 0, 0, 0 | c features] (c % 4 == 0).  rois (b,m,7) are the UN-enlarged proposals;
+ * feats (b,n,c) point-major; seg_mask, depth (b,n); pooled (b,m,sampled,8+c) need not be cleared; empty (b,m) i32. */
+int prcnn_roipool3d_canonical(int batch_size, int pts_num, int boxes_num, int feature_len, int sampled_pts_num,
+                              float pool_extra_width, const float *xyz, const float *rois, const float *feats,
+                              const float *seg_mask, const float *depth, float *pooled, int *pooled_empty_flag,
+                              void *stream);
+
 /* ---- evaluate/rotate_iou.py ---------------------------------------------------------- */
 
 /* rotate_iou_gpu_eval  evaluate/rotate_iou.py:294-329 (kernel :261-291).

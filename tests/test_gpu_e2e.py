@@ -84,6 +84,50 @@ def test_xyz_level_kernel_equals_gemm_chain_in_engine():
     assert float(a.abs().max()) > 0
 
 
+def test_roipool_canonical_kernel_equals_torch_sequence():
+    """RCNN input assembly in one kernel (enlarge + pool + canonical transform + aligned rows) vs the reference-order
+    sequence pool -> subtract centre -> rotate -> pad: the pooled coordinates agree to 1 ulp-level rounding (the torch
+    path rotates through a batched matmul), features / mask / depth rows are identical, an empty box holds the image
+    of the origin in both, and the RCNN heads agree to 1e-5."""
+    C, E, F = pkg("config"), pkg("eval_rcnn"), pkg("net.fast_infer")
+    RU = pkg("roipool3d_utils")
+    cfg = C.default_eval_cfg()
+    model = E.build_model(cfg, DEV, seed=0)
+    eng = F.FastPointRCNN(model, cfg)
+    B, N = 2, cfg.RPN.NUM_POINTS
+    pts = torch.from_numpy(pkg("synth").scenes(B, N, seed0=91)).to(DEV)
+    st = eng.rpn_stage(pts)
+    rois, _ = eng.propose(st)
+    rois = rois.clone()
+    rois[0, 3, 0:3] = torch.tensor([5.0, -40.0, 30.0], device=DEV)             # 40 m above the scene: certainly empty
+    # kernel-level comparison of the pooled tensor
+    feats, mask, depth = st["rpn_features"], st["seg_result"], (st["pts_depth"] / 70.0 - 0.5).contiguous()
+    M, S, Cf = rois.shape[1], cfg.RCNN.NUM_POINTS, feats.shape[2]
+    pooled = torch.full((B, M, S, 8 + Cf), float("nan"), device=DEV)
+    empty = torch.full((B, M), -1, dtype=torch.int32, device=DEV)
+    RU.roipool3d_cuda.forward_canonical(pts, rois.contiguous(), feats, mask.contiguous(), depth, cfg.RCNN.POOL_EXTRA_WIDTH, pooled, empty)
+    ref_in = torch.cat([mask.unsqueeze(2), depth.unsqueeze(2), feats], dim=2)
+    ref, ref_empty = RU.roipool3d_gpu(pts, ref_in, rois, cfg.RCNN.POOL_EXTRA_WIDTH, sampled_pt_num=S)
+    assert torch.equal(empty, ref_empty) and int(empty[0, 3]) == 1 and int(empty.sum()) >= 1
+    assert torch.equal(pooled[..., 3:5], ref[..., 3:5]) and torch.equal(pooled[..., 8:], ref[..., 5:])
+    assert bool((pooled[..., 5:8] == 0).all())
+    ref_xyz = ref[..., 0:3] - rois[:, :, 0:3].unsqueeze(2)
+    ref_xyz = pkg("kitti_utils").rotate_pc_along_y_torch(ref_xyz.reshape(B * M, S, 3), rois.reshape(-1, 7)[:, 6]).view(B, M, S, 3)
+    dxyz = (pooled[..., 0:3] - ref_xyz).abs()
+    print("canonical xyz: max |diff| %.3g, differing elements %d of %d" % (float(dxyz.max()), int((dxyz > 0).sum()), dxyz.numel()))
+    assert float(dxyz.max()) < 2e-5                                            # |coordinates| <= ~50 m: a few ulp at most
+    # through the RCNN
+    a = eng.rcnn_stage(st, rois)
+    F.USE_ROIPOOL_CANONICAL = False
+    try:
+        b = eng.rcnn_stage(st, rois)
+    finally:
+        F.USE_ROIPOOL_CANONICAL = True
+    for k in ("rcnn_cls", "rcnn_reg"):
+        scale = max(1.0, float(b[k].abs().max()))
+        assert float((a[k] - b[k]).abs().max()) <= 5e-5 * scale, (k, float((a[k] - b[k]).abs().max()), scale)
+
+
 def test_backbone_indices_bit_exact_full_size(oracle):
     """FPS / ball-query indices of all four RPN SA levels on a full 16384-point scene: the xyz chain
     involves no convolution, so GPU and oracle must agree exactly at every level."""
@@ -146,6 +190,61 @@ def test_full_size_gpu_vs_cpu_oracle_boxes(oracle):
     nc, ng = int(dc["num"][0]), int(dg["num"][0])
     worst, matched = match_boxes(dg["boxes"][0, :ng].cpu().numpy(), dc["boxes"][0, :nc].numpy())
     assert nc >= 3 and matched >= 0.8 * nc and worst < 1e-3, (worst, matched, nc, ng)
+
+
+def test_full_size_engine_is_complete_deterministic_and_equals_module_path():
+    """default.yaml shapes, batch of 2: the point-major engine (fused MFMA / VALU kernels, ticket scheduling, all
+    extension entry points) against the nn.Module graph on the same device and weights.
+      * every torch.empty buffer is poisoned with NaN first: a tile or row that a kernel fails to write (a lost
+        ticket, a short grid) surfaces as NaN in the heads;
+      * two runs are bit-identical (no race, no stale memory);
+      * RoIs and head outputs agree with the module path to GEMM rounding; final boxes match."""
+    C, E, F, S = pkg("config"), pkg("eval_rcnn"), pkg("net.fast_infer"), pkg("synth")
+    cfg = C.default_eval_cfg()
+    model = E.build_model(cfg, DEV, seed=3)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if ("reg_layer" in name or "cls_layer" in name) and p.dim() > 1:
+                p.copy_((torch.randn(p.shape, generator=g) * 0.3).to(DEV))
+        model.rcnn_net.cls_layer[-1].conv.weight.mul_(0.05)
+        model.rcnn_net.cls_layer[-1].conv.bias.fill_(0.5)
+    eng = F.FastPointRCNN(model, cfg)
+    pts = torch.from_numpy(S.scenes(2, cfg.RPN.NUM_POINTS, seed0=77)).to(DEV)
+    real_empty = torch.empty
+
+    def poisoned(*a, **k):
+        t = real_empty(*a, **k)
+        if t.is_cuda and t.is_floating_point():
+            t.fill_(float("nan"))
+        return t
+
+    torch.empty = poisoned
+    try:
+        d1 = E.infer_batch(model, cfg, pts, engine=eng)
+        d2 = E.infer_batch(model, cfg, pts, engine=eng)
+    finally:
+        torch.empty = real_empty
+    for k in ("rois", "rcnn_cls", "rcnn_reg", "boxes", "scores"):
+        assert torch.isfinite(d1[k]).all(), k
+        assert torch.equal(d1[k], d2[k]), (k, float((d1[k] - d2[k]).abs().max()))
+    dm = E.infer_batch(model, cfg, pts)                                   # nn.Module graph
+    for b in range(2):
+        rg, rm = d1["rois"][b].cpu().numpy(), dm["rois"][b].cpu().numpy()
+        worst, matched = match_boxes(rg, rm)
+        assert matched >= 0.95 * len(rm) and worst < 1e-3, (worst, matched)
+        # head outputs of RoIs that are (numerically) the same box in both paths
+        same = (d1["rois"][b] - dm["rois"][b]).abs().max(dim=1).values < 1e-4
+        assert int(same.sum()) >= 60
+        M = d1["rois"].shape[1]
+        for k, tol in (("rcnn_cls", 2e-3), ("rcnn_reg", 2e-3)):
+            a = d1[k].view(2, M, -1)[b][same]
+            m = dm[k].view(2, M, -1)[b][same]
+            frac_close = float(((a - m).abs().max(dim=1).values < tol).float().mean())
+            assert frac_close >= 0.9, (k, frac_close)                      # a flipped FPS pick may move a few RoIs
+        ng, nm = int(d1["num"][b]), int(dm["num"][b])
+        worst, matched = match_boxes(d1["boxes"][b, :ng].cpu().numpy(), dm["boxes"][b, :nm].cpu().numpy())
+        assert nm >= 3 and matched >= 0.8 * nm and worst < 1e-3, (worst, matched, nm, ng)
 
 
 def test_postprocess_batched_equals_per_scene_reference_order():

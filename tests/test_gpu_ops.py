@@ -383,6 +383,34 @@ def test_sa_mlp_fused_mfma_kernel(ext, c3):
     assert (got.cpu().double().view(-1, c3) - y64).abs().max().item() < 5e-5
 
 
+@pytest.mark.parametrize("c3", [128, 256])
+def test_sa_mlp_fused_serves_every_tile_at_scale(ext, c3):
+    """Ticket scheduling at a size where workgroups retire and are replaced (20 000 tiles, 2 500 workgroups): every
+    tile must be served exactly once -- the output starts as NaN and two launches are bit-identical."""
+    rng = np.random.default_rng(c3)
+    b, n, m, ns = 100, 256, 200, 64
+    xyz = T(rng.uniform(-2, 2, (b, n, 3)).astype(np.float32))
+    new_xyz = xyz[:, :m].contiguous()
+    P = T(rng.standard_normal((b, n, 128)).astype(np.float32))
+    wx = T((rng.standard_normal((3, 128)) * 0.5).astype(np.float32))
+    idx = T(rng.integers(0, n, (b, m, ns)).astype(np.int32))
+    w2 = T((rng.standard_normal((128, 128)) / 11).astype(np.float32)); b2 = T(rng.standard_normal(128).astype(np.float32) * 0.1)
+    w3 = T((rng.standard_normal((128, c3)) / 11).astype(np.float32)); b3 = T(rng.standard_normal(c3).astype(np.float32) * 0.1)
+    outs = []
+    for _ in range(2):
+        out = torch.full((b, m, c3), float("nan"), device=DEV)
+        ext.pointnet2.sa_mlp_fused_wrapper(new_xyz, xyz, P, wx, idx, w2, b2, w3, b3, out, 0)
+        outs.append(out)
+    assert torch.isfinite(outs[0]).all(), "%d values never written" % int((~torch.isfinite(outs[0])).sum())
+    assert torch.equal(outs[0], outs[1])
+    y = torch.empty((b, m * ns, 128), device=DEV)
+    ext.pointnet2.gather_affine_relu_pm_wrapper(new_xyz, xyz, P, wx, idx, y)
+    y = torch.addmm(b2, y.view(-1, 128), w2).clamp_(min=0)
+    y = torch.addmm(b3, y, w3).clamp_(min=0)
+    want = y.view(b * m, ns, c3).amax(dim=1).view(b, m, c3)
+    assert (outs[0] - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
 def test_mlp_epilogue_kernels(ext):
     rng = np.random.default_rng(34)
     x = rng.standard_normal((3, 20, 50, 16)).astype(np.float32)
