@@ -28,6 +28,7 @@
 //     as layer 3's A operand; layer 3's result is max-reduced over the tile's 64 rows (16 accumulator
 //     registers x 2 row halves per lane, then one cross-half shuffle) and 32 lanes store 128 bytes.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace prcnn {
 
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256, (C3 == 128 ? 2 : 1)) void sa_mlp_fused_kernel(
     const int *__restrict__ idx /* (b,m,64) */, const float *__restrict__ w2t /* (128,128) k-major */,
     const float *__restrict__ b2, const float *__restrict__ w3t /* (128,C3) k-major */,
     const float *__restrict__ b3, float *__restrict__ out, int out_stride, int out_col,
-    unsigned int *__restrict__ ticket)
+    unsigned int *__restrict__ ticket, int tiles_per_wg)
 {
     constexpr int NCT = C3 / 128;                 // column tiles of layer 3 per wave
     __shared__ float lds[2 * SA_NS * SA_LD + 4];  // A1 tile and Y1 tile, 64 x 132 each (+ two tile tickets)
@@ -91,13 +92,13 @@ __global__ __launch_bounds__(256, (C3 == 128 ? 2 : 1)) void sa_mlp_fused_kernel(
 #pragma unroll
         for (int i = 0; i < 8; ++i) kidx[i] = idx[t * SA_NS + (tid >> 5) + 8 * i];
     }
-    for (int served = 0; served < SA_TILES_PER_WG && t < tiles; ++served) {
+    for (int served = 0; served < tiles_per_wg && t < tiles; ++served) {
         const long b = t / m;
         const float *ct3 = new_xyz + t * 3;
         const float cx = ct3[0], cy = ct3[1], cz = ct3[2];
         // draw the next ticket now; it is read after this tile's first barrier.  Not on the last tile this
         // workgroup serves: a ticket drawn and not served would be a tile nobody computes.
-        const bool more = served + 1 < SA_TILES_PER_WG;
+        const bool more = served + 1 < tiles_per_wg;
         if (tid == 0) slot[(served + 1) & 1] = more ? atomicAdd(ticket, 1u) : 0xffffffffu;
         // ---- layer 1 into LDS
 #pragma unroll
@@ -220,14 +221,16 @@ extern "C" int prcnn_sa_mlp_fused(int b, int n, int m, int nsample, int c1, int 
     if (tiles == 0) return PRCNN_OK;
     PRCNN_REQUIRE(new_xyz && xyz && P && wxyz && idx && w2t && b2 && w3t && b3 && out, "sa_mlp_fused: null pointer");
     PRCNN_REQUIRE((((uintptr_t)P | (uintptr_t)wxyz) & 15) == 0, "sa_mlp_fused: 16-byte alignment required");
-    const int grid = (int)((tiles + SA_TILES_PER_WG - 1) / SA_TILES_PER_WG);
+    static const int env_tiles = getenv("PRCNN_SA_TILES") ? atoi(getenv("PRCNN_SA_TILES")) : 0;
+    const int per_wg = env_tiles > 0 ? env_tiles : SA_TILES_PER_WG;
+    const int grid = (int)((tiles + per_wg - 1) / per_wg);
     unsigned int *ticket = next_ticket((hipStream_t)stream);
     if (!ticket) { set_error("sa_mlp_fused: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
     if (c3 == 128)
         hipLaunchKernelGGL(sa_mlp_fused_kernel<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, m, tiles, new_xyz,
-                           xyz, (const float4 *)P, (const float4 *)wxyz, idx, w2t, b2, w3t, b3, out, out_stride, out_col, ticket);
+                           xyz, (const float4 *)P, (const float4 *)wxyz, idx, w2t, b2, w3t, b3, out, out_stride, out_col, ticket, per_wg);
     else
         hipLaunchKernelGGL(sa_mlp_fused_kernel<256>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, m, tiles, new_xyz,
-                           xyz, (const float4 *)P, (const float4 *)wxyz, idx, w2t, b2, w3t, b3, out, out_stride, out_col, ticket);
+                           xyz, (const float4 *)P, (const float4 *)wxyz, idx, w2t, b2, w3t, b3, out, out_stride, out_col, ticket, per_wg);
     return check_launch("sa_mlp_fused");
 }
