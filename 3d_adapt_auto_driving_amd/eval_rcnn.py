@@ -16,6 +16,7 @@ CLI (subset of the reference's flags):  python -m ... --cfg_file X --eval_mode r
 import argparse
 import contextlib
 import os
+import time
 
 import numpy as np
 import torch
@@ -362,23 +363,51 @@ def all_gather_detections(table, counts, device):
 
 
 @torch.no_grad()
-def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=None):
+def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=None, workers=None):
     """Evaluate ``scene_ids`` of a scene source (kitti_io.KittiSource / SyntheticSource) on this rank:
     the counterpart of the batch loop of eval_one_epoch_joint (eval_rcnn.py:493-649) incl. the KITTI
-    result files.  Returns (table, counts) as pack_detections."""
+    result files.  Returns (table, counts) as pack_detections.
+
+    ``workers`` loader processes read / filter / subsample scenes ahead of the device (the reference's
+    DataLoader workers, eval_rcnn.py:868-871): a scene costs milliseconds of numpy on the host, the device
+    needs ~1.3 ms per scene, so a single-threaded loader would be the bottleneck.  Batches arrive in order."""
     if output_dir:
         os.makedirs(output_dir, exist_ok=True)
     M = cfg.TEST.RPN_POST_NMS_TOP_N
     batches = []
-    runner = PipelinedRunner(model, cfg, device) if torch.device(device).type == "cuda" else None
+    on_gpu = torch.device(device).type == "cuda"
+    runner = PipelinedRunner(model, cfg, device) if on_gpu else None
+    if workers is None:
+        workers = int(os.environ.get("PRCNN_LOADER_WORKERS", "8"))
+    starts = list(range(0, len(scene_ids), batch_size))
+    feed = None
+    if workers > 0 and len(starts) > 2:
+        # loader PROCESSES (the scene generator / KITTI reader is Python + numpy: threads would serialise on the GIL);
+        # they only produce host arrays, the parent uploads.  prefetch_factor batches per worker stay in flight.
+        class _Scenes(torch.utils.data.Dataset):
+            def __len__(self):
+                return len(scene_ids)
+
+            def __getitem__(self, k):
+                return torch.from_numpy(source.load(scene_ids[k])[0])
+
+        feed = iter(torch.utils.data.DataLoader(_Scenes(), batch_size=batch_size, shuffle=False, num_workers=workers,
+                                                pin_memory=on_gpu, prefetch_factor=2,
+                                                multiprocessing_context="fork"))
 
     def load(s):
         ids = scene_ids[s:s + batch_size]
         if not ids:
             return None, ids, None
-        loaded = [source.load(i) for i in ids]
-        pts = torch.from_numpy(np.stack([l[0] for l in loaded], 0)).to(device, non_blocking=True)
-        return pts, ids, [(l[1], l[2]) for l in loaded]
+        if feed is not None:
+            host = next(feed)
+            meta = [source.calib_and_shape(i) for i in ids]
+        else:
+            loaded = [source.load(i) for i in ids]
+            host = torch.from_numpy(np.stack([l[0] for l in loaded], 0))
+            host = host.pin_memory() if on_gpu else host
+            meta = [(l[1], l[2]) for l in loaded]
+        return host.to(device, non_blocking=True), ids, meta
 
     def finish(det, ids, meta):
         # one D2H per batch, issued on the stream that produced the detections
@@ -411,6 +440,7 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
         det = runner.flush()
         if det is not None:
             finish(det, *prev)
+    del feed
     return pack_detections(scene_ids, batches, M)
 
 
@@ -430,6 +460,10 @@ def main(argv=None):
     ap.add_argument("--ckpt", type=str, default=None, help="reference .pth checkpoint (random init if omitted)")
     ap.add_argument("--batch_size", type=int, default=8)
     ap.add_argument("--scenes", type=int, default=16, help="number of synthetic scenes (ignored with --data_root)")
+    ap.add_argument("--raw_points", type=int, default=None,
+                    help="synthetic scenes: generate this many raw points per scene (e.g. 180000, the cross-domain "
+                         "dense-cloud case) and reduce them with the near/far sampler")
+    ap.add_argument("--workers", type=int, default=None, help="host loader threads (default 8)")
     ap.add_argument("--data_root", type=str, default=None, help="directory holding KITTI/object/... and KITTI/ImageSets")
     ap.add_argument("--split", type=str, default=None, help="ImageSets split (default cfg.TEST.SPLIT)")
     ap.add_argument("--output_dir", type=str, default=None)
@@ -459,12 +493,16 @@ def main(argv=None):
     if args.data_root:
         source = kitti_io.KittiSource(args.data_root, cfg, args.split or cfg.TEST.SPLIT)
     else:
-        source = kitti_io.SyntheticSource(cfg, args.scenes)
+        source = kitti_io.SyntheticSource(cfg, args.scenes, raw_points=args.raw_points)
     my_ids = [source.ids[i] for i in shard_scene_ids(len(source.ids), rank, world)]
-    table, counts = eval_scenes(model, cfg, device, source, my_ids, args.batch_size, out)
+    t0 = time.perf_counter()
+    table, counts = eval_scenes(model, cfg, device, source, my_ids, args.batch_size, out, workers=args.workers)
+    elapsed = time.perf_counter() - t0
     table, counts = all_gather_detections(table, counts, device)
     if rank == 0:
-        print("scenes=%d detections=%d" % (table.shape[0], int(counts.sum())))
+        print("scenes=%d detections=%d  (%.1f scenes/s on this rank incl. the host input stage%s)" %
+              (table.shape[0], int(counts.sum()), len(my_ids) / max(elapsed, 1e-9),
+               " and the result writer" if out else ""))
         if args.eval_ap:
             text, _ = evaluate_detections(table, counts, source, device_id=device.index or 0)
             print(text)
