@@ -363,14 +363,16 @@ def all_gather_detections(table, counts, device):
 
 
 @torch.no_grad()
-def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=None, workers=None):
+def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=None, workers=None, device_input=False):
     """Evaluate ``scene_ids`` of a scene source (kitti_io.KittiSource / SyntheticSource) on this rank:
     the counterpart of the batch loop of eval_one_epoch_joint (eval_rcnn.py:493-649) incl. the KITTI
     result files.  Returns (table, counts) as pack_detections.
 
     ``workers`` loader processes read / filter / subsample scenes ahead of the device (the reference's
     DataLoader workers, eval_rcnn.py:868-871): a scene costs milliseconds of numpy on the host, the device
-    needs ~1.3 ms per scene, so a single-threaded loader would be the bottleneck.  Batches arrive in order."""
+    needs ~1.3 ms per scene, so a single-threaded loader would be the bottleneck.  Batches arrive in order.
+    ``device_input``: the loaders only READ the raw clouds (``source.load_raw``); rectification, validity filter
+    and the near/far sampler run on the device (kitti_io.DeviceInputStage, csrc/input_stage.hip)."""
     if output_dir:
         os.makedirs(output_dir, exist_ok=True)
     M = cfg.TEST.RPN_POST_NMS_TOP_N
@@ -380,6 +382,13 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
     if workers is None:
         workers = int(os.environ.get("PRCNN_LOADER_WORKERS", "8"))
     starts = list(range(0, len(scene_ids), batch_size))
+    stage = None
+    if device_input:
+        if not on_gpu:
+            raise RuntimeError("eval_scenes: device_input needs a GPU")
+        from . import kitti_io
+        stage = kitti_io.DeviceInputStage(cfg, device, npoints_faraway=getattr(source, "npoints_faraway", 4000),
+                                          seed=getattr(source, "seed", 1024))
     feed = None
     if workers > 0 and len(starts) > 2:
         # loader PROCESSES (the scene generator / KITTI reader is Python + numpy: threads would serialise on the GIL);
@@ -389,16 +398,25 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
                 return len(scene_ids)
 
             def __getitem__(self, k):
+                if stage is not None:
+                    return torch.from_numpy(np.ascontiguousarray(source.load_raw(scene_ids[k])[0], dtype=np.float32))
                 return torch.from_numpy(source.load(scene_ids[k])[0])
 
         feed = iter(torch.utils.data.DataLoader(_Scenes(), batch_size=batch_size, shuffle=False, num_workers=workers,
-                                                pin_memory=on_gpu, prefetch_factor=2,
-                                                multiprocessing_context="fork"))
+                                                pin_memory=on_gpu and stage is None, prefetch_factor=2,
+                                                multiprocessing_context="fork",
+                                                collate_fn=(lambda items: items) if stage is not None else None))
 
     def load(s):
         ids = scene_ids[s:s + batch_size]
         if not ids:
             return None, ids, None
+        if stage is not None:
+            raws = [t.numpy() for t in next(feed)] if feed is not None else [source.load_raw(i)[0] for i in ids]
+            meta = [source.calib_and_shape(i) for i in ids]
+            pts, _ = stage(raws, [m[0] for m in meta], [m[1] for m in meta], ids,
+                           lidar_frame=source.raw_in_lidar_frame, image_filter=source.raw_needs_image_filter)
+            return pts, ids, meta
         if feed is not None:
             host = next(feed)
             meta = [source.calib_and_shape(i) for i in ids]
@@ -463,7 +481,9 @@ def main(argv=None):
     ap.add_argument("--raw_points", type=int, default=None,
                     help="synthetic scenes: generate this many raw points per scene (e.g. 180000, the cross-domain "
                          "dense-cloud case) and reduce them with the near/far sampler")
-    ap.add_argument("--workers", type=int, default=None, help="host loader threads (default 8)")
+    ap.add_argument("--workers", type=int, default=None, help="host loader processes (default 8)")
+    ap.add_argument("--device_input", action="store_true",
+                    help="loaders only read raw clouds; rectification, validity filter and the near/far sampler run on the GPU")
     ap.add_argument("--data_root", type=str, default=None, help="directory holding KITTI/object/... and KITTI/ImageSets")
     ap.add_argument("--split", type=str, default=None, help="ImageSets split (default cfg.TEST.SPLIT)")
     ap.add_argument("--output_dir", type=str, default=None)
@@ -496,7 +516,8 @@ def main(argv=None):
         source = kitti_io.SyntheticSource(cfg, args.scenes, raw_points=args.raw_points)
     my_ids = [source.ids[i] for i in shard_scene_ids(len(source.ids), rank, world)]
     t0 = time.perf_counter()
-    table, counts = eval_scenes(model, cfg, device, source, my_ids, args.batch_size, out, workers=args.workers)
+    table, counts = eval_scenes(model, cfg, device, source, my_ids, args.batch_size, out, workers=args.workers,
+                                device_input=args.device_input)
     elapsed = time.perf_counter() - t0
     table, counts = all_gather_detections(table, counts, device)
     if rank == 0:

@@ -101,6 +101,14 @@ class KittiSource:
         with open(os.path.join(self.dir, "label_2", "%06d.txt" % idx)) as f:
             return [l for l in f.read().split("\n") if l.strip()]
 
+    def load_raw(self, idx):
+        """Raw velodyne points (n,4) as stored + calib + image shape, for DeviceInputStage (lidar_frame=True)."""
+        calib, shape = self.calib_and_shape(idx)
+        lidar = np.fromfile(os.path.join(self.dir, "velodyne", "%06d.bin" % idx), dtype=np.float32).reshape(-1, 4)
+        return lidar, calib, shape
+
+    raw_in_lidar_frame, raw_needs_image_filter = True, True
+
     def load(self, idx):
         cfg = self.cfg
         calib = Calibration(os.path.join(self.dir, "calib", "%06d.txt" % idx))
@@ -113,6 +121,62 @@ class KittiSource:
         pts = synth.subsample_rpn(pts_rect, cfg.RPN.NUM_POINTS, self.npoints_faraway,
                                   rng=np.random.default_rng(self.seed + idx))
         return np.ascontiguousarray(pts, dtype=np.float32), calib, shape
+
+
+class DeviceInputStage:
+    """The same stage on the device (csrc/input_stage.hip): raw points in, ``pts_input`` (B, npoints, 3) out.
+    The host only reads files; transform, validity filter and the near/far sampler run as one workgroup per scene.
+    ``__call__(raws, calibs, shapes, scene_ids, lidar_frame, image_filter)`` with ``raws`` a list of (n_i, 3|4)
+    float32 arrays; returns (pts, stats) device tensors, stats (B,3) = #valid, #near, #far (and the raw index of every
+    output point with ``return_choice``)."""
+
+    def __init__(self, cfg, device, npoints_faraway=4000, seed=1024, far_depth=40.0):
+        import torch
+        self.cfg, self.device = cfg, torch.device(device)
+        self.npoints_faraway, self.seed, self.far_depth = npoints_faraway, seed, far_depth
+
+    @staticmethod
+    def pack_calib(calib, shape):
+        v2c = getattr(calib, "V2C", None)
+        r0 = getattr(calib, "R0", None)
+        row = np.zeros(35, dtype=np.float32)
+        row[0:12] = (np.asarray(v2c, np.float32) if v2c is not None else np.eye(3, 4, dtype=np.float32)).reshape(-1)
+        row[12:21] = (np.asarray(r0, np.float32) if r0 is not None else np.eye(3, dtype=np.float32)).reshape(-1)
+        row[21:33] = np.asarray(calib.P2, np.float32).reshape(-1)
+        row[33], row[34] = shape[0], shape[1]
+        return row
+
+    def __call__(self, raws, calibs, shapes, scene_ids, lidar_frame=True, image_filter=True, return_choice=False):
+        import ctypes
+        import torch
+        from . import _lib
+        cfg = self.cfg
+        B = len(raws)
+        stride = raws[0].shape[1]
+        n_max = max(1, max(r.shape[0] for r in raws))
+        host = torch.zeros((B, n_max, stride), dtype=torch.float32).pin_memory()
+        for k, r in enumerate(raws):
+            host[k, :r.shape[0]] = torch.from_numpy(np.ascontiguousarray(r, dtype=np.float32))
+        dev = self.device
+        raw = host.to(dev, non_blocking=True)
+        counts = torch.tensor([r.shape[0] for r in raws], dtype=torch.int32).to(dev, non_blocking=True)
+        cal = torch.from_numpy(np.stack([self.pack_calib(c, s) for c, s in zip(calibs, shapes)], 0)).to(dev, non_blocking=True)
+        seeds = torch.tensor([self.seed + int(i) for i in scene_ids], dtype=torch.int64).to(dev, non_blocking=True)
+        npoints = cfg.RPN.NUM_POINTS
+        out = torch.empty((B, npoints, 3), dtype=torch.float32, device=dev)
+        stats = torch.empty((B, 3), dtype=torch.int32, device=dev)
+        choice = torch.empty((B, npoints), dtype=torch.int32, device=dev) if return_choice else None
+        scope = None
+        if cfg.PC_REDUCE_BY_RANGE:
+            (x0, x1), (y0, y1), (z0, z1) = cfg.PC_AREA_SCOPE
+            self._scope = (ctypes.c_float * 6)(x0, x1, y0, y1, z0, z1)       # kept alive until the async upload is done
+            scope = ctypes.cast(self._scope, ctypes.c_void_p)
+        with torch.cuda.device(dev):
+            _lib.call("prcnn_input_stage", B, n_max, stride, int(bool(lidar_frame)), int(bool(image_filter)),
+                      counts.data_ptr(), raw.data_ptr(), cal.data_ptr(), scope, npoints, float(self.far_depth),
+                      int(self.npoints_faraway), seeds.data_ptr(), out.data_ptr(), stats.data_ptr(),
+                      _lib.ptr(choice), _lib.current_stream(out))
+        return (out, stats, choice) if return_choice else (out, stats)
 
 
 class SyntheticSource:
@@ -143,6 +207,14 @@ class SyntheticSource:
             lines.append("Car 0.00 0 %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f" %
                          (alpha, x1, y1, x2, y2, b[3], b[4], b[5], b[0], b[1], b[2], b[6]))
         return lines
+
+    def load_raw(self, idx):
+        """The generated cloud before sampling (rect frame), for DeviceInputStage (lidar_frame=False, no image filter)."""
+        n = self.raw_points or self.cfg.RPN.NUM_POINTS
+        pts = synth.dense_scene(idx, n) if self.raw_points else synth.scene(idx, n)
+        return pts, self.calib, self.calib.image_shape
+
+    raw_in_lidar_frame, raw_needs_image_filter = False, False
 
     def load(self, idx):
         n = self.cfg.RPN.NUM_POINTS

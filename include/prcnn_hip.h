@@ -237,6 +237,21 @@ int prcnn_rotate_iou_eval_segmented(int nseg, long long total, const long long *
                                     const int *q_off, const float *boxes, const float *query_boxes, float *iou,
                                     int criterion, void *stream);
 
+/* ---- lib/datasets/kitti_rcnn_dataset.py: the network-input stage on the device ---------- */
+
+/* get_lidar + get_valid_flag + the near/far sampler of get_rpn_sample (kitti_rcnn_dataset.py:249-324) with
+ * calibration.py:51-71, one workgroup per scene.  raw (b,n_max,stride) f32, stride 3 or 4, as read from velodyne .bin
+ * (lidar_frame = 1) or already rectified (0); counts (b) i32; calib (b,35) f32 = V2C 3x4 | R0 3x3 | P2 3x4 | img h, w;
+ * image_filter 0/1 (in-image + depth >= 0 test); scope_host = 6 HOST floats x0,x1,y0,y1,z0,z1 or NULL;
+ * seeds (b) u64 DEVICE.  -> out (b,npoints,3), stats (b,3) i32 = #valid, #near, #far, choice (b,npoints) i32 = raw
+ * index of each output point (may be NULL).  npoints <= 16384.
+ * The subset is random (distinct-key selection + key-sorted shuffle): same distribution as the reference's
+ * np.random.choice / shuffle, not the same draws. */
+int prcnn_input_stage(int b, int n_max, int stride, int lidar_frame, int image_filter, const int *counts,
+                      const float *raw, const float *calib, const float *scope_host, int npoints, float far_depth,
+                      int npoints_faraway, const unsigned long long *seeds, float *out, int *stats, int *choice,
+                      void *stream);
+
 /* ---- evaluate/eval2.py: host-side matching of the AP evaluator (HOST pointers, f64 / i64) ---- */
 
 /* compute_statistics_jit  evaluate/eval2.py:170-289 for one image.  overlaps (n_dt,n_gt) row-major,

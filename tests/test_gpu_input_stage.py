@@ -1,0 +1,149 @@
+"""Device input stage (csrc/input_stage.hip) vs the host numpy stage (kitti_io: Calibration, valid_flag; synth.subsample_rpn
+restating kitti_rcnn_dataset.py:288-324).  The subset is random on both sides, so the sampler is checked through its
+invariants and its distribution; the transform + filter are compared point by point."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def stage(far=4000, seed=1024):
+    C, K = pkg("config"), pkg("kitti_io")
+    cfg = C.default_eval_cfg()
+    return cfg, K.DeviceInputStage(cfg, DEV, npoints_faraway=far, seed=seed), pkg("synth").SyntheticCalib()
+
+
+def run(st, raws, ids, calib, **kw):
+    shapes = [calib.image_shape] * len(raws)
+    out, stats, choice = st(raws, [calib] * len(raws), shapes, ids, return_choice=True, **kw)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), stats.cpu().numpy(), choice.cpu().numpy()
+
+
+def test_sampler_invariants_large_cloud():
+    """More valid points than npoints: every far point up to the cap, the rest near, no duplicates, outputs are bitwise
+    copies of the chosen raw points, deterministic in the seed, different for another scene id."""
+    cfg, st, calib = stage()
+    rng = np.random.default_rng(0)
+    N = cfg.RPN.NUM_POINTS
+    clouds = []
+    for n_far in (1500, 9000, 0):
+        near = rng.uniform([-40, -1, 0], [40, 3, 39.99], (50000, 3))
+        far = rng.uniform([-40, -1, 40.0], [40, 3, 70.4], (n_far, 3))
+        pts = np.concatenate([near, far]).astype(np.float32)
+        clouds.append(pts[rng.permutation(len(pts))])
+    out, stats, choice = run(st, clouds, [5, 6, 7], calib, lidar_frame=False, image_filter=False)
+    for b, pts in enumerate(clouds):
+        ch = choice[b]
+        assert stats[b, 0] == len(pts) and stats[b, 2] == int((pts[:, 2] >= 40.0).sum())
+        assert ch.min() >= 0 and ch.max() < len(pts) and len(np.unique(ch)) == N          # without replacement
+        assert np.array_equal(out[b], pts[ch])
+        n_far = int(stats[b, 2])
+        assert int((pts[ch, 2] >= 40.0).sum()) == min(n_far, 4000)
+    out2, _, choice2 = run(st, clouds, [5, 6, 7], calib, lidar_frame=False, image_filter=False)
+    assert np.array_equal(choice, choice2) and np.array_equal(out, out2)
+    _, _, choice3 = run(st, clouds[:1], [99], calib, lidar_frame=False, image_filter=False)
+    assert not np.array_equal(choice3[0], choice[0])
+    assert len(np.intersect1d(choice3[0], choice[0])) < 0.6 * N                            # ~31 % overlap expected
+
+
+def test_sampler_small_clouds_and_empty():
+    """Fewer valid points than npoints: every point present; the extra copies are distinct points when they fit
+    (each index at most twice), drawn with replacement otherwise; an all-invalid scene gives zeros."""
+    cfg, st, calib = stage()
+    rng = np.random.default_rng(1)
+    N = cfg.RPN.NUM_POINTS
+    a = rng.uniform([-40, -1, 0], [40, 3, 70], (12000, 3)).astype(np.float32)             # extra 4384 <= 12000
+    b = rng.uniform([-40, -1, 0], [40, 3, 70], (100, 3)).astype(np.float32)               # extra > n: with replacement
+    c = np.full((500, 3), 1000.0, np.float32)                                             # outside PC_AREA_SCOPE
+    d = rng.uniform([-40, -1, 0], [40, 3, 70], (N, 3)).astype(np.float32)                 # exactly npoints
+    out, stats, choice = run(st, [a, b, c, d], [1, 2, 3, 4], calib, lidar_frame=False, image_filter=False)
+    cnt = np.bincount(choice[0], minlength=len(a))
+    assert cnt.min() == 1 and cnt.max() == 2 and int((cnt == 2).sum()) == N - len(a)
+    assert np.array_equal(out[0], a[choice[0]])
+    cnt = np.bincount(choice[1], minlength=len(b))
+    assert cnt.min() >= 1 and cnt.sum() == N and cnt.max() < 3 * N // len(b)
+    assert stats[2, 0] == 0 and (choice[2] == -1).all() and (out[2] == 0).all()
+    assert np.array_equal(np.sort(choice[3]), np.arange(N))                               # a permutation
+    assert not np.array_equal(choice[3], np.arange(N))                                    # ... that is shuffled
+
+
+def test_sampler_distribution():
+    """Selection frequency per point over many seeds is binomial (uniform subset), and the output position of a point
+    is uncorrelated with its index (uniform shuffle)."""
+    cfg, st, calib = stage()
+    rng = np.random.default_rng(2)
+    N = cfg.RPN.NUM_POINTS
+    n = 40000
+    pts = rng.uniform([-40, -1, 0], [40, 3, 39.9], (n, 3)).astype(np.float32)
+    seeds = 48
+    freq = np.zeros(n)
+    corr = []
+    for s0 in range(0, seeds, 8):
+        _, _, choice = run(st, [pts] * 8, list(range(s0, s0 + 8)), calib, lidar_frame=False, image_filter=False)
+        for ch in choice:
+            freq[ch] += 1
+            corr.append(np.corrcoef(ch.astype(np.float64), np.arange(N))[0, 1])
+    p = N / n
+    assert abs(freq.mean() - seeds * p) < 1e-9
+    var = freq.var()
+    assert 0.85 * seeds * p * (1 - p) < var < 1.15 * seeds * p * (1 - p), var           # binomial variance
+    assert max(abs(c) for c in corr) < 0.05
+    lo, hi = freq[: n // 2].mean(), freq[n // 2:].mean()
+    assert abs(lo - hi) < 0.15                                                              # no index bias
+
+
+def test_transform_and_filter_match_host_stage():
+    """Lidar-frame input with a KITTI-like calibration: the points the device keeps are the points the numpy stage
+    keeps (borderline roundings aside), and their rectified coordinates agree."""
+    K = pkg("kitti_io")
+    cfg, st, _ = stage()
+    rng = np.random.default_rng(3)
+    calib = K.Calibration({
+        "P2": [721.5377, 0, 609.5593, 44.85728, 0, 721.5377, 172.854, 0.2163791, 0, 0, 1, 0.002745884],
+        "R0": [0.9999239, 0.00983776, -0.007445048, -0.009869795, 0.9999421, -0.004278459, 0.007402527, 0.004351614, 0.9999631],
+        "Tr_velo2cam": [0.007533745, -0.9999714, -0.000616602, -0.004069766, 0.01480249, 0.0007280733, -0.9998902, -0.07631618,
+                        0.9998621, 0.007523790, 0.01480755, -0.2717806]})
+    shape = (375, 1242, 3)
+    n = 110000
+    lidar = np.concatenate([rng.uniform([-10, -60, -3], [90, 60, 2], (n, 3)), rng.uniform(0, 1, (n, 1))], 1).astype(np.float32)
+    out, stats, choice = st([lidar], [calib], [shape], [42], lidar_frame=True, image_filter=True, return_choice=True)
+    torch.cuda.synchronize()
+    out, stats, choice = out.cpu().numpy()[0], stats.cpu().numpy()[0], choice.cpu().numpy()[0]
+    rect = calib.lidar_to_rect(lidar[:, :3])
+    img, depth = calib.rect_to_img(rect)
+    flag = K.valid_flag(rect, img, depth, shape, cfg.PC_AREA_SCOPE if cfg.PC_REDUCE_BY_RANGE else None)
+    n_host = int(flag.sum())
+    assert abs(int(stats[0]) - n_host) <= max(3, n_host // 2000), (stats, n_host)
+    assert flag[choice].mean() > 0.999
+    assert np.abs(out - rect[choice]).max() < 2e-4
+    far_host = int((flag & (rect[:, 2] >= 40.0)).sum())
+    assert abs(int(stats[2]) - far_host) <= max(3, far_host // 500)
+    N = cfg.RPN.NUM_POINTS
+    assert n_host > N
+    far_keep = min(int(stats[2]), 4000)
+    n_near = int(stats[1])
+    assert int((rect[choice, 2] >= 40.0).sum()) == far_keep
+    if n_near >= N - far_keep:
+        assert len(np.unique(choice)) == N
+    else:                                   # too few near points: every near point once + copies, every kept far point once
+        cnt = np.bincount(choice, minlength=n)
+        near_idx = np.where(flag & (rect[:, 2] < 40.0))[0]
+        assert (cnt[near_idx] >= 1).mean() > 0.999 and len(np.unique(choice)) >= n_near + far_keep - 3
+
+
+def test_eval_scenes_with_device_input_stage():
+    """The harness with --device_input: loader processes only read raw clouds, the device does the rest; detections
+    come out for every scene (dense 60 k-point synthetic clouds through the sampler)."""
+    E, K = pkg("eval_rcnn"), pkg("kitti_io")
+    from test_host_logic import tiny_model
+    model, cfg, g = tiny_model(DEV)
+    src = K.SyntheticSource(cfg, 6, raw_points=60000)
+    table, counts = E.eval_scenes(model, cfg, DEV, src, src.ids, batch_size=4, workers=0, device_input=True)
+    assert table.shape[0] == 6 and int(counts.min()) >= 0 and torch.isfinite(table).all()
+    table2, counts2 = E.eval_scenes(model, cfg, DEV, src, src.ids, batch_size=4, workers=2, device_input=True)
+    assert torch.equal(table, table2) and torch.equal(counts, counts2)                    # deterministic in the scene id
