@@ -47,6 +47,8 @@ SIGNATURES = {
     "prcnn_rpn_proposals": [_I, _I, _I, _F, _F, _I, _I, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
     "prcnn_rcnn_postprocess": [_I, _I, _I, _F, _F, _I, _I, _F, _F, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_roipool3d": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "prcnn_host_pts_in_boxes3d": [_I, _I, _P, _P, _P],
+    "prcnn_host_roipool3d": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "prcnn_roipool3d_canonical": [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_input_stage": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P],
     "prcnn_rotate_iou_eval": [_I, _I, _P, _P, _P, _I, _P],

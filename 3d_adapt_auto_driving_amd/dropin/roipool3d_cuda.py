@@ -3,9 +3,10 @@
 
 ``forward`` / ``forward_slow`` are the device path (both map to the same kernel: the "slow"
 overload, roipool3d_kernel.cu:31-94, computes the identical result).  ``pts_in_boxes3d_cpu`` and
-``roipool3d_cpu`` are HOST utilities of the reference used only by its dataset / GT-database
-code (kitti_rcnn_dataset.py:507, generate_gt_database.py:75), which SURVEY.md section 8 puts
-out of scope: they raise NotImplementedError here rather than silently running on the CPU.
+``roipool3d_cpu`` are the module's HOST utilities (CPU tensors, unbatched) used by the reference's
+dataset / GT-database code (kitti_rcnn_dataset.py:507, generate_gt_database.py:75): host functions of
+the same library (csrc/roipool_host.hip), pinned to the outputs of the reference's own compiled
+roipool3d.cpp.  They are not a fallback: the device entry points refuse CPU tensors and these refuse CUDA ones.
 """
 import importlib
 import os
@@ -52,11 +53,29 @@ def forward_canonical(xyz, rois, feats, seg_mask, depth, pool_extra_width, poole
     return 1
 
 
+def _chk_host(dtype, *tensors):
+    for t in tensors:
+        if t.is_cuda:
+            raise RuntimeError("roipool3d_cuda: host utility called with a CUDA tensor")
+        if not t.is_contiguous():
+            raise RuntimeError("roipool3d_cuda: tensor must be contiguous")
+        if t.dtype != dtype:
+            raise RuntimeError("roipool3d_cuda: expected %s, got %s" % (dtype, t.dtype))
+
+
 def pts_in_boxes3d_cpu(pts_flag, pts, boxes3d):
-    raise NotImplementedError("roipool3d_cuda.pts_in_boxes3d_cpu: host-side dataset utility, out of the "
-                              "MI355X hot-path scope (no CPU paths in this build)")
+    """Host utility of the reference module (roipool3d.cpp:97-125): pts_flag (M,N) int64 <- point j inside box i."""
+    _chk_host(torch.float32, pts, boxes3d)
+    _chk_host(torch.int64, pts_flag)
+    _lib.call("prcnn_host_pts_in_boxes3d", boxes3d.size(0), pts.size(0), pts.data_ptr(), boxes3d.data_ptr(), pts_flag.data_ptr())
+    return 1
 
 
 def roipool3d_cpu(pts, boxes3d, pts_feature, pooled_pts, pooled_features, pooled_empty_flag):
-    raise NotImplementedError("roipool3d_cuda.roipool3d_cpu: host-side dataset utility, out of the "
-                              "MI355X hot-path scope (no CPU paths in this build)")
+    """Host utility of the reference module (roipool3d.cpp:127-195), unbatched, CPU tensors."""
+    _chk_host(torch.float32, pts, boxes3d, pts_feature, pooled_pts, pooled_features)
+    _chk_host(torch.int64, pooled_empty_flag)
+    _lib.call("prcnn_host_roipool3d", boxes3d.size(0), pts.size(0), pts_feature.size(1), pooled_pts.size(1), pts.data_ptr(),
+              boxes3d.data_ptr(), pts_feature.data_ptr(), pooled_pts.data_ptr(), pooled_features.data_ptr(),
+              pooled_empty_flag.data_ptr())
+    return 1

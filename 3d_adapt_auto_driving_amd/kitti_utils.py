@@ -6,6 +6,16 @@ import numpy as np
 import torch
 
 
+def rotate_pc_along_y(pc, rot_angle):
+    """numpy: pc (N, 3+C) in the rect camera frame, rot_angle scalar; x and z are rotated in place
+    (kitti_utils.py:32-42)."""
+    import numpy as np
+    cosval, sinval = np.cos(rot_angle), np.sin(rot_angle)
+    rotmat = np.array([[cosval, -sinval], [sinval, cosval]])
+    pc[:, [0, 2]] = np.dot(pc[:, [0, 2]], np.transpose(rotmat))
+    return pc
+
+
 def rotate_pc_along_y_torch(pc, rot_angle):
     """pc (N, P, 3+C) rotated in place about y by rot_angle (N): [x z] <- [x z] @ R^T with
     R = [[cos, -sin], [sin, cos]] (a batched 2x2 matmul, as the reference does it)."""

@@ -220,6 +220,16 @@ int prcnn_roipool3d_canonical(int batch_size, int pts_num, int boxes_num, int fe
                               const float *seg_mask, const float *depth, float *pooled, int *pooled_empty_flag,
                               void *stream);
 
+/* The reference module's two HOST utilities (CPU tensors, unbatched; they serve its dataset / GT-database code):
+ * pts_in_boxes3d_cpu  roipool3d.cpp:97-125 -> flags (boxes_num, pts_num) i64 in {0,1};
+ * roipool3d_cpu       roipool3d.cpp:127-195 -> pooled_pts (boxes_num,sampled,3), pooled_features
+ * (boxes_num,sampled,feature_len), empty (boxes_num) i64; rows of empty boxes stay as the caller left them.
+ * HOST pointers, no stream. */
+int prcnn_host_pts_in_boxes3d(int boxes_num, int pts_num, const float *pts, const float *boxes3d, long long *flags);
+int prcnn_host_roipool3d(int boxes_num, int pts_num, int feature_len, int sampled, const float *pts,
+                         const float *boxes3d, const float *pts_feature, float *pooled_pts, float *pooled_features,
+                         long long *empty);
+
 /* ---- evaluate/rotate_iou.py ---------------------------------------------------------- */
 
 /* rotate_iou_gpu_eval  evaluate/rotate_iou.py:294-329 (kernel :261-291).

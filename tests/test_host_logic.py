@@ -44,8 +44,8 @@ def test_no_cpu_fallback_in_product_ops():
     xyz = torch.zeros((1, 16, 3))
     with pytest.raises(RuntimeError, match="CUDA"):
         pu.furthest_point_sample(xyz, 4)
-    with pytest.raises(NotImplementedError):
-        pkg("roipool3d_utils").pts_in_boxes3d_cpu(xyz[0], torch.zeros((1, 7)))
+    with pytest.raises(RuntimeError, match="CUDA"):
+        pkg("roipool3d_utils").roipool3d_gpu(xyz, torch.zeros((1, 16, 2)), torch.zeros((1, 1, 7)), 1.0, 4)
     # nothing under the package imports the oracle
     pdir = pkg().PACKAGE_DIR
     for dp, _, files in os.walk(pdir):
@@ -53,6 +53,35 @@ def test_no_cpu_fallback_in_product_ops():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
+
+
+def test_host_utilities_match_compiled_reference_fixture():
+    """roipool3d_cuda.pts_in_boxes3d_cpu / roipool3d_cpu (the reference module's HOST utilities, host code of the C-ABI
+    library) against g5 = outputs of the reference's own compiled roipool3d.cpp on the same inputs: bit for bit; plus the
+    Python-level helpers of roipool3d_utils.py:31-108 built on them."""
+    g = load("g5_roipool_ref.npz")
+    RU, ku = pkg("roipool3d_utils"), pkg("kitti_utils")
+    pts, boxes, feat = torch.from_numpy(g["pts"]), torch.from_numpy(g["boxes"]), torch.from_numpy(g["feat"])
+    masks = RU.pts_in_boxes3d_cpu(pts, boxes)
+    assert len(masks) == boxes.shape[0]
+    assert np.array_equal(torch.stack(masks).numpy(), g["pts_flag"] > 0)
+    pp, pf, pe = RU.roipool_pc_cpu(pts, feat, boxes, 512)
+    assert np.array_equal(pe.numpy(), g["pooled_empty_flag"]) and int(pe.sum()) >= 1
+    assert np.array_equal(pp.numpy(), g["pooled_pts"]) and np.array_equal(pf.numpy(), g["pooled_features"])
+    # roipool3d_cpu: enlarge + pool + canonical transform, numpy in / out
+    extra = np.ascontiguousarray(g["feat"][:, :2])
+    rest = np.ascontiguousarray(g["feat"][:, 2:])
+    inp, fe = RU.roipool3d_cpu(g["boxes"].copy(), g["pts"], rest, extra, 1.0, sampled_pt_num=64)
+    assert inp.shape == (boxes.shape[0], 64, 5) and fe.shape == (boxes.shape[0], 64, rest.shape[1])
+    big = ku.enlarge_box3d(g["boxes"], 1.0)
+    p2, f2, e2 = RU.roipool_pc_cpu(pts, feat, torch.from_numpy(big), 64)
+    k = int(np.nonzero(e2.numpy() == 0)[0][0])
+    want = p2[k].numpy() - g["boxes"][k, 0:3]
+    want = ku.rotate_pc_along_y(want.copy(), g["boxes"][k, 6] % (2 * np.pi))
+    np.testing.assert_allclose(inp[k, :, 0:3], want, atol=1e-6)
+    assert np.array_equal(inp[k, :, 3:5], f2[k].numpy()[:, :2]) and np.array_equal(fe[k], f2[k].numpy()[:, 2:])
+    with pytest.raises(RuntimeError):
+        pkg("dropin.roipool3d_cuda").pts_in_boxes3d_cpu(torch.zeros((1, 4), dtype=torch.int32), pts[:4], boxes[:1])
 
 
 def test_glue_matches_reference_python():
