@@ -194,7 +194,7 @@ namespace prcnn {
 // 64 rotating ticket words per process (one launch uses one; zeroed by a memset on the same stream)
 static unsigned int *g_tickets = nullptr;
 static unsigned int g_ticket_next = 0;
-static unsigned int *next_ticket(hipStream_t st)
+unsigned int *next_ticket(hipStream_t st)
 {
     if (!g_tickets && hipMalloc((void **)&g_tickets, 64 * sizeof(unsigned int)) != hipSuccess) return nullptr;
     unsigned int *t = g_tickets + (g_ticket_next++ & 63);

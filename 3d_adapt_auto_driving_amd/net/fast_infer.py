@@ -27,6 +27,7 @@ from .. import roipool3d_utils
 
 
 USE_ROIPOOL_CANONICAL = True   # RCNN input assembly through roipool3d_canonical_kernel (False: torch-op sequence)
+USE_RCNN_POINT_MLP = True      # RCNN entrance chain through csrc/rcnn_point_mlp.hip (False: library GEMMs + concat)
 USE_XYZ_MLP = True      # coordinates-only SA scales through csrc/sa_xyz_mlp.hip (False: grouped GEMM chain)
 
 
@@ -158,7 +159,7 @@ class FastPointRCNN:
 
     # ------------------------------------------------------------------ building blocks
     @staticmethod
-    def _sa_scale(xyz, new_xyz, feats, idx, mlp, cin, out, out_col):
+    def _sa_scale(xyz, new_xyz, feats, idx, mlp, cin, out, out_col, P_pre=None):
         """one (radius, nsample) scale: group -> GEMM chain -> max over nsample into out[..., slice]"""
         ext = pu.pointnet2
         B, N, _ = xyz.shape
@@ -168,7 +169,7 @@ class FastPointRCNN:
                                            mlp.layers[2][0].shape[1], ns)):
             # whole scale in ONE hand-written MFMA kernel: gather -> 3 layers -> max, no HBM activations
             wf, wx, b1 = mlp.split
-            P = torch.addmm(b1, feats.view(B * N, cin), wf).view(B, N, -1)
+            P = P_pre if P_pre is not None else torch.addmm(b1, feats.view(B * N, cin), wf).view(B, N, -1)
             ext.sa_mlp_fused_wrapper(new_xyz, xyz, P, wx, idx, mlp.layers[1][0], mlp.layers[1][1],
                                      mlp.layers[2][0], mlp.layers[2][1], out, out_col)
             return
@@ -265,6 +266,22 @@ class FastPointRCNN:
         out.update(self.rcnn_stage(out, rois))
         return out
 
+    def _point_mlp_ok(self):
+        """Shapes csrc/rcnn_point_mlp.hip is written for: xyz_up 5(8) -> 128 -> 128, merge 256 -> 128, SA1 through the
+        fused MFMA kernel with a 128 -> 128 per-point part."""
+        if getattr(self, "_pm_ok", None) is None:
+            ok = len(self.xyz_up.layers) == 2 and len(self.merge_down.layers) == 1 and len(self.rcnn_sa) > 0
+            if ok:
+                (wu1, _, r1), (wu2, _, r2) = self.xyz_up.layers
+                (wm, _, r3), = self.merge_down.layers
+                mlp1, ns1 = self.rcnn_sa[0][3], self.rcnn_sa[0][2]
+                ok = (tuple(wu1.shape) == (8, 128) and tuple(wu2.shape) == (128, 128) and tuple(wm.shape) == (256, 128)
+                      and r1 and r2 and r3 and mlp1.split is not None and tuple(mlp1.split[0].shape) == (128, 128)
+                      and len(mlp1.layers) == 3 and self.rcnn_sa[0][0] is not None
+                      and pu.pointnet2.sa_mlp_fused_supported(128, mlp1.layers[1][0].shape[1], mlp1.layers[2][0].shape[1], ns1))
+            self._pm_ok = bool(ok)
+        return self._pm_ok
+
     def _rcnn(self, xyz, feats, seg_mask, pts_depth, rois):
         R = self.cfg.RCNN
         if not (R.ROI_SAMPLE_JIT and R.USE_RPN_FEATURES and not R.USE_INTENSITY):
@@ -298,10 +315,24 @@ class FastPointRCNN:
             a = rows.new_zeros((rows.shape[0], _round4(nin)))
             a[:, :nin] = rows[:, :nin]
             rpn_part = rows[:, nin:]
-        xyz_feature = self.xyz_up(a)                                           # (rows, 128)
-        merged = self.merge_down(torch.cat((xyz_feature, rpn_part), dim=1))
+        P_pre = None
+        sa1 = self.rcnn_sa[0]
+        if (USE_RCNN_POINT_MLP and W == 136 and rows.shape[0] % 64 == 0 and hasattr(ext_mod := pu.pointnet2, "rcnn_point_mlp_wrapper")
+                and self._point_mlp_ok()):
+            # xyz_up (2 layers) + concat + merge_down + the per-point part of SA1's layer 1: two MFMA kernels, no `merged`
+            (wu1, bu1, _), (wu2, bu2, _) = self.xyz_up.layers
+            (wm, bm, _), = self.merge_down.layers
+            wf, _, b1 = sa1[3].split
+            xfeat = torch.empty((rows.shape[0], 128), dtype=torch.float32, device=rows.device)
+            P_pre = torch.empty((rows.shape[0], 128), dtype=torch.float32, device=rows.device)
+            ext_mod.rcnn_point_mlp_wrapper(rows, 8, wu1, bu1, wu2, bu2, wm, bm, wf, b1, xfeat, P_pre)
+            P_pre = P_pre.view(B * M, P, 128)
+            l_feat = [None]
+        else:
+            xyz_feature = self.xyz_up(a)                                       # (rows, 128)
+            merged = self.merge_down(torch.cat((xyz_feature, rpn_part), dim=1))
+            l_feat = [merged.view(B * M, P, -1)]
         l_xyz = [flat[:, :, 0:3].contiguous()]
-        l_feat = [merged.view(B * M, P, -1)]
         ext = pu.pointnet2
         for npoint, radius, ns, mlp, cin in self.rcnn_sa:
             cur_xyz, cur_feat = l_xyz[-1], l_feat[-1]
@@ -312,7 +343,7 @@ class FastPointRCNN:
                 new_xyz = torch.gather(cur_xyz, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
                 idx = pu.ball_query(radius, ns, cur_xyz, new_xyz)
                 out = torch.empty((Bc, npoint, cout), dtype=torch.float32, device=cur_xyz.device)
-                self._sa_scale(cur_xyz, new_xyz, cur_feat, idx, mlp, cin, out, 0)
+                self._sa_scale(cur_xyz, new_xyz, cur_feat, idx, mlp, cin, out, 0, P_pre=P_pre if len(l_feat) == 1 else None)
                 l_xyz.append(new_xyz)
             else:                                                               # GroupAll: one group of n points
                 c4 = _round4(cin)

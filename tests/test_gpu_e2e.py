@@ -116,13 +116,19 @@ def test_roipool_canonical_kernel_equals_torch_sequence():
     dxyz = (pooled[..., 0:3] - ref_xyz).abs()
     print("canonical xyz: max |diff| %.3g, differing elements %d of %d" % (float(dxyz.max()), int((dxyz > 0).sum()), dxyz.numel()))
     assert float(dxyz.max()) < 2e-5                                            # |coordinates| <= ~50 m: a few ulp at most
-    # through the RCNN
+    # through the RCNN; and the MFMA entrance chain (csrc/rcnn_point_mlp.hip) vs the library GEMMs + concat
     a = eng.rcnn_stage(st, rois)
-    F.USE_ROIPOOL_CANONICAL = False
+    F.USE_RCNN_POINT_MLP = False
     try:
+        c = eng.rcnn_stage(st, rois)
+        F.USE_ROIPOOL_CANONICAL = False
         b = eng.rcnn_stage(st, rois)
     finally:
         F.USE_ROIPOOL_CANONICAL = True
+        F.USE_RCNN_POINT_MLP = True
+    for k in ("rcnn_cls", "rcnn_reg"):
+        scale = max(1.0, float(c[k].abs().max()))
+        assert float((a[k] - c[k]).abs().max()) <= 5e-5 * scale, ("point_mlp", k, float((a[k] - c[k]).abs().max()), scale)
     for k in ("rcnn_cls", "rcnn_reg"):
         scale = max(1.0, float(b[k].abs().max()))
         assert float((a[k] - b[k]).abs().max()) <= 5e-5 * scale, (k, float((a[k] - b[k]).abs().max()), scale)

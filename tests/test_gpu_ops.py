@@ -587,6 +587,34 @@ def test_sa_xyz_mlp_fused_level(ext, oracle, c1, c2, c3, ns):
     assert ext.pointnet2.sa_xyz_mlp_supported(c1, c2, c3, ns) and not ext.pointnet2.sa_xyz_mlp_supported(c1, c2, c3, 64)
 
 
+def test_rcnn_point_mlp_kernels(ext):
+    """csrc/rcnn_point_mlp.hip (xyz_up x2 + concat + merge_down + SA1 per-point part as two MFMA kernels) vs the same
+    chain with library f32 GEMMs; NaN-initialised outputs (every tile served), bit-identical reruns, 3000 tiles."""
+    rng = np.random.default_rng(71)
+    R, ld = 64 * 3000, 136
+    rows = rng.standard_normal((R, ld)).astype(np.float32)
+    rows[:, 5:8] = 0
+    W = lambda *sh: T((rng.standard_normal(sh) / np.sqrt(sh[0])).astype(np.float32))
+    wu1 = W(8, 128); wu1[5:] = 0
+    wu2, wm, wp = W(128, 128), W(256, 128), W(128, 128)
+    bu1, bu2, bm, bp = (T(rng.standard_normal(128).astype(np.float32) * 0.1) for _ in range(4))
+    trow = T(rows)
+    outs = []
+    for _ in range(2):
+        xfeat = torch.full((R, 128), float("nan"), device=DEV)
+        p = torch.full((R, 128), float("nan"), device=DEV)
+        ext.pointnet2.rcnn_point_mlp_wrapper(trow, 8, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, p)
+        outs.append((xfeat, p))
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    x = torch.relu(torch.relu(trow[:, :8] @ wu1 + bu1) @ wu2 + bu2)
+    want = torch.relu(torch.cat((x, trow[:, 8:]), dim=1) @ wm + bm) @ wp + bp
+    assert (outs[0][0] - x).abs().max().item() <= 2e-5 * max(1.0, x.abs().max().item())
+    assert (outs[0][1] - want).abs().max().item() <= 3e-5 * max(1.0, want.abs().max().item())
+    with pytest.raises(Exception):
+        ext.pointnet2.rcnn_point_mlp_wrapper(trow[:100].contiguous(), 8, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, p)   # rows % 64
+
+
 def test_randomised_operator_sweep(ext, oracle):
     """~15 s of tests/fuzz_gpu_ops.py (random shapes across every dispatch threshold, clustered / duplicated / lattice
     clouds): FPS, ball query + grouping, three_nn + interpolation, NMS + IoU, RoI pooling bit-exact vs the oracle.
