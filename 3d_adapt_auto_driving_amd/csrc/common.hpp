@@ -25,6 +25,15 @@ int check_launch(const char *what);
 // independent users (0: ball-query grid, 1: FPS ordering).
 char *scratch_for(hipStream_t st, size_t bytes, int slot = 0);
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is fence + s_barrier, and the fence drains vmcnt as
+// well: every wave then waits at the barrier for its outstanding GLOBAL loads and stores (an HBM round trip), which
+// serialises "store this tile / prefetch the next tile" against the LDS hand-off between pipeline phases.  Use this
+// where the only data exchanged between the waves goes through LDS.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // (a-b)^2 summed left to right, one rounding per operation (no fma): the distance form of

@@ -55,124 +55,95 @@ __device__ __forceinline__ void load_panel(float (&wf)[64], const float *__restr
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// ---- kernel 1: the two xyz_up layers.  rows (R, ld): columns 0..7 = [x', y', z', mask, depth, 0, 0, 0]
-__global__ __launch_bounds__(256, 2) void rcnn_xyz_up_kernel(
-    long tiles, int ld, const float *__restrict__ rows, const float4 *__restrict__ wu1 /* (8,128) k-major */,
-    const float4 *__restrict__ bu1, const float *__restrict__ wu2 /* (128,128) k-major */, const float *__restrict__ bu2,
-    float *__restrict__ xout /* (R,128) */, unsigned int *__restrict__ ticket)
+// ---- one 128-wide layer over 64-row tiles:  out = act(A0 @ W0 [+ A1 @ W1] + bias)
+//   PRO = 0: A0 = src0 rows (128 floats at column col0, row stride ld0);   PRO = 1: A0 = relu(in5 @ Wu1 + bu1) computed by
+//   the builder from columns 0..4 of src0 (the first xyz_up layer: K = 5 is VALU work);  NPANEL = 2 adds A1 = src1 rows.
+// The inputs of the NEXT tile are fetched into registers right after this tile's builder, so the HBM latency runs
+// behind the MFMAs; barriers order LDS only (lds_barrier), they do not drain those loads.  The accumulators are staged
+// through LDS (tile 0 is dead by then) so that every output row leaves as 32 x 16-byte lanes.
+template <int NPANEL, int PRO, bool RELU>
+__global__ __launch_bounds__(256, 2) void rows_layer_kernel(
+    long tiles, int per_wg, const float *__restrict__ src0, int ld0, int col0, const float *__restrict__ src1, int ld1, int col1,
+    const float4 *__restrict__ wu1, const float4 *__restrict__ bu1, const float *__restrict__ w0, const float *__restrict__ w1,
+    const float *__restrict__ bias, float *__restrict__ out, unsigned int *__restrict__ ticket)
 {
-    __shared__ float lds[PM_ROWS * PM_LD + 4];
-    float *A1 = lds;
-    unsigned int *slot = reinterpret_cast<unsigned int *>(lds + PM_ROWS * PM_LD);
+    __shared__ float lds[NPANEL * PM_ROWS * PM_LD + 4];
+    float *T0 = lds, *T1 = lds + (NPANEL - 1) * PM_ROWS * PM_LD;
+    unsigned int *slot = reinterpret_cast<unsigned int *>(lds + NPANEL * PM_ROWS * PM_LD);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, h = lane >> 5;
-    float wf[64];
-    load_panel(wf, wu2, w, j, h);
-    const float bias2 = bu2[32 * w + j];
-    const int chunk = tid & 31;
-    float4 k1[5];                                                   // layer-1 weights of this thread's 4 channels
+    const int chunk = tid & 31, r0 = tid >> 5;
+    float wa[64], wb[NPANEL == 2 ? 64 : 1];
+    load_panel(wa, w0, w, j, h);
+    if constexpr (NPANEL == 2) load_panel(wb, w1, w, j, h);
+    const float bcol = bias[32 * w + j];
+    float4 k1[PRO ? 5 : 1], b1 = {0, 0, 0, 0};
+    if constexpr (PRO == 1) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) k1[k] = wu1[k * 32 + chunk];
-    const float4 b1 = bu1[chunk];
-
-    // tickets as in sa_mlp_fused.hip: the next tile's ticket is drawn one tile ahead and never on the last tile served
-    unsigned int *slot2 = slot;                                     // [2], double-buffered
-    if (tid == 0) slot2[0] = atomicAdd(ticket, 1u);
-    __syncthreads();
-    long t = slot2[0];
-    for (int served = 0; served < PM_TILES_PER_WG && t < tiles; ++served) {
-        const bool more = served + 1 < PM_TILES_PER_WG;
-        if (tid == 0) slot2[(served + 1) & 1] = more ? atomicAdd(ticket, 1u) : 0xffffffffu;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = (tid >> 5) + 8 * i;
-            const float *src = rows + (t * PM_ROWS + row) * ld;
-            const float4 p0 = *reinterpret_cast<const float4 *>(src);
-            const float d = src[4];
-            float4 v;
-            v.x = fmaxf(b1.x + k1[0].x * p0.x + k1[1].x * p0.y + k1[2].x * p0.z + k1[3].x * p0.w + k1[4].x * d, 0.f);
-            v.y = fmaxf(b1.y + k1[0].y * p0.x + k1[1].y * p0.y + k1[2].y * p0.z + k1[3].y * p0.w + k1[4].y * d, 0.f);
-            v.z = fmaxf(b1.z + k1[0].z * p0.x + k1[1].z * p0.y + k1[2].z * p0.z + k1[3].z * p0.w + k1[4].z * d, 0.f);
-            v.w = fmaxf(b1.w + k1[0].w * p0.x + k1[1].w * p0.y + k1[2].w * p0.z + k1[3].w * p0.w + k1[4].w * d, 0.f);
-            *reinterpret_cast<float4 *>(A1 + row * PM_LD + 4 * chunk) = v;
-        }
-        __syncthreads();
-        const long t_next = slot2[(served + 1) & 1];
-        f32x16 acc0 = {0}, acc1 = {0};
-        mfma_panel(A1, wf, acc0, acc1, j, h);
-        float *o = xout + t * PM_ROWS * PM_C + 32 * w + j;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(r, h);
-            o[(long)row * PM_C] = fmaxf(acc0[r] + bias2, 0.f);
-            o[(long)(32 + row) * PM_C] = fmaxf(acc1[r] + bias2, 0.f);
-        }
-        __syncthreads();                                            // every wave has read A1 before the next builder writes it
-        t = t_next;
+        for (int k = 0; k < 5; ++k) k1[k] = wu1[k * 32 + chunk];
+        b1 = bu1[chunk];
     }
-}
 
-// ---- kernel 2: merge_down (K = 256 as two 128-panels) + the per-point part of SA1's first layer
-__global__ __launch_bounds__(256, 1) void rcnn_merge_p_kernel(
-    long tiles, int ld, int fcol, const float *__restrict__ xfeat /* (R,128) */, const float *__restrict__ rows /* (R,ld) */,
-    const float *__restrict__ wma, const float *__restrict__ wmb, const float *__restrict__ bm,
-    const float *__restrict__ wp, const float *__restrict__ bp, float *__restrict__ pout /* (R,128) */,
-    unsigned int *__restrict__ ticket)
-{
-    extern __shared__ float dyn[];                                  // X tile, F tile, Y tile: 3 x 64 x 132 floats (+ ticket slot)
-    float *X = dyn, *F = dyn + PM_ROWS * PM_LD, *Y = dyn + 2 * PM_ROWS * PM_LD;
-    unsigned int *slot = reinterpret_cast<unsigned int *>(dyn + 3 * PM_ROWS * PM_LD);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, h = lane >> 5;
-    float wa[64], wb[64], wq[64];
-    load_panel(wa, wma, w, j, h);
-    load_panel(wb, wmb, w, j, h);
-    load_panel(wq, wp, w, j, h);
-    const float biasm = bm[32 * w + j], biasp = bp[32 * w + j];
-    const int chunk = tid & 31;
+    float4 p0[8], p1[NPANEL == 2 ? 8 : 1];
+    float pd[PRO ? 8 : 1];
+#define ROWS_FETCH(tile)                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                   \
+        const long g_ = (tile) * PM_ROWS + r0 + 8 * i;                                                                \
+        if constexpr (PRO == 1) {                                                                                     \
+            p0[i] = *reinterpret_cast<const float4 *>(src0 + g_ * ld0);                                               \
+            pd[i] = src0[g_ * ld0 + 4];                                                                               \
+        } else {                                                                                                      \
+            p0[i] = *reinterpret_cast<const float4 *>(src0 + g_ * ld0 + col0 + 4 * chunk);                            \
+        }                                                                                                             \
+        if constexpr (NPANEL == 2) p1[i] = *reinterpret_cast<const float4 *>(src1 + g_ * ld1 + col1 + 4 * chunk);     \
+    }
 
     if (tid == 0) slot[0] = atomicAdd(ticket, 1u);
-    __syncthreads();
+    lds_barrier();
     long t = slot[0];
-    for (int served = 0; served < PM_TILES_PER_WG && t < tiles; ++served) {
-        const bool more = served + 1 < PM_TILES_PER_WG;
+    if (t < tiles) { ROWS_FETCH(t) }
+    for (int served = 0; served < per_wg && t < tiles; ++served) {
+        const bool more = served + 1 < per_wg;
         if (tid == 0) slot[(served + 1) & 1] = more ? atomicAdd(ticket, 1u) : 0xffffffffu;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int row = (tid >> 5) + 8 * i;
-            const long g = t * PM_ROWS + row;
-            *reinterpret_cast<float4 *>(X + row * PM_LD + 4 * chunk) =
-                *reinterpret_cast<const float4 *>(xfeat + g * PM_C + 4 * chunk);
-            *reinterpret_cast<float4 *>(F + row * PM_LD + 4 * chunk) =
-                *reinterpret_cast<const float4 *>(rows + g * ld + fcol + 4 * chunk);
+            const int row = r0 + 8 * i;
+            float4 v = p0[i];
+            if constexpr (PRO == 1) {
+                const float4 q = p0[i];
+                const float d = pd[i];
+                v.x = fmaxf(b1.x + k1[0].x * q.x + k1[1].x * q.y + k1[2].x * q.z + k1[3].x * q.w + k1[4].x * d, 0.f);
+                v.y = fmaxf(b1.y + k1[0].y * q.x + k1[1].y * q.y + k1[2].y * q.z + k1[3].y * q.w + k1[4].y * d, 0.f);
+                v.z = fmaxf(b1.z + k1[0].z * q.x + k1[1].z * q.y + k1[2].z * q.z + k1[3].z * q.w + k1[4].z * d, 0.f);
+                v.w = fmaxf(b1.w + k1[0].w * q.x + k1[1].w * q.y + k1[2].w * q.z + k1[3].w * q.w + k1[4].w * d, 0.f);
+            }
+            *reinterpret_cast<float4 *>(T0 + row * PM_LD + 4 * chunk) = v;
+            if constexpr (NPANEL == 2) *reinterpret_cast<float4 *>(T1 + row * PM_LD + 4 * chunk) = p1[i];
         }
-        __syncthreads();
+        lds_barrier();
         const long t_next = slot[(served + 1) & 1];
-        {
-            f32x16 acc0 = {0}, acc1 = {0};
-            mfma_panel(X, wa, acc0, acc1, j, h);
-            mfma_panel(F, wb, acc0, acc1, j, h);
+        if (t_next < tiles) { ROWS_FETCH(t_next) }                  // in flight during the MFMAs below
+        f32x16 acc0 = {0}, acc1 = {0};
+        mfma_panel(T0, wa, acc0, acc1, j, h);
+        if constexpr (NPANEL == 2) mfma_panel(T1, wb, acc0, acc1, j, h);
+        lds_barrier();                                              // every wave has finished reading the tiles
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = acc_row(r, h);
-                Y[row * PM_LD + 32 * w + j] = fmaxf(acc0[r] + biasm, 0.f);
-                Y[(32 + row) * PM_LD + 32 * w + j] = fmaxf(acc1[r] + biasm, 0.f);
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, h);
+            const float v0 = acc0[r] + bcol, v1 = acc1[r] + bcol;
+            T0[row * PM_LD + 32 * w + j] = RELU ? fmaxf(v0, 0.f) : v0;
+            T0[(32 + row) * PM_LD + 32 * w + j] = RELU ? fmaxf(v1, 0.f) : v1;
         }
-        __syncthreads();
-        {
-            f32x16 acc0 = {0}, acc1 = {0};
-            mfma_panel(Y, wq, acc0, acc1, j, h);
-            float *o = pout + t * PM_ROWS * PM_C + 32 * w + j;
+        lds_barrier();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = acc_row(r, h);
-                o[(long)row * PM_C] = acc0[r] + biasp;              // linear: SA1 adds the coordinate part, then ReLU
-                o[(long)(32 + row) * PM_C] = acc1[r] + biasp;
-            }
+        for (int i = 0; i < 8; ++i) {
+            const int row = r0 + 8 * i;
+            *reinterpret_cast<float4 *>(out + (t * PM_ROWS + row) * PM_C + 4 * chunk) =
+                *reinterpret_cast<const float4 *>(T0 + row * PM_LD + 4 * chunk);
         }
-        // X / F are rewritten by the next builder: every wave passed the barrier after the first layer; Y is rewritten
-        // only after the next tile's barrier, which all waves reach after this layer
+        lds_barrier();                                              // the next builder overwrites T0
         t = t_next;
     }
+#undef ROWS_FETCH
 }
 
 unsigned int *next_ticket(hipStream_t st);    // sa_mlp_fused.hip
@@ -182,35 +153,41 @@ unsigned int *next_ticket(hipStream_t st);    // sa_mlp_fused.hip
 using namespace prcnn;
 
 // rows (r, ld) f32 = the pooled RCNN input rows [x',y',z',mask,depth,0,0,0 | 128 features at column fcol] (r % 64 == 0);
-// wu1 (8,128), wu2 (128,128), wm (256,128) = [Wm_a ; Wm_b], wp (128,128): k-major, BN folded; xfeat (r,128) scratch for X;
-// p (r,128) = relu([X | F] wm + bm) wp + bp.
+// wu1 (8,128), wu2 (128,128), wm (256,128) = [Wm_a ; Wm_b], wp (128,128): k-major, BN folded.  Three launches of
+// rows_layer_kernel:   xfeat  = relu(relu(in5 wu1 + bu1) wu2 + bu2)            (xyz_up_layer)
+//                      merged = relu(xfeat wm_a + feats wm_b + bm)               (concat + merge_down_layer)
+//                      p      = merged wp + bp                                   (per-point part of SA1's layer 1)
+// xfeat, merged, p: (r,128) each, caller-allocated.
 extern "C" int prcnn_rcnn_point_mlp(long r, int ld, int fcol, const float *rows, const float *wu1, const float *bu1,
                                     const float *wu2, const float *bu2, const float *wm, const float *bm, const float *wp,
-                                    const float *bp, float *xfeat, float *p, void *stream)
+                                    const float *bp, float *xfeat, float *merged, float *p, void *stream)
 {
     PRCNN_REQUIRE(r >= 0 && r % PM_ROWS == 0, "rcnn_point_mlp: %ld rows is not a multiple of %d", r, PM_ROWS);
     PRCNN_REQUIRE(ld >= 8 && ld % 4 == 0 && fcol >= 8 && fcol % 4 == 0 && fcol + PM_C <= ld,
                   "rcnn_point_mlp: bad row layout ld=%d fcol=%d", ld, fcol);
     if (r == 0) return PRCNN_OK;
-    PRCNN_REQUIRE(rows && wu1 && bu1 && wu2 && bu2 && wm && bm && wp && bp && xfeat && p, "rcnn_point_mlp: null pointer");
-    PRCNN_REQUIRE((((uintptr_t)rows | (uintptr_t)wu1 | (uintptr_t)bu1 | (uintptr_t)xfeat | (uintptr_t)p) & 15) == 0,
+    PRCNN_REQUIRE(rows && wu1 && bu1 && wu2 && bu2 && wm && bm && wp && bp && xfeat && merged && p, "rcnn_point_mlp: null pointer");
+    PRCNN_REQUIRE((((uintptr_t)rows | (uintptr_t)wu1 | (uintptr_t)bu1 | (uintptr_t)xfeat | (uintptr_t)merged | (uintptr_t)p) & 15) == 0,
                   "rcnn_point_mlp: 16-byte alignment required");
     hipStream_t st = (hipStream_t)stream;
     const long tiles = r / PM_ROWS;
-    const int grid = (int)((tiles + PM_TILES_PER_WG - 1) / PM_TILES_PER_WG);
-    unsigned int *t1 = next_ticket(st), *t2 = next_ticket(st);
-    if (!t1 || !t2) { set_error("rcnn_point_mlp: cannot set up the tile tickets"); return PRCNN_ELAUNCH; }
-    hipLaunchKernelGGL(rcnn_xyz_up_kernel, dim3(grid), dim3(256), 0, st, tiles, ld, rows, (const float4 *)wu1,
-                       (const float4 *)bu1, wu2, bu2, xfeat, t1);
+    // one generation of workgroups when the launch is short (tiles / slots per workgroup, tickets balance the rest);
+    // at least PM_TILES_PER_WG so that long launches still turn workgroups over
+    const long slots = 512;
+    int per_wg = (int)((tiles + slots - 1) / slots);
+    if (per_wg < PM_TILES_PER_WG) per_wg = PM_TILES_PER_WG;
+    const int grid = (int)((tiles + per_wg - 1) / per_wg);
+    unsigned int *t1 = next_ticket(st), *t2 = next_ticket(st), *t3 = next_ticket(st);
+    if (!t1 || !t2 || !t3) { set_error("rcnn_point_mlp: cannot set up the tile tickets"); return PRCNN_ELAUNCH; }
+    hipLaunchKernelGGL((rows_layer_kernel<1, 1, true>), dim3(grid), dim3(256), 0, st, tiles, per_wg, rows, ld, 0, nullptr, 0, 0,
+                       (const float4 *)wu1, (const float4 *)bu1, wu2, nullptr, bu2, xfeat, t1);
     int rc = check_launch("rcnn_point_mlp(xyz_up)");
     if (rc != PRCNN_OK) return rc;
-    const size_t lds = (size_t)(3 * PM_ROWS * PM_LD + 4) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)rcnn_merge_p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(rcnn_merge_p_kernel, dim3(grid), dim3(256), lds, st, tiles, ld, fcol, xfeat, rows, wm,
-                       wm + (size_t)PM_C * PM_C, bm, wp, bp, p, t2);
-    return check_launch("rcnn_point_mlp(merge)");
+    hipLaunchKernelGGL((rows_layer_kernel<2, 0, true>), dim3(grid), dim3(256), 0, st, tiles, per_wg, xfeat, PM_C, 0, rows, ld, fcol,
+                       nullptr, nullptr, wm, wm + (size_t)PM_C * PM_C, bm, merged, t2);
+    rc = check_launch("rcnn_point_mlp(merge)");
+    if (rc != PRCNN_OK) return rc;
+    hipLaunchKernelGGL((rows_layer_kernel<1, 0, false>), dim3(grid), dim3(256), 0, st, tiles, per_wg, merged, PM_C, 0, nullptr, 0, 0,
+                       nullptr, nullptr, wp, nullptr, bp, p, t3);
+    return check_launch("rcnn_point_mlp(sa1 per-point)");
 }

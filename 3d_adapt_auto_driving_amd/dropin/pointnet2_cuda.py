@@ -187,11 +187,12 @@ def sa_xyz_mlp_wrapper(new_xyz, xyz, idx, w1, b1, w2, b2, w3, b3, out, out_col):
     return out
 
 
-def rcnn_point_mlp_wrapper(rows, fcol, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, p):
-    """RCNN entrance chain as two MFMA kernels (csrc/rcnn_point_mlp.hip): rows (R, ld) pooled rows
-    [x',y',z',mask,depth,0,0,0 | 128 feats at column fcol] -> p (R,128) = relu([xyz_up(in5) | feats] wm + bm) wp + bp."""
-    _chk(torch.float32, rows, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, p)
+def rcnn_point_mlp_wrapper(rows, fcol, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, merged, p):
+    """RCNN entrance chain as tiled MFMA layer kernels (csrc/rcnn_point_mlp.hip): rows (R, ld) pooled rows
+    [x',y',z',mask,depth,0,0,0 | 128 feats at column fcol] -> xfeat = xyz_up(in5), merged = relu([xfeat | feats] wm + bm),
+    p = merged wp + bp, each (R,128)."""
+    _chk(torch.float32, rows, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, merged, p)
     _lib.call("prcnn_rcnn_point_mlp", rows.size(0), rows.size(1), int(fcol), rows.data_ptr(), wu1.data_ptr(), bu1.data_ptr(),
               wu2.data_ptr(), bu2.data_ptr(), wm.data_ptr(), bm.data_ptr(), wp.data_ptr(), bp.data_ptr(), xfeat.data_ptr(),
-              p.data_ptr(), _lib.current_stream(rows))
+              merged.data_ptr(), p.data_ptr(), _lib.current_stream(rows))
     return p

@@ -18,6 +18,8 @@ Values differ from the module path only by f32 rounding of the GEMMs (different 
 summation orders); indices (FPS / ball query / three-NN / NMS keep) are produced by the same
 kernels.  Parity is tested against the reference fixtures with the 1e-4 box tolerance.
 """
+import os
+
 import torch
 
 from ..pointnet2 import pointnet2_utils as pu
@@ -27,7 +29,7 @@ from .. import roipool3d_utils
 
 
 USE_ROIPOOL_CANONICAL = True   # RCNN input assembly through roipool3d_canonical_kernel (False: torch-op sequence)
-USE_RCNN_POINT_MLP = True      # RCNN entrance chain through csrc/rcnn_point_mlp.hip (False: library GEMMs + concat)
+USE_RCNN_POINT_MLP = os.environ.get("PRCNN_NO_POINT_MLP") is None      # RCNN entrance chain through csrc/rcnn_point_mlp.hip (False: library GEMMs + concat)
 USE_XYZ_MLP = True      # coordinates-only SA scales through csrc/sa_xyz_mlp.hip (False: grouped GEMM chain)
 
 
@@ -319,13 +321,12 @@ class FastPointRCNN:
         sa1 = self.rcnn_sa[0]
         if (USE_RCNN_POINT_MLP and W == 136 and rows.shape[0] % 64 == 0 and hasattr(ext_mod := pu.pointnet2, "rcnn_point_mlp_wrapper")
                 and self._point_mlp_ok()):
-            # xyz_up (2 layers) + concat + merge_down + the per-point part of SA1's layer 1: two MFMA kernels, no `merged`
+            # xyz_up (2 layers) + concat + merge_down + the per-point part of SA1's layer 1: tiled MFMA layer kernels
             (wu1, bu1, _), (wu2, bu2, _) = self.xyz_up.layers
             (wm, bm, _), = self.merge_down.layers
             wf, _, b1 = sa1[3].split
-            xfeat = torch.empty((rows.shape[0], 128), dtype=torch.float32, device=rows.device)
-            P_pre = torch.empty((rows.shape[0], 128), dtype=torch.float32, device=rows.device)
-            ext_mod.rcnn_point_mlp_wrapper(rows, 8, wu1, bu1, wu2, bu2, wm, bm, wf, b1, xfeat, P_pre)
+            xfeat, merged, P_pre = (torch.empty((rows.shape[0], 128), dtype=torch.float32, device=rows.device) for _ in range(3))
+            ext_mod.rcnn_point_mlp_wrapper(rows, 8, wu1, bu1, wu2, bu2, wm, bm, wf, b1, xfeat, merged, P_pre)
             P_pre = P_pre.view(B * M, P, 128)
             l_feat = [None]
         else:

@@ -132,14 +132,15 @@ int prcnn_sa_mlp_fused(int b, int n, int m, int nsample, int c1, int c2, int c3,
                        const float *b2, const float *w3t, const float *b3, float *out, int out_stride,
                        int out_col, void *stream);
 
-/* Entrance of the RCNN as two MFMA kernels (lib/net/rcnn_net.py:139-163 xyz_up_layer + concat + merge_down_layer,
+/* Entrance of the RCNN as MFMA kernels (lib/net/rcnn_net.py:139-163 xyz_up_layer + concat + merge_down_layer,
  * fused with the per-point part of SA1's first layer): rows (r, ld) f32 = pooled rows
  * [x',y',z',mask,depth,0,0,0 | 128 RPN features at column fcol] as prcnn_roipool3d_canonical writes them, r % 64 == 0;
  * wu1 (8,128), wu2 (128,128), wm (256,128), wp (128,128) k-major with BN folded;
- * xfeat (r,128) = scratch for the xyz_up output; p (r,128) = relu([xfeat | feats] wm + bm) wp + bp. */
+ * xfeat (r,128) = xyz_up output, merged (r,128) = relu([xfeat | feats] wm + bm), p (r,128) = merged wp + bp:
+ * three launches of one tiled MFMA layer kernel, all buffers caller-allocated. */
 int prcnn_rcnn_point_mlp(long r, int ld, int fcol, const float *rows, const float *wu1, const float *bu1,
                          const float *wu2, const float *bu2, const float *wm, const float *bm, const float *wp,
-                         const float *bp, float *xfeat, float *p, void *stream);
+                         const float *bp, float *xfeat, float *merged, float *p, void *stream);
 
 /* One whole coordinates-only set-abstraction scale (first RPN SA level: QueryAndGroup without input features ->
  * 3-layer shared MLP + ReLU -> max over nsample; pointnet2_modules.py:37-53, pointnet2_utils.py:241-264) in one

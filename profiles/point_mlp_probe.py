@@ -1,0 +1,20 @@
+"""Microbench of csrc/rcnn_point_mlp.hip at the RCNN size of one batch (8 scenes x 100 RoIs x 512 points)."""
+import importlib, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+pkg = importlib.import_module("3d_adapt_auto_driving_amd"); sys.path.insert(0, pkg.DROPIN_DIR)
+import pointnet2_cuda as P
+dev = torch.device("cuda", 0)
+R, ld = 409600, 136
+g = torch.Generator(device=dev).manual_seed(0)
+rows = torch.randn((R, ld), device=dev, generator=g)
+W = lambda *s: torch.randn(s, device=dev, generator=g) / s[0] ** 0.5
+wu1, wu2, wm, wp = W(8, 128), W(128, 128), W(256, 128), W(128, 128)
+b = [torch.randn(128, device=dev, generator=g) * 0.1 for _ in range(4)]
+xfeat, merged, p = (torch.empty((R, 128), device=dev) for _ in range(3))
+run = lambda: P.rcnn_point_mlp_wrapper(rows, 8, wu1, b[0], wu2, b[1], wm, b[2], wp, b[3], xfeat, merged, p)
+for _ in range(3): run()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10): run()
+torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 100
+print("rcnn_point_mlp: %.3f ms per call (%.1f TFLOP/s over 53.7 GFLOP)" % (ms, 2 * R * (128 * 128 * 4) / ms / 1e9))

@@ -601,18 +601,17 @@ def test_rcnn_point_mlp_kernels(ext):
     trow = T(rows)
     outs = []
     for _ in range(2):
-        xfeat = torch.full((R, 128), float("nan"), device=DEV)
-        p = torch.full((R, 128), float("nan"), device=DEV)
-        ext.pointnet2.rcnn_point_mlp_wrapper(trow, 8, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, p)
-        outs.append((xfeat, p))
-    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+        xfeat, merged, p = (torch.full((R, 128), float("nan"), device=DEV) for _ in range(3))
+        ext.pointnet2.rcnn_point_mlp_wrapper(trow, 8, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, merged, p)
+        outs.append((xfeat, p, merged))
+    assert all(torch.isfinite(o).all() for o in outs[0]) and torch.equal(outs[0][2], outs[1][2])
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     x = torch.relu(torch.relu(trow[:, :8] @ wu1 + bu1) @ wu2 + bu2)
     want = torch.relu(torch.cat((x, trow[:, 8:]), dim=1) @ wm + bm) @ wp + bp
     assert (outs[0][0] - x).abs().max().item() <= 2e-5 * max(1.0, x.abs().max().item())
     assert (outs[0][1] - want).abs().max().item() <= 3e-5 * max(1.0, want.abs().max().item())
     with pytest.raises(Exception):
-        ext.pointnet2.rcnn_point_mlp_wrapper(trow[:100].contiguous(), 8, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, p)   # rows % 64
+        ext.pointnet2.rcnn_point_mlp_wrapper(trow[:100].contiguous(), 8, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, merged, p)   # rows % 64
 
 
 def test_randomised_operator_sweep(ext, oracle):
