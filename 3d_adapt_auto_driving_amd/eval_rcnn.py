@@ -197,11 +197,21 @@ class PipelinedRunner:
         if getattr(self, "tail", None) is None:
             self.tail = torch.cuda.Stream(self.device)
             self._inflight = None
+            self._chains = []                 # geometry chains in flight: dicts pts / side / state / geo / ev
         main = torch.cuda.current_stream(self.device)
-        geo, ev = self._take(cur)
-        self._prefetch_geometry(upcoming)
-        main.wait_event(ev)
-        st = self.engine.rpn_stage(cur, geo)
+        ch = self._chain(cur)
+        if ch is None:                        # cold start: nothing was prefetched for this batch
+            ch = self._chain_begin(cur, None)
+        if ch["geo"] is None:
+            self._chain_finish(ch, None)
+        self._chains.remove(ch)
+        todo = [] if upcoming is None else (list(upcoming) if isinstance(upcoming, (list, tuple)) else [upcoming])
+        todo = [p for p in todo if p is not None][:max(1, self.depth)]
+        gated = os.environ.get("PRCNN_NO_GATE") is None
+        if not gated:                         # A/B switch: geometry of the upcoming batches starts right away
+            self._advance_chains(todo, None)
+        main.wait_event(ch["ev"])
+        st = self.engine.rpn_stage(cur, ch["geo"])
         ev_rpn = torch.cuda.Event()
         ev_rpn.record(main)
         for t in (st["rpn_scores_raw"], st["rpn_reg"], st["backbone_xyz"]):
@@ -212,9 +222,58 @@ class PipelinedRunner:
             ev_prop = torch.cuda.Event()
             ev_prop.record(self.tail)
         rois.record_stream(main)
+        # Geometry of the upcoming batches is GATED on the end of this RPN stage: the library GEMMs of the RPN stage are
+        # persistent-grid kernels that stretch 40-70 % when an FPS workgroup shares a CU with them, the RCNN stage that
+        # follows is made of ticketed kernels that do not care.  So the xyz-only chains only START during RCNN stages:
+        # the next batch finishes its chain (levels 1-3 + three-NN, ~4 ms) and the batch after it runs its first link
+        # (FPS 16384 -> 4096, ~6 ms) -- both beside RCNN(i-1), on two side streams.
+        if gated:
+            self._advance_chains(todo, ev_rpn)
         done = self._finish_inflight()
         self._inflight = (cur, st, rois, roi_scores, ev_prop)
         return done
+
+    def _advance_chains(self, todo, gate):
+        for k, nxt in enumerate(todo):
+            c = self._chain(nxt)
+            if c is None:
+                c = self._chain_begin(nxt, gate)
+                if k == 0:
+                    self._chain_finish(c, None)           # needed by the very next submit: same gate, same stream
+            elif c["geo"] is None and k == 0:
+                self._chain_finish(c, gate)
+
+    def _chain(self, pts):
+        for c in self._chains:
+            if c["pts"] is pts:
+                return c
+        return None
+
+    def _chain_begin(self, pts, gate):
+        side = self.sides[self._next_side % len(self.sides)]
+        self._next_side += 1
+        if gate is None:
+            side.wait_stream(torch.cuda.current_stream(self.device))     # pts is ready on the calling stream
+        else:
+            side.wait_event(gate)
+        with torch.cuda.stream(side):
+            state = self.engine.geometry_begin(pts)
+        c = {"pts": pts, "side": side, "state": state, "geo": None, "ev": None}
+        self._chains.append(c)
+        return c
+
+    def _chain_finish(self, c, gate):
+        side = c["side"]
+        if gate is not None:
+            side.wait_event(gate)
+        with torch.cuda.stream(side):
+            c["geo"] = self.engine.geometry_finish(c["state"])
+            c["ev"] = torch.cuda.Event()
+            c["ev"].record(side)
+        c["state"] = None
+        main = torch.cuda.current_stream(self.device)
+        for t in _tensors(c["geo"]):                  # consumed on the feature stream: tell the caching allocator
+            t.record_stream(main)
 
     def _finish_inflight(self):
         if self._inflight is None:
@@ -443,12 +502,12 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
     # software pipeline: while batch i is on the device, batch i+1 is loaded and (three-stream runner) the RCNN +
     # final stage of batch i-1 complete; results are consumed one batch late
     prev = None
-    nxt, nxt_ids, nxt_meta = load(0)
+    ahead = [load(0), load(batch_size)]              # two batches ahead: the runner starts their geometry chains early
     for s in range(0, len(scene_ids), batch_size):
-        pts, ids, meta = nxt, nxt_ids, nxt_meta
-        nxt, nxt_ids, nxt_meta = load(s + batch_size)
+        pts, ids, meta = ahead.pop(0)
+        ahead.append(load(s + 2 * batch_size))
         if runner is not None:
-            det = runner.submit(pts, nxt)
+            det = runner.submit(pts, [a[0] for a in ahead])
             if det is not None:
                 finish(det, *prev)
             prev = (ids, meta)

@@ -141,23 +141,39 @@ class FastPointRCNN:
 
     # ------------------------------------------------------------------ geometry (xyz only)
     @torch.no_grad()
-    def geometry(self, xyz):
-        """FPS / ball-query / three-NN of the RPN backbone for xyz (B,N,3)."""
-        levels, l_xyz = [], [xyz]
-        for npoint, scales in self.sa:
-            cur = l_xyz[-1]
-            sel = pu.furthest_point_sample(cur, npoint)
-            new_xyz = torch.gather(cur, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
-            idxs = [pu.ball_query(radius, ns, cur, new_xyz) for radius, ns, _, _ in scales]
-            levels.append({"sel": sel, "new_xyz": new_xyz, "idx": idxs})
-            l_xyz.append(new_xyz)
+    def geometry_begin(self, xyz):
+        """First (and by far longest) link of the xyz-only chain: FPS + ball queries of SA level 0."""
+        state = {"l_xyz": [xyz], "sa": []}
+        self._geometry_level(state, 0)
+        return state
+
+    @torch.no_grad()
+    def geometry_finish(self, state):
+        """Remaining SA levels and the three-NN of every FP level -> the geometry dict ``forward`` consumes."""
+        for k in range(len(state["sa"]), len(self.sa)):
+            self._geometry_level(state, k)
+        l_xyz = state["l_xyz"]
         interp = []
         for k in range(len(self.fp)):      # FP level k: unknown = l_xyz[k], known = l_xyz[k+1]
             dist, idx = pu.three_nn(l_xyz[k], l_xyz[k + 1])
             dist_recip = 1.0 / (dist + 1e-8)
             weight = (dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)).contiguous()
             interp.append((idx, weight))
-        return {"l_xyz": l_xyz, "sa": levels, "fp": interp}
+        return {"l_xyz": l_xyz, "sa": state["sa"], "fp": interp}
+
+    def _geometry_level(self, state, k):
+        npoint, scales = self.sa[k]
+        cur = state["l_xyz"][-1]
+        sel = pu.furthest_point_sample(cur, npoint)
+        new_xyz = torch.gather(cur, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        idxs = [pu.ball_query(radius, ns, cur, new_xyz) for radius, ns, _, _ in scales]
+        state["sa"].append({"sel": sel, "new_xyz": new_xyz, "idx": idxs})
+        state["l_xyz"].append(new_xyz)
+
+    @torch.no_grad()
+    def geometry(self, xyz):
+        """FPS / ball-query / three-NN of the RPN backbone for xyz (B,N,3)."""
+        return self.geometry_finish(self.geometry_begin(xyz))
 
     # ------------------------------------------------------------------ building blocks
     @staticmethod
