@@ -42,6 +42,7 @@ SIGNATURES = {
     "prcnn_nms": [_I, _P, _P, _F, _P],
     "prcnn_nms_normal": [_I, _P, _P, _F, _P],
     "prcnn_nms_device": [_I, _I, _P, _P, _F, _I, _I, _P, _P, _P],
+    "prcnn_rows_gemm128": [_L, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P],
     "prcnn_rcnn_point_mlp": [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_sa_xyz_mlp_supported": [_I, _I, _I, _I],
     "prcnn_sa_xyz_mlp": [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],

@@ -191,3 +191,34 @@ extern "C" int prcnn_rcnn_point_mlp(long r, int ld, int fcol, const float *rows,
                        nullptr, nullptr, wp, nullptr, bp, p, t3);
     return check_launch("rcnn_point_mlp(sa1 per-point)");
 }
+
+
+// out (r,128) = act(A0 @ w[0:128] [+ A1 @ w[128:256]] + bias) for r % 64 == 0 rows: the layer kernel above as a general
+// entry for the 128-wide shared-MLP / Conv1d layers of the network (FP level 0, the first layers of the RPN heads, the
+// per-point parts of SA levels).  A0 = src0 rows (128 floats at column col0, row stride ld0); npanel = 2 adds
+// A1 = src1 rows (col1, ld1), i.e. a K = 256 layer whose input is two 128-wide halves (of one tensor or of two).
+extern "C" int prcnn_rows_gemm128(long r, int npanel, const float *src0, int ld0, int col0, const float *src1, int ld1,
+                                  int col1, const float *w, const float *bias, int relu, float *out, void *stream)
+{
+    PRCNN_REQUIRE(r >= 0 && r % PM_ROWS == 0, "rows_gemm128: %ld rows is not a multiple of %d", r, PM_ROWS);
+    PRCNN_REQUIRE(npanel == 1 || npanel == 2, "rows_gemm128: npanel must be 1 or 2");
+    PRCNN_REQUIRE(ld0 % 4 == 0 && col0 % 4 == 0 && col0 >= 0 && col0 + PM_C <= ld0, "rows_gemm128: bad layout of source 0");
+    PRCNN_REQUIRE(npanel == 1 || (ld1 % 4 == 0 && col1 % 4 == 0 && col1 >= 0 && col1 + PM_C <= ld1), "rows_gemm128: bad layout of source 1");
+    if (r == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(src0 && w && bias && out && (npanel == 1 || src1), "rows_gemm128: null pointer");
+    PRCNN_REQUIRE((((uintptr_t)src0 | (uintptr_t)out | (npanel == 2 ? (uintptr_t)src1 : 0)) & 15) == 0, "rows_gemm128: 16-byte alignment required");
+    hipStream_t st = (hipStream_t)stream;
+    const long tiles = r / PM_ROWS;
+    int per_wg = (int)((tiles + 511) / 512);
+    if (per_wg < PM_TILES_PER_WG) per_wg = PM_TILES_PER_WG;
+    const int grid = (int)((tiles + per_wg - 1) / per_wg);
+    unsigned int *t = next_ticket(st);
+    if (!t) { set_error("rows_gemm128: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
+    const float *w1 = w + (size_t)PM_C * PM_C;
+#define LAUNCH(NP, RL) hipLaunchKernelGGL((rows_layer_kernel<NP, 0, RL>), dim3(grid), dim3(256), 0, st, tiles, per_wg, src0, ld0, col0, \
+                                          src1, ld1, col1, nullptr, nullptr, w, w1, bias, out, t)
+    if (npanel == 1) { if (relu) LAUNCH(1, true); else LAUNCH(1, false); }
+    else             { if (relu) LAUNCH(2, true); else LAUNCH(2, false); }
+#undef LAUNCH
+    return check_launch("rows_gemm128");
+}

@@ -196,3 +196,19 @@ def rcnn_point_mlp_wrapper(rows, fcol, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat
               wu2.data_ptr(), bu2.data_ptr(), wm.data_ptr(), bm.data_ptr(), wp.data_ptr(), bp.data_ptr(), xfeat.data_ptr(),
               merged.data_ptr(), p.data_ptr(), _lib.current_stream(rows))
     return p
+
+
+def rows_gemm128_wrapper(a, wt, bias, relu, out=None):
+    """a (R, K) with K in (128, 256), row stride a.stride(0), unit column stride -> act(a @ wt + bias) (R, 128) on the tiled
+    MFMA layer kernel (csrc/rcnn_point_mlp.hip); R % 64 == 0, wt (K,128) k-major."""
+    if a.dim() != 2 or a.stride(1) != 1 or not a.is_cuda or a.dtype != torch.float32:
+        raise RuntimeError("pointnet2_cuda: rows_gemm128 expects a 2-D float32 CUDA matrix with unit column stride")
+    _chk(torch.float32, wt, bias)
+    R, K = a.shape
+    if out is None:
+        out = torch.empty((R, 128), dtype=torch.float32, device=a.device)
+    ld = a.stride(0)
+    off1 = a.data_ptr() + 128 * 4
+    _lib.call("prcnn_rows_gemm128", R, K // 128, a.data_ptr(), ld, 0, off1 if K == 256 else None, ld, 0, wt.data_ptr(),
+              bias.data_ptr(), int(bool(relu)), out.data_ptr(), _lib.current_stream(a))
+    return out

@@ -37,9 +37,19 @@ def _round4(c):
     return (c + 3) // 4 * 4
 
 
+# 128-wide layers (FP level 0, first layers of the RPN heads, per-point parts of SA levels) on the own tiled MFMA layer kernel
+# instead of library GEMMs: measured neutral (837-840 vs 844 scenes/s) at these smaller shapes, so it is opt-in
+USE_ROWS_GEMM128 = os.environ.get("PRCNN_ROWS_GEMM") is not None
+
+
 def gemm_bias_act(a, wt, bias, relu):
-    """a (rows, K) @ wt (K, Cout) + bias, optional ReLU, epilogue fused in the GEMM when the
-    backend offers it (hipBLASLt through torch._addmm_activation)."""
+    """a (rows, K) @ wt (K, Cout) + bias, optional ReLU.  128-wide layers with K in (128, 256) run on the tiled MFMA layer
+    kernel of csrc/rcnn_point_mlp.hip when USE_ROWS_GEMM128 is set; everything else is a
+    library GEMM with the epilogue fused when the backend offers it (hipBLASLt through torch._addmm_activation)."""
+    if (USE_ROWS_GEMM128 and a.is_cuda and wt.shape[1] == 128 and wt.shape[0] in (128, 256) and a.shape[1] == wt.shape[0]
+            and a.shape[0] % 64 == 0 and a.shape[0] >= 4096 and a.stride(1) == 1 and a.stride(0) % 4 == 0
+            and a.data_ptr() % 16 == 0 and hasattr(pu.pointnet2, "rows_gemm128_wrapper")):
+        return pu.pointnet2.rows_gemm128_wrapper(a, wt, bias, relu)
     if relu:
         try:
             return torch._addmm_activation(bias, a, wt)
@@ -187,7 +197,7 @@ class FastPointRCNN:
                                            mlp.layers[2][0].shape[1], ns)):
             # whole scale in ONE hand-written MFMA kernel: gather -> 3 layers -> max, no HBM activations
             wf, wx, b1 = mlp.split
-            P = P_pre if P_pre is not None else torch.addmm(b1, feats.view(B * N, cin), wf).view(B, N, -1)
+            P = P_pre if P_pre is not None else gemm_bias_act(feats.view(B * N, cin), wf, b1, False).view(B, N, -1)
             ext.sa_mlp_fused_wrapper(new_xyz, xyz, P, wx, idx, mlp.layers[1][0], mlp.layers[1][1],
                                      mlp.layers[2][0], mlp.layers[2][1], out, out_col)
             return

@@ -142,6 +142,12 @@ int prcnn_rcnn_point_mlp(long r, int ld, int fcol, const float *rows, const floa
                          const float *wu2, const float *bu2, const float *wm, const float *bm, const float *wp,
                          const float *bp, float *xfeat, float *merged, float *p, void *stream);
 
+/* One 128-wide shared-MLP / Conv1d layer (pytorch_utils.py:35-101 with BN folded) on the same tiled MFMA kernel:
+ * out (r,128) = act(A0 w[0:128] [+ A1 w[128:256]] + bias), r % 64 == 0; A0 = src0 rows (128 floats at column col0, row
+ * stride ld0), npanel = 2 adds A1 = src1 rows (col1, ld1): a K = 256 layer over two 128-wide halves. w k-major. */
+int prcnn_rows_gemm128(long r, int npanel, const float *src0, int ld0, int col0, const float *src1, int ld1, int col1,
+                       const float *w, const float *bias, int relu, float *out, void *stream);
+
 /* One whole coordinates-only set-abstraction scale (first RPN SA level: QueryAndGroup without input features ->
  * 3-layer shared MLP + ReLU -> max over nsample; pointnet2_modules.py:37-53, pointnet2_utils.py:241-264) in one
  * VALU kernel: a grouped row lives in one lane from the gather to the max, weights are scalar operands.

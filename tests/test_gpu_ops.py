@@ -614,6 +614,23 @@ def test_rcnn_point_mlp_kernels(ext):
         ext.pointnet2.rcnn_point_mlp_wrapper(trow[:100].contiguous(), 8, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, merged, p)   # rows % 64
 
 
+@pytest.mark.parametrize("K,relu", [(128, True), (128, False), (256, True), (256, False)])
+def test_rows_gemm128_layer(ext, K, relu):
+    """The tiled MFMA layer kernel as a general 128-wide layer: contiguous and row-strided inputs vs torch f32."""
+    rng = np.random.default_rng(K + int(relu))
+    R = 64 * 333
+    wt = T((rng.standard_normal((K, 128)) / np.sqrt(K)).astype(np.float32))
+    b = T(rng.standard_normal(128).astype(np.float32) * 0.1)
+    wide = T(rng.standard_normal((R, K + 8)).astype(np.float32))
+    for a in (wide[:, :K].contiguous(), wide[:, 4:4 + K] if False else wide[:, 8:8 + K]):   # contiguous; strided (ld = K+8, col 8)
+        out = torch.full((R, 128), float("nan"), device=DEV)
+        ext.pointnet2.rows_gemm128_wrapper(a, wt, b, relu, out)
+        want = a @ wt + b
+        want = torch.relu(want) if relu else want
+        assert torch.isfinite(out).all()
+        assert (out - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+
+
 def test_randomised_operator_sweep(ext, oracle):
     """~15 s of tests/fuzz_gpu_ops.py (random shapes across every dispatch threshold, clustered / duplicated / lattice
     clouds): FPS, ball query + grouping, three_nn + interpolation, NMS + IoU, RoI pooling bit-exact vs the oracle.
