@@ -44,7 +44,8 @@ constexpr int SA_LD = SA_C + 4;    // LDS row stride in floats
 constexpr int SA_TILES_PER_WG = 8;
 
 // C3 = 128: two workgroups per CU (2 waves per SIMD, <= 256 registers each) so that one workgroup's tile
-// builder / epilogues run beside the other's MFMAs; C3 = 256 needs ~440 registers -> one per CU.
+// builder / epilogues run beside the other's MFMAs.  (C3 = 256 would need ~440 registers in this form -> one wave per
+// SIMD; it has its own eight-wave kernel below.)
 template <int C3>
 __global__ __launch_bounds__(256, (C3 == 128 ? 2 : 1)) void sa_mlp_fused_kernel(
     int n, int m, long tiles, const float *__restrict__ new_xyz, const float *__restrict__ xyz,
@@ -188,6 +189,120 @@ __global__ __launch_bounds__(256, (C3 == 128 ? 2 : 1)) void sa_mlp_fused_kernel(
     }
 }
 
+// ---- C3 = 256 with EIGHT waves per workgroup (one workgroup per CU, two waves per SIMD).
+// The four-wave form above needs ~440 registers per lane at C3 = 256 (three weight panels), i.e. one wave per SIMD, and
+// everything that is not an MFMA (tile builder, epilogues, barriers) then runs with the matrix pipe idle.  Here the three
+// panels are spread over eight waves: wave w owns column panel (w & 3) of layer 2 for row half (w >> 2), and column panel
+// (w & 3) of column tile (w >> 2) of layer 3 for both row halves -- 64 + 64 weight registers per lane, two waves per SIMD,
+// the non-MFMA phases are shared by twice as many threads.  Each SIMD still sees two independent accumulator chains.
+__global__ __launch_bounds__(512, 1) void sa_mlp_fused256_kernel(
+    int n, int m, long tiles, const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+    const float4 *__restrict__ P, const float4 *__restrict__ wxyz, const int *__restrict__ idx,
+    const float *__restrict__ w2t, const float *__restrict__ b2, const float *__restrict__ w3t /* (128,256) */,
+    const float *__restrict__ b3, float *__restrict__ out, int out_stride, int out_col,
+    unsigned int *__restrict__ ticket, int tiles_per_wg)
+{
+    __shared__ float lds[2 * SA_NS * SA_LD + 4];
+    float *A1 = lds, *Y1 = lds + SA_NS * SA_LD;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, wp = w & 3, wg = w >> 2;     // panel, group (row half / column tile)
+    const int j = lane & 31, h = lane >> 5;
+
+    float wf2[64], wf3[64];
+#pragma unroll
+    for (int s = 0; s < 64; ++s) wf2[s] = w2t[(long)(s + 64 * h) * SA_C + 32 * wp + j];
+#pragma unroll
+    for (int s = 0; s < 64; ++s) wf3[s] = w3t[(long)(s + 64 * h) * 256 + 128 * wg + 32 * wp + j];
+    const float bias2 = b2[32 * wp + j], bias3 = b3[128 * wg + 32 * wp + j];
+
+    // tile builder: thread owns 16-byte chunk (tid & 31) of rows (tid >> 5) + 16 i, i < 4
+    const int chunk = tid & 31;
+    const float4 wx = wxyz[chunk], wy = wxyz[32 + chunk], wz = wxyz[64 + chunk];
+
+    unsigned int *slot = reinterpret_cast<unsigned int *>(lds + 2 * SA_NS * SA_LD);
+    if (tid == 0) slot[0] = atomicAdd(ticket, 1u);
+    __syncthreads();
+    long t = slot[0];
+    int kidx[4];
+    if (t < tiles) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kidx[i] = idx[t * SA_NS + (tid >> 5) + 16 * i];
+    }
+    for (int served = 0; served < tiles_per_wg && t < tiles; ++served) {
+        const long b = t / m;
+        const float *ct3 = new_xyz + t * 3;
+        const float cx = ct3[0], cy = ct3[1], cz = ct3[2];
+        const bool more = served + 1 < tiles_per_wg;
+        if (tid == 0) slot[(served + 1) & 1] = more ? atomicAdd(ticket, 1u) : 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 5) + 16 * i;
+            const int k = kidx[i];
+            const float *pt = xyz + (b * n + k) * 3;
+            const float dx = pt[0] - cx, dy = pt[1] - cy, dz = pt[2] - cz;
+            const float4 base = P[(b * n + k) * (SA_C / 4) + chunk];
+            float4 v;
+            v.x = fmaxf(base.x + wx.x * dx + wy.x * dy + wz.x * dz, 0.f);
+            v.y = fmaxf(base.y + wx.y * dx + wy.y * dy + wz.y * dz, 0.f);
+            v.z = fmaxf(base.z + wx.z * dx + wy.z * dy + wz.z * dz, 0.f);
+            v.w = fmaxf(base.w + wx.w * dx + wy.w * dy + wz.w * dz, 0.f);
+            *reinterpret_cast<float4 *>(A1 + row * SA_LD + 4 * chunk) = v;
+        }
+        __syncthreads();
+        const long t_next = slot[(served + 1) & 1];
+        if (t_next < tiles) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kidx[i] = idx[t_next * SA_NS + (tid >> 5) + 16 * i];
+        }
+
+        // ---- layer 2: rows [32 wg, 32 wg + 32) x columns [32 wp, 32 wp + 32)
+        {
+            f32x16 acc = {0};
+            const float *ap = A1 + (32 * wg + j) * SA_LD + 64 * h;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float4 a = *reinterpret_cast<const float4 *>(ap + 4 * g);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wf2[4 * g + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wf2[4 * g + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wf2[4 * g + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wf2[4 * g + 3], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * wg + (r & 3) + 8 * (r >> 2) + 4 * h;
+                Y1[row * SA_LD + 32 * wp + j] = fmaxf(acc[r] + bias2, 0.f);
+            }
+        }
+        __syncthreads();
+
+        // ---- layer 3: all 64 rows x columns [128 wg + 32 wp, +32), then max over the rows
+        {
+            const float *a0p = Y1 + j * SA_LD + 64 * h;
+            const float *a1p = Y1 + (32 + j) * SA_LD + 64 * h;
+            f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float4 a0 = *reinterpret_cast<const float4 *>(a0p + 4 * g);
+                const float4 a1 = *reinterpret_cast<const float4 *>(a1p + 4 * g);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wf3[4 * g + 0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wf3[4 * g + 0], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wf3[4 * g + 1], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, wf3[4 * g + 1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, wf3[4 * g + 2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, wf3[4 * g + 2], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, wf3[4 * g + 3], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wf3[4 * g + 3], acc1, 0, 0, 0);
+            }
+            float mx = fmaxf(acc0[0], acc1[0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(acc0[r], acc1[r]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (h == 0) out[t * out_stride + out_col + 128 * wg + 32 * wp + j] = fmaxf(mx + bias3, 0.f);
+        }
+        t = t_next;
+    }
+}
+
 }  // namespace prcnn
 
 namespace prcnn {
@@ -230,7 +345,7 @@ extern "C" int prcnn_sa_mlp_fused(int b, int n, int m, int nsample, int c1, int 
         hipLaunchKernelGGL(sa_mlp_fused_kernel<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, m, tiles, new_xyz,
                            xyz, (const float4 *)P, (const float4 *)wxyz, idx, w2t, b2, w3t, b3, out, out_stride, out_col, ticket, per_wg);
     else
-        hipLaunchKernelGGL(sa_mlp_fused_kernel<256>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, m, tiles, new_xyz,
+        hipLaunchKernelGGL(sa_mlp_fused256_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, n, m, tiles, new_xyz,
                            xyz, (const float4 *)P, (const float4 *)wxyz, idx, w2t, b2, w3t, b3, out, out_stride, out_col, ticket, per_wg);
     return check_launch("sa_mlp_fused");
 }
