@@ -253,6 +253,37 @@ def test_full_size_engine_is_complete_deterministic_and_equals_module_path():
         assert nm >= 3 and matched >= 0.8 * nm and worst < 1e-3, (worst, matched, nm, ng)
 
 
+@pytest.mark.parametrize("B", [1, 3])
+def test_full_size_engine_other_batch_sizes(B):
+    """The same engine-vs-module comparison at batch sizes 1 and 3 (tile counts that are not multiples of the workgroup
+    quota, odd grids), three-stream runner included."""
+    C, E, F, S = pkg("config"), pkg("eval_rcnn"), pkg("net.fast_infer"), pkg("synth")
+    cfg = C.default_eval_cfg()
+    model = E.build_model(cfg, DEV, seed=11)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if ("reg_layer" in name or "cls_layer" in name) and p.dim() > 1:
+                p.copy_((torch.randn(p.shape, generator=g) * 0.3).to(DEV))
+        model.rcnn_net.cls_layer[-1].conv.weight.mul_(0.05)
+        model.rcnn_net.cls_layer[-1].conv.bias.fill_(0.5)
+    pts = torch.from_numpy(S.scenes(B, cfg.RPN.NUM_POINTS, seed0=300 + B)).to(DEV)
+    runner = E.PipelinedRunner(model, cfg, DEV)
+    assert runner.submit(pts, None) is None
+    d1 = runner.flush()
+    d1["ready"].synchronize()
+    d2 = E.infer_batch(model, cfg, pts, engine=runner.engine)
+    dm = E.infer_batch(model, cfg, pts)
+    for k in ("rois", "rcnn_cls", "rcnn_reg", "boxes", "scores", "num"):
+        assert torch.equal(d1[k], d2[k]), k
+    for b in range(B):
+        worst, matched = match_boxes(d1["rois"][b].cpu().numpy(), dm["rois"][b].cpu().numpy())
+        assert matched >= 0.95 * dm["rois"].shape[1] and worst < 1e-3
+        ng, nm = int(d1["num"][b]), int(dm["num"][b])
+        worst, matched = match_boxes(d1["boxes"][b, :ng].cpu().numpy(), dm["boxes"][b, :nm].cpu().numpy())
+        assert nm >= 3 and matched >= 0.8 * nm and worst < 1e-3, (worst, matched, nm, ng)
+
+
 def test_postprocess_batched_equals_per_scene_reference_order():
     """The batched device tail (masked sort + batched NMS) == the reference's per-scene loop
     (eval_rcnn.py:611-629) run with the blocking drop-in API on the same device tensors."""
