@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256, 2) void rows_layer_kernel(
         b1 = bu1[chunk];
     }
 
+    constexpr bool PF = (NPANEL == 1);   // two panels: 128 weight registers leave no room for a 64-register prefetch
     float4 p0[8], p1[NPANEL == 2 ? 8 : 1];
     float pd[PRO ? 8 : 1];
 #define ROWS_FETCH(tile)                                                                                              \
@@ -100,10 +101,11 @@ __global__ __launch_bounds__(256, 2) void rows_layer_kernel(
     if (tid == 0) slot[0] = atomicAdd(ticket, 1u);
     lds_barrier();
     long t = slot[0];
-    if (t < tiles) { ROWS_FETCH(t) }
+    if (PF && t < tiles) { ROWS_FETCH(t) }
     for (int served = 0; served < per_wg && t < tiles; ++served) {
         const bool more = served + 1 < per_wg;
         if (tid == 0) slot[(served + 1) & 1] = more ? atomicAdd(ticket, 1u) : 0xffffffffu;
+        if (!PF) { ROWS_FETCH(t) }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = r0 + 8 * i;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void rows_layer_kernel(
         }
         lds_barrier();
         const long t_next = slot[(served + 1) & 1];
-        if (t_next < tiles) { ROWS_FETCH(t_next) }                  // in flight during the MFMAs below
+        if (PF && t_next < tiles) { ROWS_FETCH(t_next) }            // in flight during the MFMAs below
         f32x16 acc0 = {0}, acc1 = {0};
         mfma_panel(T0, wa, acc0, acc1, j, h);
         if constexpr (NPANEL == 2) mfma_panel(T1, wb, acc0, acc1, j, h);
