@@ -113,10 +113,10 @@ __global__ __launch_bounds__(256, 2) void rows_layer_kernel(
             if constexpr (PRO == 1) {
                 const float4 q = p0[i];
                 const float d = pd[i];
-                v.x = fmaxf(b1.x + k1[0].x * q.x + k1[1].x * q.y + k1[2].x * q.z + k1[3].x * q.w + k1[4].x * d, 0.f);
-                v.y = fmaxf(b1.y + k1[0].y * q.x + k1[1].y * q.y + k1[2].y * q.z + k1[3].y * q.w + k1[4].y * d, 0.f);
-                v.z = fmaxf(b1.z + k1[0].z * q.x + k1[1].z * q.y + k1[2].z * q.z + k1[3].z * q.w + k1[4].z * d, 0.f);
-                v.w = fmaxf(b1.w + k1[0].w * q.x + k1[1].w * q.y + k1[2].w * q.z + k1[3].w * q.w + k1[4].w * d, 0.f);
+                v.x = fmaxf(fmaf(k1[4].x, d, fmaf(k1[3].x, q.w, fmaf(k1[2].x, q.z, fmaf(k1[1].x, q.y, fmaf(k1[0].x, q.x, b1.x))))), 0.f);
+                v.y = fmaxf(fmaf(k1[4].y, d, fmaf(k1[3].y, q.w, fmaf(k1[2].y, q.z, fmaf(k1[1].y, q.y, fmaf(k1[0].y, q.x, b1.y))))), 0.f);
+                v.z = fmaxf(fmaf(k1[4].z, d, fmaf(k1[3].z, q.w, fmaf(k1[2].z, q.z, fmaf(k1[1].z, q.y, fmaf(k1[0].z, q.x, b1.z))))), 0.f);
+                v.w = fmaxf(fmaf(k1[4].w, d, fmaf(k1[3].w, q.w, fmaf(k1[2].w, q.z, fmaf(k1[1].w, q.y, fmaf(k1[0].w, q.x, b1.w))))), 0.f);
             }
             *reinterpret_cast<float4 *>(T0 + row * PM_LD + 4 * chunk) = v;
             if constexpr (NPANEL == 2) *reinterpret_cast<float4 *>(T1 + row * PM_LD + 4 * chunk) = p1[i];

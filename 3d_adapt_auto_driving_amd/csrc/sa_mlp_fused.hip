@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, (C3 == 128 ? 2 : 1)) void sa_mlp_fused_kernel(
         // workgroup serves: a ticket drawn and not served would be a tile nobody computes.
         const bool more = served + 1 < tiles_per_wg;
         if (tid == 0) slot[(served + 1) & 1] = more ? atomicAdd(ticket, 1u) : 0xffffffffu;
-        // ---- layer 1 into LDS
+        // ---- layer 1 into LDS (fused multiply-adds: this arithmetic decides no index, the GEMM it feeds uses FMAs too)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = (tid >> 5) + 8 * i;
@@ -110,10 +110,10 @@ __global__ __launch_bounds__(256, (C3 == 128 ? 2 : 1)) void sa_mlp_fused_kernel(
             const float dx = pt[0] - cx, dy = pt[1] - cy, dz = pt[2] - cz;
             const float4 base = P[(b * n + k) * (SA_C / 4) + chunk];
             float4 v;
-            v.x = fmaxf(base.x + wx.x * dx + wy.x * dy + wz.x * dz, 0.f);
-            v.y = fmaxf(base.y + wx.y * dx + wy.y * dy + wz.y * dz, 0.f);
-            v.z = fmaxf(base.z + wx.z * dx + wy.z * dy + wz.z * dz, 0.f);
-            v.w = fmaxf(base.w + wx.w * dx + wy.w * dy + wz.w * dz, 0.f);
+            v.x = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, base.x))), 0.f);
+            v.y = fmaxf(fmaf(wz.y, dz, fmaf(wy.y, dy, fmaf(wx.y, dx, base.y))), 0.f);
+            v.z = fmaxf(fmaf(wz.z, dz, fmaf(wy.z, dy, fmaf(wx.z, dx, base.z))), 0.f);
+            v.w = fmaxf(fmaf(wz.w, dz, fmaf(wy.w, dy, fmaf(wx.w, dx, base.w))), 0.f);
             *reinterpret_cast<float4 *>(A1 + row * SA_LD + 4 * chunk) = v;
         }
         __syncthreads();
@@ -242,10 +242,10 @@ __global__ __launch_bounds__(512, 1) void sa_mlp_fused256_kernel(
             const float dx = pt[0] - cx, dy = pt[1] - cy, dz = pt[2] - cz;
             const float4 base = P[(b * n + k) * (SA_C / 4) + chunk];
             float4 v;
-            v.x = fmaxf(base.x + wx.x * dx + wy.x * dy + wz.x * dz, 0.f);
-            v.y = fmaxf(base.y + wx.y * dx + wy.y * dy + wz.y * dz, 0.f);
-            v.z = fmaxf(base.z + wx.z * dx + wy.z * dy + wz.z * dz, 0.f);
-            v.w = fmaxf(base.w + wx.w * dx + wy.w * dy + wz.w * dz, 0.f);
+            v.x = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, base.x))), 0.f);
+            v.y = fmaxf(fmaf(wz.y, dz, fmaf(wy.y, dy, fmaf(wx.y, dx, base.y))), 0.f);
+            v.z = fmaxf(fmaf(wz.z, dz, fmaf(wy.z, dy, fmaf(wx.z, dx, base.z))), 0.f);
+            v.w = fmaxf(fmaf(wz.w, dz, fmaf(wy.w, dy, fmaf(wx.w, dx, base.w))), 0.f);
             *reinterpret_cast<float4 *>(A1 + row * SA_LD + 4 * chunk) = v;
         }
         __syncthreads();
