@@ -28,6 +28,8 @@
 //     as layer 3's A operand; layer 3's result is max-reduced over the tile's 64 rows (16 accumulator
 //     registers x 2 row halves per lane, then one cross-half shuffle) and 32 lanes store 128 bytes.
 #include "common.hpp"
+#include <map>
+#include <mutex>
 #include <stdlib.h>
 
 namespace prcnn {
@@ -306,13 +308,21 @@ __global__ __launch_bounds__(512, 1) void sa_mlp_fused256_kernel(
 }  // namespace prcnn
 
 namespace prcnn {
-// 64 rotating ticket words per process (one launch uses one; zeroed by a memset on the same stream)
-static unsigned int *g_tickets = nullptr;
-static unsigned int g_ticket_next = 0;
+// Tile-ticket words: a ring of 64 words PER STREAM (slot 6 of the per-stream scratch).  One launch uses one word, zeroed by
+// a memset queued on the same stream just before it; a word is reused 64 launches later on that same stream, i.e. strictly
+// after the launch that used it (stream order) -- launches of other streams never touch it.
+static std::mutex g_ticket_mu;
+static std::map<hipStream_t, unsigned int> g_ticket_next;
 unsigned int *next_ticket(hipStream_t st)
 {
-    if (!g_tickets && hipMalloc((void **)&g_tickets, 64 * sizeof(unsigned int)) != hipSuccess) return nullptr;
-    unsigned int *t = g_tickets + (g_ticket_next++ & 63);
+    unsigned int *ring = reinterpret_cast<unsigned int *>(scratch_for(st, 64 * sizeof(unsigned int), 6));
+    if (!ring) return nullptr;
+    unsigned int k;
+    {
+        std::lock_guard<std::mutex> lock(g_ticket_mu);
+        k = g_ticket_next[st]++;
+    }
+    unsigned int *t = ring + (k & 63);
     if (hipMemsetAsync(t, 0, sizeof(unsigned int), st) != hipSuccess) return nullptr;
     return t;
 }
