@@ -1,50 +1,58 @@
-"""PointRCNN = RPN -> proposal layer -> RCNN (inference flow of pointrcnn/lib/net/point_rcnn.py:8-70).
-Top-level children are named ``rpn`` and ``rcnn_net`` (checkpoint keys)."""
+"""Two-stage detector assembled from an RPN, its proposal layer and the RCNN refinement head
+(inference flow of pointrcnn/lib/net/point_rcnn.py:8-70).  The two children must be called ``rpn`` and
+``rcnn_net``: those names are the prefixes of the reference's checkpoint keys."""
 import torch
 import torch.nn as nn
 
-from .rpn import RPN
 from .rcnn_net import RCNNNet
+from .rpn import RPN
 
 
 class PointRCNN(nn.Module):
     def __init__(self, cfg, num_classes, use_xyz=True, mode="TRAIN"):
         super().__init__()
         self.cfg = cfg
-        assert cfg.RPN.ENABLED or cfg.RCNN.ENABLED
+        if not (cfg.RPN.ENABLED or cfg.RCNN.ENABLED):
+            raise AssertionError("at least one of RPN / RCNN must be enabled")
         if cfg.RPN.ENABLED:
             self.rpn = RPN(cfg, use_xyz=use_xyz, mode=mode)
         if cfg.RCNN.ENABLED:
             if cfg.RCNN.BACKBONE != "pointnet":
                 raise NotImplementedError("RCNN backbone %r" % cfg.RCNN.BACKBONE)
+            # 128 = width of the RPN backbone features handed to the second stage
             self.rcnn_net = RCNNNet(cfg, num_classes=num_classes, input_channels=128, use_xyz=use_xyz)
+
+    # ---- stage 1: point-wise foreground score + box regression, with the RPN frozen when cfg.RPN.FIXED
+    def _first_stage(self, batch):
+        frozen = self.cfg.RPN.FIXED
+        if frozen:
+            self.rpn.eval()
+        with torch.set_grad_enabled(self.training and not frozen):
+            return self.rpn(batch)
+
+    # ---- hand-over: scores -> segmentation mask, depth, proposals
+    @torch.no_grad()
+    def _second_stage_inputs(self, first):
+        xyz = first["backbone_xyz"]
+        raw = first["rpn_cls"][:, :, 0]
+        mask = (torch.sigmoid(raw) > self.cfg.RPN.SCORE_THRESH).float()
+        rois, roi_raw = self.rpn.proposal_layer(raw, first["rpn_reg"], xyz)
+        extras = {"rois": rois, "roi_scores_raw": roi_raw, "seg_result": mask}
+        feed = {"rpn_xyz": xyz, "rpn_features": first["backbone_features"].permute((0, 2, 1)), "seg_mask": mask,
+                "roi_boxes3d": rois, "pts_depth": torch.norm(xyz, p=2, dim=2)}
+        return extras, feed
 
     def forward(self, input_data):
         cfg = self.cfg
-        if not cfg.RPN.ENABLED:
-            if cfg.RCNN.ENABLED:
-                return self.rcnn_net(input_data)
-            raise NotImplementedError
-        output = {}
-        with torch.set_grad_enabled((not cfg.RPN.FIXED) and self.training):
-            if cfg.RPN.FIXED:
-                self.rpn.eval()
-            rpn_output = self.rpn(input_data)
-            output.update(rpn_output)
+        if not cfg.RPN.ENABLED:                      # RCNN-only: the caller supplies pooled inputs
+            if not cfg.RCNN.ENABLED:
+                raise NotImplementedError
+            return self.rcnn_net(input_data)
+        result = dict(self._first_stage(input_data))
         if cfg.RCNN.ENABLED:
-            with torch.no_grad():
-                rpn_cls, rpn_reg = rpn_output["rpn_cls"], rpn_output["rpn_reg"]
-                backbone_xyz, backbone_features = rpn_output["backbone_xyz"], rpn_output["backbone_features"]
-                rpn_scores_raw = rpn_cls[:, :, 0]
-                seg_mask = (torch.sigmoid(rpn_scores_raw) > cfg.RPN.SCORE_THRESH).float()
-                pts_depth = torch.norm(backbone_xyz, p=2, dim=2)
-                rois, roi_scores_raw = self.rpn.proposal_layer(rpn_scores_raw, rpn_reg, backbone_xyz)
-                output["rois"] = rois
-                output["roi_scores_raw"] = roi_scores_raw
-                output["seg_result"] = seg_mask
-            rcnn_input = {"rpn_xyz": backbone_xyz, "rpn_features": backbone_features.permute((0, 2, 1)),
-                          "seg_mask": seg_mask, "roi_boxes3d": rois, "pts_depth": pts_depth}
+            extras, feed = self._second_stage_inputs(result)
+            result.update(extras)
             if self.training:
-                rcnn_input["gt_boxes3d"] = input_data["gt_boxes3d"]
-            output.update(self.rcnn_net(rcnn_input))
-        return output
+                feed["gt_boxes3d"] = input_data["gt_boxes3d"]
+            result.update(self.rcnn_net(feed))
+        return result

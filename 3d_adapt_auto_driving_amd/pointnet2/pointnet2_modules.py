@@ -14,6 +14,9 @@ from . import fused_mlp
 
 
 class _PointnetSAModuleBase(nn.Module):
+    """Sample ``npoint`` centres (FPS), group around them at every scale, run the scale's shared MLP, pool over the
+    neighbourhood and concatenate the scales."""
+
     def __init__(self):
         super().__init__()
         self.npoint = None
@@ -21,28 +24,30 @@ class _PointnetSAModuleBase(nn.Module):
         self.mlps = None
         self.pool_method = "max_pool"
 
+    def _centres(self, xyz):
+        chosen = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        as_channels = xyz.transpose(1, 2).contiguous()
+        return pointnet2_utils.gather_operation(as_channels, chosen).transpose(1, 2).contiguous()
+
+    def _pool(self, x):
+        """(B, C, npoint, nsample) -> (B, C, npoint)"""
+        window = [1, x.size(3)]
+        if self.pool_method == "max_pool":
+            return F.max_pool2d(x, kernel_size=window).squeeze(-1)
+        if self.pool_method == "avg_pool":
+            return F.avg_pool2d(x, kernel_size=window).squeeze(-1)
+        raise NotImplementedError(self.pool_method)
+
     def forward(self, xyz, features=None, new_xyz=None):
         """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3), new_features (B,sum(mlp[-1]),npoint)."""
         if new_xyz is None and self.npoint is not None:
-            sel = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
-            xyz_t = xyz.transpose(1, 2).contiguous()
-            new_xyz = pointnet2_utils.gather_operation(xyz_t, sel).transpose(1, 2).contiguous()
-
-        pooled = []
+            new_xyz = self._centres(xyz)
+        fast = (not self.training) and self.pool_method == "max_pool"   # inference: GEMM + fused epilogues + pooling
+        per_scale = []
         for grouper, mlp in zip(self.groupers, self.mlps):
-            if not self.training and self.pool_method == "max_pool":
-                # inference: GEMM + fused epilogues, pooling fused with the last bias/ReLU
-                pooled.append(fused_mlp.run(mlp, grouper(xyz, new_xyz, features), pool=True))
-                continue
-            x = mlp(grouper(xyz, new_xyz, features))          # (B, mlp[-1], npoint, nsample)
-            if self.pool_method == "max_pool":
-                x = F.max_pool2d(x, kernel_size=[1, x.size(3)])
-            elif self.pool_method == "avg_pool":
-                x = F.avg_pool2d(x, kernel_size=[1, x.size(3)])
-            else:
-                raise NotImplementedError(self.pool_method)
-            pooled.append(x.squeeze(-1))
-        return new_xyz, torch.cat(pooled, dim=1)
+            grouped = grouper(xyz, new_xyz, features)                    # (B, 3+C, npoint, nsample)
+            per_scale.append(fused_mlp.run(mlp, grouped, pool=True) if fast else self._pool(mlp(grouped)))
+        return new_xyz, torch.cat(per_scale, dim=1)
 
 
 class PointnetSAModuleMSG(_PointnetSAModuleBase):
@@ -82,14 +87,14 @@ class PointnetFPModule(nn.Module):
         self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
 
     def forward(self, unknown, known, unknow_feats, known_feats):
-        if known is not None:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
-            dist_recip = 1.0 / (dist + 1e-8)
-            weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
-            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n) skip features, known_feats (B,C2,m) -> (B,mlp[-1],n)."""
+        if known is None:                                   # a single global feature: broadcast it to every point
+            carried = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         else:
-            interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
-        x = interpolated if unknow_feats is None else torch.cat([interpolated, unknow_feats], dim=1)
-        if not self.training:
-            return fused_mlp.run(self.mlp, x.unsqueeze(-1), pool=False).squeeze(-1)
-        return self.mlp(x.unsqueeze(-1)).squeeze(-1)
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            inv = 1.0 / (dist + 1e-8)
+            carried = pointnet2_utils.three_interpolate(known_feats, idx, inv / torch.sum(inv, dim=2, keepdim=True))
+        stacked = carried if unknow_feats is None else torch.cat([carried, unknow_feats], dim=1)
+        stacked = stacked.unsqueeze(-1)
+        out = self.mlp(stacked) if self.training else fused_mlp.run(self.mlp, stacked, pool=False)
+        return out.squeeze(-1)

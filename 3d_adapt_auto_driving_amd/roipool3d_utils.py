@@ -21,47 +21,49 @@ def roipool3d_gpu(pts, pts_feature, boxes3d, pool_extra_width, sampled_pt_num=51
     return pooled_features, pooled_empty_flag
 
 
+def _host_f32(t):
+    return t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+
+
 def pts_in_boxes3d_cpu(pts, boxes3d):
-    """pts (N,3), boxes3d (M,7) CPU tensors -> list of M boolean masks (N) (roipool3d_utils.py:31-49)."""
+    """Host utility (roipool3d_utils.py:31-49): for each of the M boxes a boolean mask over the N points."""
     if pts.is_cuda:
-        raise NotImplementedError
-    pts = pts.float().contiguous()
-    boxes3d = boxes3d.float().contiguous()
-    pts_flag = torch.zeros((boxes3d.size(0), pts.size(0)), dtype=torch.int64)
-    roipool3d_cuda.pts_in_boxes3d_cpu(pts_flag, pts, boxes3d)
-    return [pts_flag[k] > 0 for k in range(boxes3d.shape[0])]
+        raise NotImplementedError("pts_in_boxes3d_cpu works on CPU tensors (the device path is roipool3d_gpu)")
+    flags = torch.zeros((boxes3d.shape[0], pts.shape[0]), dtype=torch.int64)
+    roipool3d_cuda.pts_in_boxes3d_cpu(flags, _host_f32(pts), _host_f32(boxes3d))
+    return list(flags.bool().unbind(0))
 
 
 def roipool_pc_cpu(pts, pts_feature, boxes3d, sampled_pt_num):
-    """pts (N,3), pts_feature (N,C), boxes3d (M,7) -> pooled_pts (M,S,3), pooled_features (M,S,C), empty (M) i64
-    (roipool3d_utils.py:52-70)."""
-    pts = pts.cpu().float().contiguous()
-    pts_feature = pts_feature.cpu().float().contiguous()
-    boxes3d = boxes3d.cpu().float().contiguous()
-    assert pts.shape[0] == pts_feature.shape[0] and pts.shape[1] == 3, "%s %s" % (pts.shape, pts_feature.shape)
-    pooled_pts = torch.zeros((boxes3d.shape[0], sampled_pt_num, 3), dtype=torch.float32)
-    pooled_features = torch.zeros((boxes3d.shape[0], sampled_pt_num, pts_feature.shape[1]), dtype=torch.float32)
-    pooled_empty_flag = torch.zeros(boxes3d.shape[0], dtype=torch.int64)
-    roipool3d_cuda.roipool3d_cpu(pts, boxes3d, pts_feature, pooled_pts, pooled_features, pooled_empty_flag)
-    return pooled_pts, pooled_features, pooled_empty_flag
+    """Host utility (roipool3d_utils.py:52-70): first ``sampled_pt_num`` in-box points per box, wrap-around filled.
+    -> coordinates (M,S,3), features (M,S,C), empty flags (M) int64."""
+    cloud, feats, boxes = _host_f32(pts), _host_f32(pts_feature), _host_f32(boxes3d)
+    if cloud.dim() != 2 or cloud.shape[1] != 3 or feats.shape[0] != cloud.shape[0]:
+        raise AssertionError("pts %s / pts_feature %s" % (tuple(cloud.shape), tuple(feats.shape)))
+    n_box = boxes.shape[0]
+    out_xyz = torch.zeros((n_box, sampled_pt_num, 3))
+    out_feat = torch.zeros((n_box, sampled_pt_num, feats.shape[1]))
+    empty = torch.zeros(n_box, dtype=torch.int64)
+    roipool3d_cuda.roipool3d_cpu(cloud, boxes, feats, out_xyz, out_feat, empty)
+    return out_xyz, out_feat, empty
 
 
 def roipool3d_cpu(boxes3d, pts, pts_feature, pts_extra_input, pool_extra_width, sampled_pt_num=512,
                   canonical_transform=True):
-    """numpy in, numpy out (roipool3d_utils.py:73-108): enlarge, pool on the host, optional canonical transform."""
+    """numpy in / numpy out (roipool3d_utils.py:73-108): boxes enlarged by ``pool_extra_width``, pooled on the host;
+    the pooled input = [xyz | extra input], optionally moved into each RoI's canonical frame."""
     import numpy as np
-    pooled_boxes3d = kitti_utils.enlarge_box3d(boxes3d, pool_extra_width)
-    pts_feature_all = np.concatenate((pts_extra_input, pts_feature), axis=1)
-    pooled_pts, pooled_features, pooled_empty_flag = roipool_pc_cpu(
-        torch.from_numpy(pts), torch.from_numpy(pts_feature_all), torch.from_numpy(pooled_boxes3d), sampled_pt_num)
-    extra_input_len = pts_extra_input.shape[1]
-    sampled_pts_input = torch.cat((pooled_pts, pooled_features[:, :, 0:extra_input_len]), dim=2).numpy()
-    sampled_pts_feature = pooled_features[:, :, extra_input_len:].numpy()
-    if canonical_transform:
-        roi_ry = boxes3d[:, 6] % (2 * np.pi)
-        roi_center = boxes3d[:, 0:3]
-        sampled_pts_input[:, :, 0:3] = sampled_pts_input[:, :, 0:3] - roi_center[:, np.newaxis, :]
-        for k in range(sampled_pts_input.shape[0]):
-            sampled_pts_input[k] = kitti_utils.rotate_pc_along_y(sampled_pts_input[k], roi_ry[k])
-        return sampled_pts_input, sampled_pts_feature
-    return sampled_pts_input, sampled_pts_feature, pooled_empty_flag.numpy()
+    n_extra = pts_extra_input.shape[1]
+    xyz, feat, empty = roipool_pc_cpu(torch.from_numpy(pts),
+                                      torch.from_numpy(np.concatenate((pts_extra_input, pts_feature), axis=1)),
+                                      torch.from_numpy(kitti_utils.enlarge_box3d(boxes3d, pool_extra_width)),
+                                      sampled_pt_num)
+    pooled_input = np.concatenate((xyz.numpy(), feat.numpy()[:, :, :n_extra]), axis=2)
+    pooled_feature = feat.numpy()[:, :, n_extra:]
+    if not canonical_transform:
+        return pooled_input, pooled_feature, empty.numpy()
+    pooled_input[:, :, 0:3] -= boxes3d[:, None, 0:3]                 # RoI centre to the origin
+    headings = np.mod(boxes3d[:, 6], 2 * np.pi)
+    for roi in range(pooled_input.shape[0]):                         # rotate about y by the RoI heading
+        pooled_input[roi] = kitti_utils.rotate_pc_along_y(pooled_input[roi], headings[roi])
+    return pooled_input, pooled_feature
