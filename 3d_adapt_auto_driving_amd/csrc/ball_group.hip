@@ -235,14 +235,9 @@ static int launch_group_cat_lds(int b, int n, int m, int c, int nsample, const f
                                 const float *features, const int *idx, float *out, hipStream_t st)
 {
     const size_t lds = (size_t)ROWS * n * sizeof(float);
-    static size_t configured = 0;
-    if (lds > 64 * 1024 && lds > configured) {
-        if (hipFuncSetAttribute((const void *)group_cat_lds_kernel<ROWS>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            set_error("group_cat: cannot reserve %zu bytes of LDS", lds);
-            return PRCNN_ELAUNCH;
-        }
-        configured = lds;
+    if (lds > 64 * 1024) {
+        const int rc = ensure_dynamic_lds((const void *)group_cat_lds_kernel<ROWS>, lds, "group_cat");
+        if (rc != PRCNN_OK) return rc;
     }
     const int groups = ceil_div(3 + c, ROWS);
     // enough blocks to fill 256 CUs a few times over; every chunk re-stages the rows, so keep chunks large
@@ -295,14 +290,9 @@ static int launch_ball_query(int b, int n, int m, float radius, int nsample, con
                              const float *xyz, int *idx, int write_empty, hipStream_t st)
 {
     const size_t lds = ((size_t)NSEG * nsample * 64 + (size_t)NSEG * 64) * sizeof(int);
-    static size_t configured = 0;
-    if (lds > 64 * 1024 && lds > configured) {
-        if (hipFuncSetAttribute((const void *)ball_query_kernel<NSEG>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            set_error("ball_query: cannot reserve %zu bytes of LDS", lds);
-            return PRCNN_ELAUNCH;
-        }
-        configured = lds;
+    if (lds > 64 * 1024) {
+        const int rc = ensure_dynamic_lds((const void *)ball_query_kernel<NSEG>, lds, "ball_query");
+        if (rc != PRCNN_OK) return rc;
     }
     dim3 grid(ceil_div(m, 64), b);
     hipLaunchKernelGGL(ball_query_kernel<NSEG>, grid, dim3(64 * NSEG), lds, st, n, m,

@@ -21,7 +21,11 @@ int check_launch(const char *what);
         }                                        \
     } while (0)
 
-// cached device scratch, one per stream (grown on demand; hipMalloc only on growth).  `slot` separates
+int current_device();
+// raise a kernel's dynamic-LDS limit to `bytes` (> 64 KiB needs it) once per (device, kernel)
+int ensure_dynamic_lds(const void *kernel, size_t bytes, const char *what);
+
+// cached device scratch, one per (device, stream) (grown on demand; hipMalloc only on growth).  `slot` separates
 // independent users (0: ball-query grid, 1: FPS ordering).
 char *scratch_for(hipStream_t st, size_t bytes, int slot = 0);
 

@@ -436,12 +436,11 @@ extern "C" int prcnn_furthest_point_sampling(int b, int n, int m, const float *x
         // (+1.2 % end to end; only when the batch is small enough that one workgroup per CU costs no concurrency)
         static const size_t pad_cfg = (size_t)(getenv("PRCNN_FPS_LDS_PAD") ? atoi(getenv("PRCNN_FPS_LDS_PAD")) : 84) * 1024;
         const size_t pad = b <= 128 ? pad_cfg : 0;
-        static bool attr = false;
-        if (pad_cfg && !attr) {
-            (void)hipFuncSetAttribute((const void *)fps_pruned_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_cfg);
-            (void)hipFuncSetAttribute((const void *)fps_pruned_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_cfg);
-            (void)hipFuncSetAttribute((const void *)fps_pruned_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_cfg);
-            attr = true;
+        if (pad) {
+            const void *k = n <= 4096 ? (const void *)fps_pruned_kernel<4> : n <= 8192 ? (const void *)fps_pruned_kernel<8>
+                                                                                       : (const void *)fps_pruned_kernel<16>;
+            const int rc = ensure_dynamic_lds(k, pad, "furthest_point_sampling(pruned)");
+            if (rc != PRCNN_OK) return rc;
         }
         if (n <= 4096) hipLaunchKernelGGL(fps_pruned_kernel<4>, dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
         else if (n <= 8192) hipLaunchKernelGGL(fps_pruned_kernel<8>, dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);

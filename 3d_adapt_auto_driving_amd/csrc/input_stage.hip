@@ -269,10 +269,9 @@ extern "C" int prcnn_input_stage(int b, int n_max, int stride, int lidar_frame, 
         }
     }
     const size_t lds = (size_t)npad * sizeof(unsigned long long);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)input_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-        attr_set = true;
+    {
+        const int rc = ensure_dynamic_lds((const void *)input_stage_kernel, 140 * 1024, "input_stage");
+        if (rc != PRCNN_OK) return rc;
     }
     hipLaunchKernelGGL(input_stage_kernel, dim3(b), dim3(IS_THREADS), lds, st, n_max, stride, lidar_frame, image_filter, counts, raw,
                        (const SceneCalib *)calib, scope_dev, npoints, npad, far_depth, npoints_faraway, seeds,

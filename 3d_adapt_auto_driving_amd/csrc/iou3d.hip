@@ -309,23 +309,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_lazy_kernel(
     if (t == 0) num_keep_all[prob] = s_nkeep;
 }
 
-// cached device scratch for the blocking API (one per process, grown on demand)
-static int *g_scratch = nullptr;
-static size_t g_scratch_ints = 0;
-
-static int ensure_scratch(size_t ints)
-{
-    if (ints <= g_scratch_ints) return PRCNN_OK;
-    if (g_scratch) (void)hipFree(g_scratch);
-    g_scratch = nullptr;
-    g_scratch_ints = 0;
-    if (hipMalloc((void **)&g_scratch, ints * sizeof(int)) != hipSuccess) {
-        set_error("nms: cannot allocate %zu bytes of scratch", ints * sizeof(int));
-        return PRCNN_ELAUNCH;
-    }
-    g_scratch_ints = ints;
-    return PRCNN_OK;
-}
+// device scratch of the blocking API: slot 7 of the per-(device, stream) cache
 
 int nms_device(int nprob, int n_max, const int *counts, const float *boxes, float thresh,
                int rotated, int max_keep, int *keep, int *num_keep, hipStream_t st)
@@ -346,9 +330,9 @@ static int nms_blocking(int n, const float *boxes, long long *keep_host, float t
     PRCNN_REQUIRE(n >= 0, "nms: negative box count");
     if (n == 0) return 0;
     PRCNN_REQUIRE(boxes && keep_host, "nms: null pointer");
-    int rc = ensure_scratch((size_t)n + 1);
-    if (rc != PRCNN_OK) return rc;
-    rc = nms_device(1, n, nullptr, boxes, thresh, rotated, n, g_scratch + 1, g_scratch, st);
+    int *g_scratch = (int *)scratch_for(st, ((size_t)n + 1) * sizeof(int), 7);
+    if (!g_scratch) { set_error("nms: cannot allocate %zu bytes of scratch", ((size_t)n + 1) * sizeof(int)); return PRCNN_ELAUNCH; }
+    int rc = nms_device(1, n, nullptr, boxes, thresh, rotated, n, g_scratch + 1, g_scratch, st);
     if (rc != PRCNN_OK) return rc;
     int *host = (int *)malloc(sizeof(int) * ((size_t)n + 1));
     if (!host) { set_error("nms: host allocation failed"); return PRCNN_ELAUNCH; }

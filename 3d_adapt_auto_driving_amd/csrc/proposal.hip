@@ -397,13 +397,9 @@ extern "C" int prcnn_rpn_proposals(int b, int n, int channels, float loc_scope, 
     const long total = (long)b * n;
     hipLaunchKernelGGL(rpn_decode_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, total, c, xyz, reg, boxes);
     const size_t lds = (size_t)npad * sizeof(unsigned long long);
-    static size_t configured = 0;
-    if (lds > 64 * 1024 && lds > configured) {
-        if (hipFuncSetAttribute((const void *)score_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            set_error("rpn_proposals: cannot reserve %zu bytes of LDS", lds);
-            return PRCNN_ELAUNCH;
-        }
-        configured = lds;
+    if (lds > 64 * 1024) {
+        const int rc = ensure_dynamic_lds((const void *)score_sort_kernel, lds, "rpn_proposals");
+        if (rc != PRCNN_OK) return rc;
     }
     hipLaunchKernelGGL(score_sort_kernel, dim3(b), dim3(1024), lds, st, n, npad, scores, order);
     hipLaunchKernelGGL(band_select_kernel, dim3(b), dim3(1024), 0, st, n, rows, pre_near, pre_far, boxes, scores, order,

@@ -312,7 +312,7 @@ namespace prcnn {
 // a memset queued on the same stream just before it; a word is reused 64 launches later on that same stream, i.e. strictly
 // after the launch that used it (stream order) -- launches of other streams never touch it.
 static std::mutex g_ticket_mu;
-static std::map<hipStream_t, unsigned int> g_ticket_next;
+static std::map<std::pair<int, hipStream_t>, unsigned int> g_ticket_next;
 unsigned int *next_ticket(hipStream_t st)
 {
     unsigned int *ring = reinterpret_cast<unsigned int *>(scratch_for(st, 64 * sizeof(unsigned int), 6));
@@ -320,7 +320,7 @@ unsigned int *next_ticket(hipStream_t st)
     unsigned int k;
     {
         std::lock_guard<std::mutex> lock(g_ticket_mu);
-        k = g_ticket_next[st]++;
+        k = g_ticket_next[std::make_pair(current_device(), st)]++;
     }
     unsigned int *t = ring + (k & 63);
     if (hipMemsetAsync(t, 0, sizeof(unsigned int), st) != hipSuccess) return nullptr;

@@ -14,6 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 _lib = None
+_variant_libs = {}
 
 _f = C.POINTER(C.c_float)
 _i = C.POINTER(C.c_int)
@@ -28,16 +29,47 @@ def build(force=False):
     return _LIB_PATH
 
 
+def _declare(h):
+    h.orc_opt_n_threads.restype = C.c_int
+    h.orc_nms.restype = C.c_int
+    h.orc_nms_normal.restype = C.c_int
+    h.orc_num_threads.restype = C.c_int
+    h.orc_variant.restype = C.c_int
+    return h
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(_LIB_PATH)
-        _lib.orc_opt_n_threads.restype = C.c_int
-        _lib.orc_nms.restype = C.c_int
-        _lib.orc_nms_normal.restype = C.c_int
-        _lib.orc_num_threads.restype = C.c_int
+        _lib = _declare(C.CDLL(_LIB_PATH))
+        assert _lib.orc_variant() == 0
     return _lib
+
+
+def variant(name):
+    """Context manager: every front-end function of this module runs on an FMA-CONTRACTED build of the same
+    source ('fma' = liboracle_fma.so, 'fma2' = liboracle_fma2.so; oracle/Makefile) instead of the contract-off
+    oracle.  Only for counting how many decisions move under contraction -- never the parity reference."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def _cm():
+        global _lib
+        if name not in _variant_libs:
+            path = os.path.join(_HERE, "liboracle_%s.so" % name)
+            src = os.path.join(_HERE, "prcnn_oracle.c")
+            if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+                subprocess.check_call(["make", "-C", _HERE, os.path.basename(path)], stdout=subprocess.DEVNULL)
+            _variant_libs[name] = _declare(C.CDLL(path))
+            assert _variant_libs[name].orc_variant() == {"fma": 1, "fma2": 2}[name]
+        saved = lib()
+        _lib = _variant_libs[name]
+        try:
+            yield _lib
+        finally:
+            _lib = saved
+    return _cm()
 
 
 def _p(a, t):

@@ -45,7 +45,26 @@ static inline float sqdist3(const float *p, const float *q)
     float dx = p[0] - q[0];
     float dy = p[1] - q[1];
     float dz = p[2] - q[2];
+#if defined(ORC_VARIANT) && ORC_VARIANT == 2
+    /* contraction form B (the other association a compiler may pick): fma(dz,dz, fma(dy,dy, dx*dx)) */
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+#else
+    /* ORC_VARIANT 0: -ffp-contract=off, three products, two sums, five roundings (THE contract).
+     * ORC_VARIANT 1: this same expression under -ffp-contract=fast -mfma: gcc (like LLVM/NVVM) fuses the LEFT
+     * product of an add of two products first -> fma(dz,dz, fma(dx,dx, dy*dy)): contraction form A. */
     return dx * dx + dy * dy + dz * dz;
+#endif
+}
+
+/* which arithmetic variant this build of the oracle is: 0 contract-off (the parity contract), 1 / 2 FMA-contracted
+ * second oracles (bound on "oracle vs the reference's nvcc -O2 binary", pointnet2/setup.py:19-20) */
+int orc_variant(void)
+{
+#ifdef ORC_VARIANT
+    return ORC_VARIANT;
+#else
+    return 0;
+#endif
 }
 
 /* cuda_utils.h:10-13 */

@@ -26,6 +26,11 @@
 extern "C" {
 #endif
 
+/* 0 = the contract-off oracle (liboracle.so); 1 / 2 = the FMA-contracted second oracles (liboracle_fma.so:
+ * the whole file under -ffp-contract=fast -mfma, the analogue of the reference's `nvcc -O2` build,
+ * pointnet2_lib/pointnet2/setup.py:19-20; liboracle_fma2.so: the other association of the squared distance) */
+int orc_variant(void);
+
 /* cuda_utils.h:10-13 -- float-log power of two, capped at 1024 */
 int orc_opt_n_threads(int work_size);
 
