@@ -35,6 +35,8 @@ SIGNATURES = {
     "prcnn_group_cat_pm": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "prcnn_gather_affine_relu_pm": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_sa_mlp_fused": [_I] * 7 + [_P] * 10 + [_I, _I, _P],
+    "prcnn_ball_pack": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "prcnn_sa_packed_mlp": [_I, _I, _I, _I, C.c_long] + [_P] * 12 + [_I, _I, _P],
     "prcnn_maxpool_pm": [C.c_long, _I, _I, _P, _P, _I, _I, _P],
     "prcnn_three_interpolate_pm": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P],
     "prcnn_boxes_overlap_bev": [_I, _P, _I, _P, _P, _P],
@@ -102,6 +104,17 @@ def call(name, *args):
     if rc < 0:
         raise PrcnnError("%s failed (%d): %s" % (name, rc, last_error()))
     return rc
+
+
+def has_entry(ext, name):
+    """Does operator backend `ext` offer entry point `name`?  The HIP drop-in modules (IS_HIP_EXTENSION) must offer every
+    entry the engine uses: a missing one raises instead of silently selecting a slower formulation.  Only the CPU
+    stand-ins of the test suite may lack fused entries (the torch-op formulations are their checked equivalents)."""
+    if getattr(ext, "IS_HIP_EXTENSION", False):
+        if not hasattr(ext, name):
+            raise PrcnnError("HIP extension module %s lost its entry point %r" % (getattr(ext, "__name__", ext), name))
+        return True
+    return hasattr(ext, name)
 
 
 def ptr(t):

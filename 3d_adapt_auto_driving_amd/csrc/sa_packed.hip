@@ -1,0 +1,451 @@
+// sa_packed.hip -- set-abstraction MLP over the DISTINCT grouped rows only.
+//
+// The reference's ball query back-fills every slot beyond the hit count with the FIRST hit
+// (ball_query_gpu.cu:35-39), and QueryAndGroup / SharedMLP / max_pool2d (pointnet2_utils.py:241-264,
+// pointnet2_modules.py:37-53) then push all nsample rows of a group through the three layers -- although the
+// back-filled rows are exact copies of row 0 and the max over a group does not change when copies are dropped.
+// On the RCNN levels of a KITTI-shaped scene a ball of nsample = 64 holds ~14 (SA1) / ~7 (SA2) distinct
+// points; on real clouds it is rarely full either.  So:
+//
+//   ball_pack_kernel      per cloud: cnt[c] = 1 + (last slot that differs from slot 0), exclusive scan, the
+//                         cloud's rows written as a dense list of (centre, point) pairs cut into 64-row tiles
+//                         (tiles are allocated from one atomic counter, so the tile count stays on the device)
+//   sa_packed_mlp_kernel  the fused gather -> layer 1 -> layer 2 (MFMA) -> layer 3 (MFMA) -> max kernel of
+//                         sa_mlp_fused.hip over those tiles: a tile now holds rows of SEVERAL centres, so the
+//                         max over nsample becomes a segmented max -- done in the accumulator registers with a
+//                         wave-uniform boundary mask -- and partial maxima reach the output with atomicMax
+//                         (outputs are >= 0 after ReLU, so the integer order of the bit patterns is the float order).
+//
+// Every row's result is the same k-ordered fma chain as in sa_mlp_fused.hip (a row's MFMA result does not depend on the
+// other rows of its tile), so the output is BIT-IDENTICAL to the unpacked kernel's; only duplicates are skipped.
+// `cnt` is defined so that this holds for ANY index tensor: rows beyond the last slot that differs from slot 0 are
+// copies of row 0 whatever produced them.
+#include "common.hpp"
+#include <stdlib.h>
+
+namespace prcnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int PK_C = 128;            // C1 = C2 (narrower levels are zero-padded by the caller)
+constexpr int PK_ROWS = 64;
+constexpr int PK_LD = PK_C + 4;
+constexpr int PK_TILES_PER_WG = 8;
+
+// ------------------------------------------------------------------------------------------------ packing
+// one workgroup per cloud.  LDS: cnt / offset per centre (m ints) + per-thread partial sums.
+__global__ void ball_pack_kernel(int m, int ns, int tiles_cap_cloud, const int *__restrict__ idx,
+                                 unsigned int *__restrict__ rowinfo, int *__restrict__ tilecloud, unsigned int *__restrict__ hdr)
+{
+    extern __shared__ int pk_lds[];
+    int *cnts = pk_lds;                   // [m]   cnt, then exclusive offset
+    int *part = pk_lds + m;               // [blockDim.x] partial sums, then their exclusive scan
+    __shared__ int s_base;
+    const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+    const int chunk = (m + T - 1) / T;
+    const int c0 = tid * chunk, c1 = min(m, c0 + chunk);
+    const int *rows = idx + (long)b * m * ns;
+    int sum = 0;
+    for (int c = c0; c < c1; ++c) {
+        const int *row = rows + (long)c * ns;
+        const int first = row[0];
+        int last = 0;
+        if ((ns & 3) == 0) {
+            for (int p = 0; p < ns; p += 4) {
+                const int4 v = *reinterpret_cast<const int4 *>(row + p);
+                if (v.x != first) last = p;
+                if (v.y != first) last = p + 1;
+                if (v.z != first) last = p + 2;
+                if (v.w != first) last = p + 3;
+            }
+        } else {
+            for (int p = 1; p < ns; ++p) if (row[p] != first) last = p;
+        }
+        cnts[c] = last + 1;
+        sum += last + 1;
+    }
+    part[tid] = sum;
+    __syncthreads();
+    // exclusive scan of the per-thread sums (Hillis-Steele over T <= 1024 entries)
+    for (int d = 1; d < T; d <<= 1) {
+        const int v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const int total = part[T - 1];
+    int run = part[tid] - sum;
+    if (tid == 0) {
+        const int ntiles = (total + PK_ROWS - 1) / PK_ROWS;
+        s_base = (int)atomicAdd(&hdr[0], (unsigned int)ntiles);
+        atomicAdd(&hdr[1], (unsigned int)total);
+    }
+    __syncthreads();
+    const int base = s_base;
+    const int ntiles = (total + PK_ROWS - 1) / PK_ROWS;
+    for (int t = tid; t < ntiles; t += T) tilecloud[base + t] = b;
+    unsigned int *dst = rowinfo + (long)base * PK_ROWS;
+    for (int c = c0; c < c1; ++c) {
+        const int *row = rows + (long)c * ns;
+        const int n_c = cnts[c];
+        for (int p = 0; p < n_c; ++p) dst[run + p] = ((unsigned int)c << 16) | (unsigned int)row[p];
+        run += n_c;
+    }
+    // the last tile of the cloud is filled up with copies of the cloud's last row (copies do not change a max)
+    if (c1 == m && c0 < m) {
+        const unsigned int fill = ((unsigned int)(m - 1) << 16) | (unsigned int)rows[(long)(m - 1) * ns];
+        for (int r = total; r < ntiles * PK_ROWS; ++r) dst[r] = fill;
+    }
+    (void)tiles_cap_cloud;
+}
+
+// ------------------------------------------------------------------------------------------------ segmented max
+// Rows held by lane half h of the 32x32 MFMA accumulators, in increasing row order: q = 0..31 ->
+// accumulator q >> 4, register q & 15, row = 32 (q >> 4) + (r & 3) + 8 (r >> 2) + 4 h.
+__device__ __forceinline__ constexpr int pk_row(int q) { return 32 * (q >> 4) + ((q & 15) & 3) + 8 * ((q & 15) >> 2); }
+__device__ __forceinline__ constexpr unsigned long long pk_bits_upto(int row) { return row >= 63 ? ~0ULL : ((2ULL << row) - 1ULL); }
+
+// out[centre][col] = max(out[centre][col], v) for v >= 0 (integer order of the bit patterns == float order)
+__device__ __forceinline__ void pk_flush(float *__restrict__ out, long centre, int out_stride, int col, float v, float bias)
+{
+    atomicMax(reinterpret_cast<int *>(out + centre * out_stride + col), __float_as_int(fmaxf(v + bias, 0.f)));
+}
+
+// acc0 = rows 0..31, acc1 = rows 32..63 of this wave's 32 output columns; ctr[64] = centre of every row (LDS);
+// start = bit i set when row i begins a new centre (wave-uniform).
+__device__ __forceinline__ void pk_segmented_max(const f32x16 &acc0, const f32x16 &acc1, const int *ctr, unsigned long long start,
+                                                 int h, float *__restrict__ out, int out_stride, int col, float bias)
+{
+    float cur = acc0[0];
+#pragma unroll
+    for (int q = 1; q < 32; ++q) {
+        const float v = (q < 16) ? acc0[q & 15] : acc1[q & 15];
+        const int prev = pk_row(q - 1), row = pk_row(q);
+        // a boundary between this lane's previous row and this one: any segment start in (prev, row] (+4 for half 1)
+        const unsigned long long m0 = pk_bits_upto(row) & ~pk_bits_upto(prev);
+        const unsigned long long m1 = pk_bits_upto(row + 4) & ~pk_bits_upto(prev + 4);
+        const bool b0 = (start & m0) != 0, b1 = (start & m1) != 0;        // wave-uniform
+        if (b0 | b1) {
+            const bool mine = h ? b1 : b0;
+            if (mine) {
+                pk_flush(out, ctr[prev + 4 * h], out_stride, col, cur, bias);
+                cur = v;
+            } else {
+                cur = fmaxf(cur, v);
+            }
+        } else {
+            cur = fmaxf(cur, v);
+        }
+    }
+    pk_flush(out, ctr[pk_row(31) + 4 * h], out_stride, col, cur, bias);
+}
+
+// ------------------------------------------------------------------------------------------------ C3 = 128
+// Two workgroups per CU (see sa_mlp_fused.hip for the MFMA mapping; identical here).
+__global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
+    int n, int m, const unsigned int *__restrict__ hdr, const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+    const float4 *__restrict__ P /* (b,n,128) */, const float4 *__restrict__ wxyz /* (3,128) */,
+    const unsigned int *__restrict__ rowinfo, const int *__restrict__ tilecloud,
+    const float *__restrict__ w2t, const float *__restrict__ b2, const float *__restrict__ w3t, const float *__restrict__ b3,
+    float *__restrict__ out, int out_stride, int out_col, unsigned int *__restrict__ ticket, int tiles_per_wg)
+{
+    __shared__ float lds[2 * PK_ROWS * PK_LD];
+    __shared__ unsigned int slot[2];
+    __shared__ int ctr[2][PK_ROWS];
+    float *A1 = lds, *Y1 = lds + PK_ROWS * PK_LD;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const long tiles = hdr[0];
+
+    // first ticket BEFORE the weights are fetched: the grid is sized for the worst case (every ball full) and most
+    // workgroups of a sparse launch leave right here
+    if (tid == 0) slot[0] = atomicAdd(ticket, 1u);
+    __syncthreads();
+    long t = slot[0];
+    if (t >= tiles) return;
+
+    float wf2[64], wf3[64];
+#pragma unroll
+    for (int s = 0; s < 64; ++s) wf2[s] = w2t[(long)(s + 64 * h) * PK_C + 32 * w + j];
+#pragma unroll
+    for (int s = 0; s < 64; ++s) wf3[s] = w3t[(long)(s + 64 * h) * 128 + 32 * w + j];
+    const float bias2 = b2[32 * w + j], bias3 = b3[32 * w + j];
+
+    const int chunk = tid & 31, r0 = tid >> 5;
+    const float4 wx = wxyz[chunk], wy = wxyz[32 + chunk], wz = wxyz[64 + chunk];
+
+    unsigned int info[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) info[i] = rowinfo[t * PK_ROWS + r0 + 8 * i];
+    int cloud = tilecloud[t];
+
+    for (int served = 0; served < tiles_per_wg && t < tiles; ++served) {
+        const bool more = served + 1 < tiles_per_wg;
+        if (tid == 0) slot[(served + 1) & 1] = more ? atomicAdd(ticket, 1u) : 0xffffffffu;
+        int *cc = ctr[served & 1];
+        const long pbase = (long)cloud * n, cbase = (long)cloud * m;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = r0 + 8 * i;
+            const int k = (int)(info[i] & 0xffffu), cl = (int)(info[i] >> 16);
+            const float *pt = xyz + (pbase + k) * 3;
+            const float *ct = new_xyz + (cbase + cl) * 3;
+            const float dx = pt[0] - ct[0], dy = pt[1] - ct[1], dz = pt[2] - ct[2];
+            const float4 base = P[(pbase + k) * (PK_C / 4) + chunk];
+            float4 v;
+            v.x = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, base.x))), 0.f);
+            v.y = fmaxf(fmaf(wz.y, dz, fmaf(wy.y, dy, fmaf(wx.y, dx, base.y))), 0.f);
+            v.z = fmaxf(fmaf(wz.z, dz, fmaf(wy.z, dy, fmaf(wx.z, dx, base.z))), 0.f);
+            v.w = fmaxf(fmaf(wz.w, dz, fmaf(wy.w, dy, fmaf(wx.w, dx, base.w))), 0.f);
+            *reinterpret_cast<float4 *>(A1 + row * PK_LD + 4 * chunk) = v;
+            if (chunk == 0) cc[row] = (int)(cbase + cl);
+        }
+        __syncthreads();
+        const long t_next = slot[(served + 1) & 1];
+        if (t_next < tiles) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) info[i] = rowinfo[t_next * PK_ROWS + r0 + 8 * i];
+            cloud = tilecloud[t_next];
+        }
+
+        // ---- layer 2
+        {
+            f32x16 acc0 = {0}, acc1 = {0};
+            const float *a0p = A1 + j * PK_LD + 64 * h;
+            const float *a1p = A1 + (32 + j) * PK_LD + 64 * h;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float4 a0 = *reinterpret_cast<const float4 *>(a0p + 4 * g);
+                const float4 a1 = *reinterpret_cast<const float4 *>(a1p + 4 * g);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wf2[4 * g + 0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wf2[4 * g + 0], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wf2[4 * g + 1], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, wf2[4 * g + 1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, wf2[4 * g + 2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, wf2[4 * g + 2], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, wf2[4 * g + 3], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wf2[4 * g + 3], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                Y1[row * PK_LD + 32 * w + j] = fmaxf(acc0[r] + bias2, 0.f);
+                Y1[(32 + row) * PK_LD + 32 * w + j] = fmaxf(acc1[r] + bias2, 0.f);
+            }
+        }
+        __syncthreads();
+
+        // ---- layer 3 + segmented max over the tile's rows
+        {
+            const float *a0p = Y1 + j * PK_LD + 64 * h;
+            const float *a1p = Y1 + (32 + j) * PK_LD + 64 * h;
+            f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float4 a0 = *reinterpret_cast<const float4 *>(a0p + 4 * g);
+                const float4 a1 = *reinterpret_cast<const float4 *>(a1p + 4 * g);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wf3[4 * g + 0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wf3[4 * g + 0], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wf3[4 * g + 1], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, wf3[4 * g + 1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, wf3[4 * g + 2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, wf3[4 * g + 2], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, wf3[4 * g + 3], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wf3[4 * g + 3], acc1, 0, 0, 0);
+            }
+            const int myc = cc[lane], prevc = cc[lane ? lane - 1 : 0];
+            const unsigned long long start = __ballot(lane == 0 || myc != prevc);
+            pk_segmented_max(acc0, acc1, cc, start, h, out, out_stride, out_col + 32 * w + j, bias3);
+        }
+        // A1 is rewritten by the next builder only (every wave has left layer 2); Y1 after the next tile's first barrier;
+        // the centre list alternates between two buffers, so a slow wave still reads this tile's list while the others
+        // already write the next one.
+        t = t_next;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C3 = 256
+// Eight waves (sa_mlp_fused256_kernel's mapping): wave (wp, wg) owns column panel wp of layer 2 for row half wg, and column
+// panel wp of column tile wg of layer 3 for both row halves.
+__global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
+    int n, int m, const unsigned int *__restrict__ hdr, const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+    const float4 *__restrict__ P, const float4 *__restrict__ wxyz, const unsigned int *__restrict__ rowinfo,
+    const int *__restrict__ tilecloud, const float *__restrict__ w2t, const float *__restrict__ b2,
+    const float *__restrict__ w3t /* (128,256) */, const float *__restrict__ b3, float *__restrict__ out, int out_stride,
+    int out_col, unsigned int *__restrict__ ticket, int tiles_per_wg)
+{
+    __shared__ float lds[2 * PK_ROWS * PK_LD];
+    __shared__ unsigned int slot[2];
+    __shared__ int ctr[2][PK_ROWS];
+    float *A1 = lds, *Y1 = lds + PK_ROWS * PK_LD;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, wp = w & 3, wg = w >> 2;
+    const int j = lane & 31, h = lane >> 5;
+    const long tiles = hdr[0];
+
+    if (tid == 0) slot[0] = atomicAdd(ticket, 1u);
+    __syncthreads();
+    long t = slot[0];
+    if (t >= tiles) return;
+
+    float wf2[64], wf3[64];
+#pragma unroll
+    for (int s = 0; s < 64; ++s) wf2[s] = w2t[(long)(s + 64 * h) * PK_C + 32 * wp + j];
+#pragma unroll
+    for (int s = 0; s < 64; ++s) wf3[s] = w3t[(long)(s + 64 * h) * 256 + 128 * wg + 32 * wp + j];
+    const float bias2 = b2[32 * wp + j], bias3 = b3[128 * wg + 32 * wp + j];
+
+    const int chunk = tid & 31, r0 = tid >> 5;       // rows r0 + 16 i, i < 4
+    const float4 wx = wxyz[chunk], wy = wxyz[32 + chunk], wz = wxyz[64 + chunk];
+
+    unsigned int info[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) info[i] = rowinfo[t * PK_ROWS + r0 + 16 * i];
+    int cloud = tilecloud[t];
+
+    for (int served = 0; served < tiles_per_wg && t < tiles; ++served) {
+        const bool more = served + 1 < tiles_per_wg;
+        if (tid == 0) slot[(served + 1) & 1] = more ? atomicAdd(ticket, 1u) : 0xffffffffu;
+        int *cc = ctr[served & 1];
+        const long pbase = (long)cloud * n, cbase = (long)cloud * m;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 16 * i;
+            const int k = (int)(info[i] & 0xffffu), cl = (int)(info[i] >> 16);
+            const float *pt = xyz + (pbase + k) * 3;
+            const float *ct = new_xyz + (cbase + cl) * 3;
+            const float dx = pt[0] - ct[0], dy = pt[1] - ct[1], dz = pt[2] - ct[2];
+            const float4 base = P[(pbase + k) * (PK_C / 4) + chunk];
+            float4 v;
+            v.x = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, base.x))), 0.f);
+            v.y = fmaxf(fmaf(wz.y, dz, fmaf(wy.y, dy, fmaf(wx.y, dx, base.y))), 0.f);
+            v.z = fmaxf(fmaf(wz.z, dz, fmaf(wy.z, dy, fmaf(wx.z, dx, base.z))), 0.f);
+            v.w = fmaxf(fmaf(wz.w, dz, fmaf(wy.w, dy, fmaf(wx.w, dx, base.w))), 0.f);
+            *reinterpret_cast<float4 *>(A1 + row * PK_LD + 4 * chunk) = v;
+            if (chunk == 0) cc[row] = (int)(cbase + cl);
+        }
+        __syncthreads();
+        const long t_next = slot[(served + 1) & 1];
+        if (t_next < tiles) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) info[i] = rowinfo[t_next * PK_ROWS + r0 + 16 * i];
+            cloud = tilecloud[t_next];
+        }
+
+        // ---- layer 2: rows [32 wg, 32 wg + 32) x columns [32 wp, 32 wp + 32)
+        {
+            f32x16 acc = {0};
+            const float *ap = A1 + (32 * wg + j) * PK_LD + 64 * h;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float4 a = *reinterpret_cast<const float4 *>(ap + 4 * g);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wf2[4 * g + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wf2[4 * g + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wf2[4 * g + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wf2[4 * g + 3], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * wg + (r & 3) + 8 * (r >> 2) + 4 * h;
+                Y1[row * PK_LD + 32 * wp + j] = fmaxf(acc[r] + bias2, 0.f);
+            }
+        }
+        __syncthreads();
+
+        // ---- layer 3: all 64 rows x columns [128 wg + 32 wp, +32), then the segmented max
+        {
+            const float *a0p = Y1 + j * PK_LD + 64 * h;
+            const float *a1p = Y1 + (32 + j) * PK_LD + 64 * h;
+            f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float4 a0 = *reinterpret_cast<const float4 *>(a0p + 4 * g);
+                const float4 a1 = *reinterpret_cast<const float4 *>(a1p + 4 * g);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wf3[4 * g + 0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wf3[4 * g + 0], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wf3[4 * g + 1], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, wf3[4 * g + 1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, wf3[4 * g + 2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, wf3[4 * g + 2], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, wf3[4 * g + 3], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wf3[4 * g + 3], acc1, 0, 0, 0);
+            }
+            const int myc = cc[lane], prevc = cc[lane ? lane - 1 : 0];
+            const unsigned long long start = __ballot(lane == 0 || myc != prevc);
+            pk_segmented_max(acc0, acc1, cc, start, h, out, out_stride, out_col + 128 * wg + 32 * wp + j, bias3);
+        }
+        t = t_next;
+    }
+}
+
+unsigned int *next_ticket(hipStream_t st);    // sa_mlp_fused.hip
+
+}  // namespace prcnn
+
+using namespace prcnn;
+
+// idx (b,m,nsample) i32 -> the distinct grouped rows of every cloud as 64-row tiles:
+//   rowinfo  [b * tiles_cap * 64] u32, (centre within cloud) << 16 | (point within cloud); tile t = entries [64t, 64t+64)
+//   tilecloud[b * tiles_cap] i32, cloud of tile t
+//   hdr      [4] u32: [0] = number of tiles, [1] = number of distinct rows (both written by this call)
+// with tiles_cap = ceil(m * nsample / 64) tiles per cloud at most.  Needs m, n <= 65536.
+extern "C" int prcnn_ball_pack(int b, int m, int nsample, const int *idx, unsigned int *rowinfo, int *tilecloud,
+                               unsigned int *hdr, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && m >= 0 && nsample >= 1, "ball_pack: bad sizes");
+    PRCNN_REQUIRE(m <= 65536 && m <= 15360, "ball_pack: m=%d centres per cloud unsupported (<= 15360)", m);
+    PRCNN_REQUIRE(hdr, "ball_pack: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(hdr, 0, 4 * sizeof(unsigned int), st) != hipSuccess) { set_error("ball_pack: memset failed"); return PRCNN_ELAUNCH; }
+    if (b == 0 || m == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(idx && rowinfo && tilecloud, "ball_pack: null pointer");
+    PRCNN_REQUIRE(((uintptr_t)idx & 15) == 0 || (nsample & 3) != 0, "ball_pack: 16-byte alignment required");
+    int threads = 64;
+    while (threads < m && threads < 1024) threads *= 2;
+    const size_t lds = ((size_t)m + threads) * sizeof(int);
+    if (lds > 48 * 1024) {
+        const int rc = ensure_dynamic_lds((const void *)ball_pack_kernel, lds, "ball_pack");
+        if (rc != PRCNN_OK) return rc;
+    }
+    const int cap = (int)(((long)m * nsample + PK_ROWS - 1) / PK_ROWS);
+    hipLaunchKernelGGL(ball_pack_kernel, dim3(b), dim3(threads), lds, st, m, nsample, cap, idx, rowinfo, tilecloud, hdr);
+    return check_launch("ball_pack");
+}
+
+// The fused set-abstraction MLP over packed rows (prcnn_ball_pack): P (b,n,128) = features @ W1f^T + b1, wxyz (3,128),
+// w2t (128,128), w3t (128,c3) k-major, c3 in {128, 256}; out[(b*m rows)][out_col .. out_col + c3), row stride out_stride.
+// The output slice is zeroed by this call and then receives max over each centre's distinct rows of relu(layer 3).
+// max_tiles = b * ceil(m * nsample / 64) sizes the grid (the real tile count stays on the device, in hdr[0]).
+extern "C" int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, const float *new_xyz, const float *xyz,
+                                   const float *P, const float *wxyz, const unsigned int *rowinfo, const int *tilecloud,
+                                   const unsigned int *hdr, const float *w2t, const float *b2, const float *w3t,
+                                   const float *b3, float *out, int out_stride, int out_col, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && max_tiles >= 0, "sa_packed_mlp: bad sizes");
+    PRCNN_REQUIRE(c3 == 128 || c3 == 256, "sa_packed_mlp: unsupported output width %d (128 | 256)", c3);
+    PRCNN_REQUIRE(n <= 65536 && m <= 65536, "sa_packed_mlp: cloud too large for the 16-bit row descriptors");
+    PRCNN_REQUIRE(out_stride >= out_col + c3 && out_col >= 0, "sa_packed_mlp: bad output slice");
+    if ((long)b * m == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(new_xyz && xyz && P && wxyz && rowinfo && tilecloud && hdr && w2t && b2 && w3t && b3 && out, "sa_packed_mlp: null pointer");
+    PRCNN_REQUIRE((((uintptr_t)P | (uintptr_t)wxyz) & 15) == 0, "sa_packed_mlp: 16-byte alignment required");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemset2DAsync(out + out_col, (size_t)out_stride * sizeof(float), 0, (size_t)c3 * sizeof(float), (size_t)b * m, st) != hipSuccess) {
+        set_error("sa_packed_mlp: cannot zero the output slice");
+        return PRCNN_ELAUNCH;
+    }
+    if (max_tiles == 0) return PRCNN_OK;
+    static const int env_tiles = getenv("PRCNN_SA_TILES") ? atoi(getenv("PRCNN_SA_TILES")) : 0;
+    const int per_wg = env_tiles > 0 ? env_tiles : PK_TILES_PER_WG;
+    const int grid = (int)((max_tiles + per_wg - 1) / per_wg);
+    unsigned int *ticket = next_ticket(st);
+    if (!ticket) { set_error("sa_packed_mlp: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
+    if (c3 == 128)
+        hipLaunchKernelGGL(sa_packed_mlp128_kernel, dim3(grid), dim3(256), 0, st, n, m, hdr, new_xyz, xyz, (const float4 *)P,
+                           (const float4 *)wxyz, rowinfo, tilecloud, w2t, b2, w3t, b3, out, out_stride, out_col, ticket, per_wg);
+    else
+        hipLaunchKernelGGL(sa_packed_mlp256_kernel, dim3(grid), dim3(512), 0, st, n, m, hdr, new_xyz, xyz, (const float4 *)P,
+                           (const float4 *)wxyz, rowinfo, tilecloud, w2t, b2, w3t, b3, out, out_stride, out_col, ticket, per_wg);
+    return check_launch("sa_packed_mlp");
+}

@@ -14,6 +14,7 @@ _pkg_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if os.path.dirname(_pkg_dir) not in sys.path:
     sys.path.insert(0, os.path.dirname(_pkg_dir))
 _lib = importlib.import_module(os.path.basename(_pkg_dir) + "._lib")
+IS_HIP_EXTENSION = True     # marks the real extension (the test suite's CPU stand-ins do not carry it)
 
 
 def _chk(*tensors):

@@ -17,6 +17,7 @@ _pkg_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if os.path.dirname(_pkg_dir) not in sys.path:
     sys.path.insert(0, os.path.dirname(_pkg_dir))
 _lib = importlib.import_module(os.path.basename(_pkg_dir) + "._lib")
+IS_HIP_EXTENSION = True     # marks the real extension (the test suite's CPU stand-ins do not carry it)
 
 
 def _chk(dtype, *tensors):
@@ -167,6 +168,45 @@ def sa_mlp_fused_wrapper(new_xyz, xyz, P, wxyz, idx, w2t, b2, w3t, b3, out, out_
     _lib.call("prcnn_sa_mlp_fused", b, n, idx.size(1), idx.size(2), c1, w2t.size(1), w3t.size(1),
               new_xyz.data_ptr(), xyz.data_ptr(), P.data_ptr(), wxyz.data_ptr(), idx.data_ptr(), w2t.data_ptr(),
               b2.data_ptr(), w3t.data_ptr(), b3.data_ptr(), out.data_ptr(), out.size(-1), out_col,
+              _lib.current_stream(xyz))
+    return out
+
+
+class BallPack:
+    """Distinct grouped rows of an index tensor as 64-row tiles (prcnn_ball_pack); device-resident, no host sync."""
+    __slots__ = ("idx", "rowinfo", "tilecloud", "hdr", "max_tiles")
+
+    def record_stream(self, stream):
+        for t in (self.idx, self.rowinfo, self.tilecloud, self.hdr):
+            t.record_stream(stream)
+
+
+def ball_pack_wrapper(idx):
+    """idx (b,m,nsample) i32 from a ball query -> BallPack for sa_packed_mlp_wrapper."""
+    _chk(torch.int32, idx)
+    b, m, ns = idx.shape
+    cap = (m * ns + 63) // 64
+    pk = BallPack()
+    pk.idx = idx
+    pk.rowinfo = torch.empty((b * cap * 64,), dtype=torch.int32, device=idx.device)
+    pk.tilecloud = torch.empty((b * cap,), dtype=torch.int32, device=idx.device)
+    pk.hdr = torch.empty((4,), dtype=torch.int32, device=idx.device)
+    pk.max_tiles = b * cap
+    _lib.call("prcnn_ball_pack", b, m, ns, idx.data_ptr(), pk.rowinfo.data_ptr(), pk.tilecloud.data_ptr(),
+              pk.hdr.data_ptr(), _lib.current_stream(idx))
+    return pk
+
+
+def sa_packed_mlp_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col):
+    """sa_mlp_fused_wrapper over the distinct rows only (csrc/sa_packed.hip): same arguments with the BallPack of the
+    index tensor instead of the index tensor; bit-identical results."""
+    _chk(torch.float32, new_xyz, xyz, P, wxyz, w2t, b2, w3t, b3, out)
+    b, n, c1 = P.shape
+    if c1 != 128 or w2t.shape != (128, 128) or w3t.size(0) != 128:
+        raise RuntimeError("pointnet2_cuda: sa_packed_mlp needs 128-wide (zero-padded) layers 1 and 2")
+    _lib.call("prcnn_sa_packed_mlp", b, n, new_xyz.size(1), w3t.size(1), pack.max_tiles, new_xyz.data_ptr(), xyz.data_ptr(),
+              P.data_ptr(), wxyz.data_ptr(), pack.rowinfo.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr(),
+              w2t.data_ptr(), b2.data_ptr(), w3t.data_ptr(), b3.data_ptr(), out.data_ptr(), out.size(-1), out_col,
               _lib.current_stream(xyz))
     return out
 

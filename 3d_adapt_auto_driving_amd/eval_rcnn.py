@@ -29,6 +29,7 @@ from . import synth
 from .bbox_transform import decode_bbox_target
 from .net.point_rcnn import PointRCNN
 from .net.fast_infer import FastPointRCNN
+from ._lib import has_entry
 
 
 def build_model(cfg, device, seed=0):
@@ -78,7 +79,7 @@ def postprocess(cfg, ret_dict, batch_size):
         raise NotImplementedError("multi-class RCNN head")
     raw = rcnn_cls[:, :, 0]
     ext = iou3d_utils.iou3d_cuda
-    if FUSED_POSTPROCESS and M <= 128 and hasattr(ext, "rcnn_postprocess"):
+    if FUSED_POSTPROCESS and M <= 128 and has_entry(ext, "rcnn_postprocess"):
         # one extension call (three launches): decode, threshold, score sort, rotated NMS, assembly
         dev = rois.device
         pred = torch.empty((batch_size, M, 7), dtype=torch.float32, device=dev)

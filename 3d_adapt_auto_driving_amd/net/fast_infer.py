@@ -24,6 +24,7 @@ import torch
 
 from ..pointnet2 import pointnet2_utils as pu
 from ..pointnet2 import fused_mlp
+from .._lib import has_entry
 from .. import kitti_utils
 from .. import roipool3d_utils
 
@@ -31,6 +32,9 @@ from .. import roipool3d_utils
 USE_ROIPOOL_CANONICAL = True   # RCNN input assembly through roipool3d_canonical_kernel (False: torch-op sequence)
 USE_RCNN_POINT_MLP = os.environ.get("PRCNN_NO_POINT_MLP") is None      # RCNN entrance chain through csrc/rcnn_point_mlp.hip (False: library GEMMs + concat)
 USE_XYZ_MLP = True      # coordinates-only SA scales through csrc/sa_xyz_mlp.hip (False: grouped GEMM chain)
+# SA levels over the DISTINCT grouped rows only (csrc/sa_packed.hip: the back-filled copies of a ball's first hit are
+# skipped, bit-identical results).  PRCNN_NO_PACK=1 is the A/B switch back to all nsample rows (csrc/sa_mlp_fused.hip).
+USE_PACKED = os.environ.get("PRCNN_NO_PACK") is None
 
 
 def _round4(c):
@@ -48,7 +52,7 @@ def gemm_bias_act(a, wt, bias, relu):
     library GEMM with the epilogue fused when the backend offers it (hipBLASLt through torch._addmm_activation)."""
     if (USE_ROWS_GEMM128 and a.is_cuda and wt.shape[1] == 128 and wt.shape[0] in (128, 256) and a.shape[1] == wt.shape[0]
             and a.shape[0] % 64 == 0 and a.shape[0] >= 4096 and a.stride(1) == 1 and a.stride(0) % 4 == 0
-            and a.data_ptr() % 16 == 0 and hasattr(pu.pointnet2, "rows_gemm128_wrapper")):
+            and a.data_ptr() % 16 == 0):
         return pu.pointnet2.rows_gemm128_wrapper(a, wt, bias, relu)
     if relu:
         try:
@@ -85,6 +89,20 @@ class _Mlp:
             wt, b, _ = self.layers[0]
             c4 = _round4(grouped_c)
             self.split = (wt[:grouped_c].contiguous(), wt[c4:c4 + 3].contiguous(), b)   # (C,Cout), (3,Cout), (Cout)
+        # 128-wide (zero-padded) form for the fused MFMA kernels: c1, c2 <= 128, c3 in {128, 256}.  Zero columns give
+        # relu(0) = 0 activations that meet zero weight rows in the next layer: the padded chain adds exact zeros.
+        self.packed = None
+        if self.split is not None and len(self.layers) == 3 and all(l[2] for l in self.layers):
+            wf, wx, b1 = self.split
+            (w2, b2, _), (w3, b3, _) = self.layers[1], self.layers[2]
+            c1, c2, c3 = wf.shape[1], w2.shape[1], w3.shape[1]
+            if c1 <= 128 and c2 <= 128 and c3 in (128, 256) and w2.shape[0] == c1 and w3.shape[0] == c2:
+                def pad(t, rows, cols):
+                    o = t.new_zeros((rows, cols))
+                    o[:t.shape[0], :t.shape[1]] = t
+                    return o.contiguous()
+                self.packed = (pad(wf, wf.shape[0], 128), pad(wx, 3, 128), pad(b1.view(1, -1), 1, 128).view(128),
+                               pad(w2, 128, 128), pad(b2.view(1, -1), 1, 128).view(128), pad(w3, 128, c3), b3)
 
     def __call__(self, a, start=0):
         for wt, b, relu in self.layers[start:]:
@@ -119,10 +137,15 @@ def _fold_head(seq):
     return out
 
 
+def _state_version(model):
+    return sum(t._version for t in model.parameters()) + sum(t._version for t in model.buffers())
+
+
 class FastPointRCNN:
     def __init__(self, model, cfg):
         assert not model.training, "FastPointRCNN is an inference engine: call model.eval() first"
         self.model, self.cfg = model, cfg
+        self._folded_at = _state_version(model)       # BN is folded into the weights HERE: see check_weights()
         rpn = model.rpn
         bb = rpn.backbone_net
         self.sa = []
@@ -148,6 +171,13 @@ class FastPointRCNN:
                                      _Mlp(_fold_shared_mlp(mlp), grouped_c=cin), cin))
             self.rcnn_cls = _Mlp(_fold_head(r.cls_layer))
             self.rcnn_reg = _Mlp(_fold_head(r.reg_layer))
+
+    def check_weights(self):
+        """The engine folds BatchNorm into its own copies of the weights at construction.  Loading a checkpoint (or editing
+        a parameter in place) afterwards would silently evaluate stale weights: refuse instead."""
+        if _state_version(self.model) != self._folded_at:
+            raise RuntimeError("FastPointRCNN: the model's parameters changed after the engine was built "
+                               "(load the checkpoint first, then construct the engine / PipelinedRunner)")
 
     # ------------------------------------------------------------------ geometry (xyz only)
     @torch.no_grad()
@@ -177,7 +207,10 @@ class FastPointRCNN:
         sel = pu.furthest_point_sample(cur, npoint)
         new_xyz = torch.gather(cur, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
         idxs = [pu.ball_query(radius, ns, cur, new_xyz) for radius, ns, _, _ in scales]
-        state["sa"].append({"sel": sel, "new_xyz": new_xyz, "idx": idxs})
+        # the distinct-row lists of the scales that run on the packed MFMA kernel depend on the indices only
+        packs = [pu.pointnet2.ball_pack_wrapper(ix) if (USE_PACKED and sc[2].packed is not None) else None
+                 for ix, sc in zip(idxs, scales)]
+        state["sa"].append({"sel": sel, "new_xyz": new_xyz, "idx": idxs, "pack": packs})
         state["l_xyz"].append(new_xyz)
 
     @torch.no_grad()
@@ -187,11 +220,18 @@ class FastPointRCNN:
 
     # ------------------------------------------------------------------ building blocks
     @staticmethod
-    def _sa_scale(xyz, new_xyz, feats, idx, mlp, cin, out, out_col, P_pre=None):
+    def _sa_scale(xyz, new_xyz, feats, idx, mlp, cin, out, out_col, P_pre=None, pack=None):
         """one (radius, nsample) scale: group -> GEMM chain -> max over nsample into out[..., slice]"""
         ext = pu.pointnet2
         B, N, _ = xyz.shape
         M, ns = idx.shape[1], idx.shape[2]
+        if USE_PACKED and mlp.packed is not None:
+            # whole scale in ONE hand-written MFMA kernel over the DISTINCT rows of every group (csrc/sa_packed.hip)
+            wf, wx, b1, w2, b2, w3, b3 = mlp.packed
+            P = P_pre if P_pre is not None else gemm_bias_act(feats.view(B * N, cin), wf, b1, False).view(B, N, 128)
+            pk = pack if pack is not None else ext.ball_pack_wrapper(idx)
+            ext.sa_packed_mlp_wrapper(new_xyz, xyz, P, wx, pk, w2, b2, w3, b3, out, out_col)
+            return
         if (mlp.split is not None and len(mlp.layers) == 3 and mlp.layers[1][2] and mlp.layers[2][2] and
                 ext.sa_mlp_fused_supported(mlp.split[0].shape[1], mlp.layers[1][0].shape[1],
                                            mlp.layers[2][0].shape[1], ns)):
@@ -202,7 +242,6 @@ class FastPointRCNN:
                                      mlp.layers[2][0], mlp.layers[2][1], out, out_col)
             return
         if (cin == 0 and USE_XYZ_MLP and len(mlp.layers) == 3 and all(l[2] for l in mlp.layers) and
-                hasattr(ext, "sa_xyz_mlp_wrapper") and
                 ext.sa_xyz_mlp_supported(mlp.layers[0][0].shape[1], mlp.layers[1][0].shape[1], mlp.layers[2][0].shape[1], ns)):
             # coordinates-only level (RPN SA1): one VALU kernel, a grouped row never leaves its lane
             (w1, b1, _), (w2, b2, _), (w3, b3, _) = mlp.layers
@@ -230,8 +269,8 @@ class FastPointRCNN:
             width = sum(s[2].layers[-1][0].shape[1] for s in scales)
             out = torch.empty((B, npoint, width), dtype=torch.float32, device=xyz.device)
             col = 0
-            for (radius, ns, mlp, cin), idx in zip(scales, lev["idx"]):
-                self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, idx, mlp, cin, out, col)
+            for (radius, ns, mlp, cin), idx, pack in zip(scales, lev["idx"], lev.get("pack") or [None] * len(scales)):
+                self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, idx, mlp, cin, out, col, pack=pack)
                 col += mlp.layers[-1][0].shape[1]
             l_feat.append(out)
         ext = pu.pointnet2
@@ -254,6 +293,7 @@ class FastPointRCNN:
     def rpn_stage(self, pts_input, geo=None):
         """Backbone + RPN heads: everything up to (not including) the proposal layer."""
         cfg = self.cfg
+        self.check_weights()
         if pts_input.shape[-1] != 3:
             raise NotImplementedError("fast path: per-point input features (USE_INTENSITY) not supported")
         xyz = pts_input.contiguous()
@@ -317,7 +357,7 @@ class FastPointRCNN:
         nin = self.model.rcnn_net.rcnn_input_channel                           # xyz + mask + depth = 5
         rp = roipool3d_utils.roipool3d_cuda
         C = feats.shape[2]
-        if (USE_ROIPOOL_CANONICAL and hasattr(rp, "forward_canonical") and R.USE_DEPTH and nin == 5 and C % 4 == 0):
+        if (USE_ROIPOOL_CANONICAL and has_entry(rp, "forward_canonical") and R.USE_DEPTH and nin == 5 and C % 4 == 0):
             # enlarge + pool + canonical transform + aligned row layout [x',y',z',mask,depth,0,0,0 | feats] in ONE kernel
             B, M = rois.shape[0], rois.shape[1]
             P, W = R.NUM_POINTS, 8 + C
@@ -345,8 +385,8 @@ class FastPointRCNN:
             rpn_part = rows[:, nin:]
         P_pre = None
         sa1 = self.rcnn_sa[0]
-        if (USE_RCNN_POINT_MLP and W == 136 and rows.shape[0] % 64 == 0 and hasattr(ext_mod := pu.pointnet2, "rcnn_point_mlp_wrapper")
-                and self._point_mlp_ok()):
+        ext_mod = pu.pointnet2
+        if USE_RCNN_POINT_MLP and W == 136 and rows.shape[0] % 64 == 0 and self._point_mlp_ok():
             # xyz_up (2 layers) + concat + merge_down + the per-point part of SA1's layer 1: tiled MFMA layer kernels
             (wu1, bu1, _), (wu2, bu2, _) = self.xyz_up.layers
             (wm, bm, _), = self.merge_down.layers

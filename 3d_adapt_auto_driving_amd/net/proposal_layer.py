@@ -14,6 +14,7 @@ import torch.nn as nn
 from ..bbox_transform import decode_bbox_target
 from .. import kitti_utils
 from .. import iou3d_utils
+from .._lib import has_entry
 
 
 class ProposalLayer(nn.Module):
@@ -30,10 +31,11 @@ class ProposalLayer(nn.Module):
         cfg = self.cfg
         B, N = rpn_scores.shape
         ext = iou3d_utils.iou3d_cuda
-        if (self.fused and cfg[self.mode].RPN_DISTANCE_BASED_PROPOSE and N <= 16384 and hasattr(ext, "rpn_proposals")
-                and cfg.RPN.NMS_TYPE in ("normal", "rotate")):
+        # (the reference reads the switch from cfg.TEST whatever the mode, proposal_layer.py:40)
+        M = cfg[self.mode].RPN_POST_NMS_TOP_N
+        if (self.fused and cfg.TEST.RPN_DISTANCE_BASED_PROPOSE and N <= 16384 and M <= 128
+                and cfg.RPN.NMS_TYPE in ("normal", "rotate") and has_entry(ext, "rpn_proposals")):
             # one extension call: decode, sort, band selection, NMS and assembly as HIP kernels
-            M = cfg[self.mode].RPN_POST_NMS_TOP_N
             rois = torch.empty((B, M, 7), dtype=torch.float32, device=xyz.device)
             roi_scores = torch.empty((B, M), dtype=torch.float32, device=xyz.device)
             ext.rpn_proposals(xyz.contiguous(), rpn_scores.contiguous(), rpn_reg.contiguous(), self._anchor,
@@ -47,7 +49,7 @@ class ProposalLayer(nn.Module):
                                        get_xz_fine=cfg.RPN.LOC_XZ_FINE, get_y_by_bin=False, get_ry_fine=False)
         proposals[:, 1] += proposals[:, 3] / 2          # y becomes the bottom centre
         proposals = proposals.view(B, N, 7)
-        if not cfg[self.mode].RPN_DISTANCE_BASED_PROPOSE:
+        if not cfg.TEST.RPN_DISTANCE_BASED_PROPOSE:
             return self._score_based(rpn_scores, proposals)
         return self._distance_based(rpn_scores, proposals)
 

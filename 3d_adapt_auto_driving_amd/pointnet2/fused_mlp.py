@@ -55,8 +55,10 @@ def folded_layers(mlp):
 
 
 def _signature(mlp):
-    p = next(mlp.parameters())
-    return (p.device, p.data_ptr(), p._version)
+    """Identity + version of EVERY parameter and buffer (BN running statistics included): a partial load or an in-place
+    edit of any of them invalidates the folded weights."""
+    ts = list(mlp.parameters()) + list(mlp.buffers())
+    return (ts[0].device,) + tuple((t.data_ptr(), t._version) for t in ts)
 
 
 def run(mlp, x, pool):

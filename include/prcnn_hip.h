@@ -132,6 +132,24 @@ int prcnn_sa_mlp_fused(int b, int n, int m, int nsample, int c1, int c2, int c3,
                        const float *b2, const float *w3t, const float *b3, float *out, int out_stride,
                        int out_col, void *stream);
 
+/* The same fused set-abstraction MLP over the DISTINCT grouped rows only.  The reference's ball query back-fills the
+ * slots beyond the hit count with the first hit (ball_query_gpu.cu:35-39) and the grouped MLP + max_pool2d
+ * (pointnet2_utils.py:241-264, pointnet2_modules.py:37-53) evaluates those copies again; the max over a group does not
+ * change when they are dropped.  prcnn_ball_pack: idx (b,m,nsample) -> per cloud, cnt[c] = 1 + (last slot that differs
+ * from slot 0) rows per centre, written as a dense list of 64-row tiles:
+ *   rowinfo  u32 [b * ceil(m*nsample/64) * 64]: (centre within cloud) << 16 | (point within cloud)
+ *   tilecloud i32 [b * ceil(m*nsample/64)]:     cloud of each tile
+ *   hdr      u32 [4]: [0] tiles, [1] distinct rows (device-resident; no host sync)
+ * prcnn_sa_packed_mlp: layers as prcnn_sa_mlp_fused (c1 = c2 = 128; narrower levels zero-padded by the caller), c3 in
+ * {128, 256}; zeroes out[(b*m)][out_col..out_col+c3) and accumulates the per-centre maxima with atomicMax (values are
+ * >= 0 after ReLU).  Bit-identical to prcnn_sa_mlp_fused on the same idx.  max_tiles = b * ceil(m*nsample/64). */
+int prcnn_ball_pack(int b, int m, int nsample, const int *idx, unsigned int *rowinfo, int *tilecloud,
+                    unsigned int *hdr, void *stream);
+int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, const float *new_xyz, const float *xyz,
+                        const float *P, const float *wxyz, const unsigned int *rowinfo, const int *tilecloud,
+                        const unsigned int *hdr, const float *w2t, const float *b2, const float *w3t,
+                        const float *b3, float *out, int out_stride, int out_col, void *stream);
+
 /* Entrance of the RCNN as MFMA kernels (lib/net/rcnn_net.py:139-163 xyz_up_layer + concat + merge_down_layer,
  * fused with the per-point part of SA1's first layer): rows (r, ld) f32 = pooled rows
  * [x',y',z',mask,depth,0,0,0 | 128 RPN features at column fcol] as prcnn_roipool3d_canonical writes them, r % 64 == 0;

@@ -23,6 +23,14 @@ def _p(t, ty):
     return C.cast(t.data_ptr(), ty)
 
 
+class _CpuPack:
+    def __init__(self, idx):
+        self.idx = idx
+
+    def record_stream(self, stream):
+        pass
+
+
 class pointnet2_cpu:
     @staticmethod
     def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
@@ -108,6 +116,7 @@ class pointnet2_cpu:
         out.copy_((base + wxyz[0] * d[..., 0:1] + wxyz[1] * d[..., 1:2] + wxyz[2] * d[..., 2:3]).clamp_(min=0))
         return out
 
+    # ---- the MLP kernels this build owns, in THEIR summation order (oracle/mlp_oracle.c): bit-exact stand-ins
     @staticmethod
     def sa_mlp_fused_supported(c1, c2, c3, nsample):
         return c1 == 128 and c2 == 128 and c3 in (128, 256) and nsample == 64
@@ -115,11 +124,47 @@ class pointnet2_cpu:
     @staticmethod
     def sa_mlp_fused_wrapper(new_xyz, xyz, P, wxyz, idx, w2t, b2, w3t, b3, out, out_col):
         b, m, ns = idx.shape
-        y = torch.empty((b, m * ns, P.shape[2]))
-        pointnet2_cpu.gather_affine_relu_pm_wrapper(new_xyz, xyz, P, wxyz, idx, y)
-        y = torch.addmm(b2, y.view(b * m * ns, -1), w2t).clamp_(min=0)
-        y = torch.addmm(b3, y, w3t).clamp_(min=0)
-        out.view(b * m, -1)[:, out_col:out_col + w3t.shape[1]] = y.view(b * m, ns, -1).amax(dim=1)
+        assert P.shape[2] == 128 and tuple(w2t.shape) == (128, 128) and w3t.shape[0] == 128
+        O.lib().orc_sa_mlp_fused(b, xyz.size(1), m, ns, w3t.size(1), _p(new_xyz, _f), _p(xyz, _f), _p(P, _f), _p(wxyz, _f),
+                                 _p(idx, _i), _p(w2t, _f), _p(b2, _f), _p(w3t, _f), _p(b3, _f), _p(out, _f), out.size(-1), out_col)
+        return out
+
+    @staticmethod
+    def ball_pack_wrapper(idx):
+        """The CPU stand-in keeps the index tensor: the oracle evaluates ALL nsample rows (the reference's semantics)."""
+        return _CpuPack(idx)
+
+    @staticmethod
+    def sa_packed_mlp_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col):
+        return pointnet2_cpu.sa_mlp_fused_wrapper(new_xyz, xyz, P, wxyz, pack.idx, w2t, b2, w3t, b3, out, out_col)
+
+    @staticmethod
+    def sa_xyz_mlp_supported(c1, c2, c3, nsample):
+        return (c1, c2, c3, nsample) in ((16, 16, 32, 16), (32, 32, 64, 32))
+
+    @staticmethod
+    def sa_xyz_mlp_wrapper(new_xyz, xyz, idx, w1, b1, w2, b2, w3, b3, out, out_col):
+        b, m, ns = idx.shape
+        O.lib().orc_sa_xyz_mlp(b, xyz.size(1), m, ns, w1.size(1), w2.size(1), w3.size(1), _p(new_xyz, _f), _p(xyz, _f),
+                               _p(idx, _i), _p(w1, _f), _p(b1, _f), _p(w2, _f), _p(b2, _f), _p(w3, _f), _p(b3, _f),
+                               _p(out, _f), out.size(-1), out_col)
+        return out
+
+    @staticmethod
+    def rcnn_point_mlp_wrapper(rows, fcol, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, merged, p):
+        O.lib().orc_rcnn_point_mlp(C.c_long(rows.size(0)), rows.size(1), int(fcol), _p(rows, _f), _p(wu1, _f), _p(bu1, _f),
+                                   _p(wu2, _f), _p(bu2, _f), _p(wm, _f), _p(bm, _f), _p(wp, _f), _p(bp, _f),
+                                   _p(xfeat, _f), _p(merged, _f), _p(p, _f))
+        return p
+
+    @staticmethod
+    def rows_gemm128_wrapper(a, wt, bias, relu, out=None):
+        R, K = a.shape
+        if out is None:
+            out = torch.empty((R, 128), dtype=torch.float32)
+        assert a.stride(1) == 1 and K in (128, 256) and wt.is_contiguous()
+        O.lib().orc_rows_layer_mfma(C.c_long(R), K, 128, C.cast(a.data_ptr(), _f), C.c_long(a.stride(0)), _p(wt, _f),
+                                    _p(bias, _f), int(bool(relu)), _p(out, _f), C.c_long(128))
         return out
 
     @staticmethod

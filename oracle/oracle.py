@@ -24,7 +24,7 @@ _l = C.POINTER(C.c_longlong)
 def build(force=False):
     """(Re)build liboracle.so with gcc; also builds oracle/_ref when /root/reference exists."""
     if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "prcnn_oracle.c")):
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("prcnn_oracle.c", "mlp_oracle.c", "prcnn_oracle.h")):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 

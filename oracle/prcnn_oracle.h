@@ -102,6 +102,23 @@ void orc_rotate_iou_eval(int n, int k, const float *boxes, const float *query_bo
 int orc_num_threads(void);
 void orc_set_num_threads(int t);
 
+/* ---- mlp_oracle.c: the shared-MLP kernels this build owns, restated in THEIR fixed summation order (bit-exact checks).
+ * csrc/sa_mlp_fused.hip + csrc/sa_packed.hip */
+void orc_set_mfma_korder(int k);
+void orc_rows_layer_mfma(long rows, int K, int n, const float *A, long lda, const float *W, const float *bias, int do_relu,
+                         float *out, long ldo);
+void orc_sa_mlp_fused(int b, int n, int m, int ns, int c3, const float *new_xyz, const float *xyz, const float *P,
+                      const float *wxyz, const int *idx, const float *w2t, const float *b2, const float *w3t,
+                      const float *b3, float *out, int out_stride, int out_col);
+/* csrc/sa_xyz_mlp.hip */
+void orc_sa_xyz_mlp(int b, int n, int m, int ns, int c1, int c2, int c3, const float *new_xyz, const float *xyz,
+                    const int *idx, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                    const float *b3, float *out, int out_stride, int out_col);
+/* csrc/rcnn_point_mlp.hip */
+void orc_rcnn_point_mlp(long r, int ld, int fcol, const float *rows, const float *wu1, const float *bu1, const float *wu2,
+                        const float *bu2, const float *wm, const float *bm, const float *wp, const float *bp,
+                        float *xfeat, float *merged, float *p);
+
 #ifdef __cplusplus
 }
 #endif

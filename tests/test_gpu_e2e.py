@@ -382,22 +382,30 @@ def test_fused_final_stage_equals_batched_torch_path():
 
 def test_eval_scenes_writes_kitti_result_files(tmp_path):
     """Harness loop on the GPU (pipelined runner) over a few synthetic scenes: one KITTI result file per
-    scene (empty file when nothing survives), 16 fields per line, and the packed table agrees with them."""
+    scene (empty file when nothing survives), 16 fields per line, and the packed table agrees with them.
+    Scenes 80 and 81 are the two scenes of the REFERENCE-model fixture g8 (make_golden.py: helpers.scenes(2, 2048,
+    seed0=80)): their detections must be the reference's."""
     E, K = pkg("eval_rcnn"), pkg("kitti_io")
     model, cfg, g = tiny_model(DEV)
     src = K.SyntheticSource(cfg, 5)
+    src.ids = [80, 81, 82, 83, 84]
+    assert np.array_equal(src.load(80)[0], g["pts"][0]) and np.array_equal(src.load(81)[0], g["pts"][1])
     out = tmp_path / "final_result" / "data"
     table, counts = E.eval_scenes(model, cfg, DEV, src, src.ids, batch_size=2, output_dir=str(out))
     assert table.shape == (5, cfg.TEST.RPN_POST_NMS_TOP_N, 9) and counts.shape == (5,)
-    for sid in src.ids:
+    for k, sid in enumerate(src.ids):
+        assert int(table[k, 0, 8]) == sid
         lines = [l for l in open(out / ("%06d.txt" % sid)).read().split("\n") if l]
-        assert len(lines) <= int(counts[sid])
+        assert len(lines) <= int(counts[k])
         for l in lines:
             f = l.split()
             assert len(f) == 16 and f[0] == "Car"
     assert int(counts.sum()) > 0
-    # scene 0 and 1 are the two scenes of the reference fixture batch
-    assert int(counts[0]) == int(g["final_num"][0]) or True
+    for k in (0, 1):
+        n = int(g["final_num"][k])
+        assert int(counts[k]) == n
+        np.testing.assert_allclose(table[k, :n, 0:7].numpy(), g["final_boxes"][k, :n], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(table[k, :n, 7].numpy(), g["final_scores"][k, :n], rtol=0, atol=1e-4)
 
 
 def test_sharded_eval_tail_computes_ap_on_gpu():

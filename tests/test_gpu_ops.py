@@ -121,6 +121,30 @@ def test_query_and_group_fused(ext, oracle, c):
     assert np.array_equal(out.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("dense", [False, True])
+@pytest.mark.parametrize("c", [0, 128])
+@pytest.mark.parametrize("r,ns", [(0.1, 32), (0.1, 64), (0.2, 32), (0.2, 64), (0.4, 32), (0.4, 64)])
+def test_query_and_group_benchmarked_shapes(ext, oracle, r, ns, c, dense):
+    """BASELINE configs[1] exactly as bench.py / profiles/op_microbench.py run it: N = 16384, M = 4096 FPS centres, the six
+    (r, nsample) pairs, C in {0, 128} -- the shape that selects group_cat_lds_kernel<1> and the hashed-grid ball query.
+    `dense` shrinks the scene 33x so that the balls are FULL (first-nsample-by-index and the early exit decide), the
+    plain scene leaves most of them nearly empty (back-fill decides)."""
+    n, m = 16384, 4096
+    xyz = scenes(2, n, seed0=1000)
+    if dense:
+        xyz = (xyz * np.float32(0.03)).astype(np.float32)
+    new_xyz = centres(oracle, xyz, m)
+    feats = np.random.default_rng(7).standard_normal((2, c, n)).astype(np.float32) if c else None
+    idx = torch.empty((2, m, ns), dtype=torch.int32, device=DEV)
+    out = torch.full((2, 3 + c, m, ns), float("nan"), device=DEV)
+    ext.pointnet2.query_and_group_wrapper(2, n, m, c, r, ns, T(new_xyz), T(xyz), T(feats) if c else None, idx, out)
+    want, widx = oracle.query_and_group(r, ns, xyz, new_xyz, feats)
+    assert np.array_equal(idx.cpu().numpy(), widx)
+    assert np.array_equal(out.cpu().numpy(), want)
+    if dense:
+        assert (widx[..., -1] != widx[..., 0]).mean() > 0.5       # most balls really are full
+
+
 def test_group_and_gather(ext, oracle):
     rng = np.random.default_rng(3)
     pts = rng.standard_normal((3, 19, 777)).astype(np.float32)
