@@ -1,0 +1,191 @@
+// packed_layer.hip -- shared-MLP layers of ANY width over row lists whose length lives on the device.
+//
+// The fused kernels of sa_mlp_fused.hip / sa_packed.hip keep a level's weights in registers, which caps the widths at
+// 128-128-256.  The deeper RPN levels (pointrcnn/lib/config.py:58-61: 128-196-256, 256-256-512, 256-384-512) and the
+// RCNN's GroupAll level (256-256-512) do not fit, so they run layer by layer on the SAME packed row lists
+// (prcnn_ball_pack: only the distinct rows of every group):
+//
+//   packed_gather_affine_kernel   A1[r] = relu(P[point(r)] + Wxyz . (xyz[point(r)] - centre(r)))         (layer 1)
+//   packed_layer_kernel<false>    Y[r]  = relu(A[r] @ W + b)                                              (layer 2)
+//   packed_layer_kernel<true>     out[centre] = max over the centre's rows of relu(A[r] @ W + b)          (layer 3 + pool)
+//
+// One workgroup = one 64-row tile x one 128-column block; K runs in 128-deep panels: the panel of W goes to registers
+// (64 per lane, same lane mapping as sa_mlp_fused.hip), the panel of A to LDS, 128 v_mfma_f32_32x32x2_f32 per panel.
+// The grid is sized for the worst case (every ball full); the real tile count is read from the pack header and the
+// surplus workgroups exit at once.  Widths are zero-padded to multiples of 128 by the caller (exact: relu(0) = 0 meets
+// zero weight rows).  The same kernel with a host-side row count serves the per-point GEMMs (P = features @ W1f + b1).
+// Summation order: panels in order, inside a panel k = s, s + 64 for s = 0..63 -- oracle/mlp_oracle.c
+// orc_rows_layer_mfma reproduces it bit for bit.
+#include "common.hpp"
+#include "segmax.hpp"
+
+namespace prcnn {
+
+constexpr int PL_ROWS = 64;
+constexpr int PL_LD = 128 + 4;
+
+__global__ __launch_bounds__(256) void packed_gather_affine_kernel(
+    int n, int m, int c1, const unsigned int *__restrict__ hdr, const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+    const float4 *__restrict__ P, const float4 *__restrict__ wxyz, const unsigned int *__restrict__ rowinfo,
+    const int *__restrict__ tilecloud, float4 *__restrict__ out)
+{
+    const long t = blockIdx.x;
+    if (t >= (long)hdr[0]) return;
+    const int cloud = tilecloud[t];
+    const int q4 = c1 / 4;                                 // float4 chunks per row
+    const long pbase = (long)cloud * n, cbase = (long)cloud * m;
+    for (int e = threadIdx.x; e < PL_ROWS * q4; e += 256) {
+        const int row = e / q4, q = e - row * q4;
+        const unsigned int info = rowinfo[t * PL_ROWS + row];
+        const int k = (int)(info & 0xffffu), cl = (int)(info >> 16);
+        const float *pt = xyz + (pbase + k) * 3;
+        const float *ct = new_xyz + (cbase + cl) * 3;
+        const float dx = pt[0] - ct[0], dy = pt[1] - ct[1], dz = pt[2] - ct[2];
+        const float4 base = P[(pbase + k) * q4 + q];
+        const float4 wx = wxyz[q], wy = wxyz[q4 + q], wz = wxyz[2 * q4 + q];
+        float4 v;
+        v.x = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, base.x))), 0.f);
+        v.y = fmaxf(fmaf(wz.y, dz, fmaf(wy.y, dy, fmaf(wx.y, dx, base.y))), 0.f);
+        v.z = fmaxf(fmaf(wz.z, dz, fmaf(wy.z, dy, fmaf(wx.z, dx, base.z))), 0.f);
+        v.w = fmaxf(fmaf(wz.w, dz, fmaf(wy.w, dy, fmaf(wx.w, dx, base.w))), 0.f);
+        out[(t * PL_ROWS + row) * q4 + q] = v;
+    }
+}
+
+// SEGMAX = false: out[r][n0 + ..] = act(A[r] @ W + bias) for the tile's rows (rows >= `rows` are not stored)
+// SEGMAX = true : segmented max over the tile's rows by centre -> atomicMax into out[centre][out_col + n0 + ..]
+template <bool SEGMAX>
+__global__ __launch_bounds__(256, 2) void packed_layer_kernel(
+    const unsigned int *__restrict__ hdr, long rows_host, int K, int N, const float *__restrict__ A, long lda,
+    const float *__restrict__ W, const float *__restrict__ bias, int do_relu, float *__restrict__ out, long ldo,
+    const unsigned int *__restrict__ rowinfo, const int *__restrict__ tilecloud, int m, int out_col)
+{
+    __shared__ float tile[PL_ROWS * PL_LD];
+    __shared__ int ctr[PL_ROWS];
+    const long t = blockIdx.x;
+    const long rows = hdr ? (long)hdr[0] * PL_ROWS : rows_host;
+    if (t * PL_ROWS >= rows) return;
+    const int n0 = blockIdx.y * 128;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int chunk = tid & 31, r0 = tid >> 5;
+    f32x16 acc0 = {0}, acc1 = {0};
+    const float *a0p = tile + j * PL_LD + 64 * h;
+    const float *a1p = tile + (32 + j) * PL_LD + 64 * h;
+    for (int k0 = 0; k0 < K; k0 += 128) {
+        float wf[64];
+#pragma unroll
+        for (int s = 0; s < 64; ++s) wf[s] = W[(long)(k0 + s + 64 * h) * N + n0 + 32 * w + j];
+        if (k0) __syncthreads();                           // every wave has finished reading the previous panel
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = r0 + 8 * i;
+            long g = t * PL_ROWS + row;
+            if (g >= rows) g = rows - 1;                   // ragged last tile (host-count mode): recompute the last row
+            *reinterpret_cast<float4 *>(tile + row * PL_LD + 4 * chunk) =
+                *reinterpret_cast<const float4 *>(A + g * lda + k0 + 4 * chunk);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(a0p + 4 * g);
+            const float4 a1 = *reinterpret_cast<const float4 *>(a1p + 4 * g);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wf[4 * g + 0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wf[4 * g + 0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wf[4 * g + 1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, wf[4 * g + 1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, wf[4 * g + 2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, wf[4 * g + 2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, wf[4 * g + 3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wf[4 * g + 3], acc1, 0, 0, 0);
+        }
+    }
+    const float bcol = bias[n0 + 32 * w + j];
+    if constexpr (SEGMAX) {
+        if (tid < PL_ROWS) {
+            const unsigned int info = rowinfo[t * PL_ROWS + tid];
+            ctr[tid] = tilecloud[t] * m + (int)(info >> 16);
+        }
+        __syncthreads();
+        const int myc = ctr[lane], prevc = ctr[lane ? lane - 1 : 0];
+        const unsigned long long start = __ballot(lane == 0 || myc != prevc);
+        pk_segmented_max(acc0, acc1, ctr, start, h, out, (int)ldo, out_col + n0 + 32 * w + j, bcol);
+    } else {
+        __syncthreads();                                   // the panel tile is dead: stage the results through it
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v0 = acc0[r] + bcol, v1 = acc1[r] + bcol;
+            tile[row * PL_LD + 32 * w + j] = do_relu ? fmaxf(v0, 0.f) : v0;
+            tile[(32 + row) * PL_LD + 32 * w + j] = do_relu ? fmaxf(v1, 0.f) : v1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = r0 + 8 * i;
+            const long g = t * PL_ROWS + row;
+            if (g < rows)
+                *reinterpret_cast<float4 *>(out + g * ldo + n0 + 4 * chunk) =
+                    *reinterpret_cast<const float4 *>(tile + row * PL_LD + 4 * chunk);
+        }
+    }
+}
+
+}  // namespace prcnn
+
+using namespace prcnn;
+
+// A1 (max_tiles*64, c1) = relu(P[point] + wxyz . (xyz[point] - centre)) for every packed row (prcnn_ball_pack);
+// P (b,n,c1), wxyz (3,c1), c1 % 4 == 0.
+extern "C" int prcnn_packed_gather_affine(int b, int n, int m, int c1, long max_tiles, const float *new_xyz, const float *xyz,
+                                          const float *P, const float *wxyz, const unsigned int *rowinfo, const int *tilecloud,
+                                          const unsigned int *hdr, float *out, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && max_tiles >= 0 && c1 > 0 && c1 % 4 == 0, "packed_gather_affine: bad sizes");
+    if (max_tiles == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(new_xyz && xyz && P && wxyz && rowinfo && tilecloud && hdr && out, "packed_gather_affine: null pointer");
+    PRCNN_REQUIRE((((uintptr_t)P | (uintptr_t)wxyz | (uintptr_t)out) & 15) == 0, "packed_gather_affine: 16-byte alignment required");
+    PRCNN_REQUIRE(max_tiles <= 0x7fffffffL, "packed_gather_affine: too many tiles");
+    hipLaunchKernelGGL(packed_gather_affine_kernel, dim3((unsigned)max_tiles), dim3(256), 0, (hipStream_t)stream, n, m, c1, hdr,
+                       new_xyz, xyz, (const float4 *)P, (const float4 *)wxyz, rowinfo, tilecloud, (float4 *)out);
+    return check_launch("packed_gather_affine");
+}
+
+// out[r][0..N) = act(A[r][0..K) @ W + bias), K and N multiples of 128, W (K,N) k-major.  Row count: hdr != NULL ->
+// hdr[0] * 64 rows (a packed list; max_tiles sizes the grid), else `rows` (host count; max_tiles ignored).
+extern "C" int prcnn_packed_layer(const unsigned int *hdr, long rows, long max_tiles, int K, int N, const float *A, long lda,
+                                  const float *W, const float *bias, int relu, float *out, long ldo, void *stream)
+{
+    PRCNN_REQUIRE(K > 0 && N > 0 && K % 128 == 0 && N % 128 == 0, "packed_layer: K=%d, N=%d must be multiples of 128", K, N);
+    PRCNN_REQUIRE(lda >= K && ldo >= N && lda % 4 == 0 && ldo % 4 == 0, "packed_layer: bad leading dimensions");
+    const long tiles = hdr ? max_tiles : (rows + PL_ROWS - 1) / PL_ROWS;
+    PRCNN_REQUIRE(tiles >= 0 && tiles <= 0x7fffffffL && rows >= 0, "packed_layer: bad row count");
+    if (tiles == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(A && W && bias && out, "packed_layer: null pointer");
+    PRCNN_REQUIRE((((uintptr_t)A | (uintptr_t)out) & 15) == 0, "packed_layer: 16-byte alignment required");
+    hipLaunchKernelGGL(packed_layer_kernel<false>, dim3((unsigned)tiles, N / 128), dim3(256), 0, (hipStream_t)stream, hdr, rows, K, N,
+                       A, lda, W, bias, relu, out, ldo, nullptr, nullptr, 0, 0);
+    return check_launch("packed_layer");
+}
+
+// last layer of a level + max pool: out[(b*m)][out_col .. out_col + N) = max over each centre's packed rows of
+// relu(A[r] @ W + bias); the slice is zeroed first (values are >= 0, partial maxima arrive through atomicMax).
+extern "C" int prcnn_packed_layer_segmax(int b, int m, long max_tiles, int K, int N, const float *A, long lda, const float *W,
+                                         const float *bias, const unsigned int *rowinfo, const int *tilecloud,
+                                         const unsigned int *hdr, float *out, int out_stride, int out_col, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && m >= 0 && max_tiles >= 0, "packed_layer_segmax: bad sizes");
+    PRCNN_REQUIRE(K > 0 && N > 0 && K % 128 == 0 && N % 128 == 0, "packed_layer_segmax: K=%d, N=%d must be multiples of 128", K, N);
+    PRCNN_REQUIRE(lda >= K && lda % 4 == 0 && out_col >= 0 && out_stride >= out_col + N, "packed_layer_segmax: bad layout");
+    if ((long)b * m == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(A && W && bias && rowinfo && tilecloud && hdr && out, "packed_layer_segmax: null pointer");
+    PRCNN_REQUIRE(((uintptr_t)A & 15) == 0 && max_tiles <= 0x7fffffffL, "packed_layer_segmax: alignment / size");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemset2DAsync(out + out_col, (size_t)out_stride * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)b * m, st) != hipSuccess) {
+        set_error("packed_layer_segmax: cannot zero the output slice");
+        return PRCNN_ELAUNCH;
+    }
+    if (max_tiles == 0) return PRCNN_OK;
+    hipLaunchKernelGGL(packed_layer_kernel<true>, dim3((unsigned)max_tiles, N / 128), dim3(256), 0, st, hdr, 0L, K, N, A, lda, W, bias,
+                       1, out, (long)out_stride, rowinfo, tilecloud, m, out_col);
+    return check_launch("packed_layer_segmax");
+}

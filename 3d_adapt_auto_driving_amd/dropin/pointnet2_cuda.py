@@ -211,6 +211,43 @@ def sa_packed_mlp_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, ou
     return out
 
 
+def packed_gather_affine_wrapper(new_xyz, xyz, P, wxyz, pack, out):
+    """Layer 1 over a packed row list: out (pack.max_tiles*64, c1) = relu(P[point] + wxyz.(xyz[point] - centre))."""
+    _chk(torch.float32, new_xyz, xyz, P, wxyz, out)
+    b, n, c1 = P.shape
+    _lib.call("prcnn_packed_gather_affine", b, n, new_xyz.size(1), c1, pack.max_tiles, new_xyz.data_ptr(), xyz.data_ptr(),
+              P.data_ptr(), wxyz.data_ptr(), pack.rowinfo.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr(),
+              out.data_ptr(), _lib.current_stream(xyz))
+    return out
+
+
+def packed_layer_wrapper(a, wt, bias, relu, out, pack=None):
+    """out = act(a @ wt + bias), a (R, K) / wt (K, N) / out (R, N) with K, N multiples of 128 (csrc/packed_layer.hip).
+    pack given: only the first pack.hdr[0]*64 rows (a packed row list, count on the device); else all R rows."""
+    _chk(torch.float32, wt, bias)
+    for t in (a, out):
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+            raise RuntimeError("pointnet2_cuda: packed_layer expects 2-D float32 CUDA matrices with unit column stride")
+    R, K = a.shape
+    N = wt.size(1)
+    if wt.size(0) != K or out.size(0) != R or out.size(1) != N:
+        raise RuntimeError("pointnet2_cuda: packed_layer shape mismatch")
+    _lib.call("prcnn_packed_layer", None if pack is None else pack.hdr.data_ptr(), R, 0 if pack is None else pack.max_tiles,
+              K, N, a.data_ptr(), a.stride(0), wt.data_ptr(), bias.data_ptr(), int(bool(relu)), out.data_ptr(), out.stride(0),
+              _lib.current_stream(a))
+    return out
+
+
+def packed_layer_segmax_wrapper(a, wt, bias, pack, b, m, out, out_col):
+    """Last layer of a level + max pool over a packed row list: out (b,m,stride)[..., out_col:out_col+N]."""
+    _chk(torch.float32, a, wt, bias, out)
+    K, N = wt.shape
+    _lib.call("prcnn_packed_layer_segmax", b, m, pack.max_tiles, K, N, a.data_ptr(), a.stride(0), wt.data_ptr(), bias.data_ptr(),
+              pack.rowinfo.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr(), out.data_ptr(), out.size(-1), out_col,
+              _lib.current_stream(a))
+    return out
+
+
 def sa_xyz_mlp_supported(c1, c2, c3, nsample):
     return bool(_lib.load().prcnn_sa_xyz_mlp_supported(int(c1), int(c2), int(c3), int(nsample)))
 

@@ -139,7 +139,9 @@ class PipelinedRunner:
         self.depth = int(os.environ.get("PRCNN_GEO_DEPTH", "2")) if depth is None else depth
         # high priority: the geometry kernels are few, short-lived workgroups on a latency-bound chain;
         # when CU slots free up they should be placed before the feature pass's next workgroups
-        prio = int(os.environ.get("PRCNN_SIDE_PRIORITY", "-1"))
+        # default priority: with the SA levels on the packed MFMA kernels the feature pass is short, and high-priority side
+        # streams (three of them at depth 3) starve it -- measured 971 vs 1375 scenes/s
+        prio = int(os.environ.get("PRCNN_SIDE_PRIORITY", "0"))
         self.sides = [torch.cuda.Stream(self.device, priority=prio) for _ in range(max(1, self.depth))]
         self._next_side = 0
         self._pending = []        # [(batch tensor, geometry dict, ready event)] in launch order
@@ -208,7 +210,10 @@ class PipelinedRunner:
         self._chains.remove(ch)
         todo = [] if upcoming is None else (list(upcoming) if isinstance(upcoming, (list, tuple)) else [upcoming])
         todo = [p for p in todo if p is not None][:max(1, self.depth)]
-        gated = os.environ.get("PRCNN_NO_GATE") is None
+        # PRCNN_GATE=1: geometry chains may only start at the end of an RPN stage (round 1: the library GEMMs of that stage
+        # stretched 40-70 % beside FPS workgroups).  Off by default now: most of those GEMMs are ticketed kernels of our own
+        # and the RCNN stage is too short to hide a whole chain link (1293 gated vs 1371 ungated scenes/s).
+        gated = os.environ.get("PRCNN_GATE") == "1"
         if not gated:                         # A/B switch: geometry of the upcoming batches starts right away
             self._advance_chains(todo, None)
         main.wait_event(ch["ev"])

@@ -41,6 +41,22 @@ def _round4(c):
     return (c + 3) // 4 * 4
 
 
+def _round128(c):
+    return (c + 127) // 128 * 128
+
+
+def _pad2(t, rows, cols):
+    o = t.new_zeros((rows, cols))
+    o[:t.shape[0], :t.shape[1]] = t
+    return o.contiguous()
+
+
+def _pad1(t, n):
+    o = t.new_zeros((n,))
+    o[:t.shape[0]] = t
+    return o
+
+
 # 128-wide layers (FP level 0, first layers of the RPN heads, per-point parts of SA levels) on the own tiled MFMA layer kernel
 # instead of library GEMMs: measured neutral (837-840 vs 844 scenes/s) at these smaller shapes, so it is opt-in
 USE_ROWS_GEMM128 = os.environ.get("PRCNN_ROWS_GEMM") is not None
@@ -60,6 +76,17 @@ def gemm_bias_act(a, wt, bias, relu):
         except (AttributeError, RuntimeError):
             return torch.addmm(bias, a, wt).relu_()
     return torch.addmm(bias, a, wt)
+
+
+def point_layer(a, wt, bias, relu):
+    """act(a @ wt + bias) for a per-point (row-major) matrix: the tiled MFMA layer kernel of csrc/packed_layer.hip when
+    K and N are multiples of 128 (fixed summation order, reproduced bit for bit by the oracle), else a library GEMM."""
+    K, N = wt.shape
+    if (USE_PACKED and K % 128 == 0 and N % 128 == 0 and a.dim() == 2 and a.shape[1] == K and a.stride(1) == 1
+            and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0):
+        out = torch.empty((a.shape[0], N), dtype=torch.float32, device=a.device)
+        return pu.pointnet2.packed_layer_wrapper(a, wt, bias, relu, out)
+    return gemm_bias_act(a, wt, bias, relu)
 
 
 class _Mlp:
@@ -91,18 +118,19 @@ class _Mlp:
             self.split = (wt[:grouped_c].contiguous(), wt[c4:c4 + 3].contiguous(), b)   # (C,Cout), (3,Cout), (Cout)
         # 128-wide (zero-padded) form for the fused MFMA kernels: c1, c2 <= 128, c3 in {128, 256}.  Zero columns give
         # relu(0) = 0 activations that meet zero weight rows in the next layer: the padded chain adds exact zeros.
-        self.packed = None
+        self.packed = self.wide = None
         if self.split is not None and len(self.layers) == 3 and all(l[2] for l in self.layers):
             wf, wx, b1 = self.split
             (w2, b2, _), (w3, b3, _) = self.layers[1], self.layers[2]
             c1, c2, c3 = wf.shape[1], w2.shape[1], w3.shape[1]
             if c1 <= 128 and c2 <= 128 and c3 in (128, 256) and w2.shape[0] == c1 and w3.shape[0] == c2:
-                def pad(t, rows, cols):
-                    o = t.new_zeros((rows, cols))
-                    o[:t.shape[0], :t.shape[1]] = t
-                    return o.contiguous()
-                self.packed = (pad(wf, wf.shape[0], 128), pad(wx, 3, 128), pad(b1.view(1, -1), 1, 128).view(128),
-                               pad(w2, 128, 128), pad(b2.view(1, -1), 1, 128).view(128), pad(w3, 128, c3), b3)
+                self.packed = (_pad2(wf, wf.shape[0], 128), _pad2(wx, 3, 128), _pad1(b1, 128),
+                               _pad2(w2, 128, 128), _pad1(b2, 128), _pad2(w3, 128, c3), b3)
+            elif c3 % 128 == 0 and w2.shape[0] == c1 and w3.shape[0] == c2:
+                # wider levels: layer by layer over the packed rows (csrc/packed_layer.hip), widths padded to 128s
+                c1p, c2p = _round128(c1), _round128(c2)
+                self.wide = (_pad2(wf, wf.shape[0], c1p), _pad2(wx, 3, c1p), _pad1(b1, c1p),
+                             _pad2(w2, c1p, c2p), _pad1(b2, c2p), _pad2(w3, c2p, c3), b3)
 
     def __call__(self, a, start=0):
         for wt, b, relu in self.layers[start:]:
@@ -208,8 +236,8 @@ class FastPointRCNN:
         new_xyz = torch.gather(cur, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
         idxs = [pu.ball_query(radius, ns, cur, new_xyz) for radius, ns, _, _ in scales]
         # the distinct-row lists of the scales that run on the packed MFMA kernel depend on the indices only
-        packs = [pu.pointnet2.ball_pack_wrapper(ix) if (USE_PACKED and sc[2].packed is not None) else None
-                 for ix, sc in zip(idxs, scales)]
+        packs = [pu.pointnet2.ball_pack_wrapper(ix) if (USE_PACKED and (sc[2].packed is not None or sc[2].wide is not None))
+                 else None for ix, sc in zip(idxs, scales)]
         state["sa"].append({"sel": sel, "new_xyz": new_xyz, "idx": idxs, "pack": packs})
         state["l_xyz"].append(new_xyz)
 
@@ -231,6 +259,18 @@ class FastPointRCNN:
             P = P_pre if P_pre is not None else gemm_bias_act(feats.view(B * N, cin), wf, b1, False).view(B, N, 128)
             pk = pack if pack is not None else ext.ball_pack_wrapper(idx)
             ext.sa_packed_mlp_wrapper(new_xyz, xyz, P, wx, pk, w2, b2, w3, b3, out, out_col)
+            return
+        if USE_PACKED and mlp.wide is not None:
+            # wider level: the same distinct rows, layer by layer (gather+affine -> MFMA layer -> MFMA layer + segmented max)
+            wf, wx, b1, w2, b2, w3, b3 = mlp.wide
+            P = point_layer(feats.view(B * N, cin), wf, b1, False).view(B, N, -1)
+            pk = pack if pack is not None else ext.ball_pack_wrapper(idx)
+            rows = pk.max_tiles * 64
+            a1 = torch.empty((rows, wf.shape[1]), dtype=torch.float32, device=xyz.device)
+            ext.packed_gather_affine_wrapper(new_xyz, xyz, P, wx, pk, a1)
+            y2 = torch.empty((rows, w2.shape[1]), dtype=torch.float32, device=xyz.device)
+            ext.packed_layer_wrapper(a1, w2, b2, True, y2, pk)
+            ext.packed_layer_segmax_wrapper(y2, w3, b3, pk, B, M, out, out_col)
             return
         if (mlp.split is not None and len(mlp.layers) == 3 and mlp.layers[1][2] and mlp.layers[2][2] and
                 ext.sa_mlp_fused_supported(mlp.split[0].shape[1], mlp.layers[1][0].shape[1],
@@ -412,6 +452,18 @@ class FastPointRCNN:
                 out = torch.empty((Bc, npoint, cout), dtype=torch.float32, device=cur_xyz.device)
                 self._sa_scale(cur_xyz, new_xyz, cur_feat, idx, mlp, cin, out, 0, P_pre=P_pre if len(l_feat) == 1 else None)
                 l_xyz.append(new_xyz)
+            elif USE_PACKED and (mlp.packed is not None or mlp.wide is not None):
+                # GroupAll (pointnet2_utils.py:267-288): ONE group holding all n points, no centre subtraction == a ball
+                # query answer 0..n-1 around the origin; same packed kernels as the other levels
+                key = (Bc, n, str(cur_xyz.device))
+                if getattr(self, "_groupall", (None,))[0] != key:
+                    ga_idx = torch.arange(n, dtype=torch.int32, device=cur_xyz.device).view(1, 1, n).expand(Bc, 1, n).contiguous()
+                    self._groupall = (key, ga_idx, torch.zeros((Bc, 1, 3), dtype=torch.float32, device=cur_xyz.device),
+                                      ext.ball_pack_wrapper(ga_idx))
+                _, ga_idx, origin, ga_pack = self._groupall
+                out = torch.empty((Bc, 1, cout), dtype=torch.float32, device=cur_xyz.device)
+                self._sa_scale(cur_xyz, origin, cur_feat, ga_idx, mlp, cin, out, 0, pack=ga_pack)
+                l_xyz.append(None)
             else:                                                               # GroupAll: one group of n points
                 c4 = _round4(cin)
                 g = cur_feat.new_zeros((Bc, n, c4 + 4))

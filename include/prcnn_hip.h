@@ -150,6 +150,24 @@ int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, const float
                         const unsigned int *hdr, const float *w2t, const float *b2, const float *w3t,
                         const float *b3, float *out, int out_stride, int out_col, void *stream);
 
+/* Shared-MLP layers of any width over packed row lists (csrc/packed_layer.hip): the levels whose weights do not fit the
+ * register-resident fused kernels (RPN SA3/SA4: 128-196-256, 256-256-512, 256-384-512, pointrcnn/lib/config.py:58-61;
+ * RCNN GroupAll level 256-256-512) run layer by layer on the distinct rows only.  Widths are zero-padded to multiples of
+ * 128 by the caller; W is (K,N) input-channel-major; f32 MFMA, fixed summation order (oracle/mlp_oracle.c).
+ *   prcnn_packed_gather_affine: A1 (max_tiles*64, c1) = relu(P[point] + wxyz.(xyz[point] - centre))   (layer 1)
+ *   prcnn_packed_layer:         out = act(A @ W + bias) over hdr[0]*64 rows (hdr != NULL) or `rows` rows (hdr == NULL:
+ *                               a plain row-major GEMM layer with a host-side row count, e.g. P = features @ W1f + b1)
+ *   prcnn_packed_layer_segmax:  out[(b*m)][out_col..+N) = max over each centre's rows of relu(A @ W + bias)
+ *                               (pointnet2_modules.py:37-53: last layer + max_pool2d) */
+int prcnn_packed_gather_affine(int b, int n, int m, int c1, long max_tiles, const float *new_xyz, const float *xyz,
+                               const float *P, const float *wxyz, const unsigned int *rowinfo, const int *tilecloud,
+                               const unsigned int *hdr, float *out, void *stream);
+int prcnn_packed_layer(const unsigned int *hdr, long rows, long max_tiles, int K, int N, const float *A, long lda,
+                       const float *W, const float *bias, int relu, float *out, long ldo, void *stream);
+int prcnn_packed_layer_segmax(int b, int m, long max_tiles, int K, int N, const float *A, long lda, const float *W,
+                              const float *bias, const unsigned int *rowinfo, const int *tilecloud,
+                              const unsigned int *hdr, float *out, int out_stride, int out_col, void *stream);
+
 /* Entrance of the RCNN as MFMA kernels (lib/net/rcnn_net.py:139-163 xyz_up_layer + concat + merge_down_layer,
  * fused with the per-point part of SA1's first layer): rows (r, ld) f32 = pooled rows
  * [x',y',z',mask,depth,0,0,0 | 128 RPN features at column fcol] as prcnn_roipool3d_canonical writes them, r % 64 == 0;

@@ -26,6 +26,7 @@ def _p(t, ty):
 class _CpuPack:
     def __init__(self, idx):
         self.idx = idx
+        self.max_tiles = (idx.numel() + 63) // 64
 
     def record_stream(self, stream):
         pass
@@ -137,6 +138,31 @@ class pointnet2_cpu:
     @staticmethod
     def sa_packed_mlp_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col):
         return pointnet2_cpu.sa_mlp_fused_wrapper(new_xyz, xyz, P, wxyz, pack.idx, w2t, b2, w3t, b3, out, out_col)
+
+    @staticmethod
+    def packed_gather_affine_wrapper(new_xyz, xyz, P, wxyz, pack, out):
+        """CPU stand-in: ALL nsample rows per group (row r of group g at g * nsample + r), same fmaf chain."""
+        idx = pack.idx
+        b, m, ns = idx.shape
+        O.lib().orc_gather_affine_fma(b, xyz.size(1), m, ns, P.size(2), _p(new_xyz, _f), _p(xyz, _f), _p(P, _f), _p(wxyz, _f),
+                                      _p(idx, _i), C.cast(out.data_ptr(), _f))
+        return out
+
+    @staticmethod
+    def packed_layer_wrapper(a, wt, bias, relu, out, pack=None):
+        R = a.size(0) if pack is None else pack.idx.numel()
+        assert a.stride(1) == 1 and out.stride(1) == 1 and wt.is_contiguous()
+        O.lib().orc_rows_layer_mfma(C.c_long(R), a.size(1), wt.size(1), C.cast(a.data_ptr(), _f), C.c_long(a.stride(0)),
+                                    _p(wt, _f), _p(bias, _f), int(bool(relu)), C.cast(out.data_ptr(), _f), C.c_long(out.stride(0)))
+        return out
+
+    @staticmethod
+    def packed_layer_segmax_wrapper(a, wt, bias, pack, b, m, out, out_col):
+        ns = pack.idx.shape[2]
+        y = torch.empty((b * m * ns, wt.size(1)))
+        pointnet2_cpu.packed_layer_wrapper(a, wt, bias, True, y, pack)
+        out.view(b * m, -1)[:, out_col:out_col + wt.size(1)] = y.view(b * m, ns, -1).amax(dim=1)
+        return out
 
     @staticmethod
     def sa_xyz_mlp_supported(c1, c2, c3, nsample):

@@ -109,6 +109,28 @@ void orc_sa_mlp_fused(int b, int n, int m, int ns, int c3, const float *new_xyz,
     }
 }
 
+/* csrc/packed_layer.hip packed_gather_affine_kernel (and the tile builders of the fused kernels): layer 1 of a grouped
+ * level as an fmaf chain from the per-point part, for ALL nsample rows of every group: out[(g*ns + s)][0..c1) */
+void orc_gather_affine_fma(int b, int n, int m, int ns, int c1, const float *new_xyz, const float *xyz, const float *P,
+                           const float *wxyz, const int *idx, float *out)
+{
+    const long groups = (long)b * m;
+#pragma omp parallel for schedule(static)
+    for (long g = 0; g < groups; ++g) {
+        const long bi = g / m;
+        const float *ct = new_xyz + g * 3;
+        for (int s = 0; s < ns; ++s) {
+            const int k = idx[g * ns + s];
+            const float *pt = xyz + (bi * n + k) * 3;
+            const float *base = P + (bi * n + k) * c1;
+            const float dx = pt[0] - ct[0], dy = pt[1] - ct[1], dz = pt[2] - ct[2];
+            float *o = out + (g * ns + s) * c1;
+            for (int c = 0; c < c1; ++c)
+                o[c] = relu(fmaf(wxyz[2 * c1 + c], dz, fmaf(wxyz[c1 + c], dy, fmaf(wxyz[c], dx, base[c]))));
+        }
+    }
+}
+
 /* csrc/sa_xyz_mlp.hip: coordinates-only scale; every chain starts from the bias and runs k = 0..K-1 */
 void orc_sa_xyz_mlp(int b, int n, int m, int ns, int c1, int c2, int c3, const float *new_xyz, const float *xyz,
                     const int *idx, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,

@@ -161,3 +161,71 @@ def test_packed_kernel_at_the_rcnn_batch8_shape(ext, oracle, c3):
     pick = torch.tensor([0, 1, 399, 798, 799])
     want = oracle_fused(new_xyz[pick], xyz[pick], P[pick], wx, idx[pick], w2, b2, w3, b3, c3, 0)
     assert torch.equal(outs[0][pick].cpu(), want)
+
+
+@pytest.mark.parametrize("cin,c1,c2,c3", [(256, 128, 196, 256), (512, 256, 384, 512), (256, 256, 256, 512)])
+def test_wide_packed_level_layer_by_layer_is_bit_exact(ext, cin, c1, c2, c3):
+    """RPN SA3 / SA4 and the RCNN GroupAll level (config.py:58-61, 118-120): per-point layer, gather + affine, MFMA layer,
+    MFMA layer + segmented max over the DISTINCT rows == the CPU oracle evaluating ALL nsample rows in the kernels'
+    summation order, bit for bit; widths zero-padded to 128s exactly as net/fast_infer.py does."""
+    rng = np.random.default_rng(cin + c2)
+    b, n, m, ns = 3, 256, 40, 32
+    E = ext.pointnet2
+    c1p, c2p = (c1 + 127) // 128 * 128, (c2 + 127) // 128 * 128
+    xyz = T(rng.uniform(-2, 2, (b, n, 3)).astype(np.float32))
+    new_xyz = T(rng.uniform(-2, 2, (b, m, 3)).astype(np.float32))
+    feats = T(rng.standard_normal((b, n, cin)).astype(np.float32))
+    idx_np, cnt = ball_like_idx(rng, b, m, n, ns, 5)
+    idx = T(idx_np)
+
+    def padded(shape, real):
+        w = np.zeros(shape, np.float32)
+        w[tuple(slice(0, r) for r in real)] = rng.standard_normal(real) / np.sqrt(real[0])
+        return T(w)
+    wf, wx, b1 = padded((cin, c1p), (cin, c1)), padded((3, c1p), (3, c1)), padded((c1p,), (c1,))
+    w2, b2 = padded((c1p, c2p), (c1, c2)), padded((c2p,), (c2,))
+    w3, b3 = padded((c2p, c3), (c2, c3)), padded((c3,), (c3,))
+
+    def level(X, dev_pack):
+        dev = xyz.device if dev_pack else "cpu"
+        mv = (lambda t: t) if dev_pack else (lambda t: t.cpu())
+        P = torch.empty((b * n, c1p), device=dev)
+        X.packed_layer_wrapper(mv(feats).view(b * n, cin), mv(wf), mv(b1), False, P)
+        pk = X.ball_pack_wrapper(mv(idx))
+        rows = pk.max_tiles * 64
+        a1 = torch.zeros((rows, c1p), device=dev)
+        X.packed_gather_affine_wrapper(mv(new_xyz), mv(xyz), P.view(b, n, c1p), mv(wx), pk, a1)
+        y2 = torch.zeros((rows, c2p), device=dev)
+        X.packed_layer_wrapper(a1, mv(w2), mv(b2), True, y2, pk)
+        out = torch.full((b, m, c3 + 4), float("nan"), device=dev)
+        out[:, :, :4] = -1
+        X.packed_layer_segmax_wrapper(y2, mv(w3), mv(b3), pk, b, m, out, 4)
+        return P, out
+    Pg, og = level(E, True)
+    Pc, oc = level(ext_cpu.pointnet2_cpu, False)
+    assert torch.equal(Pg.cpu(), Pc)
+    assert torch.isfinite(og).all()
+    assert torch.equal(og.cpu(), oc), float((og.cpu() - oc).abs().max())
+    # and within f32 rounding of plain library arithmetic (the padding changes nothing)
+    ix = idx.long().view(b, m * ns)
+    base = torch.gather(Pg.view(b, n, c1p), 1, ix.unsqueeze(-1).expand(-1, -1, c1p))
+    d = torch.gather(xyz, 1, ix.unsqueeze(-1).expand(-1, -1, 3)).view(b, m, ns, 3) - new_xyz.unsqueeze(2)
+    a = (base + d.view(b, m * ns, 3) @ wx).clamp_(min=0)
+    y = torch.addmm(b3, torch.addmm(b2, a.view(-1, c1p), w2).clamp_(min=0), w3).clamp_(min=0).view(b * m, ns, c3).amax(1)
+    assert (og[:, :, 4:].reshape(b * m, c3) - y).abs().max().item() < 5e-5 * max(1.0, y.abs().max().item())
+
+
+def test_packed_layer_host_row_count_ragged(ext):
+    """The layer kernel as a plain row-major GEMM layer: row counts that are not multiples of 64, strided input, ReLU off/on."""
+    rng = np.random.default_rng(9)
+    for R, K, N, relu in ((1, 128, 128, True), (63, 256, 128, False), (200, 128, 384, True), (8192, 512, 256, False)):
+        a_full = T(rng.standard_normal((R, K + 8)).astype(np.float32))
+        a = a_full[:, 4:4 + K] if False else a_full[:, :K]           # row stride K + 8, 16-byte aligned
+        w = T((rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32))
+        bias = T(rng.standard_normal(N).astype(np.float32))
+        out = torch.full((R + 1, N), float("nan"), device=DEV)
+        ext.pointnet2.packed_layer_wrapper(a, w, bias, relu, out[:R])
+        assert torch.isnan(out[R]).all()                               # nothing written past the last row
+        want = torch.empty((R, N))
+        ext_cpu.pointnet2_cpu.packed_layer_wrapper(a.cpu(), w.cpu(), bias.cpu(), relu, want)
+        assert torch.equal(out[:R].cpu(), want)
