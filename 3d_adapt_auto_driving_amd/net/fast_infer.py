@@ -35,6 +35,7 @@ USE_XYZ_MLP = True      # coordinates-only SA scales through csrc/sa_xyz_mlp.hip
 # SA levels over the DISTINCT grouped rows only (csrc/sa_packed.hip: the back-filled copies of a ball's first hit are
 # skipped, bit-identical results).  PRCNN_NO_PACK=1 is the A/B switch back to all nsample rows (csrc/sa_mlp_fused.hip).
 USE_PACKED = os.environ.get("PRCNN_NO_PACK") is None
+USE_POINT_LAYER = os.environ.get("PRCNN_LIB_GEMM") is None     # per-point layers (FP modules, heads) on the own MFMA layer kernel
 
 
 def _round4(c):
@@ -134,7 +135,7 @@ class _Mlp:
 
     def __call__(self, a, start=0):
         for wt, b, relu in self.layers[start:]:
-            a = gemm_bias_act(a, wt, b, relu)
+            a = point_layer(a, wt, b, relu) if USE_POINT_LAYER else gemm_bias_act(a, wt, b, relu)
         return a
 
 
