@@ -35,7 +35,7 @@ SIGNATURES = {
     "prcnn_group_cat_pm": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "prcnn_gather_affine_relu_pm": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_sa_mlp_fused": [_I] * 7 + [_P] * 10 + [_I, _I, _P],
-    "prcnn_ball_pack": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "prcnn_ball_pack": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
     "prcnn_sa_packed_mlp": [_I, _I, _I, _I, C.c_long] + [_P] * 12 + [_I, _I, _P],
     "prcnn_packed_gather_affine": [_I, _I, _I, _I, C.c_long] + [_P] * 8 + [_P],
     "prcnn_packed_layer": [_P, C.c_long, C.c_long, _I, _I, _P, C.c_long, _P, _P, _I, _P, C.c_long, _P],
@@ -48,7 +48,8 @@ SIGNATURES = {
     "prcnn_nms_normal": [_I, _P, _P, _F, _P],
     "prcnn_nms_device": [_I, _I, _P, _P, _F, _I, _I, _P, _P, _P],
     "prcnn_rows_gemm128": [_L, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P],
-    "prcnn_rcnn_point_mlp": [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "prcnn_rcnn_point_mlp": [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "prcnn_pooled_tiles": [_I, _I, _P, _P, _P, _P],
     "prcnn_sa_xyz_mlp_supported": [_I, _I, _I, _I],
     "prcnn_sa_xyz_mlp": [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "prcnn_rpn_proposals": [_I, _I, _I, _F, _F, _I, _I, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
@@ -56,7 +57,7 @@ SIGNATURES = {
     "prcnn_roipool3d": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "prcnn_host_pts_in_boxes3d": [_I, _I, _P, _P, _P],
     "prcnn_host_roipool3d": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
-    "prcnn_roipool3d_canonical": [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    "prcnn_roipool3d_canonical": [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_input_stage": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P],
     "prcnn_rotate_iou_eval": [_I, _I, _P, _P, _P, _I, _P],
     "prcnn_rotate_iou_eval_segmented": [_I, _L, _P, _P, _P, _P, _P, _P, _I, _P],

@@ -65,8 +65,13 @@ template <int NPANEL, int PRO, bool RELU>
 __global__ __launch_bounds__(256, 2) void rows_layer_kernel(
     long tiles, int per_wg, const float *__restrict__ src0, int ld0, int col0, const float *__restrict__ src1, int ld1, int col1,
     const float4 *__restrict__ wu1, const float4 *__restrict__ bu1, const float *__restrict__ w0, const float *__restrict__ w1,
-    const float *__restrict__ bias, float *__restrict__ out, unsigned int *__restrict__ ticket)
+    const float *__restrict__ bias, float *__restrict__ out, unsigned int *__restrict__ ticket,
+    const int *__restrict__ tilemap, const unsigned int *__restrict__ ntiles_dev)
 {
+    // tilemap (optional): ticket j serves tile tilemap[j], j < *ntiles_dev -- only the tiles that hold DISTINCT pooled rows
+    // (prcnn_pooled_tiles); the grid is still sized for all tiles and surplus workgroups draw a ticket and leave.
+    if (ntiles_dev) tiles = (long)*ntiles_dev;
+#define TILE_OF(tk) (tilemap ? (long)tilemap[tk] : (long)(tk))
     __shared__ float lds[NPANEL * PM_ROWS * PM_LD + 4];
     float *T0 = lds, *T1 = lds + (NPANEL - 1) * PM_ROWS * PM_LD;
     unsigned int *slot = reinterpret_cast<unsigned int *>(lds + NPANEL * PM_ROWS * PM_LD);
@@ -101,11 +106,13 @@ __global__ __launch_bounds__(256, 2) void rows_layer_kernel(
     if (tid == 0) slot[0] = atomicAdd(ticket, 1u);
     lds_barrier();
     long t = slot[0];
-    if (PF && t < tiles) { ROWS_FETCH(t) }
+    if (t >= tiles) return;
+    long tt = TILE_OF(t);
+    if (PF) { ROWS_FETCH(tt) }
     for (int served = 0; served < per_wg && t < tiles; ++served) {
         const bool more = served + 1 < per_wg;
         if (tid == 0) slot[(served + 1) & 1] = more ? atomicAdd(ticket, 1u) : 0xffffffffu;
-        if (!PF) { ROWS_FETCH(t) }
+        if (!PF) { ROWS_FETCH(tt) }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = r0 + 8 * i;
@@ -123,7 +130,8 @@ __global__ __launch_bounds__(256, 2) void rows_layer_kernel(
         }
         lds_barrier();
         const long t_next = slot[(served + 1) & 1];
-        if (PF && t_next < tiles) { ROWS_FETCH(t_next) }            // in flight during the MFMAs below
+        const long tt_next = t_next < tiles ? TILE_OF(t_next) : 0;
+        if (PF && t_next < tiles) { ROWS_FETCH(tt_next) }           // in flight during the MFMAs below
         f32x16 acc0 = {0}, acc1 = {0};
         mfma_panel(T0, wa, acc0, acc1, j, h);
         if constexpr (NPANEL == 2) mfma_panel(T1, wb, acc0, acc1, j, h);
@@ -139,16 +147,48 @@ __global__ __launch_bounds__(256, 2) void rows_layer_kernel(
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = r0 + 8 * i;
-            *reinterpret_cast<float4 *>(out + (t * PM_ROWS + row) * PM_C + 4 * chunk) =
+            *reinterpret_cast<float4 *>(out + (tt * PM_ROWS + row) * PM_C + 4 * chunk) =
                 *reinterpret_cast<const float4 *>(T0 + row * PM_LD + 4 * chunk);
         }
         lds_barrier();                                              // the next builder overwrites T0
         t = t_next;
+        tt = tt_next;
     }
 #undef ROWS_FETCH
+#undef TILE_OF
 }
 
 unsigned int *next_ticket(hipStream_t st);    // sa_mlp_fused.hip
+
+// cnt[c] distinct rows of cloud c (rows_per_cloud rows each, a multiple of 64) -> the list of 64-row tiles that hold
+// them, in cloud order: tilemap[j], j < hdr[0].  One workgroup, clouds in chunks of 1024 with a running offset.
+__global__ __launch_bounds__(1024) void pooled_tiles_kernel(int clouds, int rows_per_cloud, const int *__restrict__ cnt,
+                                                            int *__restrict__ tilemap, unsigned int *__restrict__ hdr)
+{
+    __shared__ int part[1024];
+    __shared__ int s_run;
+    const int tid = threadIdx.x, per = rows_per_cloud / PM_ROWS;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < clouds; c0 += 1024) {
+        const int c = c0 + tid;
+        const int live = c < clouds ? min(per, (max(cnt[c], 1) + PM_ROWS - 1) / PM_ROWS) : 0;
+        part[tid] = live;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int v = tid >= d ? part[tid - d] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        const int base = s_run + part[tid] - live;
+        for (int q = 0; q < live; ++q) tilemap[base + q] = c * per + q;
+        __syncthreads();
+        if (tid == 1023) s_run += part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) hdr[0] = (unsigned int)s_run;
+}
 
 }  // namespace prcnn
 
@@ -162,8 +202,10 @@ using namespace prcnn;
 // xfeat, merged, p: (r,128) each, caller-allocated.
 extern "C" int prcnn_rcnn_point_mlp(long r, int ld, int fcol, const float *rows, const float *wu1, const float *bu1,
                                     const float *wu2, const float *bu2, const float *wm, const float *bm, const float *wp,
-                                    const float *bp, float *xfeat, float *merged, float *p, void *stream)
+                                    const float *bp, float *xfeat, float *merged, float *p, const int *tilemap,
+                                    const unsigned int *ntiles, void *stream)
 {
+    PRCNN_REQUIRE((tilemap == nullptr) == (ntiles == nullptr), "rcnn_point_mlp: tilemap and ntiles go together");
     PRCNN_REQUIRE(r >= 0 && r % PM_ROWS == 0, "rcnn_point_mlp: %ld rows is not a multiple of %d", r, PM_ROWS);
     PRCNN_REQUIRE(ld >= 8 && ld % 4 == 0 && fcol >= 8 && fcol % 4 == 0 && fcol + PM_C <= ld,
                   "rcnn_point_mlp: bad row layout ld=%d fcol=%d", ld, fcol);
@@ -182,15 +224,15 @@ extern "C" int prcnn_rcnn_point_mlp(long r, int ld, int fcol, const float *rows,
     unsigned int *t1 = next_ticket(st), *t2 = next_ticket(st), *t3 = next_ticket(st);
     if (!t1 || !t2 || !t3) { set_error("rcnn_point_mlp: cannot set up the tile tickets"); return PRCNN_ELAUNCH; }
     hipLaunchKernelGGL((rows_layer_kernel<1, 1, true>), dim3(grid), dim3(256), 0, st, tiles, per_wg, rows, ld, 0, nullptr, 0, 0,
-                       (const float4 *)wu1, (const float4 *)bu1, wu2, nullptr, bu2, xfeat, t1);
+                       (const float4 *)wu1, (const float4 *)bu1, wu2, nullptr, bu2, xfeat, t1, tilemap, ntiles);
     int rc = check_launch("rcnn_point_mlp(xyz_up)");
     if (rc != PRCNN_OK) return rc;
     hipLaunchKernelGGL((rows_layer_kernel<2, 0, true>), dim3(grid), dim3(256), 0, st, tiles, per_wg, xfeat, PM_C, 0, rows, ld, fcol,
-                       nullptr, nullptr, wm, wm + (size_t)PM_C * PM_C, bm, merged, t2);
+                       nullptr, nullptr, wm, wm + (size_t)PM_C * PM_C, bm, merged, t2, tilemap, ntiles);
     rc = check_launch("rcnn_point_mlp(merge)");
     if (rc != PRCNN_OK) return rc;
     hipLaunchKernelGGL((rows_layer_kernel<1, 0, false>), dim3(grid), dim3(256), 0, st, tiles, per_wg, merged, PM_C, 0, nullptr, 0, 0,
-                       nullptr, nullptr, wp, nullptr, bp, p, t3);
+                       nullptr, nullptr, wp, nullptr, bp, p, t3, tilemap, ntiles);
     return check_launch("rcnn_point_mlp(sa1 per-point)");
 }
 
@@ -218,9 +260,20 @@ extern "C" int prcnn_rows_gemm128(long r, int npanel, const float *src0, int ld0
     if (!t) { set_error("rows_gemm128: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
     const float *w1 = w + (size_t)PM_C * PM_C;
 #define LAUNCH(NP, RL) hipLaunchKernelGGL((rows_layer_kernel<NP, 0, RL>), dim3(grid), dim3(256), 0, st, tiles, per_wg, src0, ld0, col0, \
-                                          src1, ld1, col1, nullptr, nullptr, w, w1, bias, out, t)
+                                          src1, ld1, col1, nullptr, nullptr, w, w1, bias, out, t, nullptr, nullptr)
     if (npanel == 1) { if (relu) LAUNCH(1, true); else LAUNCH(1, false); }
     else             { if (relu) LAUNCH(2, true); else LAUNCH(2, false); }
 #undef LAUNCH
     return check_launch("rows_gemm128");
+}
+
+
+// cnt (clouds) i32 distinct rows per cloud of rows_per_cloud rows (prcnn_roipool3d_canonical's pooled_cnt) -> tilemap
+// (clouds * rows_per_cloud / 64 entries at most) and hdr[0] = number of live 64-row tiles, for prcnn_rcnn_point_mlp.
+extern "C" int prcnn_pooled_tiles(int clouds, int rows_per_cloud, const int *cnt, int *tilemap, unsigned int *hdr, void *stream)
+{
+    PRCNN_REQUIRE(clouds >= 0 && rows_per_cloud > 0 && rows_per_cloud % PM_ROWS == 0, "pooled_tiles: bad sizes");
+    PRCNN_REQUIRE(hdr && (clouds == 0 || (cnt && tilemap)), "pooled_tiles: null pointer");
+    hipLaunchKernelGGL(pooled_tiles_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, clouds, rows_per_cloud, cnt, tilemap, hdr);
+    return check_launch("pooled_tiles");
 }

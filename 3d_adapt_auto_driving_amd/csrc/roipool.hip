@@ -104,7 +104,7 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_kernel(
 __global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(
     int pts_num, int boxes_num, int feat_len, int sampled, float extra, float extra2, const float *__restrict__ xyz,
     const float *__restrict__ rois, const float *__restrict__ feats, const float *__restrict__ seg_mask,
-    const float *__restrict__ depth, float4 *__restrict__ pooled, int *__restrict__ empty_flag)
+    const float *__restrict__ depth, float4 *__restrict__ pooled, int *__restrict__ empty_flag, int *__restrict__ pooled_cnt)
 {
     __shared__ int s_sel[RP_MAX_S];
     __shared__ int s_wcnt[RP_THREADS / 64];
@@ -121,13 +121,24 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(
     float4 *__restrict__ dst = pooled + ((long)b * boxes_num + box) * (long)sampled * q4;
     const long chunks = (long)sampled * q4;
     const float cosa = cosf(heading), sina = sinf(heading);             // torch.cos / torch.sin of the f32 heading
+    // pooled_cnt (optional): number of DISTINCT rows of this box = min(#points in the box, sampled), at least 1.  Rows s >= cnt
+    // are copies of row s % cnt (roipool3d_kernel.cu:152-159); with pooled_cnt given their 128 feature columns are written
+    // only up to the next multiple of 64 rows -- the consumers (rcnn_point_mlp over the live tiles, SA1 over the distinct
+    // rows) never read beyond -- while the coordinate / mask / depth chunks of ALL rows are written (FPS and the ball query
+    // of SA1 run over all `sampled` points, copies included, exactly as the reference does).
+    if (pooled_cnt && t == 0) pooled_cnt[(long)b * boxes_num + box] = max(cnt, 1);
+    const int feat_rows = pooled_cnt ? ((max(cnt, 1) + 63) & ~63) : sampled;
     if (cnt == 0) {
         // the reference leaves zero rows and then applies the canonical transform to ALL rows (rcnn_net.py:147-156):
         // an empty box holds the image of the origin, zero features
         if (t == 0) empty_flag[(long)b * boxes_num + box] = 1;
         const float x = 0.f - rx, y = 0.f - ry_bottom, z = 0.f - rz;
         const float4 origin = make_float4(fmaf(z, -sina, __fmul_rn(x, cosa)), y, fmaf(z, cosa, __fmul_rn(x, sina)), 0.f);
-        for (long e = t; e < chunks; e += RP_THREADS) dst[e] = (e % q4 == 0) ? origin : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (long e = t; e < chunks; e += RP_THREADS) {
+            const int q = (int)(e % q4);
+            if (q >= 2 && e / q4 >= feat_rows) continue;
+            dst[e] = (q == 0) ? origin : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         return;
     }
     if (t == 0) empty_flag[(long)b * boxes_num + box] = 0;
@@ -141,6 +152,7 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(
         const int k = s_sel[s < cnt ? s : s % cnt];
         float4 v;
         if (q >= 2) {
+            if (s >= feat_rows) continue;
             v = feat4[(long)k * f4 + (q - 2)];
         } else if (q == 0) {
             const float x = pts[3 * k] - rx, y = pts[3 * k + 1] - ry_bottom, z = pts[3 * k + 2] - rz;
@@ -186,7 +198,7 @@ extern "C" int prcnn_roipool3d(int batch_size, int pts_num, int boxes_num, int f
 extern "C" int prcnn_roipool3d_canonical(int batch_size, int pts_num, int boxes_num, int feature_len, int sampled_pts_num,
                                          float pool_extra_width, const float *xyz, const float *rois, const float *feats,
                                          const float *seg_mask, const float *depth, float *pooled, int *pooled_empty_flag,
-                                         void *stream)
+                                         int *pooled_cnt, void *stream)
 {
     PRCNN_REQUIRE(batch_size >= 0 && pts_num >= 0 && boxes_num >= 0 && feature_len >= 0 && sampled_pts_num >= 0,
                   "roipool3d_canonical: bad sizes");
@@ -200,6 +212,6 @@ extern "C" int prcnn_roipool3d_canonical(int batch_size, int pts_num, int boxes_
     dim3 grid(boxes_num, batch_size);
     hipLaunchKernelGGL(roipool3d_canonical_kernel, grid, dim3(RP_THREADS), 0, (hipStream_t)stream, pts_num, boxes_num,
                        feature_len, sampled_pts_num, pool_extra_width, (float)((double)pool_extra_width * 2.0), xyz, rois, feats,
-                       seg_mask, depth, reinterpret_cast<float4 *>(pooled), pooled_empty_flag);
+                       seg_mask, depth, reinterpret_cast<float4 *>(pooled), pooled_empty_flag, pooled_cnt);
     return check_launch("roipool3d_canonical");
 }

@@ -33,7 +33,11 @@ constexpr int PK_TILES_PER_WG = 8;
 
 // ------------------------------------------------------------------------------------------------ packing
 // one workgroup per cloud.  LDS: cnt / offset per centre (m ints) + per-thread partial sums.
-__global__ void ball_pack_kernel(int m, int ns, int tiles_cap_cloud, const int *__restrict__ idx,
+// `limit` (optional, per cloud): the points k >= limit[cloud] of the cloud are COPIES of point k % limit[cloud] (the
+// wrap-around fill of RoI pooling, roipool3d_kernel.cu:152-159).  A copy lies in a ball iff its original does, and the
+// original has the lower index, so in a ball query's answer (first nsample hits in index order) every copy is preceded by
+// its original: the rows of the slots with index >= limit are duplicates of rows already listed and are dropped too.
+__global__ void ball_pack_kernel(int m, int ns, int tiles_cap_cloud, const int *__restrict__ idx, const int *__restrict__ limit,
                                  unsigned int *__restrict__ rowinfo, int *__restrict__ tilecloud, unsigned int *__restrict__ hdr)
 {
     extern __shared__ int pk_lds[];
@@ -44,6 +48,7 @@ __global__ void ball_pack_kernel(int m, int ns, int tiles_cap_cloud, const int *
     const int chunk = (m + T - 1) / T;
     const int c0 = tid * chunk, c1 = min(m, c0 + chunk);
     const int *rows = idx + (long)b * m * ns;
+    const int lim = limit ? max(limit[b], 1) : 0x7fffffff;
     int sum = 0;
     for (int c = c0; c < c1; ++c) {
         const int *row = rows + (long)c * ns;
@@ -52,13 +57,13 @@ __global__ void ball_pack_kernel(int m, int ns, int tiles_cap_cloud, const int *
         if ((ns & 3) == 0) {
             for (int p = 0; p < ns; p += 4) {
                 const int4 v = *reinterpret_cast<const int4 *>(row + p);
-                if (v.x != first) last = p;
-                if (v.y != first) last = p + 1;
-                if (v.z != first) last = p + 2;
-                if (v.w != first) last = p + 3;
+                if (v.x != first && v.x < lim) last = p;
+                if (v.y != first && v.y < lim) last = p + 1;
+                if (v.z != first && v.z < lim) last = p + 2;
+                if (v.w != first && v.w < lim) last = p + 3;
             }
         } else {
-            for (int p = 1; p < ns; ++p) if (row[p] != first) last = p;
+            for (int p = 1; p < ns; ++p) if (row[p] != first && row[p] < lim) last = p;
         }
         cnts[c] = last + 1;
         sum += last + 1;
@@ -87,7 +92,9 @@ __global__ void ball_pack_kernel(int m, int ns, int tiles_cap_cloud, const int *
     for (int c = c0; c < c1; ++c) {
         const int *row = rows + (long)c * ns;
         const int n_c = cnts[c];
-        for (int p = 0; p < n_c; ++p) dst[run + p] = ((unsigned int)c << 16) | (unsigned int)row[p];
+        // slots beyond the limit inside the kept prefix (possible only for index rows that are not a ball query's
+        // answer) fall back to the row's first entry: still a copy of a listed row
+        for (int p = 0; p < n_c; ++p) dst[run + p] = ((unsigned int)c << 16) | (unsigned int)(row[p] < lim ? row[p] : row[0]);
         run += n_c;
     }
     // the last tile of the cloud is filled up with copies of the cloud's last row (copies do not change a max)
@@ -349,8 +356,9 @@ using namespace prcnn;
 //   tilecloud[b * tiles_cap] i32, cloud of tile t
 //   hdr      [4] u32: [0] = number of tiles, [1] = number of distinct rows (both written by this call)
 // with tiles_cap = ceil(m * nsample / 64) tiles per cloud at most.  Needs m, n <= 65536.
-extern "C" int prcnn_ball_pack(int b, int m, int nsample, const int *idx, unsigned int *rowinfo, int *tilecloud,
-                               unsigned int *hdr, void *stream)
+// limit (b) i32, optional: points k >= limit[cloud] are copies of point k % limit[cloud] (see ball_pack_kernel).
+extern "C" int prcnn_ball_pack(int b, int m, int nsample, const int *idx, const int *limit, unsigned int *rowinfo,
+                               int *tilecloud, unsigned int *hdr, void *stream)
 {
     PRCNN_REQUIRE(b >= 0 && m >= 0 && nsample >= 1, "ball_pack: bad sizes");
     PRCNN_REQUIRE(m <= 65536 && m <= 15360, "ball_pack: m=%d centres per cloud unsupported (<= 15360)", m);
@@ -368,7 +376,7 @@ extern "C" int prcnn_ball_pack(int b, int m, int nsample, const int *idx, unsign
         if (rc != PRCNN_OK) return rc;
     }
     const int cap = (int)(((long)m * nsample + PK_ROWS - 1) / PK_ROWS);
-    hipLaunchKernelGGL(ball_pack_kernel, dim3(b), dim3(threads), lds, st, m, nsample, cap, idx, rowinfo, tilecloud, hdr);
+    hipLaunchKernelGGL(ball_pack_kernel, dim3(b), dim3(threads), lds, st, m, nsample, cap, idx, limit, rowinfo, tilecloud, hdr);
     return check_launch("ball_pack");
 }
 

@@ -174,25 +174,28 @@ def sa_mlp_fused_wrapper(new_xyz, xyz, P, wxyz, idx, w2t, b2, w3t, b3, out, out_
 
 class BallPack:
     """Distinct grouped rows of an index tensor as 64-row tiles (prcnn_ball_pack); device-resident, no host sync."""
-    __slots__ = ("idx", "rowinfo", "tilecloud", "hdr", "max_tiles")
+    __slots__ = ("idx", "limit", "rowinfo", "tilecloud", "hdr", "max_tiles")
 
     def record_stream(self, stream):
         for t in (self.idx, self.rowinfo, self.tilecloud, self.hdr):
             t.record_stream(stream)
 
 
-def ball_pack_wrapper(idx):
-    """idx (b,m,nsample) i32 from a ball query -> BallPack for sa_packed_mlp_wrapper."""
+def ball_pack_wrapper(idx, limit=None):
+    """idx (b,m,nsample) i32 from a ball query -> BallPack for sa_packed_mlp_wrapper.  limit (b) i32, optional: the points
+    k >= limit[cloud] of a cloud are copies of point k % limit[cloud] (RoI pooling's wrap-around fill): dropped as well."""
     _chk(torch.int32, idx)
+    if limit is not None:
+        _chk(torch.int32, limit)
     b, m, ns = idx.shape
     cap = (m * ns + 63) // 64
     pk = BallPack()
-    pk.idx = idx
+    pk.idx, pk.limit = idx, limit
     pk.rowinfo = torch.empty((b * cap * 64,), dtype=torch.int32, device=idx.device)
     pk.tilecloud = torch.empty((b * cap,), dtype=torch.int32, device=idx.device)
     pk.hdr = torch.empty((4,), dtype=torch.int32, device=idx.device)
     pk.max_tiles = b * cap
-    _lib.call("prcnn_ball_pack", b, m, ns, idx.data_ptr(), pk.rowinfo.data_ptr(), pk.tilecloud.data_ptr(),
+    _lib.call("prcnn_ball_pack", b, m, ns, idx.data_ptr(), _lib.ptr(limit), pk.rowinfo.data_ptr(), pk.tilecloud.data_ptr(),
               pk.hdr.data_ptr(), _lib.current_stream(idx))
     return pk
 
@@ -264,14 +267,25 @@ def sa_xyz_mlp_wrapper(new_xyz, xyz, idx, w1, b1, w2, b2, w3, b3, out, out_col):
     return out
 
 
-def rcnn_point_mlp_wrapper(rows, fcol, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, merged, p):
+def pooled_tiles_wrapper(cnt, rows_per_cloud):
+    """cnt (clouds) i32 distinct rows per pooled cloud -> (tilemap i32, hdr i32[4]): the 64-row tiles that hold them."""
+    _chk(torch.int32, cnt)
+    clouds = cnt.numel()
+    tilemap = torch.empty((max(1, clouds * (rows_per_cloud // 64)),), dtype=torch.int32, device=cnt.device)
+    hdr = torch.empty((4,), dtype=torch.int32, device=cnt.device)
+    _lib.call("prcnn_pooled_tiles", clouds, rows_per_cloud, cnt.data_ptr(), tilemap.data_ptr(), hdr.data_ptr(), _lib.current_stream(cnt))
+    return tilemap, hdr
+
+
+def rcnn_point_mlp_wrapper(rows, fcol, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, merged, p, tiles=None):
     """RCNN entrance chain as tiled MFMA layer kernels (csrc/rcnn_point_mlp.hip): rows (R, ld) pooled rows
     [x',y',z',mask,depth,0,0,0 | 128 feats at column fcol] -> xfeat = xyz_up(in5), merged = relu([xfeat | feats] wm + bm),
-    p = merged wp + bp, each (R,128)."""
+    p = merged wp + bp, each (R,128).  tiles = (tilemap, hdr) from pooled_tiles_wrapper: only those 64-row tiles are computed."""
     _chk(torch.float32, rows, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, merged, p)
     _lib.call("prcnn_rcnn_point_mlp", rows.size(0), rows.size(1), int(fcol), rows.data_ptr(), wu1.data_ptr(), bu1.data_ptr(),
               wu2.data_ptr(), bu2.data_ptr(), wm.data_ptr(), bm.data_ptr(), wp.data_ptr(), bp.data_ptr(), xfeat.data_ptr(),
-              merged.data_ptr(), p.data_ptr(), _lib.current_stream(rows))
+              merged.data_ptr(), p.data_ptr(), None if tiles is None else tiles[0].data_ptr(),
+              None if tiles is None else tiles[1].data_ptr(), _lib.current_stream(rows))
     return p
 
 

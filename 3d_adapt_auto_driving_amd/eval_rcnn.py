@@ -136,7 +136,7 @@ class PipelinedRunner:
         self.model, self.cfg = model, cfg
         self.engine = FastPointRCNN(model, cfg)
         self.device = torch.device(device)
-        self.depth = int(os.environ.get("PRCNN_GEO_DEPTH", "2")) if depth is None else depth
+        self.depth = int(os.environ.get("PRCNN_GEO_DEPTH", "3")) if depth is None else depth
         # high priority: the geometry kernels are few, short-lived workgroups on a latency-bound chain;
         # when CU slots free up they should be placed before the feature pass's next workgroups
         # default priority: with the SA levels on the packed MFMA kernels the feature pass is short, and high-priority side
@@ -321,6 +321,9 @@ def _tensors(obj):
     elif isinstance(obj, (list, tuple)):
         for v in obj:
             yield from _tensors(v)
+    elif hasattr(obj, "rowinfo"):                 # BallPack (distinct-row list of an index tensor)
+        for v in (obj.idx, obj.rowinfo, obj.tilecloud, obj.hdr):
+            yield v
 
 
 def kitti_result_lines(calib, bbox3d, scores, img_shape, cls_name="Car"):
@@ -382,6 +385,48 @@ def evaluate_detections(table, counts, source, current_class=0, dataset="kitti",
     return kitti_eval.get_official_eval_result(gt_annos, dt_annos, current_class, dataset, device_id=device_id)
 
 
+class RecallStats:
+    """Recall of the RoIs and of the refined boxes against the ground truth (eval_rcnn.py:539-570, :669-679): per scene the
+    3-D IoU matrix boxes x gt through the extension's BEV overlap kernel (iou3d_utils.boxes_iou3d_gpu -> K10), a gt box
+    counts as recalled at threshold t when some box overlaps it with IoU > t.  Counters stay on the device until
+    ``result()``; ALL M decoded boxes of a scene enter (before score threshold and NMS), as in the reference."""
+    THRESH = (0.1, 0.3, 0.5, 0.7, 0.9)
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.rcnn = torch.zeros(len(self.THRESH), dtype=torch.int64, device=self.device)
+        self.roi = torch.zeros(len(self.THRESH), dtype=torch.int64, device=self.device)
+        self.total_gt = 0
+        self._th = torch.tensor(self.THRESH, dtype=torch.float32, device=self.device)
+
+    @torch.no_grad()
+    def update(self, pred_boxes3d, roi_boxes3d, gt_list):
+        """pred_boxes3d / roi_boxes3d (B,M,7) device; gt_list: B arrays (n_k,7) [x,y,z,h,w,l,ry] (all-zero rows = padding)"""
+        for k, gt in enumerate(gt_list):
+            gt = np.asarray(gt, dtype=np.float32).reshape(-1, 7)
+            n = gt.shape[0]
+            while n > 0 and gt[n - 1].sum() == 0:           # trailing zero padding of the collated batch (:549-552)
+                n -= 1
+            if n == 0:
+                continue
+            g = torch.from_numpy(gt[:n]).to(self.device, non_blocking=True)
+            for boxes, acc in ((pred_boxes3d[k], self.rcnn), (roi_boxes3d[k], self.roi)):
+                iou = iou3d_utils.boxes_iou3d_gpu(boxes.contiguous(), g)
+                best = iou.max(dim=0).values
+                acc += (best.unsqueeze(0) > self._th.unsqueeze(1)).sum(dim=1)
+            self.total_gt += n
+
+    def result(self):
+        rcnn, roi = self.rcnn.cpu().tolist(), self.roi.cpu().tolist()
+        out = {"total_gt_bbox": self.total_gt}
+        for i, t in enumerate(self.THRESH):
+            out["rpn_recall(thresh=%.2f)" % t] = roi[i] / max(self.total_gt, 1.0)
+            out["rcnn_recall(thresh=%.2f)" % t] = rcnn[i] / max(self.total_gt, 1.0)
+            out["rpn_recalled(thresh=%.2f)" % t] = roi[i]
+            out["rcnn_recalled(thresh=%.2f)" % t] = rcnn[i]
+        return out
+
+
 def shard_scene_ids(num_scenes, rank, world):
     """Rank r evaluates scenes r, r+world, ... (independent units)."""
     return list(range(rank, num_scenes, world))
@@ -428,7 +473,8 @@ def all_gather_detections(table, counts, device):
 
 
 @torch.no_grad()
-def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=None, workers=None, device_input=False):
+def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=None, workers=None, device_input=False,
+                recall=None):
     """Evaluate ``scene_ids`` of a scene source (kitti_io.KittiSource / SyntheticSource) on this rank:
     the counterpart of the batch loop of eval_one_epoch_joint (eval_rcnn.py:493-649) incl. the KITTI
     result files.  Returns (table, counts) as pack_detections.
@@ -437,7 +483,9 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
     DataLoader workers, eval_rcnn.py:868-871): a scene costs milliseconds of numpy on the host, the device
     needs ~1.3 ms per scene, so a single-threaded loader would be the bottleneck.  Batches arrive in order.
     ``device_input``: the loaders only READ the raw clouds (``source.load_raw``); rectification, validity filter
-    and the near/far sampler run on the device (kitti_io.DeviceInputStage, csrc/input_stage.hip)."""
+    and the near/far sampler run on the device (kitti_io.DeviceInputStage, csrc/input_stage.hip).
+    ``recall``: a RecallStats that receives every batch's RoIs / refined boxes and the source's ground-truth boxes
+    (the reference's recall statistics, skipped with --test)."""
     if output_dir:
         os.makedirs(output_dir, exist_ok=True)
     M = cfg.TEST.RPN_POST_NMS_TOP_N
@@ -496,6 +544,8 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
         # one D2H per batch, issued on the stream that produced the detections
         with torch.cuda.stream(det["stream"]) if "stream" in det else contextlib.nullcontext():
             boxes, scores, num = (det[k].to("cpu", non_blocking=True) for k in ("boxes", "scores", "num"))
+            if recall is not None:
+                recall.update(det["pred_boxes3d"], det["rois"], [source.gt_boxes3d(i) for i in ids])
         if "stream" in det:
             det["stream"].synchronize()
         batches.append((boxes, scores, num))
@@ -553,6 +603,7 @@ def main(argv=None):
     ap.add_argument("--split", type=str, default=None, help="ImageSets split (default cfg.TEST.SPLIT)")
     ap.add_argument("--output_dir", type=str, default=None)
     ap.add_argument("--eval_ap", action="store_true", help="rank 0: KITTI AP of the gathered detections vs the labels")
+    ap.add_argument("--recall", action="store_true", help="RoI / refined-box recall vs the ground truth (the reference's statistics without --test)")
     ap.add_argument("--set", dest="set_cfgs", default=None, nargs=argparse.REMAINDER)
     args = ap.parse_args(argv)
 
@@ -581,9 +632,13 @@ def main(argv=None):
         source = kitti_io.SyntheticSource(cfg, args.scenes, raw_points=args.raw_points)
     my_ids = [source.ids[i] for i in shard_scene_ids(len(source.ids), rank, world)]
     t0 = time.perf_counter()
+    recall = RecallStats(device) if args.recall else None
     table, counts = eval_scenes(model, cfg, device, source, my_ids, args.batch_size, out, workers=args.workers,
-                                device_input=args.device_input)
+                                device_input=args.device_input, recall=recall)
     elapsed = time.perf_counter() - t0
+    if recall is not None:
+        for k, v in recall.result().items():
+            print("rank %d  %s: %s" % (rank, k, v))
     table, counts = all_gather_detections(table, counts, device)
     if rank == 0:
         print("scenes=%d detections=%d  (%.1f scenes/s on this rank incl. the host input stage%s)" %

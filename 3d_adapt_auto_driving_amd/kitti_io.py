@@ -101,6 +101,23 @@ class KittiSource:
         with open(os.path.join(self.dir, "label_2", "%06d.txt" % idx)) as f:
             return [l for l in f.read().split("\n") if l.strip()]
 
+    def gt_boxes3d(self, idx):
+        """(n,7) f32 [x, y_bottom, z, h, w, l, ry] of the labelled objects of class cfg.CLASSES inside PC_AREA_SCOPE
+        (kitti_rcnn_dataset.py:176-199 filtrate_objects + :224-247 check_pc_range), for the recall statistics."""
+        classes = (self.cfg.CLASSES,)
+        out = []
+        for l in self.label_lines(idx):
+            f = l.split()
+            if f[0] not in classes:
+                continue
+            h, w, ln, x, y, z, ry = (float(v) for v in f[8:15])
+            if self.cfg.PC_REDUCE_BY_RANGE:
+                (x0, x1), _, (z0, z1) = self.cfg.PC_AREA_SCOPE
+                if not (x0 <= x <= x1 and z0 <= z <= z1):
+                    continue
+            out.append([x, y, z, h, w, ln, ry])
+        return np.asarray(out, dtype=np.float32).reshape(-1, 7)
+
     def load_raw(self, idx):
         """Raw velodyne points (n,4) as stored + calib + image shape, for DeviceInputStage (lidar_frame=True)."""
         calib, shape = self.calib_and_shape(idx)
@@ -207,6 +224,11 @@ class SyntheticSource:
             lines.append("Car 0.00 0 %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f" %
                          (alpha, x1, y1, x2, y2, b[3], b[4], b[5], b[0], b[1], b[2], b[6]))
         return lines
+
+    def gt_boxes3d(self, idx):
+        """(n,7) f32 [x, y_bottom, z, h, w, l, ry]: the generator's car boxes (for the recall statistics)."""
+        n = self.raw_points or self.cfg.RPN.NUM_POINTS
+        return synth.scene_with_labels(idx, n, 20 if self.raw_points else 10)[1].astype(np.float32)
 
     def load_raw(self, idx):
         """The generated cloud before sampling (rect frame), for DeviceInputStage (lidar_frame=False, no image filter)."""

@@ -35,6 +35,9 @@ USE_XYZ_MLP = True      # coordinates-only SA scales through csrc/sa_xyz_mlp.hip
 # SA levels over the DISTINCT grouped rows only (csrc/sa_packed.hip: the back-filled copies of a ball's first hit are
 # skipped, bit-identical results).  PRCNN_NO_PACK=1 is the A/B switch back to all nsample rows (csrc/sa_mlp_fused.hip).
 USE_PACKED = os.environ.get("PRCNN_NO_PACK") is None
+# RoI pooling fills a box holding fewer than 512 points by repeating them (roipool3d_kernel.cu:152-159): the per-point
+# RCNN entrance chain and SA1 run over the DISTINCT pooled points only (bit-identical results).  PRCNN_NO_POOL_DEDUP=1: A/B.
+USE_POOL_DEDUP = os.environ.get("PRCNN_NO_POOL_DEDUP") is None
 USE_POINT_LAYER = os.environ.get("PRCNN_LIB_GEMM") is None     # per-point layers (FP modules, heads) on the own MFMA layer kernel
 
 
@@ -398,14 +401,17 @@ class FastPointRCNN:
         nin = self.model.rcnn_net.rcnn_input_channel                           # xyz + mask + depth = 5
         rp = roipool3d_utils.roipool3d_cuda
         C = feats.shape[2]
+        pooled_cnt = None
         if (USE_ROIPOOL_CANONICAL and has_entry(rp, "forward_canonical") and R.USE_DEPTH and nin == 5 and C % 4 == 0):
             # enlarge + pool + canonical transform + aligned row layout [x',y',z',mask,depth,0,0,0 | feats] in ONE kernel
             B, M = rois.shape[0], rois.shape[1]
             P, W = R.NUM_POINTS, 8 + C
             pooled = torch.empty((B, M, P, W), dtype=torch.float32, device=xyz.device)
             empty = torch.empty((B, M), dtype=torch.int32, device=xyz.device)
+            if USE_POOL_DEDUP and USE_PACKED and USE_RCNN_POINT_MLP and P % 64 == 0 and self._point_mlp_ok():
+                pooled_cnt = torch.empty((B, M), dtype=torch.int32, device=xyz.device)
             rp.forward_canonical(xyz, rois.contiguous(), feats, seg_mask.contiguous(),
-                                 (pts_depth / 70.0 - 0.5).contiguous(), R.POOL_EXTRA_WIDTH, pooled, empty)
+                                 (pts_depth / 70.0 - 0.5).contiguous(), R.POOL_EXTRA_WIDTH, pooled, empty, pooled_cnt)
             flat = pooled.view(B * M, P, W)
             rows = flat.view(B * M * P, W)
             a = rows[:, 0:8]                                                   # strided view: columns 5..7 are zero
@@ -433,7 +439,8 @@ class FastPointRCNN:
             (wm, bm, _), = self.merge_down.layers
             wf, _, b1 = sa1[3].split
             xfeat, merged, P_pre = (torch.empty((rows.shape[0], 128), dtype=torch.float32, device=rows.device) for _ in range(3))
-            ext_mod.rcnn_point_mlp_wrapper(rows, 8, wu1, bu1, wu2, bu2, wm, bm, wf, b1, xfeat, merged, P_pre)
+            tiles = None if pooled_cnt is None else ext_mod.pooled_tiles_wrapper(pooled_cnt.view(-1), P)
+            ext_mod.rcnn_point_mlp_wrapper(rows, 8, wu1, bu1, wu2, bu2, wm, bm, wf, b1, xfeat, merged, P_pre, tiles)
             P_pre = P_pre.view(B * M, P, 128)
             l_feat = [None]
         else:
@@ -451,7 +458,11 @@ class FastPointRCNN:
                 new_xyz = torch.gather(cur_xyz, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
                 idx = pu.ball_query(radius, ns, cur_xyz, new_xyz)
                 out = torch.empty((Bc, npoint, cout), dtype=torch.float32, device=cur_xyz.device)
-                self._sa_scale(cur_xyz, new_xyz, cur_feat, idx, mlp, cin, out, 0, P_pre=P_pre if len(l_feat) == 1 else None)
+                first = len(l_feat) == 1
+                pack = None
+                if first and pooled_cnt is not None and P_pre is not None:
+                    pack = ext.ball_pack_wrapper(idx, pooled_cnt.view(-1))       # copies of pooled points are dropped too
+                self._sa_scale(cur_xyz, new_xyz, cur_feat, idx, mlp, cin, out, 0, P_pre=P_pre if first else None, pack=pack)
                 l_xyz.append(new_xyz)
             elif USE_PACKED and (mlp.packed is not None or mlp.wide is not None):
                 # GroupAll (pointnet2_utils.py:267-288): ONE group holding all n points, no centre subtraction == a ball

@@ -140,10 +140,12 @@ int prcnn_sa_mlp_fused(int b, int n, int m, int nsample, int c1, int c2, int c3,
  *   rowinfo  u32 [b * ceil(m*nsample/64) * 64]: (centre within cloud) << 16 | (point within cloud)
  *   tilecloud i32 [b * ceil(m*nsample/64)]:     cloud of each tile
  *   hdr      u32 [4]: [0] tiles, [1] distinct rows (device-resident; no host sync)
+ *   limit    i32 [b], optional: points k >= limit[cloud] of a cloud are copies of point k % limit[cloud] (the wrap-around
+ *            fill of RoI pooling, roipool3d_kernel.cu:152-159); their rows are duplicates as well and are dropped
  * prcnn_sa_packed_mlp: layers as prcnn_sa_mlp_fused (c1 = c2 = 128; narrower levels zero-padded by the caller), c3 in
  * {128, 256}; zeroes out[(b*m)][out_col..out_col+c3) and accumulates the per-centre maxima with atomicMax (values are
  * >= 0 after ReLU).  Bit-identical to prcnn_sa_mlp_fused on the same idx.  max_tiles = b * ceil(m*nsample/64). */
-int prcnn_ball_pack(int b, int m, int nsample, const int *idx, unsigned int *rowinfo, int *tilecloud,
+int prcnn_ball_pack(int b, int m, int nsample, const int *idx, const int *limit, unsigned int *rowinfo, int *tilecloud,
                     unsigned int *hdr, void *stream);
 int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, const float *new_xyz, const float *xyz,
                         const float *P, const float *wxyz, const unsigned int *rowinfo, const int *tilecloud,
@@ -173,10 +175,15 @@ int prcnn_packed_layer_segmax(int b, int m, long max_tiles, int K, int N, const 
  * [x',y',z',mask,depth,0,0,0 | 128 RPN features at column fcol] as prcnn_roipool3d_canonical writes them, r % 64 == 0;
  * wu1 (8,128), wu2 (128,128), wm (256,128), wp (128,128) k-major with BN folded;
  * xfeat (r,128) = xyz_up output, merged (r,128) = relu([xfeat | feats] wm + bm), p (r,128) = merged wp + bp:
- * three launches of one tiled MFMA layer kernel, all buffers caller-allocated. */
+ * three launches of one tiled MFMA layer kernel, all buffers caller-allocated.
+ * tilemap / ntiles (optional, both or neither): only the 64-row tiles listed in tilemap[0 .. *ntiles) are computed -- the
+ * tiles that hold DISTINCT pooled rows (prcnn_pooled_tiles from prcnn_roipool3d_canonical's pooled_cnt); the rows of the
+ * other tiles are wrap-around copies (roipool3d_kernel.cu:152-159) that no consumer reads, and are left unwritten. */
 int prcnn_rcnn_point_mlp(long r, int ld, int fcol, const float *rows, const float *wu1, const float *bu1,
                          const float *wu2, const float *bu2, const float *wm, const float *bm, const float *wp,
-                         const float *bp, float *xfeat, float *merged, float *p, void *stream);
+                         const float *bp, float *xfeat, float *merged, float *p, const int *tilemap,
+                         const unsigned int *ntiles, void *stream);
+int prcnn_pooled_tiles(int clouds, int rows_per_cloud, const int *cnt, int *tilemap, unsigned int *hdr, void *stream);
 
 /* One 128-wide shared-MLP / Conv1d layer (pytorch_utils.py:35-101 with BN folded) on the same tiled MFMA kernel:
  * out (r,128) = act(A0 w[0:128] [+ A1 w[128:256]] + bias), r % 64 == 0; A0 = src0 rows (128 floats at column col0, row
@@ -266,11 +273,14 @@ int prcnn_roipool3d(int batch_size, int pts_num, int boxes_num, int feature_in_l
  * enlarge the RoIs by pool_extra_width, pool the first `sampled` points per box (same selection as prcnn_roipool3d),
  * move the pooled coordinates into the RoI's canonical frame and write rows
  * [x', y', z', seg mask, depth, 0, 0, 0 | c features] (c % 4 == 0).  rois (b,m,7) are the UN-enlarged proposals;
- * feats (b,n,c) point-major; seg_mask, depth (b,n); pooled (b,m,sampled,8+c) need not be cleared; empty (b,m) i32. */
+ * feats (b,n,c) point-major; seg_mask, depth (b,n); pooled (b,m,sampled,8+c) need not be cleared; empty (b,m) i32.
+ * pooled_cnt (b,m) i32, optional (NULL = off): number of DISTINCT rows of each box (min(#points in box, sampled), >= 1;
+ * rows s >= cnt are the wrap-around copies of row s % cnt, roipool3d_kernel.cu:152-159).  When given, the feature
+ * columns are written only for rows < round_up(cnt, 64): the coordinate / mask / depth columns of all rows are. */
 int prcnn_roipool3d_canonical(int batch_size, int pts_num, int boxes_num, int feature_len, int sampled_pts_num,
                               float pool_extra_width, const float *xyz, const float *rois, const float *feats,
                               const float *seg_mask, const float *depth, float *pooled, int *pooled_empty_flag,
-                              void *stream);
+                              int *pooled_cnt, void *stream);
 
 /* The reference module's two HOST utilities (CPU tensors, unbatched; they serve its dataset / GT-database code):
  * pts_in_boxes3d_cpu  roipool3d.cpp:97-125 -> flags (boxes_num, pts_num) i64 in {0,1};

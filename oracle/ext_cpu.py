@@ -24,8 +24,16 @@ def _p(t, ty):
 
 
 class _CpuPack:
-    def __init__(self, idx):
+    """CPU stand-in of a BallPack: keeps the index tensor (the oracle evaluates ALL nsample rows).  With `limit`, points
+    k >= limit[cloud] are copies of k % limit[cloud]: the per-point tensors may hold only the originals, so the indices
+    are mapped onto them (same values, hence the same result as evaluating the copies)."""
+
+    def __init__(self, idx, limit=None):
+        if limit is not None:
+            lim = limit.view(-1, 1, 1).clamp(min=1).to(idx.dtype)
+            idx = torch.where(idx >= lim, idx % lim, idx).contiguous()
         self.idx = idx
+        self.limit = limit
         self.max_tiles = (idx.numel() + 63) // 64
 
     def record_stream(self, stream):
@@ -131,9 +139,9 @@ class pointnet2_cpu:
         return out
 
     @staticmethod
-    def ball_pack_wrapper(idx):
+    def ball_pack_wrapper(idx, limit=None):
         """The CPU stand-in keeps the index tensor: the oracle evaluates ALL nsample rows (the reference's semantics)."""
-        return _CpuPack(idx)
+        return _CpuPack(idx, limit)
 
     @staticmethod
     def sa_packed_mlp_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col):
@@ -177,7 +185,11 @@ class pointnet2_cpu:
         return out
 
     @staticmethod
-    def rcnn_point_mlp_wrapper(rows, fcol, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, merged, p):
+    def pooled_tiles_wrapper(cnt, rows_per_cloud):
+        return None                                  # the CPU stand-in evaluates every row
+
+    @staticmethod
+    def rcnn_point_mlp_wrapper(rows, fcol, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, merged, p, tiles=None):
         O.lib().orc_rcnn_point_mlp(C.c_long(rows.size(0)), rows.size(1), int(fcol), _p(rows, _f), _p(wu1, _f), _p(bu1, _f),
                                    _p(wu2, _f), _p(bu2, _f), _p(wm, _f), _p(bm, _f), _p(wp, _f), _p(bp, _f),
                                    _p(xfeat, _f), _p(merged, _f), _p(p, _f))

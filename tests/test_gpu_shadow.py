@@ -29,7 +29,9 @@ def to_cpu(a):
     if torch.is_tensor(a):
         return a.detach().cpu().clone()
     if hasattr(a, "rowinfo"):                      # BallPack -> the oracle's stand-in keeps the index tensor
-        return ext_cpu._CpuPack(a.idx.detach().cpu().clone())
+        return ext_cpu._CpuPack(a.idx.detach().cpu().clone(), None if a.limit is None else a.limit.detach().cpu().clone())
+    if isinstance(a, tuple):
+        return tuple(to_cpu(x) for x in a)
     return a
 
 
@@ -73,7 +75,16 @@ class Shadow:
 def check_ball_pack(self, name, args, host, pack):
     """ball_pack returns the distinct-row list: compare its header with the definition (1 + last slot != slot 0)"""
     idx = host[0].numpy()
-    last = np.where(idx != idx[..., :1], np.arange(idx.shape[-1]), 0).max(-1)
+    keep = idx != idx[..., :1]
+    if len(host) > 1 and host[1] is not None:      # copies of pooled points (index >= the cloud's distinct count) are dropped too
+        lim = np.maximum(host[1].numpy().reshape(-1, 1, 1), 1)
+        keep &= idx < lim
+        # the contract that makes this exact: every dropped copy's original is listed in the same row
+        canon = np.where(idx >= lim, idx % lim, idx)
+        for b_, c_ in zip(*np.nonzero((idx >= lim).any(-1))):
+            row = idx[b_, c_]
+            assert set(canon[b_, c_][row >= lim[b_, 0, 0]]) <= set(row[row < lim[b_, 0, 0]])
+    last = np.where(keep, np.arange(idx.shape[-1]), 0).max(-1)
     cnt = last + 1
     hdr = pack.hdr.cpu().numpy()
     assert hdr[1] == cnt.sum(), (name, int(hdr[1]), int(cnt.sum()))
@@ -87,6 +98,7 @@ def check_forward_canonical(self, name, args, host, ret):
     from oracle import oracle as O
     xyz, rois, feats, mask, depth, extra = (h if not torch.is_tensor(h) else h.numpy() for h in host[:6])
     pooled, empty = args[6].detach().cpu().numpy(), args[7].detach().cpu().numpy()
+    pcnt = args[8].detach().cpu().numpy() if len(args) > 8 and args[8] is not None else None
     big = rois.copy()
     big[:, :, 3:6] += np.float32(extra * 2)       # kitti_utils.enlarge_box3d
     big[:, :, 1] += np.float32(extra)
@@ -94,7 +106,18 @@ def check_forward_canonical(self, name, args, host, ret):
     ref_in = np.concatenate([mask[..., None], depth[..., None], feats], axis=2)
     want, wempty = O.roipool3d(xyz, big, ref_in, S)
     assert np.array_equal(empty, wempty)
-    assert np.array_equal(pooled[..., 3:5], want[..., 3:5]) and np.array_equal(pooled[..., 8:], want[..., 5:])
+    assert np.array_equal(pooled[..., 3:5], want[..., 3:5])
+    if pcnt is None:
+        assert np.array_equal(pooled[..., 8:], want[..., 5:])
+    else:
+        # distinct rows per box = min(#points inside, S), at least 1; feature columns are written up to the next multiple of 64
+        inside = np.stack([O.pts_in_boxes3d(xyz[b_], big[b_]).sum(1) for b_ in range(xyz.shape[0])])
+        assert np.array_equal(pcnt, np.maximum(np.minimum(inside, S), 1))
+        live = np.arange(S)[None, None, :] < ((pcnt + 63) // 64 * 64)[..., None]
+        assert np.array_equal(pooled[..., 8:][live], want[..., 5:][live])
+        # rows beyond the distinct count ARE copies of row s % cnt (what the consumers rely on)
+        s_idx = np.arange(S)[None, None, :] % pcnt[..., None]
+        assert np.array_equal(want[..., 0:5], np.take_along_axis(want[..., 0:5], s_idx[..., None].repeat(5, -1), 2))
     assert (pooled[..., 5:8] == 0).all()
     rel = want[..., 0:3].astype(np.float64) - rois[:, :, None, 0:3]
     ca, sa = np.cos(rois[:, :, None, 6].astype(np.float64)), np.sin(rois[:, :, None, 6].astype(np.float64))
@@ -118,7 +141,7 @@ POINTNET2 = {
     "packed_gather_affine_wrapper": None,          # filled below: compared through the layers that consume it
     "packed_layer_wrapper": None,
     "packed_layer_segmax_wrapper": {6: "exact"},
-    "rcnn_point_mlp_wrapper": {10: "exact", 11: "exact", 12: "exact"},
+    "rcnn_point_mlp_wrapper": None,                # filled below
 }
 
 
@@ -159,6 +182,27 @@ def check_packed_layer(self, name, args, host, ret):
 
 
 POINTNET2["packed_layer_wrapper"] = check_packed_layer
+
+
+def check_rcnn_point_mlp(self, name, args, host, ret):
+    """entrance chain: with a tile list only the tiles holding distinct pooled rows are computed -- compare those"""
+    self._cpu.rcnn_point_mlp_wrapper(*host[:13])
+    rows = host[0].shape[0]
+    live = torch.ones(rows, dtype=torch.bool)
+    if len(args) > 13 and args[13] is not None:
+        tilemap, hdr = args[13]
+        n = int(hdr[0])
+        live[:] = False
+        tiles = tilemap[:n].cpu().long()
+        assert len(torch.unique(tiles)) == n
+        live.view(-1, 64)[tiles] = True
+        self._log["live_rows_fraction_x1000"] = int(1000 * n * 64 / rows)
+    for pos in (10, 11, 12):
+        got, want = args[pos].detach().cpu(), host[pos]
+        assert torch.equal(got[live], want[live]), (name, pos)
+
+
+POINTNET2["rcnn_point_mlp_wrapper"] = check_rcnn_point_mlp
 
 
 def check_packed_segmax(self, name, args, host, ret):
