@@ -474,7 +474,7 @@ def all_gather_detections(table, counts, device):
 
 @torch.no_grad()
 def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=None, workers=None, device_input=False,
-                recall=None):
+                recall=None, stats=None):
     """Evaluate ``scene_ids`` of a scene source (kitti_io.KittiSource / SyntheticSource) on this rank:
     the counterpart of the batch loop of eval_one_epoch_joint (eval_rcnn.py:493-649) incl. the KITTI
     result files.  Returns (table, counts) as pack_detections.
@@ -485,15 +485,15 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
     ``device_input``: the loaders only READ the raw clouds (``source.load_raw``); rectification, validity filter
     and the near/far sampler run on the device (kitti_io.DeviceInputStage, csrc/input_stage.hip).
     ``recall``: a RecallStats that receives every batch's RoIs / refined boxes and the source's ground-truth boxes
-    (the reference's recall statistics, skipped with --test)."""
+    (the reference's recall statistics, skipped with --test).  ``stats``: a dict that receives the completion time of
+    every batch (``batch_done``), for steady-state throughput measurements."""
     if output_dir:
         os.makedirs(output_dir, exist_ok=True)
     M = cfg.TEST.RPN_POST_NMS_TOP_N
-    batches = []
     on_gpu = torch.device(device).type == "cuda"
     runner = PipelinedRunner(model, cfg, device) if on_gpu else None
     if workers is None:
-        workers = int(os.environ.get("PRCNN_LOADER_WORKERS", "8"))
+        workers = int(os.environ.get("PRCNN_LOADER_WORKERS", "16"))
     starts = list(range(0, len(scene_ids), batch_size))
     stage = None
     if device_input:
@@ -506,19 +506,14 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
     if workers > 0 and len(starts) > 2:
         # loader PROCESSES (the scene generator / KITTI reader is Python + numpy: threads would serialise on the GIL);
         # they only produce host arrays, the parent uploads.  prefetch_factor batches per worker stay in flight.
-        class _Scenes(torch.utils.data.Dataset):
-            def __len__(self):
-                return len(scene_ids)
-
-            def __getitem__(self, k):
-                if stage is not None:
-                    return torch.from_numpy(np.ascontiguousarray(source.load_raw(scene_ids[k])[0], dtype=np.float32))
-                return torch.from_numpy(source.load(scene_ids[k])[0])
-
-        feed = iter(torch.utils.data.DataLoader(_Scenes(), batch_size=batch_size, shuffle=False, num_workers=workers,
-                                                pin_memory=on_gpu and stage is None, prefetch_factor=2,
-                                                multiprocessing_context="fork",
-                                                collate_fn=(lambda items: items) if stage is not None else None))
+        # Forking a process whose HIP runtime is already initialised is unsupported (sporadic hangs at worker start or
+        # exit): once the GPU has been touched the workers come from a fork SERVER (clean interpreters, picklable dataset).
+        ctx = "forkserver" if (on_gpu and torch.cuda.is_initialized()) else "fork"
+        ctx = os.environ.get("PRCNN_LOADER_CONTEXT", ctx)
+        feed = iter(torch.utils.data.DataLoader(_SceneDataset(source, scene_ids, stage is not None), batch_size=batch_size,
+                                                shuffle=False, num_workers=workers, pin_memory=on_gpu and stage is None,
+                                                prefetch_factor=2, multiprocessing_context=ctx,
+                                                collate_fn=_identity if stage is not None else None))
 
     def load(s):
         ids = scene_ids[s:s + batch_size]
@@ -540,41 +535,115 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
             meta = [(l[1], l[2]) for l in loaded]
         return host.to(device, non_blocking=True), ids, meta
 
-    def finish(det, ids, meta):
-        # one D2H per batch, issued on the stream that produced the detections
+    # Results are consumed LATE: the D2H copy of a batch is queued (on the stream that produced it) the moment the batch
+    # is submitted, but the host only waits for it `lag` batches later, when it has long completed -- the host thread
+    # never stalls on the GPU inside the loop and keeps enqueueing ahead of it.  The KITTI text files are written by a
+    # small thread pool (numpy projection + formatting + file I/O per scene; the reference does this inline, :635).
+    import collections
+    from concurrent.futures import ProcessPoolExecutor
+    import multiprocessing
+    lag = int(os.environ.get("PRCNN_RESULT_LAG", "3")) if runner is not None else 0
+    inflight = collections.deque()
+    # writer PROCESSES: the formatting of ~40 text lines per scene is pure Python and would hold the GIL of the thread
+    # that feeds the GPU; one job per batch
+    writers = None
+    if output_dir:
+        wctx = "forkserver" if (on_gpu and torch.cuda.is_initialized()) else "fork"
+        writers = ProcessPoolExecutor(max_workers=int(os.environ.get("PRCNN_WRITER_PROCS", "6")),
+                                      mp_context=multiprocessing.get_context(os.environ.get("PRCNN_LOADER_CONTEXT", wctx)))
+    jobs = []
+    results = {}
+
+    def start_copy(det, ids, meta, order):
         with torch.cuda.stream(det["stream"]) if "stream" in det else contextlib.nullcontext():
-            boxes, scores, num = (det[k].to("cpu", non_blocking=True) for k in ("boxes", "scores", "num"))
+            if on_gpu:
+                host = [torch.empty(det[k].shape, dtype=det[k].dtype, pin_memory=True) for k in ("boxes", "scores", "num")]
+                for h, k in zip(host, ("boxes", "scores", "num")):
+                    h.copy_(det[k], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
+            else:
+                host, done = [det[k] for k in ("boxes", "scores", "num")], None
             if recall is not None:
                 recall.update(det["pred_boxes3d"], det["rois"], [source.gt_boxes3d(i) for i in ids])
-        if "stream" in det:
-            det["stream"].synchronize()
-        batches.append((boxes, scores, num))
+        inflight.append((host, done, ids, meta, order))
+
+    def consume():
+        (boxes, scores, num), done, ids, meta, order = inflight.popleft()
+        if done is not None:
+            done.synchronize()
+        results[order] = (boxes, scores, num)
+        if stats is not None:
+            stats.setdefault("batch_done", []).append(time.perf_counter())
         if output_dir:
-            for k, sid in enumerate(ids):
-                n = int(num[k])
-                calib, shape = meta[k]
-                save_kitti_format(sid, calib, boxes[k, :n].numpy(), output_dir, scores[k, :n].numpy(), shape, cfg.CLASSES)
+            nn = num.tolist()
+            jobs.append(writers.submit(_write_batch, ids, [m[0] for m in meta], [m[1] for m in meta],
+                                       [boxes[k, :nn[k]].numpy() for k in range(len(ids))],
+                                       [scores[k, :nn[k]].numpy() for k in range(len(ids))], output_dir, cfg.CLASSES))
 
     # software pipeline: while batch i is on the device, batch i+1 is loaded and (three-stream runner) the RCNN +
-    # final stage of batch i-1 complete; results are consumed one batch late
+    # final stage of batch i-1 complete; results are consumed `lag` batches late
     prev = None
-    ahead = [load(0), load(batch_size)]              # two batches ahead: the runner starts their geometry chains early
+    order = 0
+    depth = runner.depth if runner is not None else 1
+    ahead = [load(k * batch_size) for k in range(depth)]   # `depth` batches ahead: the runner starts their geometry chains early
     for s in range(0, len(scene_ids), batch_size):
         pts, ids, meta = ahead.pop(0)
-        ahead.append(load(s + 2 * batch_size))
+        ahead.append(load(s + depth * batch_size))
         if runner is not None:
             det = runner.submit(pts, [a[0] for a in ahead])
             if det is not None:
-                finish(det, *prev)
-            prev = (ids, meta)
+                start_copy(det, *prev)
+            prev = (ids, meta, order)
         else:
-            finish(infer_batch(model, cfg, pts), ids, meta)
+            start_copy(infer_batch(model, cfg, pts), ids, meta, order)
+        order += 1
+        while len(inflight) > lag:
+            consume()
     if runner is not None:
         det = runner.flush()
         if det is not None:
-            finish(det, *prev)
+            start_copy(det, *prev)
+    while inflight:
+        consume()
+    for j in jobs:
+        j.result()
+    if writers is not None:
+        writers.shutdown()
     del feed
-    return pack_detections(scene_ids, batches, M)
+    return pack_detections(scene_ids, [results[k] for k in sorted(results)], M)
+
+
+def steady_state_rate(stats, batch_size):
+    """scenes/s between the completion of the first and of the last batch (loader / writer process start-up excluded)"""
+    t = stats.get("batch_done", [])
+    if len(t) < 3:
+        return float("nan")
+    return (len(t) - 1) * batch_size / max(t[-1] - t[0], 1e-9)
+
+
+def _write_batch(ids, calibs, shapes, boxes, scores, output_dir, cls_name):
+    """one writer job: the KITTI result files of one batch (runs in a writer process)"""
+    return sum(save_kitti_format(sid, c, b, output_dir, s, sh, cls_name) for sid, c, sh, b, s in zip(ids, calibs, shapes, boxes, scores))
+
+
+class _SceneDataset(torch.utils.data.Dataset):
+    """What a loader process produces for scene k: the sampled cloud (host input stage) or the raw cloud (device stage)."""
+
+    def __init__(self, source, scene_ids, raw):
+        self.source, self.scene_ids, self.raw = source, list(scene_ids), raw
+
+    def __len__(self):
+        return len(self.scene_ids)
+
+    def __getitem__(self, k):
+        if self.raw:
+            return torch.from_numpy(np.ascontiguousarray(self.source.load_raw(self.scene_ids[k])[0], dtype=np.float32))
+        return torch.from_numpy(self.source.load(self.scene_ids[k])[0])
+
+
+def _identity(items):
+    return items
 
 
 def eval_synthetic(model, cfg, device, scene_ids, batch_size=8, npoints=16384, output_dir=None, raw_points=None):
@@ -633,17 +702,19 @@ def main(argv=None):
     my_ids = [source.ids[i] for i in shard_scene_ids(len(source.ids), rank, world)]
     t0 = time.perf_counter()
     recall = RecallStats(device) if args.recall else None
+    stats = {}
     table, counts = eval_scenes(model, cfg, device, source, my_ids, args.batch_size, out, workers=args.workers,
-                                device_input=args.device_input, recall=recall)
+                                device_input=args.device_input, recall=recall, stats=stats)
     elapsed = time.perf_counter() - t0
     if recall is not None:
         for k, v in recall.result().items():
             print("rank %d  %s: %s" % (rank, k, v))
     table, counts = all_gather_detections(table, counts, device)
     if rank == 0:
-        print("scenes=%d detections=%d  (%.1f scenes/s on this rank incl. the host input stage%s)" %
+        print("scenes=%d detections=%d  (%.1f scenes/s on this rank incl. the host input stage%s; steady state %.1f scenes/s, "
+              "loader start-up excluded)" %
               (table.shape[0], int(counts.sum()), len(my_ids) / max(elapsed, 1e-9),
-               " and the result writer" if out else ""))
+               " and the result writer" if out else "", steady_state_rate(stats, args.batch_size)))
         if args.eval_ap:
             text, _ = evaluate_detections(table, counts, source, device_id=device.index or 0)
             print(text)

@@ -12,12 +12,23 @@ default.yaml shapes) per GPU -- BASELINE.json configs[2]; inputs are resident in
 timed region.  Scenes shard one batch per rank (weak scaling); the only collective is the final
 all_gather of the padded detection tables, inside the timed region.
 
+The SA levels run over the DISTINCT grouped rows only (csrc/sa_packed.hip: the reference's ball query back-fills a ball
+with copies of its first hit and RoI pooling fills a box with copies of its points; copies do not change a max-pool, the
+results are bit-identical -- tests/test_gpu_shadow.py).  How much that saves depends on the data: `config.distinct_rows`
+states the measured fraction per level, `config.scenes_per_s_all_rows` is the same step with every nsample row evaluated
+the way the reference does (PRCNN_NO_PACK / PRCNN_NO_POOL_DEDUP), measured in this run.
+
 The JSON line also carries
   roofline      fused ball_query+group (BASELINE.json configs[1]: B=8, N=16384, M=4096, C=128,
                 ns=32, r=0.2) timed with HIP events on the launch stream; achieved = algorithmic
                 bytes (SURVEY.md section 8d formula) / average duration of the launch pair
-  roofline_mfma the dominant kernel of the step, the hand-written f32 MFMA kernel of the RCNN SA MLP
-                (prcnn_sa_mlp_fused), against the dense f32 MFMA peak
+  roofline_mfma the dominant kernel of the step, the hand-written f32 MFMA kernel of the RCNN SA MLP over packed rows
+                (prcnn_sa_packed_mlp) on FULL balls (64 distinct rows per centre: every tile does all its flops),
+                against the dense f32 MFMA peak
+  roofline_product  the largest HBM-streaming kernel of the product step (prcnn_roipool3d_canonical) the same way
+  config.driver_scenes_per_s  the whole driver: loader processes (scene source + 16384-point sampler on the host, as the
+                reference's DataLoader workers), pinned upload, the pipelined engine, one D2H per batch, KITTI result
+                files written by writer processes -- steady-state rate of eval_rcnn.eval_scenes (rank 0, N = 1 only)
   cpu_baseline  the same model code on the host cores with the C oracle as operator backend
                 (kind "port": the reference has no CPU path for this pipeline), rank 0, N=1 only.
 """
@@ -115,7 +126,11 @@ def roofline_sa_mlp_fused(dev, reps=10):
     b2 = torch.randn(128, device=dev, generator=g)
     b3 = torch.randn(c3, device=dev, generator=g)
     out = torch.empty((b, m, c3), device=dev)
-    run = lambda: pointnet2_cuda.sa_mlp_fused_wrapper(new_xyz, xyz, P, wx, idx, w2, b2, w3, b3, out, 0)
+    # full balls: 64 DISTINCT point indices per centre (a random permutation prefix), so the packed list holds every row
+    idx = torch.argsort(torch.rand((b, m, n), device=dev, generator=g), dim=2)[:, :, :ns].to(torch.int32).contiguous()
+    pack = pointnet2_cuda.ball_pack_wrapper(idx)
+    assert int(pack.hdr[1]) == b * m * ns
+    run = lambda: pointnet2_cuda.sa_packed_mlp_wrapper(new_xyz, xyz, P, wx, pack, w2, b2, w3, b3, out, 0)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -127,9 +142,69 @@ def roofline_sa_mlp_fused(dev, reps=10):
     flops = 2.0 * b * m * ns * (128 * 128 + 128 * c3)
     achieved = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": 157.3, "unit": "TFLOP/s",
-            "frac": round(achieved / 157.3, 4), "traffic": None, "kernel": "sa_mlp_fused_kernel<128> (prcnn_sa_mlp_fused)",
+            "frac": round(achieved / 157.3, 4), "traffic": None,
+            "kernel": "sa_packed_mlp128_kernel (prcnn_sa_packed_mlp) on full balls: 64 distinct rows per centre",
             "launch_ms": round(ms, 4), "algorithmic_flops_per_launch": flops,
             "shape": {"clouds": b, "points": n, "centres": m, "nsample": ns, "mlp": [128, 128, c3]}}
+
+
+def roofline_roipool(dev, cfg, model, reps=20):
+    """The largest HBM-streaming kernel of the product step: RoI pooling + canonical transform + RCNN row layout
+    (prcnn_roipool3d_canonical) on one batch of 8 scenes x 100 RoIs x 512 points x (8 + 128) floats.
+    Algorithmic bytes (roipool row, with this kernel's row layout): read xyz, features, mask,
+    depth once and the RoIs; write EVERY pooled row in full (the all-rows form: pooled_cnt = NULL)."""
+    pkg = importlib.import_module(PKG)
+    if pkg.DROPIN_DIR not in sys.path:
+        sys.path.insert(0, pkg.DROPIN_DIR)
+    import roipool3d_cuda
+    F = importlib.import_module(PKG + ".net.fast_infer")
+    synth = importlib.import_module(PKG + ".synth")
+    eng = F.FastPointRCNN(model, cfg)
+    pts = torch.from_numpy(synth.scenes(BATCH, NPOINTS, seed0=2000)).to(dev)
+    st = eng.rpn_stage(pts)
+    rois, _ = eng.propose(st)
+    feats, mask = st["rpn_features"], st["seg_result"].contiguous()
+    depth = (st["pts_depth"] / 70.0 - 0.5).contiguous()
+    B, M, S, C = BATCH, rois.shape[1], cfg.RCNN.NUM_POINTS, feats.shape[2]
+    pooled = torch.empty((B, M, S, 8 + C), device=dev)
+    empty = torch.empty((B, M), dtype=torch.int32, device=dev)
+    run = lambda: roipool3d_cuda.forward_canonical(pts, rois.contiguous(), feats, mask, depth, cfg.RCNN.POOL_EXTRA_WIDTH, pooled, empty)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, e in evs:
+        a.record(); run(); e.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(e) for a, e in evs]))
+    nbytes = B * (NPOINTS * (12 + 4 * C + 8) + M * 28 + M * S * (8 + C) * 4 + M * 4)
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": 429.18e6, "traffic_source": "profiles/r02_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, all-rows form)",
+            "kernel": "roipool3d_canonical_kernel (prcnn_roipool3d_canonical)", "launch_ms": round(ms, 4),
+            "algorithmic_bytes_per_launch": nbytes, "shape": {"B": B, "N": NPOINTS, "rois": M, "sampled": S, "row_floats": 8 + C}}
+
+
+def driver_leg(cfg, model, dev, scenes=1536):
+    """eval_rcnn.eval_scenes over synthetic scenes with everything the reference's loop has around the model
+    (eval_rcnn.py:493-649): loader processes produce the 16384-point clouds, pinned H2D, pipelined engine, one D2H per
+    batch, KITTI result files.  Steady-state rate (loader / writer process start-up excluded)."""
+    import shutil
+    import tempfile
+    E = importlib.import_module(PKG + ".eval_rcnn")
+    K = importlib.import_module(PKG + ".kitti_io")
+    src = K.SyntheticSource(cfg, scenes)
+    out = tempfile.mkdtemp(prefix="prcnn_bench_")
+    stats = {}
+    try:
+        table, counts = E.eval_scenes(model, cfg, dev, src, src.ids, BATCH, out, stats=stats)
+        files = len(os.listdir(out))
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    return {"value": round(E.steady_state_rate(stats, BATCH), 1), "unit": "scenes/s", "scenes": scenes, "result_files": files,
+            "detections": int(counts.sum()), "loader_processes": int(os.environ.get("PRCNN_LOADER_WORKERS", "16")),
+            "what": "eval_scenes: synthetic scene source + host 16384-point stage in loader processes, pinned upload, engine, "
+                    "D2H, KITTI text files by writer processes; steady state between the first and the last batch"}
 
 
 def cpu_baseline(cfg, budget_s=30.0):
@@ -164,6 +239,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-driver", action="store_true", help="skip the whole-driver leg (loader processes + writer)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -206,62 +282,66 @@ def main():
     M = cfg.TEST.RPN_POST_NMS_TOP_N
 
     # distinct synthetic scenes per rank and per step slot, resident in HBM before timing
-    n_slots = 4
+    n_slots = 6                    # > geometry depth: a batch tensor is never its own look-ahead
     batches = [torch.from_numpy(synth.scenes(BATCH, NPOINTS, seed0=(rank * n_slots + s) * BATCH)).to(dev)
                for s in range(n_slots)]
-    total = args.warmup + args.steps
-    host_boxes = torch.empty((total, BATCH, M, 7), pin_memory=True)
-    host_scores = torch.empty((total, BATCH, M), pin_memory=True)
-    host_num = torch.empty((total, BATCH), dtype=torch.int32, pin_memory=True)
-
-    runner = E.PipelinedRunner(model, cfg, dev)     # point-major engine + geometry on a side stream
-
+    F = importlib.import_module(PKG + ".net.fast_infer")
     lagged = os.environ.get("PRCNN_TAIL_OVERLAP", "1") != "0"
 
-    def copy_out(det, i):
-        # async D2H of batch i's detections into its pinned slot, on the stream that produced them
-        with torch.cuda.stream(det["stream"]) if "stream" in det else contextlib.nullcontext():
-            host_boxes[i].copy_(det["boxes"], non_blocking=True)
-            host_scores[i].copy_(det["scores"], non_blocking=True)
-            host_num[i].copy_(det["num"], non_blocking=True)
+    def timed_run(steps, warmup):
+        """W untimed + K timed steps of the pipelined runner; returns the elapsed time of the K steps and their detections"""
+        runner = E.PipelinedRunner(model, cfg, dev)     # point-major engine + geometry chains on side streams
+        total = warmup + steps
+        host_boxes = torch.empty((total, BATCH, M, 7), pin_memory=True)
+        host_scores = torch.empty((total, BATCH, M), pin_memory=True)
+        host_num = torch.empty((total, BATCH), dtype=torch.int32, pin_memory=True)
 
-    def step(i):
-        # every timed step does one geometry pass (batch i+1, side stream), one RPN pass (batch i) and one
-        # RCNN + final pass; in the three-stream form the latter belongs to batch i-1 (software pipeline,
-        # eval_rcnn.PipelinedRunner.submit) and the per-scene tails run beside the GEMM stream
-        nxt = [batches[(i + d) % n_slots] for d in range(1, runner.depth + 1)]
-        if lagged:
-            det = runner.submit(batches[i % n_slots], nxt)
+        def copy_out(det, i):
+            # async D2H of batch i's detections into its pinned slot, on the stream that produced them
+            with torch.cuda.stream(det["stream"]) if "stream" in det else contextlib.nullcontext():
+                host_boxes[i].copy_(det["boxes"], non_blocking=True)
+                host_scores[i].copy_(det["scores"], non_blocking=True)
+                host_num[i].copy_(det["num"], non_blocking=True)
+
+        def step(i):
+            # every timed step does one geometry pass (batch i+depth, side stream), one RPN pass (batch i) and one
+            # RCNN + final pass; in the three-stream form the latter belongs to batch i-1 (software pipeline,
+            # eval_rcnn.PipelinedRunner.submit) and the per-scene tails run beside the feature stream
+            nxt = [batches[(i + d) % n_slots] for d in range(1, runner.depth + 1)]
+            if lagged:
+                det = runner.submit(batches[i % n_slots], nxt)
+                if det is not None:
+                    copy_out(det, i - 1)
+            else:
+                copy_out(runner.step(batches[i % n_slots], nxt), i)
+
+        def drain(last):
+            det = runner.flush() if lagged else None
             if det is not None:
-                copy_out(det, i - 1)
-        else:
-            copy_out(runner.step(batches[i % n_slots], nxt), i)
+                copy_out(det, last)
 
-    def drain(last):
-        det = runner.flush() if lagged else None
-        if det is not None:
-            copy_out(det, last)
+        for i in range(warmup):
+            step(i)
+        drain(warmup - 1)                      # the pipeline is empty when timing starts ...
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(warmup, total):
+            step(i)
+        drain(total - 1)                       # ... and drained inside the timed region: exactly K full batches
+        torch.cuda.synchronize()
+        return t0, [(host_boxes[i], host_scores[i], host_num[i]) for i in range(warmup, total)]
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
 
-    for i in range(args.warmup):
-        step(i)
-    drain(args.warmup - 1)                 # the pipeline is empty when timing starts ...
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, total):
-        step(i)
-    drain(total - 1)                       # ... and drained inside the timed region: exactly K full batches
-    torch.cuda.synchronize()
+    t0, dets = timed_run(args.steps, args.warmup)
     # the one exchange of the job: padded detection tables of this rank's scenes
     ids = list(range(rank * args.steps * BATCH, (rank + 1) * args.steps * BATCH))
-    table, counts = E.pack_detections(ids, [(host_boxes[i], host_scores[i], host_num[i])
-                                            for i in range(args.warmup, total)], M)
+    table, counts = E.pack_detections(ids, dets, M)
     table, counts = E.all_gather_detections(table, counts, comm_dev)
     barrier()
     torch.cuda.synchronize()
@@ -271,6 +351,33 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- context for the headline (rank 0, untimed): how many grouped rows are distinct on this data, and the same step
+    # with every nsample row evaluated (the reference's way)
+    distinct, all_rows = None, None
+    if rank == 0 and not args.no_roofline:
+        pu = importlib.import_module(PKG + ".pointnet2.pointnet2_utils")
+        real_pack, seen = pu.pointnet2.ball_pack_wrapper, []
+
+        def spy(idx, limit=None):
+            pk = real_pack(idx, limit)
+            seen.append((tuple(idx.shape), pk.hdr))
+            return pk
+        pu.pointnet2.ball_pack_wrapper = spy
+        try:
+            E.infer_batch(model, cfg, batches[0], engine=F.FastPointRCNN(model, cfg))
+            torch.cuda.synchronize()
+        finally:
+            pu.pointnet2.ball_pack_wrapper = real_pack
+        distinct = {"%dx%dx%d" % shp: round(int(hdr[1]) / float(shp[0] * shp[1] * shp[2]), 4) for shp, hdr in seen}
+        saved = (F.USE_PACKED, F.USE_POOL_DEDUP)
+        F.USE_PACKED, F.USE_POOL_DEDUP = False, False
+        try:
+            k = max(4, min(args.steps, 20))
+            t1, _ = timed_run(k, 3)
+            all_rows = round(k * BATCH / (time.perf_counter() - t1), 1)
+        finally:
+            F.USE_PACKED, F.USE_POOL_DEDUP = saved
 
     scenes_total = world * args.steps * BATCH
     line = {
@@ -282,12 +389,16 @@ def main():
                                "random-init weights, batch=8 synthetic KITTI scenes x 16384 pts per GPU per step",
                    "scenes_per_step_per_gpu": BATCH, "points_per_scene": NPOINTS, "rois_per_scene": M,
                    "parallelism": "scene-sharded x%d, one final all_gather of detections" % world,
-                   "detections_gathered": int(counts.sum()) if rank == 0 else None},
+                   "detections_gathered": int(counts.sum()) if rank == 0 else None,
+                   "distinct_rows": distinct, "scenes_per_s_all_rows": all_rows},
     }
     if rank == 0:
         if not args.no_roofline:
             line["roofline"] = roofline_query_and_group(dev)
             line["roofline_mfma"] = roofline_sa_mlp_fused(dev)
+            line["roofline_product"] = roofline_roipool(dev, cfg, model)
+        if world == 1 and not args.no_driver:
+            line["config"]["driver_scenes_per_s"] = driver_leg(cfg, model, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)

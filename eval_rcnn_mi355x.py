@@ -8,4 +8,5 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-importlib.import_module("3d_adapt_auto_driving_amd.eval_rcnn").main()
+if __name__ == "__main__":      # (loader / writer processes re-import this file: they must not run main again)
+    importlib.import_module("3d_adapt_auto_driving_amd.eval_rcnn").main()
