@@ -25,7 +25,7 @@ constexpr int PL_ROWS = 64;
 constexpr int PL_LD = 128 + 4;
 
 __global__ __launch_bounds__(256) void packed_gather_affine_kernel(
-    int n, int m, int c1, const unsigned int *__restrict__ hdr, const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+    int n, int c1, const unsigned int *__restrict__ hdr, const float4 *__restrict__ rowdxyz,
     const float4 *__restrict__ P, const float4 *__restrict__ wxyz, const unsigned int *__restrict__ rowinfo,
     const int *__restrict__ tilecloud, float4 *__restrict__ out)
 {
@@ -33,14 +33,12 @@ __global__ __launch_bounds__(256) void packed_gather_affine_kernel(
     if (t >= (long)hdr[0]) return;
     const int cloud = tilecloud[t];
     const int q4 = c1 / 4;                                 // float4 chunks per row
-    const long pbase = (long)cloud * n, cbase = (long)cloud * m;
+    const long pbase = (long)cloud * n;
     for (int e = threadIdx.x; e < PL_ROWS * q4; e += 256) {
         const int row = e / q4, q = e - row * q4;
-        const unsigned int info = rowinfo[t * PL_ROWS + row];
-        const int k = (int)(info & 0xffffu), cl = (int)(info >> 16);
-        const float *pt = xyz + (pbase + k) * 3;
-        const float *ct = new_xyz + (cbase + cl) * 3;
-        const float dx = pt[0] - ct[0], dy = pt[1] - ct[1], dz = pt[2] - ct[2];
+        const int k = (int)(rowinfo[t * PL_ROWS + row] & 0xffffu);
+        const float4 d = rowdxyz[t * PL_ROWS + row];
+        const float dx = d.x, dy = d.y, dz = d.z;
         const float4 base = P[(pbase + k) * q4 + q];
         const float4 wx = wxyz[q], wy = wxyz[q4 + q], wz = wxyz[2 * q4 + q];
         float4 v;
@@ -134,19 +132,19 @@ __global__ __launch_bounds__(256, 2) void packed_layer_kernel(
 
 using namespace prcnn;
 
-// A1 (max_tiles*64, c1) = relu(P[point] + wxyz . (xyz[point] - centre)) for every packed row (prcnn_ball_pack);
+// A1 (max_tiles*64, c1) = relu(P[point] + wxyz . rowdxyz) for every packed row (prcnn_ball_pack: rowdxyz = xyz[point] - centre);
 // P (b,n,c1), wxyz (3,c1), c1 % 4 == 0.
-extern "C" int prcnn_packed_gather_affine(int b, int n, int m, int c1, long max_tiles, const float *new_xyz, const float *xyz,
-                                          const float *P, const float *wxyz, const unsigned int *rowinfo, const int *tilecloud,
+extern "C" int prcnn_packed_gather_affine(int b, int n, int c1, long max_tiles, const float *P, const float *wxyz,
+                                          const unsigned int *rowinfo, const float *rowdxyz, const int *tilecloud,
                                           const unsigned int *hdr, float *out, void *stream)
 {
-    PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && max_tiles >= 0 && c1 > 0 && c1 % 4 == 0, "packed_gather_affine: bad sizes");
+    PRCNN_REQUIRE(b >= 0 && n >= 0 && max_tiles >= 0 && c1 > 0 && c1 % 4 == 0, "packed_gather_affine: bad sizes");
     if (max_tiles == 0) return PRCNN_OK;
-    PRCNN_REQUIRE(new_xyz && xyz && P && wxyz && rowinfo && tilecloud && hdr && out, "packed_gather_affine: null pointer");
+    PRCNN_REQUIRE(P && wxyz && rowinfo && rowdxyz && tilecloud && hdr && out, "packed_gather_affine: null pointer");
     PRCNN_REQUIRE((((uintptr_t)P | (uintptr_t)wxyz | (uintptr_t)out) & 15) == 0, "packed_gather_affine: 16-byte alignment required");
     PRCNN_REQUIRE(max_tiles <= 0x7fffffffL, "packed_gather_affine: too many tiles");
-    hipLaunchKernelGGL(packed_gather_affine_kernel, dim3((unsigned)max_tiles), dim3(256), 0, (hipStream_t)stream, n, m, c1, hdr,
-                       new_xyz, xyz, (const float4 *)P, (const float4 *)wxyz, rowinfo, tilecloud, (float4 *)out);
+    hipLaunchKernelGGL(packed_gather_affine_kernel, dim3((unsigned)max_tiles), dim3(256), 0, (hipStream_t)stream, n, c1, hdr,
+                       (const float4 *)rowdxyz, (const float4 *)P, (const float4 *)wxyz, rowinfo, tilecloud, (float4 *)out);
     return check_launch("packed_gather_affine");
 }
 

@@ -37,8 +37,12 @@ constexpr int PK_TILES_PER_WG = 8;
 // wrap-around fill of RoI pooling, roipool3d_kernel.cu:152-159).  A copy lies in a ball iff its original does, and the
 // original has the lower index, so in a ball query's answer (first nsample hits in index order) every copy is preceded by
 // its original: the rows of the slots with index >= limit are duplicates of rows already listed and are dropped too.
-__global__ void ball_pack_kernel(int m, int ns, int tiles_cap_cloud, const int *__restrict__ idx, const int *__restrict__ limit,
-                                 unsigned int *__restrict__ rowinfo, int *__restrict__ tilecloud, unsigned int *__restrict__ hdr)
+// Every listed row also gets its RELATIVE coordinates xyz[point] - new_xyz[centre] (rowdxyz): the subtraction the tile
+// builders used to do (three loads of the point + three of the centre per row) is done once here.
+__global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, const int *__restrict__ idx, const int *__restrict__ limit,
+                                 const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                 unsigned int *__restrict__ rowinfo, float4 *__restrict__ rowdxyz, int *__restrict__ tilecloud,
+                                 unsigned int *__restrict__ hdr)
 {
     extern __shared__ int pk_lds[];
     int *cnts = pk_lds;                   // [m]   cnt, then exclusive offset
@@ -89,18 +93,31 @@ __global__ void ball_pack_kernel(int m, int ns, int tiles_cap_cloud, const int *
     const int ntiles = (total + PK_ROWS - 1) / PK_ROWS;
     for (int t = tid; t < ntiles; t += T) tilecloud[base + t] = b;
     unsigned int *dst = rowinfo + (long)base * PK_ROWS;
+    float4 *dxyz = rowdxyz + (long)base * PK_ROWS;
+    const float *cloud = xyz + (long)b * n * 3;
     for (int c = c0; c < c1; ++c) {
         const int *row = rows + (long)c * ns;
         const int n_c = cnts[c];
+        const float *ct = new_xyz + ((long)b * m + c) * 3;
+        const float cx = ct[0], cy = ct[1], cz = ct[2];
         // slots beyond the limit inside the kept prefix (possible only for index rows that are not a ball query's
         // answer) fall back to the row's first entry: still a copy of a listed row
-        for (int p = 0; p < n_c; ++p) dst[run + p] = ((unsigned int)c << 16) | (unsigned int)(row[p] < lim ? row[p] : row[0]);
+        for (int p = 0; p < n_c; ++p) {
+            const int k = row[p] < lim ? row[p] : row[0];
+            dst[run + p] = ((unsigned int)c << 16) | (unsigned int)k;
+            const float *pt = cloud + 3 * (long)k;
+            dxyz[run + p] = make_float4(pt[0] - cx, pt[1] - cy, pt[2] - cz, 0.f);
+        }
         run += n_c;
     }
     // the last tile of the cloud is filled up with copies of the cloud's last row (copies do not change a max)
     if (c1 == m && c0 < m) {
-        const unsigned int fill = ((unsigned int)(m - 1) << 16) | (unsigned int)rows[(long)(m - 1) * ns];
-        for (int r = total; r < ntiles * PK_ROWS; ++r) dst[r] = fill;
+        const int k = rows[(long)(m - 1) * ns];
+        const unsigned int fill = ((unsigned int)(m - 1) << 16) | (unsigned int)k;
+        const float *ct = new_xyz + ((long)b * m + (m - 1)) * 3;
+        const float *pt = cloud + 3 * (long)k;
+        const float4 fd = make_float4(pt[0] - ct[0], pt[1] - ct[1], pt[2] - ct[2], 0.f);
+        for (int r = total; r < ntiles * PK_ROWS; ++r) { dst[r] = fill; dxyz[r] = fd; }
     }
     (void)tiles_cap_cloud;
 }
@@ -108,7 +125,7 @@ __global__ void ball_pack_kernel(int m, int ns, int tiles_cap_cloud, const int *
 // ------------------------------------------------------------------------------------------------ C3 = 128
 // Two workgroups per CU (see sa_mlp_fused.hip for the MFMA mapping; identical here).
 __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
-    int n, int m, const unsigned int *__restrict__ hdr, const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+    int n, int m, const unsigned int *__restrict__ hdr, const float4 *__restrict__ rowdxyz,
     const float4 *__restrict__ P /* (b,n,128) */, const float4 *__restrict__ wxyz /* (3,128) */,
     const unsigned int *__restrict__ rowinfo, const int *__restrict__ tilecloud,
     const float *__restrict__ w2t, const float *__restrict__ b2, const float *__restrict__ w3t, const float *__restrict__ b3,
@@ -155,9 +172,8 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
         for (int i = 0; i < 8; ++i) {
             const int row = r0 + 8 * i;
             const int k = (int)(info[i] & 0xffffu), cl = (int)(info[i] >> 16);
-            const float *pt = xyz + (pbase + k) * 3;
-            const float *ct = new_xyz + (cbase + cl) * 3;
-            const float dx = pt[0] - ct[0], dy = pt[1] - ct[1], dz = pt[2] - ct[2];
+            const float4 d = rowdxyz[t * PK_ROWS + row];
+            const float dx = d.x, dy = d.y, dz = d.z;
             const float4 base = P[(pbase + k) * (PK_C / 4) + chunk];
             float4 v;
             v.x = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, base.x))), 0.f);
@@ -235,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
 // Eight waves (sa_mlp_fused256_kernel's mapping): wave (wp, wg) owns column panel wp of layer 2 for row half wg, and column
 // panel wp of column tile wg of layer 3 for both row halves.
 __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
-    int n, int m, const unsigned int *__restrict__ hdr, const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+    int n, int m, const unsigned int *__restrict__ hdr, const float4 *__restrict__ rowdxyz,
     const float4 *__restrict__ P, const float4 *__restrict__ wxyz, const unsigned int *__restrict__ rowinfo,
     const int *__restrict__ tilecloud, const float *__restrict__ w2t, const float *__restrict__ b2,
     const float *__restrict__ w3t /* (128,256) */, const float *__restrict__ b3, float *__restrict__ out, int out_stride,
@@ -279,9 +295,8 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
         for (int i = 0; i < 4; ++i) {
             const int row = r0 + 16 * i;
             const int k = (int)(info[i] & 0xffffu), cl = (int)(info[i] >> 16);
-            const float *pt = xyz + (pbase + k) * 3;
-            const float *ct = new_xyz + (cbase + cl) * 3;
-            const float dx = pt[0] - ct[0], dy = pt[1] - ct[1], dz = pt[2] - ct[2];
+            const float4 d = rowdxyz[t * PK_ROWS + row];
+            const float dx = d.x, dy = d.y, dz = d.z;
             const float4 base = P[(pbase + k) * (PK_C / 4) + chunk];
             float4 v;
             v.x = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, base.x))), 0.f);
@@ -353,20 +368,23 @@ using namespace prcnn;
 
 // idx (b,m,nsample) i32 -> the distinct grouped rows of every cloud as 64-row tiles:
 //   rowinfo  [b * tiles_cap * 64] u32, (centre within cloud) << 16 | (point within cloud); tile t = entries [64t, 64t+64)
+//   rowdxyz  [b * tiles_cap * 64] float4, xyz[point] - new_xyz[centre] of the same rows (w = 0)
 //   tilecloud[b * tiles_cap] i32, cloud of tile t
 //   hdr      [4] u32: [0] = number of tiles, [1] = number of distinct rows (both written by this call)
 // with tiles_cap = ceil(m * nsample / 64) tiles per cloud at most.  Needs m, n <= 65536.
 // limit (b) i32, optional: points k >= limit[cloud] are copies of point k % limit[cloud] (see ball_pack_kernel).
-extern "C" int prcnn_ball_pack(int b, int m, int nsample, const int *idx, const int *limit, unsigned int *rowinfo,
-                               int *tilecloud, unsigned int *hdr, void *stream)
+extern "C" int prcnn_ball_pack(int b, int n, int m, int nsample, const int *idx, const int *limit, const float *xyz,
+                               const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr,
+                               void *stream)
 {
-    PRCNN_REQUIRE(b >= 0 && m >= 0 && nsample >= 1, "ball_pack: bad sizes");
+    PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 1, "ball_pack: bad sizes");
     PRCNN_REQUIRE(m <= 65536 && m <= 15360, "ball_pack: m=%d centres per cloud unsupported (<= 15360)", m);
     PRCNN_REQUIRE(hdr, "ball_pack: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(hdr, 0, 4 * sizeof(unsigned int), st) != hipSuccess) { set_error("ball_pack: memset failed"); return PRCNN_ELAUNCH; }
     if (b == 0 || m == 0) return PRCNN_OK;
-    PRCNN_REQUIRE(idx && rowinfo && tilecloud, "ball_pack: null pointer");
+    PRCNN_REQUIRE(idx && rowinfo && tilecloud && xyz && new_xyz && rowdxyz, "ball_pack: null pointer");
+    PRCNN_REQUIRE(((uintptr_t)rowdxyz & 15) == 0, "ball_pack: rowdxyz must be 16-byte aligned");
     PRCNN_REQUIRE(((uintptr_t)idx & 15) == 0 || (nsample & 3) != 0, "ball_pack: 16-byte alignment required");
     int threads = 64;
     while (threads < m && threads < 1024) threads *= 2;
@@ -376,7 +394,8 @@ extern "C" int prcnn_ball_pack(int b, int m, int nsample, const int *idx, const 
         if (rc != PRCNN_OK) return rc;
     }
     const int cap = (int)(((long)m * nsample + PK_ROWS - 1) / PK_ROWS);
-    hipLaunchKernelGGL(ball_pack_kernel, dim3(b), dim3(threads), lds, st, m, nsample, cap, idx, limit, rowinfo, tilecloud, hdr);
+    hipLaunchKernelGGL(ball_pack_kernel, dim3(b), dim3(threads), lds, st, n, m, nsample, cap, idx, limit, xyz, new_xyz, rowinfo,
+                       (float4 *)rowdxyz, tilecloud, hdr);
     return check_launch("ball_pack");
 }
 
@@ -384,8 +403,8 @@ extern "C" int prcnn_ball_pack(int b, int m, int nsample, const int *idx, const 
 // w2t (128,128), w3t (128,c3) k-major, c3 in {128, 256}; out[(b*m rows)][out_col .. out_col + c3), row stride out_stride.
 // The output slice is zeroed by this call and then receives max over each centre's distinct rows of relu(layer 3).
 // max_tiles = b * ceil(m * nsample / 64) sizes the grid (the real tile count stays on the device, in hdr[0]).
-extern "C" int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, const float *new_xyz, const float *xyz,
-                                   const float *P, const float *wxyz, const unsigned int *rowinfo, const int *tilecloud,
+extern "C" int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, const float *P, const float *wxyz,
+                                   const unsigned int *rowinfo, const float *rowdxyz, const int *tilecloud,
                                    const unsigned int *hdr, const float *w2t, const float *b2, const float *w3t,
                                    const float *b3, float *out, int out_stride, int out_col, void *stream)
 {
@@ -394,7 +413,7 @@ extern "C" int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, 
     PRCNN_REQUIRE(n <= 65536 && m <= 65536, "sa_packed_mlp: cloud too large for the 16-bit row descriptors");
     PRCNN_REQUIRE(out_stride >= out_col + c3 && out_col >= 0, "sa_packed_mlp: bad output slice");
     if ((long)b * m == 0) return PRCNN_OK;
-    PRCNN_REQUIRE(new_xyz && xyz && P && wxyz && rowinfo && tilecloud && hdr && w2t && b2 && w3t && b3 && out, "sa_packed_mlp: null pointer");
+    PRCNN_REQUIRE(P && wxyz && rowinfo && rowdxyz && tilecloud && hdr && w2t && b2 && w3t && b3 && out, "sa_packed_mlp: null pointer");
     PRCNN_REQUIRE((((uintptr_t)P | (uintptr_t)wxyz) & 15) == 0, "sa_packed_mlp: 16-byte alignment required");
     hipStream_t st = (hipStream_t)stream;
     if (hipMemset2DAsync(out + out_col, (size_t)out_stride * sizeof(float), 0, (size_t)c3 * sizeof(float), (size_t)b * m, st) != hipSuccess) {
@@ -408,10 +427,10 @@ extern "C" int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, 
     unsigned int *ticket = next_ticket(st);
     if (!ticket) { set_error("sa_packed_mlp: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
     if (c3 == 128)
-        hipLaunchKernelGGL(sa_packed_mlp128_kernel, dim3(grid), dim3(256), 0, st, n, m, hdr, new_xyz, xyz, (const float4 *)P,
+        hipLaunchKernelGGL(sa_packed_mlp128_kernel, dim3(grid), dim3(256), 0, st, n, m, hdr, (const float4 *)rowdxyz, (const float4 *)P,
                            (const float4 *)wxyz, rowinfo, tilecloud, w2t, b2, w3t, b3, out, out_stride, out_col, ticket, per_wg);
     else
-        hipLaunchKernelGGL(sa_packed_mlp256_kernel, dim3(grid), dim3(512), 0, st, n, m, hdr, new_xyz, xyz, (const float4 *)P,
+        hipLaunchKernelGGL(sa_packed_mlp256_kernel, dim3(grid), dim3(512), 0, st, n, m, hdr, (const float4 *)rowdxyz, (const float4 *)P,
                            (const float4 *)wxyz, rowinfo, tilecloud, w2t, b2, w3t, b3, out, out_stride, out_col, ticket, per_wg);
     return check_launch("sa_packed_mlp");
 }

@@ -22,6 +22,15 @@ __device__ __forceinline__ void pk_flush(float *__restrict__ out, long centre, i
 __device__ __forceinline__ void pk_segmented_max(const f32x16 &acc0, const f32x16 &acc1, const int *ctr, unsigned long long start,
                                                  int h, float *__restrict__ out, int out_stride, int col, float bias)
 {
+    if (start == 1ULL) {
+        // the whole tile belongs to ONE centre (a full ball): plain max over the 64 rows, one store per column
+        float mx = fmaxf(acc0[0], acc1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(acc0[r], acc1[r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (h == 0) pk_flush(out, ctr[0], out_stride, col, mx, bias);
+        return;
+    }
     float cur = acc0[0];
 #pragma unroll
     for (int q = 1; q < 32; ++q) {

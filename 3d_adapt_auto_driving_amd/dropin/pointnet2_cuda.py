@@ -174,17 +174,21 @@ def sa_mlp_fused_wrapper(new_xyz, xyz, P, wxyz, idx, w2t, b2, w3t, b3, out, out_
 
 class BallPack:
     """Distinct grouped rows of an index tensor as 64-row tiles (prcnn_ball_pack); device-resident, no host sync."""
-    __slots__ = ("idx", "limit", "rowinfo", "tilecloud", "hdr", "max_tiles")
+    __slots__ = ("idx", "limit", "rowinfo", "rowdxyz", "tilecloud", "hdr", "max_tiles")
+
+    def tensors(self):
+        return (self.idx, self.rowinfo, self.rowdxyz, self.tilecloud, self.hdr)
 
     def record_stream(self, stream):
-        for t in (self.idx, self.rowinfo, self.tilecloud, self.hdr):
+        for t in self.tensors():
             t.record_stream(stream)
 
 
-def ball_pack_wrapper(idx, limit=None):
-    """idx (b,m,nsample) i32 from a ball query -> BallPack for sa_packed_mlp_wrapper.  limit (b) i32, optional: the points
-    k >= limit[cloud] of a cloud are copies of point k % limit[cloud] (RoI pooling's wrap-around fill): dropped as well."""
-    _chk(torch.int32, idx)
+def ball_pack_wrapper(idx, xyz, new_xyz, limit=None):
+    """idx (b,m,nsample) i32 from a ball query of new_xyz (b,m,3) in xyz (b,n,3) -> BallPack for sa_packed_mlp_wrapper.
+    limit (b) i32, optional: the points k >= limit[cloud] of a cloud are copies of point k % limit[cloud] (RoI pooling's
+    wrap-around fill): dropped as well."""
+    _chk(torch.int32, idx); _chk(torch.float32, xyz, new_xyz)
     if limit is not None:
         _chk(torch.int32, limit)
     b, m, ns = idx.shape
@@ -192,10 +196,12 @@ def ball_pack_wrapper(idx, limit=None):
     pk = BallPack()
     pk.idx, pk.limit = idx, limit
     pk.rowinfo = torch.empty((b * cap * 64,), dtype=torch.int32, device=idx.device)
+    pk.rowdxyz = torch.empty((b * cap * 64, 4), dtype=torch.float32, device=idx.device)
     pk.tilecloud = torch.empty((b * cap,), dtype=torch.int32, device=idx.device)
     pk.hdr = torch.empty((4,), dtype=torch.int32, device=idx.device)
     pk.max_tiles = b * cap
-    _lib.call("prcnn_ball_pack", b, m, ns, idx.data_ptr(), _lib.ptr(limit), pk.rowinfo.data_ptr(), pk.tilecloud.data_ptr(),
+    _lib.call("prcnn_ball_pack", b, xyz.size(1), m, ns, idx.data_ptr(), _lib.ptr(limit), xyz.data_ptr(), new_xyz.data_ptr(),
+              pk.rowinfo.data_ptr(), pk.rowdxyz.data_ptr(), pk.tilecloud.data_ptr(),
               pk.hdr.data_ptr(), _lib.current_stream(idx))
     return pk
 
@@ -207,8 +213,8 @@ def sa_packed_mlp_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, ou
     b, n, c1 = P.shape
     if c1 != 128 or w2t.shape != (128, 128) or w3t.size(0) != 128:
         raise RuntimeError("pointnet2_cuda: sa_packed_mlp needs 128-wide (zero-padded) layers 1 and 2")
-    _lib.call("prcnn_sa_packed_mlp", b, n, new_xyz.size(1), w3t.size(1), pack.max_tiles, new_xyz.data_ptr(), xyz.data_ptr(),
-              P.data_ptr(), wxyz.data_ptr(), pack.rowinfo.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr(),
+    _lib.call("prcnn_sa_packed_mlp", b, n, new_xyz.size(1), w3t.size(1), pack.max_tiles,
+              P.data_ptr(), wxyz.data_ptr(), pack.rowinfo.data_ptr(), pack.rowdxyz.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr(),
               w2t.data_ptr(), b2.data_ptr(), w3t.data_ptr(), b3.data_ptr(), out.data_ptr(), out.size(-1), out_col,
               _lib.current_stream(xyz))
     return out
@@ -218,8 +224,8 @@ def packed_gather_affine_wrapper(new_xyz, xyz, P, wxyz, pack, out):
     """Layer 1 over a packed row list: out (pack.max_tiles*64, c1) = relu(P[point] + wxyz.(xyz[point] - centre))."""
     _chk(torch.float32, new_xyz, xyz, P, wxyz, out)
     b, n, c1 = P.shape
-    _lib.call("prcnn_packed_gather_affine", b, n, new_xyz.size(1), c1, pack.max_tiles, new_xyz.data_ptr(), xyz.data_ptr(),
-              P.data_ptr(), wxyz.data_ptr(), pack.rowinfo.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr(),
+    _lib.call("prcnn_packed_gather_affine", b, n, c1, pack.max_tiles,
+              P.data_ptr(), wxyz.data_ptr(), pack.rowinfo.data_ptr(), pack.rowdxyz.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr(),
               out.data_ptr(), _lib.current_stream(xyz))
     return out
 

@@ -322,7 +322,7 @@ def _tensors(obj):
         for v in obj:
             yield from _tensors(v)
     elif hasattr(obj, "rowinfo"):                 # BallPack (distinct-row list of an index tensor)
-        for v in (obj.idx, obj.rowinfo, obj.tilecloud, obj.hdr):
+        for v in obj.tensors():
             yield v
 
 

@@ -240,7 +240,7 @@ class FastPointRCNN:
         new_xyz = torch.gather(cur, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
         idxs = [pu.ball_query(radius, ns, cur, new_xyz) for radius, ns, _, _ in scales]
         # the distinct-row lists of the scales that run on the packed MFMA kernel depend on the indices only
-        packs = [pu.pointnet2.ball_pack_wrapper(ix) if (USE_PACKED and (sc[2].packed is not None or sc[2].wide is not None))
+        packs = [pu.pointnet2.ball_pack_wrapper(ix, cur, new_xyz) if (USE_PACKED and (sc[2].packed is not None or sc[2].wide is not None))
                  else None for ix, sc in zip(idxs, scales)]
         state["sa"].append({"sel": sel, "new_xyz": new_xyz, "idx": idxs, "pack": packs})
         state["l_xyz"].append(new_xyz)
@@ -261,14 +261,14 @@ class FastPointRCNN:
             # whole scale in ONE hand-written MFMA kernel over the DISTINCT rows of every group (csrc/sa_packed.hip)
             wf, wx, b1, w2, b2, w3, b3 = mlp.packed
             P = P_pre if P_pre is not None else gemm_bias_act(feats.view(B * N, cin), wf, b1, False).view(B, N, 128)
-            pk = pack if pack is not None else ext.ball_pack_wrapper(idx)
+            pk = pack if pack is not None else ext.ball_pack_wrapper(idx, xyz, new_xyz)
             ext.sa_packed_mlp_wrapper(new_xyz, xyz, P, wx, pk, w2, b2, w3, b3, out, out_col)
             return
         if USE_PACKED and mlp.wide is not None:
             # wider level: the same distinct rows, layer by layer (gather+affine -> MFMA layer -> MFMA layer + segmented max)
             wf, wx, b1, w2, b2, w3, b3 = mlp.wide
             P = point_layer(feats.view(B * N, cin), wf, b1, False).view(B, N, -1)
-            pk = pack if pack is not None else ext.ball_pack_wrapper(idx)
+            pk = pack if pack is not None else ext.ball_pack_wrapper(idx, xyz, new_xyz)
             rows = pk.max_tiles * 64
             a1 = torch.empty((rows, wf.shape[1]), dtype=torch.float32, device=xyz.device)
             ext.packed_gather_affine_wrapper(new_xyz, xyz, P, wx, pk, a1)
@@ -461,7 +461,7 @@ class FastPointRCNN:
                 first = len(l_feat) == 1
                 pack = None
                 if first and pooled_cnt is not None and P_pre is not None:
-                    pack = ext.ball_pack_wrapper(idx, pooled_cnt.view(-1))       # copies of pooled points are dropped too
+                    pack = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, pooled_cnt.view(-1))       # copies of pooled points are dropped too
                 self._sa_scale(cur_xyz, new_xyz, cur_feat, idx, mlp, cin, out, 0, P_pre=P_pre if first else None, pack=pack)
                 l_xyz.append(new_xyz)
             elif USE_PACKED and (mlp.packed is not None or mlp.wide is not None):
@@ -471,7 +471,7 @@ class FastPointRCNN:
                 if getattr(self, "_groupall", (None,))[0] != key:
                     ga_idx = torch.arange(n, dtype=torch.int32, device=cur_xyz.device).view(1, 1, n).expand(Bc, 1, n).contiguous()
                     self._groupall = (key, ga_idx, torch.zeros((Bc, 1, 3), dtype=torch.float32, device=cur_xyz.device),
-                                      ext.ball_pack_wrapper(ga_idx))
+                                      ext.ball_pack_wrapper(ga_idx, cur_xyz, torch.zeros((Bc, 1, 3), dtype=torch.float32, device=cur_xyz.device)))
                 _, ga_idx, origin, ga_pack = self._groupall
                 out = torch.empty((Bc, 1, cout), dtype=torch.float32, device=cur_xyz.device)
                 self._sa_scale(cur_xyz, origin, cur_feat, ga_idx, mlp, cin, out, 0, pack=ga_pack)

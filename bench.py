@@ -128,7 +128,7 @@ def roofline_sa_mlp_fused(dev, reps=10):
     out = torch.empty((b, m, c3), device=dev)
     # full balls: 64 DISTINCT point indices per centre (a random permutation prefix), so the packed list holds every row
     idx = torch.argsort(torch.rand((b, m, n), device=dev, generator=g), dim=2)[:, :, :ns].to(torch.int32).contiguous()
-    pack = pointnet2_cuda.ball_pack_wrapper(idx)
+    pack = pointnet2_cuda.ball_pack_wrapper(idx, xyz, new_xyz)
     assert int(pack.hdr[1]) == b * m * ns
     run = lambda: pointnet2_cuda.sa_packed_mlp_wrapper(new_xyz, xyz, P, wx, pack, w2, b2, w3, b3, out, 0)
     for _ in range(3):
@@ -359,8 +359,8 @@ def main():
         pu = importlib.import_module(PKG + ".pointnet2.pointnet2_utils")
         real_pack, seen = pu.pointnet2.ball_pack_wrapper, []
 
-        def spy(idx, limit=None):
-            pk = real_pack(idx, limit)
+        def spy(idx, xyz_, new_xyz_, limit=None):
+            pk = real_pack(idx, xyz_, new_xyz_, limit)
             seen.append((tuple(idx.shape), pk.hdr))
             return pk
         pu.pointnet2.ball_pack_wrapper = spy

@@ -138,6 +138,8 @@ int prcnn_sa_mlp_fused(int b, int n, int m, int nsample, int c1, int c2, int c3,
  * change when they are dropped.  prcnn_ball_pack: idx (b,m,nsample) -> per cloud, cnt[c] = 1 + (last slot that differs
  * from slot 0) rows per centre, written as a dense list of 64-row tiles:
  *   rowinfo  u32 [b * ceil(m*nsample/64) * 64]: (centre within cloud) << 16 | (point within cloud)
+ *   rowdxyz  float4 [same length]: xyz[point] - new_xyz[centre] of the row (the grouped, centre-relative coordinates of
+ *            pointnet2_utils.py:252), so that the MLP kernels do not gather coordinates again
  *   tilecloud i32 [b * ceil(m*nsample/64)]:     cloud of each tile
  *   hdr      u32 [4]: [0] tiles, [1] distinct rows (device-resident; no host sync)
  *   limit    i32 [b], optional: points k >= limit[cloud] of a cloud are copies of point k % limit[cloud] (the wrap-around
@@ -145,10 +147,11 @@ int prcnn_sa_mlp_fused(int b, int n, int m, int nsample, int c1, int c2, int c3,
  * prcnn_sa_packed_mlp: layers as prcnn_sa_mlp_fused (c1 = c2 = 128; narrower levels zero-padded by the caller), c3 in
  * {128, 256}; zeroes out[(b*m)][out_col..out_col+c3) and accumulates the per-centre maxima with atomicMax (values are
  * >= 0 after ReLU).  Bit-identical to prcnn_sa_mlp_fused on the same idx.  max_tiles = b * ceil(m*nsample/64). */
-int prcnn_ball_pack(int b, int m, int nsample, const int *idx, const int *limit, unsigned int *rowinfo, int *tilecloud,
-                    unsigned int *hdr, void *stream);
-int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, const float *new_xyz, const float *xyz,
-                        const float *P, const float *wxyz, const unsigned int *rowinfo, const int *tilecloud,
+int prcnn_ball_pack(int b, int n, int m, int nsample, const int *idx, const int *limit, const float *xyz,
+                    const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr,
+                    void *stream);
+int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, const float *P, const float *wxyz,
+                        const unsigned int *rowinfo, const float *rowdxyz, const int *tilecloud,
                         const unsigned int *hdr, const float *w2t, const float *b2, const float *w3t,
                         const float *b3, float *out, int out_stride, int out_col, void *stream);
 
@@ -161,8 +164,8 @@ int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, const float
  *                               a plain row-major GEMM layer with a host-side row count, e.g. P = features @ W1f + b1)
  *   prcnn_packed_layer_segmax:  out[(b*m)][out_col..+N) = max over each centre's rows of relu(A @ W + bias)
  *                               (pointnet2_modules.py:37-53: last layer + max_pool2d) */
-int prcnn_packed_gather_affine(int b, int n, int m, int c1, long max_tiles, const float *new_xyz, const float *xyz,
-                               const float *P, const float *wxyz, const unsigned int *rowinfo, const int *tilecloud,
+int prcnn_packed_gather_affine(int b, int n, int c1, long max_tiles, const float *P, const float *wxyz,
+                               const unsigned int *rowinfo, const float *rowdxyz, const int *tilecloud,
                                const unsigned int *hdr, float *out, void *stream);
 int prcnn_packed_layer(const unsigned int *hdr, long rows, long max_tiles, int K, int N, const float *A, long lda,
                        const float *W, const float *bias, int relu, float *out, long ldo, void *stream);

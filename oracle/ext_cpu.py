@@ -139,7 +139,7 @@ class pointnet2_cpu:
         return out
 
     @staticmethod
-    def ball_pack_wrapper(idx, limit=None):
+    def ball_pack_wrapper(idx, xyz=None, new_xyz=None, limit=None):
         """The CPU stand-in keeps the index tensor: the oracle evaluates ALL nsample rows (the reference's semantics)."""
         return _CpuPack(idx, limit)
 

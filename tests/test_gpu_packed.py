@@ -87,7 +87,7 @@ def test_packed_kernel_bit_identical_to_unpacked_and_to_oracle(ext, c3, mean_cnt
     w2, b2, w3, b3 = mlp_params(rng, c3)
     full = torch.full((b, m, c3 + 4), -1.0, device=DEV)
     ext.pointnet2.sa_mlp_fused_wrapper(new_xyz, xyz, P, wx, idx, w2, b2, w3, b3, full, 4)
-    pk = ext.pointnet2.ball_pack_wrapper(idx)
+    pk = ext.pointnet2.ball_pack_wrapper(idx, xyz, new_xyz)
     hdr = pk.hdr.cpu().numpy()
     assert hdr[1] == cnt.sum()                                               # distinct rows
     assert hdr[0] == sum((int(cnt[i].sum()) + 63) // 64 for i in range(b))   # tiles: per cloud, rounded up
@@ -105,6 +105,9 @@ def test_packed_kernel_bit_identical_to_unpacked_and_to_oracle(ext, c3, mean_cnt
         rows = info[tc == i].reshape(-1)[:int(cnt[i].sum())]
         want_rows = np.concatenate([(np.uint32(c) << 16) | idx_np[i, c, :cnt[i, c]].astype(np.uint32) for c in range(m)])
         assert np.array_equal(rows, want_rows)
+        d = pk.rowdxyz.cpu().numpy()[:tiles * 64].reshape(tiles, 64, 4)[tc == i].reshape(-1, 4)[:int(cnt[i].sum())]
+        xc, cc = xyz[i].cpu().numpy(), new_xyz[i].cpu().numpy()
+        assert np.array_equal(d[:, :3], xc[want_rows & 0xffff] - cc[want_rows >> 16])
 
 
 def test_packed_kernel_on_arbitrary_index_rows(ext):
@@ -125,7 +128,7 @@ def test_packed_kernel_on_arbitrary_index_rows(ext):
     full = torch.empty((b, m, 128), device=DEV)
     ext.pointnet2.sa_mlp_fused_wrapper(new_xyz, xyz, P, wx, idx, w2, b2, w3, b3, full, 0)
     got = torch.full((b, m, 128), float("nan"), device=DEV)
-    ext.pointnet2.sa_packed_mlp_wrapper(new_xyz, xyz, P, wx, ext.pointnet2.ball_pack_wrapper(idx), w2, b2, w3, b3, got, 0)
+    ext.pointnet2.sa_packed_mlp_wrapper(new_xyz, xyz, P, wx, ext.pointnet2.ball_pack_wrapper(idx, xyz, new_xyz), w2, b2, w3, b3, got, 0)
     assert torch.equal(got, full)
 
 
@@ -154,7 +157,7 @@ def test_packed_kernel_at_the_rcnn_batch8_shape(ext, oracle, c3):
     outs = []
     for _ in range(2):
         got = torch.full((b, m, c3), float("nan"), device=DEV)
-        ext.pointnet2.sa_packed_mlp_wrapper(new_xyz, xyz, P, wx, ext.pointnet2.ball_pack_wrapper(idx), w2, b2, w3, b3, got, 0)
+        ext.pointnet2.sa_packed_mlp_wrapper(new_xyz, xyz, P, wx, ext.pointnet2.ball_pack_wrapper(idx, xyz, new_xyz), w2, b2, w3, b3, got, 0)
         outs.append(got)
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], full)
@@ -191,7 +194,7 @@ def test_wide_packed_level_layer_by_layer_is_bit_exact(ext, cin, c1, c2, c3):
         mv = (lambda t: t) if dev_pack else (lambda t: t.cpu())
         P = torch.empty((b * n, c1p), device=dev)
         X.packed_layer_wrapper(mv(feats).view(b * n, cin), mv(wf), mv(b1), False, P)
-        pk = X.ball_pack_wrapper(mv(idx))
+        pk = X.ball_pack_wrapper(mv(idx), mv(xyz), mv(new_xyz))
         rows = pk.max_tiles * 64
         a1 = torch.zeros((rows, c1p), device=dev)
         X.packed_gather_affine_wrapper(mv(new_xyz), mv(xyz), P.view(b, n, c1p), mv(wx), pk, a1)

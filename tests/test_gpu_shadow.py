@@ -76,8 +76,8 @@ def check_ball_pack(self, name, args, host, pack):
     """ball_pack returns the distinct-row list: compare its header with the definition (1 + last slot != slot 0)"""
     idx = host[0].numpy()
     keep = idx != idx[..., :1]
-    if len(host) > 1 and host[1] is not None:      # copies of pooled points (index >= the cloud's distinct count) are dropped too
-        lim = np.maximum(host[1].numpy().reshape(-1, 1, 1), 1)
+    if len(host) > 3 and host[3] is not None:      # copies of pooled points (index >= the cloud's distinct count) are dropped too
+        lim = np.maximum(host[3].numpy().reshape(-1, 1, 1), 1)
         keep &= idx < lim
         # the contract that makes this exact: every dropped copy's original is listed in the same row
         canon = np.where(idx >= lim, idx % lim, idx)
