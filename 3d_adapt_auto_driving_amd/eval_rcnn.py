@@ -136,13 +136,18 @@ class PipelinedRunner:
         self.model, self.cfg = model, cfg
         self.engine = FastPointRCNN(model, cfg)
         self.device = torch.device(device)
-        self.depth = int(os.environ.get("PRCNN_GEO_DEPTH", "3")) if depth is None else depth
+        # geometry runs for GROUPS of `group` batches in one chain (FastPointRCNN.geometry_group): a scene's FPS is serial
+        # (~6.8 ms for 16384 -> 4096 on one CU) whatever the batch, so one chain over 3 batches costs the latency of one and
+        # a single chain in flight keeps up with the feature stream.  `depth` = how many batches ahead the caller should
+        # hand over (2 * group: a chain is launched `group` steps before its first batch is due, ~10 ms for a ~9 ms chain).
+        self.group = max(1, int(os.environ.get("PRCNN_GEO_GROUP", "4")))
+        self.depth = int(os.environ.get("PRCNN_GEO_DEPTH", str(2 * self.group if self.group > 1 else 3))) if depth is None else depth
         # high priority: the geometry kernels are few, short-lived workgroups on a latency-bound chain;
         # when CU slots free up they should be placed before the feature pass's next workgroups
         # default priority: with the SA levels on the packed MFMA kernels the feature pass is short, and high-priority side
         # streams (three of them at depth 3) starve it -- measured 971 vs 1375 scenes/s
         prio = int(os.environ.get("PRCNN_SIDE_PRIORITY", "0"))
-        self.sides = [torch.cuda.Stream(self.device, priority=prio) for _ in range(max(1, self.depth))]
+        self.sides = [torch.cuda.Stream(self.device, priority=prio) for _ in range(2 if self.group > 1 else max(1, self.depth))]
         self._next_side = 0
         self._pending = []        # [(batch tensor, geometry dict, ready event)] in launch order
 
@@ -202,14 +207,16 @@ class PipelinedRunner:
             self._inflight = None
             self._chains = []                 # geometry chains in flight: dicts pts / side / state / geo / ev
         main = torch.cuda.current_stream(self.device)
+        todo = [] if upcoming is None else (list(upcoming) if isinstance(upcoming, (list, tuple)) else [upcoming])
+        todo = [p for p in todo if p is not None][:max(1, self.depth)]
+        if self.group > 1:
+            return self._submit_grouped(cur, todo, main)
         ch = self._chain(cur)
         if ch is None:                        # cold start: nothing was prefetched for this batch
             ch = self._chain_begin(cur, None)
         if ch["geo"] is None:
             self._chain_finish(ch, None)
-        self._chains.remove(ch)
-        todo = [] if upcoming is None else (list(upcoming) if isinstance(upcoming, (list, tuple)) else [upcoming])
-        todo = [p for p in todo if p is not None][:max(1, self.depth)]
+        self._chains = [c for c in self._chains if c is not ch]      # by identity (dict equality would compare tensors)
         # PRCNN_GATE=1: geometry chains may only start at the end of an RPN stage (round 1: the library GEMMs of that stage
         # stretched 40-70 % beside FPS workgroups).  Off by default now: most of those GEMMs are ticketed kernels of our own
         # and the RCNN stage is too short to hide a whole chain link (1293 gated vs 1371 ungated scenes/s).
@@ -235,6 +242,49 @@ class PipelinedRunner:
         # (FPS 16384 -> 4096, ~6 ms) -- both beside RCNN(i-1), on two side streams.
         if gated:
             self._advance_chains(todo, ev_rpn)
+        done = self._finish_inflight()
+        self._inflight = (cur, st, rois, roi_scores, ev_prop)
+        return done
+
+    # ---- grouped geometry: ONE chain per `group` batches -------------------------------------------------------
+    def _launch_group(self, batch_list):
+        main = torch.cuda.current_stream(self.device)
+        side = self.sides[self._next_side % len(self.sides)]
+        self._next_side += 1
+        side.wait_stream(main)                        # the batches (and the allocator's frees) are ordered before the chain
+        with torch.cuda.stream(side):
+            geos = self.engine.geometry_group(batch_list)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for t in _tensors(geos):                      # consumed on the feature stream: tell the caching allocator
+            t.record_stream(main)
+        for pts, geo in zip(batch_list, geos):
+            self._chains.append({"pts": pts, "geo": geo, "ev": ev})
+
+    def _submit_grouped(self, cur, todo, main):
+        ch = self._chain(cur)
+        if ch is None:                                # cold start (or a caller that looks less far ahead): chain for what is known
+            self._launch_group([cur] + [p for p in todo if self._chain(p) is None][:self.group - 1])
+            ch = self._chain(cur)
+        self._chains = [c for c in self._chains if c is not ch]
+        # start the next group as soon as a whole group of upcoming batches has no chain yet (with a look-ahead of
+        # 2 * group that is `group` steps before its first batch is due), or when the look-ahead is about to run dry
+        missing = [p for p in todo if self._chain(p) is None]
+        have = len(todo) - len(missing)
+        if missing and (len(missing) >= self.group or have <= 1):
+            self._launch_group(missing[:self.group])
+        main.wait_event(ch["ev"])
+        st = self.engine.rpn_stage(cur, ch["geo"])
+        ev_rpn = torch.cuda.Event()
+        ev_rpn.record(main)
+        for t in (st["rpn_scores_raw"], st["rpn_reg"], st["backbone_xyz"]):
+            t.record_stream(self.tail)
+        with torch.cuda.stream(self.tail):
+            self.tail.wait_event(ev_rpn)
+            rois, roi_scores = self.engine.propose(st)
+            ev_prop = torch.cuda.Event()
+            ev_prop.record(self.tail)
+        rois.record_stream(main)
         done = self._finish_inflight()
         self._inflight = (cur, st, rois, roi_scores, ev_prop)
         return done

@@ -169,15 +169,20 @@ def _fold_head(seq):
     return out
 
 
-def _state_version(model):
-    return sum(t._version for t in model.parameters()) + sum(t._version for t in model.buffers())
+def _state_tensors(model):
+    return list(model.parameters()) + list(model.buffers())
+
+
+def _state_version(tensors):
+    return sum(t._version for t in tensors)
 
 
 class FastPointRCNN:
     def __init__(self, model, cfg):
         assert not model.training, "FastPointRCNN is an inference engine: call model.eval() first"
         self.model, self.cfg = model, cfg
-        self._folded_at = _state_version(model)       # BN is folded into the weights HERE: see check_weights()
+        self._state = _state_tensors(model)
+        self._folded_at = _state_version(self._state)       # BN is folded into the weights HERE: see check_weights()
         rpn = model.rpn
         bb = rpn.backbone_net
         self.sa = []
@@ -207,7 +212,7 @@ class FastPointRCNN:
     def check_weights(self):
         """The engine folds BatchNorm into its own copies of the weights at construction.  Loading a checkpoint (or editing
         a parameter in place) afterwards would silently evaluate stale weights: refuse instead."""
-        if _state_version(self.model) != self._folded_at:
+        if _state_version(self._state) != self._folded_at:
             raise RuntimeError("FastPointRCNN: the model's parameters changed after the engine was built "
                                "(load the checkpoint first, then construct the engine / PipelinedRunner)")
 
@@ -239,11 +244,41 @@ class FastPointRCNN:
         sel = pu.furthest_point_sample(cur, npoint)
         new_xyz = torch.gather(cur, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
         idxs = [pu.ball_query(radius, ns, cur, new_xyz) for radius, ns, _, _ in scales]
-        # the distinct-row lists of the scales that run on the packed MFMA kernel depend on the indices only
-        packs = [pu.pointnet2.ball_pack_wrapper(ix, cur, new_xyz) if (USE_PACKED and (sc[2].packed is not None or sc[2].wide is not None))
-                 else None for ix, sc in zip(idxs, scales)]
-        state["sa"].append({"sel": sel, "new_xyz": new_xyz, "idx": idxs, "pack": packs})
+        lev = {"sel": sel, "new_xyz": new_xyz, "idx": idxs, "pack": [None] * len(scales)}
+        if not state.get("defer_packs"):
+            self._pack_level(k, cur, lev)
+        state["sa"].append(lev)
         state["l_xyz"].append(new_xyz)
+
+    def _pack_level(self, k, cur, lev):
+        """the distinct-row lists of the scales that run on the packed MFMA kernels (they depend on the indices only)"""
+        lev["pack"] = [pu.pointnet2.ball_pack_wrapper(ix, cur, lev["new_xyz"])
+                       if (USE_PACKED and (sc[2].packed is not None or sc[2].wide is not None)) else None
+                       for ix, sc in zip(lev["idx"], self.sa[k][1])]
+
+    @torch.no_grad()
+    def geometry_group(self, xyz_list):
+        """The xyz-only chain for SEVERAL batches in one pass: the serial FPS of a scene occupies one CU for ~6 ms whatever
+        the batch, so the chain's latency does not grow with the number of scenes -- its throughput does.  Returns one
+        geometry dict per batch (views into the group's tensors; the packed row lists are built per batch)."""
+        sizes = [x.shape[0] for x in xyz_list]
+        if len(xyz_list) == 1:
+            return [self.geometry(xyz_list[0])]
+        state = {"l_xyz": [torch.cat(list(xyz_list), dim=0)], "sa": [], "defer_packs": True}
+        self._geometry_level(state, 0)
+        geo = self.geometry_finish(state)
+        out, lo = [], 0
+        for b in sizes:
+            hi = lo + b
+            g = {"l_xyz": [t[lo:hi] for t in geo["l_xyz"]], "fp": [(i[lo:hi], w[lo:hi]) for i, w in geo["fp"]], "sa": []}
+            for k, lev in enumerate(geo["sa"]):
+                part = {"sel": lev["sel"][lo:hi], "new_xyz": lev["new_xyz"][lo:hi], "idx": [ix[lo:hi] for ix in lev["idx"]],
+                        "pack": [None] * len(lev["idx"])}
+                self._pack_level(k, g["l_xyz"][k], part)
+                g["sa"].append(part)
+            out.append(g)
+            lo = hi
+        return out
 
     @torch.no_grad()
     def geometry(self, xyz):

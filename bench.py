@@ -282,7 +282,7 @@ def main():
     M = cfg.TEST.RPN_POST_NMS_TOP_N
 
     # distinct synthetic scenes per rank and per step slot, resident in HBM before timing
-    n_slots = 6                    # > geometry depth: a batch tensor is never its own look-ahead
+    n_slots = int(os.environ.get("PRCNN_GEO_DEPTH", 2 * int(os.environ.get("PRCNN_GEO_GROUP", "4")))) + 2   # > look-ahead
     batches = [torch.from_numpy(synth.scenes(BATCH, NPOINTS, seed0=(rank * n_slots + s) * BATCH)).to(dev)
                for s in range(n_slots)]
     F = importlib.import_module(PKG + ".net.fast_infer")

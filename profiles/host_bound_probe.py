@@ -4,11 +4,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 PKG = "3d_adapt_auto_driving_amd"
 C = importlib.import_module(PKG + ".config"); E = importlib.import_module(PKG + ".eval_rcnn"); synth = importlib.import_module(PKG + ".synth")
 dev = torch.device("cuda", 0); cfg = C.default_eval_cfg(); model = E.build_model(cfg, dev, seed=0)
-batches = [torch.from_numpy(synth.scenes(8, 16384, seed0=s * 8)).to(dev) for s in range(4)]
+batches = [torch.from_numpy(synth.scenes(8, 16384, seed0=s * 8)).to(dev) for s in range(6)]
 runner = E.PipelinedRunner(model, cfg, dev)
 def loop(n):
     for i in range(n):
-        runner.submit(batches[i % 4], [batches[(i + d) % 4] for d in (1, 2)])
+        runner.submit(batches[i % 6], [batches[(i + d) % 6] for d in range(1, runner.depth + 1)])
     runner.flush()
 loop(12); torch.cuda.synchronize()
 K = 60
