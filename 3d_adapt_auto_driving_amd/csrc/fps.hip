@@ -69,6 +69,54 @@ __device__ __forceinline__ void wave_argmax(float &v, uint32_t &key)
     key = rk;
 }
 
+// ---- two-pass arg-max: first the maximum VALUE (one v_max_f32 per candidate, one per DPP step), then the smallest key
+// among the candidates that hold it (compare + select + v_min_u32).  Same total order as take_if_better -- larger value
+// first, ties to the smaller key -- with a third of the instructions and much shorter dependency chains.
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v)
+{
+    return fmaxf(v, __int_as_float(dpp_mov<CTRL>(__float_as_int(v))));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_min(uint32_t v)
+{
+    const uint32_t o = (uint32_t)dpp_mov<CTRL>((int)v);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ float wave_max_f32(float v)        // wave-uniform result
+{
+    v = dpp_max<0xB1>(v); v = dpp_max<0x4E>(v); v = dpp_max<0x141>(v); v = dpp_max<0x140>(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)  // wave-uniform result
+{
+    v = dpp_min<0xB1>(v); v = dpp_min<0x4E>(v); v = dpp_min<0x141>(v); v = dpp_min<0x140>(v);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+    return a < b ? a : b;
+}
+// (value, key) of a wave as ONE unsigned 64-bit word whose integer order is the arg-max order: the value's bits made
+// monotone (negative floats flipped, positive ones offset), the key complemented so that the smaller key is the larger
+// word.  The workgroup's winner is then a single LDS atomic max per wave instead of an exchange + a 16-entry reduction.
+__device__ __forceinline__ unsigned long long pack_candidate(float v, uint32_t key)
+{
+    const uint32_t b = (uint32_t)__float_as_int(v);
+    const uint32_t mono = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ((unsigned long long)mono << 32) | (unsigned long long)(~key);
+}
+__device__ __forceinline__ void unpack_candidate(unsigned long long w, float &v, uint32_t &key)
+{
+    const uint32_t mono = (uint32_t)(w >> 32);
+    const uint32_t b = (mono & 0x80000000u) ? (mono & 0x7fffffffu) : ~mono;
+    v = __int_as_float((int)b);
+    key = ~(uint32_t)w;
+}
+
 struct KeyCodec {
     int log2bs;  // virtual block = 1 << log2bs
     int sh;      // bits reserved for k >> log2bs
@@ -95,9 +143,7 @@ __global__ __launch_bounds__(64 * WAVES) void fps_reg_kernel(
     int *__restrict__ idx)
 {
     constexpr int T = 64 * WAVES;
-    __shared__ float s_v[2][16];
-    __shared__ uint32_t s_k[2][16];
-
+    __shared__ unsigned long long s_best[3];
     const int b = blockIdx.x;
     const float *__restrict__ cloud = xyz + (long)b * n * 3;
     float *__restrict__ mind = temp + (long)b * n;
@@ -120,42 +166,39 @@ __global__ __launch_bounds__(64 * WAVES) void fps_reg_kernel(
             pk[i] = 0xffffffffu;
         }
     }
-    if (WAVES > 1 && t < 32) {  // unused exchange slots must lose every comparison
-        (&s_v[0][0])[t] = -INFINITY;
-        (&s_k[0][0])[t] = 0xffffffffu;
-    }
+    if (WAVES > 1 && t < 3) s_best[t] = 0ull;
     if (WAVES > 1) __syncthreads();
 
     int old = 0;
     if (t == 0) sel[0] = 0;
     for (int j = 1; j < m; ++j) {
         const float ox = cloud[3 * old], oy = cloud[3 * old + 1], oz = cloud[3 * old + 2];
-        float bv = -1.0f;
-        uint32_t bkey = 0xffffffffu;
+        float lv = -INFINITY;
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             const float d = sqdist3(px[i], py[i], pz[i], ox, oy, oz);
             const float d2 = fminf(d, pt[i]);  // min(d, temp[k]) of sampling_gpu.cu:134
             pt[i] = d2;
-            if (ORDERED) {
-                const bool tk = d2 > bv;
-                bv = tk ? d2 : bv;
-                bkey = tk ? pk[i] : bkey;
-            } else {
-                take_if_better(d2, pk[i], bv, bkey);
-            }
+            lv = fmaxf(lv, d2);
         }
-        wave_argmax(bv, bkey);
+        float bv = wave_max_f32(lv);
+        uint32_t lk = 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const uint32_t c = pt[i] == bv ? pk[i] : 0xffffffffu;
+            lk = c < lk ? c : lk;
+        }
+        uint32_t bkey = wave_min_u32(lk);
         if (WAVES > 1) {
-            const int buf = j & 1;
-            if ((t & 63) == 0) { s_v[buf][t >> 6] = bv; s_k[buf][t >> 6] = bkey; }
-            __syncthreads();
-            bv = s_v[buf][t & 15];
-            bkey = s_k[buf][t & 15];
-            row16_argmax(bv, bkey);
+            const int buf = j % 3;
+            if ((t & 63) == 0) atomicMax(&s_best[buf], pack_candidate(bv, bkey));
+            lds_barrier();     // orders LDS only: __syncthreads() would also drain wave 0's store of sel[j-1] every iteration
+            const unsigned long long best = s_best[buf];
+            if (t == 0) s_best[(j + 2) % 3] = 0ull;     // the slot of iteration j-1: every wave has read it (barrier j), next used at j+2
+            unpack_candidate(best, bv, bkey);
         }
         // no candidate beat the reference's initial (-1, index 0): it would return 0
-        old = (bkey == 0xffffffffu) ? 0 : kc.decode(bkey);
+        old = (bkey == 0xffffffffu || !(bv > -1.0f)) ? 0 : kc.decode(bkey);
         old = __builtin_amdgcn_readfirstlane(old);
         if (t == 0) sel[j] = old;
     }
@@ -250,8 +293,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(
     int n, int m, KeyCodec kc, const float *__restrict__ xyz, const int *__restrict__ perm,
     float *__restrict__ temp, int *__restrict__ idx)
 {
-    __shared__ float s_v[2][16];
-    __shared__ uint32_t s_k[2][16];
+    __shared__ unsigned long long s_best[3];
     const int b = blockIdx.x;
     const float *__restrict__ cloud = xyz + (long)b * n * 3;
     const int *__restrict__ order = perm + (long)b * n;
@@ -293,10 +335,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(
         }
         if (lane == i) { bx0 = x0; bx1 = x1; by0 = y0; by1 = y1; bz0 = z0; bz1 = z1; }
     }
-    if (t < 32) {
-        (&s_v[0][0])[t] = -INFINITY;
-        (&s_k[0][0])[t] = 0xffffffffu;
-    }
+    if (t < 3) s_best[t] = 0ull;
     __syncthreads();
 
     int old = 0;
@@ -320,21 +359,28 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(
                     const float d = sqdist3(px[i], py[i], pz[i], ox, oy, oz);
                     pt[i] = fminf(d, pt[i]);
                 }
-            float bv = -1.0f;
-            uint32_t bkey = 0xffffffffu;
+            float lv = pt[0];
 #pragma unroll
-            for (int i = 0; i < PPT; ++i) take_if_better(pt[i], pk[i], bv, bkey);
-            wave_argmax(bv, bkey);
-            wbv = bv; wkey = bkey;
+            for (int i = 1; i < PPT; ++i) lv = fmaxf(lv, pt[i]);
+            wbv = wave_max_f32(lv);
+            uint32_t lk = 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const uint32_t c = pt[i] == wbv ? pk[i] : 0xffffffffu;
+                lk = c < lk ? c : lk;
+            }
+            wkey = wave_min_u32(lk);
         }
-        const int buf = j & 1;
-        if (lane == 0) { s_v[buf][w] = wbv; s_k[buf][w] = wkey; }
-        __syncthreads();
-        float bv = s_v[buf][t & 15];
-        uint32_t bkey = s_k[buf][t & 15];
-        row16_argmax(bv, bkey);
+        const int buf = j % 3;
+        if (lane == 0) atomicMax(&s_best[buf], pack_candidate(wbv, wkey));
+        lds_barrier();         // orders LDS only: __syncthreads() would also drain wave 0's store of sel[j-1] every iteration
+        const unsigned long long best = s_best[buf];
+        if (t == 0) s_best[(j + 2) % 3] = 0ull;        // the slot of iteration j-1: read by every wave before barrier j, next used at j+2
+        float bv;
+        uint32_t bkey;
+        unpack_candidate(best, bv, bkey);
         vmax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bv)));
-        old = (bkey == 0xffffffffu) ? 0 : kc.decode(bkey);
+        old = (bkey == 0xffffffffu || !(bv > -1.0f)) ? 0 : kc.decode(bkey);
         old = __builtin_amdgcn_readfirstlane(old);
         if (t == 0) sel[j] = old;
     }
