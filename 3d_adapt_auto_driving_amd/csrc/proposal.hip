@@ -34,8 +34,8 @@ __device__ __forceinline__ int argmax_row(const float *p, int n)
 {
     int best = 0;
     float bv = p[0];
-    for (int i = 1; i < n; ++i)
-        if (p[i] > bv) { bv = p[i]; best = i; }   // first maximum, as torch.argmax on distinct values
+    for (int i = 1; i < n; ++i)                    // first maximum; a NaN counts as the largest value (torch.argmax)
+        if (p[i] > bv || (p[i] != p[i] && bv == bv)) { bv = p[i]; best = i; }
     return best;
 }
 
@@ -92,6 +92,7 @@ __device__ __forceinline__ unsigned long long sort_key(float score, unsigned idx
 {
     unsigned u = __float_as_uint(score);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-order image of the float
+    if (score != score) u = 0xffffffffu;              // NaN of either sign sorts FIRST, as in torch.sort(descending=True)
     return ((unsigned long long)(~u) << 32) | idx;     // inverted: larger score sorts first
 }
 

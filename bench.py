@@ -355,7 +355,7 @@ def main():
     # ---- context for the headline (rank 0, untimed): how many grouped rows are distinct on this data, and the same step
     # with every nsample row evaluated (the reference's way)
     distinct, all_rows = None, None
-    if rank == 0 and not args.no_roofline:
+    if world == 1 and not args.no_roofline:      # (N = 1 only: these legs call the timed loop, which holds rank barriers)
         pu = importlib.import_module(PKG + ".pointnet2.pointnet2_utils")
         real_pack, seen = pu.pointnet2.ball_pack_wrapper, []
 

@@ -198,6 +198,47 @@ def test_full_size_gpu_vs_cpu_oracle_boxes(oracle):
     assert nc >= 3 and matched >= 0.8 * nc and worst < 1e-3, (worst, matched, nc, ng)
 
 
+def test_full_size_batch8_engine_gpu_vs_engine_on_cpu_oracle_every_box():
+    """BASELINE configs[2] at its batch of 8, default.yaml shapes: the ENGINE on the GPU against the SAME engine code on CPU
+    tensors with the oracle as operator backend (oracle/ext_cpu.py: scalar C restatements; the MLP kernels in their fixed
+    fma-chain order).  Every operator this build owns is bit-exact against that backend (tests/test_gpu_shadow.py), so what
+    is left between the two runs is (a) the seven library GEMMs whose K or N is not a multiple of 128 (FP level 1, the last
+    head layers, the K = 96 per-point part of RPN SA2: hipBLASLt vs MKL summation order), (b) torch's elementwise glue
+    (sigmoid, norm, reciprocal) and (c) f32 sin / cos of two libraries in the decoders.  The bar of BASELINE.json's north
+    star, for EVERY box: 100 % of the RoIs and 100 % of the final boxes matched one to one, within 1e-4; equal counts."""
+    from oracle import ext_cpu
+    C, E, F, S = pkg("config"), pkg("eval_rcnn"), pkg("net.fast_infer"), pkg("synth")
+    cfg = C.default_eval_cfg()
+    model_c = E.build_model(cfg, "cpu", seed=3)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for name, p in model_c.named_parameters():
+            if ("reg_layer" in name or "cls_layer" in name) and p.dim() > 1:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+        model_c.rcnn_net.cls_layer[-1].conv.weight.mul_(0.05)
+        model_c.rcnn_net.cls_layer[-1].conv.bias.fill_(0.5)
+    model_g = E.build_model(cfg, DEV, seed=3)
+    model_g.load_state_dict(model_c.state_dict())
+    B = 8
+    pts = torch.from_numpy(S.scenes(B, 16384, seed0=77))
+    with ext_cpu.patch_package():
+        dc = E.infer_batch(model_c, cfg, pts, engine=F.FastPointRCNN(model_c, cfg))
+    dg = E.infer_batch(model_g, cfg, pts.to(DEV), engine=F.FastPointRCNN(model_g, cfg))
+    assert torch.equal(dg["num"].cpu(), dc["num"]) and int(dc["num"].min()) >= 3
+    assert float((dg["rois"].cpu() - dc["rois"]).abs().max()) <= 1e-4            # same RoIs in the same ORDER
+    assert float((dg["rcnn_cls"].cpu() - dc["rcnn_cls"]).abs().max()) <= 1e-4
+    worst_all = 0.0
+    for b in range(B):
+        n = int(dc["num"][b])
+        worst, matched = match_boxes(dg["boxes"][b, :n].cpu().numpy(), dc["boxes"][b, :n].numpy())
+        assert matched == n, (b, matched, n)
+        worst_all = max(worst_all, worst)
+        assert float((dg["boxes"][b, :n].cpu() - dc["boxes"][b, :n]).abs().max()) <= 1e-4   # ... and the same final order
+        assert float((dg["scores"][b, :n].cpu() - dc["scores"][b, :n]).abs().max()) <= 1e-4
+    assert worst_all <= 1e-4
+    print("batch 8: %d final boxes, all matched, worst |d| = %.3g" % (int(dc["num"].sum()), worst_all))
+
+
 def test_full_size_engine_is_complete_deterministic_and_equals_module_path():
     """default.yaml shapes, batch of 2: the point-major engine (fused MFMA / VALU kernels, ticket scheduling, all
     extension entry points) against the nn.Module graph on the same device and weights.
@@ -312,6 +353,37 @@ def test_pipelined_runner_full_size_many_steps_equals_serial():
         ref = serial[i % 4]
         for k in ("rois", "boxes", "scores", "num"):
             assert torch.equal(det[k], ref[k]), (i, k)
+
+
+def test_fused_proposal_sort_order_with_ties_and_nans(ext):
+    """score_sort_kernel's total order = (score descending, NaN first, index ascending on ties) == torch's STABLE descending
+    sort; argmax over regression bins treats NaN as the largest value like torch.argmax.  Exercised through the fused
+    proposal entry with every point in the near band and NMS threshold 1 (nothing suppressed): the RoIs come out in
+    exactly that order."""
+    rng = np.random.default_rng(3)
+    B, N = 2, 4096
+    xyz = torch.from_numpy(rng.uniform([-30, 0, 5], [30, 2, 35], (B, N, 3)).astype(np.float32)).to(DEV)
+    scores = torch.from_numpy(rng.integers(-3, 4, (B, N)).astype(np.float32)).to(DEV)       # heavy ties
+    scores[0, 17] = float("nan"); scores[1, 5] = float("nan"); scores[1, 900] = -float("nan")
+    C = pkg("config")
+    cfg = C.default_eval_cfg()
+    nb = int(cfg.RPN.LOC_SCOPE / cfg.RPN.LOC_BIN_SIZE) * 2
+    ch = nb * 4 + 1 + cfg.RPN.NUM_HEAD_BIN * 2 + 3
+    reg = torch.from_numpy(rng.standard_normal((B, N, ch)).astype(np.float32)).to(DEV)
+    M = 100
+    rois = torch.empty((B, M, 7), device=DEV); rs = torch.empty((B, M), device=DEV)
+    anchor = [float(v) for v in np.asarray(cfg.CLS_MEAN_SIZE[0], dtype=np.float32)]
+    ext.iou3d.rpn_proposals(xyz, scores, reg, anchor, cfg.RPN.LOC_SCOPE, cfg.RPN.LOC_BIN_SIZE, cfg.RPN.NUM_HEAD_BIN, True,
+                            9000, M, 1.0, False, rois, rs)
+    key = torch.where(torch.isnan(scores), torch.full_like(scores, float("inf")), scores)
+    order = torch.sort(key, dim=1, descending=True, stable=True).indices
+    for b in range(B):
+        near = order[b][(xyz[b, order[b], 2] <= 40.0)][:70]          # every point is in the near band here
+        got = rs[b, :70]
+        want = scores[b, near]
+        assert torch.equal(torch.isnan(got), torch.isnan(want))
+        assert torch.equal(got[~torch.isnan(got)], want[~torch.isnan(want)])
+        assert bool(torch.isnan(got[0]))                                # the NaN scores lead
 
 
 def test_postprocess_batched_equals_per_scene_reference_order():
