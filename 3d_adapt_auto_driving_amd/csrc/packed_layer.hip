@@ -56,7 +56,7 @@ template <bool SEGMAX>
 __global__ __launch_bounds__(256, 2) void packed_layer_kernel(
     const unsigned int *__restrict__ hdr, long rows_host, int K, int N, const float *__restrict__ A, long lda,
     const float *__restrict__ W, const float *__restrict__ bias, int do_relu, float *__restrict__ out, long ldo,
-    const unsigned int *__restrict__ rowinfo, const int *__restrict__ tilecloud, int m, int out_col)
+    const unsigned int *__restrict__ rowinfo, const int *__restrict__ tilecloud, int m, int out_col, int n_store)
 {
     __shared__ float tile[PL_ROWS * PL_LD];
     __shared__ int ctr[PL_ROWS];
@@ -121,16 +121,65 @@ __global__ __launch_bounds__(256, 2) void packed_layer_kernel(
         for (int i = 0; i < 8; ++i) {
             const int row = r0 + 8 * i;
             const long g = t * PL_ROWS + row;
-            if (g < rows)
-                *reinterpret_cast<float4 *>(out + g * ldo + n0 + 4 * chunk) =
-                    *reinterpret_cast<const float4 *>(tile + row * PL_LD + 4 * chunk);
+            if (g < rows) {
+                // n_store < N: only the first n_store columns exist in `out` (a head's last layer: N padded to 128 for the
+                // MFMA tiles, 1 / 46 / 76 real outputs); 16-byte stores when the row layout allows them
+                const int c0 = n0 + 4 * chunk;
+                const float4 v = *reinterpret_cast<const float4 *>(tile + row * PL_LD + 4 * chunk);
+                if (c0 + 4 <= n_store && (ldo & 3) == 0) {
+                    *reinterpret_cast<float4 *>(out + g * ldo + c0) = v;
+                } else {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c0 + q < n_store) out[g * ldo + c0 + q] = e[q];
+                }
+            }
         }
     }
+}
+
+// out[r][0..n) = A[r][0..K) @ W + bias for n <= 4 output columns (the 1-wide last layer of the classification heads): a
+// GEMV per output, no MFMA tile to fill.  32 lanes per row: lane l accumulates k = l, l + 32, ... as one fma chain (from 0),
+// the 32 partial sums are added in an xor butterfly (16, 8, 4, 2, 1), then the bias.  oracle/mlp_oracle.c orc_rows_dot
+// restates that order.
+__global__ __launch_bounds__(256) void rows_dot_kernel(long rows, int K, int n, const float *__restrict__ A, long lda,
+                                                       const float *__restrict__ W, const float *__restrict__ bias,
+                                                       float *__restrict__ out, long ldo)
+{
+    const long r = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int l = threadIdx.x & 31;
+    const long rr = r < rows ? r : rows - 1;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = l; k < K; k += 32) {
+        const float a = A[rr * lda + k];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < n) acc[c] = fmaf(a, W[(long)k * n + c], acc[c]);
+    }
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __fadd_rn(acc[c], __shfl_xor(acc[c], d, 32));
+    if (l == 0 && r < rows)
+        for (int c = 0; c < n; ++c) out[r * ldo + c] = __fadd_rn(acc[c], bias[c]);
 }
 
 }  // namespace prcnn
 
 using namespace prcnn;
+
+extern "C" int prcnn_rows_dot(long rows, int K, int n, const float *A, long lda, const float *W, const float *bias, float *out,
+                              long ldo, void *stream)
+{
+    PRCNN_REQUIRE(rows >= 0 && K > 0 && n >= 1 && n <= 4 && lda >= K && ldo >= n, "rows_dot: bad sizes (n <= 4)");
+    if (rows == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(A && W && bias && out, "rows_dot: null pointer");
+    PRCNN_REQUIRE((rows + 7) / 8 <= 0x7fffffffL, "rows_dot: too many rows");
+    hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, rows, K, n, A, lda, W,
+                       bias, out, ldo);
+    return check_launch("rows_dot");
+}
 
 // A1 (max_tiles*64, c1) = relu(P[point] + wxyz . rowdxyz) for every packed row (prcnn_ball_pack: rowdxyz = xyz[point] - centre);
 // P (b,n,c1), wxyz (3,c1), c1 % 4 == 0.
@@ -148,20 +197,23 @@ extern "C" int prcnn_packed_gather_affine(int b, int n, int c1, long max_tiles, 
     return check_launch("packed_gather_affine");
 }
 
-// out[r][0..N) = act(A[r][0..K) @ W + bias), K and N multiples of 128, W (K,N) k-major.  Row count: hdr != NULL ->
+// out[r][0..n_store) = act(A[r][0..K) @ W + bias)[0..n_store), K and N multiples of 128, W (K,N) k-major, n_store <= N (the
+// caller pads a narrow last layer's weights to N = 128 and asks for its real width).  Row count: hdr != NULL ->
 // hdr[0] * 64 rows (a packed list; max_tiles sizes the grid), else `rows` (host count; max_tiles ignored).
-extern "C" int prcnn_packed_layer(const unsigned int *hdr, long rows, long max_tiles, int K, int N, const float *A, long lda,
-                                  const float *W, const float *bias, int relu, float *out, long ldo, void *stream)
+extern "C" int prcnn_packed_layer(const unsigned int *hdr, long rows, long max_tiles, int K, int N, int n_store, const float *A,
+                                  long lda, const float *W, const float *bias, int relu, float *out, long ldo, void *stream)
 {
     PRCNN_REQUIRE(K > 0 && N > 0 && K % 128 == 0 && N % 128 == 0, "packed_layer: K=%d, N=%d must be multiples of 128", K, N);
-    PRCNN_REQUIRE(lda >= K && ldo >= N && lda % 4 == 0 && ldo % 4 == 0, "packed_layer: bad leading dimensions");
+    PRCNN_REQUIRE(n_store >= 1 && n_store <= N, "packed_layer: n_store=%d outside 1..N", n_store);
+    PRCNN_REQUIRE(lda >= K && ldo >= n_store && lda % 4 == 0, "packed_layer: bad leading dimensions");
     const long tiles = hdr ? max_tiles : (rows + PL_ROWS - 1) / PL_ROWS;
     PRCNN_REQUIRE(tiles >= 0 && tiles <= 0x7fffffffL && rows >= 0, "packed_layer: bad row count");
     if (tiles == 0) return PRCNN_OK;
     PRCNN_REQUIRE(A && W && bias && out, "packed_layer: null pointer");
-    PRCNN_REQUIRE((((uintptr_t)A | (uintptr_t)out) & 15) == 0, "packed_layer: 16-byte alignment required");
-    hipLaunchKernelGGL(packed_layer_kernel<false>, dim3((unsigned)tiles, N / 128), dim3(256), 0, (hipStream_t)stream, hdr, rows, K, N,
-                       A, lda, W, bias, relu, out, ldo, nullptr, nullptr, 0, 0);
+    PRCNN_REQUIRE(((uintptr_t)A & 15) == 0 && (((uintptr_t)out & 15) == 0 || (ldo & 3) != 0), "packed_layer: 16-byte alignment required");
+    const int col_blocks = (n_store + 127) / 128;          // column blocks that hold nothing to store are not launched
+    hipLaunchKernelGGL(packed_layer_kernel<false>, dim3((unsigned)tiles, col_blocks), dim3(256), 0, (hipStream_t)stream, hdr, rows, K, N,
+                       A, lda, W, bias, relu, out, ldo, nullptr, nullptr, 0, 0, n_store);
     return check_launch("packed_layer");
 }
 
@@ -184,6 +236,6 @@ extern "C" int prcnn_packed_layer_segmax(int b, int m, long max_tiles, int K, in
     }
     if (max_tiles == 0) return PRCNN_OK;
     hipLaunchKernelGGL(packed_layer_kernel<true>, dim3((unsigned)max_tiles, N / 128), dim3(256), 0, st, hdr, 0L, K, N, A, lda, W, bias,
-                       1, out, (long)out_stride, rowinfo, tilecloud, m, out_col);
+                       1, out, (long)out_stride, rowinfo, tilecloud, m, out_col, N);
     return check_launch("packed_layer_segmax");
 }

@@ -231,7 +231,7 @@ def packed_gather_affine_wrapper(new_xyz, xyz, P, wxyz, pack, out):
 
 
 def packed_layer_wrapper(a, wt, bias, relu, out, pack=None):
-    """out = act(a @ wt + bias), a (R, K) / wt (K, N) / out (R, N) with K, N multiples of 128 (csrc/packed_layer.hip).
+    """out = act(a @ wt + bias)[:, :out.size(1)], a (R, K) / wt (K, N) / out (R, <= N) with K, N multiples of 128 (csrc/packed_layer.hip).
     pack given: only the first pack.hdr[0]*64 rows (a packed row list, count on the device); else all R rows."""
     _chk(torch.float32, wt, bias)
     for t in (a, out):
@@ -239,11 +239,22 @@ def packed_layer_wrapper(a, wt, bias, relu, out, pack=None):
             raise RuntimeError("pointnet2_cuda: packed_layer expects 2-D float32 CUDA matrices with unit column stride")
     R, K = a.shape
     N = wt.size(1)
-    if wt.size(0) != K or out.size(0) != R or out.size(1) != N:
+    n_store = out.size(1)                     # <= N: a narrow last layer whose weights were zero-padded to N
+    if wt.size(0) != K or out.size(0) != R or n_store > N:
         raise RuntimeError("pointnet2_cuda: packed_layer shape mismatch")
     _lib.call("prcnn_packed_layer", None if pack is None else pack.hdr.data_ptr(), R, 0 if pack is None else pack.max_tiles,
-              K, N, a.data_ptr(), a.stride(0), wt.data_ptr(), bias.data_ptr(), int(bool(relu)), out.data_ptr(), out.stride(0),
+              K, N, n_store, a.data_ptr(), a.stride(0), wt.data_ptr(), bias.data_ptr(), int(bool(relu)), out.data_ptr(), out.stride(0),
               _lib.current_stream(a))
+    return out
+
+
+def rows_dot_wrapper(a, wt, bias, out):
+    """out (R, n) = a (R, K) @ wt (K, n) + bias for n <= 4 (a classification head's last layer) -- csrc/packed_layer.hip."""
+    _chk(torch.float32, wt, bias)
+    if a.dim() != 2 or a.stride(1) != 1 or out.stride(1) != 1 or not a.is_cuda:
+        raise RuntimeError("pointnet2_cuda: rows_dot expects 2-D float32 CUDA matrices with unit column stride")
+    _lib.call("prcnn_rows_dot", a.size(0), a.size(1), wt.size(1), a.data_ptr(), a.stride(0), wt.data_ptr(), bias.data_ptr(),
+              out.data_ptr(), out.stride(0), _lib.current_stream(a))
     return out
 
 

@@ -39,6 +39,9 @@ USE_PACKED = os.environ.get("PRCNN_NO_PACK") is None
 # RCNN entrance chain and SA1 run over the DISTINCT pooled points only (bit-identical results).  PRCNN_NO_POOL_DEDUP=1: A/B.
 USE_POOL_DEDUP = os.environ.get("PRCNN_NO_POOL_DEDUP") is None
 USE_POINT_LAYER = os.environ.get("PRCNN_LIB_GEMM") is None     # per-point layers (FP modules, heads) on the own MFMA layer kernel
+# every per-point width zero-padded to a multiple of 128 (SA level outputs, FP inputs, narrow head outputs), so that NO layer
+# of the engine is left to a GEMM library: fixed summation order everywhere, reproduced bit for bit by the oracle
+PAD128 = USE_PACKED and USE_POINT_LAYER
 
 
 def _round4(c):
@@ -82,25 +85,54 @@ def gemm_bias_act(a, wt, bias, relu):
     return torch.addmm(bias, a, wt)
 
 
-def point_layer(a, wt, bias, relu):
-    """act(a @ wt + bias) for a per-point (row-major) matrix: the tiled MFMA layer kernel of csrc/packed_layer.hip when
-    K and N are multiples of 128 (fixed summation order, reproduced bit for bit by the oracle), else a library GEMM."""
+def point_layer(a, wt, bias, relu, n_out=None):
+    """act(a @ wt + bias)[:, :n_out] for a per-point (row-major) matrix: the tiled MFMA layer kernel of
+    csrc/packed_layer.hip when K and N are multiples of 128 (fixed summation order, reproduced bit for bit by the oracle),
+    else a library GEMM.  n_out < N: the weights of a narrow last layer were zero-padded to N."""
     K, N = wt.shape
+    n_out = N if n_out is None else n_out
     if (USE_PACKED and K % 128 == 0 and N % 128 == 0 and a.dim() == 2 and a.shape[1] == K and a.stride(1) == 1
             and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0):
-        out = torch.empty((a.shape[0], N), dtype=torch.float32, device=a.device)
+        out = torch.empty((a.shape[0], n_out), dtype=torch.float32, device=a.device)
         return pu.pointnet2.packed_layer_wrapper(a, wt, bias, relu, out)
-    return gemm_bias_act(a, wt, bias, relu)
+    y = gemm_bias_act(a, wt, bias, relu)
+    return y if n_out == N else y[:, :n_out].contiguous()
 
 
 class _Mlp:
     """Folded weights of one SharedMLP / Conv1d chain in (K, Cout) form."""
 
-    def __init__(self, layers, grouped_c=None):
+    def __init__(self, layers, grouped_c=None, pad128=False, in_parts=None, pad_out=False):
         """layers: [(w (Cout,Cin), b (Cout), relu)].  grouped_c: if not None the first layer
         consumes a grouped row [features(grouped_c) | pad | xyz | 0] whereas the module's weight
-        columns are [xyz(3) | features]."""
+        columns are [xyz(3) | features].  pad128 (per-point chains): every K and N zero-padded to a multiple of 128 -- inputs
+        then carry zero columns up to the padded K, ``n_out`` is the real width of the last layer."""
         self.layers = []
+        self.n_out = layers[-1][0].shape[0]
+        if pad128 and grouped_c is None:
+            for i, (w, b, relu) in enumerate(layers):
+                np_ = _round128(w.shape[0])
+                if i == 0 and in_parts:
+                    # the input is a concatenation of tensors that are EACH padded to 128s (FP modules: [interpolated |
+                    # skip]): the weight rows of every part go where that part starts, zero rows in between
+                    assert sum(in_parts) == w.shape[1]
+                    wt = w.new_zeros((sum(_round128(c) for c in in_parts), np_))
+                    src = dst = 0
+                    for c in in_parts:
+                        wt[dst:dst + c, :w.shape[0]] = w[:, src:src + c].t()
+                        src, dst = src + c, dst + _round128(c)
+                else:
+                    wt = _pad2(w.t(), _round128(w.shape[1]), np_)
+                self.layers.append((wt.contiguous(), _pad1(b, np_), relu))
+            self.split = self.packed = self.wide = None
+            self.padded = not pad_out          # pad_out: the last layer's output keeps its zero columns (feeds another chain)
+            # a 1-wide (<= 4) last layer without ReLU is a GEMV per output: its own small kernel instead of a 128-wide MFMA tile
+            self.narrow = None
+            w, b, relu = layers[-1]
+            if self.padded and w.shape[0] <= 4 and not relu:
+                self.narrow = (_pad2(w.t(), _round128(w.shape[1]), w.shape[0]), b.contiguous())
+            return
+        self.padded = False
         for i, (w, b, relu) in enumerate(layers):
             if i == 0 and grouped_c is not None:
                 c, c4 = grouped_c, _round4(grouped_c)
@@ -127,18 +159,26 @@ class _Mlp:
             wf, wx, b1 = self.split
             (w2, b2, _), (w3, b3, _) = self.layers[1], self.layers[2]
             c1, c2, c3 = wf.shape[1], w2.shape[1], w3.shape[1]
+            kin = _round128(wf.shape[0]) if PAD128 else wf.shape[0]      # the feature tensor arrives padded to 128s
             if c1 <= 128 and c2 <= 128 and c3 in (128, 256) and w2.shape[0] == c1 and w3.shape[0] == c2:
-                self.packed = (_pad2(wf, wf.shape[0], 128), _pad2(wx, 3, 128), _pad1(b1, 128),
+                self.packed = (_pad2(wf, kin, 128), _pad2(wx, 3, 128), _pad1(b1, 128),
                                _pad2(w2, 128, 128), _pad1(b2, 128), _pad2(w3, 128, c3), b3)
             elif c3 % 128 == 0 and w2.shape[0] == c1 and w3.shape[0] == c2:
                 # wider levels: layer by layer over the packed rows (csrc/packed_layer.hip), widths padded to 128s
                 c1p, c2p = _round128(c1), _round128(c2)
-                self.wide = (_pad2(wf, wf.shape[0], c1p), _pad2(wx, 3, c1p), _pad1(b1, c1p),
+                self.wide = (_pad2(wf, kin, c1p), _pad2(wx, 3, c1p), _pad1(b1, c1p),
                              _pad2(w2, c1p, c2p), _pad1(b2, c2p), _pad2(w3, c2p, c3), b3)
 
     def __call__(self, a, start=0):
-        for wt, b, relu in self.layers[start:]:
-            a = point_layer(a, wt, b, relu) if USE_POINT_LAYER else gemm_bias_act(a, wt, b, relu)
+        last = len(self.layers) - 1
+        for i, (wt, b, relu) in enumerate(self.layers[start:], start):
+            if USE_POINT_LAYER and i == last and getattr(self, "narrow", None) is not None and a.stride(1) == 1:
+                out = torch.empty((a.shape[0], self.n_out), dtype=torch.float32, device=a.device)
+                a = pu.pointnet2.rows_dot_wrapper(a, self.narrow[0], self.narrow[1], out)
+            elif USE_POINT_LAYER:
+                a = point_layer(a, wt, b, relu, self.n_out if (self.padded and i == last) else None)
+            else:
+                a = gemm_bias_act(a, wt, b, relu)
         return a
 
 
@@ -192,9 +232,16 @@ class FastPointRCNN:
                 cin = mlp[0].conv.in_channels - 3
                 scales.append((grouper.radius, grouper.nsample, _Mlp(_fold_shared_mlp(mlp), grouped_c=cin), cin))
             self.sa.append((sa.npoint, scales))
-        self.fp = [_Mlp(_fold_shared_mlp(fp.mlp)) for fp in bb.FP_modules]
-        self.rpn_cls = _Mlp(_fold_head(rpn.rpn_cls_layer))
-        self.rpn_reg = _Mlp(_fold_head(rpn.rpn_reg_layer))
+        # FP module k consumes [features interpolated from level k+1 | skip features of level k]
+        sa_w = [sum(sc[2].n_out for sc in scales) for _, scales in self.sa]
+        folded = [_fold_shared_mlp(fp.mlp) for fp in bb.FP_modules]
+        self.fp = []
+        for k, lay in enumerate(folded):
+            known = sa_w[-1] if k == len(folded) - 1 else folded[k + 1][-1][0].shape[0]
+            skip = 0 if k == 0 else sa_w[k - 1]
+            self.fp.append(_Mlp(lay, pad128=PAD128, in_parts=[c for c in (known, skip) if c], pad_out=True))
+        self.rpn_cls = _Mlp(_fold_head(rpn.rpn_cls_layer), pad128=PAD128)
+        self.rpn_reg = _Mlp(_fold_head(rpn.rpn_reg_layer), pad128=PAD128)
         if cfg.RCNN.ENABLED:
             r = model.rcnn_net
             self.xyz_up = _Mlp(_fold_shared_mlp(r.xyz_up_layer))
@@ -206,8 +253,8 @@ class FastPointRCNN:
                 g = sa.groupers[0]
                 self.rcnn_sa.append((sa.npoint, getattr(g, "radius", None), getattr(g, "nsample", None),
                                      _Mlp(_fold_shared_mlp(mlp), grouped_c=cin), cin))
-            self.rcnn_cls = _Mlp(_fold_head(r.cls_layer))
-            self.rcnn_reg = _Mlp(_fold_head(r.reg_layer))
+            self.rcnn_cls = _Mlp(_fold_head(r.cls_layer), pad128=PAD128)
+            self.rcnn_reg = _Mlp(_fold_head(r.reg_layer), pad128=PAD128)
 
     def check_weights(self):
         """The engine folds BatchNorm into its own copies of the weights at construction.  Loading a checkpoint (or editing
@@ -295,14 +342,14 @@ class FastPointRCNN:
         if USE_PACKED and mlp.packed is not None:
             # whole scale in ONE hand-written MFMA kernel over the DISTINCT rows of every group (csrc/sa_packed.hip)
             wf, wx, b1, w2, b2, w3, b3 = mlp.packed
-            P = P_pre if P_pre is not None else gemm_bias_act(feats.view(B * N, cin), wf, b1, False).view(B, N, 128)
+            P = P_pre if P_pre is not None else point_layer(feats.view(B * N, feats.shape[2]), wf, b1, False).view(B, N, 128)
             pk = pack if pack is not None else ext.ball_pack_wrapper(idx, xyz, new_xyz)
             ext.sa_packed_mlp_wrapper(new_xyz, xyz, P, wx, pk, w2, b2, w3, b3, out, out_col)
             return
         if USE_PACKED and mlp.wide is not None:
             # wider level: the same distinct rows, layer by layer (gather+affine -> MFMA layer -> MFMA layer + segmented max)
             wf, wx, b1, w2, b2, w3, b3 = mlp.wide
-            P = point_layer(feats.view(B * N, cin), wf, b1, False).view(B, N, -1)
+            P = point_layer(feats.view(B * N, feats.shape[2]), wf, b1, False).view(B, N, -1)
             pk = pack if pack is not None else ext.ball_pack_wrapper(idx, xyz, new_xyz)
             rows = pk.max_tiles * 64
             a1 = torch.empty((rows, wf.shape[1]), dtype=torch.float32, device=xyz.device)
@@ -311,6 +358,10 @@ class FastPointRCNN:
             ext.packed_layer_wrapper(a1, w2, b2, True, y2, pk)
             ext.packed_layer_segmax_wrapper(y2, w3, b3, pk, B, M, out, out_col)
             return
+        # the formulations below are for scales the packed kernels do not cover (and for PRCNN_NO_PACK): they read the
+        # feature tensor in its true width
+        if feats is not None and feats.shape[2] != cin:
+            feats = feats[:, :, :cin].contiguous()
         if (mlp.split is not None and len(mlp.layers) == 3 and mlp.layers[1][2] and mlp.layers[2][2] and
                 ext.sa_mlp_fused_supported(mlp.split[0].shape[1], mlp.layers[1][0].shape[1],
                                            mlp.layers[2][0].shape[1], ns)):
@@ -346,7 +397,10 @@ class FastPointRCNN:
             cur_xyz, cur_feat = l_xyz[len(l_feat) - 1], l_feat[-1]
             B = cur_xyz.shape[0]
             width = sum(s[2].layers[-1][0].shape[1] for s in scales)
-            out = torch.empty((B, npoint, width), dtype=torch.float32, device=xyz.device)
+            wpad = _round128(width) if PAD128 else width          # consumers (next level's per-point part, FP skip) read 128s
+            out = torch.empty((B, npoint, wpad), dtype=torch.float32, device=xyz.device)
+            if wpad > width:
+                out[:, :, width:] = 0
             col = 0
             for (radius, ns, mlp, cin), idx, pack in zip(scales, lev["idx"], lev.get("pack") or [None] * len(scales)):
                 self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, idx, mlp, cin, out, col, pack=pack)
@@ -365,7 +419,7 @@ class FastPointRCNN:
             if c1:
                 buf[:, :, c2:] = skip
             l_feat[k] = self.fp[k](buf.view(B * n, c2 + c1)).view(B, n, -1)
-        return l_feat[0]                                       # (B, N, 128) point-major
+        return l_feat[0]                                       # (B, N, 128) point-major (zero-padded to 128s under PAD128)
 
     # ------------------------------------------------------------------ full forward
     @torch.no_grad()
@@ -383,6 +437,8 @@ class FastPointRCNN:
         flat = feats.view(B * N, -1)
         rpn_cls = self.rpn_cls(flat).view(B, N, -1)
         rpn_reg = self.rpn_reg(flat).view(B, N, -1)
+        if feats.shape[2] != self.fp[0].n_out:                # narrow configurations: drop the zero padding again
+            feats = feats[:, :, :self.fp[0].n_out].contiguous()
         out = {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": xyz, "rpn_features": feats}
         if cfg.RCNN.ENABLED:
             raw = rpn_cls[:, :, 0].contiguous()
@@ -522,6 +578,9 @@ class FastPointRCNN:
                 l_xyz.append(None)
             l_feat.append(out)
         top = l_feat[-1].view(l_feat[-1].shape[0], -1)                         # (B*M, 512)
+        kp = self.rcnn_cls.layers[0][0].shape[0]
+        if top.shape[1] != kp:                                                  # narrow configurations under PAD128
+            top = torch.nn.functional.pad(top, (0, kp - top.shape[1]))
         return {"rcnn_cls": self.rcnn_cls(top), "rcnn_reg": self.rcnn_reg(top)}
 
     __call__ = forward

@@ -160,15 +160,20 @@ int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, const float
  * RCNN GroupAll level 256-256-512) run layer by layer on the distinct rows only.  Widths are zero-padded to multiples of
  * 128 by the caller; W is (K,N) input-channel-major; f32 MFMA, fixed summation order (oracle/mlp_oracle.c).
  *   prcnn_packed_gather_affine: A1 (max_tiles*64, c1) = relu(P[point] + wxyz.(xyz[point] - centre))   (layer 1)
- *   prcnn_packed_layer:         out = act(A @ W + bias) over hdr[0]*64 rows (hdr != NULL) or `rows` rows (hdr == NULL:
+ *   prcnn_packed_layer:         out[:, 0..n_store) = act(A @ W + bias)[:, 0..n_store) (n_store <= N: a head's narrow last layer,
+ *                               weights zero-padded to N = 128) over hdr[0]*64 rows (hdr != NULL) or `rows` rows (hdr == NULL:
  *                               a plain row-major GEMM layer with a host-side row count, e.g. P = features @ W1f + b1)
  *   prcnn_packed_layer_segmax:  out[(b*m)][out_col..+N) = max over each centre's rows of relu(A @ W + bias)
  *                               (pointnet2_modules.py:37-53: last layer + max_pool2d) */
 int prcnn_packed_gather_affine(int b, int n, int c1, long max_tiles, const float *P, const float *wxyz,
                                const unsigned int *rowinfo, const float *rowdxyz, const int *tilecloud,
                                const unsigned int *hdr, float *out, void *stream);
-int prcnn_packed_layer(const unsigned int *hdr, long rows, long max_tiles, int K, int N, const float *A, long lda,
-                       const float *W, const float *bias, int relu, float *out, long ldo, void *stream);
+int prcnn_packed_layer(const unsigned int *hdr, long rows, long max_tiles, int K, int N, int n_store, const float *A,
+                       long lda, const float *W, const float *bias, int relu, float *out, long ldo, void *stream);
+/* out[r][0..n) = A[r] @ W + bias for n <= 4 outputs (the 1-wide last layer of the classification heads, rpn.py:36-50,
+ * rcnn_net.py:94-103): W (K,n) k-major; 32 lanes per row, fixed summation order (oracle: orc_rows_dot). */
+int prcnn_rows_dot(long rows, int K, int n, const float *A, long lda, const float *W, const float *bias, float *out,
+                   long ldo, void *stream);
 int prcnn_packed_layer_segmax(int b, int m, long max_tiles, int K, int N, const float *A, long lda, const float *W,
                               const float *bias, const unsigned int *rowinfo, const int *tilecloud,
                               const unsigned int *hdr, float *out, int out_stride, int out_col, void *stream);

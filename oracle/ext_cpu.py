@@ -160,8 +160,17 @@ class pointnet2_cpu:
     def packed_layer_wrapper(a, wt, bias, relu, out, pack=None):
         R = a.size(0) if pack is None else pack.idx.numel()
         assert a.stride(1) == 1 and out.stride(1) == 1 and wt.is_contiguous()
+        full = out if out.size(1) == wt.size(1) else torch.empty((out.size(0), wt.size(1)))     # narrow last layer: N padded
         O.lib().orc_rows_layer_mfma(C.c_long(R), a.size(1), wt.size(1), C.cast(a.data_ptr(), _f), C.c_long(a.stride(0)),
-                                    _p(wt, _f), _p(bias, _f), int(bool(relu)), C.cast(out.data_ptr(), _f), C.c_long(out.stride(0)))
+                                    _p(wt, _f), _p(bias, _f), int(bool(relu)), C.cast(full.data_ptr(), _f), C.c_long(full.stride(0)))
+        if full is not out:
+            out[:R].copy_(full[:R, :out.size(1)])
+        return out
+
+    @staticmethod
+    def rows_dot_wrapper(a, wt, bias, out):
+        O.lib().orc_rows_dot(C.c_long(a.size(0)), a.size(1), wt.size(1), C.cast(a.data_ptr(), _f), C.c_long(a.stride(0)),
+                             _p(wt, _f), _p(bias, _f), C.cast(out.data_ptr(), _f), C.c_long(out.stride(0)))
         return out
 
     @staticmethod

@@ -188,3 +188,25 @@ void orc_rcnn_point_mlp(long r, int ld, int fcol, const float *rows, const float
         for (int c = 0; c < 128; ++c) p[i * 128 + c] = acc[c] + bp[c];
     }
 }
+
+/* csrc/packed_layer.hip rows_dot_kernel: n <= 4 outputs per row; lane l of 32 accumulates k = l, l + 32, ... (fma chain from
+ * 0), the partial sums are added in an xor butterfly 16, 8, 4, 2, 1 (lane 0's view), then the bias */
+void orc_rows_dot(long rows, int K, int n, const float *A, long lda, const float *W, const float *bias, float *out, long ldo)
+{
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < rows; ++r)
+        for (int c = 0; c < n; ++c) {
+            float p[32];
+            for (int l = 0; l < 32; ++l) {
+                float acc = 0.f;
+                for (int k = l; k < K; k += 32) acc = fmaf(A[r * lda + k], W[(long)k * n + c], acc);
+                p[l] = acc;
+            }
+            for (int d = 16; d >= 1; d >>= 1) {
+                float q[32];
+                for (int l = 0; l < 32; ++l) q[l] = p[l] + p[l ^ d];
+                memcpy(p, q, sizeof(p));
+            }
+            out[r * ldo + c] = p[0] + bias[c];
+        }
+}

@@ -113,6 +113,8 @@ void orc_sa_mlp_fused(int b, int n, int m, int ns, int c3, const float *new_xyz,
 /* csrc/packed_layer.hip (layer 1 over grouped rows, fmaf chain) */
 void orc_gather_affine_fma(int b, int n, int m, int ns, int c1, const float *new_xyz, const float *xyz, const float *P,
                            const float *wxyz, const int *idx, float *out);
+/* csrc/packed_layer.hip rows_dot_kernel */
+void orc_rows_dot(long rows, int K, int n, const float *A, long lda, const float *W, const float *bias, float *out, long ldo);
 /* csrc/sa_xyz_mlp.hip */
 void orc_sa_xyz_mlp(int b, int n, int m, int ns, int c1, int c2, int c3, const float *new_xyz, const float *xyz,
                     const int *idx, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
