@@ -308,23 +308,31 @@ __global__ __launch_bounds__(512, 1) void sa_mlp_fused256_kernel(
 }  // namespace prcnn
 
 namespace prcnn {
-// Tile-ticket words: a ring of 64 words PER STREAM (slot 6 of the per-stream scratch).  One launch uses one word, zeroed by
-// a memset queued on the same stream just before it; a word is reused 64 launches later on that same stream, i.e. strictly
-// after the launch that used it (stream order) -- launches of other streams never touch it.
+// Tile-ticket words: a ring of 256 words per (device, stream) (slot 6 of the scratch cache).  One launch uses one word; the
+// WHOLE ring is zeroed by one memset queued on the same stream whenever the ring wraps (every 256 launches), i.e. strictly
+// after every launch that used the previous generation of words (stream order) -- launches of other streams never touch it.
+// (Round 1 zeroed one word per launch: a 5 us fill kernel in front of each of the ~8 ticketed launches of a step.)
+constexpr unsigned TICKET_RING = 256;
 static std::mutex g_ticket_mu;
 static std::map<std::pair<int, hipStream_t>, unsigned int> g_ticket_next;
 unsigned int *next_ticket(hipStream_t st)
 {
-    unsigned int *ring = reinterpret_cast<unsigned int *>(scratch_for(st, 64 * sizeof(unsigned int), 6));
+    unsigned int *ring = reinterpret_cast<unsigned int *>(scratch_for(st, 2 * TICKET_RING * sizeof(unsigned int), 6));
     if (!ring) return nullptr;
     unsigned int k;
     {
         std::lock_guard<std::mutex> lock(g_ticket_mu);
         k = g_ticket_next[std::make_pair(current_device(), st)]++;
     }
-    unsigned int *t = ring + (k & 63);
-    if (hipMemsetAsync(t, 0, sizeof(unsigned int), st) != hipSuccess) return nullptr;
-    return t;
+    // under hipGraph capture every launch keeps its OWN memset node (second half of the ring): a replay must find the word
+    // at zero again, which the amortised form cannot promise
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        unsigned int *word = ring + TICKET_RING + (k % TICKET_RING);
+        return hipMemsetAsync(word, 0, sizeof(unsigned int), st) == hipSuccess ? word : nullptr;
+    }
+    if ((k % TICKET_RING) == 0 && hipMemsetAsync(ring, 0, TICKET_RING * sizeof(unsigned int), st) != hipSuccess) return nullptr;
+    return ring + (k % TICKET_RING);
 }
 }  // namespace prcnn
 

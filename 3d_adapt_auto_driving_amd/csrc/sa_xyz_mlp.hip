@@ -74,9 +74,102 @@ __global__ __launch_bounds__(256) void sa_xyz_mlp_kernel(
     }
 }
 
+// ---- the same level over the DISTINCT rows only (prcnn_ball_pack lists; see sa_packed.hip).  lane = one packed row; the
+// wave's 64 rows are one tile of the list.  The relu'd outputs go through LDS so that the pool runs with lane = channel:
+// a serial pass over the tile's rows keeps a running max per channel and flushes it with ONE coalesced atomicMax per centre
+// (outputs are >= 0; the output slice is zeroed by the caller of the kernel).  Per-row arithmetic is identical to
+// sa_xyz_mlp_kernel, so the pooled result is bit-identical.
+template <int C1, int C2, int C3>
+__global__ __launch_bounds__(256) void sa_xyz_mlp_packed_kernel(
+    int m, const unsigned int *__restrict__ hdr, const unsigned int *__restrict__ rowinfo, const float4 *__restrict__ rowdxyz,
+    const int *__restrict__ tilecloud, const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w2,
+    const float *__restrict__ b2, const float *__restrict__ w3, const float *__restrict__ b3, float *__restrict__ out,
+    int out_stride, int out_col)
+{
+    __shared__ float z[4][64 * (C3 + 1)];
+    __shared__ int ctr[4][64];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long t = (long)blockIdx.x * 4 + wv;                  // this wave's tile
+    if (t >= (long)hdr[0]) return;                             // wave-uniform: no barrier below, LDS is private per wave
+    const long row = t * 64 + lane;
+    const float4 d = rowdxyz[row];
+    const float dx = d.x, dy = d.y, dz = d.z;
+    ctr[wv][lane] = tilecloud[t] * m + (int)(rowinfo[row] >> 16);
+
+    float a1[C1];
+#pragma unroll
+    for (int j = 0; j < C1; ++j)
+        a1[j] = fmaxf(fmaf(w1[2 * C1 + j], dz, fmaf(w1[C1 + j], dy, fmaf(w1[j], dx, b1[j]))), 0.f);
+    float a2[C2];
+#pragma unroll
+    for (int j = 0; j < C2; ++j) a2[j] = b2[j];
+#pragma unroll
+    for (int q = 0; q < C1; ++q)
+#pragma unroll
+        for (int j = 0; j < C2; ++j) a2[j] = fmaf(w2[q * C2 + j], a1[q], a2[j]);
+#pragma unroll
+    for (int j = 0; j < C2; ++j) a2[j] = fmaxf(a2[j], 0.f);
+    float a3[C3];
+#pragma unroll
+    for (int j = 0; j < C3; ++j) a3[j] = b3[j];
+#pragma unroll
+    for (int q = 0; q < C2; ++q)
+#pragma unroll
+        for (int j = 0; j < C3; ++j) a3[j] = fmaf(w3[q * C3 + j], a2[q], a3[j]);
+    float *zw = z[wv];
+#pragma unroll
+    for (int j = 0; j < C3; ++j) zw[lane * (C3 + 1) + j] = fmaxf(a3[j], 0.f);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // pool: lane -> channel (C3 = 64: all rows; C3 = 32: lane half hh takes rows [32 hh, 32 hh + 32))
+    constexpr int ROWS_PER = C3 == 64 ? 64 : 32;
+    const int ch = lane & (C3 - 1), hh = C3 == 64 ? 0 : (lane >> 5);
+    const int *cc = ctr[wv];
+    float cur = 0.f;
+    for (int i = 0; i < ROWS_PER; ++i) {
+        const int r = hh * ROWS_PER + i;
+        cur = fmaxf(cur, zw[r * (C3 + 1) + ch]);
+        const bool last = (i == ROWS_PER - 1) || (cc[r + 1] != cc[r]);
+        if (last) {
+            atomicMax(reinterpret_cast<int *>(out + (long)cc[r] * out_stride + out_col + ch), __float_as_int(cur));
+            cur = 0.f;
+        }
+    }
+}
+
 }  // namespace prcnn
 
 using namespace prcnn;
+
+// the same level over a packed row list (prcnn_ball_pack of the level's index tensor): out[(b*m)][out_col .. +c3) is zeroed
+// and receives the per-centre maxima.  max_tiles = b * ceil(m * nsample / 64).
+extern "C" int prcnn_sa_xyz_mlp_packed(int b, int m, int c1, int c2, int c3, long max_tiles, const unsigned int *rowinfo,
+                                       const float *rowdxyz, const int *tilecloud, const unsigned int *hdr, const float *w1,
+                                       const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                                       float *out, int out_stride, int out_col, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && m >= 0 && max_tiles >= 0, "sa_xyz_mlp_packed: bad sizes");
+    PRCNN_REQUIRE((c1 == 16 && c2 == 16 && c3 == 32) || (c1 == 32 && c2 == 32 && c3 == 64),
+                  "sa_xyz_mlp_packed: unsupported shape c1=%d c2=%d c3=%d", c1, c2, c3);
+    PRCNN_REQUIRE(out_stride >= out_col + c3 && out_col >= 0, "sa_xyz_mlp_packed: bad output slice");
+    if ((long)b * m == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(rowinfo && rowdxyz && tilecloud && hdr && w1 && b1 && w2 && b2 && w3 && b3 && out, "sa_xyz_mlp_packed: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemset2DAsync(out + out_col, (size_t)out_stride * sizeof(float), 0, (size_t)c3 * sizeof(float), (size_t)b * m, st) != hipSuccess) {
+        set_error("sa_xyz_mlp_packed: cannot zero the output slice");
+        return PRCNN_ELAUNCH;
+    }
+    if (max_tiles == 0) return PRCNN_OK;
+    const long grid = (max_tiles + 3) / 4;
+    PRCNN_REQUIRE(grid <= 0x7fffffffL, "sa_xyz_mlp_packed: too many tiles");
+    if (c3 == 32)
+        hipLaunchKernelGGL((sa_xyz_mlp_packed_kernel<16, 16, 32>), dim3((unsigned)grid), dim3(256), 0, st, m, hdr, rowinfo,
+                           (const float4 *)rowdxyz, tilecloud, w1, b1, w2, b2, w3, b3, out, out_stride, out_col);
+    else
+        hipLaunchKernelGGL((sa_xyz_mlp_packed_kernel<32, 32, 64>), dim3((unsigned)grid), dim3(256), 0, st, m, hdr, rowinfo,
+                           (const float4 *)rowdxyz, tilecloud, w1, b1, w2, b2, w3, b3, out, out_stride, out_col);
+    return check_launch("sa_xyz_mlp_packed");
+}
 
 // xyz (b,n,3), new_xyz (b,m,3), idx (b,m,nsample) -> out[(b*m rows)][out_col .. out_col + c3), row stride out_stride.
 // w1 (>=3, c1) rows = x, y, z weights; w2 (c1, c2); w3 (c2, c3): k-major ("row = input channel"), BN folded.

@@ -294,6 +294,16 @@ def pooled_tiles_wrapper(cnt, rows_per_cloud):
     return tilemap, hdr
 
 
+def sa_xyz_mlp_packed_wrapper(new_xyz, xyz, pack, w1, b1, w2, b2, w3, b3, out, out_col):
+    """sa_xyz_mlp_wrapper over the distinct rows of the level's index tensor (BallPack) -- bit-identical results."""
+    _chk(torch.float32, w1, b1, w2, b2, w3, b3, out)
+    _lib.call("prcnn_sa_xyz_mlp_packed", new_xyz.size(0), new_xyz.size(1), w1.size(1), w2.size(1), w3.size(1), pack.max_tiles,
+              pack.rowinfo.data_ptr(), pack.rowdxyz.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr(), w1.data_ptr(),
+              b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), out.data_ptr(), out.size(-1), out_col,
+              _lib.current_stream(out))
+    return out
+
+
 def rcnn_point_mlp_wrapper(rows, fcol, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, merged, p, tiles=None):
     """RCNN entrance chain as tiled MFMA layer kernels (csrc/rcnn_point_mlp.hip): rows (R, ld) pooled rows
     [x',y',z',mask,depth,0,0,0 | 128 feats at column fcol] -> xfeat = xyz_up(in5), merged = relu([xfeat | feats] wm + bm),

@@ -300,7 +300,7 @@ class FastPointRCNN:
     def _pack_level(self, k, cur, lev):
         """the distinct-row lists of the scales that run on the packed MFMA kernels (they depend on the indices only)"""
         lev["pack"] = [pu.pointnet2.ball_pack_wrapper(ix, cur, lev["new_xyz"])
-                       if (USE_PACKED and (sc[2].packed is not None or sc[2].wide is not None)) else None
+                       if (USE_PACKED and (sc[2].packed is not None or sc[2].wide is not None or sc[3] == 0)) else None
                        for ix, sc in zip(lev["idx"], self.sa[k][1])]
 
     @torch.no_grad()
@@ -375,7 +375,11 @@ class FastPointRCNN:
                 ext.sa_xyz_mlp_supported(mlp.layers[0][0].shape[1], mlp.layers[1][0].shape[1], mlp.layers[2][0].shape[1], ns)):
             # coordinates-only level (RPN SA1): one VALU kernel, a grouped row never leaves its lane
             (w1, b1, _), (w2, b2, _), (w3, b3, _) = mlp.layers
-            ext.sa_xyz_mlp_wrapper(new_xyz, xyz, idx, w1, b1, w2, b2, w3, b3, out, out_col)
+            if USE_PACKED:
+                pk = pack if pack is not None else ext.ball_pack_wrapper(idx, xyz, new_xyz)
+                ext.sa_xyz_mlp_packed_wrapper(new_xyz, xyz, pk, w1, b1, w2, b2, w3, b3, out, out_col)
+            else:
+                ext.sa_xyz_mlp_wrapper(new_xyz, xyz, idx, w1, b1, w2, b2, w3, b3, out, out_col)
             return
         if mlp.split is not None and M * ns > N:
             # layer 1 is linear before its ReLU: its feature part is one GEMM over the N points,

@@ -172,6 +172,11 @@ int prcnn_packed_layer(const unsigned int *hdr, long rows, long max_tiles, int K
                        long lda, const float *W, const float *bias, int relu, float *out, long ldo, void *stream);
 /* out[r][0..n) = A[r] @ W + bias for n <= 4 outputs (the 1-wide last layer of the classification heads, rpn.py:36-50,
  * rcnn_net.py:94-103): W (K,n) k-major; 32 lanes per row, fixed summation order (oracle: orc_rows_dot). */
+/* The coordinates-only first SA level (prcnn_sa_xyz_mlp) over a packed row list: distinct rows only, bit-identical. */
+int prcnn_sa_xyz_mlp_packed(int b, int m, int c1, int c2, int c3, long max_tiles, const unsigned int *rowinfo,
+                            const float *rowdxyz, const int *tilecloud, const unsigned int *hdr, const float *w1,
+                            const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
+                            float *out, int out_stride, int out_col, void *stream);
 int prcnn_rows_dot(long rows, int K, int n, const float *A, long lda, const float *W, const float *bias, float *out,
                    long ldo, void *stream);
 int prcnn_packed_layer_segmax(int b, int m, long max_tiles, int K, int N, const float *A, long lda, const float *W,

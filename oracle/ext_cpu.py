@@ -198,6 +198,10 @@ class pointnet2_cpu:
         return None                                  # the CPU stand-in evaluates every row
 
     @staticmethod
+    def sa_xyz_mlp_packed_wrapper(new_xyz, xyz, pack, w1, b1, w2, b2, w3, b3, out, out_col):
+        return pointnet2_cpu.sa_xyz_mlp_wrapper(new_xyz, xyz, pack.idx, w1, b1, w2, b2, w3, b3, out, out_col)
+
+    @staticmethod
     def rcnn_point_mlp_wrapper(rows, fcol, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, merged, p, tiles=None):
         O.lib().orc_rcnn_point_mlp(C.c_long(rows.size(0)), rows.size(1), int(fcol), _p(rows, _f), _p(wu1, _f), _p(bu1, _f),
                                    _p(wu2, _f), _p(bu2, _f), _p(wm, _f), _p(bm, _f), _p(wp, _f), _p(bp, _f),

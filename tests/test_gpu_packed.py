@@ -232,3 +232,29 @@ def test_packed_layer_host_row_count_ragged(ext):
         want = torch.empty((R, N))
         ext_cpu.pointnet2_cpu.packed_layer_wrapper(a.cpu(), w.cpu(), bias.cpu(), relu, want)
         assert torch.equal(out[:R].cpu(), want)
+
+
+@pytest.mark.parametrize("c1,c2,c3,ns", [(16, 16, 32, 16), (32, 32, 64, 32)])
+def test_xyz_level_over_packed_rows_bit_identical(ext, c1, c2, c3, ns):
+    """RPN SA1 (coordinates only) over the distinct rows == the all-rows VALU kernel == the oracle, bit for bit; output slice
+    inside a wider (MSG-concatenated) buffer, other columns untouched."""
+    rng = np.random.default_rng(c3)
+    b, n, m = 3, 2048, 333
+    xyz = T(rng.uniform(-3, 3, (b, n, 3)).astype(np.float32))
+    new_xyz = T(rng.uniform(-3, 3, (b, m, 3)).astype(np.float32))
+    idx_np, cnt = ball_like_idx(rng, b, m, n, ns, 2.5)
+    idx = T(idx_np)
+    w1 = T((rng.standard_normal((3, c1)) * 0.7).astype(np.float32)); b1 = T(rng.standard_normal(c1).astype(np.float32) * 0.2)
+    w2 = T((rng.standard_normal((c1, c2)) / np.sqrt(c1)).astype(np.float32)); b2 = T(rng.standard_normal(c2).astype(np.float32) * 0.2)
+    w3 = T((rng.standard_normal((c2, c3)) / np.sqrt(c2)).astype(np.float32)); b3 = T(rng.standard_normal(c3).astype(np.float32) * 0.2)
+    full = torch.full((b, m, c3 + 8), -1.0, device=DEV)
+    ext.pointnet2.sa_xyz_mlp_wrapper(new_xyz, xyz, idx, w1, b1, w2, b2, w3, b3, full, 4)
+    got = torch.full((b, m, c3 + 8), -1.0, device=DEV)
+    pk = ext.pointnet2.ball_pack_wrapper(idx, xyz, new_xyz)
+    ext.pointnet2.sa_xyz_mlp_packed_wrapper(new_xyz, xyz, pk, w1, b1, w2, b2, w3, b3, got, 4)
+    assert torch.equal(got, full)
+    want = torch.full((b, m, c3 + 8), -1.0)
+    ext_cpu.pointnet2_cpu.sa_xyz_mlp_wrapper(new_xyz.cpu(), xyz.cpu(), idx.cpu(), w1.cpu(), b1.cpu(), w2.cpu(), b2.cpu(), w3.cpu(),
+                                             b3.cpu(), want, 4)
+    assert torch.equal(got.cpu(), want)
+    assert (got[..., 4:4 + c3] > 0).float().mean() > 0.2
