@@ -134,6 +134,9 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
     __shared__ float lds[2 * PK_ROWS * PK_LD];
     __shared__ unsigned int slot[2];
     __shared__ int ctr[2][PK_ROWS];
+    // the centre-relative coordinates of a tile's rows stream from HBM (16 B per row, read once): they are fetched ONE TILE
+    // AHEAD by wave 0 and parked here, so that the builder finds them in LDS instead of waiting for memory
+    __shared__ float4 dxyz_s[2][PK_ROWS];
     float *A1 = lds, *Y1 = lds + PK_ROWS * PK_LD;
 
     const int tid = threadIdx.x;
@@ -162,17 +165,20 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i) info[i] = rowinfo[t * PK_ROWS + r0 + 8 * i];
     int cloud = tilecloud[t];
+    if (tid < PK_ROWS) dxyz_s[0][tid] = rowdxyz[t * PK_ROWS + tid];
+    __syncthreads();
 
     for (int served = 0; served < tiles_per_wg && t < tiles; ++served) {
         const bool more = served + 1 < tiles_per_wg;
         if (tid == 0) slot[(served + 1) & 1] = more ? atomicAdd(ticket, 1u) : 0xffffffffu;
         int *cc = ctr[served & 1];
+        const float4 *dcur = dxyz_s[served & 1];
         const long pbase = (long)cloud * n, cbase = (long)cloud * m;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = r0 + 8 * i;
             const int k = (int)(info[i] & 0xffffu), cl = (int)(info[i] >> 16);
-            const float4 d = rowdxyz[t * PK_ROWS + row];
+            const float4 d = dcur[row];
             const float dx = d.x, dy = d.y, dz = d.z;
             const float4 base = P[(pbase + k) * (PK_C / 4) + chunk];
             float4 v;
@@ -185,10 +191,12 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
         }
         __syncthreads();
         const long t_next = slot[(served + 1) & 1];
+        float4 dnext = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t_next < tiles) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) info[i] = rowinfo[t_next * PK_ROWS + r0 + 8 * i];
             cloud = tilecloud[t_next];
+            if (tid < PK_ROWS) dnext = rowdxyz[t_next * PK_ROWS + tid];     // in flight during layer 2
         }
 
         // ---- layer 2
@@ -216,6 +224,7 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
                 Y1[(32 + row) * PK_LD + 32 * w + j] = fmaxf(acc1[r] + bias2, 0.f);
             }
         }
+        if (tid < PK_ROWS && t_next < tiles) dxyz_s[(served + 1) & 1][tid] = dnext;   // ordered before the next builder by the barrier below
         __syncthreads();
 
         // ---- layer 3 + segmented max over the tile's rows
@@ -260,6 +269,7 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
     __shared__ float lds[2 * PK_ROWS * PK_LD];
     __shared__ unsigned int slot[2];
     __shared__ int ctr[2][PK_ROWS];
+    __shared__ float4 dxyz_s[2][PK_ROWS];             // next tile's coordinates, fetched one tile ahead (see the 128 kernel)
     float *A1 = lds, *Y1 = lds + PK_ROWS * PK_LD;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6, wp = w & 3, wg = w >> 2;
@@ -285,17 +295,20 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) info[i] = rowinfo[t * PK_ROWS + r0 + 16 * i];
     int cloud = tilecloud[t];
+    if (tid < PK_ROWS) dxyz_s[0][tid] = rowdxyz[t * PK_ROWS + tid];
+    __syncthreads();
 
     for (int served = 0; served < tiles_per_wg && t < tiles; ++served) {
         const bool more = served + 1 < tiles_per_wg;
         if (tid == 0) slot[(served + 1) & 1] = more ? atomicAdd(ticket, 1u) : 0xffffffffu;
         int *cc = ctr[served & 1];
+        const float4 *dcur = dxyz_s[served & 1];
         const long pbase = (long)cloud * n, cbase = (long)cloud * m;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = r0 + 16 * i;
             const int k = (int)(info[i] & 0xffffu), cl = (int)(info[i] >> 16);
-            const float4 d = rowdxyz[t * PK_ROWS + row];
+            const float4 d = dcur[row];
             const float dx = d.x, dy = d.y, dz = d.z;
             const float4 base = P[(pbase + k) * (PK_C / 4) + chunk];
             float4 v;
@@ -308,10 +321,12 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
         }
         __syncthreads();
         const long t_next = slot[(served + 1) & 1];
+        float4 dnext = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t_next < tiles) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) info[i] = rowinfo[t_next * PK_ROWS + r0 + 16 * i];
             cloud = tilecloud[t_next];
+            if (tid < PK_ROWS) dnext = rowdxyz[t_next * PK_ROWS + tid];
         }
 
         // ---- layer 2: rows [32 wg, 32 wg + 32) x columns [32 wp, 32 wp + 32)
@@ -332,6 +347,7 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
                 Y1[row * PK_LD + 32 * wp + j] = fmaxf(acc[r] + bias2, 0.f);
             }
         }
+        if (tid < PK_ROWS && t_next < tiles) dxyz_s[(served + 1) & 1][tid] = dnext;
         __syncthreads();
 
         // ---- layer 3: all 64 rows x columns [128 wg + 32 wp, +32), then the segmented max
