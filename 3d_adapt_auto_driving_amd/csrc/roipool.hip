@@ -23,8 +23,13 @@ constexpr int RP_MAX_S = 2048;
 
 // Sweep of one (scene, box): first `sampled` in-box point indices in index order -> s_sel; returns min(#hits, sampled).
 // bx = the (already enlarged) box [x, y_bottom, z, h, w, l, ry].
+// Each of the 4 waves sweeps its own contiguous QUARTER of the cloud, 64 points per round, and appends its hits (already
+// in index order: ballot + lane prefix) to a private LDS list -- no barrier inside the sweep (round 1 swept 256 points
+// per round with two workgroup barriers each: 64 rounds x 2 barriers per box made the kernel latency-bound at 0.25 of
+// the HBM roofline).  The four lists are concatenated in wave order afterwards = index order.  A wave stops early once
+// it alone holds `sampled` hits.  LDS (dynamic): s_sel[sampled] | s_part[4][sampled] | s_cnt[4].
 __device__ __forceinline__ int select_points(int pts_num, int sampled, const float *__restrict__ pts, float bx0, float bx1,
-                                             float bx2, float h, float w, float l, float ry, int *s_sel, int *s_wcnt)
+                                             float bx2, float h, float w, float l, float ry, int *s_sel, int *s_part, int *s_cnt)
 {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     // pt_in_box3d :14-28; the trig pair and cy depend on the box only
@@ -32,35 +37,53 @@ __device__ __forceinline__ int select_points(int pts_num, int sampled, const flo
     const float cy = (float)((double)bx1 - (double)h / 2.0);
     const float cosa = cos_f32(ry), sina = sin_f32(ry);
     const float hh = h * 0.5f, hl = l * 0.5f, hw = w * 0.5f;  // exact halves
-    __syncthreads();
-    int total = 0;
-    for (int base = 0; base < pts_num && total < sampled; base += RP_THREADS) {
-        const int k = base + t;
-        bool in = false;
-        if (k < pts_num) {
-            const float x = pts[3 * k], y = pts[3 * k + 1], z = pts[3 * k + 2];
-            if (!(fabsf(x - cx) > 10.0f || fabsf(y - cy) > hh || fabsf(z - cz) > 10.0f)) {
-                const float xr = __fadd_rn(__fmul_rn(x - cx, cosa), __fmul_rn(z - cz, -sina));
-                const float zr = __fadd_rn(__fmul_rn(x - cx, sina), __fmul_rn(z - cz, cosa));
-                in = (xr >= -hl) & (xr <= hl) & (zr >= -hw) & (zr <= hw);
-            }
-        }
-        const unsigned long long mask = __ballot(in);
-        if (lane == 0) s_wcnt[wave] = __popcll(mask);
-        __syncthreads();
-        int before = total;
+    const int quarter = ((pts_num + 4 * 64 - 1) / (4 * 64)) * 64;          // multiple of 64
+    const int lo = wave * quarter, hi = min(pts_num, lo + quarter);
+    int *mine = s_part + wave * sampled;
+    int cnt = 0;
+    // four 64-point rounds per iteration: their 12 loads per lane are in flight together, the tests and the in-order appends
+    // follow (a wave sweeps its quarter as a chain of dependent round trips otherwise)
+    for (int base = lo; base < hi && cnt < sampled; base += 256) {
+        float px[4], py[4], pz[4];
 #pragma unroll
-        for (int q = 0; q < RP_THREADS / 64; ++q) {
-            const int cq = s_wcnt[q];
-            if (q < wave) before += cq;
-            total += cq;
+        for (int u = 0; u < 4; ++u) {
+            const int k = base + 64 * u + lane;
+            const int kk = k < hi ? k : lo;                                  // (a valid address; the result is masked below)
+            px[u] = pts[3 * kk]; py[u] = pts[3 * kk + 1]; pz[u] = pts[3 * kk + 2];
         }
-        if (in) {
-            const int pos = before + __popcll(mask & ((1ull << lane) - 1ull));
-            if (pos < sampled) s_sel[pos] = k;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = base + 64 * u + lane;
+            bool in = false;
+            if (k < hi) {
+                const float x = px[u], y = py[u], z = pz[u];
+                if (!(fabsf(x - cx) > 10.0f || fabsf(y - cy) > hh || fabsf(z - cz) > 10.0f)) {
+                    const float xr = __fadd_rn(__fmul_rn(x - cx, cosa), __fmul_rn(z - cz, -sina));
+                    const float zr = __fadd_rn(__fmul_rn(x - cx, sina), __fmul_rn(z - cz, cosa));
+                    in = (xr >= -hl) & (xr <= hl) & (zr >= -hw) & (zr <= hw);
+                }
+            }
+            const unsigned long long mask = __ballot(in);
+            if (in) {
+                const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+                if (pos < sampled) mine[pos] = k;
+            }
+            cnt += __popcll(mask);
         }
-        __syncthreads();
     }
+    if (lane == 0) s_cnt[wave] = min(cnt, sampled);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < RP_THREADS / 64; ++q) {
+        const int cq = s_cnt[q];
+        if (q < wave) before += cq;
+        total += cq;
+    }
+    const int n_mine = min(cnt, sampled);
+    for (int i = lane; i < n_mine; i += 64)
+        if (before + i < sampled) s_sel[before + i] = mine[i];
+    __syncthreads();
     return min(total, sampled);
 }
 
@@ -69,14 +92,14 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_kernel(
     const float *__restrict__ boxes3d, const float *__restrict__ pts_feature,
     float *__restrict__ pooled, int *__restrict__ empty_flag)
 {
-    __shared__ int s_sel[RP_MAX_S];
-    __shared__ int s_wcnt[RP_THREADS / 64];
+    extern __shared__ int rp_lds[];
+    int *s_sel = rp_lds, *s_part = rp_lds + sampled, *s_cnt = rp_lds + 5 * sampled;
 
     const int box = blockIdx.x, b = blockIdx.y;
     const int t = threadIdx.x;
     const float *bx = boxes3d + ((long)b * boxes_num + box) * 7;
     const float *__restrict__ pts = xyz + (long)b * pts_num * 3;
-    const int cnt = select_points(pts_num, sampled, pts, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], bx[6], s_sel, s_wcnt);
+    const int cnt = select_points(pts_num, sampled, pts, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], bx[6], s_sel, s_part, s_cnt);
     if (cnt == 0) {
         if (t == 0) empty_flag[(long)b * boxes_num + box] = 1;
         return;  // rows stay as the caller left them
@@ -106,8 +129,8 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(
     const float *__restrict__ rois, const float *__restrict__ feats, const float *__restrict__ seg_mask,
     const float *__restrict__ depth, float4 *__restrict__ pooled, int *__restrict__ empty_flag, int *__restrict__ pooled_cnt)
 {
-    __shared__ int s_sel[RP_MAX_S];
-    __shared__ int s_wcnt[RP_THREADS / 64];
+    extern __shared__ int rp_lds[];
+    int *s_sel = rp_lds, *s_part = rp_lds + sampled, *s_cnt = rp_lds + 5 * sampled;
 
     const int box = blockIdx.x, b = blockIdx.y;
     const int t = threadIdx.x;
@@ -116,7 +139,7 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(
     const float *__restrict__ pts = xyz + (long)b * pts_num * 3;
     // enlarge_box3d: h, w, l += 2 * extra_width;  y += extra_width
     const int cnt = select_points(pts_num, sampled, pts, rx, ry_bottom + extra, rz, bx[3] + extra2, bx[4] + extra2,
-                                  bx[5] + extra2, heading, s_sel, s_wcnt);
+                                  bx[5] + extra2, heading, s_sel, s_part, s_cnt);
     const int q4 = 2 + feat_len / 4;                                     // float4 chunks per row
     float4 *__restrict__ dst = pooled + ((long)b * boxes_num + box) * (long)sampled * q4;
     const long chunks = (long)sampled * q4;
@@ -146,6 +169,7 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(
     const float *__restrict__ mk = seg_mask + (long)b * pts_num;
     const float *__restrict__ dp = depth + (long)b * pts_num;
     const int f4 = feat_len / 4;
+#pragma unroll 4
     for (long e = t; e < chunks; e += RP_THREADS) {
         const int s = (int)(e / q4);
         const int q = (int)(e - (long)s * q4);
@@ -186,7 +210,8 @@ extern "C" int prcnn_roipool3d(int batch_size, int pts_num, int boxes_num, int f
     PRCNN_REQUIRE(boxes3d && pooled_features && pooled_empty_flag && (xyz || pts_num == 0) &&
                   (pts_feature || feature_in_len == 0 || pts_num == 0), "roipool3d: null pointer");
     dim3 grid(boxes_num, batch_size);
-    hipLaunchKernelGGL(roipool3d_kernel, grid, dim3(RP_THREADS), 0, (hipStream_t)stream, pts_num, boxes_num,
+    const size_t lds = ((size_t)5 * sampled_pts_num + 4) * sizeof(int);
+    hipLaunchKernelGGL(roipool3d_kernel, grid, dim3(RP_THREADS), lds, (hipStream_t)stream, pts_num, boxes_num,
                        feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature, pooled_features,
                        pooled_empty_flag);
     return check_launch("roipool3d");
@@ -210,7 +235,8 @@ extern "C" int prcnn_roipool3d_canonical(int batch_size, int pts_num, int boxes_
                   "roipool3d_canonical: null pointer");
     PRCNN_REQUIRE((((uintptr_t)pooled | (uintptr_t)feats) & 15) == 0, "roipool3d_canonical: 16-byte alignment required");
     dim3 grid(boxes_num, batch_size);
-    hipLaunchKernelGGL(roipool3d_canonical_kernel, grid, dim3(RP_THREADS), 0, (hipStream_t)stream, pts_num, boxes_num,
+    const size_t lds = ((size_t)5 * sampled_pts_num + 4) * sizeof(int);
+    hipLaunchKernelGGL(roipool3d_canonical_kernel, grid, dim3(RP_THREADS), lds, (hipStream_t)stream, pts_num, boxes_num,
                        feature_len, sampled_pts_num, pool_extra_width, (float)((double)pool_extra_width * 2.0), xyz, rois, feats,
                        seg_mask, depth, reinterpret_cast<float4 *>(pooled), pooled_empty_flag, pooled_cnt);
     return check_launch("roipool3d_canonical");

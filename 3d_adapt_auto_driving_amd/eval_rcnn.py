@@ -124,6 +124,24 @@ def infer_batch(model, cfg, pts_input, engine=None, geo=None):
     return det
 
 
+_RUNNER_STREAMS = {}
+
+
+def _runner_streams(device, n_sides, prio):
+    """The side / tail streams of the pipelined runner, created ONCE per (device, priority) and shared by every runner of the
+    process.  HIP multiplexes its streams onto a few hardware queues (4 by default); two streams that land on the same queue
+    serialise -- a feature-stream kernel then waits behind a 6 ms FPS kernel of a geometry chain.  A fresh set of streams
+    per runner drew a new mapping every time (same process: 77 ms or 89 ms for the same 20 steps); with one fixed set the
+    first-created streams keep the queues they were given at start-up."""
+    key = (str(device), prio)
+    have = _RUNNER_STREAMS.setdefault(key, {"tail": None, "sides": []})
+    if have["tail"] is None:
+        have["tail"] = torch.cuda.Stream(device)
+    while len(have["sides"]) < n_sides:
+        have["sides"].append(torch.cuda.Stream(device, priority=prio))
+    return have["tail"], have["sides"][:n_sides]
+
+
 class PipelinedRunner:
     """Software pipeline over batches on HIP streams: the xyz-only GEOMETRY of upcoming batches (FPS,
     ball query, three-NN: a latency-bound chain that keeps only B CUs busy) runs on side streams while
@@ -147,7 +165,7 @@ class PipelinedRunner:
         # default priority: with the SA levels on the packed MFMA kernels the feature pass is short, and high-priority side
         # streams (three of them at depth 3) starve it -- measured 971 vs 1375 scenes/s
         prio = int(os.environ.get("PRCNN_SIDE_PRIORITY", "0"))
-        self.sides = [torch.cuda.Stream(self.device, priority=prio) for _ in range(2 if self.group > 1 else max(1, self.depth))]
+        self._shared_tail, self.sides = _runner_streams(self.device, 2 if self.group > 1 else max(1, self.depth), prio)
         self._next_side = 0
         self._pending = []        # [(batch tensor, geometry dict, ready event)] in launch order
 
@@ -203,7 +221,7 @@ class PipelinedRunner:
     @torch.no_grad()
     def submit(self, cur, upcoming=None):
         if getattr(self, "tail", None) is None:
-            self.tail = torch.cuda.Stream(self.device)
+            self.tail = self._shared_tail
             self._inflight = None
             self._chains = []                 # geometry chains in flight: dicts pts / side / state / geo / ev
         main = torch.cuda.current_stream(self.device)

@@ -240,6 +240,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-driver", action="store_true", help="skip the whole-driver leg (loader processes + writer)")
+    ap.add_argument("--prewarm", type=int, default=24, help="untimed set-up steps before the W warm-up steps (allocator pool, code objects)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -296,18 +297,31 @@ def main():
         host_scores = torch.empty((total, BATCH, M), pin_memory=True)
         host_num = torch.empty((total, BATCH), dtype=torch.int32, pin_memory=True)
 
+        import collections
+        ready = collections.deque()
+
         def copy_out(det, i):
             # async D2H of batch i's detections into its pinned slot, on the stream that produced them
             with torch.cuda.stream(det["stream"]) if "stream" in det else contextlib.nullcontext():
                 host_boxes[i].copy_(det["boxes"], non_blocking=True)
                 host_scores[i].copy_(det["scores"], non_blocking=True)
                 host_num[i].copy_(det["num"], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            # the host consumes results 3 batches late (as eval_rcnn.eval_scenes does): it never waits for the batch it
+            # just submitted, but it cannot run arbitrarily far ahead of the device either -- unbounded run-ahead keeps
+            # growing the set of live temporaries, i.e. hipMalloc calls inside the loop
+            ready.append(ev)
+            if len(ready) > 3:
+                ready.popleft().synchronize()
 
-        def step(i):
-            # every timed step does one geometry pass (batch i+depth, side stream), one RPN pass (batch i) and one
-            # RCNN + final pass; in the three-stream form the latter belongs to batch i-1 (software pipeline,
-            # eval_rcnn.PipelinedRunner.submit) and the per-scene tails run beside the feature stream
-            nxt = [batches[(i + d) % n_slots] for d in range(1, runner.depth + 1)]
+        def step(i, end):
+            # every step does one RPN pass (batch i) and one RCNN + final pass; in the three-stream form the latter belongs to
+            # batch i-1 (software pipeline, eval_rcnn.PipelinedRunner.submit) and the per-scene tails run beside the feature
+            # stream.  Geometry runs ahead in chains over groups of batches, but never beyond `end`: the warm-up and the timed
+            # region are each CLOSED -- no chain of a timed batch starts before the clock does, none is launched for a batch
+            # that will not be processed, and the first chain's latency (cold start) is inside the timed region.
+            nxt = [batches[(i + d) % n_slots] for d in range(1, runner.depth + 1) if i + d < end]
             if lagged:
                 det = runner.submit(batches[i % n_slots], nxt)
                 if det is not None:
@@ -321,16 +335,26 @@ def main():
                 copy_out(det, last)
 
         for i in range(warmup):
-            step(i)
-        drain(warmup - 1)                      # the pipeline is empty when timing starts ...
+            step(i, warmup)
+        if warmup:
+            drain(warmup - 1)                  # the pipeline is empty when timing starts ...
+        assert not getattr(runner, "_chains", None), "a geometry chain of a timed batch was started during the warm-up"
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(warmup, total):
-            step(i)
-        drain(total - 1)                       # ... and drained inside the timed region: exactly K full batches
-        torch.cuda.synchronize()
+        import gc
+        gc.collect()
+        gc.disable()                           # a generational collection inside a 70 ms timed region costs several percent
+        allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+        try:
+            t0 = time.perf_counter()
+            for i in range(warmup, total):
+                step(i, total)
+            drain(total - 1)                   # ... and drained inside the timed region: exactly K full batches
+            torch.cuda.synchronize()
+        finally:
+            gc.enable()
+        timed_run.device_allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0
         return t0, [(host_boxes[i], host_scores[i], host_num[i]) for i in range(warmup, total)]
 
     def barrier():
@@ -338,7 +362,12 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    # set-up, before the W warm-up steps: one closed run of the same loop so that the caching allocator owns the blocks the
+    # steady state needs (every hipMalloc inside a step stalls the device) and HIP has loaded every code object
+    if args.prewarm > 0:
+        timed_run(args.prewarm, 0)
     t0, dets = timed_run(args.steps, args.warmup)
+    allocs_main = getattr(timed_run, "device_allocs", None)     # hipMalloc calls inside the timed region (each one stalls the device)
     # the one exchange of the job: padded detection tables of this rank's scenes
     ids = list(range(rank * args.steps * BATCH, (rank + 1) * args.steps * BATCH))
     table, counts = E.pack_detections(ids, dets, M)
@@ -390,7 +419,8 @@ def main():
                    "scenes_per_step_per_gpu": BATCH, "points_per_scene": NPOINTS, "rois_per_scene": M,
                    "parallelism": "scene-sharded x%d, one final all_gather of detections" % world,
                    "detections_gathered": int(counts.sum()) if rank == 0 else None,
-                   "distinct_rows": distinct, "scenes_per_s_all_rows": all_rows},
+                   "distinct_rows": distinct, "scenes_per_s_all_rows": all_rows,
+                   "device_allocs_in_timed_region": allocs_main},
     }
     if rank == 0:
         if not args.no_roofline:
