@@ -163,6 +163,21 @@ class DeviceInputStage:
         row[33], row[34] = shape[0], shape[1]
         return row
 
+    def _staging(self, B, n_max, stride):
+        """Persistent PINNED staging buffers (grown on demand, two of them alternating so that the upload of batch i can
+        still be in flight while batch i+1 is packed): pinning 23 MB per call cost more than the whole device pass."""
+        import torch
+        need = B * n_max * stride
+        bufs = self.__dict__.setdefault("_pinned", [None, None])
+        k = self.__dict__.get("_flip", 0)
+        self._flip = k ^ 1
+        if bufs[k] is None or bufs[k][0].numel() < need:
+            bufs[k] = (torch.empty((need,), dtype=torch.float32).pin_memory(), torch.empty((B * 40 + 64,), dtype=torch.float32).pin_memory(), None)
+        raw, small, ev = bufs[k]
+        if ev is not None:
+            ev.synchronize()                       # the upload that last used this buffer has completed
+        return k, raw, small
+
     def __call__(self, raws, calibs, shapes, scene_ids, lidar_frame=True, image_filter=True, return_choice=False):
         import ctypes
         import torch
@@ -171,14 +186,28 @@ class DeviceInputStage:
         B = len(raws)
         stride = raws[0].shape[1]
         n_max = max(1, max(r.shape[0] for r in raws))
-        host = torch.zeros((B, n_max, stride), dtype=torch.float32).pin_memory()
-        for k, r in enumerate(raws):
-            host[k, :r.shape[0]] = torch.from_numpy(np.ascontiguousarray(r, dtype=np.float32))
         dev = self.device
+        k, pin_raw, pin_small = self._staging(B, n_max, stride)
+        host = pin_raw[:B * n_max * stride].view(B, n_max, stride)
+        hnp = host.numpy()
+        for i, r in enumerate(raws):               # rows beyond a cloud's length are never read (counts)
+            hnp[i, :r.shape[0]] = r
         raw = host.to(dev, non_blocking=True)
-        counts = torch.tensor([r.shape[0] for r in raws], dtype=torch.int32).to(dev, non_blocking=True)
-        cal = torch.from_numpy(np.stack([self.pack_calib(c, s) for c, s in zip(calibs, shapes)], 0)).to(dev, non_blocking=True)
-        seeds = torch.tensor([self.seed + int(i) for i in scene_ids], dtype=torch.int64).to(dev, non_blocking=True)
+        # the per-scene calibration rows travel as one pinned block; counts and seeds are two tiny uploads
+        meta = np.zeros((B, 38), dtype=np.float32)
+        meta[:, 0:35] = np.stack([self.pack_calib(c, s) for c, s in zip(calibs, shapes)], 0)
+        ints = np.zeros((B, 3), dtype=np.int64)
+        ints[:, 0] = [r.shape[0] for r in raws]
+        ints[:, 1] = [self.seed + int(i) for i in scene_ids]
+        small = pin_small[:B * 38].view(B, 38)
+        small.copy_(torch.from_numpy(meta))
+        small_dev = small.to(dev, non_blocking=True)
+        counts = torch.from_numpy(ints[:, 0].astype(np.int32)).to(dev, non_blocking=True)
+        seeds = torch.from_numpy(ints[:, 1]).to(dev, non_blocking=True)
+        cal = small_dev[:, 0:35].contiguous()
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        self._pinned[k] = (pin_raw, pin_small, done)
         npoints = cfg.RPN.NUM_POINTS
         out = torch.empty((B, npoints, 3), dtype=torch.float32, device=dev)
         stats = torch.empty((B, 3), dtype=torch.int32, device=dev)
