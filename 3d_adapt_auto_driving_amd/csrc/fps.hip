@@ -288,8 +288,8 @@ __global__ __launch_bounds__(1024) void fps_order_kernel(int n, const float *__r
     for (int k = t; k < n; k += 1024) perm[(long)b * n + atomicAdd(&cnt[code_of(k)], 1)] = k;
 }
 
-template <int PPT>
-__global__ __launch_bounds__(1024) void fps_pruned_kernel(
+template <int PPT, int THREADS>
+__global__ __launch_bounds__(THREADS) void fps_pruned_kernel(
     int n, int m, KeyCodec kc, const float *__restrict__ xyz, const int *__restrict__ perm,
     float *__restrict__ temp, int *__restrict__ idx)
 {
@@ -307,7 +307,6 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(
 
     float px[PPT], py[PPT], pz[PPT], pt[PPT];
     uint32_t pk[PPT];
-    int porig[PPT];
     // lane i < PPT keeps the bounding box of tile i of this wave
     float bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY, bz0 = INFINITY, bz1 = -INFINITY;
 #pragma unroll
@@ -316,13 +315,11 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(
         float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY, z0 = INFINITY, z1 = -INFINITY;
         if (s < n) {
             const int k = order[s];
-            porig[i] = k;
             px[i] = cloud[3 * k]; py[i] = cloud[3 * k + 1]; pz[i] = cloud[3 * k + 2];
             pt[i] = mind[k];
             pk[i] = kc.encode(k);
             x0 = x1 = px[i]; y0 = y1 = py[i]; z0 = z1 = pz[i];
         } else {
-            porig[i] = -1;
             px[i] = py[i] = pz[i] = 0.f;
             pt[i] = -INFINITY;
             pk[i] = 0xffffffffu;
@@ -386,7 +383,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(
     }
 #pragma unroll
     for (int i = 0; i < PPT; ++i)
-        if (porig[i] >= 0) mind[porig[i]] = pt[i];
+        if (pk[i] != 0xffffffffu) mind[kc.decode(pk[i])] = pt[i];
 }
 
 // Any-n fallback: running minima stay in `temp` (global), one 1024-thread block per cloud.
@@ -483,14 +480,18 @@ extern "C" int prcnn_furthest_point_sampling(int b, int n, int m, const float *x
         static const size_t pad_cfg = (size_t)(getenv("PRCNN_FPS_LDS_PAD") ? atoi(getenv("PRCNN_FPS_LDS_PAD")) : 84) * 1024;
         const size_t pad = b <= 128 ? pad_cfg : 0;
         if (pad) {
-            const void *k = n <= 4096 ? (const void *)fps_pruned_kernel<4> : n <= 8192 ? (const void *)fps_pruned_kernel<8>
-                                                                                       : (const void *)fps_pruned_kernel<16>;
-            const int rc = ensure_dynamic_lds(k, pad, "furthest_point_sampling(pruned)");
-            if (rc != PRCNN_OK) return rc;
+            const void *ks[3] = {(const void *)fps_pruned_kernel<4, 1024>, (const void *)fps_pruned_kernel<8, 1024>,
+                                 (const void *)fps_pruned_kernel<16, 1024>};
+            for (const void *k : ks) {
+                const int rc = ensure_dynamic_lds(k, pad, "furthest_point_sampling(pruned)");
+                if (rc != PRCNN_OK) return rc;
+            }
         }
-        if (n <= 4096) hipLaunchKernelGGL(fps_pruned_kernel<4>, dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
-        else if (n <= 8192) hipLaunchKernelGGL(fps_pruned_kernel<8>, dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
-        else hipLaunchKernelGGL(fps_pruned_kernel<16>, dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
+        // 16 waves per cloud: 8 waves x 32 points per lane runs 4.98 ms, 4 waves x 64 points 7.7 ms (16384 -> 4096, 4.2-4.3 ms here):
+        // the per-iteration update of the touched tiles parallelises over waves, the exchange does not get cheaper with fewer
+        if (n <= 4096) hipLaunchKernelGGL((fps_pruned_kernel<4, 1024>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
+        else if (n <= 8192) hipLaunchKernelGGL((fps_pruned_kernel<8, 1024>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
+        else hipLaunchKernelGGL((fps_pruned_kernel<16, 1024>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
         return check_launch("furthest_point_sampling(pruned)");
     }
     if (n <= 128) launch_reg<1, 2>(b, n, m, kc, xyz, temp, idx, st);
