@@ -9,8 +9,11 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "fps_pruned_kernel<16>" in r["Kernel_Name"]]   # one per step (SA1 FPS)
-a, b = marks[-4], marks[-3]                                                               # a late, steady-state step
+marks = [i for i, r in enumerate(rows) if "fps_pruned_kernel<16" in r["Kernel_Name"]]   # one per step (SA1 FPS)
+# a late window that holds a whole group of steps (at the cold start of a closed timed run two chains are launched back to back)
+pairs = [(a, b) for a, b in zip(marks[:-1], marks[1:])
+         if sum(1 for r in rows[a:b] if "sa_xyz_mlp" in r["Kernel_Name"] and "<32" in r["Kernel_Name"]) >= 3]
+a, b = pairs[-1]
 sel = rows[a:b]
 wall = (int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 1e3
 by = collections.defaultdict(lambda: [0, 0.0])
@@ -20,7 +23,7 @@ for r in sel:
     by[r["Kernel_Name"][:100]][0] += 1
     by[r["Kernel_Name"][:100]][1] += d
     stream[r.get("Stream_Id", "?")] += d
-steps = max(1, sum(1 for r in sel if "sa_xyz_mlp_kernel<32" in r["Kernel_Name"]))
+steps = max(1, sum(1 for r in sel if "sa_xyz_mlp" in r["Kernel_Name"] and "<32" in r["Kernel_Name"]))
 print("# %s\n" % sys.argv[2])
 print("Window between two consecutive SA1 FPS launches = one geometry group = %d steps (batches of 8 scenes).  PER STEP: wall "
       "%.2f ms under the profiler (the profiler makes the run host-bound; unprofiled step time is in the bench line), sum of "
