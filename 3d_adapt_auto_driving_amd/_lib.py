@@ -41,6 +41,7 @@ SIGNATURES = {
     "prcnn_packed_layer": [_P, C.c_long, C.c_long, _I, _I, _I, _P, C.c_long, _P, _P, _I, _P, C.c_long, _P],
     "prcnn_sa_xyz_mlp_packed": [_I, _I, _I, _I, _I, C.c_long] + [_P] * 11 + [_I, _I, _P],
     "prcnn_rows_dot": [C.c_long, _I, _I, _P, C.c_long, _P, _P, _P, C.c_long, _P],
+    "prcnn_rpn_tail": [_I, _I, _I] + [_P] * 7 + [_I] + [_P] * 4,
     "prcnn_packed_layer_segmax": [_I, _I, C.c_long, _I, _I, _P, C.c_long, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "prcnn_maxpool_pm": [C.c_long, _I, _I, _P, _P, _I, _I, _P],
     "prcnn_three_interpolate_pm": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P],

@@ -17,10 +17,12 @@
 // Summation order: panels in order, inside a panel k = s, s + 64 for s = 0..63 -- oracle/mlp_oracle.c
 // orc_rows_layer_mfma reproduces it bit for bit.
 #include "common.hpp"
+#include <cstdlib>
 #include "segmax.hpp"
 
 namespace prcnn {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int PL_ROWS = 64;
 constexpr int PL_LD = 128 + 4;
 
@@ -50,9 +52,40 @@ __global__ __launch_bounds__(256) void packed_gather_affine_kernel(
     }
 }
 
+#define PL_LOAD_W(dst, kk)                                                                              \
+    _Pragma("unroll") for (int s = 0; s < 64; ++s)                                                      \
+        dst[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, lane_off, (unsigned int)((kk) + s) * row_bytes, 0));
+#define PL_LOAD_A(dst, kk)                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                     \
+        long g = t * PL_ROWS + r0 + 8 * i;                                                              \
+        if (g >= rows) g = rows - 1; /* ragged last tile (host-count mode): recompute the last row */   \
+        dst[i] = *reinterpret_cast<const f32x4 *>(A + g * lda + (kk) + 4 * chunk);                     \
+    }
+#define PL_STORE_A(src)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                       \
+        *reinterpret_cast<f32x4 *>(tile + (r0 + 8 * i) * PL_LD + 4 * chunk) = src[i];
+// s_waitcnt vmcnt(0) (expcnt / lgkmcnt left alone): said explicitly so that the compiler's wait-count bookkeeping knows nothing
+// older than the prefetch issued next is outstanding, and puts no wait between that prefetch and the MFMAs that hide it
+#define PL_VM_DRAIN __builtin_amdgcn_s_waitcnt(0x0F70);
+#define PL_MFMA(wf)                                                                                     \
+    _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                    \
+        const float4 a0 = *reinterpret_cast<const float4 *>(a0p + 4 * g);                               \
+        const float4 a1 = *reinterpret_cast<const float4 *>(a1p + 4 * g);                               \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wf[4 * g + 0], acc0, 0, 0, 0);                \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wf[4 * g + 0], acc1, 0, 0, 0);                \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wf[4 * g + 1], acc0, 0, 0, 0);                \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, wf[4 * g + 1], acc1, 0, 0, 0);                \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, wf[4 * g + 2], acc0, 0, 0, 0);                \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, wf[4 * g + 2], acc1, 0, 0, 0);                \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, wf[4 * g + 3], acc0, 0, 0, 0);                \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wf[4 * g + 3], acc1, 0, 0, 0);                \
+    }
+
 // SEGMAX = false: out[r][n0 + ..] = act(A[r] @ W + bias) for the tile's rows (rows >= `rows` are not stored)
 // SEGMAX = true : segmented max over the tile's rows by centre -> atomicMax into out[centre][out_col + n0 + ..]
-template <bool SEGMAX>
+// PIPE: K >= 256 -- the next 128-deep panel (weights and the tile's rows of A) is fetched into registers while the MFMAs
+//       of the current one run; the k order of every dot product is the same as without it (panels in sequence).
+template <bool SEGMAX, bool PIPE>
 __global__ __launch_bounds__(256, 2) void packed_layer_kernel(
     const unsigned int *__restrict__ hdr, long rows_host, int K, int N, const float *__restrict__ A, long lda,
     const float *__restrict__ W, const float *__restrict__ bias, int do_relu, float *__restrict__ out, long ldo,
@@ -69,32 +102,48 @@ __global__ __launch_bounds__(256, 2) void packed_layer_kernel(
     f32x16 acc0 = {0}, acc1 = {0};
     const float *a0p = tile + j * PL_LD + 64 * h;
     const float *a1p = tile + (32 + j) * PL_LD + 64 * h;
-    for (int k0 = 0; k0 < K; k0 += 128) {
-        float wf[64];
-#pragma unroll
-        for (int s = 0; s < 64; ++s) wf[s] = W[(long)(k0 + s + 64 * h) * N + n0 + 32 * w + j];
-        if (k0) __syncthreads();                           // every wave has finished reading the previous panel
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = r0 + 8 * i;
-            long g = t * PL_ROWS + row;
-            if (g >= rows) g = rows - 1;                   // ragged last tile (host-count mode): recompute the last row
-            *reinterpret_cast<float4 *>(tile + row * PL_LD + 4 * chunk) =
-                *reinterpret_cast<const float4 *>(A + g * lda + k0 + 4 * chunk);
+    // weights through a buffer resource: one 32-bit lane offset in a VGPR, the row offset of each load in a scalar register
+    // (no per-load 64-bit address registers: the two-panel pipeline needs the space for the weights themselves)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, K * N * 4, 0x00020000);
+    const unsigned int row_bytes = (unsigned int)N * 4u;
+    const unsigned int lane_off = ((unsigned int)(64 * h) * (unsigned int)N + (unsigned int)(n0 + 32 * w + j)) * 4u;
+    if constexpr (PIPE) {
+        float wa[64], wb[64];
+        f32x4 ar[8];
+        PL_LOAD_W(wa, 0)
+        PL_LOAD_A(ar, 0)
+        for (int k0 = 0; k0 < K; k0 += 256) {
+            if (k0) __syncthreads();                       // every wave has finished reading the previous panel
+            PL_STORE_A(ar)
+            PL_VM_DRAIN                                    // this panel's weights came in with its rows
+            __syncthreads();
+            const bool odd = k0 + 128 < K;
+            if (odd) {
+                PL_LOAD_W(wb, k0 + 128)
+                PL_LOAD_A(ar, k0 + 128)
+            }
+            PL_MFMA(wa)
+            if (!odd) break;
+            __syncthreads();
+            PL_STORE_A(ar)
+            PL_VM_DRAIN
+            __syncthreads();
+            if (k0 + 256 < K) {
+                PL_LOAD_W(wa, k0 + 256)
+                PL_LOAD_A(ar, k0 + 256)
+            }
+            PL_MFMA(wb)
         }
-        __syncthreads();
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(a0p + 4 * g);
-            const float4 a1 = *reinterpret_cast<const float4 *>(a1p + 4 * g);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wf[4 * g + 0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wf[4 * g + 0], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wf[4 * g + 1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, wf[4 * g + 1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, wf[4 * g + 2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, wf[4 * g + 2], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, wf[4 * g + 3], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wf[4 * g + 3], acc1, 0, 0, 0);
+    } else {
+        for (int k0 = 0; k0 < K; k0 += 128) {
+            float wf[64];
+            f32x4 ar[8];
+            PL_LOAD_W(wf, k0)
+            PL_LOAD_A(ar, k0)
+            if (k0) __syncthreads();                       // every wave has finished reading the previous panel
+            PL_STORE_A(ar)
+            __syncthreads();
+            PL_MFMA(wf)
         }
     }
     const float bcol = bias[n0 + 32 * w + j];
@@ -169,6 +218,13 @@ __global__ __launch_bounds__(256) void rows_dot_kernel(long rows, int K, int n, 
 
 using namespace prcnn;
 
+// PRCNN_PL_PIPE=0: the one-panel-at-a-time loop for every K (A/B runs of profiles/layer_probe.py; same results either way)
+static bool pipe_enabled()
+{
+    static const bool on = [] { const char *e = getenv("PRCNN_PL_PIPE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 extern "C" int prcnn_rows_dot(long rows, int K, int n, const float *A, long lda, const float *W, const float *bias, float *out,
                               long ldo, void *stream)
 {
@@ -212,8 +268,9 @@ extern "C" int prcnn_packed_layer(const unsigned int *hdr, long rows, long max_t
     PRCNN_REQUIRE(A && W && bias && out, "packed_layer: null pointer");
     PRCNN_REQUIRE(((uintptr_t)A & 15) == 0 && (((uintptr_t)out & 15) == 0 || (ldo & 3) != 0), "packed_layer: 16-byte alignment required");
     const int col_blocks = (n_store + 127) / 128;          // column blocks that hold nothing to store are not launched
-    hipLaunchKernelGGL(packed_layer_kernel<false>, dim3((unsigned)tiles, col_blocks), dim3(256), 0, (hipStream_t)stream, hdr, rows, K, N,
-                       A, lda, W, bias, relu, out, ldo, nullptr, nullptr, 0, 0, n_store);
+    auto kern = K >= 256 && pipe_enabled() ? packed_layer_kernel<false, true> : packed_layer_kernel<false, false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, col_blocks), dim3(256), 0, (hipStream_t)stream, hdr, rows, K, N, A, lda, W, bias,
+                       relu, out, ldo, nullptr, nullptr, 0, 0, n_store);
     return check_launch("packed_layer");
 }
 
@@ -235,7 +292,8 @@ extern "C" int prcnn_packed_layer_segmax(int b, int m, long max_tiles, int K, in
         return PRCNN_ELAUNCH;
     }
     if (max_tiles == 0) return PRCNN_OK;
-    hipLaunchKernelGGL(packed_layer_kernel<true>, dim3((unsigned)max_tiles, N / 128), dim3(256), 0, st, hdr, 0L, K, N, A, lda, W, bias,
-                       1, out, (long)out_stride, rowinfo, tilecloud, m, out_col, N);
+    auto kern = K >= 256 && pipe_enabled() ? packed_layer_kernel<true, true> : packed_layer_kernel<true, false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)max_tiles, N / 128), dim3(256), 0, st, hdr, 0L, K, N, A, lda, W, bias, 1, out,
+                       (long)out_stride, rowinfo, tilecloud, m, out_col, N);
     return check_launch("packed_layer_segmax");
 }

@@ -1,0 +1,296 @@
+// The last stretch of the RPN over all input points, one kernel instead of nine: the finest feature-propagation module
+// (pointnet2_modules.py:136-160 PointnetFPModule with no skip features: three_interpolate -> SharedMLP 256-128-128) and the
+// two per-point heads on its output (rpn.py:28-50: cls 128-128-1, reg 128-128-reg_channel; Conv1d + BN folded, dropout is
+// the identity in eval mode).
+//
+// Layer by layer these are GEMMs at the ridge of the machine (K = N = 128: 32 flop per HBM byte), and each one writes its
+// activations to HBM for the next one to read back: 0.9 GB per B = 8 step for 26 GFLOP.  Here a 64-row tile stays in LDS from
+// the interpolation to the last head layer; HBM sees the gathered coarse features (L2-resident table), the 128 backbone
+// features, the score and the regression vector of every point -- nothing else.
+//
+// Arithmetic is that of the separate kernels, bit for bit, so the same oracle functions check it (oracle/mlp_oracle.c
+// orc_rows_layer_mfma, orc_rows_dot; oracle/prcnn_oracle.c orc_three_interpolate):
+//   interpolation  (w0*f0 + w1*f1) + w2*f2, one rounding per operation         (csrc/pointmajor.hip)
+//   layers         v_mfma_f32_32x32x2_f32 over 128-deep panels, k = s on lanes 0-31 and s + 64 on lanes 32-63, panels in
+//                  sequence, then + bias, then ReLU                           (csrc/packed_layer.hip)
+//   score          32 lanes per row, lane l sums k = l, l+32, l+64, l+96 as one fma chain, xor butterfly 16..1, + bias
+//                                                                              (csrc/packed_layer.hip rows_dot_kernel)
+//
+// One workgroup = 4 waves = a 64-row tile at a time, persistent over tiles (drawn from a ticket counter), 2 workgroups per CU.  Wave w owns
+// output columns 32w .. 32w+31 of every layer; its 128 x 32 weight slice of the NEXT layer is fetched into registers while the
+// MFMAs of the current one run (two register sets, six panel stages per tile, so the roles repeat tile after tile).
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+#include "../../include/prcnn_hip.h"
+
+namespace prcnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RT_ROWS = 64;
+constexpr int RT_LD = 128 + 4;
+#ifndef RT_IROWS
+#define RT_IROWS 4                  // rows a wave interpolates per round (3 x RT_IROWS 1 KB gathers in flight per wave)
+#endif
+
+struct RpnTailArgs {
+    long rows;
+    int n, m;                       // points per cloud (fine level), known points per cloud (coarse level)
+    const float *known;             // (b, m, 256)
+    const int *idx;                 // (rows, 3)
+    const float *weight;            // (rows, 3)
+    const float *wcat;              // (768,128): FP layer 1 (256 rows) | FP layer 2 | cls layer 1 | reg layer 1 | reg layer 2 (128 each,
+                                    // the last one zero-padded beyond n_reg columns), all k-major with BN folded
+    const float *bcat;              // (5,128): their biases
+    const float *wc2, *bc2;         // cls layer 2: (128,1), (1)
+    float *feats, *cls, *reg;       // (rows,128), (rows,1), (rows,n_reg)
+    int n_reg;
+    unsigned int *ticket;           // tile counter of this launch (zero on entry)
+};
+
+// s_waitcnt vmcnt(0): said explicitly before every prefetch so that the compiler's wait-count bookkeeping knows nothing older
+// is outstanding and puts no wait between the prefetch and the MFMAs that hide it (a vmcnt above 63 cannot be encoded)
+#define RT_VM_DRAIN __builtin_amdgcn_s_waitcnt(0x0F70);
+#define RT_LOAD_W(dst, rs, krow)                                                                          \
+    _Pragma("unroll") for (int s = 0; s < 64; ++s)                                                        \
+        dst[s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, lane_off, (unsigned int)((krow) + s) * 512u, 0)); \
+    __builtin_amdgcn_sched_barrier(0);
+// One 128-deep panel: 16 k-groups of 8 MFMAs.  A wave issues in order, so everything that is not an MFMA is placed where
+// the matrix pipe is busy anyway:
+//   * the A operands of group g+1 are read from LDS before the MFMAs of group g (a ds_read in front of its first use idles
+//     the pipe for an LDS round trip per group);
+//   * the 64 weight loads of the NEXT panel stage (wn <- rows krow.. of the weight buffer) go out four per group, behind
+//     this group's first MFMAs, instead of 64 in a row in front of the stage (their issue alone was ~10 % of a stage);
+//   * FIRST: the accumulators start from the inline constant 0 in the first MFMA (no 32 v_mov per stage).
+#define RT_STAGE(T, wf, wn, krow, FIRST)                                                                  \
+    {                                                                                                     \
+        f32x4 a0 = *reinterpret_cast<const f32x4 *>((T) + j * RT_LD + 64 * h);                            \
+        f32x4 a1 = *reinterpret_cast<const f32x4 *>((T) + (32 + j) * RT_LD + 64 * h);                     \
+        _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                  \
+            f32x4 n0 = a0, n1 = a1;                                                                       \
+            if (g < 15) {                                                                                 \
+                n0 = *reinterpret_cast<const f32x4 *>((T) + j * RT_LD + 64 * h + 4 * (g + 1));            \
+                n1 = *reinterpret_cast<const f32x4 *>((T) + (32 + j) * RT_LD + 64 * h + 4 * (g + 1));     \
+            }                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            if ((FIRST) && g == 0) {                                                                      \
+                const f32x16 zero = {0};                                                                  \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wf[0], zero, 0, 0, 0);                  \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wf[0], zero, 0, 0, 0);                  \
+            } else {                                                                                      \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wf[4 * g + 0], acc0, 0, 0, 0);          \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wf[4 * g + 0], acc1, 0, 0, 0);          \
+            }                                                                                             \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                 \
+                wn[4 * g + q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(                     \
+                    rs, lane_off, (unsigned int)((krow) + 4 * g + q) * 512u, 0));                         \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wf[4 * g + 1], acc0, 0, 0, 0);              \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, wf[4 * g + 1], acc1, 0, 0, 0);              \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, wf[4 * g + 2], acc0, 0, 0, 0);              \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, wf[4 * g + 2], acc1, 0, 0, 0);              \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, wf[4 * g + 3], acc0, 0, 0, 0);              \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wf[4 * g + 3], acc1, 0, 0, 0);              \
+            a0 = n0; a1 = n1;                                                                             \
+        }                                                                                                 \
+    }
+// act(acc + bias) of this wave's 64 x 32 block -> tile T (the next layer's A operand)
+#define RT_EPILOGUE(T, bias, RELU)                                                                        \
+    {                                                                                                     \
+        const float bcol = (bias);                                                                        \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                  \
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;                                               \
+            const float v0 = acc0[r] + bcol, v1 = acc1[r] + bcol;                                         \
+            (T)[row * RT_LD + 32 * w + j] = (RELU) ? fmaxf(v0, 0.f) : v0;                                 \
+            (T)[(32 + row) * RT_LD + 32 * w + j] = (RELU) ? fmaxf(v1, 0.f) : v1;                          \
+        }                                                                                                 \
+    }
+
+__global__ __launch_bounds__(256, 2) void rpn_tail_kernel(const RpnTailArgs a)
+{
+    __shared__ float T0[RT_ROWS * RT_LD];
+    __shared__ float T1[RT_ROWS * RT_LD];
+    __shared__ unsigned int slot[2];
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = tid & 31, r0 = tid >> 5;
+    const long tiles = (a.rows + RT_ROWS - 1) / RT_ROWS;
+    const unsigned int lane_off = ((unsigned int)(64 * h) * 128u + (unsigned int)(32 * w + j)) * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.wcat, 0, 768 * 128 * 4, 0x00020000);
+    const float wd0 = a.wc2[j], wd1 = a.wc2[j + 32], wd2 = a.wc2[j + 64], wd3 = a.wc2[j + 96], bd = a.bc2[0];
+    const f32x4 *known4 = reinterpret_cast<const f32x4 *>(a.known);
+    const float bias1 = a.bcat[32 * w + j], bias2 = a.bcat[128 + 32 * w + j], biasc = a.bcat[256 + 32 * w + j],
+                biasr1 = a.bcat[384 + 32 * w + j], biasr2 = a.bcat[512 + 32 * w + j];
+
+    // neighbour indices / weights / cloud of the 16 rows this wave interpolates in tile `tt`: one coalesced load each
+    int nx_i, nx_cloud;
+    float nx_w;
+#define RT_FETCH_IDX(tt)                                                                                  \
+    {                                                                                                     \
+        long ge = (tt) * RT_ROWS + 16 * w + lane / 3;                                                     \
+        if (ge >= a.rows) ge = a.rows - 1; /* ragged last tile (or no next tile): the last row, never stored */ \
+        const long el = ge * 3 + lane % 3;                                                                \
+        nx_i = lane < 48 ? a.idx[el] : 0;                                                                 \
+        nx_w = lane < 48 ? a.weight[el] : 0.f;                                                            \
+        nx_cloud = (int)(ge / a.n);                                                                       \
+    }
+    // Tiles come from a ticket counter, not a static stride: the step runs this kernel next to other streams' kernels
+    // (sampling chains hold 32 CUs for milliseconds), and a workgroup slowed down by a neighbour must not stretch the launch.
+    // The NEXT tile's ticket is drawn during the interpolation and published through LDS by the barrier that ends it.
+    if (tid == 0) slot[0] = atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    long t = __builtin_amdgcn_readfirstlane((int)slot[0]);   // wave-uniform: tile arithmetic stays in scalar registers
+    RT_FETCH_IDX(t)
+    float wa[64], wb[64];
+    f32x16 acc0, acc1;
+    RT_LOAD_W(wa, rs, 0)
+    for (unsigned int served = 0; t < tiles; ++served) {
+        // ---- interpolation: wave w builds rows 16w .. 16w+15 of the 64 x 256 input tile (columns 0-127 -> T0, 128-255 -> T1);
+        //      a lane owns one float4 of the row, so every neighbour row is one coalesced 1 KB read
+        {
+            // (the 16 rows' 48 neighbour indices and weights were fetched one tile ahead: lane l < 48 holds element l)
+            const int my_i = nx_i;
+            const float my_w = nx_w;
+            const int cloud_lane = nx_cloud;                   // lane 3q holds row q's cloud
+#pragma unroll
+            for (int rr = 0; rr < 16; rr += RT_IROWS) {
+                f32x4 f[RT_IROWS][3];
+#pragma unroll
+                for (int q = 0; q < RT_IROWS; ++q) {
+                    const long cloud = __builtin_amdgcn_readlane(cloud_lane, 3 * (rr + q));
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        const int i = __builtin_amdgcn_readlane(my_i, 3 * (rr + q) + e);
+                        f[q][e] = known4[(cloud * a.m + i) * 64 + lane];
+                    }
+                }
+                // the next tile's ticket, drawn behind the first round of gathers (its round trip hides in theirs); the
+                // barrier that ends the interpolation publishes it
+                if (rr == 0 && tid == 0) slot[(served + 1) & 1] = atomicAdd(a.ticket, 1u);
+#pragma unroll
+                for (int q = 0; q < RT_IROWS; ++q) {
+                    const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), 3 * (rr + q)));
+                    const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), 3 * (rr + q) + 1));
+                    const float w2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), 3 * (rr + q) + 2));
+                    f32x4 v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        v[c] = __fadd_rn(__fadd_rn(__fmul_rn(w0, f[q][0][c]), __fmul_rn(w1, f[q][1][c])), __fmul_rn(w2, f[q][2][c]));
+                    float *dst = (lane < 32 ? T0 : T1) + (16 * w + rr + q) * RT_LD + 4 * (lane & 31);
+                    *reinterpret_cast<f32x4 *>(dst) = v;
+                }
+            }
+        }
+        RT_VM_DRAIN                                            // (also: this tile's first panel, fetched during the last stage)
+        lds_barrier();
+        // ---- FP layer 1, panel 0 (wa) while panel 1 (wb) comes in
+        RT_STAGE(T0, wa, wb, 128, true)
+        // ---- FP layer 1, panel 1 (wb) while layer 2 (wa) comes in
+        RT_VM_DRAIN
+        RT_STAGE(T1, wb, wa, 256, false)
+        lds_barrier();                                         // every wave has read both input panels
+        RT_EPILOGUE(T0, bias1, true)
+        lds_barrier();
+        // ---- FP layer 2 (wa) while cls layer 1 (wb) comes in; its output = the backbone features
+        RT_VM_DRAIN
+        RT_STAGE(T0, wa, wb, 384, true)
+        RT_EPILOGUE(T1, bias2, true)
+        lds_barrier();
+        // ---- cls layer 1 (wb) while reg layer 1 (wa) comes in; the feature rows go out meanwhile
+        RT_VM_DRAIN
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = r0 + 8 * i;
+            const unsigned int g = (unsigned int)t * RT_ROWS + row;
+            if (g < (unsigned int)a.rows)
+                *reinterpret_cast<f32x4 *>(a.feats + (g * 128u + 4u * chunk)) = *reinterpret_cast<const f32x4 *>(T1 + row * RT_LD + 4 * chunk);
+        }
+        RT_STAGE(T1, wb, wa, 512, true)
+        RT_EPILOGUE(T0, biasc, true)
+        lds_barrier();
+        // ---- score = cls layer 2 (a 128-long dot product per row), then reg layer 1 (wa) while reg layer 2 (wb) comes in
+        RT_VM_DRAIN
+        const long tn = __builtin_amdgcn_readfirstlane((int)slot[(served + 1) & 1]);
+        RT_FETCH_IDX(tn)
+        {
+            // 8 rows per half-wave pass, the 8 passes side by side: 5 rounds of 8 independent lane exchanges instead of 8
+            // dependent chains of 5 (same additions per row, in the same order)
+            float sd[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const float *ar = T0 + (r0 + 8 * p) * RT_LD + j;
+                float v = fmaf(ar[0], wd0, 0.f);
+                v = fmaf(ar[32], wd1, v);
+                v = fmaf(ar[64], wd2, v);
+                sd[p] = fmaf(ar[96], wd3, v);
+            }
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) {
+                float o[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) o[p] = __shfl_xor(sd[p], d, 32);
+#pragma unroll
+                for (int p = 0; p < 8; ++p) sd[p] = __fadd_rn(sd[p], o[p]);
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const unsigned int g = (unsigned int)t * RT_ROWS + r0 + 8 * p;
+                if (j == 0 && g < (unsigned int)a.rows) a.cls[g] = __fadd_rn(sd[p], bd);
+            }
+        }
+        RT_STAGE(T1, wa, wb, 640, true)
+        lds_barrier();                                         // every wave has read the cls hidden rows
+        RT_EPILOGUE(T0, biasr1, true)
+        lds_barrier();
+        // ---- reg layer 2 (wb, no activation) while the next tile's first panel (wa) comes in
+        RT_VM_DRAIN
+        RT_STAGE(T0, wb, wa, 0, true)
+        RT_EPILOGUE(T1, biasr2, false)
+        lds_barrier();
+        if (4 * chunk < a.n_reg) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = r0 + 8 * i;
+                const unsigned int g = (unsigned int)t * RT_ROWS + row;
+                if (g < (unsigned int)a.rows)
+                    *reinterpret_cast<f32x4 *>(a.reg + (g * (unsigned int)a.n_reg + 4u * chunk)) =
+                        *reinterpret_cast<const f32x4 *>(T1 + row * RT_LD + 4 * chunk);
+            }
+        }
+        lds_barrier();                                         // T1 is free for the next tile's interpolation
+        t = tn;
+    }
+}
+
+}  // namespace prcnn
+
+namespace prcnn {
+unsigned int *next_ticket(hipStream_t st);    // sa_mlp_fused.hip
+}
+
+using namespace prcnn;
+
+extern "C" int prcnn_rpn_tail(int b, int n, int m, const float *known, const int *idx, const float *weight, const float *wcat,
+                              const float *bcat, const float *wc2, const float *bc2, int n_reg, float *feats, float *cls,
+                              float *reg, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 1 && n_reg >= 4 && n_reg <= 128 && n_reg % 4 == 0,
+                  "rpn_tail: bad sizes (n_reg=%d must be a multiple of 4 in 4..128)", n_reg);
+    const long rows = (long)b * n;
+    if (rows == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(rows <= (1L << 23), "rpn_tail: too many points (32-bit element offsets)");
+    PRCNN_REQUIRE(known && idx && weight && wcat && bcat && wc2 && bc2 && feats && cls && reg, "rpn_tail: null pointer");
+    PRCNN_REQUIRE((((uintptr_t)known | (uintptr_t)feats | (uintptr_t)wcat | (uintptr_t)reg) & 15) == 0,
+                  "rpn_tail: 16-byte alignment required");
+    RpnTailArgs a;
+    a.rows = rows; a.n = n; a.m = m; a.known = known; a.idx = idx; a.weight = weight;
+    a.wcat = wcat; a.bcat = bcat; a.wc2 = wc2; a.bc2 = bc2; a.feats = feats; a.cls = cls; a.reg = reg; a.n_reg = n_reg;
+    a.ticket = next_ticket((hipStream_t)stream);
+    if (!a.ticket) { set_error("rpn_tail: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
+    const long tiles = (rows + RT_ROWS - 1) / RT_ROWS;
+    const long grid = tiles < 512 ? tiles : 512;           // gfx950: 256 CUs x 2 resident workgroups
+    hipLaunchKernelGGL(rpn_tail_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("rpn_tail");
+}

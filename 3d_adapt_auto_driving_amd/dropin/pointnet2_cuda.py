@@ -258,6 +258,19 @@ def rows_dot_wrapper(a, wt, bias, out):
     return out
 
 
+def rpn_tail_wrapper(known, idx, weight, wcat, bcat, wc2, bc2, feats, cls, reg):
+    """Finest FP module + both RPN heads in one kernel (csrc/rpn_tail.hip): known (b,m,256), idx / weight (b,n,3) ->
+    feats (b,n,128), cls (b,n,1), reg (b,n,n_reg)."""
+    _chk(torch.float32, known, weight, wcat, bcat, wc2, bc2, feats, cls, reg); _chk(torch.int32, idx)
+    b, m, c = known.shape
+    if c != 256 or tuple(wcat.shape) != (768, 128) or tuple(bcat.shape) != (5, 128) or wc2.numel() != 128 or feats.size(-1) != 128:
+        raise RuntimeError("pointnet2_cuda: rpn_tail is written for 256 interpolated channels and 128-wide layers")
+    _lib.call("prcnn_rpn_tail", b, idx.size(1), m, known.data_ptr(), idx.data_ptr(), weight.data_ptr(), wcat.data_ptr(),
+              bcat.data_ptr(), wc2.data_ptr(), bc2.data_ptr(), reg.size(-1), feats.data_ptr(), cls.data_ptr(), reg.data_ptr(),
+              _lib.current_stream(known))
+    return feats, cls, reg
+
+
 def packed_layer_segmax_wrapper(a, wt, bias, pack, b, m, out, out_col):
     """Last layer of a level + max pool over a packed row list: out (b,m,stride)[..., out_col:out_col+N]."""
     _chk(torch.float32, a, wt, bias, out)

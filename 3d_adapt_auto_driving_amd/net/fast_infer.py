@@ -42,6 +42,8 @@ USE_POINT_LAYER = os.environ.get("PRCNN_LIB_GEMM") is None     # per-point layer
 # every per-point width zero-padded to a multiple of 128 (SA level outputs, FP inputs, narrow head outputs), so that NO layer
 # of the engine is left to a GEMM library: fixed summation order everywhere, reproduced bit for bit by the oracle
 PAD128 = USE_PACKED and USE_POINT_LAYER
+# the finest FP module and both RPN heads in one kernel (csrc/rpn_tail.hip); PRCNN_NO_RPN_TAIL=1: layer by layer (A/B, same bits)
+USE_RPN_TAIL = os.environ.get("PRCNN_NO_RPN_TAIL") is None
 
 
 def _round4(c):
@@ -242,6 +244,7 @@ class FastPointRCNN:
             self.fp.append(_Mlp(lay, pad128=PAD128, in_parts=[c for c in (known, skip) if c], pad_out=True))
         self.rpn_cls = _Mlp(_fold_head(rpn.rpn_cls_layer), pad128=PAD128)
         self.rpn_reg = _Mlp(_fold_head(rpn.rpn_reg_layer), pad128=PAD128)
+        self.rpn_tail = self._fold_rpn_tail() if (USE_RPN_TAIL and PAD128 and USE_POINT_LAYER) else None
         if cfg.RCNN.ENABLED:
             r = model.rcnn_net
             self.xyz_up = _Mlp(_fold_shared_mlp(r.xyz_up_layer))
@@ -255,6 +258,21 @@ class FastPointRCNN:
                                      _Mlp(_fold_shared_mlp(mlp), grouped_c=cin), cin))
             self.rcnn_cls = _Mlp(_fold_head(r.cls_layer), pad128=PAD128)
             self.rcnn_reg = _Mlp(_fold_head(r.reg_layer), pad128=PAD128)
+
+    def _fold_rpn_tail(self):
+        """Weights of csrc/rpn_tail.hip (finest FP module + both RPN heads in one kernel) when the network has the shape that
+        kernel is written for -- 256 interpolated channels, no skip features, 128-wide layers, a 1-wide score, a regression
+        vector of a multiple of 4 (<= 128) channels: default.yaml / double.yaml.  Anything else runs layer by layer."""
+        fp0, cl, rg = self.fp[0], self.rpn_cls, self.rpn_reg
+        shapes = lambda m: [tuple(l[0].shape) for l in m.layers]
+        relus = lambda m: [bool(l[2]) for l in m.layers]
+        if (shapes(fp0) != [(256, 128), (128, 128)] or relus(fp0) != [True, True] or
+                shapes(cl) != [(128, 128), (128, 128)] or relus(cl) != [True, False] or cl.narrow is None or cl.n_out != 1 or
+                shapes(rg) != [(128, 128), (128, 128)] or relus(rg) != [True, False] or rg.n_out % 4 or not 4 <= rg.n_out <= 128):
+            return None
+        mats = [fp0.layers[0], fp0.layers[1], cl.layers[0], rg.layers[0], rg.layers[1]]
+        return {"wcat": torch.cat([m[0] for m in mats], dim=0).contiguous(), "bcat": torch.stack([m[1] for m in mats]).contiguous(),
+                "wc2": cl.narrow[0].contiguous().view(-1), "bc2": cl.narrow[1].contiguous(), "n_reg": rg.n_out}
 
     def check_weights(self):
         """The engine folds BatchNorm into its own copies of the weights at construction.  Loading a checkpoint (or editing
@@ -395,7 +413,8 @@ class FastPointRCNN:
             y = mlp(grouped.view(B * M * ns, -1))
         ext.maxpool_pm_wrapper(y, ns, out, out_col)
 
-    def _backbone(self, xyz, geo):
+    def _backbone(self, xyz, geo, fuse_tail=False):
+        """-> the (B, N, 128) point features; fuse_tail: -> (features, None), or (None, inputs of the fused last stretch)."""
         l_xyz, l_feat = geo["l_xyz"], [None]
         for (npoint, scales), lev in zip(self.sa, geo["sa"]):
             cur_xyz, cur_feat = l_xyz[len(l_feat) - 1], l_feat[-1]
@@ -415,6 +434,8 @@ class FastPointRCNN:
             k = len(self.fp) + i                               # FP module index == fine level
             known_feat, skip = l_feat[k + 1], l_feat[k]
             idx, weight = geo["fp"][k]
+            if fuse_tail and k == 0 and self.rpn_tail is not None and skip is None and known_feat.shape[2] == 256:
+                return None, (known_feat, idx, weight)         # finest level: fused with the heads (rpn_stage)
             B, n = idx.shape[0], idx.shape[1]
             c2 = known_feat.shape[2]
             c1 = 0 if skip is None else skip.shape[2]
@@ -423,7 +444,7 @@ class FastPointRCNN:
             if c1:
                 buf[:, :, c2:] = skip
             l_feat[k] = self.fp[k](buf.view(B * n, c2 + c1)).view(B, n, -1)
-        return l_feat[0]                                       # (B, N, 128) point-major (zero-padded to 128s under PAD128)
+        return (l_feat[0], None) if fuse_tail else l_feat[0]   # (B, N, 128) point-major (zero-padded to 128s under PAD128)
 
     # ------------------------------------------------------------------ full forward
     @torch.no_grad()
@@ -437,12 +458,21 @@ class FastPointRCNN:
         if geo is None:
             geo = self.geometry(xyz)
         B, N, _ = xyz.shape
-        feats = self._backbone(xyz, geo)
-        flat = feats.view(B * N, -1)
-        rpn_cls = self.rpn_cls(flat).view(B, N, -1)
-        rpn_reg = self.rpn_reg(flat).view(B, N, -1)
-        if feats.shape[2] != self.fp[0].n_out:                # narrow configurations: drop the zero padding again
-            feats = feats[:, :, :self.fp[0].n_out].contiguous()
+        feats, tail = self._backbone(xyz, geo, fuse_tail=True)
+        if tail is not None:
+            # interpolation + FP module 0 + both heads: one kernel, a 64-point tile never leaves LDS (csrc/rpn_tail.hip)
+            known_feat, idx, weight = tail
+            tw = self.rpn_tail
+            feats = torch.empty((B, N, 128), dtype=torch.float32, device=xyz.device)
+            rpn_cls = torch.empty((B, N, 1), dtype=torch.float32, device=xyz.device)
+            rpn_reg = torch.empty((B, N, tw["n_reg"]), dtype=torch.float32, device=xyz.device)
+            pu.pointnet2.rpn_tail_wrapper(known_feat, idx, weight, tw["wcat"], tw["bcat"], tw["wc2"], tw["bc2"], feats, rpn_cls, rpn_reg)
+        else:
+            flat = feats.view(B * N, -1)
+            rpn_cls = self.rpn_cls(flat).view(B, N, -1)
+            rpn_reg = self.rpn_reg(flat).view(B, N, -1)
+            if feats.shape[2] != self.fp[0].n_out:            # narrow configurations: drop the zero padding again
+                feats = feats[:, :, :self.fp[0].n_out].contiguous()
         out = {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": xyz, "rpn_features": feats}
         if cfg.RCNN.ENABLED:
             raw = rpn_cls[:, :, 0].contiguous()

@@ -179,6 +179,16 @@ int prcnn_sa_xyz_mlp_packed(int b, int m, int c1, int c2, int c3, long max_tiles
                             float *out, int out_stride, int out_col, void *stream);
 int prcnn_rows_dot(long rows, int K, int n, const float *A, long lda, const float *W, const float *bias, float *out,
                    long ldo, void *stream);
+/* The last stretch of the RPN over all input points in one kernel (csrc/rpn_tail.hip): three_interpolate of the coarse
+ * features (pointnet2_modules.py:136-160, FP module 0, no skip features) -> SharedMLP 256-128-128 -> the backbone features,
+ * and on them the cls head 128-128-1 and the reg head 128-128-n_reg (rpn.py:28-50).  known (b,m,256), idx / weight (b,n,3)
+ * from three_nn; wcat (768,128) = [FP layer 1 (256 rows) | FP layer 2 | cls layer 1 | reg layer 1 | reg layer 2 zero-padded
+ * beyond n_reg columns], bcat (5,128) their biases, wc2 (128) / bc2 (1) the score layer; BN folded, k-major.
+ * feats (b*n,128), cls (b*n), reg (b*n,n_reg), n_reg % 4 == 0.  Same arithmetic as prcnn_three_interpolate_pm ->
+ * prcnn_packed_layer x5 -> prcnn_rows_dot, bit for bit. */
+int prcnn_rpn_tail(int b, int n, int m, const float *known, const int *idx, const float *weight, const float *wcat,
+                   const float *bcat, const float *wc2, const float *bc2, int n_reg, float *feats, float *cls, float *reg,
+                   void *stream);
 int prcnn_packed_layer_segmax(int b, int m, long max_tiles, int K, int N, const float *A, long lda, const float *W,
                               const float *bias, const unsigned int *rowinfo, const int *tilecloud,
                               const unsigned int *hdr, float *out, int out_stride, int out_col, void *stream);

@@ -174,6 +174,21 @@ class pointnet2_cpu:
         return out
 
     @staticmethod
+    def rpn_tail_wrapper(known, idx, weight, wcat, bcat, wc2, bc2, feats, cls, reg):
+        """csrc/rpn_tail.hip as the chain of oracle functions it fuses."""
+        b, n = idx.shape[0], idx.shape[1]
+        x = torch.empty((b, n, 256))
+        pointnet2_cpu.three_interpolate_pm_wrapper(known, idx, weight, x, 0)
+        layer = lambda a, k0, k1, i, relu, out: pointnet2_cpu.packed_layer_wrapper(a, wcat[k0:k1].contiguous(), bcat[i].contiguous(), relu, out)
+        h = layer(x.view(b * n, 256), 0, 256, 0, True, torch.empty((b * n, 128)))
+        layer(h, 256, 384, 1, True, feats.view(b * n, 128))
+        hc = layer(feats.view(b * n, 128), 384, 512, 2, True, torch.empty((b * n, 128)))
+        pointnet2_cpu.rows_dot_wrapper(hc, wc2.view(128, 1), bc2, cls.view(b * n, 1))
+        hr = layer(feats.view(b * n, 128), 512, 640, 3, True, torch.empty((b * n, 128)))
+        layer(hr, 640, 768, 4, False, reg.view(b * n, -1))
+        return feats, cls, reg
+
+    @staticmethod
     def packed_layer_segmax_wrapper(a, wt, bias, pack, b, m, out, out_col):
         ns = pack.idx.shape[2]
         y = torch.empty((b * m * ns, wt.size(1)))

@@ -258,3 +258,58 @@ def test_xyz_level_over_packed_rows_bit_identical(ext, c1, c2, c3, ns):
                                              b3.cpu(), want, 4)
     assert torch.equal(got.cpu(), want)
     assert (got[..., 4:4 + c3] > 0).float().mean() > 0.2
+
+
+def _rpn_tail_case(rng, b, n, m, n_reg):
+    known = T(rng.standard_normal((b, m, 256)).astype(np.float32))
+    idx = T(rng.integers(0, m, (b, n, 3)).astype(np.int32))
+    wgt = rng.random((b, n, 3)).astype(np.float32) + 0.05
+    wgt = T((wgt / wgt.sum(axis=2, keepdims=True)).astype(np.float32))
+    wcat = (rng.standard_normal((768, 128)) / 11).astype(np.float32)
+    wcat[:256] *= 0.7
+    wcat[640:, n_reg:] = 0                                           # the narrow last layer arrives zero-padded to 128 columns
+    bcat = (rng.standard_normal((5, 128)) * 0.1).astype(np.float32)
+    bcat[4, n_reg:] = 0
+    wc2 = T((rng.standard_normal(128) / 11).astype(np.float32)); bc2 = T(rng.standard_normal(1).astype(np.float32))
+    return known, idx, wgt, T(wcat), T(bcat), wc2, bc2
+
+
+@pytest.mark.parametrize("b,n,m,n_reg", [(1, 1, 3, 76), (2, 1000, 300, 76), (3, 64, 17, 128), (1, 4100, 700, 4)])
+def test_rpn_tail_kernel_equals_the_chain_of_oracle_functions(ext, b, n, m, n_reg):
+    """csrc/rpn_tail.hip (interpolation -> FP module 256-128-128 -> cls 128-128-1 and reg 128-128-n_reg, one kernel) vs the
+    oracle's three_interpolate -> five MFMA-ordered layers -> GEMV, BIT FOR BIT: ragged row counts (not multiples of 64, fewer
+    than one tile, several tiles per workgroup), regression widths 4 / 76 / 128, nothing written outside the outputs."""
+    rng = np.random.default_rng(b * 1000 + n)
+    known, idx, wgt, wcat, bcat, wc2, bc2 = _rpn_tail_case(rng, b, n, m, n_reg)
+    guard = torch.full((b * n + 8, n_reg), float("nan"), device=DEV)
+    reg = guard[:b * n].view(b, n, n_reg)
+    cls = torch.full((b, n, 1), float("nan"), device=DEV)
+    feats = torch.full((b, n, 128), float("nan"), device=DEV)
+    ext.pointnet2.rpn_tail_wrapper(known, idx, wgt, wcat, bcat, wc2, bc2, feats, cls, reg)
+    assert torch.isnan(guard[b * n:]).all()
+    wf, wc, wr = torch.empty((b, n, 128)), torch.empty((b, n, 1)), torch.empty((b, n, n_reg))
+    ext_cpu.pointnet2_cpu.rpn_tail_wrapper(known.cpu(), idx.cpu(), wgt.cpu(), wcat.cpu(), bcat.cpu(), wc2.cpu(), bc2.cpu(), wf, wc, wr)
+    assert torch.equal(feats.cpu(), wf) and torch.equal(cls.cpu(), wc) and torch.equal(reg.cpu(), wr)
+    assert float(wf.abs().max()) > 0 and float(wr.abs().max()) > 0
+
+
+def test_rpn_tail_kernel_equals_the_separate_kernels_at_the_batch8_shape(ext):
+    """B = 8 x 16384 points from 4096 coarse points (the benchmarked step): the fused kernel gives the SAME BITS as
+    three_interpolate_pm -> packed_layer x5 -> rows_dot on the GPU."""
+    rng = np.random.default_rng(5)
+    b, n, m, n_reg = 8, 16384, 4096, 76
+    known, idx, wgt, wcat, bcat, wc2, bc2 = _rpn_tail_case(rng, b, n, m, n_reg)
+    feats = torch.empty((b, n, 128), device=DEV); cls = torch.empty((b, n, 1), device=DEV); reg = torch.empty((b, n, n_reg), device=DEV)
+    ext.pointnet2.rpn_tail_wrapper(known, idx, wgt, wcat, bcat, wc2, bc2, feats, cls, reg)
+    P = ext.pointnet2
+    x = torch.empty((b, n, 256), device=DEV)
+    P.three_interpolate_pm_wrapper(known, idx, wgt, x, 0)
+    lay = lambda a, k0, k1, i, relu, width: P.packed_layer_wrapper(a, wcat[k0:k1].contiguous(), bcat[i].contiguous(), relu,
+                                                                  torch.empty((b * n, width), device=DEV))
+    h = lay(x.view(b * n, 256), 0, 256, 0, True, 128)
+    f2 = lay(h, 256, 384, 1, True, 128)
+    hc = lay(f2, 384, 512, 2, True, 128)
+    c2 = P.rows_dot_wrapper(hc, wc2.view(128, 1).contiguous(), bc2, torch.empty((b * n, 1), device=DEV))
+    hr = lay(f2, 512, 640, 3, True, 128)
+    r2 = lay(hr, 640, 768, 4, False, n_reg)
+    assert torch.equal(feats.view(-1, 128), f2) and torch.equal(cls.view(-1, 1), c2) and torch.equal(reg.view(-1, n_reg), r2)

@@ -143,6 +143,7 @@ POINTNET2 = {
     "packed_layer_wrapper": None,
     "packed_layer_segmax_wrapper": {6: "exact"},
     "rows_dot_wrapper": {3: "exact"},
+    "rpn_tail_wrapper": {7: "exact", 8: "exact", 9: "exact"},     # finest FP module + both heads in one kernel
     "rcnn_point_mlp_wrapper": None,                # filled below
 }
 
@@ -272,8 +273,8 @@ def test_batch8_step_every_kernel_call_equals_the_oracle():
     # coverage: every kernel family of the step was exercised at the batch-8 shapes
     want_calls = {"furthest_point_sampling_wrapper": 6, "ball_query_wrapper": 10, "three_nn_wrapper": 4, "ball_pack_wrapper": 10,   # (the GroupAll list is cached by the engine)
                   "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 4, "packed_layer_segmax_wrapper": 5,
-                  "three_interpolate_pm_wrapper": 4, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
+                  "three_interpolate_pm_wrapper": 3, "rpn_tail_wrapper": 1, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
     for name, n in want_calls.items():
         assert log[name] == n, (name, log[name], n)
-    assert log["packed_layer_wrapper"] >= 9 and log["packed_gather_affine_wrapper"] == 5 and log["rows_dot_wrapper"] == 2
+    assert log["packed_layer_wrapper"] >= 9 and log["packed_gather_affine_wrapper"] == 5 and log["rows_dot_wrapper"] == 1
     print("shadowed calls:", {k: v for k, v in log.items() if not k.startswith("elements:")})
