@@ -67,85 +67,83 @@ __global__ __launch_bounds__(256) void packed_gather_affine_kernel(
 // s_waitcnt vmcnt(0) (expcnt / lgkmcnt left alone): said explicitly so that the compiler's wait-count bookkeeping knows nothing
 // older than the prefetch issued next is outstanding, and puts no wait between that prefetch and the MFMAs that hide it
 #define PL_VM_DRAIN __builtin_amdgcn_s_waitcnt(0x0F70);
-#define PL_MFMA(wf)                                                                                     \
-    _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                    \
-        const float4 a0 = *reinterpret_cast<const float4 *>(a0p + 4 * g);                               \
-        const float4 a1 = *reinterpret_cast<const float4 *>(a1p + 4 * g);                               \
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wf[4 * g + 0], acc0, 0, 0, 0);                \
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wf[4 * g + 0], acc1, 0, 0, 0);                \
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wf[4 * g + 1], acc0, 0, 0, 0);                \
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, wf[4 * g + 1], acc1, 0, 0, 0);                \
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, wf[4 * g + 2], acc0, 0, 0, 0);                \
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, wf[4 * g + 2], acc1, 0, 0, 0);                \
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, wf[4 * g + 3], acc0, 0, 0, 0);                \
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wf[4 * g + 3], acc1, 0, 0, 0);                \
+// ---- one 128-deep panel = 16 k-groups of 8 MFMAs ---------------------------------------------------------------------
+// A wave issues in order, and while it streams MFMAs the other waves of its SIMD get next to no VALU / address-generation
+// slots (s_memtime stamps, profiles/r02_stage_stamps.md: two co-resident workgroups take turns, the time of a launch is the
+// SUM of every wave's MFMA time and of its non-MFMA issue time).  So everything that is not an MFMA is placed INSIDE the
+// MFMA stream of the wave that needs it, where the matrix pipe is busy anyway, and costs no VALU:
+//   * the A operands of k-group g+1 are read from LDS before the MFMAs of group g;
+//   * PREFETCH: the next panel comes in behind this one -- its 8 rows of A as buffer loads (scalar row offsets; rows past
+//     the end read as zero through the buffer's bounds check, no per-lane clamping) in groups 0-7, written to the OTHER LDS
+//     tile in groups 8-15; its 64 weights six per group in groups 0-10.  Nothing is left for the end of the stage but
+//     one barrier.
+#define PL_GROUP_MFMA_HEAD(wf)                                                                          \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wf[4 * g + 0], acc0, 0, 0, 0);                    \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wf[4 * g + 0], acc1, 0, 0, 0);
+#define PL_GROUP_MFMA_TAIL(wf)                                                                          \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wf[4 * g + 1], acc0, 0, 0, 0);                    \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, wf[4 * g + 1], acc1, 0, 0, 0);                    \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, wf[4 * g + 2], acc0, 0, 0, 0);                    \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, wf[4 * g + 2], acc1, 0, 0, 0);                    \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, wf[4 * g + 3], acc0, 0, 0, 0);                    \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wf[4 * g + 3], acc1, 0, 0, 0);
+#define PL_STAGE(T, wf)                                                                                 \
+    {                                                                                                   \
+        const float *a0p = (T) + j * PL_LD + 64 * h, *a1p = (T) + (32 + j) * PL_LD + 64 * h;            \
+        f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p);                                               \
+        f32x4 a1 = *reinterpret_cast<const f32x4 *>(a1p);                                               \
+        _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                \
+            f32x4 n0 = a0, n1 = a1;                                                                     \
+            if (g < 15) {                                                                               \
+                n0 = *reinterpret_cast<const f32x4 *>(a0p + 4 * (g + 1));                               \
+                n1 = *reinterpret_cast<const f32x4 *>(a1p + 4 * (g + 1));                               \
+            }                                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+            PL_GROUP_MFMA_HEAD(wf)                                                                      \
+            PL_GROUP_MFMA_TAIL(wf)                                                                      \
+            a0 = n0; a1 = n1;                                                                           \
+        }                                                                                               \
+    }
+#define PL_STAGE_PREFETCH(T, TN, wf, wn, kn)                                                            \
+    {                                                                                                   \
+        const float *a0p = (T) + j * PL_LD + 64 * h, *a1p = (T) + (32 + j) * PL_LD + 64 * h;            \
+        f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p);                                               \
+        f32x4 a1 = *reinterpret_cast<const f32x4 *>(a1p);                                               \
+        f32x4 ar[8];                                                                                    \
+        _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                \
+            f32x4 n0 = a0, n1 = a1;                                                                     \
+            if (g < 15) {                                                                               \
+                n0 = *reinterpret_cast<const f32x4 *>(a0p + 4 * (g + 1));                               \
+                n1 = *reinterpret_cast<const f32x4 *>(a1p + 4 * (g + 1));                               \
+            }                                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+            PL_GROUP_MFMA_HEAD(wf)                                                                      \
+            if (g < 8)                                                                                  \
+                ar[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                \
+                    ars, a_lane, (unsigned int)(8 * g) * a_row_bytes + (unsigned int)(kn) * 4u, 0));    \
+            else                                                                                        \
+                *reinterpret_cast<f32x4 *>((TN) + (r0 + 8 * (g - 8)) * PL_LD + 4 * chunk) = ar[g - 8];  \
+            _Pragma("unroll") for (int q = 0; q < 6; ++q)                                               \
+                if (6 * g + q < 64)                                                                     \
+                    wn[6 * g + q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(               \
+                        wrs, lane_off, (unsigned int)((kn) + 6 * g + q) * row_bytes, 0));               \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+            PL_GROUP_MFMA_TAIL(wf)                                                                      \
+            a0 = n0; a1 = n1;                                                                           \
+        }                                                                                               \
     }
 
-// SEGMAX = false: out[r][n0 + ..] = act(A[r] @ W + bias) for the tile's rows (rows >= `rows` are not stored)
-// SEGMAX = true : segmented max over the tile's rows by centre -> atomicMax into out[centre][out_col + n0 + ..]
-// PIPE: K >= 256 -- the next 128-deep panel (weights and the tile's rows of A) is fetched into registers while the MFMAs
-//       of the current one run; the k order of every dot product is the same as without it (panels in sequence).
-template <bool SEGMAX, bool PIPE>
-__global__ __launch_bounds__(256, 2) void packed_layer_kernel(
-    const unsigned int *__restrict__ hdr, long rows_host, int K, int N, const float *__restrict__ A, long lda,
-    const float *__restrict__ W, const float *__restrict__ bias, int do_relu, float *__restrict__ out, long ldo,
-    const unsigned int *__restrict__ rowinfo, const int *__restrict__ tilecloud, int m, int out_col, int n_store)
+// act(acc + bias): SEGMAX = false -> out[r][n0 + ..] for the tile's rows (rows >= `rows` are not stored), staged through
+// the (dead) LDS tile for coalesced 16-byte stores; SEGMAX = true -> segmented max over the tile's rows by centre, atomicMax
+// into out[centre][out_col + n0 + ..]
+template <bool SEGMAX>
+__device__ __forceinline__ void pl_epilogue(const f32x16 &acc0, const f32x16 &acc1, float *tile, int *ctr, long t, long rows, int n0,
+                                            const float *__restrict__ bias, int do_relu, float *__restrict__ out, long ldo,
+                                            const unsigned int *__restrict__ rowinfo, const int *__restrict__ tilecloud, int m,
+                                            int out_col, int n_store)
 {
-    __shared__ float tile[PL_ROWS * PL_LD];
-    __shared__ int ctr[PL_ROWS];
-    const long t = blockIdx.x;
-    const long rows = hdr ? (long)hdr[0] * PL_ROWS : rows_host;
-    if (t * PL_ROWS >= rows) return;
-    const int n0 = blockIdx.y * 128;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, h = lane >> 5;
     const int chunk = tid & 31, r0 = tid >> 5;
-    f32x16 acc0 = {0}, acc1 = {0};
-    const float *a0p = tile + j * PL_LD + 64 * h;
-    const float *a1p = tile + (32 + j) * PL_LD + 64 * h;
-    // weights through a buffer resource: one 32-bit lane offset in a VGPR, the row offset of each load in a scalar register
-    // (no per-load 64-bit address registers: the two-panel pipeline needs the space for the weights themselves)
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, K * N * 4, 0x00020000);
-    const unsigned int row_bytes = (unsigned int)N * 4u;
-    const unsigned int lane_off = ((unsigned int)(64 * h) * (unsigned int)N + (unsigned int)(n0 + 32 * w + j)) * 4u;
-    if constexpr (PIPE) {
-        float wa[64], wb[64];
-        f32x4 ar[8];
-        PL_LOAD_W(wa, 0)
-        PL_LOAD_A(ar, 0)
-        for (int k0 = 0; k0 < K; k0 += 256) {
-            if (k0) __syncthreads();                       // every wave has finished reading the previous panel
-            PL_STORE_A(ar)
-            PL_VM_DRAIN                                    // this panel's weights came in with its rows
-            __syncthreads();
-            const bool odd = k0 + 128 < K;
-            if (odd) {
-                PL_LOAD_W(wb, k0 + 128)
-                PL_LOAD_A(ar, k0 + 128)
-            }
-            PL_MFMA(wa)
-            if (!odd) break;
-            __syncthreads();
-            PL_STORE_A(ar)
-            PL_VM_DRAIN
-            __syncthreads();
-            if (k0 + 256 < K) {
-                PL_LOAD_W(wa, k0 + 256)
-                PL_LOAD_A(ar, k0 + 256)
-            }
-            PL_MFMA(wb)
-        }
-    } else {
-        for (int k0 = 0; k0 < K; k0 += 128) {
-            float wf[64];
-            f32x4 ar[8];
-            PL_LOAD_W(wf, k0)
-            PL_LOAD_A(ar, k0)
-            if (k0) __syncthreads();                       // every wave has finished reading the previous panel
-            PL_STORE_A(ar)
-            __syncthreads();
-            PL_MFMA(wf)
-        }
-    }
     const float bcol = bias[n0 + 32 * w + j];
     if constexpr (SEGMAX) {
         if (tid < PL_ROWS) {
@@ -186,6 +184,91 @@ __global__ __launch_bounds__(256, 2) void packed_layer_kernel(
             }
         }
     }
+}
+
+// K = 128: one panel, nothing to prefetch; 3 workgroups per CU cover each other's loads
+template <bool SEGMAX>
+__global__ __launch_bounds__(256, 2) void packed_layer_kernel(
+    const unsigned int *__restrict__ hdr, long rows_host, int K, int N, const float *__restrict__ A, long lda,
+    const float *__restrict__ W, const float *__restrict__ bias, int do_relu, float *__restrict__ out, long ldo,
+    const unsigned int *__restrict__ rowinfo, const int *__restrict__ tilecloud, int m, int out_col, int n_store)
+{
+    __shared__ float tile[PL_ROWS * PL_LD];
+    __shared__ int ctr[PL_ROWS];
+    const long t = blockIdx.x;
+    const long rows = hdr ? (long)hdr[0] * PL_ROWS : rows_host;
+    if (t * PL_ROWS >= rows) return;
+    const int n0 = blockIdx.y * 128;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int chunk = tid & 31, r0 = tid >> 5;
+    f32x16 acc0 = {0}, acc1 = {0};
+    // weights through a buffer resource: one 32-bit lane offset in a VGPR, the row offset of each load in a scalar register
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, K * N * 4, 0x00020000);
+    const unsigned int row_bytes = (unsigned int)N * 4u;
+    const unsigned int lane_off = ((unsigned int)(64 * h) * (unsigned int)N + (unsigned int)(n0 + 32 * w + j)) * 4u;
+    for (int k0 = 0; k0 < K; k0 += 128) {
+        float wf[64];
+        f32x4 ar[8];
+        PL_LOAD_W(wf, k0)
+        PL_LOAD_A(ar, k0)
+        if (k0) __syncthreads();                           // every wave has finished reading the previous panel
+        PL_STORE_A(ar)
+        __syncthreads();
+        PL_STAGE(tile, wf)
+    }
+    pl_epilogue<SEGMAX>(acc0, acc1, tile, ctr, t, rows, n0, bias, do_relu, out, ldo, rowinfo, tilecloud, m, out_col, n_store);
+}
+
+// K >= 256: two LDS tiles, two weight register sets, every panel fetched behind the MFMAs of the one before it
+// (PL_STAGE_PREFETCH); the k order of every dot product is the same as in the one-panel kernel (panels in sequence).
+template <bool SEGMAX>
+__global__ __launch_bounds__(256, 2) void packed_layer_pipe_kernel(
+    const unsigned int *__restrict__ hdr, long rows_host, int K, int N, const float *__restrict__ A, long lda,
+    const float *__restrict__ W, const float *__restrict__ bias, int do_relu, float *__restrict__ out, long ldo,
+    const unsigned int *__restrict__ rowinfo, const int *__restrict__ tilecloud, int m, int out_col, int n_store)
+{
+    __shared__ float tiles[2 * PL_ROWS * PL_LD];
+    __shared__ int ctr[PL_ROWS];
+    const long t = blockIdx.x;
+    const long rows = hdr ? (long)hdr[0] * PL_ROWS : rows_host;
+    if (t * PL_ROWS >= rows) return;
+    const int n0 = blockIdx.y * 128;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = tid & 31, r0 = tid >> 5;
+    f32x16 acc0 = {0}, acc1 = {0};
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, K * N * 4, 0x00020000);
+    const unsigned int row_bytes = (unsigned int)N * 4u;
+    const unsigned int lane_off = ((unsigned int)(64 * h) * (unsigned int)N + (unsigned int)(n0 + 32 * w + j)) * 4u;
+    // this tile's rows of A as their own buffer: rows past the end (a ragged last tile) are out of its range and read as 0
+    const long left = rows - t * PL_ROWS;
+    const unsigned int a_row_bytes = (unsigned int)lda * 4u;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(A + t * PL_ROWS * lda), 0, (int)((left < PL_ROWS ? left : PL_ROWS) * (long)a_row_bytes), 0x00020000);
+    const unsigned int a_lane = (unsigned int)r0 * a_row_bytes + 16u * chunk;
+    float wa[64], wb[64];
+    {
+        PL_LOAD_W(wa, 0)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<f32x4 *>(tiles + (r0 + 8 * i) * PL_LD + 4 * chunk) =
+                __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, a_lane, (unsigned int)(8 * i) * a_row_bytes, 0));
+    }
+    const int np = K >> 7;
+    for (int p = 0; p < np; ++p) {
+        PL_VM_DRAIN                                        // the panel about to be used is complete (weights; rows are in LDS)
+        lds_barrier();                                     // ... and published; the other tile is free
+        const float *T = tiles + (p & 1) * (PL_ROWS * PL_LD);
+        float *TN = tiles + ((p + 1) & 1) * (PL_ROWS * PL_LD);
+        if (p + 1 < np) {
+            PL_STAGE_PREFETCH(T, TN, wa, wb, (p + 1) * 128)
+#pragma unroll
+            for (int s = 0; s < 64; ++s) wa[s] = wb[s];
+        } else {
+            PL_STAGE(T, wa)
+        }
+    }
+    pl_epilogue<SEGMAX>(acc0, acc1, tiles, ctr, t, rows, n0, bias, do_relu, out, ldo, rowinfo, tilecloud, m, out_col, n_store);
 }
 
 // out[r][0..n) = A[r][0..K) @ W + bias for n <= 4 output columns (the 1-wide last layer of the classification heads): a
@@ -268,7 +351,7 @@ extern "C" int prcnn_packed_layer(const unsigned int *hdr, long rows, long max_t
     PRCNN_REQUIRE(A && W && bias && out, "packed_layer: null pointer");
     PRCNN_REQUIRE(((uintptr_t)A & 15) == 0 && (((uintptr_t)out & 15) == 0 || (ldo & 3) != 0), "packed_layer: 16-byte alignment required");
     const int col_blocks = (n_store + 127) / 128;          // column blocks that hold nothing to store are not launched
-    auto kern = K >= 256 && pipe_enabled() ? packed_layer_kernel<false, true> : packed_layer_kernel<false, false>;
+    auto kern = K >= 256 && pipe_enabled() ? packed_layer_pipe_kernel<false> : packed_layer_kernel<false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, col_blocks), dim3(256), 0, (hipStream_t)stream, hdr, rows, K, N, A, lda, W, bias,
                        relu, out, ldo, nullptr, nullptr, 0, 0, n_store);
     return check_launch("packed_layer");
@@ -292,7 +375,7 @@ extern "C" int prcnn_packed_layer_segmax(int b, int m, long max_tiles, int K, in
         return PRCNN_ELAUNCH;
     }
     if (max_tiles == 0) return PRCNN_OK;
-    auto kern = K >= 256 && pipe_enabled() ? packed_layer_kernel<true, true> : packed_layer_kernel<true, false>;
+    auto kern = K >= 256 && pipe_enabled() ? packed_layer_pipe_kernel<true> : packed_layer_kernel<true>;
     hipLaunchKernelGGL(kern, dim3((unsigned)max_tiles, N / 128), dim3(256), 0, st, hdr, 0L, K, N, A, lda, W, bias, 1, out,
                        (long)out_stride, rowinfo, tilecloud, m, out_col, N);
     return check_launch("packed_layer_segmax");
