@@ -592,14 +592,22 @@ class FastPointRCNN:
             elif USE_PACKED and (mlp.packed is not None or mlp.wide is not None):
                 # GroupAll (pointnet2_utils.py:267-288): ONE group holding all n points, no centre subtraction == a ball
                 # query answer 0..n-1 around the origin; same packed kernels as the other levels
-                key = (Bc, n, str(cur_xyz.device))
+                # f clouds side by side form one "cloud" with f centres (no centre is subtracted, so cloud borders mean nothing
+                # here): n = 32 points per RoI would leave every 64-row MFMA tile half full of copies.  The index tensor and the
+                # origins are constants of the shape (cached); the row list holds coordinates and is built per batch.
+                f = 1
+                while 2 * f * n <= 64 and Bc % (2 * f) == 0:
+                    f *= 2
+                key = (Bc, n, f, str(cur_xyz.device))
                 if getattr(self, "_groupall", (None,))[0] != key:
-                    ga_idx = torch.arange(n, dtype=torch.int32, device=cur_xyz.device).view(1, 1, n).expand(Bc, 1, n).contiguous()
-                    self._groupall = (key, ga_idx, torch.zeros((Bc, 1, 3), dtype=torch.float32, device=cur_xyz.device),
-                                      ext.ball_pack_wrapper(ga_idx, cur_xyz, torch.zeros((Bc, 1, 3), dtype=torch.float32, device=cur_xyz.device)))
-                _, ga_idx, origin, ga_pack = self._groupall
+                    ga_idx = torch.arange(f * n, dtype=torch.int32, device=cur_xyz.device).view(1, f, n).expand(Bc // f, f, n).contiguous()
+                    self._groupall = (key, ga_idx, torch.zeros((Bc // f, f, 3), dtype=torch.float32, device=cur_xyz.device))
+                _, ga_idx, origin = self._groupall
+                xyz_v = cur_xyz.view(Bc // f, f * n, 3)
+                feat_v = cur_feat.view(Bc // f, f * n, cur_feat.shape[2])
                 out = torch.empty((Bc, 1, cout), dtype=torch.float32, device=cur_xyz.device)
-                self._sa_scale(cur_xyz, origin, cur_feat, ga_idx, mlp, cin, out, 0, pack=ga_pack)
+                self._sa_scale(xyz_v, origin, feat_v, ga_idx, mlp, cin, out.view(Bc // f, f, cout), 0,
+                               pack=ext.ball_pack_wrapper(ga_idx, xyz_v, origin))
                 l_xyz.append(None)
             else:                                                               # GroupAll: one group of n points
                 c4 = _round4(cin)

@@ -355,6 +355,26 @@ def test_pipelined_runner_full_size_many_steps_equals_serial():
             assert torch.equal(det[k], ref[k]), (i, k)
 
 
+def test_engine_keeps_no_state_from_one_batch_to_the_next():
+    """An engine that has already evaluated other batches gives, bit for bit, what a freshly built engine gives.  (Round 2
+    cached the packed row list of the RCNN's GroupAll level -- which holds coordinates -- across batches: every batch after
+    the first was evaluated with the first batch's SA2 centre coordinates in that level.  The serial-vs-pipelined test could
+    not see it, both sides shared the engine.)"""
+    C, E, F, S = pkg("config"), pkg("eval_rcnn"), pkg("net.fast_infer"), pkg("synth")
+    cfg = C.default_eval_cfg()
+    model = E.build_model(cfg, DEV, seed=3)
+    a = torch.from_numpy(S.scenes(4, cfg.RPN.NUM_POINTS, seed0=900)).to(DEV)
+    b = torch.from_numpy(S.scenes(4, cfg.RPN.NUM_POINTS, seed0=950)).to(DEV)
+    used = F.FastPointRCNN(model, cfg)
+    E.infer_batch(model, cfg, a, engine=used)
+    E.infer_batch(model, cfg, a, engine=used)
+    got = E.infer_batch(model, cfg, b, engine=used)
+    want = E.infer_batch(model, cfg, b, engine=F.FastPointRCNN(model, cfg))
+    for k in ("rois", "rcnn_cls", "rcnn_reg", "boxes", "scores", "num"):
+        assert torch.equal(got[k], want[k]), k
+    assert not torch.equal(got["rcnn_reg"], E.infer_batch(model, cfg, a, engine=used)["rcnn_reg"])
+
+
 def test_fused_proposal_sort_order_with_ties_and_nans(ext):
     """score_sort_kernel's total order = (score descending, NaN first, index ascending on ties) == torch's STABLE descending
     sort; argmax over regression bins treats NaN as the largest value like torch.argmax.  Exercised through the fused

@@ -271,7 +271,7 @@ def test_batch8_step_every_kernel_call_equals_the_oracle():
         assert torch.isfinite(det[k].float()).all(), k
     assert (det["num"] > 0).all()
     # coverage: every kernel family of the step was exercised at the batch-8 shapes
-    want_calls = {"furthest_point_sampling_wrapper": 6, "ball_query_wrapper": 10, "three_nn_wrapper": 4, "ball_pack_wrapper": 10,   # (the GroupAll list is cached by the engine)
+    want_calls = {"furthest_point_sampling_wrapper": 6, "ball_query_wrapper": 10, "three_nn_wrapper": 4, "ball_pack_wrapper": 11,
                   "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 4, "packed_layer_segmax_wrapper": 5,
                   "three_interpolate_pm_wrapper": 3, "rpn_tail_wrapper": 1, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
     for name, n in want_calls.items():
