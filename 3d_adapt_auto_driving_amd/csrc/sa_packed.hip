@@ -437,9 +437,19 @@ extern "C" int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, 
         return PRCNN_ELAUNCH;
     }
     if (max_tiles == 0) return PRCNN_OK;
-    static const int env_tiles = getenv("PRCNN_SA_TILES") ? atoi(getenv("PRCNN_SA_TILES")) : 0;
-    const int per_wg = env_tiles > 0 ? env_tiles : PK_TILES_PER_WG;
-    const int grid = (int)((max_tiles + per_wg - 1) / per_wg);
+    // Persistent workgroups: at most 1024 (128-wide) / 512 (256-wide) of them, each drawing tiles from the ticket counter until
+    // none is left, so the 128 weight registers per lane are loaded once per workgroup.  (Until round 2 a workgroup served at most
+    // 8 tiles and the grid was sized for the worst case -- every ball full: in the sparse launches of the real step, ~2300 live
+    // tiles of 102400, some 2300 DIFFERENT workgroups each fetched 128 KB of weights to serve one tile.  RCNN SA1 at the B = 8
+    // shape: 244 -> 160 us.)  PRCNN_SA_GRID=<n> overrides the cap, PRCNN_SA_GRID=0 restores the 8-tiles-per-workgroup launch.
+    static const int env_grid = getenv("PRCNN_SA_GRID") ? atoi(getenv("PRCNN_SA_GRID")) : 1024;
+    int per_wg = PK_TILES_PER_WG;
+    int grid = (int)((max_tiles + per_wg - 1) / per_wg);
+    if (env_grid > 0) {
+        const int cap = c3 == 128 ? env_grid : (env_grid + 1) / 2;
+        if (grid > cap) grid = cap;
+        per_wg = 1 << 30;
+    }
     unsigned int *ticket = next_ticket(st);
     if (!ticket) { set_error("sa_packed_mlp: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
     if (c3 == 128)
