@@ -24,7 +24,7 @@ namespace prcnn {
 template <int NSEG>
 __global__ __launch_bounds__(64 * NSEG) void ball_query_kernel(
     int n, int m, float r2, int nsample, const float *__restrict__ new_xyz,
-    const float *__restrict__ xyz, int *__restrict__ idx, int write_empty)
+    const float *__restrict__ xyz, int *__restrict__ idx, int write_empty, const int *__restrict__ limit)
 {
     extern __shared__ int lds[];  // [NSEG][nsample][64] hits, then [NSEG][64] counts
     int *counts = lds + NSEG * nsample * 64;
@@ -42,9 +42,11 @@ __global__ __launch_bounds__(64 * NSEG) void ball_query_kernel(
         cx = c[0]; cy = c[1]; cz = c[2];
     }
     const float *__restrict__ cloud = xyz + (long)b * n * 3;
-    const int seg_len = (n + NSEG - 1) / NSEG;
+    // limit (optional): only the first limit[b] points of the cloud are scanned (prcnn_ball_query_limit)
+    const int n_scan = limit ? min(n, max(limit[b], 1)) : n;
+    const int seg_len = (n_scan + NSEG - 1) / NSEG;
     const int k0 = seg * seg_len;
-    const int k1 = min(n, k0 + seg_len);
+    const int k1 = min(n_scan, k0 + seg_len);
 
     int cnt = valid ? 0 : nsample;  // lanes past m never record anything
     int *myhits = lds + seg * nsample * 64 + lane;
@@ -287,7 +289,7 @@ static int pick_nseg(int b, int n, int m, int nsample)
 
 template <int NSEG>
 static int launch_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
-                             const float *xyz, int *idx, int write_empty, hipStream_t st)
+                             const float *xyz, int *idx, int write_empty, hipStream_t st, const int *limit = nullptr)
 {
     const size_t lds = ((size_t)NSEG * nsample * 64 + (size_t)NSEG * 64) * sizeof(int);
     if (lds > 64 * 1024) {
@@ -296,7 +298,7 @@ static int launch_ball_query(int b, int n, int m, float radius, int nsample, con
     }
     dim3 grid(ceil_div(m, 64), b);
     hipLaunchKernelGGL(ball_query_kernel<NSEG>, grid, dim3(64 * NSEG), lds, st, n, m,
-                       radius * radius, nsample, new_xyz, xyz, idx, write_empty);
+                       radius * radius, nsample, new_xyz, xyz, idx, write_empty, limit);
     return check_launch("ball_query");
 }
 
@@ -342,6 +344,20 @@ extern "C" int prcnn_ball_query(int b, int n, int m, float radius, int nsample,
                                 const float *new_xyz, const float *xyz, int *idx, void *stream)
 {
     return ball_query_dispatch(b, n, m, radius, nsample, new_xyz, xyz, idx, 0, (hipStream_t)stream);
+}
+
+// Ball query over clouds whose points k >= limit[cloud] are known to be COPIES of point k % limit[cloud] (RoI pooling's
+// wrap-around fill, roipool3d_kernel.cu:152-159): only the first limit[cloud] points are scanned.  The idx rows differ from
+// prcnn_ball_query's (slots the full scan fills with copies hold the first hit here) but name the same SET of distinct points
+// per ball, which is all a max-pooled SA level sees.  Not part of the reference ABI: an engine-side shortcut.
+extern "C" int prcnn_ball_query_limit(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                                      const int *limit, int *idx, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample > 0 && nsample <= 256 && b <= 65535, "ball_query_limit: bad sizes");
+    if (b == 0 || m == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(new_xyz && xyz && idx && limit, "ball_query_limit: null pointer");
+    // one wave per 64 centres scans the (short) live part of its cloud
+    return launch_ball_query<1>(b, n, m, radius, nsample, new_xyz, xyz, idx, 0, (hipStream_t)stream, limit);
 }
 
 extern "C" int prcnn_group_points(int b, int c, int n, int npoints, int nsample,

@@ -37,6 +37,15 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     return 1
 
 
+def ball_query_limit_wrapper(b, n, m, radius, nsample, new_xyz, xyz, limit, idx):
+    """ball_query_wrapper over clouds whose points k >= limit[cloud] are copies of point k % limit[cloud] (pooled RoI rows):
+    scans the first limit[cloud] points only -- the same distinct points per ball, slots past them repeat the first hit."""
+    _chk(torch.float32, new_xyz, xyz); _chk(torch.int32, idx, limit)
+    _lib.call("prcnn_ball_query_limit", b, n, m, radius, nsample, new_xyz.data_ptr(), xyz.data_ptr(), limit.data_ptr(),
+              idx.data_ptr(), _lib.current_stream(xyz))
+    return 1
+
+
 def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
     _chk(torch.float32, points, out); _chk(torch.int32, idx)
     _lib.call("prcnn_group_points", b, c, n, npoints, nsample, points.data_ptr(), idx.data_ptr(),

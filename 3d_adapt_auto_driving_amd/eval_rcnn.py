@@ -252,7 +252,8 @@ class PipelinedRunner:
             rois, roi_scores = self.engine.propose(st)
             ev_prop = torch.cuda.Event()
             ev_prop.record(self.tail)
-        rois.record_stream(main)
+        for t in (rois, st["seg_result"], st["pts_depth"]):       # made on the tail stream, read by the RCNN stage on the feature stream
+            t.record_stream(main)
         # Geometry of the upcoming batches is GATED on the end of this RPN stage: the library GEMMs of the RPN stage are
         # persistent-grid kernels that stretch 40-70 % when an FPS workgroup shares a CU with them, the RCNN stage that
         # follows is made of ticketed kernels that do not care.  So the xyz-only chains only START during RCNN stages:
@@ -302,7 +303,8 @@ class PipelinedRunner:
             rois, roi_scores = self.engine.propose(st)
             ev_prop = torch.cuda.Event()
             ev_prop.record(self.tail)
-        rois.record_stream(main)
+        for t in (rois, st["seg_result"], st["pts_depth"]):       # made on the tail stream, read by the RCNN stage on the feature stream
+            t.record_stream(main)
         done = self._finish_inflight()
         self._inflight = (cur, st, rois, roi_scores, ev_prop)
         return done

@@ -475,19 +475,28 @@ class FastPointRCNN:
                 feats = feats[:, :, :self.fp[0].n_out].contiguous()
         out = {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": xyz, "rpn_features": feats}
         if cfg.RCNN.ENABLED:
-            raw = rpn_cls[:, :, 0].contiguous()
-            out["rpn_scores_raw"] = raw
-            out["seg_result"] = (torch.sigmoid(raw) > cfg.RPN.SCORE_THRESH).float()
-            out["pts_depth"] = torch.norm(xyz, p=2, dim=2)
+            out["rpn_scores_raw"] = rpn_cls[:, :, 0].contiguous()
         return out
 
     @torch.no_grad()
+    def point_aux(self, st):
+        """Foreground mask and depth of every point (rcnn input features, point_rcnn.py:44-52).  Half a dozen tiny elementwise
+        launches that only the RCNN stage reads: the proposal stage computes them (on ITS stream in the pipelined runner),
+        they are off the feature stream's critical path."""
+        if "seg_result" not in st:
+            st["seg_result"] = (torch.sigmoid(st["rpn_scores_raw"]) > self.cfg.RPN.SCORE_THRESH).float()
+            st["pts_depth"] = torch.norm(st["backbone_xyz"], p=2, dim=2)
+
+    @torch.no_grad()
     def propose(self, st):
-        """The proposal layer on the RPN stage's outputs -> (rois, roi_scores_raw)."""
+        """The proposal layer on the RPN stage's outputs -> (rois, roi_scores_raw); also fills in the per-point RCNN inputs."""
+        if self.cfg.RCNN.ENABLED:
+            self.point_aux(st)
         return self.model.rpn.proposal_layer(st["rpn_scores_raw"], st["rpn_reg"], st["backbone_xyz"])
 
     @torch.no_grad()
     def rcnn_stage(self, st, rois):
+        self.point_aux(st)
         return self._rcnn(st["backbone_xyz"], st["rpn_features"], st["seg_result"], st["pts_depth"], rois)
 
     @torch.no_grad()
@@ -581,9 +590,15 @@ class FastPointRCNN:
             if npoint is not None:
                 sel = pu.furthest_point_sample(cur_xyz, npoint)
                 new_xyz = torch.gather(cur_xyz, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
-                idx = pu.ball_query(radius, ns, cur_xyz, new_xyz)
-                out = torch.empty((Bc, npoint, cout), dtype=torch.float32, device=cur_xyz.device)
                 first = len(l_feat) == 1
+                if first and pooled_cnt is not None and P_pre is not None and has_entry(ext, "ball_query_limit_wrapper"):
+                    # pooled rows k >= count are copies of row k % count: scanning the distinct rows finds every ball's points
+                    # (the row list below drops the copies anyway); a RoI holds ~60 of its 512 rows at this scene size
+                    idx = torch.zeros((Bc, npoint, ns), dtype=torch.int32, device=cur_xyz.device)
+                    ext.ball_query_limit_wrapper(Bc, n, npoint, radius, ns, new_xyz, cur_xyz, pooled_cnt.view(-1), idx)
+                else:
+                    idx = pu.ball_query(radius, ns, cur_xyz, new_xyz)
+                out = torch.empty((Bc, npoint, cout), dtype=torch.float32, device=cur_xyz.device)
                 pack = None
                 if first and pooled_cnt is not None and P_pre is not None:
                     pack = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, pooled_cnt.view(-1))       # copies of pooled points are dropped too

@@ -60,6 +60,12 @@ int prcnn_group_points(int b, int c, int n, int npoints, int nsample,
 int prcnn_group_points_grad(int b, int c, int n, int npoints, int nsample,
                             const float *grad_out, const int *idx, float *grad_points, void *stream);
 
+/* Ball query over clouds whose points k >= limit[cloud] are copies of point k % limit[cloud] (the pooled rows of a RoI that
+ * holds fewer than 512 points, roipool3d_kernel.cu:152-159): only the first limit[cloud] points are scanned.  Same distinct
+ * points per ball as prcnn_ball_query, slots past them repeat the first hit.  Engine-side shortcut, not reference ABI. */
+int prcnn_ball_query_limit(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                           const int *limit, int *idx, void *stream);
+
 /* gather_points_wrapper_fast  src/sampling.cpp:11-20 -> src/sampling_gpu.cu:8-24. */
 int prcnn_gather_points(int b, int c, int n, int npoints,
                         const float *points, const int *idx, float *out, void *stream);

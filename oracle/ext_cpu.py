@@ -47,6 +47,15 @@ class pointnet2_cpu:
         return 1
 
     @staticmethod
+    def ball_query_limit_wrapper(b, n, m, radius, nsample, new_xyz, xyz, limit, idx):
+        """the reference ball query (ball_query_gpu.cu:14-43) over the first limit[cloud] points of every cloud"""
+        for i in range(b):
+            ni = min(n, max(int(limit[i]), 1))
+            O.lib().orc_ball_query(1, ni, m, C.c_float(radius), nsample, C.cast(new_xyz[i].data_ptr(), _f), C.cast(xyz[i].data_ptr(), _f),
+                                   C.cast(idx[i].data_ptr(), _i))
+        return 1
+
+    @staticmethod
     def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
         O.lib().orc_group_points(b, c, n, npoints, nsample, _p(points, _f), _p(idx, _i), _p(out, _f))
         return 1

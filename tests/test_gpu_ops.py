@@ -106,6 +106,33 @@ def test_ball_query_rcnn_shape(ext, oracle):
     assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(0.2, 64, xyz, new_xyz))
 
 
+def test_ball_query_with_scan_limit_on_wrapped_clouds(ext, oracle):
+    """Clouds filled the way RoI pooling fills a box holding fewer than 512 points (row k >= count is a copy of row
+    k % count, roipool3d_kernel.cu:152-159; an empty box is all one point).  prcnn_ball_query_limit scans the first count
+    rows only: (1) it equals the reference ball query run on the truncated cloud, bit for bit; (2) per ball it names exactly
+    the same SET of distinct points (rows mod count) as the reference query over all 512 rows."""
+    rng = np.random.default_rng(7)
+    b, n, m, r, ns = 60, 512, 128, 0.2, 64
+    cnt = rng.integers(0, 200, b).astype(np.int32)
+    cnt[0], cnt[1], cnt[2], cnt[3] = 0, 1, 511, 512
+    xyz = np.empty((b, n, 3), np.float32)
+    for i in range(b):
+        c = max(int(cnt[i]), 1)
+        base = rng.uniform(-0.6, 0.6, (c, 3)).astype(np.float32)
+        xyz[i] = base[np.arange(n) % c]
+    new_xyz = centres(oracle, xyz, m)
+    got = torch.zeros((b, m, ns), dtype=torch.int32, device=DEV)
+    ext.pointnet2.ball_query_limit_wrapper(b, n, m, r, ns, T(new_xyz), T(xyz), T(cnt), got)
+    got = got.cpu().numpy()
+    full = oracle.ball_query(r, ns, xyz, new_xyz)
+    for i in range(b):
+        c = max(int(cnt[i]), 1)
+        want = oracle.ball_query(r, ns, xyz[i:i + 1, :c].copy(), new_xyz[i:i + 1])
+        assert np.array_equal(got[i], want[0]), i
+        for ctr in range(0, m, 7):
+            assert set(got[i, ctr] % c) == set(full[i, ctr] % c), (i, ctr)
+
+
 @pytest.mark.parametrize("c", [0, 1, 16, 128])
 def test_query_and_group_fused(ext, oracle, c):
     n, m, r, ns = 4096, 1024, 0.8, 32

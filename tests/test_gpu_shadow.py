@@ -133,6 +133,7 @@ def check_forward_canonical(self, name, args, host, ret):
 POINTNET2 = {
     "furthest_point_sampling_wrapper": {4: "exact", 5: "exact"},
     "ball_query_wrapper": {7: "exact"},
+    "ball_query_limit_wrapper": {8: "exact"},
     "three_nn_wrapper": {5: "exact", 6: "exact"},
     "three_interpolate_pm_wrapper": {3: "exact"},
     "ball_pack_wrapper": check_ball_pack,
@@ -271,7 +272,7 @@ def test_batch8_step_every_kernel_call_equals_the_oracle():
         assert torch.isfinite(det[k].float()).all(), k
     assert (det["num"] > 0).all()
     # coverage: every kernel family of the step was exercised at the batch-8 shapes
-    want_calls = {"furthest_point_sampling_wrapper": 6, "ball_query_wrapper": 10, "three_nn_wrapper": 4, "ball_pack_wrapper": 11,
+    want_calls = {"furthest_point_sampling_wrapper": 6, "ball_query_wrapper": 9, "ball_query_limit_wrapper": 1, "three_nn_wrapper": 4, "ball_pack_wrapper": 11,
                   "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 4, "packed_layer_segmax_wrapper": 5,
                   "three_interpolate_pm_wrapper": 3, "rpn_tail_wrapper": 1, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
     for name, n in want_calls.items():
