@@ -37,13 +37,13 @@ SIGNATURES = {
     "prcnn_gather_affine_relu_pm": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_sa_mlp_fused": [_I] * 7 + [_P] * 10 + [_I, _I, _P],
     "prcnn_ball_pack": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "prcnn_sa_packed_mlp": [_I, _I, _I, _I, C.c_long] + [_P] * 11 + [_I, _I, _P],
+    "prcnn_sa_packed_mlp": [_I, _I, _I, _I, C.c_long] + [_P] * 11 + [_I, _I, _I, _P],
     "prcnn_packed_gather_affine": [_I, _I, _I, C.c_long] + [_P] * 7 + [_P],
     "prcnn_packed_layer": [_P, C.c_long, C.c_long, _I, _I, _I, _P, C.c_long, _P, _P, _I, _P, C.c_long, _P],
-    "prcnn_sa_xyz_mlp_packed": [_I, _I, _I, _I, _I, C.c_long] + [_P] * 11 + [_I, _I, _P],
+    "prcnn_sa_xyz_mlp_packed": [_I, _I, _I, _I, _I, C.c_long] + [_P] * 11 + [_I, _I, _I, _P],
     "prcnn_rows_dot": [C.c_long, _I, _I, _P, C.c_long, _P, _P, _P, C.c_long, _P],
     "prcnn_rpn_tail": [_I, _I, _I] + [_P] * 7 + [_I] + [_P] * 4,
-    "prcnn_packed_layer_segmax": [_I, _I, C.c_long, _I, _I, _P, C.c_long, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "prcnn_packed_layer_segmax": [_I, _I, C.c_long, _I, _I, _P, C.c_long, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "prcnn_maxpool_pm": [C.c_long, _I, _I, _P, _P, _I, _I, _P],
     "prcnn_three_interpolate_pm": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P],
     "prcnn_boxes_overlap_bev": [_I, _P, _I, _P, _P, _P],

@@ -361,7 +361,7 @@ extern "C" int prcnn_packed_layer(const unsigned int *hdr, long rows, long max_t
 // relu(A[r] @ W + bias); the slice is zeroed first (values are >= 0, partial maxima arrive through atomicMax).
 extern "C" int prcnn_packed_layer_segmax(int b, int m, long max_tiles, int K, int N, const float *A, long lda, const float *W,
                                          const float *bias, const unsigned int *rowinfo, const int *tilecloud,
-                                         const unsigned int *hdr, float *out, int out_stride, int out_col, void *stream)
+                                         const unsigned int *hdr, float *out, int out_stride, int out_col, int out_is_zero, void *stream)
 {
     PRCNN_REQUIRE(b >= 0 && m >= 0 && max_tiles >= 0, "packed_layer_segmax: bad sizes");
     PRCNN_REQUIRE(K > 0 && N > 0 && K % 128 == 0 && N % 128 == 0, "packed_layer_segmax: K=%d, N=%d must be multiples of 128", K, N);
@@ -370,7 +370,7 @@ extern "C" int prcnn_packed_layer_segmax(int b, int m, long max_tiles, int K, in
     PRCNN_REQUIRE(A && W && bias && rowinfo && tilecloud && hdr && out, "packed_layer_segmax: null pointer");
     PRCNN_REQUIRE(((uintptr_t)A & 15) == 0 && max_tiles <= 0x7fffffffL, "packed_layer_segmax: alignment / size");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemset2DAsync(out + out_col, (size_t)out_stride * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)b * m, st) != hipSuccess) {
+    if (!out_is_zero && hipMemset2DAsync(out + out_col, (size_t)out_stride * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)b * m, st) != hipSuccess) {
         set_error("packed_layer_segmax: cannot zero the output slice");
         return PRCNN_ELAUNCH;
     }

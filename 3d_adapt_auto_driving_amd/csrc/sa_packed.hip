@@ -422,7 +422,7 @@ extern "C" int prcnn_ball_pack(int b, int n, int m, int nsample, const int *idx,
 extern "C" int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, const float *P, const float *wxyz,
                                    const unsigned int *rowinfo, const float *rowdxyz, const int *tilecloud,
                                    const unsigned int *hdr, const float *w2t, const float *b2, const float *w3t,
-                                   const float *b3, float *out, int out_stride, int out_col, void *stream)
+                                   const float *b3, float *out, int out_stride, int out_col, int out_is_zero, void *stream)
 {
     PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && max_tiles >= 0, "sa_packed_mlp: bad sizes");
     PRCNN_REQUIRE(c3 == 128 || c3 == 256, "sa_packed_mlp: unsupported output width %d (128 | 256)", c3);
@@ -432,7 +432,7 @@ extern "C" int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, 
     PRCNN_REQUIRE(P && wxyz && rowinfo && rowdxyz && tilecloud && hdr && w2t && b2 && w3t && b3 && out, "sa_packed_mlp: null pointer");
     PRCNN_REQUIRE((((uintptr_t)P | (uintptr_t)wxyz) & 15) == 0, "sa_packed_mlp: 16-byte alignment required");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemset2DAsync(out + out_col, (size_t)out_stride * sizeof(float), 0, (size_t)c3 * sizeof(float), (size_t)b * m, st) != hipSuccess) {
+    if (!out_is_zero && hipMemset2DAsync(out + out_col, (size_t)out_stride * sizeof(float), 0, (size_t)c3 * sizeof(float), (size_t)b * m, st) != hipSuccess) {
         set_error("sa_packed_mlp: cannot zero the output slice");
         return PRCNN_ELAUNCH;
     }

@@ -146,7 +146,7 @@ using namespace prcnn;
 extern "C" int prcnn_sa_xyz_mlp_packed(int b, int m, int c1, int c2, int c3, long max_tiles, const unsigned int *rowinfo,
                                        const float *rowdxyz, const int *tilecloud, const unsigned int *hdr, const float *w1,
                                        const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
-                                       float *out, int out_stride, int out_col, void *stream)
+                                       float *out, int out_stride, int out_col, int out_is_zero, void *stream)
 {
     PRCNN_REQUIRE(b >= 0 && m >= 0 && max_tiles >= 0, "sa_xyz_mlp_packed: bad sizes");
     PRCNN_REQUIRE((c1 == 16 && c2 == 16 && c3 == 32) || (c1 == 32 && c2 == 32 && c3 == 64),
@@ -155,7 +155,7 @@ extern "C" int prcnn_sa_xyz_mlp_packed(int b, int m, int c1, int c2, int c3, lon
     if ((long)b * m == 0) return PRCNN_OK;
     PRCNN_REQUIRE(rowinfo && rowdxyz && tilecloud && hdr && w1 && b1 && w2 && b2 && w3 && b3 && out, "sa_xyz_mlp_packed: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemset2DAsync(out + out_col, (size_t)out_stride * sizeof(float), 0, (size_t)c3 * sizeof(float), (size_t)b * m, st) != hipSuccess) {
+    if (!out_is_zero && hipMemset2DAsync(out + out_col, (size_t)out_stride * sizeof(float), 0, (size_t)c3 * sizeof(float), (size_t)b * m, st) != hipSuccess) {
         set_error("sa_xyz_mlp_packed: cannot zero the output slice");
         return PRCNN_ELAUNCH;
     }

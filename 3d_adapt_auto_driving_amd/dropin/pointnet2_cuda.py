@@ -215,7 +215,7 @@ def ball_pack_wrapper(idx, xyz, new_xyz, limit=None):
     return pk
 
 
-def sa_packed_mlp_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col):
+def sa_packed_mlp_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col, zeroed=False):
     """sa_mlp_fused_wrapper over the distinct rows only (csrc/sa_packed.hip): same arguments with the BallPack of the
     index tensor instead of the index tensor; bit-identical results."""
     _chk(torch.float32, new_xyz, xyz, P, wxyz, w2t, b2, w3t, b3, out)
@@ -224,7 +224,7 @@ def sa_packed_mlp_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, ou
         raise RuntimeError("pointnet2_cuda: sa_packed_mlp needs 128-wide (zero-padded) layers 1 and 2")
     _lib.call("prcnn_sa_packed_mlp", b, n, new_xyz.size(1), w3t.size(1), pack.max_tiles,
               P.data_ptr(), wxyz.data_ptr(), pack.rowinfo.data_ptr(), pack.rowdxyz.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr(),
-              w2t.data_ptr(), b2.data_ptr(), w3t.data_ptr(), b3.data_ptr(), out.data_ptr(), out.size(-1), out_col,
+              w2t.data_ptr(), b2.data_ptr(), w3t.data_ptr(), b3.data_ptr(), out.data_ptr(), out.size(-1), out_col, int(zeroed),
               _lib.current_stream(xyz))
     return out
 
@@ -280,12 +280,12 @@ def rpn_tail_wrapper(known, idx, weight, wcat, bcat, wc2, bc2, feats, cls, reg):
     return feats, cls, reg
 
 
-def packed_layer_segmax_wrapper(a, wt, bias, pack, b, m, out, out_col):
+def packed_layer_segmax_wrapper(a, wt, bias, pack, b, m, out, out_col, zeroed=False):
     """Last layer of a level + max pool over a packed row list: out (b,m,stride)[..., out_col:out_col+N]."""
     _chk(torch.float32, a, wt, bias, out)
     K, N = wt.shape
     _lib.call("prcnn_packed_layer_segmax", b, m, pack.max_tiles, K, N, a.data_ptr(), a.stride(0), wt.data_ptr(), bias.data_ptr(),
-              pack.rowinfo.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr(), out.data_ptr(), out.size(-1), out_col,
+              pack.rowinfo.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr(), out.data_ptr(), out.size(-1), out_col, int(zeroed),
               _lib.current_stream(a))
     return out
 
@@ -316,13 +316,13 @@ def pooled_tiles_wrapper(cnt, rows_per_cloud):
     return tilemap, hdr
 
 
-def sa_xyz_mlp_packed_wrapper(new_xyz, xyz, pack, w1, b1, w2, b2, w3, b3, out, out_col):
+def sa_xyz_mlp_packed_wrapper(new_xyz, xyz, pack, w1, b1, w2, b2, w3, b3, out, out_col, zeroed=False):
     """sa_xyz_mlp_wrapper over the distinct rows of the level's index tensor (BallPack) -- bit-identical results."""
     _chk(torch.float32, w1, b1, w2, b2, w3, b3, out)
     _lib.call("prcnn_sa_xyz_mlp_packed", new_xyz.size(0), new_xyz.size(1), w1.size(1), w2.size(1), w3.size(1), pack.max_tiles,
               pack.rowinfo.data_ptr(), pack.rowdxyz.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr(), w1.data_ptr(),
               b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(), b3.data_ptr(), out.data_ptr(), out.size(-1), out_col,
-              _lib.current_stream(out))
+              int(zeroed), _lib.current_stream(out))
     return out
 
 

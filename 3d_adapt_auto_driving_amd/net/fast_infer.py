@@ -352,7 +352,7 @@ class FastPointRCNN:
 
     # ------------------------------------------------------------------ building blocks
     @staticmethod
-    def _sa_scale(xyz, new_xyz, feats, idx, mlp, cin, out, out_col, P_pre=None, pack=None):
+    def _sa_scale(xyz, new_xyz, feats, idx, mlp, cin, out, out_col, P_pre=None, pack=None, zeroed=False):
         """one (radius, nsample) scale: group -> GEMM chain -> max over nsample into out[..., slice]"""
         ext = pu.pointnet2
         B, N, _ = xyz.shape
@@ -362,7 +362,7 @@ class FastPointRCNN:
             wf, wx, b1, w2, b2, w3, b3 = mlp.packed
             P = P_pre if P_pre is not None else point_layer(feats.view(B * N, feats.shape[2]), wf, b1, False).view(B, N, 128)
             pk = pack if pack is not None else ext.ball_pack_wrapper(idx, xyz, new_xyz)
-            ext.sa_packed_mlp_wrapper(new_xyz, xyz, P, wx, pk, w2, b2, w3, b3, out, out_col)
+            ext.sa_packed_mlp_wrapper(new_xyz, xyz, P, wx, pk, w2, b2, w3, b3, out, out_col, zeroed)
             return
         if USE_PACKED and mlp.wide is not None:
             # wider level: the same distinct rows, layer by layer (gather+affine -> MFMA layer -> MFMA layer + segmented max)
@@ -374,7 +374,7 @@ class FastPointRCNN:
             ext.packed_gather_affine_wrapper(new_xyz, xyz, P, wx, pk, a1)
             y2 = torch.empty((rows, w2.shape[1]), dtype=torch.float32, device=xyz.device)
             ext.packed_layer_wrapper(a1, w2, b2, True, y2, pk)
-            ext.packed_layer_segmax_wrapper(y2, w3, b3, pk, B, M, out, out_col)
+            ext.packed_layer_segmax_wrapper(y2, w3, b3, pk, B, M, out, out_col, zeroed)
             return
         # the formulations below are for scales the packed kernels do not cover (and for PRCNN_NO_PACK): they read the
         # feature tensor in its true width
@@ -395,7 +395,7 @@ class FastPointRCNN:
             (w1, b1, _), (w2, b2, _), (w3, b3, _) = mlp.layers
             if USE_PACKED:
                 pk = pack if pack is not None else ext.ball_pack_wrapper(idx, xyz, new_xyz)
-                ext.sa_xyz_mlp_packed_wrapper(new_xyz, xyz, pk, w1, b1, w2, b2, w3, b3, out, out_col)
+                ext.sa_xyz_mlp_packed_wrapper(new_xyz, xyz, pk, w1, b1, w2, b2, w3, b3, out, out_col, zeroed)
             else:
                 ext.sa_xyz_mlp_wrapper(new_xyz, xyz, idx, w1, b1, w2, b2, w3, b3, out, out_col)
             return
@@ -421,12 +421,15 @@ class FastPointRCNN:
             B = cur_xyz.shape[0]
             width = sum(s[2].layers[-1][0].shape[1] for s in scales)
             wpad = _round128(width) if PAD128 else width          # consumers (next level's per-point part, FP skip) read 128s
-            out = torch.empty((B, npoint, wpad), dtype=torch.float32, device=xyz.device)
-            if wpad > width:
+            # the packed kernels deliver through atomicMax into zeros: ONE fill for the level (all scales, the padding columns)
+            # instead of one strided fill per scale
+            pre = USE_PACKED and all(sc[2].packed is not None or sc[2].wide is not None or sc[3] == 0 for sc in scales)
+            out = (torch.zeros if pre else torch.empty)((B, npoint, wpad), dtype=torch.float32, device=xyz.device)
+            if wpad > width and not pre:
                 out[:, :, width:] = 0
             col = 0
             for (radius, ns, mlp, cin), idx, pack in zip(scales, lev["idx"], lev.get("pack") or [None] * len(scales)):
-                self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, idx, mlp, cin, out, col, pack=pack)
+                self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, idx, mlp, cin, out, col, pack=pack, zeroed=pre)
                 col += mlp.layers[-1][0].shape[1]
             l_feat.append(out)
         ext = pu.pointnet2

@@ -156,10 +156,13 @@ int prcnn_sa_mlp_fused(int b, int n, int m, int nsample, int c1, int c2, int c3,
 int prcnn_ball_pack(int b, int n, int m, int nsample, const int *idx, const int *limit, const float *xyz,
                     const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr,
                     void *stream);
+/* out_is_zero (this entry, prcnn_sa_xyz_mlp_packed, prcnn_packed_layer_segmax): the results arrive through atomicMax into a
+ * zeroed slice; 0 = the entry zeroes out[..., out_col : out_col + width) itself, 1 = the caller has zeroed it (one fill for all
+ * the scales of a level instead of one strided fill per scale). */
 int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, const float *P, const float *wxyz,
                         const unsigned int *rowinfo, const float *rowdxyz, const int *tilecloud,
                         const unsigned int *hdr, const float *w2t, const float *b2, const float *w3t,
-                        const float *b3, float *out, int out_stride, int out_col, void *stream);
+                        const float *b3, float *out, int out_stride, int out_col, int out_is_zero, void *stream);
 
 /* Shared-MLP layers of any width over packed row lists (csrc/packed_layer.hip): the levels whose weights do not fit the
  * register-resident fused kernels (RPN SA3/SA4: 128-196-256, 256-256-512, 256-384-512, pointrcnn/lib/config.py:58-61;
@@ -182,7 +185,7 @@ int prcnn_packed_layer(const unsigned int *hdr, long rows, long max_tiles, int K
 int prcnn_sa_xyz_mlp_packed(int b, int m, int c1, int c2, int c3, long max_tiles, const unsigned int *rowinfo,
                             const float *rowdxyz, const int *tilecloud, const unsigned int *hdr, const float *w1,
                             const float *b1, const float *w2, const float *b2, const float *w3, const float *b3,
-                            float *out, int out_stride, int out_col, void *stream);
+                            float *out, int out_stride, int out_col, int out_is_zero, void *stream);
 int prcnn_rows_dot(long rows, int K, int n, const float *A, long lda, const float *W, const float *bias, float *out,
                    long ldo, void *stream);
 /* The last stretch of the RPN over all input points in one kernel (csrc/rpn_tail.hip): three_interpolate of the coarse
@@ -197,7 +200,7 @@ int prcnn_rpn_tail(int b, int n, int m, const float *known, const int *idx, cons
                    void *stream);
 int prcnn_packed_layer_segmax(int b, int m, long max_tiles, int K, int N, const float *A, long lda, const float *W,
                               const float *bias, const unsigned int *rowinfo, const int *tilecloud,
-                              const unsigned int *hdr, float *out, int out_stride, int out_col, void *stream);
+                              const unsigned int *hdr, float *out, int out_stride, int out_col, int out_is_zero, void *stream);
 
 /* Entrance of the RCNN as MFMA kernels (lib/net/rcnn_net.py:139-163 xyz_up_layer + concat + merge_down_layer,
  * fused with the per-point part of SA1's first layer): rows (r, ld) f32 = pooled rows

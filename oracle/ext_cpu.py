@@ -153,7 +153,7 @@ class pointnet2_cpu:
         return _CpuPack(idx, limit)
 
     @staticmethod
-    def sa_packed_mlp_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col):
+    def sa_packed_mlp_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col, zeroed=False):
         return pointnet2_cpu.sa_mlp_fused_wrapper(new_xyz, xyz, P, wxyz, pack.idx, w2t, b2, w3t, b3, out, out_col)
 
     @staticmethod
@@ -198,7 +198,7 @@ class pointnet2_cpu:
         return feats, cls, reg
 
     @staticmethod
-    def packed_layer_segmax_wrapper(a, wt, bias, pack, b, m, out, out_col):
+    def packed_layer_segmax_wrapper(a, wt, bias, pack, b, m, out, out_col, zeroed=False):
         ns = pack.idx.shape[2]
         y = torch.empty((b * m * ns, wt.size(1)))
         pointnet2_cpu.packed_layer_wrapper(a, wt, bias, True, y, pack)
@@ -222,7 +222,7 @@ class pointnet2_cpu:
         return None                                  # the CPU stand-in evaluates every row
 
     @staticmethod
-    def sa_xyz_mlp_packed_wrapper(new_xyz, xyz, pack, w1, b1, w2, b2, w3, b3, out, out_col):
+    def sa_xyz_mlp_packed_wrapper(new_xyz, xyz, pack, w1, b1, w2, b2, w3, b3, out, out_col, zeroed=False):
         return pointnet2_cpu.sa_xyz_mlp_wrapper(new_xyz, xyz, pack.idx, w1, b1, w2, b2, w3, b3, out, out_col)
 
     @staticmethod

@@ -211,7 +211,7 @@ POINTNET2["rcnn_point_mlp_wrapper"] = check_rcnn_point_mlp
 
 def check_packed_segmax(self, name, args, host, ret):
     """last layer + pool: the oracle evaluates the layer on the GPU's packed rows and pools them by centre"""
-    a, wt, bias, _, b, m, _, out_col = host
+    a, wt, bias, _, b, m, _, out_col = host[:8]
     pack = args[3]
     tiles = int(pack.hdr[0])
     y = torch.empty((tiles * 64, wt.shape[1]))
