@@ -19,12 +19,15 @@ states the measured fraction per level, `config.scenes_per_s_all_rows` is the sa
 the way the reference does (PRCNN_NO_PACK / PRCNN_NO_POOL_DEDUP), measured in this run.
 
 The JSON line also carries
-  roofline      fused ball_query+group (BASELINE.json configs[1]: B=8, N=16384, M=4096, C=128,
-                ns=32, r=0.2) timed with HIP events on the launch stream; achieved = algorithmic
-                bytes (SURVEY.md section 8d formula) / average duration of the launch pair
-  roofline_mfma the dominant kernel of the step, the hand-written f32 MFMA kernel of the RCNN SA MLP over packed rows
-                (prcnn_sa_packed_mlp) on FULL balls (64 distinct rows per centre: every tile does all its flops),
-                against the dense f32 MFMA peak
+  roofline      the dominant kernel of the product step -- the largest single launch: the RPN's last stretch over all points
+                (prcnn_rpn_tail: interpolation + FP module 0 + both heads, csrc/rpn_tail.hip) on the engine's own inputs, timed
+                with HIP events on the launch stream; MFMA-bound: algorithmic flops / average duration against the dense
+                f32 MFMA peak; traffic = HBM bytes per launch from the PMC passes (profiles/r02_pmc_product_kernels.md)
+  roofline_mfma the hand-written f32 MFMA kernel of the RCNN SA MLP over packed rows (prcnn_sa_packed_mlp) on FULL balls
+                (64 distinct rows per centre: every tile does all its flops), against the dense f32 MFMA peak
+  roofline_reference_op  fused ball_query+group of the reference's operator API (BASELINE.json configs[1]: B=8, N=16384,
+                M=4096, C=128, ns=32, r=0.2; not on the engine's path any more): algorithmic bytes (SURVEY.md section 8d
+                formula) / average duration of the launch pair
   roofline_product  the largest HBM-streaming kernel of the product step (prcnn_roipool3d_canonical) the same way
   config.driver_scenes_per_s  the whole driver: loader processes (scene source + 16384-point sampler on the host, as the
                 reference's DataLoader workers), pinned upload, the pipelined engine, one D2H per batch, KITTI result
@@ -49,6 +52,7 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32 MFMA peak (MI355X_MICROARCH.md)
 BATCH = 8
 NPOINTS = 16384
 
@@ -141,18 +145,58 @@ def roofline_sa_mlp_fused(dev, reps=10):
     ms = float(np.mean([a.elapsed_time(e) for a, e in evs]))
     flops = 2.0 * b * m * ns * (128 * 128 + 128 * c3)
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": round(achieved, 1), "peak": 157.3, "unit": "TFLOP/s",
-            "frac": round(achieved / 157.3, 4), "traffic": None,
+    return {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
             "kernel": "sa_packed_mlp128_kernel (prcnn_sa_packed_mlp) on full balls: 64 distinct rows per centre",
             "launch_ms": round(ms, 4), "algorithmic_flops_per_launch": flops,
             "shape": {"clouds": b, "points": n, "centres": m, "nsample": ns, "mlp": [128, 128, c3]}}
 
 
+def roofline_rpn_tail(dev, cfg, model, reps=20):
+    """The dominant kernel of the product step (the largest single launch, ~9 % of a step): the RPN's last stretch over all
+    8 x 16384 points in one kernel (csrc/rpn_tail.hip: interpolation -> FP module 256-128-128 -> cls 128-128-1 and reg
+    128-128-76), on the inputs the engine really hands it (neighbour indices / weights of three_nn on a synthetic batch, the
+    FP1 output as the table).  MFMA-bound: achieved = algorithmic flops / average HIP-event duration against the dense f32
+    MFMA peak.  traffic = HBM bytes per launch from the PMC passes over the product step."""
+    F = importlib.import_module(PKG + ".net.fast_infer")
+    pu = importlib.import_module(PKG + ".pointnet2.pointnet2_utils")
+    synth = importlib.import_module(PKG + ".synth")
+    eng = F.FastPointRCNN(model, cfg)
+    if eng.rpn_tail is None:
+        return None
+    pts = torch.from_numpy(synth.scenes(BATCH, NPOINTS, seed0=3000)).to(dev)
+    geo = eng.geometry(pts)
+    _, (known, idx, weight) = eng._backbone(pts, geo, fuse_tail=True)
+    tw = eng.rpn_tail
+    B, N = idx.shape[0], idx.shape[1]
+    feats = torch.empty((B, N, 128), device=dev); cls = torch.empty((B, N, 1), device=dev); reg = torch.empty((B, N, tw["n_reg"]), device=dev)
+    run = lambda: pu.pointnet2.rpn_tail_wrapper(known, idx, weight, tw["wcat"], tw["bcat"], tw["wc2"], tw["bc2"], feats, cls, reg)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, e in evs:
+        a.record(); run(); e.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(e) for a, e in evs]))
+    rows = B * N
+    flops = 2.0 * rows * (256 * 128 + 4 * 128 * 128 + 128)
+    achieved = flops / (ms * 1e-3) / 1e12
+    alg_bytes = known.numel() * 4 + rows * 24 + rows * (128 + 1 + tw["n_reg"]) * 4
+    return {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": 328.29e6,
+            "traffic_source": "profiles/r02_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over the product step)",
+            "kernel": "rpn_tail_kernel (prcnn_rpn_tail)", "launch_ms": round(ms, 4), "algorithmic_flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "shape": {"points": rows, "coarse_points": known.shape[0] * known.shape[1], "layers": "256-128-128 | 128-128-1 | 128-128-%d" % tw["n_reg"]}}
+
+
 def roofline_roipool(dev, cfg, model, reps=20):
     """The largest HBM-streaming kernel of the product step: RoI pooling + canonical transform + RCNN row layout
-    (prcnn_roipool3d_canonical) on one batch of 8 scenes x 100 RoIs x 512 points x (8 + 128) floats.
-    Algorithmic bytes (roipool row, with this kernel's row layout): read xyz, features, mask,
-    depth once and the RoIs; write EVERY pooled row in full (the all-rows form: pooled_cnt = NULL)."""
+    (prcnn_roipool3d_canonical) on one batch of 8 scenes x 100 RoIs x 512 points x (8 + 128) floats, in the form the engine
+    launches it (pooled_cnt given: the feature columns of the wrap-around copies beyond the first multiple of 64 rows are not
+    written -- nobody reads them).  Algorithmic bytes (roipool row, with this kernel's row layout):
+    read xyz, features, mask, depth once and the RoIs; write the rows this form writes (counted from pooled_cnt)."""
     pkg = importlib.import_module(PKG)
     if pkg.DROPIN_DIR not in sys.path:
         sys.path.insert(0, pkg.DROPIN_DIR)
@@ -168,7 +212,8 @@ def roofline_roipool(dev, cfg, model, reps=20):
     B, M, S, C = BATCH, rois.shape[1], cfg.RCNN.NUM_POINTS, feats.shape[2]
     pooled = torch.empty((B, M, S, 8 + C), device=dev)
     empty = torch.empty((B, M), dtype=torch.int32, device=dev)
-    run = lambda: roipool3d_cuda.forward_canonical(pts, rois.contiguous(), feats, mask, depth, cfg.RCNN.POOL_EXTRA_WIDTH, pooled, empty)
+    cnt = torch.empty((B, M), dtype=torch.int32, device=dev)
+    run = lambda: roipool3d_cuda.forward_canonical(pts, rois.contiguous(), feats, mask, depth, cfg.RCNN.POOL_EXTRA_WIDTH, pooled, empty, cnt)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -177,12 +222,14 @@ def roofline_roipool(dev, cfg, model, reps=20):
         a.record(); run(); e.record()
     torch.cuda.synchronize()
     ms = float(np.mean([a.elapsed_time(e) for a, e in evs]))
-    nbytes = B * (NPOINTS * (12 + 4 * C + 8) + M * 28 + M * S * (8 + C) * 4 + M * 4)
+    full_rows = int(torch.clamp((cnt.long() + 63) // 64 * 64, max=S).sum())        # rows written with their feature columns
+    nbytes = B * (NPOINTS * (12 + 4 * C + 8) + M * 28 + M * 8) + full_rows * (8 + C) * 4 + (B * M * S - full_rows) * 32
     achieved = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": 429.18e6, "traffic_source": "profiles/r02_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, all-rows form)",
-            "kernel": "roipool3d_canonical_kernel (prcnn_roipool3d_canonical)", "launch_ms": round(ms, 4),
-            "algorithmic_bytes_per_launch": nbytes, "shape": {"B": B, "N": NPOINTS, "rois": M, "sampled": S, "row_floats": 8 + C}}
+            "traffic": 93.77e6, "traffic_source": "profiles/r02_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over the product step)",
+            "kernel": "roipool3d_canonical_kernel (prcnn_roipool3d_canonical, product form)", "launch_ms": round(ms, 4),
+            "algorithmic_bytes_per_launch": nbytes, "mean_points_per_roi": round(float(cnt.float().mean()), 1),
+            "shape": {"B": B, "N": NPOINTS, "rois": M, "sampled": S, "row_floats": 8 + C}}
 
 
 def driver_leg(cfg, model, dev, scenes=1536):
@@ -424,9 +471,10 @@ def main():
     }
     if rank == 0:
         if not args.no_roofline:
-            line["roofline"] = roofline_query_and_group(dev)
+            line["roofline"] = roofline_rpn_tail(dev, cfg, model) or roofline_sa_mlp_fused(dev)
             line["roofline_mfma"] = roofline_sa_mlp_fused(dev)
             line["roofline_product"] = roofline_roipool(dev, cfg, model)
+            line["roofline_reference_op"] = roofline_query_and_group(dev)
         if world == 1 and not args.no_driver:
             line["config"]["driver_scenes_per_s"] = driver_leg(cfg, model, dev)
         if world == 1 and not args.no_cpu_baseline:
