@@ -271,6 +271,115 @@ __global__ __launch_bounds__(256, 2) void packed_layer_pipe_kernel(
     pl_epilogue<SEGMAX>(acc0, acc1, tiles, ctr, t, rows, n0, bias, do_relu, out, ldo, rowinfo, tilecloud, m, out_col, n_store);
 }
 
+// ---- 32-row tiles: the layers that would give fewer than 256 workgroups of 64 rows (FP3, SA4's per-point parts, the RCNN
+// heads: a few thousand rows, many panels).  Their launch time is one workgroup's serial panel chain; halving the rows of a
+// tile halves the MFMAs of a stage (one accumulator per wave: 64 MFMAs, each waiting for the one before it -- the pipe's
+// latency equals its occupancy for this instruction) and doubles the workgroups.  Per row the k order is that of the 64-row
+// kernels: same bits.  Host-count mode only.
+#define PL32_GROUP(wf, BODY)                                                                            \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wf[4 * g + 0], acc, 0, 0, 0);                       \
+    BODY                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wf[4 * g + 1], acc, 0, 0, 0);                       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wf[4 * g + 2], acc, 0, 0, 0);                       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wf[4 * g + 3], acc, 0, 0, 0);
+__global__ __launch_bounds__(256, 2) void packed_layer_pipe32_kernel(
+    long rows, int K, int N, const float *__restrict__ A, long lda, const float *__restrict__ W, const float *__restrict__ bias,
+    int do_relu, float *__restrict__ out, long ldo, int n_store)
+{
+    constexpr int R = 32;
+    __shared__ float tiles[2 * R * PL_LD];
+    const long t = blockIdx.x;
+    const int n0 = blockIdx.y * 128;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = tid & 31, r0 = tid >> 5;
+    f32x16 acc = {0};
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, K * N * 4, 0x00020000);
+    const unsigned int row_bytes = (unsigned int)N * 4u;
+    const unsigned int lane_off = ((unsigned int)(64 * h) * (unsigned int)N + (unsigned int)(n0 + 32 * w + j)) * 4u;
+    const long left = rows - t * R;
+    const unsigned int a_row_bytes = (unsigned int)lda * 4u;
+    const __amdgpu_buffer_rsrc_t ars =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(A + t * R * lda), 0, (int)((left < R ? left : R) * (long)a_row_bytes), 0x00020000);
+    const unsigned int a_lane = (unsigned int)r0 * a_row_bytes + 16u * chunk;
+    float wa[64], wb[64];
+    {
+        PL_LOAD_W(wa, 0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4 *>(tiles + (r0 + 8 * i) * PL_LD + 4 * chunk) =
+                __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, a_lane, (unsigned int)(8 * i) * a_row_bytes, 0));
+    }
+    const int np = K >> 7;
+    for (int p = 0; p < np; ++p) {
+        PL_VM_DRAIN
+        lds_barrier();
+        const float *T = tiles + (p & 1) * (R * PL_LD);
+        float *TN = tiles + ((p + 1) & 1) * (R * PL_LD);
+        const float *ap = T + j * PL_LD + 64 * h;
+        f32x4 a = *reinterpret_cast<const f32x4 *>(ap);
+        if (p + 1 < np) {
+            const int kn = (p + 1) * 128;
+            f32x4 ar[4];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                f32x4 nx = a;
+                if (g < 15) nx = *reinterpret_cast<const f32x4 *>(ap + 4 * (g + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                PL32_GROUP(wa,
+                    if (g < 4)
+                        ar[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            ars, a_lane, (unsigned int)(8 * g) * a_row_bytes + (unsigned int)kn * 4u, 0));
+                    else if (g >= 8 && g < 12)
+                        *reinterpret_cast<f32x4 *>(TN + (r0 + 8 * (g - 8)) * PL_LD + 4 * chunk) = ar[g - 8];
+                    _Pragma("unroll") for (int q = 0; q < 6; ++q)
+                        if (6 * g + q < 64)
+                            wb[6 * g + q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                wrs, lane_off, (unsigned int)(kn + 6 * g + q) * row_bytes, 0));)
+                a = nx;
+            }
+#pragma unroll
+            for (int s = 0; s < 64; ++s) wa[s] = wb[s];
+        } else {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                f32x4 nx = a;
+                if (g < 15) nx = *reinterpret_cast<const f32x4 *>(ap + 4 * (g + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                PL32_GROUP(wa, )
+                a = nx;
+            }
+        }
+    }
+    const float bcol = bias[n0 + 32 * w + j];
+    __syncthreads();                                       // the panel tiles are dead: stage the results through one
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = acc[r] + bcol;
+        tiles[row * PL_LD + 32 * w + j] = do_relu ? fmaxf(v, 0.f) : v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = r0 + 8 * i;
+        const long g = t * R + row;
+        if (g < rows) {
+            const int c0 = n0 + 4 * chunk;
+            const float4 v = *reinterpret_cast<const float4 *>(tiles + row * PL_LD + 4 * chunk);
+            if (c0 + 4 <= n_store && (ldo & 3) == 0) {
+                *reinterpret_cast<float4 *>(out + g * ldo + c0) = v;
+            } else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c0 + q < n_store) out[g * ldo + c0 + q] = e[q];
+            }
+        }
+    }
+}
+
 // out[r][0..n) = A[r][0..K) @ W + bias for n <= 4 output columns (the 1-wide last layer of the classification heads): a
 // GEMV per output, no MFMA tile to fill.  32 lanes per row: lane l accumulates k = l, l + 32, ... as one fma chain (from 0),
 // the 32 partial sums are added in an xor butterfly (16, 8, 4, 2, 1), then the bias.  oracle/mlp_oracle.c orc_rows_dot
@@ -351,6 +460,12 @@ extern "C" int prcnn_packed_layer(const unsigned int *hdr, long rows, long max_t
     PRCNN_REQUIRE(A && W && bias && out, "packed_layer: null pointer");
     PRCNN_REQUIRE(((uintptr_t)A & 15) == 0 && (((uintptr_t)out & 15) == 0 || (ldo & 3) != 0), "packed_layer: 16-byte alignment required");
     const int col_blocks = (n_store + 127) / 128;          // column blocks that hold nothing to store are not launched
+    if (!hdr && K >= 256 && pipe_enabled() && tiles * col_blocks < 256) {
+        const long tiles32 = (rows + 31) / 32;
+        hipLaunchKernelGGL(packed_layer_pipe32_kernel, dim3((unsigned)tiles32, col_blocks), dim3(256), 0, (hipStream_t)stream, rows, K, N, A,
+                           lda, W, bias, relu, out, ldo, n_store);
+        return check_launch("packed_layer");
+    }
     auto kern = K >= 256 && pipe_enabled() ? packed_layer_pipe_kernel<false> : packed_layer_kernel<false>;
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, col_blocks), dim3(256), 0, (hipStream_t)stream, hdr, rows, K, N, A, lda, W, bias,
                        relu, out, ldo, nullptr, nullptr, 0, 0, n_store);
