@@ -15,6 +15,19 @@ _F = C.c_float
 _D = C.c_double
 _L = C.c_longlong
 
+class GatherProblem(C.Structure):
+    """prcnn_gather_problem (include/prcnn_hip.h)"""
+    _fields_ = [("b", _I), ("n", _I), ("c1", _I), ("max_tiles", C.c_long), ("P", _P), ("wxyz", _P), ("rowinfo", _P), ("rowdxyz", _P),
+                ("tilecloud", _P), ("hdr", _P), ("out", _P)]
+
+
+class LayerProblem(C.Structure):
+    """prcnn_layer_problem (include/prcnn_hip.h)"""
+    _fields_ = [("hdr", _P), ("rows", C.c_long), ("max_tiles", C.c_long), ("K", _I), ("N", _I), ("n_store", _I), ("A", _P), ("lda", C.c_long),
+                ("W", _P), ("bias", _P), ("relu", _I), ("out", _P), ("ldo", C.c_long), ("b", _I), ("m", _I), ("rowinfo", _P), ("tilecloud", _P),
+                ("out_col", _I), ("out_is_zero", _I)]
+
+
 # name -> argument types (return type is always int except where noted)
 SIGNATURES = {
     "prcnn_version": [],
@@ -42,6 +55,8 @@ SIGNATURES = {
     "prcnn_packed_layer": [_P, C.c_long, C.c_long, _I, _I, _I, _P, C.c_long, _P, _P, _I, _P, C.c_long, _P],
     "prcnn_sa_xyz_mlp_packed": [_I, _I, _I, _I, _I, C.c_long] + [_P] * 11 + [_I, _I, _I, _P],
     "prcnn_rows_dot": [C.c_long, _I, _I, _P, C.c_long, _P, _P, _P, C.c_long, _P],
+    "prcnn_packed_gather_affine_batch": [_I, C.POINTER(GatherProblem), _P],
+    "prcnn_packed_layer_batch": [_I, C.POINTER(LayerProblem), _I, _P],
     "prcnn_rpn_tail": [_I, _I, _I] + [_P] * 7 + [_I] + [_P] * 4,
     "prcnn_packed_layer_segmax": [_I, _I, C.c_long, _I, _I, _P, C.c_long, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "prcnn_maxpool_pm": [C.c_long, _I, _I, _P, _P, _I, _I, _P],

@@ -26,11 +26,31 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int PL_ROWS = 64;
 constexpr int PL_LD = 128 + 4;
 
-__global__ __launch_bounds__(256) void packed_gather_affine_kernel(
-    int n, int c1, const unsigned int *__restrict__ hdr, const float4 *__restrict__ rowdxyz,
-    const float4 *__restrict__ P, const float4 *__restrict__ wxyz, const unsigned int *__restrict__ rowinfo,
-    const int *__restrict__ tilecloud, float4 *__restrict__ out)
+// One layer problem / one gather problem; a launch carries up to PL_MAX_BATCH of them (blockIdx.z picks): the independent
+// scales of an MSG level run side by side in ONE launch instead of one small latency-bound launch each.
+constexpr int PL_MAX_BATCH = 4;
+struct PLProblem {
+    const unsigned int *hdr; long rows_host; int K, N; const float *A; long lda; const float *W; const float *bias; int do_relu;
+    float *out; long ldo; const unsigned int *rowinfo; const int *tilecloud; int m, out_col, n_store;
+};
+struct PLBatch { PLProblem p[PL_MAX_BATCH]; };
+struct PGProblem {
+    int n, c1; const unsigned int *hdr; const float4 *rowdxyz; const float4 *P; const float4 *wxyz; const unsigned int *rowinfo;
+    const int *tilecloud; float4 *out;
+};
+struct PGBatch { PGProblem p[PL_MAX_BATCH]; };
+
+__global__ __launch_bounds__(256) void packed_gather_affine_kernel(const PGBatch bt)
 {
+    const PGProblem &pb = bt.p[blockIdx.z];
+    const int n = pb.n, c1 = pb.c1;
+    const unsigned int *__restrict__ hdr = pb.hdr;
+    const float4 *__restrict__ rowdxyz = pb.rowdxyz;
+    const float4 *__restrict__ P = pb.P;
+    const float4 *__restrict__ wxyz = pb.wxyz;
+    const unsigned int *__restrict__ rowinfo = pb.rowinfo;
+    const int *__restrict__ tilecloud = pb.tilecloud;
+    float4 *__restrict__ out = pb.out;
     const long t = blockIdx.x;
     if (t >= (long)hdr[0]) return;
     const int cloud = tilecloud[t];
@@ -189,16 +209,28 @@ __device__ __forceinline__ void pl_epilogue(const f32x16 &acc0, const f32x16 &ac
 // K = 128: one panel, nothing to prefetch; 3 workgroups per CU cover each other's loads
 template <bool SEGMAX>
 __global__ __launch_bounds__(256, 2) void packed_layer_kernel(
-    const unsigned int *__restrict__ hdr, long rows_host, int K, int N, const float *__restrict__ A, long lda,
-    const float *__restrict__ W, const float *__restrict__ bias, int do_relu, float *__restrict__ out, long ldo,
-    const unsigned int *__restrict__ rowinfo, const int *__restrict__ tilecloud, int m, int out_col, int n_store)
+    const PLBatch bt)
 {
+    const PLProblem &pb = bt.p[blockIdx.z];
+    const unsigned int *__restrict__ hdr = pb.hdr;
+    const long rows_host = pb.rows_host;
+    const int K = pb.K, N = pb.N;
+    const float *__restrict__ A = pb.A;
+    const long lda = pb.lda;
+    const float *__restrict__ W = pb.W;
+    const float *__restrict__ bias = pb.bias;
+    const int do_relu = pb.do_relu;
+    float *__restrict__ out = pb.out;
+    const long ldo = pb.ldo;
+    const unsigned int *__restrict__ rowinfo = pb.rowinfo;
+    const int *__restrict__ tilecloud = pb.tilecloud;
+    const int m = pb.m, out_col = pb.out_col, n_store = pb.n_store;
     __shared__ float tile[PL_ROWS * PL_LD];
     __shared__ int ctr[PL_ROWS];
     const long t = blockIdx.x;
     const long rows = hdr ? (long)hdr[0] * PL_ROWS : rows_host;
-    if (t * PL_ROWS >= rows) return;
     const int n0 = blockIdx.y * 128;
+    if (t * PL_ROWS >= rows || n0 >= n_store) return;          // (a batched launch is sized for its largest problem)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, h = lane >> 5;
     const int chunk = tid & 31, r0 = tid >> 5;
     f32x16 acc0 = {0}, acc1 = {0};
@@ -223,16 +255,28 @@ __global__ __launch_bounds__(256, 2) void packed_layer_kernel(
 // (PL_STAGE_PREFETCH); the k order of every dot product is the same as in the one-panel kernel (panels in sequence).
 template <bool SEGMAX>
 __global__ __launch_bounds__(256, 2) void packed_layer_pipe_kernel(
-    const unsigned int *__restrict__ hdr, long rows_host, int K, int N, const float *__restrict__ A, long lda,
-    const float *__restrict__ W, const float *__restrict__ bias, int do_relu, float *__restrict__ out, long ldo,
-    const unsigned int *__restrict__ rowinfo, const int *__restrict__ tilecloud, int m, int out_col, int n_store)
+    const PLBatch bt)
 {
+    const PLProblem &pb = bt.p[blockIdx.z];
+    const unsigned int *__restrict__ hdr = pb.hdr;
+    const long rows_host = pb.rows_host;
+    const int K = pb.K, N = pb.N;
+    const float *__restrict__ A = pb.A;
+    const long lda = pb.lda;
+    const float *__restrict__ W = pb.W;
+    const float *__restrict__ bias = pb.bias;
+    const int do_relu = pb.do_relu;
+    float *__restrict__ out = pb.out;
+    const long ldo = pb.ldo;
+    const unsigned int *__restrict__ rowinfo = pb.rowinfo;
+    const int *__restrict__ tilecloud = pb.tilecloud;
+    const int m = pb.m, out_col = pb.out_col, n_store = pb.n_store;
     __shared__ float tiles[2 * PL_ROWS * PL_LD];
     __shared__ int ctr[PL_ROWS];
     const long t = blockIdx.x;
     const long rows = hdr ? (long)hdr[0] * PL_ROWS : rows_host;
-    if (t * PL_ROWS >= rows) return;
     const int n0 = blockIdx.y * 128;
+    if (t * PL_ROWS >= rows || n0 >= n_store) return;          // (a batched launch is sized for its largest problem)
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chunk = tid & 31, r0 = tid >> 5;
@@ -430,68 +474,138 @@ extern "C" int prcnn_rows_dot(long rows, int K, int n, const float *A, long lda,
 }
 
 // A1 (max_tiles*64, c1) = relu(P[point] + wxyz . rowdxyz) for every packed row (prcnn_ball_pack: rowdxyz = xyz[point] - centre);
-// P (b,n,c1), wxyz (3,c1), c1 % 4 == 0.
+// P (b,n,c1), wxyz (3,c1), c1 % 4 == 0.  Up to 4 problems (the scales of one MSG level) share one launch.
+extern "C" int prcnn_packed_gather_affine_batch(int nprob, const prcnn_gather_problem *pr, void *stream)
+{
+    PRCNN_REQUIRE(nprob >= 0 && nprob <= PL_MAX_BATCH && (nprob == 0 || pr), "packed_gather_affine: 0..%d problems", PL_MAX_BATCH);
+    PGBatch bt;
+    int k = 0;
+    long grid_x = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const prcnn_gather_problem &q = pr[i];
+        PRCNN_REQUIRE(q.b >= 0 && q.n >= 0 && q.max_tiles >= 0 && q.c1 > 0 && q.c1 % 4 == 0, "packed_gather_affine: bad sizes");
+        if (q.max_tiles == 0) continue;
+        PRCNN_REQUIRE(q.P && q.wxyz && q.rowinfo && q.rowdxyz && q.tilecloud && q.hdr && q.out, "packed_gather_affine: null pointer");
+        PRCNN_REQUIRE((((uintptr_t)q.P | (uintptr_t)q.wxyz | (uintptr_t)q.out) & 15) == 0, "packed_gather_affine: 16-byte alignment required");
+        PRCNN_REQUIRE(q.max_tiles <= 0x7fffffffL, "packed_gather_affine: too many tiles");
+        bt.p[k++] = PGProblem{q.n, q.c1, q.hdr, (const float4 *)q.rowdxyz, (const float4 *)q.P, (const float4 *)q.wxyz, q.rowinfo,
+                              q.tilecloud, (float4 *)q.out};
+        if (q.max_tiles > grid_x) grid_x = q.max_tiles;
+    }
+    if (k == 0) return PRCNN_OK;
+    hipLaunchKernelGGL(packed_gather_affine_kernel, dim3((unsigned)grid_x, 1, k), dim3(256), 0, (hipStream_t)stream, bt);
+    return check_launch("packed_gather_affine");
+}
+
 extern "C" int prcnn_packed_gather_affine(int b, int n, int c1, long max_tiles, const float *P, const float *wxyz,
                                           const unsigned int *rowinfo, const float *rowdxyz, const int *tilecloud,
                                           const unsigned int *hdr, float *out, void *stream)
 {
-    PRCNN_REQUIRE(b >= 0 && n >= 0 && max_tiles >= 0 && c1 > 0 && c1 % 4 == 0, "packed_gather_affine: bad sizes");
-    if (max_tiles == 0) return PRCNN_OK;
-    PRCNN_REQUIRE(P && wxyz && rowinfo && rowdxyz && tilecloud && hdr && out, "packed_gather_affine: null pointer");
-    PRCNN_REQUIRE((((uintptr_t)P | (uintptr_t)wxyz | (uintptr_t)out) & 15) == 0, "packed_gather_affine: 16-byte alignment required");
-    PRCNN_REQUIRE(max_tiles <= 0x7fffffffL, "packed_gather_affine: too many tiles");
-    hipLaunchKernelGGL(packed_gather_affine_kernel, dim3((unsigned)max_tiles), dim3(256), 0, (hipStream_t)stream, n, c1, hdr,
-                       (const float4 *)rowdxyz, (const float4 *)P, (const float4 *)wxyz, rowinfo, tilecloud, (float4 *)out);
-    return check_launch("packed_gather_affine");
+    const prcnn_gather_problem q = {b, n, c1, max_tiles, P, wxyz, rowinfo, rowdxyz, tilecloud, hdr, out};
+    return prcnn_packed_gather_affine_batch(1, &q, stream);
 }
 
-// out[r][0..n_store) = act(A[r][0..K) @ W + bias)[0..n_store), K and N multiples of 128, W (K,N) k-major, n_store <= N (the
-// caller pads a narrow last layer's weights to N = 128 and asks for its real width).  Row count: hdr != NULL ->
-// hdr[0] * 64 rows (a packed list; max_tiles sizes the grid), else `rows` (host count; max_tiles ignored).
+// Layer problems (plain: out[r][0..n_store) = act(A[r][0..K) @ W + bias)[0..n_store); segmax: last layer of a level + max pool,
+// out[(b*m)][out_col .. out_col + N) = max over each centre's packed rows of relu(A[r] @ W + bias) through atomicMax into a zeroed
+// slice).  K and N multiples of 128, W (K,N) k-major, n_store <= N (the caller pads a narrow last layer's weights to N = 128 and
+// asks for its real width).  Row count: hdr != NULL -> hdr[0] * 64 rows (a packed list; max_tiles sizes the grid), else `rows`
+// (host count).  Up to 4 problems that land on the same kernel share ONE launch (grid.z); others are launched one by one.
+namespace {
+enum PLClass { PL_ONE, PL_PIPE, PL_PIPE32 };
+}
+extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr, int segmax, void *stream)
+{
+    PRCNN_REQUIRE(nprob >= 0 && nprob <= PL_MAX_BATCH && (nprob == 0 || pr), "packed_layer: 0..%d problems", PL_MAX_BATCH);
+    hipStream_t st = (hipStream_t)stream;
+    PLBatch bt;
+    PLClass cls[PL_MAX_BATCH];
+    long tiles_of[PL_MAX_BATCH];
+    int blocks_of[PL_MAX_BATCH], src[PL_MAX_BATCH];
+    int k = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const prcnn_layer_problem &q = pr[i];
+        PRCNN_REQUIRE(q.K > 0 && q.N > 0 && q.K % 128 == 0 && q.N % 128 == 0, "packed_layer: K=%d, N=%d must be multiples of 128", q.K, q.N);
+        PRCNN_REQUIRE(q.lda >= q.K && q.lda % 4 == 0, "packed_layer: bad leading dimension of A");
+        long tiles;
+        int n_store;
+        if (segmax) {
+            PRCNN_REQUIRE(q.b >= 0 && q.m >= 0 && q.max_tiles >= 0 && q.out_col >= 0 && q.ldo >= q.out_col + q.N, "packed_layer_segmax: bad layout");
+            if ((long)q.b * q.m == 0) continue;
+            PRCNN_REQUIRE(q.A && q.W && q.bias && q.rowinfo && q.tilecloud && q.hdr && q.out, "packed_layer_segmax: null pointer");
+            PRCNN_REQUIRE(((uintptr_t)q.A & 15) == 0 && q.max_tiles <= 0x7fffffffL, "packed_layer_segmax: alignment / size");
+            if (!q.out_is_zero && hipMemset2DAsync(q.out + q.out_col, (size_t)q.ldo * sizeof(float), 0, (size_t)q.N * sizeof(float),
+                                                    (size_t)q.b * q.m, st) != hipSuccess) {
+                set_error("packed_layer_segmax: cannot zero the output slice");
+                return PRCNN_ELAUNCH;
+            }
+            tiles = q.max_tiles;
+            n_store = q.N;
+        } else {
+            PRCNN_REQUIRE(q.n_store >= 1 && q.n_store <= q.N && q.ldo >= q.n_store, "packed_layer: n_store=%d outside 1..N (or ldo too small)", q.n_store);
+            tiles = q.hdr ? q.max_tiles : (q.rows + PL_ROWS - 1) / PL_ROWS;
+            PRCNN_REQUIRE(tiles >= 0 && tiles <= 0x7fffffffL && q.rows >= 0, "packed_layer: bad row count");
+            n_store = q.n_store;
+            if (tiles > 0) {
+                PRCNN_REQUIRE(q.A && q.W && q.bias && q.out, "packed_layer: null pointer");
+                PRCNN_REQUIRE(((uintptr_t)q.A & 15) == 0 && (((uintptr_t)q.out & 15) == 0 || (q.ldo & 3) != 0), "packed_layer: 16-byte alignment required");
+            }
+        }
+        if (tiles == 0) continue;
+        const int col_blocks = (n_store + 127) / 128;      // column blocks that hold nothing to store are not launched
+        const bool pipe = q.K >= 256 && pipe_enabled();
+        cls[k] = (!segmax && !q.hdr && pipe && tiles * col_blocks < 256) ? PL_PIPE32 : (pipe ? PL_PIPE : PL_ONE);
+        tiles_of[k] = tiles; blocks_of[k] = col_blocks; src[k] = i;
+        bt.p[k] = PLProblem{q.hdr, q.rows, q.K, q.N, q.A, q.lda, q.W, q.bias, segmax ? 1 : q.relu, q.out, q.ldo,
+                            segmax ? q.rowinfo : nullptr, segmax ? q.tilecloud : nullptr, segmax ? q.m : 0, segmax ? q.out_col : 0, n_store};
+        ++k;
+    }
+    if (k == 0) return PRCNN_OK;
+    bool together = cls[0] != PL_PIPE32;
+    for (int i = 1; i < k; ++i) together = together && cls[i] == cls[0];
+    for (int i = 0; i < k; ++i) {
+        PLBatch one;
+        long gx = tiles_of[i];
+        int gy = blocks_of[i], gz = 1;
+        if (together) {
+            for (int r = 1; r < k; ++r) { if (tiles_of[r] > gx) gx = tiles_of[r]; if (blocks_of[r] > gy) gy = blocks_of[r]; }
+            gz = k;
+        } else {
+            one.p[0] = bt.p[i];
+        }
+        const PLBatch &arg = together ? bt : one;
+        if (cls[i] == PL_PIPE32) {
+            const prcnn_layer_problem &q = pr[src[i]];
+            hipLaunchKernelGGL(packed_layer_pipe32_kernel, dim3((unsigned)((q.rows + 31) / 32), gy), dim3(256), 0, st, q.rows, q.K, q.N, q.A,
+                               q.lda, q.W, q.bias, q.relu, q.out, q.ldo, q.n_store);
+        } else if (segmax) {
+            auto kern = cls[i] == PL_PIPE ? packed_layer_pipe_kernel<true> : packed_layer_kernel<true>;
+            hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy, gz), dim3(256), 0, st, arg);
+        } else {
+            auto kern = cls[i] == PL_PIPE ? packed_layer_pipe_kernel<false> : packed_layer_kernel<false>;
+            hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy, gz), dim3(256), 0, st, arg);
+        }
+        const int rc = check_launch(segmax ? "packed_layer_segmax" : "packed_layer");
+        if (rc != PRCNN_OK || together) return rc;
+    }
+    return PRCNN_OK;
+}
+
 extern "C" int prcnn_packed_layer(const unsigned int *hdr, long rows, long max_tiles, int K, int N, int n_store, const float *A,
                                   long lda, const float *W, const float *bias, int relu, float *out, long ldo, void *stream)
 {
-    PRCNN_REQUIRE(K > 0 && N > 0 && K % 128 == 0 && N % 128 == 0, "packed_layer: K=%d, N=%d must be multiples of 128", K, N);
-    PRCNN_REQUIRE(n_store >= 1 && n_store <= N, "packed_layer: n_store=%d outside 1..N", n_store);
-    PRCNN_REQUIRE(lda >= K && ldo >= n_store && lda % 4 == 0, "packed_layer: bad leading dimensions");
-    const long tiles = hdr ? max_tiles : (rows + PL_ROWS - 1) / PL_ROWS;
-    PRCNN_REQUIRE(tiles >= 0 && tiles <= 0x7fffffffL && rows >= 0, "packed_layer: bad row count");
-    if (tiles == 0) return PRCNN_OK;
-    PRCNN_REQUIRE(A && W && bias && out, "packed_layer: null pointer");
-    PRCNN_REQUIRE(((uintptr_t)A & 15) == 0 && (((uintptr_t)out & 15) == 0 || (ldo & 3) != 0), "packed_layer: 16-byte alignment required");
-    const int col_blocks = (n_store + 127) / 128;          // column blocks that hold nothing to store are not launched
-    if (!hdr && K >= 256 && pipe_enabled() && tiles * col_blocks < 256) {
-        const long tiles32 = (rows + 31) / 32;
-        hipLaunchKernelGGL(packed_layer_pipe32_kernel, dim3((unsigned)tiles32, col_blocks), dim3(256), 0, (hipStream_t)stream, rows, K, N, A,
-                           lda, W, bias, relu, out, ldo, n_store);
-        return check_launch("packed_layer");
-    }
-    auto kern = K >= 256 && pipe_enabled() ? packed_layer_pipe_kernel<false> : packed_layer_kernel<false>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, col_blocks), dim3(256), 0, (hipStream_t)stream, hdr, rows, K, N, A, lda, W, bias,
-                       relu, out, ldo, nullptr, nullptr, 0, 0, n_store);
-    return check_launch("packed_layer");
+    prcnn_layer_problem q = {};
+    q.hdr = hdr; q.rows = rows; q.max_tiles = max_tiles; q.K = K; q.N = N; q.n_store = n_store; q.A = A; q.lda = lda; q.W = W;
+    q.bias = bias; q.relu = relu; q.out = out; q.ldo = ldo;
+    return prcnn_packed_layer_batch(1, &q, 0, stream);
 }
 
-// last layer of a level + max pool: out[(b*m)][out_col .. out_col + N) = max over each centre's packed rows of
-// relu(A[r] @ W + bias); the slice is zeroed first (values are >= 0, partial maxima arrive through atomicMax).
 extern "C" int prcnn_packed_layer_segmax(int b, int m, long max_tiles, int K, int N, const float *A, long lda, const float *W,
                                          const float *bias, const unsigned int *rowinfo, const int *tilecloud,
                                          const unsigned int *hdr, float *out, int out_stride, int out_col, int out_is_zero, void *stream)
 {
-    PRCNN_REQUIRE(b >= 0 && m >= 0 && max_tiles >= 0, "packed_layer_segmax: bad sizes");
-    PRCNN_REQUIRE(K > 0 && N > 0 && K % 128 == 0 && N % 128 == 0, "packed_layer_segmax: K=%d, N=%d must be multiples of 128", K, N);
-    PRCNN_REQUIRE(lda >= K && lda % 4 == 0 && out_col >= 0 && out_stride >= out_col + N, "packed_layer_segmax: bad layout");
-    if ((long)b * m == 0) return PRCNN_OK;
-    PRCNN_REQUIRE(A && W && bias && rowinfo && tilecloud && hdr && out, "packed_layer_segmax: null pointer");
-    PRCNN_REQUIRE(((uintptr_t)A & 15) == 0 && max_tiles <= 0x7fffffffL, "packed_layer_segmax: alignment / size");
-    hipStream_t st = (hipStream_t)stream;
-    if (!out_is_zero && hipMemset2DAsync(out + out_col, (size_t)out_stride * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)b * m, st) != hipSuccess) {
-        set_error("packed_layer_segmax: cannot zero the output slice");
-        return PRCNN_ELAUNCH;
-    }
-    if (max_tiles == 0) return PRCNN_OK;
-    auto kern = K >= 256 && pipe_enabled() ? packed_layer_pipe_kernel<true> : packed_layer_kernel<true>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)max_tiles, N / 128), dim3(256), 0, st, hdr, 0L, K, N, A, lda, W, bias, 1, out,
-                       (long)out_stride, rowinfo, tilecloud, m, out_col, N);
-    return check_launch("packed_layer_segmax");
+    prcnn_layer_problem q = {};
+    q.hdr = hdr; q.max_tiles = max_tiles; q.K = K; q.N = N; q.n_store = N; q.A = A; q.lda = lda; q.W = W; q.bias = bias; q.relu = 1;
+    q.out = out; q.ldo = out_stride; q.b = b; q.m = m; q.rowinfo = rowinfo; q.tilecloud = tilecloud; q.out_col = out_col;
+    q.out_is_zero = out_is_zero;
+    return prcnn_packed_layer_batch(1, &q, 1, stream);
 }

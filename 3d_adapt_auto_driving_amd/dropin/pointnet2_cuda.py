@@ -257,6 +257,52 @@ def packed_layer_wrapper(a, wt, bias, relu, out, pack=None):
     return out
 
 
+def packed_gather_affine_batch_wrapper(problems):
+    """packed_gather_affine_wrapper for up to 4 independent problems [(new_xyz, xyz, P, wxyz, pack, out), ...] -- the scales of one
+    MSG level -- in ONE launch."""
+    arr = (_lib.GatherProblem * len(problems))()
+    for q, (new_xyz, xyz, P, wxyz, pack, out) in zip(arr, problems):
+        _chk(torch.float32, new_xyz, xyz, P, wxyz, out)
+        q.b, q.n, q.c1 = P.shape
+        q.max_tiles = pack.max_tiles
+        q.P, q.wxyz, q.out = P.data_ptr(), wxyz.data_ptr(), out.data_ptr()
+        q.rowinfo, q.rowdxyz, q.tilecloud, q.hdr = pack.rowinfo.data_ptr(), pack.rowdxyz.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr()
+    _lib.call("prcnn_packed_gather_affine_batch", len(problems), arr, _lib.current_stream(problems[0][2]))
+    return [p[5] for p in problems]
+
+
+def packed_layer_batch_wrapper(problems):
+    """packed_layer_wrapper for up to 4 independent problems [(a, wt, bias, relu, out, pack-or-None), ...] in ONE launch (those
+    that do not land on the same kernel are launched one by one by the library)."""
+    arr = (_lib.LayerProblem * len(problems))()
+    for q, (a, wt, bias, relu, out, pack) in zip(arr, problems):
+        _chk(torch.float32, wt, bias)
+        if a.dim() != 2 or out.dim() != 2 or a.stride(1) != 1 or out.stride(1) != 1 or not a.is_cuda:
+            raise RuntimeError("pointnet2_cuda: packed_layer expects 2-D float32 CUDA matrices with unit column stride")
+        q.K, q.N = wt.shape
+        q.n_store = out.size(1)
+        q.A, q.lda, q.W, q.bias, q.relu = a.data_ptr(), a.stride(0), wt.data_ptr(), bias.data_ptr(), int(bool(relu))
+        q.out, q.ldo = out.data_ptr(), out.stride(0)
+        q.hdr, q.rows, q.max_tiles = (None, a.size(0), 0) if pack is None else (pack.hdr.data_ptr(), 0, pack.max_tiles)
+    _lib.call("prcnn_packed_layer_batch", len(problems), arr, 0, _lib.current_stream(problems[0][0]))
+    return [p[4] for p in problems]
+
+
+def packed_layer_segmax_batch_wrapper(problems):
+    """packed_layer_segmax_wrapper for up to 4 problems [(a, wt, bias, pack, b, m, out, out_col, zeroed), ...] in ONE launch."""
+    arr = (_lib.LayerProblem * len(problems))()
+    for q, (a, wt, bias, pack, b, m, out, out_col, zeroed) in zip(arr, problems):
+        _chk(torch.float32, a, wt, bias, out)
+        q.K, q.N = wt.shape
+        q.n_store = q.N
+        q.A, q.lda, q.W, q.bias, q.relu = a.data_ptr(), a.stride(0), wt.data_ptr(), bias.data_ptr(), 1
+        q.out, q.ldo, q.out_col, q.out_is_zero = out.data_ptr(), out.size(-1), out_col, int(bool(zeroed))
+        q.b, q.m = b, m
+        q.hdr, q.max_tiles, q.rowinfo, q.tilecloud = pack.hdr.data_ptr(), pack.max_tiles, pack.rowinfo.data_ptr(), pack.tilecloud.data_ptr()
+    _lib.call("prcnn_packed_layer_batch", len(problems), arr, 1, _lib.current_stream(problems[0][0]))
+    return [p[6] for p in problems]
+
+
 def rows_dot_wrapper(a, wt, bias, out):
     """out (R, n) = a (R, K) @ wt (K, n) + bias for n <= 4 (a classification head's last layer) -- csrc/packed_layer.hip."""
     _chk(torch.float32, wt, bias)

@@ -44,6 +44,8 @@ USE_POINT_LAYER = os.environ.get("PRCNN_LIB_GEMM") is None     # per-point layer
 PAD128 = USE_PACKED and USE_POINT_LAYER
 # the finest FP module and both RPN heads in one kernel (csrc/rpn_tail.hip); PRCNN_NO_RPN_TAIL=1: layer by layer (A/B, same bits)
 USE_RPN_TAIL = os.environ.get("PRCNN_NO_RPN_TAIL") is None
+# the scales of a wide MSG level (RPN SA3 / SA4) stage by stage, side by side in one launch per stage; PRCNN_NO_SCALE_BATCH=1: A/B
+USE_SCALE_BATCH = os.environ.get("PRCNN_NO_SCALE_BATCH") is None
 
 
 def _round4(c):
@@ -413,6 +415,31 @@ class FastPointRCNN:
             y = mlp(grouped.view(B * M * ns, -1))
         ext.maxpool_pm_wrapper(y, ns, out, out_col)
 
+    @staticmethod
+    def _sa_level_wide(xyz, new_xyz, feats, scales, idxs, packs, out, zeroed):
+        """All scales of one MSG level whose layers are wider than the register-resident fused kernels take (RPN SA3 / SA4),
+        STAGE BY STAGE with the scales side by side in one launch per stage: per-point parts, gather + affine over the packed
+        rows, layer 2, layer 3 + segmented max.  On sparse levels every one of these launches is latency-bound (a handful of
+        live tiles), so 4 launches per level instead of 4 per scale.  Same kernels, same bits as `_sa_scale`'s wide branch."""
+        ext = pu.pointnet2
+        B, N, _ = xyz.shape
+        M = new_xyz.shape[1]
+        dev = xyz.device
+        wides = [sc[2].wide for sc in scales]                  # (wf, wx, b1, w2, b2, w3, b3)
+        flat = feats.view(B * N, feats.shape[2])
+        Ps = [torch.empty((B * N, w[0].shape[1]), dtype=torch.float32, device=dev) for w in wides]
+        ext.packed_layer_batch_wrapper([(flat, w[0], w[2], False, P, None) for w, P in zip(wides, Ps)])
+        pks = [pk if pk is not None else ext.ball_pack_wrapper(idx, xyz, new_xyz) for pk, idx in zip(packs, idxs)]
+        a1s = [torch.empty((pk.max_tiles * 64, w[0].shape[1]), dtype=torch.float32, device=dev) for pk, w in zip(pks, wides)]
+        ext.packed_gather_affine_batch_wrapper([(new_xyz, xyz, P.view(B, N, -1), w[1], pk, a1) for P, w, pk, a1 in zip(Ps, wides, pks, a1s)])
+        y2s = [torch.empty((pk.max_tiles * 64, w[3].shape[1]), dtype=torch.float32, device=dev) for pk, w in zip(pks, wides)]
+        ext.packed_layer_batch_wrapper([(a1, w[3], w[4], True, y2, pk) for a1, w, y2, pk in zip(a1s, wides, y2s, pks)])
+        cols, col = [], 0
+        for sc in scales:
+            cols.append(col)
+            col += sc[2].layers[-1][0].shape[1]
+        ext.packed_layer_segmax_batch_wrapper([(y2, w[5], w[6], pk, B, M, out, c, zeroed) for y2, w, pk, c in zip(y2s, wides, pks, cols)])
+
     def _backbone(self, xyz, geo, fuse_tail=False):
         """-> the (B, N, 128) point features; fuse_tail: -> (features, None), or (None, inputs of the fused last stretch)."""
         l_xyz, l_feat = geo["l_xyz"], [None]
@@ -427,10 +454,15 @@ class FastPointRCNN:
             out = (torch.zeros if pre else torch.empty)((B, npoint, wpad), dtype=torch.float32, device=xyz.device)
             if wpad > width and not pre:
                 out[:, :, width:] = 0
-            col = 0
-            for (radius, ns, mlp, cin), idx, pack in zip(scales, lev["idx"], lev.get("pack") or [None] * len(scales)):
-                self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, idx, mlp, cin, out, col, pack=pack, zeroed=pre)
-                col += mlp.layers[-1][0].shape[1]
+            packs = lev.get("pack") or [None] * len(scales)
+            if (USE_SCALE_BATCH and USE_PACKED and 2 <= len(scales) <= 4 and all(sc[2].wide is not None for sc in scales) and
+                    has_entry(pu.pointnet2, "packed_layer_batch_wrapper")):
+                self._sa_level_wide(cur_xyz, lev["new_xyz"], cur_feat, scales, lev["idx"], packs, out, pre)
+            else:
+                col = 0
+                for (radius, ns, mlp, cin), idx, pack in zip(scales, lev["idx"], packs):
+                    self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, idx, mlp, cin, out, col, pack=pack, zeroed=pre)
+                    col += mlp.layers[-1][0].shape[1]
             l_feat.append(out)
         ext = pu.pointnet2
         for i in range(-1, -(len(self.fp) + 1), -1):          # coarse -> fine

@@ -174,6 +174,22 @@ int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, const float
  *                               a plain row-major GEMM layer with a host-side row count, e.g. P = features @ W1f + b1)
  *   prcnn_packed_layer_segmax:  out[(b*m)][out_col..+N) = max over each centre's rows of relu(A @ W + bias)
  *                               (pointnet2_modules.py:37-53: last layer + max_pool2d) */
+/* Batched forms: up to 4 independent problems (the scales of one MSG level, pointnet2_modules.py:19-55 loops over them) in ONE
+ * launch -- the sparse levels are latency-bound, side by side they cost one launch instead of one each.  The single-problem
+ * entries below are these with n = 1.  segmax = 1: every problem is a level's last layer + max pool (fields b, m, rowinfo,
+ * tilecloud, out_col, out_is_zero; ldo = row stride of the level's output); segmax = 0: plain layers (fields rows, n_store,
+ * relu; hdr NULL = host row count). */
+typedef struct prcnn_gather_problem {
+    int b, n, c1; long max_tiles; const float *P; const float *wxyz; const unsigned int *rowinfo; const float *rowdxyz;
+    const int *tilecloud; const unsigned int *hdr; float *out;
+} prcnn_gather_problem;
+typedef struct prcnn_layer_problem {
+    const unsigned int *hdr; long rows; long max_tiles; int K, N, n_store; const float *A; long lda; const float *W;
+    const float *bias; int relu; float *out; long ldo;
+    int b, m; const unsigned int *rowinfo; const int *tilecloud; int out_col, out_is_zero;
+} prcnn_layer_problem;
+int prcnn_packed_gather_affine_batch(int nprob, const prcnn_gather_problem *problems, void *stream);
+int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *problems, int segmax, void *stream);
 int prcnn_packed_gather_affine(int b, int n, int c1, long max_tiles, const float *P, const float *wxyz,
                                const unsigned int *rowinfo, const float *rowdxyz, const int *tilecloud,
                                const unsigned int *hdr, float *out, void *stream);

@@ -177,6 +177,18 @@ class pointnet2_cpu:
         return out
 
     @staticmethod
+    def packed_gather_affine_batch_wrapper(problems):
+        return [pointnet2_cpu.packed_gather_affine_wrapper(*p) for p in problems]
+
+    @staticmethod
+    def packed_layer_batch_wrapper(problems):
+        return [pointnet2_cpu.packed_layer_wrapper(*p) for p in problems]
+
+    @staticmethod
+    def packed_layer_segmax_batch_wrapper(problems):
+        return [pointnet2_cpu.packed_layer_segmax_wrapper(*p) for p in problems]
+
+    @staticmethod
     def rows_dot_wrapper(a, wt, bias, out):
         O.lib().orc_rows_dot(C.c_long(a.size(0)), a.size(1), wt.size(1), C.cast(a.data_ptr(), _f), C.c_long(a.stride(0)),
                              _p(wt, _f), _p(bias, _f), C.cast(out.data_ptr(), _f), C.c_long(out.stride(0)))
