@@ -157,9 +157,10 @@ class PipelinedRunner:
         # geometry runs for GROUPS of `group` batches in one chain (FastPointRCNN.geometry_group): a scene's FPS is serial
         # (~6.8 ms for 16384 -> 4096 on one CU) whatever the batch, so one chain over 3 batches costs the latency of one and
         # a single chain in flight keeps up with the feature stream.  `depth` = how many batches ahead the caller should
-        # hand over (2 * group: a chain is launched `group` steps before its first batch is due, ~10 ms for a ~9 ms chain).
+        # hand over (3 * group: a chain is launched 2 * `group` steps before its first batch is due; with 2 * group the chain -- 7 ms alone,
+        # 11 ms beside the feature stream -- was just late for the first batch of every group: +0.5 ms once per group).
         self.group = max(1, int(os.environ.get("PRCNN_GEO_GROUP", "4")))
-        self.depth = int(os.environ.get("PRCNN_GEO_DEPTH", str(2 * self.group if self.group > 1 else 3))) if depth is None else depth
+        self.depth = int(os.environ.get("PRCNN_GEO_DEPTH", str(3 * self.group if self.group > 1 else 3))) if depth is None else depth
         # high priority: the geometry kernels are few, short-lived workgroups on a latency-bound chain;
         # when CU slots free up they should be placed before the feature pass's next workgroups
         # default priority: with the SA levels on the packed MFMA kernels the feature pass is short, and high-priority side
@@ -224,6 +225,7 @@ class PipelinedRunner:
             self.tail = self._shared_tail
             self._inflight = None
             self._chains = []                 # geometry chains in flight: dicts pts / side / state / geo / ev
+            self._retired = []                # (side stream, RPN-done event, geometry) of batches whose geometry is still kept
         main = torch.cuda.current_stream(self.device)
         todo = [] if upcoming is None else (list(upcoming) if isinstance(upcoming, (list, tuple)) else [upcoming])
         todo = [p for p in todo if p is not None][:max(1, self.depth)]
@@ -271,14 +273,22 @@ class PipelinedRunner:
         side = self.sides[self._next_side % len(self.sides)]
         self._next_side += 1
         side.wait_stream(main)                        # the batches (and the allocator's frees) are ordered before the chain
+        # Geometry tensors are allocated on a side stream and read by the RPN stage on the feature stream.  record_stream()
+        # would make that safe, but the caching allocator then records one event ON THE FEATURE STREAM per tensor when the
+        # batch's ~40 tensors are freed: 40 marker packets = 0.2 ms of feature-stream time per step (profiles/gap_probe.py,
+        # HIP API trace).  Instead a batch's tensors are KEPT (self._retired) until the side stream that owns their memory has
+        # been made to wait for the RPN stage that read them -- here, before that stream allocates again.
+        mine = [r for r in self._retired if r[0] is side]
+        self._retired = [r for r in self._retired if r[0] is not side]
+        for _, ev_read, _ in mine:
+            side.wait_event(ev_read)
+        del mine
         with torch.cuda.stream(side):
             geos = self.engine.geometry_group(batch_list)
             ev = torch.cuda.Event()
             ev.record(side)
-        for t in _tensors(geos):                      # consumed on the feature stream: tell the caching allocator
-            t.record_stream(main)
         for pts, geo in zip(batch_list, geos):
-            self._chains.append({"pts": pts, "geo": geo, "ev": ev})
+            self._chains.append({"pts": pts, "geo": geo, "ev": ev, "side": side})
 
     def _submit_grouped(self, cur, todo, main):
         ch = self._chain(cur)
@@ -296,6 +306,7 @@ class PipelinedRunner:
         st = self.engine.rpn_stage(cur, ch["geo"])
         ev_rpn = torch.cuda.Event()
         ev_rpn.record(main)
+        self._retired.append((ch["side"], ev_rpn, ch["geo"]))     # see _launch_group
         for t in (st["rpn_scores_raw"], st["rpn_reg"], st["backbone_xyz"]):
             t.record_stream(self.tail)
         with torch.cuda.stream(self.tail):
@@ -379,6 +390,9 @@ class PipelinedRunner:
         """Finish the batch still in flight (RCNN + final stage) and return its detections (or None)."""
         if getattr(self, "tail", None) is None:
             return None
+        for side, ev_read, _ in self._retired:        # the kept geometry goes back to its streams' pools, ordered after its readers
+            side.wait_event(ev_read)
+        self._retired = []
         return self._finish_inflight()
 
 
