@@ -160,6 +160,103 @@ __global__ __launch_bounds__(256, 2) void rows_layer_kernel(
 
 unsigned int *next_ticket(hipStream_t st);    // sa_mlp_fused.hip
 
+// ---- the whole entrance chain over a tile that stays in LDS (round 2, after the stage stamps of csrc/rpn_tail.hip) -----------
+// Per 64-row tile: builder (first xyz_up layer, K = 5, VALU; the tile's 128 RPN features go to the second LDS tile) ->
+// xyz_up layer 2 -> merge_down over [xfeat | feats] (two panels into one accumulator) -> SA1's per-point part; only P leaves
+// the CU.  Four panel stages per tile, each one's 128 x 32 weight slice per wave streaming in behind the MFMAs of the stage
+// before it (mfma_stream.hpp); persistent workgroups draw the live tiles from a ticket counter.  Arithmetic per row = the three
+// rows_layer_kernel launches above, bit for bit (same builder chain, same panel order, same epilogues).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int RT_LD = PM_LD;
+}  // namespace prcnn
+#include "mfma_stream.hpp"
+namespace prcnn {
+
+__global__ __launch_bounds__(256, 2) void rcnn_entrance_kernel(
+    long tiles, const float *__restrict__ rows, int ld, int fcol, const float4 *__restrict__ wu1, const float4 *__restrict__ bu1,
+    const float *__restrict__ wu2, const float *__restrict__ bu2, const float *__restrict__ wm, const float *__restrict__ bm,
+    const float *__restrict__ wp, const float *__restrict__ bp, float *__restrict__ p_out, unsigned int *__restrict__ ticket,
+    const int *__restrict__ tilemap, const unsigned int *__restrict__ ntiles_dev)
+{
+    if (ntiles_dev) tiles = (long)*ntiles_dev;
+    __shared__ float T0[PM_ROWS * PM_LD];
+    __shared__ float T1[PM_ROWS * PM_LD];
+    __shared__ unsigned int slot[2];
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = tid & 31, r0 = tid >> 5;
+    const unsigned int lane_off = ((unsigned int)(64 * h) * 128u + (unsigned int)(32 * w + j)) * 4u;
+    const __amdgpu_buffer_rsrc_t rs_u2 = __builtin_amdgcn_make_buffer_rsrc((void *)wu2, 0, 128 * 128 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void *)wm, 0, 256 * 128 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, 128 * 128 * 4, 0x00020000);
+    const float bias_u2 = bu2[32 * w + j], bias_m = bm[32 * w + j], bias_p = bp[32 * w + j];
+    float4 k1[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) k1[k] = wu1[k * 32 + chunk];
+    const float4 b1 = bu1[chunk];
+
+    if (tid == 0) slot[0] = atomicAdd(ticket, 1u);
+    __syncthreads();
+    long t = __builtin_amdgcn_readfirstlane((int)slot[0]);
+    float wa[64], wb[64];
+    f32x16 acc0, acc1;
+    RT_LOAD_W(wa, rs_u2, 0)
+    for (unsigned int served = 0; t < tiles; ++served) {
+        const long tt = tilemap ? (long)tilemap[t] : t;
+        // ---- builder: layer 1 of xyz_up from the 5 input columns -> T0, the row's RPN features -> T1
+        {
+            float4 q[8], f[8];
+            float d[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float *row = rows + (tt * PM_ROWS + r0 + 8 * i) * (long)ld;
+                q[i] = *reinterpret_cast<const float4 *>(row);
+                d[i] = row[4];
+                f[i] = *reinterpret_cast<const float4 *>(row + fcol + 4 * chunk);
+            }
+            if (tid == 0) slot[(served + 1) & 1] = atomicAdd(ticket, 1u);     // the next tile's ticket rides behind the loads
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float4 v;
+                v.x = fmaxf(fmaf(k1[4].x, d[i], fmaf(k1[3].x, q[i].w, fmaf(k1[2].x, q[i].z, fmaf(k1[1].x, q[i].y, fmaf(k1[0].x, q[i].x, b1.x))))), 0.f);
+                v.y = fmaxf(fmaf(k1[4].y, d[i], fmaf(k1[3].y, q[i].w, fmaf(k1[2].y, q[i].z, fmaf(k1[1].y, q[i].y, fmaf(k1[0].y, q[i].x, b1.y))))), 0.f);
+                v.z = fmaxf(fmaf(k1[4].z, d[i], fmaf(k1[3].z, q[i].w, fmaf(k1[2].z, q[i].z, fmaf(k1[1].z, q[i].y, fmaf(k1[0].z, q[i].x, b1.z))))), 0.f);
+                v.w = fmaxf(fmaf(k1[4].w, d[i], fmaf(k1[3].w, q[i].w, fmaf(k1[2].w, q[i].z, fmaf(k1[1].w, q[i].y, fmaf(k1[0].w, q[i].x, b1.w))))), 0.f);
+                *reinterpret_cast<float4 *>(T0 + (r0 + 8 * i) * PM_LD + 4 * chunk) = v;
+                *reinterpret_cast<float4 *>(T1 + (r0 + 8 * i) * PM_LD + 4 * chunk) = f[i];
+            }
+        }
+        RT_VM_DRAIN                                            // (also: this tile's first panel, fetched during the last stage)
+        lds_barrier();
+        // ---- xyz_up layer 2 (wa) while merge panel a (wb) comes in
+        RT_STAGE(T0, wa, wb, rs_m, 0, true)
+        lds_barrier();                                         // every wave has read the layer-1 rows
+        RT_EPILOGUE(T0, bias_u2, true)
+        lds_barrier();
+        // ---- merge_down: [xfeat | feats] as two panels into one accumulator
+        RT_VM_DRAIN
+        RT_STAGE(T0, wb, wa, rs_m, 128, true)
+        RT_VM_DRAIN
+        RT_STAGE(T1, wa, wb, rs_p, 0, false)
+        lds_barrier();                                         // every wave has read xfeat
+        RT_EPILOGUE(T0, bias_m, true)
+        lds_barrier();
+        // ---- SA1's per-point part (no activation) while the next tile's first panel (wa) comes in
+        RT_VM_DRAIN
+        RT_STAGE(T0, wb, wa, rs_u2, 0, true)
+        RT_EPILOGUE(T1, bias_p, false)
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = r0 + 8 * i;
+            *reinterpret_cast<f32x4 *>(p_out + (tt * PM_ROWS + row) * PM_C + 4 * chunk) = *reinterpret_cast<const f32x4 *>(T1 + row * PM_LD + 4 * chunk);
+        }
+        const long tn = __builtin_amdgcn_readfirstlane((int)slot[(served + 1) & 1]);
+        lds_barrier();                                         // T1 is free for the next builder
+        t = tn;
+    }
+}
+
 // cnt[c] distinct rows of cloud c (rows_per_cloud rows each, a multiple of 64) -> the list of 64-row tiles that hold
 // them, in cloud order: tilemap[j], j < hdr[0].  One workgroup, clouds in chunks of 1024 with a running offset.
 __global__ __launch_bounds__(1024) void pooled_tiles_kernel(int clouds, int rows_per_cloud, const int *__restrict__ cnt,
@@ -210,11 +307,22 @@ extern "C" int prcnn_rcnn_point_mlp(long r, int ld, int fcol, const float *rows,
     PRCNN_REQUIRE(ld >= 8 && ld % 4 == 0 && fcol >= 8 && fcol % 4 == 0 && fcol + PM_C <= ld,
                   "rcnn_point_mlp: bad row layout ld=%d fcol=%d", ld, fcol);
     if (r == 0) return PRCNN_OK;
-    PRCNN_REQUIRE(rows && wu1 && bu1 && wu2 && bu2 && wm && bm && wp && bp && xfeat && merged && p, "rcnn_point_mlp: null pointer");
+    PRCNN_REQUIRE(rows && wu1 && bu1 && wu2 && bu2 && wm && bm && wp && bp && p, "rcnn_point_mlp: null pointer");
+    PRCNN_REQUIRE((xfeat == nullptr) == (merged == nullptr), "rcnn_point_mlp: xfeat and merged are both given or both NULL");
     PRCNN_REQUIRE((((uintptr_t)rows | (uintptr_t)wu1 | (uintptr_t)bu1 | (uintptr_t)xfeat | (uintptr_t)merged | (uintptr_t)p) & 15) == 0,
                   "rcnn_point_mlp: 16-byte alignment required");
     hipStream_t st = (hipStream_t)stream;
     const long tiles = r / PM_ROWS;
+    if (!xfeat) {
+        // only P is wanted: the whole chain in one kernel, the tile never leaves LDS
+        PRCNN_REQUIRE((((uintptr_t)wu2 | (uintptr_t)wm | (uintptr_t)wp) & 15) == 0, "rcnn_point_mlp: 16-byte alignment required");
+        unsigned int *tk = next_ticket(st);
+        if (!tk) { set_error("rcnn_point_mlp: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
+        const long grid = tiles < 512 ? tiles : 512;
+        hipLaunchKernelGGL(rcnn_entrance_kernel, dim3((unsigned)grid), dim3(256), 0, st, tiles, rows, ld, fcol, (const float4 *)wu1,
+                           (const float4 *)bu1, wu2, bu2, wm, bm, wp, bp, p, tk, tilemap, ntiles);
+        return check_launch("rcnn_point_mlp(fused)");
+    }
     // one generation of workgroups when the launch is short (tiles / slots per workgroup, tickets balance the rest);
     // at least PM_TILES_PER_WG so that long launches still turn workgroups over
     const long slots = 512;

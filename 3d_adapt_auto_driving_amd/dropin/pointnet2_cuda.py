@@ -376,10 +376,15 @@ def rcnn_point_mlp_wrapper(rows, fcol, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat
     """RCNN entrance chain as tiled MFMA layer kernels (csrc/rcnn_point_mlp.hip): rows (R, ld) pooled rows
     [x',y',z',mask,depth,0,0,0 | 128 feats at column fcol] -> xfeat = xyz_up(in5), merged = relu([xfeat | feats] wm + bm),
     p = merged wp + bp, each (R,128).  tiles = (tilemap, hdr) from pooled_tiles_wrapper: only those 64-row tiles are computed."""
-    _chk(torch.float32, rows, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, merged, p)
+    _chk(torch.float32, rows, wu1, bu1, wu2, bu2, wm, bm, wp, bp, p)
+    if (xfeat is None) != (merged is None):
+        raise RuntimeError("pointnet2_cuda: rcnn_point_mlp takes xfeat and merged together or neither")
+    if xfeat is not None:
+        _chk(torch.float32, xfeat, merged)
+    # xfeat = merged = None: only p is wanted -> the whole chain in ONE kernel, a 64-row tile never leaves LDS
     _lib.call("prcnn_rcnn_point_mlp", rows.size(0), rows.size(1), int(fcol), rows.data_ptr(), wu1.data_ptr(), bu1.data_ptr(),
-              wu2.data_ptr(), bu2.data_ptr(), wm.data_ptr(), bm.data_ptr(), wp.data_ptr(), bp.data_ptr(), xfeat.data_ptr(),
-              merged.data_ptr(), p.data_ptr(), None if tiles is None else tiles[0].data_ptr(),
+              wu2.data_ptr(), bu2.data_ptr(), wm.data_ptr(), bm.data_ptr(), wp.data_ptr(), bp.data_ptr(), _lib.ptr(xfeat),
+              _lib.ptr(merged), p.data_ptr(), None if tiles is None else tiles[0].data_ptr(),
               None if tiles is None else tiles[1].data_ptr(), _lib.current_stream(rows))
     return p
 

@@ -607,9 +607,9 @@ class FastPointRCNN:
             (wu1, bu1, _), (wu2, bu2, _) = self.xyz_up.layers
             (wm, bm, _), = self.merge_down.layers
             wf, _, b1 = sa1[3].split
-            xfeat, merged, P_pre = (torch.empty((rows.shape[0], 128), dtype=torch.float32, device=rows.device) for _ in range(3))
+            P_pre = torch.empty((rows.shape[0], 128), dtype=torch.float32, device=rows.device)
             tiles = None if pooled_cnt is None else ext_mod.pooled_tiles_wrapper(pooled_cnt.view(-1), P)
-            ext_mod.rcnn_point_mlp_wrapper(rows, 8, wu1, bu1, wu2, bu2, wm, bm, wf, b1, xfeat, merged, P_pre, tiles)
+            ext_mod.rcnn_point_mlp_wrapper(rows, 8, wu1, bu1, wu2, bu2, wm, bm, wf, b1, None, None, P_pre, tiles)   # only P is needed
             P_pre = P_pre.view(B * M, P, 128)
             l_feat = [None]
         else:

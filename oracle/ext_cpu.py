@@ -239,6 +239,8 @@ class pointnet2_cpu:
 
     @staticmethod
     def rcnn_point_mlp_wrapper(rows, fcol, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, merged, p, tiles=None):
+        if xfeat is None:
+            xfeat, merged = torch.empty_like(p), torch.empty_like(p)
         O.lib().orc_rcnn_point_mlp(C.c_long(rows.size(0)), rows.size(1), int(fcol), _p(rows, _f), _p(wu1, _f), _p(bu1, _f),
                                    _p(wu2, _f), _p(bu2, _f), _p(wm, _f), _p(bm, _f), _p(wp, _f), _p(bp, _f),
                                    _p(xfeat, _f), _p(merged, _f), _p(p, _f))

@@ -663,6 +663,19 @@ def test_rcnn_point_mlp_kernels(ext):
     assert (outs[0][1] - want).abs().max().item() <= 3e-5 * max(1.0, want.abs().max().item())
     with pytest.raises(Exception):
         ext.pointnet2.rcnn_point_mlp_wrapper(trow[:100].contiguous(), 8, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat, merged, p)   # rows % 64
+    # the one-kernel form (xfeat = merged = None: a tile never leaves LDS) gives the SAME BITS as the three launches, over all
+    # tiles and over a live-tile list; tiles that are not listed stay untouched
+    p1 = torch.full((R, 128), float("nan"), device=DEV)
+    ext.pointnet2.rcnn_point_mlp_wrapper(trow, 8, wu1, bu1, wu2, bu2, wm, bm, wp, bp, None, None, p1)
+    assert torch.equal(p1, outs[0][1])
+    cnt = torch.from_numpy(rng.integers(0, 200, R // 512).astype(np.int32)).to(DEV)
+    tiles = ext.pointnet2.pooled_tiles_wrapper(cnt, 512)
+    p2 = torch.full((R, 128), float("nan"), device=DEV)
+    ext.pointnet2.rcnn_point_mlp_wrapper(trow, 8, wu1, bu1, wu2, bu2, wm, bm, wp, bp, None, None, p2, tiles)
+    live = torch.zeros(R // 64, dtype=torch.bool, device=DEV)
+    live[tiles[0][:int(tiles[1][0])].long()] = True
+    rows_live = live.repeat_interleave(64)
+    assert torch.equal(p2[rows_live], outs[0][1][rows_live]) and torch.isnan(p2[~rows_live]).all() and 0 < int(live.sum()) < R // 64
 
 
 @pytest.mark.parametrize("K,relu", [(128, True), (128, False), (256, True), (256, False)])
