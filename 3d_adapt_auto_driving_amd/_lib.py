@@ -34,6 +34,7 @@ SIGNATURES = {
     "prcnn_opt_n_threads": [_I],
     "prcnn_set_ball_query_mode": [_I],
     "prcnn_ball_query": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
+    "prcnn_fps_new_xyz": [_I, _I, _I, _P, _P, _P, _P],
     "prcnn_ball_query_limit": [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P],
     "prcnn_group_points": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "prcnn_group_points_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],

@@ -140,14 +140,18 @@ struct KeyCodec {
 template <int WAVES, int PPT, bool ORDERED>
 __global__ __launch_bounds__(64 * WAVES) void fps_reg_kernel(
     int n, int m, KeyCodec kc, const float *__restrict__ xyz, float *__restrict__ temp,
-    int *__restrict__ idx)
+    int *__restrict__ idx, float *__restrict__ new_xyz = nullptr)
 {
+    // temp == NULL: the running minima start at the reference caller's fill value (1e10, pointnet2_utils.py:26) and are not
+    // handed back; new_xyz != NULL: the selected points' coordinates are written as well (prcnn_fps_new_xyz: the caller's
+    // fill + index cast + gather launches folded into this one)
     constexpr int T = 64 * WAVES;
     __shared__ unsigned long long s_best[3];
     const int b = blockIdx.x;
     const float *__restrict__ cloud = xyz + (long)b * n * 3;
-    float *__restrict__ mind = temp + (long)b * n;
+    float *__restrict__ mind = temp ? temp + (long)b * n : nullptr;
     int *__restrict__ sel = idx + (long)b * m;
+    float *__restrict__ nxyz = new_xyz ? new_xyz + (long)b * m * 3 : nullptr;
     const int t = threadIdx.x;
     __builtin_amdgcn_s_setprio(3);   // latency-bound dependent chain: win issue arbitration (see fps_pruned_kernel)
 
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(64 * WAVES) void fps_reg_kernel(
         const int k = t + i * T;
         if (k < n) {
             px[i] = cloud[3 * k]; py[i] = cloud[3 * k + 1]; pz[i] = cloud[3 * k + 2];
-            pt[i] = mind[k];
+            pt[i] = mind ? mind[k] : 1e10f;
             pk[i] = kc.encode(k);
         } else {
             px[i] = py[i] = pz[i] = 0.f;
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(64 * WAVES) void fps_reg_kernel(
     if (t == 0) sel[0] = 0;
     for (int j = 1; j < m; ++j) {
         const float ox = cloud[3 * old], oy = cloud[3 * old + 1], oz = cloud[3 * old + 2];
+        if (nxyz && t == 0) { nxyz[3 * (j - 1)] = ox; nxyz[3 * (j - 1) + 1] = oy; nxyz[3 * (j - 1) + 2] = oz; }
         float lv = -INFINITY;
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
@@ -202,10 +207,13 @@ __global__ __launch_bounds__(64 * WAVES) void fps_reg_kernel(
         old = __builtin_amdgcn_readfirstlane(old);
         if (t == 0) sel[j] = old;
     }
+    if (nxyz && t == 0 && m > 0) { nxyz[3 * (m - 1)] = cloud[3 * old]; nxyz[3 * (m - 1) + 1] = cloud[3 * old + 1]; nxyz[3 * (m - 1) + 2] = cloud[3 * old + 2]; }
+    if (mind) {
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        const int k = t + i * T;
-        if (k < n) mind[k] = pt[i];
+        for (int i = 0; i < PPT; ++i) {
+            const int k = t + i * T;
+            if (k < n) mind[k] = pt[i];
+        }
     }
 }
 
@@ -435,12 +443,12 @@ static int host_opt_n_threads(int work_size)
 }
 
 template <int WAVES, int PPT>
-static void launch_reg(int b, int n, int m, KeyCodec kc, const float *xyz, float *temp, int *idx, hipStream_t st)
+static void launch_reg(int b, int n, int m, KeyCodec kc, const float *xyz, float *temp, int *idx, hipStream_t st, float *new_xyz = nullptr)
 {
     if ((1 << kc.log2bs) == 64 * WAVES)
-        hipLaunchKernelGGL((fps_reg_kernel<WAVES, PPT, true>), dim3(b), dim3(64 * WAVES), 0, st, n, m, kc, xyz, temp, idx);
+        hipLaunchKernelGGL((fps_reg_kernel<WAVES, PPT, true>), dim3(b), dim3(64 * WAVES), 0, st, n, m, kc, xyz, temp, idx, new_xyz);
     else
-        hipLaunchKernelGGL((fps_reg_kernel<WAVES, PPT, false>), dim3(b), dim3(64 * WAVES), 0, st, n, m, kc, xyz, temp, idx);
+        hipLaunchKernelGGL((fps_reg_kernel<WAVES, PPT, false>), dim3(b), dim3(64 * WAVES), 0, st, n, m, kc, xyz, temp, idx, new_xyz);
 }
 
 }  // namespace prcnn
@@ -504,4 +512,27 @@ extern "C" int prcnn_furthest_point_sampling(int b, int n, int m, const float *x
     else if (n <= 16384) launch_reg<16, 16>(b, n, m, kc, xyz, temp, idx, st);
     else hipLaunchKernelGGL(fps_generic_kernel, dim3(b), dim3(1024), 0, st, n, m, kc, xyz, temp, idx);
     return check_launch("furthest_point_sampling");
+}
+
+// FPS of many small clouds (n <= 1024: one wave per cloud, everything in registers) with the selected coordinates written
+// alongside the indices: what furthest_point_sample + gather_operation (pointnet2_modules.py:40-46) produce, without the
+// caller's 1e10 fill of the distance scratch, the index cast and the gather launch.  idx (b,m), new_xyz (b,m,3).
+extern "C" int prcnn_fps_new_xyz(int b, int n, int m, const float *xyz, int *idx, float *new_xyz, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && n > 0 && m >= 0 && n <= 1024, "fps_new_xyz: b=%d n=%d m=%d (1 <= n <= 1024)", b, n, m);
+    if (b == 0 || m == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(xyz && idx && new_xyz, "fps_new_xyz: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int bs = host_opt_n_threads(n);
+    KeyCodec kc;
+    kc.log2bs = 0;
+    while ((1 << kc.log2bs) < bs) ++kc.log2bs;
+    const int nq = (n + bs - 1) / bs;
+    kc.sh = 0;
+    while ((1 << kc.sh) < nq) ++kc.sh;
+    if (n <= 128) launch_reg<1, 2>(b, n, m, kc, xyz, nullptr, idx, st, new_xyz);
+    else if (n <= 256) launch_reg<1, 4>(b, n, m, kc, xyz, nullptr, idx, st, new_xyz);
+    else if (n <= 512) launch_reg<1, 8>(b, n, m, kc, xyz, nullptr, idx, st, new_xyz);
+    else launch_reg<1, 16>(b, n, m, kc, xyz, nullptr, idx, st, new_xyz);
+    return check_launch("fps_new_xyz");
 }

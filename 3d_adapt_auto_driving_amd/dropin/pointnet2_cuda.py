@@ -37,6 +37,17 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     return 1
 
 
+def fps_new_xyz_wrapper(xyz, m):
+    """xyz (b,n,3), n <= 1024 -> (idx (b,m) i32, new_xyz (b,m,3)): furthest_point_sampling_wrapper + the gather of the selected
+    coordinates in one launch (csrc/fps.hip)."""
+    _chk(torch.float32, xyz)
+    b, n, _ = xyz.shape
+    idx = torch.empty((b, m), dtype=torch.int32, device=xyz.device)
+    new_xyz = torch.empty((b, m, 3), dtype=torch.float32, device=xyz.device)
+    _lib.call("prcnn_fps_new_xyz", b, n, m, xyz.data_ptr(), idx.data_ptr(), new_xyz.data_ptr(), _lib.current_stream(xyz))
+    return idx, new_xyz
+
+
 def ball_query_limit_wrapper(b, n, m, radius, nsample, new_xyz, xyz, limit, idx):
     """ball_query_wrapper over clouds whose points k >= limit[cloud] are copies of point k % limit[cloud] (pooled RoI rows):
     scans the first limit[cloud] points only -- the same distinct points per ball, slots past them repeat the first hit."""

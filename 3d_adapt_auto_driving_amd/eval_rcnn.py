@@ -254,7 +254,7 @@ class PipelinedRunner:
             rois, roi_scores = self.engine.propose(st)
             ev_prop = torch.cuda.Event()
             ev_prop.record(self.tail)
-        for t in (rois, st["seg_result"], st["pts_depth"]):       # made on the tail stream, read by the RCNN stage on the feature stream
+        for t in (rois, st["seg_result"], st["pts_depth"], st["depth_norm"]):       # made on the tail stream, read by the RCNN stage on the feature stream
             t.record_stream(main)
         # Geometry of the upcoming batches is GATED on the end of this RPN stage: the library GEMMs of the RPN stage are
         # persistent-grid kernels that stretch 40-70 % when an FPS workgroup shares a CU with them, the RCNN stage that
@@ -314,7 +314,7 @@ class PipelinedRunner:
             rois, roi_scores = self.engine.propose(st)
             ev_prop = torch.cuda.Event()
             ev_prop.record(self.tail)
-        for t in (rois, st["seg_result"], st["pts_depth"]):       # made on the tail stream, read by the RCNN stage on the feature stream
+        for t in (rois, st["seg_result"], st["pts_depth"], st["depth_norm"]):       # made on the tail stream, read by the RCNN stage on the feature stream
             t.record_stream(main)
         done = self._finish_inflight()
         self._inflight = (cur, st, rois, roi_scores, ev_prop)

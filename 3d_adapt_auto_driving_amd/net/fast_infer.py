@@ -521,6 +521,7 @@ class FastPointRCNN:
         if "seg_result" not in st:
             st["seg_result"] = (torch.sigmoid(st["rpn_scores_raw"]) > self.cfg.RPN.SCORE_THRESH).float()
             st["pts_depth"] = torch.norm(st["backbone_xyz"], p=2, dim=2)
+            st["depth_norm"] = (st["pts_depth"] / 70.0 - 0.5).contiguous()        # the RCNN input feature (rcnn_net.py:131-137)
 
     @torch.no_grad()
     def propose(self, st):
@@ -532,7 +533,7 @@ class FastPointRCNN:
     @torch.no_grad()
     def rcnn_stage(self, st, rois):
         self.point_aux(st)
-        return self._rcnn(st["backbone_xyz"], st["rpn_features"], st["seg_result"], st["pts_depth"], rois)
+        return self._rcnn(st["backbone_xyz"], st["rpn_features"], st["seg_result"], st["pts_depth"], rois, depth_norm=st["depth_norm"])
 
     @torch.no_grad()
     def forward(self, pts_input, geo=None):
@@ -563,7 +564,7 @@ class FastPointRCNN:
             self._pm_ok = bool(ok)
         return self._pm_ok
 
-    def _rcnn(self, xyz, feats, seg_mask, pts_depth, rois):
+    def _rcnn(self, xyz, feats, seg_mask, pts_depth, rois, depth_norm=None):
         R = self.cfg.RCNN
         if not (R.ROI_SAMPLE_JIT and R.USE_RPN_FEATURES and not R.USE_INTENSITY):
             raise NotImplementedError("fast path covers the default.yaml RCNN input configuration")
@@ -580,7 +581,8 @@ class FastPointRCNN:
             if USE_POOL_DEDUP and USE_PACKED and USE_RCNN_POINT_MLP and P % 64 == 0 and self._point_mlp_ok():
                 pooled_cnt = torch.empty((B, M), dtype=torch.int32, device=xyz.device)
             rp.forward_canonical(xyz, rois.contiguous(), feats, seg_mask.contiguous(),
-                                 (pts_depth / 70.0 - 0.5).contiguous(), R.POOL_EXTRA_WIDTH, pooled, empty, pooled_cnt)
+                                 depth_norm if depth_norm is not None else (pts_depth / 70.0 - 0.5).contiguous(),
+                                 R.POOL_EXTRA_WIDTH, pooled, empty, pooled_cnt)
             flat = pooled.view(B * M, P, W)
             rows = flat.view(B * M * P, W)
             a = rows[:, 0:8]                                                   # strided view: columns 5..7 are zero
@@ -623,8 +625,11 @@ class FastPointRCNN:
             Bc, n = cur_xyz.shape[0], cur_xyz.shape[1]
             cout = mlp.layers[-1][0].shape[1]
             if npoint is not None:
-                sel = pu.furthest_point_sample(cur_xyz, npoint)
-                new_xyz = torch.gather(cur_xyz, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+                if n <= 1024 and has_entry(ext, "fps_new_xyz_wrapper"):
+                    _, new_xyz = ext.fps_new_xyz_wrapper(cur_xyz, npoint)      # sampling + the centres' coordinates, one launch
+                else:
+                    sel = pu.furthest_point_sample(cur_xyz, npoint)
+                    new_xyz = torch.gather(cur_xyz, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
                 first = len(l_feat) == 1
                 if first and pooled_cnt is not None and P_pre is not None and has_entry(ext, "ball_query_limit_wrapper"):
                     # pooled rows k >= count are copies of row k % count: scanning the distinct rows finds every ball's points

@@ -80,6 +80,11 @@ int prcnn_gather_points_grad(int b, int c, int n, int npoints,
 int prcnn_furthest_point_sampling(int b, int n, int m,
                                   const float *xyz, float *temp, int *idx, void *stream);
 
+/* FPS of many small clouds (n <= 1024) with the selected points' coordinates written beside their indices: the result of
+ * furthest_point_sample + gather_operation (pointnet2_modules.py:40-46) in one launch (no scratch fill, index cast or gather
+ * by the caller).  Same selection, same tie rule as prcnn_furthest_point_sampling. */
+int prcnn_fps_new_xyz(int b, int n, int m, const float *xyz, int *idx, float *new_xyz, void *stream);
+
 /* three_nn_wrapper_fast  src/interpolate.cpp:14-23 -> src/interpolate_gpu.cu:9-52.
  * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) SQUARED distances, idx (b,n,3). */
 int prcnn_three_nn(int b, int n, int m, const float *unknown, const float *known,

@@ -47,6 +47,14 @@ class pointnet2_cpu:
         return 1
 
     @staticmethod
+    def fps_new_xyz_wrapper(xyz, m):
+        b, n, _ = xyz.shape
+        temp = torch.full((b, n), 1e10)
+        idx = torch.empty((b, m), dtype=torch.int32)
+        pointnet2_cpu.furthest_point_sampling_wrapper(b, n, m, xyz, temp, idx)
+        return idx, torch.gather(xyz, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+
+    @staticmethod
     def ball_query_limit_wrapper(b, n, m, radius, nsample, new_xyz, xyz, limit, idx):
         """the reference ball query (ball_query_gpu.cu:14-43) over the first limit[cloud] points of every cloud"""
         for i in range(b):

@@ -106,6 +106,22 @@ def test_ball_query_rcnn_shape(ext, oracle):
     assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(0.2, 64, xyz, new_xyz))
 
 
+@pytest.mark.parametrize("n,m", [(512, 128), (128, 32), (100, 100), (1024, 37), (1, 1)])
+def test_fps_with_coordinates_output(ext, oracle, n, m):
+    """prcnn_fps_new_xyz (no distance scratch from the caller, coordinates of the selection written by the kernel) == the
+    reference sequence furthest_point_sample + gather on wrapped RoI clouds (many exact ties: copies of the same point)."""
+    rng = np.random.default_rng(n * 7 + m)
+    b = 50
+    xyz = rng.uniform(-1, 1, (b, n, 3)).astype(np.float32)
+    for i in range(0, b, 3):                                              # a third of the clouds: few distinct points, wrapped
+        c = int(rng.integers(1, max(2, n // 4)))
+        xyz[i] = xyz[i, np.arange(n) % c]
+    idx, new_xyz = ext.pointnet2.fps_new_xyz_wrapper(T(xyz), m)
+    want = oracle.furthest_point_sample(xyz, m)
+    assert np.array_equal(idx.cpu().numpy(), want)
+    assert np.array_equal(new_xyz.cpu().numpy(), np.take_along_axis(xyz, want[:, :, None].astype(np.int64), axis=1))
+
+
 def test_ball_query_with_scan_limit_on_wrapped_clouds(ext, oracle):
     """Clouds filled the way RoI pooling fills a box holding fewer than 512 points (row k >= count is a copy of row
     k % count, roipool3d_kernel.cu:152-159; an empty box is all one point).  prcnn_ball_query_limit scans the first count

@@ -233,6 +233,14 @@ def check_packed_segmax(self, name, args, host, ret):
 POINTNET2["packed_layer_segmax_wrapper"] = check_packed_segmax
 
 
+def check_fps_new_xyz(self, name, args, host, ret):
+    want_idx, want_xyz = self._cpu.fps_new_xyz_wrapper(*host)
+    assert torch.equal(ret[0].cpu(), want_idx) and torch.equal(ret[1].cpu(), want_xyz), name
+
+
+POINTNET2["fps_new_xyz_wrapper"] = check_fps_new_xyz
+
+
 def batched(check):
     """a batched wrapper takes ONE list of problems: every problem is checked like a call of the single-problem wrapper"""
     def run(self, name, args, host, ret):
@@ -290,7 +298,7 @@ def test_batch8_step_every_kernel_call_equals_the_oracle():
         assert torch.isfinite(det[k].float()).all(), k
     assert (det["num"] > 0).all()
     # coverage: every kernel family of the step was exercised at the batch-8 shapes
-    want_calls = {"furthest_point_sampling_wrapper": 6, "ball_query_wrapper": 9, "ball_query_limit_wrapper": 1, "three_nn_wrapper": 4, "ball_pack_wrapper": 11,
+    want_calls = {"furthest_point_sampling_wrapper": 4, "fps_new_xyz_wrapper": 2, "ball_query_wrapper": 9, "ball_query_limit_wrapper": 1, "three_nn_wrapper": 4, "ball_pack_wrapper": 11,
                   "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 4, "packed_layer_segmax_wrapper": 1,
                   "packed_layer_segmax_batch_wrapper": 2, "packed_gather_affine_batch_wrapper": 2, "packed_layer_batch_wrapper": 4,
                   "three_interpolate_pm_wrapper": 3, "rpn_tail_wrapper": 1, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
