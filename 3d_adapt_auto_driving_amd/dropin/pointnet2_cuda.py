@@ -268,6 +268,24 @@ def packed_layer_wrapper(a, wt, bias, relu, out, pack=None):
     return out
 
 
+def sa_wide_fused_supported(c1, c2, c3):
+    return bool(_lib.load().prcnn_sa_wide_fused_supported(int(c1), int(c2), int(c3)))
+
+
+def sa_wide_fused_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col, zeroed=False):
+    """One scale of a wide SA level over a packed row list in ONE kernel (csrc/sa_wide.hip): gather + affine, layer 2, layer 3 +
+    max pool -- packed_gather_affine_wrapper -> packed_layer_wrapper -> packed_layer_segmax_wrapper, bit for bit."""
+    _chk(torch.float32, new_xyz, xyz, P, wxyz, w2t, b2, w3t, b3, out)
+    b, n, c1 = P.shape
+    if w2t.size(0) != c1 or w3t.size(0) != w2t.size(1) or wxyz.size(1) != c1:
+        raise RuntimeError("pointnet2_cuda: sa_wide_fused shape mismatch")
+    _lib.call("prcnn_sa_wide_fused", b, n, new_xyz.size(1), c1, w2t.size(1), w3t.size(1), pack.max_tiles, P.data_ptr(), wxyz.data_ptr(),
+              pack.rowinfo.data_ptr(), pack.rowdxyz.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr(), w2t.data_ptr(),
+              b2.data_ptr(), w3t.data_ptr(), b3.data_ptr(), out.data_ptr(), out.size(-1), out_col, int(bool(zeroed)),
+              _lib.current_stream(xyz))
+    return out
+
+
 def packed_gather_affine_batch_wrapper(problems):
     """packed_gather_affine_wrapper for up to 4 independent problems [(new_xyz, xyz, P, wxyz, pack, out), ...] -- the scales of one
     MSG level -- in ONE launch."""

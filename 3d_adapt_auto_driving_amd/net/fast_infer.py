@@ -46,6 +46,8 @@ PAD128 = USE_PACKED and USE_POINT_LAYER
 USE_RPN_TAIL = os.environ.get("PRCNN_NO_RPN_TAIL") is None
 # the scales of a wide MSG level (RPN SA3 / SA4) stage by stage, side by side in one launch per stage; PRCNN_NO_SCALE_BATCH=1: A/B
 USE_SCALE_BATCH = os.environ.get("PRCNN_NO_SCALE_BATCH") is None
+# layers 1-3 + pool of a wide scale in one kernel (csrc/sa_wide.hip); PRCNN_NO_WIDE_FUSED=1: gather / layer / layer+pool launches
+USE_WIDE_FUSED = os.environ.get("PRCNN_NO_WIDE_FUSED") is None
 
 
 def _round4(c):
@@ -354,7 +356,7 @@ class FastPointRCNN:
 
     # ------------------------------------------------------------------ building blocks
     @staticmethod
-    def _sa_scale(xyz, new_xyz, feats, idx, mlp, cin, out, out_col, P_pre=None, pack=None, zeroed=False):
+    def _sa_scale(xyz, new_xyz, feats, idx, mlp, cin, out, out_col, P_pre=None, pack=None, zeroed=False, dense=False):
         """one (radius, nsample) scale: group -> GEMM chain -> max over nsample into out[..., slice]"""
         ext = pu.pointnet2
         B, N, _ = xyz.shape
@@ -371,6 +373,12 @@ class FastPointRCNN:
             wf, wx, b1, w2, b2, w3, b3 = mlp.wide
             P = point_layer(feats.view(B * N, feats.shape[2]), wf, b1, False).view(B, N, -1)
             pk = pack if pack is not None else ext.ball_pack_wrapper(idx, xyz, new_xyz)
+            if (dense and USE_WIDE_FUSED and has_entry(ext, "sa_wide_fused_wrapper") and
+                    ext.sa_wide_fused_supported(wf.shape[1], w2.shape[1], w3.shape[1])):
+                # layers 1-3 + pool in ONE kernel: the packed rows stay in LDS (csrc/sa_wide.hip).  `dense`: the caller knows that
+                # (nearly) every row is distinct -- many units of work, where serialising a unit's column blocks costs nothing
+                ext.sa_wide_fused_wrapper(new_xyz, xyz, P, wx, pk, w2, b2, w3, b3, out, out_col, zeroed)
+                return
             rows = pk.max_tiles * 64
             a1 = torch.empty((rows, wf.shape[1]), dtype=torch.float32, device=xyz.device)
             ext.packed_gather_affine_wrapper(new_xyz, xyz, P, wx, pk, a1)
@@ -430,14 +438,17 @@ class FastPointRCNN:
         Ps = [torch.empty((B * N, w[0].shape[1]), dtype=torch.float32, device=dev) for w in wides]
         ext.packed_layer_batch_wrapper([(flat, w[0], w[2], False, P, None) for w, P in zip(wides, Ps)])
         pks = [pk if pk is not None else ext.ball_pack_wrapper(idx, xyz, new_xyz) for pk, idx in zip(packs, idxs)]
-        a1s = [torch.empty((pk.max_tiles * 64, w[0].shape[1]), dtype=torch.float32, device=dev) for pk, w in zip(pks, wides)]
-        ext.packed_gather_affine_batch_wrapper([(new_xyz, xyz, P.view(B, N, -1), w[1], pk, a1) for P, w, pk, a1 in zip(Ps, wides, pks, a1s)])
-        y2s = [torch.empty((pk.max_tiles * 64, w[3].shape[1]), dtype=torch.float32, device=dev) for pk, w in zip(pks, wides)]
-        ext.packed_layer_batch_wrapper([(a1, w[3], w[4], True, y2, pk) for a1, w, y2, pk in zip(a1s, wides, y2s, pks)])
         cols, col = [], 0
         for sc in scales:
             cols.append(col)
             col += sc[2].layers[-1][0].shape[1]
+        # (not csrc/sa_wide.hip here: it walks a unit's column blocks one after the other, which is the right trade when there are
+        # hundreds of units -- the RCNN's GroupAll level -- and the wrong one for the handful of live tiles of these levels: 1.16 vs
+        # 1.13 ms for the RPN stage)
+        a1s = [torch.empty((pk.max_tiles * 64, w[0].shape[1]), dtype=torch.float32, device=dev) for pk, w in zip(pks, wides)]
+        ext.packed_gather_affine_batch_wrapper([(new_xyz, xyz, P.view(B, N, -1), w[1], pk, a1) for P, w, pk, a1 in zip(Ps, wides, pks, a1s)])
+        y2s = [torch.empty((pk.max_tiles * 64, w[3].shape[1]), dtype=torch.float32, device=dev) for pk, w in zip(pks, wides)]
+        ext.packed_layer_batch_wrapper([(a1, w[3], w[4], True, y2, pk) for a1, w, y2, pk in zip(a1s, wides, y2s, pks)])
         ext.packed_layer_segmax_batch_wrapper([(y2, w[5], w[6], pk, B, M, out, c, zeroed) for y2, w, pk, c in zip(y2s, wides, pks, cols)])
 
     def _backbone(self, xyz, geo, fuse_tail=False):
@@ -662,7 +673,7 @@ class FastPointRCNN:
                 feat_v = cur_feat.view(Bc // f, f * n, cur_feat.shape[2])
                 out = torch.empty((Bc, 1, cout), dtype=torch.float32, device=cur_xyz.device)
                 self._sa_scale(xyz_v, origin, feat_v, ga_idx, mlp, cin, out.view(Bc // f, f, cout), 0,
-                               pack=ext.ball_pack_wrapper(ga_idx, xyz_v, origin))
+                               pack=ext.ball_pack_wrapper(ga_idx, xyz_v, origin), dense=True)
                 l_xyz.append(None)
             else:                                                               # GroupAll: one group of n points
                 c4 = _round4(cin)

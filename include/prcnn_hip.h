@@ -179,6 +179,16 @@ int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, const float
  *                               a plain row-major GEMM layer with a host-side row count, e.g. P = features @ W1f + b1)
  *   prcnn_packed_layer_segmax:  out[(b*m)][out_col..+N) = max over each centre's rows of relu(A @ W + bias)
  *                               (pointnet2_modules.py:37-53: last layer + max_pool2d) */
+/* One scale of a wide set-abstraction level (layers 1-3 after the per-point part, max pool) over a packed row list in ONE
+ * kernel (csrc/sa_wide.hip): what prcnn_packed_gather_affine + prcnn_packed_layer + prcnn_packed_layer_segmax compute, bit for
+ * bit, without their activations going through HBM.  P (b,n,c1), wxyz (3,c1), w2 (c1,c2), w3 (c2,c3) k-major, widths multiples of
+ * 128 as accepted by prcnn_sa_wide_fused_supported (RPN SA3 / SA4, RCNN GroupAll: pointrcnn/lib/config.py:58-61,118-120). */
+int prcnn_sa_wide_fused_supported(int c1, int c2, int c3);
+int prcnn_sa_wide_fused(int b, int n, int m, int c1, int c2, int c3, long max_tiles, const float *P, const float *wxyz,
+                        const unsigned int *rowinfo, const float *rowdxyz, const int *tilecloud, const unsigned int *hdr,
+                        const float *w2, const float *b2, const float *w3, const float *b3, float *out, int out_stride,
+                        int out_col, int out_is_zero, void *stream);
+
 /* Batched forms: up to 4 independent problems (the scales of one MSG level, pointnet2_modules.py:19-55 loops over them) in ONE
  * launch -- the sparse levels are latency-bound, side by side they cost one launch instead of one each.  The single-problem
  * entries below are these with n = 1.  segmax = 1: every problem is a level's last layer + max pool (fields b, m, rowinfo,

@@ -185,6 +185,20 @@ class pointnet2_cpu:
         return out
 
     @staticmethod
+    def sa_wide_fused_supported(c1, c2, c3):
+        return c1 % 128 == 0 and c2 % 128 == 0 and c3 % 128 == 0
+
+    @staticmethod
+    def sa_wide_fused_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col, zeroed=False):
+        """csrc/sa_wide.hip as the chain of stand-ins it fuses (all nsample rows per group)."""
+        b, m, ns = pack.idx.shape
+        a1 = torch.empty((b * m * ns, P.size(2)))
+        pointnet2_cpu.packed_gather_affine_wrapper(new_xyz, xyz, P, wxyz, pack, a1)
+        y2 = torch.empty((b * m * ns, w2t.size(1)))
+        pointnet2_cpu.packed_layer_wrapper(a1, w2t, b2, True, y2, pack)
+        return pointnet2_cpu.packed_layer_segmax_wrapper(y2, w3t, b3, pack, b, m, out, out_col)
+
+    @staticmethod
     def packed_gather_affine_batch_wrapper(problems):
         return [pointnet2_cpu.packed_gather_affine_wrapper(*p) for p in problems]
 

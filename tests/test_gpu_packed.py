@@ -209,6 +209,15 @@ def test_wide_packed_level_layer_by_layer_is_bit_exact(ext, cin, c1, c2, c3):
     assert torch.equal(Pg.cpu(), Pc)
     assert torch.isfinite(og).all()
     assert torch.equal(og.cpu(), oc), float((og.cpu() - oc).abs().max())
+    # the three launches after the per-point part as ONE kernel (csrc/sa_wide.hip): the same bits, inside the same output slice
+    assert E.sa_wide_fused_supported(c1p, c2p, c3)
+    for zeroed in (False, True):
+        of = torch.full((b, m, c3 + 4), float("nan"), device=DEV)
+        of[:, :, :4] = -1
+        if zeroed:
+            of[:, :, 4:] = 0
+        E.sa_wide_fused_wrapper(new_xyz, xyz, Pg.view(b, n, c1p), wx, E.ball_pack_wrapper(idx, xyz, new_xyz), w2, b2, w3, b3, of, 4, zeroed)
+        assert torch.equal(of, og), (zeroed, float((of - og).abs().max()))
     # and within f32 rounding of plain library arithmetic (the padding changes nothing)
     ix = idx.long().view(b, m * ns)
     base = torch.gather(Pg.view(b, n, c1p), 1, ix.unsqueeze(-1).expand(-1, -1, c1p))

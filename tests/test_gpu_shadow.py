@@ -239,6 +239,7 @@ def check_fps_new_xyz(self, name, args, host, ret):
 
 
 POINTNET2["fps_new_xyz_wrapper"] = check_fps_new_xyz
+POINTNET2["sa_wide_fused_wrapper"] = {9: "exact"}          # one scale of a wide level in one kernel: output slice vs the oracle chain
 
 
 def batched(check):
@@ -265,8 +266,12 @@ def spread_heads(model):
         model.rcnn_net.cls_layer[-1].conv.bias.fill_(0.5)
 
 
-def test_batch8_step_every_kernel_call_equals_the_oracle():
+@pytest.mark.parametrize("wide_fused", [True, False])
+def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, monkeypatch):
+    """wide_fused = False: the RCNN's GroupAll level layer by layer (gather + affine, layer, layer + pool) like the RPN's wide levels,
+    instead of the one-kernel form of csrc/sa_wide.hip."""
     C, E, F, S = pkg("config"), pkg("eval_rcnn"), pkg("net.fast_infer"), pkg("synth")
+    monkeypatch.setattr(F, "USE_WIDE_FUSED", wide_fused)
     pu, ru = pkg("pointnet2.pointnet2_utils"), pkg("roipool3d_utils")
     cfg = C.default_eval_cfg()
     model = E.build_model(cfg, DEV, seed=3)
@@ -299,10 +304,14 @@ def test_batch8_step_every_kernel_call_equals_the_oracle():
     assert (det["num"] > 0).all()
     # coverage: every kernel family of the step was exercised at the batch-8 shapes
     want_calls = {"furthest_point_sampling_wrapper": 4, "fps_new_xyz_wrapper": 2, "ball_query_wrapper": 9, "ball_query_limit_wrapper": 1, "three_nn_wrapper": 4, "ball_pack_wrapper": 11,
-                  "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 4, "packed_layer_segmax_wrapper": 1,
-                  "packed_layer_segmax_batch_wrapper": 2, "packed_gather_affine_batch_wrapper": 2, "packed_layer_batch_wrapper": 4,
+                  "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 4,
                   "three_interpolate_pm_wrapper": 3, "rpn_tail_wrapper": 1, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
+    want_calls.update({"packed_layer_segmax_batch_wrapper": 2, "packed_gather_affine_batch_wrapper": 2, "packed_layer_batch_wrapper": 4})   # RPN SA3, SA4
+    if wide_fused:       # the RCNN's GroupAll level (every row distinct: 800 units of work) in one kernel
+        want_calls.update({"sa_wide_fused_wrapper": 1, "packed_layer_segmax_wrapper": 0, "packed_gather_affine_wrapper": 0})
+    else:
+        want_calls.update({"sa_wide_fused_wrapper": 0, "packed_layer_segmax_wrapper": 1, "packed_gather_affine_wrapper": 1})
     for name, n in want_calls.items():
         assert log[name] == n, (name, log[name], n)
-    assert log["packed_layer_wrapper"] >= 5 and log["packed_gather_affine_wrapper"] == 1 and log["rows_dot_wrapper"] == 1
+    assert log["packed_layer_wrapper"] >= 5 and log["rows_dot_wrapper"] == 1
     print("shadowed calls:", {k: v for k, v in log.items() if not k.startswith("elements:")})
