@@ -536,3 +536,46 @@ extern "C" int prcnn_fps_new_xyz(int b, int n, int m, const float *xyz, int *idx
     else launch_reg<1, 16>(b, n, m, kc, xyz, nullptr, idx, st, new_xyz);
     return check_launch("fps_new_xyz");
 }
+
+// ---- spatial groups of a cloud for the consumers that sweep it per box (csrc/roipool.hip) -------------------------------------
+// The cloud in the Morton order of fps_order_kernel, 64 points per group: pxyz (b, n) float4 = (x, y, z, original index as bits),
+// aabb (b, n / 64, 2) float4 = per-group (min x, min y, min z, -) and (max x, max y, max z, -).  A box then tests 256 group boxes
+// instead of 16384 points and reads the few groups that can hold a point of it as coalesced 16-byte lanes.
+namespace prcnn {
+__global__ __launch_bounds__(256) void point_groups_kernel(int n, const float *__restrict__ xyz, const int *__restrict__ perm,
+                                                           float4 *__restrict__ pxyz, float4 *__restrict__ aabb)
+{
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g * 64 >= n) return;
+    const long s = (long)b * n + g * 64 + lane;
+    const int k = perm[s];
+    const float *p = xyz + ((long)b * n + k) * 3;
+    const float x = p[0], y = p[1], z = p[2];
+    pxyz[s] = make_float4(x, y, z, __int_as_float(k));
+    float x0 = x, x1 = x, y0 = y, y1 = y, z0 = z, z1 = z;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, d, 64)); x1 = fmaxf(x1, __shfl_xor(x1, d, 64));
+        y0 = fminf(y0, __shfl_xor(y0, d, 64)); y1 = fmaxf(y1, __shfl_xor(y1, d, 64));
+        z0 = fminf(z0, __shfl_xor(z0, d, 64)); z1 = fmaxf(z1, __shfl_xor(z1, d, 64));
+    }
+    if (lane == 0) {
+        aabb[((long)b * (n / 64) + g) * 2] = make_float4(x0, y0, z0, 0.f);
+        aabb[((long)b * (n / 64) + g) * 2 + 1] = make_float4(x1, y1, z1, 0.f);
+    }
+}
+}  // namespace prcnn
+
+extern "C" int prcnn_point_groups(int b, int n, const float *xyz, float *pxyz, float *aabb, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && n > 0 && n % 64 == 0 && n <= 16384 && b <= 65535, "point_groups: b=%d n=%d (n a multiple of 64, <= 16384)", b, n);
+    if (b == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(xyz && pxyz && aabb && (((uintptr_t)pxyz | (uintptr_t)aabb) & 15) == 0, "point_groups: null / misaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int *perm = (int *)scratch_for(st, (size_t)b * n * sizeof(int), 2);
+    if (!perm) { set_error("point_groups: cannot allocate ordering scratch"); return PRCNN_ELAUNCH; }
+    hipLaunchKernelGGL(fps_order_kernel, dim3(b), dim3(1024), 0, st, n, xyz, perm);
+    hipLaunchKernelGGL(point_groups_kernel, dim3((n / 64 + 3) / 4, b), dim3(256), 0, st, n, xyz, perm, (float4 *)pxyz, (float4 *)aabb);
+    return check_launch("point_groups");
+}

@@ -87,12 +87,80 @@ __device__ __forceinline__ int select_points(int pts_num, int sampled, const flo
     return min(total, sampled);
 }
 
+// The same selection through the spatial groups of prcnn_point_groups (csrc/fps.hip): 256 group boxes are tested against the
+// box's footprint (conservatively: circumscribed square in x / z, the y slab, 1 mm of slack for the f32 rounding of either
+// side), the points of the groups that remain go through the SAME pt_in_box3d arithmetic, and the hits are sorted by original
+// index -- what the index-order sweep produces.  Returns -1 when more than `cap` points are inside (a scene-sized box): the
+// caller falls back to the sweep.  s_hits: cap ints, s_cand: pts_num / 64 ints, s_misc: 2 ints.
+__device__ __forceinline__ int select_points_culled(int pts_num, int sampled, const float4 *__restrict__ pxyz,
+                                                    const float4 *__restrict__ aabb, float bx0, float bx1, float bx2, float h, float w,
+                                                    float l, float ry, int *s_sel, int *s_hits, int cap, int *s_cand, int *s_misc)
+{
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float cx = bx0, cz = bx2;
+    const float cy = (float)((double)bx1 - (double)h / 2.0);
+    const float cosa = cos_f32(ry), sina = sin_f32(ry);
+    const float hh = h * 0.5f, hl = l * 0.5f, hw = w * 0.5f;
+    const float rad = fminf(sqrtf(hl * hl + hw * hw) * 1.0001f, 10.0f) + 1e-3f, ys = hh + 1e-3f;
+    const int groups = pts_num / 64;
+    if (t < 2) s_misc[t] = 0;
+    __syncthreads();
+    for (int g = t; g < groups; g += RP_THREADS) {
+        const float4 lo = aabb[2 * g], hi = aabb[2 * g + 1];
+        const bool hit = !(lo.x > cx + rad || hi.x < cx - rad || lo.z > cz + rad || hi.z < cz - rad || lo.y > cy + ys || hi.y < cy - ys);
+        if (hit) s_cand[atomicAdd(&s_misc[0], 1)] = g;
+    }
+    __syncthreads();
+    const int ncand = s_misc[0];
+    for (int c = wave; c < ncand; c += RP_THREADS / 64) {
+        const float4 p = pxyz[(long)s_cand[c] * 64 + lane];
+        const float x = p.x, y = p.y, z = p.z;
+        bool in = false;
+        if (!(fabsf(x - cx) > 10.0f || fabsf(y - cy) > hh || fabsf(z - cz) > 10.0f)) {
+            const float xr = __fadd_rn(__fmul_rn(x - cx, cosa), __fmul_rn(z - cz, -sina));
+            const float zr = __fadd_rn(__fmul_rn(x - cx, sina), __fmul_rn(z - cz, cosa));
+            in = (xr >= -hl) & (xr <= hl) & (zr >= -hw) & (zr <= hw);
+        }
+        const unsigned long long mask = __ballot(in);
+        int base = 0;
+        if (lane == 0 && mask) base = atomicAdd(&s_misc[1], __popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (in) {
+            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < cap) s_hits[pos] = __float_as_int(p.w);
+        }
+    }
+    __syncthreads();
+    const int total = s_misc[1];
+    if (total > cap) return -1;
+    int P = 64;
+    while (P < total) P <<= 1;
+    for (int i = total + t; i < P; i += RP_THREADS) s_hits[i] = 0x7fffffff;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int i = t; i < P; i += RP_THREADS) {
+                const int q = i ^ jj;
+                if (q > i) {
+                    const int a = s_hits[i], b = s_hits[q];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s_hits[i] = b; s_hits[q] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    const int cnt = min(total, sampled);
+    for (int i = t; i < cnt; i += RP_THREADS) s_sel[i] = s_hits[i];
+    __syncthreads();
+    return cnt;
+}
+
 __global__ __launch_bounds__(RP_THREADS) void roipool3d_kernel(
     int pts_num, int boxes_num, int feat_len, int sampled, const float *__restrict__ xyz,
     const float *__restrict__ boxes3d, const float *__restrict__ pts_feature,
     float *__restrict__ pooled, int *__restrict__ empty_flag)
 {
-    extern __shared__ int rp_lds[];
+    extern __shared__ __align__(16) int rp_lds[];
     int *s_sel = rp_lds, *s_part = rp_lds + sampled, *s_cnt = rp_lds + 5 * sampled;
 
     const int box = blockIdx.x, b = blockIdx.y;
@@ -127,10 +195,13 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_kernel(
 __global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(
     int pts_num, int boxes_num, int feat_len, int sampled, float extra, float extra2, const float *__restrict__ xyz,
     const float *__restrict__ rois, const float *__restrict__ feats, const float *__restrict__ seg_mask,
-    const float *__restrict__ depth, float4 *__restrict__ pooled, int *__restrict__ empty_flag, int *__restrict__ pooled_cnt)
+    const float *__restrict__ depth, float4 *__restrict__ pooled, int *__restrict__ empty_flag, int *__restrict__ pooled_cnt,
+    const float4 *__restrict__ pxyz, const float4 *__restrict__ aabb)
 {
-    extern __shared__ int rp_lds[];
-    int *s_sel = rp_lds, *s_part = rp_lds + sampled, *s_cnt = rp_lds + 5 * sampled;
+    extern __shared__ __align__(16) int rp_lds[];
+    float4 *s_c01 = reinterpret_cast<float4 *>(rp_lds);               // [sampled][2]: the two leading chunks of every distinct row
+    int *s_sel = rp_lds + 8 * sampled, *s_part = s_sel + sampled, *s_cnt = s_sel + 5 * sampled;
+    int *s_cand = s_sel + 5 * sampled + 4;                              // pts_num / 64 ints when the spatial groups are given
 
     const int box = blockIdx.x, b = blockIdx.y;
     const int t = threadIdx.x;
@@ -138,8 +209,13 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(
     const float rx = bx[0], ry_bottom = bx[1], rz = bx[2], heading = bx[6];
     const float *__restrict__ pts = xyz + (long)b * pts_num * 3;
     // enlarge_box3d: h, w, l += 2 * extra_width;  y += extra_width
-    const int cnt = select_points(pts_num, sampled, pts, rx, ry_bottom + extra, rz, bx[3] + extra2, bx[4] + extra2,
-                                  bx[5] + extra2, heading, s_sel, s_part, s_cnt);
+    int cnt = -1;
+    if (pxyz)
+        cnt = select_points_culled(pts_num, sampled, pxyz + (long)b * pts_num, aabb + (long)b * (pts_num / 64) * 2, rx, ry_bottom + extra, rz,
+                                   bx[3] + extra2, bx[4] + extra2, bx[5] + extra2, heading, s_sel, s_part, 4 * sampled, s_cand, s_cnt);
+    if (cnt < 0)                                                         // no groups given, or a box holding more than 4 x sampled points
+        cnt = select_points(pts_num, sampled, pts, rx, ry_bottom + extra, rz, bx[3] + extra2, bx[4] + extra2,
+                            bx[5] + extra2, heading, s_sel, s_part, s_cnt);
     const int q4 = 2 + feat_len / 4;                                     // float4 chunks per row
     float4 *__restrict__ dst = pooled + ((long)b * boxes_num + box) * (long)sampled * q4;
     const long chunks = (long)sampled * q4;
@@ -169,27 +245,44 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(
     const float *__restrict__ mk = seg_mask + (long)b * pts_num;
     const float *__restrict__ dp = depth + (long)b * pts_num;
     const int f4 = feat_len / 4;
-#pragma unroll 4
-    for (long e = t; e < chunks; e += RP_THREADS) {
-        const int s = (int)(e / q4);
-        const int q = (int)(e - (long)s * q4);
-        const int k = s_sel[s < cnt ? s : s % cnt];
-        float4 v;
-        if (q >= 2) {
-            if (s >= feat_rows) continue;
-            v = feat4[(long)k * f4 + (q - 2)];
-        } else if (q == 0) {
-            const float x = pts[3 * k] - rx, y = pts[3 * k + 1] - ry_bottom, z = pts[3 * k + 2] - rz;
-            // rotate_pc_along_y_torch (kitti_utils.py:45-63) is a batched (1x2)@(2x2) matmul: the GEMM library
-            // accumulates k = 0, 1 with fused multiply-adds, i.e. fma(z, r1, x * r0) -- reproduced here
-            v.x = fmaf(z, -sina, __fmul_rn(x, cosa));
-            v.y = y;
-            v.z = fmaf(z, cosa, __fmul_rn(x, sina));
-            v.w = mk[k];
-        } else {
-            v = make_float4(dp[k], 0.f, 0.f, 0.f);
+    // The two leading chunks of a row (canonical coordinates + mask, depth) are computed ONCE per distinct row into LDS; every
+    // output row s -- a distinct row or a wrap-around copy s % cnt -- takes them from there.  The 128 feature columns are read
+    // from the points' feature rows for the rows below feat_rows only, eight independent 16-byte gathers per thread in flight
+    // (the loop used to be one dependent LDS -> gather -> store chain per iteration with an integer division and a modulo in
+    // front: 70 of the kernel's 90 us).
+    for (int s2 = t; s2 < cnt; s2 += RP_THREADS) {
+        const int k = s_sel[s2];
+        const float x = pts[3 * k] - rx, y = pts[3 * k + 1] - ry_bottom, z = pts[3 * k + 2] - rz;
+        // rotate_pc_along_y_torch (kitti_utils.py:45-63) is a batched (1x2)@(2x2) matmul: the GEMM library
+        // accumulates k = 0, 1 with fused multiply-adds, i.e. fma(z, r1, x * r0) -- reproduced here
+        s_c01[2 * s2] = make_float4(fmaf(z, -sina, __fmul_rn(x, cosa)), y, fmaf(z, cosa, __fmul_rn(x, sina)), mk[k]);
+        s_c01[2 * s2 + 1] = make_float4(dp[k], 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    // chunks 0 / 1 of ALL rows: thread pair per row
+    for (int e = t; e < 2 * sampled; e += RP_THREADS) {
+        const int s2 = e >> 1, q = e & 1;
+        const int src = s2 < cnt ? s2 : s2 % cnt;
+        dst[(long)s2 * q4 + q] = s_c01[2 * src + q];
+    }
+    // feature chunks of the rows below feat_rows
+    const float inv_f4 = 1.0f / (float)f4;
+    const int nfeat = feat_rows * f4;
+    for (int e0 = t; e0 < nfeat; e0 += 8 * RP_THREADS) {
+        float4 v[8];
+        int row[8], q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * RP_THREADS;
+            const int ee = e < nfeat ? e : 0;
+            row[u] = __float2int_rz(((float)ee + 0.5f) * inv_f4);          // ee / f4 (exact: ee + 0.5 is never within rounding of a multiple)
+            q[u] = ee - row[u] * f4;
+            const int src = row[u] < cnt ? row[u] : row[u] % cnt;
+            v[u] = feat4[(long)s_sel[src] * f4 + q[u]];
         }
-        dst[e] = v;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + u * RP_THREADS < nfeat) dst[(long)row[u] * q4 + 2 + q[u]] = v[u];
     }
 }
 
@@ -223,8 +316,11 @@ extern "C" int prcnn_roipool3d(int batch_size, int pts_num, int boxes_num, int f
 extern "C" int prcnn_roipool3d_canonical(int batch_size, int pts_num, int boxes_num, int feature_len, int sampled_pts_num,
                                          float pool_extra_width, const float *xyz, const float *rois, const float *feats,
                                          const float *seg_mask, const float *depth, float *pooled, int *pooled_empty_flag,
-                                         int *pooled_cnt, void *stream)
+                                         int *pooled_cnt, const float *pxyz, const float *aabb, void *stream)
 {
+    PRCNN_REQUIRE((pxyz == nullptr) == (aabb == nullptr), "roipool3d_canonical: pxyz and aabb go together (prcnn_point_groups)");
+    PRCNN_REQUIRE(!pxyz || (pts_num % 64 == 0 && pts_num <= 16384 && (((uintptr_t)pxyz | (uintptr_t)aabb) & 15) == 0),
+                  "roipool3d_canonical: spatial groups need pts_num a multiple of 64, <= 16384");
     PRCNN_REQUIRE(batch_size >= 0 && pts_num >= 0 && boxes_num >= 0 && feature_len >= 0 && sampled_pts_num >= 0,
                   "roipool3d_canonical: bad sizes");
     PRCNN_REQUIRE(feature_len % 4 == 0, "roipool3d_canonical: feature length %d is not a multiple of 4", feature_len);
@@ -235,9 +331,14 @@ extern "C" int prcnn_roipool3d_canonical(int batch_size, int pts_num, int boxes_
                   "roipool3d_canonical: null pointer");
     PRCNN_REQUIRE((((uintptr_t)pooled | (uintptr_t)feats) & 15) == 0, "roipool3d_canonical: 16-byte alignment required");
     dim3 grid(boxes_num, batch_size);
-    const size_t lds = ((size_t)5 * sampled_pts_num + 4) * sizeof(int);
+    const size_t lds = ((size_t)13 * sampled_pts_num + 4 + (pxyz ? pts_num / 64 : 0)) * sizeof(int);   // s_c01 | s_sel | s_part | s_cnt | s_cand
+    if (lds > 64 * 1024) {
+        const int rc = ensure_dynamic_lds((const void *)roipool3d_canonical_kernel, lds, "roipool3d_canonical");
+        if (rc != PRCNN_OK) return rc;
+    }
     hipLaunchKernelGGL(roipool3d_canonical_kernel, grid, dim3(RP_THREADS), lds, (hipStream_t)stream, pts_num, boxes_num,
                        feature_len, sampled_pts_num, pool_extra_width, (float)((double)pool_extra_width * 2.0), xyz, rois, feats,
-                       seg_mask, depth, reinterpret_cast<float4 *>(pooled), pooled_empty_flag, pooled_cnt);
+                       seg_mask, depth, reinterpret_cast<float4 *>(pooled), pooled_empty_flag, pooled_cnt,
+                       reinterpret_cast<const float4 *>(pxyz), reinterpret_cast<const float4 *>(aabb));
     return check_launch("roipool3d_canonical");
 }

@@ -43,18 +43,33 @@ def forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag):
 forward_slow = forward
 
 
-def forward_canonical(xyz, rois, feats, seg_mask, depth, pool_extra_width, pooled, pooled_empty_flag, pooled_cnt=None):
+def point_groups(xyz):
+    """xyz (B,N,3), N % 64 == 0, N <= 16384 -> (pxyz (B,N,4), aabb (B,N/64,2,4)): the clouds in Morton order with the original
+    index in lane 3, and the bounding box of every 64-point group (csrc/fps.hip prcnn_point_groups) -- forward_canonical culls
+    by group when handed these."""
+    _chk(torch.float32, xyz)
+    B, N, _ = xyz.shape
+    pxyz = torch.empty((B, N, 4), dtype=torch.float32, device=xyz.device)
+    aabb = torch.empty((B, N // 64, 2, 4), dtype=torch.float32, device=xyz.device)
+    _lib.call("prcnn_point_groups", B, N, xyz.data_ptr(), pxyz.data_ptr(), aabb.data_ptr(), _lib.current_stream(xyz))
+    return pxyz, aabb
+
+
+def forward_canonical(xyz, rois, feats, seg_mask, depth, pool_extra_width, pooled, pooled_empty_flag, pooled_cnt=None, groups=None):
     """Extension beyond the reference ABI (csrc/roipool.hip roipool3d_canonical_kernel): enlarge + pool + canonical
     transform + RCNN row layout [x',y',z',mask,depth,0,0,0 | C feats] in one pass.  pooled (B,M,S,8+C).
     pooled_cnt (B,M) i32, optional: distinct rows per box (rows beyond are wrap-around copies); when given, feature columns
-    are written for rows < round_up(cnt, 64) only."""
+    are written for rows < round_up(cnt, 64) only.  groups = point_groups(xyz), optional: same result, found by culling."""
     _chk(torch.float32, xyz, rois, feats, seg_mask, depth, pooled)
+    if groups is not None:
+        _chk(torch.float32, *groups)
     _chk(torch.int32, pooled_empty_flag)
     if pooled_cnt is not None:
         _chk(torch.int32, pooled_cnt)
     _lib.call("prcnn_roipool3d_canonical", xyz.size(0), xyz.size(1), rois.size(1), feats.size(2), pooled.size(2),
               float(pool_extra_width), xyz.data_ptr(), rois.data_ptr(), feats.data_ptr(), seg_mask.data_ptr(),
-              depth.data_ptr(), pooled.data_ptr(), pooled_empty_flag.data_ptr(), _lib.ptr(pooled_cnt), _lib.current_stream(xyz))
+              depth.data_ptr(), pooled.data_ptr(), pooled_empty_flag.data_ptr(), _lib.ptr(pooled_cnt),
+              None if groups is None else groups[0].data_ptr(), None if groups is None else groups[1].data_ptr(), _lib.current_stream(xyz))
     return 1
 
 

@@ -264,7 +264,7 @@ class PipelinedRunner:
         if gated:
             self._advance_chains(todo, ev_rpn)
         done = self._finish_inflight()
-        self._inflight = (cur, st, rois, roi_scores, ev_prop)
+        self._inflight = (cur, st, rois, roi_scores, ev_prop, None, None)
         return done
 
     # ---- grouped geometry: ONE chain per `group` batches -------------------------------------------------------
@@ -306,7 +306,6 @@ class PipelinedRunner:
         st = self.engine.rpn_stage(cur, ch["geo"])
         ev_rpn = torch.cuda.Event()
         ev_rpn.record(main)
-        self._retired.append((ch["side"], ev_rpn, ch["geo"]))     # see _launch_group
         for t in (st["rpn_scores_raw"], st["rpn_reg"], st["backbone_xyz"]):
             t.record_stream(self.tail)
         with torch.cuda.stream(self.tail):
@@ -317,7 +316,7 @@ class PipelinedRunner:
         for t in (rois, st["seg_result"], st["pts_depth"], st["depth_norm"]):       # made on the tail stream, read by the RCNN stage on the feature stream
             t.record_stream(main)
         done = self._finish_inflight()
-        self._inflight = (cur, st, rois, roi_scores, ev_prop)
+        self._inflight = (cur, st, rois, roi_scores, ev_prop, ch["side"], ch["geo"])
         return done
 
     def _advance_chains(self, todo, gate):
@@ -366,12 +365,16 @@ class PipelinedRunner:
         if self._inflight is None:
             return None
         main = torch.cuda.current_stream(self.device)
-        cur, st, rois, roi_scores, ev_prop = self._inflight
+        cur, st, rois, roi_scores, ev_prop, side, geo = self._inflight
         self._inflight = None
         main.wait_event(ev_prop)
         out = self.engine.rcnn_stage(st, rois)
         ev_rcnn = torch.cuda.Event()
         ev_rcnn.record(main)
+        if side is not None:
+            # the batch's geometry (read by its RPN stage, its spatial groups by this RCNN stage) retires: kept until the side
+            # stream that owns the memory has been made to wait for this point (see _launch_group)
+            self._retired.append((side, ev_rcnn, geo))
         for t in (out["rcnn_cls"], out["rcnn_reg"]):
             t.record_stream(self.tail)
         with torch.cuda.stream(self.tail):
@@ -390,10 +393,11 @@ class PipelinedRunner:
         """Finish the batch still in flight (RCNN + final stage) and return its detections (or None)."""
         if getattr(self, "tail", None) is None:
             return None
+        det = self._finish_inflight()
         for side, ev_read, _ in self._retired:        # the kept geometry goes back to its streams' pools, ordered after its readers
             side.wait_event(ev_read)
         self._retired = []
-        return self._finish_inflight()
+        return det
 
 
 def _tensors(obj):

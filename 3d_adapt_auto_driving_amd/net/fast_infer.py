@@ -48,6 +48,8 @@ USE_RPN_TAIL = os.environ.get("PRCNN_NO_RPN_TAIL") is None
 USE_SCALE_BATCH = os.environ.get("PRCNN_NO_SCALE_BATCH") is None
 # layers 1-3 + pool of a wide scale in one kernel (csrc/sa_wide.hip); PRCNN_NO_WIDE_FUSED=1: gather / layer / layer+pool launches
 USE_WIDE_FUSED = os.environ.get("PRCNN_NO_WIDE_FUSED") is None
+# RoI pooling culls by 64-point spatial groups of the scene (built with the geometry chain); PRCNN_NO_POOL_GROUPS=1: full sweep
+USE_POOL_GROUPS = os.environ.get("PRCNN_NO_POOL_GROUPS") is None
 
 
 def _round4(c):
@@ -336,10 +338,12 @@ class FastPointRCNN:
         state = {"l_xyz": [torch.cat(list(xyz_list), dim=0)], "sa": [], "defer_packs": True}
         self._geometry_level(state, 0)
         geo = self.geometry_finish(state)
+        groups = self._point_groups(geo["l_xyz"][0])
         out, lo = [], 0
         for b in sizes:
             hi = lo + b
-            g = {"l_xyz": [t[lo:hi] for t in geo["l_xyz"]], "fp": [(i[lo:hi], w[lo:hi]) for i, w in geo["fp"]], "sa": []}
+            g = {"l_xyz": [t[lo:hi] for t in geo["l_xyz"]], "fp": [(i[lo:hi], w[lo:hi]) for i, w in geo["fp"]], "sa": [],
+                 "groups": None if groups is None else (groups[0][lo:hi], groups[1][lo:hi])}
             for k, lev in enumerate(geo["sa"]):
                 part = {"sel": lev["sel"][lo:hi], "new_xyz": lev["new_xyz"][lo:hi], "idx": [ix[lo:hi] for ix in lev["idx"]],
                         "pack": [None] * len(lev["idx"])}
@@ -349,10 +353,20 @@ class FastPointRCNN:
             lo = hi
         return out
 
+    def _point_groups(self, xyz):
+        """Spatial groups of the input clouds for the RCNN's RoI pooling (csrc/fps.hip prcnn_point_groups): xyz only, so they
+        ride with the geometry chain on its side stream."""
+        rp = roipool3d_utils.roipool3d_cuda
+        if not (USE_POOL_GROUPS and self.cfg.RCNN.ENABLED and has_entry(rp, "point_groups") and xyz.shape[1] % 64 == 0 and xyz.shape[1] <= 16384):
+            return None
+        return rp.point_groups(xyz)
+
     @torch.no_grad()
     def geometry(self, xyz):
         """FPS / ball-query / three-NN of the RPN backbone for xyz (B,N,3)."""
-        return self.geometry_finish(self.geometry_begin(xyz))
+        geo = self.geometry_finish(self.geometry_begin(xyz))
+        geo["groups"] = self._point_groups(xyz)
+        return geo
 
     # ------------------------------------------------------------------ building blocks
     @staticmethod
@@ -519,7 +533,7 @@ class FastPointRCNN:
             rpn_reg = self.rpn_reg(flat).view(B, N, -1)
             if feats.shape[2] != self.fp[0].n_out:            # narrow configurations: drop the zero padding again
                 feats = feats[:, :, :self.fp[0].n_out].contiguous()
-        out = {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": xyz, "rpn_features": feats}
+        out = {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": xyz, "rpn_features": feats, "groups": geo.get("groups")}
         if cfg.RCNN.ENABLED:
             out["rpn_scores_raw"] = rpn_cls[:, :, 0].contiguous()
         return out
@@ -544,7 +558,8 @@ class FastPointRCNN:
     @torch.no_grad()
     def rcnn_stage(self, st, rois):
         self.point_aux(st)
-        return self._rcnn(st["backbone_xyz"], st["rpn_features"], st["seg_result"], st["pts_depth"], rois, depth_norm=st["depth_norm"])
+        return self._rcnn(st["backbone_xyz"], st["rpn_features"], st["seg_result"], st["pts_depth"], rois, depth_norm=st["depth_norm"],
+                          groups=st.get("groups"))
 
     @torch.no_grad()
     def forward(self, pts_input, geo=None):
@@ -575,7 +590,7 @@ class FastPointRCNN:
             self._pm_ok = bool(ok)
         return self._pm_ok
 
-    def _rcnn(self, xyz, feats, seg_mask, pts_depth, rois, depth_norm=None):
+    def _rcnn(self, xyz, feats, seg_mask, pts_depth, rois, depth_norm=None, groups=None):
         R = self.cfg.RCNN
         if not (R.ROI_SAMPLE_JIT and R.USE_RPN_FEATURES and not R.USE_INTENSITY):
             raise NotImplementedError("fast path covers the default.yaml RCNN input configuration")
@@ -593,7 +608,7 @@ class FastPointRCNN:
                 pooled_cnt = torch.empty((B, M), dtype=torch.int32, device=xyz.device)
             rp.forward_canonical(xyz, rois.contiguous(), feats, seg_mask.contiguous(),
                                  depth_norm if depth_norm is not None else (pts_depth / 70.0 - 0.5).contiguous(),
-                                 R.POOL_EXTRA_WIDTH, pooled, empty, pooled_cnt)
+                                 R.POOL_EXTRA_WIDTH, pooled, empty, pooled_cnt, groups)
             flat = pooled.view(B * M, P, W)
             rows = flat.view(B * M * P, W)
             a = rows[:, 0:8]                                                   # strided view: columns 5..7 are zero

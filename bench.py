@@ -213,7 +213,8 @@ def roofline_roipool(dev, cfg, model, reps=20):
     pooled = torch.empty((B, M, S, 8 + C), device=dev)
     empty = torch.empty((B, M), dtype=torch.int32, device=dev)
     cnt = torch.empty((B, M), dtype=torch.int32, device=dev)
-    run = lambda: roipool3d_cuda.forward_canonical(pts, rois.contiguous(), feats, mask, depth, cfg.RCNN.POOL_EXTRA_WIDTH, pooled, empty, cnt)
+    groups = st.get("groups")             # the scene's spatial groups (built with the geometry chain): the selection culls by them
+    run = lambda: roipool3d_cuda.forward_canonical(pts, rois.contiguous(), feats, mask, depth, cfg.RCNN.POOL_EXTRA_WIDTH, pooled, empty, cnt, groups)
     for _ in range(3):
         run()
     torch.cuda.synchronize()

@@ -340,10 +340,17 @@ int prcnn_roipool3d(int batch_size, int pts_num, int boxes_num, int feature_in_l
  * pooled_cnt (b,m) i32, optional (NULL = off): number of DISTINCT rows of each box (min(#points in box, sampled), >= 1;
  * rows s >= cnt are the wrap-around copies of row s % cnt, roipool3d_kernel.cu:152-159).  When given, the feature
  * columns are written only for rows < round_up(cnt, 64): the coordinate / mask / depth columns of all rows are. */
+/* pxyz / aabb (optional, both or neither): the cloud's spatial groups from prcnn_point_groups -- the selection then tests
+ * pts_num / 64 group boxes and reads the few groups that can hold a point of the box instead of sweeping all points; same
+ * points, same order (the hits are sorted by original index).  pts_num % 64 == 0, <= 16384. */
 int prcnn_roipool3d_canonical(int batch_size, int pts_num, int boxes_num, int feature_len, int sampled_pts_num,
                               float pool_extra_width, const float *xyz, const float *rois, const float *feats,
                               const float *seg_mask, const float *depth, float *pooled, int *pooled_empty_flag,
-                              int *pooled_cnt, void *stream);
+                              int *pooled_cnt, const float *pxyz, const float *aabb, void *stream);
+/* Spatial groups of clouds xyz (b,n,3), n % 64 == 0, n <= 16384: pxyz (b,n,4) = the points in Morton order over (x,z) with the
+ * original index in the 4th lane (int bits), aabb (b, n/64, 2, 4) = min / max corner of every 64-point group.  Any box-vs-cloud
+ * sweep (RoI pooling here) can cull by group.  Not part of the reference ABI. */
+int prcnn_point_groups(int b, int n, const float *xyz, float *pxyz, float *aabb, void *stream);
 
 /* The reference module's two HOST utilities (CPU tensors, unbatched; they serve its dataset / GT-database code):
  * pts_in_boxes3d_cpu  roipool3d.cpp:97-125 -> flags (boxes_num, pts_num) i64 in {0,1};

@@ -355,6 +355,55 @@ def test_pipelined_runner_full_size_many_steps_equals_serial():
             assert torch.equal(det[k], ref[k]), (i, k)
 
 
+def test_roipool_culled_by_spatial_groups_equals_the_index_order_sweep():
+    """forward_canonical with the scene's spatial groups (prcnn_point_groups: Morton-ordered points + per-group boxes) selects
+    EXACTLY the points of the index-order sweep, in the same order: pooled rows, empty flags and distinct counts are bit-identical
+    -- for ordinary RoIs, boxes far outside the scene, boxes on the scene's border, thin / tilted boxes, and boxes that hold more
+    than 2048 points (those fall back to the sweep inside the kernel)."""
+    C, S = pkg("config"), pkg("synth")
+    RU = pkg("roipool3d_utils")
+    cfg = C.default_eval_cfg()
+    rng = np.random.default_rng(12)
+    B, N, M, Cf, P = 3, cfg.RPN.NUM_POINTS, 160, 16, cfg.RCNN.NUM_POINTS
+    xyz_np = S.scenes(B, N, seed0=400)
+    pts = torch.from_numpy(xyz_np).to(DEV)
+    rois = np.zeros((B, M, 7), np.float32)
+    for b in range(B):
+        ctr = xyz_np[b, rng.integers(0, N, M)]                               # centred on real points: non-empty boxes
+        rois[b, :, 0:3] = ctr + rng.normal(0, 0.5, (M, 3))
+        rois[b, :, 1] += 0.8                                                 # (x, y-bottom, z)
+        rois[b, :, 3:6] = rng.uniform([1.2, 1.4, 3.0], [2.2, 2.2, 5.5], (M, 3))
+        rois[b, :, 6] = rng.uniform(-np.pi, np.pi, M)
+    rois[0, 0] = [0, 2, 35, 6, 80, 90, 0.3]                                  # scene-sized: > 2048 points inside
+    rois[0, 1] = [500, 0, 500, 2, 2, 4, 0]                                   # far away: empty
+    rois[0, 2, 3:6] = [0.05, 0.05, 12.0]                                     # a needle
+    rois[1, 0, 0:3] = [xyz_np[1, :, 0].max(), 1.0, xyz_np[1, :, 2].max()]    # on the corner of the scene
+    rois[2, 0, 3:6] = [3.0, 30.0, 30.0]                                      # wide: hundreds to thousands of points
+    rois_t = torch.from_numpy(rois).to(DEV)
+    feats = torch.from_numpy(rng.standard_normal((B, N, Cf)).astype(np.float32)).to(DEV)
+    mask = (torch.rand((B, N), device=DEV) > 0.5).float()
+    depth = torch.rand((B, N), device=DEV)
+    groups = RU.roipool3d_cuda.point_groups(pts)
+    k = groups[0][..., 3].contiguous().view(torch.int32)                      # a permutation of 0..N-1 per scene, coordinates match
+    assert torch.equal(torch.sort(k, dim=1).values, torch.arange(N, device=DEV, dtype=torch.int32).expand(B, N))
+    assert torch.equal(torch.gather(pts, 1, k.long().unsqueeze(-1).expand(-1, -1, 3)), groups[0][..., :3])
+    outs = []
+    for g in (None, groups):
+        for with_cnt in (False, True):
+            pooled = torch.full((B, M, P, 8 + Cf), float("nan"), device=DEV)
+            empty = torch.full((B, M), -1, dtype=torch.int32, device=DEV)
+            cnt = torch.full((B, M), -1, dtype=torch.int32, device=DEV) if with_cnt else None
+            RU.roipool3d_cuda.forward_canonical(pts, rois_t, feats, mask, depth, cfg.RCNN.POOL_EXTRA_WIDTH, pooled, empty, cnt, groups=g)
+            outs.append((pooled, empty, cnt))
+    for a, bb in ((outs[0], outs[2]), (outs[1], outs[3])):
+        assert torch.equal(a[1], bb[1])
+        assert torch.equal(torch.nan_to_num(a[0], nan=-777.0), torch.nan_to_num(bb[0], nan=-777.0))
+        if a[2] is not None:
+            assert torch.equal(a[2], bb[2])
+    cnt = outs[3][2]
+    assert int(cnt[0, 0]) == P and int(outs[3][1][0, 1]) == 1 and int(cnt.max()) == P and int((cnt > 64).sum()) > 3 and int(outs[3][1].sum()) >= 1
+
+
 def test_engine_keeps_no_state_from_one_batch_to_the_next():
     """An engine that has already evaluated other batches gives, bit for bit, what a freshly built engine gives.  (Round 2
     cached the packed row list of the RCNN's GroupAll level -- which holds coordinates -- across batches: every batch after
