@@ -28,6 +28,9 @@ namespace prcnn {
 
 constexpr int PK_C = 128;            // C1 = C2 (narrower levels are zero-padded by the caller)
 constexpr int PK_ROWS = 64;
+#ifndef PK_PF
+#define PK_PF 4                    // rows of P per thread the 128-wide kernel gathers one tile ahead
+#endif
 constexpr int PK_LD = PK_C + 4;
 constexpr int PK_TILES_PER_WG = 8;
 
@@ -166,6 +169,12 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
     for (int i = 0; i < 8; ++i) info[i] = rowinfo[t * PK_ROWS + r0 + 8 * i];
     int cloud = tilecloud[t];
     if (tid < PK_ROWS) dxyz_s[0][tid] = rowdxyz[t * PK_ROWS + tid];
+    // half of the tile's 8 rows of P per thread are gathered ONE TILE AHEAD (behind layer 3's MFMAs; all 8 do not fit the
+    // register budget next to the 128 resident weights: 164 bytes of spills, slower on sparse tiles): the builder's wait for its
+    // gathers was 12-15k of a tile's 50k cycles (s_memtime stamps, profiles/r02_stage_stamps.md)
+    float4 pb[PK_PF];
+#pragma unroll
+    for (int i = 0; i < PK_PF; ++i) pb[i] = P[((long)cloud * n + (long)(info[i] & 0xffffu)) * (PK_C / 4) + chunk];
     __syncthreads();
 
     for (int served = 0; served < tiles_per_wg && t < tiles; ++served) {
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
             const int k = (int)(info[i] & 0xffffu), cl = (int)(info[i] >> 16);
             const float4 d = dcur[row];
             const float dx = d.x, dy = d.y, dz = d.z;
-            const float4 base = P[(pbase + k) * (PK_C / 4) + chunk];
+            const float4 base = i < PK_PF ? pb[i] : P[(pbase + k) * (PK_C / 4) + chunk];
             float4 v;
             v.x = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, base.x))), 0.f);
             v.y = fmaxf(fmaf(wz.y, dz, fmaf(wy.y, dy, fmaf(wx.y, dx, base.y))), 0.f);
@@ -225,6 +234,10 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
             }
         }
         if (tid < PK_ROWS && t_next < tiles) dxyz_s[(served + 1) & 1][tid] = dnext;   // ordered before the next builder by the barrier below
+        if (t_next < tiles) {
+#pragma unroll
+            for (int i = 0; i < PK_PF; ++i) pb[i] = P[((long)cloud * n + (long)(info[i] & 0xffffu)) * (PK_C / 4) + chunk];   // in flight during layer 3
+        }
         __syncthreads();
 
         // ---- layer 3 + segmented max over the tile's rows
@@ -296,6 +309,11 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
     for (int i = 0; i < 4; ++i) info[i] = rowinfo[t * PK_ROWS + r0 + 16 * i];
     int cloud = tilecloud[t];
     if (tid < PK_ROWS) dxyz_s[0][tid] = rowdxyz[t * PK_ROWS + tid];
+    // the tile's 4 rows of P per thread are gathered ONE TILE AHEAD (behind layer 3's MFMAs): the builder used to wait for them,
+    // a quarter of a tile's cycles (s_memtime stamps of the 128-wide kernel, profiles/r02_stage_stamps.md)
+    float4 pb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pb[i] = P[((long)cloud * n + (long)(info[i] & 0xffffu)) * (PK_C / 4) + chunk];
     __syncthreads();
 
     for (int served = 0; served < tiles_per_wg && t < tiles; ++served) {
@@ -303,14 +321,14 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
         if (tid == 0) slot[(served + 1) & 1] = more ? atomicAdd(ticket, 1u) : 0xffffffffu;
         int *cc = ctr[served & 1];
         const float4 *dcur = dxyz_s[served & 1];
-        const long pbase = (long)cloud * n, cbase = (long)cloud * m;
+        const long cbase = (long)cloud * m;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = r0 + 16 * i;
-            const int k = (int)(info[i] & 0xffffu), cl = (int)(info[i] >> 16);
+            const int cl = (int)(info[i] >> 16);
             const float4 d = dcur[row];
             const float dx = d.x, dy = d.y, dz = d.z;
-            const float4 base = P[(pbase + k) * (PK_C / 4) + chunk];
+            const float4 base = pb[i];
             float4 v;
             v.x = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, base.x))), 0.f);
             v.y = fmaxf(fmaf(wz.y, dz, fmaf(wy.y, dy, fmaf(wx.y, dx, base.y))), 0.f);
@@ -348,6 +366,10 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
             }
         }
         if (tid < PK_ROWS && t_next < tiles) dxyz_s[(served + 1) & 1][tid] = dnext;
+        if (t_next < tiles) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pb[i] = P[((long)cloud * n + (long)(info[i] & 0xffffu)) * (PK_C / 4) + chunk];   // in flight during layer 3
+        }
         __syncthreads();
 
         // ---- layer 3: all 64 rows x columns [128 wg + 32 wp, +32), then the segmented max
