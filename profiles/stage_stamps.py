@@ -9,6 +9,7 @@ substitute that answered "where does the time between the MFMAs go".  Two steps:
       product's other objects (profiles/_exp/ is git-ignored but travels with gpurun)
   python profiles/stage_stamps.py tail [grid]    (on the GPU box)   per-stage cycles of rpn_tail_kernel, B = 8 shape
   python profiles/stage_stamps.py layer R K N    (on the GPU box)   per-stage cycles of packed_layer_pipe_kernel
+  python profiles/stage_stamps.py packed [mean]  (on the GPU box)   per-stage cycles of sa_packed_mlp128_kernel, RCNN SA1 shape
 
 `grid` (tail): number of persistent workgroups (256 = one per CU, 512 = the product's two per CU).  The read-out steps load
 the instrumented library INSTEAD of lib/libprcnn_hip.so (they point _lib.LIB_PATH at it), nothing else changes."""
@@ -25,6 +26,7 @@ FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-
 def _abs_includes(s):
     return (s.replace('#include "common.hpp"', '#include <cstdlib>\n#include "%s/common.hpp"' % CSRC)
              .replace('#include "segmax.hpp"', '#include "%s/segmax.hpp"' % CSRC)
+             .replace('#include "mfma_stream.hpp"', '#include "%s/mfma_stream.hpp"' % CSRC)
              .replace('#include "../../include/prcnn_hip.h"', '#include "%s/include/prcnn_hip.h"' % ROOT))
 
 
@@ -56,9 +58,10 @@ def instrument_layer():
                   "#define STAMP(k) if (!SEGMAX && lane == 0 && (blockIdx.x + gridDim.x * blockIdx.y) < 1024) "
                   "g_pl_trace[((blockIdx.x + gridDim.x * blockIdx.y) * 4 + w) * 64 + (k)] = __builtin_amdgcn_s_memtime();\n"
                   "constexpr int PL_ROWS = 64;")
-    s = s.replace("    float wa[64], wb[64];\n    {\n        PL_LOAD_W(wa, 0)", "    float wa[64], wb[64];\n    STAMP(0)\n    {\n        PL_LOAD_W(wa, 0)")
+    # (first occurrence only: the 32-row kernel below repeats these lines)
+    s = s.replace("    float wa[64], wb[64];\n    {\n        PL_LOAD_W(wa, 0)", "    float wa[64], wb[64];\n    STAMP(0)\n    {\n        PL_LOAD_W(wa, 0)", 1)
     s = s.replace("    const int np = K >> 7;\n    for (int p = 0; p < np; ++p) {\n        PL_VM_DRAIN",
-                  "    const int np = K >> 7;\n    int sk = 1;\n    for (int p = 0; p < np; ++p) {\n        STAMP(sk++)\n        PL_VM_DRAIN")
+                  "    const int np = K >> 7;\n    int sk = 1;\n    for (int p = 0; p < np; ++p) {\n        STAMP(sk++)\n        PL_VM_DRAIN", 1)
     s = s.replace("        lds_barrier();                                     // ... and published; the other tile is free\n",
                   "        lds_barrier();                                     // ... and published; the other tile is free\n        STAMP(sk++)\n")
     s = s.replace("            PL_STAGE_PREFETCH(T, TN, wa, wb, (p + 1) * 128)\n", "            PL_STAGE_PREFETCH(T, TN, wa, wb, (p + 1) * 128)\n            STAMP(sk++)\n")
@@ -72,20 +75,46 @@ def instrument_layer():
     return s
 
 
+def instrument_packed():
+    s = _abs_includes(open(os.path.join(CSRC, "sa_packed.hip")).read())
+    a = s.index("void sa_packed_mlp128_kernel(")
+    b = s.index("// ------------------------------------------------------------------------------------------------ C3 = 256")
+    k = s[a:b]
+    def put(old, new):
+        nonlocal k
+        assert old in k, old[:60]
+        k = k.replace(old, new, 1)
+    put("    for (int served = 0; served < tiles_per_wg && t < tiles; ++served) {\n", "    for (int served = 0; served < tiles_per_wg && t < tiles; ++served) {\n        STAMP(0)\n")
+    put("        __syncthreads();\n        const long t_next = slot[(served + 1) & 1];", "        STAMP(1)\n        __syncthreads();\n        STAMP(2)\n        const long t_next = slot[(served + 1) & 1];")
+    put("#pragma unroll\n            for (int r = 0; r < 16; ++r) {\n                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;\n                Y1[row * PK_LD + 32 * w + j] = fmaxf(acc0[r] + bias2, 0.f);",
+        "            STAMP(3)\n#pragma unroll\n            for (int r = 0; r < 16; ++r) {\n                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;\n                Y1[row * PK_LD + 32 * w + j] = fmaxf(acc0[r] + bias2, 0.f);")
+    put("        if (tid < PK_ROWS && t_next < tiles) dxyz_s[(served + 1) & 1][tid] = dnext;   // ordered before", "        STAMP(4)\n        if (tid < PK_ROWS && t_next < tiles) dxyz_s[(served + 1) & 1][tid] = dnext;   // ordered before")
+    put("   // in flight during layer 3\n        }\n        __syncthreads();\n", "   // in flight during layer 3\n        }\n        __syncthreads();\n        STAMP(5)\n")
+    put("            const int myc = cc[lane], prevc = cc[lane ? lane - 1 : 0];\n            const unsigned long long start = __ballot(lane == 0 || myc != prevc);\n            pk_segmented_max(acc0, acc1, cc, start, h, out, out_stride, out_col + 32 * w + j, bias3);\n        }",
+        "            STAMP(6)\n            const int myc = cc[lane], prevc = cc[lane ? lane - 1 : 0];\n            const unsigned long long start = __ballot(lane == 0 || myc != prevc);\n            pk_segmented_max(acc0, acc1, cc, start, h, out, out_stride, out_col + 32 * w + j, bias3);\n            STAMP(7)\n        }")
+    s = s[:a] + k + s[b:]
+    s = s.replace("constexpr int PK_ROWS = 64;", "__device__ unsigned long long g_sp_trace[1024 * 4 * 8];\n"
+                  "#define STAMP(k) if ((threadIdx.x & 63) == 0 && served == 1 && blockIdx.x < 1024) g_sp_trace[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime();\n"
+                  "constexpr int PK_ROWS = 64;", 1)
+    s += ('\nextern "C" int prcnn_debug_sp_trace(unsigned long long *dst)\n{\n    return (int)hipMemcpyFromSymbol(dst, '
+          'HIP_SYMBOL(prcnn::g_sp_trace), sizeof(unsigned long long) * 1024 * 4 * 8);\n}\n')
+    return s
+
+
 def build():
     os.makedirs(EXP, exist_ok=True)
     subprocess.check_call(["make", "-C", CSRC])
     tail, names = instrument_tail()
     open(os.path.join(EXP, "trace_names.txt"), "w").write("\n".join(names))
     objs = []
-    for name, src in (("rpn_tail", tail), ("packed_layer", instrument_layer())):
+    for name, src in (("rpn_tail", tail), ("packed_layer", instrument_layer()), ("sa_packed", instrument_packed())):
         path = os.path.join(EXP, name + "_stamps.hip")
         open(path, "w").write(src)
         obj = os.path.join(EXP, name + "_stamps.o")
         subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-c", path, "-o", obj])
         objs.append(obj)
     others = [os.path.join(CSRC, "build", f) for f in sorted(os.listdir(os.path.join(CSRC, "build")))
-              if f.endswith(".o") and f not in ("rpn_tail.o", "packed_layer.o")]
+              if f.endswith(".o") and f not in ("rpn_tail.o", "packed_layer.o", "sa_packed.o")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + others + objs)
     print("built", LIB)
 
@@ -157,6 +186,34 @@ def read_layer(rows, K, N):
     _row("workgroup total", (tr[:, :, 63] - tr[:, :, 0]).ravel())
 
 
+def read_packed(mean):
+    import torch
+    X, L = _load()
+    dev = torch.device("cuda:0"); g = torch.Generator(device=dev).manual_seed(0)
+    b, n, m, ns = 800, 512, 128, 64
+    xyz = torch.randn((b, n, 3), device=dev, generator=g); new_xyz = xyz[:, :m].contiguous()
+    P = torch.randn((b, n, 128), device=dev, generator=g); wx = torch.randn((3, 128), device=dev, generator=g)
+    w2 = torch.randn((128, 128), device=dev, generator=g) / 11; w3 = torch.randn((128, 128), device=dev, generator=g) / 11
+    b2 = torch.randn(128, device=dev, generator=g); b3 = torch.randn(128, device=dev, generator=g)
+    out = torch.empty((b, m, 128), device=dev)
+    full = torch.sort(torch.argsort(torch.rand((b, m, n), device=dev, generator=g), dim=2)[:, :, :ns], dim=2).values.to(torch.int32)
+    cnt = torch.clamp((torch.rand((b, m, 1), device=dev, generator=g) * 2 * mean).long() + 1, max=ns)
+    idx = torch.where(torch.arange(ns, device=dev).view(1, 1, ns) < cnt, full, full[:, :, :1]).contiguous()
+    pk = X.ball_pack_wrapper(idx, xyz, new_xyz)
+    for _ in range(3): X.sa_packed_mlp_wrapper(new_xyz, xyz, P, wx, pk, w2, b2, w3, b3, out, 0)
+    torch.cuda.synchronize()
+    buf = np.zeros(1024 * 4 * 8, np.uint64)
+    L.prcnn_debug_sp_trace.argtypes = [ctypes.c_void_p]; assert L.prcnn_debug_sp_trace(buf.ctypes.data) == 0
+    tr = buf.reshape(1024, 4, 8).astype(np.int64); ok = tr[:, :, 0] > 0
+    d = np.diff(tr, axis=2)
+    print("sa_packed_mlp128_kernel, 800 clouds x 128 centres, ~%.1f distinct rows per centre: %d tiles; second tile of every workgroup, s_memtime cycles per wave\n" % (mean + 1, int(pk.hdr[0])))
+    print("| span | median | p10 | p90 |\n|---|---|---|---|")
+    for k, nm in enumerate(["builder (P rows + affine -> LDS)", "barrier", "next tile's row list + layer 2 MFMAs", "epilogue -> Y1", "prefetch of the next P rows + barrier",
+                            "layer 3 MFMAs", "segmented max + atomics"]):
+        _row(nm, d[:, :, k][ok])
+    _row("tile total", (tr[:, :, 7] - tr[:, :, 0])[ok])
+
+
 if __name__ == "__main__":
     cmd = sys.argv[1] if len(sys.argv) > 1 else "build"
     if cmd == "build":
@@ -165,5 +222,7 @@ if __name__ == "__main__":
         read_tail(int(sys.argv[2]) if len(sys.argv) > 2 else 512)
     elif cmd == "layer":
         read_layer(*[int(v) for v in sys.argv[2:5]])
+    elif cmd == "packed":
+        read_packed(float(sys.argv[2]) if len(sys.argv) > 2 else 0.6)
     else:
         raise SystemExit(__doc__)
