@@ -573,7 +573,7 @@ extern "C" int prcnn_point_groups(int b, int n, const float *xyz, float *pxyz, f
     if (b == 0) return PRCNN_OK;
     PRCNN_REQUIRE(xyz && pxyz && aabb && (((uintptr_t)pxyz | (uintptr_t)aabb) & 15) == 0, "point_groups: null / misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
-    int *perm = (int *)scratch_for(st, (size_t)b * n * sizeof(int), 2);
+    int *perm = (int *)scratch_for(st, (size_t)b * n * sizeof(int), 8);
     if (!perm) { set_error("point_groups: cannot allocate ordering scratch"); return PRCNN_ELAUNCH; }
     hipLaunchKernelGGL(fps_order_kernel, dim3(b), dim3(1024), 0, st, n, xyz, perm);
     hipLaunchKernelGGL(point_groups_kernel, dim3((n / 64 + 3) / 4, b), dim3(256), 0, st, n, xyz, perm, (float4 *)pxyz, (float4 *)aabb);
