@@ -47,38 +47,49 @@ __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, cons
                                  unsigned int *__restrict__ rowinfo, float4 *__restrict__ rowdxyz, int *__restrict__ tilecloud,
                                  unsigned int *__restrict__ hdr)
 {
+    // Both passes are parallel over ELEMENTS, not over centres (a thread per centre left 32 of 256 threads busy on the RoI
+    // clouds' second level and walked each centre's rows as a chain of dependent loads: 47 us for 800 clouds x 32 centres):
+    //   1. every thread takes 16-byte pieces of index rows; the centre's distinct count is an LDS atomicMax over its pieces;
+    //   2. block scan of the counts -> exclusive offsets;
+    //   3. every thread takes OUTPUT rows: centre by binary search in the offsets, slot = row - offset.
     extern __shared__ int pk_lds[];
-    int *cnts = pk_lds;                   // [m]   cnt, then exclusive offset
-    int *part = pk_lds + m;               // [blockDim.x] partial sums, then their exclusive scan
+    int *cnts = pk_lds;                   // [m]   distinct count per centre
+    int *offs = pk_lds + m;               // [m]   exclusive offsets
+    int *part = pk_lds + 2 * m;           // [blockDim.x] partial sums, then their inclusive scan
     __shared__ int s_base;
     const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
-    const int chunk = (m + T - 1) / T;
-    const int c0 = tid * chunk, c1 = min(m, c0 + chunk);
     const int *rows = idx + (long)b * m * ns;
     const int lim = limit ? max(limit[b], 1) : 0x7fffffff;
-    int sum = 0;
-    for (int c = c0; c < c1; ++c) {
-        const int *row = rows + (long)c * ns;
-        const int first = row[0];
-        int last = 0;
-        if ((ns & 3) == 0) {
-            for (int p = 0; p < ns; p += 4) {
-                const int4 v = *reinterpret_cast<const int4 *>(row + p);
-                if (v.x != first && v.x < lim) last = p;
-                if (v.y != first && v.y < lim) last = p + 1;
-                if (v.z != first && v.z < lim) last = p + 2;
-                if (v.w != first && v.w < lim) last = p + 3;
-            }
-        } else {
-            for (int p = 1; p < ns; ++p) if (row[p] != first && row[p] < lim) last = p;
+    for (int c = tid; c < m; c += T) cnts[c] = 1;
+    __syncthreads();
+    if ((ns & 3) == 0) {
+        const int q4 = ns >> 2;
+        for (int e = tid; e < m * q4; e += T) {
+            const int c = e / q4, p = (e - c * q4) * 4;
+            const int first = rows[(long)c * ns];
+            const int4 v = *reinterpret_cast<const int4 *>(rows + (long)c * ns + p);
+            int last = -1;
+            if (v.x != first && v.x < lim) last = p;
+            if (v.y != first && v.y < lim) last = p + 1;
+            if (v.z != first && v.z < lim) last = p + 2;
+            if (v.w != first && v.w < lim) last = p + 3;
+            if (last > 0) atomicMax(&cnts[c], last + 1);
         }
-        cnts[c] = last + 1;
-        sum += last + 1;
+    } else {
+        for (int e = tid; e < m * ns; e += T) {
+            const int c = e / ns, p = e - c * ns;
+            const int v = rows[e];
+            if (p > 0 && v != rows[(long)c * ns] && v < lim) atomicMax(&cnts[c], p + 1);
+        }
     }
+    __syncthreads();
+    const int chunk = (m + T - 1) / T;
+    const int c0 = min(m, tid * chunk), c1 = min(m, c0 + chunk);
+    int sum = 0;
+    for (int c = c0; c < c1; ++c) sum += cnts[c];
     part[tid] = sum;
     __syncthreads();
-    // exclusive scan of the per-thread sums (Hillis-Steele over T <= 1024 entries)
-    for (int d = 1; d < T; d <<= 1) {
+    for (int d = 1; d < T; d <<= 1) {     // inclusive scan of the per-thread sums (Hillis-Steele over T <= 1024 entries)
         const int v = tid >= d ? part[tid - d] : 0;
         __syncthreads();
         part[tid] += v;
@@ -86,6 +97,7 @@ __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, cons
     }
     const int total = part[T - 1];
     int run = part[tid] - sum;
+    for (int c = c0; c < c1; ++c) { offs[c] = run; run += cnts[c]; }
     if (tid == 0) {
         const int ntiles = (total + PK_ROWS - 1) / PK_ROWS;
         s_base = (int)atomicAdd(&hdr[0], (unsigned int)ntiles);
@@ -98,29 +110,28 @@ __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, cons
     unsigned int *dst = rowinfo + (long)base * PK_ROWS;
     float4 *dxyz = rowdxyz + (long)base * PK_ROWS;
     const float *cloud = xyz + (long)b * n * 3;
-    for (int c = c0; c < c1; ++c) {
-        const int *row = rows + (long)c * ns;
-        const int n_c = cnts[c];
-        const float *ct = new_xyz + ((long)b * m + c) * 3;
-        const float cx = ct[0], cy = ct[1], cz = ct[2];
-        // slots beyond the limit inside the kept prefix (possible only for index rows that are not a ball query's
-        // answer) fall back to the row's first entry: still a copy of a listed row
-        for (int p = 0; p < n_c; ++p) {
-            const int k = row[p] < lim ? row[p] : row[0];
-            dst[run + p] = ((unsigned int)c << 16) | (unsigned int)k;
-            const float *pt = cloud + 3 * (long)k;
-            dxyz[run + p] = make_float4(pt[0] - cx, pt[1] - cy, pt[2] - cz, 0.f);
+    // rows beyond `total` fill the cloud's last tile with copies of its last row (copies do not change a max)
+    for (int r = tid; r < ntiles * PK_ROWS; r += T) {
+        int c, p;
+        if (r < total) {
+            int lo = 0, hi = m - 1;         // the last centre whose offset is <= r
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (offs[mid] <= r) lo = mid; else hi = mid - 1;
+            }
+            c = lo; p = r - offs[lo];
+        } else {
+            c = m - 1; p = 0;
         }
-        run += n_c;
-    }
-    // the last tile of the cloud is filled up with copies of the cloud's last row (copies do not change a max)
-    if (c1 == m && c0 < m) {
-        const int k = rows[(long)(m - 1) * ns];
-        const unsigned int fill = ((unsigned int)(m - 1) << 16) | (unsigned int)k;
-        const float *ct = new_xyz + ((long)b * m + (m - 1)) * 3;
+        const int *row = rows + (long)c * ns;
+        // slots beyond the limit inside the kept prefix (possible only for index rows that are not a ball query's answer) fall
+        // back to the row's first entry: still a copy of a listed row
+        const int v = row[p];
+        const int k = v < lim ? v : row[0];
+        const float *ct = new_xyz + ((long)b * m + c) * 3;
         const float *pt = cloud + 3 * (long)k;
-        const float4 fd = make_float4(pt[0] - ct[0], pt[1] - ct[1], pt[2] - ct[2], 0.f);
-        for (int r = total; r < ntiles * PK_ROWS; ++r) { dst[r] = fill; dxyz[r] = fd; }
+        dst[r] = ((unsigned int)c << 16) | (unsigned int)k;
+        dxyz[r] = make_float4(pt[0] - ct[0], pt[1] - ct[1], pt[2] - ct[2], 0.f);
     }
     (void)tiles_cap_cloud;
 }
@@ -424,9 +435,9 @@ extern "C" int prcnn_ball_pack(int b, int n, int m, int nsample, const int *idx,
     PRCNN_REQUIRE(idx && rowinfo && tilecloud && xyz && new_xyz && rowdxyz, "ball_pack: null pointer");
     PRCNN_REQUIRE(((uintptr_t)rowdxyz & 15) == 0, "ball_pack: rowdxyz must be 16-byte aligned");
     PRCNN_REQUIRE(((uintptr_t)idx & 15) == 0 || (nsample & 3) != 0, "ball_pack: 16-byte alignment required");
-    int threads = 64;
-    while (threads < m && threads < 1024) threads *= 2;
-    const size_t lds = ((size_t)m + threads) * sizeof(int);
+    int threads = 64;                              // enough threads for the cloud's index elements, 16 bytes each
+    while (threads < (int)(((long)m * nsample + 3) / 4) && threads < 1024) threads *= 2;
+    const size_t lds = ((size_t)2 * m + threads) * sizeof(int);
     if (lds > 48 * 1024) {
         const int rc = ensure_dynamic_lds((const void *)ball_pack_kernel, lds, "ball_pack");
         if (rc != PRCNN_OK) return rc;
