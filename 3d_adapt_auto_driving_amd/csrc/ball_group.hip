@@ -357,7 +357,9 @@ extern "C" int prcnn_ball_query_limit(int b, int n, int m, float radius, int nsa
     if (b == 0 || m == 0) return PRCNN_OK;
     PRCNN_REQUIRE(new_xyz && xyz && idx && limit, "ball_query_limit: null pointer");
     // one wave per 64 centres scans the (short) live part of its cloud
-    return launch_ball_query<1>(b, n, m, radius, nsample, new_xyz, xyz, idx, 0, (hipStream_t)stream, limit);
+    // (write_empty = 1: every slot of idx is written -- an empty ball gets zeros, the value the reference's zero-filled tensor
+    // holds -- so the caller need not clear 26 MB of indices first)
+    return launch_ball_query<1>(b, n, m, radius, nsample, new_xyz, xyz, idx, 1, (hipStream_t)stream, limit);
 }
 
 extern "C" int prcnn_group_points(int b, int c, int n, int npoints, int nsample,

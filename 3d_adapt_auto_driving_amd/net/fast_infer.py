@@ -660,7 +660,7 @@ class FastPointRCNN:
                 if first and pooled_cnt is not None and P_pre is not None and has_entry(ext, "ball_query_limit_wrapper"):
                     # pooled rows k >= count are copies of row k % count: scanning the distinct rows finds every ball's points
                     # (the row list below drops the copies anyway); a RoI holds ~60 of its 512 rows at this scene size
-                    idx = torch.zeros((Bc, npoint, ns), dtype=torch.int32, device=cur_xyz.device)
+                    idx = torch.empty((Bc, npoint, ns), dtype=torch.int32, device=cur_xyz.device)     # every slot is written
                     ext.ball_query_limit_wrapper(Bc, n, npoint, radius, ns, new_xyz, cur_xyz, pooled_cnt.view(-1), idx)
                 else:
                     idx = pu.ball_query(radius, ns, cur_xyz, new_xyz)

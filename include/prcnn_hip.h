@@ -62,7 +62,8 @@ int prcnn_group_points_grad(int b, int c, int n, int npoints, int nsample,
 
 /* Ball query over clouds whose points k >= limit[cloud] are copies of point k % limit[cloud] (the pooled rows of a RoI that
  * holds fewer than 512 points, roipool3d_kernel.cu:152-159): only the first limit[cloud] points are scanned.  Same distinct
- * points per ball as prcnn_ball_query, slots past them repeat the first hit.  Engine-side shortcut, not reference ABI. */
+ * points per ball as prcnn_ball_query, slots past them repeat the first hit; every slot of idx is written (an empty ball gets
+ * zeros).  Engine-side shortcut, not reference ABI. */
 int prcnn_ball_query_limit(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
                            const int *limit, int *idx, void *stream);
 

@@ -57,6 +57,7 @@ class pointnet2_cpu:
     @staticmethod
     def ball_query_limit_wrapper(b, n, m, radius, nsample, new_xyz, xyz, limit, idx):
         """the reference ball query (ball_query_gpu.cu:14-43) over the first limit[cloud] points of every cloud"""
+        idx.zero_()                                     # the kernel writes every slot (zeros for an empty ball)
         for i in range(b):
             ni = min(n, max(int(limit[i]), 1))
             O.lib().orc_ball_query(1, ni, m, C.c_float(radius), nsample, C.cast(new_xyz[i].data_ptr(), _f), C.cast(xyz[i].data_ptr(), _f),

@@ -137,7 +137,7 @@ def test_ball_query_with_scan_limit_on_wrapped_clouds(ext, oracle):
         base = rng.uniform(-0.6, 0.6, (c, 3)).astype(np.float32)
         xyz[i] = base[np.arange(n) % c]
     new_xyz = centres(oracle, xyz, m)
-    got = torch.zeros((b, m, ns), dtype=torch.int32, device=DEV)
+    got = torch.full((b, m, ns), -5, dtype=torch.int32, device=DEV)              # every slot is written by the kernel
     ext.pointnet2.ball_query_limit_wrapper(b, n, m, r, ns, T(new_xyz), T(xyz), T(cnt), got)
     got = got.cpu().numpy()
     full = oracle.ball_query(r, ns, xyz, new_xyz)
