@@ -53,6 +53,26 @@ __device__ __forceinline__ float cos_f32(float x) { return (float)cos((double)x)
 __device__ __forceinline__ float sin_f32(float x) { return (float)sin((double)x); }
 __device__ __forceinline__ float atan2_f32(float y, float x) { return (float)atan2((double)y, (double)x); }
 
+// Packed f32 arithmetic: two components per v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32.  Every component sees exactly the
+// operation the scalar form would apply (one rounding each), so results are bit-identical; what changes is the VALU
+// INSTRUCTION count of the tile builders, and a builder that shares its SIMD with a neighbour's MFMA stream waits for a
+// slot between two MFMAs per instruction (profiles/r02_stage_stamps.md).
+typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+// acc + w * s per component, as fma(w, s, acc)
+__device__ __forceinline__ float4 pk_fma4(const float4 w, float s, const float4 acc)
+{
+    const pk_f32x2 ss = {s, s};
+    const pk_f32x2 lo = __builtin_elementwise_fma((pk_f32x2){w.x, w.y}, ss, (pk_f32x2){acc.x, acc.y});
+    const pk_f32x2 hi = __builtin_elementwise_fma((pk_f32x2){w.z, w.w}, ss, (pk_f32x2){acc.z, acc.w});
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+__device__ __forceinline__ float4 relu4(const float4 v) { return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)); }
+// relu(fma(wz, dz, fma(wy, dy, fma(wx, dx, base)))) per component: layer 1 of an SA scale applied to a neighbour offset
+__device__ __forceinline__ float4 affine_relu4(const float4 base, const float4 wx, const float4 wy, const float4 wz, float dx, float dy, float dz)
+{
+    return relu4(pk_fma4(wz, dz, pk_fma4(wy, dy, pk_fma4(wx, dx, base))));
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 }  // namespace prcnn

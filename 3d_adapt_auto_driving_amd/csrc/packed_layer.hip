@@ -63,11 +63,7 @@ __global__ __launch_bounds__(256) void packed_gather_affine_kernel(const PGBatch
         const float dx = d.x, dy = d.y, dz = d.z;
         const float4 base = P[(pbase + k) * q4 + q];
         const float4 wx = wxyz[q], wy = wxyz[q4 + q], wz = wxyz[2 * q4 + q];
-        float4 v;
-        v.x = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, base.x))), 0.f);
-        v.y = fmaxf(fmaf(wz.y, dz, fmaf(wy.y, dy, fmaf(wx.y, dx, base.y))), 0.f);
-        v.z = fmaxf(fmaf(wz.z, dz, fmaf(wy.z, dy, fmaf(wx.z, dx, base.z))), 0.f);
-        v.w = fmaxf(fmaf(wz.w, dz, fmaf(wy.w, dy, fmaf(wx.w, dx, base.w))), 0.f);
+        const float4 v = affine_relu4(base, wx, wy, wz, dx, dy, dz);
         out[(t * PL_ROWS + row) * q4 + q] = v;
     }
 }

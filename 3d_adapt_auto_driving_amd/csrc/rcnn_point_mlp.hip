@@ -120,10 +120,7 @@ __global__ __launch_bounds__(256, 2) void rows_layer_kernel(
             if constexpr (PRO == 1) {
                 const float4 q = p0[i];
                 const float d = pd[i];
-                v.x = fmaxf(fmaf(k1[4].x, d, fmaf(k1[3].x, q.w, fmaf(k1[2].x, q.z, fmaf(k1[1].x, q.y, fmaf(k1[0].x, q.x, b1.x))))), 0.f);
-                v.y = fmaxf(fmaf(k1[4].y, d, fmaf(k1[3].y, q.w, fmaf(k1[2].y, q.z, fmaf(k1[1].y, q.y, fmaf(k1[0].y, q.x, b1.y))))), 0.f);
-                v.z = fmaxf(fmaf(k1[4].z, d, fmaf(k1[3].z, q.w, fmaf(k1[2].z, q.z, fmaf(k1[1].z, q.y, fmaf(k1[0].z, q.x, b1.z))))), 0.f);
-                v.w = fmaxf(fmaf(k1[4].w, d, fmaf(k1[3].w, q.w, fmaf(k1[2].w, q.z, fmaf(k1[1].w, q.y, fmaf(k1[0].w, q.x, b1.w))))), 0.f);
+                v = relu4(pk_fma4(k1[4], d, pk_fma4(k1[3], q.w, pk_fma4(k1[2], q.z, pk_fma4(k1[1], q.y, pk_fma4(k1[0], q.x, b1))))));
             }
             *reinterpret_cast<float4 *>(T0 + row * PM_LD + 4 * chunk) = v;
             if constexpr (NPANEL == 2) *reinterpret_cast<float4 *>(T1 + row * PM_LD + 4 * chunk) = p1[i];
@@ -218,10 +215,7 @@ __global__ __launch_bounds__(256, 2) void rcnn_entrance_kernel(
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float4 v;
-                v.x = fmaxf(fmaf(k1[4].x, d[i], fmaf(k1[3].x, q[i].w, fmaf(k1[2].x, q[i].z, fmaf(k1[1].x, q[i].y, fmaf(k1[0].x, q[i].x, b1.x))))), 0.f);
-                v.y = fmaxf(fmaf(k1[4].y, d[i], fmaf(k1[3].y, q[i].w, fmaf(k1[2].y, q[i].z, fmaf(k1[1].y, q[i].y, fmaf(k1[0].y, q[i].x, b1.y))))), 0.f);
-                v.z = fmaxf(fmaf(k1[4].z, d[i], fmaf(k1[3].z, q[i].w, fmaf(k1[2].z, q[i].z, fmaf(k1[1].z, q[i].y, fmaf(k1[0].z, q[i].x, b1.z))))), 0.f);
-                v.w = fmaxf(fmaf(k1[4].w, d[i], fmaf(k1[3].w, q[i].w, fmaf(k1[2].w, q[i].z, fmaf(k1[1].w, q[i].y, fmaf(k1[0].w, q[i].x, b1.w))))), 0.f);
+                v = relu4(pk_fma4(k1[4], d[i], pk_fma4(k1[3], q[i].w, pk_fma4(k1[2], q[i].z, pk_fma4(k1[1], q[i].y, pk_fma4(k1[0], q[i].x, b1))))));
                 *reinterpret_cast<float4 *>(T0 + (r0 + 8 * i) * PM_LD + 4 * chunk) = v;
                 *reinterpret_cast<float4 *>(T1 + (r0 + 8 * i) * PM_LD + 4 * chunk) = f[i];
             }

@@ -117,10 +117,9 @@ __global__ __launch_bounds__(256, 2) void rpn_tail_kernel(const RpnTailArgs a)
                     const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), 3 * (rr + q)));
                     const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), 3 * (rr + q) + 1));
                     const float w2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), 3 * (rr + q) + 2));
-                    f32x4 v;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        v[c] = __fadd_rn(__fadd_rn(__fmul_rn(w0, f[q][0][c]), __fmul_rn(w1, f[q][1][c])), __fmul_rn(w2, f[q][2][c]));
+                    // (w0 f0 + w1 f1) + w2 f2 per component, one rounding per operation (the file is compiled with
+                    // -ffp-contract=off): v_pk_mul_f32 / v_pk_add_f32, two components per instruction
+                    const f32x4 v = (w0 * f[q][0] + w1 * f[q][1]) + w2 * f[q][2];
                     float *dst = (lane < 32 ? T0 : T1) + (16 * w + rr + q) * RT_LD + 4 * (lane & 31);
                     *reinterpret_cast<f32x4 *>(dst) = v;
                 }

@@ -201,11 +201,7 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
             const float4 d = dcur[row];
             const float dx = d.x, dy = d.y, dz = d.z;
             const float4 base = i < PK_PF ? pb[i] : P[(pbase + k) * (PK_C / 4) + chunk];
-            float4 v;
-            v.x = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, base.x))), 0.f);
-            v.y = fmaxf(fmaf(wz.y, dz, fmaf(wy.y, dy, fmaf(wx.y, dx, base.y))), 0.f);
-            v.z = fmaxf(fmaf(wz.z, dz, fmaf(wy.z, dy, fmaf(wx.z, dx, base.z))), 0.f);
-            v.w = fmaxf(fmaf(wz.w, dz, fmaf(wy.w, dy, fmaf(wx.w, dx, base.w))), 0.f);
+            const float4 v = affine_relu4(base, wx, wy, wz, dx, dy, dz);
             *reinterpret_cast<float4 *>(A1 + row * PK_LD + 4 * chunk) = v;
             if (chunk == 0) cc[row] = (int)(cbase + cl);
         }
@@ -340,11 +336,7 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
             const float4 d = dcur[row];
             const float dx = d.x, dy = d.y, dz = d.z;
             const float4 base = pb[i];
-            float4 v;
-            v.x = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, base.x))), 0.f);
-            v.y = fmaxf(fmaf(wz.y, dz, fmaf(wy.y, dy, fmaf(wx.y, dx, base.y))), 0.f);
-            v.z = fmaxf(fmaf(wz.z, dz, fmaf(wy.z, dy, fmaf(wx.z, dx, base.z))), 0.f);
-            v.w = fmaxf(fmaf(wz.w, dz, fmaf(wy.w, dy, fmaf(wx.w, dx, base.w))), 0.f);
+            const float4 v = affine_relu4(base, wx, wy, wz, dx, dy, dz);
             *reinterpret_cast<float4 *>(A1 + row * PK_LD + 4 * chunk) = v;
             if (chunk == 0) cc[row] = (int)(cbase + cl);
         }

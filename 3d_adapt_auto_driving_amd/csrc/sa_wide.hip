@@ -157,11 +157,7 @@ __global__ __launch_bounds__(256, 2) void sa_wide_fused_kernel(const SaWideArgs 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float dx = d[i].x, dy = d[i].y, dz = d[i].z;
-                    float4 v;
-                    v.x = fmaxf(fmaf(wz.x, dz, fmaf(wy.x, dy, fmaf(wx.x, dx, base[i].x))), 0.f);
-                    v.y = fmaxf(fmaf(wz.y, dz, fmaf(wy.y, dy, fmaf(wx.y, dx, base[i].y))), 0.f);
-                    v.z = fmaxf(fmaf(wz.z, dz, fmaf(wy.z, dy, fmaf(wx.z, dx, base[i].z))), 0.f);
-                    v.w = fmaxf(fmaf(wz.w, dz, fmaf(wy.w, dy, fmaf(wx.w, dx, base[i].w))), 0.f);
+                    const float4 v = affine_relu4(base[i], wx, wy, wz, dx, dy, dz);
                     *reinterpret_cast<float4 *>(A1 + pc * SW_PANEL + (r0 + 8 * i) * SW_LD + 4 * chunk) = v;
                 }
             }
