@@ -31,6 +31,9 @@ from .net.point_rcnn import PointRCNN
 from .net.fast_infer import FastPointRCNN
 from ._lib import has_entry
 
+# PRCNN_NO_RCNN_SPLIT=1: the RCNN stage's RoI pooling / sampling / grouping geometry stays on the feature stream (A/B switch)
+SPLIT_RCNN = os.environ.get("PRCNN_NO_RCNN_SPLIT") != "1"
+
 
 def build_model(cfg, device, seed=0):
     """Random-init PointRCNN in TEST mode (eval_rcnn.py:758), deterministic in ``seed``."""
@@ -249,13 +252,7 @@ class PipelinedRunner:
         ev_rpn.record(main)
         for t in (st["rpn_scores_raw"], st["rpn_reg"], st["backbone_xyz"]):
             t.record_stream(self.tail)
-        with torch.cuda.stream(self.tail):
-            self.tail.wait_event(ev_rpn)
-            rois, roi_scores = self.engine.propose(st)
-            ev_prop = torch.cuda.Event()
-            ev_prop.record(self.tail)
-        for t in (rois, st["seg_result"], st["pts_depth"], st["depth_norm"]):       # made on the tail stream, read by the RCNN stage on the feature stream
-            t.record_stream(main)
+        rois, roi_scores, ev_prop, rg = self._propose_on_tail(st, ev_rpn, main)
         # Geometry of the upcoming batches is GATED on the end of this RPN stage: the library GEMMs of the RPN stage are
         # persistent-grid kernels that stretch 40-70 % when an FPS workgroup shares a CU with them, the RCNN stage that
         # follows is made of ticketed kernels that do not care.  So the xyz-only chains only START during RCNN stages:
@@ -264,8 +261,29 @@ class PipelinedRunner:
         if gated:
             self._advance_chains(todo, ev_rpn)
         done = self._finish_inflight()
-        self._inflight = (cur, st, rois, roi_scores, ev_prop, None, None)
+        self._inflight = (cur, st, rois, roi_scores, ev_prop, None, None, rg)
         return done
+
+    def _propose_on_tail(self, st, ev_rpn, main):
+        """Proposal layer of the batch whose RPN stage ends at `ev_rpn`, on the tail stream -- and right behind it the part of
+        its RCNN stage that needs the RoIs and coordinates only (RoI pooling, FPS, ball queries, row lists: ten latency-bound
+        launches, 0.3 ms of every step while they sat on the feature stream in front of the RCNN's MFMA kernels).
+        -> rois, scores, event (RoIs and, if split, the RCNN geometry are ready), RCNN geometry state or None."""
+        rg = None
+        with torch.cuda.stream(self.tail):
+            self.tail.wait_event(ev_rpn)
+            rois, roi_scores = self.engine.propose(st)
+            if SPLIT_RCNN:
+                # reads st["rpn_features"] (feature-stream memory: st stays referenced until the feature stream has run this
+                # batch's RCNN stage, which waits for ev_prop) and makes ~15 tensors on the tail stream that the feature stream
+                # reads: they are kept in self._inflight until the tail stream has waited for that RCNN stage (_finish_inflight)
+                rg = self.engine.rcnn_geometry(st, rois)
+            ev_prop = torch.cuda.Event()
+            ev_prop.record(self.tail)
+        if rg is None:
+            for t in (rois, st["seg_result"], st["pts_depth"], st["depth_norm"]):   # made on the tail stream, read by the RCNN stage on the feature stream
+                t.record_stream(main)
+        return rois, roi_scores, ev_prop, rg
 
     # ---- grouped geometry: ONE chain per `group` batches -------------------------------------------------------
     def _launch_group(self, batch_list):
@@ -308,15 +326,9 @@ class PipelinedRunner:
         ev_rpn.record(main)
         for t in (st["rpn_scores_raw"], st["rpn_reg"], st["backbone_xyz"]):
             t.record_stream(self.tail)
-        with torch.cuda.stream(self.tail):
-            self.tail.wait_event(ev_rpn)
-            rois, roi_scores = self.engine.propose(st)
-            ev_prop = torch.cuda.Event()
-            ev_prop.record(self.tail)
-        for t in (rois, st["seg_result"], st["pts_depth"], st["depth_norm"]):       # made on the tail stream, read by the RCNN stage on the feature stream
-            t.record_stream(main)
+        rois, roi_scores, ev_prop, rg = self._propose_on_tail(st, ev_rpn, main)
         done = self._finish_inflight()
-        self._inflight = (cur, st, rois, roi_scores, ev_prop, ch["side"], ch["geo"])
+        self._inflight = (cur, st, rois, roi_scores, ev_prop, ch["side"], ch["geo"], rg)
         return done
 
     def _advance_chains(self, todo, gate):
@@ -365,10 +377,10 @@ class PipelinedRunner:
         if self._inflight is None:
             return None
         main = torch.cuda.current_stream(self.device)
-        cur, st, rois, roi_scores, ev_prop, side, geo = self._inflight
+        cur, st, rois, roi_scores, ev_prop, side, geo, rg = self._inflight
         self._inflight = None
         main.wait_event(ev_prop)
-        out = self.engine.rcnn_stage(st, rois)
+        out = self.engine.rcnn_stage(st, rois) if rg is None else self.engine.rcnn_features(rg)
         ev_rcnn = torch.cuda.Event()
         ev_rcnn.record(main)
         if side is not None:
@@ -384,6 +396,7 @@ class PipelinedRunner:
             det.update(ret)
             ready = torch.cuda.Event()
             ready.record(self.tail)
+        del rg                                        # tail-stream memory, read on the feature stream up to ev_rcnn: the tail stream waits for it above
         det["ready"] = ready
         det["stream"] = self.tail
         return det

@@ -557,9 +557,18 @@ class FastPointRCNN:
 
     @torch.no_grad()
     def rcnn_stage(self, st, rois):
+        return self.rcnn_features(self.rcnn_geometry(st, rois))
+
+    @torch.no_grad()
+    def rcnn_geometry(self, st, rois):
+        """RoI pooling + the sampling / grouping geometry of the RCNN stage (no MLP): may run on the proposal stream."""
         self.point_aux(st)
-        return self._rcnn(st["backbone_xyz"], st["rpn_features"], st["seg_result"], st["pts_depth"], rois, depth_norm=st["depth_norm"],
-                          groups=st.get("groups"))
+        return self._rcnn_geometry(st["backbone_xyz"], st["rpn_features"], st["seg_result"], st["pts_depth"], rois,
+                                   depth_norm=st["depth_norm"], groups=st.get("groups"))
+
+    @torch.no_grad()
+    def rcnn_features(self, rg):
+        return self._rcnn_features(rg)
 
     @torch.no_grad()
     def forward(self, pts_input, geo=None):
@@ -591,11 +600,20 @@ class FastPointRCNN:
         return self._pm_ok
 
     def _rcnn(self, xyz, feats, seg_mask, pts_depth, rois, depth_norm=None, groups=None):
+        return self._rcnn_features(self._rcnn_geometry(xyz, feats, seg_mask, pts_depth, rois, depth_norm=depth_norm, groups=groups))
+
+    def _rcnn_geometry(self, xyz, feats, seg_mask, pts_depth, rois, depth_norm=None, groups=None):
+        """Everything of the RCNN stage (rcnn_net.py:127-185) that needs no MLP result: RoI pooling into the canonical row layout,
+        then per SA level sampling, ball query and the distinct-row lists.  All of it hangs on the RoIs and on coordinates only
+        (the pooled FEATURES are copied, never computed on), so the pipelined runner launches it on the proposal stream right
+        behind the proposal layer -- a chain of ten latency-bound launches, 0.3 ms when it sat on the feature stream in front of
+        the MFMA kernels (profiles/r02_bench_step_kernel_stats.md).  -> state for `_rcnn_features`."""
         R = self.cfg.RCNN
         if not (R.ROI_SAMPLE_JIT and R.USE_RPN_FEATURES and not R.USE_INTENSITY):
             raise NotImplementedError("fast path covers the default.yaml RCNN input configuration")
         nin = self.model.rcnn_net.rcnn_input_channel                           # xyz + mask + depth = 5
         rp = roipool3d_utils.roipool3d_cuda
+        ext = pu.pointnet2
         C = feats.shape[2]
         pooled_cnt = None
         if (USE_ROIPOOL_CANONICAL and has_entry(rp, "forward_canonical") and R.USE_DEPTH and nin == 5 and C % 4 == 0):
@@ -627,55 +645,40 @@ class FastPointRCNN:
             a = rows.new_zeros((rows.shape[0], _round4(nin)))
             a[:, :nin] = rows[:, :nin]
             rpn_part = rows[:, nin:]
-        P_pre = None
-        sa1 = self.rcnn_sa[0]
-        ext_mod = pu.pointnet2
-        if USE_RCNN_POINT_MLP and W == 136 and rows.shape[0] % 64 == 0 and self._point_mlp_ok():
-            # xyz_up (2 layers) + concat + merge_down + the per-point part of SA1's layer 1: tiled MFMA layer kernels
-            (wu1, bu1, _), (wu2, bu2, _) = self.xyz_up.layers
-            (wm, bm, _), = self.merge_down.layers
-            wf, _, b1 = sa1[3].split
-            P_pre = torch.empty((rows.shape[0], 128), dtype=torch.float32, device=rows.device)
-            tiles = None if pooled_cnt is None else ext_mod.pooled_tiles_wrapper(pooled_cnt.view(-1), P)
-            ext_mod.rcnn_point_mlp_wrapper(rows, 8, wu1, bu1, wu2, bu2, wm, bm, wf, b1, None, None, P_pre, tiles)   # only P is needed
-            P_pre = P_pre.view(B * M, P, 128)
-            l_feat = [None]
-        else:
-            xyz_feature = self.xyz_up(a)                                       # (rows, 128)
-            merged = self.merge_down(torch.cat((xyz_feature, rpn_part), dim=1))
-            l_feat = [merged.view(B * M, P, -1)]
-        l_xyz = [flat[:, :, 0:3].contiguous()]
-        ext = pu.pointnet2
-        for npoint, radius, ns, mlp, cin in self.rcnn_sa:
-            cur_xyz, cur_feat = l_xyz[-1], l_feat[-1]
-            Bc, n = cur_xyz.shape[0], cur_xyz.shape[1]
-            cout = mlp.layers[-1][0].shape[1]
+        point_mlp = bool(USE_RCNN_POINT_MLP and W == 136 and rows.shape[0] % 64 == 0 and self._point_mlp_ok())
+        tiles = ext.pooled_tiles_wrapper(pooled_cnt.view(-1), P) if (point_mlp and pooled_cnt is not None) else None
+        cur_xyz = flat[:, :, 0:3].contiguous()
+        levels = []
+        for k, (npoint, radius, ns, mlp, cin) in enumerate(self.rcnn_sa):
+            lev = {"xyz": cur_xyz, "new_xyz": None, "idx": None, "pack": None}
             if npoint is not None:
+                Bc, n = cur_xyz.shape[0], cur_xyz.shape[1]
                 if n <= 1024 and has_entry(ext, "fps_new_xyz_wrapper"):
                     _, new_xyz = ext.fps_new_xyz_wrapper(cur_xyz, npoint)      # sampling + the centres' coordinates, one launch
                 else:
                     sel = pu.furthest_point_sample(cur_xyz, npoint)
                     new_xyz = torch.gather(cur_xyz, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
-                first = len(l_feat) == 1
-                if first and pooled_cnt is not None and P_pre is not None and has_entry(ext, "ball_query_limit_wrapper"):
+                dedup = k == 0 and pooled_cnt is not None and point_mlp
+                if dedup and has_entry(ext, "ball_query_limit_wrapper"):
                     # pooled rows k >= count are copies of row k % count: scanning the distinct rows finds every ball's points
                     # (the row list below drops the copies anyway); a RoI holds ~60 of its 512 rows at this scene size
                     idx = torch.empty((Bc, npoint, ns), dtype=torch.int32, device=cur_xyz.device)     # every slot is written
                     ext.ball_query_limit_wrapper(Bc, n, npoint, radius, ns, new_xyz, cur_xyz, pooled_cnt.view(-1), idx)
                 else:
                     idx = pu.ball_query(radius, ns, cur_xyz, new_xyz)
-                out = torch.empty((Bc, npoint, cout), dtype=torch.float32, device=cur_xyz.device)
-                pack = None
-                if first and pooled_cnt is not None and P_pre is not None:
-                    pack = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, pooled_cnt.view(-1))       # copies of pooled points are dropped too
-                self._sa_scale(cur_xyz, new_xyz, cur_feat, idx, mlp, cin, out, 0, P_pre=P_pre if first else None, pack=pack)
-                l_xyz.append(new_xyz)
+                if dedup:
+                    lev["pack"] = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, pooled_cnt.view(-1))   # copies of pooled points are dropped too
+                elif USE_PACKED and (mlp.packed is not None or mlp.wide is not None) and has_entry(ext, "ball_pack_wrapper"):
+                    lev["pack"] = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz)
+                lev["new_xyz"], lev["idx"] = new_xyz, idx
+                cur_xyz = new_xyz
             elif USE_PACKED and (mlp.packed is not None or mlp.wide is not None):
                 # GroupAll (pointnet2_utils.py:267-288): ONE group holding all n points, no centre subtraction == a ball
                 # query answer 0..n-1 around the origin; same packed kernels as the other levels
                 # f clouds side by side form one "cloud" with f centres (no centre is subtracted, so cloud borders mean nothing
                 # here): n = 32 points per RoI would leave every 64-row MFMA tile half full of copies.  The index tensor and the
                 # origins are constants of the shape (cached); the row list holds coordinates and is built per batch.
+                Bc, n = cur_xyz.shape[0], cur_xyz.shape[1]
                 f = 1
                 while 2 * f * n <= 64 and Bc % (2 * f) == 0:
                     f *= 2
@@ -685,12 +688,48 @@ class FastPointRCNN:
                     self._groupall = (key, ga_idx, torch.zeros((Bc // f, f, 3), dtype=torch.float32, device=cur_xyz.device))
                 _, ga_idx, origin = self._groupall
                 xyz_v = cur_xyz.view(Bc // f, f * n, 3)
-                feat_v = cur_feat.view(Bc // f, f * n, cur_feat.shape[2])
+                lev.update({"xyz": xyz_v, "new_xyz": origin, "idx": ga_idx, "pack": ext.ball_pack_wrapper(ga_idx, xyz_v, origin), "f": f})
+                cur_xyz = None
+            levels.append(lev)
+        return {"B": B, "M": M, "P": P, "W": W, "rows": rows, "a": a, "rpn_part": rpn_part, "pooled": pooled, "pooled_cnt": pooled_cnt,
+                "point_mlp": point_mlp, "tiles": tiles, "levels": levels}
+
+    def _rcnn_features(self, rg):
+        """The MLPs of the RCNN stage over the rows and row lists of `_rcnn_geometry`: xyz_up + merge_down + SA levels + heads."""
+        B, M, P = rg["B"], rg["M"], rg["P"]
+        rows = rg["rows"]
+        P_pre = None
+        sa1 = self.rcnn_sa[0]
+        ext = pu.pointnet2
+        if rg["point_mlp"]:
+            # xyz_up (2 layers) + concat + merge_down + the per-point part of SA1's layer 1: tiled MFMA layer kernels
+            (wu1, bu1, _), (wu2, bu2, _) = self.xyz_up.layers
+            (wm, bm, _), = self.merge_down.layers
+            wf, _, b1 = sa1[3].split
+            P_pre = torch.empty((rows.shape[0], 128), dtype=torch.float32, device=rows.device)
+            ext.rcnn_point_mlp_wrapper(rows, 8, wu1, bu1, wu2, bu2, wm, bm, wf, b1, None, None, P_pre, rg["tiles"])   # only P is needed
+            P_pre = P_pre.view(B * M, P, 128)
+            l_feat = [None]
+        else:
+            xyz_feature = self.xyz_up(rg["a"])                                 # (rows, 128)
+            merged = self.merge_down(torch.cat((xyz_feature, rg["rpn_part"]), dim=1))
+            l_feat = [merged.view(B * M, P, -1)]
+        for (npoint, radius, ns, mlp, cin), lev in zip(self.rcnn_sa, rg["levels"]):
+            cur_xyz, cur_feat = lev["xyz"], l_feat[-1]
+            cout = mlp.layers[-1][0].shape[1]
+            first = len(l_feat) == 1
+            if npoint is not None:
+                Bc = cur_xyz.shape[0]
+                out = torch.empty((Bc, npoint, cout), dtype=torch.float32, device=cur_xyz.device)
+                self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, lev["idx"], mlp, cin, out, 0, P_pre=P_pre if first else None, pack=lev["pack"])
+            elif lev["pack"] is not None:                                       # GroupAll over f RoIs per "cloud" (see _rcnn_geometry)
+                f = lev["f"]
+                Bc = cur_xyz.shape[0] * f
+                feat_v = cur_feat.view(Bc // f, cur_xyz.shape[1], cur_feat.shape[2])
                 out = torch.empty((Bc, 1, cout), dtype=torch.float32, device=cur_xyz.device)
-                self._sa_scale(xyz_v, origin, feat_v, ga_idx, mlp, cin, out.view(Bc // f, f, cout), 0,
-                               pack=ext.ball_pack_wrapper(ga_idx, xyz_v, origin), dense=True)
-                l_xyz.append(None)
+                self._sa_scale(cur_xyz, lev["new_xyz"], feat_v, lev["idx"], mlp, cin, out.view(Bc // f, f, cout), 0, pack=lev["pack"], dense=True)
             else:                                                               # GroupAll: one group of n points
+                Bc, n = cur_xyz.shape[0], cur_xyz.shape[1]
                 c4 = _round4(cin)
                 g = cur_feat.new_zeros((Bc, n, c4 + 4))
                 g[:, :, :cin] = cur_feat
@@ -698,7 +737,6 @@ class FastPointRCNN:
                 y = mlp(g.view(Bc * n, c4 + 4))
                 out = torch.empty((Bc, 1, cout), dtype=torch.float32, device=cur_xyz.device)
                 ext.maxpool_pm_wrapper(y, n, out, 0)
-                l_xyz.append(None)
             l_feat.append(out)
         top = l_feat[-1].view(l_feat[-1].shape[0], -1)                         # (B*M, 512)
         kp = self.rcnn_cls.layers[0][0].shape[0]
