@@ -139,7 +139,7 @@ def _runner_streams(device, n_sides, prio):
     key = (str(device), prio)
     have = _RUNNER_STREAMS.setdefault(key, {"tail": None, "sides": []})
     if have["tail"] is None:
-        have["tail"] = torch.cuda.Stream(device)
+        have["tail"] = torch.cuda.Stream(device, priority=int(os.environ.get("PRCNN_TAIL_PRIORITY", "0")))
     while len(have["sides"]) < n_sides:
         have["sides"].append(torch.cuda.Stream(device, priority=prio))
     return have["tail"], have["sides"][:n_sides]

@@ -23,6 +23,7 @@ def wrap(obj, name, tag):
         log.append((tag, a0, a1)); return r
     setattr(obj, name, w)
 wrap(eng, "rpn_stage", "rpn"); wrap(eng, "rcnn_stage", "rcnn"); wrap(eng, "propose", "proposals")
+wrap(eng, "rcnn_geometry", "rcnn_geo"); wrap(eng, "rcnn_features", "rcnn")
 wrap(eng, "geometry_begin", "geo_begin"); wrap(eng, "geometry_finish", "geo_finish"); wrap(E, "postprocess", "final")
 def loop(n):
     for i in range(n):
