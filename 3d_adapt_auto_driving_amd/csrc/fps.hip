@@ -72,16 +72,36 @@ __device__ __forceinline__ void wave_argmax(float &v, uint32_t &key)
 // ---- two-pass arg-max: first the maximum VALUE (one v_max_f32 per candidate, one per DPP step), then the smallest key
 // among the candidates that hold it (compare + select + v_min_u32).  Same total order as take_if_better -- larger value
 // first, ties to the smaller key -- with a third of the instructions and much shorter dependency chains.
+// The DPP permutation rides ON the max / min instruction (v_max_f32_dpp): one instruction per butterfly step.  Written as
+// update_dpp + fmaxf the compiler emits v_mov, v_mov_dpp, a canonicalising v_max and the v_max -- 20 instructions for the four
+// steps of a reduction that sits on the critical path of every FPS iteration.  (s_nop 1: a DPP operand written by the
+// previous VALU instruction needs two wait states; the hazard recogniser does not look into inline assembly.)
+#define PRCNN_DPP_OP(OP, TY, CTRL_TEXT)                                                                                       \
+    asm("s_nop 1\n\t" OP " %0, %1, %1 " CTRL_TEXT " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v))
 template <int CTRL>
 __device__ __forceinline__ float dpp_max(float v)
 {
-    return fmaxf(v, __int_as_float(dpp_mov<CTRL>(__float_as_int(v))));
+    float r;
+    if constexpr (CTRL == 0xB1) PRCNN_DPP_OP("v_max_f32_dpp", float, "quad_perm:[1,0,3,2]");
+    else if constexpr (CTRL == 0x4E) PRCNN_DPP_OP("v_max_f32_dpp", float, "quad_perm:[2,3,0,1]");
+    else if constexpr (CTRL == 0x141) PRCNN_DPP_OP("v_max_f32_dpp", float, "row_half_mirror");
+    else if constexpr (CTRL == 0x140) PRCNN_DPP_OP("v_max_f32_dpp", float, "row_mirror");
+    else r = fmaxf(v, __int_as_float(dpp_mov<CTRL>(__float_as_int(v))));
+    return r;
 }
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_min(uint32_t v)
 {
-    const uint32_t o = (uint32_t)dpp_mov<CTRL>((int)v);
-    return o < v ? o : v;
+    uint32_t r;
+    if constexpr (CTRL == 0xB1) PRCNN_DPP_OP("v_min_u32_dpp", uint32_t, "quad_perm:[1,0,3,2]");
+    else if constexpr (CTRL == 0x4E) PRCNN_DPP_OP("v_min_u32_dpp", uint32_t, "quad_perm:[2,3,0,1]");
+    else if constexpr (CTRL == 0x141) PRCNN_DPP_OP("v_min_u32_dpp", uint32_t, "row_half_mirror");
+    else if constexpr (CTRL == 0x140) PRCNN_DPP_OP("v_min_u32_dpp", uint32_t, "row_mirror");
+    else {
+        const uint32_t o = (uint32_t)dpp_mov<CTRL>((int)v);
+        r = o < v ? o : v;
+    }
+    return r;
 }
 __device__ __forceinline__ float wave_max_f32(float v)        // wave-uniform result
 {
