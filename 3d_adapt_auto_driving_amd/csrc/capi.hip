@@ -28,6 +28,12 @@ int check_launch(const char *what)
     return PRCNN_OK;
 }
 
+int mfma_grid_cap()
+{
+    static const int cap = [] { const char *e = getenv("PRCNN_MFMA_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    return cap;
+}
+
 int current_device()
 {
     int dev = 0;

@@ -38,6 +38,9 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Workgroups of a persistent (ticket-drawing) MFMA launch: PRCNN_MFMA_GRID, default in capi.hip
+int mfma_grid_cap();
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // (a-b)^2 summed left to right, one rounding per operation (no fma): the distance form of

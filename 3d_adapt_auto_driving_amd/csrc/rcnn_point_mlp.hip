@@ -312,7 +312,7 @@ extern "C" int prcnn_rcnn_point_mlp(long r, int ld, int fcol, const float *rows,
         PRCNN_REQUIRE((((uintptr_t)wu2 | (uintptr_t)wm | (uintptr_t)wp) & 15) == 0, "rcnn_point_mlp: 16-byte alignment required");
         unsigned int *tk = next_ticket(st);
         if (!tk) { set_error("rcnn_point_mlp: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
-        const long grid = tiles < 512 ? tiles : 512;
+        const long grid = tiles < mfma_grid_cap() ? tiles : mfma_grid_cap();
         hipLaunchKernelGGL(rcnn_entrance_kernel, dim3((unsigned)grid), dim3(256), 0, st, tiles, rows, ld, fcol, (const float4 *)wu1,
                            (const float4 *)bu1, wu2, bu2, wm, bm, wp, bp, p, tk, tilemap, ntiles);
         return check_launch("rcnn_point_mlp(fused)");

@@ -232,7 +232,7 @@ extern "C" int prcnn_rpn_tail(int b, int n, int m, const float *known, const int
     a.ticket = next_ticket((hipStream_t)stream);
     if (!a.ticket) { set_error("rpn_tail: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
     const long tiles = (rows + RT_ROWS - 1) / RT_ROWS;
-    const long grid = tiles < 512 ? tiles : 512;           // gfx950: 256 CUs x 2 resident workgroups
+    const long grid = tiles < mfma_grid_cap() ? tiles : mfma_grid_cap();           // gfx950: 256 CUs x 2 resident workgroups
     hipLaunchKernelGGL(rpn_tail_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("rpn_tail");
 }

@@ -257,7 +257,7 @@ extern "C" int prcnn_sa_wide_fused(int b, int n, int m, int c1, int c2, int c3, 
     a.ticket = next_ticket(st);
     if (!a.ticket) { set_error("sa_wide_fused: cannot set up the unit ticket"); return PRCNN_ELAUNCH; }
     const long units = 2 * max_tiles;
-    const long grid = units < 512 ? units : 512;
+    const long grid = units < mfma_grid_cap() ? units : mfma_grid_cap();
     hipLaunchKernelGGL(sa_wide_fused_kernel, dim3((unsigned)grid), dim3(256), lds, st, a);
     return check_launch("sa_wide_fused");
 }
