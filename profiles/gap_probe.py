@@ -10,7 +10,7 @@ batches = [torch.from_numpy(S.scenes(8, 16384, seed0=s * 8)).to(dev) for s in ra
 runner = E.PipelinedRunner(model, cfg, dev, **({'depth': int(os.environ['GAP_DEPTH'])} if os.environ.get('GAP_DEPTH') else {}))
 eng = runner.engine
 log = []
-real_rpn, real_rcnn = eng.rpn_stage, eng.rcnn_stage
+real_rpn, real_rcnn = eng.rpn_stage, eng.rcnn_features
 if os.environ.get("GAP_USER_MAIN") == "1":
     torch.cuda.set_stream(torch.cuda.Stream(dev))
 main = torch.cuda.current_stream(dev)
@@ -34,7 +34,7 @@ def rcnn(*a, **k):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     t = time.perf_counter(); e0.record(main); r = real_rcnn(*a, **k); e1.record(main)
     log.append(("rcnn", e0, e1, t, [])); return r
-eng.rpn_stage, eng.rcnn_stage = rpn, rcnn
+eng.rpn_stage, eng.rcnn_features = rpn, rcnn
 if os.environ.get("GAP_NO_FINAL") == "1":
     E.postprocess = lambda cfg, ret, B: {}
 def loop(n):
