@@ -64,6 +64,7 @@ SIGNATURES = {
     "prcnn_packed_layer_segmax": [_I, _I, C.c_long, _I, _I, _P, C.c_long, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "prcnn_maxpool_pm": [C.c_long, _I, _I, _P, _P, _I, _I, _P],
     "prcnn_three_interpolate_pm": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P],
+    "prcnn_three_interpolate_cat_pm": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     "prcnn_boxes_overlap_bev": [_I, _P, _I, _P, _P, _P],
     "prcnn_boxes_iou_bev": [_I, _P, _I, _P, _P, _P],
     "prcnn_nms": [_I, _P, _P, _F, _P],

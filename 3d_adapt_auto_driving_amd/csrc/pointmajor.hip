@@ -130,6 +130,36 @@ __global__ __launch_bounds__(256) void three_interpolate_pm_kernel(
     }
 }
 
+// FP module input in ONE pass (pointnet2_modules.py:139-151: interpolate, then torch.cat with the skip features):
+// out[b][p] = [ w0 f[i0] + w1 f[i1] + w2 f[i2]  (c4 float4s, left to right, no fma) | skip[b][p] (s4 float4s) ]
+__global__ __launch_bounds__(256) void three_interpolate_cat_pm_kernel(
+    int c4, int s4, int m, int n, const float4 *__restrict__ feat /* (b,m,c) */, const int *__restrict__ idx,
+    const float *__restrict__ weight, const float4 *__restrict__ skip /* (b,n,s) */, float4 *__restrict__ out /* (b,n,c+s) */)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int b = blockIdx.y;
+    const int row4 = c4 + s4;
+    const long total = (long)n * row4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int p = (int)(e / row4);
+        const int j = (int)(e - (long)p * row4);
+        const long pt = (long)b * n + p;
+        if (j >= c4) {
+            out[pt * row4 + j] = skip[pt * s4 + (j - c4)];
+            continue;
+        }
+        const int *ix = idx + pt * 3;
+        const float *w = weight + pt * 3;
+        const f32x4 *f = reinterpret_cast<const f32x4 *>(feat);
+        const f32x4 f0 = f[((long)b * m + ix[0]) * c4 + j];
+        const f32x4 f1 = f[((long)b * m + ix[1]) * c4 + j];
+        const f32x4 f2 = f[((long)b * m + ix[2]) * c4 + j];
+        // one rounding per operation (the file is compiled with -ffp-contract=off): v_pk_mul_f32 / v_pk_add_f32
+        const f32x4 v = (w[0] * f0 + w[1] * f1) + w[2] * f2;
+        reinterpret_cast<f32x4 *>(out)[pt * row4 + j] = v;
+    }
+}
+
 static int grid_cap(long items)
 {
     long g = (items + 255) / 256;
@@ -201,4 +231,19 @@ extern "C" int prcnn_three_interpolate_pm(int b, int c, int m, int n, const floa
     hipLaunchKernelGGL(three_interpolate_pm_kernel, grid, dim3(256), 0, (hipStream_t)stream, c / 4, m, n,
                        (const float4 *)features, idx, weight, out, out_stride, out_col);
     return check_launch("three_interpolate_pm");
+}
+
+// features (b, m, c) point-major, idx/weight (b, n, 3), skip (b, n, c_skip) -> out (b, n, c + c_skip) = [interpolated | skip]
+extern "C" int prcnn_three_interpolate_cat_pm(int b, int c, int m, int n, const float *features, const int *idx,
+                                              const float *weight, const float *skip, int c_skip, float *out, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0 && c_skip >= 0, "three_interpolate_cat_pm: bad sizes");
+    PRCNN_REQUIRE((c & 3) == 0 && (c_skip & 3) == 0 && b <= 65535, "three_interpolate_cat_pm: widths must be multiples of 4, batch <= 65535");
+    if (b == 0 || n == 0 || c + c_skip == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(features && idx && weight && out && (skip || c_skip == 0), "three_interpolate_cat_pm: null pointer");
+    PRCNN_REQUIRE((((uintptr_t)features | (uintptr_t)out | (uintptr_t)skip) & 15) == 0, "three_interpolate_cat_pm: 16-byte alignment required");
+    dim3 grid(grid_cap((long)n * ((c + c_skip) / 4)), b);
+    hipLaunchKernelGGL(three_interpolate_cat_pm_kernel, grid, dim3(256), 0, (hipStream_t)stream, c / 4, c_skip / 4, m, n,
+                       (const float4 *)features, idx, weight, (const float4 *)skip, (float4 *)out);
+    return check_launch("three_interpolate_cat_pm");
 }

@@ -167,6 +167,18 @@ def three_interpolate_pm_wrapper(features, idx, weight, out, out_col):
     return out
 
 
+def three_interpolate_cat_pm_wrapper(features, idx, weight, skip, out):
+    """features (b,m,c), idx/weight (b,n,3), skip (b,n,c_skip) -> out (b,n,c+c_skip) = [interpolated | skip]: the input of a
+    feature-propagation module in one launch."""
+    _chk(torch.float32, features, weight, skip, out); _chk(torch.int32, idx)
+    b, m, c = features.shape
+    if out.size(-1) != c + skip.size(-1):
+        raise ValueError("three_interpolate_cat_pm: out must be (b, n, c + c_skip)")
+    _lib.call("prcnn_three_interpolate_cat_pm", b, c, m, idx.size(1), features.data_ptr(), idx.data_ptr(), weight.data_ptr(),
+              skip.data_ptr(), skip.size(-1), out.data_ptr(), _lib.current_stream(features))
+    return out
+
+
 def gather_affine_relu_pm_wrapper(new_xyz, xyz, P, wxyz, idx, out):
     """P (b,n,cout), wxyz (3,cout), idx (b,m,ns) -> out (b, m*ns, cout) = relu(P[idx] + wxyz.(xyz[idx]-centre))."""
     _chk(torch.float32, new_xyz, xyz, P, wxyz, out); _chk(torch.int32, idx)

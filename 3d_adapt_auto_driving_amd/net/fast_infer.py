@@ -500,9 +500,12 @@ class FastPointRCNN:
             c2 = known_feat.shape[2]
             c1 = 0 if skip is None else skip.shape[2]
             buf = torch.empty((B, n, c2 + c1), dtype=torch.float32, device=xyz.device)
-            ext.three_interpolate_pm_wrapper(known_feat, idx, weight, buf, 0)
-            if c1:
-                buf[:, :, c2:] = skip
+            if c1 and c1 % 4 == 0 and c2 % 4 == 0 and has_entry(ext, "three_interpolate_cat_pm_wrapper"):
+                ext.three_interpolate_cat_pm_wrapper(known_feat, idx, weight, skip, buf)      # interpolation + concat, one launch
+            else:
+                ext.three_interpolate_pm_wrapper(known_feat, idx, weight, buf, 0)
+                if c1:
+                    buf[:, :, c2:] = skip
             l_feat[k] = self.fp[k](buf.view(B * n, c2 + c1)).view(B, n, -1)
         return (l_feat[0], None) if fuse_tail else l_feat[0]   # (B, N, 128) point-major (zero-padded to 128s under PAD128)
 

@@ -274,6 +274,11 @@ int prcnn_maxpool_pm(long rows_out, int ns, int c, const float *in, float *out, 
  * column slice of out (b, n, out_stride). */
 int prcnn_three_interpolate_pm(int b, int c, int m, int n, const float *features, const int *idx,
                                const float *weight, float *out, int out_stride, int out_col, void *stream);
+/* The input of a feature-propagation module in one pass (pointnet2_modules.py:139-151: three_interpolate, then torch.cat with
+ * the skip features): out (b, n, c + c_skip) = [interpolated (same arithmetic as above) | skip (b, n, c_skip)];
+ * c, c_skip multiples of 4, pointers 16-byte aligned. */
+int prcnn_three_interpolate_cat_pm(int b, int c, int m, int n, const float *features, const int *idx, const float *weight,
+                                   const float *skip, int c_skip, float *out, void *stream);
 
 /* ---- iou3d_cuda ---------------------------------------------------------------------- */
 

@@ -286,6 +286,13 @@ class pointnet2_cpu:
         return out
 
     @staticmethod
+    def three_interpolate_cat_pm_wrapper(features, idx, weight, skip, out):
+        c = features.shape[2]
+        pointnet2_cpu.three_interpolate_pm_wrapper(features, idx, weight, out, 0)
+        out[:, :, c:] = skip
+        return out
+
+    @staticmethod
     def three_interpolate_pm_wrapper(features, idx, weight, out, out_col):
         b, m, c = features.shape
         n = idx.size(1)

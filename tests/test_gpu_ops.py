@@ -394,6 +394,14 @@ def test_point_major_kernels(ext, oracle):
     buf = torch.zeros((2, 777, 40), device=DEV)
     ext.pointnet2.three_interpolate_pm_wrapper(T(np.ascontiguousarray(known.transpose(0, 2, 1))), T(i3), T(w3), buf, 8)
     assert np.array_equal(buf.cpu().numpy()[:, :, 8:32], oracle.three_interpolate(known, i3, w3).transpose(0, 2, 1))
+    # the FP module's whole input in one launch: [interpolated | skip features]; ragged row count, several widths
+    for c_skip in (4, 96, 256):
+        skip = rng.standard_normal((2, 777, c_skip)).astype(np.float32)
+        cat = torch.full((2, 777, 24 + c_skip), 7.0, device=DEV)
+        ext.pointnet2.three_interpolate_cat_pm_wrapper(T(np.ascontiguousarray(known.transpose(0, 2, 1))), T(i3), T(w3), T(skip), cat)
+        got = cat.cpu().numpy()
+        assert np.array_equal(got[:, :, :24], oracle.three_interpolate(known, i3, w3).transpose(0, 2, 1))
+        assert np.array_equal(got[:, :, 24:], skip)
 
 
 def test_gather_affine_relu_pm(ext):
