@@ -185,7 +185,7 @@ def roofline_rpn_tail(dev, cfg, model, reps=20):
     achieved = flops / (ms * 1e-3) / 1e12
     alg_bytes = known.numel() * 4 + rows * 24 + rows * (128 + 1 + tw["n_reg"]) * 4
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": 328.59e6,
+            "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": 325.87e6,
             "traffic_source": "profiles/r02_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over the product step)",
             "kernel": "rpn_tail_kernel (prcnn_rpn_tail)", "launch_ms": round(ms, 4), "algorithmic_flops_per_launch": flops,
             "algorithmic_bytes_per_launch": alg_bytes,
@@ -228,7 +228,7 @@ def roofline_roipool(dev, cfg, model, reps=20):
     nbytes = B * (NPOINTS * (12 + 4 * C + 8) + M * 28 + M * 8) + full_rows * (8 + C) * 4 + (B * M * S - full_rows) * 32
     achieved = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": 82.69e6, "traffic_source": "profiles/r02_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over the product step)",
+            "traffic": 82.65e6, "traffic_source": "profiles/r02_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over the product step)",
             "kernel": "roipool3d_canonical_kernel (prcnn_roipool3d_canonical, product form)", "launch_ms": round(ms, 4),
             "algorithmic_bytes_per_launch": nbytes, "mean_points_per_roi": round(float(cnt.float().mean()), 1),
             "shape": {"B": B, "N": NPOINTS, "rois": M, "sampled": S, "row_floats": 8 + C}}
