@@ -16,7 +16,7 @@
 //   score          32 lanes per row, lane l sums k = l, l+32, l+64, l+96 as one fma chain, xor butterfly 16..1, + bias
 //                                                                              (csrc/packed_layer.hip rows_dot_kernel)
 //
-// One workgroup = 4 waves = a 64-row tile at a time, persistent over tiles (drawn from a ticket counter), 2 workgroups per CU.  Wave w owns
+// One workgroup = 4 waves = a 64-row tile at a time, persistent over tiles (drawn from a ticket counter), ONE workgroup per CU.  Wave w owns
 // output columns 32w .. 32w+31 of every layer; its 128 x 32 weight slice of the NEXT layer is fetched into registers while the
 // MFMAs of the current one run (two register sets, six panel stages per tile, so the roles repeat tile after tile).
 #include <hip/hip_runtime.h>
@@ -51,10 +51,16 @@ struct RpnTailArgs {
     unsigned int *ticket;           // tile counter of this launch (zero on entry)
 };
 
-__global__ __launch_bounds__(256, 2) void rpn_tail_kernel(const RpnTailArgs a)
+__global__ __launch_bounds__(256, 1) void rpn_tail_kernel(const RpnTailArgs a)
 {
+    // T0 / T1: the working tiles of the layer chain; X0 / X1: the two 128-column panels of the interpolated input tile.  The input
+    // of tile t+1 is built WHILE tile t is in its last four stages, a few instructions behind every k-group's first MFMAs
+    // (RT_STAGE_HOOK): as a phase of its own the interpolation was 6.6k of a 69k-cycle tile, and a second workgroup on the CU
+    // does not hide it (profiles/r02_stage_stamps.md) -- so ONE workgroup per CU, four tiles of LDS, up to 512 registers.
     __shared__ float T0[RT_ROWS * RT_LD];
     __shared__ float T1[RT_ROWS * RT_LD];
+    __shared__ float X0[RT_ROWS * RT_LD];
+    __shared__ float X1[RT_ROWS * RT_LD];
     __shared__ unsigned int slot[2];
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,6 +74,7 @@ __global__ __launch_bounds__(256, 2) void rpn_tail_kernel(const RpnTailArgs a)
                 biasr1 = a.bcat[384 + 32 * w + j], biasr2 = a.bcat[512 + 32 * w + j];
 
     // neighbour indices / weights / cloud of the 16 rows this wave interpolates in tile `tt`: one coalesced load each
+    // (lane l < 48 holds element l of the 16 x 3 block, lane 3q the cloud of row q)
     int nx_i, nx_cloud;
     float nx_w;
 #define RT_FETCH_IDX(tt)                                                                                  \
@@ -79,130 +86,146 @@ __global__ __launch_bounds__(256, 2) void rpn_tail_kernel(const RpnTailArgs a)
         nx_w = lane < 48 ? a.weight[el] : 0.f;                                                            \
         nx_cloud = (int)(ge / a.n);                                                                       \
     }
+    // one round of the interpolation = RT_IROWS rows of this wave: a lane owns one float4 of the 256-wide row, so every
+    // neighbour row is one coalesced 1 KB read; ISSUE sends the 3 x RT_IROWS gathers, ROW finishes one row into X0 | X1
+    f32x4 f[RT_IROWS][3];
+#define RT_INTERP_ISSUE(rr)                                                                               \
+    _Pragma("unroll") for (int q = 0; q < RT_IROWS; ++q) {                                                \
+        const long cloud = __builtin_amdgcn_readlane(nx_cloud, 3 * ((rr) + q));                           \
+        _Pragma("unroll") for (int e = 0; e < 3; ++e) {                                                   \
+            const int i = __builtin_amdgcn_readlane(nx_i, 3 * ((rr) + q) + e);                            \
+            f[q][e] = known4[(cloud * a.m + i) * 64 + lane];                                              \
+        }                                                                                                 \
+    }
+    // (w0 f0 + w1 f1) + w2 f2 per component, one rounding per operation (the file is compiled with -ffp-contract=off):
+    // v_pk_mul_f32 / v_pk_add_f32, two components per instruction
+#define RT_INTERP_ROW(rr, q)                                                                              \
+    {                                                                                                     \
+        const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nx_w), 3 * ((rr) + (q)))); \
+        const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nx_w), 3 * ((rr) + (q)) + 1)); \
+        const float w2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nx_w), 3 * ((rr) + (q)) + 2)); \
+        const f32x4 v = (w0 * f[q][0] + w1 * f[q][1]) + w2 * f[q][2];                                     \
+        float *dst = (lane < 32 ? X0 : X1) + (16 * w + (rr) + (q)) * RT_LD + 4 * (lane & 31);             \
+        *reinterpret_cast<f32x4 *>(dst) = v;                                                              \
+    }
+    // the side work of one stage: round rr of the NEXT tile's interpolation, gathers behind k-group 2 (the coalesced index /
+    // weight loads of RT_FETCH_IDX are a stage old by then), one row finished behind each of the k-groups 10 .. 10 + RT_IROWS - 1
+#define RT_SIDE(rr, g)                                                                                    \
+    if ((g) == 2) { RT_INTERP_ISSUE(rr) }                                                                 \
+    else if ((g) >= 10 && (g) < 10 + RT_IROWS) { RT_INTERP_ROW(rr, (g) - 10) }
+#define RT_SIDE0(g) RT_SIDE(0, g)
+#define RT_SIDE1(g) RT_SIDE(RT_IROWS, g)
+#define RT_SIDE2(g) RT_SIDE(2 * RT_IROWS, g)
+#define RT_SIDE3(g) RT_SIDE(3 * RT_IROWS, g)
+    f32x4 co[8];                                           // a tile's rows on their way out: LDS -> registers -> 512-byte rows
+#define RT_ROWS_OUT(g, TT, T, dst, ld, live)                                                              \
+    if ((g) == 1) {                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) co[i] = *reinterpret_cast<const f32x4 *>((T) + (r0 + 8 * i) * RT_LD + 4 * chunk); \
+    } else if ((g) == 3) {                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                               \
+            const unsigned int gr = (unsigned int)(TT) * RT_ROWS + r0 + 8 * i;                        \
+            if ((live) && gr < (unsigned int)a.rows) *reinterpret_cast<f32x4 *>((dst) + (gr * (unsigned int)(ld) + 4u * chunk)) = co[i]; \
+        }                                                                                             \
+    }
+    static_assert(RT_IROWS == 4, "four stages carry four rounds of four rows");
+
     // Tiles come from a ticket counter, not a static stride: the step runs this kernel next to other streams' kernels
     // (sampling chains hold 32 CUs for milliseconds), and a workgroup slowed down by a neighbour must not stretch the launch.
-    // The NEXT tile's ticket is drawn during the interpolation and published through LDS by the barrier that ends it.
-    if (tid == 0) slot[0] = atomicAdd(a.ticket, 1u);
+    if (tid == 0) { slot[0] = atomicAdd(a.ticket, 1u); }
     __syncthreads();
     long t = __builtin_amdgcn_readfirstlane((int)slot[0]);   // wave-uniform: tile arithmetic stays in scalar registers
-    RT_FETCH_IDX(t)
     float wa[64], wb[64];
     f32x16 acc0, acc1;
     RT_LOAD_W(wa, rs, 0)
-    for (unsigned int served = 0; t < tiles; ++served) {
-        // ---- interpolation: wave w builds rows 16w .. 16w+15 of the 64 x 256 input tile (columns 0-127 -> T0, 128-255 -> T1);
-        //      a lane owns one float4 of the row, so every neighbour row is one coalesced 1 KB read
-        {
-            // (the 16 rows' 48 neighbour indices and weights were fetched one tile ahead: lane l < 48 holds element l)
-            const int my_i = nx_i;
-            const float my_w = nx_w;
-            const int cloud_lane = nx_cloud;                   // lane 3q holds row q's cloud
+    if (t < tiles) {
+        // the first tile's input: the whole interpolation in front of its first stage (every later one rides on the previous tile)
+        RT_FETCH_IDX(t)
 #pragma unroll
-            for (int rr = 0; rr < 16; rr += RT_IROWS) {
-                f32x4 f[RT_IROWS][3];
+        for (int rr = 0; rr < 16; rr += RT_IROWS) {
+            RT_INTERP_ISSUE(rr)
 #pragma unroll
-                for (int q = 0; q < RT_IROWS; ++q) {
-                    const long cloud = __builtin_amdgcn_readlane(cloud_lane, 3 * (rr + q));
-#pragma unroll
-                    for (int e = 0; e < 3; ++e) {
-                        const int i = __builtin_amdgcn_readlane(my_i, 3 * (rr + q) + e);
-                        f[q][e] = known4[(cloud * a.m + i) * 64 + lane];
-                    }
-                }
-                // the next tile's ticket, drawn behind the first round of gathers (its round trip hides in theirs); the
-                // barrier that ends the interpolation publishes it
-                if (rr == 0 && tid == 0) slot[(served + 1) & 1] = atomicAdd(a.ticket, 1u);
-#pragma unroll
-                for (int q = 0; q < RT_IROWS; ++q) {
-                    const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), 3 * (rr + q)));
-                    const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), 3 * (rr + q) + 1));
-                    const float w2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), 3 * (rr + q) + 2));
-                    // (w0 f0 + w1 f1) + w2 f2 per component, one rounding per operation (the file is compiled with
-                    // -ffp-contract=off): v_pk_mul_f32 / v_pk_add_f32, two components per instruction
-                    const f32x4 v = (w0 * f[q][0] + w1 * f[q][1]) + w2 * f[q][2];
-                    float *dst = (lane < 32 ? T0 : T1) + (16 * w + rr + q) * RT_LD + 4 * (lane & 31);
-                    *reinterpret_cast<f32x4 *>(dst) = v;
-                }
-            }
+            for (int q = 0; q < RT_IROWS; ++q) RT_INTERP_ROW(rr, q)
         }
+    }
+    long tp = 0;                                               // the previous tile of this workgroup
+    bool last = false;
+    for (unsigned int served = 0; t < tiles; ++served) {
+        // the next tile's ticket: drawn now, published by the barrier below, read behind the first layer
+        if (tid == 0) slot[(served + 1) & 1] = atomicAdd(a.ticket, 1u);
         RT_VM_DRAIN                                            // (also: this tile's first panel, fetched during the last stage)
-        lds_barrier();
+        lds_barrier();                                         // X0 | X1 hold this tile's input
         // ---- FP layer 1, panel 0 (wa) while panel 1 (wb) comes in
-        RT_STAGE(T0, wa, wb, rs, 128, true)
+#define RT_REG_OUT(g) RT_ROWS_OUT(g, tp, T1, a.reg, a.n_reg, served > 0 && 4 * chunk < a.n_reg)
+        RT_STAGE_HOOK(X0, wa, wb, rs, 128, true, RT_REG_OUT)  // side: the previous tile's regression rows go out
         // ---- FP layer 1, panel 1 (wb) while layer 2 (wa) comes in
         RT_VM_DRAIN
-        RT_STAGE(T1, wb, wa, rs, 256, false)
-        lds_barrier();                                         // every wave has read both input panels
-        RT_EPILOGUE(T0, bias1, true)
-        lds_barrier();
-        // ---- FP layer 2 (wa) while cls layer 1 (wb) comes in; its output = the backbone features
-        RT_VM_DRAIN
-        RT_STAGE(T0, wa, wb, rs, 384, true)
-        RT_EPILOGUE(T1, bias2, true)
-        lds_barrier();
-        // ---- cls layer 1 (wb) while reg layer 1 (wa) comes in; the feature rows go out meanwhile
-        RT_VM_DRAIN
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = r0 + 8 * i;
-            const unsigned int g = (unsigned int)t * RT_ROWS + row;
-            if (g < (unsigned int)a.rows)
-                *reinterpret_cast<f32x4 *>(a.feats + (g * 128u + 4u * chunk)) = *reinterpret_cast<const f32x4 *>(T1 + row * RT_LD + 4 * chunk);
-        }
-        RT_STAGE(T1, wb, wa, rs, 512, true)
-        RT_EPILOGUE(T0, biasc, true)
-        lds_barrier();
-        // ---- score = cls layer 2 (a 128-long dot product per row), then reg layer 1 (wa) while reg layer 2 (wb) comes in
-        RT_VM_DRAIN
+        RT_STAGE(X1, wb, wa, rs, 256, false)
+        lds_barrier();                                         // every wave has read both input panels: X0 | X1 are free
         const long tn = __builtin_amdgcn_readfirstlane((int)slot[(served + 1) & 1]);
         RT_FETCH_IDX(tn)
-        {
-            // 8 rows per half-wave pass, the 8 passes side by side: 5 rounds of 8 independent lane exchanges instead of 8
-            // dependent chains of 5 (same additions per row, in the same order)
-            float sd[8];
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const float *ar = T0 + (r0 + 8 * p) * RT_LD + j;
-                float v = fmaf(ar[0], wd0, 0.f);
-                v = fmaf(ar[32], wd1, v);
-                v = fmaf(ar[64], wd2, v);
-                sd[p] = fmaf(ar[96], wd3, v);
-            }
-#pragma unroll
-            for (int d = 16; d >= 1; d >>= 1) {
-                float o[8];
-#pragma unroll
-                for (int p = 0; p < 8; ++p) o[p] = __shfl_xor(sd[p], d, 32);
-#pragma unroll
-                for (int p = 0; p < 8; ++p) sd[p] = __fadd_rn(sd[p], o[p]);
-            }
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const unsigned int g = (unsigned int)t * RT_ROWS + r0 + 8 * p;
-                if (j == 0 && g < (unsigned int)a.rows) a.cls[g] = __fadd_rn(sd[p], bd);
-            }
+        RT_EPILOGUE(T0, bias1, true)
+        lds_barrier();
+        // ---- FP layer 2 (wa) while cls layer 1 (wb) comes in; its output = the backbone features.  Side: round 0 of the next input
+        RT_VM_DRAIN
+        RT_STAGE_HOOK(T0, wa, wb, rs, 384, true, RT_SIDE0)
+        RT_EPILOGUE(T1, bias2, true)
+        lds_barrier();
+        // ---- cls layer 1 (wb) while reg layer 1 (wa) comes in; the feature rows go out meanwhile.  Side: round 1
+        RT_VM_DRAIN
+#define RT_SIDE1F(g) RT_SIDE1(g) RT_ROWS_OUT(g, t, T1, a.feats, 128, true)
+        RT_STAGE_HOOK(T1, wb, wa, rs, 512, true, RT_SIDE1F)
+        RT_EPILOGUE(T0, biasc, true)
+        lds_barrier();
+        // ---- reg layer 1 (wa) while reg layer 2 (wb) comes in.  Side: round 2 of the next input, and the score = cls layer 2, a
+        //      128-long dot product per row over the cls hidden rows in T0 (this stage reads T1): 8 rows per half-wave pass, the 8
+        //      passes side by side -- 5 rounds of 8 independent lane exchanges instead of 8 dependent chains of 5 (same additions
+        //      per row, in the same order) -- one piece per k-group
+        RT_VM_DRAIN
+        float sd[8];
+#define RT_SCORE(g)                                                                                       \
+        if ((g) == 4) {                                                                                   \
+            _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                               \
+                const float *ar = T0 + (r0 + 8 * p) * RT_LD + j;                                          \
+                float v = fmaf(ar[0], wd0, 0.f);                                                          \
+                v = fmaf(ar[32], wd1, v);                                                                 \
+                v = fmaf(ar[64], wd2, v);                                                                 \
+                sd[p] = fmaf(ar[96], wd3, v);                                                             \
+            }                                                                                             \
+        } else if ((g) >= 5 && (g) <= 9) {                                                                \
+            float o[8];                                                                                   \
+            _Pragma("unroll") for (int p = 0; p < 8; ++p) o[p] = __shfl_xor(sd[p], 16 >> ((g) - 5), 32);  \
+            _Pragma("unroll") for (int p = 0; p < 8; ++p) sd[p] = __fadd_rn(sd[p], o[p]);                 \
+        } else if ((g) == 14) {                                                                           \
+            _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                               \
+                const unsigned int gr = (unsigned int)t * RT_ROWS + r0 + 8 * p;                           \
+                if (j == 0 && gr < (unsigned int)a.rows) a.cls[gr] = __fadd_rn(sd[p], bd);                \
+            }                                                                                             \
         }
-        RT_STAGE(T1, wa, wb, rs, 640, true)
+#define RT_SIDE2S(g) RT_SIDE2(g) RT_SCORE(g)
+        RT_STAGE_HOOK(T1, wa, wb, rs, 640, true, RT_SIDE2S)
         lds_barrier();                                         // every wave has read the cls hidden rows
         RT_EPILOGUE(T0, biasr1, true)
         lds_barrier();
-        // ---- reg layer 2 (wb, no activation) while the next tile's first panel (wa) comes in
+        // ---- reg layer 2 (wb, no activation) while the next tile's first panel (wa) comes in.  Side: round 3
         RT_VM_DRAIN
-        RT_STAGE(T0, wb, wa, rs, 0, true)
+        RT_STAGE_HOOK(T0, wb, wa, rs, 0, true, RT_SIDE3)
         RT_EPILOGUE(T1, biasr2, false)
+        tp = t;                                                // its regression rows leave T1 during the next tile's first stage
+        t = tn;                                                // (the barrier at the top of the loop publishes T1 and X0 | X1)
+        last = true;
+    }
+    if (last) {                                                // the last tile's regression rows
         lds_barrier();
         if (4 * chunk < a.n_reg) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int row = r0 + 8 * i;
-                const unsigned int g = (unsigned int)t * RT_ROWS + row;
+                const unsigned int g = (unsigned int)tp * RT_ROWS + row;
                 if (g < (unsigned int)a.rows)
                     *reinterpret_cast<f32x4 *>(a.reg + (g * (unsigned int)a.n_reg + 4u * chunk)) =
                         *reinterpret_cast<const f32x4 *>(T1 + row * RT_LD + 4 * chunk);
             }
         }
-        lds_barrier();                                         // T1 is free for the next tile's interpolation
-        t = tn;
     }
 }
 
@@ -232,7 +255,8 @@ extern "C" int prcnn_rpn_tail(int b, int n, int m, const float *known, const int
     a.ticket = next_ticket((hipStream_t)stream);
     if (!a.ticket) { set_error("rpn_tail: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
     const long tiles = (rows + RT_ROWS - 1) / RT_ROWS;
-    const long grid = tiles < mfma_grid_cap() ? tiles : mfma_grid_cap();           // gfx950: 256 CUs x 2 resident workgroups
+    const long cap = mfma_grid_cap() < 256 ? mfma_grid_cap() : 256;               // gfx950: 256 CUs, one resident workgroup each (135 KB of LDS)
+    const long grid = tiles < cap ? tiles : cap;
     hipLaunchKernelGGL(rpn_tail_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("rpn_tail");
 }
