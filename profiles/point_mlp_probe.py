@@ -18,3 +18,17 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): run()
 torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 100
 print("rcnn_point_mlp: %.3f ms per call (%.1f TFLOP/s over 53.7 GFLOP)" % (ms, 2 * R * (128 * 128 * 4) / ms / 1e9))
+# the fused entrance kernel (only P leaves the CU): every tile, and the live tiles of a step (a RoI holds ~54 of its 512 rows)
+def timed(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
+p2 = torch.empty((R, 128), device=dev)
+us = timed(lambda: P.rcnn_point_mlp_wrapper(rows, 8, wu1, b[0], wu2, b[1], wm, b[2], wp, b[3], None, None, p2))
+print("rcnn_entrance, all 6400 tiles : %.1f us (%.1f TFLOP/s)" % (us, 2 * R * (128 * 128 * 4) / us / 1e6))
+assert torch.equal(p2, p), "fused entrance != three launches"
+cnt = torch.from_numpy(np.random.default_rng(0).poisson(54, 800).clip(1, 512).astype(np.int32)).to(dev)
+tiles = P.pooled_tiles_wrapper(cnt, 512)
+us = timed(lambda: P.rcnn_point_mlp_wrapper(rows, 8, wu1, b[0], wu2, b[1], wm, b[2], wp, b[3], None, None, p2, tiles))
+print("rcnn_entrance, live tiles of a step (~1.3 per RoI): %.1f us" % us)
