@@ -36,17 +36,16 @@ def instrument_tail():
                   "#define STAMP(k) if (lane == 0 && served == 2) g_trace[(blockIdx.x * 4 + w) * 32 + (k)] = __builtin_amdgcn_s_memtime();\n"
                   "struct RpnTailArgs {")
     lo = s.index("    for (unsigned int served = 0; t < tiles; ++served) {")
-    hi = s.index("        t = tn;\n    }")
+    hi = s.index("        tp = t;")
     lines = s[lo:hi].split("\n")
     out, names, k = [lines[0], "        STAMP(0)"], ["start"], 1
     for ln in lines[1:]:
         out.append(ln)
         st = ln.strip()
-        if st.startswith(("lds_barrier();", "RT_STAGE(", "RT_EPILOGUE(")):
+        if st.startswith(("lds_barrier();", "RT_STAGE(", "RT_STAGE_HOOK(", "RT_EPILOGUE(")):
             out.append("        STAMP(%d)" % k); names.append(st.split(";")[0][:44]); k += 1
     s = s[:lo] + "\n".join(out) + s[hi:]
-    s = s.replace("    const long grid = tiles < 512 ? tiles : 512;",
-                  "    const char *ge = getenv(\"RT_GRID\"); const long gmax = ge ? atol(ge) : 512;\n    const long grid = tiles < gmax ? tiles : gmax;")
+    # (the launch size: PRCNN_MFMA_GRID, capped at one workgroup per CU since the kernel keeps four LDS tiles)
     s += ('\nextern "C" int prcnn_debug_trace(unsigned long long *dst)\n{\n    return (int)hipMemcpyFromSymbol(dst, '
           'HIP_SYMBOL(prcnn::g_trace), sizeof(unsigned long long) * 512 * 4 * 32);\n}\n')
     return s, names
@@ -134,7 +133,7 @@ def _row(label, v):
 
 
 def read_tail(grid):
-    os.environ["RT_GRID"] = str(grid)
+    os.environ["PRCNN_MFMA_GRID"] = str(grid)
     import torch
     X, L = _load()
     dev = torch.device("cuda:0"); g = torch.Generator(device=dev).manual_seed(0)
