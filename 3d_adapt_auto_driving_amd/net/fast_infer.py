@@ -468,15 +468,24 @@ class FastPointRCNN:
     def _backbone(self, xyz, geo, fuse_tail=False):
         """-> the (B, N, 128) point features; fuse_tail: -> (features, None), or (None, inputs of the fused last stretch)."""
         l_xyz, l_feat = geo["l_xyz"], [None]
-        for (npoint, scales), lev in zip(self.sa, geo["sa"]):
-            cur_xyz, cur_feat = l_xyz[len(l_feat) - 1], l_feat[-1]
-            B = cur_xyz.shape[0]
+        # the packed kernels deliver through atomicMax into zeros: ONE fill for all levels of the backbone (all scales, the padding
+        # columns) instead of one per level -- a 5 us launch each on the feature stream
+        B = xyz.shape[0]
+        shapes, pres = [], []
+        for npoint, scales in self.sa:
             width = sum(s[2].layers[-1][0].shape[1] for s in scales)
-            wpad = _round128(width) if PAD128 else width          # consumers (next level's per-point part, FP skip) read 128s
-            # the packed kernels deliver through atomicMax into zeros: ONE fill for the level (all scales, the padding columns)
-            # instead of one strided fill per scale
-            pre = USE_PACKED and all(sc[2].packed is not None or sc[2].wide is not None or sc[3] == 0 for sc in scales)
-            out = (torch.zeros if pre else torch.empty)((B, npoint, wpad), dtype=torch.float32, device=xyz.device)
+            shapes.append((B, npoint, _round128(width) if PAD128 else width))   # consumers (next level's per-point part, FP skip) read 128s
+            pres.append(bool(USE_PACKED and all(sc[2].packed is not None or sc[2].wide is not None or sc[3] == 0 for sc in scales)))
+        sizes = [sh[0] * sh[1] * sh[2] if pr else 0 for sh, pr in zip(shapes, pres)]
+        arena = torch.zeros((sum(sizes),), dtype=torch.float32, device=xyz.device) if sum(sizes) else None
+        offs = [sum(sizes[:k]) for k in range(len(sizes))]
+        for k, ((npoint, scales), lev) in enumerate(zip(self.sa, geo["sa"])):
+            cur_xyz, cur_feat = l_xyz[len(l_feat) - 1], l_feat[-1]
+            width = sum(s[2].layers[-1][0].shape[1] for s in scales)
+            wpad = shapes[k][2]
+            pre = pres[k]
+            out = (arena[offs[k]:offs[k] + sizes[k]].view(shapes[k]) if pre
+                   else torch.empty(shapes[k], dtype=torch.float32, device=xyz.device))
             if wpad > width and not pre:
                 out[:, :, width:] = 0
             packs = lev.get("pack") or [None] * len(scales)
