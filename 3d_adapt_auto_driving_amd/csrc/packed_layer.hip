@@ -32,6 +32,7 @@ constexpr int PL_MAX_BATCH = 4;
 struct PLProblem {
     const unsigned int *hdr; long rows_host; int K, N; const float *A; long lda; const float *W; const float *bias; int do_relu;
     float *out; long ldo; const unsigned int *rowinfo; const int *tilecloud; int m, out_col, n_store;
+    int lds_pool;               // SEGMAX: tiles with many centres pool through the dead LDS tile (segmax.hpp); needs 16-byte aligned output rows
 };
 struct PLBatch { PLProblem p[PL_MAX_BATCH]; };
 struct PGProblem {
@@ -156,7 +157,7 @@ template <bool SEGMAX>
 __device__ __forceinline__ void pl_epilogue(const f32x16 &acc0, const f32x16 &acc1, float *tile, int *ctr, long t, long rows, int n0,
                                             const float *__restrict__ bias, int do_relu, float *__restrict__ out, long ldo,
                                             const unsigned int *__restrict__ rowinfo, const int *__restrict__ tilecloud, int m,
-                                            int out_col, int n_store)
+                                            int out_col, int n_store, int lds_pool)
 {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, h = lane >> 5;
     const int chunk = tid & 31, r0 = tid >> 5;
@@ -169,7 +170,15 @@ __device__ __forceinline__ void pl_epilogue(const f32x16 &acc0, const f32x16 &ac
         __syncthreads();
         const int myc = ctr[lane], prevc = ctr[lane ? lane - 1 : 0];
         const unsigned long long start = __ballot(lane == 0 || myc != prevc);
-        pk_segmented_max(acc0, acc1, ctr, start, h, out, (int)ldo, out_col + n0 + 32 * w + j, bcol);
+        if (!lds_pool || __popcll(start) <= PK_LDS_MIN) {
+            pk_segmented_max(acc0, acc1, ctr, start, h, out, (int)ldo, out_col + n0 + 32 * w + j, bcol);
+        } else {
+            // many centres in the tile: row-major through the panel tile, which is dead (every wave is past the barrier above)
+            const float4 bias4 = *reinterpret_cast<const float4 *>(bias + n0 + 4 * chunk);
+            pk_park(acc0, acc1, tile, PL_LD, 32 * w + j, h);
+            lds_barrier();
+            pk_segmented_max_lds(tile, PL_LD, ctr, tid, out, (int)ldo, out_col + n0, bias4);
+        }
     } else {
         __syncthreads();                                   // the panel tile is dead: stage the results through it
 #pragma unroll
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void packed_layer_kernel(
         __syncthreads();
         PL_STAGE(tile, wf)
     }
-    pl_epilogue<SEGMAX>(acc0, acc1, tile, ctr, t, rows, n0, bias, do_relu, out, ldo, rowinfo, tilecloud, m, out_col, n_store);
+    pl_epilogue<SEGMAX>(acc0, acc1, tile, ctr, t, rows, n0, bias, do_relu, out, ldo, rowinfo, tilecloud, m, out_col, n_store, pb.lds_pool);
 }
 
 // K >= 256: two LDS tiles, two weight register sets, every panel fetched behind the MFMAs of the one before it
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void packed_layer_pipe_kernel(
             PL_STAGE(T, wa)
         }
     }
-    pl_epilogue<SEGMAX>(acc0, acc1, tiles, ctr, t, rows, n0, bias, do_relu, out, ldo, rowinfo, tilecloud, m, out_col, n_store);
+    pl_epilogue<SEGMAX>(acc0, acc1, tiles, ctr, t, rows, n0, bias, do_relu, out, ldo, rowinfo, tilecloud, m, out_col, n_store, pb.lds_pool);
 }
 
 // ---- 32-row tiles: the layers that would give fewer than 256 workgroups of 64 rows (FP3, SA4's per-point parts, the RCNN
@@ -457,6 +466,13 @@ static bool pipe_enabled()
     return on;
 }
 
+// PRCNN_SEGMAX_LDS=0: every tile's segmented max in registers (A/B switch, same results)
+static bool segmax_lds_enabled()
+{
+    static const bool on = [] { const char *e = getenv("PRCNN_SEGMAX_LDS"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 extern "C" int prcnn_rows_dot(long rows, int K, int n, const float *A, long lda, const float *W, const float *bias, float *out,
                               long ldo, void *stream)
 {
@@ -552,7 +568,9 @@ extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr
         cls[k] = (!segmax && !q.hdr && pipe && tiles * col_blocks < 256) ? PL_PIPE32 : (pipe ? PL_PIPE : PL_ONE);
         tiles_of[k] = tiles; blocks_of[k] = col_blocks; src[k] = i;
         bt.p[k] = PLProblem{q.hdr, q.rows, q.K, q.N, q.A, q.lda, q.W, q.bias, segmax ? 1 : q.relu, q.out, q.ldo,
-                            segmax ? q.rowinfo : nullptr, segmax ? q.tilecloud : nullptr, segmax ? q.m : 0, segmax ? q.out_col : 0, n_store};
+                            segmax ? q.rowinfo : nullptr, segmax ? q.tilecloud : nullptr, segmax ? q.m : 0, segmax ? q.out_col : 0, n_store,
+                            (segmax && segmax_lds_enabled() && (((uintptr_t)q.out | (uintptr_t)q.bias) & 15) == 0 && (q.ldo & 3) == 0 &&
+                             (q.out_col & 3) == 0) ? 1 : 0};
         ++k;
     }
     if (k == 0) return PRCNN_OK;

@@ -34,6 +34,7 @@ constexpr int PK_ROWS = 64;
 constexpr int PK_LD = PK_C + 4;
 constexpr int PK_TILES_PER_WG = 8;
 
+
 // ------------------------------------------------------------------------------------------------ packing
 // one workgroup per cloud.  LDS: cnt / offset per centre (m ints) + per-thread partial sums.
 // `limit` (optional, per cloud): the points k >= limit[cloud] of the cloud are COPIES of point k % limit[cloud] (the
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
     const float4 *__restrict__ P /* (b,n,128) */, const float4 *__restrict__ wxyz /* (3,128) */,
     const unsigned int *__restrict__ rowinfo, const int *__restrict__ tilecloud,
     const float *__restrict__ w2t, const float *__restrict__ b2, const float *__restrict__ w3t, const float *__restrict__ b3,
-    float *__restrict__ out, int out_stride, int out_col, unsigned int *__restrict__ ticket, int tiles_per_wg)
+    float *__restrict__ out, int out_stride, int out_col, unsigned int *__restrict__ ticket, int tiles_per_wg, int lds_pool)
 {
     __shared__ float lds[2 * PK_ROWS * PK_LD];
     __shared__ unsigned int slot[2];
@@ -266,8 +267,17 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wf3[4 * g + 3], acc1, 0, 0, 0);
             }
             const int myc = cc[lane], prevc = cc[lane ? lane - 1 : 0];
-            const unsigned long long start = __ballot(lane == 0 || myc != prevc);
-            pk_segmented_max(acc0, acc1, cc, start, h, out, out_stride, out_col + 32 * w + j, bias3);
+            const unsigned long long start = __ballot(lane == 0 || myc != prevc);       // the same word in every wave
+            if (!lds_pool || __popcll(start) <= PK_LDS_MIN) {
+                pk_segmented_max(acc0, acc1, cc, start, h, out, out_stride, out_col + 32 * w + j, bias3);
+            } else {
+                // many centres in the tile: through LDS, row-major (segmax.hpp).  A1 is free (last read in layer 2, two barriers ago).
+                const float4 bias4 = *reinterpret_cast<const float4 *>(b3 + 4 * (tid & 31));
+                pk_park(acc0, acc1, A1, PK_LD, 32 * w + j, h);
+                lds_barrier();
+                pk_segmented_max_lds(A1, PK_LD, cc, tid, out, out_stride, out_col, bias4);
+                lds_barrier();                                 // the next builder rewrites A1
+            }
         }
         // A1 is rewritten by the next builder only (every wave has left layer 2); Y1 after the next tile's first barrier;
         // the centre list alternates between two buffers, so a slow wave still reads this tile's list while the others
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
     const float4 *__restrict__ P, const float4 *__restrict__ wxyz, const unsigned int *__restrict__ rowinfo,
     const int *__restrict__ tilecloud, const float *__restrict__ w2t, const float *__restrict__ b2,
     const float *__restrict__ w3t /* (128,256) */, const float *__restrict__ b3, float *__restrict__ out, int out_stride,
-    int out_col, unsigned int *__restrict__ ticket, int tiles_per_wg)
+    int out_col, unsigned int *__restrict__ ticket, int tiles_per_wg, int lds_pool)
 {
     __shared__ float lds[2 * PK_ROWS * PK_LD];
     __shared__ unsigned int slot[2];
@@ -395,7 +405,19 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
             }
             const int myc = cc[lane], prevc = cc[lane ? lane - 1 : 0];
             const unsigned long long start = __ballot(lane == 0 || myc != prevc);
-            pk_segmented_max(acc0, acc1, cc, start, h, out, out_stride, out_col + 128 * wg + 32 * wp + j, bias3);
+            if (!lds_pool || __popcll(start) <= PK_LDS_MIN) {
+                pk_segmented_max(acc0, acc1, cc, start, h, out, out_stride, out_col + 128 * wg + 32 * wp + j, bias3);
+            } else {
+                // many centres in the tile: through LDS, row-major (segmax.hpp), one 64 x 128 tile per column tile: A1 is free
+                // (last read in layer 2), Y1 once every wave has left layer 3
+                float *Z = wg ? Y1 : A1;
+                const float4 bias4 = *reinterpret_cast<const float4 *>(b3 + 128 * wg + 4 * (tid & 31));
+                lds_barrier();
+                pk_park(acc0, acc1, Z, PK_LD, 32 * wp + j, h);
+                lds_barrier();
+                pk_segmented_max_lds(Z, PK_LD, cc, tid & 255, out, out_stride, out_col + 128 * wg, bias4);
+                lds_barrier();                                 // the next builder rewrites A1
+            }
         }
         t = t_next;
     }
@@ -477,11 +499,14 @@ extern "C" int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, 
     }
     unsigned int *ticket = next_ticket(st);
     if (!ticket) { set_error("sa_packed_mlp: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
+    // row-major pooling through LDS needs 16-byte aligned output rows; PRCNN_SEGMAX_LDS=0 keeps every tile on the register form
+    static const bool env_lds = !(getenv("PRCNN_SEGMAX_LDS") && atoi(getenv("PRCNN_SEGMAX_LDS")) == 0);
+    const int lds_pool = env_lds && (((uintptr_t)out | (uintptr_t)b3) & 15) == 0 && out_stride % 4 == 0 && out_col % 4 == 0;
     if (c3 == 128)
         hipLaunchKernelGGL(sa_packed_mlp128_kernel, dim3(grid), dim3(256), 0, st, n, m, hdr, (const float4 *)rowdxyz, (const float4 *)P,
-                           (const float4 *)wxyz, rowinfo, tilecloud, w2t, b2, w3t, b3, out, out_stride, out_col, ticket, per_wg);
+                           (const float4 *)wxyz, rowinfo, tilecloud, w2t, b2, w3t, b3, out, out_stride, out_col, ticket, per_wg, lds_pool);
     else
         hipLaunchKernelGGL(sa_packed_mlp256_kernel, dim3(grid), dim3(512), 0, st, n, m, hdr, (const float4 *)rowdxyz, (const float4 *)P,
-                           (const float4 *)wxyz, rowinfo, tilecloud, w2t, b2, w3t, b3, out, out_stride, out_col, ticket, per_wg);
+                           (const float4 *)wxyz, rowinfo, tilecloud, w2t, b2, w3t, b3, out, out_stride, out_col, ticket, per_wg, lds_pool);
     return check_launch("sa_packed_mlp");
 }
