@@ -75,7 +75,10 @@ def test_fused_mfma_kernel_is_bit_exact_vs_the_fma_chain_oracle(ext, c3):
 
 @pytest.mark.parametrize("c3", [128, 256])
 @pytest.mark.parametrize("mean_cnt", [1.5, 9, 40])
-def test_packed_kernel_bit_identical_to_unpacked_and_to_oracle(ext, c3, mean_cnt):
+@pytest.mark.parametrize("col", [4, 5])
+def test_packed_kernel_bit_identical_to_unpacked_and_to_oracle(ext, c3, mean_cnt, col):
+    """col = 4: output rows are 16-byte aligned -- tiles that hold many centres pool through LDS with 16-byte stores
+    (csrc/segmax.hpp), the others in registers; col = 5: unaligned rows, every tile pools in registers.  Same bits."""
     rng = np.random.default_rng(int(c3 + 10 * mean_cnt))
     b, n, m, ns = 7, 512, 53, 64
     xyz = T(rng.uniform(-2, 2, (b, n, 3)).astype(np.float32))
@@ -85,17 +88,17 @@ def test_packed_kernel_bit_identical_to_unpacked_and_to_oracle(ext, c3, mean_cnt
     idx_np, cnt = ball_like_idx(rng, b, m, n, ns, mean_cnt)
     idx = T(idx_np)
     w2, b2, w3, b3 = mlp_params(rng, c3)
-    full = torch.full((b, m, c3 + 4), -1.0, device=DEV)
-    ext.pointnet2.sa_mlp_fused_wrapper(new_xyz, xyz, P, wx, idx, w2, b2, w3, b3, full, 4)
+    full = torch.full((b, m, c3 + col), -1.0, device=DEV)
+    ext.pointnet2.sa_mlp_fused_wrapper(new_xyz, xyz, P, wx, idx, w2, b2, w3, b3, full, col)
     pk = ext.pointnet2.ball_pack_wrapper(idx, xyz, new_xyz)
     hdr = pk.hdr.cpu().numpy()
     assert hdr[1] == cnt.sum()                                               # distinct rows
     assert hdr[0] == sum((int(cnt[i].sum()) + 63) // 64 for i in range(b))   # tiles: per cloud, rounded up
-    got = torch.full((b, m, c3 + 4), float("nan"), device=DEV)
-    got[:, :, :4] = -1.0
-    ext.pointnet2.sa_packed_mlp_wrapper(new_xyz, xyz, P, wx, pk, w2, b2, w3, b3, got, 4)
+    got = torch.full((b, m, c3 + col), float("nan"), device=DEV)
+    got[:, :, :col] = -1.0
+    ext.pointnet2.sa_packed_mlp_wrapper(new_xyz, xyz, P, wx, pk, w2, b2, w3, b3, got, col)
     assert torch.equal(got, full), float((got - full).abs().max())
-    want = oracle_fused(new_xyz, xyz, P, wx, idx, w2, b2, w3, b3, c3 + 4, 4)
+    want = oracle_fused(new_xyz, xyz, P, wx, idx, w2, b2, w3, b3, c3 + col, col)
     assert torch.equal(got.cpu(), want)
     # the row list: every centre's distinct points, in slot order, tiles of one cloud each
     tiles = int(hdr[0])
