@@ -32,6 +32,10 @@ __device__ __forceinline__ void pk_segmented_max(const f32x16 &acc0, const f32x1
         return;
     }
     float cur = acc0[0];
+    // half 1 holds the rows of half 0 + 4: its boundary mask m1 is m0 << 4, so one shifted copy of `start` per lane serves both
+    // halves with the compile-time constant m0 (as `h ? b1 : b0` the compiler kept 31 per-lane 64-bit masks in registers and
+    // spilled them: a scratch reload + full wait per step of this chain)
+    const unsigned long long sh = h ? (start >> 4) : start;
 #pragma unroll
     for (int q = 1; q < 32; ++q) {
         const float v = (q < 16) ? acc0[q & 15] : acc1[q & 15];
@@ -41,7 +45,7 @@ __device__ __forceinline__ void pk_segmented_max(const f32x16 &acc0, const f32x1
         const unsigned long long m1 = pk_bits_upto(row + 4) & ~pk_bits_upto(prev + 4);
         const bool b0 = (start & m0) != 0, b1 = (start & m1) != 0;        // wave-uniform
         if (b0 | b1) {
-            const bool mine = h ? b1 : b0;
+            const bool mine = (sh & m0) != 0;
             if (mine) {
                 pk_flush(out, ctr[prev + 4 * h], out_stride, col, cur, bias);
                 cur = v;
