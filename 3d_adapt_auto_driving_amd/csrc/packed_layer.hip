@@ -150,6 +150,33 @@ __global__ __launch_bounds__(256) void packed_gather_affine_kernel(const PGBatch
         }                                                                                               \
     }
 
+// the same stage with the NEXT ROW TILE of a K = 128 layer coming in behind it (packed_layer_stream_kernel: the weights stay):
+// 8 rows per thread as buffer loads at scalar offset `soff` in k-groups 0-7, written to the other LDS tile in k-groups 8-15
+#define PL_STAGE_ROWS(T, TN, wf, soff)                                                                  \
+    {                                                                                                   \
+        const float *a0p = (T) + j * PL_LD + 64 * h, *a1p = (T) + (32 + j) * PL_LD + 64 * h;            \
+        f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p);                                               \
+        f32x4 a1 = *reinterpret_cast<const f32x4 *>(a1p);                                               \
+        f32x4 ar[8];                                                                                    \
+        _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                \
+            f32x4 n0_ = a0, n1_ = a1;                                                                   \
+            if (g < 15) {                                                                               \
+                n0_ = *reinterpret_cast<const f32x4 *>(a0p + 4 * (g + 1));                              \
+                n1_ = *reinterpret_cast<const f32x4 *>(a1p + 4 * (g + 1));                              \
+            }                                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+            PL_GROUP_MFMA_HEAD(wf)                                                                      \
+            if (g < 8)                                                                                  \
+                ar[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                \
+                    ars, a_lane, (soff) + (unsigned int)(8 * g) * a_row_bytes, 0));                     \
+            else                                                                                        \
+                *reinterpret_cast<f32x4 *>((TN) + (r0 + 8 * (g - 8)) * PL_LD + 4 * chunk) = ar[g - 8];  \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+            PL_GROUP_MFMA_TAIL(wf)                                                                      \
+            a0 = n0_; a1 = n1_;                                                                         \
+        }                                                                                               \
+    }
+
 // act(acc + bias): SEGMAX = false -> out[r][n0 + ..] for the tile's rows (rows >= `rows` are not stored), staged through
 // the (dead) LDS tile for coalesced 16-byte stores; SEGMAX = true -> segmented max over the tile's rows by centre, atomicMax
 // into out[centre][out_col + n0 + ..]
@@ -320,6 +347,58 @@ __global__ __launch_bounds__(256, 2) void packed_layer_pipe_kernel(
     pl_epilogue<SEGMAX>(acc0, acc1, tiles, ctr, t, rows, n0, bias, do_relu, out, ldo, rowinfo, tilecloud, m, out_col, n_store, pb.lds_pool);
 }
 
+// ---- K = 128 layers over many row tiles (the per-point parts of the SA levels: 10^5 rows, one panel): PERSISTENT workgroups.
+// With one tile per workgroup every tile paid its own 64 weight loads (64 KB per workgroup from L2), an exposed round trip for
+// its rows and an epilogue nobody overlapped: 55-59 TFLOP/s (profiles/r02_microbench.md).  Here a workgroup keeps its 128 x 32
+// weight slices in registers and strides over the row tiles; the next tile's rows arrive behind the MFMAs of the running one
+// (PL_STAGE_ROWS, two LDS tiles).  Per row the arithmetic is that of packed_layer_kernel: same bits.  Host-count mode, no pooling.
+__global__ __launch_bounds__(256, 2) void packed_layer_stream_kernel(long rows, int N, const float *__restrict__ A, long lda,
+                                                                     const float *__restrict__ W, const float *__restrict__ bias,
+                                                                     int do_relu, float *__restrict__ out, long ldo, int n_store)
+{
+    __shared__ float tiles[2 * PL_ROWS * PL_LD];
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = tid & 31, r0 = tid >> 5;
+    const int n0 = blockIdx.y * 128;
+    const long ntiles = (rows + PL_ROWS - 1) / PL_ROWS;
+    long t = blockIdx.x;
+    if (t >= ntiles || n0 >= n_store) return;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, 128 * N * 4, 0x00020000);
+    const unsigned int row_bytes = (unsigned int)N * 4u;
+    const unsigned int lane_off = ((unsigned int)(64 * h) * (unsigned int)N + (unsigned int)(n0 + 32 * w + j)) * 4u;
+    float wf[64];
+    PL_LOAD_W(wf, 0)
+    // the whole matrix as one buffer: rows past the end (the ragged last tile) are out of its range and read as zero
+    const unsigned int a_row_bytes = (unsigned int)lda * 4u;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, (int)(rows * (long)a_row_bytes), 0x00020000);
+    const unsigned int a_lane = (unsigned int)r0 * a_row_bytes + 16u * chunk;
+    {
+        const unsigned int soff = (unsigned int)(t * PL_ROWS) * a_row_bytes;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<f32x4 *>(tiles + (r0 + 8 * i) * PL_LD + 4 * chunk) =
+                __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, a_lane, soff + (unsigned int)(8 * i) * a_row_bytes, 0));
+    }
+    for (int it = 0;; ++it) {
+        PL_VM_DRAIN
+        lds_barrier();                                     // this tile's rows are published; the other tile is free (its copy-out is over)
+        float *T = tiles + (it & 1) * (PL_ROWS * PL_LD);
+        float *TN = tiles + ((it + 1) & 1) * (PL_ROWS * PL_LD);
+        const long tn = t + gridDim.x;
+        f32x16 acc0 = {0}, acc1 = {0};
+        if (tn < ntiles) {
+            const unsigned int soff = (unsigned int)(tn * PL_ROWS) * a_row_bytes;
+            PL_STAGE_ROWS(T, TN, wf, soff)
+        } else {
+            PL_STAGE(T, wf)
+        }
+        pl_epilogue<false>(acc0, acc1, T, nullptr, t, rows, n0, bias, do_relu, out, ldo, nullptr, nullptr, 0, 0, n_store, 0);
+        if (tn >= ntiles) break;
+        t = tn;
+    }
+}
+
 // ---- 32-row tiles: the layers that would give fewer than 256 workgroups of 64 rows (FP3, SA4's per-point parts, the RCNN
 // heads: a few thousand rows, many panels).  Their launch time is one workgroup's serial panel chain; halving the rows of a
 // tile halves the MFMAs of a stage (one accumulator per wave: 64 MFMAs, each waiting for the one before it -- the pipe's
@@ -466,6 +545,13 @@ static bool pipe_enabled()
     return on;
 }
 
+// PRCNN_PL_STREAM=0: K = 128 layers with one row tile per workgroup (A/B switch, same results)
+static bool stream_enabled()
+{
+    static const bool on = [] { const char *e = getenv("PRCNN_PL_STREAM"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // PRCNN_SEGMAX_LDS=0: every tile's segmented max in registers (A/B switch, same results)
 static bool segmax_lds_enabled()
 {
@@ -523,7 +609,7 @@ extern "C" int prcnn_packed_gather_affine(int b, int n, int c1, long max_tiles, 
 // asks for its real width).  Row count: hdr != NULL -> hdr[0] * 64 rows (a packed list; max_tiles sizes the grid), else `rows`
 // (host count).  Up to 4 problems that land on the same kernel share ONE launch (grid.z); others are launched one by one.
 namespace {
-enum PLClass { PL_ONE, PL_PIPE, PL_PIPE32 };
+enum PLClass { PL_ONE, PL_PIPE, PL_PIPE32, PL_STREAM };
 }
 extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr, int segmax, void *stream)
 {
@@ -566,6 +652,10 @@ extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr
         const int col_blocks = (n_store + 127) / 128;      // column blocks that hold nothing to store are not launched
         const bool pipe = q.K >= 256 && pipe_enabled();
         cls[k] = (!segmax && !q.hdr && pipe && tiles * col_blocks < 256) ? PL_PIPE32 : (pipe ? PL_PIPE : PL_ONE);
+        // one panel, many row tiles, rows counted on the host: persistent workgroups (PRCNN_PL_STREAM=0: one tile per workgroup)
+        if (cls[k] == PL_ONE && !segmax && !q.hdr && q.K == 128 && tiles * col_blocks >= 512 && stream_enabled() &&
+            q.rows * q.lda * 4 < (1L << 31))
+            cls[k] = PL_STREAM;
         tiles_of[k] = tiles; blocks_of[k] = col_blocks; src[k] = i;
         bt.p[k] = PLProblem{q.hdr, q.rows, q.K, q.N, q.A, q.lda, q.W, q.bias, segmax ? 1 : q.relu, q.out, q.ldo,
                             segmax ? q.rowinfo : nullptr, segmax ? q.tilecloud : nullptr, segmax ? q.m : 0, segmax ? q.out_col : 0, n_store,
@@ -574,7 +664,7 @@ extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr
         ++k;
     }
     if (k == 0) return PRCNN_OK;
-    bool together = cls[0] != PL_PIPE32;
+    bool together = cls[0] != PL_PIPE32 && cls[0] != PL_STREAM;
     for (int i = 1; i < k; ++i) together = together && cls[i] == cls[0];
     for (int i = 0; i < k; ++i) {
         PLBatch one;
@@ -587,7 +677,12 @@ extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr
             one.p[0] = bt.p[i];
         }
         const PLBatch &arg = together ? bt : one;
-        if (cls[i] == PL_PIPE32) {
+        if (cls[i] == PL_STREAM) {
+            const prcnn_layer_problem &q = pr[src[i]];
+            const long cap = 512 / gy > 0 ? 512 / gy : 1;  // two resident workgroups per CU over all column blocks
+            hipLaunchKernelGGL(packed_layer_stream_kernel, dim3((unsigned)(tiles_of[i] < cap ? tiles_of[i] : cap), gy), dim3(256), 0, st,
+                               q.rows, q.N, q.A, q.lda, q.W, q.bias, q.relu, q.out, q.ldo, q.n_store);
+        } else if (cls[i] == PL_PIPE32) {
             const prcnn_layer_problem &q = pr[src[i]];
             hipLaunchKernelGGL(packed_layer_pipe32_kernel, dim3((unsigned)((q.rows + 31) / 32), gy), dim3(256), 0, st, q.rows, q.K, q.N, q.A,
                                q.lda, q.W, q.bias, q.relu, q.out, q.ldo, q.n_store);

@@ -234,8 +234,11 @@ def test_packed_layer_host_row_count_ragged(ext):
     """The layer kernel as a plain row-major GEMM layer: row counts that are not multiples of 64, strided input, ReLU off/on."""
     rng = np.random.default_rng(9)
     # (K >= 256 and fewer than 256 tiles of 64 rows x 128 columns -> the 32-row-tile kernel; otherwise the 64-row kernels)
+    # (K = 128 and 512 or more tiles x column blocks -> persistent workgroups that stream over the row tiles, ragged last tile read
+    #  as zeros through the buffer's bounds check: 40000 rows x 128 columns = 625 tiles, 20037 rows x 256 columns = 2 x 314)
     for R, K, N, relu in ((1, 128, 128, True), (63, 256, 128, False), (200, 128, 384, True), (8192, 512, 256, False),
-                          (33, 384, 256, True), (2048, 1536, 512, True), (800, 512, 256, False)):
+                          (33, 384, 256, True), (2048, 1536, 512, True), (800, 512, 256, False), (40000, 128, 128, True),
+                          (20037, 128, 256, False)):
         a_full = T(rng.standard_normal((R, K + 8)).astype(np.float32))
         a = a_full[:, 4:4 + K] if False else a_full[:, :K]           # row stride K + 8, 16-byte aligned
         w = T((rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32))
