@@ -545,6 +545,8 @@ static bool pipe_enabled()
     return on;
 }
 
+static long stream_min() { static const long v = getenv("PRCNN_PL_STREAM_MIN") ? atol(getenv("PRCNN_PL_STREAM_MIN")) : 512; return v; }
+static long stream_cap() { static const long v = getenv("PRCNN_PL_STREAM_CAP") ? atol(getenv("PRCNN_PL_STREAM_CAP")) : 512; return v; }
 // PRCNN_PL_STREAM=0: K = 128 layers with one row tile per workgroup (A/B switch, same results)
 static bool stream_enabled()
 {
@@ -653,7 +655,7 @@ extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr
         const bool pipe = q.K >= 256 && pipe_enabled();
         cls[k] = (!segmax && !q.hdr && pipe && tiles * col_blocks < 256) ? PL_PIPE32 : (pipe ? PL_PIPE : PL_ONE);
         // one panel, many row tiles, rows counted on the host: persistent workgroups (PRCNN_PL_STREAM=0: one tile per workgroup)
-        if (cls[k] == PL_ONE && !segmax && !q.hdr && q.K == 128 && tiles * col_blocks >= 512 && stream_enabled() &&
+        if (cls[k] == PL_ONE && !segmax && !q.hdr && q.K == 128 && tiles * col_blocks >= stream_min() && stream_enabled() &&
             q.rows * q.lda * 4 < (1L << 31))
             cls[k] = PL_STREAM;
         tiles_of[k] = tiles; blocks_of[k] = col_blocks; src[k] = i;
@@ -679,7 +681,7 @@ extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr
         const PLBatch &arg = together ? bt : one;
         if (cls[i] == PL_STREAM) {
             const prcnn_layer_problem &q = pr[src[i]];
-            const long cap = 512 / gy > 0 ? 512 / gy : 1;  // two resident workgroups per CU over all column blocks
+            const long cap = stream_cap() / gy > 0 ? stream_cap() / gy : 1;  // two resident workgroups per CU over all column blocks
             hipLaunchKernelGGL(packed_layer_stream_kernel, dim3((unsigned)(tiles_of[i] < cap ? tiles_of[i] : cap), gy), dim3(256), 0, st,
                                q.rows, q.N, q.A, q.lda, q.W, q.bias, q.relu, q.out, q.ldo, q.n_store);
         } else if (cls[i] == PL_PIPE32) {
