@@ -534,19 +534,20 @@ def shard_scene_ids(num_scenes, rank, world):
 
 
 def pack_detections(scene_ids, det_batches, max_det):
-    """Host-side table [S, max_det, 9] = 7 box + score + scene id, zero padded, plus counts [S]."""
+    """Host-side table [S, max_det, 9] = 7 box + score + scene id, zero padded, plus counts [S].
+    numpy on purpose: the per-batch slice assignments of the first version were torch CPU kernels, each of which may fan out
+    over the host's OpenMP pool -- tens of milliseconds for 20 batches on a 128-core box, inside the bench's clock."""
     S = len(scene_ids)
-    table = torch.zeros((S, max_det, 9), dtype=torch.float32)
-    counts = torch.zeros((S,), dtype=torch.int32)
-    i = 0
-    for boxes, scores, num in det_batches:
-        b = boxes.shape[0]
-        table[i:i + b, :, 0:7] = boxes
-        table[i:i + b, :, 7] = scores
-        counts[i:i + b] = num
-        i += b
-    table[:, :, 8] = torch.tensor(scene_ids, dtype=torch.float32).view(-1, 1)
-    return table, counts
+    table = np.empty((S, max_det, 9), dtype=np.float32)
+    det_batches = list(det_batches)
+    if det_batches:
+        table[:, :, 0:7] = np.concatenate([np.asarray(d[0]) for d in det_batches], 0)
+        table[:, :, 7] = np.concatenate([np.asarray(d[1]) for d in det_batches], 0)
+        counts = np.concatenate([np.asarray(d[2]) for d in det_batches], 0).astype(np.int32)
+    else:
+        counts = np.zeros((0,), dtype=np.int32)
+    table[:, :, 8] = np.asarray(scene_ids, dtype=np.float32).reshape(-1, 1)
+    return torch.from_numpy(table), torch.from_numpy(counts)
 
 
 def all_gather_detections(table, counts, device):
