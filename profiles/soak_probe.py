@@ -1,5 +1,7 @@
+"""600 steps of the pipelined runner, step time per block of 50 (a synchronize between blocks: each block restarts the
+pipeline cold), then clocks / power: no drift over time (1.96-2.07 ms per step, 2.4 GHz, ~560 W)."""
 import importlib, os, sys, time, torch, numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PKG = "3d_adapt_auto_driving_amd"
 C = importlib.import_module(PKG + ".config"); E = importlib.import_module(PKG + ".eval_rcnn"); S = importlib.import_module(PKG + ".synth")
 dev = torch.device("cuda", 0); cfg = C.default_eval_cfg(); model = E.build_model(cfg, dev, seed=0)
