@@ -726,20 +726,36 @@ class FastPointRCNN:
             xyz_feature = self.xyz_up(rg["a"])                                 # (rows, 128)
             merged = self.merge_down(torch.cat((xyz_feature, rg["rpn_part"]), dim=1))
             l_feat = [merged.view(B * M, P, -1)]
+        # the levels that pool through atomicMax (packed rows) want zeroed outputs: ONE fill for all of them
+        shapes = []
         for (npoint, radius, ns, mlp, cin), lev in zip(self.rcnn_sa, rg["levels"]):
+            cout = mlp.layers[-1][0].shape[1]
+            if lev["pack"] is not None and USE_PACKED and (mlp.packed is not None or mlp.wide is not None):
+                rows_out = lev["xyz"].shape[0] * (npoint if npoint is not None else lev["f"])
+                shapes.append(rows_out * cout)
+            else:
+                shapes.append(0)
+        arena = torch.zeros((sum(shapes),), dtype=torch.float32, device=rows.device) if sum(shapes) else None
+        offs = [sum(shapes[:k]) for k in range(len(shapes))]
+        for k, ((npoint, radius, ns, mlp, cin), lev) in enumerate(zip(self.rcnn_sa, rg["levels"])):
             cur_xyz, cur_feat = lev["xyz"], l_feat[-1]
             cout = mlp.layers[-1][0].shape[1]
             first = len(l_feat) == 1
+            pre = shapes[k] > 0
             if npoint is not None:
                 Bc = cur_xyz.shape[0]
-                out = torch.empty((Bc, npoint, cout), dtype=torch.float32, device=cur_xyz.device)
-                self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, lev["idx"], mlp, cin, out, 0, P_pre=P_pre if first else None, pack=lev["pack"])
+                out = (arena[offs[k]:offs[k] + shapes[k]].view(Bc, npoint, cout) if pre
+                       else torch.empty((Bc, npoint, cout), dtype=torch.float32, device=cur_xyz.device))
+                self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, lev["idx"], mlp, cin, out, 0, P_pre=P_pre if first else None, pack=lev["pack"],
+                               zeroed=pre)
             elif lev["pack"] is not None:                                       # GroupAll over f RoIs per "cloud" (see _rcnn_geometry)
                 f = lev["f"]
                 Bc = cur_xyz.shape[0] * f
                 feat_v = cur_feat.view(Bc // f, cur_xyz.shape[1], cur_feat.shape[2])
-                out = torch.empty((Bc, 1, cout), dtype=torch.float32, device=cur_xyz.device)
-                self._sa_scale(cur_xyz, lev["new_xyz"], feat_v, lev["idx"], mlp, cin, out.view(Bc // f, f, cout), 0, pack=lev["pack"], dense=True)
+                out = (arena[offs[k]:offs[k] + shapes[k]].view(Bc, 1, cout) if pre
+                       else torch.empty((Bc, 1, cout), dtype=torch.float32, device=cur_xyz.device))
+                self._sa_scale(cur_xyz, lev["new_xyz"], feat_v, lev["idx"], mlp, cin, out.view(Bc // f, f, cout), 0, pack=lev["pack"], dense=True,
+                               zeroed=pre)
             else:                                                               # GroupAll: one group of n points
                 Bc, n = cur_xyz.shape[0], cur_xyz.shape[1]
                 c4 = _round4(cin)
