@@ -264,6 +264,13 @@ class FastPointRCNN:
                                      _Mlp(_fold_shared_mlp(mlp), grouped_c=cin), cin))
             self.rcnn_cls = _Mlp(_fold_head(r.cls_layer), pad128=PAD128)
             self.rcnn_reg = _Mlp(_fold_head(r.reg_layer), pad128=PAD128)
+            # both heads read the same 512 features: their first layers side by side are ONE layer of twice the width (a launch less
+            # on a chain of six launches over 800 rows; every output column is the same dot product as before)
+            self.rcnn_head1 = None
+            c0, r0 = self.rcnn_cls.layers[0], self.rcnn_reg.layers[0]
+            if (USE_POINT_LAYER and USE_PACKED and len(self.rcnn_cls.layers) > 1 and len(self.rcnn_reg.layers) > 1 and c0[2] and r0[2] and
+                    c0[0].shape == r0[0].shape and c0[0].shape[0] % 128 == 0 and c0[0].shape[1] % 128 == 0):
+                self.rcnn_head1 = (torch.cat([c0[0], r0[0]], 1).contiguous(), torch.cat([c0[1], r0[1]]).contiguous(), c0[0].shape[1])
 
     def _fold_rpn_tail(self):
         """Weights of csrc/rpn_tail.hip (finest FP module + both RPN heads in one kernel) when the network has the shape that
@@ -770,6 +777,10 @@ class FastPointRCNN:
         kp = self.rcnn_cls.layers[0][0].shape[0]
         if top.shape[1] != kp:                                                  # narrow configurations under PAD128
             top = torch.nn.functional.pad(top, (0, kp - top.shape[1]))
+        if self.rcnn_head1 is not None and top.stride(1) == 1:
+            wt, b, n1 = self.rcnn_head1
+            h = point_layer(top, wt, b, True)
+            return {"rcnn_cls": self.rcnn_cls(h[:, :n1], start=1), "rcnn_reg": self.rcnn_reg(h[:, n1:], start=1)}
         return {"rcnn_cls": self.rcnn_cls(top), "rcnn_reg": self.rcnn_reg(top)}
 
     __call__ = forward
