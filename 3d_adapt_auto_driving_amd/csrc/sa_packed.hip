@@ -46,7 +46,7 @@ constexpr int PK_TILES_PER_WG = 8;
 __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, const int *__restrict__ idx, const int *__restrict__ limit,
                                  const float *__restrict__ xyz, const float *__restrict__ new_xyz,
                                  unsigned int *__restrict__ rowinfo, float4 *__restrict__ rowdxyz, int *__restrict__ tilecloud,
-                                 unsigned int *__restrict__ hdr)
+                                 unsigned int *__restrict__ hdr, int group)
 {
     // Both passes are parallel over ELEMENTS, not over centres (a thread per centre left 32 of 256 threads busy on the RoI
     // clouds' second level and walked each centre's rows as a chain of dependent loads: 47 us for 800 clouds x 32 centres):
@@ -58,9 +58,15 @@ __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, cons
     int *offs = pk_lds + m;               // [m]   exclusive offsets
     int *part = pk_lds + 2 * m;           // [blockDim.x] partial sums, then their inclusive scan
     __shared__ int s_base;
-    const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
-    const int *rows = idx + (long)b * m * ns;
-    const int lim = limit ? max(limit[b], 1) : 0x7fffffff;
+    // `group` consecutive clouds share one row list (one batch of a geometry group: csrc entry prcnn_ball_pack_groups): list l =
+    // blockIdx.x / group owns its own slice of the outputs and its own header; tiles record the cloud's index INSIDE its list
+    const int gb = blockIdx.x, list = gb / group, b = gb - list * group, tid = threadIdx.x, T = blockDim.x;
+    rowinfo += (long)list * group * tiles_cap_cloud * PK_ROWS;
+    rowdxyz += (long)list * group * tiles_cap_cloud * PK_ROWS;
+    tilecloud += (long)list * group * tiles_cap_cloud;
+    hdr += 4 * list;
+    const int *rows = idx + (long)gb * m * ns;
+    const int lim = limit ? max(limit[gb], 1) : 0x7fffffff;
     for (int c = tid; c < m; c += T) cnts[c] = 1;
     __syncthreads();
     if ((ns & 3) == 0) {
@@ -110,7 +116,7 @@ __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, cons
     for (int t = tid; t < ntiles; t += T) tilecloud[base + t] = b;
     unsigned int *dst = rowinfo + (long)base * PK_ROWS;
     float4 *dxyz = rowdxyz + (long)base * PK_ROWS;
-    const float *cloud = xyz + (long)b * n * 3;
+    const float *cloud = xyz + (long)gb * n * 3;
     // rows beyond `total` fill the cloud's last tile with copies of its last row (copies do not change a max)
     for (int r = tid; r < ntiles * PK_ROWS; r += T) {
         int c, p;
@@ -129,12 +135,11 @@ __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, cons
         // back to the row's first entry: still a copy of a listed row
         const int v = row[p];
         const int k = v < lim ? v : row[0];
-        const float *ct = new_xyz + ((long)b * m + c) * 3;
+        const float *ct = new_xyz + ((long)gb * m + c) * 3;
         const float *pt = cloud + 3 * (long)k;
         dst[r] = ((unsigned int)c << 16) | (unsigned int)k;
         dxyz[r] = make_float4(pt[0] - ct[0], pt[1] - ct[1], pt[2] - ct[2], 0.f);
     }
-    (void)tiles_cap_cloud;
 }
 
 // ------------------------------------------------------------------------------------------------ C3 = 128
@@ -436,15 +441,16 @@ using namespace prcnn;
 //   hdr      [4] u32: [0] = number of tiles, [1] = number of distinct rows (both written by this call)
 // with tiles_cap = ceil(m * nsample / 64) tiles per cloud at most.  Needs m, n <= 65536.
 // limit (b) i32, optional: points k >= limit[cloud] are copies of point k % limit[cloud] (see ball_pack_kernel).
-extern "C" int prcnn_ball_pack(int b, int n, int m, int nsample, const int *idx, const int *limit, const float *xyz,
-                               const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr,
-                               void *stream)
+static int ball_pack_launch(int b, int group, int n, int m, int nsample, const int *idx, const int *limit, const float *xyz,
+                            const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr, void *stream)
 {
     PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 1, "ball_pack: bad sizes");
+    PRCNN_REQUIRE(group >= 1 && b % group == 0, "ball_pack: %d clouds do not split into lists of %d", b, group);
     PRCNN_REQUIRE(m <= 65536 && m <= 15360, "ball_pack: m=%d centres per cloud unsupported (<= 15360)", m);
     PRCNN_REQUIRE(hdr, "ball_pack: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(hdr, 0, 4 * sizeof(unsigned int), st) != hipSuccess) { set_error("ball_pack: memset failed"); return PRCNN_ELAUNCH; }
+    const int lists = b > 0 ? b / group : 1;
+    if (hipMemsetAsync(hdr, 0, (size_t)lists * 4 * sizeof(unsigned int), st) != hipSuccess) { set_error("ball_pack: memset failed"); return PRCNN_ELAUNCH; }
     if (b == 0 || m == 0) return PRCNN_OK;
     PRCNN_REQUIRE(idx && rowinfo && tilecloud && xyz && new_xyz && rowdxyz, "ball_pack: null pointer");
     PRCNN_REQUIRE(((uintptr_t)rowdxyz & 15) == 0, "ball_pack: rowdxyz must be 16-byte aligned");
@@ -458,8 +464,26 @@ extern "C" int prcnn_ball_pack(int b, int n, int m, int nsample, const int *idx,
     }
     const int cap = (int)(((long)m * nsample + PK_ROWS - 1) / PK_ROWS);
     hipLaunchKernelGGL(ball_pack_kernel, dim3(b), dim3(threads), lds, st, n, m, nsample, cap, idx, limit, xyz, new_xyz, rowinfo,
-                       (float4 *)rowdxyz, tilecloud, hdr);
+                       (float4 *)rowdxyz, tilecloud, hdr, group);
     return check_launch("ball_pack");
+}
+
+extern "C" int prcnn_ball_pack(int b, int n, int m, int nsample, const int *idx, const int *limit, const float *xyz,
+                               const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr,
+                               void *stream)
+{
+    return ball_pack_launch(b, b > 0 ? b : 1, n, m, nsample, idx, limit, xyz, new_xyz, rowinfo, rowdxyz, tilecloud, hdr, stream);
+}
+
+// The same for b = lists x group clouds in ONE launch: list l = clouds [l group, (l + 1) group) gets its own row list
+//   rowinfo / rowdxyz  [lists][group * tiles_cap * 64], tilecloud [lists][group * tiles_cap] (cloud index inside the list),
+//   hdr [lists][4]
+// -- the packed row lists of every batch of a geometry group (one list per batch: each batch's kernels walk their own tiles).
+extern "C" int prcnn_ball_pack_groups(int b, int group, int n, int m, int nsample, const int *idx, const int *limit, const float *xyz,
+                                      const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr,
+                                      void *stream)
+{
+    return ball_pack_launch(b, group, n, m, nsample, idx, limit, xyz, new_xyz, rowinfo, rowdxyz, tilecloud, hdr, stream);
 }
 
 // The fused set-abstraction MLP over packed rows (prcnn_ball_pack): P (b,n,128) = features @ W1f^T + b1, wxyz (3,128),

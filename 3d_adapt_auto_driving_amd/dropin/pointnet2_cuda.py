@@ -238,6 +238,30 @@ def ball_pack_wrapper(idx, xyz, new_xyz, limit=None):
     return pk
 
 
+def ball_pack_groups_wrapper(idx, xyz, new_xyz, group):
+    """ball_pack_wrapper for b = lists x group clouds in ONE launch -> a list of BallPack, one per `group` consecutive clouds
+    (views into shared buffers), each exactly what ball_pack_wrapper returns for idx[l*group:(l+1)*group]."""
+    _chk(torch.int32, idx); _chk(torch.float32, xyz, new_xyz)
+    b, m, ns = idx.shape
+    if group < 1 or b % group:
+        raise ValueError("ball_pack_groups: %d clouds do not split into lists of %d" % (b, group))
+    lists, cap = b // group, (m * ns + 63) // 64
+    L = group * cap
+    rowinfo = torch.empty((lists, L * 64), dtype=torch.int32, device=idx.device)
+    rowdxyz = torch.empty((lists, L * 64, 4), dtype=torch.float32, device=idx.device)
+    tilecloud = torch.empty((lists, L), dtype=torch.int32, device=idx.device)
+    hdr = torch.empty((lists, 4), dtype=torch.int32, device=idx.device)
+    _lib.call("prcnn_ball_pack_groups", b, group, xyz.size(1), m, ns, idx.data_ptr(), None, xyz.data_ptr(), new_xyz.data_ptr(),
+              rowinfo.data_ptr(), rowdxyz.data_ptr(), tilecloud.data_ptr(), hdr.data_ptr(), _lib.current_stream(idx))
+    out = []
+    for l in range(lists):
+        pk = BallPack()
+        pk.idx, pk.limit = idx[l * group:(l + 1) * group], None
+        pk.rowinfo, pk.rowdxyz, pk.tilecloud, pk.hdr, pk.max_tiles = rowinfo[l], rowdxyz[l], tilecloud[l], hdr[l], L
+        out.append(pk)
+    return out
+
+
 def sa_packed_mlp_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col, zeroed=False):
     """sa_mlp_fused_wrapper over the distinct rows only (csrc/sa_packed.hip): same arguments with the BallPack of the
     index tensor instead of the index tensor; bit-identical results."""

@@ -346,15 +346,27 @@ class FastPointRCNN:
         self._geometry_level(state, 0)
         geo = self.geometry_finish(state)
         groups = self._point_groups(geo["l_xyz"][0])
+        # the packed row lists: one list per batch (each batch's kernels walk their own tiles), all batches of the group in ONE
+        # launch per (level, scale) when the batches have the same size (4 x 8 launches + 4 x 8 header memsets otherwise)
+        ext = pu.pointnet2
+        same = len(set(sizes)) == 1 and has_entry(ext, "ball_pack_groups_wrapper")
+        gpacks = None
+        if same:
+            gpacks = [[ext.ball_pack_groups_wrapper(ix, geo["l_xyz"][k], lev["new_xyz"], sizes[0])
+                       if (USE_PACKED and (sc[2].packed is not None or sc[2].wide is not None or sc[3] == 0)) else None
+                       for ix, sc in zip(lev["idx"], self.sa[k][1])] for k, lev in enumerate(geo["sa"])]
         out, lo = [], 0
-        for b in sizes:
+        for bi, b in enumerate(sizes):
             hi = lo + b
             g = {"l_xyz": [t[lo:hi] for t in geo["l_xyz"]], "fp": [(i[lo:hi], w[lo:hi]) for i, w in geo["fp"]], "sa": [],
                  "groups": None if groups is None else (groups[0][lo:hi], groups[1][lo:hi])}
             for k, lev in enumerate(geo["sa"]):
                 part = {"sel": lev["sel"][lo:hi], "new_xyz": lev["new_xyz"][lo:hi], "idx": [ix[lo:hi] for ix in lev["idx"]],
                         "pack": [None] * len(lev["idx"])}
-                self._pack_level(k, g["l_xyz"][k], part)
+                if gpacks is not None:
+                    part["pack"] = [None if p is None else p[bi] for p in gpacks[k]]
+                else:
+                    self._pack_level(k, g["l_xyz"][k], part)
                 g["sa"].append(part)
             out.append(g)
             lo = hi

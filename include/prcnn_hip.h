@@ -162,6 +162,12 @@ int prcnn_sa_mlp_fused(int b, int n, int m, int nsample, int c1, int c2, int c3,
 int prcnn_ball_pack(int b, int n, int m, int nsample, const int *idx, const int *limit, const float *xyz,
                     const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr,
                     void *stream);
+/* The same for b = lists x group clouds in one launch: list l = clouds [l group, (l+1) group) gets its own row list and header --
+ * rowinfo / rowdxyz [lists][group * tiles_cap * 64], tilecloud [lists][group * tiles_cap] (cloud index INSIDE the list),
+ * hdr [lists][4].  Used for the packed row lists of the batches of one geometry group (each batch's kernels walk their own tiles). */
+int prcnn_ball_pack_groups(int b, int group, int n, int m, int nsample, const int *idx, const int *limit, const float *xyz,
+                           const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr,
+                           void *stream);
 /* out_is_zero (this entry, prcnn_sa_xyz_mlp_packed, prcnn_packed_layer_segmax): the results arrive through atomicMax into a
  * zeroed slice; 0 = the entry zeroes out[..., out_col : out_col + width) itself, 1 = the caller has zeroed it (one fill for all
  * the scales of a level instead of one strided fill per scale). */

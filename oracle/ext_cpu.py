@@ -162,6 +162,10 @@ class pointnet2_cpu:
         return _CpuPack(idx, limit)
 
     @staticmethod
+    def ball_pack_groups_wrapper(idx, xyz, new_xyz, group):
+        return [_CpuPack(idx[l:l + group], None) for l in range(0, idx.shape[0], group)]
+
+    @staticmethod
     def sa_packed_mlp_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col, zeroed=False):
         return pointnet2_cpu.sa_mlp_fused_wrapper(new_xyz, xyz, P, wxyz, pack.idx, w2t, b2, w3t, b3, out, out_col)
 

@@ -113,6 +113,35 @@ def test_packed_kernel_bit_identical_to_unpacked_and_to_oracle(ext, c3, mean_cnt
         assert np.array_equal(d[:, :3], xc[want_rows & 0xffff] - cc[want_rows >> 16])
 
 
+def test_grouped_pack_equals_the_pack_of_every_batch(ext):
+    """prcnn_ball_pack_groups: the row lists of several batches in one launch == prcnn_ball_pack on each batch's slice (tile
+    counts, row counts, rows, relative coordinates; the order of a list's tiles may differ -- tiles are allocated by an atomic
+    counter -- so tiles are compared cloud by cloud)."""
+    rng = np.random.default_rng(123)
+    lists, group, n, m, ns = 3, 4, 256, 37, 16
+    b = lists * group
+    xyz = T(rng.uniform(-2, 2, (b, n, 3)).astype(np.float32))
+    new_xyz = T(rng.uniform(-2, 2, (b, m, 3)).astype(np.float32))
+    idx_np, cnt = ball_like_idx(rng, b, m, n, ns, 3.0)
+    idx = T(idx_np)
+    packs = ext.pointnet2.ball_pack_groups_wrapper(idx, xyz, new_xyz, group)
+    assert len(packs) == lists
+    for l, pk in enumerate(packs):
+        lo, hi = l * group, (l + 1) * group
+        one = ext.pointnet2.ball_pack_wrapper(idx[lo:hi].contiguous(), xyz[lo:hi].contiguous(), new_xyz[lo:hi].contiguous())
+        assert pk.max_tiles == one.max_tiles
+        ha, hb = pk.hdr.cpu().numpy(), one.hdr.cpu().numpy()
+        assert ha[0] == hb[0] and ha[1] == hb[1] == cnt[lo:hi].sum()
+        tiles = int(ha[0])
+        def by_cloud(p):
+            tc = p.tilecloud.cpu().numpy()[:tiles]
+            info = p.rowinfo.cpu().numpy().view(np.uint32)[:tiles * 64].reshape(tiles, 64)
+            d = p.rowdxyz.cpu().numpy()[:tiles * 64].reshape(tiles, 64, 4)
+            return [(info[tc == c], d[tc == c]) for c in range(group)]
+        for (ia, da), (ib, db) in zip(by_cloud(pk), by_cloud(one)):
+            assert np.array_equal(ia, ib) and np.array_equal(da, db)
+
+
 def test_packed_kernel_on_arbitrary_index_rows(ext):
     """cnt = 1 + (last slot that differs from slot 0): correct for ANY index tensor, not only ball-query output --
     random rows with repeats anywhere, rows of one repeated index, and strictly distinct rows."""
