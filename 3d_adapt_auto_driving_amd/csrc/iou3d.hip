@@ -212,6 +212,88 @@ __device__ __forceinline__ RBox load_col(const float *p)
     return r;
 }
 
+// ---- quota form: max_keep <= NMS_QUOTA_MAX (the proposal layer keeps 70 + 30 of up to 6300 + 2700 boxes per scene) ------------
+// The general kernel below lets the kept rows of a block knock out EVERY later column before it moves on: 6236 columns x 64
+// rows of IoUs after the first block of a 6300-box problem whose quota is reached inside the second block (0.22 ms, the
+// longest kernel of the proposal stream).  Here the kept boxes (at most max_keep of them) stay in LDS and a block's 64 columns
+// are tested against them when the block is staged: 64 x kept IoUs per block, nothing for columns that are never reached.
+// Same decisions: a column is dropped iff an earlier KEPT row overlaps it (row, column argument order as nms_kernel :285).
+constexpr int NMS_QUOTA_MAX = 256;
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_quota_kernel(
+    int n_max, const int *__restrict__ counts, const float *__restrict__ boxes_all, float thresh,
+    int max_keep, int *__restrict__ keep_all, int *__restrict__ num_keep_all)
+{
+    __shared__ float s_row[64 * 7];             // the 64 row boxes of the block
+    __shared__ float s_kbox[NMS_QUOTA_MAX * 7]; // the kept boxes so far (same 7-float slots as s_row)
+    __shared__ unsigned long long s_diag[64];   // word(c): rows of the block with IoU > thresh, r < c
+    __shared__ unsigned long long s_gone;       // columns of the block dropped by earlier kept rows
+    __shared__ int s_nkeep;
+
+    const int prob = blockIdx.x;
+    int n = counts ? counts[prob] : n_max;
+    n = min(max(n, 0), n_max);
+    const float *__restrict__ boxes = boxes_all + (long)prob * n_max * 5;
+    int *__restrict__ keep = keep_all + (long)prob * max_keep;
+    const int t = threadIdx.x;
+    for (int i = t; i < max_keep; i += NMS_THREADS) keep[i] = -1;
+    if (t == 0) s_nkeep = 0;
+    __syncthreads();
+
+    const int nblocks = (n + 63) / 64;
+    for (int rb = 0; rb < nblocks; ++rb) {
+        const int r0 = rb * 64;
+        const int rows = min(64, n - r0);
+        const int nk0 = s_nkeep;                 // kept before this block
+        if (t < rows) {
+            const float *p = boxes + (long)(r0 + t) * 5;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) s_row[t * 7 + q] = p[q];
+        }
+        if (t < 64) s_diag[t] = 0ull;
+        if (t == 0) s_gone = 0ull;
+        __syncthreads();
+        // A: the block's columns against the kept boxes of earlier blocks; B: against the earlier rows of the block itself.
+        //    item = (column, chunk): 512 threads = 64 columns x 8 chunks
+        {
+            const int cl = t & 63, ch = t >> 6;
+            if (cl < rows) {
+                RBox C;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) C.v[q] = s_row[cl * 7 + q];
+                C.cosv = 1.f; C.sinv = 0.f;
+                bool gone = false;
+                for (int k = ch; k < nk0 && !gone; k += 8) gone = aabox_iou(&s_kbox[k * 7], C.v) > thresh;
+                if (gone) atomicOr(&s_gone, 1ull << cl);
+                const int rlo = ch * NMS_RCH, rhi = min(rlo + NMS_RCH, cl);
+                unsigned long long w = 0;
+                for (int r = rlo; r < rhi; ++r)
+                    if (aabox_iou(&s_row[r * 7], C.v) > thresh) w |= 1ull << r;
+                if (w) atomicOr(&s_diag[cl], w);
+            }
+        }
+        __syncthreads();
+        // C: serial resolve of the 64 rows, exactly the host loop of iou3d.cpp:100-119
+        if (t == 0) {
+            unsigned long long kept = 0;
+            const unsigned long long gone = s_gone;
+            int nk = nk0;
+            for (int cl = 0; cl < rows && nk < max_keep; ++cl) {
+                if ((gone >> cl) & 1ull) continue;
+                if (s_diag[cl] & kept) continue;
+                kept |= 1ull << cl;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) s_kbox[nk * 7 + q] = s_row[cl * 7 + q];
+                keep[nk++] = r0 + cl;
+            }
+            s_nkeep = nk;
+        }
+        __syncthreads();
+        if (s_nkeep >= max_keep) break;
+    }
+    if (t == 0) num_keep_all[prob] = s_nkeep;
+}
+
 template <bool ROTATED>
 __global__ __launch_bounds__(NMS_THREADS) void nms_lazy_kernel(
     int n_max, const int *__restrict__ counts, const float *__restrict__ boxes_all, float thresh,
@@ -318,8 +400,11 @@ int nms_device(int nprob, int n_max, const int *counts, const float *boxes, floa
     PRCNN_REQUIRE(n_max <= NMS_MAX_N, "nms: %d boxes > %d unsupported", n_max, NMS_MAX_N);
     if (nprob == 0) return PRCNN_OK;
     PRCNN_REQUIRE(num_keep && (keep || max_keep == 0) && (boxes || n_max == 0), "nms: null pointer");
+    static const bool quota_form = !(getenv("PRCNN_NMS_QUOTA") && atoi(getenv("PRCNN_NMS_QUOTA")) == 0);   // A/B switch, same results
     if (rotated)
         hipLaunchKernelGGL(nms_lazy_kernel<true>, dim3(nprob), dim3(NMS_THREADS), 0, st, n_max, counts, boxes, thresh, max_keep, keep, num_keep);
+    else if (quota_form && max_keep >= 1 && max_keep <= NMS_QUOTA_MAX)
+        hipLaunchKernelGGL(nms_quota_kernel, dim3(nprob), dim3(NMS_THREADS), 0, st, n_max, counts, boxes, thresh, max_keep, keep, num_keep);
     else
         hipLaunchKernelGGL(nms_lazy_kernel<false>, dim3(nprob), dim3(NMS_THREADS), 0, st, n_max, counts, boxes, thresh, max_keep, keep, num_keep);
     return check_launch("nms");

@@ -319,17 +319,21 @@ def test_nms_rotated(ext, oracle, n, thresh):
     assert k == len(want) and np.array_equal(keep[:k].numpy(), want)
 
 
-def test_nms_device_batched_prefix(ext, oracle):
+@pytest.mark.parametrize("K,thresh,spread", [(70, 0.8, 15.0), (70, 0.3, 6.0), (256, 0.2, 4.0), (300, 0.3, 6.0)])
+def test_nms_device_batched_prefix(ext, oracle, K, thresh, spread):
+    """The quota kernel (max_keep <= 256: a block's columns are tested against the KEPT boxes when the block is staged) and
+    the general kernel (kept rows knock out all later columns) == the first K entries of the oracle's greedy list; dense
+    boxes and low thresholds so that most drops come from boxes kept many blocks earlier."""
     rng = np.random.default_rng(12)
-    P, nmax, K = 6, 3000, 70
+    P, nmax = 6, 3000
     counts = np.array([3000, 2999, 64, 0, 1500, 1], np.int32)
-    boxes = np.stack([bev_boxes(rng, nmax, spread=15.0, rotated=False) for _ in range(P)], 0)
+    boxes = np.stack([bev_boxes(rng, nmax, spread=spread, rotated=False) for _ in range(P)], 0)
     keep = torch.empty((P, K), dtype=torch.int32, device=DEV)
     num = torch.empty((P,), dtype=torch.int32, device=DEV)
-    ext.iou3d.nms_device(T(boxes), T(counts), 0.8, False, K, keep, num)
+    ext.iou3d.nms_device(T(boxes), T(counts), thresh, False, K, keep, num)
     keep, num = keep.cpu().numpy(), num.cpu().numpy()
     for p in range(P):
-        want = oracle.nms_normal(boxes[p, :counts[p]], 0.8)[:K]
+        want = oracle.nms_normal(boxes[p, :counts[p]], thresh)[:K]
         assert num[p] == len(want)
         assert np.array_equal(keep[p, :num[p]], want)
         assert (keep[p, num[p]:] == -1).all()
