@@ -49,6 +49,7 @@ USE_SCALE_BATCH = os.environ.get("PRCNN_NO_SCALE_BATCH") is None
 # layers 1-3 + pool of a wide scale in one kernel (csrc/sa_wide.hip); PRCNN_NO_WIDE_FUSED=1: gather / layer / layer+pool launches
 USE_WIDE_FUSED = os.environ.get("PRCNN_NO_WIDE_FUSED") is None
 # RoI pooling culls by 64-point spatial groups of the scene (built with the geometry chain); PRCNN_NO_POOL_GROUPS=1: full sweep
+USE_XYZ_LEVEL_EARLY = os.environ.get("PRCNN_NO_XYZ_EARLY") != "1"    # coordinates-only SA level 0 computed with the geometry (side stream)
 USE_POOL_GROUPS = os.environ.get("PRCNN_NO_POOL_GROUPS") is None
 
 
@@ -368,6 +369,7 @@ class FastPointRCNN:
                 else:
                     self._pack_level(k, g["l_xyz"][k], part)
                 g["sa"].append(part)
+            self._xyz_level(g)
             out.append(g)
             lo = hi
         return out
@@ -385,7 +387,35 @@ class FastPointRCNN:
         """FPS / ball-query / three-NN of the RPN backbone for xyz (B,N,3)."""
         geo = self.geometry_finish(self.geometry_begin(xyz))
         geo["groups"] = self._point_groups(xyz)
+        self._xyz_level(geo)
         return geo
+
+    def _xyz_level(self, geo):
+        """SA level 0 of a coordinates-only backbone (USE_INTENSITY False: no input features) depends on xyz and the model's
+        weights only -- not on any feature tensor -- so it is computed WITH the geometry, on the geometry's stream (the pipelined
+        runner: a side stream, off the feature stream's critical path: 0.05 ms of a 1.7 ms step).  Stored as geo["sa"][0]["out"];
+        `_backbone` then starts at level 1.  Same kernels, same arguments as `_sa_scale` would use: same bits."""
+        if not (USE_XYZ_LEVEL_EARLY and USE_PACKED and USE_XYZ_MLP and self.sa):
+            return
+        ext = pu.pointnet2
+        npoint, scales = self.sa[0]
+        lev = geo["sa"][0]
+        packs = lev.get("pack") or [None] * len(scales)
+        ok = all(sc[3] == 0 and pk is not None and len(sc[2].layers) == 3 and all(l[2] for l in sc[2].layers) and
+                 ext.sa_xyz_mlp_supported(sc[2].layers[0][0].shape[1], sc[2].layers[1][0].shape[1], sc[2].layers[2][0].shape[1], sc[1])
+                 for sc, pk in zip(scales, packs))
+        if not ok or not has_entry(ext, "sa_xyz_mlp_packed_wrapper"):
+            return
+        xyz, new_xyz = geo["l_xyz"][0], lev["new_xyz"]
+        width = sum(sc[2].layers[-1][0].shape[1] for sc in scales)
+        wpad = _round128(width) if PAD128 else width
+        out = torch.zeros((xyz.shape[0], npoint, wpad), dtype=torch.float32, device=xyz.device)
+        col = 0
+        for (radius, ns, mlp, cin), pk in zip(scales, packs):
+            (w1, b1, _), (w2, b2, _), (w3, b3, _) = mlp.layers
+            ext.sa_xyz_mlp_packed_wrapper(new_xyz, xyz, pk, w1, b1, w2, b2, w3, b3, out, col, True)
+            col += w3.shape[1]
+        lev["out"] = out
 
     # ------------------------------------------------------------------ building blocks
     @staticmethod
@@ -495,10 +525,15 @@ class FastPointRCNN:
             width = sum(s[2].layers[-1][0].shape[1] for s in scales)
             shapes.append((B, npoint, _round128(width) if PAD128 else width))   # consumers (next level's per-point part, FP skip) read 128s
             pres.append(bool(USE_PACKED and all(sc[2].packed is not None or sc[2].wide is not None or sc[3] == 0 for sc in scales)))
-        sizes = [sh[0] * sh[1] * sh[2] if pr else 0 for sh, pr in zip(shapes, pres)]
+        # levels that came with the geometry (the coordinates-only level 0, `_xyz_level`)
+        early = [lev.get("out") if (lev.get("out") is not None and tuple(lev["out"].shape) == sh) else None for lev, sh in zip(geo["sa"], shapes)]
+        sizes = [sh[0] * sh[1] * sh[2] if (pr and e is None) else 0 for sh, pr, e in zip(shapes, pres, early)]
         arena = torch.zeros((sum(sizes),), dtype=torch.float32, device=xyz.device) if sum(sizes) else None
         offs = [sum(sizes[:k]) for k in range(len(sizes))]
         for k, ((npoint, scales), lev) in enumerate(zip(self.sa, geo["sa"])):
+            if early[k] is not None:
+                l_feat.append(early[k])
+                continue
             cur_xyz, cur_feat = l_xyz[len(l_feat) - 1], l_feat[-1]
             width = sum(s[2].layers[-1][0].shape[1] for s in scales)
             wpad = shapes[k][2]
