@@ -169,7 +169,7 @@ class PipelinedRunner:
         # default priority: with the SA levels on the packed MFMA kernels the feature pass is short, and high-priority side
         # streams (three of them at depth 3) starve it -- measured 971 vs 1375 scenes/s
         prio = int(os.environ.get("PRCNN_SIDE_PRIORITY", "0"))
-        self._shared_tail, self.sides = _runner_streams(self.device, 2 if self.group > 1 else max(1, self.depth), prio)
+        self._shared_tail, self.sides = _runner_streams(self.device, int(os.environ.get("PRCNN_SIDE_STREAMS", "2")) if self.group > 1 else max(1, self.depth), prio)
         self._next_side = 0
         self._pending = []        # [(batch tensor, geometry dict, ready event)] in launch order
 
@@ -301,11 +301,19 @@ class PipelinedRunner:
         for _, ev_read, _ in mine:
             side.wait_event(ev_read)
         del mine
+        evs = []
+
+        def mark(_):                                  # one event per batch: its RPN stage need not wait for the rest of the group
+            e = torch.cuda.Event()
+            e.record(side)
+            evs.append(e)
         with torch.cuda.stream(side):
-            geos = self.engine.geometry_group(batch_list)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        for pts, geo in zip(batch_list, geos):
+            geos = self.engine.geometry_group(batch_list, on_batch_done=mark)
+            if len(evs) != len(geos):
+                ev = torch.cuda.Event()
+                ev.record(side)
+                evs = [ev] * len(geos)
+        for pts, geo, ev in zip(batch_list, geos, evs):
             self._chains.append({"pts": pts, "geo": geo, "ev": ev, "side": side})
 
     def _submit_grouped(self, cur, todo, main):

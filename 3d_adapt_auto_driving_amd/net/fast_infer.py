@@ -49,7 +49,8 @@ USE_SCALE_BATCH = os.environ.get("PRCNN_NO_SCALE_BATCH") is None
 # layers 1-3 + pool of a wide scale in one kernel (csrc/sa_wide.hip); PRCNN_NO_WIDE_FUSED=1: gather / layer / layer+pool launches
 USE_WIDE_FUSED = os.environ.get("PRCNN_NO_WIDE_FUSED") is None
 # RoI pooling culls by 64-point spatial groups of the scene (built with the geometry chain); PRCNN_NO_POOL_GROUPS=1: full sweep
-USE_XYZ_LEVEL_EARLY = os.environ.get("PRCNN_NO_XYZ_EARLY") != "1"    # coordinates-only SA level 0 computed with the geometry (side stream)
+USE_XYZ_LEVEL_EARLY = os.environ.get("PRCNN_NO_XYZ_EARLY") != "1"    # leading SA levels of a coordinates-only backbone computed with the geometry (side stream)
+EARLY_LEVELS = int(os.environ.get("PRCNN_EARLY_LEVELS", "4"))
 USE_POOL_GROUPS = os.environ.get("PRCNN_NO_POOL_GROUPS") is None
 
 
@@ -336,13 +337,16 @@ class FastPointRCNN:
                        for ix, sc in zip(lev["idx"], self.sa[k][1])]
 
     @torch.no_grad()
-    def geometry_group(self, xyz_list):
+    def geometry_group(self, xyz_list, on_batch_done=None):
         """The xyz-only chain for SEVERAL batches in one pass: the serial FPS of a scene occupies one CU for ~6 ms whatever
         the batch, so the chain's latency does not grow with the number of scenes -- its throughput does.  Returns one
         geometry dict per batch (views into the group's tensors; the packed row lists are built per batch)."""
         sizes = [x.shape[0] for x in xyz_list]
         if len(xyz_list) == 1:
-            return [self.geometry(xyz_list[0])]
+            geo1 = [self.geometry(xyz_list[0])]
+            if on_batch_done is not None:
+                on_batch_done(0)
+            return geo1
         state = {"l_xyz": [torch.cat(list(xyz_list), dim=0)], "sa": [], "defer_packs": True}
         self._geometry_level(state, 0)
         geo = self.geometry_finish(state)
@@ -371,6 +375,8 @@ class FastPointRCNN:
                 g["sa"].append(part)
             self._xyz_level(g)
             out.append(g)
+            if on_batch_done is not None:
+                on_batch_done(bi)                               # (the runner records an event here: batch bi can start before the group's last batch is done)
             lo = hi
         return out
 
@@ -391,31 +397,26 @@ class FastPointRCNN:
         return geo
 
     def _xyz_level(self, geo):
-        """SA level 0 of a coordinates-only backbone (USE_INTENSITY False: no input features) depends on xyz and the model's
-        weights only -- not on any feature tensor -- so it is computed WITH the geometry, on the geometry's stream (the pipelined
-        runner: a side stream, off the feature stream's critical path: 0.05 ms of a 1.7 ms step).  Stored as geo["sa"][0]["out"];
-        `_backbone` then starts at level 1.  Same kernels, same arguments as `_sa_scale` would use: same bits."""
-        if not (USE_XYZ_LEVEL_EARLY and USE_PACKED and USE_XYZ_MLP and self.sa):
+        """The first EARLY_LEVELS SA levels of a coordinates-only backbone (USE_INTENSITY False: no input features) depend on xyz
+        and the model's weights only -- so does the whole backbone -- and are computed WITH the geometry, on the geometry's stream
+        (the pipelined runner: a side stream that has slack, off the feature stream's critical path).  Stored as
+        geo["sa"][k]["out"]; `_backbone` starts behind them.  Same kernels, same arguments as in `_backbone`: same bits."""
+        if not (USE_XYZ_LEVEL_EARLY and USE_PACKED and USE_XYZ_MLP and self.sa and self.sa[0][1] and
+                all(sc[3] == 0 for sc in self.sa[0][1])):
             return
-        ext = pu.pointnet2
-        npoint, scales = self.sa[0]
-        lev = geo["sa"][0]
-        packs = lev.get("pack") or [None] * len(scales)
-        ok = all(sc[3] == 0 and pk is not None and len(sc[2].layers) == 3 and all(l[2] for l in sc[2].layers) and
-                 ext.sa_xyz_mlp_supported(sc[2].layers[0][0].shape[1], sc[2].layers[1][0].shape[1], sc[2].layers[2][0].shape[1], sc[1])
-                 for sc, pk in zip(scales, packs))
-        if not ok or not has_entry(ext, "sa_xyz_mlp_packed_wrapper"):
-            return
-        xyz, new_xyz = geo["l_xyz"][0], lev["new_xyz"]
-        width = sum(sc[2].layers[-1][0].shape[1] for sc in scales)
-        wpad = _round128(width) if PAD128 else width
-        out = torch.zeros((xyz.shape[0], npoint, wpad), dtype=torch.float32, device=xyz.device)
-        col = 0
-        for (radius, ns, mlp, cin), pk in zip(scales, packs):
-            (w1, b1, _), (w2, b2, _), (w3, b3, _) = mlp.layers
-            ext.sa_xyz_mlp_packed_wrapper(new_xyz, xyz, pk, w1, b1, w2, b2, w3, b3, out, col, True)
-            col += w3.shape[1]
-        lev["out"] = out
+        l_xyz, prev = geo["l_xyz"], None
+        B = l_xyz[0].shape[0]
+        for k in range(min(EARLY_LEVELS, len(self.sa))):
+            npoint, scales = self.sa[k]
+            lev = geo["sa"][k]
+            packs = lev.get("pack") or [None] * len(scales)
+            pre = bool(all(sc[2].packed is not None or sc[2].wide is not None or sc[3] == 0 for sc in scales))
+            if not pre or any(pk is None for pk in packs):
+                return                                          # a level off the packed kernels: it (and what follows) stays in _backbone
+            width = sum(sc[2].layers[-1][0].shape[1] for sc in scales)
+            out = torch.zeros((B, npoint, _round128(width) if PAD128 else width), dtype=torch.float32, device=l_xyz[0].device)
+            self._sa_level(scales, lev, l_xyz[k], prev, out, True)
+            lev["out"] = prev = out
 
     # ------------------------------------------------------------------ building blocks
     @staticmethod
@@ -514,6 +515,18 @@ class FastPointRCNN:
         ext.packed_layer_batch_wrapper([(a1, w[3], w[4], True, y2, pk) for a1, w, y2, pk in zip(a1s, wides, y2s, pks)])
         ext.packed_layer_segmax_batch_wrapper([(y2, w[5], w[6], pk, B, M, out, c, zeroed) for y2, w, pk, c in zip(y2s, wides, pks, cols)])
 
+    def _sa_level(self, scales, lev, cur_xyz, cur_feat, out, pre):
+        """all scales of one MSG level into out (pre: out is zeroed, the packed kernels pool through atomicMax)"""
+        packs = lev.get("pack") or [None] * len(scales)
+        if (USE_SCALE_BATCH and USE_PACKED and 2 <= len(scales) <= 4 and all(sc[2].wide is not None for sc in scales) and
+                has_entry(pu.pointnet2, "packed_layer_batch_wrapper")):
+            self._sa_level_wide(cur_xyz, lev["new_xyz"], cur_feat, scales, lev["idx"], packs, out, pre)
+        else:
+            col = 0
+            for (radius, ns, mlp, cin), idx, pack in zip(scales, lev["idx"], packs):
+                self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, idx, mlp, cin, out, col, pack=pack, zeroed=pre)
+                col += mlp.layers[-1][0].shape[1]
+
     def _backbone(self, xyz, geo, fuse_tail=False):
         """-> the (B, N, 128) point features; fuse_tail: -> (features, None), or (None, inputs of the fused last stretch)."""
         l_xyz, l_feat = geo["l_xyz"], [None]
@@ -542,15 +555,7 @@ class FastPointRCNN:
                    else torch.empty(shapes[k], dtype=torch.float32, device=xyz.device))
             if wpad > width and not pre:
                 out[:, :, width:] = 0
-            packs = lev.get("pack") or [None] * len(scales)
-            if (USE_SCALE_BATCH and USE_PACKED and 2 <= len(scales) <= 4 and all(sc[2].wide is not None for sc in scales) and
-                    has_entry(pu.pointnet2, "packed_layer_batch_wrapper")):
-                self._sa_level_wide(cur_xyz, lev["new_xyz"], cur_feat, scales, lev["idx"], packs, out, pre)
-            else:
-                col = 0
-                for (radius, ns, mlp, cin), idx, pack in zip(scales, lev["idx"], packs):
-                    self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, idx, mlp, cin, out, col, pack=pack, zeroed=pre)
-                    col += mlp.layers[-1][0].shape[1]
+            self._sa_level(scales, lev, cur_xyz, cur_feat, out, pre)
             l_feat.append(out)
         ext = pu.pointnet2
         for i in range(-1, -(len(self.fp) + 1), -1):          # coarse -> fine
