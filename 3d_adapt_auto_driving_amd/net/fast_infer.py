@@ -51,6 +51,7 @@ USE_WIDE_FUSED = os.environ.get("PRCNN_NO_WIDE_FUSED") is None
 # RoI pooling culls by 64-point spatial groups of the scene (built with the geometry chain); PRCNN_NO_POOL_GROUPS=1: full sweep
 USE_XYZ_LEVEL_EARLY = os.environ.get("PRCNN_NO_XYZ_EARLY") != "1"    # leading SA levels of a coordinates-only backbone computed with the geometry (side stream)
 EARLY_LEVELS = int(os.environ.get("PRCNN_EARLY_LEVELS", "4"))
+GROUP_SA = os.environ.get("PRCNN_NO_GROUP_SA") != "1"                 # ... and over all batches of a geometry group at once
 USE_POOL_GROUPS = os.environ.get("PRCNN_NO_POOL_GROUPS") is None
 
 
@@ -356,7 +357,18 @@ class FastPointRCNN:
         ext = pu.pointnet2
         same = len(set(sizes)) == 1 and has_entry(ext, "ball_pack_groups_wrapper")
         gpacks = None
-        if same:
+        # GROUP_SA: the early SA levels (see _xyz_level) over ALL clouds of the group in one pass -- one row list per (level, scale)
+        # over the group's clouds, one launch per stage instead of one per batch: a quarter of the host's launches for these levels
+        # (the host's enqueue time is what limits a step now).  A cloud's rows do not depend on which list holds them: same bits.
+        # Every batch then gets views of the group's outputs and needs no row lists of its own for those levels.
+        n_early = 0
+        if GROUP_SA:
+            for k in range(min(EARLY_LEVELS, len(self.sa))):
+                self._pack_level(k, geo["l_xyz"][k], geo["sa"][k])
+            self._xyz_level(geo)
+            while n_early < len(geo["sa"]) and geo["sa"][n_early].get("out") is not None:
+                n_early += 1
+        if same and n_early < len(geo["sa"]):
             gpacks = [[ext.ball_pack_groups_wrapper(ix, geo["l_xyz"][k], lev["new_xyz"], sizes[0])
                        if (USE_PACKED and (sc[2].packed is not None or sc[2].wide is not None or sc[3] == 0)) else None
                        for ix, sc in zip(lev["idx"], self.sa[k][1])] for k, lev in enumerate(geo["sa"])]
@@ -368,12 +380,15 @@ class FastPointRCNN:
             for k, lev in enumerate(geo["sa"]):
                 part = {"sel": lev["sel"][lo:hi], "new_xyz": lev["new_xyz"][lo:hi], "idx": [ix[lo:hi] for ix in lev["idx"]],
                         "pack": [None] * len(lev["idx"])}
-                if gpacks is not None:
+                if k < n_early:
+                    part["out"] = lev["out"][lo:hi]             # computed over the whole group above
+                elif gpacks is not None:
                     part["pack"] = [None if p is None else p[bi] for p in gpacks[k]]
                 else:
                     self._pack_level(k, g["l_xyz"][k], part)
                 g["sa"].append(part)
-            self._xyz_level(g)
+            if n_early == 0:
+                self._xyz_level(g)
             out.append(g)
             if on_batch_done is not None:
                 on_batch_done(bi)                               # (the runner records an event here: batch bi can start before the group's last batch is done)
