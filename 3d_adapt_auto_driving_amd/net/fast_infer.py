@@ -51,6 +51,7 @@ USE_WIDE_FUSED = os.environ.get("PRCNN_NO_WIDE_FUSED") is None
 # RoI pooling culls by 64-point spatial groups of the scene (built with the geometry chain); PRCNN_NO_POOL_GROUPS=1: full sweep
 USE_XYZ_LEVEL_EARLY = os.environ.get("PRCNN_NO_XYZ_EARLY") != "1"    # leading SA levels of a coordinates-only backbone computed with the geometry (side stream)
 EARLY_LEVELS = int(os.environ.get("PRCNN_EARLY_LEVELS", "4"))
+EARLY_FP = int(os.environ.get("PRCNN_EARLY_FP", "0"))                 # ... plus this many of the coarsest FP modules
 GROUP_SA = os.environ.get("PRCNN_NO_GROUP_SA") != "1"                 # ... and over all batches of a geometry group at once
 USE_POOL_GROUPS = os.environ.get("PRCNN_NO_POOL_GROUPS") is None
 
@@ -377,6 +378,8 @@ class FastPointRCNN:
             hi = lo + b
             g = {"l_xyz": [t[lo:hi] for t in geo["l_xyz"]], "fp": [(i[lo:hi], w[lo:hi]) for i, w in geo["fp"]], "sa": [],
                  "groups": None if groups is None else (groups[0][lo:hi], groups[1][lo:hi])}
+            if geo.get("fp_out"):
+                g["fp_out"] = {kk: v[lo:hi] for kk, v in geo["fp_out"].items()}
             for k, lev in enumerate(geo["sa"]):
                 part = {"sel": lev["sel"][lo:hi], "new_xyz": lev["new_xyz"][lo:hi], "idx": [ix[lo:hi] for ix in lev["idx"]],
                         "pack": [None] * len(lev["idx"])}
@@ -432,6 +435,15 @@ class FastPointRCNN:
             out = torch.zeros((B, npoint, _round128(width) if PAD128 else width), dtype=torch.float32, device=l_xyz[0].device)
             self._sa_level(scales, lev, l_xyz[k], prev, out, True)
             lev["out"] = prev = out
+        # ... and, with every SA level done, the coarsest EARLY_FP feature-propagation modules (a few thousand rows each: launches
+        # that leave most of the chip idle on the feature stream, and depend on xyz only like everything else here)
+        if EARLY_FP > 0 and all(lev.get("out") is not None for lev in geo["sa"]) and len(geo["sa"]) == len(self.sa):
+            l_feat = [None] + [lev["out"] for lev in geo["sa"]]
+            geo["fp_out"] = {}
+            for i in range(-1, -(min(EARLY_FP, len(self.fp) - 1) + 1), -1):      # coarse -> fine, never the finest (fused with the heads)
+                kk = len(self.fp) + i
+                idx, weight = geo["fp"][kk]
+                l_feat[kk] = geo["fp_out"][kk] = self._fp_module(kk, l_feat[kk + 1], l_feat[kk], idx, weight)
 
     # ------------------------------------------------------------------ building blocks
     @staticmethod
@@ -575,22 +587,30 @@ class FastPointRCNN:
         ext = pu.pointnet2
         for i in range(-1, -(len(self.fp) + 1), -1):          # coarse -> fine
             k = len(self.fp) + i                               # FP module index == fine level
+            if geo.get("fp_out", {}).get(k) is not None:       # came with the geometry (`_xyz_level`)
+                l_feat[k] = geo["fp_out"][k]
+                continue
             known_feat, skip = l_feat[k + 1], l_feat[k]
             idx, weight = geo["fp"][k]
             if fuse_tail and k == 0 and self.rpn_tail is not None and skip is None and known_feat.shape[2] == 256:
                 return None, (known_feat, idx, weight)         # finest level: fused with the heads (rpn_stage)
-            B, n = idx.shape[0], idx.shape[1]
-            c2 = known_feat.shape[2]
-            c1 = 0 if skip is None else skip.shape[2]
-            buf = torch.empty((B, n, c2 + c1), dtype=torch.float32, device=xyz.device)
-            if c1 and c1 % 4 == 0 and c2 % 4 == 0 and has_entry(ext, "three_interpolate_cat_pm_wrapper"):
-                ext.three_interpolate_cat_pm_wrapper(known_feat, idx, weight, skip, buf)      # interpolation + concat, one launch
-            else:
-                ext.three_interpolate_pm_wrapper(known_feat, idx, weight, buf, 0)
-                if c1:
-                    buf[:, :, c2:] = skip
-            l_feat[k] = self.fp[k](buf.view(B * n, c2 + c1)).view(B, n, -1)
+            l_feat[k] = self._fp_module(k, known_feat, skip, idx, weight)
         return (l_feat[0], None) if fuse_tail else l_feat[0]   # (B, N, 128) point-major (zero-padded to 128s under PAD128)
+
+    def _fp_module(self, k, known_feat, skip, idx, weight):
+        """feature-propagation module k: interpolate the coarse features, concatenate the skip features, two layers"""
+        ext = pu.pointnet2
+        B, n = idx.shape[0], idx.shape[1]
+        c2 = known_feat.shape[2]
+        c1 = 0 if skip is None else skip.shape[2]
+        buf = torch.empty((B, n, c2 + c1), dtype=torch.float32, device=known_feat.device)
+        if c1 and c1 % 4 == 0 and c2 % 4 == 0 and has_entry(ext, "three_interpolate_cat_pm_wrapper"):
+            ext.three_interpolate_cat_pm_wrapper(known_feat, idx, weight, skip, buf)      # interpolation + concat, one launch
+        else:
+            ext.three_interpolate_pm_wrapper(known_feat, idx, weight, buf, 0)
+            if c1:
+                buf[:, :, c2:] = skip
+        return self.fp[k](buf.view(B * n, c2 + c1)).view(B, n, -1)
 
     # ------------------------------------------------------------------ full forward
     @torch.no_grad()
