@@ -286,7 +286,7 @@ class PipelinedRunner:
         return rois, roi_scores, ev_prop, rg
 
     # ---- grouped geometry: ONE chain per `group` batches -------------------------------------------------------
-    def _launch_group(self, batch_list):
+    def _launch_group(self, batch_list, urgent=False):
         main = torch.cuda.current_stream(self.device)
         side = self.sides[self._next_side % len(self.sides)]
         self._next_side += 1
@@ -308,7 +308,9 @@ class PipelinedRunner:
             e.record(side)
             evs.append(e)
         with torch.cuda.stream(side):
-            geos = self.engine.geometry_group(batch_list, on_batch_done=mark)
+            # urgent (cold start: the first batch of this group is waited for right now): SA levels batch by batch, so that batch 0
+            # is ready before the other three are computed; otherwise over the group's clouds at once (a quarter of the launches)
+            geos = self.engine.geometry_group(batch_list, on_batch_done=mark, group_sa=False if urgent else None)
             if len(evs) != len(geos):
                 ev = torch.cuda.Event()
                 ev.record(side)
@@ -319,7 +321,7 @@ class PipelinedRunner:
     def _submit_grouped(self, cur, todo, main):
         ch = self._chain(cur)
         if ch is None:                                # cold start (or a caller that looks less far ahead): chain for what is known
-            self._launch_group([cur] + [p for p in todo if self._chain(p) is None][:self.group - 1])
+            self._launch_group([cur] + [p for p in todo if self._chain(p) is None][:self.group - 1], urgent=True)
             ch = self._chain(cur)
         self._chains = [c for c in self._chains if c is not ch]
         # start the next group as soon as a whole group of upcoming batches has no chain yet (with a look-ahead of

@@ -339,7 +339,7 @@ class FastPointRCNN:
                        for ix, sc in zip(lev["idx"], self.sa[k][1])]
 
     @torch.no_grad()
-    def geometry_group(self, xyz_list, on_batch_done=None):
+    def geometry_group(self, xyz_list, on_batch_done=None, group_sa=None):
         """The xyz-only chain for SEVERAL batches in one pass: the serial FPS of a scene occupies one CU for ~6 ms whatever
         the batch, so the chain's latency does not grow with the number of scenes -- its throughput does.  Returns one
         geometry dict per batch (views into the group's tensors; the packed row lists are built per batch)."""
@@ -363,7 +363,7 @@ class FastPointRCNN:
         # (the host's enqueue time is what limits a step now).  A cloud's rows do not depend on which list holds them: same bits.
         # Every batch then gets views of the group's outputs and needs no row lists of its own for those levels.
         n_early = 0
-        if GROUP_SA:
+        if GROUP_SA if group_sa is None else group_sa:
             for k in range(min(EARLY_LEVELS, len(self.sa))):
                 self._pack_level(k, geo["l_xyz"][k], geo["sa"][k])
             self._xyz_level(geo)
