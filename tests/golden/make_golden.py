@@ -12,9 +12,14 @@ The fixtures are DATA (inputs + expected outputs); no reference source is stored
                        operator backend) on a tiny config: weights, input, rois, rcnn_cls, rcnn_reg and the
                        final boxes produced with the reference's own decode + nms_gpu sequence
                        (eval_rcnn.py:516-530,611-629)
+  g9_rotate_iou_ref.npz  the reference's OWN evaluate/rotate_iou.py (K18: host function + kernel + device functions) run by the
+                       numba / numba.cuda interpreter of tests/golden/numba_shim.py (numba's float32 typing rules
+                       reproduced) on 256 x 256 centre-format boxes: random, identical, touching, nested, thin,
+                       axis-aligned and far-apart pairs, all four criteria, plus the mask of pairs that overrun
+                       the reference's 8-point intersection buffer (undefined behaviour on CUDA)
   g10_ap_eval_ref.npz  the reference's AP evaluator (evaluate/eval2.py imported with ``numba.jit`` shimmed to the
-                       identity, an empty ``skimage`` stand-in for kitti_common's unused import, and its ``rotate_iou`` dependency -- a numba.cuda module -- backed by the oracle's
-                       K18 restatement) on 60 synthetic label / result files (the reference needs >= 50 images: it cuts the split into 50 parts): label lines in, mAP arrays,
+                       identity, an empty ``skimage`` stand-in for kitti_common's unused import, and its ``rotate_iou`` dependency -- a numba.cuda module -- IMPORTED FROM THE
+                       REFERENCE and run by the same interpreter; round 2 fed it the oracle's K18 restatement) on 60 synthetic label / result files (the reference needs >= 50 images: it cuts the split into 50 parts): label lines in, mAP arrays,
                        precision / recall curves and the result text out
   g_ops_oracle.npz     oracle outputs for ball query / FPS / three_nn / group / NMS / overlap / rotate_iou
                        on small seeded inputs with the edge cases of SURVEY.md section 8c (regression pins; the
@@ -231,19 +236,19 @@ def g10():
     """Reference AP evaluator on the synthetic label sets (see the header for the two import shims)."""
     import tempfile
     import types
-    numba = types.ModuleType("numba")
+    import numba_shim as NS
+    riou, cu = NS.import_reference_rotate_iou()      # the reference's own K18 (numba + numba.cuda interpreted)
+    calls = {"n": 0, "pairs": 0, "undefined": 0}
+    _ref_eval = riou.rotate_iou_gpu_eval
 
-    def jit(*a, **k):
-        if len(a) == 1 and callable(a[0]) and not k:
-            return a[0]
-        return lambda f: f
-    numba.jit = jit
-    sys.modules["numba"] = numba
-    riou = types.ModuleType("rotate_iou")
-    riou.rotate_iou_gpu_eval = lambda boxes, query_boxes, criterion=-1, device_id=0: O.rotate_iou_eval(
-        np.ascontiguousarray(boxes, dtype=np.float32), np.ascontiguousarray(query_boxes, dtype=np.float32),
-        criterion).astype(boxes.dtype)
-    sys.modules["rotate_iou"] = riou
+    def counted(boxes, query_boxes, criterion=-1, device_id=0):
+        out = _ref_eval(boxes, query_boxes, criterion, device_id)
+        calls["n"] += 1
+        calls["pairs"] += out.size
+        if out.size and cu.last_undefined is not None:
+            calls["undefined"] += int(cu.last_undefined.sum())
+        return out
+    riou.rotate_iou_gpu_eval = counted
     if "skimage" not in sys.modules:                  # kitti_common imports skimage.io for image sizes only (unused here)
         sk = types.ModuleType("skimage")
         sk.io = types.ModuleType("skimage.io")
@@ -288,8 +293,69 @@ def g10():
                                                                 dcb, 2, 0.5, th, fp_pass, False)
             stats.append([i, int(fp_pass), tp, fp, fn, len(thr), float(np.sum(thr))])
     out["image_stats_3d"] = np.array(stats, dtype=np.float64)
+    assert sys.modules["rotate_iou"].__file__.startswith("/root/reference/") and eval2.rotate_iou_gpu_eval is counted
+    assert calls["n"] > 0 and calls["undefined"] == 0, calls
+    out["riou_source"] = np.array("reference evaluate/rotate_iou.py via tests/golden/numba_shim.py: %(n)d calls, %(pairs)d pairs" % calls)
     np.savez_compressed(os.path.join(HERE, "g10_ap_eval_ref.npz"), **out)
-    print("g10:", text.split("\n")[0], "|", text.split("\n")[3])
+    print("g10:", text.split("\n")[0], "|", text.split("\n")[3], "|", calls)
+
+
+def g9_boxes():
+    """256 + 256 centre-format boxes [cx, cy, w, h, angle] with the pair classes VERDICT r2 asked for."""
+    rng = np.random.default_rng(909)
+    n = 256
+
+    def rnd(m, spread):
+        return np.stack([rng.uniform(-spread, spread, m), rng.uniform(-spread, spread, m), rng.uniform(1.4, 2.2, m),
+                         rng.uniform(3.0, 5.0, m), rng.uniform(-np.pi, np.pi, m)], 1)
+    a, q = rnd(n, 9.0), rnd(n, 9.0)
+    q[0:16] = a[0:16]                                                   # identical (diagonal pairs)
+    q[16:24] = a[16:24]; q[16:24, 4] += np.pi                           # identical up to a half turn
+    a[24:32, 4] = 0; q[24:32] = a[24:32]; q[24:32, 0] += a[24:32, 2]    # axis-aligned, touching along an edge
+    a[32:40, 4] = 0; q[32:40] = a[32:40]; q[32:40, 0] += a[32:40, 2]; q[32:40, 1] += a[32:40, 3]   # touching at a corner
+    q[40:56] = a[40:56]; q[40:56, 2:4] *= 0.4                           # nested, same angle
+    q[56:72] = a[56:72]; q[56:72, 2:4] *= 0.3; q[56:72, 4] = rng.uniform(-np.pi, np.pi, 16)       # nested, other angle
+    a[72:88, 2] = 0.05; q[72:88, :2] = a[72:88, :2]                     # thin slivers crossing a box
+    q[88:96, 2] = 0.02; q[88:96, 3] = 0.02                              # tiny boxes
+    a[96:112] = rnd(16, 9.0); a[96:112, :2] += 1000.0                   # far apart from everything
+    a[112:128, 4] = rng.choice([0, np.pi / 2, -np.pi / 2, np.pi], 16)   # axis-aligned angles among rotated ones
+    q[112:128, 4] = rng.choice([0, np.pi / 2, -np.pi / 2, np.pi], 16)
+    q[128:136] = a[128:136]; q[128:136, :2] += rng.normal(0, 1e-3, (8, 2))   # nearly identical
+    a[136:144, 2:4] = [[30.0, 30.0]]                                     # huge boxes that contain many others
+    a[144:160] = rnd(16, 2.0); q[144:160] = rnd(16, 2.0)                # a dense clump: every pair overlaps
+    return a.astype(np.float32), q.astype(np.float32)
+
+
+def _g9_rows(args):
+    lo, hi = args
+    import numba_shim as NS
+    mod, cu = NS.import_reference_rotate_iou()
+    a, q = g9_boxes()
+    res = {}
+    for crit in (-1, 0, 1, 2):
+        res[crit] = NS.reference_rotate_iou_eval(mod, cu, a[lo:hi], q, crit)
+    return lo, hi, res
+
+
+def g9():
+    """The reference's own rotate_iou.py on the interpreter of numba_shim.py (see the header)."""
+    import multiprocessing as mp
+    a, q = g9_boxes()
+    n = a.shape[0]
+    chunks = [(lo, min(lo + 16, n)) for lo in range(0, n, 16)]
+    out = {"boxes": a, "query_boxes": q}
+    iou = {c: np.zeros((n, q.shape[0]), np.float32) for c in (-1, 0, 1, 2)}
+    und = np.zeros((n, q.shape[0]), bool)
+    with mp.get_context("fork").Pool(min(8, os.cpu_count() or 1)) as pool:
+        for lo, hi, res in pool.imap_unordered(_g9_rows, chunks):
+            for c in (-1, 0, 1, 2):
+                iou[c][lo:hi] = res[c][0]
+                und[lo:hi] |= res[c][1]
+    for c in (-1, 0, 1, 2):
+        out["iou_c%d" % c] = iou[c]
+    out["undefined"] = und
+    np.savez_compressed(os.path.join(HERE, "g9_rotate_iou_ref.npz"), **out)
+    print("g9: pairs", und.size, "overlapping", int((iou[2] > 0).sum()), "undefined in the reference", int(und.sum()))
 
 
 def g_ops():
@@ -339,11 +405,9 @@ def g_ops():
 
 if __name__ == "__main__":
     assert H.available(), "/root/reference is not mounted: fixtures can only be regenerated in the build container"
-    g5()
-    g7()
-    g_ops()
-    g8()
-    g10()
+    todo = sys.argv[1:] or ["g5", "g7", "g_ops", "g8", "g9", "g10"]      # e.g. ``make_golden.py g9 g10``
+    for name in todo:
+        {"g5": g5, "g7": g7, "g_ops": g_ops, "g8": g8, "g9": g9, "g10": g10}[name]()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -369,6 +369,28 @@ def test_rotate_iou_eval(oracle):
         np.testing.assert_allclose(out.cpu().numpy(), oracle.rotate_iou_eval(a, q, crit), rtol=0, atol=1e-5)
 
 
+def test_rotate_iou_kernel_vs_reference_python_fixture():
+    """rotate_iou.hip against g9 = output of the reference's OWN evaluate/rotate_iou.py (run in the build container by
+    tests/golden/numba_shim.py), not against the builder's oracle.  The kernel follows the same numba typing
+    (f64 area sum and final ratio), so the only freedom is OCML's f64 cos/sin vs glibc's inside the (float) f64
+    trig contract: tolerance 1e-6 absolute on ratios <= 1 and 1e-5 on areas (criterion 2, values up to ~20 m^2),
+    and at least 99 % of the pairs bit for bit."""
+    import importlib
+    lib = importlib.import_module("3d_adapt_auto_driving_amd._lib")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g9_rotate_iou_ref.npz"))
+    a, q, und = g["boxes"], g["query_boxes"], g["undefined"]
+    ta, tq = T(a), T(q)
+    for crit in (-1, 0, 1, 2):
+        out = torch.full((256, 256), float("nan"), device=DEV)
+        lib.call("prcnn_rotate_iou_eval", 256, 256, ta.data_ptr(), tq.data_ptr(), out.data_ptr(), crit,
+                 lib.current_stream(out))
+        got, want = out.cpu().numpy(), g["iou_c%d" % crit]
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got[~und], want[~und], rtol=0, atol=1e-5 if crit == 2 else 1e-6)
+        same = (got.view(np.uint32) == want.view(np.uint32))[~und].mean()
+        assert same >= 0.99, (crit, same)
+
+
 def test_point_major_kernels(ext, oracle):
     """group_cat_pm / maxpool_pm / three_interpolate_pm against the oracle's channel-major results
     rearranged to the point-major row layout [features | pad | dx dy dz | 0] (pure data movement and

@@ -1,6 +1,9 @@
 """AP evaluator (3d_adapt_auto_driving_amd/kitti_eval.py + csrc/kitti_stats.hip) against the fixture produced
-by the REFERENCE's evaluate/eval2.py (tests/golden/make_golden.py g10: numba.jit shimmed to the identity,
-rotate_iou backed by the oracle's K18 restatement).  On CPU the rotated IoU comes from the oracle too (so this
+by the REFERENCE's evaluate/eval2.py (tests/golden/make_golden.py g10: numba.jit shimmed to the identity, and --
+since round 3 -- its rotate_iou dependency is the REFERENCE's own evaluate/rotate_iou.py run by the numba.cuda
+interpreter of tests/golden/numba_shim.py; ``riou_source`` in the fixture says so: the fixture is no longer
+self-fed on its IoU inputs).  On CPU the rotated IoU comes from the oracle (bit-identical to that reference run:
+tests/test_oracle.py::test_rotate_iou_oracle_equals_the_references_own_python) (so this
 file pins everything around the kernel: label parsing, distance-based difficulty, greedy matching in the
 C-ABI host functions, recall thresholds, PR envelope, mAP, result text); the GPU test swaps in the segmented HIP
 launch and additionally checks it block by block."""
@@ -26,6 +29,7 @@ def fixture_annos():
 
 def check_against_fixture(z, gt, dt):
     KE = pkg("kitti_eval")
+    assert "reference evaluate/rotate_iou.py" in str(z["riou_source"])
     text, ret = KE.get_official_eval_result(gt, dt, 0, "kitti")
     assert text == str(z["result_text"])
     for k in ("Car_3d_easy", "Car_3d_moderate", "Car_3d_hard", "Car_bev_easy", "Car_bev_moderate", "Car_bev_hard",

@@ -223,6 +223,66 @@ def test_rotate_iou_vs_clipper_and_golden(oracle):
     assert oracle.rotate_iou_eval(cb[:0], cb[50:], -1).shape == (0, 30)
 
 
+def test_rotate_iou_oracle_equals_the_references_own_python(oracle):
+    """K18 pinned to REFERENCE-EXECUTED output: g9 holds what the reference's own evaluate/rotate_iou.py
+    (host function :294-329, kernel :261-291, device functions :16-259) computes when its numba / numba.cuda
+    imports are served by the interpreter of tests/golden/numba_shim.py (numba's float32 typing rules
+    reproduced: f32 (op) f32 -> f32, f32 (op) literal -> f64, stores round).  256 x 256 pairs incl. identical,
+    touching, nested, thin, tiny, huge, axis-aligned and far-apart boxes, all four criteria.
+    Tolerance: NONE -- the restatement must reproduce the fixture bit for bit.  (What the fixture cannot see is
+    CUDA's ``__nv_cosf/__nv_sinf`` and NVVM's fma contraction: both sides use (float) f64-libm trig and no
+    contraction)  Pairs flagged ``undefined`` overran the reference's 8-point
+    intersection buffer (rotate_iou.py:234) -- undefined behaviour on CUDA; there the oracle only has to be finite."""
+    g = load("g9_rotate_iou_ref.npz")
+    a, q, und = g["boxes"], g["query_boxes"], g["undefined"]
+    assert a.shape == (256, 5) and q.shape == (256, 5) and und.sum() <= 4
+    assert (g["iou_c2"] > 0).sum() > 5000                     # thousands of genuinely overlapping pairs
+    for crit in (-1, 0, 1, 2):
+        got = oracle.rotate_iou_eval(a, q, crit)
+        want = g["iou_c%d" % crit]
+        assert np.isfinite(got).all()
+        np.testing.assert_array_equal(got[~und].view(np.uint32), want[~und].view(np.uint32))
+    # the classes the fixture was built to hold (make_golden.g9_boxes)
+    iou = g["iou_c-1"]
+    d = np.arange(16)
+    # IDENTICAL boxes: the reference's algorithm lists every shared corner twice (both point_in_quadrilateral tests
+    # pass, rotate_iou.py:183-192) and its fan triangulation over the sorted duplicates returns 0, 1/3 or 1 -- a
+    # property of the reference that the fixture records and the restatement must (and does) reproduce.
+    assert set(np.round(iou[d, d].astype(np.float64), 3).tolist()) <= {0.0, 0.333, 1.0} and (iou[d, d] < 0.5).any()
+    assert np.all(iou[96:112] == 0)                           # far apart
+    nested = g["iou_c0"][np.arange(56, 72), np.arange(56, 72)]   # criterion 0 divides by rbox1 = the QUERY box (:287-291)
+    assert np.all(np.abs(nested - 1) < 1e-4)                  # nested at another angle: inter / area(query) = 1
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/evaluate"), reason="build container only: runs the reference's Python")
+def test_rotate_iou_live_reference_run_matches_oracle(oracle):
+    """The same pin, live: import the reference's rotate_iou.py under the interpreter and compare a fresh random
+    sample with the oracle bit for bit (guards the fixture against going stale with the shim)."""
+    import sys
+    sys.path.insert(0, G)
+    import numba_shim as NS
+    saved = {k: sys.modules.get(k) for k in ("numba", "numba.cuda", "rotate_iou")}
+    try:
+        mod, cu = NS.import_reference_rotate_iou()
+        rng = np.random.default_rng(77)
+
+        def cb(n):
+            return np.stack([rng.uniform(-4, 4, n), rng.uniform(-4, 4, n), rng.uniform(1.4, 2.2, n), rng.uniform(3, 5, n),
+                             rng.uniform(-np.pi, np.pi, n)], 1).astype(np.float32)
+        a, q = cb(70), cb(20)                                  # 70 rows: two thread blocks, the second one ragged
+        for crit in (-1, 1):
+            ref, und = NS.reference_rotate_iou_eval(mod, cu, a, q, crit)
+            got = oracle.rotate_iou_eval(a, q, crit)
+            assert (ref > 0).sum() > 200
+            np.testing.assert_array_equal(got[~und].view(np.uint32), ref[~und].view(np.uint32))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 def test_roipool_vs_compiled_reference_fixture(oracle):
     """g5 holds outputs of the reference's OWN roipool3d.cpp CPU functions (compiled in the build
     container, oracle/Makefile): the oracle must reproduce them bit for bit."""
