@@ -132,9 +132,13 @@ __device__ __forceinline__ int select_points_culled(int pts_num, int sampled, co
     }
     __syncthreads();
     const int total = s_misc[1];
-    if (total > cap) return -1;
     int P = 64;
     while (P < total) P <<= 1;
+    // (1) s_misc shares its words with the sweep's s_cnt -- every wave must have read `total` before a wave that
+    // falls back starts writing them; (2) the sort pads to a power of two, which must fit the `cap` ints of s_hits
+    // (sampled not a power of two, or < 16): otherwise fall back to the sweep as well.
+    __syncthreads();
+    if (total > cap || P > cap) return -1;
     for (int i = total + t; i < P; i += RP_THREADS) s_hits[i] = 0x7fffffff;
     __syncthreads();
     for (int k = 2; k <= P; k <<= 1)

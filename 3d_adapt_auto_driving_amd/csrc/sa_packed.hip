@@ -447,6 +447,7 @@ static int ball_pack_launch(int b, int group, int n, int m, int nsample, const i
     PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 1, "ball_pack: bad sizes");
     PRCNN_REQUIRE(group >= 1 && b % group == 0, "ball_pack: %d clouds do not split into lists of %d", b, group);
     PRCNN_REQUIRE(m <= 65536 && m <= 15360, "ball_pack: m=%d centres per cloud unsupported (<= 15360)", m);
+    PRCNN_REQUIRE(n <= 65536, "ball_pack: n=%d points per cloud unsupported (rowinfo keeps the point in 16 bits)", n);
     PRCNN_REQUIRE(hdr, "ball_pack: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int lists = b > 0 ? b / group : 1;

@@ -163,7 +163,7 @@ class PipelinedRunner:
         # hand over (3 * group: a chain is launched 2 * `group` steps before its first batch is due; with 2 * group the chain -- 7 ms alone,
         # 11 ms beside the feature stream -- was just late for the first batch of every group: +0.5 ms once per group).
         self.group = max(1, int(os.environ.get("PRCNN_GEO_GROUP", "4")))
-        self.depth = int(os.environ.get("PRCNN_GEO_DEPTH", str(3 * self.group if self.group > 1 else 3))) if depth is None else depth
+        self.depth = self.default_depth() if depth is None else depth
         # high priority: the geometry kernels are few, short-lived workgroups on a latency-bound chain;
         # when CU slots free up they should be placed before the feature pass's next workgroups
         # default priority: with the SA levels on the packed MFMA kernels the feature pass is short, and high-priority side
@@ -172,6 +172,12 @@ class PipelinedRunner:
         self._shared_tail, self.sides = _runner_streams(self.device, int(os.environ.get("PRCNN_SIDE_STREAMS", "2")) if self.group > 1 else max(1, self.depth), prio)
         self._next_side = 0
         self._pending = []        # [(batch tensor, geometry dict, ready event)] in launch order
+
+    @staticmethod
+    def default_depth():
+        """Batches of look-ahead a caller should hand over (PRCNN_GEO_DEPTH; 3 x PRCNN_GEO_GROUP by default)."""
+        group = max(1, int(os.environ.get("PRCNN_GEO_GROUP", "4")))
+        return int(os.environ.get("PRCNN_GEO_DEPTH", str(3 * group if group > 1 else 3)))
 
     @property
     def side(self):

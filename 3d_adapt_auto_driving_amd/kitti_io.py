@@ -101,9 +101,12 @@ class KittiSource:
         with open(os.path.join(self.dir, "label_2", "%06d.txt" % idx)) as f:
             return [l for l in f.read().split("\n") if l.strip()]
 
-    def gt_boxes3d(self, idx):
-        """(n,7) f32 [x, y_bottom, z, h, w, l, ry] of the labelled objects of class cfg.CLASSES inside PC_AREA_SCOPE
-        (kitti_rcnn_dataset.py:176-199 filtrate_objects + :224-247 check_pc_range), for the recall statistics."""
+    def gt_boxes3d(self, idx, train_mode=False):
+        """(n,7) f32 [x, y_bottom, z, h, w, l, ry] of the labelled objects of class cfg.CLASSES, for the recall statistics.
+        As the reference's ``filtrate_objects`` (kitti_rcnn_dataset.py:155-176): in EVAL mode the ONLY filter is the class
+        -- every labelled object of the class counts towards total_gt_bbox, in range or not; the PC_AREA_SCOPE test
+        (``check_pc_range`` :186-196, all three axes) applies in TRAIN mode only (``train_mode=True``).  Round 2 dropped
+        out-of-range GT boxes in eval as well (and tested x / z only), which inflated the recall figures."""
         classes = (self.cfg.CLASSES,)
         out = []
         for l in self.label_lines(idx):
@@ -111,9 +114,9 @@ class KittiSource:
             if f[0] not in classes:
                 continue
             h, w, ln, x, y, z, ry = (float(v) for v in f[8:15])
-            if self.cfg.PC_REDUCE_BY_RANGE:
-                (x0, x1), _, (z0, z1) = self.cfg.PC_AREA_SCOPE
-                if not (x0 <= x <= x1 and z0 <= z <= z1):
+            if train_mode and self.cfg.PC_REDUCE_BY_RANGE:
+                (x0, x1), (y0, y1), (z0, z1) = self.cfg.PC_AREA_SCOPE
+                if not (x0 <= x <= x1 and y0 <= y <= y1 and z0 <= z <= z1):
                     continue
             out.append([x, y, z, h, w, ln, ry])
         return np.asarray(out, dtype=np.float32).reshape(-1, 7)
@@ -171,11 +174,14 @@ class DeviceInputStage:
         bufs = self.__dict__.setdefault("_pinned", [None, None])
         k = self.__dict__.get("_flip", 0)
         self._flip = k ^ 1
-        if bufs[k] is None or bufs[k][0].numel() < need:
-            bufs[k] = (torch.empty((need,), dtype=torch.float32).pin_memory(), torch.empty((B * 40 + 64,), dtype=torch.float32).pin_memory(), None)
-        raw, small, ev = bufs[k]
-        if ev is not None:
-            ev.synchronize()                       # the upload that last used this buffer has completed
+        if bufs[k] is not None and bufs[k][2] is not None:
+            bufs[k][2].synchronize()               # the upload that last used this buffer has completed
+        raw, small = (None, None) if bufs[k] is None else bufs[k][:2]
+        if raw is None or raw.numel() < need:      # the two buffers grow INDEPENDENTLY (a later call with more,
+            raw = torch.empty((need,), dtype=torch.float32).pin_memory()     # smaller clouds overran the small one)
+        if small is None or small.numel() < B * 40 + 64:
+            small = torch.empty((B * 40 + 64,), dtype=torch.float32).pin_memory()
+        bufs[k] = (raw, small, None)
         return k, raw, small
 
     def __call__(self, raws, calibs, shapes, scene_ids, lidar_frame=True, image_filter=True, return_choice=False):

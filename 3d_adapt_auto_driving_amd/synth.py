@@ -71,6 +71,97 @@ def subsample_rpn(pts, npoints=16384, npoints_faraway=4000, rng=None):
     return pts[choice]
 
 
+# ---------------------------------------------------------------------------------------------------------
+# LiDAR-shaped scenes (round 3, VERDICT r2 "what's weak" 2): the uniform scene above spreads 16384 points over
+# 80 x 70 m, so most balls of the backbone hold one point and the distinct-row saving is at its
+# best case.  ``lidar_scene`` ray-casts a 64-beam spinning sensor instead, so density falls with range as on
+# KITTI: rings on the ground a few centimetres apart in azimuth near the car, metres apart at 60 m.
+
+def _ray_boxes(d, boxes):
+    """Nearest hit of rays from the origin with directions d (R,3) on oriented boxes
+    (K,7) = [cx, cy, cz, h(y), w(z'), l(x'), ry]  (centre, camera frame, rotation about y) -> t (R,), inf = miss."""
+    t_best = np.full(d.shape[0], np.inf)
+    for cx, cy, cz, h, w, l, ry in boxes:
+        c, s = np.cos(ry), np.sin(ry)
+        # world -> box frame (inverse of x = lx*c + lz*s, z = -lx*s + lz*c)
+        ox, oz = -(cx * c - cz * s), -(cx * s + cz * c)
+        oy = -cy
+        dx, dz = d[:, 0] * c - d[:, 2] * s, d[:, 0] * s + d[:, 2] * c
+        dy = d[:, 1]
+        lo, hi = np.full(d.shape[0], -np.inf), np.full(d.shape[0], np.inf)
+        for o, dd, half in ((ox, dx, l / 2), (oy, dy, h / 2), (oz, dz, w / 2)):
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t1, t2 = (-half - o) / dd, (half - o) / dd
+            par = dd == 0
+            t1 = np.where(par, -np.inf if abs(o) <= half else np.inf, t1)
+            t2 = np.where(par, np.inf if abs(o) <= half else -np.inf, t2)
+            lo = np.maximum(lo, np.minimum(t1, t2))
+            hi = np.minimum(hi, np.maximum(t1, t2))
+        hit = (lo <= hi) & (lo > 0.5)
+        t_best = np.where(hit & (lo < t_best), lo, t_best)
+    return t_best
+
+
+def lidar_raw_with_labels(seed, n_cars=10, az_step_deg=0.1728, ground_y=1.65):
+    """Raw in-scope cloud of one sweep -> (pts (R,3) f32 in ring / azimuth order, car boxes (n_cars,7) f64 =
+    [x, y_bottom, z, h, w, l, ry]).  64 beams between +2 and -24.8 degrees of elevation (HDL-64E), azimuth step
+    0.1728 degrees (10 Hz), +-40.5 degrees of azimuth (the camera's field of view), sensor at the camera origin
+    1.65 m above a slightly rough ground; ~10 cars standing on it, facade segments on both sides of the road,
+    poles and bushes; 2 cm range noise; cut to PC_AREA_SCOPE (lib/config.py:28-30)."""
+    rng = np.random.default_rng(seed)
+    el = np.deg2rad(np.linspace(2.0, -24.8, 64))
+    az = np.deg2rad(np.arange(-40.5, 40.5, az_step_deg))
+    azg, elg = np.meshgrid(az, el)                                  # ring-major, like a .bin file
+    azg, elg = azg.ravel(), elg.ravel()
+    d = np.stack([np.sin(azg) * np.cos(elg), -np.sin(elg), np.cos(azg) * np.cos(elg)], 1)
+    cars, objs = [], []
+    for _ in range(n_cars):
+        x, z, ry = rng.uniform(-12, 12), rng.uniform(6, 62), rng.uniform(-np.pi, np.pi)
+        h, w, l = rng.normal(1.52, 0.08), rng.normal(1.63, 0.06), rng.normal(3.9, 0.3)
+        cars.append([x, ground_y, z, h, w, l, ry])
+        objs.append([x, ground_y - h / 2, z, h, w, l, ry])
+    for side in (-1, 1):                                             # facades: thin long boxes parallel to the road
+        z0 = rng.uniform(0, 8)
+        while z0 < 75:
+            length, height = rng.uniform(6, 25), rng.uniform(2.5, 7)
+            x = side * rng.uniform(9, 24)
+            objs.append([x, ground_y - height / 2, z0 + length / 2, height, length, 0.4, 0.0])
+            z0 += length + rng.uniform(1, 12)
+    for _ in range(int(rng.integers(8, 16))):                        # poles / trunks
+        objs.append([rng.uniform(-20, 20), ground_y - 2.5, rng.uniform(5, 68), 5.0, 0.25, 0.25, 0.0])
+    for _ in range(int(rng.integers(6, 14))):                        # bushes, bins, pedestrians' bulk
+        h = rng.uniform(0.6, 1.8)
+        objs.append([rng.uniform(-18, 18), ground_y - h / 2, rng.uniform(4, 66), h, rng.uniform(0.5, 2), rng.uniform(0.5, 2),
+                     rng.uniform(-np.pi, np.pi)])
+    t = _ray_boxes(d, objs)
+    with np.errstate(divide="ignore"):
+        tg = np.where(d[:, 1] > 1e-6, ground_y / d[:, 1], np.inf)   # ground plane y = ground_y (camera y points down)
+    on_ground = tg < t
+    t = np.minimum(t, tg)
+    keep = np.isfinite(t) & (t < 120.0)
+    t = t + 0.02 * rng.standard_normal(t.shape)
+    pts = d * t[:, None]
+    pts[:, 1] += np.where(on_ground, 0.03 * rng.standard_normal(t.shape), 0.0)      # ground roughness
+    scope = (np.abs(pts[:, 0]) < 40) & (pts[:, 1] > -1) & (pts[:, 1] < 3) & (pts[:, 2] > 0) & (pts[:, 2] < 70.4)
+    pts = pts[keep & scope].astype(np.float32)
+    return pts, np.array(cars, dtype=np.float64).reshape(-1, 7)
+
+
+def lidar_scene_with_labels(seed, n=16384, n_cars=10):
+    """One LiDAR-shaped scene of exactly n points: the raw sweep above through the reference's near / far
+    sampler (kitti_rcnn_dataset.py:288-324: every point beyond 40 m, the rest from the near points, shuffled)."""
+    raw, boxes = lidar_raw_with_labels(seed, n_cars)
+    return subsample_rpn(raw, n, rng=np.random.default_rng(seed + 7919)), boxes
+
+
+def lidar_scene(seed, n=16384, n_cars=10):
+    return lidar_scene_with_labels(seed, n, n_cars)[0]
+
+
+def lidar_scenes(b, n=16384, seed0=0):
+    return np.stack([lidar_scene(seed0 + i, n) for i in range(b)], 0)
+
+
 class SyntheticCalib:
     """KITTI-like P2 (f = 707.05, cu = 604, cv = 180), 375 x 1242 image; rect == camera frame.
     corners3d_to_img_boxes follows pointrcnn/lib/utils/calibration.py:107-125."""

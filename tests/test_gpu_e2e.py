@@ -202,9 +202,9 @@ def test_full_size_batch8_engine_gpu_vs_engine_on_cpu_oracle_every_box():
     """BASELINE configs[2] at its batch of 8, default.yaml shapes: the ENGINE on the GPU against the SAME engine code on CPU
     tensors with the oracle as operator backend (oracle/ext_cpu.py: scalar C restatements; the MLP kernels in their fixed
     fma-chain order).  Every operator this build owns is bit-exact against that backend (tests/test_gpu_shadow.py), so what
-    is left between the two runs is (a) the seven library GEMMs whose K or N is not a multiple of 128 (FP level 1, the last
-    head layers, the K = 96 per-point part of RPN SA2: hipBLASLt vs MKL summation order), (b) torch's elementwise glue
-    (sigmoid, norm, reciprocal) and (c) f32 sin / cos of two libraries in the decoders.  The bar of BASELINE.json's north
+    is left between the two runs is (a) torch's elementwise glue (sigmoid, norm, reciprocal) and (b) f32 sin / cos of two
+    libraries in the decoders -- no library GEMM is left on either side since the end of round 2 (every width is zero-padded to a
+    multiple of 128 and runs on this build's layer kernels, whose order the oracle backend reproduces).  The bar of BASELINE.json's north
     star, for EVERY box: 100 % of the RoIs and 100 % of the final boxes matched one to one, within 1e-4; equal counts."""
     from oracle import ext_cpu
     C, E, F, S = pkg("config"), pkg("eval_rcnn"), pkg("net.fast_infer"), pkg("synth")

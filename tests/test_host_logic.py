@@ -309,3 +309,53 @@ def test_config_merge_and_set():
         C.cfg_from_list(cfg, ["RPN.NUM_POINTS", "'x'"])
     with pytest.raises(KeyError):
         C.merge_into({"NOPE": 1}, cfg, strict=True)
+
+
+LABELS_GT = """Car 0.00 0 -1.57 600.0 150.0 650.0 200.0 1.50 1.60 3.90 2.00 1.65 20.00 -1.60
+Car 0.00 1 -1.20 100.0 150.0 180.0 200.0 1.45 1.55 3.70 -55.00 1.70 30.00 0.30
+Car 0.30 2 1.00 700.0 160.0 720.0 175.0 1.50 1.60 4.10 5.00 1.60 85.00 1.57
+Car 0.00 0 1.00 700.0 160.0 720.0 175.0 1.50 1.60 4.10 5.00 4.20 35.00 1.57
+Van 0.00 0 -1.57 300.0 150.0 380.0 210.0 2.10 1.90 5.20 -6.00 1.75 25.00 -1.50
+Pedestrian 0.00 0 0.20 400.0 150.0 420.0 210.0 1.75 0.60 0.80 3.00 1.60 12.00 0.10
+DontCare -1 -1 -10 500.0 160.0 540.0 190.0 -1 -1 -1 -1000 -1000 -1000 -10
+"""
+
+
+def test_recall_gt_set_is_class_only_in_eval_like_the_reference(tmp_path):
+    """the --recall ground truth must be every labelled object of the class -- the reference's
+    filtrate_objects applies check_pc_range in TRAIN mode only (kitti_rcnn_dataset.py:155-176).  The label file holds
+    four Cars: one in range, one beyond x = -40, one beyond z = 70.4, one below y = 3 -> eval keeps all 4, train keeps 1.
+    In the build container the reference's own filtrate_objects is run on the same file and must agree."""
+    K = pkg("kitti_io")
+    cfg = pkg("config").default_eval_cfg()
+    d = tmp_path / "KITTI" / "object" / "training"
+    for sub in ("velodyne", "calib", "label_2"):
+        (d / sub).mkdir(parents=True)
+    (tmp_path / "KITTI" / "ImageSets").mkdir(parents=True)
+    (tmp_path / "KITTI" / "ImageSets" / "val.txt").write_text("000001\n")
+    (d / "label_2" / "000001.txt").write_text(LABELS_GT)
+    src = K.KittiSource(str(tmp_path), cfg, "val")
+    ev = src.gt_boxes3d(1)
+    tr = src.gt_boxes3d(1, train_mode=True)
+    assert ev.shape == (4, 7) and tr.shape == (1, 7)
+    np.testing.assert_allclose(ev[1], [-55.0, 1.70, 30.0, 1.45, 1.55, 3.70, 0.30], rtol=1e-6)
+    np.testing.assert_allclose(tr[0], ev[0])
+    if os.path.isdir("/root/reference/pointrcnn"):
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+        import ref_harness as H
+        H.install()
+        from lib.datasets.kitti_rcnn_dataset import KittiRCNNDataset
+        import lib.utils.kitti_utils as ku
+        from lib.config import cfg as rcfg
+        assert rcfg.PC_REDUCE_BY_RANGE
+        objs = ku.get_objects_from_label(str(d / "label_2" / "000001.txt"))
+
+        class Fake:
+            classes = ("Background", "Car")
+            check_pc_range = staticmethod(KittiRCNNDataset.check_pc_range)
+        for mode, want in (("EVAL", ev), ("TRAIN", tr)):
+            Fake.mode = mode
+            kept = KittiRCNNDataset.filtrate_objects(Fake, objs)
+            ref = ku.objs_to_boxes3d(kept)
+            np.testing.assert_allclose(ref, want, rtol=1e-6)
