@@ -304,8 +304,10 @@ static int launch_ball_query(int b, int n, int m, float radius, int nsample, con
 
 int ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
                     int *idx, int write_empty, hipStream_t st, int *used);   // ball_grid.hip
+int ball_query_dense(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                     int *idx, int write_empty, hipStream_t st, int *used);  // ball_dense.hip
 
-static int g_ball_query_mode = 0;   // 0 auto, 1 brute force only, 2 grid whenever it accepts
+static int g_ball_query_mode = 0;   // 0 auto (bucket-sorted grid, wave per centre), 1 brute force only, 2 linked-list grid (round 1)
 
 static int ball_query_dispatch(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                                const float *xyz, int *idx, int write_empty, hipStream_t st)
@@ -315,6 +317,11 @@ static int ball_query_dispatch(int b, int n, int m, float radius, int nsample, c
     PRCNN_REQUIRE(b <= 65535, "ball_query: batch %d > 65535", b);
     if (b == 0 || m == 0) return PRCNN_OK;
     PRCNN_REQUIRE(new_xyz && xyz && idx, "ball_query: null pointer");
+    if (g_ball_query_mode == 0) {
+        int used = 0;
+        const int rc = ball_query_dense(b, n, m, radius, nsample, new_xyz, xyz, idx, write_empty, st, &used);
+        if (rc != PRCNN_OK || used) return rc;
+    }
     if (g_ball_query_mode != 1) {
         int used = 0;
         const int rc = ball_query_grid(b, n, m, radius, nsample, new_xyz, xyz, idx, write_empty, st, &used);
@@ -332,10 +339,11 @@ static int ball_query_dispatch(int b, int n, int m, float radius, int nsample, c
 
 using namespace prcnn;
 
-// 0 = automatic (hashed grid for n >= 4096, brute force otherwise), 1 = brute force only
+// 0 = automatic (bucket-sorted hashed grid with a wave per centre for n >= 2048, ball_dense.hip; brute force otherwise),
+// 1 = brute force only, 2 = the linked-list hashed grid of round 1 (ball_grid.hip, n >= 4096) instead of the bucket-sorted one
 extern "C" int prcnn_set_ball_query_mode(int mode)
 {
-    PRCNN_REQUIRE(mode >= 0 && mode <= 1, "set_ball_query_mode: mode %d", mode);
+    PRCNN_REQUIRE(mode >= 0 && mode <= 2, "set_ball_query_mode: mode %d", mode);
     g_ball_query_mode = mode;
     return PRCNN_OK;
 }

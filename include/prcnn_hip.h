@@ -47,8 +47,10 @@ int prcnn_opt_n_threads(int work_size);
 int prcnn_ball_query(int b, int n, int m, float radius, int nsample,
                      const float *new_xyz, const float *xyz, int *idx, void *stream);
 
-/* Algorithm selector for ball query (results are identical): 0 = automatic (hashed uniform grid for
- * n >= 4096 points, brute-force scan otherwise), 1 = brute-force scan only.  For tests / profiling. */
+/* Algorithm selector for ball query (results are identical): 0 = automatic (bucket-sorted hashed grid with a
+ * wave per centre for n >= 2048 points -- csrc/ball_dense.hip --, brute-force scan otherwise), 1 = brute-force
+ * scan only, 2 = round 1's linked-list hashed grid (n >= 4096) in place of the bucket-sorted one.  For tests /
+ * profiling. */
 int prcnn_set_ball_query_mode(int mode);
 
 /* group_points_wrapper_fast  src/group_points.cpp:25-36 -> src/group_points_gpu.cu:47-66.

@@ -2,6 +2,8 @@
 through the C ABI of libprcnn_hip.so), against the CPU oracle on the same seeded inputs.
 Index outputs must be bit-exact; float outputs of pure copies/selects bit-exact as well;
 geometric float outputs within the tolerance stated next to the assert."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -75,8 +77,9 @@ def test_ball_query_matches_oracle(ext, oracle, n, m, r, ns):
 @pytest.mark.parametrize("n,m,r,ns", [(16384, 4096, 0.1, 16), (16384, 4096, 0.2, 32), (16384, 4096, 0.5, 32),
                                       (8192, 1000, 1.0, 64), (4096, 1024, 3.0, 16), (16384, 300, 0.05, 8)])
 def test_ball_query_grid_equals_brute_force(ext, oracle, n, m, r, ns):
-    """The hashed-grid path (automatic for n >= 4096) and the brute-force scan return the same bits,
-    also on a cloud with duplicated points, far-away centres and coordinates on cell boundaries."""
+    """The bucket-sorted grid with a wave per centre (mode 0, automatic for n >= 2048: csrc/ball_dense.hip), the brute-force
+    scan (mode 1) and round 1's linked-list grid (mode 2) return the same bits, also on a cloud with duplicated points,
+    far-away centres and coordinates on cell boundaries."""
     import importlib
     lib = importlib.import_module("3d_adapt_auto_driving_amd._lib")
     xyz = scenes(2, n, seed0=n + m)
@@ -85,13 +88,13 @@ def test_ball_query_grid_equals_brute_force(ext, oracle, n, m, r, ns):
     new_xyz = centres(oracle, xyz, m)
     new_xyz[0, 1] = [1e6, 0, -1e6]
     res = []
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         lib.call("prcnn_set_ball_query_mode", mode)
         idx = torch.full((2, m, ns), -3, dtype=torch.int32, device=DEV)
         ext.pointnet2.ball_query_wrapper(2, n, m, r, ns, T(new_xyz), T(xyz), idx)
         res.append(idx.cpu().numpy())
     lib.call("prcnn_set_ball_query_mode", 0)
-    assert np.array_equal(res[0], res[1])
+    assert np.array_equal(res[0], res[1]) and np.array_equal(res[2], res[1])
     want = np.full((2, m, ns), -3, np.int32)
     oracle.ball_query_into(r, ns, xyz, new_xyz, want)
     assert np.array_equal(res[0], want)
@@ -162,6 +165,28 @@ def test_query_and_group_fused(ext, oracle, c):
     want, widx = oracle.query_and_group(r, ns, xyz, new_xyz, feats)
     assert np.array_equal(idx.cpu().numpy(), widx)
     assert np.array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("n,m,r,ns", [(16384, 4096, 0.1, 16), (16384, 4096, 0.5, 32), (16384, 4096, 0.4, 64), (16384, 4096, 2.0, 64),
+                                      (4096, 1024, 0.5, 16), (4096, 1024, 1.0, 32), (2048, 512, 1.0, 32)])
+def test_ball_query_on_lidar_shaped_clouds(ext, oracle, n, m, r, ns):
+    """LiDAR-shaped clouds (synth.lidar_scene: hundreds of points per cell near the sensor, none far away): the regime in
+    which the nsample smallest indices of a FULL ball decide, the wave's sorted insertion runs thousands of times and the
+    chunk pruning of csrc/ball_dense.hip skips most of every bucket range.  Centres = the cloud's own FPS picks (as in the
+    backbone), one cloud with exact duplicates, one centre far outside.  Bit-exact vs the oracle's index-order scan."""
+    import importlib
+    S = importlib.import_module("3d_adapt_auto_driving_amd.synth")
+    xyz = np.stack([S.lidar_scene(11, 16384)[:n], S.lidar_scene(12, 16384)[:n]], 0)
+    xyz[1, n // 2:] = xyz[1, :n // 2]
+    new_xyz = centres(oracle, xyz, m)
+    new_xyz[0, 3] = [700, 2, -700]
+    idx = torch.full((2, m, ns), -5, dtype=torch.int32, device=DEV)
+    ext.pointnet2.ball_query_wrapper(2, n, m, r, ns, T(new_xyz), T(xyz), idx)
+    want = np.full((2, m, ns), -5, np.int32)
+    oracle.ball_query_into(r, ns, xyz, new_xyz, want)
+    assert np.array_equal(idx.cpu().numpy(), want)
+    if r >= 0.4:
+        assert (want[0, :, -1] != want[0, :, 0]).mean() > 0.1       # a good share of the balls are full (14 % at r = 0.4 / 64)
 
 
 @pytest.mark.parametrize("dense", [False, True])
@@ -238,6 +263,24 @@ def test_three_nn_and_interpolate(ext, oracle, n, m):
     out = torch.empty((2, 24, n), device=DEV)
     ext.pointnet2.three_interpolate_wrapper(2, 24, m, n, T(feats), idx, T(w), out)
     assert np.array_equal(out.cpu().numpy(), oracle.three_interpolate(feats, widx, w))  # same rounding sequence
+
+
+@pytest.mark.parametrize("n,m", [(16384, 4096), (4096, 1024)])
+def test_three_nn_on_lidar_shaped_clouds(ext, oracle, n, m):
+    """The FP levels' three_nn on LiDAR-shaped clouds (known = the cloud's FPS picks, as in the backbone): the known points
+    crowd into an eighth of their bounding rectangle, the queries are served in cell order (csrc/three_nn_grid.hip, round 3)
+    and written back at their own position.  One cloud with exact duplicates (distance ties -> lowest index).  Bit-exact."""
+    import importlib
+    S = importlib.import_module("3d_adapt_auto_driving_amd.synth")
+    unknown = np.stack([S.lidar_scene(21, 16384)[:n], S.lidar_scene(22, 16384)[:n]], 0)
+    unknown[1, n // 2:] = unknown[1, :n // 2]
+    known = centres(oracle, unknown, m)
+    d2 = torch.full((2, n, 3), float("nan"), device=DEV)
+    idx = torch.full((2, n, 3), -1, dtype=torch.int32, device=DEV)
+    ext.pointnet2.three_nn_wrapper(2, n, m, T(unknown), T(known), d2, idx)
+    wd2, widx = oracle.three_nn(unknown, known)
+    assert np.array_equal(idx.cpu().numpy(), widx)
+    assert np.array_equal(d2.cpu().numpy(), wd2)
 
 
 def test_three_nn_grid_edge_cases(ext, oracle):
