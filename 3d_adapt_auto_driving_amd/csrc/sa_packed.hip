@@ -43,10 +43,16 @@ constexpr int PK_TILES_PER_WG = 8;
 // its original: the rows of the slots with index >= limit are duplicates of rows already listed and are dropped too.
 // Every listed row also gets its RELATIVE coordinates xyz[point] - new_xyz[centre] (rowdxyz): the subtraction the tile
 // builders used to do (three loads of the point + three of the centre per row) is done once here.
+// `rep` (optional, (b, n) i32, round 3): rep[cloud][k] = the lowest-indexed point of the cloud that is an exact copy of point k
+// (coordinates AND features; k itself when it is the first of its kind) -- the SA1 centres of a RoI that were sampled from
+// wrap-around copies of the same pooled point.  Same argument as for `limit`: a copy lies in a ball iff its representative
+// does, and the representative has the lower index, so it is listed earlier in the same row; the slots whose point is not
+// its own representative are dropped.  They may sit anywhere in a row, so with `rep` the kept slots are a 64-bit MASK per
+// centre (nsample <= 64) instead of a prefix, and output row p of a centre is its p-th kept slot.
 __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, const int *__restrict__ idx, const int *__restrict__ limit,
                                  const float *__restrict__ xyz, const float *__restrict__ new_xyz,
                                  unsigned int *__restrict__ rowinfo, float4 *__restrict__ rowdxyz, int *__restrict__ tilecloud,
-                                 unsigned int *__restrict__ hdr, int group)
+                                 unsigned int *__restrict__ hdr, int group, const int *__restrict__ rep)
 {
     // Both passes are parallel over ELEMENTS, not over centres (a thread per centre left 32 of 256 threads busy on the RoI
     // clouds' second level and walked each centre's rows as a chain of dependent loads: 47 us for 800 clouds x 32 centres):
@@ -57,6 +63,7 @@ __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, cons
     int *cnts = pk_lds;                   // [m]   distinct count per centre
     int *offs = pk_lds + m;               // [m]   exclusive offsets
     int *part = pk_lds + 2 * m;           // [blockDim.x] partial sums, then their inclusive scan
+    unsigned int *keep = reinterpret_cast<unsigned int *>(pk_lds + 2 * m + blockDim.x);   // [2 m] kept-slot masks (only with rep)
     __shared__ int s_base;
     // `group` consecutive clouds share one row list (one batch of a geometry group: csrc entry prcnn_ball_pack_groups): list l =
     // blockIdx.x / group owns its own slice of the outputs and its own header; tiles record the cloud's index INSIDE its list
@@ -67,9 +74,20 @@ __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, cons
     hdr += 4 * list;
     const int *rows = idx + (long)gb * m * ns;
     const int lim = limit ? max(limit[gb], 1) : 0x7fffffff;
+    const int *__restrict__ rp = rep ? rep + (long)gb * n : nullptr;
     for (int c = tid; c < m; c += T) cnts[c] = 1;
+    if (rp)
+        for (int c = tid; c < 2 * m; c += T) keep[c] = (c & 1) ? 0u : 1u;       // slot 0 is always kept
     __syncthreads();
-    if ((ns & 3) == 0) {
+    if (rp) {
+        for (int e = tid; e < m * ns; e += T) {
+            const int c = e / ns, p = e - c * ns;
+            const int v = rows[e];
+            if (p > 0 && v != rows[(long)c * ns] && v < lim && rp[v] == v) atomicOr(&keep[2 * c + (p >> 5)], 1u << (p & 31));
+        }
+        __syncthreads();
+        for (int c = tid; c < m; c += T) cnts[c] = __popc(keep[2 * c]) + __popc(keep[2 * c + 1]);
+    } else if ((ns & 3) == 0) {
         const int q4 = ns >> 2;
         for (int e = tid; e < m * q4; e += T) {
             const int c = e / q4, p = (e - c * q4) * 4;
@@ -131,6 +149,16 @@ __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, cons
             c = m - 1; p = 0;
         }
         const int *row = rows + (long)c * ns;
+        if (rp) {                           // p-th kept slot of the centre: select in its 64-bit mask
+            unsigned long long mm = ((unsigned long long)keep[2 * c + 1] << 32) | keep[2 * c];
+            int slot = 0;
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                const int below = __popcll(mm & ((1ull << sft) - 1ull));
+                if (p >= below) { p -= below; mm >>= sft; slot += sft; }
+            }
+            p = slot;
+        }
         // slots beyond the limit inside the kept prefix (possible only for index rows that are not a ball query's answer) fall
         // back to the row's first entry: still a copy of a listed row
         const int v = row[p];
@@ -442,7 +470,8 @@ using namespace prcnn;
 // with tiles_cap = ceil(m * nsample / 64) tiles per cloud at most.  Needs m, n <= 65536.
 // limit (b) i32, optional: points k >= limit[cloud] are copies of point k % limit[cloud] (see ball_pack_kernel).
 static int ball_pack_launch(int b, int group, int n, int m, int nsample, const int *idx, const int *limit, const float *xyz,
-                            const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr, void *stream)
+                            const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr, void *stream,
+                            const int *rep = nullptr)
 {
     PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 1, "ball_pack: bad sizes");
     PRCNN_REQUIRE(group >= 1 && b % group == 0, "ball_pack: %d clouds do not split into lists of %d", b, group);
@@ -458,15 +487,63 @@ static int ball_pack_launch(int b, int group, int n, int m, int nsample, const i
     PRCNN_REQUIRE(((uintptr_t)idx & 15) == 0 || (nsample & 3) != 0, "ball_pack: 16-byte alignment required");
     int threads = 64;                              // enough threads for the cloud's index elements, 16 bytes each
     while (threads < (int)(((long)m * nsample + 3) / 4) && threads < 1024) threads *= 2;
-    const size_t lds = ((size_t)2 * m + threads) * sizeof(int);
+    PRCNN_REQUIRE(!rep || nsample <= 64, "ball_pack: a representative map needs nsample <= 64 (got %d)", nsample);
+    const size_t lds = ((size_t)2 * m + threads + (rep ? 2 * m : 0)) * sizeof(int);
     if (lds > 48 * 1024) {
         const int rc = ensure_dynamic_lds((const void *)ball_pack_kernel, lds, "ball_pack");
         if (rc != PRCNN_OK) return rc;
     }
     const int cap = (int)(((long)m * nsample + PK_ROWS - 1) / PK_ROWS);
     hipLaunchKernelGGL(ball_pack_kernel, dim3(b), dim3(threads), lds, st, n, m, nsample, cap, idx, limit, xyz, new_xyz, rowinfo,
-                       (float4 *)rowdxyz, tilecloud, hdr, group);
+                       (float4 *)rowdxyz, tilecloud, hdr, group, rep);
     return check_launch("ball_pack");
+}
+
+// prcnn_ball_pack with a representative map (see ball_pack_kernel): rep (b, n) i32, rep[cloud][k] <= k, rep[cloud][rep[cloud][k]] ==
+// rep[cloud][k]; the slots whose point is not its own representative are dropped as well.
+extern "C" int prcnn_ball_pack_rep(int b, int n, int m, int nsample, const int *idx, const int *limit, const int *rep, const float *xyz,
+                                   const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr,
+                                   void *stream)
+{
+    return ball_pack_launch(b, b > 0 ? b : 1, n, m, nsample, idx, limit, xyz, new_xyz, rowinfo, rowdxyz, tilecloud, hdr, stream, rep);
+}
+
+namespace prcnn {
+// rep[cloud][j] = the lowest j' with src(sel[cloud][j']) == src(sel[cloud][j]), where src(i) = prev ? prev[cloud][i] : i % limit[cloud]
+// (limit: the points k >= limit[cloud] are copies of k % limit[cloud]; prev: the representative map of the level below).
+__global__ void dup_rep_kernel(int n, int m, const int *__restrict__ sel, const int *__restrict__ limit, const int *__restrict__ prev,
+                               int *__restrict__ rep)
+{
+    extern __shared__ int first[];             // [n]: lowest j sampled from each source point
+    const int b = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+    for (int i = tid; i < n; i += T) first[i] = 0x7fffffff;
+    __syncthreads();
+    const int lim = limit ? max(limit[b], 1) : 0x7fffffff;
+    const int *__restrict__ s = sel + (long)b * m;
+    const int *__restrict__ pv = prev ? prev + (long)b * n : nullptr;
+    for (int j = tid; j < m; j += T) {
+        const int i = s[j];
+        const int src = pv ? pv[i] : (i >= lim ? i % lim : i);
+        atomicMin(&first[src], j);
+    }
+    __syncthreads();
+    for (int j = tid; j < m; j += T) {
+        const int i = s[j];
+        const int src = pv ? pv[i] : (i >= lim ? i % lim : i);
+        rep[(long)b * m + j] = first[src];
+    }
+}
+}  // namespace prcnn
+
+/* sel (b, m) i32: indices into clouds of n points (an FPS answer).  limit (b) i32 and / or prev (b, n) i32 say which of the n
+ * points are exact copies of one another; rep (b, m) i32 <- for every sampled point the first sampled point of the same source. */
+extern "C" int prcnn_dup_rep(int b, int n, int m, const int *sel, const int *limit, const int *prev, int *rep, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && n >= 1 && m >= 0 && n <= 12288, "dup_rep: bad sizes b=%d n=%d m=%d", b, n, m);
+    if (b == 0 || m == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(sel && rep && (limit || prev), "dup_rep: null pointer");
+    hipLaunchKernelGGL(dup_rep_kernel, dim3(b), dim3(128), (size_t)n * sizeof(int), (hipStream_t)stream, n, m, sel, limit, prev, rep);
+    return check_launch("dup_rep");
 }
 
 extern "C" int prcnn_ball_pack(int b, int n, int m, int nsample, const int *idx, const int *limit, const float *xyz,

@@ -38,6 +38,10 @@ USE_PACKED = os.environ.get("PRCNN_NO_PACK") is None
 # RoI pooling fills a box holding fewer than 512 points by repeating them (roipool3d_kernel.cu:152-159): the per-point
 # RCNN entrance chain and SA1 run over the DISTINCT pooled points only (bit-identical results).  PRCNN_NO_POOL_DEDUP=1: A/B.
 USE_POOL_DEDUP = os.environ.get("PRCNN_NO_POOL_DEDUP") is None
+# ... and the SA1 centres FPS picks among those copies are copies of one another (same coordinates, same ball, same SA1 output):
+# the deeper RCNN levels drop the rows of every point that is not the first of its kind (prcnn_dup_rep + prcnn_ball_pack_rep;
+# round 3: 7.5x fewer SA2 rows on LiDAR-shaped scenes, bit-identical results).  PRCNN_NO_CENTRE_DEDUP=1: A/B.
+USE_CENTRE_DEDUP = os.environ.get("PRCNN_NO_CENTRE_DEDUP") is None
 USE_POINT_LAYER = os.environ.get("PRCNN_LIB_GEMM") is None     # per-point layers (FP modules, heads) on the own MFMA layer kernel
 # every per-point width zero-padded to a multiple of 128 (SA level outputs, FP inputs, narrow head outputs), so that NO layer
 # of the engine is left to a GEMM library: fixed summation order everywhere, reproduced bit for bit by the oracle
@@ -755,12 +759,17 @@ class FastPointRCNN:
         tiles = ext.pooled_tiles_wrapper(pooled_cnt.view(-1), P) if (point_mlp and pooled_cnt is not None) else None
         cur_xyz = flat[:, :, 0:3].contiguous()
         levels = []
+        # representative map of the CURRENT level's points (None: every point counts as distinct): which of them are exact copies
+        # of one another.  Level 0: pooled point k >= count is a copy of k % count (`limit`); deeper: the centres the sampling
+        # picked from copies of one source are copies of one another -- coordinates, ball and therefore features (dup_rep).
+        centre_dedup = bool(USE_CENTRE_DEDUP and pooled_cnt is not None and point_mlp and has_entry(ext, "dup_rep_wrapper"))
+        rep = None
         for k, (npoint, radius, ns, mlp, cin) in enumerate(self.rcnn_sa):
             lev = {"xyz": cur_xyz, "new_xyz": None, "idx": None, "pack": None}
             if npoint is not None:
                 Bc, n = cur_xyz.shape[0], cur_xyz.shape[1]
                 if n <= 1024 and has_entry(ext, "fps_new_xyz_wrapper"):
-                    _, new_xyz = ext.fps_new_xyz_wrapper(cur_xyz, npoint)      # sampling + the centres' coordinates, one launch
+                    sel, new_xyz = ext.fps_new_xyz_wrapper(cur_xyz, npoint)    # sampling + the centres' coordinates, one launch
                 else:
                     sel = pu.furthest_point_sample(cur_xyz, npoint)
                     new_xyz = torch.gather(cur_xyz, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
@@ -775,7 +784,12 @@ class FastPointRCNN:
                 if dedup:
                     lev["pack"] = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, pooled_cnt.view(-1))   # copies of pooled points are dropped too
                 elif USE_PACKED and (mlp.packed is not None or mlp.wide is not None) and has_entry(ext, "ball_pack_wrapper"):
-                    lev["pack"] = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz)
+                    lev["pack"] = (ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, None, rep) if (rep is not None and ns <= 64)
+                                   else ext.ball_pack_wrapper(idx, cur_xyz, new_xyz))
+                if centre_dedup and (k == 0 or rep is not None):
+                    rep = ext.dup_rep_wrapper(sel, n, pooled_cnt.view(-1) if k == 0 else None, rep if k > 0 else None)
+                else:
+                    rep = None
                 lev["new_xyz"], lev["idx"] = new_xyz, idx
                 cur_xyz = new_xyz
             elif USE_PACKED and (mlp.packed is not None or mlp.wide is not None):
@@ -791,10 +805,16 @@ class FastPointRCNN:
                 key = (Bc, n, f, str(cur_xyz.device))
                 if getattr(self, "_groupall", (None,))[0] != key:
                     ga_idx = torch.arange(f * n, dtype=torch.int32, device=cur_xyz.device).view(1, f, n).expand(Bc // f, f, n).contiguous()
-                    self._groupall = (key, ga_idx, torch.zeros((Bc // f, f, 3), dtype=torch.float32, device=cur_xyz.device))
-                _, ga_idx, origin = self._groupall
+                    self._groupall = (key, ga_idx, torch.zeros((Bc // f, f, 3), dtype=torch.float32, device=cur_xyz.device),
+                                      (torch.arange(f, dtype=torch.int32, device=cur_xyz.device) * n).view(1, f, 1))
+                _, ga_idx, origin, shift = self._groupall
                 xyz_v = cur_xyz.view(Bc // f, f * n, 3)
-                lev.update({"xyz": xyz_v, "new_xyz": origin, "idx": ga_idx, "pack": ext.ball_pack_wrapper(ga_idx, xyz_v, origin), "f": f})
+                rep_v = None
+                if rep is not None and n <= 64:          # the f clouds' maps side by side, shifted to the merged cloud's numbering
+                    rep_v = (rep.view(Bc // f, f, n) + shift).view(Bc // f, f * n)
+                lev.update({"xyz": xyz_v, "new_xyz": origin, "idx": ga_idx,
+                            "pack": ext.ball_pack_wrapper(ga_idx, xyz_v, origin, None, rep_v) if rep_v is not None else ext.ball_pack_wrapper(ga_idx, xyz_v, origin),
+                            "f": f})
                 cur_xyz = None
             levels.append(lev)
         return {"B": B, "M": M, "P": P, "W": W, "rows": rows, "a": a, "rpn_part": rpn_part, "pooled": pooled, "pooled_cnt": pooled_cnt,

@@ -170,6 +170,21 @@ int prcnn_ball_pack(int b, int n, int m, int nsample, const int *idx, const int 
 int prcnn_ball_pack_groups(int b, int group, int n, int m, int nsample, const int *idx, const int *limit, const float *xyz,
                            const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr,
                            void *stream);
+
+/* prcnn_ball_pack with a representative map (round 3): rep (b,n) i32, rep[cloud][k] = the lowest-indexed point of the cloud
+ * that is an exact copy of point k (coordinates and features; k when it is the first of its kind).  A copy lies in a ball
+ * iff its representative does and the representative is listed earlier in the same row, so the slots whose point is not
+ * its own representative are dropped from the row list as well (a max-pool over copies is the max-pool over the
+ * originals: same bits as pointnet2_modules.py:37-53 over all nsample rows).  nsample <= 64. */
+int prcnn_ball_pack_rep(int b, int n, int m, int nsample, const int *idx, const int *limit, const int *rep, const float *xyz,
+                        const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr,
+                        void *stream);
+
+/* The representative map of the points an FPS call sampled: sel (b,m) i32 indexes clouds of n points of which the points
+ * k >= limit[cloud] are copies of point k % limit[cloud] (RoI pooling's wrap-around fill, roipool3d_kernel.cu:152-159)
+ * and / or prev (b,n) i32 is the representative map of those n points; rep (b,m) i32 <- the first sampled point with the
+ * same source as sampled point j. */
+int prcnn_dup_rep(int b, int n, int m, const int *sel, const int *limit, const int *prev, int *rep, void *stream);
 /* out_is_zero (this entry, prcnn_sa_xyz_mlp_packed, prcnn_packed_layer_segmax): the results arrive through atomicMax into a
  * zeroed slice; 0 = the entry zeroes out[..., out_col : out_col + width) itself, 1 = the caller has zeroed it (one fill for all
  * the scales of a level instead of one strided fill per scale). */

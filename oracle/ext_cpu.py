@@ -28,7 +28,8 @@ class _CpuPack:
     k >= limit[cloud] are copies of k % limit[cloud]: the per-point tensors may hold only the originals, so the indices
     are mapped onto them (same values, hence the same result as evaluating the copies)."""
 
-    def __init__(self, idx, limit=None):
+    def __init__(self, idx, limit=None, rep=None):
+        self.rep = rep                                  # kept for the record only: the oracle evaluates the copies as well
         if limit is not None:
             lim = limit.view(-1, 1, 1).clamp(min=1).to(idx.dtype)
             idx = torch.where(idx >= lim, idx % lim, idx).contiguous()
@@ -157,9 +158,23 @@ class pointnet2_cpu:
         return out
 
     @staticmethod
-    def ball_pack_wrapper(idx, xyz=None, new_xyz=None, limit=None):
+    def ball_pack_wrapper(idx, xyz=None, new_xyz=None, limit=None, rep=None):
         """The CPU stand-in keeps the index tensor: the oracle evaluates ALL nsample rows (the reference's semantics)."""
-        return _CpuPack(idx, limit)
+        return _CpuPack(idx, limit, rep)
+
+    @staticmethod
+    def dup_rep_wrapper(sel, n, limit=None, prev=None):
+        """for every sampled point the first sampled point with the same source (plain loops; see prcnn_dup_rep)"""
+        b, m = sel.shape
+        rep = torch.empty((b, m), dtype=torch.int32)
+        for i in range(b):
+            first = {}
+            lim = max(int(limit[i]), 1) if limit is not None else None
+            for j in range(m):
+                k = int(sel[i, j])
+                src = int(prev[i, k]) if prev is not None else (k % lim if k >= lim else k)
+                rep[i, j] = first.setdefault(src, j)
+        return rep
 
     @staticmethod
     def ball_pack_groups_wrapper(idx, xyz, new_xyz, group):

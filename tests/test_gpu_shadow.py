@@ -79,7 +79,8 @@ class Shadow:
 
 
 def check_ball_pack(self, name, args, host, pack):
-    """ball_pack returns the distinct-row list: compare its header with the definition (1 + last slot != slot 0)"""
+    """ball_pack returns the distinct-row list: compare its header with the definition (1 + last slot != slot 0; with a
+    representative map: slot 0 + every slot whose point differs from slot 0's, is below the limit and is its own representative)"""
     idx = host[0].numpy()
     keep = idx != idx[..., :1]
     if len(host) > 3 and host[3] is not None:      # copies of pooled points (index >= the cloud's distinct count) are dropped too
@@ -90,11 +91,28 @@ def check_ball_pack(self, name, args, host, pack):
         for b_, c_ in zip(*np.nonzero((idx >= lim).any(-1))):
             row = idx[b_, c_]
             assert set(canon[b_, c_][row >= lim[b_, 0, 0]]) <= set(row[row < lim[b_, 0, 0]])
-    last = np.where(keep, np.arange(idx.shape[-1]), 0).max(-1)
-    cnt = last + 1
     hdr = pack.hdr.cpu().numpy()
+    if len(host) > 4 and host[4] is not None:      # copies among the points themselves (SA centres sampled from copies)
+        rep = host[4].numpy()
+        assert (rep <= np.arange(rep.shape[1])[None]).all() and (np.take_along_axis(rep, rep, 1) == rep).all()
+        mine = np.take_along_axis(rep[:, None, :].repeat(idx.shape[1], 1), idx, 2)       # representative of every slot's point
+        own = mine == idx
+        # the contract: a dropped slot's representative is listed in the same row (it lies in the same ball and has a lower index)
+        srt = np.sort(idx, -1)
+        pos = np.minimum((srt[..., None, :] < mine[..., :, None]).sum(-1), idx.shape[-1] - 1)
+        assert (np.take_along_axis(srt, pos, -1) == mine).all()
+        cnt = 1 + (keep & own)[..., 1:].sum(-1)
+        self._log["rep_rows_dropped"] += int(((keep & ~own)[..., 1:]).sum())
+    else:
+        last = np.where(keep, np.arange(idx.shape[-1]), 0).max(-1)
+        cnt = last + 1
     assert hdr[1] == cnt.sum(), (name, int(hdr[1]), int(cnt.sum()))
     assert hdr[0] == sum((int(c.sum()) + 63) // 64 for c in cnt)
+
+
+def check_dup_rep(self, name, args, host, ret):
+    want = self._cpu.dup_rep_wrapper(*host)
+    assert torch.equal(ret.cpu(), want), name
 
 
 def check_forward_canonical(self, name, args, host, ret):
@@ -244,6 +262,7 @@ def check_fps_new_xyz(self, name, args, host, ret):
 
 
 POINTNET2["fps_new_xyz_wrapper"] = check_fps_new_xyz
+POINTNET2["dup_rep_wrapper"] = check_dup_rep
 POINTNET2["sa_wide_fused_wrapper"] = {9: "exact"}          # one scale of a wide level in one kernel: output slice vs the oracle chain
 
 
@@ -309,7 +328,7 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
         assert torch.isfinite(det[k].float()).all(), k
     assert (det["num"] > 0).all()
     # coverage: every kernel family of the step was exercised at the batch-8 shapes
-    want_calls = {"furthest_point_sampling_wrapper": 4, "fps_new_xyz_wrapper": 2, "ball_query_wrapper": 9, "ball_query_limit_wrapper": 1, "three_nn_wrapper": 4, "ball_pack_wrapper": 11,
+    want_calls = {"furthest_point_sampling_wrapper": 4, "fps_new_xyz_wrapper": 2, "dup_rep_wrapper": 2, "ball_query_wrapper": 9, "ball_query_limit_wrapper": 1, "three_nn_wrapper": 4, "ball_pack_wrapper": 11,
                   "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 4,
                   "three_interpolate_cat_pm_wrapper": 3, "rpn_tail_wrapper": 1, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
     want_calls.update({"packed_layer_segmax_batch_wrapper": 2, "packed_gather_affine_batch_wrapper": 2, "packed_layer_batch_wrapper": 4})   # RPN SA3, SA4
@@ -320,4 +339,5 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
     for name, n in want_calls.items():
         assert log[name] == n, (name, log[name], n)
     assert log["packed_layer_wrapper"] >= 5 and log["rows_dot_wrapper"] == 1
+    assert log["rep_rows_dropped"] > 1000            # the deeper RCNN levels really dropped rows of copied centres
     print("shadowed calls:", {k: v for k, v in log.items() if not k.startswith("elements:")})
