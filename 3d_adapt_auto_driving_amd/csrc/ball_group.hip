@@ -53,14 +53,20 @@ __global__ __launch_bounds__(64 * NSEG) void ball_query_kernel(
 
     for (int kb = k0; kb < k1; kb += 64) {
         if (__all(cnt >= nsample)) break;
-        const int ke = min(k1, kb + 64);
-#pragma unroll 4
-        for (int k = kb; k < ke; ++k) {
-            // wave-uniform address -> scalar loads
-            const float x = cloud[3 * k], y = cloud[3 * k + 1], z = cloud[3 * k + 2];
+        // 64 points per round: ONE vector load per coordinate (lane j holds point kb + j), then point j reaches every lane as
+        // an SGPR operand through v_readlane.  (Rounds 1-2 fetched every point with three scalar loads: their latency was most
+        // of the loop on the 800 RoI clouds of a batch -- 91 us per call for 8 M distance tests.)
+        const int kk = kb + lane;
+        float vx = 0.f, vy = 0.f, vz = 0.f;
+        if (kk < k1) { vx = cloud[3 * kk]; vy = cloud[3 * kk + 1]; vz = cloud[3 * kk + 2]; }
+        const int nb = min(64, k1 - kb);
+        for (int j = 0; j < nb; ++j) {
+            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vx), j));
+            const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vy), j));
+            const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vz), j));
             const float d2 = sqdist3(cx, cy, cz, x, y, z);
             if (d2 < r2 && cnt < nsample) {
-                myhits[cnt * 64] = k;
+                myhits[cnt * 64] = kb + j;
                 ++cnt;
             }
         }

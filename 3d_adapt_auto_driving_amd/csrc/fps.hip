@@ -196,7 +196,23 @@ __global__ __launch_bounds__(64 * WAVES) void fps_reg_kernel(
     int old = 0;
     if (t == 0) sel[0] = 0;
     for (int j = 1; j < m; ++j) {
-        const float ox = cloud[3 * old], oy = cloud[3 * old + 1], oz = cloud[3 * old + 2];
+        float ox, oy, oz;
+        if constexpr (WAVES == 1) {
+            // one wave per cloud (the 800 RoI clouds of a batch): the pivot's coordinates come out of the REGISTERS that hold the
+            // cloud (point k = lane + 64 i) instead of a dependent scalar load per iteration -- the memory round trip was most
+            // of an iteration here (round 3: 138 -> ~50 us for 800 x (512 -> 128))
+            const int pl = old & 63, pi = old >> 6;
+            ox = oy = oz = 0.f;
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const float vx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[i]), pl));
+                const float vy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[i]), pl));
+                const float vz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[i]), pl));
+                if (i == pi) { ox = vx; oy = vy; oz = vz; }
+            }
+        } else {
+            ox = cloud[3 * old]; oy = cloud[3 * old + 1]; oz = cloud[3 * old + 2];
+        }
         if (nxyz && t == 0) { nxyz[3 * (j - 1)] = ox; nxyz[3 * (j - 1) + 1] = oy; nxyz[3 * (j - 1) + 2] = oz; }
         float lv = -INFINITY;
 #pragma unroll
@@ -226,6 +242,18 @@ __global__ __launch_bounds__(64 * WAVES) void fps_reg_kernel(
         old = (bkey == 0xffffffffu || !(bv > -1.0f)) ? 0 : kc.decode(bkey);
         old = __builtin_amdgcn_readfirstlane(old);
         if (t == 0) sel[j] = old;
+        if (bv == 0.f) {
+            // Every running minimum is 0: all distinct points have been picked, what is left are exact copies (a RoI that holds
+            // fewer points than it is sampled to, roipool3d_kernel.cu:152-159).  The arg-max over equal values is the point
+            // with the lowest tie key, point 0 -- in this and in every later iteration (min(d, 0) stays 0): the remaining
+            // picks are 0 without computing them.  (`old` is already 0 here by the same rule.)
+            for (int jj = j + 1 + t; jj < m; jj += T) {
+                sel[jj] = 0;
+                if (nxyz) { nxyz[3 * (jj - 1)] = cloud[0]; nxyz[3 * (jj - 1) + 1] = cloud[1]; nxyz[3 * (jj - 1) + 2] = cloud[2]; }
+            }
+            if (nxyz && t == 0) { nxyz[3 * j] = cloud[0]; nxyz[3 * j + 1] = cloud[1]; nxyz[3 * j + 2] = cloud[2]; }   // slot j is written by iteration j + 1 otherwise
+            break;
+        }
     }
     if (nxyz && t == 0 && m > 0) { nxyz[3 * (m - 1)] = cloud[3 * old]; nxyz[3 * (m - 1) + 1] = cloud[3 * old + 1]; nxyz[3 * (m - 1) + 2] = cloud[3 * old + 2]; }
     if (mind) {

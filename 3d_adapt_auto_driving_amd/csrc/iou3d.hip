@@ -391,6 +391,82 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_lazy_kernel(
     if (t == 0) num_keep_all[prob] = s_nkeep;
 }
 
+
+// ---- dense form for small problems (n <= 128: the FINAL rotated NMS of a scene runs over <= 100 boxes, eval_rcnn.py:626) --------
+// The lazy kernel above is one workgroup per problem walking 64-row blocks: for 100 boxes its critical path is ~24 rotated IoUs
+// evaluated one after the other by the same thread (175 us, the longest kernel of the final stage).  Here the reference's own
+// split is used (iou3d_kernel.cu:250-292 + iou3d.cpp:100-119): every pair (row r, column c > r) is one IoU evaluated by its own
+// thread -- 8 rows x 32 column lanes per workgroup, ~1.5 IoUs per thread -- into a 128-bit suppression mask per row, and one wave
+// per problem then runs the host loop over the masks.  Same argument order (row, column), same expression: same keep list.
+constexpr int ND_ROWS = 8, ND_LANES = 32, ND_MAX = 128;
+
+template <bool ROTATED>
+__global__ __launch_bounds__(ND_ROWS * ND_LANES) void nms_dense_mask_kernel(
+    int n_max, const int *__restrict__ counts, const float *__restrict__ boxes_all, float thresh,
+    unsigned long long *__restrict__ mask_all)
+{
+    __shared__ float s_row[ND_ROWS * 7];
+    __shared__ unsigned long long s_mask[ND_ROWS][2];
+    const int prob = blockIdx.y, r0 = blockIdx.x * ND_ROWS;
+    int n = counts ? counts[prob] : n_max;
+    n = min(max(n, 0), n_max);
+    if (r0 >= n) return;
+    const float *__restrict__ boxes = boxes_all + (long)prob * n_max * 5;
+    const int t = threadIdx.x, rl = t / ND_LANES, cl = t % ND_LANES;
+    const int rows = min(ND_ROWS, n - r0);
+    if (t < rows) {
+        const float *p = boxes + (long)(r0 + t) * 5;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) s_row[t * 7 + q] = p[q];
+        if (ROTATED) {
+            s_row[t * 7 + 5] = cos_f32(p[4]);
+            s_row[t * 7 + 6] = sin_f32(p[4]);
+        }
+    }
+    if (t < ND_ROWS * 2) s_mask[t >> 1][t & 1] = 0ull;
+    __syncthreads();
+    if (rl < rows) {
+        unsigned long long w0 = 0ull, w1 = 0ull;
+        for (int c = r0 + rl + 1 + cl; c < n; c += ND_LANES) {
+            const RBox C = load_col<ROTATED>(boxes + (long)c * 5);
+            if (suppresses<ROTATED>(s_row, rl, C, thresh)) {
+                if (c < 64) w0 |= 1ull << c; else w1 |= 1ull << (c - 64);
+            }
+        }
+        if (w0) atomicOr(&s_mask[rl][0], w0);
+        if (w1) atomicOr(&s_mask[rl][1], w1);
+    }
+    __syncthreads();
+    if (t < rows * 2) mask_all[((long)prob * ND_MAX + r0 + (t >> 1)) * 2 + (t & 1)] = s_mask[t >> 1][t & 1];
+}
+
+// one wave per problem: the host loop of iou3d.cpp:100-119 over the row masks
+__global__ __launch_bounds__(64) void nms_dense_resolve_kernel(
+    int n_max, const int *__restrict__ counts, const unsigned long long *__restrict__ mask_all, int max_keep,
+    int *__restrict__ keep_all, int *__restrict__ num_keep_all)
+{
+    __shared__ unsigned long long s_m[ND_MAX][2];
+    const int prob = blockIdx.x, t = threadIdx.x;
+    int n = counts ? counts[prob] : n_max;
+    n = min(max(n, 0), n_max);
+    int *__restrict__ keep = keep_all + (long)prob * max_keep;
+    for (int i = t; i < 2 * n; i += 64) s_m[i >> 1][i & 1] = mask_all[((long)prob * ND_MAX) * 2 + i];
+    for (int i = t; i < max_keep; i += 64) keep[i] = -1;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long gone0 = 0ull, gone1 = 0ull;
+        int nk = 0;
+        for (int c = 0; c < n && nk < max_keep; ++c) {
+            const bool gone = c < 64 ? (gone0 >> c) & 1ull : (gone1 >> (c - 64)) & 1ull;
+            if (gone) continue;
+            keep[nk++] = c;
+            gone0 |= s_m[c][0];
+            gone1 |= s_m[c][1];
+        }
+        num_keep_all[prob] = nk;
+    }
+}
+
 // device scratch of the blocking API: slot 7 of the per-(device, stream) cache
 
 int nms_device(int nprob, int n_max, const int *counts, const float *boxes, float thresh,
@@ -401,6 +477,19 @@ int nms_device(int nprob, int n_max, const int *counts, const float *boxes, floa
     if (nprob == 0) return PRCNN_OK;
     PRCNN_REQUIRE(num_keep && (keep || max_keep == 0) && (boxes || n_max == 0), "nms: null pointer");
     static const bool quota_form = !(getenv("PRCNN_NMS_QUOTA") && atoi(getenv("PRCNN_NMS_QUOTA")) == 0);   // A/B switch, same results
+    static const bool dense_form = !(getenv("PRCNN_NMS_DENSE") && atoi(getenv("PRCNN_NMS_DENSE")) == 0);   // A/B switch, same results
+    if (dense_form && n_max >= 1 && n_max <= ND_MAX) {
+        // small problems (the final stage: <= 100 boxes per scene): all pairs at once + a one-wave resolve
+        unsigned long long *mask = (unsigned long long *)scratch_for(st, (size_t)nprob * ND_MAX * 2 * sizeof(unsigned long long), 10);
+        if (!mask) { set_error("nms: cannot allocate the mask scratch"); return PRCNN_ELAUNCH; }
+        const dim3 grid(ceil_div(n_max, ND_ROWS), nprob);
+        if (rotated)
+            hipLaunchKernelGGL(nms_dense_mask_kernel<true>, grid, dim3(ND_ROWS * ND_LANES), 0, st, n_max, counts, boxes, thresh, mask);
+        else
+            hipLaunchKernelGGL(nms_dense_mask_kernel<false>, grid, dim3(ND_ROWS * ND_LANES), 0, st, n_max, counts, boxes, thresh, mask);
+        hipLaunchKernelGGL(nms_dense_resolve_kernel, dim3(nprob), dim3(64), 0, st, n_max, counts, mask, max_keep, keep, num_keep);
+        return check_launch("nms(dense)");
+    }
     if (rotated)
         hipLaunchKernelGGL(nms_lazy_kernel<true>, dim3(nprob), dim3(NMS_THREADS), 0, st, n_max, counts, boxes, thresh, max_keep, keep, num_keep);
     else if (quota_form && max_keep >= 1 && max_keep <= NMS_QUOTA_MAX)

@@ -382,6 +382,28 @@ def test_nms_device_batched_prefix(ext, oracle, K, thresh, spread):
         assert (keep[p, num[p]:] == -1).all()
 
 
+@pytest.mark.parametrize("rotated", [True, False])
+@pytest.mark.parametrize("nmax,K,thresh,spread", [(100, 100, 0.1, 6.0), (128, 128, 0.1, 3.0), (128, 40, 0.3, 2.0), (65, 65, 0.01, 4.0), (7, 7, 0.1, 1.0)])
+def test_nms_device_small_problems_dense_form(ext, oracle, nmax, K, thresh, spread, rotated):
+    """n <= 128 (the final rotated NMS of a scene: <= 100 boxes, threshold 0.1): the all-pairs mask + one-wave resolve of
+    csrc/iou3d.hip (round 3) against the oracle's greedy loop, ragged counts (incl. 0 and 1), a keep quota below the answer,
+    boxes packed so tightly that most are suppressed by a box kept long before them."""
+    rng = np.random.default_rng(nmax + K)
+    P = 9
+    counts = np.array([nmax, nmax - 1, 64, 65, 0, 1, 2, nmax // 2, nmax], np.int32)
+    boxes = np.stack([bev_boxes(rng, nmax, spread=spread, rotated=rotated) for _ in range(P)], 0)
+    boxes[8, 1::2] = boxes[8, 0::2][:boxes[8, 1::2].shape[0]]                  # exact duplicates: every second box identical to its predecessor
+    keep = torch.full((P, K), -9, dtype=torch.int32, device=DEV)
+    num = torch.full((P,), -9, dtype=torch.int32, device=DEV)
+    ext.iou3d.nms_device(T(boxes), T(counts), thresh, rotated, K, keep, num)
+    keep, num = keep.cpu().numpy(), num.cpu().numpy()
+    for p in range(P):
+        want = (oracle.nms if rotated else oracle.nms_normal)(boxes[p, :counts[p]], thresh)[:K]
+        assert num[p] == len(want), (p, num[p], len(want))
+        assert np.array_equal(keep[p, :num[p]], want)
+        assert (keep[p, num[p]:] == -1).all()
+
+
 def test_overlap_and_iou_bev(ext, oracle):
     rng = np.random.default_rng(13)
     a, b = bev_boxes(rng, 256, spread=8.0), bev_boxes(rng, 200, spread=8.0)
