@@ -52,7 +52,7 @@ SIGNATURES = {
     "prcnn_sa_mlp_fused": [_I] * 7 + [_P] * 10 + [_I, _I, _P],
     "prcnn_ball_pack": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_ball_pack_groups": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "prcnn_ball_pack_rep": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "prcnn_ball_pack_rep": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_dup_rep": [_I, _I, _I, _P, _P, _P, _P, _P],
     "prcnn_sa_packed_mlp": [_I, _I, _I, _I, C.c_long] + [_P] * 11 + [_I, _I, _I, _P],
     "prcnn_packed_gather_affine": [_I, _I, _I, C.c_long] + [_P] * 7 + [_P],

@@ -14,6 +14,7 @@
 //   5. assemble_rois_kernel  near keeps, then far keeps, zero padded -> rois (B, M, 7), scores (B, M)
 // No host synchronisation anywhere.
 #include "common.hpp"
+#include <stdlib.h>
 #include <math.h>
 
 namespace prcnn {
@@ -116,6 +117,68 @@ __global__ __launch_bounds__(1024) void score_sort_kernel(int n, int npad, const
             __syncthreads();
         }
     for (int i = t; i < n; i += 1024) order[(long)b * n + i] = (int)(keys[i] & 0xffffffffu);
+}
+
+
+// ---- the same order from several workgroups per scene (round 3) ------------------------------------------------------------
+// score_sort_kernel is one workgroup per scene: 105 bitonic passes of 8 rounds each over 16384 keys, 183 us on 8 CUs while the
+// proposal stream waits.  Here every 4096-key chunk of a scene is sorted by its own workgroup (78 passes of 2
+// rounds, 32 KB of LDS), and the sorted runs are merged pairwise by merge-path kernels (a thread finds its 8 outputs' split point
+// by binary search and merges them): 4 x 4096 -> 2 x 8192 -> 16384.  Keys are distinct (the index is part of the key), so the
+// result is THE sorted order: identical to the one-workgroup kernel's (tests/test_gpu_e2e.py compares the two).
+constexpr int SS_CHUNK = 4096;
+constexpr int SS_MERGE_V = 8;
+
+__global__ __launch_bounds__(1024) void score_sort_chunk_kernel(int n, int npad, const float *__restrict__ scores,
+                                                                unsigned long long *__restrict__ keys_out)
+{
+    __shared__ unsigned long long keys[SS_CHUNK];
+    const int b = blockIdx.y, c0 = blockIdx.x * SS_CHUNK, t = threadIdx.x;
+    for (int i = t; i < SS_CHUNK; i += 1024) {
+        const int g = c0 + i;
+        keys[i] = g < n ? sort_key(scores[(long)b * n + g], (unsigned)g) : ~0ull;
+    }
+    __syncthreads();
+    for (int k = 2; k <= SS_CHUNK; k <<= 1)
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            for (int i = t; i < SS_CHUNK / 2; i += 1024) {
+                const int lo = ((i / j) * 2 * j) + (i % j), hi = lo + j;
+                const bool up = ((lo & k) == 0);
+                const unsigned long long a = keys[lo], c = keys[hi];
+                if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int i = t; i < SS_CHUNK; i += 1024) keys_out[(long)b * npad + c0 + i] = keys[i];
+}
+
+// src: per scene npad keys = sorted runs of `run` keys; dst <- runs of 2 * run (or, last round, order (b, n) i32 <- the indices)
+__global__ __launch_bounds__(256) void score_merge_kernel(int n, int npad, int run, const unsigned long long *__restrict__ src,
+                                                          unsigned long long *__restrict__ dst, int *__restrict__ order)
+{
+    const int b = blockIdx.y;
+    const int g0 = (blockIdx.x * 256 + threadIdx.x) * SS_MERGE_V;
+    if (g0 >= npad) return;
+    const int pair = g0 / (2 * run), d = g0 - pair * 2 * run;
+    const unsigned long long *__restrict__ A = src + (long)b * npad + (long)pair * 2 * run;
+    const unsigned long long *__restrict__ B = A + run;
+    int lo = max(0, d - run), hi = min(d, run);            // how many of the first d outputs come from A
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (A[mid] < B[d - 1 - mid]) lo = mid + 1; else hi = mid;
+    }
+    int ia = lo, ib = d - lo;
+    unsigned long long va = ia < run ? A[ia] : ~0ull, vb = ib < run ? B[ib] : ~0ull;
+#pragma unroll
+    for (int q = 0; q < SS_MERGE_V; ++q) {
+        // exhausted runs read as the all-ones pad key, which also ends every run's tail: take A on equality (only pads are equal)
+        const bool from_a = ib >= run || (ia < run && va <= vb);
+        const unsigned long long v = from_a ? va : vb;
+        if (from_a) { ++ia; va = ia < run ? A[ia] : ~0ull; } else { ++ib; vb = ib < run ? B[ib] : ~0ull; }
+        const int g = g0 + q;
+        if (order) { if (g < n) order[(long)b * n + g] = (int)(v & 0xffffffffu); }
+        else dst[(long)b * npad + g] = v;
+    }
 }
 
 // tables: payload (b, 2, rows, 8) = box7 + score, bev (b, 2, rows, 5), counts (b, 2)
@@ -397,12 +460,27 @@ extern "C" int prcnn_rpn_proposals(int b, int n, int channels, float loc_scope, 
 
     const long total = (long)b * n;
     hipLaunchKernelGGL(rpn_decode_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, total, c, xyz, reg, boxes);
-    const size_t lds = (size_t)npad * sizeof(unsigned long long);
-    if (lds > 64 * 1024) {
-        const int rc = ensure_dynamic_lds((const void *)score_sort_kernel, lds, "rpn_proposals");
-        if (rc != PRCNN_OK) return rc;
+    static const bool split_sort = !(getenv("PRCNN_SORT_SPLIT") && atoi(getenv("PRCNN_SORT_SPLIT")) == 0);   // A/B, same order
+    if (split_sort && npad > SS_CHUNK) {
+        // chunks of 4096 keys sorted by a workgroup each, then pairwise merge-path rounds (ping-pong between two key buffers)
+        unsigned long long *kbuf = (unsigned long long *)scratch_for(st, (size_t)2 * b * npad * sizeof(unsigned long long), 11);
+        if (!kbuf) { set_error("rpn_proposals: cannot allocate the sort scratch"); return PRCNN_ELAUNCH; }
+        unsigned long long *ka = kbuf, *kb = kbuf + (size_t)b * npad;
+        hipLaunchKernelGGL(score_sort_chunk_kernel, dim3(npad / SS_CHUNK, b), dim3(1024), 0, st, n, npad, scores, ka);
+        for (int run = SS_CHUNK; run < npad; run <<= 1) {
+            const bool final_round = 2 * run >= npad;
+            hipLaunchKernelGGL(score_merge_kernel, dim3(ceil_div(npad, 256 * SS_MERGE_V), b), dim3(256), 0, st, n, npad, run, ka,
+                               kb, final_round ? order : nullptr);
+            unsigned long long *tmp = ka; ka = kb; kb = tmp;
+        }
+    } else {
+        const size_t lds = (size_t)npad * sizeof(unsigned long long);
+        if (lds > 64 * 1024) {
+            const int rc = ensure_dynamic_lds((const void *)score_sort_kernel, lds, "rpn_proposals");
+            if (rc != PRCNN_OK) return rc;
+        }
+        hipLaunchKernelGGL(score_sort_kernel, dim3(b), dim3(1024), lds, st, n, npad, scores, order);
     }
-    hipLaunchKernelGGL(score_sort_kernel, dim3(b), dim3(1024), lds, st, n, npad, scores, order);
     hipLaunchKernelGGL(band_select_kernel, dim3(b), dim3(1024), 0, st, n, rows, pre_near, pre_far, boxes, scores, order,
                        payload, bev, counts);
     int rc = check_launch("rpn_proposals");

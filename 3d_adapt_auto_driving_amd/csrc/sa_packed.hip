@@ -52,7 +52,8 @@ constexpr int PK_TILES_PER_WG = 8;
 __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, const int *__restrict__ idx, const int *__restrict__ limit,
                                  const float *__restrict__ xyz, const float *__restrict__ new_xyz,
                                  unsigned int *__restrict__ rowinfo, float4 *__restrict__ rowdxyz, int *__restrict__ tilecloud,
-                                 unsigned int *__restrict__ hdr, int group, const int *__restrict__ rep)
+                                 unsigned int *__restrict__ hdr, int group, const int *__restrict__ rep,
+                                 const int *__restrict__ crep)
 {
     // Both passes are parallel over ELEMENTS, not over centres (a thread per centre left 32 of 256 threads busy on the RoI
     // clouds' second level and walked each centre's rows as a chain of dependent loads: 47 us for 800 clouds x 32 centres):
@@ -108,6 +109,15 @@ __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, cons
         }
     }
     __syncthreads();
+    if (crep) {
+        // `crep` (optional, (b, m) i32): centre c is an exact copy of centre crep[c] <= c (same coordinates, hence the same ball and
+        // the same pooled output): it gets NO rows -- its output row stays as the caller left it (zero) and nobody may read it;
+        // the level above lists only representatives (its `rep` is this map)
+        const int *__restrict__ cr = crep + (long)gb * m;
+        for (int c = tid; c < m; c += T)
+            if (cr[c] != c) cnts[c] = 0;
+        __syncthreads();
+    }
     const int chunk = (m + T - 1) / T;
     const int c0 = min(m, tid * chunk), c1 = min(m, c0 + chunk);
     int sum = 0;
@@ -471,7 +481,7 @@ using namespace prcnn;
 // limit (b) i32, optional: points k >= limit[cloud] are copies of point k % limit[cloud] (see ball_pack_kernel).
 static int ball_pack_launch(int b, int group, int n, int m, int nsample, const int *idx, const int *limit, const float *xyz,
                             const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr, void *stream,
-                            const int *rep = nullptr)
+                            const int *rep = nullptr, const int *crep = nullptr)
 {
     PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 1, "ball_pack: bad sizes");
     PRCNN_REQUIRE(group >= 1 && b % group == 0, "ball_pack: %d clouds do not split into lists of %d", b, group);
@@ -495,17 +505,18 @@ static int ball_pack_launch(int b, int group, int n, int m, int nsample, const i
     }
     const int cap = (int)(((long)m * nsample + PK_ROWS - 1) / PK_ROWS);
     hipLaunchKernelGGL(ball_pack_kernel, dim3(b), dim3(threads), lds, st, n, m, nsample, cap, idx, limit, xyz, new_xyz, rowinfo,
-                       (float4 *)rowdxyz, tilecloud, hdr, group, rep);
+                       (float4 *)rowdxyz, tilecloud, hdr, group, rep, crep);
     return check_launch("ball_pack");
 }
 
-// prcnn_ball_pack with a representative map (see ball_pack_kernel): rep (b, n) i32, rep[cloud][k] <= k, rep[cloud][rep[cloud][k]] ==
-// rep[cloud][k]; the slots whose point is not its own representative are dropped as well.
-extern "C" int prcnn_ball_pack_rep(int b, int n, int m, int nsample, const int *idx, const int *limit, const int *rep, const float *xyz,
-                                   const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr,
-                                   void *stream)
+// prcnn_ball_pack with representative maps (see ball_pack_kernel): rep (b, n) i32 over the POINTS, rep[cloud][k] <= k,
+// rep[cloud][rep[cloud][k]] == rep[cloud][k]: the slots whose point is not its own representative are dropped as well;
+// crep (b, m) i32 over the CENTRES, same properties: a centre that is not its own representative gets no rows at all.  Either may be null.
+extern "C" int prcnn_ball_pack_rep(int b, int n, int m, int nsample, const int *idx, const int *limit, const int *rep, const int *crep,
+                                   const float *xyz, const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud,
+                                   unsigned int *hdr, void *stream)
 {
-    return ball_pack_launch(b, b > 0 ? b : 1, n, m, nsample, idx, limit, xyz, new_xyz, rowinfo, rowdxyz, tilecloud, hdr, stream, rep);
+    return ball_pack_launch(b, b > 0 ? b : 1, n, m, nsample, idx, limit, xyz, new_xyz, rowinfo, rowdxyz, tilecloud, hdr, stream, rep, crep);
 }
 
 namespace prcnn {

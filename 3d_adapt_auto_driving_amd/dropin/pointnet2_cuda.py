@@ -206,7 +206,7 @@ def sa_mlp_fused_wrapper(new_xyz, xyz, P, wxyz, idx, w2t, b2, w3t, b3, out, out_
 
 class BallPack:
     """Distinct grouped rows of an index tensor as 64-row tiles (prcnn_ball_pack); device-resident, no host sync."""
-    __slots__ = ("idx", "limit", "rep", "rowinfo", "rowdxyz", "tilecloud", "hdr", "max_tiles")
+    __slots__ = ("idx", "limit", "rep", "crep", "rowinfo", "rowdxyz", "tilecloud", "hdr", "max_tiles")
 
     def tensors(self):
         return (self.idx, self.rowinfo, self.rowdxyz, self.tilecloud, self.hdr)
@@ -216,11 +216,12 @@ class BallPack:
             t.record_stream(stream)
 
 
-def ball_pack_wrapper(idx, xyz, new_xyz, limit=None, rep=None):
+def ball_pack_wrapper(idx, xyz, new_xyz, limit=None, rep=None, crep=None):
     """idx (b,m,nsample) i32 from a ball query of new_xyz (b,m,3) in xyz (b,n,3) -> BallPack for sa_packed_mlp_wrapper.
     limit (b) i32, optional: the points k >= limit[cloud] of a cloud are copies of point k % limit[cloud] (RoI pooling's
     wrap-around fill): dropped as well.  rep (b,n) i32, optional: rep[cloud][k] = the lowest-indexed exact copy of point k
-    (dup_rep_wrapper): the slots whose point is not its own representative are dropped too (prcnn_ball_pack_rep)."""
+    (dup_rep_wrapper): the slots whose point is not its own representative are dropped too (prcnn_ball_pack_rep).  crep (b,m) i32,
+    optional: the same map over the centres -- a centre that copies an earlier one gets no rows (its output row is never written)."""
     _chk(torch.int32, idx); _chk(torch.float32, xyz, new_xyz)
     if limit is not None:
         _chk(torch.int32, limit)
@@ -228,18 +229,22 @@ def ball_pack_wrapper(idx, xyz, new_xyz, limit=None, rep=None):
         _chk(torch.int32, rep)
         if tuple(rep.shape) != (idx.shape[0], xyz.shape[1]):
             raise ValueError("ball_pack: rep must be (b, n)")
+    if crep is not None:
+        _chk(torch.int32, crep)
+        if tuple(crep.shape) != (idx.shape[0], idx.shape[1]):
+            raise ValueError("ball_pack: crep must be (b, m)")
     b, m, ns = idx.shape
     cap = (m * ns + 63) // 64
     pk = BallPack()
-    pk.idx, pk.limit, pk.rep = idx, limit, rep
+    pk.idx, pk.limit, pk.rep, pk.crep = idx, limit, rep, crep
     pk.rowinfo = torch.empty((b * cap * 64,), dtype=torch.int32, device=idx.device)
     pk.rowdxyz = torch.empty((b * cap * 64, 4), dtype=torch.float32, device=idx.device)
     pk.tilecloud = torch.empty((b * cap,), dtype=torch.int32, device=idx.device)
     pk.hdr = torch.empty((4,), dtype=torch.int32, device=idx.device)
     pk.max_tiles = b * cap
-    if rep is not None:
-        _lib.call("prcnn_ball_pack_rep", b, xyz.size(1), m, ns, idx.data_ptr(), _lib.ptr(limit), rep.data_ptr(), xyz.data_ptr(),
-                  new_xyz.data_ptr(), pk.rowinfo.data_ptr(), pk.rowdxyz.data_ptr(), pk.tilecloud.data_ptr(),
+    if rep is not None or crep is not None:
+        _lib.call("prcnn_ball_pack_rep", b, xyz.size(1), m, ns, idx.data_ptr(), _lib.ptr(limit), _lib.ptr(rep), _lib.ptr(crep),
+                  xyz.data_ptr(), new_xyz.data_ptr(), pk.rowinfo.data_ptr(), pk.rowdxyz.data_ptr(), pk.tilecloud.data_ptr(),
                   pk.hdr.data_ptr(), _lib.current_stream(idx))
         return pk
     _lib.call("prcnn_ball_pack", b, xyz.size(1), m, ns, idx.data_ptr(), _lib.ptr(limit), xyz.data_ptr(), new_xyz.data_ptr(),
@@ -280,7 +285,7 @@ def ball_pack_groups_wrapper(idx, xyz, new_xyz, group):
     out = []
     for l in range(lists):
         pk = BallPack()
-        pk.idx, pk.limit, pk.rep = idx[l * group:(l + 1) * group], None, None
+        pk.idx, pk.limit, pk.rep, pk.crep = idx[l * group:(l + 1) * group], None, None, None
         pk.rowinfo, pk.rowdxyz, pk.tilecloud, pk.hdr, pk.max_tiles = rowinfo[l], rowdxyz[l], tilecloud[l], hdr[l], L
         out.append(pk)
     return out

@@ -42,6 +42,7 @@ USE_POOL_DEDUP = os.environ.get("PRCNN_NO_POOL_DEDUP") is None
 # the deeper RCNN levels drop the rows of every point that is not the first of its kind (prcnn_dup_rep + prcnn_ball_pack_rep;
 # round 3: 7.5x fewer SA2 rows on LiDAR-shaped scenes, bit-identical results).  PRCNN_NO_CENTRE_DEDUP=1: A/B.
 USE_CENTRE_DEDUP = os.environ.get("PRCNN_NO_CENTRE_DEDUP") is None
+USE_CENTRE_SKIP = os.environ.get("PRCNN_NO_CENTRE_SKIP") is None       # ... and such a centre gets no rows of its own either (A/B)
 USE_POINT_LAYER = os.environ.get("PRCNN_LIB_GEMM") is None     # per-point layers (FP modules, heads) on the own MFMA layer kernel
 # every per-point width zero-padded to a multiple of 128 (SA level outputs, FP inputs, narrow head outputs), so that NO layer
 # of the engine is left to a GEMM library: fixed summation order everywhere, reproduced bit for bit by the oracle
@@ -781,15 +782,19 @@ class FastPointRCNN:
                     ext.ball_query_limit_wrapper(Bc, n, npoint, radius, ns, new_xyz, cur_xyz, pooled_cnt.view(-1), idx)
                 else:
                     idx = pu.ball_query(radius, ns, cur_xyz, new_xyz)
-                if dedup:
-                    lev["pack"] = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, pooled_cnt.view(-1))   # copies of pooled points are dropped too
-                elif USE_PACKED and (mlp.packed is not None or mlp.wide is not None) and has_entry(ext, "ball_pack_wrapper"):
-                    lev["pack"] = (ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, None, rep) if (rep is not None and ns <= 64)
-                                   else ext.ball_pack_wrapper(idx, cur_xyz, new_xyz))
+                # which of THIS level's centres are copies of one another (= the next level's point map): a centre that copies an
+                # earlier one gets no rows of its own -- the next level never lists it, so its output is never read
+                rep_in = rep
                 if centre_dedup and (k == 0 or rep is not None):
-                    rep = ext.dup_rep_wrapper(sel, n, pooled_cnt.view(-1) if k == 0 else None, rep if k > 0 else None)
+                    rep = ext.dup_rep_wrapper(sel, n, pooled_cnt.view(-1) if k == 0 else None, rep_in if k > 0 else None)
                 else:
                     rep = None
+                crep = rep if USE_CENTRE_SKIP else None
+                if dedup:
+                    lev["pack"] = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, pooled_cnt.view(-1), None, crep)   # copies of pooled points are dropped too
+                elif USE_PACKED and (mlp.packed is not None or mlp.wide is not None) and has_entry(ext, "ball_pack_wrapper"):
+                    lev["pack"] = (ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, None, rep_in, crep) if (rep_in is not None and ns <= 64)
+                                   else ext.ball_pack_wrapper(idx, cur_xyz, new_xyz))
                 lev["new_xyz"], lev["idx"] = new_xyz, idx
                 cur_xyz = new_xyz
             elif USE_PACKED and (mlp.packed is not None or mlp.wide is not None):

@@ -498,8 +498,8 @@ def main():
         """Fraction of the grouped rows that are distinct, per ball-query shape of one product step on `batch`."""
         real_pack, seen = pu.pointnet2.ball_pack_wrapper, []
 
-        def spy(idx, xyz_, new_xyz_, limit=None, rep=None):
-            pk = real_pack(idx, xyz_, new_xyz_, limit, rep)
+        def spy(idx, *a):
+            pk = real_pack(idx, *a)
             seen.append((tuple(idx.shape), pk.hdr))
             return pk
         pu.pointnet2.ball_pack_wrapper = spy

@@ -175,10 +175,13 @@ int prcnn_ball_pack_groups(int b, int group, int n, int m, int nsample, const in
  * that is an exact copy of point k (coordinates and features; k when it is the first of its kind).  A copy lies in a ball
  * iff its representative does and the representative is listed earlier in the same row, so the slots whose point is not
  * its own representative are dropped from the row list as well (a max-pool over copies is the max-pool over the
- * originals: same bits as pointnet2_modules.py:37-53 over all nsample rows).  nsample <= 64. */
-int prcnn_ball_pack_rep(int b, int n, int m, int nsample, const int *idx, const int *limit, const int *rep, const float *xyz,
-                        const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr,
-                        void *stream);
+ * originals: same bits as pointnet2_modules.py:37-53 over all nsample rows).  nsample <= 64 with rep.
+ * crep (b,m) i32, optional: the same kind of map over the CENTRES (new_xyz): a centre that is an exact copy of an earlier
+ * one gets no rows at all -- its pooled output is never computed (the caller's zero stays) and must not be read; the level
+ * above passes this map as its `rep`, so it never is.  rep and crep may each be null. */
+int prcnn_ball_pack_rep(int b, int n, int m, int nsample, const int *idx, const int *limit, const int *rep, const int *crep,
+                        const float *xyz, const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud,
+                        unsigned int *hdr, void *stream);
 
 /* The representative map of the points an FPS call sampled: sel (b,m) i32 indexes clouds of n points of which the points
  * k >= limit[cloud] are copies of point k % limit[cloud] (RoI pooling's wrap-around fill, roipool3d_kernel.cu:152-159)

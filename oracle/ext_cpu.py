@@ -26,13 +26,17 @@ def _p(t, ty):
 class _CpuPack:
     """CPU stand-in of a BallPack: keeps the index tensor (the oracle evaluates ALL nsample rows).  With `limit`, points
     k >= limit[cloud] are copies of k % limit[cloud]: the per-point tensors may hold only the originals, so the indices
-    are mapped onto them (same values, hence the same result as evaluating the copies)."""
+    are mapped onto them (same values, hence the same result as evaluating the copies).  Likewise with `rep`: point k is
+    an exact copy of point rep[cloud][k], and the level below may have computed the representative's features only."""
 
-    def __init__(self, idx, limit=None, rep=None):
-        self.rep = rep                                  # kept for the record only: the oracle evaluates the copies as well
+    def __init__(self, idx, limit=None, rep=None, crep=None):
+        self.rep, self.crep = rep, crep
         if limit is not None:
             lim = limit.view(-1, 1, 1).clamp(min=1).to(idx.dtype)
             idx = torch.where(idx >= lim, idx % lim, idx).contiguous()
+        if rep is not None:
+            b, m, ns = idx.shape
+            idx = torch.gather(rep.to(idx.dtype).unsqueeze(1).expand(b, m, rep.shape[1]), 2, idx.long()).contiguous()
         self.idx = idx
         self.limit = limit
         self.max_tiles = (idx.numel() + 63) // 64
@@ -158,9 +162,9 @@ class pointnet2_cpu:
         return out
 
     @staticmethod
-    def ball_pack_wrapper(idx, xyz=None, new_xyz=None, limit=None, rep=None):
+    def ball_pack_wrapper(idx, xyz=None, new_xyz=None, limit=None, rep=None, crep=None):
         """The CPU stand-in keeps the index tensor: the oracle evaluates ALL nsample rows (the reference's semantics)."""
-        return _CpuPack(idx, limit, rep)
+        return _CpuPack(idx, limit, rep, crep)
 
     @staticmethod
     def dup_rep_wrapper(sel, n, limit=None, prev=None):

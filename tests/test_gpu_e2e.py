@@ -424,13 +424,15 @@ def test_engine_keeps_no_state_from_one_batch_to_the_next():
     assert not torch.equal(got["rcnn_reg"], E.infer_batch(model, cfg, a, engine=used)["rcnn_reg"])
 
 
-def test_fused_proposal_sort_order_with_ties_and_nans(ext):
-    """score_sort_kernel's total order = (score descending, NaN first, index ascending on ties) == torch's STABLE descending
+@pytest.mark.parametrize("N", [4096, 16384, 10000, 5000])
+def test_fused_proposal_sort_order_with_ties_and_nans(ext, N):
+    """The score sort's total order = (score descending, NaN first, index ascending on ties) == torch's STABLE descending
     sort; argmax over regression bins treats NaN as the largest value like torch.argmax.  Exercised through the fused
     proposal entry with every point in the near band and NMS threshold 1 (nothing suppressed): the RoIs come out in
-    exactly that order."""
+    exactly that order.  N = 4096: one workgroup per scene (score_sort_kernel); larger N: 4096-key chunks sorted by a
+    workgroup each + merge-path rounds (round 3), incl. sizes that are not a power of two (pad keys in the last chunks)."""
     rng = np.random.default_rng(3)
-    B, N = 2, 4096
+    B = 2
     xyz = torch.from_numpy(rng.uniform([-30, 0, 5], [30, 2, 35], (B, N, 3)).astype(np.float32)).to(DEV)
     scores = torch.from_numpy(rng.integers(-3, 4, (B, N)).astype(np.float32)).to(DEV)       # heavy ties
     scores[0, 17] = float("nan"); scores[1, 5] = float("nan"); scores[1, 900] = -float("nan")

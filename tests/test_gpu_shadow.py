@@ -33,7 +33,8 @@ def to_cpu(a):
     if torch.is_tensor(a):
         return a.detach().cpu().clone()
     if hasattr(a, "rowinfo"):                      # BallPack -> the oracle's stand-in keeps the index tensor
-        return ext_cpu._CpuPack(a.idx.detach().cpu().clone(), None if a.limit is None else a.limit.detach().cpu().clone())
+        cp = lambda t: None if t is None else t.detach().cpu().clone()
+        return ext_cpu._CpuPack(a.idx.detach().cpu().clone(), cp(a.limit), cp(getattr(a, "rep", None)), cp(getattr(a, "crep", None)))
     if isinstance(a, tuple):
         return tuple(to_cpu(x) for x in a)
     if isinstance(a, list):
@@ -106,8 +107,39 @@ def check_ball_pack(self, name, args, host, pack):
     else:
         last = np.where(keep, np.arange(idx.shape[-1]), 0).max(-1)
         cnt = last + 1
+    if len(host) > 5 and host[5] is not None:      # centres that copy an earlier centre get no rows at all
+        crep = host[5].numpy()
+        assert (crep <= np.arange(crep.shape[1])[None]).all() and (np.take_along_axis(crep, crep, 1) == crep).all()
+        # the contract: a dropped centre has the coordinates of its representative (same ball, same pooled output)
+        nx = host[2].numpy()
+        assert np.array_equal(np.take_along_axis(nx, crep[..., None].repeat(3, -1).astype(np.int64), 1), nx)
+        self._log["centres_skipped"] += int((crep != np.arange(crep.shape[1])[None]).sum())
+        cnt = np.where(crep == np.arange(crep.shape[1])[None], cnt, 0)
     assert hdr[1] == cnt.sum(), (name, int(hdr[1]), int(cnt.sum()))
     assert hdr[0] == sum((int(c.sum()) + 63) // 64 for c in cnt)
+
+
+def check_sa_packed(self, name, args, host, ret):
+    """the fused SA kernel over a row list: every centre that has rows == the oracle over all nsample rows, bit for bit; a centre
+    that copies an earlier one (crep) has none -- its output row must still be what the caller put there (zero)"""
+    self._cpu.sa_packed_mlp_wrapper(*host)
+    got, want = args[9].detach().cpu(), host[9]
+    pack = args[4]
+    if getattr(pack, "crep", None) is None:
+        assert torch.equal(got, want), name
+        return
+    crep = pack.crep.cpu()
+    own = crep == torch.arange(crep.shape[1]).view(1, -1)
+    c0 = host[10]
+    width = host[7].shape[1]
+    assert torch.equal(got[own], want[own]), name
+    # (untouched = the caller's zero; the one exception is the cloud's LAST centre, which also owns the rows that pad the cloud's last
+    # tile -- copies of its own first row, so it may hold the max over that one row: between 0 and the true value.  Nobody reads it.)
+    skipped, truth = got[~own][:, c0:c0 + width], want[~own][:, c0:c0 + width]
+    assert bool(((skipped >= 0) & (skipped <= truth)).all()), name
+    # ... and what the skipped centres WOULD have produced is exactly their representative's row (why skipping is exact)
+    repl = torch.gather(want, 1, crep.long().unsqueeze(-1).expand(-1, -1, want.shape[2]))
+    assert torch.equal(repl, want), name
 
 
 def check_dup_rep(self, name, args, host, ret):
@@ -164,7 +196,7 @@ POINTNET2 = {
     "ball_pack_wrapper": check_ball_pack,
     "sa_xyz_mlp_wrapper": {9: "exact"},
     "sa_xyz_mlp_packed_wrapper": {9: "exact"},
-    "sa_packed_mlp_wrapper": {9: "exact"},
+    "sa_packed_mlp_wrapper": None,                 # filled below (centres without rows)
     "packed_gather_affine_wrapper": None,          # filled below: compared through the layers that consume it
     "packed_layer_wrapper": None,
     "packed_layer_segmax_wrapper": {6: "exact"},
@@ -263,6 +295,7 @@ def check_fps_new_xyz(self, name, args, host, ret):
 
 POINTNET2["fps_new_xyz_wrapper"] = check_fps_new_xyz
 POINTNET2["dup_rep_wrapper"] = check_dup_rep
+POINTNET2["sa_packed_mlp_wrapper"] = check_sa_packed
 POINTNET2["sa_wide_fused_wrapper"] = {9: "exact"}          # one scale of a wide level in one kernel: output slice vs the oracle chain
 
 
@@ -340,4 +373,5 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
         assert log[name] == n, (name, log[name], n)
     assert log["packed_layer_wrapper"] >= 5 and log["rows_dot_wrapper"] == 1
     assert log["rep_rows_dropped"] > 1000            # the deeper RCNN levels really dropped rows of copied centres
+    assert log["centres_skipped"] > 1000             # ... and skipped the centres that copy an earlier one
     print("shadowed calls:", {k: v for k, v in log.items() if not k.startswith("elements:")})
