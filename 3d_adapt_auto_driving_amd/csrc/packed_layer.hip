@@ -33,6 +33,9 @@ struct PLProblem {
     const unsigned int *hdr; long rows_host; int K, N; const float *A; long lda; const float *W; const float *bias; int do_relu;
     float *out; long ldo; const unsigned int *rowinfo; const int *tilecloud; int m, out_col, n_store;
     int lds_pool;               // SEGMAX: tiles with many centres pool through the dead LDS tile (segmax.hpp); needs 16-byte aligned output rows
+    // interpolation addend (prcnn_packed_layer_interp, round 3): out[r] = relu((A[r] @ W + bias) + ((w0 G[i0] + w1 G[i1]) + w2 G[i2])),
+    // G (clouds, add_m, N-wide rows, leading dimension add_ldg), idx / weight (rows, 3), row r belongs to cloud r / add_n
+    const float *addG; const int *addIdx; const float *addW; int add_n, add_m; long add_ldg;
 };
 struct PLBatch { PLProblem p[PL_MAX_BATCH]; };
 struct PGProblem {
@@ -184,7 +187,7 @@ template <bool SEGMAX>
 __device__ __forceinline__ void pl_epilogue(const f32x16 &acc0, const f32x16 &acc1, float *tile, int *ctr, long t, long rows, int n0,
                                             const float *__restrict__ bias, int do_relu, float *__restrict__ out, long ldo,
                                             const unsigned int *__restrict__ rowinfo, const int *__restrict__ tilecloud, int m,
-                                            int out_col, int n_store, int lds_pool)
+                                            int out_col, int n_store, int lds_pool, const PLProblem *add = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, h = lane >> 5;
     const int chunk = tid & 31, r0 = tid >> 5;
@@ -207,13 +210,14 @@ __device__ __forceinline__ void pl_epilogue(const f32x16 &acc0, const f32x16 &ac
             pk_segmented_max_lds(tile, PL_LD, ctr, tid, out, (int)ldo, out_col + n0, bias4);
         }
     } else {
+        const bool with_add = add && add->addG;
         __syncthreads();                                   // the panel tile is dead: stage the results through it
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
             const float v0 = acc0[r] + bcol, v1 = acc1[r] + bcol;
-            tile[row * PL_LD + 32 * w + j] = do_relu ? fmaxf(v0, 0.f) : v0;
-            tile[(32 + row) * PL_LD + 32 * w + j] = do_relu ? fmaxf(v1, 0.f) : v1;
+            tile[row * PL_LD + 32 * w + j] = (do_relu && !with_add) ? fmaxf(v0, 0.f) : v0;
+            tile[(32 + row) * PL_LD + 32 * w + j] = (do_relu && !with_add) ? fmaxf(v1, 0.f) : v1;
         }
         __syncthreads();
 #pragma unroll
@@ -224,7 +228,23 @@ __device__ __forceinline__ void pl_epilogue(const f32x16 &acc0, const f32x16 &ac
                 // n_store < N: only the first n_store columns exist in `out` (a head's last layer: N padded to 128 for the
                 // MFMA tiles, 1 / 46 / 76 real outputs); 16-byte stores when the row layout allows them
                 const int c0 = n0 + 4 * chunk;
-                const float4 v = *reinterpret_cast<const float4 *>(tile + row * PL_LD + 4 * chunk);
+                float4 v = *reinterpret_cast<const float4 *>(tile + row * PL_LD + 4 * chunk);
+                if (with_add) {
+                    // + the interpolated coarse-level product, then the activation: (w0 g0 + w1 g1) + w2 g2 per component with one
+                    // rounding per operation (the order of three_interpolate, interpolate_gpu.cu:92-94), added to (acc + bias)
+                    const int *ix = add->addIdx + g * 3;
+                    const float *wv = add->addW + g * 3;
+                    const long cb = (g / add->add_n) * (long)add->add_m;
+                    const float4 g0 = *reinterpret_cast<const float4 *>(add->addG + (cb + ix[0]) * add->add_ldg + c0);
+                    const float4 g1 = *reinterpret_cast<const float4 *>(add->addG + (cb + ix[1]) * add->add_ldg + c0);
+                    const float4 g2 = *reinterpret_cast<const float4 *>(add->addG + (cb + ix[2]) * add->add_ldg + c0);
+                    const float w0 = wv[0], w1 = wv[1], w2 = wv[2];
+                    v.x = __fadd_rn(v.x, __fadd_rn(__fadd_rn(__fmul_rn(w0, g0.x), __fmul_rn(w1, g1.x)), __fmul_rn(w2, g2.x)));
+                    v.y = __fadd_rn(v.y, __fadd_rn(__fadd_rn(__fmul_rn(w0, g0.y), __fmul_rn(w1, g1.y)), __fmul_rn(w2, g2.y)));
+                    v.z = __fadd_rn(v.z, __fadd_rn(__fadd_rn(__fmul_rn(w0, g0.z), __fmul_rn(w1, g1.z)), __fmul_rn(w2, g2.z)));
+                    v.w = __fadd_rn(v.w, __fadd_rn(__fadd_rn(__fmul_rn(w0, g0.w), __fmul_rn(w1, g1.w)), __fmul_rn(w2, g2.w)));
+                    if (do_relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                }
                 if (c0 + 4 <= n_store && (ldo & 3) == 0) {
                     *reinterpret_cast<float4 *>(out + g * ldo + c0) = v;
                 } else {
@@ -280,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void packed_layer_kernel(
         __syncthreads();
         PL_STAGE(tile, wf)
     }
-    pl_epilogue<SEGMAX>(acc0, acc1, tile, ctr, t, rows, n0, bias, do_relu, out, ldo, rowinfo, tilecloud, m, out_col, n_store, pb.lds_pool);
+    pl_epilogue<SEGMAX>(acc0, acc1, tile, ctr, t, rows, n0, bias, do_relu, out, ldo, rowinfo, tilecloud, m, out_col, n_store, pb.lds_pool, &pb);
 }
 
 // K >= 256: two LDS tiles, two weight register sets, every panel fetched behind the MFMAs of the one before it
@@ -344,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void packed_layer_pipe_kernel(
             PL_STAGE(T, wa)
         }
     }
-    pl_epilogue<SEGMAX>(acc0, acc1, tiles, ctr, t, rows, n0, bias, do_relu, out, ldo, rowinfo, tilecloud, m, out_col, n_store, pb.lds_pool);
+    pl_epilogue<SEGMAX>(acc0, acc1, tiles, ctr, t, rows, n0, bias, do_relu, out, ldo, rowinfo, tilecloud, m, out_col, n_store, pb.lds_pool, &pb);
 }
 
 // ---- K = 128 layers over many row tiles (the per-point parts of the SA levels: 10^5 rows, one panel): PERSISTENT workgroups.
@@ -662,7 +682,8 @@ extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr
         bt.p[k] = PLProblem{q.hdr, q.rows, q.K, q.N, q.A, q.lda, q.W, q.bias, segmax ? 1 : q.relu, q.out, q.ldo,
                             segmax ? q.rowinfo : nullptr, segmax ? q.tilecloud : nullptr, segmax ? q.m : 0, segmax ? q.out_col : 0, n_store,
                             (segmax && segmax_lds_enabled() && (((uintptr_t)q.out | (uintptr_t)q.bias) & 15) == 0 && (q.ldo & 3) == 0 &&
-                             (q.out_col & 3) == 0) ? 1 : 0};
+                             (q.out_col & 3) == 0) ? 1 : 0,
+                            nullptr, nullptr, nullptr, 0, 0, 0};
         ++k;
     }
     if (k == 0) return PRCNN_OK;
@@ -719,4 +740,33 @@ extern "C" int prcnn_packed_layer_segmax(int b, int m, long max_tiles, int K, in
     q.out = out; q.ldo = out_stride; q.b = b; q.m = m; q.rowinfo = rowinfo; q.tilecloud = tilecloud; q.out_col = out_col;
     q.out_is_zero = out_is_zero;
     return prcnn_packed_layer_batch(1, &q, 1, stream);
+}
+
+
+// The first layer of a feature-propagation module WITHOUT the interpolated tensor (round 3).  The reference interpolates the coarse
+// level's features to the fine level, concatenates the skip features and applies the layer (pointnet2_modules.py:139-156):
+// relu(W [interp(f) | skip] + b).  The layer is linear in front of its ReLU and the interpolation is a weighted sum, so
+//     W_a interp(f) = interp(W_a f):   G = f @ W_a at the COARSE level (a quarter of the rows), then
+//     out[r] = relu((skip[r] @ W_b + b) + ((w0 G[i0] + w1 G[i1]) + w2 G[i2]))     -- this entry, the addend inside the layer's epilogue.
+// A (rows, K) = the skip features, W (K, N) = W_b, G (clouds * m_known rows, N wide, leading dimension ldg), idx / weight (rows, 3) from
+// three_nn, row r in cloud r / n_per_cloud.  Not the reference's order of operations (the products are summed in another
+// association): results agree to ~1e-7 relative, inside BASELINE's 1e-4 box tolerance; oracle/ext_cpu.py restates THIS order.
+extern "C" int prcnn_packed_layer_interp(long rows, int K, int N, const float *A, long lda, const float *W, const float *bias, int relu,
+                                         float *out, long ldo, int n_per_cloud, int m_known, const float *G, long ldg, const int *idx,
+                                         const float *weight, void *stream)
+{
+    PRCNN_REQUIRE(rows >= 0 && K > 0 && N > 0 && K % 128 == 0 && N % 128 == 0, "packed_layer_interp: K=%d, N=%d must be multiples of 128", K, N);
+    PRCNN_REQUIRE(lda >= K && lda % 4 == 0 && ldo >= N && ldo % 4 == 0 && ldg >= N && ldg % 4 == 0, "packed_layer_interp: bad leading dimensions");
+    PRCNN_REQUIRE(n_per_cloud >= 1 && m_known >= 1 && rows % n_per_cloud == 0, "packed_layer_interp: rows must be whole clouds");
+    if (rows == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(A && W && bias && out && G && idx && weight, "packed_layer_interp: null pointer");
+    PRCNN_REQUIRE((((uintptr_t)A | (uintptr_t)out | (uintptr_t)G) & 15) == 0, "packed_layer_interp: 16-byte alignment required");
+    const long tiles = (rows + PL_ROWS - 1) / PL_ROWS;
+    PRCNN_REQUIRE(tiles <= 0x7fffffffL, "packed_layer_interp: too many rows");
+    PLBatch bt;
+    bt.p[0] = PLProblem{nullptr, rows, K, N, A, lda, W, bias, relu, out, ldo, nullptr, nullptr, 0, 0, N, 0,
+                        G, idx, weight, n_per_cloud, m_known, ldg};
+    auto kern = (K >= 256 && pipe_enabled()) ? packed_layer_pipe_kernel<false> : packed_layer_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, N / 128, 1), dim3(256), 0, (hipStream_t)stream, bt);
+    return check_launch("packed_layer_interp");
 }

@@ -333,6 +333,26 @@ def packed_layer_wrapper(a, wt, bias, relu, out, pack=None):
     return out
 
 
+def packed_layer_interp_wrapper(a, wt, bias, relu, out, G, idx, weight):
+    """out = act((a @ wt + bias) + interp3(G)): the first layer of a feature-propagation module with the interpolation behind the
+    layer's linear part (prcnn_packed_layer_interp).  a (B*n, K) skip features, wt (K, N), G (B, m, N) = coarse features @ the
+    interpolated columns of the layer, idx / weight (B, n, 3) from three_nn."""
+    _chk(torch.float32, wt, bias, G, weight)
+    _chk(torch.int32, idx)
+    for t in (a, out):
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+            raise RuntimeError("pointnet2_cuda: packed_layer_interp expects 2-D float32 CUDA matrices with unit column stride")
+    R, K = a.shape
+    N = wt.size(1)
+    B, n = idx.shape[0], idx.shape[1]
+    if wt.size(0) != K or tuple(out.shape) != (R, N) or R != B * n or G.shape[0] != B or G.shape[2] != N or tuple(weight.shape) != tuple(idx.shape):
+        raise RuntimeError("pointnet2_cuda: packed_layer_interp shape mismatch")
+    _lib.call("prcnn_packed_layer_interp", R, K, N, a.data_ptr(), a.stride(0), wt.data_ptr(), bias.data_ptr(), int(bool(relu)),
+              out.data_ptr(), out.stride(0), n, G.shape[1], G.data_ptr(), G.stride(1), idx.data_ptr(), weight.data_ptr(),
+              _lib.current_stream(a))
+    return out
+
+
 def sa_wide_fused_supported(c1, c2, c3):
     return bool(_lib.load().prcnn_sa_wide_fused_supported(int(c1), int(c2), int(c3)))
 

@@ -59,6 +59,11 @@ EARLY_LEVELS = int(os.environ.get("PRCNN_EARLY_LEVELS", "4"))
 EARLY_FP = int(os.environ.get("PRCNN_EARLY_FP", "0"))                 # ... plus this many of the coarsest FP modules
 GROUP_SA = os.environ.get("PRCNN_NO_GROUP_SA") != "1"                 # ... and over all batches of a geometry group at once
 USE_POOL_GROUPS = os.environ.get("PRCNN_NO_POOL_GROUPS") is None
+# feature-propagation modules: the first layer is linear in front of its ReLU and the interpolation is a weighted sum, so the
+# interpolated columns of the layer are applied at the COARSE level (a quarter of the rows) and the product is interpolated in the
+# epilogue of the layer over the skip features (prcnn_packed_layer_interp).  Another association of the same sums than the
+# reference's (~1e-7 relative); PRCNN_NO_FP_LINEAR=1: interpolate, concatenate, then the layer, as the reference does (A/B).
+USE_FP_LINEAR = os.environ.get("PRCNN_NO_FP_LINEAR") is None
 
 
 def _round4(c):
@@ -608,6 +613,20 @@ class FastPointRCNN:
         B, n = idx.shape[0], idx.shape[1]
         c2 = known_feat.shape[2]
         c1 = 0 if skip is None else skip.shape[2]
+        mlp = self.fp[k]
+        wt, b1, relu1 = mlp.layers[0]
+        if (USE_FP_LINEAR and USE_POINT_LAYER and PAD128 and c1 and c1 % 128 == 0 and c2 % 128 == 0 and wt.shape[0] == c2 + c1
+                and wt.shape[1] % 128 == 0 and len(mlp.layers) >= 2 and has_entry(ext, "packed_layer_interp_wrapper")):
+            # G = known_feat @ W[:c2] at the coarse level (no bias, no activation), then layer 1 over the skip features with the
+            # interpolated G added in its epilogue
+            m = known_feat.shape[1]
+            N1 = wt.shape[1]
+            if getattr(self, "_zero_bias", None) is None or self._zero_bias.numel() < N1 or self._zero_bias.device != wt.device:
+                self._zero_bias = torch.zeros((max(N1, 1024),), dtype=torch.float32, device=wt.device)
+            G = point_layer(known_feat.view(B * m, c2), wt[:c2], self._zero_bias[:N1], False).view(B, m, N1)
+            y1 = torch.empty((B * n, N1), dtype=torch.float32, device=known_feat.device)
+            ext.packed_layer_interp_wrapper(skip.view(B * n, c1), wt[c2:], b1, relu1, y1, G, idx, weight)
+            return mlp(y1, start=1).view(B, n, -1)
         buf = torch.empty((B, n, c2 + c1), dtype=torch.float32, device=known_feat.device)
         if c1 and c1 % 4 == 0 and c2 % 4 == 0 and has_entry(ext, "three_interpolate_cat_pm_wrapper"):
             ext.three_interpolate_cat_pm_wrapper(known_feat, idx, weight, skip, buf)      # interpolation + concat, one launch

@@ -237,6 +237,13 @@ int prcnn_packed_gather_affine(int b, int n, int c1, long max_tiles, const float
                                const unsigned int *hdr, float *out, void *stream);
 int prcnn_packed_layer(const unsigned int *hdr, long rows, long max_tiles, int K, int N, int n_store, const float *A,
                        long lda, const float *W, const float *bias, int relu, float *out, long ldo, void *stream);
+/* First layer of a feature-propagation module (pointnet2_modules.py:139-156) with the interpolation moved behind the layer's
+ * linear part: out[r] = act((A[r] @ W + bias) + ((w0 G[i0] + w1 G[i1]) + w2 G[i2])), A (rows,K) = the skip features, W (K,N) = the
+ * skip columns of the layer, G = coarse features @ the interpolated columns of the layer (clouds * m_known rows, N wide),
+ * idx / weight (rows,3) from prcnn_three_nn, row r in cloud r / n_per_cloud.  K, N multiples of 128. */
+int prcnn_packed_layer_interp(long rows, int K, int N, const float *A, long lda, const float *W, const float *bias, int relu,
+                              float *out, long ldo, int n_per_cloud, int m_known, const float *G, long ldg, const int *idx,
+                              const float *weight, void *stream);
 /* out[r][0..n) = A[r] @ W + bias for n <= 4 outputs (the 1-wide last layer of the classification heads, rpn.py:36-50,
  * rcnn_net.py:94-103): W (K,n) k-major; 32 lanes per row, fixed summation order (oracle: orc_rows_dot). */
 /* The coordinates-only first SA level (prcnn_sa_xyz_mlp) over a packed row list: distinct rows only, bit-identical. */

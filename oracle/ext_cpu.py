@@ -209,6 +209,20 @@ class pointnet2_cpu:
         return out
 
     @staticmethod
+    def packed_layer_interp_wrapper(a, wt, bias, relu, out, G, idx, weight):
+        """prcnn_packed_layer_interp restated: the layer in the MFMA kernels' k order (orc_rows_layer_mfma, no activation), then
+        + ((w0 g0 + w1 g1) + w2 g2) with one f32 rounding per operation, then the activation."""
+        h = torch.empty_like(out)
+        pointnet2_cpu.packed_layer_wrapper(a, wt, bias, False, h)
+        B, n = idx.shape[0], idx.shape[1]
+        ix = idx.long()
+        g = [torch.gather(G, 1, ix[:, :, e:e + 1].expand(-1, -1, G.shape[2])).reshape(B * n, -1) for e in range(3)]
+        w = [weight[:, :, e].reshape(B * n, 1) for e in range(3)]
+        y = h + ((w[0] * g[0] + w[1] * g[1]) + w[2] * g[2])
+        out.copy_(torch.relu(y) if relu else y)
+        return out
+
+    @staticmethod
     def sa_wide_fused_supported(c1, c2, c3):
         return c1 % 128 == 0 and c2 % 128 == 0 and c3 % 128 == 0
 
