@@ -65,6 +65,7 @@ SIGNATURES = {
     "prcnn_packed_gather_affine_batch": [_I, C.POINTER(GatherProblem), _P],
     "prcnn_packed_layer_batch": [_I, C.POINTER(LayerProblem), _I, _P],
     "prcnn_rpn_tail": [_I, _I, _I] + [_P] * 7 + [_I] + [_P] * 4,
+    "prcnn_rpn_tail_lin": [_I, _I, _I] + [_P] * 7 + [_I] + [_P] * 4,
     "prcnn_packed_layer_segmax": [_I, _I, C.c_long, _I, _I, _P, C.c_long, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "prcnn_maxpool_pm": [C.c_long, _I, _I, _P, _P, _I, _I, _P],
     "prcnn_three_interpolate_pm": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P],

@@ -229,6 +229,132 @@ __global__ __launch_bounds__(256, 1) void rpn_tail_kernel(const RpnTailArgs a)
     }
 }
 
+
+// ---- the same stretch with the FIRST layer of the FP module applied at the coarse level (round 3) ----------------------------------
+// relu(W1 interp(f) + b1) = relu(interp(W1 f) + b1): the layer is linear in front of its ReLU and the interpolation is a weighted
+// sum.  G = f @ W1 is computed over the 4096 coarse points of a scene (a quarter of the rows: prcnn_packed_layer), and this kernel
+// interpolates the 128-wide G instead of the 256-wide f, adds the bias, applies the ReLU and starts at layer 2: four panel stages
+// per tile instead of six, half the gathered bytes (the 16 MB table of G stays in L2; the 33 MB one of f did not).  Not the
+// reference's association of the sums (~1e-7 relative); the oracle stand-in (oracle/ext_cpu.py rpn_tail_lin_wrapper) restates
+// THIS order -- (w0 g0 + w1 g1) + w2 g2, + b1, ReLU, then the layers in the MFMA kernels' k order -- and is matched bit for bit.
+// A 128-wide row is 32 float4 lanes: a wave interpolates TWO rows per gather instruction (lanes 0-31 / 32-63), 8 such sets per tile;
+// the next tile's input is built behind the MFMAs of all four stages into the input panel the running tile does not use (X0 / X1
+// alternate).
+__global__ __launch_bounds__(256, 1) void rpn_tail_lin_kernel(const RpnTailArgs a)
+{
+    __shared__ float T0[RT_ROWS * RT_LD];
+    __shared__ float T1[RT_ROWS * RT_LD];
+    __shared__ float X0[RT_ROWS * RT_LD];
+    __shared__ float X1[RT_ROWS * RT_LD];
+    __shared__ unsigned int slot[2];
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = tid & 31, r0 = tid >> 5;
+    const long tiles = (a.rows + RT_ROWS - 1) / RT_ROWS;
+    const unsigned int lane_off = ((unsigned int)(64 * h) * 128u + (unsigned int)(32 * w + j)) * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.wcat, 0, 512 * 128 * 4, 0x00020000);
+    const float wd0 = a.wc2[j], wd1 = a.wc2[j + 32], wd2 = a.wc2[j + 64], wd3 = a.wc2[j + 96], bd = a.bc2[0];
+    const f32x4 *known4 = reinterpret_cast<const f32x4 *>(a.known);       // G (b, m, 128)
+    const f32x4 bias1v = *reinterpret_cast<const f32x4 *>(a.bcat + 4 * j);
+    const float bias2 = a.bcat[128 + 32 * w + j], biasc = a.bcat[256 + 32 * w + j], biasr1 = a.bcat[384 + 32 * w + j],
+                biasr2 = a.bcat[512 + 32 * w + j];
+    int nx_i, nx_cloud;
+    float nx_w;
+    f32x4 fl[2][3];
+    // set s of a tile = rows 16 w + 2 s (lanes 0-31) and 16 w + 2 s + 1 (lanes 32-63) of this wave
+#define RL_ISSUE(sl, s)                                                                                   \
+    {                                                                                                     \
+        const int q_ = 2 * (s) + h;                                                                       \
+        const long cloud_ = __shfl(nx_cloud, 3 * q_);                                                     \
+        _Pragma("unroll") for (int e = 0; e < 3; ++e) {                                                   \
+            const int i_ = __shfl(nx_i, 3 * q_ + e);                                                      \
+            fl[sl][e] = known4[(cloud_ * a.m + i_) * 32 + j];                                             \
+        }                                                                                                 \
+    }
+#define RL_ROW(sl, s, XN)                                                                                 \
+    {                                                                                                     \
+        const int q_ = 2 * (s) + h;                                                                       \
+        const float w0_ = __shfl(nx_w, 3 * q_), w1_ = __shfl(nx_w, 3 * q_ + 1), w2_ = __shfl(nx_w, 3 * q_ + 2); \
+        f32x4 v_ = ((w0_ * fl[sl][0] + w1_ * fl[sl][1]) + w2_ * fl[sl][2]) + bias1v;                      \
+        v_.x = fmaxf(v_.x, 0.f); v_.y = fmaxf(v_.y, 0.f); v_.z = fmaxf(v_.z, 0.f); v_.w = fmaxf(v_.w, 0.f); \
+        *reinterpret_cast<f32x4 *>((XN) + (16 * w + q_) * RT_LD + 4 * j) = v_;                             \
+    }
+    // round r (two sets) of the next tile's input behind one stage: both sets' gathers at k-group gi, one set finished at gf, gf + 1
+#define RL_SIDE(r, g, gi, gf)                                                                             \
+    if ((g) == (gi)) { RL_ISSUE(0, 2 * (r)) RL_ISSUE(1, 2 * (r) + 1) }                                    \
+    else if ((g) == (gf)) { RL_ROW(0, 2 * (r), Xn) }                                                      \
+    else if ((g) == (gf) + 1) { RL_ROW(1, 2 * (r) + 1, Xn) }
+    f32x4 co[8];
+
+    if (tid == 0) { slot[0] = atomicAdd(a.ticket, 1u); }
+    __syncthreads();
+    long t = __builtin_amdgcn_readfirstlane((int)slot[0]);
+    float wa[64], wb[64];
+    f32x16 acc0, acc1;
+    RT_LOAD_W(wa, rs, 0)
+    if (t < tiles) {
+        RT_FETCH_IDX(t)
+        float *Xn = X0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            RL_ISSUE(0, 2 * r) RL_ISSUE(1, 2 * r + 1)
+            RL_ROW(0, 2 * r, Xn) RL_ROW(1, 2 * r + 1, Xn)
+        }
+    }
+    long tp = 0;
+    bool last = false;
+    for (unsigned int served = 0; t < tiles; ++served) {
+        if (tid == 0) slot[(served + 1) & 1] = atomicAdd(a.ticket, 1u);
+        RT_VM_DRAIN
+        lds_barrier();                                         // this tile's input panel, the previous tile's regression rows in T1, the ticket
+        const float *Xc = (served & 1) ? X1 : X0;
+        float *Xn = (served & 1) ? X0 : X1;
+        const long tn = __builtin_amdgcn_readfirstlane((int)slot[(served + 1) & 1]);
+        RT_FETCH_IDX(tn)                                       // consumed from k-group 8 of the first stage on
+        // ---- FP layer 2 (wa) while cls layer 1 (wb) comes in; side: the previous tile's regression rows leave T1, round 0
+#define RL_H1(g) RT_ROWS_OUT(g, tp, T1, a.reg, a.n_reg, served > 0 && 4 * chunk < a.n_reg) RL_SIDE(0, g, 8, 13)
+        RT_STAGE_HOOK(Xc, wa, wb, rs, 128, true, RL_H1)
+        lds_barrier();                                         // every wave has taken the old rows out of T1
+        RT_EPILOGUE(T1, bias2, true)                           // = the backbone features
+        lds_barrier();
+        // ---- cls layer 1 (wb) while reg layer 1 (wa) comes in; side: the feature rows go out, round 1
+        RT_VM_DRAIN
+#define RL_H2(g) RT_ROWS_OUT(g, t, T1, a.feats, 128, true) RL_SIDE(1, g, 2, 10)
+        RT_STAGE_HOOK(T1, wb, wa, rs, 256, true, RL_H2)
+        RT_EPILOGUE(T0, biasc, true)
+        lds_barrier();
+        // ---- reg layer 1 (wa) while reg layer 2 (wb) comes in; side: the score (cls layer 2 over the hidden rows in T0), round 2
+        RT_VM_DRAIN
+        float sd[8];
+#define RL_H3(g) RT_SCORE(g) RL_SIDE(2, g, 2, 10)
+        RT_STAGE_HOOK(T1, wa, wb, rs, 384, true, RL_H3)
+        lds_barrier();                                         // every wave has read the cls hidden rows
+        RT_EPILOGUE(T0, biasr1, true)
+        lds_barrier();
+        // ---- reg layer 2 (wb, no activation) while the next tile's layer 2 (wa) comes in; side: round 3
+        RT_VM_DRAIN
+#define RL_H4(g) RL_SIDE(3, g, 2, 10)
+        RT_STAGE_HOOK(T0, wb, wa, rs, 0, true, RL_H4)
+        RT_EPILOGUE(T1, biasr2, false)
+        tp = t;
+        t = tn;
+        last = true;
+    }
+    if (last) {
+        lds_barrier();
+        if (4 * chunk < a.n_reg) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = r0 + 8 * i;
+                const unsigned int g = (unsigned int)tp * RT_ROWS + row;
+                if (g < (unsigned int)a.rows)
+                    *reinterpret_cast<f32x4 *>(a.reg + (g * (unsigned int)a.n_reg + 4u * chunk)) =
+                        *reinterpret_cast<const f32x4 *>(T1 + row * RT_LD + 4 * chunk);
+            }
+        }
+    }
+}
+
 }  // namespace prcnn
 
 namespace prcnn {
@@ -259,4 +385,32 @@ extern "C" int prcnn_rpn_tail(int b, int n, int m, const float *known, const int
     const long grid = tiles < cap ? tiles : cap;
     hipLaunchKernelGGL(rpn_tail_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("rpn_tail");
+}
+
+
+/* prcnn_rpn_tail with the FP module's first layer already applied at the coarse level (csrc/rpn_tail.hip rpn_tail_lin_kernel):
+ * G (b,m,128) = coarse features @ the layer's weights (no bias); wcat (512,128) = [FP layer 2 | cls layer 1 | reg layer 1 | reg layer 2],
+ * bcat (5,128) = the biases of FP layer 1 (added after the interpolation) and of those four. */
+extern "C" int prcnn_rpn_tail_lin(int b, int n, int m, const float *G, const int *idx, const float *weight, const float *wcat,
+                                  const float *bcat, const float *wc2, const float *bc2, int n_reg, float *feats, float *cls,
+                                  float *reg, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 1 && n_reg >= 4 && n_reg <= 128 && n_reg % 4 == 0,
+                  "rpn_tail_lin: bad sizes (n_reg=%d must be a multiple of 4 in 4..128)", n_reg);
+    const long rows = (long)b * n;
+    if (rows == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(rows <= (1L << 23), "rpn_tail_lin: too many points (32-bit element offsets)");
+    PRCNN_REQUIRE(G && idx && weight && wcat && bcat && wc2 && bc2 && feats && cls && reg, "rpn_tail_lin: null pointer");
+    PRCNN_REQUIRE((((uintptr_t)G | (uintptr_t)feats | (uintptr_t)wcat | (uintptr_t)reg | (uintptr_t)bcat) & 15) == 0,
+                  "rpn_tail_lin: 16-byte alignment required");
+    RpnTailArgs a;
+    a.rows = rows; a.n = n; a.m = m; a.known = G; a.idx = idx; a.weight = weight;
+    a.wcat = wcat; a.bcat = bcat; a.wc2 = wc2; a.bc2 = bc2; a.feats = feats; a.cls = cls; a.reg = reg; a.n_reg = n_reg;
+    a.ticket = next_ticket((hipStream_t)stream);
+    if (!a.ticket) { set_error("rpn_tail_lin: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
+    const long tiles = (rows + RT_ROWS - 1) / RT_ROWS;
+    const long cap = mfma_grid_cap() < 256 ? mfma_grid_cap() : 256;
+    const long grid = tiles < cap ? tiles : cap;
+    hipLaunchKernelGGL(rpn_tail_lin_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("rpn_tail_lin");
 }

@@ -440,6 +440,19 @@ def rpn_tail_wrapper(known, idx, weight, wcat, bcat, wc2, bc2, feats, cls, reg):
     return feats, cls, reg
 
 
+def rpn_tail_lin_wrapper(G, idx, weight, wcat, bcat, wc2, bc2, feats, cls, reg):
+    """rpn_tail_wrapper with the FP module's first layer already applied at the coarse level: G (b,m,128) = coarse features @ W1 (no
+    bias), wcat (512,128) = [FP layer 2 | cls 1 | reg 1 | reg 2], bcat (5,128) as in rpn_tail_wrapper (prcnn_rpn_tail_lin)."""
+    _chk(torch.float32, G, weight, wcat, bcat, wc2, bc2, feats, cls, reg); _chk(torch.int32, idx)
+    b, m, c = G.shape
+    if c != 128 or tuple(wcat.shape) != (512, 128) or tuple(bcat.shape) != (5, 128) or wc2.numel() != 128 or feats.size(-1) != 128:
+        raise RuntimeError("pointnet2_cuda: rpn_tail_lin is written for a 128-wide coarse product and 128-wide layers")
+    _lib.call("prcnn_rpn_tail_lin", b, idx.size(1), m, G.data_ptr(), idx.data_ptr(), weight.data_ptr(), wcat.data_ptr(),
+              bcat.data_ptr(), wc2.data_ptr(), bc2.data_ptr(), reg.size(-1), feats.data_ptr(), cls.data_ptr(), reg.data_ptr(),
+              _lib.current_stream(G))
+    return feats, cls, reg
+
+
 def packed_layer_segmax_wrapper(a, wt, bias, pack, b, m, out, out_col, zeroed=False):
     """Last layer of a level + max pool over a packed row list: out (b,m,stride)[..., out_col:out_col+N]."""
     _chk(torch.float32, a, wt, bias, out)

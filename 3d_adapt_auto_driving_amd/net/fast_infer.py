@@ -299,7 +299,10 @@ class FastPointRCNN:
             return None
         mats = [fp0.layers[0], fp0.layers[1], cl.layers[0], rg.layers[0], rg.layers[1]]
         return {"wcat": torch.cat([m[0] for m in mats], dim=0).contiguous(), "bcat": torch.stack([m[1] for m in mats]).contiguous(),
-                "wc2": cl.narrow[0].contiguous().view(-1), "bc2": cl.narrow[1].contiguous(), "n_reg": rg.n_out}
+                "wc2": cl.narrow[0].contiguous().view(-1), "bc2": cl.narrow[1].contiguous(), "n_reg": rg.n_out,
+                # linear-first form (USE_FP_LINEAR): layer 1 at the coarse level, the kernel starts at layer 2
+                "w1": mats[0][0].contiguous(), "wcat_lin": torch.cat([m[0] for m in mats[1:]], dim=0).contiguous(),
+                "zero128": torch.zeros((128,), dtype=torch.float32, device=mats[0][0].device)}
 
     def check_weights(self):
         """The engine folds BatchNorm into its own copies of the weights at construction.  Loading a checkpoint (or editing
@@ -656,7 +659,13 @@ class FastPointRCNN:
             feats = torch.empty((B, N, 128), dtype=torch.float32, device=xyz.device)
             rpn_cls = torch.empty((B, N, 1), dtype=torch.float32, device=xyz.device)
             rpn_reg = torch.empty((B, N, tw["n_reg"]), dtype=torch.float32, device=xyz.device)
-            pu.pointnet2.rpn_tail_wrapper(known_feat, idx, weight, tw["wcat"], tw["bcat"], tw["wc2"], tw["bc2"], feats, rpn_cls, rpn_reg)
+            if USE_FP_LINEAR and has_entry(pu.pointnet2, "rpn_tail_lin_wrapper"):
+                # FP layer 1 over the coarse points (a quarter of the rows), interpolated inside the fused kernel
+                m = known_feat.shape[1]
+                G = point_layer(known_feat.view(B * m, known_feat.shape[2]), tw["w1"], tw["zero128"], False).view(B, m, 128)
+                pu.pointnet2.rpn_tail_lin_wrapper(G, idx, weight, tw["wcat_lin"], tw["bcat"], tw["wc2"], tw["bc2"], feats, rpn_cls, rpn_reg)
+            else:
+                pu.pointnet2.rpn_tail_wrapper(known_feat, idx, weight, tw["wcat"], tw["bcat"], tw["wc2"], tw["bc2"], feats, rpn_cls, rpn_reg)
         else:
             flat = feats.view(B * N, -1)
             rpn_cls = self.rpn_cls(flat).view(B, N, -1)

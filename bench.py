@@ -53,6 +53,10 @@ import torch
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32 MFMA peak (MI355X_MICROARCH.md)
+# HBM traffic per launch from the rocprofv3 PMC passes over the product step (FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950
+# + WRITE_SIZE), kept with the profile it came from; a kernel that has no entry reports null
+PMC_SOURCE = "profiles/r03_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the product step)"
+PMC_TRAFFIC = {"rpn_tail_kernel": 325.87e6, "roipool3d_canonical_kernel": 82.65e6}      # r02 values until the r03 passes are in
 HOST_LAG = int(os.environ.get("PRCNN_BENCH_LAG", "3"))   # the host consumes a batch's detections this many batches late
 BATCH = 8
 NPOINTS = 16384
@@ -171,7 +175,15 @@ def roofline_rpn_tail(dev, cfg, model, reps=20):
     tw = eng.rpn_tail
     B, N = idx.shape[0], idx.shape[1]
     feats = torch.empty((B, N, 128), device=dev); cls = torch.empty((B, N, 1), device=dev); reg = torch.empty((B, N, tw["n_reg"]), device=dev)
-    run = lambda: pu.pointnet2.rpn_tail_wrapper(known, idx, weight, tw["wcat"], tw["bcat"], tw["wc2"], tw["bc2"], feats, cls, reg)
+    lin = bool(F.USE_FP_LINEAR and hasattr(pu.pointnet2, "rpn_tail_lin_wrapper"))
+    if lin:
+        # the engine's form since round 3: FP layer 1 applied over the coarse points (its own small launch, not timed here), the fused
+        # kernel interpolates the 128-wide product and starts at layer 2
+        m = known.shape[1]
+        G = F.point_layer(known.view(B * m, known.shape[2]), tw["w1"], tw["zero128"], False).view(B, m, 128)
+        run = lambda: pu.pointnet2.rpn_tail_lin_wrapper(G, idx, weight, tw["wcat_lin"], tw["bcat"], tw["wc2"], tw["bc2"], feats, cls, reg)
+    else:
+        run = lambda: pu.pointnet2.rpn_tail_wrapper(known, idx, weight, tw["wcat"], tw["bcat"], tw["wc2"], tw["bc2"], feats, cls, reg)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -181,21 +193,25 @@ def roofline_rpn_tail(dev, cfg, model, reps=20):
     torch.cuda.synchronize()
     ms = float(np.mean([a.elapsed_time(e) for a, e in evs]))
     rows = B * N
-    # ALGORITHMIC flops: FP module 0 (256-128-128), cls head 128-128-1, reg head 128-128-n_reg (76 under default.yaml).
-    # The kernel computes the regression layer as a zero-padded tile (`padded_flops`): those columns multiply zeros and
-    # are NOT counted in `achieved`.
-    flops = 2.0 * rows * (256 * 128 + 3 * 128 * 128 + 128 + 128 * tw["n_reg"])
-    padded_flops = 2.0 * rows * (256 * 128 + 3 * 128 * 128 + 128 + 128 * tw.get("n_reg_pad", 128))
+    # ALGORITHMIC flops of what THIS kernel computes: [FP layer 1 (256-128) only in the round-2 form] FP layer 2 (128-128), cls head
+    # 128-128-1, reg head 128-128-n_reg (76 under default.yaml).  The kernel computes the regression layer as a zero-padded 128-column
+    # tile (`padded_flops`): those columns multiply zeros and are NOT counted in `achieved`.
+    l1 = 0 if lin else 256 * 128
+    flops = 2.0 * rows * (l1 + 3 * 128 * 128 + 128 + 128 * tw["n_reg"])
+    padded_flops = 2.0 * rows * (l1 + 3 * 128 * 128 + 128 + 128 * 128)
     achieved = flops / (ms * 1e-3) / 1e12
-    alg_bytes = known.numel() * 4 + rows * 24 + rows * (128 + 1 + tw["n_reg"]) * 4
+    table = (G if lin else known).numel() * 4
+    alg_bytes = table + rows * 24 + rows * (128 + 1 + tw["n_reg"]) * 4
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": 325.87e6,
-            "traffic_source": "profiles/r02_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over the product step)",
-            "kernel": "rpn_tail_kernel (prcnn_rpn_tail): the largest single launch on the FEATURE stream (the longest launch of "
-                      "the step overall is the sampling kernel on a side stream: see roofline_longest)",
+            "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": PMC_TRAFFIC.get("rpn_tail_lin_kernel" if lin else "rpn_tail_kernel"),
+            "traffic_source": PMC_SOURCE,
+            "kernel": "%s (prcnn_rpn_tail%s): the largest single launch on the FEATURE stream (the longest launch of "
+                      "the step overall is the sampling kernel on a side stream: see roofline_longest)" % (
+                          "rpn_tail_lin_kernel" if lin else "rpn_tail_kernel", "_lin" if lin else ""),
             "launch_ms": round(ms, 4), "algorithmic_flops_per_launch": flops, "padded_flops_per_launch": padded_flops,
             "algorithmic_bytes_per_launch": alg_bytes,
-            "shape": {"points": rows, "coarse_points": known.shape[0] * known.shape[1], "layers": "256-128-128 | 128-128-1 | 128-128-%d" % tw["n_reg"]}}
+            "shape": {"points": rows, "coarse_points": known.shape[0] * known.shape[1],
+                      "layers": ("interp(128) | 128-128 | 128-128-1 | 128-128-%d" if lin else "256-128-128 | 128-128-1 | 128-128-%d") % tw["n_reg"]}}
 
 
 def roofline_roipool(dev, cfg, model, reps=20):
@@ -239,7 +255,7 @@ def roofline_roipool(dev, cfg, model, reps=20):
               + full_rows * (8 + C) * 4 + (B * M * S - full_rows) * 32)
     achieved = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": 82.65e6, "traffic_source": "profiles/r02_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over the product step)",
+            "traffic": PMC_TRAFFIC.get("roipool3d_canonical_kernel"), "traffic_source": PMC_SOURCE,
             "kernel": "roipool3d_canonical_kernel (prcnn_roipool3d_canonical, product form)", "launch_ms": round(ms, 4),
             "algorithmic_bytes_per_launch": nbytes, "mean_points_per_roi": round(float(cnt.float().mean()), 1),
             "shape": {"B": B, "N": NPOINTS, "rois": M, "sampled": S, "row_floats": 8 + C}}

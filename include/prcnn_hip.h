@@ -263,6 +263,14 @@ int prcnn_rows_dot(long rows, int K, int n, const float *A, long lda, const floa
 int prcnn_rpn_tail(int b, int n, int m, const float *known, const int *idx, const float *weight, const float *wcat,
                    const float *bcat, const float *wc2, const float *bc2, int n_reg, float *feats, float *cls, float *reg,
                    void *stream);
+/* prcnn_rpn_tail with the FP module's first layer applied at the COARSE level (round 3): relu(W1 interp(f) + b1) =
+ * relu(interp(W1 f) + b1).  G (b,m,128) = f @ W1 (no bias; prcnn_packed_layer over the 4096 coarse points of a scene, a
+ * quarter of the rows); wcat (512,128) = [FP layer 2 | cls layer 1 | reg layer 1 | reg layer 2 zero-padded beyond n_reg
+ * columns], bcat (5,128) = the biases of FP layer 1 (added after the interpolation), FP layer 2, cls 1, reg 1, reg 2.
+ * Another association of the same sums than pointnet2_modules.py:139-156 (~1e-7 relative). */
+int prcnn_rpn_tail_lin(int b, int n, int m, const float *G, const int *idx, const float *weight, const float *wcat,
+                       const float *bcat, const float *wc2, const float *bc2, int n_reg, float *feats, float *cls,
+                       float *reg, void *stream);
 int prcnn_packed_layer_segmax(int b, int m, long max_tiles, int K, int N, const float *A, long lda, const float *W,
                               const float *bias, const unsigned int *rowinfo, const int *tilecloud,
                               const unsigned int *hdr, float *out, int out_stride, int out_col, int out_is_zero, void *stream);

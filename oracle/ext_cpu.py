@@ -270,6 +270,23 @@ class pointnet2_cpu:
         return feats, cls, reg
 
     @staticmethod
+    def rpn_tail_lin_wrapper(G, idx, weight, wcat, bcat, wc2, bc2, feats, cls, reg):
+        """csrc/rpn_tail.hip rpn_tail_lin_kernel restated: relu(((w0 g0 + w1 g1) + w2 g2) + b1) with one f32 rounding per operation,
+        then the four layers in the MFMA kernels' k order and the score GEMV."""
+        b, n = idx.shape[0], idx.shape[1]
+        ix = idx.long()
+        g = [torch.gather(G, 1, ix[:, :, e:e + 1].expand(-1, -1, 128)) for e in range(3)]
+        w = [weight[:, :, e:e + 1] for e in range(3)]
+        h = torch.relu(((w[0] * g[0] + w[1] * g[1]) + w[2] * g[2]) + bcat[0].view(1, 1, 128)).reshape(b * n, 128).contiguous()
+        layer = lambda a, k0, k1, i, relu, out: pointnet2_cpu.packed_layer_wrapper(a, wcat[k0:k1].contiguous(), bcat[i].contiguous(), relu, out)
+        layer(h, 0, 128, 1, True, feats.view(b * n, 128))
+        hc = layer(feats.view(b * n, 128), 128, 256, 2, True, torch.empty((b * n, 128)))
+        pointnet2_cpu.rows_dot_wrapper(hc, wc2.view(128, 1), bc2, cls.view(b * n, 1))
+        hr = layer(feats.view(b * n, 128), 256, 384, 3, True, torch.empty((b * n, 128)))
+        layer(hr, 384, 512, 4, False, reg.view(b * n, -1))
+        return feats, cls, reg
+
+    @staticmethod
     def packed_layer_segmax_wrapper(a, wt, bias, pack, b, m, out, out_col, zeroed=False):
         ns = pack.idx.shape[2]
         y = torch.empty((b * m * ns, wt.size(1)))

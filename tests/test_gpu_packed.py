@@ -339,6 +339,34 @@ def test_rpn_tail_kernel_equals_the_chain_of_oracle_functions(ext, b, n, m, n_re
     assert float(wf.abs().max()) > 0 and float(wr.abs().max()) > 0
 
 
+@pytest.mark.parametrize("b,n,m,n_reg", [(1, 1, 3, 76), (2, 1000, 300, 76), (3, 64, 17, 128), (1, 4100, 700, 4), (8, 16384, 4096, 76)])
+def test_rpn_tail_lin_kernel_equals_its_oracle_restatement(ext, b, n, m, n_reg):
+    """csrc/rpn_tail.hip rpn_tail_lin_kernel (FP layer 1 applied at the coarse level: the 128-wide product is interpolated, + bias,
+    ReLU, then FP layer 2 and both heads in one kernel) vs oracle/ext_cpu.py rpn_tail_lin_wrapper, BIT FOR BIT: ragged sizes, several
+    tiles per workgroup, regression widths 4 / 76 / 128, the benchmarked B = 8 shape; nothing written outside the outputs.  And the
+    new association agrees with the reference's order (interpolate the 256-wide features, then the layer) to ~1e-6."""
+    rng = np.random.default_rng(b * 1000 + n + 1)
+    known, idx, wgt, wcat, bcat, wc2, bc2 = _rpn_tail_case(rng, b, n, m, n_reg)
+    P = ext.pointnet2
+    G = P.packed_layer_wrapper(known.view(b * m, 256), wcat[:256].contiguous(), torch.zeros(128, device=DEV), False,
+                               torch.empty((b * m, 128), device=DEV)).view(b, m, 128)
+    wlin = wcat[256:].contiguous()
+    guard = torch.full((b * n + 8, n_reg), float("nan"), device=DEV)
+    reg = guard[:b * n].view(b, n, n_reg)
+    cls = torch.full((b, n, 1), float("nan"), device=DEV)
+    feats = torch.full((b, n, 128), float("nan"), device=DEV)
+    P.rpn_tail_lin_wrapper(G, idx, wgt, wlin, bcat, wc2, bc2, feats, cls, reg)
+    assert torch.isnan(guard[b * n:]).all()
+    wf, wc, wr = torch.empty((b, n, 128)), torch.empty((b, n, 1)), torch.empty((b, n, n_reg))
+    ext_cpu.pointnet2_cpu.rpn_tail_lin_wrapper(G.cpu(), idx.cpu(), wgt.cpu(), wlin.cpu(), bcat.cpu(), wc2.cpu(), bc2.cpu(), wf, wc, wr)
+    assert torch.equal(feats.cpu(), wf) and torch.equal(cls.cpu(), wc) and torch.equal(reg.cpu(), wr)
+    # against the reference's order of operations (the round-2 kernel): same numbers up to the association of the sums
+    f0 = torch.empty((b, n, 128), device=DEV); c0 = torch.empty((b, n, 1), device=DEV); r0 = torch.empty((b, n, n_reg), device=DEV)
+    P.rpn_tail_wrapper(known, idx, wgt, wcat, bcat, wc2, bc2, f0, c0, r0)
+    for got, ref in ((feats, f0), (cls, c0), (reg, r0)):
+        assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_rpn_tail_kernel_equals_the_separate_kernels_at_the_batch8_shape(ext):
     """B = 8 x 16384 points from 4096 coarse points (the benchmarked step): the fused kernel gives the SAME BITS as
     three_interpolate_pm -> packed_layer x5 -> rows_dot on the GPU."""

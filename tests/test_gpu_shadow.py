@@ -202,7 +202,8 @@ POINTNET2 = {
     "packed_layer_wrapper": None,
     "packed_layer_segmax_wrapper": {6: "exact"},
     "rows_dot_wrapper": {3: "exact"},
-    "rpn_tail_wrapper": {7: "exact", 8: "exact", 9: "exact"},     # finest FP module + both heads in one kernel
+    "rpn_tail_wrapper": {7: "exact", 8: "exact", 9: "exact"},     # finest FP module + both heads in one kernel (PRCNN_NO_FP_LINEAR=1)
+    "rpn_tail_lin_wrapper": {7: "exact", 8: "exact", 9: "exact"}, # ... its first layer applied at the coarse level
     "rcnn_point_mlp_wrapper": None,                # filled below
 }
 
@@ -365,7 +366,7 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
     want_calls = {"furthest_point_sampling_wrapper": 4, "fps_new_xyz_wrapper": 2, "dup_rep_wrapper": 2, "ball_query_wrapper": 9, "ball_query_limit_wrapper": 1, "three_nn_wrapper": 4, "ball_pack_wrapper": 11,
                   "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 4,
                   "three_interpolate_cat_pm_wrapper": 0 if F.USE_FP_LINEAR else 3, "packed_layer_interp_wrapper": 3 if F.USE_FP_LINEAR else 0,
-                  "rpn_tail_wrapper": 1, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
+                  "rpn_tail_wrapper": 0 if F.USE_FP_LINEAR else 1, "rpn_tail_lin_wrapper": 1 if F.USE_FP_LINEAR else 0, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
     want_calls.update({"packed_layer_segmax_batch_wrapper": 2, "packed_gather_affine_batch_wrapper": 2, "packed_layer_batch_wrapper": 4})   # RPN SA3, SA4
     if wide_fused:       # the RCNN's GroupAll level (every row distinct: 800 units of work) in one kernel
         want_calls.update({"sa_wide_fused_wrapper": 1, "packed_layer_segmax_wrapper": 0, "packed_gather_affine_wrapper": 0})
