@@ -33,6 +33,7 @@ from ._lib import has_entry
 
 # PRCNN_NO_RCNN_SPLIT=1: the RCNN stage's RoI pooling / sampling / grouping geometry stays on the feature stream (A/B switch)
 SPLIT_RCNN = os.environ.get("PRCNN_NO_RCNN_SPLIT") != "1"
+RCNN_GEO_STREAM = os.environ.get("PRCNN_RCNN_GEO_STREAM", "0") == "1"     # the RCNN's geometry on a stream of its own (needs a 5th hardware queue)
 
 
 def build_model(cfg, device, seed=0):
@@ -137,9 +138,11 @@ def _runner_streams(device, n_sides, prio):
     per runner drew a new mapping every time (same process: 77 ms or 89 ms for the same 20 steps); with one fixed set the
     first-created streams keep the queues they were given at start-up."""
     key = (str(device), prio)
-    have = _RUNNER_STREAMS.setdefault(key, {"tail": None, "sides": []})
+    have = _RUNNER_STREAMS.setdefault(key, {"tail": None, "sides": [], "geo2": None})
     if have["tail"] is None:
         have["tail"] = torch.cuda.Stream(device, priority=int(os.environ.get("PRCNN_TAIL_PRIORITY", "0")))
+    if have["geo2"] is None and RCNN_GEO_STREAM:
+        have["geo2"] = torch.cuda.Stream(device, priority=int(os.environ.get("PRCNN_TAIL_PRIORITY", "0")))
     while len(have["sides"]) < n_sides:
         have["sides"].append(torch.cuda.Stream(device, priority=prio))
     return have["tail"], have["sides"][:n_sides]
@@ -276,6 +279,25 @@ class PipelinedRunner:
         launches, 0.3 ms of every step while they sat on the feature stream in front of the RCNN's MFMA kernels).
         -> rois, scores, event (RoIs and, if split, the RCNN geometry are ready), RCNN geometry state or None."""
         rg = None
+        geo2 = _RUNNER_STREAMS[(str(self.device), int(os.environ.get("PRCNN_SIDE_PRIORITY", "0")))].get("geo2") if SPLIT_RCNN else None
+        if geo2 is not None:
+            # PRCNN_RCNN_GEO_STREAM=1: the RCNN's geometry on a stream of its own -- proposals(i) -> geometry(i) -> final(i-1) in a row
+            # on the tail stream are 1.3-1.4 ms per step, the whole step period once the feature stream dropped to 1.2 ms
+            with torch.cuda.stream(self.tail):
+                self.tail.wait_event(ev_rpn)
+                rois, roi_scores = self.engine.propose(st)
+                ev_rois = torch.cuda.Event()
+                ev_rois.record(self.tail)
+            with torch.cuda.stream(geo2):
+                geo2.wait_event(ev_rois)
+                for _, ev_read in getattr(self, "_geo2_retired", []):
+                    geo2.wait_event(ev_read)                 # its own memory of earlier batches was read by their RCNN stages
+                self._geo2_retired = []
+                rg = self.engine.rcnn_geometry(st, rois)
+                ev_prop = torch.cuda.Event()
+                ev_prop.record(geo2)
+            self._geo2 = geo2
+            return rois, roi_scores, ev_prop, rg
         with torch.cuda.stream(self.tail):
             self.tail.wait_event(ev_rpn)
             rois, roi_scores = self.engine.propose(st)
@@ -412,6 +434,9 @@ class PipelinedRunner:
             det.update(ret)
             ready = torch.cuda.Event()
             ready.record(self.tail)
+        if rg is not None and getattr(self, "_geo2", None) is not None:
+            # geometry-stream memory read on the feature stream up to ev_rcnn: kept until that stream has waited for it
+            self._geo2_retired = getattr(self, "_geo2_retired", []) + [(rg, ev_rcnn)]
         del rg                                        # tail-stream memory, read on the feature stream up to ev_rcnn: the tail stream waits for it above
         det["ready"] = ready
         det["stream"] = self.tail
@@ -426,6 +451,9 @@ class PipelinedRunner:
         for side, ev_read, _ in self._retired:        # the kept geometry goes back to its streams' pools, ordered after its readers
             side.wait_event(ev_read)
         self._retired = []
+        for _, ev_read in getattr(self, "_geo2_retired", []):
+            self._geo2.wait_event(ev_read)
+        self._geo2_retired = []
         return det
 
 
@@ -544,6 +572,41 @@ class RecallStats:
         return out
 
 
+def host_budget(world=None, local_rank=None, cores=None):
+    """The share of the host one rank may use when W ranks of a node each drive a GPU with loader and writer processes
+    (at 16 loaders + 6 writers per rank, 8 ranks are 176 processes on 128-256 cores with no placement).
+    -> dict: cores (the CPU ids of this rank: a contiguous slice of the node's CPUs -- on the MI355X hosts GPUs 0-3 hang off
+    socket 0 and 4-7 off socket 1, and Linux numbers a socket's cores contiguously, so the slice stays on the GPU's NUMA node),
+    loaders, writers.  PRCNN_LOADER_WORKERS / PRCNN_WRITER_PROCS override the counts, PRCNN_NO_AFFINITY=1 the pinning."""
+    world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) if world is None else int(world)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else int(local_rank)
+    if cores is None:
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            cores = list(range(os.cpu_count() or 1))
+    world = max(1, world)
+    per = max(1, len(cores) // world)
+    mine = cores[(local_rank % world) * per:(local_rank % world) * per + per] or cores
+    # one core for the thread that feeds the GPU, a quarter of the rest for the writers (text formatting), the rest for the loaders
+    spare = max(1, len(mine) - 1)
+    writers = max(1, min(6, spare // 4))
+    loaders = max(1, min(16, spare - writers))
+    return {"cores": mine, "loaders": int(os.environ.get("PRCNN_LOADER_WORKERS", loaders)),
+            "writers": int(os.environ.get("PRCNN_WRITER_PROCS", writers)), "world": world, "local_rank": local_rank}
+
+
+def pin_to_budget(budget):
+    """Restrict this process (and the loader / writer processes it starts: affinity is inherited) to the rank's cores."""
+    if os.environ.get("PRCNN_NO_AFFINITY") == "1" or budget["world"] <= 1:
+        return False
+    try:
+        os.sched_setaffinity(0, budget["cores"])
+        return True
+    except (AttributeError, OSError):
+        return False
+
+
 def shard_scene_ids(num_scenes, rank, world):
     """Rank r evaluates scenes r, r+world, ... (independent units)."""
     return list(range(rank, num_scenes, world))
@@ -610,8 +673,14 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
     M = cfg.TEST.RPN_POST_NMS_TOP_N
     on_gpu = torch.device(device).type == "cuda"
     runner = PipelinedRunner(model, cfg, device) if on_gpu else None
+    budget = host_budget()
+    if stats is not None:
+        stats["host_budget"] = {"loaders": budget["loaders"], "writers": budget["writers"], "cores": len(budget["cores"]),
+                                "pinned": pin_to_budget(budget)}
+    else:
+        pin_to_budget(budget)
     if workers is None:
-        workers = int(os.environ.get("PRCNN_LOADER_WORKERS", "16"))
+        workers = budget["loaders"]
     starts = list(range(0, len(scene_ids), batch_size))
     stage = None
     if device_input:
@@ -667,7 +736,7 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
     writers = None
     if output_dir:
         wctx = "forkserver" if (on_gpu and torch.cuda.is_initialized()) else "fork"
-        writers = ProcessPoolExecutor(max_workers=int(os.environ.get("PRCNN_WRITER_PROCS", "6")),
+        writers = ProcessPoolExecutor(max_workers=budget["writers"],
                                       mp_context=multiprocessing.get_context(os.environ.get("PRCNN_LOADER_CONTEXT", wctx)))
     jobs = []
     results = {}

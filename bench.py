@@ -278,7 +278,7 @@ def driver_leg(cfg, model, dev, scenes=1536):
     finally:
         shutil.rmtree(out, ignore_errors=True)
     return {"value": round(E.steady_state_rate(stats, BATCH), 1), "unit": "scenes/s", "scenes": scenes, "result_files": files,
-            "detections": int(counts.sum()), "loader_processes": int(os.environ.get("PRCNN_LOADER_WORKERS", "16")),
+            "detections": int(counts.sum()), "host_budget": stats.get("host_budget"),
             "what": "eval_scenes: synthetic scene source + host 16384-point stage in loader processes, pinned upload, engine, "
                     "D2H, KITTI text files by writer processes; steady state between the first and the last batch"}
 

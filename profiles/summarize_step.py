@@ -12,7 +12,7 @@ marks = [i for i, r in enumerate(rows) if "fps_pruned_kernel<16" in r["Kernel_Na
 # steady-state window: from the second sampling launch after the middle of the trace to the last one; a STEP = one launch of
 # the fused RPN tail (one per batch).  (Round 2 counted sa_xyz_mlp<32> launches, which moved into the group chain -- one per
 # group -- at the end of that round: the window search found nothing and the committed table was empty.)
-STEP_KERNEL = "rpn_tail_kernel"
+STEP_KERNEL = "rpn_tail"          # rpn_tail_kernel or rpn_tail_lin_kernel
 assert len(marks) >= 3, "need at least three geometry groups in the trace"
 a, b = marks[max(1, len(marks) // 2)], marks[-1]
 sel = rows[a:b]

@@ -125,3 +125,22 @@ def test_sharded_detections_gathered_then_ap_on_rank0():
     assert shape[0] == 16 and ids == list(range(16))
     assert abs(ap3d - 100.0) < 1e-9 and abs(apbev - 100.0) < 1e-9
     assert head.startswith("Car AP@0.70, 0.70, 0.70")
+
+
+def test_host_budget_splits_the_node_between_ranks():
+    """8 ranks on a 128-core node: disjoint contiguous 16-core slices (GPU r on the cores of its own socket half), and a loader /
+    writer count that fits the slice instead of 16 + 6 processes per rank (176 host processes with no placement)."""
+    from conftest import pkg
+    E = pkg("eval_rcnn")
+    cores = list(range(128))
+    seen = set()
+    for r in range(8):
+        b = E.host_budget(world=8, local_rank=r, cores=cores)
+        assert b["cores"] == list(range(16 * r, 16 * r + 16))
+        assert not (seen & set(b["cores"]))
+        seen |= set(b["cores"])
+        assert b["loaders"] + b["writers"] + 1 <= 16 and b["loaders"] >= 8 and b["writers"] >= 1
+    one = E.host_budget(world=1, local_rank=0, cores=cores)
+    assert one["cores"] == cores and one["loaders"] == 16 and one["writers"] == 6        # a single rank keeps round 2's counts
+    tiny = E.host_budget(world=8, local_rank=5, cores=list(range(4)))                    # more ranks than cores: still valid
+    assert tiny["loaders"] >= 1 and tiny["writers"] >= 1 and tiny["cores"]

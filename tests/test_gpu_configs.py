@@ -132,3 +132,28 @@ def test_recall_statistics_with_ground_truth():
     st3 = E.RecallStats(DEV)
     E.eval_scenes(model, cfg, DEV, src, src.ids, batch_size=2, workers=0, recall=st3)
     assert st3.result()["total_gt_bbox"] == 40
+
+
+def test_bench_two_ranks_on_one_gpu_self_launch_barrier_and_gather():
+    """BASELINE configs[3] rehearsed on the one GPU of this box (no 8-GPU node was ever available to the driver): `python bench.py
+    --gpus 2` as ONE command re-launches itself as two ranks under torch.distributed.run on 127.0.0.1; with
+    PRCNN_BENCH_SHARE_GPU=1 both ranks drive cuda:0 and the exchange runs over gloo (RCCL refuses two ranks on one device).
+    Proves the self-launch, the rank barriers around the timed region, the max-over-ranks clock and the final all_gather of the
+    padded detection tables on hardware: one JSON line from rank 0, n_gpus = 2, twice the scenes of one rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PRCNN_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--prewarm", "6",
+                          "--no-roofline", "--no-driver", "--no-cpu-baseline", "--no-lidar"], env=env, cwd=root, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["scaling"] == "weak" and line["value"] > 0
+    assert abs(line["value"] - 2 * 6 * 8 / (line["ms_per_step"] * 6 * 1e-3)) < 1e-3 * line["value"]     # whole-job scenes / max-over-ranks time
+    assert line["config"]["detections_gathered"] > 0                                                   # both ranks' tables arrived on rank 0
