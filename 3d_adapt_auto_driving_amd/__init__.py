@@ -8,5 +8,8 @@ The directory name starts with a digit, so import it with
 import os as _os
 
 PACKAGE_DIR = _os.path.dirname(_os.path.abspath(__file__))
-DROPIN_DIR = _os.path.join(PACKAGE_DIR, "dropin")
+DROPIN_DIR = _os.path.join(PACKAGE_DIR, "dropin")                  # pointnet2_cuda / iou3d_cuda / roipool3d_cuda as Python modules over ctypes
+# the same three names as COMPILED extension modules (pybind11 over the C ABI, csrc/bindings/; built by __graft_entry__.build()):
+# the reference's own entry points only, with its bindings' signatures -- put this directory on sys.path instead of DROPIN_DIR
+NATIVE_DROPIN_DIR = _os.path.join(PACKAGE_DIR, "dropin_native")
 __version__ = "0.1.0"

@@ -91,6 +91,18 @@ def _pad1(t, n):
 USE_ROWS_GEMM128 = os.environ.get("PRCNN_ROWS_GEMM") is not None
 
 
+_STRICT = [False]        # set while an engine whose every layer is covered by the hand-written kernels runs a stage (FastPointRCNN._strictly)
+
+
+def _lib_gemm_allowed():
+    """A GEMM library may only appear on the engine's path when an A/B switch asked for it (all-rows mode, PRCNN_LIB_GEMM,
+    PRCNN_NO_POINT_MLP, ...) or when the network's shapes are not the ones the hand-written kernels cover (tiny test
+    configurations).  With a covered network (default.yaml) and every product switch at its default, a layer that lands here means
+    a silently different engine was about to run."""
+    return (not _STRICT[0] or not USE_PACKED or not USE_POINT_LAYER or not USE_RCNN_POINT_MLP or not USE_POOL_DEDUP
+            or not USE_ROIPOOL_CANONICAL or os.environ.get("PRCNN_ALLOW_LIB_GEMM") == "1")
+
+
 def gemm_bias_act(a, wt, bias, relu):
     """a (rows, K) @ wt (K, Cout) + bias, optional ReLU.  128-wide layers with K in (128, 256) run on the tiled MFMA layer
     kernel of csrc/rcnn_point_mlp.hip when USE_ROWS_GEMM128 is set; everything else is a
@@ -99,6 +111,10 @@ def gemm_bias_act(a, wt, bias, relu):
             and a.shape[0] % 64 == 0 and a.shape[0] >= 4096 and a.stride(1) == 1 and a.stride(0) % 4 == 0
             and a.data_ptr() % 16 == 0):
         return pu.pointnet2.rows_gemm128_wrapper(a, wt, bias, relu)
+    if a.is_cuda and not _lib_gemm_allowed():
+        raise RuntimeError("FastPointRCNN: a %dx%d layer over %d rows would run on a GEMM library although no A/B switch selects one "
+                           "(shape not covered by csrc/packed_layer.hip?); set PRCNN_ALLOW_LIB_GEMM=1 to permit it"
+                           % (wt.shape[0], wt.shape[1], a.shape[0]))
     if relu:
         try:
             return torch._addmm_activation(bias, a, wt)
@@ -285,6 +301,35 @@ class FastPointRCNN:
             if (USE_POINT_LAYER and USE_PACKED and len(self.rcnn_cls.layers) > 1 and len(self.rcnn_reg.layers) > 1 and c0[2] and r0[2] and
                     c0[0].shape == r0[0].shape and c0[0].shape[0] % 128 == 0 and c0[0].shape[1] % 128 == 0):
                 self.rcnn_head1 = (torch.cat([c0[0], r0[0]], 1).contiguous(), torch.cat([c0[1], r0[1]]).contiguous(), c0[0].shape[1])
+
+    def _covered(self):
+        """True when every MLP of this network runs on a kernel of this build with the product switches at their defaults:
+        RPN SA scales on the packed / wide / coordinates-only kernels, the fused RPN tail, the RCNN entrance chain and SA levels."""
+        try:
+            ok = bool(PAD128 and self.rpn_tail is not None)
+            for _, scales in self.sa:
+                ok = ok and all(sc[2].packed is not None or sc[2].wide is not None or sc[3] == 0 for sc in scales)
+            if self.cfg.RCNN.ENABLED:
+                ok = ok and self._point_mlp_ok() and all(m[3].packed is not None or m[3].wide is not None for m in self.rcnn_sa)
+            return ok
+        except Exception:
+            return False
+
+    def _strictly(self):
+        """context manager: while it is open, a layer of a covered network that falls to a GEMM library raises (gemm_bias_act)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            if getattr(self, "_is_covered", None) is None:
+                self._is_covered = self._covered()
+            prev = _STRICT[0]
+            _STRICT[0] = bool(self._is_covered)
+            try:
+                yield
+            finally:
+                _STRICT[0] = prev
+        return cm()
 
     def _fold_rpn_tail(self):
         """Weights of csrc/rpn_tail.hip (finest FP module + both RPN heads in one kernel) when the network has the shape that
@@ -651,7 +696,8 @@ class FastPointRCNN:
         if geo is None:
             geo = self.geometry(xyz)
         B, N, _ = xyz.shape
-        feats, tail = self._backbone(xyz, geo, fuse_tail=True)
+        with self._strictly():
+            feats, tail = self._backbone(xyz, geo, fuse_tail=True)
         if tail is not None:
             # interpolation + FP module 0 + both heads: one kernel, a 64-point tile never leaves LDS (csrc/rpn_tail.hip)
             known_feat, idx, weight = tail
@@ -707,7 +753,8 @@ class FastPointRCNN:
 
     @torch.no_grad()
     def rcnn_features(self, rg):
-        return self._rcnn_features(rg)
+        with self._strictly():
+            return self._rcnn_features(rg)
 
     @torch.no_grad()
     def forward(self, pts_input, geo=None):

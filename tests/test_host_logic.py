@@ -359,3 +359,45 @@ def test_recall_gt_set_is_class_only_in_eval_like_the_reference(tmp_path):
             kept = KittiRCNNDataset.filtrate_objects(Fake, objs)
             ref = ku.objs_to_boxes3d(kept)
             np.testing.assert_allclose(ref, want, rtol=1e-6)
+
+
+def test_compiled_extension_modules_load_and_export_the_reference_bindings():
+    """The pybind11 modules of csrc/bindings/ (built by __graft_entry__.build() into dropin_native/): importable without a GPU,
+    named like the reference's extension modules, exporting exactly the functions the reference binds
+    (pointnet2_api.cpp:10-24, iou3d.cpp:174-179, roipool3d.cpp:198-203); device entry points refuse CPU tensors instead of
+    computing anything (there is no CPU product path); the two host utilities of roipool3d_cuda do run on CPU tensors and
+    reproduce the reference's own compiled roipool3d.cpp (fixture g5)."""
+    import importlib
+    import sys
+    import torch
+    p = pkg()
+    want = {"pointnet2_cuda": {"ball_query_wrapper", "group_points_wrapper", "group_points_grad_wrapper", "gather_points_wrapper",
+                               "gather_points_grad_wrapper", "furthest_point_sampling_wrapper", "three_nn_wrapper",
+                               "three_interpolate_wrapper", "three_interpolate_grad_wrapper"},
+            "iou3d_cuda": {"boxes_overlap_bev_gpu", "boxes_iou_bev_gpu", "nms_gpu", "nms_normal_gpu"},
+            "roipool3d_cuda": {"pts_in_boxes3d_cpu", "roipool3d_cpu", "forward", "forward_slow"}}
+    saved = {n: sys.modules.pop(n, None) for n in want}
+    sys.path.insert(0, p.NATIVE_DROPIN_DIR)
+    try:
+        mods = {n: importlib.import_module(n) for n in want}
+        for n, m in mods.items():
+            assert m.__file__.endswith(".so") and os.path.dirname(m.__file__) == p.NATIVE_DROPIN_DIR
+            assert {f for f in dir(m) if not f.startswith("_")} == want[n], n
+        with pytest.raises(RuntimeError):
+            mods["pointnet2_cuda"].ball_query_wrapper(1, 4, 2, 1.0, 2, torch.zeros(1, 2, 3), torch.zeros(1, 4, 3),
+                                                      torch.zeros(1, 2, 2, dtype=torch.int32))
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g5_roipool_ref.npz"))
+        rp = mods["roipool3d_cuda"]
+        flag = torch.zeros((16, 4096), dtype=torch.long)
+        rp.pts_in_boxes3d_cpu(flag, torch.from_numpy(g["pts"]), torch.from_numpy(g["boxes"]))
+        assert np.array_equal(flag.numpy().astype(np.uint8), g["pts_flag"])
+        pp, pf, pe = torch.zeros(16, 512, 3), torch.zeros(16, 512, 9), torch.zeros(16, dtype=torch.long)
+        rp.roipool3d_cpu(torch.from_numpy(g["pts"]), torch.from_numpy(g["boxes"]), torch.from_numpy(g["feat"]), pp, pf, pe)
+        assert np.array_equal(pp.numpy(), g["pooled_pts"]) and np.array_equal(pf.numpy(), g["pooled_features"])
+        assert np.array_equal(pe.numpy(), g["pooled_empty_flag"])
+    finally:
+        sys.path.remove(p.NATIVE_DROPIN_DIR)
+        for n in want:
+            sys.modules.pop(n, None)
+            if saved[n] is not None:
+                sys.modules[n] = saved[n]
