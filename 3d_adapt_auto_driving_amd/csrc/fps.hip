@@ -627,3 +627,240 @@ extern "C" int prcnn_point_groups(int b, int n, const float *xyz, float *pxyz, f
     hipLaunchKernelGGL(point_groups_kernel, dim3((n / 64 + 3) / 4, b), dim3(256), 0, st, n, xyz, perm, (float4 *)pxyz, (float4 *)aabb);
     return check_launch("point_groups");
 }
+
+// ---- the whole geometry chain of the RCNN's RoI clouds in ONE kernel (round 3) -----------------------------------------------
+// rcnn_net.py:165-175 runs, per RoI, SA level 1 (sample 128 of the 512 pooled points, ball query r1 / 64) and SA level 2 (sample 32 of
+// those 128, ball query r2 / 64).  As separate launches over the 800 RoI clouds of a batch that was FPS, limited ball query,
+// representative map, FPS, ball query, representative map: six latency-bound kernels (one wave per cloud each, ~0.8 us per dependent
+// FPS iteration) that were 0.41 ms of the proposal stream in the pipelined step and a quarter of a millisecond of host time.
+// Here ONE WAVE serves a RoI from the pooled coordinates to both index tensors: the cloud stays in registers (8 points per lane)
+// through sampling and the first ball query, the 128 sampled centres stay in registers (2 per lane) through the second pair; the hit
+// lists are staged in LDS ([slot][centre]) and leave as coalesced rows.  Per operator the arithmetic is that of fps_reg_kernel /
+// ball_query_kernel / dup_rep_kernel: same indices, bit for bit (tests/test_gpu_ops.py compares with the separate entry points,
+// tests/test_gpu_shadow.py with the oracle).
+namespace prcnn {
+
+constexpr int RG_N = 512, RG_M1 = 128, RG_M2 = 32, RG_NS = 64;
+
+// FPS of the PPT * 64 points held in registers (point k = lane + 64 i) -> sel[0..m) in LDS; returns nothing, all lanes in step
+template <int PPT>
+__device__ __forceinline__ void roi_fps(int n, int m, KeyCodec kc, const float (&px)[PPT], const float (&py)[PPT], const float (&pz)[PPT],
+                                        int *__restrict__ s_sel, const int lane)
+{
+    float pt[PPT];
+    uint32_t pk[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int k = lane + 64 * i;
+        pt[i] = k < n ? 1e10f : -INFINITY;
+        pk[i] = k < n ? kc.encode(k) : 0xffffffffu;
+    }
+    int old = 0;
+    if (lane == 0) s_sel[0] = 0;
+    for (int j = 1; j < m; ++j) {
+        const int pl = old & 63, pi = old >> 6;
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const float vx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[i]), pl));
+            const float vy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[i]), pl));
+            const float vz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[i]), pl));
+            if (i == pi) { ox = vx; oy = vy; oz = vz; }
+        }
+        float lv = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const float d = sqdist3(px[i], py[i], pz[i], ox, oy, oz);
+            const float d2 = fminf(d, pt[i]);
+            pt[i] = d2;
+            lv = fmaxf(lv, d2);
+        }
+        const float bv = wave_max_f32(lv);
+        uint32_t lk = 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const uint32_t c = pt[i] == bv ? pk[i] : 0xffffffffu;
+            lk = c < lk ? c : lk;
+        }
+        const uint32_t bkey = wave_min_u32(lk);
+        old = (bkey == 0xffffffffu || !(bv > -1.0f)) ? 0 : kc.decode(bkey);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (lane == 0) s_sel[j] = old;
+        if (bv == 0.f) {                     // only copies are left: every later pick is point 0 (see fps_reg_kernel)
+            for (int jj = j + 1 + lane; jj < m; jj += 64) s_sel[jj] = 0;
+            break;
+        }
+    }
+}
+
+// first `ns` in-range points (k < n_scan, index order) of CPL centres per lane among the PPT * 64 points in registers -> hit lists in
+// LDS, s_hits[slot * stride + centre], counts in s_cnt[centre]; lanes whose centres are all full stop the scan early together
+template <int PPT, int CPL>
+__device__ __forceinline__ void roi_ball_query(int n_scan, int ns, float r2, const float (&px)[PPT], const float (&py)[PPT],
+                                               const float (&pz)[PPT], const float (&cx)[CPL], const float (&cy)[CPL], const float (&cz)[CPL],
+                                               const bool (&live)[CPL], int *__restrict__ s_hits, int stride, int *__restrict__ s_cnt, const int lane)
+{
+    int cnt[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) cnt[q] = live[q] ? 0 : ns;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int base = 64 * i;
+        if (base >= n_scan) break;
+        bool full = true;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) full = full && cnt[q] >= ns;
+        if (__all(full)) break;
+        const int nb = min(64, n_scan - base);
+        for (int l = 0; l < nb; ++l) {
+            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[i]), l));
+            const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[i]), l));
+            const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[i]), l));
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const float d2 = sqdist3(cx[q], cy[q], cz[q], x, y, z);
+                if (d2 < r2 && cnt[q] < ns) {
+                    s_hits[cnt[q] * stride + lane + 64 * q] = base + l;
+                    ++cnt[q];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CPL; ++q)
+        if (live[q]) s_cnt[lane + 64 * q] = cnt[q];
+}
+
+__global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
+    KeyCodec kc1, KeyCodec kc2, float r1sq, float r2sq, int ns1, int ns2, const float *__restrict__ xyz /* (b, 512, 3) */,
+    const int *__restrict__ limit /* (b) */, float *__restrict__ new_xyz1 /* (b,128,3) */, int *__restrict__ idx1 /* (b,128,ns1) */,
+    int *__restrict__ rep1 /* (b,128) */, float *__restrict__ new_xyz2 /* (b,32,3) */, int *__restrict__ idx2 /* (b,32,ns2) */,
+    int *__restrict__ rep2 /* (b,32) */)
+{
+    __shared__ int s_hits[RG_NS * RG_M1];            // 32 KB: hit lists of the running ball query, [slot][centre]
+    __shared__ int s_cnt[RG_M1];
+    __shared__ int s_sel1[RG_M1], s_sel2[RG_M2];
+    __shared__ int s_first[RG_N];
+    __shared__ int s_rep1[RG_M1];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float *__restrict__ cloud = xyz + (long)b * RG_N * 3;
+    const int lim = limit ? max(limit[b], 1) : RG_N;
+    __builtin_amdgcn_s_setprio(3);
+
+    // ---- level 1: sample 128 of the 512 pooled points
+    float px[8], py[8], pz[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = lane + 64 * i;
+        px[i] = cloud[3 * k]; py[i] = cloud[3 * k + 1]; pz[i] = cloud[3 * k + 2];
+    }
+    roi_fps<8>(RG_N, RG_M1, kc1, px, py, pz, s_sel1, lane);
+    __syncthreads();
+    // the sampled centres: coordinates into registers (centre c = lane + 64 q) and out to new_xyz1
+    float qx[2], qy[2], qz[2];
+    int src1[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = lane + 64 * q, k = s_sel1[c];
+        qx[q] = cloud[3 * k]; qy[q] = cloud[3 * k + 1]; qz[q] = cloud[3 * k + 2];
+        float *o = new_xyz1 + ((long)b * RG_M1 + c) * 3;
+        o[0] = qx[q]; o[1] = qy[q]; o[2] = qz[q];
+        src1[q] = k >= lim ? k % lim : k;                        // the distinct pooled point behind this centre
+    }
+    // ---- ball query of level 1 over the DISTINCT pooled points only (prcnn_ball_query_limit)
+    {
+        const bool live[2] = {true, true};
+        roi_ball_query<8, 2>(min(RG_N, lim), ns1, r1sq, px, py, pz, qx, qy, qz, live, s_hits, RG_M1, s_cnt, lane);
+    }
+    // representative map of the centres: the first centre sampled from the same source (prcnn_dup_rep)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s_first[lane + 64 * i] = 0x7fffffff;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) atomicMin(&s_first[src1[q]], lane + 64 * q);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = s_first[src1[q]];
+        s_rep1[lane + 64 * q] = r;
+        rep1[(long)b * RG_M1 + lane + 64 * q] = r;
+    }
+    {   // rows out: slot s of centre c; slots past the hit count repeat the first hit, an empty ball is a row of zeros
+        int *out = idx1 + (long)b * RG_M1 * ns1;
+        for (int e = lane; e < RG_M1 * ns1; e += 64) {
+            const int c = e / ns1, s = e - c * ns1;
+            const int tot = s_cnt[c];
+            out[e] = tot == 0 ? 0 : s_hits[(s < tot ? s : 0) * RG_M1 + c];
+        }
+    }
+    __syncthreads();                                              // s_hits / s_cnt are reused below
+
+    // ---- level 2: sample 32 of the 128 centres (held in registers as points k = lane + 64 q), ball query over all 128
+    roi_fps<2>(RG_M1, RG_M2, kc2, qx, qy, qz, s_sel2, lane);
+    __syncthreads();
+    float cx[1] = {0.f}, cy[1] = {0.f}, cz[1] = {0.f};
+    const bool has = lane < RG_M2;
+    const int src2 = has ? s_rep1[s_sel2[lane]] : 0;            // the first level-1 centre with the same source as this one's pick
+    // centre coordinates of level 2 by a cross-lane read of the registers that hold the 128 points
+    {
+        const int k = has ? s_sel2[lane] : 0;
+        const int ql = k & 63, qi = k >> 6;
+        const float x0 = __shfl(qx[0], ql), x1 = __shfl(qx[1], ql);
+        const float y0 = __shfl(qy[0], ql), y1 = __shfl(qy[1], ql);
+        const float z0 = __shfl(qz[0], ql), z1 = __shfl(qz[1], ql);
+        cx[0] = qi ? x1 : x0; cy[0] = qi ? y1 : y0; cz[0] = qi ? z1 : z0;
+        if (has) {
+            float *o = new_xyz2 + ((long)b * RG_M2 + lane) * 3;
+            o[0] = cx[0]; o[1] = cy[0]; o[2] = cz[0];
+        }
+    }
+    {
+        const bool live[1] = {has};
+        roi_ball_query<2, 1>(RG_M1, ns2, r2sq, qx, qy, qz, cx, cy, cz, live, s_hits, RG_M2, s_cnt, lane);
+    }
+    // representative map of level 2's centres through the map of level 1
+    for (int i = lane; i < RG_M1; i += 64) s_first[i] = 0x7fffffff;
+    __syncthreads();
+    if (has) atomicMin(&s_first[src2], lane);
+    __syncthreads();
+    if (has) rep2[(long)b * RG_M2 + lane] = s_first[src2];
+    {
+        int *out = idx2 + (long)b * RG_M2 * ns2;
+        for (int e = lane; e < RG_M2 * ns2; e += 64) {
+            const int c = e / ns2, s = e - c * ns2;
+            const int tot = s_cnt[c];
+            out[e] = tot == 0 ? 0 : s_hits[(s < tot ? s : 0) * RG_M2 + c];
+        }
+    }
+}
+
+}  // namespace prcnn
+
+/* RoI clouds xyz (b,512,3) whose points k >= limit[cloud] are copies of point k % limit[cloud] (pooled RoI rows) ->
+ *   new_xyz1 (b,128,3), idx1 (b,128,ns1), rep1 (b,128): furthest_point_sample(128) + ball_query(r1, ns1) over the distinct points
+ *                                                        (= prcnn_fps_new_xyz, prcnn_ball_query_limit, prcnn_dup_rep with `limit`);
+ *   new_xyz2 (b,32,3), idx2 (b,32,ns2), rep2 (b,32): the same one level up over the 128 centres (prcnn_fps_new_xyz, prcnn_ball_query
+ *                                                      with empty balls written as zeros, prcnn_dup_rep with prev = rep1).
+ * ns1, ns2 <= 64.  The shape of rcnn_net.py:165-175 under default.yaml (RCNN.NUM_POINTS 512, SA_CONFIG NPOINTS [128, 32, -1]). */
+extern "C" int prcnn_rcnn_roi_geometry(int b, int n, int m1, float r1, int ns1, int m2, float r2, int ns2, const float *xyz,
+                                       const int *limit, float *new_xyz1, int *idx1, int *rep1, float *new_xyz2, int *idx2, int *rep2,
+                                       void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && n == RG_N && m1 == RG_M1 && m2 == RG_M2, "rcnn_roi_geometry: written for 512 -> 128 -> 32 points (got %d -> %d -> %d)", n, m1, m2);
+    PRCNN_REQUIRE(ns1 >= 1 && ns1 <= RG_NS && ns2 >= 1 && ns2 <= RG_NS && r1 > 0.f && r2 > 0.f, "rcnn_roi_geometry: nsample must be 1..64, radii positive");
+    if (b == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(xyz && new_xyz1 && idx1 && rep1 && new_xyz2 && idx2 && rep2, "rcnn_roi_geometry: null pointer");
+    auto codec = [](int npts) {
+        const int bs = host_opt_n_threads(npts);
+        KeyCodec kc;
+        kc.log2bs = 0;
+        while ((1 << kc.log2bs) < bs) ++kc.log2bs;
+        const int nq = (npts + bs - 1) / bs;
+        kc.sh = 0;
+        while ((1 << kc.sh) < nq) ++kc.sh;
+        return kc;
+    };
+    hipLaunchKernelGGL(rcnn_roi_geometry_kernel, dim3(b), dim3(64), 0, (hipStream_t)stream, codec(RG_N), codec(RG_M1), r1 * r1, r2 * r2,
+                       ns1, ns2, xyz, limit, new_xyz1, idx1, rep1, new_xyz2, idx2, rep2);
+    return check_launch("rcnn_roi_geometry");
+}

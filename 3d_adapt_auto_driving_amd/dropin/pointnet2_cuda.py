@@ -253,6 +253,29 @@ def ball_pack_wrapper(idx, xyz, new_xyz, limit=None, rep=None, crep=None):
     return pk
 
 
+def rcnn_roi_geometry_supported(n, m1, ns1, m2, ns2):
+    return n == 512 and m1 == 128 and m2 == 32 and 1 <= ns1 <= 64 and 1 <= ns2 <= 64
+
+
+def rcnn_roi_geometry_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2):
+    """The geometry of the RCNN's two sampled SA levels for every RoI cloud in ONE launch (prcnn_rcnn_roi_geometry): xyz (b,512,3),
+    limit (b) i32 -> (new_xyz1 (b,128,3), idx1 (b,128,ns1), rep1 (b,128), new_xyz2 (b,32,3), idx2 (b,32,ns2), rep2 (b,32)) -- what
+    fps_new_xyz_wrapper, ball_query_limit_wrapper, dup_rep_wrapper, fps_new_xyz_wrapper, ball_query_wrapper (into zeros),
+    dup_rep_wrapper return one after the other."""
+    _chk(torch.float32, xyz); _chk(torch.int32, limit)
+    b, n, _ = xyz.shape
+    dev = xyz.device
+    new1 = torch.empty((b, m1, 3), dtype=torch.float32, device=dev)
+    idx1 = torch.empty((b, m1, ns1), dtype=torch.int32, device=dev)
+    rep1 = torch.empty((b, m1), dtype=torch.int32, device=dev)
+    new2 = torch.empty((b, m2, 3), dtype=torch.float32, device=dev)
+    idx2 = torch.empty((b, m2, ns2), dtype=torch.int32, device=dev)
+    rep2 = torch.empty((b, m2), dtype=torch.int32, device=dev)
+    _lib.call("prcnn_rcnn_roi_geometry", b, n, m1, float(r1), ns1, m2, float(r2), ns2, xyz.data_ptr(), limit.data_ptr(), new1.data_ptr(),
+              idx1.data_ptr(), rep1.data_ptr(), new2.data_ptr(), idx2.data_ptr(), rep2.data_ptr(), _lib.current_stream(xyz))
+    return new1, idx1, rep1, new2, idx2, rep2
+
+
 def dup_rep_wrapper(sel, n, limit=None, prev=None):
     """sel (b,m) i32 = an FPS answer over clouds of n points whose copies are described by limit (b) i32 (points k >= limit are
     copies of k % limit) and / or prev (b,n) i32 (their representative map) -> rep (b,m) i32: for every sampled point the

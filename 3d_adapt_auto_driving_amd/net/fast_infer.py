@@ -43,6 +43,9 @@ USE_POOL_DEDUP = os.environ.get("PRCNN_NO_POOL_DEDUP") is None
 # round 3: 7.5x fewer SA2 rows on LiDAR-shaped scenes, bit-identical results).  PRCNN_NO_CENTRE_DEDUP=1: A/B.
 USE_CENTRE_DEDUP = os.environ.get("PRCNN_NO_CENTRE_DEDUP") is None
 USE_CENTRE_SKIP = os.environ.get("PRCNN_NO_CENTRE_SKIP") is None       # ... and such a centre gets no rows of its own either (A/B)
+# sampling, ball query and representative map of both sampled RCNN levels for every RoI cloud in one launch; PRCNN_NO_ROI_GEOMETRY=1:
+# the six separate launches (A/B, same results)
+USE_ROI_GEOMETRY = os.environ.get("PRCNN_NO_ROI_GEOMETRY") is None
 USE_POINT_LAYER = os.environ.get("PRCNN_LIB_GEMM") is None     # per-point layers (FP modules, heads) on the own MFMA layer kernel
 # every per-point width zero-padded to a multiple of 128 (SA level outputs, FP inputs, narrow head outputs), so that NO layer
 # of the engine is left to a GEMM library: fixed summation order everywhere, reproduced bit for bit by the oracle
@@ -840,9 +843,27 @@ class FastPointRCNN:
         # picked from copies of one source are copies of one another -- coordinates, ball and therefore features (dup_rep).
         centre_dedup = bool(USE_CENTRE_DEDUP and pooled_cnt is not None and point_mlp and has_entry(ext, "dup_rep_wrapper"))
         rep = None
+        # The two sampled levels' geometry for every RoI cloud in ONE launch (a wave per RoI: csrc/fps.hip rcnn_roi_geometry_kernel)
+        # instead of FPS, ball query, representative map -- twice -- as six latency-bound launches
+        fused_geo = None
+        sa = self.rcnn_sa
+        if (USE_ROI_GEOMETRY and centre_dedup and USE_CENTRE_SKIP and len(sa) >= 2 and sa[0][0] is not None and sa[1][0] is not None
+                and has_entry(ext, "rcnn_roi_geometry_wrapper") and USE_PACKED
+                and all(m_[3].packed is not None or m_[3].wide is not None for m_ in sa[:2])
+                and ext.rcnn_roi_geometry_supported(cur_xyz.shape[1], sa[0][0], sa[0][2], sa[1][0], sa[1][2])):
+            fused_geo = ext.rcnn_roi_geometry_wrapper(cur_xyz, pooled_cnt.view(-1), sa[0][0], sa[0][1], sa[0][2], sa[1][0], sa[1][1], sa[1][2])
         for k, (npoint, radius, ns, mlp, cin) in enumerate(self.rcnn_sa):
             lev = {"xyz": cur_xyz, "new_xyz": None, "idx": None, "pack": None}
-            if npoint is not None:
+            if npoint is not None and fused_geo is not None and k < 2:
+                new_xyz, idx, rep_out = fused_geo[3 * k:3 * k + 3]
+                if k == 0:
+                    lev["pack"] = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, pooled_cnt.view(-1), None, rep_out)
+                else:
+                    lev["pack"] = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, None, rep, rep_out)
+                rep = rep_out
+                lev["new_xyz"], lev["idx"] = new_xyz, idx
+                cur_xyz = new_xyz
+            elif npoint is not None:
                 Bc, n = cur_xyz.shape[0], cur_xyz.shape[1]
                 if n <= 1024 and has_entry(ext, "fps_new_xyz_wrapper"):
                     sel, new_xyz = ext.fps_new_xyz_wrapper(cur_xyz, npoint)    # sampling + the centres' coordinates, one launch

@@ -188,6 +188,17 @@ int prcnn_ball_pack_rep(int b, int n, int m, int nsample, const int *idx, const 
  * and / or prev (b,n) i32 is the representative map of those n points; rep (b,m) i32 <- the first sampled point with the
  * same source as sampled point j. */
 int prcnn_dup_rep(int b, int n, int m, const int *sel, const int *limit, const int *prev, int *rep, void *stream);
+
+/* The whole geometry chain of the RCNN's RoI clouds in ONE launch, a wave per RoI (csrc/fps.hip, round 3): xyz (b,512,3) pooled
+ * coordinates whose points k >= limit[cloud] are copies of point k % limit[cloud] ->
+ *   new_xyz1 (b,128,3), idx1 (b,128,ns1), rep1 (b,128)  = prcnn_fps_new_xyz(128), prcnn_ball_query_limit(r1, ns1), prcnn_dup_rep(limit)
+ *   new_xyz2 (b,32,3),  idx2 (b,32,ns2),  rep2 (b,32)   = the same one level up over the 128 centres: prcnn_fps_new_xyz(32),
+ *                                                         prcnn_ball_query(r2, ns2) into a zero-filled tensor, prcnn_dup_rep(prev = rep1)
+ * -- rcnn_net.py:165-175 (SA modules 1 and 2 of the RCNN: pointnet2_modules.py:37-46 sampling + grouping indices) under
+ * default.yaml's RCNN.NUM_POINTS 512, SA_CONFIG.NPOINTS [128, 32, -1].  n == 512, m1 == 128, m2 == 32, ns1, ns2 <= 64. */
+int prcnn_rcnn_roi_geometry(int b, int n, int m1, float r1, int ns1, int m2, float r2, int ns2, const float *xyz,
+                            const int *limit, float *new_xyz1, int *idx1, int *rep1, float *new_xyz2, int *idx2, int *rep2,
+                            void *stream);
 /* out_is_zero (this entry, prcnn_sa_xyz_mlp_packed, prcnn_packed_layer_segmax): the results arrive through atomicMax into a
  * zeroed slice; 0 = the entry zeroes out[..., out_col : out_col + width) itself, 1 = the caller has zeroed it (one fill for all
  * the scales of a level instead of one strided fill per scale). */

@@ -167,6 +167,25 @@ class pointnet2_cpu:
         return _CpuPack(idx, limit, rep, crep)
 
     @staticmethod
+    def rcnn_roi_geometry_supported(n, m1, ns1, m2, ns2):
+        return n == 512 and m1 == 128 and m2 == 32 and 1 <= ns1 <= 64 and 1 <= ns2 <= 64
+
+    @staticmethod
+    def rcnn_roi_geometry_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2):
+        """prcnn_rcnn_roi_geometry as the chain of stand-ins it fuses"""
+        P = pointnet2_cpu
+        b, n, _ = xyz.shape
+        sel1, new1 = P.fps_new_xyz_wrapper(xyz, m1)
+        idx1 = torch.empty((b, m1, ns1), dtype=torch.int32)
+        P.ball_query_limit_wrapper(b, n, m1, r1, ns1, new1, xyz, limit, idx1)
+        rep1 = P.dup_rep_wrapper(sel1, n, limit, None)
+        sel2, new2 = P.fps_new_xyz_wrapper(new1, m2)
+        idx2 = torch.zeros((b, m2, ns2), dtype=torch.int32)
+        P.ball_query_wrapper(b, m1, m2, r2, ns2, new2, new1, idx2)
+        rep2 = P.dup_rep_wrapper(sel2, m1, None, rep1)
+        return new1, idx1, rep1, new2, idx2, rep2
+
+    @staticmethod
     def dup_rep_wrapper(sel, n, limit=None, prev=None):
         """for every sampled point the first sampled point with the same source (plain loops; see prcnn_dup_rep)"""
         b, m = sel.shape

@@ -456,6 +456,44 @@ def test_rotate_iou_kernel_vs_reference_python_fixture():
         assert same >= 0.99, (crit, same)
 
 
+@pytest.mark.parametrize("ns1,ns2", [(64, 64), (16, 48)])
+def test_rcnn_roi_geometry_equals_the_separate_entry_points(ext, ns1, ns2):
+    """prcnn_rcnn_roi_geometry (one wave per RoI: FPS 512 -> 128, limited ball query, representative map, FPS 128 -> 32, ball query,
+    representative map) == the six separate entry points and == the oracle chain, bit for bit.  RoI clouds as RoI pooling makes
+    them: `count` distinct points (1, a handful, ~60, 127-129, 300, 511, 512), the rest wrap-around copies (k % count); duplicates
+    inside the distinct part; a cloud whose points all coincide."""
+    from oracle import ext_cpu
+    rng = np.random.default_rng(ns1 * 100 + ns2)
+    counts = [1, 2, 7, 33, 60, 64, 65, 100, 127, 128, 129, 200, 300, 511, 512, 512, 50, 90]
+    b = len(counts)
+    xyz = np.zeros((b, 512, 3), np.float32)
+    for i, c in enumerate(counts):
+        base = (rng.standard_normal((c, 3)) * [1.2, 0.5, 0.6]).astype(np.float32)
+        if i == 5:
+            base[10:20] = base[0:10]                        # duplicates among the "distinct" points
+        if i == 16:
+            base[:] = base[0]                               # all points coincide
+        xyz[i] = base[np.arange(512) % c]
+    limit = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    P = ext.pointnet2
+    X = T(xyz)
+    got = P.rcnn_roi_geometry_wrapper(X, limit, 128, 0.2, ns1, 32, 0.4, ns2)
+    sel1, new1 = P.fps_new_xyz_wrapper(X, 128)
+    idx1 = torch.full((b, 128, ns1), -1, dtype=torch.int32, device=DEV)
+    P.ball_query_limit_wrapper(b, 512, 128, 0.2, ns1, new1, X, limit, idx1)
+    rep1 = P.dup_rep_wrapper(sel1, 512, limit, None)
+    sel2, new2 = P.fps_new_xyz_wrapper(new1, 32)
+    idx2 = torch.zeros((b, 32, ns2), dtype=torch.int32, device=DEV)
+    P.ball_query_wrapper(b, 128, 32, 0.4, ns2, new2, new1, idx2)
+    rep2 = P.dup_rep_wrapper(sel2, 128, None, rep1)
+    for k, (g, w) in enumerate(zip(got, (new1, idx1, rep1, new2, idx2, rep2))):
+        assert torch.equal(g, w), k
+    cpu = ext_cpu.pointnet2_cpu.rcnn_roi_geometry_wrapper(X.cpu(), limit.cpu(), 128, 0.2, ns1, 32, 0.4, ns2)
+    for k, (g, w) in enumerate(zip(got, cpu)):
+        assert torch.equal(g.cpu(), w), k
+    assert int((got[2] != torch.arange(128, device=DEV).view(1, -1)).sum()) > 500        # many centres are copies of earlier ones
+
+
 def test_point_major_kernels(ext, oracle):
     """group_cat_pm / maxpool_pm / three_interpolate_pm against the oracle's channel-major results
     rearranged to the point-major row layout [features | pad | dx dy dz | 0] (pure data movement and

@@ -142,6 +142,14 @@ def check_sa_packed(self, name, args, host, ret):
     assert torch.equal(repl, want), name
 
 
+def check_roi_geometry(self, name, args, host, ret):
+    """the fused geometry of the RoI clouds (FPS, limited ball query, representative map, twice) == the chain of oracle stand-ins,
+    all six outputs bit for bit"""
+    want = self._cpu.rcnn_roi_geometry_wrapper(*host)
+    for k, (g, w) in enumerate(zip(ret, want)):
+        assert torch.equal(g.cpu(), w), (name, k)
+
+
 def check_dup_rep(self, name, args, host, ret):
     want = self._cpu.dup_rep_wrapper(*host)
     assert torch.equal(ret.cpu(), want), name
@@ -297,6 +305,7 @@ def check_fps_new_xyz(self, name, args, host, ret):
 
 POINTNET2["fps_new_xyz_wrapper"] = check_fps_new_xyz
 POINTNET2["dup_rep_wrapper"] = check_dup_rep
+POINTNET2["rcnn_roi_geometry_wrapper"] = check_roi_geometry
 POINTNET2["sa_packed_mlp_wrapper"] = check_sa_packed
 POINTNET2["sa_wide_fused_wrapper"] = {9: "exact"}          # one scale of a wide level in one kernel: output slice vs the oracle chain
 
@@ -363,7 +372,9 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
         assert torch.isfinite(det[k].float()).all(), k
     assert (det["num"] > 0).all()
     # coverage: every kernel family of the step was exercised at the batch-8 shapes
-    want_calls = {"furthest_point_sampling_wrapper": 4, "fps_new_xyz_wrapper": 2, "dup_rep_wrapper": 2, "ball_query_wrapper": 9, "ball_query_limit_wrapper": 1, "three_nn_wrapper": 4, "ball_pack_wrapper": 11,
+    fg = F.USE_ROI_GEOMETRY          # the RoI clouds' FPS / ball query / representative maps of both sampled levels in one launch
+    want_calls = {"furthest_point_sampling_wrapper": 4, "fps_new_xyz_wrapper": 0 if fg else 2, "dup_rep_wrapper": 0 if fg else 2,
+                  "ball_query_wrapper": 8 if fg else 9, "ball_query_limit_wrapper": 0 if fg else 1, "rcnn_roi_geometry_wrapper": 1 if fg else 0, "three_nn_wrapper": 4, "ball_pack_wrapper": 11,
                   "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 4,
                   "three_interpolate_cat_pm_wrapper": 0 if F.USE_FP_LINEAR else 3, "packed_layer_interp_wrapper": 3 if F.USE_FP_LINEAR else 0,
                   "rpn_tail_wrapper": 0 if F.USE_FP_LINEAR else 1, "rpn_tail_lin_wrapper": 1 if F.USE_FP_LINEAR else 0, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
