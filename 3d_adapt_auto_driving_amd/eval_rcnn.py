@@ -33,6 +33,7 @@ from ._lib import has_entry
 
 # PRCNN_NO_RCNN_SPLIT=1: the RCNN stage's RoI pooling / sampling / grouping geometry stays on the feature stream (A/B switch)
 SPLIT_RCNN = os.environ.get("PRCNN_NO_RCNN_SPLIT") != "1"
+GEO_THREAD = os.environ.get("PRCNN_GEO_THREAD", "0") == "1"               # geometry chains enqueued by a helper thread (tried: GIL contention costs more than it frees)
 RCNN_GEO_STREAM = os.environ.get("PRCNN_RCNN_GEO_STREAM", "0") == "1"     # the RCNN's geometry on a stream of its own (needs a 5th hardware queue)
 
 
@@ -329,22 +330,53 @@ class PipelinedRunner:
         for _, ev_read, _ in mine:
             side.wait_event(ev_read)
         del mine
-        evs = []
+        entries = [{"pts": pts, "geo": None, "ev": None, "side": side, "future": None} for pts in batch_list]
 
-        def mark(_):                                  # one event per batch: its RPN stage need not wait for the rest of the group
-            e = torch.cuda.Event()
-            e.record(side)
-            evs.append(e)
-        with torch.cuda.stream(side):
-            # urgent (cold start: the first batch of this group is waited for right now): SA levels batch by batch, so that batch 0
-            # is ready before the other three are computed; otherwise over the group's clouds at once (a quarter of the launches)
-            geos = self.engine.geometry_group(batch_list, on_batch_done=mark, group_sa=False if urgent else None)
-            if len(evs) != len(geos):
-                ev = torch.cuda.Event()
-                ev.record(side)
-                evs = [ev] * len(geos)
-        for pts, geo, ev in zip(batch_list, geos, evs):
-            self._chains.append({"pts": pts, "geo": geo, "ev": ev, "side": side})
+        def enqueue():
+            evs = []
+
+            def mark(_):                              # one event per batch: its RPN stage need not wait for the rest of the group
+                e = torch.cuda.Event()
+                e.record(side)
+                evs.append(e)
+            with torch.cuda.device(self.device), torch.cuda.stream(side):
+                # urgent (cold start: the first batch of this group is waited for right now): SA levels batch by batch, so that batch 0
+                # is ready before the other three are computed; otherwise over the group's clouds at once (a quarter of the launches)
+                geos = self.engine.geometry_group(batch_list, on_batch_done=mark, group_sa=False if urgent else None)
+                if len(evs) != len(geos):
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    evs = [ev] * len(geos)
+            for c, geo, ev in zip(entries, geos, evs):
+                c["geo"], c["ev"] = geo, ev
+
+        # The chain of a group is ~120 launches = 1.7 ms of Python + launch time every 4 steps, none of it on the critical path (the
+        # group is launched 8-12 batches ahead).  PRCNN_GEO_THREAD=1 hands it to a helper thread (ctypes and the HIP runtime release
+        # the GIL inside every launch; the main thread joins the helper only when it needs a batch of that group, `_chain_ready`).
+        # Measured (round 3): WORSE -- 5264 vs 5466 scenes/s at K = 100, the main thread's enqueue time rises from 1.15-1.37 to
+        # 1.46 ms per step: the helper's Python holds the GIL half of the time.  Off by default; the hook stays for A/B.
+        if urgent or not GEO_THREAD:
+            enqueue()
+        else:
+            fut = self._geo_pool().submit(enqueue)
+            for c in entries:
+                c["future"] = fut
+        self._chains.extend(entries)
+
+    def _geo_pool(self):
+        if getattr(self, "_pool", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prcnn-geometry")
+        return self._pool
+
+    @staticmethod
+    def _chain_ready(ch):
+        """the chain entry with its geometry enqueued (joins the helper thread if it is still at it)"""
+        fut = ch.get("future")
+        if fut is not None:
+            fut.result()
+            ch["future"] = None
+        return ch
 
     def _submit_grouped(self, cur, todo, main):
         ch = self._chain(cur)
@@ -352,6 +384,7 @@ class PipelinedRunner:
             self._launch_group([cur] + [p for p in todo if self._chain(p) is None][:self.group - 1], urgent=True)
             ch = self._chain(cur)
         self._chains = [c for c in self._chains if c is not ch]
+        self._chain_ready(ch)
         # start the next group as soon as a whole group of upcoming batches has no chain yet (with a look-ahead of
         # 2 * group that is `group` steps before its first batch is due), or when the look-ahead is about to run dry
         missing = [p for p in todo if self._chain(p) is None]
@@ -448,6 +481,8 @@ class PipelinedRunner:
         if getattr(self, "tail", None) is None:
             return None
         det = self._finish_inflight()
+        for c in getattr(self, "_chains", []):        # a helper thread may still be enqueuing a chain nobody consumed
+            self._chain_ready(c)
         for side, ev_read, _ in self._retired:        # the kept geometry goes back to its streams' pools, ordered after its readers
             side.wait_event(ev_read)
         self._retired = []
