@@ -499,6 +499,103 @@ int nms_device(int nprob, int n_max, const int *counts, const float *boxes, floa
     return check_launch("nms");
 }
 
+// ---- full-mask form for the blocking API (one problem, every kept box wanted: iou3d_cuda.nms_gpu / nms_normal_gpu) --------------
+// The lazy kernels above are one workgroup per problem and stop at max_keep: right for 8 scenes x 100 proposals, wrong for the
+// reference's own call shape (one scene, up to 9000 boxes, the whole keep list: 8-12 ms).  Here every (row block, column block
+// >= row block) pair is its own workgroup -- lane = column, and one __ballot per row IS the 64-bit mask word of that row for the
+// column block (wave64: the word the reference builds bit by bit, iou3d_kernel.cu:277-290) -- and one workgroup then walks the
+// blocks in order: the 64 rows of a block are resolved on a wave from the diagonal words (iou3d.cpp:100-119's loop), the rows
+// it kept OR their words into the removed bitmap, all threads in parallel.  Same (row, column) argument order: same keep list.
+constexpr int NF_WAVES = 4;
+
+template <bool ROTATED>
+__global__ __launch_bounds__(64 * NF_WAVES) void nms_full_mask_kernel(
+    int n, int W, const float *__restrict__ boxes, float thresh, unsigned long long *__restrict__ mask)
+{
+    __shared__ float s_row[64 * 7];
+    // blockIdx.x enumerates the pairs (rb <= cb) of the upper triangle, row block major
+    int rb = 0, rest = blockIdx.x;
+    while (rest >= W - rb) { rest -= W - rb; ++rb; }
+    const int cb = rb + rest;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int r0 = rb * 64, rows = min(64, n - r0);
+    if (t < rows) {
+        const float *p = boxes + (long)(r0 + t) * 5;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) s_row[t * 7 + q] = p[q];
+        if (ROTATED) {
+            s_row[t * 7 + 5] = cos_f32(p[4]);
+            s_row[t * 7 + 6] = sin_f32(p[4]);
+        }
+    }
+    __syncthreads();
+    const int c = cb * 64 + lane;
+    const bool live = c < n;
+    const RBox C = load_col<ROTATED>(boxes + (long)(live ? c : 0) * 5);
+    for (int r = wv; r < rows; r += NF_WAVES) {
+        const bool hit = live && c > r0 + r && suppresses<ROTATED>(s_row, r, C, thresh);
+        const unsigned long long w = __ballot(hit);
+        if (lane == 0) mask[(long)(r0 + r) * W + cb] = w;
+    }
+}
+
+constexpr int NF_RES_THREADS = 1024;
+__global__ __launch_bounds__(NF_RES_THREADS) void nms_full_resolve_kernel(
+    int n, int W, const unsigned long long *__restrict__ mask, int *__restrict__ keep, int *__restrict__ num_keep)
+{
+    __shared__ unsigned long long s_removed[NMS_MAX_N / 64];
+    __shared__ unsigned long long s_kept;
+    const int t = threadIdx.x;
+    for (int i = t; i < W; i += NF_RES_THREADS) s_removed[i] = 0ull;
+    __syncthreads();
+    int nk = 0;                                        // tracked by every thread (uniform)
+    for (int b = 0; b < W; ++b) {
+        const int r0 = b * 64, rows = min(64, n - r0);
+        if (t < 64) {
+            const unsigned long long diag = t < rows ? mask[(long)(r0 + t) * W + b] : 0ull;
+            unsigned long long rem = s_removed[b], kept = 0ull;      // uniform across the wave
+            for (int cl = 0; cl < rows; ++cl) {
+                const unsigned long long d = __shfl(diag, cl);
+                if (!((rem >> cl) & 1ull)) { kept |= 1ull << cl; rem |= d; }
+            }
+            if ((kept >> t) & 1ull) keep[nk + __popcll(kept & ((1ull << t) - 1ull))] = r0 + t;
+            if (t == 0) s_kept = kept;
+        }
+        __syncthreads();
+        const unsigned long long kept = s_kept;
+        nk += __popcll(kept);
+        // the kept rows OR their words into the bitmap: 16 row groups x 64 word lanes, independent loads, one LDS atomic per word
+        {
+            const int g = t >> 6, wl = t & 63;
+            for (int w = b + 1 + wl; w < W; w += 64) {
+                unsigned long long acc = 0ull;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = g + 16 * q;
+                    if ((kept >> cl) & 1ull) acc |= mask[(long)(r0 + cl) * W + w];
+                }
+                if (acc) atomicOr(&s_removed[w], acc);
+            }
+        }
+        __syncthreads();
+    }
+    if (t == 0) *num_keep = nk;
+}
+
+static int nms_full(int n, const float *boxes, float thresh, int rotated, int *keep, int *num_keep, hipStream_t st)
+{
+    const int W = ceil_div(n, 64);
+    unsigned long long *mask = (unsigned long long *)scratch_for(st, (size_t)n * W * sizeof(unsigned long long), 10);
+    if (!mask) { set_error("nms: cannot allocate %zu bytes of mask scratch", (size_t)n * W * 8); return PRCNN_ELAUNCH; }
+    const long pairs = (long)W * (W + 1) / 2;
+    if (rotated)
+        hipLaunchKernelGGL(nms_full_mask_kernel<true>, dim3((unsigned)pairs), dim3(64 * NF_WAVES), 0, st, n, W, boxes, thresh, mask);
+    else
+        hipLaunchKernelGGL(nms_full_mask_kernel<false>, dim3((unsigned)pairs), dim3(64 * NF_WAVES), 0, st, n, W, boxes, thresh, mask);
+    hipLaunchKernelGGL(nms_full_resolve_kernel, dim3(1), dim3(NF_RES_THREADS), 0, st, n, W, mask, keep, num_keep);
+    return check_launch("nms(full mask)");
+}
+
 static int nms_blocking(int n, const float *boxes, long long *keep_host, float thresh, int rotated, hipStream_t st)
 {
     PRCNN_REQUIRE(n >= 0, "nms: negative box count");
@@ -506,7 +603,10 @@ static int nms_blocking(int n, const float *boxes, long long *keep_host, float t
     PRCNN_REQUIRE(boxes && keep_host, "nms: null pointer");
     int *g_scratch = (int *)scratch_for(st, ((size_t)n + 1) * sizeof(int), 7);
     if (!g_scratch) { set_error("nms: cannot allocate %zu bytes of scratch", ((size_t)n + 1) * sizeof(int)); return PRCNN_ELAUNCH; }
-    int rc = nms_device(1, n, nullptr, boxes, thresh, rotated, n, g_scratch + 1, g_scratch, st);
+    static const bool full_form = !(getenv("PRCNN_NMS_FULL") && atoi(getenv("PRCNN_NMS_FULL")) == 0);   // A/B switch, same results
+    PRCNN_REQUIRE(n <= NMS_MAX_N, "nms: %d boxes > %d unsupported", n, NMS_MAX_N);
+    int rc = full_form && n > ND_MAX ? nms_full(n, boxes, thresh, rotated, g_scratch + 1, g_scratch, st)
+                                     : nms_device(1, n, nullptr, boxes, thresh, rotated, n, g_scratch + 1, g_scratch, st);
     if (rc != PRCNN_OK) return rc;
     int *host = (int *)malloc(sizeof(int) * ((size_t)n + 1));
     if (!host) { set_error("nms: host allocation failed"); return PRCNN_ELAUNCH; }

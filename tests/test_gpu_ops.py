@@ -353,7 +353,7 @@ def test_nms_normal(ext, oracle, n, thresh):
     assert k == len(want) and np.array_equal(keep[:k].numpy(), want)
 
 
-@pytest.mark.parametrize("n,thresh", [(100, 0.1), (300, 0.3), (64, 0.01), (700, 0.5)])
+@pytest.mark.parametrize("n,thresh", [(100, 0.1), (300, 0.3), (64, 0.01), (700, 0.5), (129, 0.2), (2000, 0.3), (4097, 0.05)])
 def test_nms_rotated(ext, oracle, n, thresh):
     boxes = bev_boxes(np.random.default_rng(n + 1), n, spread=12.0)
     keep = torch.zeros(n, dtype=torch.int64)
