@@ -1,4 +1,5 @@
 // capi.hip -- error reporting and version of libprcnn_hip.so (see include/prcnn_hip.h).
+#include <cstring>
 #include "common.hpp"
 #include <stdarg.h>
 #include <stdio.h>
@@ -8,14 +9,20 @@
 
 namespace prcnn {
 
-static thread_local char g_err[512] = "";
+static thread_local char g_err[768] = "";
+static thread_local char g_note[256] = "";     // why scratch_for() just refused (its callers report "cannot allocate" in their own words)
 
 void set_error(const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    const int n = vsnprintf(g_err, sizeof(g_err) - sizeof(g_note) - 4, fmt, ap);
     va_end(ap);
+    if (g_note[0] && n >= 0) {
+        const size_t at = strlen(g_err);
+        snprintf(g_err + at, sizeof(g_err) - at, " [%s]", g_note);
+        g_note[0] = 0;
+    }
 }
 
 int check_launch(const char *what)
@@ -67,6 +74,7 @@ struct Scratch {
     int slot;
     char *ptr;
     size_t bytes;
+    bool captured;                       // a hipGraph captured on this stream holds `ptr`: the buffer may never move again
 };
 constexpr int SCRATCH_ENTRIES = 256;     // (stream, slot) pairs; a pipelined host uses ~5 slots on 2-8 streams
 static Scratch g_scratch[SCRATCH_ENTRIES];
@@ -95,15 +103,27 @@ char *scratch_for(hipStream_t st, size_t bytes, int slot)
                 (void)hipSetDevice(dev);
                 s->ptr = nullptr; s->bytes = 0;
             }
-            s->device = dev; s->stream = st; s->slot = slot;
+            s->device = dev; s->stream = st; s->slot = slot; s->captured = false;
         } else {
             s = &g_scratch[g_scratch_n++];
-            s->device = dev; s->stream = st; s->slot = slot; s->ptr = nullptr; s->bytes = 0;
+            s->device = dev; s->stream = st; s->slot = slot; s->ptr = nullptr; s->bytes = 0; s->captured = false;
         }
     }
+    // hipGraph capture (eval_rcnn.GraphedRunner): the captured launches keep this pointer for the life of the graph.  The stream must
+    // have been warmed up with the same shapes BEFORE the capture (no hipMalloc inside a capture).  A later, larger request on the
+    // same stream gets a NEW buffer and the old one is left to the graphs that point to it (never freed: a few MB per growth, and a
+    // process captures for a handful of shapes) -- launches on one stream are ordered, so the two never serve the same call.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if (s->bytes < bytes && capturing) {
+        snprintf(g_note, sizeof(g_note), "scratch: %zu bytes wanted, %zu held (slot %d): the stream is being captured -- run the same "
+                 "calls once on it before the capture", bytes, s->bytes, slot);
+        return nullptr;
+    }
+    if (capturing) s->captured = true;
     if (s->bytes < bytes) {
-        if (s->ptr) { (void)hipStreamSynchronize(st); (void)hipFree(s->ptr); }
-        s->ptr = nullptr; s->bytes = 0;
+        if (s->ptr && !s->captured) { (void)hipStreamSynchronize(st); (void)hipFree(s->ptr); }
+        s->ptr = nullptr; s->bytes = 0; s->captured = false;
         if (hipMalloc((void **)&s->ptr, bytes) != hipSuccess) return nullptr;
         s->bytes = bytes;
     }

@@ -139,7 +139,7 @@ def _runner_streams(device, n_sides, prio):
     per runner drew a new mapping every time (same process: 77 ms or 89 ms for the same 20 steps); with one fixed set the
     first-created streams keep the queues they were given at start-up."""
     key = (str(device), prio)
-    have = _RUNNER_STREAMS.setdefault(key, {"tail": None, "sides": [], "geo2": None})
+    have = _RUNNER_STREAMS.setdefault(key, {"tail": None, "sides": [], "geo2": None, "feat": None})
     if have["tail"] is None:
         have["tail"] = torch.cuda.Stream(device, priority=int(os.environ.get("PRCNN_TAIL_PRIORITY", "0")))
     if have["geo2"] is None and RCNN_GEO_STREAM:
@@ -492,6 +492,269 @@ class PipelinedRunner:
         return det
 
 
+USE_GRAPHS = os.environ.get("PRCNN_GRAPHS", "1") != "0"                   # hipGraph replay of the stages (GraphedRunner); 0: eager enqueue (PipelinedRunner)
+
+
+_GRAPH_DEBUG = int(os.environ.get("PRCNN_GRAPH_DEBUG", "0"))   # 1: device sync before a geometry graph, 2: after it (bisecting overlaps)
+
+
+def make_runner(model, cfg, device, depth=None):
+    """The runner of the product path: hipGraph replay unless PRCNN_GRAPHS=0 (same streams, same kernels, same results)."""
+    return (GraphedRunner if USE_GRAPHS else PipelinedRunner)(model, cfg, device, depth)
+
+
+class GraphedRunner:
+    """PipelinedRunner with every stage captured ONCE into a hipGraph and replayed: the same kernels with the same arguments on the
+    same streams in the same order -- the host's part of a step falls from ~70 extension calls + their torch glue (0.8 ms of Python
+    per step, more than half of the step's period: the host thread was co-limiting, profiles/r03_microbench.md) to four graph
+    launches and a dozen event operations.
+
+    A graph replays fixed addresses, so the pipeline runs over SLOTS instead of freshly allocated tensors:
+      * a group slot holds the coordinates of `group` batches (copied in when their chain is launched: 1.5 MB per batch), the
+        geometry graph of the group (FastPointRCNN.geometry_group: FPS / ball queries / row lists / three-NN / the early SA levels,
+        on a side stream) and, per batch of the group, four graphs: RPN stage (feature stream), proposal layer + RCNN geometry
+        (tail stream), RCNN features (feature stream), final stage (tail stream);
+      * depth / group + 2 group slots rotate: a slot is rewritten only after the RCNN stages of its previous batches (an event wait
+        on the side stream, normally long past);
+      * the detections returned by submit() / flush() live in the slot: they stay valid for (slots - 1) * group further submits
+        (16 by default) -- copy them out (on det["stream"]) before that, as eval_scenes and bench.py do right away.
+    Every graph has a memory pool of its own (see _build); everything a later graph or the caller reads is kept referenced here.  Batches of another shape than the first one seen (the last, short batch of a split) run eagerly.
+    Nondeterminism is that of the eager path: the worklists built with atomics (point groups, pooled tiles) come out in
+    a different order every run, the results computed from them do not (tests/test_gpu_graphs.py: detections bit for bit)."""
+
+    def __init__(self, model, cfg, device, depth=None):
+        self.model, self.cfg = model, cfg
+        self.engine = FastPointRCNN(model, cfg)
+        self.device = torch.device(device)
+        self.group = max(1, int(os.environ.get("PRCNN_GEO_GROUP", "4")))
+        self.depth = PipelinedRunner.default_depth() if depth is None else depth
+        prio = int(os.environ.get("PRCNN_SIDE_PRIORITY", "0"))
+        self.tail, self.sides = _runner_streams(self.device, int(os.environ.get("PRCNN_SIDE_STREAMS", "2")), prio)
+        have = _RUNNER_STREAMS[(str(self.device), prio)]
+        # the feature-stream graphs are CAPTURED on a stream of their own (a capture cannot run on the default stream) and REPLAYED on
+        # the caller's stream, as PipelinedRunner runs them: a fifth busy stream would share one of the four hardware queues with
+        # another one and serialise behind it (measured: 4155 instead of 5470 scenes/s at K = 100).  The C library's scratch of the
+        # capture stream is theirs alone -- every one of these graphs replays on the same stream, in order.
+        if have.get("feat") is None:
+            have["feat"] = torch.cuda.Stream(self.device)
+        self.feat = have["feat"]
+        self.n_slots = max(2, -(-self.depth // self.group) + 2)
+        self.shape = None
+        self._assigned = []          # [(batch tensor, group slot, member)] chains launched, batch not yet submitted
+        self._chains = self._assigned
+        self._inflight = None        # ("graph", slot, member) | ("eager", det)
+        self._next_slot = 0
+        self.captures = 0
+
+    # ---- capture -------------------------------------------------------------------------------------------------------------
+    def _capture(self, stream, pool, fn):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(stream):
+            stream.synchronize()
+            # thread_local: other threads of the process (pinned-memory loaders, writers) may call into HIP during a capture
+            g.capture_begin(pool=pool, capture_error_mode="thread_local")
+            try:
+                out = fn()
+            finally:
+                g.capture_end()
+        self.captures += 1
+        return g, out
+
+    @torch.no_grad()
+    def _build(self, first):
+        """slots, warm-up of every role stream (the C library's per-stream scratch must exist before a capture), the captures"""
+        eng, cfg, G = self.engine, self.cfg, self.group
+        B, N, _ = first.shape
+        self.shape = tuple(first.shape)
+        eng.check_weights()
+        torch.cuda.synchronize(self.device)
+        self.xin = [torch.empty((G * B, N, 3), dtype=torch.float32, device=self.device) for _ in range(self.n_slots)]
+        for x in self.xin:
+            for k in range(G):
+                x[k * B:(k + 1) * B].copy_(first)              # valid clouds everywhere: a partly filled group computes on them
+        parts = lambda s: [self.xin[s][k * B:(k + 1) * B] for k in range(G)]
+
+        def tail_stage(st):
+            rois, roi_scores = eng.propose(st)
+            return {"rois": rois, "roi_scores": roi_scores, "rg": eng.rcnn_geometry(st, rois)}
+
+        def final_stage(tl, out):
+            ret = {"rois": tl["rois"], "rcnn_cls": out["rcnn_cls"], "rcnn_reg": out["rcnn_reg"]}
+            det = postprocess(cfg, ret, B)
+            det.update(ret)
+            return det
+
+        # warm-up, eagerly, once per stream that will capture (and to have real data behind every pointer while capturing)
+        for side in self.sides:
+            with torch.cuda.stream(side):
+                geos = eng.geometry_group(parts(0))
+            side.synchronize()
+        with torch.cuda.stream(self.feat):
+            st = eng.rpn_stage(parts(0)[0], geos[0])
+        self.feat.synchronize()
+        with torch.cuda.stream(self.tail):
+            tl = tail_stage(st)
+        self.tail.synchronize()
+        with torch.cuda.stream(self.feat):
+            out = eng.rcnn_features(tl["rg"])
+        self.feat.synchronize()
+        with torch.cuda.stream(self.tail):
+            final_stage(tl, out)
+        self.tail.synchronize()
+        del geos, st, tl, out
+
+        # ONE MEMORY POOL PER GRAPH.  Graphs that share a pool may only be replayed in the order of their capture with the outputs of
+        # the later ones dead: the temporaries of an earlier capture are free memory when the later one allocates its OUTPUTS, so
+        # replaying the earlier graph writes over them (seen: the geometry graph of slot 0 replayed while the RPN stages of slot 4
+        # still needed slot 4's index tables -> memory fault).  The slots rotate, so no such order exists here.
+        mem0 = torch.cuda.memory_reserved(self.device)
+        pool = torch.cuda.graph_pool_handle
+        self.slots = []
+        for s in range(self.n_slots):
+            side = self.sides[s % len(self.sides)]
+            g_geo, geos = self._capture(side, pool(), lambda: eng.geometry_group(parts(s)))
+            slot = {"side": side, "g_geo": g_geo, "geos": geos, "ev_geo": torch.cuda.Event(), "members": []}
+            for k in range(G):
+                xb = parts(s)[k]
+                g_rpn, st = self._capture(self.feat, pool(), lambda: eng.rpn_stage(xb, geos[k]))
+                g_tail, tl = self._capture(self.tail, pool(), lambda: tail_stage(st))
+                g_rcnn, out = self._capture(self.feat, pool(), lambda: eng.rcnn_features(tl["rg"]))
+                g_post, det = self._capture(self.tail, pool(), lambda: final_stage(tl, out))
+                slot["members"].append({"g_rpn": g_rpn, "g_tail": g_tail, "g_rcnn": g_rcnn, "g_post": g_post,
+                                        "st": st, "tl": tl, "out": out, "det": det,
+                                        "ev_rpn": torch.cuda.Event(), "ev_prop": torch.cuda.Event(), "ev_rcnn": torch.cuda.Event(),
+                                        "ready": torch.cuda.Event(), "used": False})
+            self.slots.append(slot)
+        self.graph_bytes = torch.cuda.memory_reserved(self.device) - mem0
+        torch.cuda.synchronize(self.device)
+
+    def _conforms(self, pts):
+        return (pts is not None and pts.is_cuda and pts.dtype == torch.float32 and pts.dim() == 3 and pts.shape[-1] == 3 and
+                (self.shape is None or tuple(pts.shape) == self.shape))
+
+    # ---- replay --------------------------------------------------------------------------------------------------------------
+    def _where(self, pts):
+        for a in self._assigned:
+            if a[0] is pts:
+                return a
+        return None
+
+    def _launch_group(self, batch_list, main):
+        s = self._next_slot % self.n_slots
+        self._next_slot += 1
+        slot = self.slots[s]
+        side = slot["side"]
+        B = self.shape[0]
+        side.wait_stream(main)                              # the batches are ready on the caller's stream
+        for m in slot["members"]:
+            if m["used"]:
+                side.wait_event(m["ev_rcnn"])               # the slot's previous batches have been read to the end
+                m["used"] = False
+        with torch.cuda.stream(side):
+            for k, pts in enumerate(batch_list):
+                self.xin[s][k * B:(k + 1) * B].copy_(pts, non_blocking=True)
+            if _GRAPH_DEBUG & 1:
+                torch.cuda.synchronize(self.device)
+                print("[graph debug] geometry of slot %d: %d batches" % (s, len(batch_list)), flush=True)
+            slot["g_geo"].replay()
+            slot["ev_geo"].record(side)
+            if _GRAPH_DEBUG & 2:
+                torch.cuda.synchronize(self.device)
+                print("[graph debug] geometry of slot %d done" % s, flush=True)
+        for k, pts in enumerate(batch_list):
+            self._assigned.append((pts, s, k))
+
+    @torch.no_grad()
+    def submit(self, cur, upcoming=None):
+        main = torch.cuda.current_stream(self.device)
+        todo = [] if upcoming is None else (list(upcoming) if isinstance(upcoming, (list, tuple)) else [upcoming])
+        todo = [p for p in todo if p is not None][:max(1, self.depth)]
+        if self.shape is None and self._conforms(cur):
+            self._build(cur)
+        if not self._conforms(cur) or self.shape is None:
+            return self._submit_eager(cur, main)
+        todo = [p for p in todo if self._conforms(p)]
+        a = self._where(cur)
+        if a is None:                                       # cold start (or a caller that looks less far ahead)
+            self.engine.check_weights()
+            self._launch_group([cur] + [p for p in todo if self._where(p) is None][:self.group - 1], main)
+            a = self._where(cur)
+        self._assigned[:] = [x for x in self._assigned if x is not a]
+        missing = [p for p in todo if self._where(p) is None]
+        have = len(todo) - len(missing)
+        if missing and (len(missing) >= self.group or have <= 1):
+            self.engine.check_weights()
+            self._launch_group(missing[:self.group], main)
+        _, s, k = a
+        slot = self.slots[s]
+        m = slot["members"][k]
+        feat, tail = main, self.tail
+        feat.wait_event(slot["ev_geo"])
+        with torch.cuda.stream(feat):
+            m["g_rpn"].replay()
+            m["ev_rpn"].record(feat)
+        if _GRAPH_DEBUG & 4:
+            torch.cuda.synchronize(self.device)
+            print("[graph debug] slot %d member %d rpn done" % (s, k), flush=True)
+        tail.wait_event(m["ev_rpn"])
+        with torch.cuda.stream(tail):
+            m["g_tail"].replay()
+            m["ev_prop"].record(tail)
+        if _GRAPH_DEBUG & 4:
+            torch.cuda.synchronize(self.device)
+            print("[graph debug] slot %d member %d tail done" % (s, k), flush=True)
+        done = self._finish_inflight()
+        m["used"] = True
+        self._inflight = ("graph", s, k)
+        return done
+
+    def _submit_eager(self, cur, main):
+        done = self._finish_inflight()
+        det = infer_batch(self.model, self.cfg, cur, engine=self.engine)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        det["ready"], det["stream"] = ready, main
+        self._inflight = ("eager", det)
+        return done
+
+    def _finish_inflight(self):
+        if self._inflight is None:
+            return None
+        kind = self._inflight[0]
+        if kind == "eager":
+            det = self._inflight[1]
+            self._inflight = None
+            return det
+        _, s, k = self._inflight
+        self._inflight = None
+        m = self.slots[s]["members"][k]
+        feat, tail = torch.cuda.current_stream(self.device), self.tail
+        feat.wait_event(m["ev_prop"])
+        with torch.cuda.stream(feat):
+            m["g_rcnn"].replay()
+            m["ev_rcnn"].record(feat)
+        if _GRAPH_DEBUG & 4:
+            torch.cuda.synchronize(self.device)
+            print("[graph debug] slot %d member %d rcnn done" % (s, k), flush=True)
+        tail.wait_event(m["ev_rcnn"])
+        with torch.cuda.stream(tail):
+            m["g_post"].replay()
+            m["ready"].record(tail)
+        if _GRAPH_DEBUG & 4:
+            torch.cuda.synchronize(self.device)
+            print("[graph debug] slot %d member %d done" % (s, k), flush=True)
+        det = dict(m["det"])
+        det["ready"], det["stream"] = m["ready"], tail
+        return det
+
+    @torch.no_grad()
+    def flush(self):
+        """Finish the batch still in flight and return its detections (or None); chains of batches never submitted are dropped."""
+        det = self._finish_inflight()
+        self._assigned[:] = []
+        return det
+
+
 def _tensors(obj):
     if torch.is_tensor(obj):
         yield obj
@@ -707,7 +970,7 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
         os.makedirs(output_dir, exist_ok=True)
     M = cfg.TEST.RPN_POST_NMS_TOP_N
     on_gpu = torch.device(device).type == "cuda"
-    runner = PipelinedRunner(model, cfg, device) if on_gpu else None
+    runner = make_runner(model, cfg, device) if on_gpu else None
     budget = host_budget()
     if stats is not None:
         stats["host_budget"] = {"loaders": budget["loaders"], "writers": budget["writers"], "cores": len(budget["cores"]),

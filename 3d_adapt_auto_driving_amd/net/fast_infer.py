@@ -904,11 +904,13 @@ class FastPointRCNN:
                 while 2 * f * n <= 64 and Bc % (2 * f) == 0:
                     f *= 2
                 key = (Bc, n, f, str(cur_xyz.device))
-                if getattr(self, "_groupall", (None,))[0] != key:
+                # (one entry per shape, never replaced: a captured hipGraph of another batch size may hold these addresses)
+                cache = self.__dict__.setdefault("_groupall", {})
+                if key not in cache:
                     ga_idx = torch.arange(f * n, dtype=torch.int32, device=cur_xyz.device).view(1, f, n).expand(Bc // f, f, n).contiguous()
-                    self._groupall = (key, ga_idx, torch.zeros((Bc // f, f, 3), dtype=torch.float32, device=cur_xyz.device),
-                                      (torch.arange(f, dtype=torch.int32, device=cur_xyz.device) * n).view(1, f, 1))
-                _, ga_idx, origin, shift = self._groupall
+                    cache[key] = (key, ga_idx, torch.zeros((Bc // f, f, 3), dtype=torch.float32, device=cur_xyz.device),
+                                  (torch.arange(f, dtype=torch.int32, device=cur_xyz.device) * n).view(1, f, 1))
+                _, ga_idx, origin, shift = cache[key]
                 xyz_v = cur_xyz.view(Bc // f, f * n, 3)
                 rep_v = None
                 if rep is not None and n <= 64:          # the f clouds' maps side by side, shifted to the merged cloud's numbering

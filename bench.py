@@ -412,9 +412,18 @@ def main():
     F = importlib.import_module(PKG + ".net.fast_infer")
     lagged = os.environ.get("PRCNN_TAIL_OVERLAP", "1") != "0"
 
-    def timed_run(steps, warmup, batches=batches):
+    shared_runner = {}
+
+    def timed_run(steps, warmup, batches=batches, fresh=False):
         """W untimed + K timed steps of the pipelined runner; returns the elapsed time of the K steps and their detections"""
-        runner = E.PipelinedRunner(model, cfg, dev)     # point-major engine + geometry chains on side streams
+        # point-major engine + geometry chains on side streams; E.make_runner: the stages replayed as hipGraphs (captured once, at the
+        # runner's first batch = during the set-up run below: graphs are part of the engine like the folded weights) unless PRCNN_GRAPHS=0.
+        # `fresh`: an eager runner of its own (the caller changed engine switches; a captured graph would not see them)
+        if fresh:
+            runner = E.PipelinedRunner(model, cfg, dev)
+        else:
+            runner = shared_runner.setdefault("runner", None) or E.make_runner(model, cfg, dev)
+            shared_runner["runner"] = runner
         assert runner.depth + 2 <= len(batches), "batch slots must outnumber the look-ahead"
         n_slots = len(batches)
         total = warmup + steps
@@ -530,7 +539,7 @@ def main():
         saved = (F.USE_PACKED, F.USE_POOL_DEDUP)
         F.USE_PACKED, F.USE_POOL_DEDUP = False, False
         try:
-            t1, _ = timed_run(k, 3, batch_set)
+            t1, _ = timed_run(k, 3, batch_set, fresh=True)
             return round(k * BATCH / (time.perf_counter() - t1), 1)
         finally:
             F.USE_PACKED, F.USE_POOL_DEDUP = saved
@@ -583,7 +592,9 @@ def main():
                    # every PRCNN_* switch this process saw (22 of them select kernels at import time): a line
                    # measured with a non-default engine says so
                    "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith("PRCNN_")},
-                   "batch_slots": n_slots, "look_ahead": E.PipelinedRunner.default_depth()},
+                   "batch_slots": n_slots, "look_ahead": E.PipelinedRunner.default_depth(),
+                   "hip_graphs": ({"captured": shared_runner["runner"].captures, "group_slots": shared_runner["runner"].n_slots}
+                                  if getattr(shared_runner.get("runner"), "captures", 0) else None)},
     }
     if rank == 0:
         if not args.no_roofline:

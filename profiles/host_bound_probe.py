@@ -6,7 +6,8 @@ C = importlib.import_module(PKG + ".config"); E = importlib.import_module(PKG + 
 dev = torch.device("cuda", 0); cfg = C.default_eval_cfg(); model = E.build_model(cfg, dev, seed=0)
 NB = E.PipelinedRunner.default_depth() + 2        # more slots than the look-ahead: no aliasing of upcoming batches
 batches = [torch.from_numpy(synth.scenes(8, 16384, seed0=s * 8)).to(dev) for s in range(NB)]
-runner = E.PipelinedRunner(model, cfg, dev)
+runner = E.make_runner(model, cfg, dev)          # hipGraph replay unless PRCNN_GRAPHS=0
+print('runner:', type(runner).__name__)
 import collections
 def loop(n):
     pend = collections.deque()

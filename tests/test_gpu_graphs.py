@@ -1,0 +1,94 @@
+"""hipGraph replay of the stages (eval_rcnn.GraphedRunner) against the eager enqueue (eval_rcnn.PipelinedRunner): the same kernels with the
+same arguments, so every detection tensor must come out bit for bit -- over full groups, a partly filled group, a batch of another
+shape (eager fallback inside the graphed runner) and a second pass over the same slots."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+PKG = "3d_adapt_auto_driving_amd"
+KEYS = ("boxes", "scores", "num", "pred_boxes3d", "rois", "rcnn_cls", "rcnn_reg")
+
+
+def _run(runner, batches, depth):
+    outs = []
+
+    def take(det):
+        if det is not None:
+            with torch.cuda.stream(det["stream"]):
+                outs.append({k: det[k].clone() for k in KEYS})
+    for i, b in enumerate(batches):
+        take(runner.submit(b, batches[i + 1:i + 1 + depth]))
+    take(runner.flush())
+    torch.cuda.synchronize()
+    return outs
+
+
+@pytest.mark.parametrize("scene", ["uniform", "lidar"])
+def test_graph_replay_equals_eager_enqueue(scene):
+    C = importlib.import_module(PKG + ".config"); E = importlib.import_module(PKG + ".eval_rcnn"); S = importlib.import_module(PKG + ".synth")
+    dev = torch.device("cuda", 0)
+    cfg = C.default_eval_cfg()
+    model = E.build_model(cfg, dev, seed=0)
+    make = S.lidar_scenes if scene == "lidar" else S.scenes
+    full = [torch.from_numpy(make(4, 16384, seed0=100 + 4 * s)).to(dev) for s in range(11)]   # 2 full groups + a group of 3
+    short = torch.from_numpy(make(2, 16384, seed0=900)).to(dev)                               # another shape: runs eagerly
+    batches = full[:6] + [short] + full[6:]
+    eager = E.PipelinedRunner(model, cfg, dev)
+    graphed = E.GraphedRunner(model, cfg, dev)
+    want = _run(eager, batches, eager.depth)
+    got = _run(graphed, batches, graphed.depth)
+    assert graphed.captures == graphed.n_slots * (1 + 4 * graphed.group)
+    assert len(got) == len(want) == len(batches)
+    for i, (g, w) in enumerate(zip(got, want)):
+        for k in KEYS:
+            assert torch.equal(g[k], w[k]), "batch %d: %s differs between graph replay and eager enqueue" % (i, k)
+    assert sum(int(w["num"].sum()) for w in want) > 0
+    # the same runner again (every slot has been used once: replays over recycled slots), with a shorter look-ahead
+    again = _run(graphed, batches, 5)
+    for i, (g, w) in enumerate(zip(again, want)):
+        for k in KEYS:
+            assert torch.equal(g[k], w[k]), "second pass, batch %d: %s" % (i, k)
+    assert graphed.captures == graphed.n_slots * (1 + 4 * graphed.group)          # nothing was captured again
+
+
+def test_scratch_of_a_captured_graph_stays_where_it_is():
+    """the C library's per-stream scratch: a larger request on a stream whose graphs point to the old buffer gets a new buffer (the graph
+    still replays correctly afterwards), and a request that would have to allocate DURING a capture fails loudly"""
+    I = importlib.import_module(PKG + ".iou3d_utils")
+    L = importlib.import_module(PKG + "._lib")
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.Stream(dev)
+    rng = np.random.default_rng(0)
+
+    def boxes(n):
+        c = rng.uniform(-20, 20, (n, 2)); d = rng.uniform(1, 4, (n, 2))
+        return torch.from_numpy(np.concatenate([c - d / 2, c + d / 2, rng.uniform(-3, 3, (n, 1))], 1).astype(np.float32)).to(dev)
+    a = boxes(64).view(1, 64, 5)
+    cnt = torch.full((1,), 64, dtype=torch.int32, device=dev)
+    with torch.cuda.stream(s):
+        want_keep, want_num = I.nms_device_batched(a, cnt, 0.3, True, 64)         # warm-up: the mask scratch of this stream exists
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(capture_error_mode="thread_local")
+        keep, num = I.nms_device_batched(a, cnt, 0.3, True, 64)
+        g.capture_end()
+        g.replay(); s.synchronize()
+        assert int(num[0]) > 0 and torch.equal(keep, want_keep)
+        big = boxes(128 * 40).view(40, 128, 5)
+        bk, bn = I.nms_device_batched(big, torch.full((40,), 128, dtype=torch.int32, device=dev), 0.3, True, 128)   # 40x the scratch
+        s.synchronize()
+        assert int(bn.min()) > 0
+        keep.fill_(-5); num.fill_(-5)
+        g.replay(); s.synchronize()                                                # the graph still has its (old) buffer
+        assert torch.equal(keep, want_keep) and torch.equal(num, want_num)
+        huge = boxes(128 * 400).view(400, 128, 5)
+        g2 = torch.cuda.CUDAGraph()
+        g2.capture_begin(capture_error_mode="thread_local")
+        try:
+            with pytest.raises(L.PrcnnError, match="being captured"):
+                I.nms_device_batched(huge, torch.full((400,), 128, dtype=torch.int32, device=dev), 0.3, True, 128)
+        finally:
+            g2.capture_end()
