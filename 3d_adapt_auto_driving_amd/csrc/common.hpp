@@ -29,6 +29,19 @@ int ensure_dynamic_lds(const void *kernel, size_t bytes, const char *what);
 // independent users (0: ball-query grid, 1: FPS ordering).
 char *scratch_for(hipStream_t st, size_t bytes, int slot = 0);
 
+// Tile tickets of the persistent kernels: a PAIR of words per launch, [0] the draw counter, [1] the workgroups that have drawn
+// their last ticket.  Thread 0 of every workgroup calls this once, after its last draw (on every exit path): the last one to arrive
+// zeroes the pair, so the words are clean for their next user -- no fill in front of a launch, none inside a captured hipGraph
+// (a memset node per ticketed launch cost the graph replay ~4 % of a step).  Launches that share a pair are ordered by their stream.
+__device__ __forceinline__ void ticket_release(unsigned int *ticket)
+{
+    __threadfence();
+    if (atomicAdd(ticket + 1, 1u) == gridDim.x * gridDim.y * gridDim.z - 1u) {
+        atomicExch(ticket, 0u);
+        atomicExch(ticket + 1, 0u);
+    }
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is fence + s_barrier, and the fence drains vmcnt as
 // well: every wave then waits at the barrier for its outstanding GLOBAL loads and stores (an HBM round trip), which
 // serialises "store this tile / prefetch the next tile" against the LDS hand-off between pipeline phases.  Use this

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void rows_layer_kernel(
     if (tid == 0) slot[0] = atomicAdd(ticket, 1u);
     lds_barrier();
     long t = slot[0];
-    if (t >= tiles) return;
+    if (t >= tiles) { if (tid == 0) ticket_release(ticket); return; }
     long tt = TILE_OF(t);
     if (PF) { ROWS_FETCH(tt) }
     for (int served = 0; served < per_wg && t < tiles; ++served) {
@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void rows_layer_kernel(
     }
 #undef ROWS_FETCH
 #undef TILE_OF
+    if (tid == 0) ticket_release(ticket);          // the launch's last workgroup zeroes the counter for the word's next user
 }
 
 unsigned int *next_ticket(hipStream_t st);    // sa_mlp_fused.hip
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void rcnn_entrance_kernel(
         lds_barrier();                                         // T1 is free for the next builder
         t = tn;
     }
+    if (tid == 0) ticket_release(ticket);          // the launch's last workgroup zeroes the counter for the word's next user
 }
 
 // cnt[c] distinct rows of cloud c (rows_per_cloud rows each, a multiple of 64) -> the list of 64-row tiles that hold

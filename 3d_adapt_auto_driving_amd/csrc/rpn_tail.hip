@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256, 1) void rpn_tail_kernel(const RpnTailArgs a)
             }
         }
     }
+    if (tid == 0) ticket_release(a.ticket);          // the launch's last workgroup zeroes the counter for the word's next user
 }
 
 
@@ -353,6 +354,7 @@ __global__ __launch_bounds__(256, 1) void rpn_tail_lin_kernel(const RpnTailArgs 
             }
         }
     }
+    if (tid == 0) ticket_release(a.ticket);          // the launch's last workgroup zeroes the counter for the word's next user
 }
 
 }  // namespace prcnn

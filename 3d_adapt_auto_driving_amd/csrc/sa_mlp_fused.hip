@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256, (C3 == 128 ? 2 : 1)) void sa_mlp_fused_kernel(
         // after it; it is rewritten two tiles later, after two more barriers.
         t = t_next;
     }
+    if (tid == 0) ticket_release(ticket);          // the launch's last workgroup zeroes the counter for the word's next user
 }
 
 // ---- C3 = 256 with EIGHT waves per workgroup (one workgroup per CU, two waves per SIMD).
@@ -303,36 +304,31 @@ __global__ __launch_bounds__(512, 1) void sa_mlp_fused256_kernel(
         }
         t = t_next;
     }
+    if (tid == 0) ticket_release(ticket);          // the launch's last workgroup zeroes the counter for the word's next user
 }
 
 }  // namespace prcnn
 
 namespace prcnn {
-// Tile-ticket words: a ring of 256 words per (device, stream) (slot 6 of the scratch cache).  One launch uses one word; the
-// WHOLE ring is zeroed by one memset queued on the same stream whenever the ring wraps (every 256 launches), i.e. strictly
-// after every launch that used the previous generation of words (stream order) -- launches of other streams never touch it.
-// (Round 1 zeroed one word per launch: a 5 us fill kernel in front of each of the ~8 ticketed launches of a step.)
-constexpr unsigned TICKET_RING = 256;
+// Tile-ticket words: a ring of 128 PAIRS of words per (device, stream) (slot 6 of the scratch cache), zeroed once when the stream's
+// ring is created.  One launch uses one pair and leaves it at zero (common.hpp ticket_release: the launch's last workgroup resets it),
+// so nothing is filled in front of a launch -- eagerly or inside a captured hipGraph, whose replays find the pair clean as well.
+// (Round 1 zeroed one word per launch: a 5 us fill kernel in front of each ticketed launch; round 2 one memset per 256 launches
+// and, under capture, a memset node per launch.)  Launches of other streams never touch the ring.
+constexpr unsigned TICKET_RING = 128;
 static std::mutex g_ticket_mu;
 static std::map<std::pair<int, hipStream_t>, unsigned int> g_ticket_next;
 unsigned int *next_ticket(hipStream_t st)
 {
     unsigned int *ring = reinterpret_cast<unsigned int *>(scratch_for(st, 2 * TICKET_RING * sizeof(unsigned int), 6));
-    if (!ring) return nullptr;
+    if (!ring) return nullptr;                 // (a first use under capture ends here: the stream needs its warm-up)
     unsigned int k;
     {
         std::lock_guard<std::mutex> lock(g_ticket_mu);
         k = g_ticket_next[std::make_pair(current_device(), st)]++;
     }
-    // under hipGraph capture every launch keeps its OWN memset node (second half of the ring): a replay must find the word
-    // at zero again, which the amortised form cannot promise
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
-        unsigned int *word = ring + TICKET_RING + (k % TICKET_RING);
-        return hipMemsetAsync(word, 0, sizeof(unsigned int), st) == hipSuccess ? word : nullptr;
-    }
-    if ((k % TICKET_RING) == 0 && hipMemsetAsync(ring, 0, TICKET_RING * sizeof(unsigned int), st) != hipSuccess) return nullptr;
-    return ring + (k % TICKET_RING);
+    if (k == 0 && hipMemsetAsync(ring, 0, 2 * TICKET_RING * sizeof(unsigned int), st) != hipSuccess) return nullptr;
+    return ring + 2 * (k % TICKET_RING);
 }
 }  // namespace prcnn
 

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
     if (tid == 0) slot[0] = atomicAdd(ticket, 1u);
     __syncthreads();
     long t = slot[0];
-    if (t >= tiles) return;
+    if (t >= tiles) { if (tid == 0) ticket_release(ticket); return; }
 
     float wf2[64], wf3[64];
 #pragma unroll
@@ -327,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
         // already write the next one.
         t = t_next;
     }
+    if (tid == 0) ticket_release(ticket);          // the launch's last workgroup zeroes the counter for the word's next user
 }
 
 // ------------------------------------------------------------------------------------------------ C3 = 256
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
     if (tid == 0) slot[0] = atomicAdd(ticket, 1u);
     __syncthreads();
     long t = slot[0];
-    if (t >= tiles) return;
+    if (t >= tiles) { if (tid == 0) ticket_release(ticket); return; }
 
     float wf2[64], wf3[64];
 #pragma unroll
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
         }
         t = t_next;
     }
+    if (tid == 0) ticket_release(ticket);          // the launch's last workgroup zeroes the counter for the word's next user
 }
 
 unsigned int *next_ticket(hipStream_t st);    // sa_mlp_fused.hip

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void sa_wide_fused_kernel(const SaWideArgs 
     if (tid == 0) slot[0] = atomicAdd(a.ticket, 1u);
     __syncthreads();
     long u = __builtin_amdgcn_readfirstlane((int)slot[0]);
-    if (u >= units) return;
+    if (u >= units) { if (tid == 0) ticket_release(a.ticket); return; }
     float wa[64], wb[64];
     f32x16 acc;
     // stage 0 of every unit: layer 2, column block 0, K panel 0
@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void sa_wide_fused_kernel(const SaWideArgs 
         lds_barrier();                                                     // A1 / Y1 / ctr are free for the next unit
         u = un;
     }
+    if (tid == 0) ticket_release(a.ticket);          // the launch's last workgroup zeroes the counter for the word's next user
 }
 
 }  // namespace prcnn

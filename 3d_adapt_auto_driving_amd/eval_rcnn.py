@@ -500,7 +500,12 @@ _GRAPH_DEBUG = int(os.environ.get("PRCNN_GRAPH_DEBUG", "0"))   # 1: device sync 
 
 def make_runner(model, cfg, device, depth=None):
     """The runner of the product path: hipGraph replay unless PRCNN_GRAPHS=0 (same streams, same kernels, same results)."""
-    return (GraphedRunner if USE_GRAPHS else PipelinedRunner)(model, cfg, device, depth)
+    from . import GRAPH_REPLAY_SAFE
+    if USE_GRAPHS and not GRAPH_REPLAY_SAFE:
+        import warnings
+        warnings.warn("hipGraph replay disabled: the HIP runtime was initialised before DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 could be set "
+                      "(import the package, or export the variable, before the first torch.cuda call); using the eager runner")
+    return (GraphedRunner if USE_GRAPHS and GRAPH_REPLAY_SAFE else PipelinedRunner)(model, cfg, device, depth)
 
 
 class GraphedRunner:
@@ -523,6 +528,10 @@ class GraphedRunner:
     a different order every run, the results computed from them do not (tests/test_gpu_graphs.py: detections bit for bit)."""
 
     def __init__(self, model, cfg, device, depth=None):
+        from . import GRAPH_REPLAY_SAFE
+        if not GRAPH_REPLAY_SAFE:
+            raise RuntimeError("GraphedRunner: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was not in place when the HIP runtime started "
+                               "(see the package's __init__): replaying graphs is unsafe on this runtime; use make_runner()")
         self.model, self.cfg = model, cfg
         self.engine = FastPointRCNN(model, cfg)
         self.device = torch.device(device)

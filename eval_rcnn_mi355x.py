@@ -6,6 +6,7 @@ inference:  --cfg_file --eval_mode --ckpt --batch_size --output_dir --set K V ..
 import importlib
 import os
 import sys
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the HIP runtime starts: see 3d_adapt_auto_driving_amd/__init__.py (graph replay)
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 if __name__ == "__main__":      # (loader / writer processes re-import this file: they must not run main again)

@@ -1,6 +1,7 @@
 import importlib
 import os
 import sys
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the HIP runtime starts: see 3d_adapt_auto_driving_amd/__init__.py (graph replay)
 
 import pytest
 
