@@ -498,8 +498,43 @@ USE_GRAPHS = os.environ.get("PRCNN_GRAPHS", "1") != "0"                   # hipG
 _GRAPH_DEBUG = int(os.environ.get("PRCNN_GRAPH_DEBUG", "0"))   # 1: device sync before a geometry graph, 2: after it (bisecting overlaps)
 
 
+def engine_covers(cfg):
+    """Does the point-major engine (net/fast_infer.py) cover this configuration?  It is written for coordinates-only clouds -- every
+    yaml file the reference ships; cfg.RPN.USE_INTENSITY (a 4-channel pts_input, rpn.py:17 / kitti_rcnn_dataset.py:321-338) runs on the
+    nn.Module graph in the reference's operation order over the same HIP operators (ModuleRunner)."""
+    return not bool(cfg.RPN.USE_INTENSITY)
+
+
+class ModuleRunner:
+    """submit() / flush() of the pipelined runners over the nn.Module graph (the reference's operation order, HIP operators through the
+    drop-in modules, no side streams): for configurations the point-major engine does not cover.  Same one-batch-late protocol."""
+    depth = 1
+
+    def __init__(self, model, cfg, device, depth=None):
+        self.model, self.cfg, self.device = model, cfg, torch.device(device)
+        self._pending = None
+
+    @torch.no_grad()
+    def submit(self, cur, upcoming=None):
+        done = self._pending
+        det = infer_batch(self.model, self.cfg, cur)
+        if self.device.type == "cuda":
+            stream = torch.cuda.current_stream(self.device)
+            det["ready"] = torch.cuda.Event()
+            det["ready"].record(stream)
+            det["stream"] = stream
+        self._pending = det
+        return done
+
+    def flush(self):
+        done, self._pending = self._pending, None
+        return done
+
+
 def make_runner(model, cfg, device, depth=None):
     """The runner of the product path: hipGraph replay unless PRCNN_GRAPHS=0 (same streams, same kernels, same results)."""
+    if not engine_covers(cfg):
+        return ModuleRunner(model, cfg, device, depth)
     from . import GRAPH_REPLAY_SAFE
     if USE_GRAPHS and not GRAPH_REPLAY_SAFE:
         import warnings

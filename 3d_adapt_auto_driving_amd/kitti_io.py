@@ -137,7 +137,11 @@ class KittiSource:
         pts_rect = calib.lidar_to_rect(lidar[:, 0:3])
         pts_img, depth = calib.rect_to_img(pts_rect)
         scope = cfg.PC_AREA_SCOPE if cfg.PC_REDUCE_BY_RANGE else None
-        pts_rect = pts_rect[valid_flag(pts_rect, pts_img, depth, shape, scope)][:, 0:3]
+        keep = valid_flag(pts_rect, pts_img, depth, shape, scope)
+        pts_rect = pts_rect[keep][:, 0:3]
+        if cfg.RPN.USE_INTENSITY:
+            # pts_input = xyz | intensity - 0.5 (kitti_rcnn_dataset.py:274-275, 321-338); the sampler picks rows, so the column rides along
+            pts_rect = np.concatenate([pts_rect, lidar[keep][:, 3:4] - np.float32(0.5)], axis=1)
         pts = synth.subsample_rpn(pts_rect, cfg.RPN.NUM_POINTS, self.npoints_faraway,
                                   rng=np.random.default_rng(self.seed + idx))
         return np.ascontiguousarray(pts, dtype=np.float32), calib, shape
@@ -152,6 +156,9 @@ class DeviceInputStage:
 
     def __init__(self, cfg, device, npoints_faraway=4000, seed=1024, far_depth=40.0):
         import torch
+        if cfg.RPN.USE_INTENSITY:
+            raise NotImplementedError("DeviceInputStage produces coordinates only; with cfg.RPN.USE_INTENSITY use the host stage "
+                                      "(eval_scenes(device_input=False))")
         self.cfg, self.device = cfg, torch.device(device)
         self.npoints_faraway, self.seed, self.far_depth = npoints_faraway, seed, far_depth
 
@@ -279,4 +286,7 @@ class SyntheticSource:
             pts = synth.subsample_rpn(synth.dense_scene(idx, self.raw_points), n, rng=np.random.default_rng(1024 + idx))
         else:
             pts = synth.scene(idx, n)
+        if self.cfg.RPN.USE_INTENSITY:                      # a synthetic reflectance column, already shifted to [-0.5, 0.5)
+            refl = np.random.default_rng(77000 + idx).random((len(pts), 1)).astype(np.float32) - np.float32(0.5)
+            pts = np.concatenate([pts, refl], axis=1)
         return pts, self.calib, self.calib.image_shape

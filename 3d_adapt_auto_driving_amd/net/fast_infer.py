@@ -261,6 +261,9 @@ def _state_version(tensors):
 class FastPointRCNN:
     def __init__(self, model, cfg):
         assert not model.training, "FastPointRCNN is an inference engine: call model.eval() first"
+        if cfg.RPN.USE_INTENSITY:
+            raise NotImplementedError("fast path: per-point input features (cfg.RPN.USE_INTENSITY) are not covered; "
+                                      "eval_rcnn.make_runner() runs such a configuration on the nn.Module graph")
         self.model, self.cfg = model, cfg
         self._state = _state_tensors(model)
         self._folded_at = _state_version(self._state)       # BN is folded into the weights HERE: see check_weights()

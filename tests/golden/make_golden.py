@@ -8,6 +8,7 @@ The fixtures are DATA (inputs + expected outputs); no reference source is stored
   g7_glue_ref.npz      outputs of the reference's importable Python glue: decode_bbox_target (both
                        flag sets used on the path), boxes3d_to_bev_torch, enlarge_box3d,
                        rotate_pc_along_y_torch, boxes3d_to_corners3d, Calibration.corners3d_to_img_boxes
+  g8i_e2e_tiny_intensity_ref.npz  the same with cfg.RPN.USE_INTENSITY = True and a 4-channel input
   g8_e2e_tiny_ref.npz  the reference PointRCNN (imported under tests/golden/ref_harness.py shims, oracle
                        operator backend) on a tiny config: weights, input, rois, rcnn_cls, rcnn_reg and the
                        final boxes produced with the reference's own decode + nms_gpu sequence
@@ -115,9 +116,16 @@ def g7():
     print("g7 done")
 
 
-def g8():
-    model, cfg = H.reference_model(TINY)
-    torch.manual_seed(8)
+def g8(intensity=False):
+    """the reference PointRCNN (tiny shapes) run here: inputs, weights and every output of one joint RPN+RCNN pass + the final stage
+    of eval_rcnn.py.  intensity: cfg.RPN.USE_INTENSITY = True, pts_input (B, N, 4) = xyz | intensity - 0.5 (kitti_rcnn_dataset.py:321-338)
+    -> g8i_e2e_tiny_intensity_ref.npz"""
+    import copy
+    over = copy.deepcopy(TINY)
+    if intensity:
+        over["RPN"]["USE_INTENSITY"] = True
+    model, cfg = H.reference_model(over)
+    torch.manual_seed(9 if intensity else 8)
     # random-init leaves the heads near zero; spread them so that decisions are not degenerate
     with torch.no_grad():
         for name, p in model.named_parameters():
@@ -132,6 +140,9 @@ def g8():
                 m.running_mean.copy_(torch.randn_like(m.running_mean) * 0.1)
                 m.running_var.copy_(torch.rand_like(m.running_var) + 0.5)
     pts = torch.from_numpy(helpers.scenes(2, 2048, seed0=80))
+    if intensity:
+        refl = np.random.default_rng(81).random((2, 2048, 1)).astype(np.float32) - np.float32(0.5)
+        pts = torch.cat([pts, torch.from_numpy(refl)], dim=2)
     with torch.no_grad():
         ret = model({"pts_input": pts})
         # centre the segmentation threshold (sigmoid > 0.3 <=> raw > -0.8473) on the median score so
@@ -165,13 +176,15 @@ def g8():
         final_boxes[k, :n] = sel_boxes[keep].numpy(); final_scores[k, :n] = sel_raw[keep].view(-1).numpy()
         final_num[k] = n
     sd = {k: v.numpy() for k, v in model.state_dict().items()}
-    np.savez_compressed(os.path.join(HERE, "g8_e2e_tiny_ref.npz"), pts=pts.numpy(),
+    np.savez_compressed(os.path.join(HERE, "g8i_e2e_tiny_intensity_ref.npz" if intensity else "g8_e2e_tiny_ref.npz"), pts=pts.numpy(),
                         rois=ret["rois"].numpy(), roi_scores_raw=ret["roi_scores_raw"].numpy(),
                         rpn_cls=ret["rpn_cls"].numpy(), rcnn_cls=ret["rcnn_cls"].numpy(), rcnn_reg=ret["rcnn_reg"].numpy(),
                         seg_result=ret["seg_result"].numpy(), final_boxes=final_boxes, final_scores=final_scores,
                         final_num=final_num, state_keys=np.array(list(sd.keys())),
                         **{"w/" + k: v for k, v in sd.items()})
-    print("g8: params", sum(v.size for v in sd.values()), "final_num", final_num.tolist(),
+    if intensity:
+        cfg.RPN.USE_INTENSITY = False                     # (the reference's cfg is a module global: leave it as found)
+    print("g8i:" if intensity else "g8:", "params", sum(v.size for v in sd.values()), "final_num", final_num.tolist(),
           "seg fg", int(ret["seg_result"].sum()), "nonzero rois", int((ret["rois"].abs().sum(-1) > 0).sum()))
 
 
@@ -405,9 +418,9 @@ def g_ops():
 
 if __name__ == "__main__":
     assert H.available(), "/root/reference is not mounted: fixtures can only be regenerated in the build container"
-    todo = sys.argv[1:] or ["g5", "g7", "g_ops", "g8", "g9", "g10"]      # e.g. ``make_golden.py g9 g10``
+    todo = sys.argv[1:] or ["g5", "g7", "g_ops", "g8", "g8i", "g9", "g10"]      # e.g. ``make_golden.py g9 g10``
     for name in todo:
-        {"g5": g5, "g7": g7, "g_ops": g_ops, "g8": g8, "g9": g9, "g10": g10}[name]()
+        {"g5": g5, "g7": g7, "g_ops": g_ops, "g8": g8, "g8i": lambda: g8(intensity=True), "g9": g9, "g10": g10}[name]()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -31,6 +31,29 @@ def test_tiny_model_gpu_matches_reference_fixture():
     np.testing.assert_allclose(det["scores"].cpu().numpy(), g["final_scores"], rtol=0, atol=1e-4)
 
 
+def test_tiny_model_with_intensity_gpu_matches_reference_fixture(tmp_path):
+    """cfg.RPN.USE_INTENSITY = True, pts_input (B, N, 4): the nn.Module graph over the HIP operators against the fixture recorded from
+    the REFERENCE model in that configuration (g8i), and the whole driver on such a configuration (make_runner -> ModuleRunner)"""
+    E = pkg("eval_rcnn")
+    model, cfg, g = tiny_model(DEV, intensity=True)
+    det = E.infer_batch(model, cfg, torch.from_numpy(g["pts"]).to(DEV))
+    np.testing.assert_allclose(det["rois"].cpu().numpy(), g["rois"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(det["rcnn_reg"].cpu().numpy(), g["rcnn_reg"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(det["rcnn_cls"].cpu().numpy(), g["rcnn_cls"], rtol=0, atol=1e-4)
+    assert np.array_equal(det["num"].cpu().numpy(), g["final_num"])
+    np.testing.assert_allclose(det["boxes"].cpu().numpy(), g["final_boxes"], rtol=0, atol=1e-4)
+    runner = E.make_runner(model, cfg, DEV)
+    assert isinstance(runner, E.ModuleRunner)
+    with pytest.raises(NotImplementedError):
+        pkg("net.fast_infer").FastPointRCNN(model, cfg)
+    src = pkg("kitti_io").SyntheticSource(cfg, 5)
+    table, counts = E.eval_scenes(model, cfg, DEV, src, src.ids, batch_size=2, output_dir=str(tmp_path), workers=0)
+    assert table.shape[0] == 5 and len(list(tmp_path.glob("*.txt"))) == 5
+    one = E.infer_batch(model, cfg, torch.from_numpy(np.stack([src.load(i)[0] for i in (0, 1)])).to(DEV))
+    n0 = int(one["num"][0])
+    assert int(counts[0]) == n0 and np.allclose(table[0, :n0, :7], one["boxes"][0, :n0].cpu().numpy(), atol=1e-5)
+
+
 def test_fast_engine_gpu_matches_reference_fixture_and_pipelining_is_transparent():
     """Point-major engine on the GPU vs the reference fixture; and the two-stream pipelined runner
     returns exactly what the same engine returns when called serially."""

@@ -133,27 +133,33 @@ TINY = {"RPN": {"NUM_POINTS": 2048,
         "TEST": {"RPN_PRE_NMS_TOP_N": 600, "RPN_POST_NMS_TOP_N": 20}}
 
 
-def tiny_model(device="cpu"):
+def tiny_model(device="cpu", intensity=False):
+    """the tiny PointRCNN with the weights of the REFERENCE model the fixture was recorded from; intensity: cfg.RPN.USE_INTENSITY,
+    4-channel input (g8i)"""
     C = pkg("config")
     cfg = C.default_eval_cfg()
     C.merge_into(TINY, cfg)
+    if intensity:
+        C.merge_into({"RPN": {"USE_INTENSITY": True}}, cfg)
     model = pkg("eval_rcnn").build_model(cfg, device)
-    g = load("g8_e2e_tiny_ref.npz")
+    g = load("g8i_e2e_tiny_intensity_ref.npz" if intensity else "g8_e2e_tiny_ref.npz")
     sd = {str(k): torch.from_numpy(g["w/" + str(k)]) for k in g["state_keys"]}
     model.load_state_dict(sd)          # strict: the key tree must equal the reference's
     return model, cfg, g
 
 
-def test_e2e_tiny_matches_reference_model(oracle):
+@pytest.mark.parametrize("intensity", [False, True])
+def test_e2e_tiny_matches_reference_model(oracle, intensity):
     """My model + oracle operator backend on CPU vs the reference PointRCNN (run under the shim
-    harness when the fixture was made).  With the shared MLPs executed as nn.Modules (reference
+    harness when the fixture was made); intensity: cfg.RPN.USE_INTENSITY = True, (B, N, 4) input (rpn.py:17, pointnet2_msg.py:151-160).  With the shared MLPs executed as nn.Modules (reference
     operation order) every tensor is IDENTICAL; with the fused inference path (BN folded into the
     GEMM, fused epilogues) values move by f32 rounding only: within the 1e-4 box tolerance, same
     RoI order, same NMS keep counts."""
     from oracle import ext_cpu
     fm = pkg("pointnet2.fused_mlp")
-    model, cfg, g = tiny_model()
+    model, cfg, g = tiny_model(intensity=intensity)
     pts = torch.from_numpy(g["pts"])
+    assert pts.shape[-1] == (4 if intensity else 3)
     with ext_cpu.patch_package():
         fm.ENABLED = False
         try:
@@ -297,6 +303,42 @@ def test_kitti_input_stage(tmp_path):
     raw = {tuple(np.round(r, 4)) for r in rect}
     assert all(tuple(np.round(p, 4)) in raw for p in pts[:200])
     assert (pts[:, 2] >= 40).sum() <= 4000                       # at most npoints_faraway far points
+    # cfg.RPN.USE_INTENSITY: the same rows with the reflectance column shifted to [-0.5, 0.5) (kitti_rcnn_dataset.py:321-338)
+    cfg_i = pkg("config").default_eval_cfg()
+    pkg("config").merge_into({"RPN": {"USE_INTENSITY": True}}, cfg_i)
+    pts4, _, _ = K.KittiSource(str(root), cfg_i, "val").load(7)
+    assert pts4.shape == (16384, 4) and pts4.dtype == np.float32
+    assert np.array_equal(pts4[:, :3], pts)                      # same seed, same sampler decisions
+    refl = {tuple(np.round(r, 4)): v for r, v in zip(rect, lidar[:, 3])}
+    for p in pts4[:200]:
+        assert abs(refl[tuple(np.round(p[:3], 4))] - 0.5 - p[3]) < 1e-6
+    assert pts4[:, 3].min() >= -0.5 and pts4[:, 3].max() < 0.5
+
+
+def test_runner_choice_follows_the_configuration():
+    """make_runner: the point-major engine's runners for coordinates-only configurations, the nn.Module graph for cfg.RPN.USE_INTENSITY;
+    ModuleRunner speaks the one-batch-late protocol of the others (here on the CPU with the oracle operator backend)"""
+    from oracle import ext_cpu
+    E = pkg("eval_rcnn")
+    model, cfg, g = tiny_model(intensity=True)
+    assert not E.engine_covers(cfg) and E.engine_covers(pkg("config").default_eval_cfg())
+    runner = E.make_runner(model, cfg, "cpu")
+    assert isinstance(runner, E.ModuleRunner)
+    pts = torch.from_numpy(g["pts"])
+    with ext_cpu.patch_package():
+        assert runner.submit(pts, None) is None
+        first = runner.submit(pts[:1].contiguous(), None)
+        second = runner.flush()
+    assert runner.flush() is None
+    np.testing.assert_allclose(first["rois"].numpy(), g["rois"], rtol=0, atol=1e-4)     # (BN folded into the layers: f32 rounding only)
+    assert np.array_equal(first["num"].numpy(), g["final_num"])
+    np.testing.assert_allclose(first["boxes"].numpy(), g["final_boxes"], rtol=0, atol=1e-4)
+    assert second["boxes"].shape[0] == 1
+    np.testing.assert_allclose(second["boxes"].numpy(), g["final_boxes"][:1], rtol=0, atol=1e-4)
+    src = pkg("kitti_io").SyntheticSource(cfg, 2)
+    assert src.load(1)[0].shape == (cfg.RPN.NUM_POINTS, 4)
+    with pytest.raises(NotImplementedError):
+        pkg("kitti_io").DeviceInputStage(cfg, "cpu")
 
 
 def test_config_merge_and_set():
