@@ -33,9 +33,11 @@ char *scratch_for(hipStream_t st, size_t bytes, int slot = 0);
 // their last ticket.  Thread 0 of every workgroup calls this once, after its last draw (on every exit path): the last one to arrive
 // zeroes the pair, so the words are clean for their next user -- no fill in front of a launch, none inside a captured hipGraph
 // (a memset node per ticketed launch cost the graph replay ~4 % of a step).  Launches that share a pair are ordered by their stream.
+// No fence: the thread has CONSUMED the value of its last draw before it gets here (it decided to leave on it), both counters are
+// only ever touched by device-scope atomics, and a kernel boundary orders the reset against the next launch.  (An agent-scope fence
+// here is an L2 write-back per workgroup on a multi-XCD part: it cost rpn_tail_lin_kernel 10 us of 181.)
 __device__ __forceinline__ void ticket_release(unsigned int *ticket)
 {
-    __threadfence();
     if (atomicAdd(ticket + 1, 1u) == gridDim.x * gridDim.y * gridDim.z - 1u) {
         atomicExch(ticket, 0u);
         atomicExch(ticket + 1, 0u);
