@@ -3,7 +3,7 @@ O=gpurun_out/r03; mkdir -p $O; export TMPDIR=/tmp
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-driver > $O/bench_k20.json 2>/dev/null
 timeout 600 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-driver --no-lidar > $O/bench_k100.json 2>/dev/null
-( echo '## profiles/geo_probe.py both'; python profiles/geo_probe.py both; for s in uniform lidar; do echo; echo "## profiles/stage_probe.py $s"; python profiles/stage_probe.py $s; done; for s in uniform lidar; do echo; echo "## profiles/call_probe.py $s rcnn"; python profiles/call_probe.py $s rcnn; done; echo; echo '## profiles/host_bound_probe.py'; python profiles/host_bound_probe.py; echo; echo '## profiles/fps_probe.py'; python profiles/fps_probe.py; echo; echo '## profiles/graph_probe.py'; timeout 300 python profiles/graph_probe.py; echo; echo '## PRCNN_GRAPHS=0 profiles/host_bound_probe.py'; PRCNN_GRAPHS=0 python profiles/host_bound_probe.py; echo; echo '## profiles/ref_kernels_probe.py'; timeout 300 python profiles/ref_kernels_probe.py ) 2>&1 | grep -v amdgpu.ids > $O/microbench.txt
+( echo '## profiles/geo_probe.py both'; python profiles/geo_probe.py both; for s in uniform lidar; do echo; echo "## profiles/stage_probe.py $s"; python profiles/stage_probe.py $s; done; for s in uniform lidar; do echo; echo "## profiles/call_probe.py $s rcnn"; python profiles/call_probe.py $s rcnn; done; echo; echo '## profiles/host_bound_probe.py'; python profiles/host_bound_probe.py; echo; echo '## profiles/fps_probe.py'; python profiles/fps_probe.py; echo; echo '## profiles/graph_probe.py'; timeout 300 python profiles/graph_probe.py; echo; echo '## PRCNN_GRAPHS=0 profiles/host_bound_probe.py'; PRCNN_GRAPHS=0 python profiles/host_bound_probe.py; echo; echo '## tests/ref_kernels_probe.py'; timeout 300 python tests/ref_kernels_probe.py ) 2>&1 | grep -v amdgpu.ids > $O/microbench.txt
 for sc in uniform lidar; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$sc -- python bench.py --scene $sc --steps 40 --warmup 8 --prewarm 8 --no-cpu-baseline --no-roofline --no-driver --no-lidar > $O/kt_$sc.log 2>&1
   f=$(ls $O/kt_$sc/*/*kernel_trace.csv | head -1)

@@ -1,6 +1,6 @@
 """The REFERENCE'S OWN kernels (oracle/_ref/*.so: its .cu files compiled for gfx950 from the sources in place, oracle/Makefile) timed on
 the MI355X beside this build's kernels for the same operator on the same inputs (B = 8 scenes; uniform and LiDAR-shaped clouds).
-Operator level only -- the reference's Python cannot travel to the GPU box.  usage: python profiles/ref_kernels_probe.py"""
+Operator level only -- the reference's Python cannot travel to the GPU box.  usage: python tests/ref_kernels_probe.py"""
 import importlib, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
