@@ -140,6 +140,9 @@ def _runner_streams(device, n_sides, prio):
     first-created streams keep the queues they were given at start-up."""
     key = (str(device), prio)
     have = _RUNNER_STREAMS.setdefault(key, {"tail": None, "sides": [], "geo2": None, "feat": None})
+    if have["tail"] is None and int(os.environ.get("PRCNN_STREAM_SKEW", "0")) > 0:
+        # experiment: shift the round-robin stream -> hardware-queue assignment by creating (and keeping) unused streams first
+        have["skew"] = [torch.cuda.Stream(device) for _ in range(int(os.environ["PRCNN_STREAM_SKEW"]))]
     if have["tail"] is None:
         have["tail"] = torch.cuda.Stream(device, priority=int(os.environ.get("PRCNN_TAIL_PRIORITY", "0")))
     if have["geo2"] is None and RCNN_GEO_STREAM:
