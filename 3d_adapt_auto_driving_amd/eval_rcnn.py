@@ -557,10 +557,10 @@ class GraphedRunner:
         geometry graph of the group (FastPointRCNN.geometry_group: FPS / ball queries / row lists / three-NN / the early SA levels,
         on a side stream) and, per batch of the group, four graphs: RPN stage (feature stream), proposal layer + RCNN geometry
         (tail stream), RCNN features (feature stream), final stage (tail stream);
-      * depth / group + 2 group slots rotate: a slot is rewritten only after the RCNN stages of its previous batches (an event wait
+      * depth / group + 1 group slots rotate: a slot is rewritten only after the RCNN stages of its previous batches (an event wait
         on the side stream, normally long past);
       * the detections returned by submit() / flush() live in the slot: they stay valid for (slots - 1) * group further submits
-        (16 by default) -- copy them out (on det["stream"]) before that, as eval_scenes and bench.py do right away.
+        (12 by default) -- copy them out (on det["stream"]) before that, as eval_scenes and bench.py do right away.
     Every graph has a memory pool of its own (see _build); everything a later graph or the caller reads is kept referenced here.  Batches of another shape than the first one seen (the last, short batch of a split) run eagerly.
     Nondeterminism is that of the eager path: the worklists built with atomics (point groups, pooled tiles) come out in
     a different order every run, the results computed from them do not (tests/test_gpu_graphs.py: detections bit for bit)."""
@@ -585,7 +585,9 @@ class GraphedRunner:
         if have.get("feat") is None:
             have["feat"] = torch.cuda.Stream(self.device)
         self.feat = have["feat"]
-        self.n_slots = max(2, -(-self.depth // self.group) + 2)
+        # depth / group groups ahead + the one being consumed.  One more (the first version) costs 5.5 % at K = 96 -- 5100-5160 instead of
+        # 5406 scenes/s, the eager runner's figure: a fifth of the slots' 23 GB more to walk through per rotation; one less stalls (2765)
+        self.n_slots = int(os.environ.get("PRCNN_GRAPH_SLOTS", "0")) or max(2, -(-self.depth // self.group) + 1)
         self.shape = None
         self._assigned = []          # [(batch tensor, group slot, member)] chains launched, batch not yet submitted
         self._chains = self._assigned
