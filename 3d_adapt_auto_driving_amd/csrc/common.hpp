@@ -44,6 +44,44 @@ __device__ __forceinline__ void ticket_release(unsigned int *ticket)
     }
 }
 
+// The same with one draw counter per XCD (words [2..9] of the launch's 16-word ticket record): a workgroup draws from the counter of
+// its own XCD first -- block b runs on XCD b % 8 (observed placement; a different one costs locality, never correctness) -- so that
+// the tiles of one eighth of the problem, and the tables they gather from, stay in ONE L2 (the 8 L2s are 4 MB each and private).
+struct XcdTickets {
+    unsigned int *rec;        // the 16-word record
+    unsigned int chunk;       // tiles per partition
+    unsigned int tiles;
+    unsigned int xcd, dead;   // this workgroup's XCD; how many partitions (starting at its own) it has found empty
+    __device__ __forceinline__ unsigned int draw()      // thread 0 only; 0x7fffffff = nothing left anywhere
+    {
+        while (dead < 8u) {
+            const unsigned int y = (xcd + dead) & 7u;
+            const unsigned int k = atomicAdd(rec + 2 + y, 1u);
+            const unsigned long tile = (unsigned long)y * chunk + k;
+            if (k < chunk && tile < tiles) return (unsigned int)tile;
+            ++dead;
+        }
+        return 0x7fffffffu;
+    }
+    // thread 0 only, no wait on the result: the next ticket of the partition the workgroup is on, as a tile index -- or a value
+    // >= 0x40000000 when that partition has run out (the reader then calls draw(), which moves on to the next partition)
+    __device__ __forceinline__ unsigned int issue()
+    {
+        if (dead >= 8u) return 0x7fffffffu;
+        const unsigned int y = (xcd + dead) & 7u;
+        const unsigned int k = atomicAdd(rec + 2 + y, 1u);
+        const unsigned int lim = min(chunk, tiles > y * chunk ? tiles - y * chunk : 0u);      // tiles of partition y
+        return k < lim ? y * chunk + k : 0x40000000u;                                        // (a select, not a branch)
+    }
+    __device__ __forceinline__ void release()           // thread 0 of every workgroup, once, after its last draw
+    {
+        if (atomicAdd(rec + 1, 1u) == gridDim.x * gridDim.y * gridDim.z - 1u) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) atomicExch(rec + i, 0u);
+        }
+    }
+};
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is fence + s_barrier, and the fence drains vmcnt as
 // well: every wave then waits at the barrier for its outstanding GLOBAL loads and stores (an HBM round trip), which
 // serialises "store this tile / prefetch the next tile" against the LDS hand-off between pipeline phases.  Use this

@@ -48,7 +48,8 @@ struct RpnTailArgs {
     const float *wc2, *bc2;         // cls layer 2: (128,1), (1)
     float *feats, *cls, *reg;       // (rows,128), (rows,1), (rows,n_reg)
     int n_reg;
-    unsigned int *ticket;           // tile counter of this launch (zero on entry)
+    unsigned int *ticket;           // tile counter record of this launch (zero on entry)
+    int xcd_split;                  // rpn_tail_lin: tiles drawn per XCD partition (1) or from one counter (0: A/B switch PRCNN_TAIL_XCD=0)
 };
 
 __global__ __launch_bounds__(256, 1) void rpn_tail_kernel(const RpnTailArgs a)
@@ -287,7 +288,12 @@ __global__ __launch_bounds__(256, 1) void rpn_tail_lin_kernel(const RpnTailArgs 
     else if ((g) == (gf) + 1) { RL_ROW(1, 2 * (r) + 1, Xn) }
     f32x4 co[8];
 
-    if (tid == 0) { slot[0] = atomicAdd(a.ticket, 1u); }
+    // tiles by XCD: one eighth of the rows (one scene of a batch of 8) and its 2 MB of G per L2 instead of all 16.8 MB through every L2
+    XcdTickets tk;
+    tk.rec = a.ticket; tk.tiles = (unsigned int)tiles; tk.dead = 0u;
+    tk.chunk = a.xcd_split ? (unsigned int)((tiles + 7) / 8) : (unsigned int)tiles;
+    tk.xcd = a.xcd_split ? (blockIdx.x & 7u) : 0u;
+    if (tid == 0) { slot[0] = tk.issue(); }
     __syncthreads();
     long t = __builtin_amdgcn_readfirstlane((int)slot[0]);
     float wa[64], wb[64];
@@ -305,7 +311,9 @@ __global__ __launch_bounds__(256, 1) void rpn_tail_lin_kernel(const RpnTailArgs 
     long tp = 0;
     bool last = false;
     for (unsigned int served = 0; t < tiles; ++served) {
-        if (tid == 0) slot[(served + 1) & 1] = atomicAdd(a.ticket, 1u);
+        // the next tile's ticket from this workgroup's XCD partition (a select on the returned value, no control flow: any branch
+        // in this hand-scheduled loop cost 10 % of the kernel when tried, so a workgroup does not go stealing from other partitions)
+        if (tid == 0) slot[(served + 1) & 1] = tk.issue();
         RT_VM_DRAIN
         lds_barrier();                                         // this tile's input panel, the previous tile's regression rows in T1, the ticket
         const float *Xc = (served & 1) ? X1 : X0;
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(256, 1) void rpn_tail_lin_kernel(const RpnTailArgs 
             }
         }
     }
-    if (tid == 0) ticket_release(a.ticket);          // the launch's last workgroup zeroes the counter for the word's next user
+    if (tid == 0) tk.release();                      // the launch's last workgroup zeroes the record for its next user
 }
 
 }  // namespace prcnn
@@ -382,6 +390,7 @@ extern "C" int prcnn_rpn_tail(int b, int n, int m, const float *known, const int
     a.wcat = wcat; a.bcat = bcat; a.wc2 = wc2; a.bc2 = bc2; a.feats = feats; a.cls = cls; a.reg = reg; a.n_reg = n_reg;
     a.ticket = next_ticket((hipStream_t)stream);
     if (!a.ticket) { set_error("rpn_tail: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
+    a.xcd_split = 0;
     const long tiles = (rows + RT_ROWS - 1) / RT_ROWS;
     const long cap = mfma_grid_cap() < 256 ? mfma_grid_cap() : 256;               // gfx950: 256 CUs, one resident workgroup each (135 KB of LDS)
     const long grid = tiles < cap ? tiles : cap;
@@ -410,6 +419,8 @@ extern "C" int prcnn_rpn_tail_lin(int b, int n, int m, const float *G, const int
     a.wcat = wcat; a.bcat = bcat; a.wc2 = wc2; a.bc2 = bc2; a.feats = feats; a.cls = cls; a.reg = reg; a.n_reg = n_reg;
     a.ticket = next_ticket((hipStream_t)stream);
     if (!a.ticket) { set_error("rpn_tail_lin: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
+    static const int xcd_split = !(getenv("PRCNN_TAIL_XCD") && atoi(getenv("PRCNN_TAIL_XCD")) == 0);
+    a.xcd_split = xcd_split;
     const long tiles = (rows + RT_ROWS - 1) / RT_ROWS;
     const long cap = mfma_grid_cap() < 256 ? mfma_grid_cap() : 256;
     const long grid = tiles < cap ? tiles : cap;

@@ -310,7 +310,8 @@ __global__ __launch_bounds__(512, 1) void sa_mlp_fused256_kernel(
 }  // namespace prcnn
 
 namespace prcnn {
-// Tile-ticket words: a ring of 128 PAIRS of words per (device, stream) (slot 6 of the scratch cache), zeroed once when the stream's
+// Tile-ticket words: a ring of 128 records of 16 words per (device, stream) ([0] draw counter, [1] workgroups done, [2..9] per-XCD draw
+// counters of the kernels that partition their tiles by XCD, common.hpp XcdTickets) (slot 6 of the scratch cache), zeroed once when the stream's
 // ring is created.  One launch uses one pair and leaves it at zero (common.hpp ticket_release: the launch's last workgroup resets it),
 // so nothing is filled in front of a launch -- eagerly or inside a captured hipGraph, whose replays find the pair clean as well.
 // (Round 1 zeroed one word per launch: a 5 us fill kernel in front of each ticketed launch; round 2 one memset per 256 launches
@@ -320,15 +321,15 @@ static std::mutex g_ticket_mu;
 static std::map<std::pair<int, hipStream_t>, unsigned int> g_ticket_next;
 unsigned int *next_ticket(hipStream_t st)
 {
-    unsigned int *ring = reinterpret_cast<unsigned int *>(scratch_for(st, 2 * TICKET_RING * sizeof(unsigned int), 6));
+    unsigned int *ring = reinterpret_cast<unsigned int *>(scratch_for(st, 16 * TICKET_RING * sizeof(unsigned int), 6));
     if (!ring) return nullptr;                 // (a first use under capture ends here: the stream needs its warm-up)
     unsigned int k;
     {
         std::lock_guard<std::mutex> lock(g_ticket_mu);
         k = g_ticket_next[std::make_pair(current_device(), st)]++;
     }
-    if (k == 0 && hipMemsetAsync(ring, 0, 2 * TICKET_RING * sizeof(unsigned int), st) != hipSuccess) return nullptr;
-    return ring + 2 * (k % TICKET_RING);
+    if (k == 0 && hipMemsetAsync(ring, 0, 16 * TICKET_RING * sizeof(unsigned int), st) != hipSuccess) return nullptr;
+    return ring + 16 * (k % TICKET_RING);
 }
 }  // namespace prcnn
 

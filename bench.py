@@ -57,7 +57,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32 MFMA peak (MI355X_MICROARCH.md)
 # HBM traffic per launch from the rocprofv3 PMC passes over the product step (FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950
 # + WRITE_SIZE), kept with the profile it came from; a kernel that has no entry reports null
 PMC_SOURCE = "profiles/r03_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the product step)"
-PMC_TRAFFIC = {"rpn_tail_lin_kernel": 210.20e6, "rpn_tail_kernel": 325.87e6, "roipool3d_canonical_kernel": 82.66e6}
+PMC_TRAFFIC = {"rpn_tail_lin_kernel": 149.01e6, "rpn_tail_kernel": 325.87e6, "roipool3d_canonical_kernel": 82.66e6}
 HOST_LAG = int(os.environ.get("PRCNN_BENCH_LAG", "3"))   # the host consumes a batch's detections this many batches late
 BATCH = int(os.environ.get("PRCNN_BENCH_BATCH", "8"))     # scenes per step per GPU (BASELINE configs[2]: 8; the override is for experiments and is echoed in config.env_overrides)
 NPOINTS = 16384
