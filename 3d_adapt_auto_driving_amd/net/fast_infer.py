@@ -59,7 +59,7 @@ USE_WIDE_FUSED = os.environ.get("PRCNN_NO_WIDE_FUSED") is None
 # RoI pooling culls by 64-point spatial groups of the scene (built with the geometry chain); PRCNN_NO_POOL_GROUPS=1: full sweep
 USE_XYZ_LEVEL_EARLY = os.environ.get("PRCNN_NO_XYZ_EARLY") != "1"    # leading SA levels of a coordinates-only backbone computed with the geometry (side stream)
 EARLY_LEVELS = int(os.environ.get("PRCNN_EARLY_LEVELS", "4"))
-EARLY_FP = int(os.environ.get("PRCNN_EARLY_FP", "0"))                 # ... plus this many of the coarsest FP modules
+EARLY_FP = int(os.environ.get("PRCNN_EARLY_FP", "1"))                 # ... plus this many of the coarsest FP modules (round 3: 1 -- over the 32 clouds of a group in one launch each: +1.2 % at K = 20, +2.5 % at K = 96; 2: the same; 3: -1 %)
 GROUP_SA = os.environ.get("PRCNN_NO_GROUP_SA") != "1"                 # ... and over all batches of a geometry group at once
 USE_POOL_GROUPS = os.environ.get("PRCNN_NO_POOL_GROUPS") is None
 # feature-propagation modules: the first layer is linear in front of its ReLU and the interpolation is a weighted sum, so the
