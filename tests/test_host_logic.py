@@ -341,6 +341,24 @@ def test_runner_choice_follows_the_configuration():
         pkg("kitti_io").DeviceInputStage(cfg, "cpu")
 
 
+def test_graph_replay_is_refused_when_the_runtime_switch_came_too_late(monkeypatch):
+    """the package sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 at import (tests/conftest.py does it first thing); a process whose HIP runtime was up
+    before that must not replay graphs: make_runner() hands out the eager runner with a warning, GraphedRunner itself refuses"""
+    import warnings
+    P, E = pkg(), pkg("eval_rcnn")
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0" and P.GRAPH_REPLAY_SAFE
+    monkeypatch.setattr(P, "GRAPH_REPLAY_SAFE", False)
+    with pytest.raises(RuntimeError, match="DEBUG_CLR_GRAPH_PACKET_CAPTURE"):
+        E.GraphedRunner(None, None, "cpu")
+    made = []
+    monkeypatch.setattr(E, "PipelinedRunner", lambda *a: made.append(a) or "eager")
+    cfg = pkg("config").default_eval_cfg()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert E.make_runner("model", cfg, "cuda:0") == "eager"
+    assert made and any("hipGraph replay disabled" in str(x.message) for x in w)
+
+
 def test_config_merge_and_set():
     C = pkg("config")
     cfg = C.default_eval_cfg()
