@@ -262,7 +262,7 @@ def roofline_roipool(dev, cfg, model, reps=20):
             "shape": {"B": B, "N": NPOINTS, "rois": M, "sampled": S, "row_floats": 8 + C}}
 
 
-def driver_leg(cfg, model, dev, scenes=1536):
+def driver_leg(cfg, model, dev, scenes=4096):
     """eval_rcnn.eval_scenes over synthetic scenes with everything the reference's loop has around the model
     (eval_rcnn.py:493-649): loader processes produce the 16384-point clouds, pinned H2D, pipelined engine, one D2H per
     batch, KITTI result files.  Steady-state rate (loader / writer process start-up excluded)."""
