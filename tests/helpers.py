@@ -22,3 +22,43 @@ def boxes3d(rng, n, xz_scope=((-20, 20), (5, 60))):
     h = rng.uniform(1.3, 1.8, n); w = rng.uniform(1.4, 1.9, n); l = rng.uniform(3.2, 4.6, n)
     ry = rng.uniform(-np.pi, np.pi, n)
     return np.stack([x, y, z, h, w, l, ry], 1).astype(np.float32)
+
+
+def seeded_state_dict(template, seed):
+    """Full-size model weights that regenerate from ONE seed on any machine (numpy PCG64, keys in sorted order), so that a
+    fixture recorded from the reference model (tests/golden/make_golden.py g12) needs to carry only the seed and a checksum.
+    ``template``: a state dict (names -> tensors) giving names, shapes and dtypes.  He-scaled convolution weights (activations
+    stay O(1) through the ReLU chains, so the heads' outputs are spread and decisions are not near-ties), small biases, BatchNorm
+    statistics away from the identity, the RCNN's last classification layer scaled down (scores near their bias).
+    -> (dict name -> torch tensor, float64 checksum)"""
+    import torch
+    rng = np.random.default_rng(seed)
+    out, acc = {}, 0.0
+    for name in sorted(template.keys()):
+        t = template[name]
+        shape = tuple(t.shape)
+        if name.endswith("num_batches_tracked"):
+            v = np.zeros(shape, np.int64)
+        elif name.endswith("running_var"):
+            v = rng.uniform(0.5, 1.5, shape)
+        elif name.endswith("running_mean"):
+            v = 0.1 * rng.standard_normal(shape)
+        elif ".bn." in name and name.endswith("weight"):
+            v = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif name.endswith("bias"):
+            v = 0.1 * rng.standard_normal(shape)
+        else:                                                     # conv / linear weight (out, in, 1[, 1])
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+            v = rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)
+            if name.startswith("rcnn_net.cls_layer.3."):          # RCNN scores stay near the bias (0.5, set below):
+                v = v * 0.2                                       # most RoIs pass the 0.3 threshold and the NMS does the rest
+            elif name.startswith("rcnn_net.reg_layer.3."):        # no BatchNorm in the RCNN: its activations grow with depth;
+                v = v * 0.1                                       # keep the regression outputs O(1) like a trained head's
+            elif name.startswith("rpn.rpn_cls_layer.2."):         # 16384 scores per scene: spread them (std ~2) so that the
+                v = v * 20.0                                      # score sort has no near-ties at f32 rounding level
+        if name == "rcnn_net.cls_layer.3.conv.bias":
+            v = np.full(shape, 0.5)
+        v = v.astype(np.int64 if name.endswith("num_batches_tracked") else np.float32)
+        acc += float(np.abs(v.astype(np.float64)).sum())
+        out[name] = torch.from_numpy(v)
+    return out, acc

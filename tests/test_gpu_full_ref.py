@@ -1,0 +1,74 @@
+"""-m gpu: BASELINE configs[2] at its FULL shapes (cfgs/default.yaml: 16384 points, 4096/1024/256/64 backbone levels, 100 RoIs x 512
+points per scene) against fixtures recorded from the REFERENCE PointRCNN itself (tests/golden/make_golden.py g12: the reference's
+point_rcnn.py:26-70, rcnn_net.py:127-185, proposal_layer.py:15-119 run under the shims of tests/golden/ref_harness.py), B = 2,
+on uniform scenes (g12u) and on LiDAR-shaped sweeps (g12l).  Bar (BASELINE.json north_star): every RoI, every head output and every
+final box within 1e-4 IN THE REFERENCE'S ORDER, equal counts -- for the nn.Module graph over the HIP operators (the drop-in path)
+AND for the point-major engine (the product path).  Replaces the 1e-3 / >= 90 % bars that round 3 held against a
+self-comparison.
+
+On a miss the test names the first stage where the GPU and the reference part (RPN scores -> foreground mask -> RoIs -> pooled
+clouds -> sampled centres -> heads -> decoded boxes -> final keep lists)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from test_host_logic import full_model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+def _report(ret, det, g):
+    """stage by stage: max |GPU - reference| and the number of rows beyond 1e-4"""
+    rep = []
+
+    def stage(name, got, want, rows_axis=None):
+        got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+        d = np.abs(got - want)
+        bad = int((d.reshape(d.shape[0], -1).max(1) > TOL).sum()) if rows_axis is None else int((d.max(rows_axis) > TOL).sum())
+        rep.append((name, float(d.max()) if d.size else 0.0, bad, d.shape))
+        return float(d.max()) if d.size else 0.0
+    B = g["rois"].shape[0]
+    stage("rpn_cls (B,N)", ret["rpn_cls"][..., 0].cpu().numpy(), g["rpn_cls"])
+    sub = slice(0, 16384, 64)
+    stage("rpn_reg every 64th point", ret["rpn_reg"][:, sub].cpu().numpy().reshape(-1, ret["rpn_reg"].shape[-1]), g["rpn_reg_sub"].reshape(-1, g["rpn_reg_sub"].shape[-1]))
+    seg = np.unpackbits(g["seg_result"], axis=1)[:, :16384]
+    flips = int((ret["seg_result"].cpu().numpy().astype(np.uint8) != seg).sum())
+    rep.append(("seg_result flips", float(flips), flips, seg.shape))
+    stage("rois (B*M,7)", ret["rois"].cpu().numpy().reshape(-1, 7), g["rois"].reshape(-1, 7))
+    stage("roi_scores_raw", ret["roi_scores_raw"].cpu().numpy().reshape(-1, 1), g["roi_scores_raw"].reshape(-1, 1))
+    stage("rcnn_cls (B*M,1)", ret["rcnn_cls"].cpu().numpy(), g["rcnn_cls"])
+    stage("rcnn_reg (B*M,46)", ret["rcnn_reg"].cpu().numpy(), g["rcnn_reg"])
+    if "pred_boxes3d" in det:
+        stage("decoded boxes (B*M,7)", det["pred_boxes3d"].cpu().numpy().reshape(-1, 7), g["decoded"].reshape(-1, 7))
+    rep.append(("final_num", float(np.abs(det["num"].cpu().numpy() - g["final_num"]).max()), int((det["num"].cpu().numpy() != g["final_num"]).sum()), (B,)))
+    stage("final_boxes (B*M,7)", det["boxes"].cpu().numpy().reshape(-1, 7), g["final_boxes"].reshape(-1, 7))
+    stage("final_scores", det["scores"].cpu().numpy().reshape(-1, 1), g["final_scores"].reshape(-1, 1))
+    return rep
+
+
+def _run(kind, use_engine):
+    E, F = pkg("eval_rcnn"), pkg("net.fast_infer")
+    model, cfg, g, pts = full_model(DEV, kind)
+    x = torch.from_numpy(pts).to(DEV)
+    with torch.no_grad():
+        ret = F.FastPointRCNN(model, cfg)(x) if use_engine else model({"pts_input": x})
+        if "seg_result" not in ret:
+            ret["seg_result"] = (torch.sigmoid(ret["rpn_cls"][..., 0]) > cfg.RPN.SCORE_THRESH).float()
+        det = E.postprocess(cfg, ret, x.shape[0])
+    torch.cuda.synchronize()
+    rep = _report(ret, det, g)
+    text = "\n".join("  %-28s max|d| %.3g   rows > 1e-4: %d of %s" % r for r in rep)
+    print("g12%s %s:\n%s" % (kind, "engine" if use_engine else "module path", text))
+    return rep, text, g
+
+
+@pytest.mark.parametrize("kind", ["u", "l"])
+@pytest.mark.parametrize("use_engine", [False, True], ids=["module", "engine"])
+def test_full_size_vs_reference_model_fixture_every_roi_and_box(kind, use_engine):
+    rep, text, g = _run(kind, use_engine)
+    first_bad = next((r for r in rep if r[2] > 0), None)
+    assert first_bad is None, "first stage that parts from the reference: %s\n%s" % (first_bad[0], text)
+    assert int(g["final_num"].min()) >= 10

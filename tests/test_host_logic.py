@@ -148,6 +148,46 @@ def tiny_model(device="cpu", intensity=False):
     return model, cfg, g
 
 
+def full_model(device="cpu", kind="u"):
+    """default.yaml PointRCNN with the seeded weights of the REFERENCE model that the full-size fixture g12u / g12l was recorded
+    from (tests/golden/make_golden.py g12; helpers.seeded_state_dict regenerates the 3.9 M parameters from the seed, the fixture
+    holds their checksum and the calibrated RPN classification bias) -> model, cfg, fixture, input batch (2, 16384, 3) numpy"""
+    import helpers
+    C, S = pkg("config"), pkg("synth")
+    cfg = C.default_eval_cfg()
+    model = pkg("eval_rcnn").build_model(cfg, "cpu")
+    g = load("g12%s_e2e_full_ref.npz" % kind)
+    sd, checksum = helpers.seeded_state_dict(model.state_dict(), int(g["seed"]))
+    assert abs(checksum - float(g["weights_checksum"])) < 1e-6 * checksum, "seeded weights differ from the ones the fixture was made with"
+    sd["rpn.rpn_cls_layer.2.conv.bias"] = torch.from_numpy(g["rpn_cls_bias"])
+    model.load_state_dict(sd)          # strict: the key tree must equal the reference's
+    seed = int(g["seed"])
+    pts = np.stack([(S.scene if kind == "u" else S.lidar_scene)(seed + i, 16384) for i in range(2)], 0)
+    return model.to(device).eval(), cfg, g, pts
+
+
+@pytest.mark.parametrize("kind", ["u", "l"])
+def test_e2e_full_size_matches_reference_model(oracle, kind):
+    """BASELINE configs[2] shapes (default.yaml, N = 16384, 100 RoIs x 512 points, B = 2; uniform and LiDAR-shaped scenes): this
+    build's model + the oracle operator backend on CPU, shared MLPs as nn.Modules (the reference's operation order), against
+    the fixture recorded from the REFERENCE PointRCNN at the same shapes (g12): every RoI, head output and final box."""
+    from oracle import ext_cpu
+    fm = pkg("pointnet2.fused_mlp")
+    model, cfg, g, pts = full_model("cpu", kind)
+    with ext_cpu.patch_package():
+        fm.ENABLED = False
+        try:
+            det = pkg("eval_rcnn").infer_batch(model, cfg, torch.from_numpy(pts))
+        finally:
+            fm.ENABLED = True
+    assert np.array_equal(det["rois"].numpy(), g["rois"])
+    np.testing.assert_allclose(det["rcnn_cls"].numpy(), g["rcnn_cls"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(det["rcnn_reg"].numpy(), g["rcnn_reg"], rtol=0, atol=1e-5)
+    assert np.array_equal(det["num"].numpy(), g["final_num"]) and g["final_num"].min() >= 10
+    np.testing.assert_allclose(det["boxes"].numpy(), g["final_boxes"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(det["scores"].numpy(), g["final_scores"], rtol=0, atol=1e-5)
+
+
 @pytest.mark.parametrize("intensity", [False, True])
 def test_e2e_tiny_matches_reference_model(oracle, intensity):
     """My model + oracle operator backend on CPU vs the reference PointRCNN (run under the shim
