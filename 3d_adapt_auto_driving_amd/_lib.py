@@ -89,6 +89,7 @@ SIGNATURES = {
     "prcnn_roipool3d_canonical": [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_point_groups": [_I, _I, _P, _P, _P, _P],
     "prcnn_input_stage": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P],
+    "prcnn_valid_flags": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P],
     "prcnn_rotate_iou_eval": [_I, _I, _P, _P, _P, _I, _P],
     "prcnn_rotate_iou_eval_segmented": [_I, _L, _P, _P, _P, _P, _P, _P, _I, _P],
     "prcnn_kitti_image_stats": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _D, _D, _I, _I, _P, _P, _P, _P],

@@ -18,9 +18,11 @@
 // chosen at random) + a random subset of the near ones; fewer -> every point + random extra copies.
 // The choice is random, so parity with the host sampler is distributional, not bitwise; the tests check the
 // invariants (valid points only, exact counts per class, no duplicates unless the cloud is too small, determinism
-// in the seed, uniformity) and the filter flags against the numpy implementation.
+// in the seed, uniformity).  The transform and the filter ARE bitwise the reference's (round 4): flags and rectified
+// coordinates equal what the reference's own numpy code produced on the fixture scenes (tests/golden g11).
 #include "common.hpp"
 #include <math.h>
+#include <algorithm>
 
 namespace prcnn {
 
@@ -38,6 +40,55 @@ __device__ __forceinline__ unsigned fmix32(unsigned h)
 {
     h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
     return h;                // a bijection on 32-bit words
+}
+
+// lidar -> rectified frame -> image, validity, near / far class of ONE raw point, in the arithmetic the reference's numpy code
+// performs (pinned by tests/golden g11, reference-executed): ``np.dot`` of float32 operands is a chain of fused multiply-adds
+// over the inner index, first term a plain product -- for the tiny (4,3) = V2C^T . R0^T product of Calibration.lidar_to_rect
+// (calibration.py:51-59) as well as for the (n,4) . (4,3) products; rect_to_img divides by the rect depth (0 -> 1e-9,
+// calibration.py:66-68) and subtracts P2[2][3] for the depth; get_valid_flag (kitti_rcnn_dataset.py:201-222) compares in f32.
+struct LidarToRect {
+    float m[4][3];           // np.dot(V2C.T, R0.T)
+    __device__ void set(const SceneCalib &cb)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float acc = __fmul_rn(cb.v2c[i], cb.r0[3 * j]);                       // V2C^T[i][0] * R0^T[0][j]
+                acc = __fmaf_rn(cb.v2c[4 + i], cb.r0[3 * j + 1], acc);
+                m[i][j] = __fmaf_rn(cb.v2c[8 + i], cb.r0[3 * j + 2], acc);
+            }
+    }
+    __device__ __forceinline__ float row(int j, float px, float py, float pz) const
+    {
+        float acc = __fmul_rn(px, m[0][j]);
+        acc = __fmaf_rn(py, m[1][j], acc);
+        acc = __fmaf_rn(pz, m[2][j], acc);
+        return __fadd_rn(acc, m[3][j]);                                               // fma(1, m, acc)
+    }
+};
+
+// -> class: 0 = invalid, 1 = near (z < far_depth), 2 = far; x, y, z = rectified coordinates
+__device__ __forceinline__ int classify_point(const SceneCalib &cb, const LidarToRect &l2r, int lidar_frame, int image_filter,
+                                              const float *__restrict__ scope, float far_depth, float px, float py, float pz,
+                                              float &x, float &y, float &z)
+{
+    x = px; y = py; z = pz;
+    if (lidar_frame) { x = l2r.row(0, px, py, pz); y = l2r.row(1, px, py, pz); z = l2r.row(2, px, py, pz); }
+    bool ok = true;
+    if (image_filter) {
+        float hu = __fmul_rn(x, cb.p2[0]); hu = __fmaf_rn(y, cb.p2[1], hu); hu = __fmaf_rn(z, cb.p2[2], hu); hu = __fadd_rn(hu, cb.p2[3]);
+        float hv = __fmul_rn(x, cb.p2[4]); hv = __fmaf_rn(y, cb.p2[5], hv); hv = __fmaf_rn(z, cb.p2[6], hv); hv = __fadd_rn(hv, cb.p2[7]);
+        float hw = __fmul_rn(x, cb.p2[8]); hw = __fmaf_rn(y, cb.p2[9], hw); hw = __fmaf_rn(z, cb.p2[10], hw); hw = __fadd_rn(hw, cb.p2[11]);
+        const float zz = (z == 0.f) ? 1e-9f : z;
+        const float u = __fdiv_rn(hu, zz), v = __fdiv_rn(hv, zz);
+        const float depth = __fsub_rn(hw, cb.p2[11]);
+        ok = u >= 0.f && u < cb.img_w && v >= 0.f && v < cb.img_h && depth >= 0.f;
+    }
+    if (scope)
+        ok = ok && x >= scope[0] && x <= scope[1] && y >= scope[2] && y <= scope[3] && z >= scope[4] && z <= scope[5];
+    return !ok ? 0 : (z < far_depth ? 1 : 2);
 }
 
 __device__ __forceinline__ int block_sum(int v, int *red)
@@ -103,31 +154,17 @@ __global__ __launch_bounds__(IS_THREADS) void input_stage_kernel(
     const unsigned long long seed = seeds[b];
     const unsigned sa = fmix32((unsigned)seed), sb = fmix32((unsigned)(seed >> 32) ^ 0x9e3779b9u), sc = sa ^ 0x7f4a7c15u;
     const SceneCalib cb = calib[b];
+    LidarToRect l2r;
+    l2r.set(cb);
 
     // ---- 1. transform + filter + classify
     int n_near = 0, n_far = 0;
     for (int i = t; i < n; i += IS_THREADS) {
         const float px = src[(long)i * stride], py = src[(long)i * stride + 1], pz = src[(long)i * stride + 2];
-        float x = px, y = py, z = pz;
-        if (lidar_frame) {
-            const float cx = cb.v2c[0] * px + cb.v2c[1] * py + cb.v2c[2] * pz + cb.v2c[3];
-            const float cy = cb.v2c[4] * px + cb.v2c[5] * py + cb.v2c[6] * pz + cb.v2c[7];
-            const float cz = cb.v2c[8] * px + cb.v2c[9] * py + cb.v2c[10] * pz + cb.v2c[11];
-            x = cb.r0[0] * cx + cb.r0[1] * cy + cb.r0[2] * cz;
-            y = cb.r0[3] * cx + cb.r0[4] * cy + cb.r0[5] * cz;
-            z = cb.r0[6] * cx + cb.r0[7] * cy + cb.r0[8] * cz;
-        }
-        const float hu = cb.p2[0] * x + cb.p2[1] * y + cb.p2[2] * z + cb.p2[3];
-        const float hv = cb.p2[4] * x + cb.p2[5] * y + cb.p2[6] * z + cb.p2[7];
-        const float hw = cb.p2[8] * x + cb.p2[9] * y + cb.p2[10] * z + cb.p2[11];
-        const float u = hu / z, v = hv / z;                 // rect_to_img divides by the rect depth (calibration.py:66)
-        const float depth = hw - cb.p2[11];
-        bool ok = !image_filter || (u >= 0.f && u < cb.img_w && v >= 0.f && v < cb.img_h && depth >= 0.f);
-        if (scope)
-            ok = ok && x >= scope[0] && x <= scope[1] && y >= scope[2] && y <= scope[3] && z >= scope[4] && z <= scope[5];
+        float x, y, z;
+        const int c = classify_point(cb, l2r, lidar_frame, image_filter, scope, far_depth, px, py, pz, x, y, z);
         rc[3 * (long)i] = x; rc[3 * (long)i + 1] = y; rc[3 * (long)i + 2] = z;
         ky[i] = fmix32((unsigned)i ^ sa);
-        const int c = !ok ? 0 : (z < far_depth ? 1 : 2);
         cl[i] = (unsigned char)c;
         n_near += (c == 1);
         n_far += (c == 2);
@@ -227,6 +264,29 @@ __global__ __launch_bounds__(IS_THREADS) void input_stage_kernel(
     }
 }
 
+// the front half alone (get_valid_flag + lidar_to_rect as an operator): rect (b, n_max, 3), cls (b, n_max) u8
+__global__ __launch_bounds__(256) void valid_flags_kernel(int n_max, int stride, int lidar_frame, int image_filter,
+                                                           const int *__restrict__ counts, const float *__restrict__ raw,
+                                                           const SceneCalib *__restrict__ calib, const float *__restrict__ scope,
+                                                           float far_depth, float *__restrict__ rect, unsigned char *__restrict__ cls)
+{
+    const int b = blockIdx.y;
+    const int n = min(counts[b], n_max);
+    const SceneCalib cb = calib[b];
+    LidarToRect l2r;
+    l2r.set(cb);
+    const float *__restrict__ src = raw + (long)b * n_max * stride;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_max; i += gridDim.x * blockDim.x) {
+        float x = 0.f, y = 0.f, z = 0.f;
+        int c = 0;
+        if (i < n)
+            c = classify_point(cb, l2r, lidar_frame, image_filter, scope, far_depth, src[(long)i * stride], src[(long)i * stride + 1],
+                               src[(long)i * stride + 2], x, y, z);
+        if (rect) { float *r = rect + ((long)b * n_max + i) * 3; r[0] = x; r[1] = y; r[2] = z; }
+        cls[(long)b * n_max + i] = (unsigned char)c;
+    }
+}
+
 static size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace prcnn
@@ -277,4 +337,33 @@ extern "C" int prcnn_input_stage(int b, int n_max, int stride, int lidar_frame, 
                        (const SceneCalib *)calib, scope_dev, npoints, npad, far_depth, npoints_faraway, seeds,
                        (float *)(base + o_rect), (unsigned *)(base + o_key), (unsigned char *)(base + o_cls), out, stats, choice);
     return check_launch("input_stage");
+}
+
+
+// get_valid_flag (kitti_rcnn_dataset.py:201-222) + Calibration.lidar_to_rect / rect_to_img (calibration.py:51-71) for whole
+// batches: the front half of prcnn_input_stage as an operator of its own, same arguments.  -> cls (b, n_max) u8: 0 = not valid,
+// 1 = valid with z < far_depth, 2 = valid beyond (rows >= counts[b]: 0); rect (b, n_max, 3) f32 rectified coordinates (may be
+// NULL).  Bit-identical to the reference's numpy results (float32 np.dot = fma chains; tests/golden g11).
+extern "C" int prcnn_valid_flags(int b, int n_max, int stride, int lidar_frame, int image_filter, const int *counts, const float *raw,
+                                 const float *calib, const float *scope_host, float far_depth, float *rect, unsigned char *cls,
+                                 void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && n_max >= 0 && (stride == 3 || stride == 4), "valid_flags: bad sizes (stride 3 or 4)");
+    if (b == 0 || n_max == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(counts && calib && raw && cls, "valid_flags: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    float *scope_dev = nullptr;
+    if (scope_host) {
+        char *base = scratch_for(st, 256, 5);
+        if (!base) { set_error("valid_flags: cannot allocate scratch"); return PRCNN_ELAUNCH; }
+        scope_dev = (float *)base;
+        if (hipMemcpyAsync(scope_dev, scope_host, 6 * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) {
+            set_error("valid_flags: scope upload failed");
+            return PRCNN_ELAUNCH;
+        }
+    }
+    const int gx = (int)std::min<long>(1024, ((long)n_max + 255) / 256);
+    hipLaunchKernelGGL(valid_flags_kernel, dim3(gx, b), dim3(256), 0, st, n_max, stride, lidar_frame, image_filter, counts, raw,
+                       (const SceneCalib *)calib, scope_dev, far_depth, rect, cls);
+    return check_launch("valid_flags");
 }

@@ -818,40 +818,47 @@ def _tensors(obj):
             yield v
 
 
+_RESULT_ROW = " -1 -1" + " %.4f" * 13 + "\n"
+
+
+def kitti_result_text(calib, bbox3d, scores, img_shape, cls_name="Car"):
+    """The result file of one scene as ONE string (tools/eval_rcnn.py:76-101 ``save_kitti_format``; pinned to the text the
+    reference writes by tests/golden g11): per surviving box ``<class> -1 -1 alpha x1 y1 x2 y2 h w l x y z ry score``, %.4f.
+    Whole-array form: the image boxes of all corners in one projection, clipped to the image; boxes that project wider or
+    taller than 80 % of it are dropped; the observation angle alpha = ry + beta - sign(beta) * pi / 2 with beta = atan2(z, x) in the
+    boxes' own precision; the 13 numeric columns of all rows go through a single format call."""
+    n = int(bbox3d.shape[0])
+    if n == 0:
+        return ""
+    bbox3d = np.asarray(bbox3d)
+    img_boxes = calib.corners3d_to_img_boxes(kitti_utils.boxes3d_to_corners3d(bbox3d))[0]
+    h, w = img_shape[0], img_shape[1]
+    img_boxes = np.clip(img_boxes, 0, np.array([w - 1, h - 1, w - 1, h - 1]))
+    ok = ((img_boxes[:, 2] - img_boxes[:, 0]) < w * 0.8) & ((img_boxes[:, 3] - img_boxes[:, 1]) < h * 0.8)
+    beta = np.arctan2(bbox3d[:, 2], bbox3d[:, 0])
+    alpha = -np.sign(beta) * np.pi / 2 + beta + bbox3d[:, 6]
+    table = np.empty((n, 13), dtype=np.float64)
+    table[:, 0] = alpha
+    table[:, 1:5] = img_boxes
+    table[:, 5:8] = bbox3d[:, 3:6]
+    table[:, 8:11] = bbox3d[:, 0:3]
+    table[:, 11] = bbox3d[:, 6]
+    table[:, 12] = np.asarray(scores)
+    table = table[ok]
+    return ((cls_name + _RESULT_ROW) * len(table)) % tuple(table.reshape(-1).tolist())
+
+
 def kitti_result_lines(calib, bbox3d, scores, img_shape, cls_name="Car"):
-    """16-field KITTI label lines, %.4f (eval_rcnn.py:76-101): boxes projecting wider/taller than
-    80 % of the image are dropped; alpha = -sign(beta)*pi/2 + beta + ry with beta = atan2(z, x)."""
-    if bbox3d.shape[0] == 0:
-        return []
-    corners3d = kitti_utils.boxes3d_to_corners3d(bbox3d)
-    img_boxes, _ = calib.corners3d_to_img_boxes(corners3d)
-    img_boxes[:, 0] = np.clip(img_boxes[:, 0], 0, img_shape[1] - 1)
-    img_boxes[:, 1] = np.clip(img_boxes[:, 1], 0, img_shape[0] - 1)
-    img_boxes[:, 2] = np.clip(img_boxes[:, 2], 0, img_shape[1] - 1)
-    img_boxes[:, 3] = np.clip(img_boxes[:, 3], 0, img_shape[0] - 1)
-    bw, bh = img_boxes[:, 2] - img_boxes[:, 0], img_boxes[:, 3] - img_boxes[:, 1]
-    ok = np.logical_and(bw < img_shape[1] * 0.8, bh < img_shape[0] * 0.8)
-    lines = []
-    for k in range(bbox3d.shape[0]):
-        if not ok[k]:
-            continue
-        x, z, ry = bbox3d[k, 0], bbox3d[k, 2], bbox3d[k, 6]
-        beta = np.arctan2(z, x)
-        alpha = -np.sign(beta) * np.pi / 2 + beta + ry
-        lines.append("%s -1 -1 %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f %.4f" %
-                     (cls_name, alpha, img_boxes[k, 0], img_boxes[k, 1], img_boxes[k, 2], img_boxes[k, 3],
-                      bbox3d[k, 3], bbox3d[k, 4], bbox3d[k, 5], bbox3d[k, 0], bbox3d[k, 1], bbox3d[k, 2],
-                      bbox3d[k, 6], scores[k]))
-    return lines
+    """The same as a list of lines (for the in-memory AP evaluation)."""
+    return kitti_result_text(calib, bbox3d, scores, img_shape, cls_name).split("\n")[:-1]
 
 
 def save_kitti_format(sample_id, calib, bbox3d, kitti_output_dir, scores, img_shape, cls_name="Car"):
     """One result file per scene (empty when nothing survives); returns the number of lines."""
-    lines = kitti_result_lines(calib, bbox3d, scores, img_shape, cls_name)
+    text = kitti_result_text(calib, bbox3d, scores, img_shape, cls_name)
     with open(os.path.join(kitti_output_dir, "%06d.txt" % sample_id), "w") as f:
-        for l in lines:
-            print(l, file=f)
-    return len(lines)
+        f.write(text)
+    return text.count("\n")
 
 
 def detections_to_annos(table, counts, source, cls_name="Car"):

@@ -129,7 +129,9 @@ class KittiSource:
 
     raw_in_lidar_frame, raw_needs_image_filter = True, True
 
-    def load(self, idx):
+    def rect_and_flags(self, idx):
+        """-> (raw velodyne (n,4), rectified coordinates (n,3) f32, validity flags (n,) bool, calib, image shape): the part of
+        get_rpn_sample in front of the sampler (kitti_rcnn_dataset.py:252-269)."""
         cfg = self.cfg
         calib = Calibration(os.path.join(self.dir, "calib", "%06d.txt" % idx))
         lidar = np.fromfile(os.path.join(self.dir, "velodyne", "%06d.bin" % idx), dtype=np.float32).reshape(-1, 4)
@@ -137,13 +139,23 @@ class KittiSource:
         pts_rect = calib.lidar_to_rect(lidar[:, 0:3])
         pts_img, depth = calib.rect_to_img(pts_rect)
         scope = cfg.PC_AREA_SCOPE if cfg.PC_REDUCE_BY_RANGE else None
-        keep = valid_flag(pts_rect, pts_img, depth, shape, scope)
+        return lidar, pts_rect, valid_flag(pts_rect, pts_img, depth, shape, scope), calib, shape
+
+    def load(self, idx, rng=None):
+        """``rng``: the random stream of the sampler.  Default: a LEGACY ``np.random.RandomState(seed + idx)`` per scene -- the
+        reference samples from the global legacy stream (np.random.choice / shuffle, seeded once with 1024 at
+        tools/eval_rcnn.py:26), so with the same generator type and the same call sequence (synth.subsample_rpn) the chosen
+        rows are the reference's, bit for bit, given the same stream state (pinned by tests/golden g11 -- both per-scene
+        seeding and one stream consumed in scene order, the single-process loader's behaviour); per-scene seeding keeps the
+        result independent of which loader process serves which scene."""
+        cfg = self.cfg
+        lidar, pts_rect, keep, calib, shape = self.rect_and_flags(idx)
         pts_rect = pts_rect[keep][:, 0:3]
         if cfg.RPN.USE_INTENSITY:
             # pts_input = xyz | intensity - 0.5 (kitti_rcnn_dataset.py:274-275, 321-338); the sampler picks rows, so the column rides along
             pts_rect = np.concatenate([pts_rect, lidar[keep][:, 3:4] - np.float32(0.5)], axis=1)
         pts = synth.subsample_rpn(pts_rect, cfg.RPN.NUM_POINTS, self.npoints_faraway,
-                                  rng=np.random.default_rng(self.seed + idx))
+                                  rng=rng if rng is not None else np.random.RandomState(self.seed + idx))
         return np.ascontiguousarray(pts, dtype=np.float32), calib, shape
 
 
@@ -236,6 +248,36 @@ class DeviceInputStage:
                       int(self.npoints_faraway), seeds.data_ptr(), out.data_ptr(), stats.data_ptr(),
                       _lib.ptr(choice), _lib.current_stream(out))
         return (out, stats, choice) if return_choice else (out, stats)
+
+
+def device_valid_flags(cfg, device, raws, calibs, shapes, lidar_frame=True, image_filter=True, far_depth=40.0):
+    """get_valid_flag + lidar_to_rect on the device for a list of raw clouds (csrc/input_stage.hip ``prcnn_valid_flags``):
+    -> (cls (B, n_max) uint8 device tensor: 0 invalid / 1 near / 2 far, rect (B, n_max, 3) f32).  Bitwise the reference's
+    numpy results (tests/golden g11)."""
+    import ctypes
+    import torch
+    from . import _lib
+    dev = torch.device(device)
+    B, stride = len(raws), raws[0].shape[1]
+    n_max = max(1, max(r.shape[0] for r in raws))
+    host = np.zeros((B, n_max, stride), dtype=np.float32)
+    for i, r in enumerate(raws):
+        host[i, :r.shape[0]] = r
+    raw = torch.from_numpy(host).to(dev)
+    cal = torch.from_numpy(np.stack([DeviceInputStage.pack_calib(c, s) for c, s in zip(calibs, shapes)], 0)).to(dev)
+    counts = torch.tensor([r.shape[0] for r in raws], dtype=torch.int32, device=dev)
+    cls = torch.empty((B, n_max), dtype=torch.uint8, device=dev)
+    rect = torch.empty((B, n_max, 3), dtype=torch.float32, device=dev)
+    scope = None
+    if cfg.PC_REDUCE_BY_RANGE:
+        (x0, x1), (y0, y1), (z0, z1) = cfg.PC_AREA_SCOPE
+        keep = (ctypes.c_float * 6)(x0, x1, y0, y1, z0, z1)
+        scope = ctypes.cast(keep, ctypes.c_void_p)
+    with torch.cuda.device(dev):
+        _lib.call("prcnn_valid_flags", B, n_max, stride, int(bool(lidar_frame)), int(bool(image_filter)), counts.data_ptr(),
+                  raw.data_ptr(), cal.data_ptr(), scope, float(far_depth), rect.data_ptr(), cls.data_ptr(), _lib.current_stream(cls))
+        torch.cuda.current_stream(dev).synchronize()          # the scope upload reads a host buffer of this frame
+    return cls, rect
 
 
 class SyntheticSource:

@@ -446,10 +446,19 @@ int prcnn_rotate_iou_eval_segmented(int nseg, long long total, const long long *
  * seeds (b) u64 DEVICE.  -> out (b,npoints,3), stats (b,3) i32 = #valid, #near, #far, choice (b,npoints) i32 = raw
  * index of each output point (may be NULL).  npoints <= 16384.
  * The subset is random (distinct-key selection + key-sorted shuffle): same distribution as the reference's
- * np.random.choice / shuffle, not the same draws. */
+ * np.random.choice / shuffle, not the same draws; transform and filter are bitwise the reference's (see prcnn_valid_flags). */
 int prcnn_input_stage(int b, int n_max, int stride, int lidar_frame, int image_filter, const int *counts,
                       const float *raw, const float *calib, const float *scope_host, int npoints, float far_depth,
                       int npoints_faraway, const unsigned long long *seeds, float *out, int *stats, int *choice,
+                      void *stream);
+
+/* get_valid_flag (kitti_rcnn_dataset.py:201-222) + Calibration.lidar_to_rect / rect_to_img (calibration.py:51-71) for whole
+ * batches -- the front half of prcnn_input_stage as an operator, same arguments.  -> cls (b,n_max) u8: 0 = not valid,
+ * 1 = valid and z < far_depth, 2 = valid beyond (rows >= counts[b]: 0); rect (b,n_max,3) f32 rectified coordinates (may be
+ * NULL).  Bit-identical to the reference's numpy results: float32 np.dot is a chain of fused multiply-adds over the inner
+ * index, which the kernel reproduces (tests/golden g11, recorded by running the reference's code). */
+int prcnn_valid_flags(int b, int n_max, int stride, int lidar_frame, int image_filter, const int *counts, const float *raw,
+                      const float *calib, const float *scope_host, float far_depth, float *rect, unsigned char *cls,
                       void *stream);
 
 /* ---- evaluate/eval2.py: host-side matching of the AP evaluator (HOST pointers, f64 / i64) ---- */

@@ -191,10 +191,10 @@ def g8(intensity=False):
 FULL_SEED = 1204            # g12: weights (helpers.seeded_state_dict) and scenes
 
 
-def full_scenes(kind):
+def full_scenes(kind, seed0):
     """g12's input batches (B = 2, N = 16384): kind "u" = SURVEY 8d's uniform scene, "l" = LiDAR-shaped sweeps (synth.lidar_scene)."""
     S = importlib.import_module("3d_adapt_auto_driving_amd.synth")
-    return np.stack([(S.scene if kind == "u" else S.lidar_scene)(FULL_SEED + i, 16384) for i in range(2)], 0)
+    return np.stack([(S.scene if kind == "u" else S.lidar_scene)(seed0 + i, 16384) for i in range(2)], 0)
 
 
 def g12(kind):
@@ -208,11 +208,12 @@ def g12(kind):
     model, cfg = H.reference_model()
     sd, checksum = helpers.seeded_state_dict(model.state_dict(), FULL_SEED)
     model.load_state_dict(sd)
-    pts = torch.from_numpy(full_scenes(kind))
     hooks, cap = [], {}
     for i, m in enumerate(model.rcnn_net.SA_modules):
         hooks.append(m.register_forward_hook(lambda mod, inp, out, i=i: cap.__setitem__("sa%d" % i, (inp[0].clone(), out[0].clone() if out[0] is not None else None))))
     t0 = time.time()
+    seed0 = FULL_SEED
+    pts = torch.from_numpy(full_scenes(kind, seed0))
     with torch.no_grad():
         ret = model({"pts_input": pts})
         # centre the segmentation threshold (sigmoid > 0.3 <=> raw > -0.8473) on the 70th percentile of the scores: ~30 % foreground
@@ -220,7 +221,11 @@ def g12(kind):
         model.rpn.rpn_cls_layer[-1].conv.bias += shift
         cls_bias = model.rpn.rpn_cls_layer[-1].conv.bias.detach().clone().numpy()
         ret = model({"pts_input": pts})
-    print("g12%s: two reference passes in %.1f s" % (kind, time.time() - t0))
+    # NOTE for the tests: with 100 RoIs per scene some neighbours in the score order are closer than f32 rounding of the MLPs
+    # (printed below); their ORDER is not defined by the reference either (cuDNN there, MKL here), so tests compare RoI rows up to
+    # swaps inside groups of RoIs whose reference scores agree within the tolerance.
+    print("g12%s: min gap between neighbouring RoI scores %.3g" % (kind, np.abs(np.diff(ret["roi_scores_raw"].numpy(), axis=1)).min()))
+    print("g12%s: reference passes in %.1f s" % (kind, time.time() - t0))
     for h in hooks:
         h.remove()
     from lib.utils.bbox_transform import decode_bbox_target
@@ -250,7 +255,7 @@ def g12(kind):
         final_num[k] = n
     sub = slice(0, 16384, 64)
     pooled_xyz = cap["sa0"][0]                                       # (200, 512, 3) canonical RoI clouds
-    np.savez_compressed(os.path.join(HERE, "g12%s_e2e_full_ref.npz" % kind), seed=np.int64(FULL_SEED), weights_checksum=np.float64(checksum),
+    np.savez_compressed(os.path.join(HERE, "g12%s_e2e_full_ref.npz" % kind), seed=np.int64(FULL_SEED), scene_seed0=np.int64(seed0), weights_checksum=np.float64(checksum),
                         rpn_cls_bias=cls_bias, rois=ret["rois"].numpy(), roi_scores_raw=ret["roi_scores_raw"].numpy(),
                         rpn_cls=ret["rpn_cls"].numpy()[..., 0], rpn_reg_sub=ret["rpn_reg"].numpy()[:, sub],
                         backbone_features_sub=ret["backbone_features"].numpy()[:, :, sub],
@@ -262,6 +267,107 @@ def g12(kind):
     print("g12%s: checksum %.6f, final_num %s, seg fg %s, nonzero rois %s, rcnn score range %.3f..%.3f" % (
         kind, checksum, final_num.tolist(), ret["seg_result"].sum(1).tolist(), (ret["rois"].abs().sum(-1) > 0).sum(1).tolist(),
         float(rcnn_cls.min()), float(rcnn_cls.max())))
+
+
+KITTI_SEED = 1100           # g11: fake KITTI tree (helpers.write_fake_kitti_tree) and writer boxes
+
+
+def g11():
+    """Reference-EXECUTED pins of the host input stage and of the result writer (VERDICT r3 task 8): on a fake KITTI tree
+    (helpers.write_fake_kitti_tree: five scenes, one per branch of the sampler) the reference's own
+    KittiRCNNDataset.get_rpn_sample (kitti_rcnn_dataset.py:249-342: Calibration.lidar_to_rect / rect_to_img, get_valid_flag :201,
+    the near / far sampler on the legacy ``np.random`` stream) in TEST mode, and the reference's save_kitti_format
+    (tools/eval_rcnn.py:76-101) with its Calibration (calibration.py:107-125).  The tree regenerates from the seed; the fixture
+    holds the reference's OUTPUTS: per scene the valid flags, the chosen rows (recovered from pts_rect: every valid row is
+    unique), pts_input, and the result text."""
+    import logging
+    import tempfile
+    import types
+    H.install()
+    if "tensorboardX" not in sys.modules:            # tools/eval_rcnn.py imports it for the checkpoint-polling loop (unused here)
+        try:
+            import tensorboardX  # noqa: F401
+        except ImportError:
+            tb = types.ModuleType("tensorboardX"); tb.SummaryWriter = None
+            sys.modules["tensorboardX"] = tb
+    argv, sys.argv = sys.argv, ["eval_rcnn.py", "--eval_mode", "rcnn"]     # the reference parses its command line at import
+    sys.path.append(os.path.join(H.REF, "tools"))
+    try:
+        ref_eval = importlib.import_module("eval_rcnn")
+    finally:
+        sys.argv = argv
+    assert ref_eval.__file__.startswith("/root/reference/")
+    from lib.config import cfg, cfg_from_file
+    cfg_from_file(os.path.join(H.REF, "tools", "cfgs", "default.yaml"))
+    cfg.RCNN.ENABLED = True; cfg.RPN.ENABLED = cfg.RPN.FIXED = True
+    from lib.datasets.kitti_rcnn_dataset import KittiRCNNDataset
+    from lib.utils.calibration import Calibration
+    out = {"seed": np.int64(KITTI_SEED)}
+    with tempfile.TemporaryDirectory() as tmp:
+        ids = helpers.write_fake_kitti_tree(tmp, KITTI_SEED)
+        ds = KittiRCNNDataset(root_dir=tmp, npoints=cfg.RPN.NUM_POINTS, split="val", mode="TEST", random_select=True,
+                              classes=cfg.CLASSES, logger=logging.getLogger("g11"), npoints_faraway=4000)
+        out["ids"] = np.array(ids, np.int64)
+        branches = []
+        for pos, sid in enumerate(ids):
+            calib = ds.get_calib(sid)
+            lidar = ds.get_lidar(sid)
+            shape = ds.get_image_shape(sid)
+            rect = calib.lidar_to_rect(lidar[:, 0:3])
+            img, depth = calib.rect_to_img(rect)
+            flag = ds.get_valid_flag(rect, img, depth, shape)
+            for variant, seed_fn in (("", lambda: np.random.seed(1024 + sid)),):
+                seed_fn()
+                sample = ds.get_rpn_sample(pos)
+            pin = sample["pts_input"]
+            assert sample["sample_id"] == sid and pin.shape == (cfg.RPN.NUM_POINTS, 3) and pin.dtype == np.float32
+            valid_rows = rect[flag][:, 0:3]
+            # recover the chosen row of every output point (rows of a sweep are unique)
+            order = np.lexsort(valid_rows.T[::-1])
+            sorted_rows = valid_rows[order]
+            keyv = np.ascontiguousarray(sorted_rows).view([("", np.float32)] * 3).ravel()
+            keyp = np.ascontiguousarray(pin).view([("", np.float32)] * 3).ravel()
+            where = np.searchsorted(keyv, keyp)
+            choice = order[where]
+            assert np.array_equal(valid_rows[choice], pin)
+            nv, nnear = int(flag.sum()), int((valid_rows[:, 2] < 40.0).sum())
+            branches.append((helpers.KITTI_CASES[pos], nv, nnear, nv - nnear))
+            out["lidar_sum_%d" % sid] = np.float64(lidar.astype(np.float64).sum())
+            out["shape_%d" % sid] = np.array(shape[:2], np.int64)
+            out["valid_%d" % sid] = np.packbits(flag)
+            out["n_raw_%d" % sid] = np.int64(len(lidar))
+            out["choice_%d" % sid] = choice.astype(np.int32)
+            out["rect_sub_%d" % sid] = rect[::97].astype(np.float32)
+            out["img_sub_%d" % sid] = img[::97].astype(np.float32)
+            out["depth_sub_%d" % sid] = depth[::97].astype(np.float32)
+            out["pts_input_sum_%d" % sid] = np.float64(pin.astype(np.float64).sum())
+        # the sequential stream of a single-process loader: np.random.seed(1024) as tools/eval_rcnn.py:26 sets it, scenes in order
+        np.random.seed(1024)
+        seq = [ds.get_rpn_sample(pos)["pts_input"] for pos in range(len(ids))]
+        out["seq_pts_input_sum"] = np.array([p.astype(np.float64).sum() for p in seq])
+        out["seq_first_rows"] = np.stack([p[:8] for p in seq], 0)
+        print("g11 sampler branches (case, valid, near, far):", branches)
+        b = {c: (nv, nn, nf) for c, nv, nn, nf in branches}
+        assert b["normal"][0] > 16384 and b["normal"][2] <= 4000 and b["normal"][1] >= 16384 - b["normal"][2]
+        assert b["many_far"][2] > 4000 and b["many_far"][1] >= 12384
+        assert 8192 < b["pad_without_replacement"][0] < 16384 and b["pad_with_replacement"][0] < 8192
+        assert b["near_short"][0] > 16384 and b["near_short"][1] < 16384 - min(4000, b["near_short"][2])
+        # the writer
+        boxes, scores = helpers.writer_boxes(KITTI_SEED + 50)
+        texts = []
+        for sid in ids[:2]:
+            calib = Calibration(os.path.join(tmp, "KITTI", "object", "training", "calib", "%06d.txt" % sid))
+            shape = ds.get_image_shape(sid)
+            os.makedirs(os.path.join(tmp, "res"), exist_ok=True)
+            ref_eval.save_kitti_format(sid, calib, boxes.copy(), os.path.join(tmp, "res"), scores.copy(), shape)
+            texts.append(open(os.path.join(tmp, "res", "%06d.txt" % sid)).read())
+        ref_eval.save_kitti_format(999, calib, boxes[:0].copy(), os.path.join(tmp, "res"), scores[:0].copy(), shape)
+        assert open(os.path.join(tmp, "res", "000999.txt")).read() == ""
+        out["writer_text"] = np.array(texts)
+        out["writer_lines"] = np.array([t.count("\n") for t in texts])
+        print("g11 writer: %d boxes -> %s lines" % (len(boxes), out["writer_lines"].tolist()))
+        assert 0 < out["writer_lines"].min() < len(boxes)
+    np.savez_compressed(os.path.join(HERE, "g11_input_writer_ref.npz"), **out)
 
 
 def synth_label_sets(n_img=60, seed=2024):
@@ -494,9 +600,9 @@ def g_ops():
 
 if __name__ == "__main__":
     assert H.available(), "/root/reference is not mounted: fixtures can only be regenerated in the build container"
-    todo = sys.argv[1:] or ["g5", "g7", "g_ops", "g8", "g8i", "g9", "g10", "g12u", "g12l"]      # e.g. ``make_golden.py g9 g10``
+    todo = sys.argv[1:] or ["g5", "g7", "g_ops", "g8", "g8i", "g9", "g10", "g11", "g12u", "g12l"]      # e.g. ``make_golden.py g9 g10``
     for name in todo:
-        {"g5": g5, "g7": g7, "g_ops": g_ops, "g8": g8, "g8i": lambda: g8(intensity=True), "g9": g9, "g10": g10, "g12u": lambda: g12("u"), "g12l": lambda: g12("l")}[name]()
+        {"g5": g5, "g7": g7, "g_ops": g_ops, "g8": g8, "g8i": lambda: g8(intensity=True), "g9": g9, "g10": g10, "g11": g11, "g12u": lambda: g12("u"), "g12l": lambda: g12("l")}[name]()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

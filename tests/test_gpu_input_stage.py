@@ -118,11 +118,15 @@ def test_transform_and_filter_match_host_stage():
     img, depth = calib.rect_to_img(rect)
     flag = K.valid_flag(rect, img, depth, shape, cfg.PC_AREA_SCOPE if cfg.PC_REDUCE_BY_RANGE else None)
     n_host = int(flag.sum())
-    assert abs(int(stats[0]) - n_host) <= max(3, n_host // 2000), (stats, n_host)
-    assert flag[choice].mean() > 0.999
-    assert np.abs(out - rect[choice]).max() < 2e-4
+    # round 4: the device reproduces numpy's float32 arithmetic (fma chains), so the two stages agree exactly wherever this
+    # host's BLAS computes np.dot the way the reference fixture's host did (g11 pins the device to the reference-made data;
+    # here a handful of borderline roundings are tolerated in case another CPU's sgemm kernel accumulates differently)
+    assert abs(int(stats[0]) - n_host) <= 3, (stats, n_host)
+    assert flag[choice].mean() > 0.9995
+    assert np.abs(out - rect[choice]).max() < 2e-5
+    print("device vs host numpy: valid %d / %d, max |d rect| %.3g" % (int(stats[0]), n_host, float(np.abs(out - rect[choice]).max())))
     far_host = int((flag & (rect[:, 2] >= 40.0)).sum())
-    assert abs(int(stats[2]) - far_host) <= max(3, far_host // 500)
+    assert abs(int(stats[2]) - far_host) <= 3
     N = cfg.RPN.NUM_POINTS
     assert n_host > N
     far_keep = min(int(stats[2]), 4000)
@@ -134,6 +138,50 @@ def test_transform_and_filter_match_host_stage():
         cnt = np.bincount(choice, minlength=n)
         near_idx = np.where(flag & (rect[:, 2] < 40.0))[0]
         assert (cnt[near_idx] >= 1).mean() > 0.999 and len(np.unique(choice)) >= n_near + far_keep - 3
+
+
+def test_device_filter_equals_reference_executed_flags(tmp_path):
+    """g11: the reference's OWN lidar_to_rect / rect_to_img / get_valid_flag (calibration.py:51-71, kitti_rcnn_dataset.py:201-222)
+    were run on the five scenes of the fake KITTI tree (regenerated here from the seed).  The device stage must produce the
+    SAME flag for every raw point and the same rectified coordinates bit for bit (float32 np.dot = fma chains over the inner
+    index, reproduced in csrc/input_stage.hip), and its sampler must take each of the reference sampler's branches with the
+    reference's counts (all far points up to the cap / every point once + copies / copies with replacement)."""
+    import os
+    import helpers
+    K = pkg("kitti_io")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_input_writer_ref.npz"))
+    cfg, st, _ = stage()
+    ids = helpers.write_fake_kitti_tree(str(tmp_path), int(g["seed"]), with_images=False)
+    src = K.KittiSource(str(tmp_path), cfg, split="val")
+    raws, calibs, shapes = [], [], []
+    for sid in ids:
+        lidar, calib, _ = src.load_raw(sid)
+        assert abs(float(lidar.astype(np.float64).sum()) - float(g["lidar_sum_%d" % sid])) < 1e-9, "the regenerated tree differs"
+        raws.append(lidar); calibs.append(calib); shapes.append(tuple(g["shape_%d" % sid]) + (3,))
+    cls, rect = K.device_valid_flags(cfg, DEV, raws, calibs, shapes)
+    cls, rect = cls.cpu().numpy(), rect.cpu().numpy()
+    out, stats, choice = st(raws, calibs, shapes, ids, lidar_frame=True, image_filter=True, return_choice=True)
+    torch.cuda.synchronize()
+    out, stats, choice = out.cpu().numpy(), stats.cpu().numpy(), choice.cpu().numpy()
+    N = cfg.RPN.NUM_POINTS
+    for b, sid in enumerate(ids):
+        n = len(raws[b])
+        want = np.unpackbits(g["valid_%d" % sid])[:n].astype(bool)
+        assert np.array_equal(cls[b, :n] > 0, want), (sid, int(((cls[b, :n] > 0) != want).sum()))
+        assert (cls[b, n:] == 0).all()
+        assert np.array_equal(rect[b, :n][::97], g["rect_sub_%d" % sid]), sid             # the reference's rectified coordinates
+        z = rect[b, :n, 2]
+        assert np.array_equal(cls[b, :n] == 2, want & (z >= 40.0))
+        nv, nf = int(want.sum()), int((want & (z >= 40.0)).sum())
+        assert stats[b].tolist() == [nv, nv - nf, nf]
+        ch = choice[b]
+        assert want[ch].all() and np.array_equal(out[b], rect[b, ch])
+        # the reference's own choice on this scene and the device's: the same branch, the same class counts
+        ref_choice = np.nonzero(want)[0][g["choice_%d" % sid]]
+        assert int((z[ch] >= 40.0).sum()) == int((z[ref_choice] >= 40.0).sum())
+        assert len(np.unique(ch)) == len(np.unique(ref_choice)) or nv - nf < N - min(nf, 4000)   # (copies with replacement: random)
+        if nv <= N:
+            assert len(np.unique(ch)) == nv == len(np.unique(ref_choice))                 # every valid point at least once
 
 
 def test_eval_scenes_with_device_input_stage():

@@ -161,8 +161,8 @@ def full_model(device="cpu", kind="u"):
     assert abs(checksum - float(g["weights_checksum"])) < 1e-6 * checksum, "seeded weights differ from the ones the fixture was made with"
     sd["rpn.rpn_cls_layer.2.conv.bias"] = torch.from_numpy(g["rpn_cls_bias"])
     model.load_state_dict(sd)          # strict: the key tree must equal the reference's
-    seed = int(g["seed"])
-    pts = np.stack([(S.scene if kind == "u" else S.lidar_scene)(seed + i, 16384) for i in range(2)], 0)
+    seed0 = int(g["scene_seed0"])
+    pts = np.stack([(S.scene if kind == "u" else S.lidar_scene)(seed0 + i, 16384) for i in range(2)], 0)
     return model.to(device).eval(), cfg, g, pts
 
 
@@ -294,6 +294,48 @@ def test_kitti_writer_format(tmp_path):
     assert f[0] == "Car" and len(f) == 16 and f[-1] == "1.5000" and f[11:14] == ["1.0000", "1.6000", "20.0000"]
     E.save_kitti_format(8, S.SyntheticCalib(), boxes[:0], str(tmp_path), np.zeros(0), (375, 1242))
     assert open(tmp_path / "000008.txt").read() == ""
+
+
+def test_writer_and_host_input_stage_match_reference_executed_fixture(tmp_path):
+    """g11 (tests/golden/make_golden.py): the reference's own KittiRCNNDataset.get_rpn_sample / Calibration / get_valid_flag
+    (kitti_rcnn_dataset.py:201-342, calibration.py:51-125) and save_kitti_format (tools/eval_rcnn.py:76-101) were RUN on a fake
+    KITTI tree (one scene per sampler branch) that regenerates here from the seed.  This build's host stage must give the same
+    validity flags, the same chosen rows (legacy np.random stream, per-scene seeding and the sequential single-process stream)
+    and the same pts_input bit for bit; the writer the same text, character for character."""
+    import helpers
+    K, E = pkg("kitti_io"), pkg("eval_rcnn")
+    g = load("g11_input_writer_ref.npz")
+    cfg = pkg("config").default_eval_cfg()
+    ids = helpers.write_fake_kitti_tree(str(tmp_path), int(g["seed"]))
+    assert ids == g["ids"].tolist()
+    src = K.KittiSource(str(tmp_path), cfg, split="val", npoints_faraway=4000, seed=1024)
+    assert src.ids == ids
+    for sid in ids:
+        lidar, rect, flag, calib, shape = src.rect_and_flags(sid)
+        assert abs(float(lidar.astype(np.float64).sum()) - float(g["lidar_sum_%d" % sid])) < 1e-9, "the regenerated tree differs"
+        assert tuple(shape[:2]) == tuple(g["shape_%d" % sid]) and len(lidar) == int(g["n_raw_%d" % sid])
+        assert rect.dtype == np.float32 and np.array_equal(rect[::97], g["rect_sub_%d" % sid])
+        img, depth = calib.rect_to_img(rect)
+        assert np.array_equal(img[::97].astype(np.float32), g["img_sub_%d" % sid])
+        assert np.array_equal(depth[::97].astype(np.float32), g["depth_sub_%d" % sid])
+        want_flag = np.unpackbits(g["valid_%d" % sid])[:len(lidar)].astype(bool)
+        assert np.array_equal(flag, want_flag)
+        pts, _, _ = src.load(sid)
+        want = rect[want_flag][:, 0:3][g["choice_%d" % sid]]
+        assert pts.dtype == np.float32 and np.array_equal(pts, want)
+        assert float(pts.astype(np.float64).sum()) == float(g["pts_input_sum_%d" % sid])
+    stream = np.random.RandomState(1024)                               # tools/eval_rcnn.py:26, one loader process, scenes in order
+    seq = [src.load(sid, rng=stream)[0] for sid in ids]
+    assert np.array_equal(np.array([p.astype(np.float64).sum() for p in seq]), g["seq_pts_input_sum"])
+    assert np.array_equal(np.stack([p[:8] for p in seq], 0), g["seq_first_rows"])
+    # the writer: 96 boxes incl. clipped / dropped / x = 0 / x < 0 cases, two calibrations and image sizes
+    boxes, scores = helpers.writer_boxes(int(g["seed"]) + 50)
+    for k, sid in enumerate(ids[:2]):
+        calib, shape = src.calib_and_shape(sid)
+        n = E.save_kitti_format(sid, calib, boxes.copy(), str(tmp_path), scores.copy(), shape)
+        text = open(tmp_path / ("%06d.txt" % sid)).read()
+        assert text == str(g["writer_text"][k]) and n == int(g["writer_lines"][k]) < len(boxes)
+        assert E.kitti_result_lines(calib, boxes, scores, shape) == text.split("\n")[:-1]
 
 
 def test_subsample_rpn_semantics():
