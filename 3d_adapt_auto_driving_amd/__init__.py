@@ -22,12 +22,33 @@ __version__ = "0.1.0"
 # null stream between two replays reproduce it; the same launches on another stream do not; with the switch at 0 nothing happens).
 # The switch is read when the HIP runtime initialises, so it is set here unless the runtime is already up -- in which case graph
 # replay is declared unsafe and eval_rcnn.make_runner() hands out the eager runner instead (same results, 1.2 ms of host time per step).
-GRAPH_REPLAY_SAFE = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
-if "DEBUG_CLR_GRAPH_PACKET_CAPTURE" not in _os.environ:           # (an explicit setting of the user is left alone)
+# NOTE: a preset value of "0" is trusted to have been in the environment when the runtime started; setting it after a HIP call
+# (os.environ[...] = "0" behind torch.cuda.is_available()) defeats the check -- export it in the shell or set it before importing torch.
+# "Already up" is NOT torch.cuda.is_initialized(): torch.cuda.is_available() / device_count() start the HIP runtime --
+# which reads its DEBUG_CLR_* switches on its first call -- without touching torch's lazy-init flag.  What the runtime cannot do
+# without is the kernel driver's device node: a process whose HIP / HSA runtime has started holds an open descriptor of /dev/kfd.
+def _hip_runtime_started():
+    try:
+        for fd in _os.listdir("/proc/self/fd"):
+            try:
+                if _os.readlink("/proc/self/fd/" + fd) == "/dev/kfd":
+                    return True
+            except OSError:
+                pass
+    except OSError:
+        pass
     import sys as _sys
     _torch = _sys.modules.get("torch")
-    if _torch is None or not _torch.cuda.is_initialized():
-        _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
-        GRAPH_REPLAY_SAFE = True
+    return bool(_torch is not None and _torch.cuda.is_initialized())
+
+
+_preset = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")
+if _preset is not None:                                           # an explicit setting (of the user, or of conftest / bench.py /
+    GRAPH_REPLAY_SAFE = _preset == "0"                            # __graft_entry__ before anything else ran) is left alone
+elif _hip_runtime_started():
+    GRAPH_REPLAY_SAFE = False                                     # too late: the switch would not be read any more
+else:
+    _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+    GRAPH_REPLAY_SAFE = True
 if _os.environ.get("PRCNN_GRAPHS_FORCE") == "1":                  # profiles/graph_fault_probe.py: replay although it is unsafe
     GRAPH_REPLAY_SAFE = True

@@ -82,8 +82,9 @@ static int g_scratch_n = 0;
 static unsigned g_scratch_rr = 0;
 static std::mutex g_scratch_mu;
 
-char *scratch_for(hipStream_t st, size_t bytes, int slot)
+char *scratch_for(hipStream_t st, size_t bytes, int slot, bool *fresh)
 {
+    if (fresh) *fresh = false;
     // keyed by DEVICE as well: the default stream handle (0) is the same on every GPU of a process
     const int dev = current_device();
     std::lock_guard<std::mutex> lock(g_scratch_mu);
@@ -94,8 +95,18 @@ char *scratch_for(hipStream_t st, size_t bytes, int slot)
         if (g_scratch_n == SCRATCH_ENTRIES) {
             // table full: take over the entry of the least recently created pair after draining the device
             // (its buffer may still be read by work queued on its old stream)
+            // -- never one that a captured hipGraph points into: its buffer would be shared with another stream and freed on growth
+            // under the graph's next replay
             (void)hipDeviceSynchronize();
-            s = &g_scratch[g_scratch_rr++ % SCRATCH_ENTRIES];
+            for (int tries = 0; tries < SCRATCH_ENTRIES; ++tries) {
+                Scratch *c = &g_scratch[g_scratch_rr++ % SCRATCH_ENTRIES];
+                if (!c->captured) { s = c; break; }
+            }
+            if (!s) {
+                snprintf(g_note, sizeof(g_note), "scratch: all %d (stream, slot) entries are held by captured graphs", SCRATCH_ENTRIES);
+                return nullptr;
+            }
+            if (fresh) *fresh = true;              // the new owner must not trust what the previous one left in the buffer
             if (s->device != dev && s->ptr) {      // the old buffer lives on another device: free it there
                 (void)hipSetDevice(s->device);
                 (void)hipDeviceSynchronize();
@@ -126,6 +137,7 @@ char *scratch_for(hipStream_t st, size_t bytes, int slot)
         s->ptr = nullptr; s->bytes = 0; s->captured = false;
         if (hipMalloc((void **)&s->ptr, bytes) != hipSuccess) return nullptr;
         s->bytes = bytes;
+        if (fresh) *fresh = true;
     }
     return s->ptr;
 }

@@ -27,7 +27,7 @@ int ensure_dynamic_lds(const void *kernel, size_t bytes, const char *what);
 
 // cached device scratch, one per (device, stream) (grown on demand; hipMalloc only on growth).  `slot` separates
 // independent users (0: ball-query grid, 1: FPS ordering).
-char *scratch_for(hipStream_t st, size_t bytes, int slot = 0);
+char *scratch_for(hipStream_t st, size_t bytes, int slot = 0, bool *fresh = nullptr);   // *fresh: the buffer is new (or changed owner): contents undefined
 
 // Tile tickets of the persistent kernels: a PAIR of words per launch, [0] the draw counter, [1] the workgroups that have drawn
 // their last ticket.  Thread 0 of every workgroup calls this once, after its last draw (on every exit path): the last one to arrive

@@ -420,10 +420,12 @@ extern "C" int prcnn_rpn_tail_lin(int b, int n, int m, const float *G, const int
     a.ticket = next_ticket((hipStream_t)stream);
     if (!a.ticket) { set_error("rpn_tail_lin: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
     static const int xcd_split = !(getenv("PRCNN_TAIL_XCD") && atoi(getenv("PRCNN_TAIL_XCD")) == 0);
-    a.xcd_split = xcd_split;
     const long tiles = (rows + RT_ROWS - 1) / RT_ROWS;
     const long cap = mfma_grid_cap() < 256 ? mfma_grid_cap() : 256;
     const long grid = tiles < cap ? tiles : cap;
+    // a workgroup draws only from partition blockIdx.x & 7 (no stealing): every non-empty partition needs a workgroup of its own --
+    // with fewer than 8 workgroups for 8 or more tiles (PRCNN_MFMA_GRID < 8) the tiles come from one counter instead
+    a.xcd_split = xcd_split && (grid >= 8 || grid == tiles);
     hipLaunchKernelGGL(rpn_tail_lin_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("rpn_tail_lin");
 }

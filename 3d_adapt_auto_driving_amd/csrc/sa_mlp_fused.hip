@@ -311,8 +311,8 @@ __global__ __launch_bounds__(512, 1) void sa_mlp_fused256_kernel(
 
 namespace prcnn {
 // Tile-ticket words: a ring of 128 records of 16 words per (device, stream) ([0] draw counter, [1] workgroups done, [2..9] per-XCD draw
-// counters of the kernels that partition their tiles by XCD, common.hpp XcdTickets) (slot 6 of the scratch cache), zeroed once when the stream's
-// ring is created.  One launch uses one pair and leaves it at zero (common.hpp ticket_release: the launch's last workgroup resets it),
+// counters of the kernels that partition their tiles by XCD, common.hpp XcdTickets) (slot 6 of the scratch cache), zeroed when the stream's
+// ring is created (scratch_for's `fresh` flag).  One launch uses one pair and leaves it at zero (common.hpp ticket_release: the launch's last workgroup resets it),
 // so nothing is filled in front of a launch -- eagerly or inside a captured hipGraph, whose replays find the pair clean as well.
 // (Round 1 zeroed one word per launch: a 5 us fill kernel in front of each ticketed launch; round 2 one memset per 256 launches
 // and, under capture, a memset node per launch.)  Launches of other streams never touch the ring.
@@ -321,14 +321,17 @@ static std::mutex g_ticket_mu;
 static std::map<std::pair<int, hipStream_t>, unsigned int> g_ticket_next;
 unsigned int *next_ticket(hipStream_t st)
 {
-    unsigned int *ring = reinterpret_cast<unsigned int *>(scratch_for(st, 16 * TICKET_RING * sizeof(unsigned int), 6));
+    bool fresh = false;
+    unsigned int *ring = reinterpret_cast<unsigned int *>(scratch_for(st, 16 * TICKET_RING * sizeof(unsigned int), 6, &fresh));
     if (!ring) return nullptr;                 // (a first use under capture ends here: the stream needs its warm-up)
     unsigned int k;
     {
         std::lock_guard<std::mutex> lock(g_ticket_mu);
         k = g_ticket_next[std::make_pair(current_device(), st)]++;
     }
-    if (k == 0 && hipMemsetAsync(ring, 0, 16 * TICKET_RING * sizeof(unsigned int), st) != hipSuccess) return nullptr;
+    // zeroed whenever the ring's memory is new to this (device, stream) -- first use, or an entry of the scratch table that changed
+    // owner -- not keyed on the launch counter (a ring re-created after an eviction was never zeroed)
+    if (fresh && hipMemsetAsync(ring, 0, 16 * TICKET_RING * sizeof(unsigned int), st) != hipSuccess) return nullptr;
     return ring + 16 * (k % TICKET_RING);
 }
 }  // namespace prcnn

@@ -587,7 +587,11 @@ class GraphedRunner:
         self.feat = have["feat"]
         # depth / group groups ahead + the one being consumed.  One more (the first version) costs 5.5 % at K = 96 -- 5100-5160 instead of
         # 5406 scenes/s, the eager runner's figure: a fifth of the slots' 23 GB more to walk through per rotation; one less stalls (2765)
-        self.n_slots = int(os.environ.get("PRCNN_GRAPH_SLOTS", "0")) or max(2, -(-self.depth // self.group) + 1)
+        # never fewer than 2: the slot of the batch in flight must not be the one the next chain is written into
+        want = int(os.environ.get("PRCNN_GRAPH_SLOTS", "0"))
+        if want == 1 or want < 0:
+            raise ValueError("PRCNN_GRAPH_SLOTS=%d: the graphed runner needs at least 2 group slots" % want)
+        self.n_slots = want or max(2, -(-self.depth // self.group) + 1)
         self.shape = None
         self._assigned = []          # [(batch tensor, group slot, member)] chains launched, batch not yet submitted
         self._chains = self._assigned
@@ -688,6 +692,13 @@ class GraphedRunner:
                 return a
         return None
 
+    def _target_slot_state(self):
+        """the slot the next chain would be written into -> (slot index, holds the batch in flight?, holds assigned batches that were
+        not submitted yet?)"""
+        s = self._next_slot % self.n_slots
+        inflight = self._inflight is not None and self._inflight[0] == "graph" and self._inflight[1] == s
+        return s, inflight, any(a[1] == s for a in self._assigned)
+
     def _launch_group(self, batch_list, main):
         s = self._next_slot % self.n_slots
         self._next_slot += 1
@@ -724,16 +735,28 @@ class GraphedRunner:
             return self._submit_eager(cur, main)
         todo = [p for p in todo if self._conforms(p)]
         a = self._where(cur)
+        done, finished = None, False
         if a is None:                                       # cold start (or a caller that looks less far ahead)
             self.engine.check_weights()
+            s_next, holds_inflight, holds_assigned = self._target_slot_state()
+            if holds_inflight:                              # few slots: the batch in flight lives where this chain goes -- its RCNN and
+                done, finished = self._finish_inflight(), True     # final stages are enqueued first (the chain waits for ev_rcnn)
+            if holds_assigned:                              # batches announced earlier and never submitted: their chain is dropped
+                self._assigned[:] = [x for x in self._assigned if x[1] != s_next]
             self._launch_group([cur] + [p for p in todo if self._where(p) is None][:self.group - 1], main)
             a = self._where(cur)
         self._assigned[:] = [x for x in self._assigned if x is not a]
         missing = [p for p in todo if self._where(p) is None]
         have = len(todo) - len(missing)
         if missing and (len(missing) >= self.group or have <= 1):
-            self.engine.check_weights()
-            self._launch_group(missing[:self.group], main)
+            s_next, holds_inflight, holds_assigned = self._target_slot_state()
+            # a look-ahead chain is optional: it waits for a later submit while its slot still holds the current batch or batches
+            # that were assigned and not submitted yet; the slot of the batch in flight is released by finishing that batch first
+            if not holds_assigned and s_next != a[1]:
+                if holds_inflight and not finished:
+                    done, finished = self._finish_inflight(), True
+                self.engine.check_weights()
+                self._launch_group(missing[:self.group], main)
         _, s, k = a
         slot = self.slots[s]
         m = slot["members"][k]
@@ -752,7 +775,8 @@ class GraphedRunner:
         if _GRAPH_DEBUG & 4:
             torch.cuda.synchronize(self.device)
             print("[graph debug] slot %d member %d tail done" % (s, k), flush=True)
-        done = self._finish_inflight()
+        if not finished:
+            done = self._finish_inflight()
         m["used"] = True
         self._inflight = ("graph", s, k)
         return done
@@ -926,6 +950,19 @@ class RecallStats:
         return out
 
 
+_NODE_AFFINITY = None          # the affinity this process STARTED with (captured once: eval_scenes may run several times per process)
+
+
+def _node_affinity():
+    global _NODE_AFFINITY
+    if _NODE_AFFINITY is None:
+        try:
+            _NODE_AFFINITY = sorted(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            _NODE_AFFINITY = list(range(os.cpu_count() or 1))
+    return _NODE_AFFINITY
+
+
 def host_budget(world=None, local_rank=None, cores=None):
     """The share of the host one rank may use when W ranks of a node each drive a GPU with loader and writer processes
     (at 16 loaders + 6 writers per rank, 8 ranks are 176 processes on 128-256 cores with no placement).
@@ -934,14 +971,21 @@ def host_budget(world=None, local_rank=None, cores=None):
     loaders, writers.  PRCNN_LOADER_WORKERS / PRCNN_WRITER_PROCS override the counts, PRCNN_NO_AFFINITY=1 the pinning."""
     world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) if world is None else int(world)
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else int(local_rank)
-    if cores is None:
-        try:
-            cores = sorted(os.sched_getaffinity(0))
-        except (AttributeError, OSError):
-            cores = list(range(os.cpu_count() or 1))
     world = max(1, world)
-    per = max(1, len(cores) // world)
-    mine = cores[(local_rank % world) * per:(local_rank % world) * per + per] or cores
+    if cores is None:
+        # always sliced from the affinity the process started with, never from a slice an earlier call pinned it to (ADVICE r3:
+        # 128 cores became 16, then 2, then 1 over repeated eval_scenes calls); a rank its launcher already confined to a 1/W share
+        # of the node (or less) keeps that share whole
+        cores = _node_affinity()
+        if world > 1 and len(cores) * world <= (os.cpu_count() or 0):
+            world_slices = 1
+        else:
+            world_slices = world
+    else:
+        world_slices = world
+    per = max(1, len(cores) // world_slices)
+    k = local_rank % world_slices
+    mine = cores[k * per:k * per + per] or cores
     # one core for the thread that feeds the GPU, a quarter of the rest for the writers (text formatting), the rest for the loaders
     spare = max(1, len(mine) - 1)
     writers = max(1, min(6, spare // 4))

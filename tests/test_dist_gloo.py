@@ -144,3 +144,29 @@ def test_host_budget_splits_the_node_between_ranks():
     assert one["cores"] == cores and one["loaders"] == 16 and one["writers"] == 6        # a single rank keeps round 2's counts
     tiny = E.host_budget(world=8, local_rank=5, cores=list(range(4)))                    # more ranks than cores: still valid
     assert tiny["loaders"] >= 1 and tiny["writers"] >= 1 and tiny["cores"]
+
+
+def test_host_budget_is_idempotent_after_pinning(monkeypatch):
+    """eval_scenes calls host_budget() + pin_to_budget() on every invocation; the second call must slice the node's
+    ORIGINAL affinity again (same cores), not the slice the first call pinned the process to (128 -> 16 -> 2 -> 1)."""
+    import os
+    from conftest import pkg
+    E = pkg("eval_rcnn")
+    node = list(range(64))
+    state = {"aff": set(node)}
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(state["aff"]))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cores: state.__setitem__("aff", set(cores)))
+    monkeypatch.setattr(os, "cpu_count", lambda: 64)
+    monkeypatch.setattr(E, "_NODE_AFFINITY", None)
+    first = E.host_budget(world=4, local_rank=2)
+    assert first["cores"] == list(range(32, 48))
+    assert E.pin_to_budget(first) and state["aff"] == set(range(32, 48))
+    for _ in range(3):
+        again = E.host_budget(world=4, local_rank=2)
+        assert again["cores"] == first["cores"] and again["loaders"] == first["loaders"]
+        E.pin_to_budget(again)
+    # a rank its launcher already confined to a quarter of the node keeps the quarter whole
+    monkeypatch.setattr(E, "_NODE_AFFINITY", None)
+    state["aff"] = set(range(16, 32))
+    kept = E.host_budget(world=4, local_rank=3)
+    assert kept["cores"] == list(range(16, 32))

@@ -60,8 +60,14 @@ def _report(ret, det, g):
     sub = slice(0, 16384, 64)
     stage("rpn_reg every 64th point", ret["rpn_reg"][:, sub].cpu().numpy().reshape(-1, ret["rpn_reg"].shape[-1]), g["rpn_reg_sub"].reshape(-1, g["rpn_reg_sub"].shape[-1]))
     seg = np.unpackbits(g["seg_result"], axis=1)[:, :16384]
-    flips = int((ret["seg_result"].cpu().numpy().astype(np.uint8) != seg).sum())
-    rep.append(("seg_result flips", float(flips), flips, seg.shape))
+    # the foreground flag is sigmoid(score) > 0.3 <=> score > logit(0.3): it is compared where the reference's score is farther from
+    # that threshold than the tolerance (a score inside the band may fall on either side in the reference's own build as well)
+    thr = float(np.log(0.3 / 0.7))
+    decided = np.abs(g["rpn_cls"].astype(np.float64) - thr) > TOL * np.maximum(1.0, np.abs(g["rpn_cls"]))
+    differ = ret["seg_result"].cpu().numpy().astype(np.uint8) != seg
+    flips = int((differ & decided).sum())
+    rep.append(("seg_result flips (%d of %d points within tolerance of the threshold: %d differ)" % (int((~decided).sum()), seg.size, int((differ & ~decided).sum())),
+                float(flips), flips, seg.shape))
     rois = ret["rois"].cpu().numpy()
     perm, moved = _roi_permutation(rois, g["roi_scores_raw"], g["rois"])
     rep.append(("rois without a partner", float((perm < 0).sum()), int((perm < 0).sum()), perm.shape))
