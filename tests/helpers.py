@@ -159,3 +159,90 @@ def writer_boxes(seed, n=96):
     b[18, 6] = np.float32(np.pi); b[19, 6] = np.float32(-np.pi); b[20, 6] = 0.0
     scores = rng.uniform(-3, 8, n).astype(np.float32)
     return b.astype(np.float32), scores
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Stage-by-stage comparison of one RPN + RCNN + final pass with a reference record (a fixture made by the REFERENCE model,
+# tests/golden g12, or the record of another path of this build): tests/test_gpu_full_ref.py, tests/test_gpu_e2e.py.
+TOL = 1e-4
+
+
+def roi_permutation(rois, scores_ref, rois_ref):
+    """The reference orders RoIs by RPN score; two RoIs whose reference scores agree within the tolerance have no defined order
+    (the reference's convolutions ran in another library).  -> perm (B, M): perm[b, i] = the row of the GPU result that holds
+    reference row i, searched only among rows whose reference score is within 1e-4 * max(1, |score|) of row i's (i itself
+    first); -1 where there is none.  Also the number of rows that moved."""
+    B, M, _ = rois_ref.shape
+    perm = -np.ones((B, M), np.int64)
+    moved = 0
+    for b in range(B):
+        used = np.zeros(M, bool)
+        for i in range(M):
+            tie = TOL * max(1.0, abs(float(scores_ref[b, i])))
+            cand = [i] + [j for j in range(M) if j != i and abs(float(scores_ref[b, j]) - float(scores_ref[b, i])) <= tie]
+            for j in cand:
+                if not used[j] and np.abs(rois[b, j] - rois_ref[b, i]).max() <= TOL:
+                    perm[b, i], used[j] = j, True
+                    moved += int(j != i)
+                    break
+    return perm, moved
+
+
+def e2e_report(ret, det, g):
+    """stage by stage: max |GPU - reference| and the number of rows beyond tolerance (1e-4 absolute for boxes and regression
+    outputs, 1e-4 * max(1, |value|) for classification logits, which reach +-10)"""
+    rep = []
+
+    def stage(name, got, want, relative=False):
+        got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+        d = np.abs(got - want)
+        if relative:
+            d = d / np.maximum(1.0, np.abs(want))
+        bad = int((d.reshape(d.shape[0], -1).max(1) > TOL).sum())
+        rep.append((name, float(d.max()) if d.size else 0.0, bad, d.shape))
+    B, M = g["rois"].shape[:2]
+    stage("rpn_cls (B,N) [relative]", ret["rpn_cls"][..., 0].cpu().numpy(), g["rpn_cls"], relative=True)
+    sub = slice(0, g["rpn_cls"].shape[1], 64)
+    stage("rpn_reg every 64th point", ret["rpn_reg"][:, sub].cpu().numpy().reshape(-1, ret["rpn_reg"].shape[-1]), g["rpn_reg_sub"].reshape(-1, g["rpn_reg_sub"].shape[-1]))
+    seg = g["seg"] if "seg" in g else np.unpackbits(g["seg_result"], axis=1)[:, :g["rpn_cls"].shape[1]]
+    # the foreground flag is sigmoid(score) > 0.3 <=> score > logit(0.3): it is compared where the reference's score is farther from
+    # that threshold than the tolerance (a score inside the band may fall on either side in the reference's own build as well)
+    thr = float(np.log(0.3 / 0.7))
+    decided = np.abs(g["rpn_cls"].astype(np.float64) - thr) > TOL * np.maximum(1.0, np.abs(g["rpn_cls"]))
+    differ = ret["seg_result"].cpu().numpy().astype(np.uint8) != seg
+    flips = int((differ & decided).sum())
+    rep.append(("seg_result flips (%d of %d points within tolerance of the threshold: %d differ)" % (int((~decided).sum()), seg.size, int((differ & ~decided).sum())),
+                float(flips), flips, seg.shape))
+    rois = ret["rois"].cpu().numpy()
+    perm, moved = roi_permutation(rois, g["roi_scores_raw"], g["rois"])
+    rep.append(("rois without a partner", float((perm < 0).sum()), int((perm < 0).sum()), perm.shape))
+    rep.append(("(rois swapped inside score ties: %d)" % moved, 0.0, 0, perm.shape))
+    take = np.where(perm < 0, np.arange(M)[None], perm)
+
+    def rows(x, width):
+        x = x.reshape(B, M, width)
+        return np.stack([x[b, take[b]] for b in range(B)], 0).reshape(-1, width)
+    stage("rois (B*M,7)", rows(rois, 7), g["rois"].reshape(-1, 7))
+    stage("roi_scores_raw [relative]", rows(ret["roi_scores_raw"].cpu().numpy(), 1), g["roi_scores_raw"].reshape(-1, 1), relative=True)
+    stage("rcnn_cls (B*M,1)", rows(ret["rcnn_cls"].cpu().numpy(), 1), g["rcnn_cls"])
+    stage("rcnn_reg (B*M,46)", rows(ret["rcnn_reg"].cpu().numpy(), g["rcnn_reg"].shape[1]), g["rcnn_reg"])
+    if "pred_boxes3d" in det:
+        stage("decoded boxes (B*M,7)", rows(det["pred_boxes3d"].cpu().numpy(), 7), g["decoded"].reshape(-1, 7))
+    rep.append(("final_num", float(np.abs(det["num"].cpu().numpy() - g["final_num"]).max()), int((det["num"].cpu().numpy() != g["final_num"]).sum()), (B,)))
+    stage("final_boxes (B*M,7)", det["boxes"].cpu().numpy().reshape(-1, 7), g["final_boxes"].reshape(-1, 7))
+    stage("final_scores", det["scores"].cpu().numpy().reshape(-1, 1), g["final_scores"].reshape(-1, 1))
+    return rep
+
+
+
+def e2e_record(ret, det):
+    """the record e2e_report compares against, from a run of this build (e.g. the nn.Module path as the reference of the engine)"""
+    c = lambda t: t.detach().cpu().numpy()
+    return {"rpn_cls": c(ret["rpn_cls"])[..., 0], "rpn_reg_sub": c(ret["rpn_reg"])[:, ::64], "seg": c(ret["seg_result"]).astype(np.uint8),
+            "rois": c(ret["rois"]), "roi_scores_raw": c(ret["roi_scores_raw"]), "rcnn_cls": c(ret["rcnn_cls"]),
+            "rcnn_reg": c(ret["rcnn_reg"]), "decoded": c(det["pred_boxes3d"]), "final_num": c(det["num"]),
+            "final_boxes": c(det["boxes"]), "final_scores": c(det["scores"])}
+
+
+def e2e_text(rep):
+    return "\n".join("  %-28s max|d| %.3g   rows > 1e-4: %d of %s" % r for r in rep)

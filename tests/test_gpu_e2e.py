@@ -191,34 +191,9 @@ def match_boxes(a, b):
     return worst, matched
 
 
-def test_full_size_gpu_vs_cpu_oracle_boxes(oracle):
-    """default.yaml shapes, 1 scene, random init: GPU pipeline vs CPU pipeline with oracle operators."""
-    from oracle import ext_cpu
-    C, E, S = pkg("config"), pkg("eval_rcnn"), pkg("synth")
-    cfg = C.default_eval_cfg()
-    model_c = E.build_model(cfg, "cpu", seed=3)
-    # spread the heads (random init leaves them ~0, which makes every decision a near-tie)
-    g = torch.Generator().manual_seed(5)
-    with torch.no_grad():
-        for name, p in model_c.named_parameters():
-            if ("reg_layer" in name or "cls_layer" in name) and p.dim() > 1:
-                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
-        model_c.rcnn_net.cls_layer[-1].conv.weight.mul_(0.05)     # scores stay near the bias: most RoIs pass
-        model_c.rcnn_net.cls_layer[-1].conv.bias.fill_(0.5)       # the 0.3 threshold and NMS does the rest
-    model_g = E.build_model(cfg, DEV, seed=3)
-    model_g.load_state_dict(model_c.state_dict())
-    pts = torch.from_numpy(S.scenes(1, 16384, seed0=77))
-    with ext_cpu.patch_package():
-        dc = E.infer_batch(model_c, cfg, pts)
-    dg = E.infer_batch(model_g, cfg, pts.to(DEV))
-    # RPN head outputs: same convolutions up to library rounding
-    rois_c, rois_g = dc["rois"][0].numpy(), dg["rois"][0].cpu().numpy()
-    worst, matched = match_boxes(rois_g, rois_c)
-    assert matched >= 0.9 * len(rois_c), "only %d of %d RoIs matched" % (matched, len(rois_c))
-    assert worst < 1e-3
-    nc, ng = int(dc["num"][0]), int(dg["num"][0])
-    worst, matched = match_boxes(dg["boxes"][0, :ng].cpu().numpy(), dc["boxes"][0, :nc].numpy())
-    assert nc >= 3 and matched >= 0.8 * nc and worst < 1e-3, (worst, matched, nc, ng)
+# (the full-size comparison of the nn.Module path with a CPU run of this build -- bars 1e-3 / 90 % of the RoIs -- is replaced by
+#  tests/test_gpu_full_ref.py: module path AND engine against fixtures recorded from the REFERENCE model at default.yaml shapes,
+#  1e-4 for every RoI and every final box)
 
 
 def test_full_size_batch8_engine_gpu_vs_engine_on_cpu_oracle_every_box():
@@ -262,25 +237,40 @@ def test_full_size_batch8_engine_gpu_vs_engine_on_cpu_oracle_every_box():
     print("batch 8: %d final boxes, all matched, worst |d| = %.3g" % (int(dc["num"].sum()), worst_all))
 
 
+def _seeded_full_model():
+    """default.yaml PointRCNN with the seeded weights the reference-made fixture g12u was recorded with"""
+    from test_host_logic import full_model
+    model, cfg, g, pts = full_model(DEV, "u")
+    return model, cfg, pts
+
+
+def _run_both(model, cfg, pts, eng):
+    """-> (engine run, module-path run) as (ret, det) pairs"""
+    E = pkg("eval_rcnn")
+    out = []
+    with torch.no_grad():
+        for use_engine in (True, False):
+            ret = eng(pts) if use_engine else model({"pts_input": pts})
+            if "seg_result" not in ret:
+                ret["seg_result"] = (torch.sigmoid(ret["rpn_cls"][..., 0]) > cfg.RPN.SCORE_THRESH).float()
+            out.append((ret, E.postprocess(cfg, ret, pts.shape[0])))
+    torch.cuda.synchronize()
+    return out
+
+
 def test_full_size_engine_is_complete_deterministic_and_equals_module_path():
     """default.yaml shapes, batch of 2: the point-major engine (fused MFMA / VALU kernels, ticket scheduling, all
     extension entry points) against the nn.Module graph on the same device and weights.
       * every torch.empty buffer is poisoned with NaN first: a tile or row that a kernel fails to write (a lost
         ticket, a short grid) surfaces as NaN in the heads;
       * two runs are bit-identical (no race, no stale memory);
-      * RoIs and head outputs agree with the module path to GEMM rounding; final boxes match."""
-    C, E, F, S = pkg("config"), pkg("eval_rcnn"), pkg("net.fast_infer"), pkg("synth")
-    cfg = C.default_eval_cfg()
-    model = E.build_model(cfg, DEV, seed=3)
-    g = torch.Generator().manual_seed(5)
-    with torch.no_grad():
-        for name, p in model.named_parameters():
-            if ("reg_layer" in name or "cls_layer" in name) and p.dim() > 1:
-                p.copy_((torch.randn(p.shape, generator=g) * 0.3).to(DEV))
-        model.rcnn_net.cls_layer[-1].conv.weight.mul_(0.05)
-        model.rcnn_net.cls_layer[-1].conv.bias.fill_(0.5)
+      * EVERY RoI, head output and final box agrees with the module path within 1e-4, equal counts (round 3 held 1e-3 / 90 %
+        here; both paths are also held to the reference-made fixture in tests/test_gpu_full_ref.py)."""
+    import helpers
+    E, F = pkg("eval_rcnn"), pkg("net.fast_infer")
+    model, cfg, pts_np = _seeded_full_model()
     eng = F.FastPointRCNN(model, cfg)
-    pts = torch.from_numpy(S.scenes(2, cfg.RPN.NUM_POINTS, seed0=77)).to(DEV)
+    pts = torch.from_numpy(pts_np).to(DEV)
     real_empty = torch.empty
 
     def poisoned(*a, **k):
@@ -298,54 +288,33 @@ def test_full_size_engine_is_complete_deterministic_and_equals_module_path():
     for k in ("rois", "rcnn_cls", "rcnn_reg", "boxes", "scores"):
         assert torch.isfinite(d1[k]).all(), k
         assert torch.equal(d1[k], d2[k]), (k, float((d1[k] - d2[k]).abs().max()))
-    dm = E.infer_batch(model, cfg, pts)                                   # nn.Module graph
-    for b in range(2):
-        rg, rm = d1["rois"][b].cpu().numpy(), dm["rois"][b].cpu().numpy()
-        worst, matched = match_boxes(rg, rm)
-        assert matched >= 0.95 * len(rm) and worst < 1e-3, (worst, matched)
-        # head outputs of RoIs that are (numerically) the same box in both paths
-        same = (d1["rois"][b] - dm["rois"][b]).abs().max(dim=1).values < 1e-4
-        assert int(same.sum()) >= 60
-        M = d1["rois"].shape[1]
-        for k, tol in (("rcnn_cls", 2e-3), ("rcnn_reg", 2e-3)):
-            a = d1[k].view(2, M, -1)[b][same]
-            m = dm[k].view(2, M, -1)[b][same]
-            frac_close = float(((a - m).abs().max(dim=1).values < tol).float().mean())
-            assert frac_close >= 0.9, (k, frac_close)                      # a flipped FPS pick may move a few RoIs
-        ng, nm = int(d1["num"][b]), int(dm["num"][b])
-        worst, matched = match_boxes(d1["boxes"][b, :ng].cpu().numpy(), dm["boxes"][b, :nm].cpu().numpy())
-        assert nm >= 3 and matched >= 0.8 * nm and worst < 1e-3, (worst, matched, nm, ng)
+    (ret_e, det_e), (ret_m, det_m) = _run_both(model, cfg, pts, eng)
+    rep = helpers.e2e_report(ret_e, det_e, helpers.e2e_record(ret_m, det_m))
+    print("engine vs module path (B = 2):\n" + helpers.e2e_text(rep))
+    assert all(r[2] == 0 for r in rep), helpers.e2e_text(rep)
+    assert int(det_m["num"].min()) >= 10
 
 
 @pytest.mark.parametrize("B", [1, 3])
 def test_full_size_engine_other_batch_sizes(B):
     """The same engine-vs-module comparison at batch sizes 1 and 3 (tile counts that are not multiples of the workgroup
-    quota, odd grids), three-stream runner included."""
-    C, E, F, S = pkg("config"), pkg("eval_rcnn"), pkg("net.fast_infer"), pkg("synth")
-    cfg = C.default_eval_cfg()
-    model = E.build_model(cfg, DEV, seed=11)
-    g = torch.Generator().manual_seed(7)
-    with torch.no_grad():
-        for name, p in model.named_parameters():
-            if ("reg_layer" in name or "cls_layer" in name) and p.dim() > 1:
-                p.copy_((torch.randn(p.shape, generator=g) * 0.3).to(DEV))
-        model.rcnn_net.cls_layer[-1].conv.weight.mul_(0.05)
-        model.rcnn_net.cls_layer[-1].conv.bias.fill_(0.5)
+    quota, odd grids), three-stream runner included: 1e-4 on every RoI, head output and final box."""
+    import helpers
+    E, S = pkg("eval_rcnn"), pkg("synth")
+    model, cfg, _ = _seeded_full_model()
     pts = torch.from_numpy(S.scenes(B, cfg.RPN.NUM_POINTS, seed0=300 + B)).to(DEV)
     runner = E.PipelinedRunner(model, cfg, DEV)
     assert runner.submit(pts, None) is None
     d1 = runner.flush()
     d1["ready"].synchronize()
     d2 = E.infer_batch(model, cfg, pts, engine=runner.engine)
-    dm = E.infer_batch(model, cfg, pts)
     for k in ("rois", "rcnn_cls", "rcnn_reg", "boxes", "scores", "num"):
         assert torch.equal(d1[k], d2[k]), k
-    for b in range(B):
-        worst, matched = match_boxes(d1["rois"][b].cpu().numpy(), dm["rois"][b].cpu().numpy())
-        assert matched >= 0.95 * dm["rois"].shape[1] and worst < 1e-3
-        ng, nm = int(d1["num"][b]), int(dm["num"][b])
-        worst, matched = match_boxes(d1["boxes"][b, :ng].cpu().numpy(), dm["boxes"][b, :nm].cpu().numpy())
-        assert nm >= 3 and matched >= 0.8 * nm and worst < 1e-3, (worst, matched, nm, ng)
+    (ret_e, det_e), (ret_m, det_m) = _run_both(model, cfg, pts, runner.engine)
+    rep = helpers.e2e_report(ret_e, det_e, helpers.e2e_record(ret_m, det_m))
+    print("engine vs module path (B = %d):\n" % B + helpers.e2e_text(rep))
+    assert all(r[2] == 0 for r in rep), helpers.e2e_text(rep)
+    assert int(det_m["num"].min()) >= 3
 
 
 def test_pipelined_runner_full_size_many_steps_equals_serial():
