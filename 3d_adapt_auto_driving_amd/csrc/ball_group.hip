@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void group_cat_kernel(
 // with 16-byte loads, the (B, 3+C, M, ns) output is written with 16-byte stores on consecutive
 // addresses.  Output channels 0..2 are xyz[idx] - centre, channels 3.. are features[idx]
 // (pointnet2_utils.py:249-257).  grid = (row groups, slot chunks, B); block = 1024 threads.
-template <int ROWS>
+// CAT = false: plain group_points (K2, group_points_gpu.cu:47-66) -- every output channel is a feature row, nothing is subtracted.
+template <int ROWS, bool CAT = true>
 __global__ __launch_bounds__(1024) void group_cat_lds_kernel(
     int n, int m, int c, int nsample, const float *__restrict__ new_xyz, const float *__restrict__ xyz,
     const float *__restrict__ features, const int *__restrict__ idx, float *__restrict__ out)
@@ -163,7 +164,8 @@ __global__ __launch_bounds__(1024) void group_cat_lds_kernel(
     extern __shared__ float rows[];  // [ROWS][n]
     const int b = blockIdx.z;
     const int ch0 = blockIdx.x * ROWS;
-    const int cout = 3 + c;
+    constexpr int NX = CAT ? 3 : 0;            // leading coordinate channels
+    const int cout = NX + c;
     const long slots = (long)m * nsample;
     const int t = threadIdx.x;
 
@@ -172,11 +174,11 @@ __global__ __launch_bounds__(1024) void group_cat_lds_kernel(
         const int ch = ch0 + r;
         if (ch >= cout) break;
         float *dst = rows + (long)r * n;
-        if (ch < 3) {
+        if (ch < NX) {
             const float *src = xyz + (long)b * n * 3 + ch;
             for (int k = t; k < n; k += 1024) dst[k] = src[3 * (long)k];
         } else {
-            const float *src = features + ((long)b * c + (ch - 3)) * n;
+            const float *src = features + ((long)b * c + (ch - NX)) * n;
             for (int k = t; k < n; k += 1024) dst[k] = src[k];
         }
     }
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(1024) void group_cat_lds_kernel(
                 const long q = qb + t + (long)u * 1024;
                 if (q >= q1) continue;
                 float4 v = make_float4(row[k[u].x], row[k[u].y], row[k[u].z], row[k[u].w]);
-                if (ch < 3) {
+                if (ch < NX) {
                     const long s0 = q << 2;
                     v.x -= ctr[((s0 + 0) / nsample) * 3 + ch];
                     v.y -= ctr[((s0 + 1) / nsample) * 3 + ch];
@@ -231,32 +233,32 @@ __global__ __launch_bounds__(1024) void group_cat_lds_kernel(
                 const int ch = ch0 + r;
                 if (ch >= cout) break;
                 float v = rows[(long)r * n + k];
-                if (ch < 3) v -= ctr[(s / nsample) * 3 + ch];
+                if (ch < NX) v -= ctr[(s / nsample) * 3 + ch];
                 out[((long)b * cout + ch) * slots + s] = v;
             }
         }
     }
 }
 
-template <int ROWS>
+template <int ROWS, bool CAT = true>
 static int launch_group_cat_lds(int b, int n, int m, int c, int nsample, const float *new_xyz, const float *xyz,
                                 const float *features, const int *idx, float *out, hipStream_t st)
 {
     const size_t lds = (size_t)ROWS * n * sizeof(float);
     if (lds > 64 * 1024) {
-        const int rc = ensure_dynamic_lds((const void *)group_cat_lds_kernel<ROWS>, lds, "group_cat");
+        const int rc = ensure_dynamic_lds((const void *)group_cat_lds_kernel<ROWS, CAT>, lds, "group_cat");
         if (rc != PRCNN_OK) return rc;
     }
-    const int groups = ceil_div(3 + c, ROWS);
+    const int groups = ceil_div((CAT ? 3 : 0) + c, ROWS);
     // enough blocks to fill 256 CUs a few times over; every chunk re-stages the rows, so keep chunks large
     int chunks = 1;
     const long slots = (long)m * nsample;
     while ((long)b * groups * chunks < 1024 && slots / (chunks * 2) >= 16384) chunks *= 2;
     if (const char *e = getenv("PRCNN_GROUP_CHUNKS")) chunks = atoi(e) > 0 ? atoi(e) : chunks;   // tuning knob
     dim3 grid(groups, chunks, b);
-    hipLaunchKernelGGL(group_cat_lds_kernel<ROWS>, grid, dim3(1024), lds, st, n, m, c, nsample, new_xyz, xyz,
+    hipLaunchKernelGGL((group_cat_lds_kernel<ROWS, CAT>), grid, dim3(1024), lds, st, n, m, c, nsample, new_xyz, xyz,
                        features, idx, out);
-    return check_launch("query_and_group");
+    return check_launch(CAT ? "query_and_group" : "group_points");
 }
 
 // K4 / K5
@@ -384,6 +386,15 @@ extern "C" int prcnn_group_points(int b, int c, int n, int npoints, int nsample,
     const long slots = (long)npoints * nsample;
     if (b == 0 || c == 0 || slots == 0) return PRCNN_OK;
     PRCNN_REQUIRE(points && idx && out, "group_points: null pointer");
+    // round 4: the channel rows staged in LDS (the kernel of the fused operator without its coordinate channels): the gather is an
+    // LDS read and the (b, c, npoints, nsample) output leaves in 16-byte stores -- 0.35 ms -> see profiles/r04_dropin_ops.md for
+    // C = 128, nsample = 32, b = 8 (the direct kernel below: one 4-byte gather per element through L2, 1.8 TB/s)
+    if ((((uintptr_t)idx | (uintptr_t)out) & 15) == 0 && (slots & 3) == 0 && slots >= 2L * n && (long)n * 4 <= 128 * 1024) {
+        hipStream_t st = (hipStream_t)stream;
+        if ((long)n * 4 * 4 <= 64 * 1024) return launch_group_cat_lds<4, false>(b, n, npoints, c, nsample, nullptr, nullptr, points, idx, out, st);
+        if ((long)n * 4 * 2 <= 64 * 1024) return launch_group_cat_lds<2, false>(b, n, npoints, c, nsample, nullptr, nullptr, points, idx, out, st);
+        return launch_group_cat_lds<1, false>(b, n, npoints, c, nsample, nullptr, nullptr, points, idx, out, st);
+    }
     dim3 grid(ceil_div(slots, 256), c, b);
     hipLaunchKernelGGL(group_points_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, slots, points, idx, out);
     return check_launch("group_points");

@@ -73,6 +73,67 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(
     }
 }
 
+// The same operator at HBM speed (round 4; the kernel above gathers 3 x 4 bytes per output element through L2: 1.0 TB/s on
+// (8, 256, 4096) -> (8, 256, 16384)): the m-float rows of ROWS channels are staged in LDS, a thread owns 4 consecutive points --
+// their 12 indices and 12 weights come in as six 16-byte loads, once for all ROWS channels -- and every channel leaves as one
+// 16-byte store per thread.  Same operation order (w0 f0 + w1 f1, + w2 f2; no fma).  grid = (point chunks, channel groups, b).
+template <int ROWS>
+__global__ __launch_bounds__(1024) void three_interpolate_lds_kernel(
+    int c, int m, int n, const float *__restrict__ points, const int *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ out)
+{
+    extern __shared__ float rows[];            // [ROWS][m]
+    const int b = blockIdx.z, c0 = blockIdx.y * ROWS, t = threadIdx.x;
+    const int nrows = min(ROWS, c - c0);
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(points + ((long)b * c + c0) * m);   // consecutive channels are contiguous
+        float4 *dst = reinterpret_cast<float4 *>(rows);
+        const int quads = nrows * m / 4;
+        for (int k = t; k < quads; k += 1024) dst[k] = src[k];
+    }
+    __syncthreads();
+    const int quads = n >> 2;
+    const int per = (quads + gridDim.x - 1) / gridDim.x;
+    const int q0 = blockIdx.x * per, q1 = min(quads, q0 + per);
+    const int4 *ix4 = reinterpret_cast<const int4 *>(idx + (long)b * n * 3);
+    const float4 *w4 = reinterpret_cast<const float4 *>(weight + (long)b * n * 3);
+    for (int q = q0 + t; q < q1; q += 1024) {
+        const int4 ia = ix4[3 * q], ib = ix4[3 * q + 1], ic = ix4[3 * q + 2];          // points 4q .. 4q + 3: (i0 i1 i2)(i0 i1 i2)...
+        const float4 wa = w4[3 * q], wb = w4[3 * q + 1], wc = w4[3 * q + 2];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            if (r >= nrows) break;
+            const float *f = rows + r * m;
+            float4 v;
+            v.x = __fadd_rn(__fadd_rn(__fmul_rn(wa.x, f[ia.x]), __fmul_rn(wa.y, f[ia.y])), __fmul_rn(wa.z, f[ia.z]));
+            v.y = __fadd_rn(__fadd_rn(__fmul_rn(wa.w, f[ia.w]), __fmul_rn(wb.x, f[ib.x])), __fmul_rn(wb.y, f[ib.y]));
+            v.z = __fadd_rn(__fadd_rn(__fmul_rn(wb.z, f[ib.z]), __fmul_rn(wb.w, f[ib.w])), __fmul_rn(wc.x, f[ic.x]));
+            v.w = __fadd_rn(__fadd_rn(__fmul_rn(wc.y, f[ic.y]), __fmul_rn(wc.z, f[ic.z])), __fmul_rn(wc.w, f[ic.w]));
+            float4 *dst = reinterpret_cast<float4 *>(out + ((long)b * c + c0 + r) * n) + q;
+            __builtin_nontemporal_store(v.x, &dst->x);
+            __builtin_nontemporal_store(v.y, &dst->y);
+            __builtin_nontemporal_store(v.z, &dst->z);
+            __builtin_nontemporal_store(v.w, &dst->w);
+        }
+    }
+}
+
+template <int ROWS>
+static int launch_three_interpolate_lds(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                                        float *out, hipStream_t st)
+{
+    const size_t lds = (size_t)ROWS * m * sizeof(float);
+    if (lds > 64 * 1024) {
+        const int rc = ensure_dynamic_lds((const void *)three_interpolate_lds_kernel<ROWS>, lds, "three_interpolate");
+        if (rc != PRCNN_OK) return rc;
+    }
+    const int groups = ceil_div(c, ROWS);
+    int chunks = 1;                            // every chunk re-stages its rows: split the points only while the chip is not covered
+    while ((long)b * groups * chunks < 512 && n / (chunks * 2) >= 8192) chunks *= 2;
+    hipLaunchKernelGGL(three_interpolate_lds_kernel<ROWS>, dim3(chunks, groups, b), dim3(1024), lds, st, c, m, n, points, idx, weight, out);
+    return check_launch("three_interpolate");
+}
+
 __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
     int c, int n, int m, const float *__restrict__ grad_out, const int *__restrict__ idx,
     const float *__restrict__ weight, float *__restrict__ grad_points)
@@ -122,6 +183,12 @@ extern "C" int prcnn_three_interpolate(int b, int c, int m, int n, const float *
     PRCNN_REQUIRE(b <= 65535 && c <= 65535 * 8, "three_interpolate: b/c too large");
     if (b == 0 || c == 0 || n == 0) return PRCNN_OK;
     PRCNN_REQUIRE(points && idx && weight && out, "three_interpolate: null pointer");
+    if ((((uintptr_t)points | (uintptr_t)idx | (uintptr_t)weight | (uintptr_t)out) & 15) == 0 && (n & 3) == 0 && (m & 3) == 0 &&
+        n >= 2 * m && b <= 65535 && (long)m * 4 * 4 <= 128 * 1024) {
+        // rows staged in LDS; 8 channels per workgroup while that keeps two workgroups per CU, else 4
+        if ((long)m * 4 * 8 <= 64 * 1024) return launch_three_interpolate_lds<8>(b, c, m, n, points, idx, weight, out, (hipStream_t)stream);
+        return launch_three_interpolate_lds<4>(b, c, m, n, points, idx, weight, out, (hipStream_t)stream);
+    }
     dim3 grid(ceil_div(n, 256), ceil_div(c, 8), b);
     hipLaunchKernelGGL(three_interpolate_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, m, n, points, idx, weight, out);
     return check_launch("three_interpolate");

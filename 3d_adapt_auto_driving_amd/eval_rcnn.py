@@ -102,6 +102,21 @@ def postprocess(cfg, ret_dict, batch_size):
                               get_xz_fine=True, get_y_by_bin=R.LOC_Y_BY_BIN, loc_y_scope=R.LOC_Y_SCOPE,
                               loc_y_bin_size=R.LOC_Y_BIN_SIZE, get_ry_fine=True).view(batch_size, M, 7)
     selected = torch.sigmoid(raw) > R.SCORE_THRESH
+    if not hasattr(ext, "nms_device"):
+        # the reference's four entry points only (compiled dropin_native/iou3d_cuda): scene by scene over the blocking nms_gpu,
+        # as eval_rcnn.py:611-629
+        boxes, scores = torch.zeros_like(pred), torch.zeros_like(raw)
+        num = torch.zeros((batch_size,), dtype=torch.int32, device=raw.device)
+        for k in range(batch_size):
+            cur = selected[k]
+            if int(cur.sum()) == 0:
+                continue
+            b_sel, s_sel = pred[k][cur], raw[k][cur]
+            keep = iou3d_utils.nms_gpu(kitti_utils.boxes3d_to_bev_torch(b_sel), s_sel, R.NMS_THRESH)
+            boxes[k, :keep.numel()] = b_sel[keep]
+            scores[k, :keep.numel()] = s_sel[keep]
+            num[k] = keep.numel()
+        return {"boxes": boxes, "scores": scores, "num": num, "pred_boxes3d": pred, "raw_scores": raw}
     key = torch.where(selected, raw, torch.full_like(raw, float("-inf")))
     _, order = torch.sort(key, dim=1, descending=True)          # selected boxes first, by raw score
     counts = selected.sum(dim=1).to(torch.int32)
@@ -506,6 +521,59 @@ def engine_covers(cfg):
     yaml file the reference ships; cfg.RPN.USE_INTENSITY (a 4-channel pts_input, rpn.py:17 / kitti_rcnn_dataset.py:321-338) runs on the
     nn.Module graph in the reference's operation order over the same HIP operators (ModuleRunner)."""
     return not bool(cfg.RPN.USE_INTENSITY)
+
+
+_NATIVE_MODULES = None
+
+
+def native_modules():
+    """The three COMPILED extension modules (dropin_native/: pybind11 over the C ABI, the reference's 9 + 4 + 4 entry points and
+    nothing else), loaded once from their directory without shadowing the ctypes modules of the same names."""
+    global _NATIVE_MODULES
+    if _NATIVE_MODULES is None:
+        import importlib.util
+        from . import NATIVE_DROPIN_DIR
+        mods = []
+        for name in ("pointnet2_cuda", "iou3d_cuda", "roipool3d_cuda"):
+            hits = [f for f in os.listdir(NATIVE_DROPIN_DIR) if f.startswith(name + ".") and f.endswith(".so")]
+            if not hits:
+                raise RuntimeError("%s: compiled module %s not built (python __graft_entry__.py)" % (NATIVE_DROPIN_DIR, name))
+            spec = importlib.util.spec_from_file_location(name, os.path.join(NATIVE_DROPIN_DIR, hits[0]))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            mods.append(mod)
+        _NATIVE_MODULES = tuple(mods)
+    return _NATIVE_MODULES
+
+
+@contextlib.contextmanager
+def reference_api_only(native=True):
+    """What a user of the reference's Python gets from the drop-in modules: inside this context the nn.Module graph runs in the
+    reference's operation order over the reference's 17 entry points ONLY -- FPS -> gather -> ball_query -> group (x2) ->
+    subtract -> cat -> Conv2d / BatchNorm / ReLU modules -> max_pool2d (pointnet2_modules.py:19-55), three_nn -> three_interpolate
+    -> cat -> Conv (:139-151), the per-scene proposal layer and final stage over the blocking nms_gpu / nms_normal_gpu, roipool3d
+    forward -- no fused entry, no folded MLP, no engine.  ``native``: through the compiled dropin_native modules (default) or the
+    ctypes ones."""
+    from .pointnet2 import pointnet2_utils as pu, fused_mlp
+    from . import roipool3d_utils as ru
+    saved = (pu.pointnet2, iou3d_utils.iou3d_cuda, ru.roipool3d_cuda, pu.REFERENCE_ORDER, fused_mlp.ENABLED)
+    if native:
+        pu.pointnet2, iou3d_utils.iou3d_cuda, ru.roipool3d_cuda = native_modules()
+    else:
+        class _Only:
+            def __init__(self, mod, names):
+                for n in names:
+                    setattr(self, n, getattr(mod, n))
+        pu.pointnet2 = _Only(pu.pointnet2, ("ball_query_wrapper", "group_points_wrapper", "group_points_grad_wrapper",
+                                            "gather_points_wrapper", "gather_points_grad_wrapper", "furthest_point_sampling_wrapper",
+                                            "three_nn_wrapper", "three_interpolate_wrapper", "three_interpolate_grad_wrapper"))
+        iou3d_utils.iou3d_cuda = _Only(iou3d_utils.iou3d_cuda, ("boxes_overlap_bev_gpu", "boxes_iou_bev_gpu", "nms_gpu", "nms_normal_gpu"))
+        ru.roipool3d_cuda = _Only(ru.roipool3d_cuda, ("forward", "forward_slow", "pts_in_boxes3d_cpu", "roipool3d_cpu"))
+    pu.REFERENCE_ORDER, fused_mlp.ENABLED = True, False
+    try:
+        yield
+    finally:
+        pu.pointnet2, iou3d_utils.iou3d_cuda, ru.roipool3d_cuda, pu.REFERENCE_ORDER, fused_mlp.ENABLED = saved
 
 
 class ModuleRunner:

@@ -49,9 +49,54 @@ class ProposalLayer(nn.Module):
                                        get_xz_fine=cfg.RPN.LOC_XZ_FINE, get_y_by_bin=False, get_ry_fine=False)
         proposals[:, 1] += proposals[:, 3] / 2          # y becomes the bottom centre
         proposals = proposals.view(B, N, 7)
+        if not hasattr(ext, "nms_device"):
+            # an extension module with the reference's four entry points only (the compiled dropin_native/iou3d_cuda): the NMS is
+            # the blocking nms_gpu / nms_normal_gpu, one call per scene and distance band, as in proposal_layer.py:40-119
+            return self._per_scene_blocking(rpn_scores, proposals)
         if not cfg.TEST.RPN_DISTANCE_BASED_PROPOSE:
             return self._score_based(rpn_scores, proposals)
         return self._distance_based(rpn_scores, proposals)
+
+    def _per_scene_blocking(self, scores, proposals):
+        """The proposal layer over the reference's blocking NMS API: scene by scene, scores sorted, (distance-based) the near
+        band (0, 40] m and the far band (40, 80] m cut to 70 % / 30 % of RPN_PRE_NMS_TOP_N, NMS per band, 70 % / 30 % of
+        RPN_POST_NMS_TOP_N kept; a scene without far points takes the next near candidates instead.  Two host round trips per
+        band (the keep list comes back through host memory) -- the cost the batched device path above avoids."""
+        cfg, mode = self.cfg, self.cfg[self.mode]
+        B = scores.shape[0]
+        post_tot = mode.RPN_POST_NMS_TOP_N
+        rois = scores.new_zeros((B, post_tot, 7))
+        roi_scores = scores.new_zeros((B, post_tot))
+        nms = iou3d_utils.nms_gpu if cfg.RPN.NMS_TYPE == "rotate" else iou3d_utils.nms_normal_gpu
+        if cfg.RPN.NMS_TYPE not in ("rotate", "normal"):
+            raise NotImplementedError(cfg.RPN.NMS_TYPE)
+        for b in range(B):
+            s_sorted, order = torch.sort(scores[b], descending=True)
+            p_sorted = proposals[b][order]
+            kept_s, kept_p = [], []
+            if cfg.TEST.RPN_DISTANCE_BASED_PROPOSE:
+                pre = [int(mode.RPN_PRE_NMS_TOP_N * 0.7)]
+                pre.append(mode.RPN_PRE_NMS_TOP_N - pre[0])
+                post = [int(post_tot * 0.7)]
+                post.append(post_tot - post[0])
+                dist = p_sorted[:, 2]
+                near = (dist > 0.0) & (dist <= 40.0)
+                for band, lo, hi in ((0, 0.0, 40.0), (1, 40.0, 80.0)):
+                    m = (dist > lo) & (dist <= hi)
+                    if int(m.sum()) != 0:
+                        cs, cp = s_sorted[m][:pre[band]], p_sorted[m][:pre[band]]
+                    else:                                       # no point that far: the near candidates behind the first cut
+                        cs, cp = s_sorted[near][pre[0]:][:pre[band]], p_sorted[near][pre[0]:][:pre[band]]
+                    keep = nms(kitti_utils.boxes3d_to_bev_torch(cp), cs, mode.RPN_NMS_THRESH)[:post[band]]
+                    kept_s.append(cs[keep]); kept_p.append(cp[keep])
+            else:
+                cs, cp = s_sorted[:mode.RPN_PRE_NMS_TOP_N], p_sorted[:mode.RPN_PRE_NMS_TOP_N]
+                keep = iou3d_utils.nms_gpu(kitti_utils.boxes3d_to_bev_torch(cp), cs, mode.RPN_NMS_THRESH)[:post_tot]
+                kept_s.append(cs[keep]); kept_p.append(cp[keep])
+            ks, kp = torch.cat(kept_s), torch.cat(kept_p)
+            rois[b, :kp.shape[0]] = kp
+            roi_scores[b, :ks.shape[0]] = ks
+        return rois, roi_scores
 
     # ------------------------------------------------------------------ helpers
     @staticmethod

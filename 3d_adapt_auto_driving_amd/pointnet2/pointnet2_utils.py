@@ -13,6 +13,12 @@ from torch.autograd import Function
 
 from ..dropin import pointnet2_cuda as pointnet2
 
+# True: QueryAndGroup runs the reference's own sequence over the reference's entry points only (pointnet2_utils.py:241-264:
+# ball_query, two grouping_operation calls, centre subtraction, cat) instead of the one fused extension call -- what a user of
+# the reference's Python gets from the drop-in modules (eval_rcnn.reference_api_only(); bench.py config.dropin_module_scenes_per_s).
+# Also taken when the extension module offers no fused entry (the compiled dropin_native modules export the reference's 9 names).
+REFERENCE_ORDER = False
+
 
 def _contig(*ts):
     for t in ts:
@@ -192,10 +198,15 @@ class QueryAndGroup(nn.Module):
     def forward(self, xyz, new_xyz, features=None):
         if features is None:
             assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
-        if self.use_xyz:
+        if self.use_xyz and not REFERENCE_ORDER and hasattr(pointnet2, "query_and_group_wrapper"):
             return _QueryAndGroupFused.apply(self.radius, self.nsample, xyz, new_xyz, features)
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
-        return grouping_operation(features, idx)
+        if not self.use_xyz:
+            return grouping_operation(features, idx)
+        # the reference's operation order: neighbours' coordinates as channels, made relative to their centre, features behind
+        rel = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)
+        rel -= new_xyz.transpose(1, 2).unsqueeze(-1)
+        return rel if features is None else torch.cat([rel, grouping_operation(features, idx)], dim=1)
 
 
 class GroupAll(nn.Module):

@@ -7,11 +7,11 @@ reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 CONFIGS = [(B, R, NS, C) for B in (1, 8) for R in (0.1, 0.2, 0.4) for NS in (32, 64) for C in (0, 1, 128)]
 N, M = 16384, 4096
 alg = lambda B, C, NS: B * (12 * N + 12 * M + 4 * C * N + 4 * M * NS + 4 * (3 + C) * M * NS)
-OURS = ("dense_build_kernel", "dense_query_kernel", "group_cat", "ball_query_kernel", "grid_")
+OURS = ("dense_build", "dense_query_kernel", "group_cat", "ball_query_kernel")
 
 
 def short(name):
-    for k in ("dense_build_kernel", "dense_query_kernel", "group_cat_lds_kernel", "group_cat_kernel", "ball_query_kernel"):
+    for k in ("dense_build_reg_kernel", "dense_build_kernel", "dense_query_kernel", "group_cat_lds_kernel", "group_cat_kernel", "ball_query_kernel"):
         if k in name:
             return k
     return name[:40]
@@ -23,9 +23,10 @@ def calls_of(rows, start_key="Start_Timestamp"):
     rows.sort(key=lambda r: int(r[start_key]) if r.get(start_key) else int(r["Dispatch_Id"]))
     calls = []
     for r in rows:
-        if "dense_build_kernel" in r["Kernel_Name"] or not calls:
+        if "dense_build" in r["Kernel_Name"]:
             calls.append([])
-        calls[-1].append(r)
+        if calls:
+            calls[-1].append(r)
     return calls
 
 
