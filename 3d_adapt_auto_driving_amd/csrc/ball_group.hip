@@ -156,6 +156,10 @@ __global__ __launch_bounds__(256) void group_cat_kernel(
 // addresses.  Output channels 0..2 are xyz[idx] - centre, channels 3.. are features[idx]
 // (pointnet2_utils.py:249-257).  grid = (row groups, slot chunks, B); block = 1024 threads.
 // CAT = false: plain group_points (K2, group_points_gpu.cu:47-66) -- every output channel is a feature row, nothing is subtracted.
+// CAT = true (round 4): a workgroup owns ROWS FEATURE rows (output channels 3 + ...) and, beside them, a 1/gridDim.x slice of the
+// slots of the three COORDINATE channels, which it gathers straight from the (L2-resident, 196 KB) cloud -- 3 of 131 channels,
+// 12 bytes per slot.  Before, the coordinate channels were row groups of their own: 131 x 8 = 1048 equal workgroups on 512
+// resident slots = two full rounds and a third one of 24 workgroups (116 us against 98 us for the 128-channel group_points).
 template <int ROWS, bool CAT = true>
 __global__ __launch_bounds__(1024) void group_cat_lds_kernel(
     int n, int m, int c, int nsample, const float *__restrict__ new_xyz, const float *__restrict__ xyz,
@@ -163,8 +167,8 @@ __global__ __launch_bounds__(1024) void group_cat_lds_kernel(
 {
     extern __shared__ float rows[];  // [ROWS][n]
     const int b = blockIdx.z;
-    const int ch0 = blockIdx.x * ROWS;
     constexpr int NX = CAT ? 3 : 0;            // leading coordinate channels
+    const int ch0 = NX + blockIdx.x * ROWS;
     const int cout = NX + c;
     const long slots = (long)m * nsample;
     const int t = threadIdx.x;
@@ -174,23 +178,50 @@ __global__ __launch_bounds__(1024) void group_cat_lds_kernel(
         const int ch = ch0 + r;
         if (ch >= cout) break;
         float *dst = rows + (long)r * n;
-        if (ch < NX) {
-            const float *src = xyz + (long)b * n * 3 + ch;
-            for (int k = t; k < n; k += 1024) dst[k] = src[3 * (long)k];
-        } else {
-            const float *src = features + ((long)b * c + (ch - NX)) * n;
-            for (int k = t; k < n; k += 1024) dst[k] = src[k];
+        const float *src = features + ((long)b * c + (ch - NX)) * n;
+        for (int k = t; k < n; k += 1024) dst[k] = src[k];
+    }
+    const long quads = slots >> 2;
+    const int4 *idx4 = reinterpret_cast<const int4 *>(idx + (long)b * slots);
+    if (CAT && blockIdx.y == 0) {
+        // this workgroup's slice of the coordinate channels (before the barrier: it does not touch LDS)
+        const long per = (quads + gridDim.x - 1) / gridDim.x;
+        const long a0 = (long)blockIdx.x * per, a1 = min(quads, a0 + per);
+        const float *pts = xyz + (long)b * n * 3;
+        const float *ctr = new_xyz + (long)b * m * 3;
+        float *o = out + (long)b * cout * slots;
+        for (long q = a0 + t; q < a1; q += 1024) {
+            const int4 k = idx4[q];
+            const long s0 = q << 2;
+            const int kk[4] = {k.x, k.y, k.z, k.w};
+            float v[3][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float *p = pts + 3 * (long)kk[e];
+                const float *cc = ctr + ((s0 + e) / nsample) * 3;
+                v[0][e] = p[0] - cc[0]; v[1][e] = p[1] - cc[1]; v[2][e] = p[2] - cc[2];
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                float4 *dst = reinterpret_cast<float4 *>(o + (long)ch * slots) + q;
+                __builtin_nontemporal_store(v[ch][0], &dst->x);
+                __builtin_nontemporal_store(v[ch][1], &dst->y);
+                __builtin_nontemporal_store(v[ch][2], &dst->z);
+                __builtin_nontemporal_store(v[ch][3], &dst->w);
+            }
         }
+        if (blockIdx.x == gridDim.x - 1)                   // tail slots (slots % 4)
+            for (long sl = (quads << 2) + t; sl < slots; sl += 1024) {
+                const int k = idx[(long)b * slots + sl];
+                for (int ch = 0; ch < 3; ++ch) o[(long)ch * slots + sl] = pts[3 * (long)k + ch] - ctr[(sl / nsample) * 3 + ch];
+            }
     }
     __syncthreads();
 
     // this block's share of the slots, in units of 4 consecutive slots
-    const long quads = slots >> 2;
     const long per = (quads + gridDim.y - 1) / gridDim.y;
     const long q0 = (long)blockIdx.y * per;
     const long q1 = min(quads, q0 + per);
-    const int4 *idx4 = reinterpret_cast<const int4 *>(idx + (long)b * slots);
-    const float *ctr = new_xyz + (long)b * m * 3;
     constexpr int U = 4;   // quads in flight per thread: idx loads issued first, then gathers, then stores
     for (long qb = q0; qb < q1; qb += 1024 * U) {
         int4 k[U];
@@ -209,14 +240,7 @@ __global__ __launch_bounds__(1024) void group_cat_lds_kernel(
             for (int u = 0; u < U; ++u) {
                 const long q = qb + t + (long)u * 1024;
                 if (q >= q1) continue;
-                float4 v = make_float4(row[k[u].x], row[k[u].y], row[k[u].z], row[k[u].w]);
-                if (ch < NX) {
-                    const long s0 = q << 2;
-                    v.x -= ctr[((s0 + 0) / nsample) * 3 + ch];
-                    v.y -= ctr[((s0 + 1) / nsample) * 3 + ch];
-                    v.z -= ctr[((s0 + 2) / nsample) * 3 + ch];
-                    v.w -= ctr[((s0 + 3) / nsample) * 3 + ch];
-                }
+                const float4 v = make_float4(row[k[u].x], row[k[u].y], row[k[u].z], row[k[u].w]);
                 __builtin_nontemporal_store(v.x, &dst[q].x);
                 __builtin_nontemporal_store(v.y, &dst[q].y);
                 __builtin_nontemporal_store(v.z, &dst[q].z);
@@ -226,15 +250,13 @@ __global__ __launch_bounds__(1024) void group_cat_lds_kernel(
     }
     // tail slots (slots % 4), handled by the last chunk
     if (blockIdx.y == gridDim.y - 1) {
-        for (long s = (quads << 2) + t; s < slots; s += 1024) {
-            const int k = idx[(long)b * slots + s];
+        for (long sl = (quads << 2) + t; sl < slots; sl += 1024) {
+            const int k = idx[(long)b * slots + sl];
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
                 const int ch = ch0 + r;
                 if (ch >= cout) break;
-                float v = rows[(long)r * n + k];
-                if (ch < NX) v -= ctr[(s / nsample) * 3 + ch];
-                out[((long)b * cout + ch) * slots + s] = v;
+                out[((long)b * cout + ch) * slots + sl] = rows[(long)r * n + k];
             }
         }
     }
@@ -249,7 +271,7 @@ static int launch_group_cat_lds(int b, int n, int m, int c, int nsample, const f
         const int rc = ensure_dynamic_lds((const void *)group_cat_lds_kernel<ROWS, CAT>, lds, "group_cat");
         if (rc != PRCNN_OK) return rc;
     }
-    const int groups = ceil_div((CAT ? 3 : 0) + c, ROWS);
+    const int groups = ceil_div(c, ROWS);       // feature row groups (CAT: the coordinate channels ride along as slot slices)
     // enough blocks to fill 256 CUs a few times over; every chunk re-stages the rows, so keep chunks large
     int chunks = 1;
     const long slots = (long)m * nsample;
@@ -449,7 +471,7 @@ extern "C" int prcnn_query_and_group(int b, int n, int m, int c, float radius, i
     // LDS row staging pays when every staged row is reused by many slots and fits in LDS
     const long slots = (long)m * nsample;
     const bool aligned = (((uintptr_t)idx | (uintptr_t)out) & 15) == 0 && (slots & 3) == 0;
-    if (aligned && b <= 65535 && slots >= 4L * n && (long)n * 4 <= 128 * 1024) {
+    if (aligned && c > 0 && b <= 65535 && slots >= 4L * n && (long)n * 4 <= 128 * 1024) {
         hipStream_t st = (hipStream_t)stream;
         int force = 0;
         if (const char *e = getenv("PRCNN_GROUP_ROWS")) force = atoi(e);                     // tuning knob

@@ -32,6 +32,8 @@ The JSON line also carries
   config.driver_scenes_per_s  the whole driver: loader processes (scene source + 16384-point sampler on the host, as the
                 reference's DataLoader workers), pinned upload, the pipelined engine, one D2H per batch, KITTI result
                 files written by writer processes -- steady-state rate of eval_rcnn.eval_scenes (rank 0, N = 1 only)
+  config.dropin_module_scenes_per_s  the nn.Module graph in the REFERENCE'S operation order over the compiled drop-in modules
+                (the reference's 17 entry points only): what a user of the reference's Python gets before touching the engine
   cpu_baseline  the same model code on the host cores with the C oracle as operator backend
                 (kind "port": the reference has no CPU path for this pipeline), rank 0, N=1 only.
 """
@@ -282,6 +284,36 @@ def driver_leg(cfg, model, dev, scenes=4096):
             "detections": int(counts.sum()), "host_budget": stats.get("host_budget"),
             "what": "eval_scenes: synthetic scene source + host 16384-point stage in loader processes, pinned upload, engine, "
                     "D2H, KITTI text files by writer processes; steady state between the first and the last batch"}
+
+
+def dropin_module_leg(cfg, model, dev, steps=6):
+    """What a user of the REFERENCE'S Python gets from the drop-in modules (north_star: "models load unmodified"): the nn.Module
+    graph in the reference's operation order -- FPS -> gather -> ball_query -> group_points x 2 -> subtract -> cat -> Conv2d /
+    BatchNorm / ReLU modules -> max_pool2d (pointnet2_modules.py:19-55), three_nn -> three_interpolate -> cat -> Conv1d, the per-scene
+    proposal layer and final stage over the blocking nms_gpu / nms_normal_gpu, roipool3d forward -- through the COMPILED modules
+    of dropin_native/ (the reference's 17 entry points and nothing else; eval_rcnn.reference_api_only).  One batch of 8 scenes
+    per step on the default stream, detections copied out; no engine, no fused entry, no side stream."""
+    E = importlib.import_module(PKG + ".eval_rcnn")
+    synth = importlib.import_module(PKG + ".synth")
+    batches = [torch.from_numpy(synth.scenes(BATCH, NPOINTS, seed0=9000 + BATCH * k)).to(dev) for k in range(2)]
+    out = {}
+    for name, ctx in (("reference_order_native_modules", lambda: E.reference_api_only(native=True)),
+                      ("this_builds_module_graph", contextlib.nullcontext)):
+        with ctx():
+            for k in range(2):
+                E.infer_batch(model, cfg, batches[k])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                det = E.infer_batch(model, cfg, batches[k % 2])
+                host = [det[key].cpu() for key in ("boxes", "scores", "num")]
+            torch.cuda.synchronize()
+            out[name] = round(steps * BATCH / (time.perf_counter() - t0), 1)
+    return {"value": out["reference_order_native_modules"], "unit": "scenes/s", "steps": steps,
+            "module_graph_with_fused_entries": out["this_builds_module_graph"],
+            "what": "nn.Module graph in the reference's operation order over the compiled dropin_native modules (the reference's 17 entry "
+                    "points only; library convolutions), batch of %d scenes per step; beside it the same graph with this build's "
+                    "fused entries (query_and_group, folded MLPs, device-side proposal / final stage)" % BATCH}
 
 
 def cpu_baseline(cfg, budget_s=30.0):
@@ -617,6 +649,9 @@ def main():
             line["roofline_reference_op"] = roofline_query_and_group(dev)
         if world == 1 and not args.no_driver:
             line["config"]["driver_scenes_per_s"] = driver_leg(cfg, model, dev)
+        if world == 1 and not args.no_roofline:
+            note("drop-in module path")
+            line["config"]["dropin_module_scenes_per_s"] = dropin_module_leg(cfg, model, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)

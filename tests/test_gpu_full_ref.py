@@ -45,3 +45,29 @@ def test_full_size_vs_reference_model_fixture_every_roi_and_box(kind, use_engine
     first_bad = next((r for r in rep if r[2] > 0), None)
     assert first_bad is None, "first stage that parts from the reference: %s\n%s" % (first_bad[0], text)
     assert int(g["final_num"].min()) >= 10
+
+
+@pytest.mark.parametrize("native", [True, False], ids=["compiled_modules", "ctypes_modules"])
+def test_reference_operation_order_over_the_reference_api_only(native):
+    """The drop-in path proper (north_star: "models load unmodified"): the nn.Module graph in the REFERENCE'S operation order over
+    the reference's 17 entry points only -- separate ball_query / group_points x 2 / subtract / cat, Conv2d + BatchNorm + ReLU
+    modules, max_pool2d, per-scene proposal layer and final stage over the blocking nms_gpu / nms_normal_gpu
+    (eval_rcnn.reference_api_only) -- against the fixture recorded from the reference model at default.yaml shapes: every RoI,
+    head output and final box within 1e-4."""
+    E = pkg("eval_rcnn")
+    model, cfg, g, pts = full_model(DEV, "u")
+    x = torch.from_numpy(pts).to(DEV)
+    with E.reference_api_only(native=native), torch.no_grad():
+        pu = pkg("pointnet2.pointnet2_utils")
+        assert not hasattr(pu.pointnet2, "query_and_group_wrapper") and not hasattr(pkg("iou3d_utils").iou3d_cuda, "nms_device")
+        if native:
+            assert pu.pointnet2.__file__.endswith(".so")
+        ret = model({"pts_input": x})
+        ret["seg_result"] = (torch.sigmoid(ret["rpn_cls"][..., 0]) > cfg.RPN.SCORE_THRESH).float()
+        det = E.postprocess(cfg, ret, x.shape[0])
+    torch.cuda.synchronize()
+    assert hasattr(pkg("pointnet2.pointnet2_utils").pointnet2, "query_and_group_wrapper")     # restored
+    rep = helpers.e2e_report(ret, det, g)
+    text = helpers.e2e_text(rep)
+    print("g12u reference order, %s:\n%s" % ("compiled modules" if native else "ctypes modules", text))
+    assert all(r[2] == 0 for r in rep), text
