@@ -42,6 +42,7 @@ SIGNATURES = {
     "prcnn_gather_points_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
     "prcnn_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],
     "prcnn_three_nn": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "prcnn_three_nn_weights": [_I, _I, _I, _P, _P, _P, _P, _P],
     "prcnn_three_interpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "prcnn_three_interpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "prcnn_query_and_group": [_I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],

@@ -183,10 +183,11 @@ __global__ __launch_bounds__(1024) void group_cat_lds_kernel(
     }
     const long quads = slots >> 2;
     const int4 *idx4 = reinterpret_cast<const int4 *>(idx + (long)b * slots);
-    if (CAT && blockIdx.y == 0) {
+    if (CAT) {
         // this workgroup's slice of the coordinate channels (before the barrier: it does not touch LDS)
-        const long per = (quads + gridDim.x - 1) / gridDim.x;
-        const long a0 = (long)blockIdx.x * per, a1 = min(quads, a0 + per);
+        const long parts = (long)gridDim.x * gridDim.y, part = (long)blockIdx.y * gridDim.x + blockIdx.x;
+        const long per = (quads + parts - 1) / parts;
+        const long a0 = part * per, a1 = min(quads, a0 + per);
         const float *pts = xyz + (long)b * n * 3;
         const float *ctr = new_xyz + (long)b * m * 3;
         float *o = out + (long)b * cout * slots;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(1024) void group_cat_lds_kernel(
                 __builtin_nontemporal_store(v[ch][3], &dst->w);
             }
         }
-        if (blockIdx.x == gridDim.x - 1)                   // tail slots (slots % 4)
+        if (part == parts - 1)                             // tail slots (slots % 4)
             for (long sl = (quads << 2) + t; sl < slots; sl += 1024) {
                 const int k = idx[(long)b * slots + sl];
                 for (int ch = 0; ch < 3; ++ch) o[(long)ch * slots + sl] = pts[3 * (long)k + ch] - ctr[(sl / nsample) * 3 + ch];

@@ -16,7 +16,7 @@ namespace prcnn {
 
 __global__ __launch_bounds__(256) void three_nn_kernel(
     int n, int m, const float *__restrict__ unknown, const float *__restrict__ known,
-    float *__restrict__ dist2, int *__restrict__ idx)
+    float *__restrict__ dist2, int *__restrict__ idx, float *__restrict__ weight)
 {
     const int b = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -44,10 +44,13 @@ __global__ __launch_bounds__(256) void three_nn_kernel(
         }
     }
     if (valid) {
-        float *od = dist2 + ((long)b * n + p) * 3;
         int *oi = idx + ((long)b * n + p) * 3;
-        od[0] = b1; od[1] = b2; od[2] = b3;
         oi[0] = i1; oi[1] = i2; oi[2] = i3;
+        if (dist2) {
+            float *od = dist2 + ((long)b * n + p) * 3;
+            od[0] = b1; od[1] = b2; od[2] = b3;
+        }
+        if (weight) three_nn_weights(b1, b2, b3, weight + ((long)b * n + p) * 3);
     }
 }
 
@@ -154,26 +157,41 @@ __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
 
 namespace prcnn {
 int three_nn_grid(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
-                  hipStream_t st, int *used);   // three_nn_grid.hip
+                  hipStream_t st, int *used, float *weight);   // three_nn_grid.hip
 }
 using namespace prcnn;
 
-extern "C" int prcnn_three_nn(int b, int n, int m, const float *unknown, const float *known,
-                              float *dist2, int *idx, void *stream)
+static int three_nn_any(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx, float *weight,
+                        void *stream)
 {
     PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "three_nn: bad sizes");
     PRCNN_REQUIRE(b <= 65535, "three_nn: batch > 65535");
     if (b == 0 || n == 0) return PRCNN_OK;
-    PRCNN_REQUIRE(unknown && dist2 && idx && (known || m == 0), "three_nn: null pointer");
+    PRCNN_REQUIRE(unknown && (dist2 || weight) && idx && (known || m == 0), "three_nn: null pointer");
     static const bool brute_only = getenv("PRCNN_THREE_NN_BRUTE") != nullptr;
     if (!brute_only) {
         int used = 0;
-        const int rc = three_nn_grid(b, n, m, unknown, known, dist2, idx, (hipStream_t)stream, &used);
+        const int rc = three_nn_grid(b, n, m, unknown, known, dist2, idx, (hipStream_t)stream, &used, weight);
         if (rc != PRCNN_OK || used) return rc;
     }
     dim3 grid(ceil_div(n, 256), b);
-    hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, m, unknown, known, dist2, idx);
+    hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, m, unknown, known, dist2, idx, weight);
     return check_launch("three_nn");
+}
+
+extern "C" int prcnn_three_nn(int b, int n, int m, const float *unknown, const float *known,
+                              float *dist2, int *idx, void *stream)
+{
+    return three_nn_any(b, n, m, unknown, known, dist2, idx, nullptr, stream);
+}
+
+// three_nn + the inverse-distance weights PointnetFPModule.forward derives from it (pointnet2_modules.py:139-144) in the same
+// kernel: idx (b,n,3) i32 and weight (b,n,3) f32 = r_k / (r_0 + r_1 + r_2), r_k = 1 / (sqrt(dist2_k) + 1e-8).
+extern "C" int prcnn_three_nn_weights(int b, int n, int m, const float *unknown, const float *known,
+                                      int *idx, float *weight, void *stream)
+{
+    PRCNN_REQUIRE(weight, "three_nn_weights: null pointer");
+    return three_nn_any(b, n, m, unknown, known, nullptr, idx, weight, stream);
 }
 
 extern "C" int prcnn_three_interpolate(int b, int c, int m, int n, const float *points,

@@ -164,11 +164,151 @@ __global__ __launch_bounds__(TB) void tnn_build_kernel(int m, int g, const float
     }
 }
 
+// The same build with both clouds in the workgroup's REGISTERS (round 4; n <= 16 * 1024 queries, m <= 4 * 1024 known points:
+// every FP level of the backbone).  The kernel above reads the known points three times and the queries twice from global memory,
+// each time as a loop of dependent (load -> LDS atomic) rounds; here every coordinate is loaded once, all loads in flight
+// together, and the rest is LDS and ALU work.  Same cell assignment, same counting sort: the query kernel sees the same tables
+// up to the order of points INSIDE a cell (atomics), which the (d, index) insertion makes irrelevant.
+template <int NK, int NQ>
+__global__ __launch_bounds__(TB) void tnn_build_reg_kernel(int m, int g, const float *__restrict__ known,
+                                                           GridParams *__restrict__ params, int *__restrict__ cell_start,
+                                                           float4 *__restrict__ sorted, int n, const float *__restrict__ unknown,
+                                                           int *__restrict__ order)
+{
+    extern __shared__ int hist[];          // g*g counters, then cursors
+    __shared__ float red[4][TB / 64];
+    __shared__ int wsum[TB / 64];
+    __shared__ GridParams gp;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const float *__restrict__ kn = known + (long)b * m * 3;
+    const float *__restrict__ un = unknown + (long)b * n * 3;
+    const int cells = g * g;
+    float kx[NK], ky[NK], kz[NK], qx[NQ], qz[NQ];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        const int k = j * TB + t;
+        kx[j] = ky[j] = kz[j] = 0.f;
+        if (k < m) { kx[j] = kn[3 * k]; ky[j] = kn[3 * k + 1]; kz[j] = kn[3 * k + 2]; }
+    }
+    if (order) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int k = j * TB + t;
+            qx[j] = qz[j] = 0.f;
+            if (k < n) { qx[j] = un[3 * k]; qz[j] = un[3 * k + 2]; }
+        }
+    }
+    // bounding rectangle of the finite known points
+    float xmin = INFINITY, xmax = -INFINITY, zmin = INFINITY, zmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        if (j * TB + t >= m) continue;
+        if (isfinite(kx[j])) { xmin = fminf(xmin, kx[j]); xmax = fmaxf(xmax, kx[j]); }
+        if (isfinite(kz[j])) { zmin = fminf(zmin, kz[j]); zmax = fmaxf(zmax, kz[j]); }
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        xmin = fminf(xmin, __shfl_xor(xmin, off)); xmax = fmaxf(xmax, __shfl_xor(xmax, off));
+        zmin = fminf(zmin, __shfl_xor(zmin, off)); zmax = fmaxf(zmax, __shfl_xor(zmax, off));
+    }
+    if (lane == 0) { red[0][w] = xmin; red[1][w] = xmax; red[2][w] = zmin; red[3][w] = zmax; }
+    for (int c = t; c < cells; c += TB) hist[c] = 0;
+    __syncthreads();
+    if (t == 0) {
+        for (int i = 1; i < TB / 64; ++i) {
+            xmin = fminf(xmin, red[0][i]); xmax = fmaxf(xmax, red[1][i]);
+            zmin = fminf(zmin, red[2][i]); zmax = fmaxf(zmax, red[3][i]);
+        }
+        if (!(xmin <= xmax)) { xmin = 0.f; xmax = 0.f; }
+        if (!(zmin <= zmax)) { zmin = 0.f; zmax = 0.f; }
+        double ext = fmax((double)xmax - (double)xmin, (double)zmax - (double)zmin);
+        if (!(ext > 1e-6)) ext = 1e-6;
+        const double s = ext / g * (1.0 + 1e-9);
+        gp.x0 = xmin; gp.z0 = zmin; gp.inv_s = 1.0 / s; gp.s = (float)s; gp.g = g;
+        params[b] = gp;
+    }
+    __syncthreads();
+    const double x0 = gp.x0, z0 = gp.z0, inv_s = gp.inv_s;
+    int kc[NK];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        kc[j] = grid_coord(kz[j], z0, inv_s, g) * g + grid_coord(kx[j], x0, inv_s, g);
+        if (j * TB + t < m) atomicAdd(&hist[kc[j]], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the cell counts: each thread owns a contiguous chunk (cells of a grid row must stay contiguous)
+    const int per = (cells + TB - 1) / TB;
+    const int lo = min(t * per, cells), hi = min(lo + per, cells);
+    int sum = 0;
+    for (int c = lo; c < hi; ++c) sum += hist[c];
+    int incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int i = 0; i < w; ++i) base += wsum[i];
+    int *__restrict__ cs = cell_start + (long)b * (TG_MAX * TG_MAX + 1);
+    for (int c = lo; c < hi; ++c) {
+        const int cnt = hist[c];
+        cs[c] = base;
+        hist[c] = base;                    // becomes the scatter cursor
+        base += cnt;
+    }
+    if (t == TB - 1) cs[cells] = m;
+    __syncthreads();
+    float4 *__restrict__ so = sorted + (long)b * m;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        const int k = j * TB + t;
+        if (k < m) so[atomicAdd(&hist[kc[j]], 1)] = make_float4(kx[j], ky[j], kz[j], __int_as_float(k));
+    }
+    if (!order) return;
+
+    // the queries, counting-sorted by the cell they fall into (clamped like the ring search clamps them): order[b][0..n)
+    __syncthreads();
+    for (int c = t; c < cells; c += TB) hist[c] = 0;
+    __syncthreads();
+    int qc[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        qc[j] = grid_coord(qz[j], z0, inv_s, g) * g + grid_coord(qx[j], x0, inv_s, g);
+        if (j * TB + t < n) atomicAdd(&hist[qc[j]], 1);
+    }
+    __syncthreads();
+    sum = 0;
+    for (int c = lo; c < hi; ++c) sum += hist[c];
+    incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    __syncthreads();                           // wsum is rewritten
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    base = incl - sum;
+    for (int i = 0; i < w; ++i) base += wsum[i];
+    for (int c = lo; c < hi; ++c) {
+        const int cnt = hist[c];
+        hist[c] = base;
+        base += cnt;
+    }
+    __syncthreads();
+    int *__restrict__ od = order + (long)b * n;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int k = j * TB + t;
+        if (k < n) od[atomicAdd(&hist[qc[j]], 1)] = k;
+    }
+}
+
 __global__ __launch_bounds__(256) void tnn_query_kernel(int n, int m, const float *__restrict__ unknown,
                                                         const GridParams *__restrict__ params,
                                                         const int *__restrict__ cell_start,
                                                         const float4 *__restrict__ sorted, float *__restrict__ dist2,
-                                                        int *__restrict__ idx, const int *__restrict__ order)
+                                                        int *__restrict__ idx, const int *__restrict__ order,
+                                                        float *__restrict__ weight)
 {
     const int b = blockIdx.y;
     const int slot = blockIdx.x * 256 + threadIdx.x;
@@ -220,17 +360,20 @@ __global__ __launch_bounds__(256) void tnn_query_kernel(int n, int m, const floa
         const float bound = (float)r * gp.s;
         if (b3 < bound * bound * 0.99999f) break;
     }
-    float *od = dist2 + ((long)b * n + p) * 3;
     int *oi = idx + ((long)b * n + p) * 3;
-    od[0] = b1; od[1] = b2; od[2] = b3;
     oi[0] = i1; oi[1] = i2; oi[2] = i3;
+    if (dist2) {
+        float *od = dist2 + ((long)b * n + p) * 3;
+        od[0] = b1; od[1] = b2; od[2] = b3;
+    }
+    if (weight) three_nn_weights(b1, b2, b3, weight + ((long)b * n + p) * 3);
 }
 
 static size_t align_up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // Returns PRCNN_OK or an error; *used = 0 when the grid path declines (caller runs the brute-force scan).
 int three_nn_grid(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
-                  hipStream_t st, int *used)
+                  hipStream_t st, int *used, float *weight)
 {
     *used = 0;
     if (m < 1024 || n < 1024 || m > (1 << 20)) return PRCNN_OK;
@@ -249,10 +392,14 @@ int three_nn_grid(int b, int n, int m, const float *unknown, const float *known,
     int *cs = (int *)(base + o_cs);
     float4 *sorted = (float4 *)(base + o_sorted);
     int *order = ordered ? (int *)(base + o_order) : nullptr;
-    hipLaunchKernelGGL(tnn_build_kernel, dim3(b), dim3(TB), (size_t)g * g * sizeof(int), st, m, g, known, params, cs, sorted,
-                       n, unknown, order);
+    if (m <= 4 * TB && n <= 16 * TB)
+        hipLaunchKernelGGL((tnn_build_reg_kernel<4, 16>), dim3(b), dim3(TB), (size_t)g * g * sizeof(int), st, m, g, known, params, cs,
+                           sorted, n, unknown, order);
+    else
+        hipLaunchKernelGGL(tnn_build_kernel, dim3(b), dim3(TB), (size_t)g * g * sizeof(int), st, m, g, known, params, cs, sorted,
+                           n, unknown, order);
     hipLaunchKernelGGL(tnn_query_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, st, n, m, unknown, params, cs,
-                       sorted, dist2, idx, order);
+                       sorted, dist2, idx, order, weight);
     *used = 1;
     return check_launch("three_nn(grid)");
 }

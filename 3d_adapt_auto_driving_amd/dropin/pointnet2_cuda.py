@@ -98,6 +98,13 @@ def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
               idx.data_ptr(), _lib.current_stream(unknown))
 
 
+def three_nn_weights_wrapper(b, n, m, unknown, known, idx, weight):
+    """three_nn + the FP module's inverse-distance weights in one kernel (engine-side entry, not in the reference's API)"""
+    _chk(torch.float32, unknown, known, weight); _chk(torch.int32, idx)
+    _lib.call("prcnn_three_nn_weights", b, n, m, unknown.data_ptr(), known.data_ptr(), idx.data_ptr(), weight.data_ptr(),
+              _lib.current_stream(unknown))
+
+
 def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
     _chk(torch.float32, points, weight, out); _chk(torch.int32, idx)
     _lib.call("prcnn_three_interpolate", b, c, m, n, points.data_ptr(), idx.data_ptr(),

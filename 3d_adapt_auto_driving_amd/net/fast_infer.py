@@ -377,10 +377,20 @@ class FastPointRCNN:
             self._geometry_level(state, k)
         l_xyz = state["l_xyz"]
         interp = []
+        ext = pu.pointnet2
         for k in range(len(self.fp)):      # FP level k: unknown = l_xyz[k], known = l_xyz[k+1]
-            dist, idx = pu.three_nn(l_xyz[k], l_xyz[k + 1])
-            dist_recip = 1.0 / (dist + 1e-8)
-            weight = (dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)).contiguous()
+            unknown, known = l_xyz[k], l_xyz[k + 1]
+            if has_entry(ext, "three_nn_weights_wrapper"):
+                # neighbours and inverse-distance weights from one kernel (round 4: the weights were sqrt, add, reciprocal, sum and
+                # divide launches of torch, five per FP level on the geometry stream)
+                B, n, m = unknown.shape[0], unknown.shape[1], known.shape[1]
+                idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknown.device)
+                weight = torch.empty((B, n, 3), dtype=torch.float32, device=unknown.device)
+                ext.three_nn_weights_wrapper(B, n, m, unknown, known, idx, weight)
+            else:
+                dist, idx = pu.three_nn(unknown, known)
+                dist_recip = 1.0 / (dist + 1e-8)
+                weight = (dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)).contiguous()
             interp.append((idx, weight))
         return {"l_xyz": l_xyz, "sa": state["sa"], "fp": interp}
 

@@ -92,6 +92,13 @@ int prcnn_fps_new_xyz(int b, int n, int m, const float *xyz, int *idx, float *ne
  * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) SQUARED distances, idx (b,n,3). */
 int prcnn_three_nn(int b, int n, int m, const float *unknown, const float *known,
                    float *dist2, int *idx, void *stream);
+
+/* three_nn followed by the weights of PointnetFPModule.forward (pointnet2_lib/pointnet2/pointnet2_modules.py:139-144;
+ * pointnet2_utils.py:97 takes the square root) in the kernel's epilogue: idx (b,n,3) i32, weight (b,n,3) f32 with
+ * r_k = 1 / (sqrt(dist2_k) + 1e-8), weight_k = r_k / ((r_0 + r_1) + r_2), one rounding per operation.  The engine's form: the
+ * reference's Python runs this as sqrt, add, reciprocal, sum, divide -- five launches per FP level. */
+int prcnn_three_nn_weights(int b, int n, int m, const float *unknown, const float *known, int *idx, float *weight,
+                           void *stream);
 /* three_interpolate_wrapper_fast  src/interpolate.cpp:26-39 -> src/interpolate_gpu.cu:77-97.
  * points (b,c,m), idx/weight (b,n,3) -> out (b,c,n). */
 int prcnn_three_interpolate(int b, int c, int m, int n, const float *points,

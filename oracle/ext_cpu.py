@@ -99,6 +99,18 @@ class pointnet2_cpu:
         O.lib().orc_three_nn(b, n, m, _p(unknown, _f), _p(known, _f), _p(dist2, _f), _p(idx, _i))
 
     @staticmethod
+    def three_nn_weights_wrapper(b, n, m, unknown, known, idx, weight):
+        """orc_three_nn + the weights of pointnet2_modules.py:139-144, one f32 rounding per operation: r = 1 / (sqrt(d2) + 1e-8),
+        w = r / ((r0 + r1) + r2)  (csrc/common.hpp three_nn_weights)"""
+        import numpy as np
+        d2 = torch.empty((b, n, 3), dtype=torch.float32)
+        O.lib().orc_three_nn(b, n, m, _p(unknown, _f), _p(known, _f), _p(d2, _f), _p(idx, _i))
+        one, eps = np.float32(1.0), np.float32(1e-8)
+        r = one / (np.sqrt(d2.numpy()) + eps)
+        s = (r[..., 0] + r[..., 1]) + r[..., 2]
+        weight.copy_(torch.from_numpy((r / s[..., None]).astype(np.float32)))
+
+    @staticmethod
     def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
         O.lib().orc_three_interpolate(b, c, m, n, _p(points, _f), _p(idx, _i), _p(weight, _f), _p(out, _f))
 

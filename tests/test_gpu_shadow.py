@@ -199,6 +199,7 @@ POINTNET2 = {
     "ball_query_wrapper": {7: "exact"},
     "ball_query_limit_wrapper": {8: "exact"},
     "three_nn_wrapper": {5: "exact", 6: "exact"},
+    "three_nn_weights_wrapper": {5: "exact", 6: "exact"},      # round 4: neighbours + inverse-distance weights from one kernel
     "three_interpolate_pm_wrapper": {3: "exact"},
     "three_interpolate_cat_pm_wrapper": {4: "exact"},            # interpolation + concat with the skip features (FP modules 3-1, PRCNN_NO_FP_LINEAR=1)
     "packed_layer_interp_wrapper": {4: "exact"},                 # FP modules 3-1, first layer with the interpolated coarse product in its epilogue
@@ -374,7 +375,7 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
     # coverage: every kernel family of the step was exercised at the batch-8 shapes
     fg = F.USE_ROI_GEOMETRY          # the RoI clouds' FPS / ball query / representative maps of both sampled levels in one launch
     want_calls = {"furthest_point_sampling_wrapper": 4, "fps_new_xyz_wrapper": 0 if fg else 2, "dup_rep_wrapper": 0 if fg else 2,
-                  "ball_query_wrapper": 8 if fg else 9, "ball_query_limit_wrapper": 0 if fg else 1, "rcnn_roi_geometry_wrapper": 1 if fg else 0, "three_nn_wrapper": 4, "ball_pack_wrapper": 11,
+                  "ball_query_wrapper": 8 if fg else 9, "ball_query_limit_wrapper": 0 if fg else 1, "rcnn_roi_geometry_wrapper": 1 if fg else 0, "three_nn_wrapper": 0, "three_nn_weights_wrapper": 4, "ball_pack_wrapper": 11,
                   "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 4,
                   "three_interpolate_cat_pm_wrapper": 0 if F.USE_FP_LINEAR else 3, "packed_layer_interp_wrapper": 3 if F.USE_FP_LINEAR else 0,
                   "rpn_tail_wrapper": 0 if F.USE_FP_LINEAR else 1, "rpn_tail_lin_wrapper": 1 if F.USE_FP_LINEAR else 0, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
