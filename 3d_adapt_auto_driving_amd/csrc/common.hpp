@@ -106,13 +106,13 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
 
 // Interpolation weights of PointnetFPModule.forward (pointnet2_modules.py:139-144) from the three squared distances of three_nn
 // (pointnet2_utils.py:97: the Python wrapper returns sqrt(dist2)): r_k = 1 / (sqrt(d2_k) + 1e-8), w_k = r_k / ((r_0 + r_1) + r_2).
-// One rounding per operation (sqrt, add, divide: all correctly rounded) -- the sequence torch executes as five elementwise /
+// One rounding per operation (sqrtf -- NOT __fsqrt_rn, which compiles to the bare 1-ulp v_sqrt_f32 --, add, divide: all correctly rounded) -- the sequence torch executes as five elementwise /
 // reduction launches per FP level; here it is the epilogue of the three_nn kernels (prcnn_three_nn_weights).
 __device__ __forceinline__ void three_nn_weights(float d0, float d1, float d2, float *__restrict__ w)
 {
-    const float r0 = __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(d0), 1e-8f));
-    const float r1 = __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(d1), 1e-8f));
-    const float r2 = __fdiv_rn(1.0f, __fadd_rn(__fsqrt_rn(d2), 1e-8f));
+    const float r0 = __fdiv_rn(1.0f, __fadd_rn(sqrtf(d0), 1e-8f));
+    const float r1 = __fdiv_rn(1.0f, __fadd_rn(sqrtf(d1), 1e-8f));
+    const float r2 = __fdiv_rn(1.0f, __fadd_rn(sqrtf(d2), 1e-8f));
     const float s = __fadd_rn(__fadd_rn(r0, r1), r2);
     w[0] = __fdiv_rn(r0, s); w[1] = __fdiv_rn(r1, s); w[2] = __fdiv_rn(r2, s);
 }

@@ -82,7 +82,7 @@ __device__ double rinter(const float *r1, const float *r2)
     ctr1 = (float)((double)ctr1 / cnt);
     for (int i = 0; i < cnt; ++i) {
         float v0 = ip[2 * i] - ctr0, v1 = ip[2 * i + 1] - ctr1;
-        const float d = __fsqrt_rn(__fadd_rn(__fmul_rn(v0, v0), __fmul_rn(v1, v1)));
+        const float d = sqrtf(__fadd_rn(__fmul_rn(v0, v0), __fmul_rn(v1, v1)));     // (sqrtf is the correctly rounded one; __fsqrt_rn is the bare v_sqrt_f32)
         v0 = __fdiv_rn(v0, d); v1 = __fdiv_rn(v1, d);
         if (v1 < 0) v0 = -2 - v0;
         vs[i] = v0;

@@ -303,39 +303,29 @@ __global__ __launch_bounds__(TB) void tnn_build_reg_kernel(int m, int g, const f
     }
 }
 
-__global__ __launch_bounds__(256) void tnn_query_kernel(int n, int m, const float *__restrict__ unknown,
-                                                        const GridParams *__restrict__ params,
-                                                        const int *__restrict__ cell_start,
-                                                        const float4 *__restrict__ sorted, float *__restrict__ dist2,
-                                                        int *__restrict__ idx, const int *__restrict__ order,
-                                                        float *__restrict__ weight)
+// one query against one cloud's tables (cs: cell starts, so: known points sorted by cell) -- in global memory or staged in LDS
+template <typename CS, typename SO>
+__device__ __forceinline__ void tnn_search(const GridParams &gp, float ux, float uy, float uz, CS cs, SO so,
+                                           float &b1, float &b2, float &b3, int &i1, int &i2, int &i3)
 {
-    const int b = blockIdx.y;
-    const int slot = blockIdx.x * 256 + threadIdx.x;
-    if (slot >= n) return;
-    const int p = order ? order[(long)b * n + slot] : slot;       // queries in cell order: a wave's lanes are neighbours
-    const GridParams gp = params[b];
     const int g = gp.g;
-    const float *u = unknown + ((long)b * n + p) * 3;
-    const float ux = u[0], uy = u[1], uz = u[2];
     const int ix = grid_coord(ux, gp.x0, gp.inv_s, g), iz = grid_coord(uz, gp.z0, gp.inv_s, g);
-    const int *__restrict__ cs = cell_start + (long)b * (TG_MAX * TG_MAX + 1);
-    const float4 *__restrict__ so = sorted + (long)b * m;
-
-    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
-    int i1 = 0, i2 = 0, i3 = 0;
-    auto take = [&](const float4 pt) {
+    b1 = INFINITY; b2 = INFINITY; b3 = INFINITY;
+    i1 = 0; i2 = 0; i3 = 0;
+    // branch-free insertion into the sorted triple ((b1,i1) <= (b2,i2) <= (b3,i3) lexicographically, so lt1 => lt2 => lt3).  Written
+    // as an if / else-if chain (round 3) the compiler turned the triple into a dynamically indexed STACK array: 141 scratch loads and
+    // 126 scratch stores in the kernel's ISA, every candidate a round trip through scratch memory.
+    auto take = [&](const float4 pt) __attribute__((always_inline)) {
         const int k = __float_as_int(pt.w);
         const float d = sqdist3(ux, uy, uz, pt.x, pt.y, pt.z);
-        if (d < b1 || (d == b1 && k < i1)) {
-            b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k;
-        } else if (d < b2 || (d == b2 && k < i2)) {
-            b3 = b2; i3 = i2; b2 = d; i2 = k;
-        } else if (d < b3 || (d == b3 && k < i3)) {
-            b3 = d; i3 = k;
-        }
+        const bool lt1 = d < b1 || (d == b1 && k < i1);
+        const bool lt2 = d < b2 || (d == b2 && k < i2);
+        const bool lt3 = d < b3 || (d == b3 && k < i3);
+        b3 = lt2 ? b2 : (lt3 ? d : b3); i3 = lt2 ? i2 : (lt3 ? k : i3);
+        b2 = lt1 ? b1 : (lt2 ? d : b2); i2 = lt1 ? i1 : (lt2 ? k : i2);
+        b1 = lt1 ? d : b1;              i1 = lt1 ? k : i1;
     };
-    auto scan = [&](int first, int last) {
+    auto scan = [&](int first, int last) __attribute__((always_inline)) {
         int q = first;
         for (; q + 4 <= last; q += 4) {                             // four independent 16-byte loads in flight
             const float4 p0 = so[q], p1 = so[q + 1], p2 = so[q + 2], p3 = so[q + 3];
@@ -360,6 +350,11 @@ __global__ __launch_bounds__(256) void tnn_query_kernel(int n, int m, const floa
         const float bound = (float)r * gp.s;
         if (b3 < bound * bound * 0.99999f) break;
     }
+}
+
+__device__ __forceinline__ void tnn_store(int b, int n, int p, float b1, float b2, float b3, int i1, int i2, int i3,
+                                          float *__restrict__ dist2, int *__restrict__ idx, float *__restrict__ weight)
+{
     int *oi = idx + ((long)b * n + p) * 3;
     oi[0] = i1; oi[1] = i2; oi[2] = i3;
     if (dist2) {
@@ -367,6 +362,57 @@ __global__ __launch_bounds__(256) void tnn_query_kernel(int n, int m, const floa
         od[0] = b1; od[1] = b2; od[2] = b3;
     }
     if (weight) three_nn_weights(b1, b2, b3, weight + ((long)b * n + p) * 3);
+}
+
+__global__ __launch_bounds__(256) void tnn_query_kernel(int n, int m, const float *__restrict__ unknown,
+                                                        const GridParams *__restrict__ params,
+                                                        const int *__restrict__ cell_start,
+                                                        const float4 *__restrict__ sorted, float *__restrict__ dist2,
+                                                        int *__restrict__ idx, const int *__restrict__ order,
+                                                        float *__restrict__ weight)
+{
+    const int b = blockIdx.y;
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= n) return;
+    const int p = order ? order[(long)b * n + slot] : slot;       // queries in cell order: a wave's lanes are neighbours
+    const GridParams gp = params[b];
+    const float *u = unknown + ((long)b * n + p) * 3;
+    float b1, b2, b3;
+    int i1, i2, i3;
+    tnn_search(gp, u[0], u[1], u[2], cell_start + (long)b * (TG_MAX * TG_MAX + 1), sorted + (long)b * m, b1, b2, b3, i1, i2, i3);
+    tnn_store(b, n, p, b1, b2, b3, i1, i2, i3, dist2, idx, weight);
+}
+
+// The same search with the cloud's tables STAGED IN LDS (round 4; m <= 4096 known points: 64 KB of sorted points + <= 36 KB of cell
+// starts per workgroup of 1024 queries).  A query's ring walk is a chain of dependent loads -- cell starts, then candidates, ring
+// after ring; from global memory each link costs an L2 round trip and a batch of 8 clouds has only 8 waves per CU to hide it
+// behind (62 us for 8 x 16384 queries); from LDS a link is ~100 ns.  Same visiting order, same insertion: same bits.
+__global__ __launch_bounds__(1024) void tnn_query_lds_kernel(int n, int m, const float *__restrict__ unknown,
+                                                             const GridParams *__restrict__ params,
+                                                             const int *__restrict__ cell_start,
+                                                             const float4 *__restrict__ sorted, float *__restrict__ dist2,
+                                                             int *__restrict__ idx, const int *__restrict__ order,
+                                                             float *__restrict__ weight)
+{
+    extern __shared__ float4 tnn_lds[];        // m points, then g*g + 1 cell starts
+    const int b = blockIdx.y, t = threadIdx.x;
+    const GridParams gp = params[b];
+    const int cells1 = gp.g * gp.g + 1;
+    float4 *lpts = tnn_lds;
+    int *lcs = reinterpret_cast<int *>(tnn_lds + m);
+    const float4 *__restrict__ so = sorted + (long)b * m;
+    const int *__restrict__ cs = cell_start + (long)b * (TG_MAX * TG_MAX + 1);
+    for (int i = t; i < m; i += 1024) lpts[i] = so[i];
+    for (int i = t; i < cells1; i += 1024) lcs[i] = cs[i];
+    __syncthreads();
+    const int slot = blockIdx.x * 1024 + t;
+    if (slot >= n) return;
+    const int p = order ? order[(long)b * n + slot] : slot;
+    const float *u = unknown + ((long)b * n + p) * 3;
+    float b1, b2, b3;
+    int i1, i2, i3;
+    tnn_search(gp, u[0], u[1], u[2], lcs, lpts, b1, b2, b3, i1, i2, i3);
+    tnn_store(b, n, p, b1, b2, b3, i1, i2, i3, dist2, idx, weight);
 }
 
 static size_t align_up256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -398,8 +444,16 @@ int three_nn_grid(int b, int n, int m, const float *unknown, const float *known,
     else
         hipLaunchKernelGGL(tnn_build_kernel, dim3(b), dim3(TB), (size_t)g * g * sizeof(int), st, m, g, known, params, cs, sorted,
                            n, unknown, order);
-    hipLaunchKernelGGL(tnn_query_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, st, n, m, unknown, params, cs,
-                       sorted, dist2, idx, order, weight);
+    const size_t qlds = (size_t)m * sizeof(float4) + ((size_t)g * g + 1) * sizeof(int);
+    static const bool no_lds = getenv("PRCNN_TNN_NO_LDS") != nullptr;                  // A/B switch
+    if (!no_lds && qlds <= 128 * 1024 && n >= 2 * m) {
+        const int rc = ensure_dynamic_lds((const void *)tnn_query_lds_kernel, qlds, "three_nn(query)");
+        if (rc != PRCNN_OK) return rc;
+        hipLaunchKernelGGL(tnn_query_lds_kernel, dim3(ceil_div(n, 1024), b), dim3(1024), qlds, st, n, m, unknown, params, cs,
+                           sorted, dist2, idx, order, weight);
+    } else
+        hipLaunchKernelGGL(tnn_query_kernel, dim3(ceil_div(n, 256), b), dim3(256), 0, st, n, m, unknown, params, cs,
+                           sorted, dist2, idx, order, weight);
     *used = 1;
     return check_launch("three_nn(grid)");
 }

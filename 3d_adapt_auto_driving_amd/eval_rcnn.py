@@ -517,10 +517,11 @@ _GRAPH_DEBUG = int(os.environ.get("PRCNN_GRAPH_DEBUG", "0"))   # 1: device sync 
 
 
 def engine_covers(cfg):
-    """Does the point-major engine (net/fast_infer.py) cover this configuration?  It is written for coordinates-only clouds -- every
-    yaml file the reference ships; cfg.RPN.USE_INTENSITY (a 4-channel pts_input, rpn.py:17 / kitti_rcnn_dataset.py:321-338) runs on the
-    nn.Module graph in the reference's operation order over the same HIP operators (ModuleRunner)."""
-    return not bool(cfg.RPN.USE_INTENSITY)
+    """Does the point-major engine (net/fast_infer.py) cover this configuration?  Round 4: cfg.RPN.USE_INTENSITY (a 4-channel
+    pts_input, rpn.py:17 / kitti_rcnn_dataset.py:321-338; the reference's code default, lib/config.py:40) runs on the engine too --
+    on its general kernels, serially (EngineRunner); the stream-pipelined / graph-replayed runners are written for the (B, N, 3)
+    clouds of the shipped configurations.  cfg.RCNN.USE_INTENSITY stays on the nn.Module graph (ModuleRunner)."""
+    return not bool(cfg.RCNN.ENABLED and cfg.RCNN.USE_INTENSITY)
 
 
 _NATIVE_MODULES = None
@@ -588,7 +589,7 @@ class ModuleRunner:
     @torch.no_grad()
     def submit(self, cur, upcoming=None):
         done = self._pending
-        det = infer_batch(self.model, self.cfg, cur)
+        det = self._infer(cur)
         if self.device.type == "cuda":
             stream = torch.cuda.current_stream(self.device)
             det["ready"] = torch.cuda.Event()
@@ -601,11 +602,28 @@ class ModuleRunner:
         done, self._pending = self._pending, None
         return done
 
+    def _infer(self, cur):
+        return infer_batch(self.model, self.cfg, cur)
+
+
+class EngineRunner(ModuleRunner):
+    """The same protocol over the point-major engine, one batch after the other on the caller's stream: configurations the
+    engine covers on its general kernels only (cfg.RPN.USE_INTENSITY)."""
+
+    def __init__(self, model, cfg, device, depth=None):
+        super().__init__(model, cfg, device, depth)
+        self.engine = FastPointRCNN(model, cfg)
+
+    def _infer(self, cur):
+        return infer_batch(self.model, self.cfg, cur, engine=self.engine)
+
 
 def make_runner(model, cfg, device, depth=None):
     """The runner of the product path: hipGraph replay unless PRCNN_GRAPHS=0 (same streams, same kernels, same results)."""
     if not engine_covers(cfg):
         return ModuleRunner(model, cfg, device, depth)
+    if cfg.RPN.USE_INTENSITY:
+        return EngineRunner(model, cfg, device, depth)
     from . import GRAPH_REPLAY_SAFE
     if USE_GRAPHS and not GRAPH_REPLAY_SAFE:
         import warnings

@@ -261,10 +261,16 @@ def _state_version(tensors):
 class FastPointRCNN:
     def __init__(self, model, cfg):
         assert not model.training, "FastPointRCNN is an inference engine: call model.eval() first"
-        if cfg.RPN.USE_INTENSITY:
-            raise NotImplementedError("fast path: per-point input features (cfg.RPN.USE_INTENSITY) are not covered; "
-                                      "eval_rcnn.make_runner() runs such a configuration on the nn.Module graph")
+        if cfg.RCNN.ENABLED and cfg.RCNN.USE_INTENSITY:
+            raise NotImplementedError("fast path: cfg.RCNN.USE_INTENSITY (reflectance as an RCNN input feature) is not covered")
         self.model, self.cfg = model, cfg
+        # per-point input features of the backbone (cfg.RPN.USE_INTENSITY: one reflectance column, rpn.py:17 /
+        # pointnet2_msg.py:151-160; lib/config.py:40 turns it on by default, every shipped yaml turns it off).  Round 4: the
+        # engine takes them on its GENERAL kernels -- SA level 0 groups [xyz | feature] rows (csrc/pointmajor.hip) and runs its
+        # three layers on the layer kernels, the finest FP module gets the features as its skip input (linear-first form) and the
+        # heads run layer by layer; the coordinates-only specialisations (csrc/sa_xyz_mlp.hip, the early SA levels on the
+        # geometry stream, csrc/rpn_tail.hip) are for the shipped configurations.
+        self.in_feat = int(model.rpn.backbone_net.SA_modules[0].mlps[0][0].conv.in_channels) - 3
         self._state = _state_tensors(model)
         self._folded_at = _state_version(self._state)       # BN is folded into the weights HERE: see check_weights()
         rpn = model.rpn
@@ -282,7 +288,7 @@ class FastPointRCNN:
         self.fp = []
         for k, lay in enumerate(folded):
             known = sa_w[-1] if k == len(folded) - 1 else folded[k + 1][-1][0].shape[0]
-            skip = 0 if k == 0 else sa_w[k - 1]
+            skip = self.in_feat if k == 0 else sa_w[k - 1]
             self.fp.append(_Mlp(lay, pad128=PAD128, in_parts=[c for c in (known, skip) if c], pad_out=True))
         self.rpn_cls = _Mlp(_fold_head(rpn.rpn_cls_layer), pad128=PAD128)
         self.rpn_reg = _Mlp(_fold_head(rpn.rpn_reg_layer), pad128=PAD128)
@@ -628,9 +634,10 @@ class FastPointRCNN:
                 self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, idx, mlp, cin, out, col, pack=pack, zeroed=pre)
                 col += mlp.layers[-1][0].shape[1]
 
-    def _backbone(self, xyz, geo, fuse_tail=False):
-        """-> the (B, N, 128) point features; fuse_tail: -> (features, None), or (None, inputs of the fused last stretch)."""
-        l_xyz, l_feat = geo["l_xyz"], [None]
+    def _backbone(self, xyz, geo, fuse_tail=False, feats0=None):
+        """-> the (B, N, 128) point features; fuse_tail: -> (features, None), or (None, inputs of the fused last stretch).
+        feats0: per-point input features (B, N, C padded to 128) of a backbone built with input channels, else None."""
+        l_xyz, l_feat = geo["l_xyz"], [feats0]
         # the packed kernels deliver through atomicMax into zeros: ONE fill for all levels of the backbone (all scales, the padding
         # columns) instead of one per level -- a 5 us launch each on the feature stream
         B = xyz.shape[0]
@@ -706,14 +713,22 @@ class FastPointRCNN:
         """Backbone + RPN heads: everything up to (not including) the proposal layer."""
         cfg = self.cfg
         self.check_weights()
-        if pts_input.shape[-1] != 3:
-            raise NotImplementedError("fast path: per-point input features (USE_INTENSITY) not supported")
-        xyz = pts_input.contiguous()
+        if pts_input.shape[-1] != 3 + self.in_feat:
+            raise ValueError("pts_input has %d channels, the backbone was built for 3 + %d" % (pts_input.shape[-1], self.in_feat))
+        feats0 = None
+        if self.in_feat:
+            xyz = pts_input[..., 0:3].contiguous()
+            # point-major like every feature tensor of the engine, zero-padded to 128 columns (what the FP module's padded
+            # weights expect of each part of its input)
+            feats0 = pts_input.new_zeros((pts_input.shape[0], pts_input.shape[1], _round128(self.in_feat) if PAD128 else self.in_feat))
+            feats0[..., :self.in_feat] = pts_input[..., 3:]
+        else:
+            xyz = pts_input.contiguous()
         if geo is None:
             geo = self.geometry(xyz)
         B, N, _ = xyz.shape
         with self._strictly():
-            feats, tail = self._backbone(xyz, geo, fuse_tail=True)
+            feats, tail = self._backbone(xyz, geo, fuse_tail=True, feats0=feats0)
         if tail is not None:
             # interpolation + FP module 0 + both heads: one kernel, a 64-point tile never leaves LDS (csrc/rpn_tail.hip)
             known_feat, idx, weight = tail

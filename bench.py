@@ -97,21 +97,24 @@ def roofline_query_and_group(dev, reps=20):
     ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     nbytes = B * algorithmic_bytes_qg(N, M, C, NS)
     achieved = nbytes / (ms * 1e-3) / 1e9
-    # HBM traffic cannot be measured from inside the process: it comes from the committed rocprofv3
-    # PMC passes of this same function (profiles/r01_pmc_query_and_group.json; FETCH_SIZE doubled as
-    # MI355X_MICROARCH.md prescribes for gfx950), and is reported only if the shape matches.
-    traffic = None
+    # HBM traffic cannot be measured from inside the process: it comes from the committed rocprofv3 PMC passes over this same
+    # operator with the kernels that run NOW (profiles/r04_pmc_query_and_group.json, produced by profiles/measure_r04.sh:
+    # separate --pmc FETCH_SIZE / WRITE_SIZE passes over profiles/qg_sweep.py, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    # prescribes for gfx950), and is reported only if shape and kernel names match.
+    kernels = "dense_build_reg_kernel<16> + dense_query_kernel + group_cat_lds_kernel<1, true>"
+    traffic = per_kernel = None
+    src = os.path.join("profiles", "r04_pmc_query_and_group.json")
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_query_and_group.json")) as f:
+        with open(os.path.join(ROOT, src)) as f:
             pmc = json.load(f)
-        if pmc.get("algorithmic_bytes_per_launch") == nbytes:
-            traffic = pmc["hbm_traffic_bytes_per_launch"]
+        if pmc.get("algorithmic_bytes_per_launch") == nbytes and pmc.get("kernels") == kernels:
+            traffic, per_kernel = pmc["hbm_traffic_bytes_per_launch"], pmc.get("per_kernel")
     except (OSError, ValueError, KeyError):
         pass
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_source": "profiles/r01_pmc_query_and_group.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
-            "kernel": "prcnn_query_and_group = grid_link_kernel + grid_query_kernel + group_cat_lds_kernel",
+            "traffic_source": (src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over profiles/qg_sweep.py)") if traffic else None,
+            "kernel": "prcnn_query_and_group = " + kernels, "per_kernel_profile": per_kernel,
             "launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": nbytes,
             "shape": {"B": B, "N": N, "M": M, "C": C, "nsample": NS, "radius": R}}
 

@@ -1,7 +1,9 @@
 """Per-kernel durations (rocprofv3 --kernel-trace) and HBM traffic (--pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as
 MI355X_MICROARCH.md prescribes for gfx950, both counters in KB) of profiles/qg_sweep.py, per configuration.
-usage: python profiles/qg_sweep_summarize.py <kernel_trace.csv> <fetch counter_collection.csv> <write counter_collection.csv> [reps]"""
-import collections, csv, os, sys
+usage: python profiles/qg_sweep_summarize.py <kernel_trace.csv> <fetch counter_collection.csv> <write counter_collection.csv> [reps] [json out]
+The JSON (profiles/r04_pmc_query_and_group.json) holds the B = 8, r = 0.2, nsample = 32, C = 128 configuration: bench.py's
+roofline_reference_op reads its traffic from it."""
+import collections, csv, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 CONFIGS = [(B, R, NS, C) for B in (1, 8) for R in (0.1, 0.2, 0.4) for NS in (32, 64) for C in (0, 1, 128)]
@@ -55,6 +57,7 @@ for k, (B, R, NS, C) in enumerate(CONFIGS):
     mine = calls[k * per + 1:(k + 1) * per]
     names = [short(r["Kernel_Name"]) for r in mine[0]]
     tot_d = tot_t = 0.0
+    detail = []
     for j, nm in enumerate(names):
         d = sum((int(c[j]["End_Timestamp"]) - int(c[j]["Start_Timestamp"])) / 1e3 for c in mine) / len(mine)
         f = w = None
@@ -64,8 +67,16 @@ for k, (B, R, NS, C) in enumerate(CONFIGS):
             w = sum(c[j]["v"] for c in write[k * per + 1:(k + 1) * per]) / reps * 1024 / 1e6
         tot_d += d
         tot_t += (f or 0) + (w or 0)
+        detail.append({"kernel": nm, "avg_us": round(d, 1), "fetch_MB_x2": None if f is None else round(f, 2), "write_MB": None if w is None else round(w, 2)})
         print("| %d | %g | %d | %d | `%s` | %.1f | %s | %s | %s |" % (B, R, NS, C, nm, d, "%.2f" % f if f is not None else "-",
                                                                  "%.2f" % w if w is not None else "-", "%.2f" % (f + w) if f is not None and w is not None else "-"))
     a = alg(B, C, NS)
     print("| %d | %g | %d | %d | **sum** (algorithmic %.2f MB) | **%.1f** = %.0f GB/s = %.3f of 8 TB/s | | | %s |" % (
         B, R, NS, C, a / 1e6, tot_d, a / tot_d / 1e3, a / tot_d / 1e3 / 8000, ("**%.2f** = %.2f x algorithmic" % (tot_t, tot_t * 1e6 / a)) if tot_t else "-"))
+    if (B, R, NS, C) == (8, 0.2, 32, 128) and len(sys.argv) > 5 and tot_t:
+        full = {"dense_build_reg_kernel": "dense_build_reg_kernel<16>", "group_cat_lds_kernel": "group_cat_lds_kernel<1, true>"}
+        json.dump({"what": "prcnn_query_and_group, B = 8, N = 16384, M = 4096, C = 128, nsample = 32, r = 0.2: rocprofv3 --kernel-trace averages and "
+                           "--pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE passes over profiles/qg_sweep.py (profiles/measure_r04.sh)",
+                   "kernels": " + ".join(full.get(n, n) for n in names), "algorithmic_bytes_per_launch": a,
+                   "hbm_traffic_bytes_per_launch": int(tot_t * 1e6), "sum_of_kernel_durations_us": round(tot_d, 1), "per_kernel": detail},
+                  open(sys.argv[5], "w"), indent=1)

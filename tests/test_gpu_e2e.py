@@ -42,10 +42,13 @@ def test_tiny_model_with_intensity_gpu_matches_reference_fixture(tmp_path):
     np.testing.assert_allclose(det["rcnn_cls"].cpu().numpy(), g["rcnn_cls"], rtol=0, atol=1e-4)
     assert np.array_equal(det["num"].cpu().numpy(), g["final_num"])
     np.testing.assert_allclose(det["boxes"].cpu().numpy(), g["final_boxes"], rtol=0, atol=1e-4)
+    # round 4: the point-major engine covers the configuration (general kernels; EngineRunner): same fixture, same tolerance
     runner = E.make_runner(model, cfg, DEV)
-    assert isinstance(runner, E.ModuleRunner)
-    with pytest.raises(NotImplementedError):
-        pkg("net.fast_infer").FastPointRCNN(model, cfg)
+    assert isinstance(runner, E.EngineRunner)
+    de = E.infer_batch(model, cfg, torch.from_numpy(g["pts"]).to(DEV), engine=runner.engine)
+    for key, ref in (("rois", "rois"), ("rcnn_cls", "rcnn_cls"), ("rcnn_reg", "rcnn_reg"), ("boxes", "final_boxes"), ("scores", "final_scores")):
+        np.testing.assert_allclose(de[key].cpu().numpy(), g[ref], rtol=0, atol=1e-4)
+    assert np.array_equal(de["num"].cpu().numpy(), g["final_num"])
     src = pkg("kitti_io").SyntheticSource(cfg, 5)
     table, counts = E.eval_scenes(model, cfg, DEV, src, src.ids, batch_size=2, output_dir=str(tmp_path), workers=0)
     assert table.shape[0] == 5 and len(list(tmp_path.glob("*.txt"))) == 5
@@ -256,6 +259,33 @@ def _run_both(model, cfg, pts, eng):
             out.append((ret, E.postprocess(cfg, ret, pts.shape[0])))
     torch.cuda.synchronize()
     return out
+
+
+def test_full_size_engine_with_intensity_equals_module_path():
+    """cfg.RPN.USE_INTENSITY at default.yaml shapes (the reference's CODE default, lib/config.py:40; (B, N, 4) input): the engine on
+    its general kernels against the nn.Module graph, seeded weights, B = 2: every RoI, head output and final box within 1e-4."""
+    import helpers
+    C, E, F, S = pkg("config"), pkg("eval_rcnn"), pkg("net.fast_infer"), pkg("synth")
+    cfg = C.default_eval_cfg()
+    C.merge_into({"RPN": {"USE_INTENSITY": True}}, cfg)
+    model = E.build_model(cfg, "cpu")
+    sd, _ = helpers.seeded_state_dict(model.state_dict(), 1204)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    pts = np.concatenate([S.scenes(2, cfg.RPN.NUM_POINTS, seed0=1204),
+                          np.random.default_rng(5).random((2, cfg.RPN.NUM_POINTS, 1)).astype(np.float32) - np.float32(0.5)], axis=2)
+    x = torch.from_numpy(pts).to(DEV)
+    with torch.no_grad():
+        # centre the segmentation threshold on the 70th percentile of the scores, as the fixtures do
+        raw = model({"pts_input": x})["rpn_cls"]
+        model.rpn.rpn_cls_layer[-1].conv.bias += float(-0.8473 - torch.quantile(raw.view(-1), 0.7))
+    eng = F.FastPointRCNN(model, cfg)
+    assert eng.in_feat == 1
+    (ret_e, det_e), (ret_m, det_m) = _run_both(model, cfg, x, eng)
+    rep = helpers.e2e_report(ret_e, det_e, helpers.e2e_record(ret_m, det_m))
+    print("engine vs module path, USE_INTENSITY (B = 2):\n" + helpers.e2e_text(rep))
+    assert all(r[2] == 0 for r in rep), helpers.e2e_text(rep)
+    assert int(det_m["num"].min()) >= 3
 
 
 def test_full_size_engine_is_complete_deterministic_and_equals_module_path():

@@ -109,6 +109,24 @@ def test_glue_matches_reference_python():
     np.testing.assert_allclose(ic, g["img_corners"], rtol=1e-6, atol=1e-4)
 
 
+def test_engine_with_intensity_matches_reference_fixture_on_cpu(oracle):
+    """cfg.RPN.USE_INTENSITY on the point-major engine (round 4; general kernels), oracle operator backend on CPU tensors, against
+    the fixture recorded from the REFERENCE model in that configuration (g8i)."""
+    from oracle import ext_cpu
+    E, F = pkg("eval_rcnn"), pkg("net.fast_infer")
+    model, cfg, g = tiny_model(intensity=True)
+    with ext_cpu.patch_package():
+        eng = F.FastPointRCNN(model, cfg)
+        assert eng.in_feat == 1
+        det = E.infer_batch(model, cfg, torch.from_numpy(g["pts"]), engine=eng)
+        with pytest.raises(ValueError):
+            eng.rpn_stage(torch.from_numpy(g["pts"][..., :3].copy()))
+    for key, ref in (("rois", "rois"), ("rcnn_cls", "rcnn_cls"), ("rcnn_reg", "rcnn_reg"), ("boxes", "final_boxes"), ("scores", "final_scores")):
+        np.testing.assert_allclose(det[key].numpy(), g[ref], rtol=0, atol=2e-5)
+    assert np.array_equal(det["num"].numpy(), g["final_num"])
+    assert isinstance(E.make_runner(model, cfg, "cpu"), E.EngineRunner)
+
+
 def test_state_dict_layout_default_cfg():
     cfg = pkg("config").default_eval_cfg()
     model = pkg("eval_rcnn").build_model(cfg, "cpu")
@@ -398,14 +416,19 @@ def test_kitti_input_stage(tmp_path):
 
 
 def test_runner_choice_follows_the_configuration():
-    """make_runner: the point-major engine's runners for coordinates-only configurations, the nn.Module graph for cfg.RPN.USE_INTENSITY;
-    ModuleRunner speaks the one-batch-late protocol of the others (here on the CPU with the oracle operator backend)"""
+    """make_runner: the stream-pipelined runners for coordinates-only configurations, the serial EngineRunner for cfg.RPN.USE_INTENSITY
+    (round 4: the engine covers it on its general kernels), the nn.Module graph (ModuleRunner) for what the engine does not cover
+    (cfg.RCNN.USE_INTENSITY); both speak the one-batch-late protocol of the others (here on the CPU with the oracle operator backend)"""
+    import copy
     from oracle import ext_cpu
     E = pkg("eval_rcnn")
     model, cfg, g = tiny_model(intensity=True)
-    assert not E.engine_covers(cfg) and E.engine_covers(pkg("config").default_eval_cfg())
-    runner = E.make_runner(model, cfg, "cpu")
-    assert isinstance(runner, E.ModuleRunner)
+    assert E.engine_covers(cfg) and E.engine_covers(pkg("config").default_eval_cfg())
+    cfg_r = copy.deepcopy(cfg)
+    cfg_r.RCNN.USE_INTENSITY = True
+    assert not E.engine_covers(cfg_r) and type(E.make_runner(model, cfg_r, "cpu")) is E.ModuleRunner
+    assert type(E.make_runner(model, cfg, "cpu")) is E.EngineRunner
+    runner = E.ModuleRunner(model, cfg, "cpu")
     pts = torch.from_numpy(g["pts"])
     with ext_cpu.patch_package():
         assert runner.submit(pts, None) is None
