@@ -41,6 +41,7 @@ SIGNATURES = {
     "prcnn_gather_points": [_I, _I, _I, _I, _P, _P, _P, _P],
     "prcnn_gather_points_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
     "prcnn_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],
+    "prcnn_set_fps_arithmetic": [_I],
     "prcnn_three_nn": [_I, _I, _I, _P, _P, _P, _P, _P],
     "prcnn_three_nn_weights": [_I, _I, _I, _P, _P, _P, _P, _P],
     "prcnn_three_interpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],

@@ -137,9 +137,24 @@ __device__ __forceinline__ void unpack_candidate(unsigned long long w, float &v,
     key = ~(uint32_t)w;
 }
 
+// The squared distance of sampling_gpu.cu:133, `(x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1)`.
+// HIPCC = false: the source's arithmetic, one rounding per operation (the parity contract).
+// HIPCC = true (prcnn_set_fps_arithmetic(1), round 4): the arithmetic of the reference's KERNEL BINARY as hipcc 7.2 builds that file
+// for gfx950 with its default contraction -- read off the disassembly of oracle/_ref/pointnet2_kernels_ref.so, the same in all
+// eleven block-size instantiations: v_pk_mul (dx^2, dz^2), v_fma dy*dy + dx^2, v_add + dz^2, i.e. (fma(dy, dy, dx*dx)) + dz*dz.
+// With it the picks equal the reference kernel's on every cloud of tests/test_gpu_reference_kernels.py, near-ties included.
+template <bool HIPCC>
+__device__ __forceinline__ float fps_dist(float px, float py, float pz, float ox, float oy, float oz)
+{
+    if (!HIPCC) return sqdist3(px, py, pz, ox, oy, oz);
+    const float dx = px - ox, dy = py - oy, dz = pz - oz;
+    return __fadd_rn(__fmaf_rn(dy, dy, __fmul_rn(dx, dx)), __fmul_rn(dz, dz));
+}
+
 struct KeyCodec {
     int log2bs;  // virtual block = 1 << log2bs
     int sh;      // bits reserved for k >> log2bs
+    int hipcc;   // 1: distances as the reference's hipcc-built binary computes them (fps_dist<true>); wave-uniform
     __device__ __forceinline__ uint32_t encode(int k) const
     {
         const uint32_t low = (uint32_t)k & ((1u << log2bs) - 1u);
@@ -215,12 +230,21 @@ __global__ __launch_bounds__(64 * WAVES) void fps_reg_kernel(
         }
         if (nxyz && t == 0) { nxyz[3 * (j - 1)] = ox; nxyz[3 * (j - 1) + 1] = oy; nxyz[3 * (j - 1) + 2] = oz; }
         float lv = -INFINITY;
+        if (kc.hipcc) {
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const float d = sqdist3(px[i], py[i], pz[i], ox, oy, oz);
-            const float d2 = fminf(d, pt[i]);  // min(d, temp[k]) of sampling_gpu.cu:134
-            pt[i] = d2;
-            lv = fmaxf(lv, d2);
+            for (int i = 0; i < PPT; ++i) {
+                const float d2 = fminf(fps_dist<true>(px[i], py[i], pz[i], ox, oy, oz), pt[i]);
+                pt[i] = d2;
+                lv = fmaxf(lv, d2);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const float d = sqdist3(px[i], py[i], pz[i], ox, oy, oz);
+                const float d2 = fminf(d, pt[i]);  // min(d, temp[k]) of sampling_gpu.cu:134
+                pt[i] = d2;
+                lv = fmaxf(lv, d2);
+            }
         }
         float bv = wave_max_f32(lv);
         uint32_t lk = 0xffffffffu;
@@ -406,12 +430,18 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(
         const bool touch = (lane < PPT) && !(lb * 0.99999f >= vmax);   // empty boxes give lb = +inf
         const unsigned long long mask = __ballot(touch);
         if (mask != 0ull) {                                              // wave-uniform
+            if (kc.hipcc) {
 #pragma unroll
-            for (int i = 0; i < PPT; ++i)
-                if ((mask >> i) & 1ull) {
-                    const float d = sqdist3(px[i], py[i], pz[i], ox, oy, oz);
-                    pt[i] = fminf(d, pt[i]);
-                }
+                for (int i = 0; i < PPT; ++i)
+                    if ((mask >> i) & 1ull) pt[i] = fminf(fps_dist<true>(px[i], py[i], pz[i], ox, oy, oz), pt[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PPT; ++i)
+                    if ((mask >> i) & 1ull) {
+                        const float d = sqdist3(px[i], py[i], pz[i], ox, oy, oz);
+                        pt[i] = fminf(d, pt[i]);
+                    }
+            }
             float lv = pt[0];
 #pragma unroll
             for (int i = 1; i < PPT; ++i) lv = fmaxf(lv, pt[i]);
@@ -462,7 +492,8 @@ __global__ __launch_bounds__(1024) void fps_generic_kernel(
         float bv = -1.0f;
         uint32_t bkey = 0xffffffffu;
         for (int k = t; k < n; k += 1024) {
-            const float d = sqdist3(cloud[3 * k], cloud[3 * k + 1], cloud[3 * k + 2], ox, oy, oz);
+            const float d = kc.hipcc ? fps_dist<true>(cloud[3 * k], cloud[3 * k + 1], cloud[3 * k + 2], ox, oy, oz)
+                                     : sqdist3(cloud[3 * k], cloud[3 * k + 1], cloud[3 * k + 2], ox, oy, oz);
             const float d2 = fminf(d, mind[k]);
             mind[k] = d2;
             take_if_better(d2, kc.encode(k), bv, bkey);
@@ -505,6 +536,17 @@ using namespace prcnn;
 
 extern "C" int prcnn_opt_n_threads(int work_size) { return work_size > 0 ? host_opt_n_threads(work_size) : 1; }
 
+// 0 (default): the distance of sampling_gpu.cu:133 with one rounding per source operation (the parity contract: what the source says,
+// whatever a compiler contracts); 1: the arithmetic of the reference's kernel binary as hipcc builds it for gfx950
+// ((fma(dy, dy, dx*dx)) + dz*dz: see fps_dist).  Process-wide, read at launch; applies to every FPS entry point of the library.
+static int g_fps_hipcc = 0;
+extern "C" int prcnn_set_fps_arithmetic(int mode)
+{
+    PRCNN_REQUIRE(mode == 0 || mode == 1, "set_fps_arithmetic: mode %d", mode);
+    g_fps_hipcc = mode;
+    return PRCNN_OK;
+}
+
 extern "C" int prcnn_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp,
                                              int *idx, void *stream)
 {
@@ -516,6 +558,7 @@ extern "C" int prcnn_furthest_point_sampling(int b, int n, int m, const float *x
 
     const int bs = host_opt_n_threads(n);
     KeyCodec kc;
+    kc.hipcc = g_fps_hipcc;
     kc.log2bs = 0;
     while ((1 << kc.log2bs) < bs) ++kc.log2bs;
     const int nq = (n + bs - 1) / bs;  // values of k div bs: 0 .. nq-1
@@ -573,6 +616,7 @@ extern "C" int prcnn_fps_new_xyz(int b, int n, int m, const float *xyz, int *idx
     hipStream_t st = (hipStream_t)stream;
     const int bs = host_opt_n_threads(n);
     KeyCodec kc;
+    kc.hipcc = g_fps_hipcc;
     kc.log2bs = 0;
     while ((1 << kc.log2bs) < bs) ++kc.log2bs;
     const int nq = (n + bs - 1) / bs;
@@ -668,12 +712,21 @@ __device__ __forceinline__ void roi_fps(int n, int m, KeyCodec kc, const float (
             if (i == pi) { ox = vx; oy = vy; oz = vz; }
         }
         float lv = -INFINITY;
+        if (kc.hipcc) {
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const float d = sqdist3(px[i], py[i], pz[i], ox, oy, oz);
-            const float d2 = fminf(d, pt[i]);
-            pt[i] = d2;
-            lv = fmaxf(lv, d2);
+            for (int i = 0; i < PPT; ++i) {
+                const float d2 = fminf(fps_dist<true>(px[i], py[i], pz[i], ox, oy, oz), pt[i]);
+                pt[i] = d2;
+                lv = fmaxf(lv, d2);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const float d = sqdist3(px[i], py[i], pz[i], ox, oy, oz);
+                const float d2 = fminf(d, pt[i]);
+                pt[i] = d2;
+                lv = fmaxf(lv, d2);
+            }
         }
         const float bv = wave_max_f32(lv);
         uint32_t lk = 0xffffffffu;
@@ -853,6 +906,7 @@ extern "C" int prcnn_rcnn_roi_geometry(int b, int n, int m1, float r1, int ns1, 
     auto codec = [](int npts) {
         const int bs = host_opt_n_threads(npts);
         KeyCodec kc;
+        kc.hipcc = g_fps_hipcc;
         kc.log2bs = 0;
         while ((1 << kc.log2bs) < bs) ++kc.log2bs;
         const int nq = (npts + bs - 1) / bs;

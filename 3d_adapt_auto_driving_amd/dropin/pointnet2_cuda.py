@@ -98,6 +98,11 @@ def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
               idx.data_ptr(), _lib.current_stream(unknown))
 
 
+def set_fps_arithmetic(mode):
+    """0: the source's arithmetic (default, the parity contract); 1: the reference's hipcc-built kernel binary's (include/prcnn_hip.h)"""
+    _lib.call("prcnn_set_fps_arithmetic", int(mode))
+
+
 def three_nn_weights_wrapper(b, n, m, unknown, known, idx, weight):
     """three_nn + the FP module's inverse-distance weights in one kernel (engine-side entry, not in the reference's API)"""
     _chk(torch.float32, unknown, known, weight); _chk(torch.int32, idx)

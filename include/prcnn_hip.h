@@ -83,6 +83,14 @@ int prcnn_gather_points_grad(int b, int c, int n, int npoints,
 int prcnn_furthest_point_sampling(int b, int n, int m,
                                   const float *xyz, float *temp, int *idx, void *stream);
 
+/* Which ARITHMETIC the squared distance of sampling_gpu.cu:133 is evaluated in, for every FPS entry point of the library
+ * (process-wide, read at launch).  0 (default): the source's -- (dx*dx + dy*dy) + dz*dz, one rounding per operation: the parity
+ * contract of this build, independent of any compiler's contraction choices.  1: the reference's KERNEL BINARY as hipcc builds
+ * that file for gfx950 -- (fma(dy, dy, dx*dx)) + dz*dz, read off its disassembly: a user who migrates from the hipcc-compiled
+ * reference and wants its picks bit for bit (near-ties included) selects this one.  (What nvcc made of the expression on the
+ * reference's original platform is not observable here; oracle/fma_table.py counts how rarely any contraction moves a pick.) */
+int prcnn_set_fps_arithmetic(int mode);
+
 /* FPS of many small clouds (n <= 1024) with the selected points' coordinates written beside their indices: the result of
  * furthest_point_sample + gather_operation (pointnet2_modules.py:40-46) in one launch (no scratch fill, index cast or gather
  * by the caller).  Same selection, same tie rule as prcnn_furthest_point_sampling. */

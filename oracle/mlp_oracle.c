@@ -210,3 +210,47 @@ void orc_rows_dot(long rows, int K, int n, const float *A, long lda, const float
             out[r * ldo + c] = p[0] + bias[c];
         }
 }
+
+/* K6 (sampling_gpu.cu:93-209) with the distance ARITHMETIC OF THE REFERENCE'S KERNEL BINARY as hipcc 7.2 builds that file for gfx950
+ * (default contraction; read off the disassembly of oracle/_ref/pointnet2_kernels_ref.so, the same in all eleven block-size
+ * instantiations):  d = (fma(dy, dy, dx*dx)) + dz*dz  -- v_pk_mul (dx^2, dz^2), v_fma, v_add.  Everything else as
+ * orc_furthest_point_sampling_bs (prcnn_oracle.c): per-thread strict '>' scan over k = t, t + bs, ..., tree with strict '>'.
+ * The counterpart of prcnn_set_fps_arithmetic(1); lives in this file because it is built with hardware fmaf. */
+void orc_furthest_point_sampling_hipcc_bs(int b, int n, int m, int bs, const float *xyz, float *temp, int *idx)
+{
+    if (m <= 0) return;
+#pragma omp parallel for
+    for (int bi = 0; bi < b; ++bi) {
+        const float *cloud = xyz + (long)bi * n * 3;
+        float *mind = temp + (long)bi * n;
+        int *sel = idx + (long)bi * m;
+        float *best = (float *)malloc(sizeof(float) * (size_t)bs);
+        int *besti = (int *)malloc(sizeof(int) * (size_t)bs);
+        int old = 0;
+        sel[0] = old;
+        for (int j = 1; j < m; ++j) {
+            const float x1 = cloud[3 * old], y1 = cloud[3 * old + 1], z1 = cloud[3 * old + 2];
+            for (int t = 0; t < bs; ++t) {
+                float bv = -1.0f;
+                int bk = 0;
+                for (int k = t; k < n; k += bs) {
+                    const float dx = cloud[3 * k] - x1, dy = cloud[3 * k + 1] - y1, dz = cloud[3 * k + 2] - z1;
+                    const float dxx = dx * dx, dzz = dz * dz;
+                    const float d = fmaf(dy, dy, dxx) + dzz;
+                    const float d2 = d < mind[k] ? d : mind[k];
+                    mind[k] = d2;
+                    if (d2 > bv) { bv = d2; bk = k; }
+                }
+                best[t] = bv;
+                besti[t] = bk;
+            }
+            for (int s = bs >> 1; s >= 1; s >>= 1)
+                for (int t = 0; t < s; ++t)
+                    if (best[t + s] > best[t]) { best[t] = best[t + s]; besti[t] = besti[t + s]; }
+            old = besti[0];
+            sel[j] = old;
+        }
+        free(best);
+        free(besti);
+    }
+}

@@ -145,12 +145,17 @@ def gather_points_grad(grad_out, idx, n):
     return g
 
 
-def furthest_point_sample(xyz, npoint, block_size=None, return_temp=False):
+def furthest_point_sample(xyz, npoint, block_size=None, return_temp=False, hipcc_arithmetic=False):
+    """hipcc_arithmetic: the distance as the reference's kernel binary computes it when hipcc builds sampling_gpu.cu for gfx950
+    ((fma(dy, dy, dx*dx)) + dz*dz, mlp_oracle.c) instead of the source's one-rounding-per-operation contract"""
     xyz = _f32(xyz)
     b, n, _ = xyz.shape
     temp = np.full((b, n), 1e10, np.float32)  # pointnet2_utils.py:26
     idx = np.empty((b, npoint), np.int32)
-    if block_size is None:
+    if hipcc_arithmetic:
+        bs = int(block_size) if block_size is not None else int(lib().orc_opt_n_threads(n))
+        lib().orc_furthest_point_sampling_hipcc_bs(b, n, npoint, bs, _p(xyz, _f), _p(temp, _f), _p(idx, _i))
+    elif block_size is None:
         lib().orc_furthest_point_sampling(b, n, npoint, _p(xyz, _f), _p(temp, _f), _p(idx, _i))
     else:
         lib().orc_furthest_point_sampling_bs(b, n, npoint, int(block_size), _p(xyz, _f), _p(temp, _f), _p(idx, _i))

@@ -49,6 +49,8 @@ void orc_gather_points(int b, int c, int n, int npoints,
 /* K5 sampling_gpu.cu:46-63 */
 void orc_gather_points_grad(int b, int c, int n, int npoints,
                             const float *grad_out, const int *idx, float *grad_points);
+/* K6 with the distance arithmetic of the reference's hipcc-built kernel binary: (fma(dy, dy, dx*dx)) + dz*dz  (mlp_oracle.c) */
+void orc_furthest_point_sampling_hipcc_bs(int b, int n, int m, int bs, const float *xyz, float *temp, int *idx);
 /* K6 sampling_gpu.cu:86-209 with block size = orc_opt_n_threads(n) (dispatch :211-253) */
 void orc_furthest_point_sampling(int b, int n, int m,
                                  const float *xyz, float *temp, int *idx);

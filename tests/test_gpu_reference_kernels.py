@@ -166,6 +166,39 @@ def test_reference_fps_kernel_pins_the_tie_rule_and_the_oracle(ext, oracle):
     assert moved <= 3
 
 
+def test_fps_in_the_reference_binarys_arithmetic_equals_the_reference_kernel_on_every_cloud(ext, oracle):
+    """VERDICT r3 W2 / task 10: with prcnn_set_fps_arithmetic(1) the distance is evaluated as the reference's kernel binary evaluates
+    it when hipcc builds sampling_gpu.cu for gfx950 -- (fma(dy, dy, dx*dx)) + dz*dz, read off the disassembly of
+    oracle/_ref/pointnet2_kernels_ref.so.  Then EVERY pick equals the reference kernel's on all 16 random / LiDAR-shaped clouds of the
+    test above (where the default, contraction-free contract moves at a near-tie on up to 3 of them), on the lattices, and the CPU
+    restatement in that arithmetic (oracle.furthest_point_sample(hipcc_arithmetic=True)) agrees as well.  The default mode is
+    restored and still equals the contraction-free oracle."""
+    ext.pointnet2.set_fps_arithmetic(1)
+    try:
+        for kind, n, m in (("uniform", 16384, 4096), ("lidar", 16384, 4096), ("uniform", 4096, 1024), ("uniform", 512, 128)):
+            xyz = _clouds(kind, 4, n, 830)
+            ref, rtemp = ref_gpu.furthest_point_sample(T(xyz), m)
+            temp = torch.full((4, n), 1e10, device=DEV); sel = torch.empty((4, m), dtype=torch.int32, device=DEV)
+            ext.pointnet2.furthest_point_sampling_wrapper(4, n, m, T(xyz), temp, sel)
+            assert torch.equal(sel, ref), (kind, n, m, int((sel != ref).sum()))
+            assert torch.equal(temp, rtemp), (kind, n, m)                     # the running minima too, bit for bit
+            if n <= 4096:
+                want = oracle.furthest_point_sample(xyz, m, hipcc_arithmetic=True)
+                assert np.array_equal(ref.cpu().numpy(), want), (kind, n, m)
+        # small clouds through the one-wave kernels (the RoI clouds' shapes)
+        xyz = _clouds("uniform", 64, 512, 77)
+        ref, _ = ref_gpu.furthest_point_sample(T(xyz), 128)
+        temp = torch.full((64, 512), 1e10, device=DEV); sel = torch.empty((64, 128), dtype=torch.int32, device=DEV)
+        ext.pointnet2.furthest_point_sampling_wrapper(64, 512, 128, T(xyz), temp, sel)
+        assert torch.equal(sel, ref)
+    finally:
+        ext.pointnet2.set_fps_arithmetic(0)
+    xyz = _clouds("uniform", 2, 4096, 830)
+    temp = torch.full((2, 4096), 1e10, device=DEV); sel = torch.empty((2, 1024), dtype=torch.int32, device=DEV)
+    ext.pointnet2.furthest_point_sampling_wrapper(2, 4096, 1024, T(xyz), temp, sel)
+    assert np.array_equal(sel.cpu().numpy(), oracle.furthest_point_sample(xyz, 1024))
+
+
 def test_reference_three_nn_interpolate_group_gather_kernels_vs_oracle_and_this_build(ext, oracle):
     """K7, K8, K9 (interpolate_gpu.cu), K2, K3 (group_points_gpu.cu), K4, K5 (sampling_gpu.cu) of the reference on the MI355X."""
     rng = np.random.default_rng(840)
