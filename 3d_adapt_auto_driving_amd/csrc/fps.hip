@@ -472,6 +472,221 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(
         if (pk[i] != 0xffffffffu) mind[kc.decode(pk[i])] = pt[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// SPECULATIVE multi-pick FPS (round 4) -- the same picks as the sequential scan, several per exchange.
+//
+// fps_pruned_kernel pays one workgroup-wide exchange (LDS atomic, barrier, LDS read, scalar load of the pivot) per PICK:
+// 0.99 us x 4095 picks = 4.07 ms for 16384 -> 4096, the longest launch of the step and the limiter on LiDAR-shaped scenes.
+// An exchange can decide MORE than one pick.  Let the points be ordered by (running minimum desc, tie key asc) and let
+// g0, g1, ... be the head of that order.  g0 is the next pick.  If adding g0 leaves g1's minimum unchanged
+// (d(g1, g0) >= min(g1)) then g1 is the pick after it -- every other minimum can only have decreased -- and so on: g_q
+// follows as long as it is unchanged by ALL of g0 .. g_{q-1}.  Once the sampled points are dense these heads are the centres
+// of separate holes and rarely interact, so a round decides several picks and the distance updates of all of them run
+// behind ONE barrier.
+//
+// What every wave publishes per round (16 waves, double-buffered LDS table, one barrier per round):
+//   E1 = its best point (value, key, coordinates); E2 = the best point of its OTHER lanes; and a bound B = the largest value
+//   any of its unpublished points can have (third among the lanes' bests, and the second bests of the two publishing lanes).
+// Every wave then merges the 32 published entries the same way (deterministic, redundant): take the best remaining entry g;
+// accept it if it is the first one, or if (a) its value is STRICTLY above max_w B_w -- then every unpublished point of the
+// cloud comes after it in the order -- and (b) none of the pivots accepted in this round is closer to it than its minimum
+// (d < min would change it).  The first entry that fails ends the round.  Accepted pivots update the registers (tile boxes
+// prune as before, against the wave's own maximum), touched waves rebuild their entries, untouched ones re-publish.
+// Same picks, same tie rule, same running minima as the sequential scan, bit for bit (tests/test_gpu_ops.py,
+// tests/test_gpu_reference_kernels.py: lattices and duplicate clouds with thousands of exact ties included).
+// ---------------------------------------------------------------------------------------------
+constexpr int FS_RMAX = 8;      // picks per round at most
+
+template <int PPT>
+__device__ __forceinline__ float fs_pick(const float (&a)[PPT], int slot, int lane)   // a[slot] of `lane`; slot, lane wave-uniform
+{
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i)
+        if (slot == i) r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[i]), lane));
+    return r;
+}
+
+struct FsEntry { float v; uint32_t key; float x, y, z; };
+
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_spec_kernel(
+    int n, int m, KeyCodec kc, const float *__restrict__ xyz, const int *__restrict__ perm,
+    float *__restrict__ temp, int *__restrict__ idx)
+{
+    constexpr int SB = PPT == 16 ? 4 : (PPT == 8 ? 3 : 2);          // slot bits below the tie key
+    __shared__ unsigned long long s_vk[2][32];                       // packed (value, key) of the published entries
+    __shared__ float s_xyz[2][32][3];
+    __shared__ float s_bound[2][16];
+    const int b = blockIdx.x;
+    const float *__restrict__ cloud = xyz + (long)b * n * 3;
+    const int *__restrict__ order = perm + (long)b * n;
+    float *__restrict__ mind = temp + (long)b * n;
+    int *__restrict__ sel = idx + (long)b * m;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    __builtin_amdgcn_s_setprio(3);
+
+    float px[PPT], py[PPT], pz[PPT], pt[PPT];
+    uint32_t pc[PPT];                                                 // (tie key << SB) | slot; ~0 for a slot beyond the cloud
+    float bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY, bz0 = INFINITY, bz1 = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int s = w * (64 * PPT) + i * 64 + lane;                // position in Morton order
+        float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY, z0 = INFINITY, z1 = -INFINITY;
+        if (s < n) {
+            const int k = order[s];
+            px[i] = cloud[3 * k]; py[i] = cloud[3 * k + 1]; pz[i] = cloud[3 * k + 2];
+            pt[i] = mind[k];
+            pc[i] = (kc.encode(k) << SB) | (uint32_t)i;
+            x0 = x1 = px[i]; y0 = y1 = py[i]; z0 = z1 = pz[i];
+        } else {
+            px[i] = py[i] = pz[i] = 0.f;
+            pt[i] = -INFINITY;
+            pc[i] = 0xffffffffu;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            x0 = fminf(x0, __shfl_xor(x0, d, 64)); x1 = fmaxf(x1, __shfl_xor(x1, d, 64));
+            y0 = fminf(y0, __shfl_xor(y0, d, 64)); y1 = fmaxf(y1, __shfl_xor(y1, d, 64));
+            z0 = fminf(z0, __shfl_xor(z0, d, 64)); z1 = fmaxf(z1, __shfl_xor(z1, d, 64));
+        }
+        if (lane == i) { bx0 = x0; bx1 = x1; by0 = y0; by1 = y1; bz0 = z0; bz1 = z1; }
+    }
+
+    // one pivot against the registers: tile boxes prune against `bound`, an upper bound of every running minimum of this wave
+    unsigned long long touched = 0ull;
+    float bound = INFINITY;
+    auto apply = [&](float ox, float oy, float oz) __attribute__((always_inline)) {
+        const float dx = fmaxf(fmaxf(bx0 - ox, ox - bx1), 0.f);
+        const float dy = fmaxf(fmaxf(by0 - oy, oy - by1), 0.f);
+        const float dz = fmaxf(fmaxf(bz0 - oz, oz - bz1), 0.f);
+        const float lb = dx * dx + dy * dy + dz * dz;
+        const unsigned long long mask = __ballot((lane < PPT) && !(lb * 0.99999f >= bound));   // empty boxes give lb = +inf
+        if (mask != 0ull) {
+            touched |= mask;
+            if (kc.hipcc) {
+#pragma unroll
+                for (int i = 0; i < PPT; ++i)
+                    if ((mask >> i) & 1ull) pt[i] = fminf(fps_dist<true>(px[i], py[i], pz[i], ox, oy, oz), pt[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PPT; ++i)
+                    if ((mask >> i) & 1ull) pt[i] = fminf(sqdist3(px[i], py[i], pz[i], ox, oy, oz), pt[i]);
+            }
+        }
+    };
+    if (t == 0) sel[0] = 0;
+    int j = 1;                                                        // picks made so far
+    if (m > 1) apply(cloud[0], cloud[1], cloud[2]);                  // the given start point, index 0
+    FsEntry e1 = {-INFINITY, 0xffffffffu, 0.f, 0.f, 0.f}, e2 = e1;    // this wave's published entries
+    float wB = -INFINITY;
+    touched = ~0ull;                                                  // the entries have to be built
+    int buf = 0;
+    while (j < m) {
+        // ---- 1. this wave's entries: rebuilt when one of its tiles changed
+        if (touched != 0ull) {
+            float bv = -INFINITY, sv = -INFINITY;                     // best and second-best VALUE of this lane
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                sv = fmaxf(sv, fminf(bv, pt[i]));
+                bv = fmaxf(bv, pt[i]);
+            }
+            uint32_t lk = 0xffffffffu;                                // (key, slot) of this lane's best
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const uint32_t c = pt[i] == bv ? pc[i] : 0xffffffffu;
+                lk = c < lk ? c : lk;
+            }
+            // best lane, best of the other lanes, third value
+            const float v1 = wave_max_f32(bv);
+            const uint32_t c1 = wave_min_u32(bv == v1 ? lk : 0xffffffffu);
+            const unsigned long long m1 = __ballot(bv == v1 && lk == c1);
+            const int l1 = m1 ? (int)__builtin_ctzll(m1) : 0;
+            const float bv2 = lane == l1 ? -INFINITY : bv;
+            const float v2 = wave_max_f32(bv2);
+            const uint32_t c2 = wave_min_u32(bv2 == v2 ? lk : 0xffffffffu);
+            const unsigned long long m2 = __ballot(lane != l1 && bv2 == v2 && lk == c2);
+            const int l2 = m2 ? (int)__builtin_ctzll(m2) : l1;
+            const float v3 = wave_max_f32((lane == l1 || lane == l2) ? -INFINITY : bv);
+            const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), l1));
+            const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), l2));
+            wB = fmaxf(v3, fmaxf(s1, s2));
+            bound = v1;
+            const int sl1 = (int)(c1 & ((1u << SB) - 1u)), sl2 = (int)(c2 & ((1u << SB) - 1u));
+            e1.v = v1; e1.key = c1 == 0xffffffffu ? 0xffffffffu : (c1 >> SB);
+            e1.x = fs_pick<PPT>(px, sl1, l1); e1.y = fs_pick<PPT>(py, sl1, l1); e1.z = fs_pick<PPT>(pz, sl1, l1);
+            const bool has2 = m2 != 0ull && c2 != 0xffffffffu;
+            e2.v = has2 ? v2 : -INFINITY; e2.key = has2 ? (c2 >> SB) : 0xffffffffu;
+            e2.x = fs_pick<PPT>(px, sl2, l2); e2.y = fs_pick<PPT>(py, sl2, l2); e2.z = fs_pick<PPT>(pz, sl2, l2);
+        }
+        // ---- 2. publish, one barrier
+        if (lane < 2) {
+            const FsEntry &e = lane == 0 ? e1 : e2;
+            s_vk[buf][2 * w + lane] = pack_candidate(e.v, e.key);
+            s_xyz[buf][2 * w + lane][0] = e.x; s_xyz[buf][2 * w + lane][1] = e.y; s_xyz[buf][2 * w + lane][2] = e.z;
+            if (lane == 0) s_bound[buf][w] = wB;
+        }
+        lds_barrier();
+        // ---- 3. merge: every wave decides the same picks from the same table (lane q < 32 holds entry q)
+        float cv; uint32_t ck;
+        unpack_candidate(s_vk[buf][lane & 31], cv, ck);
+        if (lane >= 32) { cv = -INFINITY; ck = 0xffffffffu; }
+        const float cx = s_xyz[buf][lane & 31][0], cy = s_xyz[buf][lane & 31][1], cz = s_xyz[buf][lane & 31][2];
+        const float gB = wave_max_f32(lane < 16 ? s_bound[buf][lane] : -INFINITY);
+        bool ok = true;                                               // unchanged by the pivots accepted so far in this round
+        const int left = m - j;
+        int r = 0;
+        unsigned long long picked = 0ull;                             // table slots of the accepted entries, 8 bits each; 0xff: point 0
+        bool open = true;
+#pragma unroll
+        for (int q = 0; q < FS_RMAX; ++q) {
+            if (open) {
+                const float v = wave_max_f32(cv);
+                const uint32_t k = wave_min_u32(cv == v ? ck : 0xffffffffu);
+                const unsigned long long mm = __ballot(cv == v && ck == k);
+                const int l = mm ? (int)__builtin_ctzll(mm) : 0;
+                const unsigned long long okm = __ballot(ok);
+                // the first entry of a round IS the sequential scan's pick; a further one has to lie strictly above every unpublished
+                // point (gB) and to be unchanged by the pivots accepted before it in this round
+                const bool valid = !(k == 0xffffffffu || !(v > -1.0f));   // (reference: best starts at -1, besti at 0)
+                const bool take = q == 0 || ((v > gB) && (v > 0.f) && ((okm >> l) & 1ull) && valid);
+                if (take) {
+                    if (t == 0) sel[j + q] = valid ? kc.decode(k) : 0;
+                    picked |= (unsigned long long)(valid ? l : 0xff) << (8 * q);
+                    r = q + 1;
+                    const float nx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), l));
+                    const float ny = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), l));
+                    const float nz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cz), l));
+                    const float d = kc.hipcc ? fps_dist<true>(cx, cy, cz, nx, ny, nz) : sqdist3(cx, cy, cz, nx, ny, nz);
+                    ok = ok && !(d < cv);
+                    if (lane == l) { cv = -INFINITY; ck = 0xffffffffu; }
+                    open = valid && r < left;
+                } else {
+                    open = false;
+                }
+            }
+        }
+        j += r;
+        // ---- 4. running minima against this round's pivots (the last pick of the whole run does not update them: sampling_gpu.cu)
+        const int apply_n = j >= m ? r - 1 : r;
+        touched = 0ull;
+        for (int q = 0; q < apply_n; ++q) {
+            const int l = (int)((picked >> (8 * q)) & 0xffull);
+            float ox, oy, oz;
+            if (l == 0xff) { ox = cloud[0]; oy = cloud[1]; oz = cloud[2]; }
+            else { ox = s_xyz[buf][l][0]; oy = s_xyz[buf][l][1]; oz = s_xyz[buf][l][2]; }
+            ox = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ox)));
+            oy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(oy)));
+            oz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(oz)));
+            apply(ox, oy, oz);
+        }
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < PPT; ++i)
+        if (pc[i] != 0xffffffffu) mind[kc.decode(pc[i] >> SB)] = pt[i];
+}
+
 // Any-n fallback: running minima stay in `temp` (global), one 1024-thread block per cloud.
 __global__ __launch_bounds__(1024) void fps_generic_kernel(
     int n, int m, KeyCodec kc, const float *__restrict__ xyz, float *__restrict__ temp,
@@ -588,6 +803,19 @@ extern "C" int prcnn_furthest_point_sampling(int b, int n, int m, const float *x
         }
         // 16 waves per cloud: 8 waves x 32 points per lane runs 4.98 ms, 4 waves x 64 points 7.7 ms (16384 -> 4096, 4.2-4.3 ms here):
         // the per-iteration update of the touched tiles parallelises over waves, the exchange does not get cheaper with fewer
+        static const bool sequential = getenv("PRCNN_FPS_SEQUENTIAL") != nullptr;          // A/B: one pick per exchange (round 3)
+        if (!sequential) {
+            const void *ss[3] = {(const void *)fps_spec_kernel<4>, (const void *)fps_spec_kernel<8>, (const void *)fps_spec_kernel<16>};
+            if (pad)
+                for (const void *k : ss) {
+                    const int rc = ensure_dynamic_lds(k, pad, "furthest_point_sampling(speculative)");
+                    if (rc != PRCNN_OK) return rc;
+                }
+            if (n <= 4096) hipLaunchKernelGGL((fps_spec_kernel<4>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
+            else if (n <= 8192) hipLaunchKernelGGL((fps_spec_kernel<8>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
+            else hipLaunchKernelGGL((fps_spec_kernel<16>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
+            return check_launch("furthest_point_sampling(speculative)");
+        }
         if (n <= 4096) hipLaunchKernelGGL((fps_pruned_kernel<4, 1024>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
         else if (n <= 8192) hipLaunchKernelGGL((fps_pruned_kernel<8, 1024>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
         else hipLaunchKernelGGL((fps_pruned_kernel<16, 1024>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
