@@ -484,10 +484,10 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(
 // of separate holes and rarely interact, so a round decides several picks and the distance updates of all of them run
 // behind ONE barrier.
 //
-// What every wave publishes per round (16 waves, double-buffered LDS table, one barrier per round):
+// What a wave publishes when its entries changed (16 waves, one LDS table; two barriers per round: table complete / verdict in):
 //   E1 = its best point (value, key, coordinates); E2 = the best point of its OTHER lanes; and a bound B = the largest value
 //   any of its unpublished points can have (third among the lanes' bests, and the second bests of the two publishing lanes).
-// Every wave then merges the 32 published entries the same way (deterministic, redundant): take the best remaining entry g;
+// ONE wave then merges the 32 published entries: take the best remaining entry g;
 // accept it if it is the first one, or if (a) its value is STRICTLY above max_w B_w -- then every unpublished point of the
 // cloud comes after it in the order -- and (b) none of the pivots accepted in this round is closer to it than its minimum
 // (d < min would change it).  The first entry that fails ends the round.  Accepted pivots update the registers (tile boxes
@@ -495,19 +495,23 @@ __global__ __launch_bounds__(THREADS) void fps_pruned_kernel(
 // Same picks, same tie rule, same running minima as the sequential scan, bit for bit (tests/test_gpu_ops.py,
 // tests/test_gpu_reference_kernels.py: lattices and duplicate clouds with thousands of exact ties included).
 // ---------------------------------------------------------------------------------------------
-constexpr int FS_RMAX = 8;      // picks per round at most
+constexpr int FS_RMAX = 16;     // picks per round at most
 
-template <int PPT>
-__device__ __forceinline__ float fs_pick(const float (&a)[PPT], int slot, int lane)   // a[slot] of `lane`; slot, lane wave-uniform
+// coordinates of point (lane l, slot) -- both wave-uniform -- as three v_readlane behind a scalar compare ladder.  (Indexing the
+// register arrays with the uniform slot made the compiler keep scratch copies of px / py / pz once the kernel was at its 128-VGPR
+// limit; a per-lane select chain would cost 3 x PPT VALU instructions per rebuild.)
+template <int PPT, int I = 0>
+__device__ __forceinline__ void fs_pick3(const float (&px)[PPT], const float (&py)[PPT], const float (&pz)[PPT], int slot, int l,
+                                         float &x, float &y, float &z)
 {
-    float r = 0.f;
-#pragma unroll
-    for (int i = 0; i < PPT; ++i)
-        if (slot == i) r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[i]), lane));
-    return r;
+    if (slot == I) {
+        x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[I]), l));
+        y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[I]), l));
+        z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[I]), l));
+    } else if constexpr (I + 1 < PPT) {
+        fs_pick3<PPT, I + 1>(px, py, pz, slot, l, x, y, z);
+    }
 }
-
-struct FsEntry { float v; uint32_t key; float x, y, z; };
 
 template <int PPT>
 __global__ __launch_bounds__(1024) void fps_spec_kernel(
@@ -515,9 +519,10 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
     float *__restrict__ temp, int *__restrict__ idx)
 {
     constexpr int SB = PPT == 16 ? 4 : (PPT == 8 ? 3 : 2);          // slot bits below the tie key
-    __shared__ unsigned long long s_vk[2][32];                       // packed (value, key) of the published entries
-    __shared__ float s_xyz[2][32][3];
-    __shared__ float s_bound[2][16];
+    __shared__ unsigned long long s_vk[32];                          // packed (value, key) of the published entries
+    __shared__ float s_xyz[32][3];
+    __shared__ float s_bound[16];
+    __shared__ float s_res[64];                                      // the round's verdict: [0] = number of picks, [1 + 3 q ..] = pivot q
     const int b = blockIdx.x;
     const float *__restrict__ cloud = xyz + (long)b * n * 3;
     const int *__restrict__ order = perm + (long)b * n;
@@ -578,10 +583,7 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
     if (t == 0) sel[0] = 0;
     int j = 1;                                                        // picks made so far
     if (m > 1) apply(cloud[0], cloud[1], cloud[2]);                  // the given start point, index 0
-    FsEntry e1 = {-INFINITY, 0xffffffffu, 0.f, 0.f, 0.f}, e2 = e1;    // this wave's published entries
-    float wB = -INFINITY;
     touched = ~0ull;                                                  // the entries have to be built
-    int buf = 0;
     while (j < m) {
         // ---- 1. this wave's entries: rebuilt when one of its tiles changed
         if (touched != 0ull) {
@@ -610,37 +612,38 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
             const float v3 = wave_max_f32((lane == l1 || lane == l2) ? -INFINITY : bv);
             const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), l1));
             const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), l2));
-            wB = fmaxf(v3, fmaxf(s1, s2));
+            const float wB = fmaxf(v3, fmaxf(s1, s2));
             bound = v1;
             const int sl1 = (int)(c1 & ((1u << SB) - 1u)), sl2 = (int)(c2 & ((1u << SB) - 1u));
-            e1.v = v1; e1.key = c1 == 0xffffffffu ? 0xffffffffu : (c1 >> SB);
-            e1.x = fs_pick<PPT>(px, sl1, l1); e1.y = fs_pick<PPT>(py, sl1, l1); e1.z = fs_pick<PPT>(pz, sl1, l1);
             const bool has2 = m2 != 0ull && c2 != 0xffffffffu;
-            e2.v = has2 ? v2 : -INFINITY; e2.key = has2 ? (c2 >> SB) : 0xffffffffu;
-            e2.x = fs_pick<PPT>(px, sl2, l2); e2.y = fs_pick<PPT>(py, sl2, l2); e2.z = fs_pick<PPT>(pz, sl2, l2);
+            // ---- 2. publish (only a wave whose entries changed writes: the table keeps the others'): lane 0 the best point, lane 1
+            // the best point of the other lanes
+            float x1 = 0.f, y1 = 0.f, z1 = 0.f, x2 = 0.f, y2 = 0.f, z2 = 0.f;
+            fs_pick3<PPT>(px, py, pz, __builtin_amdgcn_readfirstlane(sl1), l1, x1, y1, z1);
+            fs_pick3<PPT>(px, py, pz, __builtin_amdgcn_readfirstlane(sl2), l2, x2, y2, z2);
+            const float ex = lane == 0 ? x1 : x2, ey = lane == 0 ? y1 : y2, ez = lane == 0 ? z1 : z2;
+            if (lane < 2) {
+                const float ev = lane == 0 ? v1 : (has2 ? v2 : -INFINITY);
+                const uint32_t ek = lane == 0 ? (c1 == 0xffffffffu ? 0xffffffffu : (c1 >> SB)) : (has2 ? (c2 >> SB) : 0xffffffffu);
+                s_vk[2 * w + lane] = pack_candidate(ev, ek);
+                s_xyz[2 * w + lane][0] = ex; s_xyz[2 * w + lane][1] = ey; s_xyz[2 * w + lane][2] = ez;
+                if (lane == 0) s_bound[w] = wB;
+            }
         }
-        // ---- 2. publish, one barrier
-        if (lane < 2) {
-            const FsEntry &e = lane == 0 ? e1 : e2;
-            s_vk[buf][2 * w + lane] = pack_candidate(e.v, e.key);
-            s_xyz[buf][2 * w + lane][0] = e.x; s_xyz[buf][2 * w + lane][1] = e.y; s_xyz[buf][2 * w + lane][2] = e.z;
-            if (lane == 0) s_bound[buf][w] = wB;
-        }
-        lds_barrier();
-        // ---- 3. merge: every wave decides the same picks from the same table (lane q < 32 holds entry q)
-        float cv; uint32_t ck;
-        unpack_candidate(s_vk[buf][lane & 31], cv, ck);
-        if (lane >= 32) { cv = -INFINITY; ck = 0xffffffffu; }
-        const float cx = s_xyz[buf][lane & 31][0], cy = s_xyz[buf][lane & 31][1], cz = s_xyz[buf][lane & 31][2];
-        const float gB = wave_max_f32(lane < 16 ? s_bound[buf][lane] : -INFINITY);
-        bool ok = true;                                               // unchanged by the pivots accepted so far in this round
+        lds_barrier();                                                // A: the table is complete
+        // ---- 3. merge, by ONE wave (every wave doing it costs the other fifteen 5 x 45 VALU instructions per round: the kernel was
+        // issue-bound with it, 5.2 ms against the sequential kernel's 4.2); the others wait at B
         const int left = m - j;
-        int r = 0;
-        unsigned long long picked = 0ull;                             // table slots of the accepted entries, 8 bits each; 0xff: point 0
-        bool open = true;
-#pragma unroll
-        for (int q = 0; q < FS_RMAX; ++q) {
-            if (open) {
+        if (w == 0) {
+            float cv; uint32_t ck;
+            unpack_candidate(s_vk[lane & 31], cv, ck);
+            if (lane >= 32) { cv = -INFINITY; ck = 0xffffffffu; }
+            const float cx = s_xyz[lane & 31][0], cy = s_xyz[lane & 31][1], cz = s_xyz[lane & 31][2];
+            const float gB = wave_max_f32(lane < 16 ? s_bound[lane] : -INFINITY);
+            bool ok = true;                                           // unchanged by the pivots accepted so far in this round
+            int r = 0;
+            float res = 0.f;                                          // lane 1 + 3 q + c collects coordinate c of pivot q
+            for (int q = 0; q < FS_RMAX; ++q) {
                 const float v = wave_max_f32(cv);
                 const uint32_t k = wave_min_u32(cv == v ? ck : 0xffffffffu);
                 const unsigned long long mm = __ballot(cv == v && ck == k);
@@ -650,37 +653,37 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
                 // point (gB) and to be unchanged by the pivots accepted before it in this round
                 const bool valid = !(k == 0xffffffffu || !(v > -1.0f));   // (reference: best starts at -1, besti at 0)
                 const bool take = q == 0 || ((v > gB) && (v > 0.f) && ((okm >> l) & 1ull) && valid);
-                if (take) {
-                    if (t == 0) sel[j + q] = valid ? kc.decode(k) : 0;
-                    picked |= (unsigned long long)(valid ? l : 0xff) << (8 * q);
-                    r = q + 1;
-                    const float nx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), l));
-                    const float ny = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), l));
-                    const float nz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cz), l));
-                    const float d = kc.hipcc ? fps_dist<true>(cx, cy, cz, nx, ny, nz) : sqdist3(cx, cy, cz, nx, ny, nz);
-                    ok = ok && !(d < cv);
-                    if (lane == l) { cv = -INFINITY; ck = 0xffffffffu; }
-                    open = valid && r < left;
-                } else {
-                    open = false;
-                }
+                if (!take) break;
+                if (lane == 0) sel[j + q] = valid ? kc.decode(k) : 0;
+                float nx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), l));
+                float ny = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), l));
+                float nz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cz), l));
+                if (!valid) { nx = cloud[0]; ny = cloud[1]; nz = cloud[2]; }
+                if (lane == 1 + 3 * q) res = nx;
+                if (lane == 2 + 3 * q) res = ny;
+                if (lane == 3 + 3 * q) res = nz;
+                r = q + 1;
+                if (!valid || r >= left) break;
+                const float d = kc.hipcc ? fps_dist<true>(cx, cy, cz, nx, ny, nz) : sqdist3(cx, cy, cz, nx, ny, nz);
+                ok = ok && !(d < cv);
+                if (lane == l) { cv = -INFINITY; ck = 0xffffffffu; }
             }
+            if (lane == 0) res = __int_as_float(r);
+            s_res[lane] = res;
         }
-        j += r;
+        lds_barrier();                                                // B: the verdict is in
         // ---- 4. running minima against this round's pivots (the last pick of the whole run does not update them: sampling_gpu.cu)
+        const float rv = s_res[lane];
+        const int r = __builtin_amdgcn_readfirstlane(__float_as_int(rv));
+        j += r;
         const int apply_n = j >= m ? r - 1 : r;
         touched = 0ull;
         for (int q = 0; q < apply_n; ++q) {
-            const int l = (int)((picked >> (8 * q)) & 0xffull);
-            float ox, oy, oz;
-            if (l == 0xff) { ox = cloud[0]; oy = cloud[1]; oz = cloud[2]; }
-            else { ox = s_xyz[buf][l][0]; oy = s_xyz[buf][l][1]; oz = s_xyz[buf][l][2]; }
-            ox = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ox)));
-            oy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(oy)));
-            oz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(oz)));
+            const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 1 + 3 * q));
+            const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 2 + 3 * q));
+            const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 3 + 3 * q));
             apply(ox, oy, oz);
         }
-        buf ^= 1;
     }
 #pragma unroll
     for (int i = 0; i < PPT; ++i)
