@@ -558,15 +558,23 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
         if (lane == i) { bx0 = x0; bx1 = x1; by0 = y0; by1 = y1; bz0 = z0; bz1 = z1; }
     }
 
-    // one pivot against the registers: tile boxes prune against `bound`, an upper bound of every running minimum of this wave
+    // every group of PPT lanes holds the PPT tile boxes (lane -> tile lane % PPT): 64 / PPT pivots are box-tested per pass
+    constexpr int GP = 64 / PPT;
+    bx0 = __shfl(bx0, lane & (PPT - 1), 64); bx1 = __shfl(bx1, lane & (PPT - 1), 64);
+    by0 = __shfl(by0, lane & (PPT - 1), 64); by1 = __shfl(by1, lane & (PPT - 1), 64);
+    bz0 = __shfl(bz0, lane & (PPT - 1), 64); bz1 = __shfl(bz1, lane & (PPT - 1), 64);
+    // pivots against the registers: tile boxes prune against `bound`, an upper bound of every running minimum of this wave
     unsigned long long touched = 0ull;
     float bound = INFINITY;
-    auto apply = [&](float ox, float oy, float oz) __attribute__((always_inline)) {
+    // which tiles can a pivot (per lane group: ox, oy, oz differ by group) change?  bit g * PPT + i: tile i, the group's pivot
+    auto box_mask = [&](float ox, float oy, float oz, bool live) __attribute__((always_inline)) {
         const float dx = fmaxf(fmaxf(bx0 - ox, ox - bx1), 0.f);
         const float dy = fmaxf(fmaxf(by0 - oy, oy - by1), 0.f);
         const float dz = fmaxf(fmaxf(bz0 - oz, oz - bz1), 0.f);
         const float lb = dx * dx + dy * dy + dz * dz;
-        const unsigned long long mask = __ballot((lane < PPT) && !(lb * 0.99999f >= bound));   // empty boxes give lb = +inf
+        return __ballot(live && !(lb * 0.99999f >= bound));           // empty boxes give lb = +inf
+    };
+    auto update = [&](float ox, float oy, float oz, unsigned long long mask) __attribute__((always_inline)) {
         if (mask != 0ull) {
             touched |= mask;
             if (kc.hipcc) {
@@ -582,7 +590,10 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
     };
     if (t == 0) sel[0] = 0;
     int j = 1;                                                        // picks made so far
-    if (m > 1) apply(cloud[0], cloud[1], cloud[2]);                  // the given start point, index 0
+    if (m > 1) {                                                      // the given start point, index 0
+        const float ox = cloud[0], oy = cloud[1], oz = cloud[2];
+        update(ox, oy, oz, box_mask(ox, oy, oz, lane < PPT));
+    }
     touched = ~0ull;                                                  // the entries have to be built
     while (j < m) {
         // ---- 1. this wave's entries: rebuilt when one of its tiles changed
@@ -631,45 +642,48 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
             }
         }
         lds_barrier();                                                // A: the table is complete
-        // ---- 3. merge, by ONE wave (every wave doing it costs the other fifteen 5 x 45 VALU instructions per round: the kernel was
-        // issue-bound with it, 5.2 ms against the sequential kernel's 4.2); the others wait at B
+        // ---- 3. merge, by ONE wave (every wave doing it -- the first version -- made the kernel issue-bound: 5.2 ms against the
+        // sequential kernel's 4.2); the others wait at B
         const int left = m - j;
         if (w == 0) {
+            // all 32 x 32 pairs at once: lane = (entry i = lane & 31, half h = lane >> 5) walks the 16 entries e of its half; entry i's
+            // RANK = how many entries precede it in the order (value desc, key asc); it is BLOCKED if an entry that precedes it lies
+            // closer than its running minimum.  The picks of the round are the ranks 0 .. r-1 up to the first rank that fails.
+            const int i = lane & 31, h = lane >> 5;
+            const unsigned long long pki = s_vk[i];
             float cv; uint32_t ck;
-            unpack_candidate(s_vk[lane & 31], cv, ck);
-            if (lane >= 32) { cv = -INFINITY; ck = 0xffffffffu; }
-            const float cx = s_xyz[lane & 31][0], cy = s_xyz[lane & 31][1], cz = s_xyz[lane & 31][2];
+            unpack_candidate(pki, cv, ck);
+            const float cx = s_xyz[i][0], cy = s_xyz[i][1], cz = s_xyz[i][2];
             const float gB = wave_max_f32(lane < 16 ? s_bound[lane] : -INFINITY);
-            bool ok = true;                                           // unchanged by the pivots accepted so far in this round
-            int r = 0;
-            float res = 0.f;                                          // lane 1 + 3 q + c collects coordinate c of pivot q
-            for (int q = 0; q < FS_RMAX; ++q) {
-                const float v = wave_max_f32(cv);
-                const uint32_t k = wave_min_u32(cv == v ? ck : 0xffffffffu);
-                const unsigned long long mm = __ballot(cv == v && ck == k);
-                const int l = mm ? (int)__builtin_ctzll(mm) : 0;
-                const unsigned long long okm = __ballot(ok);
-                // the first entry of a round IS the sequential scan's pick; a further one has to lie strictly above every unpublished
-                // point (gB) and to be unchanged by the pivots accepted before it in this round
-                const bool valid = !(k == 0xffffffffu || !(v > -1.0f));   // (reference: best starts at -1, besti at 0)
-                const bool take = q == 0 || ((v > gB) && (v > 0.f) && ((okm >> l) & 1ull) && valid);
-                if (!take) break;
-                if (lane == 0) sel[j + q] = valid ? kc.decode(k) : 0;
-                float nx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), l));
-                float ny = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), l));
-                float nz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cz), l));
-                if (!valid) { nx = cloud[0]; ny = cloud[1]; nz = cloud[2]; }
-                if (lane == 1 + 3 * q) res = nx;
-                if (lane == 2 + 3 * q) res = ny;
-                if (lane == 3 + 3 * q) res = nz;
-                r = q + 1;
-                if (!valid || r >= left) break;
-                const float d = kc.hipcc ? fps_dist<true>(cx, cy, cz, nx, ny, nz) : sqdist3(cx, cy, cz, nx, ny, nz);
-                ok = ok && !(d < cv);
-                if (lane == l) { cv = -INFINITY; ck = 0xffffffffu; }
+            int rank = 0;
+            bool blocked = false;
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int e = 16 * h + it;
+                const unsigned long long pke = s_vk[e];
+                const float ex = s_xyz[e][0], ey = s_xyz[e][1], ez = s_xyz[e][2];
+                const bool before = pke > pki;
+                rank += before ? 1 : 0;
+                const float d = kc.hipcc ? fps_dist<true>(cx, cy, cz, ex, ey, ez) : sqdist3(cx, cy, cz, ex, ey, ez);
+                blocked = blocked || (before && (d < cv));
             }
-            if (lane == 0) res = __int_as_float(r);
-            s_res[lane] = res;
+            rank += __shfl_xor(rank, 32, 64);
+            blocked = blocked || (__shfl_xor(blocked ? 1 : 0, 32, 64) != 0);
+            const bool valid = !(ck == 0xffffffffu || !(cv > -1.0f));      // (reference: best starts at -1, besti at 0)
+            const bool pass = rank == 0 ? true : ((cv > gB) && (cv > 0.f) && valid && !blocked);
+            // a round ends behind an invalid first entry (the reference then picks index 0: every running minimum is below -1 / NaN)
+            const bool stop = !pass || (rank == 0 && !valid);
+            int r = (int)wave_min_u32((stop && !(rank == 0)) ? (uint32_t)rank : ((rank == 0 && !valid) ? 1u : 32u));
+            r = min(min(r, left), FS_RMAX);
+            if (r < 1) r = 1;
+            if (h == 0 && rank < r) {
+                sel[j + rank] = valid ? kc.decode(ck) : 0;
+                const bool v0 = valid;
+                s_res[1 + 3 * rank] = v0 ? cx : cloud[0];
+                s_res[2 + 3 * rank] = v0 ? cy : cloud[1];
+                s_res[3 + 3 * rank] = v0 ? cz : cloud[2];
+            }
+            if (lane == 0) s_res[0] = __int_as_float(r);
         }
         lds_barrier();                                                // B: the verdict is in
         // ---- 4. running minima against this round's pivots (the last pick of the whole run does not update them: sampling_gpu.cu)
@@ -678,11 +692,24 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
         j += r;
         const int apply_n = j >= m ? r - 1 : r;
         touched = 0ull;
-        for (int q = 0; q < apply_n; ++q) {
-            const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 1 + 3 * q));
-            const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 2 + 3 * q));
-            const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 3 + 3 * q));
-            apply(ox, oy, oz);
+        for (int q0 = 0; q0 < apply_n; q0 += GP) {
+            // lane group g tests pivot q0 + g against the PPT tile boxes
+            const int qg = q0 + lane / PPT;
+            const int src = 1 + 3 * min(qg, FS_RMAX - 1);
+            const float gx = __shfl(rv, src, 64), gy = __shfl(rv, src + 1, 64), gz = __shfl(rv, src + 2, 64);
+            const unsigned long long masks = box_mask(gx, gy, gz, qg < apply_n);
+            if (masks == 0ull) continue;
+#pragma unroll
+            for (int g = 0; g < GP; ++g) {
+                const unsigned long long mk = (masks >> (g * PPT)) & ((PPT == 64) ? ~0ull : ((1ull << PPT) - 1ull));
+                if (mk != 0ull) {
+                    const int q = q0 + g;
+                    const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 1 + 3 * q));
+                    const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 2 + 3 * q));
+                    const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 3 + 3 * q));
+                    update(ox, oy, oz, mk);
+                }
+            }
         }
     }
 #pragma unroll
