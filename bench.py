@@ -350,12 +350,13 @@ def cpu_baseline(cfg, budget_s=30.0):
 
 
 def roofline_fps(dev, reps=3):
-    """The LONGEST launch of the step (23 % of all kernel time in round 2's trace, on a side stream, one launch per group of
-    4 batches): furthest point sampling 16384 -> 4096 over the 32 clouds of a geometry group.  A serial chain: M - 1
-    dependent iterations per cloud, one workgroup per cloud.  Reported as time per dependent iteration against the measured
-    floor of the loop skeleton (0.69 us: scalar pivot load, box test, one LDS atomic, one barrier, one LDS read),
-    and, for completeness, on its algorithmic bytes (12 N + 4 M per cloud) against HBM -- a latency-bound kernel is far
-    from any bandwidth roofline by construction."""
+    """The LONGEST launch of the step (on a side stream, one launch per group of 4 batches): furthest point sampling
+    16384 -> 4096 over the 32 clouds of a geometry group, one workgroup per cloud.  A chain of M - 1 dependent picks; since
+    round 4 a workgroup exchange decides SEVERAL of them (csrc/fps.hip fps_spec_kernel: ~5.5 picks per round on the uniform
+    scene, ~4.4 on LiDAR-shaped ones).  Reported as time per pick beside the floor of the one-pick-per-exchange skeleton
+    (0.69 us: scalar pivot load, box test, one LDS atomic, one barrier, one LDS read) that round 3's kernel ran at 0.99 us
+    against, and, for completeness, on its algorithmic bytes (12 N + 4 M per cloud) against HBM -- a latency-bound kernel is
+    far from any bandwidth roofline by construction."""
     pkg = importlib.import_module(PKG)
     if pkg.DROPIN_DIR not in sys.path:
         sys.path.insert(0, pkg.DROPIN_DIR)
@@ -377,9 +378,13 @@ def roofline_fps(dev, reps=3):
     ms = float(np.mean([a.elapsed_time(e) for a, e in evs]))
     nbytes = B * (12 * N + 4 * M)
     achieved = nbytes / (ms * 1e-3) / 1e9
-    return {"bound": "latency", "kernel": "fps_pruned_kernel<16,1024> (+ fps_order_kernel), %d clouds per launch" % B,
-            "launch_ms": round(ms, 4), "us_per_dependent_iteration": round(ms * 1e3 / (M - 1), 4), "skeleton_floor_us": 0.69,
-            "frac_of_floor": round(0.69 / (ms * 1e3 / (M - 1)), 4), "algorithmic_bytes_per_launch": nbytes,
+    seq = os.environ.get("PRCNN_FPS_SEQUENTIAL") is not None
+    return {"bound": "latency", "kernel": "%s (+ fps_order_kernel), %d clouds per launch" % (
+                "fps_pruned_kernel<16,1024>: one pick per workgroup exchange" if seq else
+                "fps_spec_kernel<16>: speculative multi-pick (round 4), several exact picks per workgroup exchange", B),
+            "launch_ms": round(ms, 4), "us_per_pick": round(ms * 1e3 / (M - 1), 4),
+            "sequential_exchange_floor_us": 0.69,      # what ONE pick per exchange cannot go below (round 3's kernel: 0.99 us per pick)
+            "algorithmic_bytes_per_launch": nbytes,
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
             "workgroups": B, "cus_held": B, "shape": {"clouds": B, "N": N, "M": M}}
 
