@@ -89,8 +89,27 @@ __device__ __forceinline__ RBox make_rbox(const float *p)
     return r;
 }
 
+// where the clipped polygon's vertices live while they are collected, sorted and summed.  The reference keeps them in local arrays
+// (iou3d_kernel.cu:129-131) that are indexed with run-time counts: on gfx950 such arrays go to SCRATCH memory (208 bytes per thread,
+// every access a trip through the vector memory pipe).  PolyLds puts them into LDS instead, element k of thread t at [k][t]
+// (conflict-free across a wave), for the kernels on the step's critical path; PolyPriv is the local-array form.
+struct PolyPriv {
+    float px[24], py[24], an[24];
+    __device__ __forceinline__ float &x(int k) { return px[k]; }
+    __device__ __forceinline__ float &y(int k) { return py[k]; }
+    __device__ __forceinline__ float &a(int k) { return an[k]; }
+};
+struct PolyLds {
+    float *base; int stride;                 // base = this thread's first element, stride = threads of the workgroup
+    __device__ __forceinline__ float &x(int k) { return base[(3 * k) * stride]; }
+    __device__ __forceinline__ float &y(int k) { return base[(3 * k + 1) * stride]; }
+    __device__ __forceinline__ float &a(int k) { return base[(3 * k + 2) * stride]; }
+};
+constexpr int POLY_LDS_FLOATS = 72;          // per thread
+
 // iou3d_kernel.cu:108-212
-__device__ float rbox_overlap(const RBox &A, const RBox &B)
+template <class POLY>
+__device__ __forceinline__ float rbox_overlap_in(const RBox &A, const RBox &B, POLY &poly)
 {
     const P2 ca = { (A.v[0] + A.v[2]) / 2, (A.v[1] + A.v[3]) / 2 };
     const P2 cb = { (B.v[0] + B.v[2]) / 2, (B.v[1] + B.v[3]) / 2 };
@@ -106,48 +125,60 @@ __device__ float rbox_overlap(const RBox &A, const RBox &B)
     pa[4] = pa[0];
     pb[4] = pb[0];
 
-    P2 poly[24];
-    float ang[24];
     P2 centre = { 0.f, 0.f };
     int cnt = 0;
+#pragma unroll
     for (int i = 0; i < 4; ++i)
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             P2 hit;
             if (seg_intersection(pa[i + 1], pa[i], pb[j + 1], pb[j], hit)) {
-                poly[cnt] = hit;
+                poly.x(cnt) = hit.x; poly.y(cnt) = hit.y;
                 centre.x = centre.x + hit.x;
                 centre.y = centre.y + hit.y;
                 ++cnt;
             }
         }
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (corner_in_box(A.v, A.cosv, A.sinv, pb[k])) {
             centre.x = centre.x + pb[k].x; centre.y = centre.y + pb[k].y;
-            poly[cnt++] = pb[k];
+            poly.x(cnt) = pb[k].x; poly.y(cnt) = pb[k].y; ++cnt;
         }
         if (corner_in_box(B.v, B.cosv, B.sinv, pa[k])) {
             centre.x = centre.x + pa[k].x; centre.y = centre.y + pa[k].y;
-            poly[cnt++] = pa[k];
+            poly.x(cnt) = pa[k].x; poly.y(cnt) = pa[k].y; ++cnt;
         }
     }
     if (cnt < 3) return 0.f;  // fewer than 3 vertices: the shoelace sum below is exactly 0
     centre.x = __fdiv_rn(centre.x, (float)cnt);
     centre.y = __fdiv_rn(centre.y, (float)cnt);
 
-    for (int i = 0; i < cnt; ++i) ang[i] = atan2_f32(poly[i].y - centre.y, poly[i].x - centre.x);
+    for (int i = 0; i < cnt; ++i) poly.a(i) = atan2_f32(poly.y(i) - centre.y, poly.x(i) - centre.x);
     for (int j = 0; j < cnt - 1; ++j)
-        for (int i = 0; i < cnt - j - 1; ++i)
-            if (ang[i] > ang[i + 1]) {
-                const P2 tp = poly[i]; poly[i] = poly[i + 1]; poly[i + 1] = tp;
-                const float ta = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = ta;
+        for (int i = 0; i < cnt - j - 1; ++i) {
+            const float a0 = poly.a(i), a1 = poly.a(i + 1);
+            if (a0 > a1) {
+                const float tx = poly.x(i), ty = poly.y(i);
+                poly.x(i) = poly.x(i + 1); poly.y(i) = poly.y(i + 1);
+                poly.x(i + 1) = tx; poly.y(i + 1) = ty;
+                poly.a(i) = a1; poly.a(i + 1) = a0;
             }
+        }
     float area = 0.f;
+    const float x0 = poly.x(0), y0 = poly.y(0);
     for (int k = 0; k < cnt - 1; ++k) {
-        const float ux = poly[k].x - poly[0].x, uy = poly[k].y - poly[0].y;
-        const float vx = poly[k + 1].x - poly[0].x, vy = poly[k + 1].y - poly[0].y;
+        const float ux = poly.x(k) - x0, uy = poly.y(k) - y0;
+        const float vx = poly.x(k + 1) - x0, vy = poly.y(k + 1) - y0;
         area = __fadd_rn(area, __fsub_rn(__fmul_rn(ux, vy), __fmul_rn(uy, vx)));
     }
     return fabsf(area) * 0.5f;
+}
+
+__device__ float rbox_overlap(const RBox &A, const RBox &B)
+{
+    PolyPriv poly;
+    return rbox_overlap_in(A, B, poly);
 }
 
 // iou3d_kernel.cu:214-221
@@ -156,6 +187,15 @@ __device__ __forceinline__ float rbox_iou(const RBox &A, const RBox &B)
     const float sa = __fmul_rn(A.v[2] - A.v[0], A.v[3] - A.v[1]);
     const float sb = __fmul_rn(B.v[2] - B.v[0], B.v[3] - B.v[1]);
     const float so = rbox_overlap(A, B);
+    return __fdiv_rn(so, fmaxf(__fsub_rn(__fadd_rn(sa, sb), so), IOU_EPS));
+}
+
+__device__ __forceinline__ float rbox_iou_lds(const RBox &A, const RBox &B, float *scr, int stride)
+{
+    const float sa = __fmul_rn(A.v[2] - A.v[0], A.v[3] - A.v[1]);
+    const float sb = __fmul_rn(B.v[2] - B.v[0], B.v[3] - B.v[1]);
+    PolyLds poly = {scr, stride};
+    const float so = rbox_overlap_in(A, B, poly);
     return __fdiv_rn(so, fmaxf(__fsub_rn(__fadd_rn(sa, sb), so), IOU_EPS));
 }
 
@@ -187,8 +227,8 @@ constexpr int NMS_THREADS = 512;
 constexpr int NMS_MAX_N = 65536;   // removed-bitmask lives in LDS (8 KiB)
 constexpr int NMS_RCH = 8;         // rows per work item
 
-template <bool ROTATED>
-__device__ __forceinline__ bool suppresses(const float *s_row, int r, const RBox &C, float thresh)
+template <bool ROTATED, bool LDS_POLY = false>
+__device__ __forceinline__ bool suppresses(const float *s_row, int r, const RBox &C, float thresh, float *scr = nullptr, int stride = 0)
 {
     if (ROTATED) {
         RBox R;
@@ -196,7 +236,8 @@ __device__ __forceinline__ bool suppresses(const float *s_row, int r, const RBox
         for (int q = 0; q < 5; ++q) R.v[q] = s_row[r * 7 + q];
         R.cosv = s_row[r * 7 + 5];
         R.sinv = s_row[r * 7 + 6];
-        return rbox_iou(R, C) > thresh;  // (row, column) order as nms_kernel :285
+        if constexpr (LDS_POLY) return rbox_iou_lds(R, C, scr, stride) > thresh;
+        else return rbox_iou(R, C) > thresh;  // (row, column) order as nms_kernel :285
     }
     return aabox_iou(&s_row[r * 7], C.v) > thresh;
 }
@@ -407,6 +448,7 @@ __global__ __launch_bounds__(ND_ROWS * ND_LANES) void nms_dense_mask_kernel(
 {
     __shared__ float s_row[ND_ROWS * 7];
     __shared__ unsigned long long s_mask[ND_ROWS][2];
+    __shared__ float s_poly[ROTATED ? POLY_LDS_FLOATS * ND_ROWS * ND_LANES : 1];      // the clipped polygons (72 KB): see PolyLds
     const int prob = blockIdx.y, r0 = blockIdx.x * ND_ROWS;
     int n = counts ? counts[prob] : n_max;
     n = min(max(n, 0), n_max);
@@ -429,7 +471,7 @@ __global__ __launch_bounds__(ND_ROWS * ND_LANES) void nms_dense_mask_kernel(
         unsigned long long w0 = 0ull, w1 = 0ull;
         for (int c = r0 + rl + 1 + cl; c < n; c += ND_LANES) {
             const RBox C = load_col<ROTATED>(boxes + (long)c * 5);
-            if (suppresses<ROTATED>(s_row, rl, C, thresh)) {
+            if (suppresses<ROTATED, ROTATED>(s_row, rl, C, thresh, s_poly + t, ND_ROWS * ND_LANES)) {
                 if (c < 64) w0 |= 1ull << c; else w1 |= 1ull << (c - 64);
             }
         }
