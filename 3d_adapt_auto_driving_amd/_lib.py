@@ -42,6 +42,8 @@ SIGNATURES = {
     "prcnn_gather_points_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
     "prcnn_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],
     "prcnn_set_fps_arithmetic": [_I],
+    "prcnn_ball_query_full": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
+    "prcnn_point_aux": [_L, _F, _P, _P, _P, _P, _P, _P],
     "prcnn_three_nn": [_I, _I, _I, _P, _P, _P, _P, _P],
     "prcnn_three_nn_weights": [_I, _I, _I, _P, _P, _P, _P, _P],
     "prcnn_three_interpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],

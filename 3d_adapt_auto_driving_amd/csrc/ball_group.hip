@@ -385,6 +385,14 @@ extern "C" int prcnn_ball_query(int b, int n, int m, float radius, int nsample,
     return ball_query_dispatch(b, n, m, radius, nsample, new_xyz, xyz, idx, 0, (hipStream_t)stream);
 }
 
+// The same with EVERY slot written: an empty ball gets the zeros the reference's caller-side zero fill would hold (pointnet2_utils.py:218),
+// so the engine need not clear the index tensor first (a fill launch per ball query).
+extern "C" int prcnn_ball_query_full(int b, int n, int m, float radius, int nsample,
+                                     const float *new_xyz, const float *xyz, int *idx, void *stream)
+{
+    return ball_query_dispatch(b, n, m, radius, nsample, new_xyz, xyz, idx, 1, (hipStream_t)stream);
+}
+
 // Ball query over clouds whose points k >= limit[cloud] are known to be COPIES of point k % limit[cloud] (RoI pooling's
 // wrap-around fill, roipool3d_kernel.cu:152-159): only the first limit[cloud] points are scanned.  The idx rows differ from
 // prcnn_ball_query's (slots the full scan fills with copies hold the first hit here) but name the same SET of distinct points

@@ -516,8 +516,10 @@ __device__ __forceinline__ void fs_pick3(const float (&px)[PPT], const float (&p
 template <int PPT>
 __global__ __launch_bounds__(1024) void fps_spec_kernel(
     int n, int m, KeyCodec kc, const float *__restrict__ xyz, const int *__restrict__ perm,
-    float *__restrict__ temp, int *__restrict__ idx)
+    float *__restrict__ temp, int *__restrict__ idx, float *__restrict__ new_xyz)
 {
+    // temp == NULL: the running minima start at the reference caller's fill value (1e10, pointnet2_utils.py:26) and are not handed back;
+    // new_xyz != NULL: the coordinates of the picks are written as well (prcnn_fps_new_xyz: the caller's gather launch folded in)
     constexpr int SB = PPT == 16 ? 4 : (PPT == 8 ? 3 : 2);          // slot bits below the tie key
     __shared__ unsigned long long s_vk[32];                          // packed (value, key) of the published entries
     __shared__ float s_xyz[32][3];
@@ -526,8 +528,9 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
     const int b = blockIdx.x;
     const float *__restrict__ cloud = xyz + (long)b * n * 3;
     const int *__restrict__ order = perm + (long)b * n;
-    float *__restrict__ mind = temp + (long)b * n;
+    float *__restrict__ mind = temp ? temp + (long)b * n : nullptr;
     int *__restrict__ sel = idx + (long)b * m;
+    float *__restrict__ nxyz = new_xyz ? new_xyz + (long)b * m * 3 : nullptr;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     __builtin_amdgcn_s_setprio(3);
 
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
         if (s < n) {
             const int k = order[s];
             px[i] = cloud[3 * k]; py[i] = cloud[3 * k + 1]; pz[i] = cloud[3 * k + 2];
-            pt[i] = mind[k];
+            pt[i] = mind ? mind[k] : 1e10f;
             pc[i] = (kc.encode(k) << SB) | (uint32_t)i;
             x0 = x1 = px[i]; y0 = y1 = py[i]; z0 = z1 = pz[i];
         } else {
@@ -588,7 +591,10 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
             }
         }
     };
-    if (t == 0) sel[0] = 0;
+    if (t == 0) {
+        sel[0] = 0;
+        if (nxyz) { nxyz[0] = cloud[0]; nxyz[1] = cloud[1]; nxyz[2] = cloud[2]; }
+    }
     int j = 1;                                                        // picks made so far
     if (m > 1) {                                                      // the given start point, index 0
         const float ox = cloud[0], oy = cloud[1], oz = cloud[2];
@@ -679,9 +685,9 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
             if (h == 0 && rank < r) {
                 sel[j + rank] = valid ? kc.decode(ck) : 0;
                 const bool v0 = valid;
-                s_res[1 + 3 * rank] = v0 ? cx : cloud[0];
-                s_res[2 + 3 * rank] = v0 ? cy : cloud[1];
-                s_res[3 + 3 * rank] = v0 ? cz : cloud[2];
+                const float ox = v0 ? cx : cloud[0], oy = v0 ? cy : cloud[1], oz = v0 ? cz : cloud[2];
+                s_res[1 + 3 * rank] = ox; s_res[2 + 3 * rank] = oy; s_res[3 + 3 * rank] = oz;
+                if (nxyz) { nxyz[3 * (j + rank)] = ox; nxyz[3 * (j + rank) + 1] = oy; nxyz[3 * (j + rank) + 2] = oz; }
             }
             if (lane == 0) s_res[0] = __int_as_float(r);
         }
@@ -712,9 +718,11 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
             }
         }
     }
+    if (mind) {
 #pragma unroll
-    for (int i = 0; i < PPT; ++i)
-        if (pc[i] != 0xffffffffu) mind[kc.decode(pc[i] >> SB)] = pt[i];
+        for (int i = 0; i < PPT; ++i)
+            if (pc[i] != 0xffffffffu) mind[kc.decode(pc[i] >> SB)] = pt[i];
+    }
 }
 
 // Any-n fallback: running minima stay in `temp` (global), one 1024-thread block per cloud.
@@ -792,13 +800,14 @@ extern "C" int prcnn_set_fps_arithmetic(int mode)
     return PRCNN_OK;
 }
 
-extern "C" int prcnn_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp,
-                                             int *idx, void *stream)
+// new_xyz != NULL (prcnn_fps_new_xyz): only the shapes whose kernels write the coordinates themselves -- the speculative kernel
+// (2048 < n <= 16384, m >= 256) -- come through here with it; temp may then be NULL
+static int fps_any(int b, int n, int m, const float *xyz, float *temp, int *idx, float *new_xyz, void *stream)
 {
     PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "fps: bad sizes b=%d n=%d m=%d", b, n, m);
     if (b == 0 || m == 0) return PRCNN_OK;
     PRCNN_REQUIRE(n > 0, "fps: empty cloud with m=%d", m);
-    PRCNN_REQUIRE(xyz && temp && idx, "fps: null pointer");
+    PRCNN_REQUIRE(xyz && (temp || new_xyz) && idx, "fps: null pointer");
     hipStream_t st = (hipStream_t)stream;
 
     const int bs = host_opt_n_threads(n);
@@ -814,6 +823,8 @@ extern "C" int prcnn_furthest_point_sampling(int b, int n, int m, const float *x
     // large clouds: Morton ordering + pruned scan (exact).  It needs (n ints) of scratch per scene and pays
     // off when the sample count is large enough for the pruning radius to shrink.
     static const bool no_prune = getenv("PRCNN_FPS_NO_PRUNE") != nullptr;
+    static const bool sequential = getenv("PRCNN_FPS_SEQUENTIAL") != nullptr;          // A/B: one pick per exchange (round 3)
+    PRCNN_REQUIRE(!new_xyz || (!no_prune && !sequential && n > 2048 && n <= 16384 && m >= 256), "fps_new_xyz: shape n=%d m=%d not served", n, m);
     if (!no_prune && n > 2048 && n <= 16384 && m >= 256) {
         int *perm = (int *)scratch_for(st, (size_t)b * n * sizeof(int), 1);
         if (!perm) { set_error("fps: cannot allocate ordering scratch"); return PRCNN_ELAUNCH; }
@@ -833,7 +844,6 @@ extern "C" int prcnn_furthest_point_sampling(int b, int n, int m, const float *x
         }
         // 16 waves per cloud: 8 waves x 32 points per lane runs 4.98 ms, 4 waves x 64 points 7.7 ms (16384 -> 4096, 4.2-4.3 ms here):
         // the per-iteration update of the touched tiles parallelises over waves, the exchange does not get cheaper with fewer
-        static const bool sequential = getenv("PRCNN_FPS_SEQUENTIAL") != nullptr;          // A/B: one pick per exchange (round 3)
         if (!sequential) {
             const void *ss[3] = {(const void *)fps_spec_kernel<4>, (const void *)fps_spec_kernel<8>, (const void *)fps_spec_kernel<16>};
             if (pad)
@@ -841,9 +851,9 @@ extern "C" int prcnn_furthest_point_sampling(int b, int n, int m, const float *x
                     const int rc = ensure_dynamic_lds(k, pad, "furthest_point_sampling(speculative)");
                     if (rc != PRCNN_OK) return rc;
                 }
-            if (n <= 4096) hipLaunchKernelGGL((fps_spec_kernel<4>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
-            else if (n <= 8192) hipLaunchKernelGGL((fps_spec_kernel<8>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
-            else hipLaunchKernelGGL((fps_spec_kernel<16>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
+            if (n <= 4096) hipLaunchKernelGGL((fps_spec_kernel<4>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx, new_xyz);
+            else if (n <= 8192) hipLaunchKernelGGL((fps_spec_kernel<8>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx, new_xyz);
+            else hipLaunchKernelGGL((fps_spec_kernel<16>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx, new_xyz);
             return check_launch("furthest_point_sampling(speculative)");
         }
         if (n <= 4096) hipLaunchKernelGGL((fps_pruned_kernel<4, 1024>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
@@ -863,14 +873,22 @@ extern "C" int prcnn_furthest_point_sampling(int b, int n, int m, const float *x
     return check_launch("furthest_point_sampling");
 }
 
+extern "C" int prcnn_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp,
+                                             int *idx, void *stream)
+{
+    PRCNN_REQUIRE(temp || b == 0 || m == 0, "fps: null pointer");
+    return fps_any(b, n, m, xyz, temp, idx, nullptr, stream);
+}
+
 // FPS of many small clouds (n <= 1024: one wave per cloud, everything in registers) with the selected coordinates written
 // alongside the indices: what furthest_point_sample + gather_operation (pointnet2_modules.py:40-46) produce, without the
 // caller's 1e10 fill of the distance scratch, the index cast and the gather launch.  idx (b,m), new_xyz (b,m,3).
 extern "C" int prcnn_fps_new_xyz(int b, int n, int m, const float *xyz, int *idx, float *new_xyz, void *stream)
 {
-    PRCNN_REQUIRE(b >= 0 && n > 0 && m >= 0 && n <= 1024, "fps_new_xyz: b=%d n=%d m=%d (1 <= n <= 1024)", b, n, m);
+    PRCNN_REQUIRE(b >= 0 && n > 0 && m >= 0, "fps_new_xyz: b=%d n=%d m=%d", b, n, m);
     if (b == 0 || m == 0) return PRCNN_OK;
     PRCNN_REQUIRE(xyz && idx && new_xyz, "fps_new_xyz: null pointer");
+    if (n > 1024) return fps_any(b, n, m, xyz, nullptr, idx, new_xyz, stream);      // round 4: the speculative kernel writes them too
     hipStream_t st = (hipStream_t)stream;
     const int bs = host_opt_n_threads(n);
     KeyCodec kc;
@@ -883,7 +901,8 @@ extern "C" int prcnn_fps_new_xyz(int b, int n, int m, const float *xyz, int *idx
     if (n <= 128) launch_reg<1, 2>(b, n, m, kc, xyz, nullptr, idx, st, new_xyz);
     else if (n <= 256) launch_reg<1, 4>(b, n, m, kc, xyz, nullptr, idx, st, new_xyz);
     else if (n <= 512) launch_reg<1, 8>(b, n, m, kc, xyz, nullptr, idx, st, new_xyz);
-    else launch_reg<1, 16>(b, n, m, kc, xyz, nullptr, idx, st, new_xyz);
+    else if (b >= 128) launch_reg<1, 16>(b, n, m, kc, xyz, nullptr, idx, st, new_xyz);
+    else launch_reg<4, 4>(b, n, m, kc, xyz, nullptr, idx, st, new_xyz);             // few clouds: four waves each (as prcnn_furthest_point_sampling)
     return check_launch("fps_new_xyz");
 }
 

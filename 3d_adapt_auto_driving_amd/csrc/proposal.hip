@@ -416,6 +416,35 @@ static size_t aligned(size_t v) { return (v + 255) & ~(size_t)255; }
 
 using namespace prcnn;
 
+// The per-point RCNN inputs of point_rcnn.py:44-52 / rcnn_net.py:131-137 in ONE launch (round 4; torch ran them as six: sigmoid, compare,
+// cast, norm, divide, subtract): seg = sigmoid(score) > thresh as 0 / 1 floats, depth = |xyz|, depth_norm = depth / 70 - 0.5.
+namespace prcnn {
+__global__ __launch_bounds__(256) void point_aux_kernel(long rows, float thresh, const float *__restrict__ scores,
+                                                        const float *__restrict__ xyz, float *__restrict__ seg,
+                                                        float *__restrict__ depth, float *__restrict__ depth_norm)
+{
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float sg = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-scores[r])));
+    seg[r] = sg > thresh ? 1.0f : 0.0f;
+    const float x = xyz[3 * r], y = xyz[3 * r + 1], z = xyz[3 * r + 2];
+    const float d = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+    depth[r] = d;
+    depth_norm[r] = __fsub_rn(__fdiv_rn(d, 70.0f), 0.5f);
+}
+}  // namespace prcnn
+
+extern "C" int prcnn_point_aux(long rows, float thresh, const float *scores, const float *xyz, float *seg, float *depth,
+                               float *depth_norm, void *stream)
+{
+    PRCNN_REQUIRE(rows >= 0, "point_aux: bad sizes");
+    if (rows == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(scores && xyz && seg && depth && depth_norm, "point_aux: null pointer");
+    hipLaunchKernelGGL(point_aux_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, thresh, scores, xyz,
+                       seg, depth, depth_norm);
+    return check_launch("point_aux");
+}
+
 // xyz (b,n,3), scores (b,n) raw RPN scores, reg (b,n,channels) -> rois (b, post_top_n, 7), roi_scores (b, post_top_n)
 // distance-based proposal (RPN_DISTANCE_BASED_PROPOSE), get_y_by_bin = False, get_ry_fine = False.
 extern "C" int prcnn_rpn_proposals(int b, int n, int channels, float loc_scope, float loc_bin_size,

@@ -37,9 +37,29 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     return 1
 
 
+def fps_new_xyz_supported(n, m):
+    """shapes prcnn_fps_new_xyz serves: many small clouds, or the speculative kernel's range"""
+    return n <= 1024 or (2048 < n <= 16384 and m >= 256)
+
+
+def ball_query_full_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+    """ball_query_wrapper with every slot of idx written (an empty ball's row holds zeros): idx may be uninitialised memory"""
+    _chk(torch.float32, new_xyz, xyz); _chk(torch.int32, idx)
+    _lib.call("prcnn_ball_query_full", b, n, m, radius, nsample, new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr(),
+              _lib.current_stream(xyz))
+    return 1
+
+
+def point_aux_wrapper(scores, xyz, thresh, seg, depth, depth_norm):
+    """scores (B,N), xyz (B,N,3) -> seg (B,N) 0/1 floats = sigmoid(score) > thresh, depth (B,N) = |xyz|, depth_norm = depth / 70 - 0.5"""
+    _chk(torch.float32, scores, xyz, seg, depth, depth_norm)
+    _lib.call("prcnn_point_aux", scores.numel(), float(thresh), scores.data_ptr(), xyz.data_ptr(), seg.data_ptr(), depth.data_ptr(),
+              depth_norm.data_ptr(), _lib.current_stream(xyz))
+
+
 def fps_new_xyz_wrapper(xyz, m):
-    """xyz (b,n,3), n <= 1024 -> (idx (b,m) i32, new_xyz (b,m,3)): furthest_point_sampling_wrapper + the gather of the selected
-    coordinates in one launch (csrc/fps.hip)."""
+    """xyz (b,n,3) -> (idx (b,m) i32, new_xyz (b,m,3)): furthest_point_sampling_wrapper + the gather of the selected
+    coordinates in one launch (csrc/fps.hip); shapes: fps_new_xyz_supported."""
     _chk(torch.float32, xyz)
     b, n, _ = xyz.shape
     idx = torch.empty((b, m), dtype=torch.int32, device=xyz.device)

@@ -403,9 +403,22 @@ class FastPointRCNN:
     def _geometry_level(self, state, k):
         npoint, scales = self.sa[k]
         cur = state["l_xyz"][-1]
-        sel = pu.furthest_point_sample(cur, npoint)
-        new_xyz = torch.gather(cur, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
-        idxs = [pu.ball_query(radius, ns, cur, new_xyz) for radius, ns, _, _ in scales]
+        ext = pu.pointnet2
+        if has_entry(ext, "fps_new_xyz_wrapper") and has_entry(ext, "fps_new_xyz_supported") and ext.fps_new_xyz_supported(cur.shape[1], npoint):
+            sel, new_xyz = ext.fps_new_xyz_wrapper(cur, npoint)        # sampling + the centres' coordinates, one launch (round 4: every level)
+        else:
+            sel = pu.furthest_point_sample(cur, npoint)
+            new_xyz = torch.gather(cur, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        if has_entry(ext, "ball_query_full_wrapper"):
+            # every slot written by the kernel: no zero fill in front of each query
+            B_, N_ = cur.shape[0], cur.shape[1]
+            idxs = []
+            for radius, ns, _, _ in scales:
+                ix = torch.empty((B_, npoint, ns), dtype=torch.int32, device=cur.device)
+                ext.ball_query_full_wrapper(B_, N_, npoint, radius, ns, new_xyz, cur, ix)
+                idxs.append(ix)
+        else:
+            idxs = [pu.ball_query(radius, ns, cur, new_xyz) for radius, ns, _, _ in scales]
         lev = {"sel": sel, "new_xyz": new_xyz, "idx": idxs, "pack": [None] * len(scales)}
         if not state.get("defer_packs"):
             self._pack_level(k, cur, lev)
@@ -760,6 +773,14 @@ class FastPointRCNN:
         launches that only the RCNN stage reads: the proposal stage computes them (on ITS stream in the pipelined runner),
         they are off the feature stream's critical path."""
         if "seg_result" not in st:
+            ext = pu.pointnet2
+            if has_entry(ext, "point_aux_wrapper"):
+                # one launch (round 4) instead of sigmoid, compare, cast, norm, divide, subtract
+                sc, xyz = st["rpn_scores_raw"], st["backbone_xyz"]
+                seg, depth, dn = torch.empty_like(sc), torch.empty_like(sc), torch.empty_like(sc)
+                ext.point_aux_wrapper(sc, xyz, float(self.cfg.RPN.SCORE_THRESH), seg, depth, dn)
+                st["seg_result"], st["pts_depth"], st["depth_norm"] = seg, depth, dn
+                return
             st["seg_result"] = (torch.sigmoid(st["rpn_scores_raw"]) > self.cfg.RPN.SCORE_THRESH).float()
             st["pts_depth"] = torch.norm(st["backbone_xyz"], p=2, dim=2)
             st["depth_norm"] = (st["pts_depth"] / 70.0 - 0.5).contiguous()        # the RCNN input feature (rcnn_net.py:131-137)

@@ -47,6 +47,11 @@ int prcnn_opt_n_threads(int work_size);
 int prcnn_ball_query(int b, int n, int m, float radius, int nsample,
                      const float *new_xyz, const float *xyz, int *idx, void *stream);
 
+/* prcnn_ball_query with EVERY slot of idx written: the row of an empty ball holds the zeros the reference's caller fills the tensor
+ * with first (pointnet2_utils.py:218) -- the engine's form (no fill launch in front of each query). */
+int prcnn_ball_query_full(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx,
+                          void *stream);
+
 /* Algorithm selector for ball query (results are identical): 0 = automatic (bucket-sorted hashed grid with a
  * wave per centre for n >= 2048 points -- csrc/ball_dense.hip --, brute-force scan otherwise), 1 = brute-force
  * scan only, 2 = round 1's linked-list hashed grid (n >= 4096) in place of the bucket-sorted one.  For tests /
@@ -91,9 +96,10 @@ int prcnn_furthest_point_sampling(int b, int n, int m,
  * reference's original platform is not observable here; oracle/fma_table.py counts how rarely any contraction moves a pick.) */
 int prcnn_set_fps_arithmetic(int mode);
 
-/* FPS of many small clouds (n <= 1024) with the selected points' coordinates written beside their indices: the result of
- * furthest_point_sample + gather_operation (pointnet2_modules.py:40-46) in one launch (no scratch fill, index cast or gather
- * by the caller).  Same selection, same tie rule as prcnn_furthest_point_sampling. */
+/* FPS with the selected points' coordinates written beside their indices: the result of furthest_point_sample + gather_operation
+ * (pointnet2_modules.py:40-46) in one launch (no scratch fill, index cast or gather by the caller).  Served shapes: n <= 1024 (many small
+ * clouds, a wave or four per cloud) and, since round 4, 2048 < n <= 16384 with m >= 256 (the speculative kernel).  Same selection, same
+ * tie rule as prcnn_furthest_point_sampling. */
 int prcnn_fps_new_xyz(int b, int n, int m, const float *xyz, int *idx, float *new_xyz, void *stream);
 
 /* three_nn_wrapper_fast  src/interpolate.cpp:14-23 -> src/interpolate_gpu.cu:9-52.
@@ -371,6 +377,12 @@ int prcnn_nms_normal(int boxes_num, const float *boxes, long long *keep_host, fl
  * iou_normal.  Asynchronous. */
 int prcnn_nms_device(int nprob, int n_max, const int *counts, const float *boxes, float thresh,
                      int rotated, int max_keep, int *keep, int *num_keep, void *stream);
+
+/* The per-point RCNN inputs of point_rcnn.py:44-52 and rcnn_net.py:131-137 in one launch: seg[r] = sigmoid(scores[r]) > thresh ? 1 : 0,
+ * depth[r] = |xyz[r]|, depth_norm[r] = depth[r] / 70 - 0.5  (rows = b * n; the reference's Python: sigmoid, compare, cast, norm, divide,
+ * subtract -- six launches). */
+int prcnn_point_aux(long rows, float thresh, const float *scores, const float *xyz, float *seg, float *depth, float *depth_norm,
+                    void *stream);
 
 /* Whole RPN proposal layer (lib/rpn/proposal_layer.py:15-119 + decode_bbox_target of
  * lib/utils/bbox_transform.py:24-121, distance-based variant) in five launches and no host sync:

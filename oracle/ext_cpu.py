@@ -60,6 +60,27 @@ class pointnet2_cpu:
         return idx, torch.gather(xyz, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
 
     @staticmethod
+    def fps_new_xyz_supported(n, m):
+        return True
+
+    @staticmethod
+    def ball_query_full_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+        idx.zero_()                                     # the kernel writes every slot (zeros for an empty ball)
+        return pointnet2_cpu.ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx)
+
+    @staticmethod
+    def point_aux_wrapper(scores, xyz, thresh, seg, depth, depth_norm):
+        """point_rcnn.py:44-52 / rcnn_net.py:131-137 with one f32 rounding per operation (csrc/proposal.hip point_aux_kernel)"""
+        import numpy as np
+        s = scores.numpy().astype(np.float32)
+        sg = np.float32(1.0) / (np.float32(1.0) + np.exp(-s, dtype=np.float32))
+        seg.copy_(torch.from_numpy((sg > np.float32(thresh)).astype(np.float32)))
+        p = xyz.numpy().astype(np.float32)
+        d = np.sqrt((p[..., 0] * p[..., 0] + p[..., 1] * p[..., 1]) + p[..., 2] * p[..., 2])
+        depth.copy_(torch.from_numpy(d))
+        depth_norm.copy_(torch.from_numpy(d / np.float32(70.0) - np.float32(0.5)))
+
+    @staticmethod
     def ball_query_limit_wrapper(b, n, m, radius, nsample, new_xyz, xyz, limit, idx):
         """the reference ball query (ball_query_gpu.cu:14-43) over the first limit[cloud] points of every cloud"""
         idx.zero_()                                     # the kernel writes every slot (zeros for an empty ball)

@@ -33,7 +33,7 @@ python profiles/qg_sweep_summarize.py $(ls $O/qg_kt/*/*kernel_trace.csv | head -
 rm -rf $O/qg_kt $O/qg_FETCH_SIZE $O/qg_WRITE_SIZE
 # the drop-in operators' traffic (group_points, three_interpolate, three_nn, ball_query)
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/ops_$c -- python profiles/dropin_ops_probe.py uniform > /dev/null 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/ops_$c -- python profiles/dropin_pmc_probe.py > /dev/null 2>&1
 done
 python profiles/pmc_step_summarize.py $(ls $O/ops_FETCH_SIZE/*/*counter_collection.csv | head -1) $(ls $O/ops_WRITE_SIZE/*/*counter_collection.csv | head -1) > $O/pmc_dropin_ops.md
 rm -rf $O/ops_FETCH_SIZE $O/ops_WRITE_SIZE

@@ -197,6 +197,7 @@ def check_forward_canonical(self, name, args, host, ret):
 POINTNET2 = {
     "furthest_point_sampling_wrapper": {4: "exact", 5: "exact"},
     "ball_query_wrapper": {7: "exact"},
+    "ball_query_full_wrapper": {7: "exact"},       # round 4: every slot written by the kernel (no zero fill by the caller)
     "ball_query_limit_wrapper": {8: "exact"},
     "three_nn_wrapper": {5: "exact", 6: "exact"},
     "three_nn_weights_wrapper": {5: "exact", 6: "exact"},      # round 4: neighbours + inverse-distance weights from one kernel
@@ -305,6 +306,22 @@ def check_fps_new_xyz(self, name, args, host, ret):
 
 
 POINTNET2["fps_new_xyz_wrapper"] = check_fps_new_xyz
+
+
+def check_point_aux(self, name, args, host, ret):
+    """seg / depth / depth_norm of every point in one launch: depth and depth_norm bit for bit (sqrt, divide, subtract are correctly rounded
+    on both sides); the foreground flag wherever the sigmoid is not within 2 ulp of the threshold (expf of two libraries)"""
+    scores, xyz, thresh = host[0], host[1], host[2]
+    seg, depth, dn = (torch.empty_like(scores) for _ in range(3))
+    self._cpu.point_aux_wrapper(scores, xyz, thresh, seg, depth, dn)
+    assert torch.equal(args[4].cpu(), depth) and torch.equal(args[5].cpu(), dn), name
+    sg = torch.sigmoid(scores.double())
+    decided = (sg - thresh).abs() > 1e-6
+    assert torch.equal(args[3].cpu()[decided], seg[decided]), name
+    assert float(seg.mean()) > 0.0
+
+
+POINTNET2["point_aux_wrapper"] = check_point_aux
 POINTNET2["dup_rep_wrapper"] = check_dup_rep
 POINTNET2["rcnn_roi_geometry_wrapper"] = check_roi_geometry
 POINTNET2["sa_packed_mlp_wrapper"] = check_sa_packed
@@ -374,8 +391,8 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
     assert (det["num"] > 0).all()
     # coverage: every kernel family of the step was exercised at the batch-8 shapes
     fg = F.USE_ROI_GEOMETRY          # the RoI clouds' FPS / ball query / representative maps of both sampled levels in one launch
-    want_calls = {"furthest_point_sampling_wrapper": 4, "fps_new_xyz_wrapper": 0 if fg else 2, "dup_rep_wrapper": 0 if fg else 2,
-                  "ball_query_wrapper": 8 if fg else 9, "ball_query_limit_wrapper": 0 if fg else 1, "rcnn_roi_geometry_wrapper": 1 if fg else 0, "three_nn_wrapper": 0, "three_nn_weights_wrapper": 4, "ball_pack_wrapper": 11,
+    want_calls = {"furthest_point_sampling_wrapper": 0, "fps_new_xyz_wrapper": 4 if fg else 6, "dup_rep_wrapper": 0 if fg else 2, "point_aux_wrapper": 1,
+                  "ball_query_full_wrapper": 8, "ball_query_wrapper": 0 if fg else 1, "ball_query_limit_wrapper": 0 if fg else 1, "rcnn_roi_geometry_wrapper": 1 if fg else 0, "three_nn_wrapper": 0, "three_nn_weights_wrapper": 4, "ball_pack_wrapper": 11,
                   "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 4,
                   "three_interpolate_cat_pm_wrapper": 0 if F.USE_FP_LINEAR else 3, "packed_layer_interp_wrapper": 3 if F.USE_FP_LINEAR else 0,
                   "rpn_tail_wrapper": 0 if F.USE_FP_LINEAR else 1, "rpn_tail_lin_wrapper": 1 if F.USE_FP_LINEAR else 0, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
