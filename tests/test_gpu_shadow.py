@@ -318,7 +318,6 @@ def check_point_aux(self, name, args, host, ret):
     sg = torch.sigmoid(scores.double())
     decided = (sg - thresh).abs() > 1e-6
     assert torch.equal(args[3].cpu()[decided], seg[decided]), name
-    assert float(seg.mean()) > 0.0
 
 
 POINTNET2["point_aux_wrapper"] = check_point_aux
