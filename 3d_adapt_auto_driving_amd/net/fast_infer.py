@@ -59,7 +59,11 @@ USE_WIDE_FUSED = os.environ.get("PRCNN_NO_WIDE_FUSED") is None
 # RoI pooling culls by 64-point spatial groups of the scene (built with the geometry chain); PRCNN_NO_POOL_GROUPS=1: full sweep
 USE_XYZ_LEVEL_EARLY = os.environ.get("PRCNN_NO_XYZ_EARLY") != "1"    # leading SA levels of a coordinates-only backbone computed with the geometry (side stream)
 EARLY_LEVELS = int(os.environ.get("PRCNN_EARLY_LEVELS", "4"))
-EARLY_FP = int(os.environ.get("PRCNN_EARLY_FP", "1"))                 # ... plus this many of the coarsest FP modules (round 3: 1 -- over the 32 clouds of a group in one launch each: +1.2 % at K = 20, +2.5 % at K = 96; 2: the same; 3: -1 %)
+EARLY_FP = int(os.environ.get("PRCNN_EARLY_FP", "3"))                 # ... plus this many of the coarsest FP modules (round 3: 1 -- over the 32 clouds of a group in one launch each: +1.2 % at K = 20, +2.5 % at K = 96; 2: the same; 3: -1 %)
+# ... and the finest FP module + both RPN heads as well (round 4, needs EARLY_FP >= number of FP modules - 1): the RPN backbone has no input
+# features, so the WHOLE RPN stage is a function of xyz and the weights -- with the geometry chains twice as fast as in round 3 the
+# feature stream (1.10 ms of kernels per step against 0.6 on each geometry stream) is what binds; its RPN part moves over
+EARLY_TAIL = os.environ.get("PRCNN_EARLY_TAIL", "1") != "0"
 GROUP_SA = os.environ.get("PRCNN_NO_GROUP_SA") != "1"                 # ... and over all batches of a geometry group at once
 USE_POOL_GROUPS = os.environ.get("PRCNN_NO_POOL_GROUPS") is None
 # feature-propagation modules: the first layer is linear in front of its ReLU and the interpolation is a weighted sum, so the
@@ -473,6 +477,8 @@ class FastPointRCNN:
                  "groups": None if groups is None else (groups[0][lo:hi], groups[1][lo:hi])}
             if geo.get("fp_out"):
                 g["fp_out"] = {kk: v[lo:hi] for kk, v in geo["fp_out"].items()}
+            if geo.get("tail_out") is not None:
+                g["tail_out"] = tuple(v[lo:hi] for v in geo["tail_out"])
             for k, lev in enumerate(geo["sa"]):
                 part = {"sel": lev["sel"][lo:hi], "new_xyz": lev["new_xyz"][lo:hi], "idx": [ix[lo:hi] for ix in lev["idx"]],
                         "pack": [None] * len(lev["idx"])}
@@ -537,6 +543,24 @@ class FastPointRCNN:
                 kk = len(self.fp) + i
                 idx, weight = geo["fp"][kk]
                 l_feat[kk] = geo["fp_out"][kk] = self._fp_module(kk, l_feat[kk + 1], l_feat[kk], idx, weight)
+            if (EARLY_TAIL and EARLY_FP >= len(self.fp) - 1 and self.rpn_tail is not None and self.in_feat == 0
+                    and l_feat[1].shape[2] == 256 and USE_FP_LINEAR and has_entry(pu.pointnet2, "rpn_tail_lin_wrapper")):
+                idx, weight = geo["fp"][0]
+                geo["tail_out"] = self._fused_tail(l_feat[1], idx, weight)
+
+    def _fused_tail(self, known_feat, idx, weight):
+        """interpolation + FP module 0 + both heads: one kernel, a 64-point tile never leaves LDS (csrc/rpn_tail.hip);
+        FP layer 1 over the coarse points (a quarter of the rows), interpolated inside the fused kernel -> (feats, rpn_cls, rpn_reg)"""
+        tw = self.rpn_tail
+        B, N = idx.shape[0], idx.shape[1]
+        dev = known_feat.device
+        feats = torch.empty((B, N, 128), dtype=torch.float32, device=dev)
+        rpn_cls = torch.empty((B, N, 1), dtype=torch.float32, device=dev)
+        rpn_reg = torch.empty((B, N, tw["n_reg"]), dtype=torch.float32, device=dev)
+        m = known_feat.shape[1]
+        G = point_layer(known_feat.view(B * m, known_feat.shape[2]), tw["w1"], tw["zero128"], False).view(B, m, 128)
+        pu.pointnet2.rpn_tail_lin_wrapper(G, idx, weight, tw["wcat_lin"], tw["bcat"], tw["wc2"], tw["bc2"], feats, rpn_cls, rpn_reg)
+        return feats, rpn_cls, rpn_reg
 
     # ------------------------------------------------------------------ building blocks
     @staticmethod
@@ -740,6 +764,13 @@ class FastPointRCNN:
         if geo is None:
             geo = self.geometry(xyz)
         B, N, _ = xyz.shape
+        if geo.get("tail_out") is not None:
+            # the whole RPN stage came with the geometry (EARLY_TAIL): nothing left to compute here
+            feats, rpn_cls, rpn_reg = geo["tail_out"]
+            out = {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": xyz, "rpn_features": feats, "groups": geo.get("groups")}
+            if cfg.RCNN.ENABLED:
+                out["rpn_scores_raw"] = rpn_cls[:, :, 0].contiguous()
+            return out
         with self._strictly():
             feats, tail = self._backbone(xyz, geo, fuse_tail=True, feats0=feats0)
         if tail is not None:
