@@ -59,11 +59,13 @@ USE_WIDE_FUSED = os.environ.get("PRCNN_NO_WIDE_FUSED") is None
 # RoI pooling culls by 64-point spatial groups of the scene (built with the geometry chain); PRCNN_NO_POOL_GROUPS=1: full sweep
 USE_XYZ_LEVEL_EARLY = os.environ.get("PRCNN_NO_XYZ_EARLY") != "1"    # leading SA levels of a coordinates-only backbone computed with the geometry (side stream)
 EARLY_LEVELS = int(os.environ.get("PRCNN_EARLY_LEVELS", "4"))
-EARLY_FP = int(os.environ.get("PRCNN_EARLY_FP", "3"))                 # ... plus this many of the coarsest FP modules (round 3: 1 -- over the 32 clouds of a group in one launch each: +1.2 % at K = 20, +2.5 % at K = 96; 2: the same; 3: -1 %)
-# ... and the finest FP module + both RPN heads as well (round 4, needs EARLY_FP >= number of FP modules - 1): the RPN backbone has no input
-# features, so the WHOLE RPN stage is a function of xyz and the weights -- with the geometry chains twice as fast as in round 3 the
-# feature stream (1.10 ms of kernels per step against 0.6 on each geometry stream) is what binds; its RPN part moves over
-EARLY_TAIL = os.environ.get("PRCNN_EARLY_TAIL", "1") != "0"
+EARLY_FP = int(os.environ.get("PRCNN_EARLY_FP", "3"))                 # ... plus this many of the coarsest FP modules, over the 32 clouds of a group in one launch each (round 3: 1 -- the geometry chains were the longer side then; round 4: 3, see EARLY_TAIL)
+# ... and the finest FP module + both RPN heads as well (round 4 experiment, needs EARLY_FP >= number of FP modules - 1): the RPN backbone has
+# no input features, so the WHOLE RPN stage is a function of xyz and the weights.  With the geometry chains twice as fast as in round 3 the
+# feature stream binds (1.10 ms of kernels per step against 0.6 on each geometry stream): EARLY_FP = 3 (all FP modules but the finest over
+# the 32 clouds of a group) buys +4.6 % at K = 100 (6382 against 6103 scenes/s; K = 20: level).  The fused tail on top of it -- a 256-workgroup
+# MFMA kernel of 0.7 ms per group on a geometry stream -- costs it again: 6042 at K = 100, 5158 against 5314 at K = 20.  Off.
+EARLY_TAIL = os.environ.get("PRCNN_EARLY_TAIL", "0") == "1"
 GROUP_SA = os.environ.get("PRCNN_NO_GROUP_SA") != "1"                 # ... and over all batches of a geometry group at once
 USE_POOL_GROUPS = os.environ.get("PRCNN_NO_POOL_GROUPS") is None
 # feature-propagation modules: the first layer is linear in front of its ReLU and the interpolation is a weighted sum, so the
