@@ -55,6 +55,11 @@ def load_checkpoint(model, filename, logger=None):
 
 _ANCHORS = {}
 FUSED_POSTPROCESS = True     # final stage through the fused HIP entry when the extension offers it
+# Round 4: the final stage (decode + threshold + rotated NMS, 0.2 ms) runs BEHIND the RCNN features on the feature stream instead of
+# on the proposal stream: with the FP modules on the geometry streams (fast_infer.EARLY_FP = 3) the proposal stream -- proposal layer,
+# RoI pooling, the RoI clouds' geometry, final stage -- was the longest of the four, and the hop feature -> proposal -> host costs two
+# event waits.  PRCNN_FINAL_ON_FEATURE=0: as in round 3.
+FINAL_ON_FEATURE = os.environ.get("PRCNN_FINAL_ON_FEATURE", "1") != "0"
 
 
 def _anchor_host(cfg):
@@ -476,21 +481,26 @@ class PipelinedRunner:
             # the batch's geometry (read by its RPN stage, its spatial groups by this RCNN stage) retires: kept until the side
             # stream that owns the memory has been made to wait for this point (see _launch_group)
             self._retired.append((side, ev_rcnn, geo))
-        for t in (out["rcnn_cls"], out["rcnn_reg"]):
-            t.record_stream(self.tail)
-        with torch.cuda.stream(self.tail):
-            self.tail.wait_event(ev_rcnn)
+        post = main if FINAL_ON_FEATURE else self.tail
+        if not FINAL_ON_FEATURE:
+            for t in (out["rcnn_cls"], out["rcnn_reg"]):
+                t.record_stream(self.tail)
+        with torch.cuda.stream(post):
+            if not FINAL_ON_FEATURE:
+                self.tail.wait_event(ev_rcnn)
             ret = {"rois": rois, "rcnn_cls": out["rcnn_cls"], "rcnn_reg": out["rcnn_reg"]}
             det = postprocess(self.cfg, ret, cur.shape[0])
             det.update(ret)
             ready = torch.cuda.Event()
-            ready.record(self.tail)
+            ready.record(post)
+        if FINAL_ON_FEATURE:
+            rois.record_stream(main)                  # produced on the proposal stream, read by the final stage here
         if rg is not None and getattr(self, "_geo2", None) is not None:
             # geometry-stream memory read on the feature stream up to ev_rcnn: kept until that stream has waited for it
             self._geo2_retired = getattr(self, "_geo2_retired", []) + [(rg, ev_rcnn)]
         del rg                                        # tail-stream memory, read on the feature stream up to ev_rcnn: the tail stream waits for it above
         det["ready"] = ready
-        det["stream"] = self.tail
+        det["stream"] = post
         return det
 
     @torch.no_grad()
@@ -737,9 +747,10 @@ class GraphedRunner:
         with torch.cuda.stream(self.feat):
             out = eng.rcnn_features(tl["rg"])
         self.feat.synchronize()
-        with torch.cuda.stream(self.tail):
+        post_stream = self.feat if FINAL_ON_FEATURE else self.tail
+        with torch.cuda.stream(post_stream):
             final_stage(tl, out)
-        self.tail.synchronize()
+        post_stream.synchronize()
         del geos, st, tl, out
 
         # ONE MEMORY POOL PER GRAPH.  Graphs that share a pool may only be replayed in the order of their capture with the outputs of
@@ -758,7 +769,9 @@ class GraphedRunner:
                 g_rpn, st = self._capture(self.feat, pool(), lambda: eng.rpn_stage(xb, geos[k]))
                 g_tail, tl = self._capture(self.tail, pool(), lambda: tail_stage(st))
                 g_rcnn, out = self._capture(self.feat, pool(), lambda: eng.rcnn_features(tl["rg"]))
-                g_post, det = self._capture(self.tail, pool(), lambda: final_stage(tl, out))
+                # (captured on the stream family it replays on: its kernels' library scratch is keyed by the capture stream, and graphs
+                #  that share scratch must replay on one stream, in order)
+                g_post, det = self._capture(post_stream, pool(), lambda: final_stage(tl, out))
                 slot["members"].append({"g_rpn": g_rpn, "g_tail": g_tail, "g_rcnn": g_rcnn, "g_post": g_post,
                                         "st": st, "tl": tl, "out": out, "det": det,
                                         "ev_rpn": torch.cuda.Event(), "ev_prop": torch.cuda.Event(), "ev_rcnn": torch.cuda.Event(),
@@ -895,15 +908,17 @@ class GraphedRunner:
         if _GRAPH_DEBUG & 4:
             torch.cuda.synchronize(self.device)
             print("[graph debug] slot %d member %d rcnn done" % (s, k), flush=True)
-        tail.wait_event(m["ev_rcnn"])
-        with torch.cuda.stream(tail):
+        post = feat if FINAL_ON_FEATURE else tail
+        if not FINAL_ON_FEATURE:
+            tail.wait_event(m["ev_rcnn"])
+        with torch.cuda.stream(post):
             m["g_post"].replay()
-            m["ready"].record(tail)
+            m["ready"].record(post)
         if _GRAPH_DEBUG & 4:
             torch.cuda.synchronize(self.device)
             print("[graph debug] slot %d member %d done" % (s, k), flush=True)
         det = dict(m["det"])
-        det["ready"], det["stream"] = m["ready"], tail
+        det["ready"], det["stream"] = m["ready"], post
         return det
 
     @torch.no_grad()
