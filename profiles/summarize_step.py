@@ -19,11 +19,14 @@ sel = rows[a:b]
 wall = (int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 1e3
 by = collections.defaultdict(lambda: [0, 0.0])
 stream = collections.defaultdict(float)
+per_stream = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for r in sel:
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     by[r["Kernel_Name"][:100]][0] += 1
     by[r["Kernel_Name"][:100]][1] += d
     stream[r.get("Stream_Id", "?")] += d
+    e = per_stream[r.get("Stream_Id", "?")][r["Kernel_Name"].replace("void ", "").replace("prcnn::", "").split("(")[0][:60]]
+    e[0] += 1; e[1] += d
 steps = max(1, sum(1 for r in sel if STEP_KERNEL in r["Kernel_Name"]))
 print("# %s\n" % sys.argv[2])
 print("Window between SA1 FPS launches (whole geometry groups) = %d steps (batches of 8 scenes).  PER STEP: wall "
@@ -34,3 +37,7 @@ print("Window between SA1 FPS launches (whole geometry groups) = %d steps (batch
 print("| kernel | calls per step | total us per step | avg us per call |\n|---|---|---|---|")
 for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])[:50]:
     print("| `%s` | %.2f | %.1f | %.1f |" % (k, v[0] / steps, v[1] / steps, v[1] / v[0]))
+print("\n## The same window by stream (kernels of at least 10 us per step)\n")
+for sid, ks in sorted(per_stream.items()):
+    print("* stream %s, %.2f ms per step: %s" % (sid, stream[sid] / 1e3 / steps, ", ".join(
+        "`%s` %.0f us (%.2f x)" % (k, v[1] / steps, v[0] / steps) for k, v in sorted(ks.items(), key=lambda kv: -kv[1][1]) if v[1] / steps >= 10)))
