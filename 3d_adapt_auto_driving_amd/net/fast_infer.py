@@ -66,6 +66,9 @@ EARLY_FP = int(os.environ.get("PRCNN_EARLY_FP", "3"))                 # ... plus
 # the 32 clouds of a group) buys +4.6 % at K = 100 (6382 against 6103 scenes/s; K = 20: level).  The fused tail on top of it -- a 256-workgroup
 # MFMA kernel of 0.7 ms per group on a geometry stream -- costs it again: 6042 at K = 100, 5158 against 5314 at K = 20.  Off.
 EARLY_TAIL = os.environ.get("PRCNN_EARLY_TAIL", "0") == "1"
+# ... in between: only the coarse-level product G of the finest FP module (4096 rows per cloud, K = 256) goes with the geometry; the fused
+# tail kernel, which reads it, stays on the feature stream
+EARLY_G0 = os.environ.get("PRCNN_EARLY_G0", "1") == "1"
 GROUP_SA = os.environ.get("PRCNN_NO_GROUP_SA") != "1"                 # ... and over all batches of a geometry group at once
 USE_POOL_GROUPS = os.environ.get("PRCNN_NO_POOL_GROUPS") is None
 # feature-propagation modules: the first layer is linear in front of its ReLU and the interpolation is a weighted sum, so the
@@ -481,6 +484,8 @@ class FastPointRCNN:
                 g["fp_out"] = {kk: v[lo:hi] for kk, v in geo["fp_out"].items()}
             if geo.get("tail_out") is not None:
                 g["tail_out"] = tuple(v[lo:hi] for v in geo["tail_out"])
+            if geo.get("tail_G") is not None:
+                g["tail_G"] = geo["tail_G"][lo:hi]
             for k, lev in enumerate(geo["sa"]):
                 part = {"sel": lev["sel"][lo:hi], "new_xyz": lev["new_xyz"][lo:hi], "idx": [ix[lo:hi] for ix in lev["idx"]],
                         "pack": [None] * len(lev["idx"])}
@@ -549,6 +554,10 @@ class FastPointRCNN:
                     and l_feat[1].shape[2] == 256 and USE_FP_LINEAR and has_entry(pu.pointnet2, "rpn_tail_lin_wrapper")):
                 idx, weight = geo["fp"][0]
                 geo["tail_out"] = self._fused_tail(l_feat[1], idx, weight)
+            elif (EARLY_G0 and EARLY_FP >= len(self.fp) - 1 and self.rpn_tail is not None and self.in_feat == 0
+                    and l_feat[1].shape[2] == 256 and USE_FP_LINEAR and has_entry(pu.pointnet2, "rpn_tail_lin_wrapper")):
+                kf = l_feat[1]
+                geo["tail_G"] = point_layer(kf.view(-1, kf.shape[2]), self.rpn_tail["w1"], self.rpn_tail["zero128"], False).view(kf.shape[0], kf.shape[1], 128)
 
     def _fused_tail(self, known_feat, idx, weight):
         """interpolation + FP module 0 + both heads: one kernel, a 64-point tile never leaves LDS (csrc/rpn_tail.hip);
@@ -785,7 +794,9 @@ class FastPointRCNN:
             if USE_FP_LINEAR and has_entry(pu.pointnet2, "rpn_tail_lin_wrapper"):
                 # FP layer 1 over the coarse points (a quarter of the rows), interpolated inside the fused kernel
                 m = known_feat.shape[1]
-                G = point_layer(known_feat.view(B * m, known_feat.shape[2]), tw["w1"], tw["zero128"], False).view(B, m, 128)
+                G = geo.get("tail_G")                          # came with the geometry (EARLY_G0)
+                if G is None:
+                    G = point_layer(known_feat.view(B * m, known_feat.shape[2]), tw["w1"], tw["zero128"], False).view(B, m, 128)
                 pu.pointnet2.rpn_tail_lin_wrapper(G, idx, weight, tw["wcat_lin"], tw["bcat"], tw["wc2"], tw["bc2"], feats, rpn_cls, rpn_reg)
             else:
                 pu.pointnet2.rpn_tail_wrapper(known_feat, idx, weight, tw["wcat"], tw["bcat"], tw["wc2"], tw["bc2"], feats, rpn_cls, rpn_reg)
