@@ -91,6 +91,7 @@ SIGNATURES = {
     "prcnn_host_pts_in_boxes3d": [_I, _I, _P, _P, _P],
     "prcnn_host_roipool3d": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "prcnn_roipool3d_canonical": [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "prcnn_roipool3d_canonical_xyz": [_I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_point_groups": [_I, _I, _P, _P, _P, _P],
     "prcnn_input_stage": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _F, _I, _P, _P, _P, _P, _P],
     "prcnn_valid_flags": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P],

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(
     int pts_num, int boxes_num, int feat_len, int sampled, float extra, float extra2, const float *__restrict__ xyz,
     const float *__restrict__ rois, const float *__restrict__ feats, const float *__restrict__ seg_mask,
     const float *__restrict__ depth, float4 *__restrict__ pooled, int *__restrict__ empty_flag, int *__restrict__ pooled_cnt,
-    const float4 *__restrict__ pxyz, const float4 *__restrict__ aabb)
+    const float4 *__restrict__ pxyz, const float4 *__restrict__ aabb, float *__restrict__ xyz_out)
 {
     extern __shared__ __align__(16) int rp_lds[];
     float4 *s_c01 = reinterpret_cast<float4 *>(rp_lds);               // [sampled][2]: the two leading chunks of every distinct row
@@ -242,6 +242,10 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(
             if (q >= 2 && e / q4 >= feat_rows) continue;
             dst[e] = (q == 0) ? origin : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if (xyz_out) {
+            float *xo = xyz_out + ((long)b * boxes_num + box) * (long)sampled * 3;
+            for (int e = t; e < sampled; e += RP_THREADS) { xo[3 * e] = origin.x; xo[3 * e + 1] = origin.y; xo[3 * e + 2] = origin.z; }
+        }
         return;
     }
     if (t == 0) empty_flag[(long)b * boxes_num + box] = 0;
@@ -268,6 +272,17 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(
         const int s2 = e >> 1, q = e & 1;
         const int src = s2 < cnt ? s2 : s2 % cnt;
         dst[(long)s2 * q4 + q] = s_c01[2 * src + q];
+    }
+    // (optional) the canonical coordinates once more as a dense (sampled, 3) cloud: what the RCNN's sampling and ball queries read --
+    // the caller used to cut them out of the 544-byte rows with a strided copy, 30 us on the proposal stream
+    if (xyz_out) {
+        float *xo = xyz_out + ((long)b * boxes_num + box) * (long)sampled * 3;
+        const float *sc = reinterpret_cast<const float *>(s_c01);
+        for (int e = t; e < 3 * sampled; e += RP_THREADS) {
+            const int s2 = e / 3, c = e - 3 * s2;
+            const int src = s2 < cnt ? s2 : s2 % cnt;
+            xo[e] = sc[8 * src + c];
+        }
     }
     // feature chunks of the rows below feat_rows
     const float inv_f4 = 1.0f / (float)f4;
@@ -317,10 +332,24 @@ extern "C" int prcnn_roipool3d(int batch_size, int pts_num, int boxes_num, int f
 
 // Fast-path RCNN input assembly (see roipool3d_canonical_kernel).  xyz (b,n,3), rois (b,m,7) NOT enlarged,
 // feats (b,n,c) point-major with c % 4 == 0, seg_mask / depth (b,n) -> pooled (b,m,sampled,8+c), empty (b,m) i32.
+// xyz_out (optional, (b, m, sampled, 3)): the rows' canonical coordinates as dense clouds as well.
+extern "C" int prcnn_roipool3d_canonical_xyz(int batch_size, int pts_num, int boxes_num, int feature_len, int sampled_pts_num,
+                                             float pool_extra_width, const float *xyz, const float *rois, const float *feats,
+                                             const float *seg_mask, const float *depth, float *pooled, int *pooled_empty_flag,
+                                             int *pooled_cnt, const float *pxyz, const float *aabb, float *xyz_out, void *stream);
 extern "C" int prcnn_roipool3d_canonical(int batch_size, int pts_num, int boxes_num, int feature_len, int sampled_pts_num,
                                          float pool_extra_width, const float *xyz, const float *rois, const float *feats,
                                          const float *seg_mask, const float *depth, float *pooled, int *pooled_empty_flag,
                                          int *pooled_cnt, const float *pxyz, const float *aabb, void *stream)
+{
+    return prcnn_roipool3d_canonical_xyz(batch_size, pts_num, boxes_num, feature_len, sampled_pts_num, pool_extra_width, xyz, rois, feats,
+                                         seg_mask, depth, pooled, pooled_empty_flag, pooled_cnt, pxyz, aabb, nullptr, stream);
+}
+
+extern "C" int prcnn_roipool3d_canonical_xyz(int batch_size, int pts_num, int boxes_num, int feature_len, int sampled_pts_num,
+                                             float pool_extra_width, const float *xyz, const float *rois, const float *feats,
+                                             const float *seg_mask, const float *depth, float *pooled, int *pooled_empty_flag,
+                                             int *pooled_cnt, const float *pxyz, const float *aabb, float *xyz_out, void *stream)
 {
     PRCNN_REQUIRE((pxyz == nullptr) == (aabb == nullptr), "roipool3d_canonical: pxyz and aabb go together (prcnn_point_groups)");
     PRCNN_REQUIRE(!pxyz || (pts_num % 64 == 0 && pts_num <= 16384 && (((uintptr_t)pxyz | (uintptr_t)aabb) & 15) == 0),
@@ -343,6 +372,6 @@ extern "C" int prcnn_roipool3d_canonical(int batch_size, int pts_num, int boxes_
     hipLaunchKernelGGL(roipool3d_canonical_kernel, grid, dim3(RP_THREADS), lds, (hipStream_t)stream, pts_num, boxes_num,
                        feature_len, sampled_pts_num, pool_extra_width, (float)((double)pool_extra_width * 2.0), xyz, rois, feats,
                        seg_mask, depth, reinterpret_cast<float4 *>(pooled), pooled_empty_flag, pooled_cnt,
-                       reinterpret_cast<const float4 *>(pxyz), reinterpret_cast<const float4 *>(aabb));
+                       reinterpret_cast<const float4 *>(pxyz), reinterpret_cast<const float4 *>(aabb), xyz_out);
     return check_launch("roipool3d_canonical");
 }

@@ -7,16 +7,41 @@
 // scenes) for 9 GFLOP of arithmetic.  Here a grouped row lives in ONE LANE from the gather to the max:
 //   * lane = one (centre, sample) row; the ns rows of a centre are ns consecutive lanes of a wave;
 //   * weights are wave-uniform: they come in through scalar loads and enter the FMAs as SGPR operands
-//     (v_fmac_f32 v, s, v), so the inner loops are pure VALU with no LDS and no vector loads;
+//     (round 4: v_pk_fma_f32 v[2], s[2], v -- two output channels per instruction, see xyz_layer), so the inner loops are pure VALU
+//     with no LDS and no vector loads;
 //   * activations (C1 + C2 + C3 <= 160 values) stay in VGPRs, loops fully unrolled;
 //   * max over nsample = xor-butterfly across the ns lanes of the centre; each lane then stores its share
 //     of the C3 outputs.
 // HBM traffic: idx (4 B/row), the gathered coordinates (L2-resident cloud), C3 floats per centre out.
-// Bound: VALU f32 (2 * rows * (3 C1 + C1 C2 + C2 C3) flop).  The MLP arithmetic decides no index, so FMAs
+// Bound: VALU f32 (2 * rows * (3 C1 + C1 C2 + C2 C3) flop) at the PACKED rate, 256 flop / clock / CU = the f32 MFMA's own peak (157 TFLOP/s):
+// an MFMA version would gain nothing at f32 and pay a transpose through LDS between the layers; and VALU work overlaps with the MFMA
+// kernels of the other streams on the same CU, MFMA work queues behind them.  The MLP arithmetic decides no index, so FMAs
 // are used (the GEMM libraries it replaces do the same); results agree with the GEMM path to f32 rounding.
 #include "common.hpp"
 
 namespace prcnn {
+
+// y[j] = fma(w[K-1][j], a[K-1], ... fma(w[0][j], a[0], b[j])) for j < N: the FMA chain over k of one row's layer, TWO output channels per
+// v_pk_fma_f32 (the weights of a channel pair are an SGPR pair, the activation one VGPR used for both halves).  Each component sees exactly
+// the scalar chain: same bits as N v_fmac_f32 per k, half the VALU instructions -- packed f32 is the full 256 flop / clock / CU of the
+// chip's f32 rate (as much as the f32 MFMA), plain v_fmac_f32 half of it.
+template <int K, int N>
+__device__ __forceinline__ void xyz_layer(const float *__restrict__ w, const float *__restrict__ b, const float (&a)[K], float (&y)[N])
+{
+    static_assert(N % 2 == 0, "channel pairs");
+    pk_f32x2 acc[N / 2];
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) acc[j] = (pk_f32x2){b[2 * j], b[2 * j + 1]};
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        const pk_f32x2 s = {a[q], a[q]};
+#pragma unroll
+        for (int j = 0; j < N / 2; ++j)
+            acc[j] = __builtin_elementwise_fma((pk_f32x2){w[q * N + 2 * j], w[q * N + 2 * j + 1]}, s, acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) { y[2 * j] = acc[j].x; y[2 * j + 1] = acc[j].y; }
+}
 
 template <int C1, int C2, int C3, int NS>
 __global__ __launch_bounds__(256) void sa_xyz_mlp_kernel(
@@ -36,27 +61,20 @@ __global__ __launch_bounds__(256) void sa_xyz_mlp_kernel(
     const float dx = p[0] - c[0], dy = p[1] - c[1], dz = p[2] - c[2];
 
     float a1[C1];
+    {
+        const float d3[3] = {dx, dy, dz};
+        xyz_layer<3, C1>(w1, b1, d3, a1);
+    }
 #pragma unroll
-    for (int j = 0; j < C1; ++j)
-        a1[j] = fmaxf(fmaf(w1[2 * C1 + j], dz, fmaf(w1[C1 + j], dy, fmaf(w1[j], dx, b1[j]))), 0.f);
+    for (int j = 0; j < C1; ++j) a1[j] = fmaxf(a1[j], 0.f);
 
     float a2[C2];
-#pragma unroll
-    for (int j = 0; j < C2; ++j) a2[j] = b2[j];
-#pragma unroll
-    for (int q = 0; q < C1; ++q)
-#pragma unroll
-        for (int j = 0; j < C2; ++j) a2[j] = fmaf(w2[q * C2 + j], a1[q], a2[j]);
+    xyz_layer<C1, C2>(w2, b2, a1, a2);
 #pragma unroll
     for (int j = 0; j < C2; ++j) a2[j] = fmaxf(a2[j], 0.f);
 
     float a3[C3];
-#pragma unroll
-    for (int j = 0; j < C3; ++j) a3[j] = b3[j];
-#pragma unroll
-    for (int q = 0; q < C2; ++q)
-#pragma unroll
-        for (int j = 0; j < C3; ++j) a3[j] = fmaf(w3[q * C3 + j], a2[q], a3[j]);
+    xyz_layer<C2, C3>(w3, b3, a2, a3);
 
     // ReLU commutes with max; reduce across the NS lanes of this centre
 #pragma unroll
@@ -97,25 +115,18 @@ __global__ __launch_bounds__(256) void sa_xyz_mlp_packed_kernel(
     ctr[wv][lane] = tilecloud[t] * m + (int)(rowinfo[row] >> 16);
 
     float a1[C1];
+    {
+        const float d3[3] = {dx, dy, dz};
+        xyz_layer<3, C1>(w1, b1, d3, a1);
+    }
 #pragma unroll
-    for (int j = 0; j < C1; ++j)
-        a1[j] = fmaxf(fmaf(w1[2 * C1 + j], dz, fmaf(w1[C1 + j], dy, fmaf(w1[j], dx, b1[j]))), 0.f);
+    for (int j = 0; j < C1; ++j) a1[j] = fmaxf(a1[j], 0.f);
     float a2[C2];
-#pragma unroll
-    for (int j = 0; j < C2; ++j) a2[j] = b2[j];
-#pragma unroll
-    for (int q = 0; q < C1; ++q)
-#pragma unroll
-        for (int j = 0; j < C2; ++j) a2[j] = fmaf(w2[q * C2 + j], a1[q], a2[j]);
+    xyz_layer<C1, C2>(w2, b2, a1, a2);
 #pragma unroll
     for (int j = 0; j < C2; ++j) a2[j] = fmaxf(a2[j], 0.f);
     float a3[C3];
-#pragma unroll
-    for (int j = 0; j < C3; ++j) a3[j] = b3[j];
-#pragma unroll
-    for (int q = 0; q < C2; ++q)
-#pragma unroll
-        for (int j = 0; j < C3; ++j) a3[j] = fmaf(w3[q * C3 + j], a2[q], a3[j]);
+    xyz_layer<C2, C3>(w3, b3, a2, a3);
     float *zw = z[wv];
 #pragma unroll
     for (int j = 0; j < C3; ++j) zw[lane * (C3 + 1) + j] = fmaxf(a3[j], 0.f);

@@ -55,21 +55,27 @@ def point_groups(xyz):
     return pxyz, aabb
 
 
-def forward_canonical(xyz, rois, feats, seg_mask, depth, pool_extra_width, pooled, pooled_empty_flag, pooled_cnt=None, groups=None):
+def forward_canonical(xyz, rois, feats, seg_mask, depth, pool_extra_width, pooled, pooled_empty_flag, pooled_cnt=None, groups=None, xyz_out=None):
     """Extension beyond the reference ABI (csrc/roipool.hip roipool3d_canonical_kernel): enlarge + pool + canonical
     transform + RCNN row layout [x',y',z',mask,depth,0,0,0 | C feats] in one pass.  pooled (B,M,S,8+C).
     pooled_cnt (B,M) i32, optional: distinct rows per box (rows beyond are wrap-around copies); when given, feature columns
-    are written for rows < round_up(cnt, 64) only.  groups = point_groups(xyz), optional: same result, found by culling."""
+    are written for rows < round_up(cnt, 64) only.  groups = point_groups(xyz), optional: same result, found by culling.
+    xyz_out (B,M,S,3), optional: receives pooled[..., 0:3] as dense clouds in the same pass."""
     _chk(torch.float32, xyz, rois, feats, seg_mask, depth, pooled)
     if groups is not None:
         _chk(torch.float32, *groups)
     _chk(torch.int32, pooled_empty_flag)
     if pooled_cnt is not None:
         _chk(torch.int32, pooled_cnt)
-    _lib.call("prcnn_roipool3d_canonical", xyz.size(0), xyz.size(1), rois.size(1), feats.size(2), pooled.size(2),
+    if xyz_out is not None:
+        _chk(torch.float32, xyz_out)
+        if tuple(xyz_out.shape) != (xyz.size(0), rois.size(1), pooled.size(2), 3):
+            raise RuntimeError("roipool3d_cuda.forward_canonical: xyz_out must be (B, M, S, 3)")
+    _lib.call("prcnn_roipool3d_canonical_xyz", xyz.size(0), xyz.size(1), rois.size(1), feats.size(2), pooled.size(2),
               float(pool_extra_width), xyz.data_ptr(), rois.data_ptr(), feats.data_ptr(), seg_mask.data_ptr(),
               depth.data_ptr(), pooled.data_ptr(), pooled_empty_flag.data_ptr(), _lib.ptr(pooled_cnt),
-              None if groups is None else groups[0].data_ptr(), None if groups is None else groups[1].data_ptr(), _lib.current_stream(xyz))
+              None if groups is None else groups[0].data_ptr(), None if groups is None else groups[1].data_ptr(),
+              _lib.ptr(xyz_out), _lib.current_stream(xyz))
     return 1
 
 

@@ -906,9 +906,11 @@ class FastPointRCNN:
             empty = torch.empty((B, M), dtype=torch.int32, device=xyz.device)
             if USE_POOL_DEDUP and USE_PACKED and USE_RCNN_POINT_MLP and P % 64 == 0 and self._point_mlp_ok():
                 pooled_cnt = torch.empty((B, M), dtype=torch.int32, device=xyz.device)
+            # ... and the rows' coordinates once more as dense clouds (what sampling and ball queries read; was a strided copy)
+            xyz_dense = torch.empty((B, M, P, 3), dtype=torch.float32, device=xyz.device)
             rp.forward_canonical(xyz, rois.contiguous(), feats, seg_mask.contiguous(),
                                  depth_norm if depth_norm is not None else (pts_depth / 70.0 - 0.5).contiguous(),
-                                 R.POOL_EXTRA_WIDTH, pooled, empty, pooled_cnt, groups)
+                                 R.POOL_EXTRA_WIDTH, pooled, empty, pooled_cnt, groups, xyz_dense)
             flat = pooled.view(B * M, P, W)
             rows = flat.view(B * M * P, W)
             a = rows[:, 0:8]                                                   # strided view: columns 5..7 are zero
@@ -920,6 +922,7 @@ class FastPointRCNN:
             pts_feature = torch.cat(extra + [feats], dim=2)                   # (B,N,2+128), already point-major
             pooled, _ = roipool3d_utils.roipool3d_gpu(xyz, pts_feature, rois, R.POOL_EXTRA_WIDTH, sampled_pt_num=R.NUM_POINTS)
             B, M, P, W = pooled.shape
+            xyz_dense = None
             pooled[:, :, :, 0:3] -= rois[:, :, 0:3].unsqueeze(2)
             flat = pooled.view(B * M, P, W)
             flat[:, :, 0:3] = kitti_utils.rotate_pc_along_y_torch(flat[:, :, 0:3], rois.reshape(-1, 7)[:, 6])
@@ -929,7 +932,7 @@ class FastPointRCNN:
             rpn_part = rows[:, nin:]
         point_mlp = bool(USE_RCNN_POINT_MLP and W == 136 and rows.shape[0] % 64 == 0 and self._point_mlp_ok())
         tiles = ext.pooled_tiles_wrapper(pooled_cnt.view(-1), P) if (point_mlp and pooled_cnt is not None) else None
-        cur_xyz = flat[:, :, 0:3].contiguous()
+        cur_xyz = xyz_dense.view(B * M, P, 3) if xyz_dense is not None else flat[:, :, 0:3].contiguous()
         levels = []
         # representative map of the CURRENT level's points (None: every point counts as distinct): which of them are exact copies
         # of one another.  Level 0: pooled point k >= count is a copy of k % count (`limit`); deeper: the centres the sampling

@@ -432,6 +432,12 @@ int prcnn_roipool3d_canonical(int batch_size, int pts_num, int boxes_num, int fe
                               float pool_extra_width, const float *xyz, const float *rois, const float *feats,
                               const float *seg_mask, const float *depth, float *pooled, int *pooled_empty_flag,
                               int *pooled_cnt, const float *pxyz, const float *aabb, void *stream);
+/* the same with xyz_out (b,m,sampled,3), optional (NULL = off): the rows' canonical coordinates once more as dense clouds -- what the
+ * RCNN stage's sampling and ball queries (rcnn_net.py:165-175: pointnet2 SA modules over xyz = pooled[..., 0:3]) read. */
+int prcnn_roipool3d_canonical_xyz(int batch_size, int pts_num, int boxes_num, int feature_len, int sampled_pts_num,
+                                  float pool_extra_width, const float *xyz, const float *rois, const float *feats,
+                                  const float *seg_mask, const float *depth, float *pooled, int *pooled_empty_flag,
+                                  int *pooled_cnt, const float *pxyz, const float *aabb, float *xyz_out, void *stream);
 /* Spatial groups of clouds xyz (b,n,3), n % 64 == 0, n <= 16384: pxyz (b,n,4) = the points in Morton order over (x,z) with the
  * original index in the 4th lane (int bits), aabb (b, n/64, 2, 4) = min / max corner of every 64-point group.  Any box-vs-cloud
  * sweep (RoI pooling here) can cull by group.  Not part of the reference ABI. */

@@ -192,6 +192,8 @@ def check_forward_canonical(self, name, args, host, ret):
         [(-rois[..., 0] * ca[..., 0] + rois[..., 2] * sa[..., 0]), -rois[..., 1], (-rois[..., 0] * sa[..., 0] - rois[..., 2] * ca[..., 0])],
         -1)[wempty.astype(bool)][:, None, :]
     assert np.abs(pooled[..., 0:3] - canon).max() < 2e-5
+    if len(args) > 10 and args[10] is not None:          # round 4: the same coordinates once more as dense clouds
+        assert np.array_equal(args[10].detach().cpu().numpy(), pooled[..., 0:3])
 
 
 POINTNET2 = {
