@@ -37,7 +37,7 @@ print("Window between SA1 FPS launches (whole geometry groups) = %d steps (batch
 print("| kernel | calls per step | total us per step | avg us per call |\n|---|---|---|---|")
 for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])[:50]:
     print("| `%s` | %.2f | %.1f | %.1f |" % (k, v[0] / steps, v[1] / steps, v[1] / v[0]))
-print("\n## The same window by stream (kernels of at least 10 us per step)\n")
+print("\n## The same window by stream (kernels of at least 10 us per step, and every launch that is not one of the library's)\n")
 for sid, ks in sorted(per_stream.items()):
     print("* stream %s, %.2f ms per step: %s" % (sid, stream[sid] / 1e3 / steps, ", ".join(
-        "`%s` %.0f us (%.2f x)" % (k, v[1] / steps, v[0] / steps) for k, v in sorted(ks.items(), key=lambda kv: -kv[1][1]) if v[1] / steps >= 10)))
+        "`%s` %.0f us (%.2f x)" % (k, v[1] / steps, v[0] / steps) for k, v in sorted(ks.items(), key=lambda kv: -kv[1][1]) if v[1] / steps >= 10 or "at::" in k or "rocclr" in k)))
