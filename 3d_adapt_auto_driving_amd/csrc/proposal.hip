@@ -14,6 +14,7 @@
 //   5. assemble_rois_kernel  near keeps, then far keeps, zero padded -> rois (B, M, 7), scores (B, M)
 // No host synchronisation anywhere.
 #include "common.hpp"
+#include "rbox_iou.hpp"
 #include <stdlib.h>
 #include <math.h>
 
@@ -295,6 +296,47 @@ struct RcnnCfg {
     float anchor[3];
 };
 
+// decode_bbox_target of one RoI (bbox_transform.py:30-127 with get_xz_fine = get_ry_fine = True): r = its regression row, roi = its box
+__device__ __forceinline__ void rcnn_decode_box(const RcnnCfg &c, const float *__restrict__ r, const float *__restrict__ roi, float (&box)[7])
+{
+    const int nb = c.nbin;
+    const int xb = argmax_row(r, nb), zb = argmax_row(r + nb, nb);
+    const float half_bin = c.loc_bin_size / 2;
+    float px = __fsub_rn(__fadd_rn(__fmul_rn((float)xb, c.loc_bin_size), half_bin), c.loc_scope);
+    float pz = __fsub_rn(__fadd_rn(__fmul_rn((float)zb, c.loc_bin_size), half_bin), c.loc_scope);
+    px = __fadd_rn(px, __fmul_rn(r[2 * nb + xb], c.loc_bin_size));      // get_xz_fine = True
+    pz = __fadd_rn(pz, __fmul_rn(r[3 * nb + zb], c.loc_bin_size));
+    int cur = 4 * nb;
+    float py;
+    if (c.y_by_bin) {
+        const int yb = argmax_row(r + cur, c.nbin_y);
+        const float y_res = __fmul_rn(r[cur + c.nbin_y + yb], c.loc_y_bin_size);
+        py = __fadd_rn(__fsub_rn(__fadd_rn(__fmul_rn((float)yb, c.loc_y_bin_size), c.loc_y_bin_size / 2), c.loc_y_scope), y_res);
+        py = __fadd_rn(py, roi[1]);
+        cur += 2 * c.nbin_y;
+    } else {
+        py = __fadd_rn(roi[1], r[cur]);
+        cur += 1;
+    }
+    const int rb = argmax_row(r + cur, c.num_head_bin);
+    const float res_norm = r[cur + c.num_head_bin + rb];
+    // get_ry_fine = True: bins over +-pi/4 around the RoI heading
+    const float apc = (float)((M_PI / 2) / c.num_head_bin);
+    const float apc_half = (float)(((M_PI / 2) / c.num_head_bin) / 2.0);
+    float ry = __fsub_rn(__fadd_rn(__fadd_rn(__fmul_rn((float)rb, apc), apc_half), __fmul_rn(res_norm, apc_half)), (float)(M_PI / 4));
+    cur += 2 * c.num_head_bin;
+    const float h = __fadd_rn(__fmul_rn(r[cur], c.anchor[0]), c.anchor[0]);
+    const float w = __fadd_rn(__fmul_rn(r[cur + 1], c.anchor[1]), c.anchor[1]);
+    const float l = __fadd_rn(__fmul_rn(r[cur + 2], c.anchor[2]), c.anchor[2]);
+    // rotate (px, pz) by -roi_ry back to the scene frame (rotate_pc_along_y_torch with -ry), add the RoI centre
+    const float roi_ry = roi[6];
+    const float cosa = cosf(-roi_ry), sina = sinf(-roi_ry);
+    const float nx = __fadd_rn(__fmul_rn(px, cosa), __fmul_rn(pz, -sina));
+    const float nz = __fadd_rn(__fmul_rn(px, sina), __fmul_rn(pz, cosa));
+    box[0] = __fadd_rn(nx, roi[0]); box[1] = py; box[2] = __fadd_rn(nz, roi[2]);
+    box[3] = h; box[4] = w; box[5] = l; box[6] = __fadd_rn(ry, roi_ry);
+}
+
 __global__ __launch_bounds__(128) void rcnn_decode_select_kernel(
     int m, RcnnCfg c, const float *__restrict__ rois, const float *__restrict__ reg, const float *__restrict__ cls,
     float *__restrict__ pred /* (b,m,7) decoded, RoI order */, float *__restrict__ sorted /* (b,m,8) box7+raw, score order */,
@@ -309,44 +351,7 @@ __global__ __launch_bounds__(128) void rcnn_decode_select_kernel(
     if (t == 0) nsel = 0;
     __syncthreads();
     if (t < m) {
-        const float *r = reg + ((long)b * m + t) * c.channels;
-        const float *roi = rois + ((long)b * m + t) * 7;
-        const int nb = c.nbin;
-        const int xb = argmax_row(r, nb), zb = argmax_row(r + nb, nb);
-        const float half_bin = c.loc_bin_size / 2;
-        float px = __fsub_rn(__fadd_rn(__fmul_rn((float)xb, c.loc_bin_size), half_bin), c.loc_scope);
-        float pz = __fsub_rn(__fadd_rn(__fmul_rn((float)zb, c.loc_bin_size), half_bin), c.loc_scope);
-        px = __fadd_rn(px, __fmul_rn(r[2 * nb + xb], c.loc_bin_size));      // get_xz_fine = True
-        pz = __fadd_rn(pz, __fmul_rn(r[3 * nb + zb], c.loc_bin_size));
-        int cur = 4 * nb;
-        float py;
-        if (c.y_by_bin) {
-            const int yb = argmax_row(r + cur, c.nbin_y);
-            const float y_res = __fmul_rn(r[cur + c.nbin_y + yb], c.loc_y_bin_size);
-            py = __fadd_rn(__fsub_rn(__fadd_rn(__fmul_rn((float)yb, c.loc_y_bin_size), c.loc_y_bin_size / 2), c.loc_y_scope), y_res);
-            py = __fadd_rn(py, roi[1]);
-            cur += 2 * c.nbin_y;
-        } else {
-            py = __fadd_rn(roi[1], r[cur]);
-            cur += 1;
-        }
-        const int rb = argmax_row(r + cur, c.num_head_bin);
-        const float res_norm = r[cur + c.num_head_bin + rb];
-        // get_ry_fine = True: bins over +-pi/4 around the RoI heading
-        const float apc = (float)((M_PI / 2) / c.num_head_bin);
-        const float apc_half = (float)(((M_PI / 2) / c.num_head_bin) / 2.0);
-        float ry = __fsub_rn(__fadd_rn(__fadd_rn(__fmul_rn((float)rb, apc), apc_half), __fmul_rn(res_norm, apc_half)), (float)(M_PI / 4));
-        cur += 2 * c.num_head_bin;
-        const float h = __fadd_rn(__fmul_rn(r[cur], c.anchor[0]), c.anchor[0]);
-        const float w = __fadd_rn(__fmul_rn(r[cur + 1], c.anchor[1]), c.anchor[1]);
-        const float l = __fadd_rn(__fmul_rn(r[cur + 2], c.anchor[2]), c.anchor[2]);
-        // rotate (px, pz) by -roi_ry back to the scene frame (rotate_pc_along_y_torch with -ry), add the RoI centre
-        const float roi_ry = roi[6];
-        const float cosa = cosf(-roi_ry), sina = sinf(-roi_ry);
-        const float nx = __fadd_rn(__fmul_rn(px, cosa), __fmul_rn(pz, -sina));
-        const float nz = __fadd_rn(__fmul_rn(px, sina), __fmul_rn(pz, cosa));
-        box[0] = __fadd_rn(nx, roi[0]); box[1] = py; box[2] = __fadd_rn(nz, roi[2]);
-        box[3] = h; box[4] = w; box[5] = l; box[6] = __fadd_rn(ry, roi_ry);
+        rcnn_decode_box(c, reg + ((long)b * m + t) * c.channels, rois + ((long)b * m + t) * 7, box);
         raw = cls[(long)b * m + t];
         const float norm = 1.0f / (1.0f + expf(-raw));
         selected = norm > c.score_thresh;
@@ -407,6 +412,126 @@ __global__ __launch_bounds__(128) void rcnn_final_gather_kernel(int m, const flo
 #pragma unroll
         for (int e = 0; e < 7; ++e) o[e] = 0.f;
         scores[(long)b * m + j] = 0.f;
+    }
+}
+
+// ---- the whole final stage of a scene in ONE workgroup (round 4).  The four launches above and in iou3d.hip (decode + sort, all-pairs
+// suppression mask, resolve, gather: 88 us of the feature stream per step, most of it launch gaps and half-empty waves) become one:
+//   decode and score-sort as rcnn_decode_select_kernel (same code), the sorted BEV rows stay in LDS;
+//   CANDIDATE pairs: every (row r, column c > r) whose boxes can touch at all (rbox_far_apart: bounding circles) goes onto a list in
+//     LDS -- of the 4950 pairs of 100 boxes a few hundred; the rotated IoU (~600 VALU instructions, divergent) then runs over the
+//     compacted list only, full waves;
+//   the greedy resolve over the row masks (iou3d.cpp:100-119) by one thread, then the gather of the kept boxes.
+// Same expressions in the same (row, column) order as nms_dense_mask_kernel: the same keep list (a pair the filter drops has overlap
+// exactly 0 in the reference's arithmetic as well -- no vertex of the clipped polygon exists).
+constexpr int RF_THREADS = 256, RF_MAX = 128;
+
+__global__ __launch_bounds__(RF_THREADS) void rcnn_final_kernel(
+    int m, RcnnCfg c, float nms_thresh, const float *__restrict__ rois, const float *__restrict__ reg, const float *__restrict__ cls,
+    float *__restrict__ pred /* (b,m,7) decoded, RoI order */, float *__restrict__ boxes /* (b,m,7) */, float *__restrict__ scores /* (b,m) */,
+    int *__restrict__ num /* (b) */)
+{
+    __shared__ unsigned long long keys[RF_MAX];
+    __shared__ unsigned long long s_mask[RF_MAX][2];
+    __shared__ float s_box[RF_MAX * 8];                  // decoded box + raw score, RoI order
+    __shared__ float s_row[RF_MAX * 7];                  // BEV box + cos, sin of the heading, score order
+    __shared__ int s_src[RF_MAX], s_keep[RF_MAX];
+    __shared__ unsigned int s_pair[RF_MAX * (RF_MAX - 1) / 2];      // (r << 16) | c
+    __shared__ int nsel, s_npair, s_nkeep;
+    __shared__ float s_poly[POLY_LDS_FLOATS * RF_THREADS];          // the clipped polygons (72 KB): see PolyLds
+    const int b = blockIdx.x, t = threadIdx.x;
+    float raw = 0.f;
+    bool selected = false;
+    if (t == 0) { nsel = 0; s_npair = 0; }
+    __syncthreads();
+    if (t < m) {
+        float box[7];
+        rcnn_decode_box(c, reg + ((long)b * m + t) * c.channels, rois + ((long)b * m + t) * 7, box);
+        raw = cls[(long)b * m + t];
+        const float norm = 1.0f / (1.0f + expf(-raw));
+        selected = norm > c.score_thresh;
+        float *o = pred + ((long)b * m + t) * 7;
+#pragma unroll
+        for (int e = 0; e < 7; ++e) { o[e] = box[e]; s_box[t * 8 + e] = box[e]; }
+        s_box[t * 8 + 7] = raw;
+    }
+    if (t < RF_MAX) {
+        keys[t] = (t < m && selected) ? sort_key(raw, (unsigned)t) : (~0ull - 127 + t);
+        if (t < m && selected) atomicAdd(&nsel, 1);
+        s_mask[t][0] = 0ull; s_mask[t][1] = 0ull;
+    }
+    __syncthreads();
+    for (int k = 2; k <= RF_MAX; k <<= 1)
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            const int partner = t ^ j;
+            if (t < RF_MAX && partner > t) {
+                const bool up = ((t & k) == 0);
+                const unsigned long long a = keys[t], d = keys[partner];
+                if ((a > d) == up) { keys[t] = d; keys[partner] = a; }
+            }
+            __syncthreads();
+        }
+    const int n = nsel;
+    if (t < n) {                                         // slot t of the score order holds RoI `src`
+        const int src = (int)(keys[t] & 0xffffffffu);
+        s_src[t] = src;
+        const float *q = s_box + src * 8;
+        const float hl = q[5] / 2, hw = q[4] / 2;
+        float *v = s_row + t * 7;
+        v[0] = q[0] - hl; v[1] = q[2] - hw; v[2] = q[0] + hl; v[3] = q[2] + hw; v[4] = q[6];
+        v[5] = cos_f32(q[6]); v[6] = sin_f32(q[6]);
+    }
+    __syncthreads();
+    // candidate pairs: e = r (2 n - r - 1) / 2 + (c - r - 1) enumerates (r, c > r) row by row
+    const int P = n * (n - 1) / 2;
+    for (int e = t; e < P; e += RF_THREADS) {
+        const float tn = (float)(2 * n - 1);
+        int r = (int)((tn - sqrtf(tn * tn - 8.0f * (float)e)) * 0.5f);
+        r = min(max(r, 0), n - 2);
+        while (r > 0 && r * (2 * n - r - 1) / 2 > e) --r;
+        while ((r + 1) * (2 * n - r - 2) / 2 <= e) ++r;
+        const int cc = r + 1 + (e - r * (2 * n - r - 1) / 2);
+        if (!rbox_far_apart(s_row + r * 7, s_row + cc * 7)) s_pair[atomicAdd(&s_npair, 1)] = ((unsigned)r << 16) | (unsigned)cc;
+    }
+    __syncthreads();
+    const int np = s_npair;
+    for (int i = t; i < np; i += RF_THREADS) {
+        const unsigned int rc = s_pair[i];
+        const int r = (int)(rc >> 16), cc = (int)(rc & 0xffffu);
+        RBox C;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) C.v[q] = s_row[cc * 7 + q];
+        C.cosv = s_row[cc * 7 + 5]; C.sinv = s_row[cc * 7 + 6];
+        if (suppresses<true, true>(s_row, r, C, nms_thresh, s_poly + t, RF_THREADS))
+            atomicOr(&s_mask[r][cc >> 6], 1ull << (cc & 63));
+    }
+    __syncthreads();
+    if (t == 0) {                                        // the host loop of iou3d.cpp:100-119 over the row masks
+        unsigned long long gone0 = 0ull, gone1 = 0ull;
+        int nk = 0;
+        for (int cc = 0; cc < n; ++cc) {
+            const bool gone = cc < 64 ? (gone0 >> cc) & 1ull : (gone1 >> (cc - 64)) & 1ull;
+            if (gone) continue;
+            s_keep[nk++] = cc;
+            gone0 |= s_mask[cc][0];
+            gone1 |= s_mask[cc][1];
+        }
+        s_nkeep = nk;
+        num[b] = nk;
+    }
+    __syncthreads();
+    if (t < m) {
+        float *o = boxes + ((long)b * m + t) * 7;
+        if (t < s_nkeep) {
+            const float *q = s_box + s_src[s_keep[t]] * 8;
+#pragma unroll
+            for (int e = 0; e < 7; ++e) o[e] = q[e];
+            scores[(long)b * m + t] = q[7];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 7; ++e) o[e] = 0.f;
+            scores[(long)b * m + t] = 0.f;
+        }
     }
 }
 
@@ -545,6 +670,12 @@ extern "C" int prcnn_rcnn_postprocess(int b, int m, int channels, float loc_scop
     if (b == 0) return PRCNN_OK;
     PRCNN_REQUIRE(rois && rcnn_reg && rcnn_cls && pred_boxes3d && boxes && scores && num, "rcnn_postprocess: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    static const bool fused = !(getenv("PRCNN_FINAL_FUSED") && atoi(getenv("PRCNN_FINAL_FUSED")) == 0);     // A/B switch, same results
+    if (fused && nms_thresh >= 0.f) {
+        hipLaunchKernelGGL(rcnn_final_kernel, dim3(b), dim3(RF_THREADS), 0, st, m, c, nms_thresh, rois, rcnn_reg, rcnn_cls, pred_boxes3d,
+                           boxes, scores, num);
+        return check_launch("rcnn_postprocess");
+    }
     const size_t o_sorted = 0;
     const size_t o_bev = o_sorted + aligned((size_t)b * m * 8 * 4);
     const size_t o_cnt = o_bev + aligned((size_t)b * m * 5 * 4);

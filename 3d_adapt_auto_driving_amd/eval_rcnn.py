@@ -76,6 +76,12 @@ def _anchor_on(cfg, device):
     return _ANCHORS[key]
 
 
+def split_detections(blob, batch_size, M):
+    """blob (batch_size * (8 M + 1)) f32, device or host -> views boxes (B,M,7) f32, scores (B,M) f32, num (B) i32 (the same bytes)."""
+    nb, ns = batch_size * M * 7, batch_size * M
+    return (blob[:nb].view(batch_size, M, 7), blob[nb:nb + ns].view(batch_size, M), blob[nb + ns:nb + ns + batch_size].view(torch.int32))
+
+
 @torch.no_grad()
 def postprocess(cfg, ret_dict, batch_size):
     """Final box decoding + score threshold + rotated NMS, batched (eval_rcnn.py:506-530,611-629).
@@ -93,14 +99,15 @@ def postprocess(cfg, ret_dict, batch_size):
         # one extension call (three launches): decode, threshold, score sort, rotated NMS, assembly
         dev = rois.device
         pred = torch.empty((batch_size, M, 7), dtype=torch.float32, device=dev)
-        boxes = torch.empty((batch_size, M, 7), dtype=torch.float32, device=dev)
-        scores = torch.empty((batch_size, M), dtype=torch.float32, device=dev)
-        num = torch.empty((batch_size,), dtype=torch.int32, device=dev)
+        # the three results in ONE allocation ("blob": boxes | scores | num, see split_detections): the consumer brings them to the host
+        # with one copy instead of three
+        blob = torch.empty((batch_size * (M * 8 + 1),), dtype=torch.float32, device=dev)
+        boxes, scores, num = split_detections(blob, batch_size, M)
         raw = raw.contiguous()
         ext.rcnn_postprocess(rois.contiguous(), rcnn_reg.contiguous(), raw, _anchor_host(cfg), R.LOC_SCOPE,
                              R.LOC_BIN_SIZE, R.NUM_HEAD_BIN, R.LOC_Y_BY_BIN, R.LOC_Y_SCOPE, R.LOC_Y_BIN_SIZE,
                              R.SCORE_THRESH, R.NMS_THRESH, pred, boxes, scores, num)
-        return {"boxes": boxes, "scores": scores, "num": num, "pred_boxes3d": pred, "raw_scores": raw}
+        return {"boxes": boxes, "scores": scores, "num": num, "pred_boxes3d": pred, "raw_scores": raw, "blob": blob}
     anchor = _anchor_on(cfg, rois.device)
     pred = decode_bbox_target(rois.view(-1, 7), rcnn_reg.view(-1, rcnn_reg.shape[-1]), anchor_size=anchor,
                               loc_scope=R.LOC_SCOPE, loc_bin_size=R.LOC_BIN_SIZE, num_head_bin=R.NUM_HEAD_BIN,
@@ -1242,7 +1249,13 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
 
     def start_copy(det, ids, meta, order):
         with torch.cuda.stream(det["stream"]) if "stream" in det else contextlib.nullcontext():
-            if on_gpu:
+            if on_gpu and det.get("blob") is not None:
+                hb = torch.empty(det["blob"].shape, dtype=torch.float32, pin_memory=True)
+                hb.copy_(det["blob"], non_blocking=True)            # boxes | scores | num in one transfer
+                host = list(split_detections(hb, det["boxes"].shape[0], det["boxes"].shape[1]))
+                done = torch.cuda.Event()
+                done.record()
+            elif on_gpu:
                 host = [torch.empty(det[k].shape, dtype=det[k].dtype, pin_memory=True) for k in ("boxes", "scores", "num")]
                 for h, k in zip(host, ("boxes", "scores", "num")):
                     h.copy_(det[k], non_blocking=True)

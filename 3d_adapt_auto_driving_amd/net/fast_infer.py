@@ -1016,8 +1016,17 @@ class FastPointRCNN:
                             "f": f})
                 cur_xyz = None
             levels.append(lev)
+        shapes = []
+        for (npoint, radius, ns, mlp, cin), lev in zip(self.rcnn_sa, levels):
+            cout = mlp.layers[-1][0].shape[1]
+            if lev["pack"] is not None and USE_PACKED and (mlp.packed is not None or mlp.wide is not None):
+                rows_out = lev["xyz"].shape[0] * (npoint if npoint is not None else lev["f"])
+                shapes.append(rows_out * cout)
+            else:
+                shapes.append(0)
+        arena = torch.zeros((sum(shapes),), dtype=torch.float32, device=rows.device) if sum(shapes) else None
         return {"B": B, "M": M, "P": P, "W": W, "rows": rows, "a": a, "rpn_part": rpn_part, "pooled": pooled, "pooled_cnt": pooled_cnt,
-                "point_mlp": point_mlp, "tiles": tiles, "levels": levels}
+                "point_mlp": point_mlp, "tiles": tiles, "levels": levels, "arena": arena, "arena_shapes": shapes}
 
     def _rcnn_features(self, rg):
         """The MLPs of the RCNN stage over the rows and row lists of `_rcnn_geometry`: xyz_up + merge_down + SA levels + heads."""
@@ -1039,16 +1048,9 @@ class FastPointRCNN:
             xyz_feature = self.xyz_up(rg["a"])                                 # (rows, 128)
             merged = self.merge_down(torch.cat((xyz_feature, rg["rpn_part"]), dim=1))
             l_feat = [merged.view(B * M, P, -1)]
-        # the levels that pool through atomicMax (packed rows) want zeroed outputs: ONE fill for all of them
-        shapes = []
-        for (npoint, radius, ns, mlp, cin), lev in zip(self.rcnn_sa, rg["levels"]):
-            cout = mlp.layers[-1][0].shape[1]
-            if lev["pack"] is not None and USE_PACKED and (mlp.packed is not None or mlp.wide is not None):
-                rows_out = lev["xyz"].shape[0] * (npoint if npoint is not None else lev["f"])
-                shapes.append(rows_out * cout)
-            else:
-                shapes.append(0)
-        arena = torch.zeros((sum(shapes),), dtype=torch.float32, device=rows.device) if sum(shapes) else None
+        # the levels that pool through atomicMax (packed rows) want zeroed outputs: ONE fill for all of them -- made with the geometry
+        # (80 MB per batch of 800 RoIs: 16 us that the proposal stream has to spare and the feature stream has not)
+        shapes, arena = rg["arena_shapes"], rg["arena"]
         offs = [sum(shapes[:k]) for k in range(len(shapes))]
         for k, ((npoint, radius, ns, mlp, cin), lev) in enumerate(zip(self.rcnn_sa, rg["levels"])):
             cur_xyz, cur_feat = lev["xyz"], l_feat[-1]

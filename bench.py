@@ -468,9 +468,10 @@ def main():
         assert runner.depth + 2 <= len(batches), "batch slots must outnumber the look-ahead"
         n_slots = len(batches)
         total = warmup + steps
-        host_boxes = torch.empty((total, BATCH, M, 7), pin_memory=True)
-        host_scores = torch.empty((total, BATCH, M), pin_memory=True)
-        host_num = torch.empty((total, BATCH), dtype=torch.int32, pin_memory=True)
+        # one pinned record per batch: boxes | scores | num (E.split_detections) -- the runner hands them over in one allocation
+        host_blob = torch.empty((total, BATCH * (M * 8 + 1)), pin_memory=True)
+        views = [E.split_detections(host_blob[i], BATCH, M) for i in range(total)]
+        host_boxes = [v[0] for v in views]; host_scores = [v[1] for v in views]; host_num = [v[2] for v in views]
 
         import collections
         ready = collections.deque()
@@ -478,9 +479,12 @@ def main():
         def copy_out(det, i):
             # async D2H of batch i's detections into its pinned slot, on the stream that produced them
             with torch.cuda.stream(det["stream"]) if "stream" in det else contextlib.nullcontext():
-                host_boxes[i].copy_(det["boxes"], non_blocking=True)
-                host_scores[i].copy_(det["scores"], non_blocking=True)
-                host_num[i].copy_(det["num"], non_blocking=True)
+                if det.get("blob") is not None:
+                    host_blob[i].copy_(det["blob"], non_blocking=True)
+                else:
+                    host_boxes[i].copy_(det["boxes"], non_blocking=True)
+                    host_scores[i].copy_(det["scores"], non_blocking=True)
+                    host_num[i].copy_(det["num"], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
             # the host consumes results 3 batches late (as eval_rcnn.eval_scenes does): it never waits for the batch it
