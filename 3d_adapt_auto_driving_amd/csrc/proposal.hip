@@ -742,7 +742,9 @@ extern "C" int prcnn_rpn_proposals(int b, int n, int channels, float loc_scope, 
         }
         hipLaunchKernelGGL(score_sort_kernel, dim3(b), dim3(1024), lds, st, n, npad, scores, order);
     }
-    static const bool select2 = !(getenv("PRCNN_BAND_SELECT2") && atoi(getenv("PRCNN_BAND_SELECT2")) == 0);   // A/B, same tables
+    // opt-in (PRCNN_BAND_SELECT2=1): same tables; 12 us instead of 61 alone, but the step did not move (6460 / 6484 scenes/s with it, 6518 /
+    // 6522 without, K = 96): the proposal stream's latency kernels are not what bounds a step
+    static const bool select2 = getenv("PRCNN_BAND_SELECT2") && atoi(getenv("PRCNN_BAND_SELECT2")) != 0;
     const size_t tab_lds = (size_t)(pre_near + pre_far) * sizeof(int);
     if (select2 && n <= 1024 * BS_V && tab_lds <= 120 * 1024) {
         if (tab_lds > 48 * 1024) {
