@@ -52,3 +52,7 @@ else:
     GRAPH_REPLAY_SAFE = True
 if _os.environ.get("PRCNN_GRAPHS_FORCE") == "1":                  # profiles/graph_fault_probe.py: replay although it is unsafe
     GRAPH_REPLAY_SAFE = True
+
+# every PRCNN_* switch is declared in switches.py; a variable of that prefix that nobody reads is most likely a typo
+from . import switches as _switches  # noqa: E402
+_switches.check_environment()

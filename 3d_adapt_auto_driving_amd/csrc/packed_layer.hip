@@ -22,6 +22,8 @@
 
 namespace prcnn {
 
+unsigned int *next_ticket(hipStream_t st);    // sa_mlp_fused.hip: a zeroed, self-resetting 16-word ticket record of the stream's ring
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int PL_ROWS = 64;
 constexpr int PL_LD = 128 + 4;
@@ -124,12 +126,18 @@ __global__ __launch_bounds__(256) void packed_gather_affine_kernel(const PGBatch
             a0 = n0; a1 = n1;                                                                           \
         }                                                                                               \
     }
-#define PL_STAGE_PREFETCH(T, TN, wf, wn, kn)                                                            \
+// (the scalar offsets of the 64 weight loads and the 8 row loads RUN -- one s_add each, opaque to the optimiser: written as products
+//  of constants with row_bytes the compiler hoists all 72 of them into SGPRs of their own, and a kernel with anything else to keep in
+//  scalar registers -- the persistent one below -- spills them into VGPR lanes: 248 v_readlane / v_writelane inside the MFMA stream)
+#define PL_SADD(x, y) asm volatile("s_add_u32 %0, %0, %1" : "+s"(x) : "s"(y) : "scc");
+#define PL_STAGE_PREFETCH_X(T, TN, wf, wn, kn, ARS, LOFF)                                               \
     {                                                                                                   \
         const float *a0p = (T) + j * PL_LD + 64 * h, *a1p = (T) + (32 + j) * PL_LD + 64 * h;            \
         f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p);                                               \
         f32x4 a1 = *reinterpret_cast<const f32x4 *>(a1p);                                               \
         f32x4 ar[8];                                                                                    \
+        unsigned int wo_ = (unsigned int)(kn) * row_bytes, ao_ = (unsigned int)(kn) * 4u;               \
+        const unsigned int a8_ = 8u * a_row_bytes;                                                      \
         _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                \
             f32x4 n0 = a0, n1 = a1;                                                                     \
             if (g < 15) {                                                                               \
@@ -138,20 +146,22 @@ __global__ __launch_bounds__(256) void packed_gather_affine_kernel(const PGBatch
             }                                                                                           \
             __builtin_amdgcn_sched_barrier(0);                                                          \
             PL_GROUP_MFMA_HEAD(wf)                                                                      \
-            if (g < 8)                                                                                  \
-                ar[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                \
-                    ars, a_lane, (unsigned int)(8 * g) * a_row_bytes + (unsigned int)(kn) * 4u, 0));    \
-            else                                                                                        \
+            if (g < 8) {                                                                                \
+                ar[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((ARS), a_lane, ao_, 0)); \
+                PL_SADD(ao_, a8_)                                                                       \
+            } else                                                                                      \
                 *reinterpret_cast<f32x4 *>((TN) + (r0 + 8 * (g - 8)) * PL_LD + 4 * chunk) = ar[g - 8];  \
             _Pragma("unroll") for (int q = 0; q < 6; ++q)                                               \
-                if (6 * g + q < 64)                                                                     \
-                    wn[6 * g + q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(               \
-                        wrs, lane_off, (unsigned int)((kn) + 6 * g + q) * row_bytes, 0));               \
+                if (6 * g + q < 64) {                                                                   \
+                    wn[6 * g + q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, (LOFF), wo_, 0)); \
+                    PL_SADD(wo_, row_bytes)                                                             \
+                }                                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                                          \
             PL_GROUP_MFMA_TAIL(wf)                                                                      \
             a0 = n0; a1 = n1;                                                                           \
         }                                                                                               \
     }
+#define PL_STAGE_PREFETCH(T, TN, wf, wn, kn) PL_STAGE_PREFETCH_X(T, TN, wf, wn, kn, ars, lane_off)
 
 // the same stage with the NEXT ROW TILE of a K = 128 layer coming in behind it (packed_layer_stream_kernel: the weights stay):
 // 8 rows per thread as buffer loads at scalar offset `soff` in k-groups 0-7, written to the other LDS tile in k-groups 8-15
@@ -367,6 +377,122 @@ __global__ __launch_bounds__(256, 2) void packed_layer_pipe_kernel(
     pl_epilogue<SEGMAX>(acc0, acc1, tiles, ctr, t, rows, n0, bias, do_relu, out, ldo, rowinfo, tilecloud, m, out_col, n_store, pb.lds_pool, &pb);
 }
 
+// ---- K >= 256 layers, PERSISTENT (round 4).  packed_layer_pipe_kernel pays per 64 x 128 tile what profiles/layer_k_sweep.py measures as
+// the intercept of time over K: 9.4 us per round of workgroups -- dispatch, an exposed round trip for the first panel (64 weights per
+// lane + 8 rows), the LDS-staged epilogue with two barriers, the drain of its stores -- against 7.8 us of MFMAs per panel: 0.55 of
+// the MFMA peak at K = 256, 0.67 at K = 512 (0.88 is the slope).  Here a workgroup draws (row tile, column block) items from a ticket
+// and never leaves the panel pipeline: the FIRST panel of the next item is fetched behind the MFMAs of the last panel of the running
+// one (same PL_STAGE_PREFETCH, other buffer resources), and the epilogue needs no LDS and no barrier -- every lane stores its 32
+// results straight from the accumulators (a wave's store instruction covers two 128-byte row segments).  Per output element the
+// MFMA sequence, the bias add and the ReLU are those of the one-tile kernels: same bits.  Host-count mode, N == n_store, no pooling,
+// no interpolation addend.
+__global__ __launch_bounds__(256, 2) void packed_layer_persist_kernel(
+    long rows, int K, int N, const float *__restrict__ A, long lda, const float *__restrict__ W, const float *__restrict__ bias,
+    int do_relu, float *__restrict__ out, long ldo, unsigned int *__restrict__ ticket)
+{
+    __shared__ float tiles[2 * PL_ROWS * PL_LD];
+    __shared__ unsigned int s_item[2];
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = tid & 31, r0 = tid >> 5;
+    const unsigned int col_blocks = (unsigned int)(N >> 7);
+    const unsigned int n_tiles = (unsigned int)((rows + PL_ROWS - 1) / PL_ROWS);
+    const unsigned int n_items = n_tiles * col_blocks;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, K * N * 4, 0x00020000);
+    const unsigned int row_bytes = (unsigned int)N * 4u;
+    const unsigned int a_row_bytes = (unsigned int)lda * 4u;
+    const unsigned int a_lane = (unsigned int)r0 * a_row_bytes + 16u * chunk;
+    const int np = K >> 7;
+    // the rows of a tile as their own buffer: rows past the end (a ragged last tile) read as 0
+    auto tile_rsrc = [&](unsigned int t) __attribute__((always_inline)) {
+        const long left = rows - (long)t * PL_ROWS;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(A + (long)t * PL_ROWS * lda), 0,
+                                                 (int)((left < PL_ROWS ? left : PL_ROWS) * (long)a_row_bytes), 0x00020000);
+    };
+    auto loff = [&](unsigned int cb) __attribute__((always_inline)) {
+        return ((unsigned int)(64 * h) * (unsigned int)N + (cb * 128u + (unsigned int)(32 * w + j))) * 4u;
+    };
+    // the first item is the workgroup's index (no round trip in front of the first loads; the host launches no more workgroups than
+    // items), the later ones are drawn: gridDim.x + ticket
+    unsigned int item = blockIdx.x;
+    // items in column-block-minor order: neighbours in the draw order share their rows of A
+    unsigned int t = item / col_blocks, cb = item - t * col_blocks;
+    __amdgpu_buffer_rsrc_t ars = tile_rsrc(t);
+    unsigned int lane_off = loff(cb);
+    float wa[64], wb[64];
+    {
+        PL_LOAD_W(wa, 0)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<f32x4 *>(tiles + (r0 + 8 * i) * PL_LD + 4 * chunk) =
+                __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, a_lane, (unsigned int)(8 * i) * a_row_bytes, 0));
+    }
+    int pp = 0;                                              // panels staged so far: the LDS tile alternates across items too
+    int slot = 1;
+    PL_VM_DRAIN                                              // the first item's first panel has arrived
+    while (true) {
+        f32x16 acc0 = {0}, acc1 = {0};
+        unsigned int next = 0xffffffffu, tn = 0, cbn = 0, drawn = 0;
+        const float bcol = bias[(int)cb * 128 + 32 * w + j];    // (arrives behind the first panel: waited for by the drain of the second)
+        for (int p = 0; p < np; ++p, ++pp) {
+            // the panel about to be used is complete (weights in registers, rows in LDS): panel 0 of an item was waited for at the end
+            // of the item before it (or above) -- no wait here, so that the stores of that item's results stay in flight behind this
+            // panel's MFMAs (vmcnt counts loads and stores alike)
+            if (p > 0) {
+                PL_VM_DRAIN
+                if (p == 1 && tid == 0) s_item[slot] = drawn;
+            }
+            lds_barrier();                                   // ... and published; the other tile is free
+            // the NEXT item is drawn here: the atomic's round trip hides behind this panel's MFMAs, its value is read at the last panel
+            if (p == 0 && tid == 0) drawn = gridDim.x + atomicAdd(ticket, 1u);
+            const float *T = tiles + (pp & 1) * (PL_ROWS * PL_LD);
+            float *TN = tiles + ((pp + 1) & 1) * (PL_ROWS * PL_LD);
+            if (p + 1 < np) {
+                PL_STAGE_PREFETCH(T, TN, wa, wb, (p + 1) * 128)
+#pragma unroll
+                for (int s2 = 0; s2 < 64; ++s2) wa[s2] = wb[s2];
+            } else {
+                next = s_item[slot];                         // (np >= 2: published before this panel's barrier)
+                if (next < n_items) {
+                    tn = next / col_blocks; cbn = next - tn * col_blocks;
+                    const __amdgpu_buffer_rsrc_t ars_n = tile_rsrc(tn);
+                    const unsigned int loff_n = loff(cbn);
+                    PL_STAGE_PREFETCH_X(T, TN, wa, wb, 0, ars_n, loff_n)
+#pragma unroll
+                    for (int s2 = 0; s2 < 64; ++s2) wa[s2] = wb[s2];
+                    PL_VM_DRAIN                              // (fetched behind 128 MFMAs: normally there already)
+                } else {
+                    PL_STAGE(T, wa)
+                }
+            }
+        }
+        // epilogue straight from the accumulators: lane (column j of its wave's 32, rows (r & 3) + 8 (r >> 2) + 4 h [+ 32]), as buffer
+        // stores into the tile's own rows of `out` -- rows past the end of a ragged last tile are outside the buffer and dropped by its
+        // bounds check: no per-lane compare, no 64-bit address arithmetic, and above all no wait in front of a store (a store under a
+        // per-lane condition made the compiler wait for vmcnt(0) -- i.e. for the store before it -- 32 times per item)
+        {
+            const long left = rows - (long)t * PL_ROWS;
+            const unsigned int o_row_bytes = (unsigned int)ldo * 4u;
+            const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(out + (long)t * PL_ROWS * ldo), 0, (int)((left < PL_ROWS ? left : PL_ROWS) * (long)o_row_bytes), 0x00020000);
+            const unsigned int o_lane = (unsigned int)(4 * h) * o_row_bytes + (cb * 128u + (unsigned int)(32 * w + j)) * 4u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned int so = (unsigned int)((r & 3) + 8 * (r >> 2)) * o_row_bytes;
+                const float v0 = acc0[r] + bcol, v1 = acc1[r] + bcol;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(do_relu ? fmaxf(v0, 0.f) : v0), ors, o_lane, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(do_relu ? fmaxf(v1, 0.f) : v1), ors, o_lane, so + 32u * o_row_bytes, 0);
+            }
+        }
+        if (next >= n_items) break;
+        t = tn; cb = cbn;
+        ars = tile_rsrc(t);
+        lane_off = loff(cb);
+        slot ^= 1;
+    }
+    if (tid == 0) ticket_release(ticket);
+}
+
 // ---- K = 128 layers over many row tiles (the per-point parts of the SA levels: 10^5 rows, one panel): PERSISTENT workgroups.
 // With one tile per workgroup every tile paid its own 64 weight loads (64 KB per workgroup from L2), an exposed round trip for
 // its rows and an epilogue nobody overlapped: 55-59 TFLOP/s (profiles/r02_microbench.md).  Here a workgroup keeps its 128 x 32
@@ -566,6 +692,7 @@ static bool pipe_enabled()
 }
 
 static long stream_min() { static const long v = getenv("PRCNN_PL_STREAM_MIN") ? atol(getenv("PRCNN_PL_STREAM_MIN")) : 512; return v; }
+static long persist_min() { static const long v = getenv("PRCNN_PL_PERSIST_MIN") ? atol(getenv("PRCNN_PL_PERSIST_MIN")) : 256; return v; }
 static long stream_cap() { static const long v = getenv("PRCNN_PL_STREAM_CAP") ? atol(getenv("PRCNN_PL_STREAM_CAP")) : 512; return v; }
 // PRCNN_PL_STREAM=0: K = 128 layers with one row tile per workgroup (A/B switch, same results)
 static bool stream_enabled()
@@ -687,6 +814,18 @@ extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr
         ++k;
     }
     if (k == 0) return PRCNN_OK;
+    // one plain K >= 256 layer over rows counted on the host, whole 128-column blocks stored: the persistent pipeline (round 4;
+    // PRCNN_PL_PERSIST=0: one tile per workgroup as in round 3, same bits)
+    static const bool persist = !(getenv("PRCNN_PL_PERSIST") && atoi(getenv("PRCNN_PL_PERSIST")) == 0);
+    if (persist && k == 1 && cls[0] == PL_PIPE && !segmax && !bt.p[0].hdr && bt.p[0].n_store == bt.p[0].N && !pr[src[0]].hdr &&
+        tiles_of[0] * blocks_of[0] > stream_cap() && tiles_of[0] * blocks_of[0] >= persist_min()) {   // (items <= workgroups: nothing to pipeline)
+        const PLProblem &q = bt.p[0];
+        const long items = tiles_of[0] * blocks_of[0];
+        const long cap = stream_cap();
+        hipLaunchKernelGGL(packed_layer_persist_kernel, dim3((unsigned)(items < cap ? items : cap)), dim3(256), 0, st, q.rows_host, q.K, q.N,
+                           q.A, q.lda, q.W, q.bias, q.do_relu, q.out, q.ldo, next_ticket(st));
+        return check_launch("packed_layer");
+    }
     bool together = cls[0] != PL_PIPE32 && cls[0] != PL_STREAM;
     for (int i = 1; i < k; ++i) together = together && cls[i] == cls[0];
     for (int i = 0; i < k; ++i) {

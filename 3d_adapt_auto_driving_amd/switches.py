@@ -1,0 +1,126 @@
+"""Every PRCNN_* environment switch of the package, the C library and bench.py in ONE table ("a lot of surface").
+
+kind:
+  operational  sizes the runner / the host side for a deployment (streams, slots, worker processes): the ones a user may have to touch
+  numerics     changes the association of a sum or routes a layer through a library GEMM: results move inside BASELINE's 1e-4 box
+               tolerance; everything the parity tests pin runs with these at their defaults
+  ab           A/B switch kept so that a measurement quoted in DESIGN.md / profiles/ can be repeated: SAME results, bit for bit, either
+               way (each has a test or a shadow check behind it); the default is the measured-faster form
+  tuning       a launch-geometry knob of one kernel (grid, tile or cell counts): same results
+  debug, bench what the names say
+All of them are read ONCE (module import / first call of the C entry that owns them): set them before the process starts.
+`check_environment()` (called by the package's __init__) warns about PRCNN_* variables that are not in this table -- a typo would
+otherwise be silently ignored; `python -m 3d_adapt_auto_driving_amd.switches` prints the table and what is set.
+tests/test_host_logic.py::test_every_switch_is_registered keeps the table and the sources in step."""
+import os
+import warnings
+
+# name: (kind, default, read by, meaning)
+SWITCHES = {
+    # ---- operational
+    "PRCNN_GRAPHS": ("operational", "1", "eval_rcnn.py", "0: eager enqueue (PipelinedRunner) instead of hipGraph replay (GraphedRunner)"),
+    "PRCNN_GRAPH_SLOTS": ("operational", "depth/group+1", "eval_rcnn.py", "group slots of the graphed runner (>= 2; 5.9 GB of HBM each at batch 8)"),
+    "PRCNN_GEO_GROUP": ("operational", "4", "eval_rcnn.py", "batches per geometry chain"),
+    "PRCNN_GEO_DEPTH": ("operational", "3*group", "eval_rcnn.py", "batches the geometry runs ahead"),
+    "PRCNN_SIDE_STREAMS": ("operational", "2", "eval_rcnn.py", "geometry side streams (with feature + proposal stream: the 4 hardware queues)"),
+    "PRCNN_LOADER_WORKERS": ("operational", "budget", "eval_rcnn.py", "loader processes of eval_scenes (default: host_budget)"),
+    "PRCNN_WRITER_PROCS": ("operational", "budget", "eval_rcnn.py", "KITTI result writer processes"),
+    "PRCNN_LOADER_CONTEXT": ("operational", "forkserver/fork", "eval_rcnn.py", "multiprocessing start method of loaders and writers"),
+    "PRCNN_NO_AFFINITY": ("operational", "unset", "eval_rcnn.py", "1: do not pin a rank to its share of the host cores"),
+    "PRCNN_RESULT_LAG": ("operational", "3", "eval_rcnn.py", "batches between submitting a batch and reading its detections on the host"),
+    "PRCNN_GRAPHS_FORCE": ("debug", "unset", "__init__.py", "1: replay graphs although DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was not in place (profiles/graph_fault_probe.py)"),
+    "PRCNN_GRAPH_DEBUG": ("debug", "0", "eval_rcnn.py", "bit mask: device syncs + prints around the graph replays"),
+    # ---- numerics
+    "PRCNN_NO_FP_LINEAR": ("numerics", "unset", "net/fast_infer.py", "FP layer 1 over the interpolated tensor (reference association) instead of interp(W f)"),
+    "PRCNN_LIB_GEMM": ("numerics", "unset", "net/fast_infer.py", "per-point layers through torch (library GEMM) instead of csrc/packed_layer.hip"),
+    "PRCNN_ALLOW_LIB_GEMM": ("numerics", "unset", "net/fast_infer.py", "1: permit a library GEMM for a shape the layer kernels do not cover (else: error)"),
+    "PRCNN_ROWS_GEMM": ("numerics", "unset", "net/fast_infer.py", "128-wide row layers through rows_gemm128 (round-1 form)"),
+    # ---- scheduling A/B (same results)
+    "PRCNN_EARLY_LEVELS": ("ab", "4", "net/fast_infer.py", "leading SA levels computed with the geometry"),
+    "PRCNN_EARLY_FP": ("ab", "3", "net/fast_infer.py", "coarsest FP modules computed with the geometry"),
+    "PRCNN_EARLY_G0": ("ab", "1", "net/fast_infer.py", "the finest FP module's coarse product computed with the geometry (round 4: +1.2 %)"),
+    "PRCNN_EARLY_TAIL": ("ab", "0", "net/fast_infer.py", "1: the whole RPN tail with the geometry (round 4: slower, 6042 vs 6382)"),
+    "PRCNN_NO_XYZ_EARLY": ("ab", "unset", "net/fast_infer.py", "1: no SA level rides with the geometry"),
+    "PRCNN_NO_GROUP_SA": ("ab", "unset", "net/fast_infer.py", "1: early SA levels per batch instead of per geometry group"),
+    "PRCNN_FINAL_ON_FEATURE": ("ab", "1", "eval_rcnn.py", "0: final stage on the proposal stream (round 3)"),
+    "PRCNN_NO_RCNN_SPLIT": ("ab", "unset", "eval_rcnn.py", "1: RCNN geometry on the feature stream"),
+    "PRCNN_RCNN_GEO_STREAM": ("ab", "0", "eval_rcnn.py", "1: RCNN geometry on a stream of its own (a 5th queue: slower)"),
+    "PRCNN_GEO_THREAD": ("ab", "0", "eval_rcnn.py", "1: geometry chains enqueued by a helper thread (slower: GIL)"),
+    "PRCNN_GATE": ("ab", "unset", "eval_rcnn.py", "1: gate a chain's second link behind the previous RPN stage"),
+    "PRCNN_SIDE_PRIORITY": ("ab", "0", "eval_rcnn.py", "HIP priority of the side streams"),
+    "PRCNN_TAIL_PRIORITY": ("ab", "0", "eval_rcnn.py", "HIP priority of the proposal stream"),
+    "PRCNN_STREAM_SKEW": ("ab", "0", "eval_rcnn.py", "dummy streams created first (moves the streams to other hardware queues)"),
+    # ---- engine formulations A/B (same results)
+    "PRCNN_NO_PACK": ("ab", "unset", "net/fast_infer.py", "all grouped rows instead of the distinct rows (prcnn_ball_pack)"),
+    "PRCNN_NO_POOL_DEDUP": ("ab", "unset", "net/fast_infer.py", "RCNN point MLP over all 512 pooled rows"),
+    "PRCNN_NO_CENTRE_DEDUP": ("ab", "unset", "net/fast_infer.py", "no representative map over sampled centres"),
+    "PRCNN_NO_CENTRE_SKIP": ("ab", "unset", "net/fast_infer.py", "copies of a centre keep rows of their own"),
+    "PRCNN_NO_POOL_GROUPS": ("ab", "unset", "net/fast_infer.py", "RoI pooling sweeps all points (no spatial groups)"),
+    "PRCNN_NO_POINT_MLP": ("ab", "unset", "net/fast_infer.py", "RCNN entrance as separate layers"),
+    "PRCNN_NO_ROI_GEOMETRY": ("ab", "unset", "net/fast_infer.py", "RCNN sampling / ball queries as six launches"),
+    "PRCNN_NO_RPN_TAIL": ("ab", "unset", "net/fast_infer.py", "finest FP module and RPN heads layer by layer"),
+    "PRCNN_NO_SCALE_BATCH": ("ab", "unset", "net/fast_infer.py", "one launch per MSG scale"),
+    "PRCNN_NO_WIDE_FUSED": ("ab", "unset", "net/fast_infer.py", "GroupAll level layer by layer"),
+    # ---- kernel forms A/B (C library; same results)
+    "PRCNN_FPS_SEQUENTIAL": ("ab", "unset", "csrc/fps.hip", "one pick per exchange (round 3 kernel)"),
+    "PRCNN_FPS_NO_PRUNE": ("ab", "unset", "csrc/fps.hip", "full scan per pick"),
+    "PRCNN_THREE_NN_BRUTE": ("ab", "unset", "csrc/interp.hip", "three_nn without the grid"),
+    "PRCNN_TNN_NO_LDS": ("ab", "unset", "csrc/three_nn_grid.hip", "ring search from global memory"),
+    "PRCNN_TNN_UNORDERED": ("ab", "unset", "csrc/three_nn_grid.hip", "queries in input order"),
+    "PRCNN_NMS_DENSE": ("ab", "1", "csrc/iou3d.hip", "0: lazy kernel for small problems"),
+    "PRCNN_NMS_FULL": ("ab", "1", "csrc/iou3d.hip", "0: no full-mask form of the blocking NMS"),
+    "PRCNN_NMS_QUOTA": ("ab", "1", "csrc/iou3d.hip", "0: lazy kernel for the proposal NMS"),
+    "PRCNN_SORT_SPLIT": ("ab", "1", "csrc/proposal.hip", "0: one workgroup sorts a scene's scores"),
+    "PRCNN_BAND_SELECT2": ("ab", "0", "csrc/proposal.hip", "1: band selection in two steps (12 us instead of 61 alone; the step did not move)"),
+    "PRCNN_FINAL_FUSED": ("ab", "1", "csrc/proposal.hip", "0: final stage as four launches (round 3)"),
+    "PRCNN_PACK_NO_MEMSET": ("ab", "unset", "csrc/sa_packed.hip", "1: pack headers counted in a ticket record (slower than the memset)"),
+    "PRCNN_PL_PIPE": ("ab", "1", "csrc/packed_layer.hip", "0: K >= 256 layers without the panel pipeline"),
+    "PRCNN_PL_STREAM": ("ab", "1", "csrc/packed_layer.hip", "0: K = 128 layers one tile per workgroup"),
+    "PRCNN_PL_PERSIST": ("ab", "1", "csrc/packed_layer.hip", "0: K >= 256 layers one tile per workgroup (round 3)"),
+    "PRCNN_SEGMAX_LDS": ("ab", "1", "csrc/packed_layer.hip", "0: segmented max from registers only"),
+    "PRCNN_TAIL_XCD": ("ab", "1", "csrc/rpn_tail.hip", "0: one tile counter instead of one per XCD"),
+    # ---- tuning
+    "PRCNN_MFMA_GRID": ("tuning", "512", "csrc/capi.hip", "workgroups of a persistent MFMA launch"),
+    "PRCNN_SA_GRID": ("tuning", "1024", "csrc/sa_packed.hip", "workgroups of the packed SA kernels"),
+    "PRCNN_SA_TILES": ("tuning", "0", "csrc/sa_mlp_fused.hip", "tiles per workgroup of the fused SA kernel (0 = tickets)"),
+    "PRCNN_PL_STREAM_CAP": ("tuning", "512", "csrc/packed_layer.hip", "workgroups of the persistent layer kernels"),
+    "PRCNN_PL_STREAM_MIN": ("tuning", "512", "csrc/packed_layer.hip", "items from which a K = 128 layer runs persistently"),
+    "PRCNN_PL_PERSIST_MIN": ("tuning", "256", "csrc/packed_layer.hip", "items from which a K >= 256 layer runs persistently (and more than the cap)"),
+    "PRCNN_FPS_LDS_PAD": ("tuning", "84", "csrc/fps.hip", "KB of dynamic LDS an FPS workgroup claims (keeps its CU to itself)"),
+    "PRCNN_TNN_CELLS": ("tuning", "2", "csrc/three_nn_grid.hip", "grid cells per known point"),
+    "PRCNN_GROUP_CHUNKS": ("tuning", "auto", "csrc/ball_group.hip", "channel chunks of the grouping kernels"),
+    "PRCNN_GROUP_ROWS": ("tuning", "auto", "csrc/ball_group.hip", "rows per workgroup of the LDS grouping kernels"),
+    # ---- bench.py
+    "PRCNN_BENCH_BATCH": ("bench", "8", "bench.py", "scenes per step (echoed in config.env_overrides)"),
+    "PRCNN_BENCH_LAG": ("bench", "3", "bench.py", "host result lag of the timed loop"),
+    "PRCNN_BENCH_SHARE_GPU": ("bench", "unset", "bench.py", "1: all ranks on GPU 0 (CPU-side rehearsal of N > 1)"),
+    "PRCNN_BENCH_TRACE": ("bench", "unset", "bench.py", "1: print the per-step host timeline"),
+    "PRCNN_TAIL_OVERLAP": ("bench", "1", "bench.py", "0: runner.step (no software pipeline) instead of submit / flush"),
+}
+
+
+def set_in_environment():
+    return {k: v for k, v in os.environ.items() if k.startswith("PRCNN_")}
+
+
+def check_environment():
+    """Warn about PRCNN_* variables nobody reads (typos)."""
+    unknown = sorted(k for k in set_in_environment() if k not in SWITCHES)
+    if unknown:
+        warnings.warn("unknown PRCNN_* environment variables (ignored): %s -- see python -m 3d_adapt_auto_driving_amd.switches"
+                      % ", ".join(unknown), RuntimeWarning, stacklevel=2)
+    return unknown
+
+
+def table():
+    rows = ["| switch | kind | default | read by | meaning |", "|---|---|---|---|---|"]
+    for name, (kind, default, where, what) in sorted(SWITCHES.items(), key=lambda kv: (kv[1][0], kv[0])):
+        rows.append("| `%s` | %s | %s | `%s` | %s |" % (name, kind, default, where, what))
+    return "\n".join(rows)
+
+
+if __name__ == "__main__":
+    print(table())
+    cur = set_in_environment()
+    print("\nset in this environment: %s" % (", ".join("%s=%s" % kv for kv in sorted(cur.items())) or "none"))
+    check_environment()

@@ -267,7 +267,11 @@ def test_packed_layer_host_row_count_ragged(ext):
     #  as zeros through the buffer's bounds check: 40000 rows x 128 columns = 625 tiles, 20037 rows x 256 columns = 2 x 314)
     for R, K, N, relu in ((1, 128, 128, True), (63, 256, 128, False), (200, 128, 384, True), (8192, 512, 256, False),
                           (33, 384, 256, True), (2048, 1536, 512, True), (800, 512, 256, False), (40000, 128, 128, True),
-                          (20037, 128, 256, False)):
+                          (20037, 128, 256, False),
+                          # K >= 256 and 256 or more (tile, column block) items: the persistent pipeline (round 4) -- fewer workgroups than
+                          # items (each walks several, the next item's first panel fetched behind the last panel of the running one),
+                          # ragged last tile, 2 / 3 / 4 panels
+                          (20037, 256, 256, True), (33001, 384, 128, False), (16400, 512, 384, True)):
         a_full = T(rng.standard_normal((R, K + 8)).astype(np.float32))
         a = a_full[:, 4:4 + K] if False else a_full[:, :K]           # row stride K + 8, 16-byte aligned
         w = T((rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32))

@@ -566,3 +566,35 @@ def test_compiled_extension_modules_load_and_export_the_reference_bindings():
             sys.modules.pop(n, None)
             if saved[n] is not None:
                 sys.modules[n] = saved[n]
+
+
+def test_every_switch_is_registered():
+    """switches.py lists exactly the PRCNN_* environment variables the sources read (package, C library, bench.py): a switch that is
+    added without a line in the table, or a line whose switch is gone, fails here."""
+    import glob
+    import re
+    import warnings
+    SW = pkg("switches")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [f for pat in ("3d_adapt_auto_driving_amd/**/*.py", "3d_adapt_auto_driving_amd/csrc/**/*.hip", "3d_adapt_auto_driving_amd/csrc/**/*.hpp",
+                           "3d_adapt_auto_driving_amd/csrc/**/*.cpp", "bench.py") for f in glob.glob(os.path.join(root, pat), recursive=True)]
+    read = set()
+    for f in files:
+        if f.endswith("switches.py"):
+            continue
+        text = open(f).read()
+        read |= set(re.findall(r'getenv\("(PRCNN_[A-Z0-9_]+)"\)', text))
+        read |= set(re.findall(r'environ\.get\("(PRCNN_[A-Z0-9_]+)"', text))
+    assert read, "no switch found: the scan is broken"
+    assert read - set(SW.SWITCHES) == set(), "read but not in switches.py: %s" % sorted(read - set(SW.SWITCHES))
+    assert set(SW.SWITCHES) - read == set(), "in switches.py but read nowhere: %s" % sorted(set(SW.SWITCHES) - read)
+    for name, (kind, default, where, what) in SW.SWITCHES.items():
+        assert kind in ("operational", "numerics", "ab", "tuning", "debug", "bench") and what
+        assert any(f.endswith(where) for f in files), (name, where)
+    os.environ["PRCNN_NO_SUCH_SWITCH"] = "1"
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert SW.check_environment() == ["PRCNN_NO_SUCH_SWITCH"] and len(w) == 1
+    finally:
+        del os.environ["PRCNN_NO_SUCH_SWITCH"]
