@@ -386,9 +386,10 @@ __global__ __launch_bounds__(256, 2) void packed_layer_pipe_kernel(
 // results straight from the accumulators (a wave's store instruction covers two 128-byte row segments).  Per output element the
 // MFMA sequence, the bias add and the ReLU are those of the one-tile kernels: same bits.  Host-count mode, N == n_store, no pooling,
 // no interpolation addend.
+template <bool ADD>
 __global__ __launch_bounds__(256, 2) void packed_layer_persist_kernel(
     long rows, int K, int N, const float *__restrict__ A, long lda, const float *__restrict__ W, const float *__restrict__ bias,
-    int do_relu, float *__restrict__ out, long ldo, unsigned int *__restrict__ ticket)
+    int do_relu, float *__restrict__ out, long ldo, unsigned int *__restrict__ ticket, const PLProblem addp)
 {
     __shared__ float tiles[2 * PL_ROWS * PL_LD];
     __shared__ unsigned int s_item[2];
@@ -470,7 +471,13 @@ __global__ __launch_bounds__(256, 2) void packed_layer_persist_kernel(
         // stores into the tile's own rows of `out` -- rows past the end of a ragged last tile are outside the buffer and dropped by its
         // bounds check: no per-lane compare, no 64-bit address arithmetic, and above all no wait in front of a store (a store under a
         // per-lane condition made the compiler wait for vmcnt(0) -- i.e. for the store before it -- 32 times per item)
-        {
+        if constexpr (ADD) {
+            // ADD: + the interpolated coarse-level product (prcnn_packed_layer_interp) -- the staged epilogue of the one-tile kernels, through
+            // the LDS tile of the panel just consumed (the next item's first panel sits in the OTHER tile)
+            float *Tlast = tiles + ((pp - 1) & 1) * (PL_ROWS * PL_LD);
+            pl_epilogue<false>(acc0, acc1, Tlast, nullptr, (long)t, rows, (int)cb * 128, bias, do_relu, out, ldo, nullptr, nullptr, 0, 0, N, 0, &addp);
+            __syncthreads();
+        } else {
             const long left = rows - (long)t * PL_ROWS;
             const unsigned int o_row_bytes = (unsigned int)ldo * 4u;
             const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
@@ -500,7 +507,8 @@ __global__ __launch_bounds__(256, 2) void packed_layer_persist_kernel(
 // (PL_STAGE_ROWS, two LDS tiles).  Per row the arithmetic is that of packed_layer_kernel: same bits.  Host-count mode, no pooling.
 __global__ __launch_bounds__(256, 2) void packed_layer_stream_kernel(long rows, int N, const float *__restrict__ A, long lda,
                                                                      const float *__restrict__ W, const float *__restrict__ bias,
-                                                                     int do_relu, float *__restrict__ out, long ldo, int n_store)
+                                                                     int do_relu, float *__restrict__ out, long ldo, int n_store,
+                                                                     const PLProblem addp /* .addG != NULL: the interpolation addend */)
 {
     __shared__ float tiles[2 * PL_ROWS * PL_LD];
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
@@ -526,9 +534,16 @@ __global__ __launch_bounds__(256, 2) void packed_layer_stream_kernel(long rows, 
             *reinterpret_cast<f32x4 *>(tiles + (r0 + 8 * i) * PL_LD + 4 * chunk) =
                 __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, a_lane, soff + (unsigned int)(8 * i) * a_row_bytes, 0));
     }
+    // round 4: the bias column of this workgroup is loaded once; no wait at the top of an iteration (the rows of the tile were waited for
+    // when they went to LDS) -- so the results of the tile before stay in flight behind this tile's MFMAs -- and the epilogue writes
+    // straight from the accumulators as buffer stores (see packed_layer_persist_kernel) when whole 128-column blocks are stored
+    const float bcol = bias[n0 + 32 * w + j];
+    const bool direct = n0 + 128 <= n_store && !addp.addG;
+    const unsigned int o_row_bytes = (unsigned int)ldo * 4u;
+    const unsigned int o_lane = (unsigned int)(4 * h) * o_row_bytes + (unsigned int)(n0 + 32 * w + j) * 4u;
+    PL_VM_DRAIN
     for (int it = 0;; ++it) {
-        PL_VM_DRAIN
-        lds_barrier();                                     // this tile's rows are published; the other tile is free (its copy-out is over)
+        lds_barrier();                                     // this tile's rows are published; the other tile is free
         float *T = tiles + (it & 1) * (PL_ROWS * PL_LD);
         float *TN = tiles + ((it + 1) & 1) * (PL_ROWS * PL_LD);
         const long tn = t + gridDim.x;
@@ -539,7 +554,21 @@ __global__ __launch_bounds__(256, 2) void packed_layer_stream_kernel(long rows, 
         } else {
             PL_STAGE(T, wf)
         }
-        pl_epilogue<false>(acc0, acc1, T, nullptr, t, rows, n0, bias, do_relu, out, ldo, nullptr, nullptr, 0, 0, n_store, 0);
+        if (direct) {
+            const long left = rows - t * PL_ROWS;
+            const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(out + t * PL_ROWS * ldo), 0, (int)((left < PL_ROWS ? left : PL_ROWS) * (long)o_row_bytes), 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned int so = (unsigned int)((r & 3) + 8 * (r >> 2)) * o_row_bytes;
+                const float v0 = acc0[r] + bcol, v1 = acc1[r] + bcol;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(do_relu ? fmaxf(v0, 0.f) : v0), ors, o_lane, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(do_relu ? fmaxf(v1, 0.f) : v1), ors, o_lane, so + 32u * o_row_bytes, 0);
+            }
+        } else {
+            pl_epilogue<false>(acc0, acc1, T, nullptr, t, rows, n0, bias, do_relu, out, ldo, nullptr, nullptr, 0, 0, n_store, 0, &addp);
+            __syncthreads();                               // (its staging through T is over before the next stage prefetches into it)
+        }
         if (tn >= ntiles) break;
         t = tn;
     }
@@ -822,8 +851,8 @@ extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr
         const PLProblem &q = bt.p[0];
         const long items = tiles_of[0] * blocks_of[0];
         const long cap = stream_cap();
-        hipLaunchKernelGGL(packed_layer_persist_kernel, dim3((unsigned)(items < cap ? items : cap)), dim3(256), 0, st, q.rows_host, q.K, q.N,
-                           q.A, q.lda, q.W, q.bias, q.do_relu, q.out, q.ldo, next_ticket(st));
+        hipLaunchKernelGGL(packed_layer_persist_kernel<false>, dim3((unsigned)(items < cap ? items : cap)), dim3(256), 0, st, q.rows_host, q.K, q.N,
+                           q.A, q.lda, q.W, q.bias, q.do_relu, q.out, q.ldo, next_ticket(st), PLProblem{});
         return check_launch("packed_layer");
     }
     bool together = cls[0] != PL_PIPE32 && cls[0] != PL_STREAM;
@@ -843,7 +872,7 @@ extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr
             const prcnn_layer_problem &q = pr[src[i]];
             const long cap = stream_cap() / gy > 0 ? stream_cap() / gy : 1;  // two resident workgroups per CU over all column blocks
             hipLaunchKernelGGL(packed_layer_stream_kernel, dim3((unsigned)(tiles_of[i] < cap ? tiles_of[i] : cap), gy), dim3(256), 0, st,
-                               q.rows, q.N, q.A, q.lda, q.W, q.bias, q.relu, q.out, q.ldo, q.n_store);
+                               q.rows, q.N, q.A, q.lda, q.W, q.bias, q.relu, q.out, q.ldo, q.n_store, PLProblem{});
         } else if (cls[i] == PL_PIPE32) {
             const prcnn_layer_problem &q = pr[src[i]];
             hipLaunchKernelGGL(packed_layer_pipe32_kernel, dim3((unsigned)((q.rows + 31) / 32), gy), dim3(256), 0, st, q.rows, q.K, q.N, q.A,
@@ -905,7 +934,24 @@ extern "C" int prcnn_packed_layer_interp(long rows, int K, int N, const float *A
     PLBatch bt;
     bt.p[0] = PLProblem{nullptr, rows, K, N, A, lda, W, bias, relu, out, ldo, nullptr, nullptr, 0, 0, N, 0,
                         G, idx, weight, n_per_cloud, m_known, ldg};
+    // round 4: the persistent forms (weights resident / next tile fetched behind the running one) when there is more than one round of
+    // workgroups to run; same epilogue, same bits
+    static const bool persist = !(getenv("PRCNN_PL_PERSIST") && atoi(getenv("PRCNN_PL_PERSIST")) == 0);
+    const long items = tiles * (N / 128);
+    hipStream_t st = (hipStream_t)stream;
+    if (persist && K == 128 && stream_enabled() && items >= stream_min() && rows * lda * 4 < (1L << 31)) {
+        const long cap = stream_cap() / (N / 128) > 0 ? stream_cap() / (N / 128) : 1;
+        hipLaunchKernelGGL(packed_layer_stream_kernel, dim3((unsigned)(tiles < cap ? tiles : cap), N / 128), dim3(256), 0, st, rows, N, A, lda,
+                           W, bias, relu, out, ldo, N, bt.p[0]);
+        return check_launch("packed_layer_interp");
+    }
+    if (persist && K >= 256 && pipe_enabled() && items > stream_cap() && items >= persist_min()) {
+        const long cap = stream_cap();
+        hipLaunchKernelGGL(packed_layer_persist_kernel<true>, dim3((unsigned)(items < cap ? items : cap)), dim3(256), 0, st, rows, K, N, A, lda,
+                           W, bias, relu, out, ldo, next_ticket(st), bt.p[0]);
+        return check_launch("packed_layer_interp");
+    }
     auto kern = (K >= 256 && pipe_enabled()) ? packed_layer_pipe_kernel<false> : packed_layer_kernel<false>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, N / 128, 1), dim3(256), 0, (hipStream_t)stream, bt);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, N / 128, 1), dim3(256), 0, st, bt);
     return check_launch("packed_layer_interp");
 }

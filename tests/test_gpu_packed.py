@@ -284,6 +284,30 @@ def test_packed_layer_host_row_count_ragged(ext):
         assert torch.equal(out[:R].cpu(), want)
 
 
+def test_packed_layer_interp_persistent_forms(ext):
+    """prcnn_packed_layer_interp (FP layer 1 over the skip features + the interpolated coarse product in the epilogue) at sizes that take
+    the persistent kernels of round 4 -- K = 128: weights resident, rows streamed (625 tiles x 2 column blocks); K >= 256: the panel
+    pipeline that runs on into the next tile (628 / 771 items for 512 workgroups) -- against the oracle's restatement, bit for bit;
+    ragged last tiles, ReLU on and off."""
+    rng = np.random.default_rng(77)
+    for b, n, m, K, N, relu in ((5, 8000, 2000, 128, 256, True), (3, 6679, 1500, 256, 256, False), (2, 8200, 1000, 384, 384, True)):
+        rows = b * n
+        a = T(rng.standard_normal((rows, K)).astype(np.float32))
+        w = T((rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32))
+        bias = T(rng.standard_normal(N).astype(np.float32))
+        G = T(rng.standard_normal((b, m, N)).astype(np.float32))
+        idx = T(rng.integers(0, m, (b, n, 3)).astype(np.int32))
+        wt = rng.uniform(0.05, 1.0, (b, n, 3)).astype(np.float32)
+        wt /= wt.sum(-1, keepdims=True)
+        weight = T(wt.astype(np.float32))
+        out = torch.full((rows + 1, N), float("nan"), device=DEV)
+        ext.pointnet2.packed_layer_interp_wrapper(a, w, bias, relu, out[:rows], G, idx, weight)
+        assert torch.isnan(out[rows]).all()
+        want = torch.empty((rows, N))
+        ext_cpu.pointnet2_cpu.packed_layer_interp_wrapper(a.cpu(), w.cpu(), bias.cpu(), relu, want, G.cpu(), idx.cpu(), weight.cpu())
+        assert torch.equal(out[:rows].cpu(), want), (b, n, m, K, N, float((out[:rows].cpu() - want).abs().max()))
+
+
 @pytest.mark.parametrize("c1,c2,c3,ns", [(16, 16, 32, 16), (32, 32, 64, 32)])
 def test_xyz_level_over_packed_rows_bit_identical(ext, c1, c2, c3, ns):
     """RPN SA1 (coordinates only) over the distinct rows == the all-rows VALU kernel == the oracle, bit for bit; output slice
