@@ -586,14 +586,26 @@ __global__ __launch_bounds__(256, 2) void packed_layer_stream_kernel(long rows, 
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wf[4 * g + 1], acc, 0, 0, 0);                       \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wf[4 * g + 2], acc, 0, 0, 0);                       \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, wf[4 * g + 3], acc, 0, 0, 0);
-__global__ __launch_bounds__(256, 2) void packed_layer_pipe32_kernel(
-    long rows, int K, int N, const float *__restrict__ A, long lda, const float *__restrict__ W, const float *__restrict__ bias,
-    int do_relu, float *__restrict__ out, long ldo, int n_store)
+__global__ __launch_bounds__(256, 2) void packed_layer_pipe32_kernel(const PLBatch bt)
 {
+    // (round 4: up to PL_MAX_BATCH independent problems per launch, blockIdx.z picks -- the two branches of the RCNN head run side by
+    //  side instead of one 20-us launch after the other on the feature stream; the grid is sized for the largest problem)
+    const PLProblem &pb = bt.p[blockIdx.z];
+    const long rows = pb.rows_host;
+    const int K = pb.K, N = pb.N;
+    const float *__restrict__ A = pb.A;
+    const long lda = pb.lda;
+    const float *__restrict__ W = pb.W;
+    const float *__restrict__ bias = pb.bias;
+    const int do_relu = pb.do_relu;
+    float *__restrict__ out = pb.out;
+    const long ldo = pb.ldo;
+    const int n_store = pb.n_store;
     constexpr int R = 32;
     __shared__ float tiles[2 * R * PL_LD];
     const long t = blockIdx.x;
     const int n0 = blockIdx.y * 128;
+    if (t * R >= rows || n0 >= n_store) return;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chunk = tid & 31, r0 = tid >> 5;
@@ -855,8 +867,19 @@ extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr
                            q.A, q.lda, q.W, q.bias, q.do_relu, q.out, q.ldo, next_ticket(st), PLProblem{});
         return check_launch("packed_layer");
     }
-    bool together = cls[0] != PL_PIPE32 && cls[0] != PL_STREAM;
+    bool together = cls[0] != PL_STREAM;
     for (int i = 1; i < k; ++i) together = together && cls[i] == cls[0];
+    if (together && cls[0] == PL_PIPE32) {
+        long gx = 0;
+        int gy = 0;
+        for (int r = 0; r < k; ++r) {
+            const long t32 = (bt.p[r].rows_host + 31) / 32;
+            if (t32 > gx) gx = t32;
+            if (blocks_of[r] > gy) gy = blocks_of[r];
+        }
+        hipLaunchKernelGGL(packed_layer_pipe32_kernel, dim3((unsigned)gx, gy, k), dim3(256), 0, st, bt);
+        return check_launch("packed_layer");
+    }
     for (int i = 0; i < k; ++i) {
         PLBatch one;
         long gx = tiles_of[i];
@@ -875,8 +898,7 @@ extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr
                                q.rows, q.N, q.A, q.lda, q.W, q.bias, q.relu, q.out, q.ldo, q.n_store, PLProblem{});
         } else if (cls[i] == PL_PIPE32) {
             const prcnn_layer_problem &q = pr[src[i]];
-            hipLaunchKernelGGL(packed_layer_pipe32_kernel, dim3((unsigned)((q.rows + 31) / 32), gy), dim3(256), 0, st, q.rows, q.K, q.N, q.A,
-                               q.lda, q.W, q.bias, q.relu, q.out, q.ldo, q.n_store);
+            hipLaunchKernelGGL(packed_layer_pipe32_kernel, dim3((unsigned)((q.rows + 31) / 32), gy), dim3(256), 0, st, one);
         } else if (segmax) {
             auto kern = cls[i] == PL_PIPE ? packed_layer_pipe_kernel<true> : packed_layer_kernel<true>;
             hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy, gz), dim3(256), 0, st, arg);

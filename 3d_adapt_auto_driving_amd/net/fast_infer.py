@@ -1088,7 +1088,19 @@ class FastPointRCNN:
         if self.rcnn_head1 is not None and top.stride(1) == 1:
             wt, b, n1 = self.rcnn_head1
             h = point_layer(top, wt, b, True)
-            return {"rcnn_cls": self.rcnn_cls(h[:, :n1], start=1), "rcnn_reg": self.rcnn_reg(h[:, n1:], start=1)}
+            hc, hr = h[:, :n1], h[:, n1:]
+            lc, lr = self.rcnn_cls.layers, self.rcnn_reg.layers
+            if (USE_POINT_LAYER and USE_PACKED and len(lc) >= 3 and len(lr) >= 3 and has_entry(ext, "packed_layer_batch_wrapper")
+                    and all(w_.shape[0] % 128 == 0 and w_.shape[1] % 128 == 0 for w_ in (lc[1][0], lr[1][0]))
+                    and hc.shape[1] == lc[1][0].shape[0] and hr.shape[1] == lr[1][0].shape[0] and hc.stride(0) % 4 == 0
+                    and hc.data_ptr() % 16 == 0 and hr.data_ptr() % 16 == 0):
+                # the second layers of the two branches side by side in ONE launch (800 rows: each is a 20-us launch of a few dozen
+                # workgroups on the feature stream); same kernel, same arguments per problem: same bits
+                yc = torch.empty((hc.shape[0], lc[1][0].shape[1]), dtype=torch.float32, device=h.device)
+                yr = torch.empty((hr.shape[0], lr[1][0].shape[1]), dtype=torch.float32, device=h.device)
+                ext.packed_layer_batch_wrapper([(hc, lc[1][0], lc[1][1], lc[1][2], yc, None), (hr, lr[1][0], lr[1][1], lr[1][2], yr, None)])
+                return {"rcnn_cls": self.rcnn_cls(yc, start=2), "rcnn_reg": self.rcnn_reg(yr, start=2)}
+            return {"rcnn_cls": self.rcnn_cls(hc, start=1), "rcnn_reg": self.rcnn_reg(hr, start=1)}
         return {"rcnn_cls": self.rcnn_cls(top), "rcnn_reg": self.rcnn_reg(top)}
 
     __call__ = forward

@@ -397,7 +397,7 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
                   "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 4,
                   "three_interpolate_cat_pm_wrapper": 0 if F.USE_FP_LINEAR else 3, "packed_layer_interp_wrapper": 3 if F.USE_FP_LINEAR else 0,
                   "rpn_tail_wrapper": 0 if F.USE_FP_LINEAR else 1, "rpn_tail_lin_wrapper": 1 if F.USE_FP_LINEAR else 0, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
-    want_calls.update({"packed_layer_segmax_batch_wrapper": 2, "packed_gather_affine_batch_wrapper": 2, "packed_layer_batch_wrapper": 4})   # RPN SA3, SA4
+    want_calls.update({"packed_layer_segmax_batch_wrapper": 2, "packed_gather_affine_batch_wrapper": 2, "packed_layer_batch_wrapper": 5})   # RPN SA3, SA4; the two branches of the RCNN head (round 4)
     if wide_fused:       # the RCNN's GroupAll level (every row distinct: 800 units of work) in one kernel
         want_calls.update({"sa_wide_fused_wrapper": 1, "packed_layer_segmax_wrapper": 0, "packed_gather_affine_wrapper": 0})
     else:
