@@ -628,12 +628,14 @@ extern "C" int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, 
         return PRCNN_ELAUNCH;
     }
     if (max_tiles == 0) return PRCNN_OK;
-    // Persistent workgroups: at most 1024 (128-wide) / 512 (256-wide) of them, each drawing tiles from the ticket counter until
+    // Persistent workgroups: at most 512 (128-wide) / 256 (256-wide) of them (round 4: 1024 / 512 until then -- the sweep 256 / 384 / 512 /
+    // 640 / 768 / 1024 at K = 96 gave 6546 / 6633 / 6639 / 6625 / 6638 / 6591 scenes/s, LiDAR-shaped 4752 / 4788 / 4775 / 4753 / 4729 / 4733:
+    // two resident workgroups per CU hold the LDS of 512, a second round only queues), each drawing tiles from the ticket counter until
     // none is left, so the 128 weight registers per lane are loaded once per workgroup.  (Until round 2 a workgroup served at most
     // 8 tiles and the grid was sized for the worst case -- every ball full: in the sparse launches of the real step, ~2300 live
     // tiles of 102400, some 2300 DIFFERENT workgroups each fetched 128 KB of weights to serve one tile.  RCNN SA1 at the B = 8
     // shape: 244 -> 160 us.)  PRCNN_SA_GRID=<n> overrides the cap, PRCNN_SA_GRID=0 restores the 8-tiles-per-workgroup launch.
-    static const int env_grid = getenv("PRCNN_SA_GRID") ? atoi(getenv("PRCNN_SA_GRID")) : 1024;
+    static const int env_grid = getenv("PRCNN_SA_GRID") ? atoi(getenv("PRCNN_SA_GRID")) : 512;
     int per_wg = PK_TILES_PER_WG;
     int grid = (int)((max_tiles + per_wg - 1) / per_wg);
     if (env_grid > 0) {

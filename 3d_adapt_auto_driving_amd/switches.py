@@ -81,7 +81,7 @@ SWITCHES = {
     "PRCNN_TAIL_XCD": ("ab", "1", "csrc/rpn_tail.hip", "0: one tile counter instead of one per XCD"),
     # ---- tuning
     "PRCNN_MFMA_GRID": ("tuning", "512", "csrc/capi.hip", "workgroups of a persistent MFMA launch"),
-    "PRCNN_SA_GRID": ("tuning", "1024", "csrc/sa_packed.hip", "workgroups of the packed SA kernels"),
+    "PRCNN_SA_GRID": ("tuning", "512", "csrc/sa_packed.hip", "workgroups of the packed SA kernels"),
     "PRCNN_SA_TILES": ("tuning", "0", "csrc/sa_mlp_fused.hip", "tiles per workgroup of the fused SA kernel (0 = tickets)"),
     "PRCNN_PL_STREAM_CAP": ("tuning", "512", "csrc/packed_layer.hip", "workgroups of the persistent layer kernels"),
     "PRCNN_PL_STREAM_MIN": ("tuning", "512", "csrc/packed_layer.hip", "items from which a K = 128 layer runs persistently"),
