@@ -3,7 +3,7 @@ O=gpurun_out/r04; mkdir -p $O; export TMPDIR=/tmp
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-driver > $O/bench_k20.json 2>/dev/null
 timeout 600 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-driver --no-lidar > $O/bench_k100.json 2>/dev/null
-( echo '## profiles/geo_probe.py both'; python profiles/geo_probe.py both; for s in uniform lidar; do echo; echo "## profiles/stage_probe.py $s"; python profiles/stage_probe.py $s; done; echo; echo '## profiles/fps_probe.py'; python profiles/fps_probe.py; echo; echo '## PRCNN_FPS_SEQUENTIAL=1 profiles/fps_probe.py'; PRCNN_FPS_SEQUENTIAL=1 python profiles/fps_probe.py; echo; echo '## profiles/host_bound_probe.py'; python profiles/host_bound_probe.py ) 2>&1 | grep -v amdgpu.ids > $O/microbench.txt
+( echo '## profiles/geo_probe.py both'; python profiles/geo_probe.py both; for s in uniform lidar; do echo; echo "## profiles/stage_probe.py $s"; python profiles/stage_probe.py $s; done; echo; echo '## profiles/fps_probe.py'; python profiles/fps_probe.py; echo; echo '## PRCNN_FPS_SEQUENTIAL=1 profiles/fps_probe.py'; PRCNN_FPS_SEQUENTIAL=1 python profiles/fps_probe.py; echo; echo '## profiles/host_bound_probe.py'; python profiles/host_bound_probe.py; echo; echo '## profiles/layer_k_sweep.py (persistent layer kernels)'; python profiles/layer_k_sweep.py; echo; echo '## PRCNN_PL_PERSIST=0 profiles/layer_k_sweep.py (one tile per workgroup, round 3)'; PRCNN_PL_PERSIST=0 python profiles/layer_k_sweep.py ) 2>&1 | grep -v amdgpu.ids > $O/microbench.txt
 ( for s in uniform lidar; do python profiles/dropin_ops_probe.py $s; echo; done; echo '## profiles/dropin_path_probe.py 4'; python profiles/dropin_path_probe.py 4; echo; echo '## tests/ref_kernels_probe.py'; timeout 300 python tests/ref_kernels_probe.py ) 2>&1 | grep -v amdgpu.ids > $O/dropin_ops.md
 # the drop-in path proper under a kernel trace
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/kt_dropin -- python profiles/dropin_path_probe.py 4 > /dev/null 2>&1
@@ -14,6 +14,7 @@ for sc in uniform lidar; do
   f=$(ls $O/kt_$sc/*/*kernel_trace.csv | head -1)
   python profiles/summarize_step.py $f "round 4, $sc scenes (rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --scene $sc --steps 40 --warmup 8 --prewarm 8 --no-cpu-baseline --no-roofline --no-driver --no-lidar)" > $O/step_$sc.md
   head -70 $(ls $O/kt_$sc/*/*kernel_stats.csv | head -1) > $O/kernel_stats_$sc.csv
+  python profiles/mfma_launch_shapes.py $f > $O/mfma_shapes_$sc.md
   rm -rf $O/kt_$sc
 done
 # HBM traffic per kernel of the product step: one counter per pass (the TCC block cannot hold both), single stream
