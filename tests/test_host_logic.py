@@ -591,6 +591,8 @@ def test_every_switch_is_registered():
     for name, (kind, default, where, what) in SW.SWITCHES.items():
         assert kind in ("operational", "numerics", "ab", "tuning", "debug", "bench") and what
         assert any(f.endswith(where) for f in files), (name, where)
+    doc = open(os.path.join(root, "docs", "SWITCHES.md")).read()
+    assert SW.table() in doc, "docs/SWITCHES.md is stale: regenerate it from switches.table()"
     os.environ["PRCNN_NO_SUCH_SWITCH"] = "1"
     try:
         with warnings.catch_warnings(record=True) as w:
