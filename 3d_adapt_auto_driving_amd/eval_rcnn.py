@@ -33,8 +33,9 @@ from ._lib import has_entry
 
 # PRCNN_NO_RCNN_SPLIT=1: the RCNN stage's RoI pooling / sampling / grouping geometry stays on the feature stream (A/B switch)
 SPLIT_RCNN = os.environ.get("PRCNN_NO_RCNN_SPLIT") != "1"
-GEO_THREAD = os.environ.get("PRCNN_GEO_THREAD", "0") == "1"               # geometry chains enqueued by a helper thread (tried: GIL contention costs more than it frees)
-RCNN_GEO_STREAM = os.environ.get("PRCNN_RCNN_GEO_STREAM", "0") == "1"     # the RCNN's geometry on a stream of its own (needs a 5th hardware queue)
+# (removed in round 4, results in DESIGN.md section 7: PRCNN_GEO_THREAD -- geometry chains enqueued by a helper thread, slower: the GIL;
+#  PRCNN_RCNN_GEO_STREAM -- the RCNN's geometry on a stream of its own, slower: a 5th busy stream shares a hardware queue; PRCNN_GATE --
+#  chains only started at the end of an RPN stage, slower since the stages are our own ticketed kernels; PRCNN_STREAM_SKEW)
 
 
 def build_model(cfg, device, seed=0):
@@ -166,14 +167,9 @@ def _runner_streams(device, n_sides, prio):
     per runner drew a new mapping every time (same process: 77 ms or 89 ms for the same 20 steps); with one fixed set the
     first-created streams keep the queues they were given at start-up."""
     key = (str(device), prio)
-    have = _RUNNER_STREAMS.setdefault(key, {"tail": None, "sides": [], "geo2": None, "feat": None})
-    if have["tail"] is None and int(os.environ.get("PRCNN_STREAM_SKEW", "0")) > 0:
-        # experiment: shift the round-robin stream -> hardware-queue assignment by creating (and keeping) unused streams first
-        have["skew"] = [torch.cuda.Stream(device) for _ in range(int(os.environ["PRCNN_STREAM_SKEW"]))]
+    have = _RUNNER_STREAMS.setdefault(key, {"tail": None, "sides": [], "feat": None})
     if have["tail"] is None:
         have["tail"] = torch.cuda.Stream(device, priority=int(os.environ.get("PRCNN_TAIL_PRIORITY", "0")))
-    if have["geo2"] is None and RCNN_GEO_STREAM:
-        have["geo2"] = torch.cuda.Stream(device, priority=int(os.environ.get("PRCNN_TAIL_PRIORITY", "0")))
     while len(have["sides"]) < n_sides:
         have["sides"].append(torch.cuda.Stream(device, priority=prio))
     return have["tail"], have["sides"][:n_sides]
@@ -280,12 +276,7 @@ class PipelinedRunner:
         if ch["geo"] is None:
             self._chain_finish(ch, None)
         self._chains = [c for c in self._chains if c is not ch]      # by identity (dict equality would compare tensors)
-        # PRCNN_GATE=1: geometry chains may only start at the end of an RPN stage (round 1: the library GEMMs of that stage
-        # stretched 40-70 % beside FPS workgroups).  Off by default now: most of those GEMMs are ticketed kernels of our own
-        # and the RCNN stage is too short to hide a whole chain link (1293 gated vs 1371 ungated scenes/s).
-        gated = os.environ.get("PRCNN_GATE") == "1"
-        if not gated:                         # A/B switch: geometry of the upcoming batches starts right away
-            self._advance_chains(todo, None)
+        self._advance_chains(todo, None)      # geometry of the upcoming batches starts right away
         main.wait_event(ch["ev"])
         st = self.engine.rpn_stage(cur, ch["geo"])
         ev_rpn = torch.cuda.Event()
@@ -293,13 +284,6 @@ class PipelinedRunner:
         for t in (st["rpn_scores_raw"], st["rpn_reg"], st["backbone_xyz"]):
             t.record_stream(self.tail)
         rois, roi_scores, ev_prop, rg = self._propose_on_tail(st, ev_rpn, main)
-        # Geometry of the upcoming batches is GATED on the end of this RPN stage: the library GEMMs of the RPN stage are
-        # persistent-grid kernels that stretch 40-70 % when an FPS workgroup shares a CU with them, the RCNN stage that
-        # follows is made of ticketed kernels that do not care.  So the xyz-only chains only START during RCNN stages:
-        # the next batch finishes its chain (levels 1-3 + three-NN, ~4 ms) and the batch after it runs its first link
-        # (FPS 16384 -> 4096, ~6 ms) -- both beside RCNN(i-1), on two side streams.
-        if gated:
-            self._advance_chains(todo, ev_rpn)
         done = self._finish_inflight()
         self._inflight = (cur, st, rois, roi_scores, ev_prop, None, None, rg)
         return done
@@ -310,25 +294,6 @@ class PipelinedRunner:
         launches, 0.3 ms of every step while they sat on the feature stream in front of the RCNN's MFMA kernels).
         -> rois, scores, event (RoIs and, if split, the RCNN geometry are ready), RCNN geometry state or None."""
         rg = None
-        geo2 = _RUNNER_STREAMS[(str(self.device), int(os.environ.get("PRCNN_SIDE_PRIORITY", "0")))].get("geo2") if SPLIT_RCNN else None
-        if geo2 is not None:
-            # PRCNN_RCNN_GEO_STREAM=1: the RCNN's geometry on a stream of its own -- proposals(i) -> geometry(i) -> final(i-1) in a row
-            # on the tail stream are 1.3-1.4 ms per step, the whole step period once the feature stream dropped to 1.2 ms
-            with torch.cuda.stream(self.tail):
-                self.tail.wait_event(ev_rpn)
-                rois, roi_scores = self.engine.propose(st)
-                ev_rois = torch.cuda.Event()
-                ev_rois.record(self.tail)
-            with torch.cuda.stream(geo2):
-                geo2.wait_event(ev_rois)
-                for _, ev_read in getattr(self, "_geo2_retired", []):
-                    geo2.wait_event(ev_read)                 # its own memory of earlier batches was read by their RCNN stages
-                self._geo2_retired = []
-                rg = self.engine.rcnn_geometry(st, rois)
-                ev_prop = torch.cuda.Event()
-                ev_prop.record(geo2)
-            self._geo2 = geo2
-            return rois, roi_scores, ev_prop, rg
         with torch.cuda.stream(self.tail):
             self.tail.wait_event(ev_rpn)
             rois, roi_scores = self.engine.propose(st)
@@ -380,32 +345,11 @@ class PipelinedRunner:
             for c, geo, ev in zip(entries, geos, evs):
                 c["geo"], c["ev"] = geo, ev
 
-        # The chain of a group is ~120 launches = 1.7 ms of Python + launch time every 4 steps, none of it on the critical path (the
-        # group is launched 8-12 batches ahead).  PRCNN_GEO_THREAD=1 hands it to a helper thread (ctypes and the HIP runtime release
-        # the GIL inside every launch; the main thread joins the helper only when it needs a batch of that group, `_chain_ready`).
-        # Measured (round 3): WORSE -- 5264 vs 5466 scenes/s at K = 100, the main thread's enqueue time rises from 1.15-1.37 to
-        # 1.46 ms per step: the helper's Python holds the GIL half of the time.  Off by default; the hook stays for A/B.
-        if urgent or not GEO_THREAD:
-            enqueue()
-        else:
-            fut = self._geo_pool().submit(enqueue)
-            for c in entries:
-                c["future"] = fut
+        enqueue()
         self._chains.extend(entries)
-
-    def _geo_pool(self):
-        if getattr(self, "_pool", None) is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="prcnn-geometry")
-        return self._pool
 
     @staticmethod
     def _chain_ready(ch):
-        """the chain entry with its geometry enqueued (joins the helper thread if it is still at it)"""
-        fut = ch.get("future")
-        if fut is not None:
-            fut.result()
-            ch["future"] = None
         return ch
 
     def _submit_grouped(self, cur, todo, main):
@@ -502,9 +446,6 @@ class PipelinedRunner:
             ready.record(post)
         if FINAL_ON_FEATURE:
             rois.record_stream(main)                  # produced on the proposal stream, read by the final stage here
-        if rg is not None and getattr(self, "_geo2", None) is not None:
-            # geometry-stream memory read on the feature stream up to ev_rcnn: kept until that stream has waited for it
-            self._geo2_retired = getattr(self, "_geo2_retired", []) + [(rg, ev_rcnn)]
         del rg                                        # tail-stream memory, read on the feature stream up to ev_rcnn: the tail stream waits for it above
         det["ready"] = ready
         det["stream"] = post
@@ -516,14 +457,9 @@ class PipelinedRunner:
         if getattr(self, "tail", None) is None:
             return None
         det = self._finish_inflight()
-        for c in getattr(self, "_chains", []):        # a helper thread may still be enqueuing a chain nobody consumed
-            self._chain_ready(c)
         for side, ev_read, _ in self._retired:        # the kept geometry goes back to its streams' pools, ordered after its readers
             side.wait_event(ev_read)
         self._retired = []
-        for _, ev_read in getattr(self, "_geo2_retired", []):
-            self._geo2.wait_event(ev_read)
-        self._geo2_retired = []
         return det
 
 

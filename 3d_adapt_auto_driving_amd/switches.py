@@ -44,12 +44,8 @@ SWITCHES = {
     "PRCNN_NO_GROUP_SA": ("ab", "unset", "net/fast_infer.py", "1: early SA levels per batch instead of per geometry group"),
     "PRCNN_FINAL_ON_FEATURE": ("ab", "1", "eval_rcnn.py", "0: final stage on the proposal stream (round 3)"),
     "PRCNN_NO_RCNN_SPLIT": ("ab", "unset", "eval_rcnn.py", "1: RCNN geometry on the feature stream"),
-    "PRCNN_RCNN_GEO_STREAM": ("ab", "0", "eval_rcnn.py", "1: RCNN geometry on a stream of its own (a 5th queue: slower)"),
-    "PRCNN_GEO_THREAD": ("ab", "0", "eval_rcnn.py", "1: geometry chains enqueued by a helper thread (slower: GIL)"),
-    "PRCNN_GATE": ("ab", "unset", "eval_rcnn.py", "1: gate a chain's second link behind the previous RPN stage"),
     "PRCNN_SIDE_PRIORITY": ("ab", "0", "eval_rcnn.py", "HIP priority of the side streams"),
     "PRCNN_TAIL_PRIORITY": ("ab", "0", "eval_rcnn.py", "HIP priority of the proposal stream"),
-    "PRCNN_STREAM_SKEW": ("ab", "0", "eval_rcnn.py", "dummy streams created first (moves the streams to other hardware queues)"),
     # ---- engine formulations A/B (same results)
     "PRCNN_NO_PACK": ("ab", "unset", "net/fast_infer.py", "all grouped rows instead of the distinct rows (prcnn_ball_pack)"),
     "PRCNN_NO_POOL_DEDUP": ("ab", "unset", "net/fast_infer.py", "RCNN point MLP over all 512 pooled rows"),
