@@ -58,8 +58,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32 MFMA peak (MI355X_MICROARCH.md)
 # HBM traffic per launch from the rocprofv3 PMC passes over the product step (FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950
 # + WRITE_SIZE), kept with the profile it came from; a kernel that has no entry reports null
-PMC_SOURCE = "profiles/r03_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the product step)"
-PMC_TRAFFIC = {"rpn_tail_lin_kernel": 149.01e6, "rpn_tail_kernel": 325.87e6, "roipool3d_canonical_kernel": 82.66e6}
+PMC_SOURCE = "profiles/r04_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the product step)"
+PMC_TRAFFIC = {"rpn_tail_lin_kernel": 148.96e6, "rpn_tail_kernel": 325.87e6, "roipool3d_canonical_kernel": 87.06e6}
 HOST_LAG = int(os.environ.get("PRCNN_BENCH_LAG", "3"))   # the host consumes a batch's detections this many batches late
 BATCH = int(os.environ.get("PRCNN_BENCH_BATCH", "8"))     # scenes per step per GPU (BASELINE configs[2]: 8; the override is for experiments and is echoed in config.env_overrides)
 NPOINTS = 16384
@@ -243,7 +243,8 @@ def roofline_roipool(dev, cfg, model, reps=20):
     empty = torch.empty((B, M), dtype=torch.int32, device=dev)
     cnt = torch.empty((B, M), dtype=torch.int32, device=dev)
     groups = st.get("groups")             # the scene's spatial groups (built with the geometry chain): the selection culls by them
-    run = lambda: roipool3d_cuda.forward_canonical(pts, rois.contiguous(), feats, mask, depth, cfg.RCNN.POOL_EXTRA_WIDTH, pooled, empty, cnt, groups)
+    xyz_dense = torch.empty((B, M, S, 3), device=dev)     # round 4: the pooled coordinates once more as dense clouds (what the RCNN's SA levels read)
+    run = lambda: roipool3d_cuda.forward_canonical(pts, rois.contiguous(), feats, mask, depth, cfg.RCNN.POOL_EXTRA_WIDTH, pooled, empty, cnt, groups, xyz_dense)
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -258,7 +259,7 @@ def roofline_roipool(dev, cfg, model, reps=20):
     # and depth of every point once; the RoIs; the feature row of every DISTINCT pooled point once (a gather: rows no box holds
     # are never read); every row it writes (with feature columns up to the first multiple of 64 rows, 32 B beyond)
     nbytes = (B * NPOINTS * (12 + 8) + B * M * (28 + 8) + distinct_rows * 4 * C
-              + full_rows * (8 + C) * 4 + (B * M * S - full_rows) * 32)
+              + full_rows * (8 + C) * 4 + (B * M * S - full_rows) * 32 + B * M * S * 12)
     achieved = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": PMC_TRAFFIC.get("roipool3d_canonical_kernel"), "traffic_source": PMC_SOURCE,
