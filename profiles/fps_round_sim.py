@@ -1,0 +1,89 @@
+"""How many picks does one exchange of the speculative FPS kernel decide?  A numpy model of csrc/fps.hip fps_spec_kernel's rounds (16 waves,
+each publishing its best point, the best point of its other lanes and a bound; entries accepted in order while they beat the global bound
+and are not changed by the entries before them): rounds, picks per round and why rounds end, for the blocked Morton layout the kernel uses,
+for tiles interleaved across the waves, and for more published entries per wave.  CPU only.
+usage: python profiles/fps_round_sim.py uniform|lidar [m]
+(round 4: uniform 480 rounds = 8.5 picks per round, LiDAR-shaped 742 = 5.5; interleaved tiles 467 / 595 -- but every wave then rebuilds
+its entries every round, four waves per SIMD; 3 / 4 entries per wave 395 / 383 and 587 / 522 -- at the price of a 64-entry merge.)"""
+import os, sys, importlib, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+S = importlib.import_module('3d_adapt_auto_driving_amd.synth')
+
+def morton_order(p):
+    x, z = p[:, 0], p[:, 2]
+    gx = np.clip(((x - x.min()) / max(x.max() - x.min(), 1e-9) * 64).astype(int), 0, 63)
+    gz = np.clip(((z - z.min()) / max(z.max() - z.min(), 1e-9) * 64).astype(int), 0, 63)
+    def part(v):
+        v = v.astype(np.uint32); r = np.zeros_like(v)
+        for b in range(6): r |= ((v >> b) & 1) << (2 * b)
+        return r
+    code = part(gx) | (part(gz) << 1)
+    return np.argsort(code, kind='stable')
+
+def simulate(p, m, layout, PPT=16, top=2, rmax=16, stats=None):
+    n = p.shape[0]
+    order = morton_order(p)
+    W = 16
+    # slot index array [w][i][lane] -> position s in Morton order
+    w_, i_, l_ = np.meshgrid(np.arange(W), np.arange(PPT), np.arange(64), indexing='ij')
+    if layout == 'blocked':
+        s = w_ * 64 * PPT + i_ * 64 + l_
+    elif layout == 'interleaved':
+        s = (i_ * W + w_) * 64 + l_
+    elif layout == 'quad':       # tiles interleaved across groups of 4 waves
+        g, wi = w_ // 4, w_ % 4
+        s = g * (4 * 64 * PPT) + (i_ * 4 + wi) * 64 + l_
+    idx = order[s]                      # [W][PPT][64] original index
+    P = p[idx].astype(np.float32)       # [W][PPT][64][3]
+    pt = np.full((W, PPT, 64), 1e10, np.float32)
+    def upd(o):
+        d = ((P - o) ** 2).sum(-1).astype(np.float32)
+        np.minimum(pt, d, out=pt)
+    upd(p[0].astype(np.float32))
+    j, rounds = 1, 0
+    hist = np.zeros(rmax + 1, int)
+    why = {'bound': 0, 'blocked': 0, 'rmax': 0, 'end': 0}
+    while j < m:
+        lane_best = pt.max(1)                                    # [W][64]
+        lane_arg = pt.argmax(1)
+        srt = np.sort(pt, axis=1)
+        lane_second = srt[:, -2, :]
+        ordl = np.argsort(-lane_best, axis=1, kind='stable')     # lanes by best desc
+        ents = []
+        wB = np.zeros(W, np.float32)
+        for w in range(W):
+            ls = ordl[w, :top]
+            third = lane_best[w, ordl[w, top]]
+            wB[w] = max(third, lane_second[w, ls].max())
+            for l in ls:
+                ents.append((lane_best[w, l], idx[w, lane_arg[w, l], l], w))
+        ents.sort(key=lambda e: (-e[0], e[1]))
+        gB = wB.max()
+        acc = [ents[0]]
+        reason = 'rmax'
+        for e in ents[1:]:
+            if len(acc) >= min(rmax, m - j): reason = 'rmax' if len(acc) >= rmax else 'end'; break
+            if not (e[0] > gB): reason = 'bound'; break
+            pe = p[e[1]].astype(np.float32)
+            blk = False
+            for a in ents:
+                if a is e: break
+                if ((p[a[1]].astype(np.float32) - pe) ** 2).sum() < e[0]: blk = True; break
+            if blk: reason = 'blocked'; break
+            acc.append(e)
+        else:
+            reason = 'rmax'
+        why[reason] += 1
+        hist[len(acc)] += 1
+        for a in acc: upd(p[a[1]].astype(np.float32))
+        j += len(acc); rounds += 1
+    return rounds, hist, why
+
+if __name__ == '__main__':
+    kind = sys.argv[1]; m = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    make = S.lidar_scenes if kind == 'lidar' else S.scenes
+    pts = make(2, 16384, seed0=0)
+    for layout in ('blocked', 'quad', 'interleaved'):
+        for top in (2,):
+            r, h, why = simulate(pts[0][:, :3], m, layout, top=top)
+            print(kind, layout, 'top', top, 'rounds', r, 'picks/round %.2f' % ((m - 1) / r), why, 'hist', h.tolist(), flush=True)
