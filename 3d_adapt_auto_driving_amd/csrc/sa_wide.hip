@@ -91,9 +91,10 @@ __device__ __forceinline__ void sw_segmented_max(const f32x16 &acc, const int *c
             } else {                                                                                      \
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, wf[4 * g + 0], acc, 0, 0, 0);             \
             }                                                                                             \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                 \
-                wn[4 * g + q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(                     \
-                    RS, VOFF, (SOFF) + (unsigned int)(4 * g + q) * (RB), 0));                             \
+            _Pragma("unroll") for (int q = 0; q < 6; ++q)      /* six per k-group: all 64 are out by group 10 */ \
+                if (6 * g + q < 64)                                                                       \
+                    wn[6 * g + q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(                 \
+                        RS, VOFF, (SOFF) + (unsigned int)(6 * g + q) * (RB), 0));                         \
             __builtin_amdgcn_sched_barrier(0);                                                            \
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, wf[4 * g + 1], acc, 0, 0, 0);                 \
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, wf[4 * g + 2], acc, 0, 0, 0);                 \
@@ -109,6 +110,9 @@ __global__ __launch_bounds__(256, 2) void sa_wide_fused_kernel(const SaWideArgs 
     float *A1 = sw_lds, *Y1 = sw_lds + kp1 * SW_PANEL;
     int *ctr = reinterpret_cast<int *>(Y1 + kp2 * SW_PANEL);               // centre of every row
     unsigned int *slot = reinterpret_cast<unsigned int *>(ctr + SW_R);
+    // the two bias vectors in LDS (round 4): read at every epilogue -- six per unit -- they were global loads issued at their point of
+    // use, each an exposed round trip (~1 us of a unit's ~25) with the matrix pipe idle
+    float *sb2 = reinterpret_cast<float *>(slot + 2), *sb3 = sb2 + a.c2;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chunk = tid & 31, r0 = tid >> 5;
@@ -124,6 +128,8 @@ __global__ __launch_bounds__(256, 2) void sa_wide_fused_kernel(const SaWideArgs 
     const int q1 = a.c1 >> 2;                                              // float4 chunks per row of P
 
     if (tid == 0) slot[0] = atomicAdd(a.ticket, 1u);
+    for (int i = tid; i < a.c2; i += 256) sb2[i] = a.b2[i];
+    for (int i = tid; i < a.c3; i += 256) sb3[i] = a.b3[i];
     __syncthreads();
     long u = __builtin_amdgcn_readfirstlane((int)slot[0]);
     if (u >= units) { if (tid == 0) ticket_release(a.ticket); return; }
@@ -184,22 +190,25 @@ __global__ __launch_bounds__(256, 2) void sa_wide_fused_kernel(const SaWideArgs 
                 const unsigned int voffn = n3 ? voff3 : voff2;
                 const unsigned int soffn = (unsigned int)(kpn2 * 128) * rbn + (unsigned int)nbn * 512u;
                 if (l3 && kp == 0 && nb == 0) lds_barrier();               // every wave has written its columns of Y1
-                SW_VM_DRAIN
                 if (half == 0) {
                     if (n3) { SW_STAGE(T, wa, wb, rs3, voffn, soffn, rbn, kp == 0) } else { SW_STAGE(T, wa, wb, rs2, voffn, soffn, rbn, kp == 0) }
                 } else {
                     if (n3) { SW_STAGE(T, wb, wa, rs3, voffn, soffn, rbn, kp == 0) } else { SW_STAGE(T, wb, wa, rs2, voffn, soffn, rbn, kp == 0) }
                 }
+                // the next stage's weights have arrived (the last of them went out five k-groups ago); waited for HERE, in front of the
+                // epilogue, and not in front of the next stage as until round 4: the pooling's atomics then stay in flight behind the
+                // next stage's MFMAs instead of being waited for with the matrix pipe idle (vmcnt counts them like loads)
+                SW_VM_DRAIN
                 if (kp == kpn - 1) {
                     if (!l3) {
-                        const float bcol = a.b2[nb * 128 + 32 * w + j];
+                        const float bcol = sb2[nb * 128 + 32 * w + j];
                         float *Y = Y1 + nb * SW_PANEL;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) Y[((r & 3) + 8 * (r >> 2) + 4 * h) * SW_LD + 32 * w + j] = fmaxf(acc[r] + bcol, 0.f);
                     } else {
                         const int myc = ctr[j], prevc = ctr[j ? j - 1 : 0];
                         const unsigned int start = (unsigned int)__ballot(lane < 32 && (lane == 0 || myc != prevc));
-                        sw_segmented_max(acc, ctr, start, h, a.out, a.out_stride, a.out_col + nb * 128 + 32 * w + j, a.b3[nb * 128 + 32 * w + j]);
+                        sw_segmented_max(acc, ctr, start, h, a.out, a.out_stride, a.out_col + nb * 128 + 32 * w + j, sb3[nb * 128 + 32 * w + j]);
                     }
                 }
             }
@@ -248,7 +257,8 @@ extern "C" int prcnn_sa_wide_fused(int b, int n, int m, int c1, int c2, int c3, 
         return PRCNN_ELAUNCH;
     }
     if (max_tiles == 0) return PRCNN_OK;
-    const size_t lds = (size_t)(c1 / 128 + c2 / 128) * SW_PANEL * sizeof(float) + SW_R * sizeof(int) + 2 * sizeof(unsigned int);
+    const size_t lds = (size_t)(c1 / 128 + c2 / 128) * SW_PANEL * sizeof(float) + SW_R * sizeof(int) + 2 * sizeof(unsigned int) +
+                       (size_t)(c2 + c3) * sizeof(float);
     const int rc = ensure_dynamic_lds((const void *)sa_wide_fused_kernel, lds, "sa_wide_fused");
     if (rc != PRCNN_OK) return rc;
     SaWideArgs a;
