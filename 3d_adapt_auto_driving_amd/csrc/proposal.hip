@@ -263,113 +263,6 @@ __global__ __launch_bounds__(1024) void band_select_kernel(
     }
 }
 
-// ---- the same selection in TWO steps instead of a 16-round dependent scan (round 4; n <= 16384).  The kernel above walks the sorted
-// order 1024 positions at a time: gather the box's depth, ballot, LDS prefix, two barriers, emit (gather 8 floats, 13 scattered
-// stores) -- sixteen dependent memory round trips per scene, 61 us alone and 96 us in the step, for 8 workgroups.  Here
-//   A. thread t owns the 16 CONSECUTIVE positions 16 t .. 16 t + 15 of the sorted order: all its depth gathers are in flight at once, one
-//      workgroup-wide exclusive scan of the (near, far) counts gives every position its rank, and the selected positions write their
-//      point index into the band tables IN LDS (slot -> point);
-//   B. the tables are emitted slot by slot, consecutive slots by consecutive threads: independent gathers, coalesced stores.
-// Same tables, same counts (tests/test_gpu_e2e.py compares the proposal layer's results with the torch formulation).
-constexpr int BS_V = 16;
-
-__global__ __launch_bounds__(1024) void band_select2_kernel(
-    int n, int rows, int pre_near, int pre_far, const float *__restrict__ boxes, const float *__restrict__ scores,
-    const int *__restrict__ order, float *__restrict__ payload, float *__restrict__ bev, int *__restrict__ counts)
-{
-    extern __shared__ int bs_tab[];                              // [pre_near] near slots | [pre_far] far slots: the point of each slot
-    __shared__ int wsum[2][16];
-    __builtin_amdgcn_s_setprio(2);
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const float *__restrict__ bx = boxes + (long)b * n * 7;
-    const float *__restrict__ sc = scores + (long)b * n;
-    const int *__restrict__ ord = order + (long)b * n;
-    float *__restrict__ pay = payload + (long)b * 2 * rows * 8;
-    float *__restrict__ bv = bev + (long)b * 2 * rows * 5;
-    int *tab_near = bs_tab, *tab_far = bs_tab + pre_near;
-
-    int k[BS_V];
-    float dist[BS_V];
-#pragma unroll
-    for (int i = 0; i < BS_V; ++i) {
-        const int s = t * BS_V + i;
-        k[i] = s < n ? ord[s] : -1;
-    }
-#pragma unroll
-    for (int i = 0; i < BS_V; ++i) dist[i] = k[i] >= 0 ? bx[(long)k[i] * 7 + 2] : -1.f;
-    unsigned int mn = 0u, mf = 0u;
-#pragma unroll
-    for (int i = 0; i < BS_V; ++i) {
-        if (dist[i] > 0.f && dist[i] <= 40.0f) mn |= 1u << i;
-        if (dist[i] > 40.0f && dist[i] <= 80.0f) mf |= 1u << i;
-    }
-    const int cn = __popc(mn), cf = __popc(mf);
-    // exclusive scan over the 1024 threads: inclusive scan inside the wave (shuffles), wave totals through LDS
-    int in = cn, jf = cf;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int a = __shfl_up(in, d, 64), c2 = __shfl_up(jf, d, 64);
-        if (lane >= d) { in += a; jf += c2; }
-    }
-    if (lane == 63) { wsum[0][w] = in; wsum[1][w] = jf; }
-    __syncthreads();
-    int base_n = in - cn, base_f = jf - cf, tot_n = 0, tot_f = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        if (q < w) { base_n += wsum[0][q]; base_f += wsum[1][q]; }
-        tot_n += wsum[0][q]; tot_f += wsum[1][q];
-    }
-    const bool spill = tot_f == 0;                              // no far point: the far band takes the NEXT pre_far near candidates
-    int rn = base_n, rf = base_f;
-#pragma unroll
-    for (int i = 0; i < BS_V; ++i) {
-        if ((mn >> i) & 1u) {
-            if (rn < pre_near) tab_near[rn] = k[i];
-            else if (spill && rn < pre_near + pre_far) tab_far[rn - pre_near] = k[i];
-            ++rn;
-        }
-        if ((mf >> i) & 1u) {
-            if (rf < pre_far) tab_far[rf] = k[i];
-            ++rf;
-        }
-    }
-    const int c_near = min(tot_n, pre_near);
-    const int c_far = spill ? max(0, min(tot_n, pre_near + pre_far) - pre_near) : min(tot_f, pre_far);
-    if (t == 0) { counts[b * 2] = c_near; counts[b * 2 + 1] = c_far; }
-    __syncthreads();
-    // B: slot e of the two tables, near first
-    const int total = c_near + c_far;
-    for (int e0 = t; e0 < total; e0 += 4 * 1024) {
-        int kk[4];
-        float q[4][8];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * 1024;
-            kk[u] = e < total ? (e < c_near ? tab_near[e] : tab_far[e - c_near]) : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (kk[u] >= 0) {
-                const float *p = bx + (long)kk[u] * 7;
-#pragma unroll
-                for (int c = 0; c < 7; ++c) q[u][c] = p[c];
-                q[u][7] = sc[kk[u]];
-            }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (kk[u] >= 0) {
-                const int e = e0 + u * 1024;
-                const int band = e < c_near ? 0 : 1, slot = e < c_near ? e : e - c_near;
-                float *o = pay + ((long)band * rows + slot) * 8;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) o[c] = q[u][c];
-                float *v = bv + ((long)band * rows + slot) * 5;
-                const float hl = q[u][5] / 2, hw = q[u][4] / 2;       // boxes3d_to_bev_torch (kitti_utils.py:134-147)
-                v[0] = q[u][0] - hl; v[1] = q[u][2] - hw; v[2] = q[u][0] + hl; v[3] = q[u][2] + hw; v[4] = q[u][6];
-            }
-    }
-}
-
 __global__ __launch_bounds__(128) void assemble_rois_kernel(
     int rows, int keep_stride, int post_near, int post_far, const float *__restrict__ payload,
     const int *__restrict__ keep, const int *__restrict__ num, float *__restrict__ rois, float *__restrict__ scores)
@@ -742,21 +635,10 @@ extern "C" int prcnn_rpn_proposals(int b, int n, int channels, float loc_scope, 
         }
         hipLaunchKernelGGL(score_sort_kernel, dim3(b), dim3(1024), lds, st, n, npad, scores, order);
     }
-    // opt-in (PRCNN_BAND_SELECT2=1): same tables; 12 us instead of 61 alone, but the step did not move (6460 / 6484 scenes/s with it, 6518 /
-    // 6522 without, K = 96): the proposal stream's latency kernels are not what bounds a step
-    static const bool select2 = getenv("PRCNN_BAND_SELECT2") && atoi(getenv("PRCNN_BAND_SELECT2")) != 0;
-    const size_t tab_lds = (size_t)(pre_near + pre_far) * sizeof(int);
-    if (select2 && n <= 1024 * BS_V && tab_lds <= 120 * 1024) {
-        if (tab_lds > 48 * 1024) {
-            const int rc0 = ensure_dynamic_lds((const void *)band_select2_kernel, tab_lds, "rpn_proposals");
-            if (rc0 != PRCNN_OK) return rc0;
-        }
-        hipLaunchKernelGGL(band_select2_kernel, dim3(b), dim3(1024), tab_lds, st, n, rows, pre_near, pre_far, boxes, scores, order,
-                           payload, bev, counts);
-    } else {
-        hipLaunchKernelGGL(band_select_kernel, dim3(b), dim3(1024), 0, st, n, rows, pre_near, pre_far, boxes, scores, order,
-                           payload, bev, counts);
-    }
+    // (round 4 tried the selection in two steps -- one scan over 16 consecutive positions per thread + table emission from LDS: 12 us instead of
+    //  61 alone, 6460 / 6484 scenes/s against 6518 / 6522 at K = 96: the proposal stream's latency kernels do not bound a step.  Not kept.)
+    hipLaunchKernelGGL(band_select_kernel, dim3(b), dim3(1024), 0, st, n, rows, pre_near, pre_far, boxes, scores, order,
+                       payload, bev, counts);
     int rc = check_launch("rpn_proposals");
     if (rc != PRCNN_OK) return rc;
     rc = nms_device(2 * b, rows, counts, bev, nms_thresh, rotated_nms, post_near, keep, num, st);

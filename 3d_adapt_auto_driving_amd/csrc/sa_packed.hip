@@ -53,12 +53,8 @@ __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, cons
                                  const float *__restrict__ xyz, const float *__restrict__ new_xyz,
                                  unsigned int *__restrict__ rowinfo, float4 *__restrict__ rowdxyz, int *__restrict__ tilecloud,
                                  unsigned int *__restrict__ hdr, int group, const int *__restrict__ rep,
-                                 const int *__restrict__ crep, unsigned int *__restrict__ rec)
+                                 const int *__restrict__ crep)
 {
-    // rec != NULL (round 4, opt-in: PRCNN_PACK_NO_MEMSET): the list headers need no memset in front of the launch.  Tiles and rows are counted in a 16-word record of
-    // the stream's ticket ring (zero at rest: words 3 l, 3 l + 1 for list l, word 15 = workgroups done); the LAST workgroup to finish
-    // copies the totals into hdr and zeroes the record for its next user (the self-resetting scheme of common.hpp ticket_release).
-    // Five memset launches per step fewer (one per row list), and no memset node per pack inside the captured graphs.
     // Both passes are parallel over ELEMENTS, not over centres (a thread per centre left 32 of 256 threads busy on the RoI
     // clouds' second level and walked each centre's rows as a chain of dependent loads: 47 us for 800 clouds x 32 centres):
     //   1. every thread takes 16-byte pieces of index rows; the centre's distinct count is an LDS atomicMax over its pieces;
@@ -139,14 +135,8 @@ __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, cons
     for (int c = c0; c < c1; ++c) { offs[c] = run; run += cnts[c]; }
     if (tid == 0) {
         const int ntiles = (total + PK_ROWS - 1) / PK_ROWS;
-        if (rec) {
-            s_base = (int)atomicAdd(&rec[3 * list], (unsigned int)ntiles);
-            const unsigned int seen = atomicAdd(&rec[3 * list + 1], (unsigned int)total);
-            asm volatile("" ::"v"(seen) : "memory");       // both counts have been PERFORMED (their old values are back) before anything below
-        } else {
-            s_base = (int)atomicAdd(&hdr[0], (unsigned int)ntiles);
-            atomicAdd(&hdr[1], (unsigned int)total);
-        }
+        s_base = (int)atomicAdd(&hdr[0], (unsigned int)ntiles);
+        atomicAdd(&hdr[1], (unsigned int)total);
     }
     __syncthreads();
     const int base = s_base;
@@ -187,20 +177,6 @@ __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, cons
         const float *pt = cloud + 3 * (long)k;
         dst[r] = ((unsigned int)c << 16) | (unsigned int)k;
         dxyz[r] = make_float4(pt[0] - ct[0], pt[1] - ct[1], pt[2] - ct[2], 0.f);
-    }
-    if (rec && tid == 0) {
-        // no fence (cf. ticket_release in common.hpp): the record is only ever touched by device-scope atomics, this thread's two
-        // counts had returned before it came here, and the header words below are plain stores that the kernel boundary publishes
-        if (atomicAdd(&rec[15], 1u) == gridDim.x - 1u) {
-            const int lists = gridDim.x / group;
-            unsigned int *h0 = hdr - 4 * list;             // (hdr was advanced to this workgroup's list above)
-            for (int l = 0; l < lists; ++l) {
-                h0[4 * l] = atomicExch(&rec[3 * l], 0u);
-                h0[4 * l + 1] = atomicExch(&rec[3 * l + 1], 0u);
-                h0[4 * l + 2] = 0u; h0[4 * l + 3] = 0u;
-            }
-            atomicExch(&rec[15], 0u);
-        }
     }
 }
 
@@ -516,12 +492,9 @@ static int ball_pack_launch(int b, int group, int n, int m, int nsample, const i
     PRCNN_REQUIRE(hdr, "ball_pack: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int lists = b > 0 ? b / group : 1;
-    // PRCNN_PACK_NO_MEMSET=1: count in a self-resetting ticket record instead of a zeroed header (see the kernel).  Measured round 4,
-    // K = 96, two runs each: 6323 / 6337 scenes/s against 6362 / 6402 with the memset (and 6103 / 6120 with agent-scope fences around the
-    // arrival count): the five fills per step are not on anybody's critical path, the serial hand-over of the last workgroup is.  Off.
-    static const bool use_rec = getenv("PRCNN_PACK_NO_MEMSET") != nullptr;
-    unsigned int *rec = (use_rec && b > 0 && m > 0 && lists <= 5) ? next_ticket(st) : nullptr;
-    if (!rec && hipMemsetAsync(hdr, 0, (size_t)lists * 4 * sizeof(unsigned int), st) != hipSuccess) { set_error("ball_pack: memset failed"); return PRCNN_ELAUNCH; }
+    // (round 4 tried counting in a self-resetting ticket record instead of this memset: 6323 / 6337 scenes/s against 6362 / 6402 at K = 96,
+    //  6103 / 6120 with agent-scope fences around the arrival count -- the five fills per step are on nobody's critical path.  Not kept.)
+    if (hipMemsetAsync(hdr, 0, (size_t)lists * 4 * sizeof(unsigned int), st) != hipSuccess) { set_error("ball_pack: memset failed"); return PRCNN_ELAUNCH; }
     if (b == 0 || m == 0) return PRCNN_OK;
     PRCNN_REQUIRE(idx && rowinfo && tilecloud && xyz && new_xyz && rowdxyz, "ball_pack: null pointer");
     PRCNN_REQUIRE(((uintptr_t)rowdxyz & 15) == 0, "ball_pack: rowdxyz must be 16-byte aligned");
@@ -536,7 +509,7 @@ static int ball_pack_launch(int b, int group, int n, int m, int nsample, const i
     }
     const int cap = (int)(((long)m * nsample + PK_ROWS - 1) / PK_ROWS);
     hipLaunchKernelGGL(ball_pack_kernel, dim3(b), dim3(threads), lds, st, n, m, nsample, cap, idx, limit, xyz, new_xyz, rowinfo,
-                       (float4 *)rowdxyz, tilecloud, hdr, group, rep, crep, rec);
+                       (float4 *)rowdxyz, tilecloud, hdr, group, rep, crep);
     return check_launch("ball_pack");
 }
 

@@ -67,9 +67,7 @@ SWITCHES = {
     "PRCNN_NMS_FULL": ("ab", "1", "csrc/iou3d.hip", "0: no full-mask form of the blocking NMS"),
     "PRCNN_NMS_QUOTA": ("ab", "1", "csrc/iou3d.hip", "0: lazy kernel for the proposal NMS"),
     "PRCNN_SORT_SPLIT": ("ab", "1", "csrc/proposal.hip", "0: one workgroup sorts a scene's scores"),
-    "PRCNN_BAND_SELECT2": ("ab", "0", "csrc/proposal.hip", "1: band selection in two steps (12 us instead of 61 alone; the step did not move)"),
     "PRCNN_FINAL_FUSED": ("ab", "1", "csrc/proposal.hip", "0: final stage as four launches (round 3)"),
-    "PRCNN_PACK_NO_MEMSET": ("ab", "unset", "csrc/sa_packed.hip", "1: pack headers counted in a ticket record (slower than the memset)"),
     "PRCNN_PL_PIPE": ("ab", "1", "csrc/packed_layer.hip", "0: K >= 256 layers without the panel pipeline"),
     "PRCNN_PL_STREAM": ("ab", "1", "csrc/packed_layer.hip", "0: K = 128 layers one tile per workgroup"),
     "PRCNN_PL_PERSIST": ("ab", "1", "csrc/packed_layer.hip", "0: K >= 256 layers one tile per workgroup (round 3)"),

@@ -575,6 +575,41 @@ def test_fused_final_stage_equals_batched_torch_path():
         assert (f["boxes"] - t["boxes"]).abs().max().item() < 1e-5
 
 
+def test_final_stage_with_every_pair_a_candidate():
+    """The one-workgroup final stage when EVERY pair of boxes is a candidate (128 boxes jittered around one spot: 8128 pairs on the
+    compacted list, its capacity), when boxes are exact copies of one another (score ties broken by index, IoU exactly 1), with
+    degenerate (zero-width) boxes among them, and with one selected box: same survivors as the batched torch path."""
+    C, E = pkg("config"), pkg("eval_rcnn")
+    rng = np.random.default_rng(48)
+    cfg = C.default_eval_cfg()
+    B, M = 4, 128
+    ch = 4 * 6 + 1 + 2 * 9 + 3
+    rois = np.zeros((B, M, 7), np.float32)
+    rois[:, :, :3] = np.array([3.0, 1.5, 20.0], np.float32) + rng.normal(0, 0.3, (B, M, 3))
+    rois[:, :, 3:6] = [1.5, 1.6, 3.9]
+    rois[:, :, 6] = rng.uniform(-np.pi, np.pi, (B, M))
+    reg = (rng.standard_normal((B, M, ch)) * 0.05).astype(np.float32)
+    cls = (rng.standard_normal((B, M, 1)) * 0.5 + 2.0).astype(np.float32)          # everything passes the threshold
+    rois[1, 1::2] = rois[1, 0::2]; reg[1, 1::2] = reg[1, 0::2]; cls[1, 1::2] = cls[1, 0::2]      # scene 1: pairs of exact copies
+    reg[2, :, -3:-1] = -1.0                                                        # scene 2: h = w = 0 for every box (zero-area BEV boxes)
+    cls[3, 1:] = -6.0                                                              # scene 3: one box
+    ret = {"rois": torch.from_numpy(rois).to(DEV), "rcnn_reg": torch.from_numpy(reg).to(DEV).view(B * M, ch),
+           "rcnn_cls": torch.from_numpy(cls).to(DEV).view(B * M, 1)}
+    E.FUSED_POSTPROCESS = True
+    f = E.postprocess(cfg, ret, B)
+    E.FUSED_POSTPROCESS = False
+    try:
+        t = E.postprocess(cfg, ret, B)
+    finally:
+        E.FUSED_POSTPROCESS = True
+    torch.cuda.synchronize()
+    assert torch.equal(f["num"], t["num"]), (f["num"], t["num"])
+    assert int(f["num"][3]) == 1 and int(f["num"][0]) >= 1 and int(f["num"][1]) <= M // 2
+    assert torch.equal(f["scores"], t["scores"])
+    assert (f["boxes"] - t["boxes"]).abs().max().item() < 1e-5
+    assert (f["pred_boxes3d"] - t["pred_boxes3d"]).abs().max().item() < 1e-5
+
+
 def test_eval_scenes_writes_kitti_result_files(tmp_path):
     """Harness loop on the GPU (pipelined runner) over a few synthetic scenes: one KITTI result file per
     scene (empty file when nothing survives), 16 fields per line, and the packed table agrees with them.
