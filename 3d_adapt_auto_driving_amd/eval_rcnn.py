@@ -595,7 +595,7 @@ class GraphedRunner:
       * a group slot holds the coordinates of `group` batches (copied in when their chain is launched: 1.5 MB per batch), the
         geometry graph of the group (FastPointRCNN.geometry_group: FPS / ball queries / row lists / three-NN / the early SA levels,
         on a side stream) and, per batch of the group, four graphs: RPN stage (feature stream), proposal layer + RCNN geometry
-        (tail stream), RCNN features (feature stream), final stage (tail stream);
+        (tail stream), RCNN features (feature stream), final stage (behind them on the feature stream; FINAL_ON_FEATURE = 0: tail stream);
       * depth / group + 1 group slots rotate: a slot is rewritten only after the RCNN stages of its previous batches (an event wait
         on the side stream, normally long past);
       * the detections returned by submit() / flush() live in the slot: they stay valid for (slots - 1) * group further submits
