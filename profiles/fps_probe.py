@@ -5,7 +5,9 @@ pkg = importlib.import_module("3d_adapt_auto_driving_amd"); sys.path.insert(0, p
 import pointnet2_cuda as P
 synth = importlib.import_module("3d_adapt_auto_driving_amd.synth")
 dev = torch.device("cuda", 0)
-xyz = torch.from_numpy(synth.scenes(8, 16384, seed0=0)).to(dev)
+KIND = sys.argv[1] if len(sys.argv) > 1 else "uniform"        # uniform | lidar
+xyz = torch.from_numpy((synth.lidar_scenes if KIND == "lidar" else synth.scenes)(8, 16384, seed0=0)).to(dev)
+print("(%s scenes)" % KIND)
 for n, m in ((16384, 4096), (4096, 1024), (1024, 256), (256, 64)):
     pts = xyz[:, :n].contiguous()
     temp = torch.empty((8, n), device=dev); idx = torch.empty((8, m), dtype=torch.int32, device=dev)
