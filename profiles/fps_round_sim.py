@@ -20,10 +20,9 @@ def morton_order(p):
     code = part(gx) | (part(gz) << 1)
     return np.argsort(code, kind='stable')
 
-def simulate(p, m, layout, PPT=16, top=2, rmax=16, stats=None):
+def simulate(p, m, layout, PPT=16, top=2, rmax=16, stats=None, W=16):
     n = p.shape[0]
     order = morton_order(p)
-    W = 16
     # slot index array [w][i][lane] -> position s in Morton order
     w_, i_, l_ = np.meshgrid(np.arange(W), np.arange(PPT), np.arange(64), indexing='ij')
     if layout == 'blocked':
