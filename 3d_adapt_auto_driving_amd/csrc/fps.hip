@@ -525,6 +525,7 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
     __shared__ float s_xyz[32][3];
     __shared__ float s_bound[16];
     __shared__ float s_res[64];                                      // the round's verdict: [0] = number of picks, [1 + 3 q ..] = pivot q
+    __shared__ int s_rank[32], s_blk[32];                            // per entry: entries that precede it / one of them blocks it
     const int b = blockIdx.x;
     const float *__restrict__ cloud = xyz + (long)b * n * 3;
     const int *__restrict__ order = perm + (long)b * n;
@@ -595,6 +596,7 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
         sel[0] = 0;
         if (nxyz) { nxyz[0] = cloud[0]; nxyz[1] = cloud[1]; nxyz[2] = cloud[2]; }
     }
+    if (t < 32) { s_rank[t] = 0; s_blk[t] = 0; }                      // (the first barrier A orders this before any atomic)
     int j = 1;                                                        // picks made so far
     if (m > 1) {                                                      // the given start point, index 0
         const float ox = cloud[0], oy = cloud[1], oz = cloud[2];
@@ -648,33 +650,40 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
             }
         }
         lds_barrier();                                                // A: the table is complete
-        // ---- 3. merge, by ONE wave (every wave doing it -- the first version -- made the kernel issue-bound: 5.2 ms against the
-        // sequential kernel's 4.2); the others wait at B
+        // ---- 3. merge.  All 32 x 32 pairs at once, over ALL 16 waves: lane = (entry i = lane & 31, half h = lane >> 5) of wave w
+        // compares entry i with entry e = 2 w + h; entry i's RANK = how many entries precede it in the order (value desc, key asc);
+        // it is BLOCKED if an entry that precedes it lies closer than its running minimum.  The per-pair bits are summed / or-ed
+        // per entry through LDS atomics (s_rank / s_blk, zero between rounds), and one wave reads the verdict off: the picks of the
+        // round are the ranks 0 .. r-1 up to the first rank that fails.  (History: every wave merging the whole table redundantly --
+        // the first version -- made the kernel issue-bound, 5.2 ms against the sequential kernel's 4.2; ONE wave walking its
+        // half of the table, 16 dependent LDS round trips, was 2.6 k of a round's 10.2 k cycles with 15 waves waiting.)
         const int left = m - j;
+        const int i = lane & 31, h = lane >> 5;
+        const unsigned long long pki = s_vk[i];
+        float cv; uint32_t ck;
+        unpack_candidate(pki, cv, ck);
+        const float cx = s_xyz[i][0], cy = s_xyz[i][1], cz = s_xyz[i][2];
+        {
+            const int e = 2 * w + h;
+            const unsigned long long pke = s_vk[e];
+            const float ex = s_xyz[e][0], ey = s_xyz[e][1], ez = s_xyz[e][2];
+            const bool before = pke > pki;
+            const float d = kc.hipcc ? fps_dist<true>(cx, cy, cz, ex, ey, ez) : sqdist3(cx, cy, cz, ex, ey, ez);
+            const bool blk = before && (d < cv);
+            // both bits of the pair in ONE exchange with the other half's lane (and never behind a short-circuit: a shuffle that only
+            // the lanes with a false left operand execute reads inactive lanes)
+            const int mine = (before ? 1 : 0) | (blk ? 2 : 0);
+            const int other = __shfl_xor(mine, 32, 64);
+            const int rk = (mine & 1) + (other & 1);
+            const bool bl = ((mine | other) & 2) != 0;
+            if (h == 0 && rk) atomicAdd(&s_rank[i], rk);
+            if (h == 0 && bl) atomicOr(&s_blk[i], 1);
+        }
+        lds_barrier();                                                // A2: every pair has been looked at
         if (w == 0) {
-            // all 32 x 32 pairs at once: lane = (entry i = lane & 31, half h = lane >> 5) walks the 16 entries e of its half; entry i's
-            // RANK = how many entries precede it in the order (value desc, key asc); it is BLOCKED if an entry that precedes it lies
-            // closer than its running minimum.  The picks of the round are the ranks 0 .. r-1 up to the first rank that fails.
-            const int i = lane & 31, h = lane >> 5;
-            const unsigned long long pki = s_vk[i];
-            float cv; uint32_t ck;
-            unpack_candidate(pki, cv, ck);
-            const float cx = s_xyz[i][0], cy = s_xyz[i][1], cz = s_xyz[i][2];
+            const int rank = s_rank[i];
+            const bool blocked = s_blk[i] != 0;
             const float gB = wave_max_f32(lane < 16 ? s_bound[lane] : -INFINITY);
-            int rank = 0;
-            bool blocked = false;
-#pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int e = 16 * h + it;
-                const unsigned long long pke = s_vk[e];
-                const float ex = s_xyz[e][0], ey = s_xyz[e][1], ez = s_xyz[e][2];
-                const bool before = pke > pki;
-                rank += before ? 1 : 0;
-                const float d = kc.hipcc ? fps_dist<true>(cx, cy, cz, ex, ey, ez) : sqdist3(cx, cy, cz, ex, ey, ez);
-                blocked = blocked || (before && (d < cv));
-            }
-            rank += __shfl_xor(rank, 32, 64);
-            blocked = blocked || (__shfl_xor(blocked ? 1 : 0, 32, 64) != 0);
             const bool valid = !(ck == 0xffffffffu || !(cv > -1.0f));      // (reference: best starts at -1, besti at 0)
             const bool pass = rank == 0 ? true : ((cv > gB) && (cv > 0.f) && valid && !blocked);
             // a round ends behind an invalid first entry (the reference then picks index 0: every running minimum is below -1 / NaN)
@@ -689,6 +698,7 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
                 s_res[1 + 3 * rank] = ox; s_res[2 + 3 * rank] = oy; s_res[3 + 3 * rank] = oz;
                 if (nxyz) { nxyz[3 * (j + rank)] = ox; nxyz[3 * (j + rank) + 1] = oy; nxyz[3 * (j + rank) + 2] = oz; }
             }
+            if (h == 0) { s_rank[i] = 0; s_blk[i] = 0; }              // for the next round (read above, program order)
             if (lane == 0) s_res[0] = __int_as_float(r);
         }
         lds_barrier();                                                // B: the verdict is in
