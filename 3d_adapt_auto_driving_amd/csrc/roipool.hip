@@ -19,6 +19,7 @@
 namespace prcnn {
 
 constexpr int RP_THREADS = 256;
+constexpr int RP_RANK_MAX = 512;    // hits of a box placed by counting (above: bitonic sort)
 constexpr int RP_MAX_S = 2048;
 
 // Sweep of one (scene, box): first `sampled` in-box point indices in index order -> s_sel; returns min(#hits, sampled).
@@ -112,33 +113,70 @@ __device__ __forceinline__ int select_points_culled(int pts_num, int sampled, co
     }
     __syncthreads();
     const int ncand = s_misc[0];
-    for (int c = wave; c < ncand; c += RP_THREADS / 64) {
-        const float4 p = pxyz[(long)s_cand[c] * 64 + lane];
-        const float x = p.x, y = p.y, z = p.z;
-        bool in = false;
-        if (!(fabsf(x - cx) > 10.0f || fabsf(y - cy) > hh || fabsf(z - cz) > 10.0f)) {
-            const float xr = __fadd_rn(__fmul_rn(x - cx, cosa), __fmul_rn(z - cz, -sina));
-            const float zr = __fadd_rn(__fmul_rn(x - cx, sina), __fmul_rn(z - cz, cosa));
-            in = (xr >= -hl) & (xr <= hl) & (zr >= -hw) & (zr <= hw);
+    // four candidate groups of a wave per round: their loads are in flight together (one dependent round trip per group otherwise)
+    for (int c0 = wave; c0 < ncand; c0 += 4 * (RP_THREADS / 64)) {
+        float4 pp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * (RP_THREADS / 64);
+            pp[u] = pxyz[(long)s_cand[c < ncand ? c : c0] * 64 + lane];
         }
-        const unsigned long long mask = __ballot(in);
-        int base = 0;
-        if (lane == 0 && mask) base = atomicAdd(&s_misc[1], __popcll(mask));
-        base = __shfl(base, 0, 64);
-        if (in) {
-            const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-            if (pos < cap) s_hits[pos] = __float_as_int(p.w);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (c0 + u * (RP_THREADS / 64) >= ncand) break;                 // wave-uniform
+            const float4 p = pp[u];
+            const float x = p.x, y = p.y, z = p.z;
+            bool in = false;
+            if (!(fabsf(x - cx) > 10.0f || fabsf(y - cy) > hh || fabsf(z - cz) > 10.0f)) {
+                const float xr = __fadd_rn(__fmul_rn(x - cx, cosa), __fmul_rn(z - cz, -sina));
+                const float zr = __fadd_rn(__fmul_rn(x - cx, sina), __fmul_rn(z - cz, cosa));
+                in = (xr >= -hl) & (xr <= hl) & (zr >= -hw) & (zr <= hw);
+            }
+            const unsigned long long mask = __ballot(in);
+            int base = 0;
+            if (lane == 0 && mask) base = atomicAdd(&s_misc[1], __popcll(mask));
+            base = __shfl(base, 0, 64);
+            if (in) {
+                const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                if (pos < cap) s_hits[pos] = __float_as_int(p.w);
+            }
         }
     }
     __syncthreads();
     const int total = s_misc[1];
+    // s_misc shares its words with the sweep's s_cnt -- every wave must have read `total` before a wave that falls back
+    // starts writing them
+    __syncthreads();
+    if (total > cap) return -1;
+    if (total <= RP_RANK_MAX) {
+        // the usual case (54-106 points per RoI): a hit's place in index order = the number of hits with a smaller index (indices are
+        // distinct) -- thread t counts them for hit t over the list in LDS, four per 16-byte broadcast read, and writes the hit
+        // straight into s_sel.  ONE barrier instead of the bitonic network's log2(P) (log2(P) + 1) / 2 = 21-45 (7.7 of the kernel's
+        // 40 us: profiles/r04_microbench.md, roipool phases)
+        const int padded = (total + 3) & ~3;
+        for (int i = total + t; i < padded; i += RP_THREADS) s_hits[i] = 0x7fffffff;
+        __syncthreads();
+        for (int i = t; i < total; i += RP_THREADS) {
+            const int mine = s_hits[i];
+            int rank = 0;
+            if ((sampled & 3) == 0) {                                          // s_hits starts 9 * sampled ints into the LDS block: 16-byte aligned
+                for (int q = 0; q < padded; q += 4) {
+                    const int4 o = *reinterpret_cast<const int4 *>(s_hits + q);
+                    rank += (o.x < mine) + (o.y < mine) + (o.z < mine) + (o.w < mine);
+                }
+            } else {
+                for (int q = 0; q < total; ++q) rank += s_hits[q] < mine;
+            }
+            if (rank < sampled) s_sel[rank] = mine;
+        }
+        __syncthreads();
+        return min(total, sampled);
+    }
     int P = 64;
     while (P < total) P <<= 1;
-    // (1) s_misc shares its words with the sweep's s_cnt -- every wave must have read `total` before a wave that
-    // falls back starts writing them; (2) the sort pads to a power of two, which must fit the `cap` ints of s_hits
-    // (sampled not a power of two, or < 16): otherwise fall back to the sweep as well.
-    __syncthreads();
-    if (total > cap || P > cap) return -1;
+    // the sort pads to a power of two, which must fit the `cap` ints of s_hits (sampled not a power of two, or < 16): otherwise fall
+    // back to the sweep as well
+    if (P > cap) return -1;
     for (int i = total + t; i < P; i += RP_THREADS) s_hits[i] = 0x7fffffff;
     __syncthreads();
     for (int k = 2; k <= P; k <<= 1)
@@ -257,7 +295,8 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(
     // output row s -- a distinct row or a wrap-around copy s % cnt -- takes them from there.  The 128 feature columns are read
     // from the points' feature rows for the rows below feat_rows only, eight independent 16-byte gathers per thread in flight
     // (the loop used to be one dependent LDS -> gather -> store chain per iteration with an integer division and a modulo in
-    // front: 70 of the kernel's 90 us).
+    // front: 70 of the kernel's 90 us).  (Sending the first batch out in FRONT of the coordinate phase was tried: 48 instead of 40 us --
+    // the phase's own dependent loads queue behind the eight gathers, and the barrier drains them anyway.)
     for (int s2 = t; s2 < cnt; s2 += RP_THREADS) {
         const int k = s_sel[s2];
         const float x = pts[3 * k] - rx, y = pts[3 * k + 1] - ry_bottom, z = pts[3 * k + 2] - rz;
@@ -284,7 +323,8 @@ __global__ __launch_bounds__(RP_THREADS) void roipool3d_canonical_kernel(
             xo[e] = sc[8 * src + c];
         }
     }
-    // feature chunks of the rows below feat_rows
+    // feature chunks of the rows below feat_rows.  (Sending the first batch of gathers out in FRONT of the coordinate phase, to overlap its
+    // loads and its barrier, was tried in round 4: the compiler keeps the eight rows in scratch across the barrier -- 42 instead of 35 us.)
     const float inv_f4 = 1.0f / (float)f4;
     const int nfeat = feat_rows * f4;
     for (int e0 = t; e0 < nfeat; e0 += 8 * RP_THREADS) {
