@@ -67,6 +67,8 @@ SIGNATURES = {
     "prcnn_rows_dot": [C.c_long, _I, _I, _P, C.c_long, _P, _P, _P, C.c_long, _P],
     "prcnn_sa_wide_fused_supported": [_I, _I, _I],
     "prcnn_sa_wide_fused": [_I, _I, _I, _I, _I, _I, C.c_long] + [_P] * 11 + [_I, _I, _I, _P],
+    "prcnn_sa_wide_fused3_supported": [_I, _I, _I, _I],
+    "prcnn_sa_wide_fused3": [_I, _I, _I, _I, _I, _I, _I, C.c_long] + [_P] * 11 + [_I, _I, _I, _P],
     "prcnn_packed_gather_affine_batch": [_I, C.POINTER(GatherProblem), _P],
     "prcnn_packed_layer_batch": [_I, C.POINTER(LayerProblem), _I, _P],
     "prcnn_rpn_tail": [_I, _I, _I] + [_P] * 7 + [_I] + [_P] * 4,

@@ -426,6 +426,26 @@ def sa_wide_fused_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, ou
     return out
 
 
+def sa_wide_fused3_supported(c0, c1, c2, c3):
+    return bool(_lib.load().prcnn_sa_wide_fused3_supported(int(c0), int(c1), int(c2), int(c3)))
+
+
+def sa_wide_fused3_wrapper(new_xyz, xyz, feats, wcat, b1, wxyz, pack, b2, b3, widths, out, out_col, zeroed=False):
+    """sa_wide_fused_wrapper with layer 1 inside (csrc/sa_wide3.hip): feats (b, n, c0) point features, wcat = w1 | w2 | w3 (k-major, one
+    tensor), widths = (c0, c1, c2, c3) -- packed_layer_wrapper (P = feats w1 + b1) -> sa_wide_fused_wrapper, bit for bit, for a level
+    that groups every point once."""
+    _chk(torch.float32, new_xyz, xyz, feats, wcat, b1, wxyz, b2, b3, out)
+    b, n, c0 = feats.shape
+    c0w, c1, c2, c3 = (int(v) for v in widths)
+    if c0 != c0w or wcat.numel() != c0 * c1 + c1 * c2 + c2 * c3 or wxyz.size(1) != c1 or b1.numel() != c1 or b2.numel() != c2 or b3.numel() != c3:
+        raise RuntimeError("pointnet2_cuda: sa_wide_fused3 shape mismatch")
+    _lib.call("prcnn_sa_wide_fused3", b, n, new_xyz.size(1), c0, c1, c2, c3, pack.max_tiles, feats.data_ptr(), wxyz.data_ptr(),
+              pack.rowinfo.data_ptr(), pack.rowdxyz.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr(), wcat.data_ptr(),
+              b1.data_ptr(), b2.data_ptr(), b3.data_ptr(), out.data_ptr(), out.size(-1), out_col, int(bool(zeroed)),
+              _lib.current_stream(xyz))
+    return out
+
+
 def packed_gather_affine_batch_wrapper(problems):
     """packed_gather_affine_wrapper for up to 4 independent problems [(new_xyz, xyz, P, wxyz, pack, out), ...] -- the scales of one
     MSG level -- in ONE launch."""

@@ -56,6 +56,9 @@ USE_RPN_TAIL = os.environ.get("PRCNN_NO_RPN_TAIL") is None
 USE_SCALE_BATCH = os.environ.get("PRCNN_NO_SCALE_BATCH") is None
 # layers 1-3 + pool of a wide scale in one kernel (csrc/sa_wide.hip); PRCNN_NO_WIDE_FUSED=1: gather / layer / layer+pool launches
 USE_WIDE_FUSED = os.environ.get("PRCNN_NO_WIDE_FUSED") is None
+# ... and layer 1 inside as well where a level groups every point once (the RCNN's GroupAll level; csrc/sa_wide3.hip);
+# PRCNN_NO_WIDE_FUSED3=1: the per-point layer as a launch of its own in front of csrc/sa_wide.hip (A/B, same bits)
+USE_WIDE_FUSED3 = os.environ.get("PRCNN_NO_WIDE_FUSED3") is None
 # RoI pooling culls by 64-point spatial groups of the scene (built with the geometry chain); PRCNN_NO_POOL_GROUPS=1: full sweep
 USE_XYZ_LEVEL_EARLY = os.environ.get("PRCNN_NO_XYZ_EARLY") != "1"    # leading SA levels of a coordinates-only backbone computed with the geometry (side stream)
 EARLY_LEVELS = int(os.environ.get("PRCNN_EARLY_LEVELS", "4"))
@@ -174,7 +177,7 @@ class _Mlp:
                 else:
                     wt = _pad2(w.t(), _round128(w.shape[1]), np_)
                 self.layers.append((wt.contiguous(), _pad1(b, np_), relu))
-            self.split = self.packed = self.wide = None
+            self.split = self.packed = self.wide = self.wide_cat = None
             self.padded = not pad_out          # pad_out: the last layer's output keeps its zero columns (feeds another chain)
             # a 1-wide (<= 4) last layer without ReLU is a GEMV per output: its own small kernel instead of a 128-wide MFMA tile
             self.narrow = None
@@ -204,7 +207,7 @@ class _Mlp:
             self.split = (wt[:grouped_c].contiguous(), wt[c4:c4 + 3].contiguous(), b)   # (C,Cout), (3,Cout), (Cout)
         # 128-wide (zero-padded) form for the fused MFMA kernels: c1, c2 <= 128, c3 in {128, 256}.  Zero columns give
         # relu(0) = 0 activations that meet zero weight rows in the next layer: the padded chain adds exact zeros.
-        self.packed = self.wide = None
+        self.packed = self.wide = self.wide_cat = None
         if self.split is not None and len(self.layers) == 3 and all(l[2] for l in self.layers):
             wf, wx, b1 = self.split
             (w2, b2, _), (w3, b3, _) = self.layers[1], self.layers[2]
@@ -218,6 +221,8 @@ class _Mlp:
                 c1p, c2p = _round128(c1), _round128(c2)
                 self.wide = (_pad2(wf, kin, c1p), _pad2(wx, 3, c1p), _pad1(b1, c1p),
                              _pad2(w2, c1p, c2p), _pad1(b2, c2p), _pad2(w3, c2p, c3), b3)
+                # w1 | w2 | w3 in one allocation: csrc/sa_wide3.hip streams all three through one buffer resource
+                self.wide_cat = torch.cat([t.reshape(-1) for t in (self.wide[0], self.wide[3], self.wide[5])]).contiguous()
 
     def __call__(self, a, start=0):
         last = len(self.layers) - 1
@@ -590,8 +595,15 @@ class FastPointRCNN:
         if USE_PACKED and mlp.wide is not None:
             # wider level: the same distinct rows, layer by layer (gather+affine -> MFMA layer -> MFMA layer + segmented max)
             wf, wx, b1, w2, b2, w3, b3 = mlp.wide
-            P = point_layer(feats.view(B * N, feats.shape[2]), wf, b1, False).view(B, N, -1)
             pk = pack if pack is not None else ext.ball_pack_wrapper(idx, xyz, new_xyz)
+            if (dense and USE_WIDE_FUSED and USE_WIDE_FUSED3 and has_entry(ext, "sa_wide_fused3_wrapper") and feats.is_contiguous() and
+                    feats.shape[2] == wf.shape[0] and ext.sa_wide_fused3_supported(wf.shape[0], wf.shape[1], w2.shape[1], w3.shape[1])):
+                # a level that groups every point once (GroupAll): layer 1 runs inside the kernel as well -- no per-point launch, no P
+                # through HBM (csrc/sa_wide3.hip); same bits as the two calls below
+                ext.sa_wide_fused3_wrapper(new_xyz, xyz, feats, mlp.wide_cat, b1, wx, pk, b2, b3,
+                                           (wf.shape[0], wf.shape[1], w2.shape[1], w3.shape[1]), out, out_col, zeroed)
+                return
+            P = point_layer(feats.view(B * N, feats.shape[2]), wf, b1, False).view(B, N, -1)
             if (dense and USE_WIDE_FUSED and has_entry(ext, "sa_wide_fused_wrapper") and
                     ext.sa_wide_fused_supported(wf.shape[1], w2.shape[1], w3.shape[1])):
                 # layers 1-3 + pool in ONE kernel: the packed rows stay in LDS (csrc/sa_wide.hip).  `dense`: the caller knows that

@@ -57,6 +57,7 @@ SWITCHES = {
     "PRCNN_NO_RPN_TAIL": ("ab", "unset", "net/fast_infer.py", "finest FP module and RPN heads layer by layer"),
     "PRCNN_NO_SCALE_BATCH": ("ab", "unset", "net/fast_infer.py", "one launch per MSG scale"),
     "PRCNN_NO_WIDE_FUSED": ("ab", "unset", "net/fast_infer.py", "GroupAll level layer by layer"),
+    "PRCNN_NO_WIDE_FUSED3": ("ab", "unset", "net/fast_infer.py", "1: the GroupAll level's layer 1 as a per-point launch in front of csrc/sa_wide.hip instead of inside csrc/sa_wide3.hip"),
     # ---- kernel forms A/B (C library; same results)
     "PRCNN_FPS_SEQUENTIAL": ("ab", "unset", "csrc/fps.hip", "one pick per exchange (round 3 kernel)"),
     "PRCNN_FPS_NO_PRUNE": ("ab", "unset", "csrc/fps.hip", "full scan per pick"),

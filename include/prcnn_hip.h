@@ -248,6 +248,17 @@ int prcnn_sa_wide_fused(int b, int n, int m, int c1, int c2, int c3, long max_ti
                         const float *w2, const float *b2, const float *w3, const float *b3, float *out, int out_stride,
                         int out_col, int out_is_zero, void *stream);
 
+/* The same scale with layer 1 inside as well (csrc/sa_wide3.hip): for a level that groups every point exactly once -- the RCNN's GroupAll
+ * level, rcnn_net.py:64-92 with pointnet2_modules.py:19-55 -- the per-point part of layer 1 is the layer itself, and the separate
+ * prcnn_packed_layer launch that made P (and P's trip through HBM) goes away.  F (b,n,c0) point features; wcat = w1 (c0,c1) | w2 (c1,c2) |
+ * w3 (c2,c3), k-major, in ONE allocation; b1 / b2 / b3 the biases; the rest as prcnn_sa_wide_fused.  Results: prcnn_packed_layer (P = F w1 + b1)
+ * followed by prcnn_sa_wide_fused, bit for bit. */
+int prcnn_sa_wide_fused3_supported(int c0, int c1, int c2, int c3);
+int prcnn_sa_wide_fused3(int b, int n, int m, int c0, int c1, int c2, int c3, long max_tiles, const float *F, const float *wxyz,
+                         const unsigned int *rowinfo, const float *rowdxyz, const int *tilecloud, const unsigned int *hdr,
+                         const float *wcat, const float *b1, const float *b2, const float *b3, float *out, int out_stride,
+                         int out_col, int out_is_zero, void *stream);
+
 /* Batched forms: up to 4 independent problems (the scales of one MSG level, pointnet2_modules.py:19-55 loops over them) in ONE
  * launch -- the sparse levels are latency-bound, side by side they cost one launch instead of one each.  The single-problem
  * entries below are these with n = 1.  segmax = 1: every problem is a level's last layer + max pool (fields b, m, rowinfo,

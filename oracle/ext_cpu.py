@@ -289,6 +289,22 @@ class pointnet2_cpu:
         return pointnet2_cpu.packed_layer_segmax_wrapper(y2, w3t, b3, pack, b, m, out, out_col)
 
     @staticmethod
+    def sa_wide_fused3_supported(c0, c1, c2, c3):
+        return c0 % 128 == 0 and c1 % 128 == 0 and c2 % 128 == 0 and c3 % 128 == 0
+
+    @staticmethod
+    def sa_wide_fused3_wrapper(new_xyz, xyz, feats, wcat, b1, wxyz, pack, b2, b3, widths, out, out_col, zeroed=False):
+        """csrc/sa_wide3.hip as the chain it fuses: the per-point layer P = feats w1 + b1 (packed_layer_wrapper), then sa_wide_fused_wrapper."""
+        c0, c1, c2, c3 = (int(v) for v in widths)
+        w1 = wcat[:c0 * c1].view(c0, c1)
+        w2 = wcat[c0 * c1:c0 * c1 + c1 * c2].view(c1, c2)
+        w3 = wcat[c0 * c1 + c1 * c2:].view(c2, c3)
+        b, n, _ = feats.shape
+        P = torch.empty((b * n, c1))
+        pointnet2_cpu.packed_layer_wrapper(feats.reshape(b * n, c0), w1, b1, False, P)
+        return pointnet2_cpu.sa_wide_fused_wrapper(new_xyz, xyz, P.view(b, n, c1), wxyz, pack, w2, b2, w3, b3, out, out_col, zeroed)
+
+    @staticmethod
     def packed_gather_affine_batch_wrapper(problems):
         return [pointnet2_cpu.packed_gather_affine_wrapper(*p) for p in problems]
 

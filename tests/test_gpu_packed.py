@@ -250,6 +250,25 @@ def test_wide_packed_level_layer_by_layer_is_bit_exact(ext, cin, c1, c2, c3):
             of[:, :, 4:] = 0
         E.sa_wide_fused_wrapper(new_xyz, xyz, Pg.view(b, n, c1p), wx, E.ball_pack_wrapper(idx, xyz, new_xyz), w2, b2, w3, b3, of, 4, zeroed)
         assert torch.equal(of, og), (zeroed, float((of - og).abs().max()))
+    # ... and with the per-point layer inside as well (csrc/sa_wide3.hip; the engine uses it where a level groups every point once):
+    # the same bits again, for any row list
+    if E.sa_wide_fused3_supported(cin, c1p, c2p, c3):
+        wcat = torch.cat([wf.reshape(-1), w2.reshape(-1), w3.reshape(-1)]).contiguous()
+        for zeroed in (False, True):
+            of = torch.full((b, m, c3 + 4), float("nan"), device=DEV)
+            of[:, :, :4] = -1
+            if zeroed:
+                of[:, :, 4:] = 0
+            E.sa_wide_fused3_wrapper(new_xyz, xyz, feats, wcat, b1, wx, E.ball_pack_wrapper(idx, xyz, new_xyz), b2, b3, (cin, c1p, c2p, c3), of, 4, zeroed)
+            assert torch.equal(of, og), ("fused3", zeroed, float((of - og).abs().max()))
+        oc3 = torch.full((b, m, c3 + 4), float("nan"))
+        oc3[:, :, :4] = -1
+        ext_cpu.pointnet2_cpu.sa_wide_fused3_wrapper(new_xyz.cpu(), xyz.cpu(), feats.cpu(), wcat.cpu(), b1.cpu(), wx.cpu(),
+                                                     ext_cpu.pointnet2_cpu.ball_pack_wrapper(idx.cpu(), xyz.cpu(), new_xyz.cpu()), b2.cpu(), b3.cpu(),
+                                                     (cin, c1p, c2p, c3), oc3, 4)
+        assert torch.equal(oc3, oc)
+    else:
+        assert (cin, c1, c2, c3) != (256, 256, 256, 512), "the RCNN GroupAll shape must be served"
     # and within f32 rounding of plain library arithmetic (the padding changes nothing)
     ix = idx.long().view(b, m * ns)
     base = torch.gather(Pg.view(b, n, c1p), 1, ix.unsqueeze(-1).expand(-1, -1, c1p))

@@ -327,6 +327,7 @@ POINTNET2["dup_rep_wrapper"] = check_dup_rep
 POINTNET2["rcnn_roi_geometry_wrapper"] = check_roi_geometry
 POINTNET2["sa_packed_mlp_wrapper"] = check_sa_packed
 POINTNET2["sa_wide_fused_wrapper"] = {9: "exact"}          # one scale of a wide level in one kernel: output slice vs the oracle chain
+POINTNET2["sa_wide_fused3_wrapper"] = {10: "exact"}        # ... with the per-point layer inside (the RCNN's GroupAll level)
 
 
 def batched(check):
@@ -399,9 +400,10 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
                   "rpn_tail_wrapper": 0 if F.USE_FP_LINEAR else 1, "rpn_tail_lin_wrapper": 1 if F.USE_FP_LINEAR else 0, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
     want_calls.update({"packed_layer_segmax_batch_wrapper": 2, "packed_gather_affine_batch_wrapper": 2, "packed_layer_batch_wrapper": 5})   # RPN SA3, SA4; the two branches of the RCNN head (round 4)
     if wide_fused:       # the RCNN's GroupAll level (every row distinct: 800 units of work) in one kernel
-        want_calls.update({"sa_wide_fused_wrapper": 1, "packed_layer_segmax_wrapper": 0, "packed_gather_affine_wrapper": 0})
+        f3 = 1 if F.USE_WIDE_FUSED3 else 0   # ... and its per-point layer inside that kernel (csrc/sa_wide3.hip)
+        want_calls.update({"sa_wide_fused3_wrapper": f3, "sa_wide_fused_wrapper": 1 - f3, "packed_layer_segmax_wrapper": 0, "packed_gather_affine_wrapper": 0})
     else:
-        want_calls.update({"sa_wide_fused_wrapper": 0, "packed_layer_segmax_wrapper": 1, "packed_gather_affine_wrapper": 1})
+        want_calls.update({"sa_wide_fused3_wrapper": 0, "sa_wide_fused_wrapper": 0, "packed_layer_segmax_wrapper": 1, "packed_gather_affine_wrapper": 1})
     for name, n in want_calls.items():
         assert log[name] == n, (name, log[name], n)
     assert log["packed_layer_wrapper"] >= 5 and log["rows_dot_wrapper"] == 1
