@@ -4,6 +4,8 @@ import importlib, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("RP_LIB"):          # an experimental build of the library (profiles/_exp/)
+    importlib.import_module("3d_adapt_auto_driving_amd._lib").LIB_PATH = os.path.abspath(os.environ["RP_LIB"])
 pkg = importlib.import_module("3d_adapt_auto_driving_amd")
 sys.path.insert(0, pkg.DROPIN_DIR)
 import pointnet2_cuda as X
@@ -43,6 +45,14 @@ def separate():
 flops = 2.0 * b * n * (256 * 128 + 4 * 128 * 128 + 128)
 t = timeit(lambda: X.rpn_tail_wrapper(known, idx, w, wcat, bcat, wc2, bc2, feats, cls, reg))
 print("fused    : %.1f us  %.1f TF/s (f32 MFMA)" % (t * 1e3, flops / t / 1e9))
+# the product form (rpn_tail_lin: FP layer 1 applied at the coarse level, G = known @ W1 interpolated): four stages per tile
+G = torch.randn((b, m, 128), device=dev, generator=g)
+wlin = wcat[256:].contiguous()
+flops_lin = 2.0 * b * n * (3 * 128 * 128 + 128 * n_reg + 128)
+t3 = timeit(lambda: X.rpn_tail_lin_wrapper(G, idx, w, wlin, bcat, wc2, bc2, feats, cls, reg), reps=40)
+print("lin      : %.1f us  %.1f TF/s algorithmic (f32 MFMA)" % (t3 * 1e3, flops_lin / t3 / 1e9))
+if len(sys.argv) > 1 and sys.argv[1] == "lin":
+    sys.exit(0)
 t2 = timeit(separate)
 print("separate : %.1f us  %.1f TF/s   (7 launches)" % (t2 * 1e3, flops / t2 / 1e9))
 separate(); torch.cuda.synchronize()
