@@ -118,13 +118,13 @@ __global__ __launch_bounds__(256, 1) void rpn_tail_kernel(const RpnTailArgs a)
 #define RT_SIDE1(g) RT_SIDE(RT_IROWS, g)
 #define RT_SIDE2(g) RT_SIDE(2 * RT_IROWS, g)
 #define RT_SIDE3(g) RT_SIDE(3 * RT_IROWS, g)
-    f32x4 co[8];                                           // a tile's rows on their way out: LDS -> registers -> 512-byte rows
+    f32x4 co[4];                                           // a tile's rows on their way out, four at a time: LDS -> registers -> 512-byte rows
 #define RT_ROWS_OUT(g, TT, T, dst, ld, live)                                                              \
-    if ((g) == 1) {                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) co[i] = *reinterpret_cast<const f32x4 *>((T) + (r0 + 8 * i) * RT_LD + 4 * chunk); \
-    } else if ((g) == 3) {                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                               \
-            const unsigned int gr = (unsigned int)(TT) * RT_ROWS + r0 + 8 * i;                        \
+    if ((g) == 1 || (g) == 4) {                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) co[i] = *reinterpret_cast<const f32x4 *>((T) + (r0 + 8 * (i + ((g) == 4 ? 4 : 0))) * RT_LD + 4 * chunk); \
+    } else if ((g) == 3 || (g) == 6) {                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+            const unsigned int gr = (unsigned int)(TT) * RT_ROWS + r0 + 8 * (i + ((g) == 6 ? 4 : 0)); \
             if ((live) && gr < (unsigned int)a.rows) *reinterpret_cast<f32x4 *>((dst) + (gr * (unsigned int)(ld) + 4u * chunk)) = co[i]; \
         }                                                                                             \
     }
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void rpn_tail_lin_kernel(const RpnTailArgs 
     if ((g) == (gi)) { RL_ISSUE(0, 2 * (r)) RL_ISSUE(1, 2 * (r) + 1) }                                    \
     else if ((g) == (gf)) { RL_ROW(0, 2 * (r), Xn) }                                                      \
     else if ((g) == (gf) + 1) { RL_ROW(1, 2 * (r) + 1, Xn) }
-    f32x4 co[8];
+    f32x4 co[4];
 
     // tiles by XCD: one eighth of the rows (one scene of a batch of 8) and its 2 MB of G per L2 instead of all 16.8 MB through every L2
     XcdTickets tk;
