@@ -40,6 +40,10 @@ python profiles/pmc_step_summarize.py $(ls $O/ops_FETCH_SIZE/*/*counter_collecti
 rm -rf $O/ops_FETCH_SIZE $O/ops_WRITE_SIZE
 # MFMA counters of the step's MFMA kernels
 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -- python profiles/pmc_step_probe.py 6 > $O/pmc_mfma.log 2>&1
-for k in rpn_tail_lin_kernel rcnn_entrance_kernel sa_wide_fused_kernel sa_packed_mlp256_kernel sa_packed_mlp128_kernel "packed_layer_pipe_kernel<false>" "packed_layer_persist_kernel<false>" packed_layer_stream_kernel; do echo "## $k"; python profiles/pmc_generic.py $(ls $O/pmc_mfma/*/*counter_collection.csv | head -1) "$k"; done > $O/pmc_mfma_product_kernels.txt 2>&1
+for k in rpn_tail_lin_kernel rcnn_entrance_kernel sa_wide3_kernel sa_packed_mlp256_kernel sa_packed_mlp128_kernel "packed_layer_pipe_kernel<false>" "packed_layer_persist_kernel<false>" packed_layer_stream_kernel; do echo "## $k"; python profiles/pmc_generic.py $(ls $O/pmc_mfma/*/*counter_collection.csv | head -1) "$k"; done > $O/pmc_mfma_product_kernels.txt 2>&1
 rm -rf $O/pmc_mfma
+# second session: what shares a SIMD with an MFMA stream; instruction mix of the MFMA kernels; RoI pooling and the fused tail alone
+( ./profiles/_exp/coexec_probe ) > $O/coexec_probe.md 2>/dev/null      # built here: hipcc --offload-arch=gfx950 -O3 -o profiles/_exp/coexec_probe profiles/coexec_probe.hip
+bash profiles/pmc_inst_mix.sh > /dev/null 2>&1; cp gpurun_out/pmc_inst_mix.txt $O/pmc_inst_mix.txt
+( echo '## profiles/roipool_probe.py'; python profiles/roipool_probe.py; echo; echo '## profiles/tail_probe.py'; python profiles/tail_probe.py ) 2>&1 | grep -v amdgpu.ids > $O/kernel_probes.txt
 cut -c1-400 $O/bench_default.json; head -12 $O/pmc_product_kernels.md
