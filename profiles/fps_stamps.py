@@ -74,7 +74,7 @@ def run(kind):
     assert lib.prcnn_debug_fps_acc(buf) == 0
     a = np.array(buf, dtype=np.float64).reshape(16, NPH)
     rounds = a[:, 5]
-    print("%s scenes, cloud 0, 16384 -> 4096: %d rounds; s_memtime ticks per round (100 MHz: x 10 ns) by wave" % (kind, int(rounds[0])))
+    print("%s scenes, cloud 0, 16384 -> 4096: %d rounds; s_memtime cycles per round by wave" % (kind, int(rounds[0])))
     print("wave | rebuild+publish | wait A | merge | wait B | updates | sum")
     for w in range(16):
         v = a[w, :5] / rounds[w]
