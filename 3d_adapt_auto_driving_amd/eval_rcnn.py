@@ -14,6 +14,7 @@ CLI (subset of the reference's flags):  python -m ... --cfg_file X --eval_mode r
   --batch_size 8 --output_dir out [--set K V ...] [--scenes 64]
 """
 import argparse
+import collections
 import contextlib
 import os
 import time
@@ -61,6 +62,10 @@ FUSED_POSTPROCESS = True     # final stage through the fused HIP entry when the 
 # RoI pooling, the RoI clouds' geometry, final stage -- was the longest of the four, and the hop feature -> proposal -> host costs two
 # event waits.  PRCNN_FINAL_ON_FEATURE=0: as in round 3.
 FINAL_ON_FEATURE = os.environ.get("PRCNN_FINAL_ON_FEATURE", "1") != "0"
+# batches of a geometry group that share the launches of the stages behind the geometry in the graphed runner (GraphedRunner.pair):
+# 2 (measured: 6040-6150 / 6980-7050 scenes/s at K = 20 / 100 against 5800-5860 / 6730-6750 with 1, LiDAR-shaped 4270-4350 / 4930-4970
+# against 4140-4160 / 4830; 4: 6060 / 6780 and 4330 / 4750); 1: every batch its own launches
+RCNN_PAIR = int(os.environ.get("PRCNN_PAIR", "2"))
 
 
 def _anchor_host(cfg):
@@ -631,10 +636,19 @@ class GraphedRunner:
         if want == 1 or want < 0:
             raise ValueError("PRCNN_GRAPH_SLOTS=%d: the graphed runner needs at least 2 group slots" % want)
         self.n_slots = want or max(2, -(-self.depth // self.group) + 1)
+        # PAIR consecutive batches of a group share the launches of every stage behind the geometry (RPN stage, proposal layer + RoI
+        # geometry, RCNN features, final stage): one MEMBER of a slot = `pair` batches = pair x B scenes per launch.  Fatter launches:
+        # the same 160 / 800 scenes run 4 % / 3.5 % faster in steps of 16 than in steps of 8; the detections of a
+        # batch come back up to 2 pair - 1 submits late instead of 1.
+        self.pair = max(1, RCNN_PAIR)
+        if self.group % self.pair:
+            self.pair = 1
         self.shape = None
-        self._assigned = []          # [(batch tensor, group slot, member)] chains launched, batch not yet submitted
+        self._assigned = []          # [(batch tensor, group slot, batch index within the slot)] chains launched, batch not yet submitted
         self._chains = self._assigned
-        self._inflight = None        # ("graph", slot, member) | ("eager", det)
+        self._pending = None         # the member being filled: {"s": slot, "m": member, "halves": set of batch positions submitted so far}
+        self._inflights = collections.deque()    # ("graph", slot, member, [valid batch positions]) | ("eager", det), oldest first
+        self._out = collections.deque()          # detections finished and not handed back yet, in submit order
         self._next_slot = 0
         self.captures = 0
 
@@ -658,13 +672,15 @@ class GraphedRunner:
         eng, cfg, G = self.engine, self.cfg, self.group
         B, N, _ = first.shape
         self.shape = tuple(first.shape)
+        P = self.pair
+        Bm, Gm = P * B, G // P                                   # scenes per member launch, members per slot
         eng.check_weights()
         torch.cuda.synchronize(self.device)
         self.xin = [torch.empty((G * B, N, 3), dtype=torch.float32, device=self.device) for _ in range(self.n_slots)]
         for x in self.xin:
             for k in range(G):
                 x[k * B:(k + 1) * B].copy_(first)              # valid clouds everywhere: a partly filled group computes on them
-        parts = lambda s: [self.xin[s][k * B:(k + 1) * B] for k in range(G)]
+        parts = lambda s: [self.xin[s][k * Bm:(k + 1) * Bm] for k in range(Gm)]
 
         def tail_stage(st):
             rois, roi_scores = eng.propose(st)
@@ -672,7 +688,7 @@ class GraphedRunner:
 
         def final_stage(tl, out):
             ret = {"rois": tl["rois"], "rcnn_cls": out["rcnn_cls"], "rcnn_reg": out["rcnn_reg"]}
-            det = postprocess(cfg, ret, B)
+            det = postprocess(cfg, ret, Bm)
             det.update(ret)
             return det
 
@@ -707,7 +723,7 @@ class GraphedRunner:
             side = self.sides[s % len(self.sides)]
             g_geo, geos = self._capture(side, pool(), lambda: eng.geometry_group(parts(s)))
             slot = {"side": side, "g_geo": g_geo, "geos": geos, "ev_geo": torch.cuda.Event(), "members": []}
-            for k in range(G):
+            for k in range(Gm):
                 xb = parts(s)[k]
                 g_rpn, st = self._capture(self.feat, pool(), lambda: eng.rpn_stage(xb, geos[k]))
                 g_tail, tl = self._capture(self.tail, pool(), lambda: tail_stage(st))
@@ -735,11 +751,11 @@ class GraphedRunner:
         return None
 
     def _target_slot_state(self):
-        """the slot the next chain would be written into -> (slot index, holds the batch in flight?, holds assigned batches that were
-        not submitted yet?)"""
+        """the slot the next chain would be written into -> (slot index, holds a batch in flight or the member being filled?, holds
+        assigned batches that were not submitted yet?)"""
         s = self._next_slot % self.n_slots
-        inflight = self._inflight is not None and self._inflight[0] == "graph" and self._inflight[1] == s
-        return s, inflight, any(a[1] == s for a in self._assigned)
+        busy = any(f[0] == "graph" and f[1] == s for f in self._inflights) or (self._pending is not None and self._pending["s"] == s)
+        return s, busy, any(a[1] == s for a in self._assigned)
 
     def _launch_group(self, batch_list, main):
         s = self._next_slot % self.n_slots
@@ -768,6 +784,7 @@ class GraphedRunner:
 
     @torch.no_grad()
     def submit(self, cur, upcoming=None):
+        """-> the detections of an EARLIER batch (in submit order), or None"""
         main = torch.cuda.current_stream(self.device)
         todo = [] if upcoming is None else (list(upcoming) if isinstance(upcoming, (list, tuple)) else [upcoming])
         todo = [p for p in todo if p is not None][:max(1, self.depth)]
@@ -777,12 +794,12 @@ class GraphedRunner:
             return self._submit_eager(cur, main)
         todo = [p for p in todo if self._conforms(p)]
         a = self._where(cur)
-        done, finished = None, False
         if a is None:                                       # cold start (or a caller that looks less far ahead)
             self.engine.check_weights()
-            s_next, holds_inflight, holds_assigned = self._target_slot_state()
-            if holds_inflight:                              # few slots: the batch in flight lives where this chain goes -- its RCNN and
-                done, finished = self._finish_inflight(), True     # final stages are enqueued first (the chain waits for ev_rcnn)
+            self._close_pending(main)                       # a member left half filled: its batches run now
+            s_next, busy, holds_assigned = self._target_slot_state()
+            if busy:                                        # few slots: a batch in flight lives where this chain goes -- its RCNN and
+                self._finish_slot(s_next)                   # final stages are enqueued first (the chain waits for ev_rcnn)
             if holds_assigned:                              # batches announced earlier and never submitted: their chain is dropped
                 self._assigned[:] = [x for x in self._assigned if x[1] != s_next]
             self._launch_group([cur] + [p for p in todo if self._where(p) is None][:self.group - 1], main)
@@ -791,17 +808,35 @@ class GraphedRunner:
         missing = [p for p in todo if self._where(p) is None]
         have = len(todo) - len(missing)
         if missing and (len(missing) >= self.group or have <= 1):
-            s_next, holds_inflight, holds_assigned = self._target_slot_state()
+            s_next, busy, holds_assigned = self._target_slot_state()
             # a look-ahead chain is optional: it waits for a later submit while its slot still holds the current batch or batches
-            # that were assigned and not submitted yet; the slot of the batch in flight is released by finishing that batch first
-            if not holds_assigned and s_next != a[1]:
-                if holds_inflight and not finished:
-                    done, finished = self._finish_inflight(), True
+            # that were assigned and not submitted yet; the slot of a batch in flight is released by finishing that batch first
+            pend_here = self._pending is not None and self._pending["s"] == s_next
+            if not holds_assigned and s_next != a[1] and not pend_here:
+                if busy:
+                    self._finish_slot(s_next)
                 self.engine.check_weights()
                 self._launch_group(missing[:self.group], main)
         _, s, k = a
+        m, h = k // self.pair, k % self.pair
+        if self._pending is not None and (self._pending["s"], self._pending["m"]) != (s, m):
+            self._close_pending(main)                       # the caller skipped the rest of that member
+        if self._pending is None:
+            self._pending = {"s": s, "m": m, "halves": set()}
+        self._pending["halves"].add(h)
+        if h == self.pair - 1:
+            self._close_pending(main)
+        return self._out.popleft() if self._out else None
+
+    def _close_pending(self, main):
+        """RPN stage and proposal stage of the member being filled (its batches not submitted hold an earlier pass's clouds: computed,
+        never handed back), then the RCNN + final stages of the member in flight behind them"""
+        p, self._pending = self._pending, None
+        if p is None:
+            return
+        s, mi = p["s"], p["m"]
         slot = self.slots[s]
-        m = slot["members"][k]
+        m = slot["members"][mi]
         feat, tail = main, self.tail
         feat.wait_event(slot["ev_geo"])
         with torch.cuda.stream(feat):
@@ -809,40 +844,47 @@ class GraphedRunner:
             m["ev_rpn"].record(feat)
         if _GRAPH_DEBUG & 4:
             torch.cuda.synchronize(self.device)
-            print("[graph debug] slot %d member %d rpn done" % (s, k), flush=True)
+            print("[graph debug] slot %d member %d rpn done" % (s, mi), flush=True)
         tail.wait_event(m["ev_rpn"])
         with torch.cuda.stream(tail):
             m["g_tail"].replay()
             m["ev_prop"].record(tail)
         if _GRAPH_DEBUG & 4:
             torch.cuda.synchronize(self.device)
-            print("[graph debug] slot %d member %d tail done" % (s, k), flush=True)
-        if not finished:
-            done = self._finish_inflight()
+            print("[graph debug] slot %d member %d tail done" % (s, mi), flush=True)
+        if self._inflights:
+            self._finish_inflight()
         m["used"] = True
-        self._inflight = ("graph", s, k)
-        return done
+        self._inflights.append(("graph", s, mi, sorted(p["halves"])))
 
     def _submit_eager(self, cur, main):
-        done = self._finish_inflight()
+        self._close_pending(main)
+        while self._inflights:                              # another shape: the pipeline drains first (results stay in order)
+            self._finish_inflight()
         det = infer_batch(self.model, self.cfg, cur, engine=self.engine)
         ready = torch.cuda.Event()
         ready.record(main)
         det["ready"], det["stream"] = ready, main
-        self._inflight = ("eager", det)
-        return done
+        self._inflights.append(("eager", det))
+        return self._out.popleft() if self._out else None
+
+    def _finish_slot(self, s):
+        """RCNN + final stages of every batch in flight up to the last one that lives in group slot `s` (in order)"""
+        if self._pending is not None and self._pending["s"] == s:
+            self._close_pending(torch.cuda.current_stream(self.device))
+        while any(f[0] == "graph" and f[1] == s for f in self._inflights):
+            self._finish_inflight()
 
     def _finish_inflight(self):
-        if self._inflight is None:
-            return None
-        kind = self._inflight[0]
-        if kind == "eager":
-            det = self._inflight[1]
-            self._inflight = None
-            return det
-        _, s, k = self._inflight
-        self._inflight = None
-        m = self.slots[s]["members"][k]
+        """RCNN + final stages of the OLDEST member in flight; its batches' detections go onto self._out"""
+        if not self._inflights:
+            return
+        f = self._inflights.popleft()
+        if f[0] == "eager":
+            self._out.append(f[1])
+            return
+        _, s, mi, halves = f
+        m = self.slots[s]["members"][mi]
         feat, tail = torch.cuda.current_stream(self.device), self.tail
         feat.wait_event(m["ev_prop"])
         with torch.cuda.stream(feat):
@@ -850,7 +892,7 @@ class GraphedRunner:
             m["ev_rcnn"].record(feat)
         if _GRAPH_DEBUG & 4:
             torch.cuda.synchronize(self.device)
-            print("[graph debug] slot %d member %d rcnn done" % (s, k), flush=True)
+            print("[graph debug] slot %d member %d rcnn done" % (s, mi), flush=True)
         post = feat if FINAL_ON_FEATURE else tail
         if not FINAL_ON_FEATURE:
             tail.wait_event(m["ev_rcnn"])
@@ -859,17 +901,34 @@ class GraphedRunner:
             m["ready"].record(post)
         if _GRAPH_DEBUG & 4:
             torch.cuda.synchronize(self.device)
-            print("[graph debug] slot %d member %d done" % (s, k), flush=True)
-        det = dict(m["det"])
-        det["ready"], det["stream"] = m["ready"], post
-        return det
+            print("[graph debug] slot %d member %d done" % (s, mi), flush=True)
+        if self.pair == 1:
+            det = dict(m["det"])
+            det["ready"], det["stream"] = m["ready"], post
+            self._out.append(det)
+            return
+        B = self.shape[0]
+        for h in halves:                                    # one detections dict per batch: views of the member's tensors
+            det = {}
+            for key, v in m["det"].items():
+                if key == "blob" or not torch.is_tensor(v):
+                    continue
+                per = v.shape[0] // self.pair               # rows of this tensor per batch (B scenes, or B x rois)
+                det[key] = v[h * per:(h + 1) * per]
+            det["blob"] = None                              # (the member's single allocation holds both batches: three copies per batch)
+            det["ready"], det["stream"] = m["ready"], post
+            self._out.append(det)
 
     @torch.no_grad()
     def flush(self):
-        """Finish the batch still in flight and return its detections (or None); chains of batches never submitted are dropped."""
-        det = self._finish_inflight()
+        """Finish what is still in the pipeline and return the detections of the OLDEST batch not handed back yet; None when nothing is
+        left (call until then: with pair = 2 up to three batches are outstanding).  Chains of batches never submitted are dropped."""
         self._assigned[:] = []
-        return det
+        if not self._out:
+            self._close_pending(torch.cuda.current_stream(self.device))
+            while self._inflights and not self._out:
+                self._finish_inflight()
+        return self._out.popleft() if self._out else None
 
 
 def _tensors(obj):
@@ -1218,7 +1277,7 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
 
     # software pipeline: while batch i is on the device, batch i+1 is loaded and (three-stream runner) the RCNN +
     # final stage of batch i-1 complete; results are consumed `lag` batches late
-    prev = None
+    submitted = collections.deque()        # (ids, meta, order) of the batches whose detections have not come back yet, oldest first
     order = 0
     depth = runner.depth if runner is not None else 1
     ahead = [load(k * batch_size) for k in range(depth)]   # `depth` batches ahead: the runner starts their geometry chains early
@@ -1226,19 +1285,20 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
         pts, ids, meta = ahead.pop(0)
         ahead.append(load(s + depth * batch_size))
         if runner is not None:
-            det = runner.submit(pts, [a[0] for a in ahead])
+            det = runner.submit(pts, [a[0] for a in ahead])        # an earlier batch's detections (in submit order), or None
+            submitted.append((ids, meta, order))
             if det is not None:
-                start_copy(det, *prev)
-            prev = (ids, meta, order)
+                start_copy(det, *submitted.popleft())
         else:
             start_copy(infer_batch(model, cfg, pts), ids, meta, order)
         order += 1
         while len(inflight) > lag:
             consume()
-    if runner is not None:
-        det = runner.flush()
-        if det is not None:
-            start_copy(det, *prev)
+    while runner is not None and submitted:
+        det = runner.flush()                                        # one batch per call, oldest first
+        if det is None:
+            raise RuntimeError("eval_scenes: the runner returned no detections for %d submitted batches" % len(submitted))
+        start_copy(det, *submitted.popleft())
     while inflight:
         consume()
     for j in jobs:

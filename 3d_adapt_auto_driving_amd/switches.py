@@ -21,6 +21,7 @@ SWITCHES = {
     "PRCNN_GRAPHS": ("operational", "1", "eval_rcnn.py", "0: eager enqueue (PipelinedRunner) instead of hipGraph replay (GraphedRunner)"),
     "PRCNN_GRAPH_SLOTS": ("operational", "depth/group+1", "eval_rcnn.py", "group slots of the graphed runner (>= 2; 5.9 GB of HBM each at batch 8)"),
     "PRCNN_GEO_GROUP": ("operational", "4", "eval_rcnn.py", "batches per geometry chain"),
+    "PRCNN_PAIR": ("operational", "2", "eval_rcnn.py", "batches of a geometry group that share the launches of the RPN / proposal / RCNN / final stages in the graphed runner (must divide the group; detections come back up to 2 x pair - 1 submits late)"),
     "PRCNN_GEO_DEPTH": ("operational", "3*group", "eval_rcnn.py", "batches the geometry runs ahead"),
     "PRCNN_SIDE_STREAMS": ("operational", "2", "eval_rcnn.py", "geometry side streams (with feature + proposal stream: the 4 hardware queues)"),
     "PRCNN_LOADER_WORKERS": ("operational", "budget", "eval_rcnn.py", "loader processes of eval_scenes (default: host_budget)"),

@@ -503,16 +503,23 @@ def main():
             # that will not be processed, and the first chain's latency (cold start) is inside the timed region.
             nxt = [batches[(i + d) % n_slots] for d in range(1, runner.depth + 1) if i + d < end]
             if lagged:
-                det = runner.submit(batches[i % n_slots], nxt)
+                det = runner.submit(batches[i % n_slots], nxt)         # the detections of an EARLIER batch (in submit order), or None
                 if det is not None:
-                    copy_out(det, i - 1)
+                    copy_out(det, out_next[0])
+                    out_next[0] += 1
             else:
                 copy_out(runner.step(batches[i % n_slots], nxt), i)
 
+        out_next = [0]                         # index of the batch whose detections come back next
+
         def drain(last):
-            det = runner.flush() if lagged else None
-            if det is not None:
-                copy_out(det, last)
+            while lagged:                      # the runner hands back one batch per call until its pipeline is empty
+                det = runner.flush()
+                if det is None:
+                    break
+                copy_out(det, out_next[0])
+                out_next[0] += 1
+            assert not lagged or out_next[0] == last + 1, "detections of %d batches came back, %d were submitted" % (out_next[0], last + 1)
 
         for i in range(warmup):
             step(i, warmup)

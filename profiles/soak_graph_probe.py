@@ -22,16 +22,18 @@ def check(i, ev, slot):
     if first.setdefault(i % NS, h) != h:
         bad += 1
         print("step %d (batch %d): detections differ from the first pass" % (i, i % NS))
+came = 0
 t0 = time.perf_counter()
 for i in range(N):
     det = runner.submit(batches[i % NS], [batches[(i + d) % NS] for d in range(1, runner.depth + 1) if i + d < N])
-    if det is not None:
-        slot = (i - 1) % 8
+    if det is not None:                                  # an EARLIER batch's detections, in submit order (paired members: up to 3 submits late)
+        j = came; came += 1
+        slot = j % 8
         with torch.cuda.stream(det["stream"]):
             for h, k in zip(host[slot], ("boxes", "scores", "num")):
                 h.copy_(det[k], non_blocking=True)
             ev = torch.cuda.Event(); ev.record()
-        pend.append((i - 1, ev, slot))
+        pend.append((j, ev, slot))
         if len(pend) > 3:
             check(*pend.popleft())
     if (i + 1) % 200 == 0:
