@@ -599,12 +599,15 @@ class GraphedRunner:
     A graph replays fixed addresses, so the pipeline runs over SLOTS instead of freshly allocated tensors:
       * a group slot holds the coordinates of `group` batches (copied in when their chain is launched: 1.5 MB per batch), the
         geometry graph of the group (FastPointRCNN.geometry_group: FPS / ball queries / row lists / three-NN / the early SA levels,
-        on a side stream) and, per batch of the group, four graphs: RPN stage (feature stream), proposal layer + RCNN geometry
-        (tail stream), RCNN features (feature stream), final stage (behind them on the feature stream; FINAL_ON_FEATURE = 0: tail stream);
+        on a side stream) and, per MEMBER of the group (`pair` consecutive batches: 2 by default), four graphs: RPN stage (feature
+        stream), proposal layer + RCNN geometry (tail stream), RCNN features (feature stream), final stage (behind them on the feature
+        stream; FINAL_ON_FEATURE = 0: tail stream) -- pair x B scenes per launch of each;
       * depth / group + 1 group slots rotate: a slot is rewritten only after the RCNN stages of its previous batches (an event wait
         on the side stream, normally long past);
-      * the detections returned by submit() / flush() live in the slot: they stay valid for (slots - 1) * group further submits
-        (12 by default) -- copy them out (on det["stream"]) before that, as eval_scenes and bench.py do right away.
+      * submit() hands back the detections of an EARLIER batch, in submit order, or None (a member's stages are launched when its
+        last batch is submitted, its RCNN + final stages behind the next member's RPN stage: up to 2 pair - 1 submits late); flush()
+        one batch per call until None.  They are views into the slot: valid for (slots - 1) * group - 2 pair further submits (8 by
+        default) -- copy them out (on det["stream"]) before that, as eval_scenes and bench.py do right away.
     Every graph has a memory pool of its own (see _build); everything a later graph or the caller reads is kept referenced here.  Batches of another shape than the first one seen (the last, short batch of a split) run eagerly.
     Nondeterminism is that of the eager path: the worklists built with atomics (point groups, pooled tiles) come out in
     a different order every run, the results computed from them do not (tests/test_gpu_graphs.py: detections bit for bit)."""
