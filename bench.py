@@ -59,7 +59,21 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32 MFMA peak (MI355X_MICROARCH.md)
 # HBM traffic per launch from the rocprofv3 PMC passes over the product step (FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950
 # + WRITE_SIZE), kept with the profile it came from; a kernel that has no entry reports null
 PMC_SOURCE = "profiles/r04_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the product step)"
-PMC_TRAFFIC = {"rpn_tail_lin_kernel": 148.96e6, "rpn_tail_kernel": 325.87e6, "roipool3d_canonical_kernel": 87.06e6}
+# keyed by the scenes per launch the passes ran at (profiles/pmc_step_probe.py: 16 = a pair of batches, the product's launch since the
+# second session of round 4; 8: the passes of rounds 2-4 over single batches)
+PMC_TRAFFIC = {8: {"rpn_tail_lin_kernel": 148.96e6, "rpn_tail_kernel": 325.87e6, "roipool3d_canonical_kernel": 87.06e6},
+               16: {"rpn_tail_lin_kernel": 297.60e6, "roipool3d_canonical_kernel": 172.60e6}}
+# scenes per launch of the stages behind the geometry in the product runner (eval_rcnn.GraphedRunner pairs batches: PRCNN_PAIR = 2): the
+# roofline legs of those kernels run at THIS size, and their PMC traffic comes from passes at this size
+def launch_scenes():
+    E = importlib.import_module(PKG + ".eval_rcnn")
+    pkg = importlib.import_module(PKG)
+    paired = E.USE_GRAPHS and getattr(pkg, "GRAPH_REPLAY_SAFE", False)
+    group = max(1, int(os.environ.get("PRCNN_GEO_GROUP", "4")))
+    pair = max(1, E.RCNN_PAIR) if paired else 1
+    return BATCH * (pair if group % pair == 0 else 1)
+
+
 HOST_LAG = int(os.environ.get("PRCNN_BENCH_LAG", "3"))   # the host consumes a batch's detections this many batches late
 BATCH = int(os.environ.get("PRCNN_BENCH_BATCH", "8"))     # scenes per step per GPU (BASELINE configs[2]: 8; the override is for experiments and is echoed in config.env_overrides)
 NPOINTS = 16384
@@ -175,7 +189,7 @@ def roofline_rpn_tail(dev, cfg, model, reps=20):
     eng = F.FastPointRCNN(model, cfg)
     if eng.rpn_tail is None:
         return None
-    pts = torch.from_numpy(synth.scenes(BATCH, NPOINTS, seed0=3000)).to(dev)
+    pts = torch.from_numpy(synth.scenes(launch_scenes(), NPOINTS, seed0=3000)).to(dev)      # one launch of the product = a pair of batches
     geo = eng.geometry(pts)
     _, (known, idx, weight) = eng._backbone(pts, geo, fuse_tail=True)
     tw = eng.rpn_tail
@@ -209,14 +223,14 @@ def roofline_rpn_tail(dev, cfg, model, reps=20):
     table = (G if lin else known).numel() * 4
     alg_bytes = table + rows * 24 + rows * (128 + 1 + tw["n_reg"]) * 4
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": PMC_TRAFFIC.get("rpn_tail_lin_kernel" if lin else "rpn_tail_kernel"),
+            "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": PMC_TRAFFIC.get(B, {}).get("rpn_tail_lin_kernel" if lin else "rpn_tail_kernel"),
             "traffic_source": PMC_SOURCE,
             "kernel": "%s (prcnn_rpn_tail%s): the largest single launch on the FEATURE stream (the longest launch of "
                       "the step overall is the sampling kernel on a side stream: see roofline_longest)" % (
                           "rpn_tail_lin_kernel" if lin else "rpn_tail_kernel", "_lin" if lin else ""),
             "launch_ms": round(ms, 4), "algorithmic_flops_per_launch": flops, "padded_flops_per_launch": padded_flops,
             "algorithmic_bytes_per_launch": alg_bytes,
-            "shape": {"points": rows, "coarse_points": known.shape[0] * known.shape[1],
+            "shape": {"scenes_per_launch": B, "points": rows, "coarse_points": known.shape[0] * known.shape[1],
                       "layers": ("interp(128) | 128-128 | 128-128-1 | 128-128-%d" if lin else "256-128-128 | 128-128-1 | 128-128-%d") % tw["n_reg"]}}
 
 
@@ -233,12 +247,13 @@ def roofline_roipool(dev, cfg, model, reps=20):
     F = importlib.import_module(PKG + ".net.fast_infer")
     synth = importlib.import_module(PKG + ".synth")
     eng = F.FastPointRCNN(model, cfg)
-    pts = torch.from_numpy(synth.scenes(BATCH, NPOINTS, seed0=2000)).to(dev)
+    LB = launch_scenes()                    # one launch of the product = a pair of batches
+    pts = torch.from_numpy(synth.scenes(LB, NPOINTS, seed0=2000)).to(dev)
     st = eng.rpn_stage(pts)
     rois, _ = eng.propose(st)
     feats, mask = st["rpn_features"], st["seg_result"].contiguous()
     depth = (st["pts_depth"] / 70.0 - 0.5).contiguous()
-    B, M, S, C = BATCH, rois.shape[1], cfg.RCNN.NUM_POINTS, feats.shape[2]
+    B, M, S, C = LB, rois.shape[1], cfg.RCNN.NUM_POINTS, feats.shape[2]
     pooled = torch.empty((B, M, S, 8 + C), device=dev)
     empty = torch.empty((B, M), dtype=torch.int32, device=dev)
     cnt = torch.empty((B, M), dtype=torch.int32, device=dev)
@@ -262,7 +277,7 @@ def roofline_roipool(dev, cfg, model, reps=20):
               + full_rows * (8 + C) * 4 + (B * M * S - full_rows) * 32 + B * M * S * 12)
     achieved = nbytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": PMC_TRAFFIC.get("roipool3d_canonical_kernel"), "traffic_source": PMC_SOURCE,
+            "traffic": PMC_TRAFFIC.get(B, {}).get("roipool3d_canonical_kernel"), "traffic_source": PMC_SOURCE,
             "kernel": "roipool3d_canonical_kernel (prcnn_roipool3d_canonical, product form)", "launch_ms": round(ms, 4),
             "algorithmic_bytes_per_launch": nbytes, "mean_points_per_roi": round(float(cnt.float().mean()), 1),
             "shape": {"B": B, "N": NPOINTS, "rois": M, "sampled": S, "row_floats": 8 + C}}

@@ -3,12 +3,13 @@ layer kernels, whose grid is (row tiles, N / 128, problems) -- nothing else is k
 engine's shapes.  usage: python profiles/mfma_launch_shapes.py <kernel_trace.csv>"""
 import collections
 import csv
+import os
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 half = rows[len(rows) // 2:]
-steps = max(1, sum(1 for r in half if "rpn_tail" in r["Kernel_Name"]))
+steps = max(1, int(os.environ.get("PRCNN_PAIR", "2")) * sum(1 for r in half if "rpn_tail" in r["Kernel_Name"]))    # a tail launch = PRCNN_PAIR batches
 by = collections.defaultdict(lambda: [0, 0.0])
 for r in half:
     name = r["Kernel_Name"]

@@ -1,4 +1,5 @@
-"""Single-stream run of the product step (engine forward + final stage on one batch of 8 scenes) for rocprofv3 --pmc passes:
+"""Single-stream run of the product step (engine forward + final stage on one LAUNCH of the graphed runner: PRCNN_PAIR = 2 batches of 8 scenes
+since the second session of round 4; argv[2] = scenes) for rocprofv3 --pmc passes:
 counter collection serialises dispatches, so the multi-stream pipeline of bench.py is not used here; the kernels and
 their arguments are the same.  usage: rocprofv3 --pmc FETCH_SIZE --kernel-trace ... -- python profiles/pmc_step_probe.py"""
 import importlib, os, sys
@@ -12,7 +13,8 @@ dev = torch.device("cuda:0")
 cfg = C.default_eval_cfg()
 model = E.build_model(cfg, dev, seed=0)
 eng = F.FastPointRCNN(model, cfg)
-pts = torch.from_numpy(S.scenes(8, 16384, seed0=0)).to(dev)
+NSC = int(sys.argv[2]) if len(sys.argv) > 2 else 8 * max(1, E.RCNN_PAIR)
+pts = torch.from_numpy(S.scenes(NSC, 16384, seed0=0)).to(dev)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     det = E.infer_batch(model, cfg, pts, engine=eng)
 torch.cuda.synchronize()

@@ -27,13 +27,16 @@ for r in sel:
     stream[r.get("Stream_Id", "?")] += d
     e = per_stream[r.get("Stream_Id", "?")][r["Kernel_Name"].replace("void ", "").replace("prcnn::", "").split("(")[0][:60]]
     e[0] += 1; e[1] += d
-steps = max(1, sum(1 for r in sel if STEP_KERNEL in r["Kernel_Name"]))
+# (second session of round 4: PAIRS of batches share a launch of every stage behind the geometry -- one tail launch = PRCNN_PAIR steps)
+import os
+PAIR = int(os.environ.get("PRCNN_PAIR", "2"))
+steps = max(1, PAIR * sum(1 for r in sel if STEP_KERNEL in r["Kernel_Name"]))
 print("# %s\n" % sys.argv[2])
-print("Window between SA1 FPS launches (whole geometry groups) = %d steps (batches of 8 scenes).  PER STEP: wall "
-      "%.2f ms under the profiler (the profiler makes the run host-bound; unprofiled step time is in the bench line), sum of "
-      "kernel durations %.2f ms, %.0f launches; busy time per stream: %s.\n"
-      % (steps, wall / 1e3 / steps, sum(v[1] for v in by.values()) / 1e3 / steps, len(sel) / steps,
-         ", ".join("stream %s %.2f ms" % (k, v / 1e3 / steps) for k, v in sorted(stream.items()))))
+head = ("Window between SA1 FPS launches (whole geometry groups) = %%d steps (batches of 8 scenes; %d batches per launch of the stages "
+        "behind the geometry).  PER STEP: wall %%.2f ms under the profiler (the profiler makes the run host-bound; unprofiled step time is "
+        "in the bench line), sum of kernel durations %%.2f ms, %%.0f launches; busy time per stream: %%s.\n" % PAIR)
+print(head % (steps, wall / 1e3 / steps, sum(v[1] for v in by.values()) / 1e3 / steps, len(sel) / steps,
+              ", ".join("stream %s %.2f ms" % (k, v / 1e3 / steps) for k, v in sorted(stream.items()))))
 print("| kernel | calls per step | total us per step | avg us per call |\n|---|---|---|---|")
 for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])[:50]:
     print("| `%s` | %.2f | %.1f | %.1f |" % (k, v[0] / steps, v[1] / steps, v[1] / v[0]))
