@@ -672,7 +672,10 @@ def main():
                    "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith("PRCNN_")},
                    "batch_slots": n_slots, "look_ahead": E.PipelinedRunner.default_depth(),
                    "hip_graphs": ({"captured": shared_runner["runner"].captures, "group_slots": shared_runner["runner"].n_slots}
-                                  if getattr(shared_runner.get("runner"), "captures", 0) else None)},
+                                  if getattr(shared_runner.get("runner"), "captures", 0) else None),
+                   # the graphed runner launches every stage behind the geometry once per PAIR of consecutive steps (16 scenes, 1600 RoIs
+                   # per launch): K steps = K batches of 8 scenes all the same, each batch's detections handed back separately
+                   "steps_per_launch": getattr(shared_runner.get("runner"), "pair", 1)},
     }
     if rank == 0:
         if not args.no_roofline:

@@ -58,6 +58,41 @@ def test_graph_replay_equals_eager_enqueue(scene):
     assert graphed.captures == graphed.n_slots * (1 + 4 * (graphed.group // graphed.pair))          # nothing was captured again
 
 
+def test_paired_members_when_the_caller_changes_its_mind():
+    """Pairs of batches share a launch (GraphedRunner.pair = 2).  A pair the caller leaves half filled -- an announced batch that is
+    never submitted, an odd count, a run that ends on a first half -- runs with an earlier pass's clouds in its other half; the batches
+    that WERE submitted come back in submit order with the eager runner's bits, nothing else comes back."""
+    C = importlib.import_module(PKG + ".config"); E = importlib.import_module(PKG + ".eval_rcnn"); S = importlib.import_module(PKG + ".synth")
+    dev = torch.device("cuda", 0)
+    cfg = C.default_eval_cfg()
+    model = E.build_model(cfg, dev, seed=1)
+    bs = [torch.from_numpy(S.scenes(4, 16384, seed0=700 + 4 * s)).to(dev) for s in range(9)]
+    graphed = E.GraphedRunner(model, cfg, dev)
+    assert graphed.pair == 2
+    eager = E.PipelinedRunner(model, cfg, dev)
+    # announce 0..8, but submit 0, 1, 2, 4 (3 is skipped: the pair (2, 3) stays half filled), 5, 6, 7 and end on 8 (a first half)
+    order = [0, 1, 2, 4, 5, 6, 7, 8]
+    outs = []
+
+    def take(det):
+        if det is not None:
+            with torch.cuda.stream(det["stream"]):
+                outs.append({k: det[k].clone() for k in KEYS})
+    for n, i in enumerate(order):
+        take(graphed.submit(bs[i], bs[i + 1:i + 7]))
+    while True:
+        det = graphed.flush()
+        if det is None:
+            break
+        take(det)
+    torch.cuda.synchronize()
+    want = _run(eager, [bs[i] for i in order], eager.depth)
+    assert len(outs) == len(order) == len(want)
+    for n, (g, w) in enumerate(zip(outs, want)):
+        for k in KEYS:
+            assert torch.equal(g[k], w[k]), "submit %d (batch %d): %s" % (n, order[n], k)
+
+
 def test_scratch_of_a_captured_graph_stays_where_it_is():
     """the C library's per-stream scratch: a larger request on a stream whose graphs point to the old buffer gets a new buffer (the graph
     still replays correctly afterwards), and a request that would have to allocate DURING a capture fails loudly"""
