@@ -20,7 +20,7 @@ def morton_order(p):
     code = part(gx) | (part(gz) << 1)
     return np.argsort(code, kind='stable')
 
-def simulate(p, m, layout, PPT=16, top=2, rmax=16, stats=None, W=16):
+def simulate(p, m, layout, PPT=16, top=2, rmax=16, stats=None, W=16, greedy=False):
     n = p.shape[0]
     order = morton_order(p)
     # slot index array [w][i][lane] -> position s in Morton order
@@ -58,6 +58,28 @@ def simulate(p, m, layout, PPT=16, top=2, rmax=16, stats=None, W=16):
                 ents.append((lane_best[w, l], idx[w, lane_arg[w, l], l], w))
         ents.sort(key=lambda e: (-e[0], e[1]))
         gB = wB.max()
+        if greedy:
+            # the exact sequential selection over the PUBLISHED entries with their values updated by the pivots accepted so far: the best
+            # remaining entry is the true next pick as long as its updated value is strictly above the bound of everything unpublished
+            E = np.array([p[e[1]] for e in ents], np.float32)
+            val = np.array([e[0] for e in ents], np.float32)
+            key = np.array([e[1] for e in ents])
+            alive = np.ones(len(ents), bool)
+            acc, reason = [], 'rmax'
+            while True:
+                if len(acc) >= min(rmax, m - j): reason = 'rmax' if len(acc) >= rmax else 'end'; break
+                cand = np.where(alive)[0]
+                if len(cand) == 0: reason = 'entries'; break
+                b = cand[np.lexsort((key[cand], -val[cand]))[0]]
+                if acc and not (val[b] > gB): reason = 'bound'; break
+                acc.append(ents[b]); alive[b] = False
+                d = ((E - E[b]) ** 2).sum(-1).astype(np.float32)
+                val = np.minimum(val, d)
+            why[reason] = why.get(reason, 0) + 1
+            hist[len(acc)] += 1
+            for a in acc: upd(p[a[1]].astype(np.float32))
+            j += len(acc); rounds += 1
+            continue
         acc = [ents[0]]
         reason = 'rmax'
         for e in ents[1:]:
@@ -82,6 +104,11 @@ if __name__ == '__main__':
     kind = sys.argv[1]; m = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     make = S.lidar_scenes if kind == 'lidar' else S.scenes
     pts = make(2, 16384, seed0=0)
+    if len(sys.argv) > 3 and sys.argv[3] == 'greedy':      # the merge as an exact greedy selection over the published entries (not built)
+        for g in (False, True):
+            r, h, why = simulate(pts[0][:, :3], m, 'blocked', top=2, greedy=g)
+            print(kind, 'blocked', 'greedy' if g else 'prefix', 'rounds', r, 'picks/round %.2f' % ((m - 1) / r), why, 'hist', h.tolist(), flush=True)
+        sys.exit(0)
     for layout in ('blocked', 'quad', 'interleaved'):
         for top in (2,):
             r, h, why = simulate(pts[0][:, :3], m, layout, top=top)
