@@ -68,7 +68,7 @@ def test_paired_members_when_the_caller_changes_its_mind():
     model = E.build_model(cfg, dev, seed=1)
     bs = [torch.from_numpy(S.scenes(4, 16384, seed0=700 + 4 * s)).to(dev) for s in range(9)]
     graphed = E.GraphedRunner(model, cfg, dev)
-    assert graphed.pair == 2
+    assert graphed.pair == E.RCNN_PAIR                       # (2 by default; the scenario holds for PRCNN_PAIR=1 / 4 as well)
     eager = E.PipelinedRunner(model, cfg, dev)
     # announce 0..8, but submit 0, 1, 2, 4 (3 is skipped: the pair (2, 3) stays half filled), 5, 6, 7 and end on 8 (a first half)
     order = [0, 1, 2, 4, 5, 6, 7, 8]
