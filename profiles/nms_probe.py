@@ -1,5 +1,7 @@
-import importlib, sys, time, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+"""The reference's blocking NMS entries (iou3d_cuda.nms_gpu / nms_normal_gpu: mask kernel + resolve kernel + D2H of the keep list) alone, on
+boxes that (almost) all survive -- the resolve's worst case: every row is walked.  usage: python profiles/nms_probe.py"""
+import importlib, os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("3d_adapt_auto_driving_amd"); sys.path.insert(0, pkg.DROPIN_DIR)
 import iou3d_cuda as I
 dev = torch.device("cuda:0"); rng = np.random.default_rng(0)
