@@ -12,6 +12,10 @@ default.yaml shapes) per GPU -- BASELINE.json configs[2]; inputs are resident in
 timed region.  Scenes shard one batch per rank (weak scaling); the only collective is the final
 all_gather of the padded detection tables, inside the timed region.
 
+Launch granularity: the geometry of 4 consecutive steps shares one chain of launches (32 clouds), and since the second session of round 4
+every stage behind the geometry is launched once per PAIR of consecutive steps (16 scenes, 1600 RoIs: eval_rcnn.GraphedRunner.pair,
+`config.steps_per_launch`); each step's batch of 8 scenes still gets its own detections, all K of them inside the closed timed region.
+
 The SA levels run over the DISTINCT grouped rows only (csrc/sa_packed.hip: the reference's ball query back-fills a ball
 with copies of its first hit and RoI pooling fills a box with copies of its points; copies do not change a max-pool, the
 results are bit-identical -- tests/test_gpu_shadow.py).  How much that saves depends on the data: `config.distinct_rows`
