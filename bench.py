@@ -475,7 +475,7 @@ def main():
 
     shared_runner = {}
 
-    def timed_run(steps, warmup, batches=batches, fresh=False):
+    def timed_run(steps, warmup, batches=batches, fresh=False, keep_gc_off=False):
         """W untimed + K timed steps of the pipelined runner; returns the elapsed time of the K steps and their detections"""
         # point-major engine + geometry chains on side streams; E.make_runner: the stages replayed as hipGraphs (captured once, at the
         # runner's first batch = during the set-up run below: graphs are part of the engine like the folded weights) unless PRCNN_GRAPHS=0.
@@ -540,17 +540,24 @@ def main():
                 out_next[0] += 1
             assert not lagged or out_next[0] == last + 1, "detections of %d batches came back, %d were submitted" % (out_next[0], last + 1)
 
-        for i in range(warmup):
-            step(i, warmup)
-        if warmup:
-            drain(warmup - 1)                  # the pipeline is empty when timing starts ...
-        assert not getattr(runner, "_chains", None), "a geometry chain of a timed batch was started during the warm-up"
-        torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
+        # host housekeeping BEFORE the warm-up steps, not between them and the clock: a full collection takes tens of milliseconds, the GPU
+        # falls back to its idle clocks meanwhile, and the ramp back up landed inside the timed region -- one K = 20 run in eight came out
+        # 5-25 % low while the K = 100 loop of the same process did not move (second session of round 4)
         import gc
         gc.collect()
         gc.disable()                           # a generational collection inside a 70 ms timed region costs several percent
+        try:
+            for i in range(warmup):
+                step(i, warmup)
+            if warmup:
+                drain(warmup - 1)              # the pipeline is empty when timing starts ...
+            assert not getattr(runner, "_chains", None), "a geometry chain of a timed batch was started during the warm-up"
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+        except BaseException:
+            gc.enable()
+            raise
         allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
         try:
             t0 = time.perf_counter()
@@ -559,7 +566,8 @@ def main():
             drain(total - 1)                   # ... and drained inside the timed region: exactly K full batches
             torch.cuda.synchronize()
         finally:
-            gc.enable()
+            if not keep_gc_off:                # (the headline run: the caller's exchange step belongs to the timed region as well)
+                gc.enable()
         timed_run.device_allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0
         return t0, [(host_boxes[i], host_scores[i], host_num[i]) for i in range(warmup, total)]
 
@@ -572,7 +580,7 @@ def main():
     # steady state needs (every hipMalloc inside a step stalls the device) and HIP has loaded every code object
     if args.prewarm > 0:
         timed_run(args.prewarm, 0)
-    t0, dets = timed_run(args.steps, args.warmup)
+    t0, dets = timed_run(args.steps, args.warmup, keep_gc_off=True)
     allocs_main = getattr(timed_run, "device_allocs", None)     # hipMalloc calls inside the timed region (each one stalls the device)
     # the one exchange of the job: padded detection tables of this rank's scenes
     ids = list(range(rank * args.steps * BATCH, (rank + 1) * args.steps * BATCH))
@@ -581,6 +589,8 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    import gc
+    gc.enable()
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
