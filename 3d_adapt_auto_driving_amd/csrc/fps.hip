@@ -810,8 +810,28 @@ extern "C" int prcnn_set_fps_arithmetic(int mode)
     return PRCNN_OK;
 }
 
-// new_xyz != NULL (prcnn_fps_new_xyz): only the shapes whose kernels write the coordinates themselves -- the speculative kernel
-// (2048 < n <= 16384, m >= 256) -- come through here with it; temp may then be NULL
+namespace prcnn {
+__global__ __launch_bounds__(256) void fps_fill_kernel(long count, float v, float *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) out[i] = v;
+}
+__global__ __launch_bounds__(256) void fps_gather_xyz_kernel(int n, int m, const float *__restrict__ xyz, const int *__restrict__ idx,
+                                                             float *__restrict__ new_xyz)
+{
+    const int chunks = (m + 255) / 256;
+    const int b = blockIdx.x / chunks, j = (blockIdx.x % chunks) * 256 + threadIdx.x;
+    if (j >= m) return;
+    const float *p = xyz + ((long)b * n + idx[(long)b * m + j]) * 3;
+    float *o = new_xyz + ((long)b * m + j) * 3;
+    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+}
+}  // namespace prcnn
+
+// new_xyz != NULL (prcnn_fps_new_xyz; temp may then be NULL): the speculative kernel (2048 < n <= 16384, m >= 256) writes the
+// coordinates itself; every other route (PRCNN_FPS_SEQUENTIAL / PRCNN_FPS_NO_PRUNE, few samples, n > 16384) runs its kernel over an
+// internal distance scratch filled with the reference caller's 1e10 and gathers the coordinates behind it -- same indices, same
+// coordinates, two small launches more (round 5; ADVICE r4: those routes used to refuse)
 static int fps_any(int b, int n, int m, const float *xyz, float *temp, int *idx, float *new_xyz, void *stream)
 {
     PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "fps: bad sizes b=%d n=%d m=%d", b, n, m);
@@ -834,7 +854,18 @@ static int fps_any(int b, int n, int m, const float *xyz, float *temp, int *idx,
     // off when the sample count is large enough for the pruning radius to shrink.
     static const bool no_prune = getenv("PRCNN_FPS_NO_PRUNE") != nullptr;
     static const bool sequential = getenv("PRCNN_FPS_SEQUENTIAL") != nullptr;          // A/B: one pick per exchange (round 3)
-    PRCNN_REQUIRE(!new_xyz || (!no_prune && !sequential && n > 2048 && n <= 16384 && m >= 256), "fps_new_xyz: shape n=%d m=%d not served", n, m);
+    const bool writes_xyz = !no_prune && !sequential && n > 2048 && n <= 16384 && m >= 256;
+    if (new_xyz && !writes_xyz) {
+        if (!temp) {
+            temp = (float *)scratch_for(st, (size_t)b * n * sizeof(float), 12);
+            if (!temp) { set_error("fps_new_xyz: cannot allocate the distance scratch"); return PRCNN_ELAUNCH; }
+            hipLaunchKernelGGL(fps_fill_kernel, dim3((unsigned)(((long)b * n + 255) / 256)), dim3(256), 0, st, (long)b * n, 1e10f, temp);
+        }
+        const int rc = fps_any(b, n, m, xyz, temp, idx, nullptr, stream);
+        if (rc != PRCNN_OK) return rc;
+        hipLaunchKernelGGL(fps_gather_xyz_kernel, dim3((unsigned)((long)((m + 255) / 256) * b)), dim3(256), 0, st, n, m, xyz, idx, new_xyz);
+        return check_launch("fps_new_xyz(gather)");
+    }
     if (!no_prune && n > 2048 && n <= 16384 && m >= 256) {
         int *perm = (int *)scratch_for(st, (size_t)b * n * sizeof(int), 1);
         if (!perm) { set_error("fps: cannot allocate ordering scratch"); return PRCNN_ELAUNCH; }

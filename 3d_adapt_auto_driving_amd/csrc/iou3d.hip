@@ -396,14 +396,22 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v)
 //   * waves 1-15 OR the kept rows' words b + 4 .. W - 1 into the bitmap in LDS TWO blocks behind wave 0: the loads of block b go out
 //     behind barrier b and are consumed behind barrier b + 2 (the barrier orders LDS only; the raw words wait in registers), so
 //     a block costs wave 0's walk, not a global round trip.
+//   * the words BEHIND that window (w >= b + NF_NEAR_END: there are none up to 8448 boxes) are not needed before block b + NF_NEAR_END; every
+//     64 blocks the whole workgroup ORs them in for the kept rows of the 64 blocks just resolved (a wave per block, lanes over the words:
+//     coalesced), from the kept words wave 0 left in LDS.  (Round 5: until then they were dropped -- keep lists too long beyond 8448 boxes.)
 // (Round 4, second session.  Before: per block a diagonal load, a 64-step walk, a barrier, every thread ORing its words, a barrier -- two
 // global round trips per block on the critical path: 394 us for 6300 proposals, 6.3 of the 63 ms the reference-order graph takes per batch.)
 constexpr int NF_FAST = 3;           // words of a block's rows that wave 0 handles itself (b + 1 .. b + NF_FAST)
+constexpr int NF_PASSES = 2;         // passes of 64 words that waves 1-15 keep in flight per block
+constexpr int NF_NEAR_END = 1 + NF_FAST + 64 * NF_PASSES;   // block b's words b + 1 .. b + NF_NEAR_END - 1 are handled inside the walk
+constexpr int NF_FAR_PERIOD = 64;    // the far words are ORed in every NF_FAR_PERIOD blocks (must be < NF_NEAR_END)
+static_assert(NF_FAR_PERIOD < NF_NEAR_END, "a far pass must run before its first word is read");
 __global__ __launch_bounds__(NF_RES_THREADS) void nms_full_resolve_kernel(
     int n, int W, const unsigned long long *__restrict__ mask, int *__restrict__ keep, int *__restrict__ num_keep)
 {
     __shared__ unsigned long long s_removed[NMS_MAX_N / 64];
     __shared__ unsigned long long s_kept[2];
+    __shared__ unsigned long long s_hist[NF_FAR_PERIOD];         // kept words of the last NF_FAR_PERIOD blocks (far pass)
     const int t = threadIdx.x, lane = t & 63;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);       // wave-uniform: the walk below runs on the scalar unit
     for (int i = t; i < W; i += NF_RES_THREADS) s_removed[i] = 0ull;
@@ -416,13 +424,34 @@ __global__ __launch_bounds__(NF_RES_THREADS) void nms_full_resolve_kernel(
             if (1 + f < W) nextw[f] = mask[(long)lane * W + 1 + f];
     }
     // waves 1-15: the raw words of the block before (newer) and of the block before that (older): 5 rows x 2 passes of 64 words
-    unsigned long long rawN[5][2], rawO[5][2];
+    unsigned long long rawN[5][NF_PASSES], rawO[5][NF_PASSES];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) { rawN[q][0] = rawN[q][1] = rawO[q][0] = rawO[q][1] = 0ull; }
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int k = 0; k < NF_PASSES; ++k) rawN[q][k] = rawO[q][k] = 0ull;
     __syncthreads();
+    const bool far_words = W > NF_NEAR_END;            // n > 8448
     int nk = 0;                                        // tracked by every thread (uniform)
     for (int b = 0; b < W; ++b) {
         const int r0 = b * 64, rows = min(64, n - r0);
+        if (far_words && b > 0 && b % NF_FAR_PERIOD == 0) {
+            // blocks b - 64 .. b - 1 are resolved: their kept rows' words w >= block + NF_NEAR_END go into the bitmap now (the earliest of
+            // them is read at block b - 64 + NF_NEAR_END > b)
+            for (int q = wv; q < NF_FAR_PERIOD; q += NF_RES_THREADS / 64) {
+                const int bb = b - NF_FAR_PERIOD + q;
+                unsigned long long kk = s_hist[q];
+                while (kk) {
+                    const int cl = __builtin_ctzll(kk);
+                    kk &= kk - 1ull;
+                    const unsigned long long *row = mask + (long)(bb * 64 + cl) * W;
+                    for (int w = bb + NF_NEAR_END + lane; w < W; w += 64) {
+                        const unsigned long long v = row[w];
+                        if (v) atomicOr(&s_removed[w], v);
+                    }
+                }
+            }
+            __syncthreads();
+        }
         if (wv == 0) {
             const unsigned long long valid = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
             // (the walk runs on the scalar unit: its state is made wave-uniform in SGPRs here)
@@ -445,7 +474,7 @@ __global__ __launch_bounds__(NF_RES_THREADS) void nms_full_resolve_kernel(
 #pragma unroll
             for (int f = 0; f < NF_FAST; ++f) carry[f] |= wave_or_u64(mine ? nextw[f] : 0ull);
             if ((kept >> lane) & 1ull) keep[nk + __popcll(kept & ((1ull << lane) - 1ull))] = r0 + lane;
-            if (lane == 0) s_kept[b & 1] = kept;
+            if (lane == 0) { s_kept[b & 1] = kept; s_hist[b % NF_FAR_PERIOD] = kept; }
             // the next block's words, for all of its rows: independent of every decision, fetched BEHIND this block's walk (in front of it the walk's first use of `diag` made the compiler wait for them as well)
             unsigned long long ndiag = 0ull, nnext[NF_FAST] = {0ull, 0ull, 0ull};
             const long row1 = (long)r0 + 64 + lane;
@@ -466,7 +495,7 @@ __global__ __launch_bounds__(NF_RES_THREADS) void nms_full_resolve_kernel(
             // consume what was fetched two blocks ago (block b - 2: words b + 2 .. ), then fetch this block's words b + 1 + NF_FAST ..
             if (b >= 2) {
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < NF_PASSES; ++k) {
                     const int w = (b - 2) + 1 + NF_FAST + lane + 64 * k;
                     unsigned long long acc = 0ull;
 #pragma unroll
@@ -475,9 +504,11 @@ __global__ __launch_bounds__(NF_RES_THREADS) void nms_full_resolve_kernel(
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 5; ++q) { rawO[q][0] = rawN[q][0]; rawO[q][1] = rawN[q][1]; }
+            for (int q = 0; q < 5; ++q)
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < NF_PASSES; ++k) rawO[q][k] = rawN[q][k];
+#pragma unroll
+            for (int k = 0; k < NF_PASSES; ++k) {
                 const int w = b + 1 + NF_FAST + lane + 64 * k;
 #pragma unroll
                 for (int q = 0; q < 5; ++q) {

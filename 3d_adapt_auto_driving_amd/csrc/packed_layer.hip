@@ -863,8 +863,10 @@ extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr
         const PLProblem &q = bt.p[0];
         const long items = tiles_of[0] * blocks_of[0];
         const long cap = stream_cap();
+        unsigned int *ticket = next_ticket(st);
+        if (!ticket) { set_error("packed_layer: cannot set up the item ticket"); return PRCNN_ELAUNCH; }
         hipLaunchKernelGGL(packed_layer_persist_kernel<false>, dim3((unsigned)(items < cap ? items : cap)), dim3(256), 0, st, q.rows_host, q.K, q.N,
-                           q.A, q.lda, q.W, q.bias, q.do_relu, q.out, q.ldo, next_ticket(st), PLProblem{});
+                           q.A, q.lda, q.W, q.bias, q.do_relu, q.out, q.ldo, ticket, PLProblem{});
         return check_launch("packed_layer");
     }
     bool together = cls[0] != PL_STREAM;
@@ -969,8 +971,10 @@ extern "C" int prcnn_packed_layer_interp(long rows, int K, int N, const float *A
     }
     if (persist && K >= 256 && pipe_enabled() && items > stream_cap() && items >= persist_min()) {
         const long cap = stream_cap();
+        unsigned int *ticket = next_ticket(st);
+        if (!ticket) { set_error("packed_layer_interp: cannot set up the item ticket"); return PRCNN_ELAUNCH; }
         hipLaunchKernelGGL(packed_layer_persist_kernel<true>, dim3((unsigned)(items < cap ? items : cap)), dim3(256), 0, st, rows, K, N, A, lda,
-                           W, bias, relu, out, ldo, next_ticket(st), bt.p[0]);
+                           W, bias, relu, out, ldo, ticket, bt.p[0]);
         return check_launch("packed_layer_interp");
     }
     auto kern = (K >= 256 && pipe_enabled()) ? packed_layer_pipe_kernel<false> : packed_layer_kernel<false>;

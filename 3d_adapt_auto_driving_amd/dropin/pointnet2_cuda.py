@@ -38,8 +38,10 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
 
 
 def fps_new_xyz_supported(n, m):
-    """shapes prcnn_fps_new_xyz serves: many small clouds, or the speculative kernel's range"""
-    return n <= 1024 or (2048 < n <= 16384 and m >= 256)
+    """prcnn_fps_new_xyz serves every shape since round 5 (one launch for n <= 1024 and in the speculative kernel's range
+    2048 < n <= 16384, m >= 256; elsewhere -- and under PRCNN_FPS_SEQUENTIAL / PRCNN_FPS_NO_PRUNE -- FPS over an internal
+    distance scratch + a gather launch inside the library)."""
+    return True
 
 
 def ball_query_full_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):

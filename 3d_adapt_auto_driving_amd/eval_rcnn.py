@@ -467,6 +467,16 @@ class PipelinedRunner:
         self._retired = []
         return det
 
+    def drain(self):
+        """flush() until the pipeline is empty: the detections of every batch not handed back yet, oldest first (probes and
+        timing loops call this in front of a synchronize -- ONE flush() leaves up to two batches' RCNN + final stages unlaunched)."""
+        out = []
+        while True:
+            det = self.flush()
+            if det is None:
+                return out
+            out.append(det)
+
 
 USE_GRAPHS = os.environ.get("PRCNN_GRAPHS", "1") != "0"                   # hipGraph replay of the stages (GraphedRunner); 0: eager enqueue (PipelinedRunner)
 
@@ -559,6 +569,16 @@ class ModuleRunner:
     def flush(self):
         done, self._pending = self._pending, None
         return done
+
+    def drain(self):
+        """flush() until the pipeline is empty: the detections of every batch not handed back yet, oldest first (probes and
+        timing loops call this in front of a synchronize -- ONE flush() leaves up to two batches' RCNN + final stages unlaunched)."""
+        out = []
+        while True:
+            det = self.flush()
+            if det is None:
+                return out
+            out.append(det)
 
     def _infer(self, cur):
         return infer_batch(self.model, self.cfg, cur)
@@ -937,6 +957,16 @@ class GraphedRunner:
             while self._inflights and not self._out:
                 self._finish_inflight()
         return self._out.popleft() if self._out else None
+
+    def drain(self):
+        """flush() until the pipeline is empty: the detections of every batch not handed back yet, oldest first (probes and
+        timing loops call this in front of a synchronize -- ONE flush() leaves up to two batches' RCNN + final stages unlaunched)."""
+        out = []
+        while True:
+            det = self.flush()
+            if det is None:
+                return out
+            out.append(det)
 
 
 def _tensors(obj):

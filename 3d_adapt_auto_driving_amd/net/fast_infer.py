@@ -1063,6 +1063,10 @@ class FastPointRCNN:
         # the levels that pool through atomicMax (packed rows) want zeroed outputs: ONE fill for all of them -- made with the geometry
         # (80 MB per batch of 800 RoIs: 16 us that the proposal stream has to spare and the feature stream has not)
         shapes, arena = rg["arena_shapes"], rg["arena"]
+        if arena is not None:
+            if rg.get("arena_used"):           # a second pass over the same geometry (another set of weights, a probe): the atomicMax pools
+                arena.zero_()                  # must not start from the first pass's maxima -- the first pass stays fill-free
+            rg["arena_used"] = True
         offs = [sum(shapes[:k]) for k in range(len(shapes))]
         for k, ((npoint, radius, ns, mlp, cin), lev) in enumerate(zip(self.rcnn_sa, rg["levels"])):
             cur_xyz, cur_feat = lev["xyz"], l_feat[-1]

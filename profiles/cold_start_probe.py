@@ -19,7 +19,7 @@ def run(K, log):
     wrap(eng, "rpn_stage", "rpn"); wrap(eng, "rcnn_features", "rcnn"); wrap(eng, "rcnn_geometry", "rcnn_geo"); wrap(eng, "geometry_group", "geo")
     for i in range(K):
         runner.submit(batches[i % 10], [batches[(i + d) % 10] for d in range(1, runner.depth + 1) if i + d < K])
-    runner.flush()
+    runner.drain()
 for rep in range(3):
     log = []
     torch.cuda.synchronize()

@@ -18,7 +18,7 @@ runner = E.PipelinedRunner(model, cfg, dev)
 def loop(n):
     for i in range(n):
         runner.submit(batches[i % 10], [batches[(i + k) % 10] for k in range(1, runner.depth + 1)])
-    runner.flush()
+    runner.drain()
 loop(10); torch.cuda.synchronize(); t0 = time.perf_counter(); loop(40); torch.cuda.synchronize()
 print("dense scenes (scale %.3f): %.1f scenes/s" % (scale, 40 * 8 / (time.perf_counter() - t0)))
 # packed vs all-rows engines on the dense batch: the network outputs before any discrete decision

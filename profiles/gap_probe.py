@@ -40,7 +40,7 @@ if os.environ.get("GAP_NO_FINAL") == "1":
 def loop(n):
     for i in range(n):
         runner.submit(batches[i % 6], [batches[(i + d) % 6] for d in range(1, runner.depth + 1)])
-    runner.flush()
+    runner.drain()
 loop(10); torch.cuda.synchronize(); log.clear()
 origin = torch.cuda.Event(enable_timing=True); origin.record(main); t_origin = time.perf_counter()
 loop(24); torch.cuda.synchronize()

@@ -16,7 +16,7 @@ def loop(n):
         if det is not None:
             pend.append(det["ready"])
             if len(pend) > 3: pend.popleft().synchronize()        # the host consumes results 3 batches late, like bench.py
-    runner.flush()
+    runner.drain()
 loop(24); torch.cuda.synchronize()
 K = 100
 t0 = time.perf_counter(); loop(K); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
@@ -25,7 +25,7 @@ print("with the 3-batch result lag: loop %.3f ms/step (host enqueue + waits for 
 def loop_free(n):
     for i in range(n):
         runner.submit(batches[i % NB], [batches[(i + d) % NB] for d in range(1, runner.depth + 1) if i + d < n])
-    runner.flush()
+    runner.drain()
 torch.cuda.synchronize()
 t0 = time.perf_counter(); loop_free(40); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print("free-running: host enqueue %.3f ms/step, wall %.3f ms/step" % ((t1 - t0) / 40 * 1e3, (t2 - t0) / 40 * 1e3))

@@ -16,7 +16,7 @@ def loop(n):
         if det is not None:
             pend.append(det["ready"])
             if len(pend) > 3: pend.popleft().synchronize()
-    runner.flush(); torch.cuda.synchronize()
+    runner.drain(); torch.cuda.synchronize()
 loop(40)
 pr = cProfile.Profile(); pr.enable(); loop(N); pr.disable()
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(30); print(s.getvalue()[:7000])

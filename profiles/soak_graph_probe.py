@@ -38,7 +38,7 @@ for i in range(N):
             check(*pend.popleft())
     if (i + 1) % 200 == 0:
         torch.cuda.synchronize(); t1 = time.perf_counter(); t_block.append((t1 - t0) / 200 * 1e3); t0 = t1
-det = runner.flush()
+runner.drain()
 while pend:
     check(*pend.popleft())
 print("steps %d, repeats that differ: %d, ms per step in blocks of 200: %s" % (N, bad, ["%.3f" % t for t in t_block]))

@@ -19,7 +19,7 @@ for i in range(N):
         if len(pend) > 3: pend.popleft().synchronize()
     if i % 50 == 49:
         torch.cuda.synchronize(); t_marks.append(time.perf_counter())
-runner.flush(); torch.cuda.synchronize()
+runner.drain(); torch.cuda.synchronize()
 prev = t0
 for k, t in enumerate(t_marks):
     print("steps %3d-%3d: %.3f ms/step" % (50 * k, 50 * k + 49, (t - prev) / 50 * 1e3)); prev = t

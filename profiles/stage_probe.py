@@ -31,7 +31,7 @@ wrap(eng, "geometry_begin", "geo_begin"); wrap(eng, "geometry_finish", "geo_fini
 def loop(n):
     for i in range(n):
         runner.submit(batches[i % NB], [batches[(i + d) % NB] for d in range(1, runner.depth + 1)])
-    runner.flush()
+    runner.drain()
 loop(16); torch.cuda.synchronize(); log.clear()
 origin.record(torch.cuda.current_stream(dev))
 K = 24

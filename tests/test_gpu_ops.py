@@ -125,6 +125,41 @@ def test_fps_with_coordinates_output(ext, oracle, n, m):
     assert np.array_equal(new_xyz.cpu().numpy(), np.take_along_axis(xyz, want[:, :, None].astype(np.int64), axis=1))
 
 
+@pytest.mark.parametrize("b,n,m", [(3, 16384, 4096), (2, 4096, 1024), (2, 16384, 100), (3, 2000, 300), (2, 1500, 64), (1, 32768, 8192), (2, 20000, 50)])
+def test_fps_with_coordinates_output_every_shape(ext, oracle, b, n, m):
+    """prcnn_fps_new_xyz beyond the small-cloud range: the speculative kernel writes the coordinates itself, every other shape
+    (few samples, n > 16384: double.yaml's 32768 points) runs over an internal distance scratch + a gather (round 5)."""
+    xyz = np.random.default_rng(n + m).uniform(-20, 20, (b, n, 3)).astype(np.float32)
+    idx, new_xyz = ext.pointnet2.fps_new_xyz_wrapper(T(xyz), m)
+    want = oracle.furthest_point_sample(xyz, m)
+    assert np.array_equal(idx.cpu().numpy(), want)
+    assert np.array_equal(new_xyz.cpu().numpy(), np.take_along_axis(xyz, want[:, :, None].astype(np.int64), axis=1))
+
+
+@pytest.mark.parametrize("switch", ["PRCNN_FPS_SEQUENTIAL", "PRCNN_FPS_NO_PRUNE"])
+def test_fps_with_coordinates_output_under_the_ab_switches(switch):
+    """with either A/B switch set the engine's SA levels (fps_new_xyz on 16384 -> 4096 and 4096 -> 1024) raised
+    'shape not served'.  The switches are read once per process, hence the child process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, importlib, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from oracle import oracle as O\n"
+        "pkg = importlib.import_module('3d_adapt_auto_driving_amd'); sys.path.insert(0, pkg.DROPIN_DIR)\n"
+        "import pointnet2_cuda as P\n"
+        "for n, m in ((16384, 4096), (4096, 1024), (16384, 128)):\n"
+        "    xyz = np.random.default_rng(n).uniform(-20, 20, (2, n, 3)).astype(np.float32)\n"
+        "    idx, new = P.fps_new_xyz_wrapper(torch.from_numpy(xyz).cuda(), m)\n"
+        "    want = O.furthest_point_sample(xyz, m)\n"
+        "    assert np.array_equal(idx.cpu().numpy(), want)\n"
+        "    assert np.array_equal(new.cpu().numpy(), np.take_along_axis(xyz, want[:, :, None].astype(np.int64), axis=1))\n"
+        "print('ok')\n") % root
+    env = dict(os.environ); env[switch] = "1"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
 def test_ball_query_with_scan_limit_on_wrapped_clouds(ext, oracle):
     """Clouds filled the way RoI pooling fills a box holding fewer than 512 points (row k >= count is a copy of row
     k % count, roipool3d_kernel.cu:152-159; an empty box is all one point).  prcnn_ball_query_limit scans the first count
@@ -359,6 +394,42 @@ def test_nms_rotated(ext, oracle, n, thresh):
     keep = torch.zeros(n, dtype=torch.int64)
     k = ext.iou3d.nms_gpu(T(boxes), keep, thresh)
     want = oracle.nms(boxes, thresh)
+    assert k == len(want) and np.array_equal(keep[:k].numpy(), want)
+
+
+@pytest.mark.parametrize("rotated", [False, True])
+@pytest.mark.parametrize("n,thresh,spread", [(8449, 0.5, 40.0), (9000, 0.8, 25.0), (9000, 0.3, 60.0), (8512 + 64 * 64 + 1, 0.4, 70.0), (20000, 0.5, 80.0)])
+def test_nms_beyond_the_near_window(ext, oracle, n, thresh, spread, rotated):
+    """More than 8448 boxes (W > 132 mask words per row; iou3d.hip's header names 9000, the reference's RPN_PRE_NMS_TOP_N): a kept
+    row's words further than 131 blocks behind it are ORed in by the resolve kernel's far pass (they were dropped)."""
+    boxes = bev_boxes(np.random.default_rng(n + int(rotated)), n, spread=spread, rotated=rotated)
+    keep = torch.zeros(n, dtype=torch.int64)
+    k = (ext.iou3d.nms_gpu if rotated else ext.iou3d.nms_normal_gpu)(T(boxes), keep, thresh)
+    want = (oracle.nms if rotated else oracle.nms_normal)(boxes, thresh)
+    assert 0.05 * n < len(want) <= n - 50                           # both outcomes represented
+    assert k == len(want) and np.array_equal(keep[:k].numpy(), want)
+
+
+@pytest.mark.parametrize("rotated", [False, True])
+@pytest.mark.parametrize("gap", [8448 - 300, 8448, 8448 + 64 * 70, 30000])
+def test_nms_suppressed_only_by_a_far_row(ext, oracle, rotated, gap):
+    """300 disjoint boxes, ``gap`` disjoint fillers elsewhere, then copies of the first 300: each copy overlaps exactly one earlier box,
+    300 + gap rows in front of it -- it falls through the far words alone (or, for the smallest gap, through the near window)."""
+    rng = np.random.default_rng(gap)
+    gx, gz = np.meshgrid(np.arange(20) * 8.0, np.arange(15) * 8.0)
+    head = np.stack([gx.ravel() - 2, gz.ravel() - 1, gx.ravel() + 2, gz.ravel() + 1,
+                     rng.uniform(-3, 3, 300) if rotated else np.zeros(300)], 1)
+    side = int(np.ceil(np.sqrt(gap)))
+    fx, fz = np.meshgrid(1000.0 + np.arange(side) * 8.0, np.arange(side) * 8.0)
+    fill = np.stack([fx.ravel() - 2, fz.ravel() - 1, fx.ravel() + 2, fz.ravel() + 1, np.zeros(side * side)], 1)[:gap]
+    tail = head.copy(); tail[:, :4] += 0.05
+    tail = tail[rng.permutation(300)][:257]
+    boxes = np.concatenate([head, fill, tail], 0).astype(np.float32)
+    n = boxes.shape[0]
+    keep = torch.zeros(n, dtype=torch.int64)
+    k = (ext.iou3d.nms_gpu if rotated else ext.iou3d.nms_normal_gpu)(T(boxes), keep, 0.5)
+    want = (oracle.nms if rotated else oracle.nms_normal)(boxes, 0.5)
+    assert len(want) == 300 + gap
     assert k == len(want) and np.array_equal(keep[:k].numpy(), want)
 
 
