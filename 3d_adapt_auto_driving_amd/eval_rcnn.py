@@ -1171,7 +1171,8 @@ def pack_detections(scene_ids, det_batches, max_det):
 def all_gather_detections(table, counts, device):
     """The ONE collective of the job: all ranks exchange their padded detection tables
     (RCCL all_gather over xGMI when the backend is nccl; gloo in the CPU tests).  Tables are
-    padded to the largest per-rank scene count so that all_gather_into_tensor applies."""
+    padded to the largest per-rank scene count so that all_gather_into_tensor applies; the padding rows
+    (count -1) are stripped and the rows come back in scene-id order on every rank."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return table, counts
@@ -1189,7 +1190,11 @@ def all_gather_detections(table, counts, device):
     dist.all_gather_into_tensor(out_t, pad_t)
     dist.all_gather_into_tensor(out_c, pad_c)
     real = out_c >= 0
-    return out_t[real].cpu(), out_c[real].cpu()
+    out_t, out_c = out_t[real].cpu(), out_c[real].cpu()
+    # rank-major as gathered (r, r + W, ... per rank) -> scene-id order, the order of a single-process run: what rank 0 writes and
+    # scores does not depend on the world size (ids are exact in float32 up to 2^24 scenes)
+    order = torch.argsort(out_t[:, 0, 8], stable=True) if out_t.shape[0] and out_t.shape[1] else torch.arange(out_t.shape[0])
+    return out_t[order].contiguous(), out_c[order].contiguous()
 
 
 @torch.no_grad()

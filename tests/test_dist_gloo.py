@@ -1,4 +1,4 @@
-"""world_size-2 CPU test (gloo) of the multi-GPU path: scene sharding + the single all_gather of
+"""world_size-2 and world_size-8 CPU tests (gloo) of the multi-GPU path: scene sharding + the single all_gather of
 padded detection tables (eval_rcnn.shard_scene_ids / pack_detections / all_gather_detections).
 The same code runs over RCCL (backend "nccl") on the GPU node; only the backend string differs."""
 import os
@@ -67,6 +67,86 @@ def test_sharded_eval_all_gather_equals_single_process(tmp_path, oracle):
     assert np.array_equal(got["counts"][order], counts.numpy())
     np.testing.assert_allclose(got["table"][order], table.numpy(), rtol=0, atol=1e-6)
     assert counts.sum() > 0
+
+
+def _scene_table(ids, max_det=100):
+    """A detection table that regenerates from the scene ids alone (no model): box k of scene s = s + k / 128 + column / 1024,
+    score = 1 / (1 + k), count = s % (max_det + 1) -- enough to tell any misplaced, duplicated or truncated row."""
+    ids = np.asarray(ids, dtype=np.int64)
+    k = np.arange(max_det, dtype=np.float32)[None, :, None]
+    col = np.arange(7, dtype=np.float32)[None, None, :]
+    table = np.zeros((len(ids), max_det, 9), np.float32)
+    table[:, :, 0:7] = ids[:, None, None].astype(np.float32) + k / 128 + col / 1024
+    table[:, :, 7] = 1.0 / (1.0 + k[:, :, 0])
+    table[:, :, 8] = ids[:, None].astype(np.float32)
+    counts = (ids % (max_det + 1)).astype(np.int32)
+    return torch.from_numpy(table), torch.from_numpy(counts)
+
+
+def _gather8_worker(rank, world, port, n_scenes, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.set_num_threads(1)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from conftest import pkg
+        E = pkg("eval_rcnn")
+        mine = E.shard_scene_ids(n_scenes, rank, world)
+        table, counts = _scene_table(mine)
+        t, c = E.all_gather_detections(table, counts, torch.device("cpu"))
+        want_t, want_c = _scene_table(np.arange(n_scenes))
+        ok = (tuple(t.shape) == (n_scenes, 100, 9) and torch.equal(t, want_t) and torch.equal(c, want_c) and c.dtype == torch.int32)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, len(mine), bool(ok), tuple(t.shape)))
+    except Exception:
+        q.put((rank, -1, "ERR " + traceback.format_exc(), None))
+
+
+def test_world8_gather_of_the_kitti_val_split():
+    """BASELINE configs[3] at its real shard sizes, without a model: 3769 scenes (split/kitti/val.txt) over 8 ranks = 472 on ranks
+    0 .. 0 and 471 on the rest (r, r + 8, ...: pointrcnn/tools/batch_inference.py:95-107's split), one padded all_gather of
+    (472, 100, 9) tables -- EVERY rank ends up with all 3769 rows, each exactly once, in scene-id order, the -1 padding rows of
+    the seven shorter ranks stripped, counts int32."""
+    from conftest import pkg
+    E = pkg("eval_rcnn")
+    n, world = 3769, 8
+    sizes = [len(E.shard_scene_ids(n, r, world)) for r in range(world)]
+    assert sizes == [472] + [471] * 7 and sum(sizes) == n
+    assert sorted(i for r in range(world) for i in E.shard_scene_ids(n, r, world)) == list(range(n))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather8_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(60)
+    for rank, n_mine, ok, shape in res:
+        assert ok is True, (rank, ok, shape)
+        assert n_mine == sizes[rank]
+
+
+@pytest.mark.parametrize("ncores", [256, 128, 64])
+def test_host_budget_world8_slices(ncores):
+    """8 local ranks on a 256- / 128- / 64-core host: disjoint contiguous slices that cover the node, enqueue thread + loaders +
+    writers inside the slice (a 256-core host keeps the single-rank counts 16 + 6; a 128-core one gets 12 + 3; DESIGN.md section 8
+    prices what that does to the per-rank driver rate)."""
+    from conftest import pkg
+    E = pkg("eval_rcnn")
+    cores = list(range(ncores))
+    per = ncores // 8
+    seen = []
+    for r in range(8):
+        b = E.host_budget(world=8, local_rank=r, cores=cores)
+        assert b["cores"] == list(range(per * r, per * r + per))
+        assert b["loaders"] >= 1 and b["writers"] >= 1 and b["loaders"] + b["writers"] + 1 <= per
+        seen += b["cores"]
+    assert seen == cores
+    want = {256: (16, 6), 128: (12, 3), 64: (6, 1)}[ncores]
+    assert (b["loaders"], b["writers"]) == want
 
 
 def test_all_gather_is_identity_without_process_group():

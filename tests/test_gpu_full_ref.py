@@ -71,3 +71,49 @@ def test_reference_operation_order_over_the_reference_api_only(native):
     text = helpers.e2e_text(rep)
     print("g12u reference order, %s:\n%s" % ("compiled modules" if native else "ctypes modules", text))
     assert all(r[2] == 0 for r in rep), text
+
+
+def test_configs2_literal_batch_through_the_product_runner():
+    """VERDICT r4 'missing 2': BASELINE configs[2] at its LITERAL batch through the PRODUCT runner against reference-made data.
+    Fixture g12p = the reference PointRCNN on two batches of B = 8 (eight uniform scenes, eight LiDAR-shaped sweeps).  The same 16
+    scenes go through ``eval_rcnn.make_runner()`` = GraphedRunner with graph replay on, pairs of batches per launch (16 scenes /
+    1600 RoIs per stage launch: what bench.py times) -- twice, so that the second pass is pure REPLAY of the captured graphs -- and
+    every RoI, head output, decoded and final box must lie within 1e-4 of the reference's, counts equal, in the reference's order
+    (RoIs up to swaps inside groups whose reference scores agree within the tolerance; the number of swaps is printed)."""
+    E = pkg("eval_rcnn")
+    model, cfg, g, batches = full_model(DEV, "p")
+    xs = [torch.from_numpy(b).to(DEV) for b in batches]
+    runner = E.make_runner(model, cfg, DEV)
+    assert type(runner).__name__ == "GraphedRunner" and runner.pair == 2, "the product runner is the graphed one with pairs of batches"
+    keys = ("rois", "rcnn_cls", "rcnn_reg", "boxes", "scores", "num", "pred_boxes3d")
+    for rep_no in range(2):
+        dets = []
+        for i, x in enumerate(xs):
+            d = runner.submit(x, xs[i + 1:])
+            if d is not None:
+                dets.append(d)
+        dets += runner.drain()
+        assert len(dets) == 2
+        got = []
+        for d in dets:
+            d["ready"].synchronize()
+            got.append({k: d[k].clone() for k in keys})
+        torch.cuda.synchronize()
+        if rep_no == 0:
+            captures = runner.captures
+    assert captures == runner.captures and captures > 0                  # nothing was captured behind the first pass: pass 2 replayed
+    ret = {k: torch.cat([b[k] for b in got], 0) for k in ("rois", "rcnn_cls", "rcnn_reg")}
+    det = {k: torch.cat([b[k] for b in got], 0) for k in ("boxes", "scores", "num", "pred_boxes3d")}
+    # what the stages in front of the RoIs left in the member's slot (pass 2 ran in the slot before the next one to be written)
+    m = runner.slots[(runner._next_slot - 1) % runner.n_slots]["members"][0]
+    for k in ("rpn_cls", "rpn_reg", "seg_result"):
+        if m["st"].get(k) is not None:
+            ret[k] = m["st"][k]
+    if m["tl"].get("roi_scores") is not None:
+        ret["roi_scores_raw"] = m["tl"]["roi_scores"]
+    rep = helpers.e2e_report(ret, det, g)
+    text = helpers.e2e_text(rep)
+    print("g12p through GraphedRunner (pairs, replay):\n" + text)
+    first_bad = next((r for r in rep if r[2] > 0), None)
+    assert first_bad is None, "first stage that parts from the reference: %s\n%s" % (first_bad[0], text)
+    assert g["rois"].shape[0] == 16 and int(g["final_num"].min()) >= 5

@@ -169,7 +169,8 @@ def tiny_model(device="cpu", intensity=False):
 def full_model(device="cpu", kind="u"):
     """default.yaml PointRCNN with the seeded weights of the REFERENCE model that the full-size fixture g12u / g12l was recorded
     from (tests/golden/make_golden.py g12; helpers.seeded_state_dict regenerates the 3.9 M parameters from the seed, the fixture
-    holds their checksum and the calibrated RPN classification bias) -> model, cfg, fixture, input batch (2, 16384, 3) numpy"""
+    holds their checksum and the calibrated RPN classification bias) -> model, cfg, fixture, input batch (2, 16384, 3) numpy
+    (kind "p", fixture g12p: a list of two batches (8, 16384, 3))"""
     import helpers
     C, S = pkg("config"), pkg("synth")
     cfg = C.default_eval_cfg()
@@ -180,7 +181,10 @@ def full_model(device="cpu", kind="u"):
     sd["rpn.rpn_cls_layer.2.conv.bias"] = torch.from_numpy(g["rpn_cls_bias"])
     model.load_state_dict(sd)          # strict: the key tree must equal the reference's
     seed0 = int(g["scene_seed0"])
-    pts = np.stack([(S.scene if kind == "u" else S.lidar_scene)(seed0 + i, 16384) for i in range(2)], 0)
+    if kind == "p":       # configs[2]'s literal batch, one pair of the graphed runner: 8 uniform scenes, then 8 LiDAR-shaped sweeps
+        pts = [np.stack([S.scene(seed0 + i, 16384) for i in range(8)], 0), np.stack([S.lidar_scene(seed0 + 8 + i, 16384) for i in range(8)], 0)]
+    else:
+        pts = np.stack([(S.scene if kind == "u" else S.lidar_scene)(seed0 + i, 16384) for i in range(2)], 0)
     return model.to(device).eval(), cfg, g, pts
 
 
