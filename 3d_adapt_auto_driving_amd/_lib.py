@@ -73,6 +73,10 @@ SIGNATURES = {
     "prcnn_packed_layer_batch": [_I, C.POINTER(LayerProblem), _I, _P],
     "prcnn_rpn_tail": [_I, _I, _I] + [_P] * 7 + [_I] + [_P] * 4,
     "prcnn_rpn_tail_lin": [_I, _I, _I] + [_P] * 7 + [_I] + [_P] * 4,
+    "prcnn_rpn_tail_boxes_supported": [_I, _F, _F, _I, _I],
+    "prcnn_rpn_tail_lin_boxes": [_I, _I, _I] + [_P] * 7 + [_I, _F, _F, _I, _I] + [_P] * 6,
+    "prcnn_selftest_fmod_two_pi": [_L, _P, _P, _P, _P],
+    "prcnn_rpn_proposals_boxes": [_I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P],
     "prcnn_packed_layer_segmax": [_I, _I, C.c_long, _I, _I, _P, C.c_long, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "prcnn_maxpool_pm": [C.c_long, _I, _I, _P, _P, _I, _I, _P],
     "prcnn_three_interpolate_pm": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P],

@@ -570,23 +570,12 @@ extern "C" int prcnn_point_aux(long rows, float thresh, const float *scores, con
     return check_launch("point_aux");
 }
 
-// xyz (b,n,3), scores (b,n) raw RPN scores, reg (b,n,channels) -> rois (b, post_top_n, 7), roi_scores (b, post_top_n)
-// distance-based proposal (RPN_DISTANCE_BASED_PROPOSE), get_y_by_bin = False, get_ry_fine = False.
-extern "C" int prcnn_rpn_proposals(int b, int n, int channels, float loc_scope, float loc_bin_size,
-                                   int num_head_bin, int xz_fine, const float *anchor_size_host,
-                                   int pre_nms_top_n, int post_nms_top_n, float nms_thresh, int rotated_nms,
-                                   const float *xyz, const float *scores, const float *reg, float *rois,
-                                   float *roi_scores, void *stream)
+// the proposal layer behind the decode: boxes_in != NULL = every point's decoded box (b,n,7) as prcnn_rpn_tail_lin_boxes leaves it
+// (round 5: the decode rides in the RPN tail kernel), else reg + xyz are decoded here first
+static int rpn_proposals_any(int b, int n, const DecodeCfg *dc, int pre_nms_top_n, int post_nms_top_n, float nms_thresh, int rotated_nms,
+                             const float *xyz, const float *scores, const float *reg, const float *boxes_in, float *rois,
+                             float *roi_scores, void *stream)
 {
-    PRCNN_REQUIRE(b >= 0 && n > 0 && channels > 0 && num_head_bin > 0 && loc_bin_size > 0, "rpn_proposals: bad sizes");
-    PRCNN_REQUIRE(anchor_size_host, "rpn_proposals: anchor size missing");
-    DecodeCfg c;
-    c.loc_scope = loc_scope; c.loc_bin_size = loc_bin_size;
-    c.nbin = (int)(loc_scope / loc_bin_size) * 2;
-    c.num_head_bin = num_head_bin; c.xz_fine = xz_fine ? 1 : 0; c.channels = channels;
-    for (int i = 0; i < 3; ++i) c.anchor[i] = anchor_size_host[i];
-    const int expect = c.nbin * (c.xz_fine ? 4 : 2) + 1 + 2 * num_head_bin + 3;
-    PRCNN_REQUIRE(channels == expect, "rpn_proposals: %d regression channels, layout needs %d", channels, expect);
     int npad = 1;
     while (npad < n) npad <<= 1;
     PRCNN_REQUIRE(npad <= 16384, "rpn_proposals: n=%d > 16384 points per scene unsupported by the fused path", n);
@@ -594,11 +583,11 @@ extern "C" int prcnn_rpn_proposals(int b, int n, int channels, float loc_scope, 
     const int post_near = (int)(post_nms_top_n * 0.7), post_far = post_nms_top_n - post_near;
     PRCNN_REQUIRE(post_nms_top_n <= 128 && post_near >= post_far && pre_near >= pre_far, "rpn_proposals: unsupported quotas");
     if (b == 0) return PRCNN_OK;
-    PRCNN_REQUIRE(xyz && scores && reg && rois && roi_scores, "rpn_proposals: null pointer");
+    PRCNN_REQUIRE(scores && rois && roi_scores && (boxes_in || (xyz && reg)), "rpn_proposals: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int rows = pre_near;
     const size_t o_boxes = 0;
-    const size_t o_order = o_boxes + aligned((size_t)b * n * 7 * 4);
+    const size_t o_order = o_boxes + (boxes_in ? 0 : aligned((size_t)b * n * 7 * 4));
     const size_t o_pay = o_order + aligned((size_t)b * n * 4);
     const size_t o_bev = o_pay + aligned((size_t)b * 2 * rows * 8 * 4);
     const size_t o_cnt = o_bev + aligned((size_t)b * 2 * rows * 5 * 4);
@@ -607,13 +596,14 @@ extern "C" int prcnn_rpn_proposals(int b, int n, int channels, float loc_scope, 
     const size_t need = o_num + aligned((size_t)b * 2 * 4);
     char *base = scratch_for(st, need, 2);
     if (!base) { set_error("rpn_proposals: cannot allocate %zu bytes of scratch", need); return PRCNN_ELAUNCH; }
-    float *boxes = (float *)(base + o_boxes);
+    const float *boxes = boxes_in ? boxes_in : (const float *)(base + o_boxes);
     int *order = (int *)(base + o_order);
     float *payload = (float *)(base + o_pay), *bev = (float *)(base + o_bev);
     int *counts = (int *)(base + o_cnt), *keep = (int *)(base + o_keep), *num = (int *)(base + o_num);
 
     const long total = (long)b * n;
-    hipLaunchKernelGGL(rpn_decode_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, total, c, xyz, reg, boxes);
+    if (!boxes_in)
+        hipLaunchKernelGGL(rpn_decode_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, total, *dc, xyz, reg, (float *)(base + o_boxes));
     static const bool split_sort = !(getenv("PRCNN_SORT_SPLIT") && atoi(getenv("PRCNN_SORT_SPLIT")) == 0);   // A/B, same order
     if (split_sort && npad > SS_CHUNK) {
         // chunks of 4096 keys sorted by a workgroup each, then pairwise merge-path rounds (ping-pong between two key buffers)
@@ -646,6 +636,38 @@ extern "C" int prcnn_rpn_proposals(int b, int n, int channels, float loc_scope, 
     hipLaunchKernelGGL(assemble_rois_kernel, dim3(b), dim3(128), 0, st, rows, post_near, post_near, post_far, payload, keep,
                        num, rois, roi_scores);
     return check_launch("rpn_proposals");
+}
+
+// xyz (b,n,3), scores (b,n) raw RPN scores, reg (b,n,channels) -> rois (b, post_top_n, 7), roi_scores (b, post_top_n)
+// distance-based proposal (RPN_DISTANCE_BASED_PROPOSE), get_y_by_bin = False, get_ry_fine = False.
+extern "C" int prcnn_rpn_proposals(int b, int n, int channels, float loc_scope, float loc_bin_size,
+                                   int num_head_bin, int xz_fine, const float *anchor_size_host,
+                                   int pre_nms_top_n, int post_nms_top_n, float nms_thresh, int rotated_nms,
+                                   const float *xyz, const float *scores, const float *reg, float *rois,
+                                   float *roi_scores, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && n > 0 && channels > 0 && num_head_bin > 0 && loc_bin_size > 0, "rpn_proposals: bad sizes");
+    PRCNN_REQUIRE(anchor_size_host, "rpn_proposals: anchor size missing");
+    DecodeCfg c;
+    c.loc_scope = loc_scope; c.loc_bin_size = loc_bin_size;
+    c.nbin = (int)(loc_scope / loc_bin_size) * 2;
+    c.num_head_bin = num_head_bin; c.xz_fine = xz_fine ? 1 : 0; c.channels = channels;
+    for (int i = 0; i < 3; ++i) c.anchor[i] = anchor_size_host[i];
+    const int expect = c.nbin * (c.xz_fine ? 4 : 2) + 1 + 2 * num_head_bin + 3;
+    PRCNN_REQUIRE(channels == expect, "rpn_proposals: %d regression channels, layout needs %d", channels, expect);
+    PRCNN_REQUIRE(b == 0 || (xyz && reg), "rpn_proposals: null pointer");
+    return rpn_proposals_any(b, n, &c, pre_nms_top_n, post_nms_top_n, nms_thresh, rotated_nms, xyz, scores, reg, nullptr, rois, roi_scores,
+                             stream);
+}
+
+// the same layer over boxes decoded already (prcnn_rpn_tail_lin_boxes): boxes (b,n,7), scores (b,n)
+extern "C" int prcnn_rpn_proposals_boxes(int b, int n, int pre_nms_top_n, int post_nms_top_n, float nms_thresh, int rotated_nms,
+                                         const float *scores, const float *boxes, float *rois, float *roi_scores, void *stream)
+{
+    PRCNN_REQUIRE(b >= 0 && n > 0, "rpn_proposals_boxes: bad sizes");
+    PRCNN_REQUIRE(b == 0 || boxes, "rpn_proposals_boxes: null pointer");
+    return rpn_proposals_any(b, n, nullptr, pre_nms_top_n, post_nms_top_n, nms_thresh, rotated_nms, nullptr, scores, nullptr, boxes, rois,
+                             roi_scores, stream);
 }
 
 

@@ -50,7 +50,33 @@ struct RpnTailArgs {
     int n_reg;
     unsigned int *ticket;           // tile counter record of this launch (zero on entry)
     int xcd_split;                  // rpn_tail_lin: tiles drawn per XCD partition (1) or from one counter (0: A/B switch PRCNN_TAIL_XCD=0)
+    // rpn_tail_lin_kernel<true> (round 5): the regression rows are DECODED where they stand in LDS and only the 7-float box leaves
+    const float *xyz;               // (rows, 3)
+    float *boxes;                   // (rows, 7)
+    float loc_scope, loc_bin_size, anchor[3];
 };
+
+// fmodf(a, (float)(2 pi)) WITHOUT the library's loop (the decode below rides inside a hand-scheduled MFMA stage: no control flow).
+// The remainder of two floats is exact in f32's own format, so it can be taken in f64: three reduction steps modulo b 2^80, b 2^40
+// and b (b = the f32 value of 2 pi) -- each one q = trunc(r * (1 / B)), r = fma(-q, B, r): q < 2^46 is an exact integer that misses the
+// true quotient by at most one, the fma's true result is a multiple of B's last bit below 2 B and therefore exact, and every step
+// keeps r congruent to a modulo b -- then two corrective steps into [0, b), a's sign put back (a zero remainder takes it too, as
+// fmod's does).  inf -> NaN and NaN -> NaN as fmodf.  Checked against fmodf in tests/test_gpu_packed.py through the fused decode:
+// huge quotients up to 3e38, negatives, +-0, denormals, inf, NaN.
+__device__ __forceinline__ float fmod_two_pi(float a)
+{
+    constexpr double B0 = (double)(float)(2.0 * M_PI), B1 = B0 * 1099511627776.0 /* 2^40 */, B2 = B1 * 1099511627776.0;
+    constexpr double I0 = 1.0 / B0, I1 = 1.0 / B1, I2 = 1.0 / B2;
+    double r = __builtin_fabs((double)a);
+    r = __builtin_fma(-__builtin_trunc(r * I2), B2, r);
+    r = __builtin_fma(-__builtin_trunc(r * I1), B1, r);
+    r = __builtin_fma(-__builtin_trunc(r * I0), B0, r);
+    r = r < 0.0 ? r + B0 : r;
+    r = r < 0.0 ? r + B0 : r;
+    r = r >= B0 ? r - B0 : r;
+    r = r >= B0 ? r - B0 : r;
+    return __builtin_copysignf((float)r, a);
+}
 
 __global__ __launch_bounds__(256, 1) void rpn_tail_kernel(const RpnTailArgs a)
 {
@@ -242,6 +268,15 @@ __global__ __launch_bounds__(256, 1) void rpn_tail_kernel(const RpnTailArgs a)
 // A 128-wide row is 32 float4 lanes: a wave interpolates TWO rows per gather instruction (lanes 0-31 / 32-63), 8 such sets per tile;
 // the next tile's input is built behind the MFMAs of all four stages into the input panel the running tile does not use (X0 / X1
 // alternate).
+// DECODE (round 5): the regression head's 76 outputs of a row are decoded where they stand in LDS (tile T1) -- arg-max over the
+// 12 x bins / 12 z bins / 12 heading bins, residual look-ups, anchor sizes: decode_bbox_target of lib/utils/bbox_transform.py:24-121 with
+// get_xz_fine, then proposal_layer.py:31's y shift, in rpn_decode_kernel's f32 operation order (csrc/proposal.hip) -- and the 7-float box
+// leaves instead of the 304-byte row: the 80 MB `reg` tensor of a 16-scene launch and the kernel that read it back with one lane per
+// row (537 MB of HBM traffic for 85 MB of algorithmic bytes) are gone.  Four lanes per row (x | z | heading | y + sizes),
+// 16 rows per wave, spread over four k-groups of the NEXT tile's first stage like the row stores it replaces; no control flow.
+// The layout is the shipped one only (12 + 12 + 12 + 12 + 1 + 12 + 12 + 3 = 76 channels: every cfgs/*.yaml); other layouts keep `reg`.
+constexpr int RD_NB = 12;           // per_loc_bin_num = 2 * int(LOC_SCOPE / LOC_BIN_SIZE) = 2 * int(3.0 / 0.5), = NUM_HEAD_BIN
+template <bool DECODE>
 __global__ __launch_bounds__(256, 1) void rpn_tail_lin_kernel(const RpnTailArgs a)
 {
     __shared__ float T0[RT_ROWS * RT_LD];
@@ -287,6 +322,64 @@ __global__ __launch_bounds__(256, 1) void rpn_tail_lin_kernel(const RpnTailArgs 
     else if ((g) == (gf)) { RL_ROW(0, 2 * (r), Xn) }                                                      \
     else if ((g) == (gf) + 1) { RL_ROW(1, 2 * (r) + 1, Xn) }
     f32x4 co[4];
+    // ---- DECODE: lane = (row 16 w + lane / 4, part lane % 4); part 0: x, 1: z, 2: heading, 3: y + sizes
+    const int dpart = lane & 3;
+    const float *drow = T1 + (16 * w + (lane >> 2)) * RT_LD;
+    const int dstart = dpart == 0 ? 0 : dpart == 1 ? RD_NB : dpart == 2 ? 4 * RD_NB + 1 : 6 * RD_NB + 4 - RD_NB;   // 12 values from here: bins | bins | bins | .. h w l
+    const int dexb = dpart == 0 ? 2 * RD_NB : dpart == 1 ? 3 * RD_NB : dpart == 2 ? 5 * RD_NB + 1 : 4 * RD_NB;     // + bin: residual (part 3: the y offset)
+    const int dxo = dpart == 0 ? 0 : dpart == 1 ? 2 : dpart == 2 ? 0 : 1;                                          // which coordinate of the point
+    const int dbo = dpart == 0 ? 0 : dpart == 1 ? 2 : dpart == 2 ? 6 : 1;                                          // which slot of the box
+    float dv[RD_NB], dp = 0.f, dex = 0.f, dout = 0.f, dh = 0.f, dw = 0.f, dl = 0.f;
+    int dbi = 0;
+#define RL_DEC_READ(TT)                                                                                   \
+    {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < RD_NB; ++i) dv[i] = drow[dstart + i];                        \
+        unsigned int gr_ = (unsigned int)(TT) * RT_ROWS + 16 * w + (lane >> 2);                           \
+        if (gr_ >= (unsigned int)a.rows) gr_ = (unsigned int)a.rows - 1u;                                  \
+        dp = a.xyz[gr_ * 3u + dxo];                                                                        \
+    }
+    // first maximum; a NaN counts as the largest value (torch.argmax; proposal.hip argmax_row)
+#define RL_DEC_ARGMAX                                                                                     \
+    {                                                                                                     \
+        float bv_ = dv[0];                                                                                \
+        dbi = 0;                                                                                          \
+        _Pragma("unroll") for (int i = 1; i < RD_NB; ++i) {                                                \
+            const bool tk_ = dv[i] > bv_ || (dv[i] != dv[i] && bv_ == bv_);                                \
+            bv_ = tk_ ? dv[i] : bv_;                                                                      \
+            dbi = tk_ ? i : dbi;                                                                          \
+        }                                                                                                 \
+        dex = drow[dexb + (dpart < 3 ? dbi : 0)];                                                          \
+    }
+#define RL_DEC_MATH                                                                                       \
+    {                                                                                                     \
+        const float fb_ = (float)dbi, bin_ = a.loc_bin_size;                                               \
+        float loc_ = __fsub_rn(__fadd_rn(__fmul_rn(fb_, bin_), bin_ / 2), a.loc_scope);                    \
+        loc_ = __fadd_rn(__fadd_rn(loc_, __fmul_rn(dex, bin_)), dp);                                       \
+        const float apc_ = (float)((2.0 * M_PI) / RD_NB), apch_ = (float)(((2.0 * M_PI) / RD_NB) / 2.0);   \
+        const float two_pi_ = (float)(2.0 * M_PI), pi_ = (float)M_PI;                                      \
+        float ry_ = fmod_two_pi(__fadd_rn(__fmul_rn(fb_, apc_), __fmul_rn(dex, apch_)));           \
+        ry_ = (ry_ != 0.f && ry_ < 0.f) ? __fadd_rn(ry_, two_pi_) : ry_;                                   \
+        ry_ = ry_ > pi_ ? __fsub_rn(ry_, two_pi_) : ry_;                                                   \
+        dh = __fadd_rn(__fmul_rn(dv[RD_NB - 3], a.anchor[0]), a.anchor[0]);                                \
+        dw = __fadd_rn(__fmul_rn(dv[RD_NB - 2], a.anchor[1]), a.anchor[1]);                                \
+        dl = __fadd_rn(__fmul_rn(dv[RD_NB - 1], a.anchor[2]), a.anchor[2]);                                \
+        const float y_ = __fadd_rn(__fadd_rn(dp, dex), dh / 2);                                            \
+        dout = dpart < 2 ? loc_ : dpart == 2 ? ry_ : y_;                                                   \
+    }
+#define RL_DEC_STORE(TT, live)                                                                            \
+    {                                                                                                     \
+        const unsigned int gr_ = (unsigned int)(TT) * RT_ROWS + 16 * w + (lane >> 2);                     \
+        if ((live) && gr_ < (unsigned int)a.rows) {                                                        \
+            float *o_ = a.boxes + gr_ * 7u;                                                                \
+            o_[dbo] = dout;                                                                                \
+            if (dpart == 3) { o_[3] = dh; o_[4] = dw; o_[5] = dl; }                                        \
+        }                                                                                                 \
+    }
+#define RL_DECODE(g, TT, live)                                                                            \
+    if ((g) == 1) RL_DEC_READ(TT)                                                                         \
+    else if ((g) == 3) RL_DEC_ARGMAX                                                                      \
+    else if ((g) == 5) RL_DEC_MATH                                                                        \
+    else if ((g) == 7) RL_DEC_STORE(TT, live)
 
     // tiles by XCD: one eighth of the rows (one scene of a batch of 8) and its 2 MB of G per L2 instead of all 16.8 MB through every L2
     XcdTickets tk;
@@ -321,8 +414,10 @@ __global__ __launch_bounds__(256, 1) void rpn_tail_lin_kernel(const RpnTailArgs 
         const long tn = __builtin_amdgcn_readfirstlane((int)slot[(served + 1) & 1]);
         RT_FETCH_IDX(tn)                                       // consumed from k-group 8 of the first stage on
         // ---- FP layer 2 (wa) while cls layer 1 (wb) comes in; side: the previous tile's regression rows leave T1, round 0
-#define RL_H1(g) RT_ROWS_OUT(g, tp, T1, a.reg, a.n_reg, served > 0 && 4 * chunk < a.n_reg) RL_SIDE(0, g, 8, 13)
-        RT_STAGE_HOOK(Xc, wa, wb, rs, 128, true, RL_H1)
+#define RL_H1R(g) RT_ROWS_OUT(g, tp, T1, a.reg, a.n_reg, served > 0 && 4 * chunk < a.n_reg) RL_SIDE(0, g, 8, 13)
+#define RL_H1D(g) RL_DECODE(g, tp, served > 0) RL_SIDE(0, g, 8, 13)
+        if (DECODE) { RT_STAGE_HOOK(Xc, wa, wb, rs, 128, true, RL_H1D) }
+        else { RT_STAGE_HOOK(Xc, wa, wb, rs, 128, true, RL_H1R) }
         lds_barrier();                                         // every wave has taken the old rows out of T1
         RT_EPILOGUE(T1, bias2, true)                           // = the backbone features
         lds_barrier();
@@ -351,7 +446,9 @@ __global__ __launch_bounds__(256, 1) void rpn_tail_lin_kernel(const RpnTailArgs 
     }
     if (last) {
         lds_barrier();
-        if (4 * chunk < a.n_reg) {
+        if (DECODE) {
+            RL_DEC_READ(tp) RL_DEC_ARGMAX RL_DEC_MATH RL_DEC_STORE(tp, true)
+        } else if (4 * chunk < a.n_reg) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int row = r0 + 8 * i;
@@ -369,6 +466,15 @@ __global__ __launch_bounds__(256, 1) void rpn_tail_lin_kernel(const RpnTailArgs 
 
 namespace prcnn {
 unsigned int *next_ticket(hipStream_t st);    // sa_mlp_fused.hip
+
+__global__ __launch_bounds__(256) void fmod_two_pi_selftest_kernel(long n, const float *__restrict__ a, float *__restrict__ mine,
+                                                                   float *__restrict__ lib)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    mine[i] = fmod_two_pi(a[i]);
+    lib[i] = fmodf(a[i], (float)(2.0 * M_PI));
+}
 }
 
 using namespace prcnn;
@@ -401,24 +507,28 @@ extern "C" int prcnn_rpn_tail(int b, int n, int m, const float *known, const int
 
 /* prcnn_rpn_tail with the FP module's first layer already applied at the coarse level (csrc/rpn_tail.hip rpn_tail_lin_kernel):
  * G (b,m,128) = coarse features @ the layer's weights (no bias); wcat (512,128) = [FP layer 2 | cls layer 1 | reg layer 1 | reg layer 2],
- * bcat (5,128) = the biases of FP layer 1 (added after the interpolation) and of those four. */
-extern "C" int prcnn_rpn_tail_lin(int b, int n, int m, const float *G, const int *idx, const float *weight, const float *wcat,
-                                  const float *bcat, const float *wc2, const float *bc2, int n_reg, float *feats, float *cls,
-                                  float *reg, void *stream)
+ * bcat (5,128) = the biases of FP layer 1 (added after the interpolation) and of those four.
+ * boxes != NULL (prcnn_rpn_tail_lin_boxes): the regression rows are decoded in the kernel and `reg` is not written (may be NULL). */
+static int rpn_tail_lin_any(int b, int n, int m, const float *G, const int *idx, const float *weight, const float *wcat,
+                            const float *bcat, const float *wc2, const float *bc2, int n_reg, float *feats, float *cls,
+                            float *reg, const float *xyz, float *boxes, float loc_scope, float loc_bin_size, const float *anchor,
+                            void *stream, const char *who)
 {
     PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 1 && n_reg >= 4 && n_reg <= 128 && n_reg % 4 == 0,
-                  "rpn_tail_lin: bad sizes (n_reg=%d must be a multiple of 4 in 4..128)", n_reg);
+                  "%s: bad sizes (n_reg=%d must be a multiple of 4 in 4..128)", who, n_reg);
     const long rows = (long)b * n;
     if (rows == 0) return PRCNN_OK;
-    PRCNN_REQUIRE(rows <= (1L << 23), "rpn_tail_lin: too many points (32-bit element offsets)");
-    PRCNN_REQUIRE(G && idx && weight && wcat && bcat && wc2 && bc2 && feats && cls && reg, "rpn_tail_lin: null pointer");
+    PRCNN_REQUIRE(rows <= (1L << 23), "%s: too many points (32-bit element offsets)", who);
+    PRCNN_REQUIRE(G && idx && weight && wcat && bcat && wc2 && bc2 && feats && cls && (reg || boxes), "%s: null pointer", who);
     PRCNN_REQUIRE((((uintptr_t)G | (uintptr_t)feats | (uintptr_t)wcat | (uintptr_t)reg | (uintptr_t)bcat) & 15) == 0,
-                  "rpn_tail_lin: 16-byte alignment required");
+                  "%s: 16-byte alignment required", who);
     RpnTailArgs a;
     a.rows = rows; a.n = n; a.m = m; a.known = G; a.idx = idx; a.weight = weight;
     a.wcat = wcat; a.bcat = bcat; a.wc2 = wc2; a.bc2 = bc2; a.feats = feats; a.cls = cls; a.reg = reg; a.n_reg = n_reg;
+    a.xyz = xyz; a.boxes = boxes; a.loc_scope = loc_scope; a.loc_bin_size = loc_bin_size;
+    for (int i = 0; i < 3; ++i) a.anchor[i] = anchor ? anchor[i] : 0.f;
     a.ticket = next_ticket((hipStream_t)stream);
-    if (!a.ticket) { set_error("rpn_tail_lin: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
+    if (!a.ticket) { set_error("%s: cannot set up the tile ticket", who); return PRCNN_ELAUNCH; }
     static const int xcd_split = !(getenv("PRCNN_TAIL_XCD") && atoi(getenv("PRCNN_TAIL_XCD")) == 0);
     const long tiles = (rows + RT_ROWS - 1) / RT_ROWS;
     const long cap = mfma_grid_cap() < 256 ? mfma_grid_cap() : 256;
@@ -426,6 +536,50 @@ extern "C" int prcnn_rpn_tail_lin(int b, int n, int m, const float *G, const int
     // a workgroup draws only from partition blockIdx.x & 7 (no stealing): every non-empty partition needs a workgroup of its own --
     // with fewer than 8 workgroups for 8 or more tiles (PRCNN_MFMA_GRID < 8) the tiles come from one counter instead
     a.xcd_split = xcd_split && (grid >= 8 || grid == tiles);
-    hipLaunchKernelGGL(rpn_tail_lin_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
-    return check_launch("rpn_tail_lin");
+    if (boxes) hipLaunchKernelGGL(rpn_tail_lin_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(rpn_tail_lin_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch(who);
+}
+
+extern "C" int prcnn_rpn_tail_lin(int b, int n, int m, const float *G, const int *idx, const float *weight, const float *wcat,
+                                  const float *bcat, const float *wc2, const float *bc2, int n_reg, float *feats, float *cls,
+                                  float *reg, void *stream)
+{
+    PRCNN_REQUIRE(reg || (long)b * n == 0, "rpn_tail_lin: null pointer");
+    return rpn_tail_lin_any(b, n, m, G, idx, weight, wcat, bcat, wc2, bc2, n_reg, feats, cls, reg, nullptr, nullptr, 0.f, 0.f, nullptr,
+                            stream, "rpn_tail_lin");
+}
+
+/* prcnn_rpn_tail_lin with the proposal layer's decode inside (round 5): boxes (b*n,7) = decode_bbox_target(xyz, reg, get_xz_fine = True,
+ * get_y_by_bin = False, get_ry_fine = False) with y += h / 2 (bbox_transform.py:24-121, proposal_layer.py:23-31) -- what rpn_decode_kernel
+ * of csrc/proposal.hip computes from the stored rows, operation for operation -- and the regression rows themselves are not
+ * written.  Served layout: LOC_SCOPE / LOC_BIN_SIZE = 6 bins per side (12 x bins, 12 z bins), NUM_HEAD_BIN = 12, LOC_XZ_FINE: the 76
+ * channels of every shipped configuration (prcnn_rpn_tail_boxes_supported); anchor_size_host = (h, w, l) in host memory. */
+/* test hook: out_mine[i] = the branch-free fmod of the fused decode, out_lib[i] = fmodf(a[i], (float)(2 pi)) on the same device */
+extern "C" int prcnn_selftest_fmod_two_pi(long n, const float *a, float *out_mine, float *out_lib, void *stream)
+{
+    PRCNN_REQUIRE(n >= 0, "selftest_fmod_two_pi: bad size");
+    if (n == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(a && out_mine && out_lib, "selftest_fmod_two_pi: null pointer");
+    hipLaunchKernelGGL(fmod_two_pi_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, a, out_mine, out_lib);
+    return check_launch("selftest_fmod_two_pi");
+}
+
+extern "C" int prcnn_rpn_tail_boxes_supported(int channels, float loc_scope, float loc_bin_size, int num_head_bin, int xz_fine)
+{
+    return loc_bin_size > 0.f && (int)(loc_scope / loc_bin_size) * 2 == RD_NB && num_head_bin == RD_NB && xz_fine &&
+           channels == 6 * RD_NB + 4;
+}
+
+extern "C" int prcnn_rpn_tail_lin_boxes(int b, int n, int m, const float *G, const int *idx, const float *weight, const float *wcat,
+                                        const float *bcat, const float *wc2, const float *bc2, int n_reg, float loc_scope,
+                                        float loc_bin_size, int num_head_bin, int xz_fine, const float *anchor_size_host,
+                                        const float *xyz, float *feats, float *cls, float *boxes, void *stream)
+{
+    PRCNN_REQUIRE(prcnn_rpn_tail_boxes_supported(n_reg, loc_scope, loc_bin_size, num_head_bin, xz_fine),
+                  "rpn_tail_lin_boxes: regression layout (%d channels, scope %g / bin %g, %d heading bins, xz_fine %d) not served",
+                  n_reg, loc_scope, loc_bin_size, num_head_bin, xz_fine);
+    PRCNN_REQUIRE(anchor_size_host && ((xyz && boxes) || (long)b * n == 0), "rpn_tail_lin_boxes: null pointer");
+    return rpn_tail_lin_any(b, n, m, G, idx, weight, wcat, bcat, wc2, bc2, n_reg, feats, cls, nullptr, xyz, boxes, loc_scope, loc_bin_size,
+                            anchor_size_host, stream, "rpn_tail_lin_boxes");
 }

@@ -83,6 +83,15 @@ def rpn_proposals(xyz, scores, reg, anchor_size, loc_scope, loc_bin_size, num_he
     return rois, roi_scores
 
 
+def rpn_proposals_boxes(scores, boxes, pre_nms_top_n, post_nms_top_n, nms_thresh, rotated, rois, roi_scores):
+    """The proposal layer over boxes decoded already (pointnet2_cuda.rpn_tail_lin_boxes_wrapper): scores (B,N), boxes (B,N,7) ->
+    rois (B,post,7), roi_scores (B,post)."""
+    _chk(scores, boxes, rois, roi_scores)
+    _lib.call("prcnn_rpn_proposals_boxes", boxes.size(0), boxes.size(1), int(pre_nms_top_n), int(post_nms_top_n), float(nms_thresh),
+              int(bool(rotated)), scores.data_ptr(), boxes.data_ptr(), rois.data_ptr(), roi_scores.data_ptr(), _lib.current_stream(boxes))
+    return rois, roi_scores
+
+
 def rcnn_postprocess(rois, rcnn_reg, rcnn_cls, anchor_size, loc_scope, loc_bin_size, num_head_bin, y_by_bin,
                      loc_y_scope, loc_y_bin_size, score_thresh, nms_thresh, pred_boxes3d, boxes, scores, num):
     """Fused final stage (csrc/proposal.hip): decode against the RoIs, score threshold, rotated NMS.

@@ -7,6 +7,7 @@ order and pre-allocated-output convention, bound to libprcnn_hip.so through the 
 Like the reference wrappers, kernels go to torch's current stream.  Inputs must be CUDA(HIP),
 contiguous, f32/i32 (ball_query.cpp:10-12 checks only ball_query's inputs; we check all).
 """
+import ctypes
 import importlib
 import os
 import sys
@@ -528,6 +529,39 @@ def rpn_tail_lin_wrapper(G, idx, weight, wcat, bcat, wc2, bc2, feats, cls, reg):
               bcat.data_ptr(), wc2.data_ptr(), bc2.data_ptr(), reg.size(-1), feats.data_ptr(), cls.data_ptr(), reg.data_ptr(),
               _lib.current_stream(G))
     return feats, cls, reg
+
+
+def rpn_tail_boxes_supported(channels, loc_scope, loc_bin_size, num_head_bin, xz_fine):
+    """does prcnn_rpn_tail_lin_boxes serve this regression layout? (the 76 channels of the shipped configurations)"""
+    return bool(_lib.call("prcnn_rpn_tail_boxes_supported", int(channels), float(loc_scope), float(loc_bin_size), int(num_head_bin),
+                          int(bool(xz_fine))))
+
+
+def rpn_tail_lin_boxes_wrapper(G, idx, weight, wcat, bcat, wc2, bc2, n_reg, loc_scope, loc_bin_size, num_head_bin, xz_fine, anchor_size,
+                               xyz, feats, cls, boxes):
+    """rpn_tail_lin_wrapper with the proposal layer's decode inside (round 5): boxes (b,n,7) = decode_bbox_target(xyz, reg) with
+    y += h / 2 (bbox_transform.py:24-121, proposal_layer.py:23-31); the (b,n,n_reg) regression rows are never stored.
+    anchor_size: 3 python floats (h, w, l); xyz (b,n,3)."""
+    _chk(torch.float32, G, weight, wcat, bcat, wc2, bc2, feats, cls, boxes, xyz); _chk(torch.int32, idx)
+    b, m, c = G.shape
+    if c != 128 or tuple(wcat.shape) != (512, 128) or tuple(bcat.shape) != (5, 128) or wc2.numel() != 128 or feats.size(-1) != 128:
+        raise RuntimeError("pointnet2_cuda: rpn_tail_lin is written for a 128-wide coarse product and 128-wide layers")
+    if boxes.size(-1) != 7 or boxes.numel() != 7 * b * idx.size(1) or xyz.numel() != 3 * b * idx.size(1):
+        raise RuntimeError("pointnet2_cuda: rpn_tail_lin_boxes wants xyz (b,n,3) and boxes (b,n,7)")
+    anchor = (ctypes.c_float * 3)(*[float(v) for v in anchor_size])
+    _lib.call("prcnn_rpn_tail_lin_boxes", b, idx.size(1), m, G.data_ptr(), idx.data_ptr(), weight.data_ptr(), wcat.data_ptr(),
+              bcat.data_ptr(), wc2.data_ptr(), bc2.data_ptr(), int(n_reg), float(loc_scope), float(loc_bin_size), int(num_head_bin),
+              int(bool(xz_fine)), ctypes.cast(anchor, ctypes.c_void_p), xyz.data_ptr(), feats.data_ptr(), cls.data_ptr(),
+              boxes.data_ptr(), _lib.current_stream(G))
+    return feats, cls, boxes
+
+
+def selftest_fmod_two_pi(a):
+    """-> (the fused decode's branch-free fmod(a, 2 pi), the device library's fmodf(a, 2 pi)) for a float32 tensor"""
+    _chk(torch.float32, a)
+    mine, lib = torch.empty_like(a), torch.empty_like(a)
+    _lib.call("prcnn_selftest_fmod_two_pi", a.numel(), a.data_ptr(), mine.data_ptr(), lib.data_ptr(), _lib.current_stream(a))
+    return mine, lib
 
 
 def packed_layer_segmax_wrapper(a, wt, bias, pack, b, m, out, out_col, zeroed=False):

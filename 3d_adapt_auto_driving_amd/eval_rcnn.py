@@ -154,7 +154,7 @@ def infer_batch(model, cfg, pts_input, engine=None, geo=None):
     """pts_input (B,N,3) device f32 -> detections dict (all device tensors, fixed shapes).
     ``engine`` = a FastPointRCNN built from ``model`` (point-major fused path); without it the
     nn.Module graph (reference operation order) runs."""
-    ret = engine(pts_input, geo) if engine is not None else model({"pts_input": pts_input})
+    ret = engine(pts_input, geo, want_reg=False) if engine is not None else model({"pts_input": pts_input})
     det = postprocess(cfg, ret, pts_input.shape[0])
     det["rois"] = ret["rois"]
     det["rcnn_reg"] = ret["rcnn_reg"]
@@ -286,8 +286,9 @@ class PipelinedRunner:
         st = self.engine.rpn_stage(cur, ch["geo"])
         ev_rpn = torch.cuda.Event()
         ev_rpn.record(main)
-        for t in (st["rpn_scores_raw"], st["rpn_reg"], st["backbone_xyz"]):
-            t.record_stream(self.tail)
+        for t in (st["rpn_scores_raw"], st["rpn_reg"], st.get("rpn_boxes"), st["backbone_xyz"]):
+            if t is not None:
+                t.record_stream(self.tail)
         rois, roi_scores, ev_prop, rg = self._propose_on_tail(st, ev_rpn, main)
         done = self._finish_inflight()
         self._inflight = (cur, st, rois, roi_scores, ev_prop, None, None, rg)
@@ -374,8 +375,9 @@ class PipelinedRunner:
         st = self.engine.rpn_stage(cur, ch["geo"])
         ev_rpn = torch.cuda.Event()
         ev_rpn.record(main)
-        for t in (st["rpn_scores_raw"], st["rpn_reg"], st["backbone_xyz"]):
-            t.record_stream(self.tail)
+        for t in (st["rpn_scores_raw"], st["rpn_reg"], st.get("rpn_boxes"), st["backbone_xyz"]):
+            if t is not None:
+                t.record_stream(self.tail)
         rois, roi_scores, ev_prop, rg = self._propose_on_tail(st, ev_rpn, main)
         done = self._finish_inflight()
         self._inflight = (cur, st, rois, roi_scores, ev_prop, ch["side"], ch["geo"], rg)

@@ -27,6 +27,7 @@ from ..pointnet2 import fused_mlp
 from .._lib import has_entry
 from .. import kitti_utils
 from .. import roipool3d_utils
+from .. import iou3d_utils
 
 
 USE_ROIPOOL_CANONICAL = True   # RCNN input assembly through roipool3d_canonical_kernel (False: torch-op sequence)
@@ -79,6 +80,15 @@ USE_POOL_GROUPS = os.environ.get("PRCNN_NO_POOL_GROUPS") is None
 # epilogue of the layer over the skip features (prcnn_packed_layer_interp).  Another association of the same sums than the
 # reference's (~1e-7 relative); PRCNN_NO_FP_LINEAR=1: interpolate, concatenate, then the layer, as the reference does (A/B).
 USE_FP_LINEAR = os.environ.get("PRCNN_NO_FP_LINEAR") is None
+# round 5: the proposal layer's box decode inside the fused RPN tail kernel (csrc/rpn_tail.hip rpn_tail_lin_kernel<true>): the (B, N, 76)
+# regression tensor never reaches HBM and rpn_decode_kernel leaves the proposal stream; 0: tail writes the rows, the proposal layer
+# decodes them (same boxes, bit for bit: A/B)
+USE_TAIL_DECODE = os.environ.get("PRCNN_TAIL_DECODE", "1") != "0"
+
+
+def pl_ext():
+    """the iou3d operator backend in force (looked up per call: the test suite swaps it)"""
+    return iou3d_utils.iou3d_cuda
 
 
 def _round4(c):
@@ -769,8 +779,24 @@ class FastPointRCNN:
 
     # ------------------------------------------------------------------ full forward
     @torch.no_grad()
-    def rpn_stage(self, pts_input, geo=None):
-        """Backbone + RPN heads: everything up to (not including) the proposal layer."""
+    def _tail_decode_cfg(self):
+        """-> the arguments of the fused tail's decode when this configuration's proposal layer can take decoded boxes (the fused
+        device-side layer of net/proposal_layer.py over the served regression layout), else None"""
+        cfg, pl = self.cfg, self.model.rpn.proposal_layer
+        M = cfg[pl.mode].RPN_POST_NMS_TOP_N
+        ext3 = pl_ext()
+        if not (USE_TAIL_DECODE and USE_FP_LINEAR and self.rpn_tail is not None and getattr(pl, "fused", False)
+                and cfg.TEST.RPN_DISTANCE_BASED_PROPOSE and M <= 128 and cfg.RPN.NMS_TYPE in ("normal", "rotate")
+                and has_entry(pu.pointnet2, "rpn_tail_lin_boxes_wrapper") and has_entry(ext3, "rpn_proposals_boxes")
+                and pu.pointnet2.rpn_tail_boxes_supported(self.rpn_tail["n_reg"], cfg.RPN.LOC_SCOPE, cfg.RPN.LOC_BIN_SIZE,
+                                                         cfg.RPN.NUM_HEAD_BIN, cfg.RPN.LOC_XZ_FINE)):
+            return None
+        return (cfg.RPN.LOC_SCOPE, cfg.RPN.LOC_BIN_SIZE, cfg.RPN.NUM_HEAD_BIN, cfg.RPN.LOC_XZ_FINE, pl._anchor)
+
+    def rpn_stage(self, pts_input, geo=None, want_reg=False):
+        """Backbone + RPN heads: everything up to (not including) the proposal layer.  ``want_reg`` = False (the runners): where the
+        fused tail can decode the boxes itself the state carries "rpn_boxes" (B, N, 7) and "rpn_reg" is None; True: the regression
+        rows are always produced (forward(): the dict of the reference's PointRCNN.forward)."""
         cfg = self.cfg
         self.check_weights()
         if pts_input.shape[-1] != 3 + self.in_feat:
@@ -802,14 +828,22 @@ class FastPointRCNN:
             tw = self.rpn_tail
             feats = torch.empty((B, N, 128), dtype=torch.float32, device=xyz.device)
             rpn_cls = torch.empty((B, N, 1), dtype=torch.float32, device=xyz.device)
-            rpn_reg = torch.empty((B, N, tw["n_reg"]), dtype=torch.float32, device=xyz.device)
+            dec = None if want_reg or self.in_feat else self._tail_decode_cfg()
+            rpn_reg = torch.empty((B, N, tw["n_reg"]), dtype=torch.float32, device=xyz.device) if dec is None else None
+            rpn_boxes = None
             if USE_FP_LINEAR and has_entry(pu.pointnet2, "rpn_tail_lin_wrapper"):
                 # FP layer 1 over the coarse points (a quarter of the rows), interpolated inside the fused kernel
                 m = known_feat.shape[1]
                 G = geo.get("tail_G")                          # came with the geometry (EARLY_G0)
                 if G is None:
                     G = point_layer(known_feat.view(B * m, known_feat.shape[2]), tw["w1"], tw["zero128"], False).view(B, m, 128)
-                pu.pointnet2.rpn_tail_lin_wrapper(G, idx, weight, tw["wcat_lin"], tw["bcat"], tw["wc2"], tw["bc2"], feats, rpn_cls, rpn_reg)
+                if dec is not None:
+                    # ... and the proposal layer's decode too: the 7-float box leaves the kernel instead of the 76-float row
+                    rpn_boxes = torch.empty((B, N, 7), dtype=torch.float32, device=xyz.device)
+                    pu.pointnet2.rpn_tail_lin_boxes_wrapper(G, idx, weight, tw["wcat_lin"], tw["bcat"], tw["wc2"], tw["bc2"], tw["n_reg"],
+                                                            dec[0], dec[1], dec[2], dec[3], dec[4], xyz, feats, rpn_cls, rpn_boxes)
+                else:
+                    pu.pointnet2.rpn_tail_lin_wrapper(G, idx, weight, tw["wcat_lin"], tw["bcat"], tw["wc2"], tw["bc2"], feats, rpn_cls, rpn_reg)
             else:
                 pu.pointnet2.rpn_tail_wrapper(known_feat, idx, weight, tw["wcat"], tw["bcat"], tw["wc2"], tw["bc2"], feats, rpn_cls, rpn_reg)
         else:
@@ -818,7 +852,8 @@ class FastPointRCNN:
             rpn_reg = self.rpn_reg(flat).view(B, N, -1)
             if feats.shape[2] != self.fp[0].n_out:            # narrow configurations: drop the zero padding again
                 feats = feats[:, :, :self.fp[0].n_out].contiguous()
-        out = {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": xyz, "rpn_features": feats, "groups": geo.get("groups")}
+            rpn_boxes = None
+        out = {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "rpn_boxes": rpn_boxes, "backbone_xyz": xyz, "rpn_features": feats, "groups": geo.get("groups")}
         if cfg.RCNN.ENABLED:
             out["rpn_scores_raw"] = rpn_cls[:, :, 0].contiguous()
         return out
@@ -846,6 +881,15 @@ class FastPointRCNN:
         """The proposal layer on the RPN stage's outputs -> (rois, roi_scores_raw); also fills in the per-point RCNN inputs."""
         if self.cfg.RCNN.ENABLED:
             self.point_aux(st)
+        if st.get("rpn_boxes") is not None:                  # decoded by the fused tail (rpn_stage): sort, bands, NMS, assembly
+            cfg, pl = self.cfg, self.model.rpn.proposal_layer
+            boxes, scores = st["rpn_boxes"], st["rpn_scores_raw"]
+            M = cfg[pl.mode].RPN_POST_NMS_TOP_N
+            rois = torch.empty((boxes.shape[0], M, 7), dtype=torch.float32, device=boxes.device)
+            roi_scores = torch.empty((boxes.shape[0], M), dtype=torch.float32, device=boxes.device)
+            pl_ext().rpn_proposals_boxes(scores, boxes, cfg[pl.mode].RPN_PRE_NMS_TOP_N, M, cfg[pl.mode].RPN_NMS_THRESH,
+                                         cfg.RPN.NMS_TYPE == "rotate", rois, roi_scores)
+            return rois, roi_scores
         return self.model.rpn.proposal_layer(st["rpn_scores_raw"], st["rpn_reg"], st["backbone_xyz"])
 
     @torch.no_grad()
@@ -865,11 +909,12 @@ class FastPointRCNN:
             return self._rcnn_features(rg)
 
     @torch.no_grad()
-    def forward(self, pts_input, geo=None):
+    def forward(self, pts_input, geo=None, want_reg=True):
         """pts_input (B,N,3) -> the dict PointRCNN.forward returns in TEST mode (rpn_cls, rpn_reg,
         backbone_xyz, rois, roi_scores_raw, seg_result, rcnn_cls, rcnn_reg); backbone features are
-        returned point-major under 'rpn_features' (B,N,C)."""
-        out = self.rpn_stage(pts_input, geo)
+        returned point-major under 'rpn_features' (B,N,C).  ``want_reg`` = False (eval_rcnn.infer_batch: only the detections are
+        wanted): rpn_reg may be None -- the boxes were decoded inside the fused tail kernel (rpn_stage)."""
+        out = self.rpn_stage(pts_input, geo, want_reg=want_reg)
         if not self.cfg.RCNN.ENABLED:
             return out
         rois, roi_scores_raw = self.propose(out)

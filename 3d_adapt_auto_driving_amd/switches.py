@@ -56,6 +56,7 @@ SWITCHES = {
     "PRCNN_NO_POINT_MLP": ("ab", "unset", "net/fast_infer.py", "RCNN entrance as separate layers"),
     "PRCNN_NO_ROI_GEOMETRY": ("ab", "unset", "net/fast_infer.py", "RCNN sampling / ball queries as six launches"),
     "PRCNN_NO_RPN_TAIL": ("ab", "unset", "net/fast_infer.py", "finest FP module and RPN heads layer by layer"),
+    "PRCNN_TAIL_DECODE": ("ab", "1", "net/fast_infer.py", "0: the fused RPN tail stores the (B, N, 76) regression rows and the proposal layer decodes them (rpn_decode_kernel) instead of decoding inside the tail kernel (round 5)"),
     "PRCNN_NO_SCALE_BATCH": ("ab", "unset", "net/fast_infer.py", "one launch per MSG scale"),
     "PRCNN_NO_WIDE_FUSED": ("ab", "unset", "net/fast_infer.py", "GroupAll level layer by layer"),
     "PRCNN_NO_WIDE_FUSED3": ("ab", "unset", "net/fast_infer.py", "1: the GroupAll level's layer 1 as a per-point launch in front of csrc/sa_wide.hip instead of inside csrc/sa_wide3.hip"),

@@ -314,6 +314,18 @@ int prcnn_rpn_tail(int b, int n, int m, const float *known, const int *idx, cons
 int prcnn_rpn_tail_lin(int b, int n, int m, const float *G, const int *idx, const float *weight, const float *wcat,
                        const float *bcat, const float *wc2, const float *bc2, int n_reg, float *feats, float *cls,
                        float *reg, void *stream);
+/* prcnn_rpn_tail_lin with the proposal layer's decode INSIDE (round 5): boxes (b*n,7) = decode_bbox_target(xyz, reg, anchor,
+ * get_xz_fine = True, get_y_by_bin = False, get_ry_fine = False) with y += h / 2 (lib/utils/bbox_transform.py:24-121,
+ * lib/rpn/proposal_layer.py:23-31), operation for operation what prcnn_rpn_proposals' decode computes from the stored rows; the
+ * (b*n, n_reg) regression rows themselves never reach HBM.  Served regression layout: prcnn_rpn_tail_boxes_supported (12 x / z bins,
+ * 12 heading bins, fine residuals: the 76 channels of every shipped yaml); anchor_size_host: (h, w, l) in HOST memory; xyz (b,n,3). */
+int prcnn_rpn_tail_boxes_supported(int channels, float loc_scope, float loc_bin_size, int num_head_bin, int xz_fine);
+/* test hook of that decode's branch-free f32 fmod by 2 pi: out_mine[i] = its value, out_lib[i] = fmodf(a[i], (float)(2 pi)) */
+int prcnn_selftest_fmod_two_pi(long n, const float *a, float *out_mine, float *out_lib, void *stream);
+int prcnn_rpn_tail_lin_boxes(int b, int n, int m, const float *G, const int *idx, const float *weight, const float *wcat,
+                             const float *bcat, const float *wc2, const float *bc2, int n_reg, float loc_scope, float loc_bin_size,
+                             int num_head_bin, int xz_fine, const float *anchor_size_host, const float *xyz, float *feats,
+                             float *cls, float *boxes, void *stream);
 int prcnn_packed_layer_segmax(int b, int m, long max_tiles, int K, int N, const float *A, long lda, const float *W,
                               const float *bias, const unsigned int *rowinfo, const int *tilecloud,
                               const unsigned int *hdr, float *out, int out_stride, int out_col, int out_is_zero, void *stream);
@@ -405,6 +417,9 @@ int prcnn_rpn_proposals(int b, int n, int channels, float loc_scope, float loc_b
                         int xz_fine, const float *anchor_size_host, int pre_nms_top_n, int post_nms_top_n,
                         float nms_thresh, int rotated_nms, const float *xyz, const float *scores,
                         const float *reg, float *rois, float *roi_scores, void *stream);
+/* The same layer over boxes decoded already (prcnn_rpn_tail_lin_boxes): boxes (b,n,7), scores (b,n). */
+int prcnn_rpn_proposals_boxes(int b, int n, int pre_nms_top_n, int post_nms_top_n, float nms_thresh, int rotated_nms,
+                              const float *scores, const float *boxes, float *rois, float *roi_scores, void *stream);
 
 /* Final detection stage of eval_rcnn.py (tools/eval_rcnn.py:506-530 decode with get_xz_fine = get_ry_fine
  * = True, :611-629 score threshold + rotated NMS) in three launches and no host sync.

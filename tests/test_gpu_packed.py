@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle import ext_cpu
+from conftest import pkg
 from helpers import scenes
 
 pytestmark = pytest.mark.gpu
@@ -412,6 +413,87 @@ def test_rpn_tail_lin_kernel_equals_its_oracle_restatement(ext, b, n, m, n_reg):
     P.rpn_tail_wrapper(known, idx, wgt, wcat, bcat, wc2, bc2, f0, c0, r0)
     for got, ref in ((feats, f0), (cls, c0), (reg, r0)):
         assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("b,n,m,wild", [(1, 1, 3, False), (2, 1000, 300, False), (1, 4100, 700, True), (3, 65, 17, True), (8, 16384, 4096, False)])
+def test_rpn_tail_lin_with_the_decode_inside_equals_decode_of_the_stored_rows(ext, b, n, m, wild):
+    """rpn_tail_lin_kernel<true> (round 5: the proposal layer's decode rides in the fused RPN tail, the (B, N, 76) regression tensor
+    never reaches HBM): features and scores are the bits of the row-storing kernel, and the boxes are BIT FOR BIT (a) this package's
+    decode_bbox_target (pinned to the reference's by fixture g7) + proposal_layer.py:31's y shift over the rows the other kernel
+    stores, and (b) what csrc/proposal.hip's rpn_decode_kernel makes of them -- checked through the whole proposal layer: the RoIs
+    of prcnn_rpn_proposals_boxes(boxes) equal those of prcnn_rpn_proposals(reg).  ``wild``: heading / location residuals scaled to
+    +-1e5 and a few NaN / inf rows (arg-max with NaN, the branch-free fmod at large quotients); ragged tiles; nothing written
+    outside the outputs."""
+    C = pkg("config")
+    cfg = C.default_eval_cfg()
+    dec = pkg("bbox_transform").decode_bbox_target
+    rng = np.random.default_rng(b * 1000 + n + 7)
+    n_reg = 76
+    known, idx, wgt, wcat, bcat, wc2, bc2 = _rpn_tail_case(rng, b, n, m, n_reg)
+    if wild:
+        wcat = wcat.clone(); bcat = bcat.clone()
+        wcat[640:, 24:48] *= 3e4; wcat[640:, 61:73] *= 1e5               # residual columns
+        bcat[4, 61] = 3e38; bcat[4, 30] = -1e30
+    P = ext.pointnet2
+    G = P.packed_layer_wrapper(known.view(b * m, 256), wcat[:256].contiguous(), torch.zeros(128, device=DEV), False,
+                               torch.empty((b * m, 128), device=DEV)).view(b, m, 128)
+    if wild and b * m > 10:
+        G.view(-1, 128)[3] = float("nan"); G.view(-1, 128)[7] = float("inf")     # rows that interpolate these carry NaN / inf through the heads
+    wlin = wcat[256:].contiguous()
+    xyz = T(rng.uniform([-40, -1, 0.5], [40, 3, 70], (b, n, 3)).astype(np.float32))
+    feats = torch.empty((b, n, 128), device=DEV); cls = torch.empty((b, n, 1), device=DEV); reg = torch.empty((b, n, n_reg), device=DEV)
+    P.rpn_tail_lin_wrapper(G, idx, wgt, wlin, bcat, wc2, bc2, feats, cls, reg)
+    anchor = [float(v) for v in np.asarray(cfg.CLS_MEAN_SIZE[0], dtype=np.float32)]
+    assert P.rpn_tail_boxes_supported(n_reg, cfg.RPN.LOC_SCOPE, cfg.RPN.LOC_BIN_SIZE, cfg.RPN.NUM_HEAD_BIN, cfg.RPN.LOC_XZ_FINE)
+    assert not P.rpn_tail_boxes_supported(n_reg, cfg.RPN.LOC_SCOPE, cfg.RPN.LOC_BIN_SIZE / 2, cfg.RPN.NUM_HEAD_BIN, True)
+    guard = torch.full((b * n + 8, 7), float("nan"), device=DEV)
+    boxes = guard[:b * n].view(b, n, 7)
+    f2 = torch.full((b, n, 128), float("nan"), device=DEV); c2 = torch.full((b, n, 1), float("nan"), device=DEV)
+    P.rpn_tail_lin_boxes_wrapper(G, idx, wgt, wlin, bcat, wc2, bc2, n_reg, cfg.RPN.LOC_SCOPE, cfg.RPN.LOC_BIN_SIZE, cfg.RPN.NUM_HEAD_BIN,
+                                 cfg.RPN.LOC_XZ_FINE, anchor, xyz, f2, c2, boxes)
+    torch.cuda.synchronize()
+    assert torch.isnan(guard[b * n:]).all()
+    same = lambda x, y: torch.equal(torch.nan_to_num(x, nan=1.25e38), torch.nan_to_num(y, nan=1.25e38))
+    assert same(f2, feats) and same(c2, cls)
+    want = dec(xyz.view(-1, 3), reg.view(-1, n_reg), anchor_size=torch.tensor(anchor, device=DEV), loc_scope=cfg.RPN.LOC_SCOPE,
+               loc_bin_size=cfg.RPN.LOC_BIN_SIZE, num_head_bin=cfg.RPN.NUM_HEAD_BIN, get_xz_fine=cfg.RPN.LOC_XZ_FINE, get_y_by_bin=False,
+               get_ry_fine=False)
+    want[:, 1] += want[:, 3] / 2
+    got = boxes.view(-1, 7)
+    bad = ~((got == want) | (torch.isnan(got) & torch.isnan(want)))
+    assert not bool(bad.any()), (int(bad.sum()), got[bad.any(1)][:4], want[bad.any(1)][:4], reg.view(-1, n_reg)[bad.any(1)][:4, 49:73])
+    if wild:
+        assert float(reg[..., 61:73].abs().max()) > 1e4 or b * n < 10
+    # (b) through the proposal layer: decoded-in-the-tail boxes vs rows decoded by rpn_decode_kernel
+    if not wild and n >= 1000:
+        scores = cls.view(b, n).contiguous()
+        M = 100
+        r1 = torch.empty((b, M, 7), device=DEV); s1 = torch.empty((b, M), device=DEV)
+        r2 = torch.empty((b, M, 7), device=DEV); s2 = torch.empty((b, M), device=DEV)
+        ext.iou3d.rpn_proposals(xyz, scores, reg, anchor, cfg.RPN.LOC_SCOPE, cfg.RPN.LOC_BIN_SIZE, cfg.RPN.NUM_HEAD_BIN, True, 9000, M, 0.8,
+                                False, r1, s1)
+        ext.iou3d.rpn_proposals_boxes(scores, boxes, 9000, M, 0.8, False, r2, s2)
+        assert torch.equal(r1, r2) and torch.equal(s1, s2) and float(r1.abs().sum()) > 0
+
+
+def test_branch_free_fmod_by_two_pi_equals_fmodf(ext):
+    """The fused decode takes torch.remainder's fmod without the library's loop (csrc/rpn_tail.hip fmod_two_pi: three exact f64
+    reduction steps): bit for bit fmodf(a, (float)(2 pi)) on the same device -- uniform values, every binade up to 3.4e38 in both
+    signs, neighbours of multiples of 2 pi, zeros, denormals, inf, NaN."""
+    rng = np.random.default_rng(9)
+    two_pi = np.float32(2.0 * np.pi)
+    mult = (np.arange(1, 200001, dtype=np.float64) * float(two_pi)).astype(np.float32)
+    parts = [rng.uniform(-100, 100, 1 << 20).astype(np.float32),
+             (rng.uniform(1, 2, 1 << 20) * np.exp2(rng.integers(-149, 128, 1 << 20))).astype(np.float32) * rng.choice([-1, 1], 1 << 20).astype(np.float32),
+             mult, np.nextafter(mult, np.float32(0)), np.nextafter(mult, np.float32(np.inf)), -mult,
+             (mult.astype(np.float64) * 1e6).astype(np.float32), (mult.astype(np.float64) * 1e30).astype(np.float32),
+             np.array([0.0, -0.0, 1e-45, -1e-45, 1e-39, 3.4028235e38, -3.4028235e38, np.inf, -np.inf, np.nan, two_pi, -two_pi], np.float32)]
+    a = T(np.concatenate(parts))
+    mine, lib = ext.pointnet2.selftest_fmod_two_pi(a)
+    mi, li = mine.view(torch.int32), lib.view(torch.int32)
+    bad = (mi != li) & ~(torch.isnan(mine) & torch.isnan(lib))
+    assert not bool(bad.any()), (int(bad.sum()), a[bad][:8], mine[bad][:8], lib[bad][:8])
+    assert bool(torch.isnan(mine[-3])) and bool(torch.isnan(mine[-5])) and float(mine[-2]) == 0.0
 
 
 def test_rpn_tail_kernel_equals_the_separate_kernels_at_the_batch8_shape(ext):

@@ -216,6 +216,7 @@ POINTNET2 = {
     "rows_dot_wrapper": {3: "exact"},
     "rpn_tail_wrapper": {7: "exact", 8: "exact", 9: "exact"},     # finest FP module + both heads in one kernel (PRCNN_NO_FP_LINEAR=1)
     "rpn_tail_lin_wrapper": {7: "exact", 8: "exact", 9: "exact"}, # ... its first layer applied at the coarse level
+    "rpn_tail_lin_boxes_wrapper": {14: "exact", 15: "exact", 16: "exact"},   # ... and the proposal layer's decode inside (round 5): features, scores, BOXES
     "rcnn_point_mlp_wrapper": None,                # filled below
 }
 
@@ -397,7 +398,8 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
                   "ball_query_full_wrapper": 8, "ball_query_wrapper": 0 if fg else 1, "ball_query_limit_wrapper": 0 if fg else 1, "rcnn_roi_geometry_wrapper": 1 if fg else 0, "three_nn_wrapper": 0, "three_nn_weights_wrapper": 4, "ball_pack_wrapper": 11,
                   "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 4,
                   "three_interpolate_cat_pm_wrapper": 0 if F.USE_FP_LINEAR else 3, "packed_layer_interp_wrapper": 3 if F.USE_FP_LINEAR else 0,
-                  "rpn_tail_wrapper": 0 if F.USE_FP_LINEAR else 1, "rpn_tail_lin_wrapper": 1 if F.USE_FP_LINEAR else 0, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
+                  "rpn_tail_wrapper": 0 if F.USE_FP_LINEAR else 1, "rpn_tail_lin_wrapper": 1 if F.USE_FP_LINEAR and not F.USE_TAIL_DECODE else 0,
+                  "rpn_tail_lin_boxes_wrapper": 1 if F.USE_FP_LINEAR and F.USE_TAIL_DECODE else 0, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
     want_calls.update({"packed_layer_segmax_batch_wrapper": 2, "packed_gather_affine_batch_wrapper": 2, "packed_layer_batch_wrapper": 5})   # RPN SA3, SA4; the two branches of the RCNN head (round 4)
     if wide_fused:       # the RCNN's GroupAll level (every row distinct: 800 units of work) in one kernel
         f3 = 1 if F.USE_WIDE_FUSED3 else 0   # ... and its per-point layer inside that kernel (csrc/sa_wide3.hip)
