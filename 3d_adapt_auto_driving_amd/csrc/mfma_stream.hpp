@@ -20,7 +20,7 @@
 //   * the 64 weight loads of the NEXT panel stage (wn <- rows krow.. of the weight buffer) go out four per group, behind
 //     this group's first MFMAs, instead of 64 in a row in front of the stage (their issue alone was ~10 % of a stage);
 //   * FIRST: the accumulators start from the inline constant 0 in the first MFMA (no 32 v_mov per stage).
-#define RT_STAGE_HOOK(T, wf, wn, RS, krow, FIRST, HOOK)                                                                \
+#define RT_STAGE_HOOK_LO(T, wf, wn, RS, krow, FIRST, HOOK, LOFF)                                                     \
     {                                                                                                     \
         f32x4 a0 = *reinterpret_cast<const f32x4 *>((T) + j * RT_LD + 64 * h);                            \
         f32x4 a1 = *reinterpret_cast<const f32x4 *>((T) + (32 + j) * RT_LD + 64 * h);                     \
@@ -41,7 +41,7 @@
             }                                                                                             \
             _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                 \
                 wn[4 * g + q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(                     \
-                    RS, lane_off, (unsigned int)((krow) + 4 * g + q) * 512u, 0));                         \
+                    RS, (LOFF), (unsigned int)((krow) + 4 * g + q) * 512u, 0));                           \
             __builtin_amdgcn_sched_barrier(0);                                                            \
             HOOK(g)                                                                                       \
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wf[4 * g + 1], acc0, 0, 0, 0);              \
@@ -56,6 +56,9 @@
 //   * HOOK(g): side work of the caller issued behind the first two MFMAs of k-group g (g is a compile-time constant after
 //     unrolling): a wave has ~14 free issue cycles behind every MFMA (profiles/r02_stage_stamps.md), enough for a few
 //     instructions per group that would otherwise sit in a phase of their own in front of a stage
+//   * LOFF: the lane's byte offset for the NEXT stage's weight slice (RT_STAGE_HOOK: lane_off, the slice this wave owns in every layer;
+//     rpn_tail_lin_kernel's narrow last stage gives its waves other column blocks)
+#define RT_STAGE_HOOK(T, wf, wn, RS, krow, FIRST, HOOK) RT_STAGE_HOOK_LO(T, wf, wn, RS, krow, FIRST, HOOK, lane_off)
 #define RT_NO_HOOK(g)
 #define RT_STAGE(T, wf, wn, RS, krow, FIRST) RT_STAGE_HOOK(T, wf, wn, RS, krow, FIRST, RT_NO_HOOK)
 // act(acc + bias) of this wave's 64 x 32 block -> tile T (the next layer's A operand)

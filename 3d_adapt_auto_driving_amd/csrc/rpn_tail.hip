@@ -276,7 +276,14 @@ __global__ __launch_bounds__(256, 1) void rpn_tail_kernel(const RpnTailArgs a)
 // 16 rows per wave, spread over four k-groups of the NEXT tile's first stage like the row stores it replaces; no control flow.
 // The layout is the shipped one only (12 + 12 + 12 + 12 + 1 + 12 + 12 + 3 = 76 channels: every cfgs/*.yaml); other layouts keep `reg`.
 constexpr int RD_NB = 12;           // per_loc_bin_num = 2 * int(LOC_SCOPE / LOC_BIN_SIZE) = 2 * int(3.0 / 0.5), = NUM_HEAD_BIN
-template <bool DECODE>
+// NARROW (round 5, 64 < n_reg <= 80: the 76 channels of the shipped configurations): the last stage computes 80 columns instead of a
+// zero-padded 128 -- until then 52 of its 128 columns (10 % of the kernel's MFMAs) multiplied padding.  Columns 0..63 = two 32-column
+// blocks x two 32-row blocks, ONE block per wave (v_mfma_f32_32x32x2_f32, the k order of every other layer: the same bits as
+// before); columns 64..79 = a 16-column block, 16 rows per wave, on v_mfma_f32_16x16x4_f32 -- bitwise a chain of fused multiply-adds
+// too (profiles/mfma16_probe.hip: 0 of 51 200 outputs differ), step s = 0..31 over k = s, 32 + s, 64 + s, 96 + s in that order
+// (oracle/mlp_oracle.c orc_rows_layer_mfma16).  96 MFMA issues of 64 / 32 cycles per wave instead of 128 of 64: 5120 cycles, not 8192.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <bool DECODE, bool NARROW>
 __global__ __launch_bounds__(256, 1) void rpn_tail_lin_kernel(const RpnTailArgs a)
 {
     __shared__ float T0[RT_ROWS * RT_LD];
@@ -295,6 +302,11 @@ __global__ __launch_bounds__(256, 1) void rpn_tail_lin_kernel(const RpnTailArgs 
     const f32x4 bias1v = *reinterpret_cast<const f32x4 *>(a.bcat + 4 * j);
     const float bias2 = a.bcat[128 + 32 * w + j], biasc = a.bcat[256 + 32 * w + j], biasr1 = a.bcat[384 + 32 * w + j],
                 biasr2 = a.bcat[512 + 32 * w + j];
+    // NARROW last stage: wave w = 32 x 32 block (row block w & 1, column block w >> 1) + rows 16 w .. 16 w + 15 of the 16-column block
+    const int nrb = w & 1, ncb = w >> 1;
+    const unsigned int lane_off_n = ((unsigned int)(64 * h) * 128u + (unsigned int)(32 * ncb + j)) * 4u;          // k = s + 64 h, column 32 ncb + j
+    const unsigned int lane_off_x = ((unsigned int)(32 * (lane >> 4)) * 128u + (unsigned int)(64 + (lane & 15))) * 4u;   // k = s + 32 (lane / 16), column 64 + lane % 16
+    const float biasn = a.bcat[512 + 32 * ncb + j], biasx = a.bcat[512 + 64 + (lane & 15)];
     int nx_i, nx_cloud;
     float nx_w;
     f32x4 fl[2][3];
@@ -431,15 +443,74 @@ __global__ __launch_bounds__(256, 1) void rpn_tail_lin_kernel(const RpnTailArgs 
         RT_VM_DRAIN
         float sd[8];
 #define RL_H3(g) RT_SCORE(g) RL_SIDE(2, g, 2, 10)
-        RT_STAGE_HOOK(T1, wa, wb, rs, 384, true, RL_H3)
+        RT_STAGE_HOOK_LO(T1, wa, wb, rs, 384, true, RL_H3, (NARROW ? lane_off_n : lane_off))
         lds_barrier();                                         // every wave has read the cls hidden rows
         RT_EPILOGUE(T0, biasr1, true)
         lds_barrier();
         // ---- reg layer 2 (wb, no activation) while the next tile's layer 2 (wa) comes in; side: round 3
         RT_VM_DRAIN
 #define RL_H4(g) RL_SIDE(3, g, 2, 10)
-        RT_STAGE_HOOK(T0, wb, wa, rs, 0, true, RL_H4)
-        RT_EPILOGUE(T1, biasr2, false)
+        if (NARROW) {
+            float wx[32];
+            f32x4 accx;
+            {
+                const float *ap = T0 + (32 * nrb + j) * RT_LD + 64 * h;
+                f32x4 a0 = *reinterpret_cast<const f32x4 *>(ap);
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    f32x4 n0 = a0;
+                    if (g < 15) n0 = *reinterpret_cast<const f32x4 *>(ap + 4 * (g + 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g == 0) {
+                        const f32x16 zero = {0};
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wb[0], zero, 0, 0, 0);
+                    } else {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wb[4 * g + 0], acc0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)          // the next tile's first stage (FP layer 2): this wave's usual slice
+                        wa[4 * g + q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, lane_off, (unsigned int)(4 * g + q) * 512u, 0));
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)          // the 16-column block's weights, consumed behind this loop
+                        wx[2 * g + q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, lane_off_x, (unsigned int)(384 + 2 * g + q) * 512u, 0));
+                    __builtin_amdgcn_sched_barrier(0);
+                    RL_H4(g)
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wb[4 * g + 1], acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, wb[4 * g + 2], acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, wb[4 * g + 3], acc0, 0, 0, 0);
+                    a0 = n0;
+                }
+                const float *xp = T0 + (16 * w + (lane & 15)) * RT_LD + 32 * (lane >> 4);
+                f32x4 x = *reinterpret_cast<const f32x4 *>(xp);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    f32x4 nx = x;
+                    if (q < 7) nx = *reinterpret_cast<const f32x4 *>(xp + 4 * (q + 1));
+                    if (q == 0) {
+                        const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+                        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, wx[0], zero4, 0, 0, 0);
+                    } else {
+                        accx = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, wx[4 * q + 0], accx, 0, 0, 0);
+                    }
+                    accx = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, wx[4 * q + 1], accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, wx[4 * q + 2], accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, wx[4 * q + 3], accx, 0, 0, 0);
+                    x = nx;
+                }
+            }
+            // + bias (no activation) -> T1: this wave's 32 x 32 block, then its 16 rows of columns 64..79 (columns 80.. keep what the
+            // FP layer left there: nobody reads them)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * nrb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                T1[row * RT_LD + 32 * ncb + j] = acc0[r] + biasn;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T1[(16 * w + 4 * (lane >> 4) + r) * RT_LD + 64 + (lane & 15)] = accx[r] + biasx;
+        } else {
+            RT_STAGE_HOOK(T0, wb, wa, rs, 0, true, RL_H4)
+            RT_EPILOGUE(T1, biasr2, false)
+        }
         tp = t;
         t = tn;
         last = true;
@@ -536,8 +607,14 @@ static int rpn_tail_lin_any(int b, int n, int m, const float *G, const int *idx,
     // a workgroup draws only from partition blockIdx.x & 7 (no stealing): every non-empty partition needs a workgroup of its own --
     // with fewer than 8 workgroups for 8 or more tiles (PRCNN_MFMA_GRID < 8) the tiles come from one counter instead
     a.xcd_split = xcd_split && (grid >= 8 || grid == tiles);
-    if (boxes) hipLaunchKernelGGL(rpn_tail_lin_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(rpn_tail_lin_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    // the narrow last stage (80 columns instead of 128) for 64 < n_reg <= 80; PRCNN_TAIL_NARROW=0: the padded stage everywhere (another
+    // k order in columns 64.. -- a numerics switch: ~1e-7 relative)
+    static const bool narrow_ok = !(getenv("PRCNN_TAIL_NARROW") && atoi(getenv("PRCNN_TAIL_NARROW")) == 0);
+    const bool narrow = narrow_ok && n_reg > 64 && n_reg <= 80;
+    if (boxes && narrow) hipLaunchKernelGGL((rpn_tail_lin_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    else if (boxes) hipLaunchKernelGGL((rpn_tail_lin_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    else if (narrow) hipLaunchKernelGGL((rpn_tail_lin_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((rpn_tail_lin_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch(who);
 }
 

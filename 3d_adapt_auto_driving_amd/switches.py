@@ -35,6 +35,7 @@ SWITCHES = {
     "PRCNN_NO_FP_LINEAR": ("numerics", "unset", "net/fast_infer.py", "FP layer 1 over the interpolated tensor (reference association) instead of interp(W f)"),
     "PRCNN_LIB_GEMM": ("numerics", "unset", "net/fast_infer.py", "per-point layers through torch (library GEMM) instead of csrc/packed_layer.hip"),
     "PRCNN_ALLOW_LIB_GEMM": ("numerics", "unset", "net/fast_infer.py", "1: permit a library GEMM for a shape the layer kernels do not cover (else: error)"),
+    "PRCNN_TAIL_NARROW": ("numerics", "1", "csrc/rpn_tail.hip", "0: the RPN regression head's last layer as a zero-padded 128-column stage (rounds 2-4) instead of 64 columns on 32x32x2 + 16 on v_mfma_f32_16x16x4_f32 (another k order in columns 64..75, ~1e-7 relative; the oracle stand-in reads the same switch)"),
     "PRCNN_ROWS_GEMM": ("numerics", "unset", "net/fast_infer.py", "128-wide row layers through rows_gemm128 (round-1 form)"),
     # ---- scheduling A/B (same results)
     "PRCNN_EARLY_LEVELS": ("ab", "4", "net/fast_infer.py", "leading SA levels computed with the geometry"),

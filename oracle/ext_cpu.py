@@ -7,6 +7,7 @@ code on CPU tensors with the oracle as the operator backend.  The shipped packag
 this file and has no CPU path of its own.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -43,6 +44,9 @@ class _CpuPack:
 
     def record_stream(self, stream):
         pass
+
+
+TAIL_NARROW = os.environ.get("PRCNN_TAIL_NARROW", "1") != "0"     # mirrors csrc/rpn_tail.hip's switch (which k order columns 64.. of the 76-wide regression layer take)
 
 
 class pointnet2_cpu:
@@ -352,6 +356,12 @@ class pointnet2_cpu:
         pointnet2_cpu.rows_dot_wrapper(hc, wc2.view(128, 1), bc2, cls.view(b * n, 1))
         hr = layer(feats.view(b * n, 128), 256, 384, 3, True, torch.empty((b * n, 128)))
         layer(hr, 384, 512, 4, False, reg.view(b * n, -1))
+        n_reg = reg.shape[-1]
+        if 64 < n_reg <= 80 and TAIL_NARROW:
+            # the kernel's narrow last stage (round 5): columns 64.. on v_mfma_f32_16x16x4_f32, another k order (orc_rows_layer_mfma16)
+            w4, b4, r2 = wcat[384:512].contiguous(), bcat[4].contiguous(), reg.view(b * n, n_reg)
+            O.lib().orc_rows_layer_mfma16(C.c_long(b * n), 64, n_reg - 64, _p(hr, _f), C.c_long(128), _p(w4, _f), 128, _p(b4, _f), 0,
+                                          C.cast(r2.data_ptr(), _f), C.c_long(r2.stride(0)))
         return feats, cls, reg
 
     @staticmethod

@@ -72,6 +72,25 @@ void orc_rows_layer_mfma(long rows, int K, int n, const float *A, long lda, cons
     }
 }
 
+/* out[r][c0..c0+n) = act(A[r][0..128) @ W[:, c0..c0+n) + bias[c0..]) in the order of v_mfma_f32_16x16x4_f32 as csrc/rpn_tail.hip's
+ * narrow last stage feeds it (round 5; the instruction is bitwise an fma chain over its four k values, profiles/mfma16_probe.hip):
+ * step s = 0..31 accumulates k = s, 32 + s, 64 + s, 96 + s in that order.  W (128, ldw) k-major. */
+void orc_rows_layer_mfma16(long rows, int c0, int n, const float *A, long lda, const float *W, int ldw, const float *bias, int do_relu,
+                           float *out, long ldo)
+{
+#pragma omp parallel for schedule(static)
+    for (long r = 0; r < rows; ++r) {
+        const float *a = A + r * lda;
+        for (int c = c0; c < c0 + n; ++c) {
+            float acc = 0.f;
+            for (int s = 0; s < 32; ++s)
+                for (int kk = 0; kk < 4; ++kk) acc = fmaf(a[32 * kk + s], W[(long)(32 * kk + s) * ldw + c], acc);
+            const float v = acc + bias[c];
+            out[r * ldo + c] = do_relu ? relu(v) : v;
+        }
+    }
+}
+
 /* csrc/sa_mlp_fused.hip and csrc/sa_packed.hip: one set-abstraction scale, all nsample rows of every group (duplicates
  * included -- this is the reference's semantics; the packed kernel must give the same bits without them). */
 void orc_sa_mlp_fused(int b, int n, int m, int ns, int c3, const float *new_xyz, const float *xyz, const float *P,

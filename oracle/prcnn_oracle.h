@@ -107,6 +107,8 @@ void orc_set_num_threads(int t);
 /* ---- mlp_oracle.c: the shared-MLP kernels this build owns, restated in THEIR fixed summation order (bit-exact checks).
  * csrc/sa_mlp_fused.hip + csrc/sa_packed.hip */
 void orc_set_mfma_korder(int k);
+void orc_rows_layer_mfma16(long rows, int c0, int n, const float *A, long lda, const float *W, int ldw, const float *bias, int do_relu,
+                           float *out, long ldo);
 void orc_rows_layer_mfma(long rows, int K, int n, const float *A, long lda, const float *W, const float *bias, int do_relu,
                          float *out, long ldo);
 void orc_sa_mlp_fused(int b, int n, int m, int ns, int c3, const float *new_xyz, const float *xyz, const float *P,
