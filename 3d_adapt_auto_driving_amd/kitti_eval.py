@@ -184,59 +184,55 @@ def calculate_iou(dt_annos, gt_annos, metric, device_id=0):
 # per-image bookkeeping
 # ---------------------------------------------------------------------------------------------------
 def clean_data(gt_anno, dt_anno, current_class, dataset, difficulty):
-    """-> num_valid_gt, ignored_gt (0 care / 1 ignore / -1 other class), ignored_dt, dc_bboxes
-    (eval2.py:28-98): difficulty = distance band + occlusion/truncation caps; the image-height rule of the
-    official protocol is switched off in the reference."""
+    """-> num_valid_gt, ignored_gt (n_gt) i64: 0 care / 1 ignore / -1 other class, ignored_dt (n_dt) i64, dc_bboxes (k, 4)
+    (the per-image bookkeeping of evaluate/eval2.py:28-98, whole-array): a ground-truth box is CARED FOR when it carries the evaluated
+    class name and passes the difficulty level's caps -- occlusion, truncation, and the distance band the reference uses instead of
+    the official image-height rule; it is IGNORED (matches cost nothing) when it fails a cap or carries the neighbouring class
+    (Van for Car, Person_sitting for Pedestrian); everything else is another class.  A detection outside the distance band is
+    ignored, one of another class does not take part.  DontCare boxes are handed back for the false-positive exemption."""
     cls = CLASS_NAMES[current_class]
-    lo, hi = DIST_BOUNDARY[0, difficulty], DIST_BOUNDARY[1, difficulty]
-    ignored_gt, dc_bboxes = [], []
-    num_valid_gt = 0
-    for i in range(len(gt_anno["name"])):
-        name = gt_anno["name"][i].lower()
-        if name == cls:
-            valid_class = 1
-        elif cls == "pedestrian" and name == "person_sitting":
-            valid_class = 0
-        elif cls == "car" and name == "van":
-            valid_class = 0
-        else:
-            valid_class = -1
-        ignore = (gt_anno["occluded"][i] > MAX_OCCLUSION[difficulty] or gt_anno["truncated"][i] > MAX_TRUNCATION[difficulty]
-                  or not (lo < gt_anno["location"][i, 2] < hi))
-        if valid_class == 1 and not ignore:
-            ignored_gt.append(0)
-            num_valid_gt += 1
-        elif valid_class == 0 or (ignore and valid_class == 1):
-            ignored_gt.append(1)
-        else:
-            ignored_gt.append(-1)
-        if gt_anno["name"][i] == "DontCare":
-            dc_bboxes.append(gt_anno["bbox"][i])
-    ignored_dt = []
-    for i in range(len(dt_anno["name"])):
-        if not (lo < dt_anno["location"][i, 2] < hi):
-            ignored_dt.append(1)
-        elif dt_anno["name"][i].lower() == cls:
-            ignored_dt.append(0)
-        else:
-            ignored_dt.append(-1)
-    return num_valid_gt, ignored_gt, ignored_dt, dc_bboxes
+    near, far = DIST_BOUNDARY[0, difficulty], DIST_BOUNDARY[1, difficulty]
+    raw = np.asarray(gt_anno["name"], dtype=str).reshape(-1)
+    names = np.char.lower(raw) if raw.size else raw
+    depth = np.asarray(gt_anno["location"], dtype=np.float64).reshape(-1, 3)[:, 2]
+    capped = ((np.asarray(gt_anno["occluded"]).reshape(-1) > MAX_OCCLUSION[difficulty]) |
+              (np.asarray(gt_anno["truncated"]).reshape(-1) > MAX_TRUNCATION[difficulty]) | ~((near < depth) & (depth < far)))
+    own = names == cls
+    sibling = names == {"pedestrian": "person_sitting", "car": "van"}.get(cls, "\0")
+    ignored_gt = np.full(names.shape, -1, dtype=np.int64)
+    ignored_gt[sibling | (own & capped)] = 1
+    ignored_gt[own & ~capped] = 0
+    dc_bboxes = np.asarray(gt_anno["bbox"], dtype=np.float64).reshape(-1, 4)[raw == "DontCare"]
+    det = np.asarray(dt_anno["name"], dtype=str).reshape(-1)
+    det_depth = np.asarray(dt_anno["location"], dtype=np.float64).reshape(-1, 3)[:, 2]
+    in_band = (near < det_depth) & (det_depth < far)
+    det_own = (np.char.lower(det) if det.size else det) == cls
+    ignored_dt = np.where(in_band, np.where(det_own, 0, -1), 1).astype(np.int64)
+    return int(np.count_nonzero(ignored_gt == 0)), ignored_gt, ignored_dt, dc_bboxes
 
 
 def get_thresholds(scores, num_gt, num_sample_pts=N_SAMPLE_PTS):
-    """Score thresholds at (about) equally spaced recall positions (eval2.py:8-25)."""
-    scores = np.sort(np.asarray(scores, dtype=np.float64))[::-1]
-    current_recall = 0
-    thresholds = []
-    n = len(scores)
-    for i, score in enumerate(scores):
-        l_recall = (i + 1) / num_gt
-        r_recall = (i + 2) / num_gt if i < n - 1 else l_recall
-        if (r_recall - current_recall) < (current_recall - l_recall) and i < n - 1:
-            continue
-        thresholds.append(score)
-        current_recall += 1 / (num_sample_pts - 1.0)
-    return thresholds
+    """Score thresholds at (about) equally spaced recall positions -- the selection rule of evaluate/eval2.py:8-25 in closed form.
+    With the true-positive scores in descending order, score i spans the recall interval [(i + 1) / num_gt, (i + 2) / num_gt] and
+    the targets are c_t = t / (num_sample_pts - 1), accumulated by repeated addition as the reference does.  Target t may take score
+    i unless the interval's far end is closer to the target than its near end (then a later score serves it better); the last score
+    serves any target.  So a_t = the first score target t may take, and since every score is offered to one target only, the score
+    taken for target t is i_t = max(a_t, i_(t-1) + 1), i.e. t + running max of (a_s - s): one comparison matrix, no loop."""
+    s = np.sort(np.asarray(scores, dtype=np.float64))[::-1]
+    n = len(s)
+    if n == 0:
+        return []
+    step = 1 / (num_sample_pts - 1.0)
+    n_targets = min(n, int(np.ceil((n + 2) / (num_gt * step))) + 2)                 # targets beyond recall n / num_gt all take the last score
+    targets = np.concatenate([[0.0], np.cumsum(np.full(max(n_targets - 1, 0), step))])     # 0, step, step + step, ...: the reference's sums
+    pos = np.arange(n)
+    near_end, far_end = (pos + 1) / num_gt, np.where(pos < n - 1, (pos + 2) / num_gt, (pos + 1) / num_gt)
+    later_is_better = (far_end[None, :] - targets[:, None]) < (targets[:, None] - near_end[None, :])
+    later_is_better[:, n - 1] = False
+    first_ok = np.argmin(later_is_better, axis=1)                                   # a_t (the last column is always admissible)
+    t = np.arange(len(targets))
+    taken = t + np.maximum.accumulate(first_ok - t)
+    return list(s[taken[taken < n]])
 
 
 def _ptr(a):
@@ -252,9 +248,9 @@ class _Split:
         for g, d in zip(gt_annos, dt_annos):
             nv, ignored_gt, ignored_dt, dc = clean_data(g, d, current_class, dataset, difficulty)
             self.num_valid_gt += nv
-            ig.append(np.array(ignored_gt, dtype=np.int64))
-            idt.append(np.array(ignored_dt, dtype=np.int64))
-            dcs.append(np.stack(dc, 0).astype(np.float64) if len(dc) else np.zeros((0, 4), np.float64))
+            ig.append(ignored_gt)
+            idt.append(ignored_dt)
+            dcs.append(dc)
             gts.append(np.concatenate([g["bbox"], g["alpha"][..., np.newaxis]], 1).astype(np.float64).reshape(-1, 5))
             dts.append(np.concatenate([d["bbox"], d["alpha"][..., np.newaxis], d["score"][..., np.newaxis]], 1)
                        .astype(np.float64).reshape(-1, 6))
@@ -308,11 +304,9 @@ def eval_class(gt_annos, dt_annos, current_classes, dataset, difficultys, metric
 
 
 def get_mAP(prec):
-    """11-point interpolation: every 4th of the 41 samples (eval2.py:572-576)."""
-    sums = 0
-    for i in range(0, prec.shape[-1], 4):
-        sums = sums + prec[..., i]
-    return sums / 11 * 100
+    """11-point interpolated AP in percent from the 41-sample precision curve: the samples at recall 0, 0.1, ..., 1 (every 4th one),
+    added left to right (a cumulative sum: the reference's order of additions, evaluate/eval2.py:572-576), over 11."""
+    return np.cumsum(prec[..., ::4], axis=-1)[..., -1] / 11 * 100
 
 
 def do_eval(gt_annos, dt_annos, current_classes, dataset, min_overlaps, compute_aos=False, device_id=0):

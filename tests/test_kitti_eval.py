@@ -67,7 +67,7 @@ def test_label_parsing_and_difficulty_bands():
     }
     for diff, (nv, ig, idt) in expect.items():
         n, g, t, dc = KE.clean_data(a, d, 0, "kitti", diff)
-        assert (n, g, t) == (nv, ig, idt), diff
+        assert (n, list(g), list(t)) == (nv, ig, idt), diff
         assert len(dc) == 1 and dc[0].tolist() == [500.0, 100.0, 600.0, 150.0]
     empty = KE.annos_from_lines([])
     assert empty["bbox"].shape == (0, 4) and empty["location"].shape == (0, 3) and empty["score"].shape == (0,)
