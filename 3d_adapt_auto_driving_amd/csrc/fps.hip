@@ -735,6 +735,274 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The speculative kernel for 16384 < n <= 32768 (round 5: tools/cfgs/double.yaml, NUM_POINTS 32768): TWO workgroups per cloud.
+//
+// 32768 points x (x, y, z, running minimum) do not fit one compute unit's registers (a 1024-thread workgroup has 128 VGPRs per thread:
+// 16 points each), and streaming half of them from L2 for every pick is what fps_generic_kernel does (~3.5 us per pick).  Here the
+// cloud in Morton order is cut in two and each half lives in the registers of a workgroup of its own, exactly as in fps_spec_kernel<16>;
+// the two workgroups run the SAME rounds in lockstep:
+//   * every wave publishes its two entries + its bound into the round's table in GLOBAL memory (64 entries, two tables alternating:
+//     a table is rewritten two rounds later, when both workgroups are provably past reading it);
+//   * one cross-workgroup barrier per round (a monotonic counter per cloud: agent-scope release add, acquire spin);
+//   * each workgroup copies the 64 entries into its LDS and computes the verdict over all 64 x 64 pairs REDUNDANTLY -- the merge is
+//     deterministic, both arrive at the same picks, no second exchange is needed; workgroup 0 writes the outputs;
+//   * each updates the running minima of its own half against the round's pivots.
+// Same picks, tie rule and running minima as the sequential scan (tests/test_gpu_ops.py: oracle-exact, lattices and duplicates).
+// Placement: the halves of a cloud are blocks q and q + 8 -- dispatched to the same XCD, one right after the other, so a half never
+// waits for a partner that cannot be scheduled behind workgroups that themselves wait (see fps_any).
+// ---------------------------------------------------------------------------------------------
+struct Fps2Table {                                                   // per cloud, in the library's scratch (zeroed `sync` per launch)
+    unsigned long long vk[2][64];
+    float xyz[2][64][4];
+    float bound[2][32];
+    unsigned int sync;
+    unsigned int pad[63];
+};
+
+__device__ __forceinline__ unsigned long long ld_agent_u64(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent_f32(const float *p)
+{
+    return __int_as_float(__hip_atomic_load(reinterpret_cast<const int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+__global__ __launch_bounds__(1024) void fps_spec2_kernel(
+    int nclouds, int n, int m, KeyCodec kc, const float *__restrict__ xyz, const int *__restrict__ perm,
+    float *__restrict__ temp, int *__restrict__ idx, float *__restrict__ new_xyz, Fps2Table *__restrict__ tables)
+{
+    constexpr int PPT = 16, SB = 4, NE = 64;
+    __shared__ unsigned long long s_vk[NE];
+    __shared__ float s_xyz[NE][3];
+    __shared__ float s_bound[32];
+    __shared__ float s_res[64];
+    __shared__ int s_rank[NE], s_blk[NE];
+    __shared__ unsigned long long s_evk[32];                         // this workgroup's published entries between rebuilds (the registers are full)
+    __shared__ float s_exyz[32][3], s_eb[16];
+    // blocks q and q + 8 (same XCD) are the two halves of cloud (q / 16) * 8 + q % 8
+    const int q_ = blockIdx.x;
+    const int b = (q_ >> 4) * 8 + (q_ & 7), half = (q_ >> 3) & 1;
+    if (b >= nclouds) return;
+    const float *__restrict__ cloud = xyz + (long)b * n * 3;
+    const int *__restrict__ order = perm + (long)b * n;
+    float *__restrict__ mind = temp ? temp + (long)b * n : nullptr;
+    int *__restrict__ sel = idx + (long)b * m;
+    float *__restrict__ nxyz = new_xyz ? new_xyz + (long)b * m * 3 : nullptr;
+    Fps2Table *__restrict__ tb = tables + b;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, gw = 16 * half + w;       // gw: this wave among the cloud's 32
+    __builtin_amdgcn_s_setprio(3);
+
+    float px[PPT], py[PPT], pz[PPT], pt[PPT];
+    uint32_t pc[PPT];
+    float bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY, bz0 = INFINITY, bz1 = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int s = gw * (64 * PPT) + i * 64 + lane;
+        float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY, z0 = INFINITY, z1 = -INFINITY;
+        if (s < n) {
+            const int k = order[s];
+            px[i] = cloud[3 * k]; py[i] = cloud[3 * k + 1]; pz[i] = cloud[3 * k + 2];
+            pt[i] = mind ? mind[k] : 1e10f;
+            pc[i] = (kc.encode(k) << SB) | (uint32_t)i;
+            x0 = x1 = px[i]; y0 = y1 = py[i]; z0 = z1 = pz[i];
+        } else {
+            px[i] = py[i] = pz[i] = 0.f;
+            pt[i] = -INFINITY;
+            pc[i] = 0xffffffffu;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            x0 = fminf(x0, __shfl_xor(x0, d, 64)); x1 = fmaxf(x1, __shfl_xor(x1, d, 64));
+            y0 = fminf(y0, __shfl_xor(y0, d, 64)); y1 = fmaxf(y1, __shfl_xor(y1, d, 64));
+            z0 = fminf(z0, __shfl_xor(z0, d, 64)); z1 = fmaxf(z1, __shfl_xor(z1, d, 64));
+        }
+        if (lane == i) { bx0 = x0; bx1 = x1; by0 = y0; by1 = y1; bz0 = z0; bz1 = z1; }
+    }
+    constexpr int GP = 64 / PPT;
+    bx0 = __shfl(bx0, lane & (PPT - 1), 64); bx1 = __shfl(bx1, lane & (PPT - 1), 64);
+    by0 = __shfl(by0, lane & (PPT - 1), 64); by1 = __shfl(by1, lane & (PPT - 1), 64);
+    bz0 = __shfl(bz0, lane & (PPT - 1), 64); bz1 = __shfl(bz1, lane & (PPT - 1), 64);
+    unsigned long long touched = 0ull;
+    float bound = INFINITY;
+    auto box_mask = [&](float ox, float oy, float oz, bool live) __attribute__((always_inline)) {
+        const float dx = fmaxf(fmaxf(bx0 - ox, ox - bx1), 0.f);
+        const float dy = fmaxf(fmaxf(by0 - oy, oy - by1), 0.f);
+        const float dz = fmaxf(fmaxf(bz0 - oz, oz - bz1), 0.f);
+        const float lb = dx * dx + dy * dy + dz * dz;
+        return __ballot(live && !(lb * 0.99999f >= bound));
+    };
+    auto update = [&](float ox, float oy, float oz, unsigned long long mask) __attribute__((always_inline)) {
+        if (mask != 0ull) {
+            touched |= mask;
+            if (kc.hipcc) {
+#pragma unroll
+                for (int i = 0; i < PPT; ++i)
+                    if ((mask >> i) & 1ull) pt[i] = fminf(fps_dist<true>(px[i], py[i], pz[i], ox, oy, oz), pt[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PPT; ++i)
+                    if ((mask >> i) & 1ull) pt[i] = fminf(sqdist3(px[i], py[i], pz[i], ox, oy, oz), pt[i]);
+            }
+        }
+    };
+    if (t == 0 && half == 0) {
+        sel[0] = 0;
+        if (nxyz) { nxyz[0] = cloud[0]; nxyz[1] = cloud[1]; nxyz[2] = cloud[2]; }
+    }
+    if (t < NE) { s_rank[t] = 0; s_blk[t] = 0; }
+    int j = 1;
+    if (m > 1) {
+        const float ox = cloud[0], oy = cloud[1], oz = cloud[2];
+        update(ox, oy, oz, box_mask(ox, oy, oz, lane < PPT));
+    }
+    touched = ~0ull;
+    // this wave's published entries are kept in LDS between rebuilds; every round copies them into the round's table
+    unsigned int round = 0;
+    while (j < m) {
+        if (touched != 0ull) {
+            float bv = -INFINITY, sv = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                sv = fmaxf(sv, fminf(bv, pt[i]));
+                bv = fmaxf(bv, pt[i]);
+            }
+            uint32_t lk = 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const uint32_t c = pt[i] == bv ? pc[i] : 0xffffffffu;
+                lk = c < lk ? c : lk;
+            }
+            const float v1 = wave_max_f32(bv);
+            const uint32_t c1 = wave_min_u32(bv == v1 ? lk : 0xffffffffu);
+            const unsigned long long m1 = __ballot(bv == v1 && lk == c1);
+            const int l1 = m1 ? (int)__builtin_ctzll(m1) : 0;
+            const float bv2 = lane == l1 ? -INFINITY : bv;
+            const float v2 = wave_max_f32(bv2);
+            const uint32_t c2 = wave_min_u32(bv2 == v2 ? lk : 0xffffffffu);
+            const unsigned long long m2 = __ballot(lane != l1 && bv2 == v2 && lk == c2);
+            const int l2 = m2 ? (int)__builtin_ctzll(m2) : l1;
+            const float v3 = wave_max_f32((lane == l1 || lane == l2) ? -INFINITY : bv);
+            const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), l1));
+            const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), l2));
+            const float e_b = fmaxf(v3, fmaxf(s1, s2));
+            bound = v1;
+            const int sl1 = (int)(c1 & ((1u << SB) - 1u)), sl2 = (int)(c2 & ((1u << SB) - 1u));
+            const bool has2 = m2 != 0ull && c2 != 0xffffffffu;
+            float x1 = 0.f, y1 = 0.f, z1 = 0.f, x2 = 0.f, y2 = 0.f, z2 = 0.f;
+            fs_pick3<PPT>(px, py, pz, __builtin_amdgcn_readfirstlane(sl1), l1, x1, y1, z1);
+            fs_pick3<PPT>(px, py, pz, __builtin_amdgcn_readfirstlane(sl2), l2, x2, y2, z2);
+            const float ev = lane == 0 ? v1 : (has2 ? v2 : -INFINITY);
+            const uint32_t ek = lane == 0 ? (c1 == 0xffffffffu ? 0xffffffffu : (c1 >> SB)) : (has2 ? (c2 >> SB) : 0xffffffffu);
+            if (lane < 2) {
+                s_evk[2 * w + lane] = pack_candidate(ev, ek);
+                s_exyz[2 * w + lane][0] = lane == 0 ? x1 : x2; s_exyz[2 * w + lane][1] = lane == 0 ? y1 : y2; s_exyz[2 * w + lane][2] = lane == 0 ? z1 : z2;
+                if (lane == 0) s_eb[w] = e_b;
+            }
+        }
+        const int par = (int)(round & 1u);
+        if (lane < 2) {                                               // (the same lanes wrote the LDS copy: program order)
+            const int e = 2 * gw + lane, le = 2 * w + lane;
+            tb->vk[par][e] = s_evk[le];
+            tb->xyz[par][e][0] = s_exyz[le][0]; tb->xyz[par][e][1] = s_exyz[le][1]; tb->xyz[par][e][2] = s_exyz[le][2];
+            if (lane == 0) tb->bound[par][gw] = s_eb[w];
+        }
+        // ---- the round's cross-workgroup barrier: both halves have published
+        __syncthreads();
+        if (t == 0) {
+            __hip_atomic_fetch_add(&tb->sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int want = 2u * (round + 1u);
+            while (__hip_atomic_load(&tb->sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        if (t < NE) {
+            s_vk[t] = ld_agent_u64(&tb->vk[par][t]);
+            s_xyz[t][0] = ld_agent_f32(&tb->xyz[par][t][0]);
+            s_xyz[t][1] = ld_agent_f32(&tb->xyz[par][t][1]);
+            s_xyz[t][2] = ld_agent_f32(&tb->xyz[par][t][2]);
+            if (t < 32) s_bound[t] = ld_agent_f32(&tb->bound[par][t]);
+        }
+        __syncthreads();                                              // A: the table is complete (in this workgroup's LDS)
+        // ---- merge: lane = entry i, wave w compares it with entries 4 w .. 4 w + 3 (all 64 x 64 pairs over the 16 waves)
+        const int left = m - j;
+        const int i = lane;
+        const unsigned long long pki = s_vk[i];
+        float cv; uint32_t ck;
+        unpack_candidate(pki, cv, ck);
+        const float cx = s_xyz[i][0], cy = s_xyz[i][1], cz = s_xyz[i][2];
+        {
+            int rk = 0;
+            bool bl = false;
+#pragma unroll 1
+            for (int u = 0; u < 4; ++u) {
+                const int e = 4 * w + u;
+                const unsigned long long pke = s_vk[e];
+                const float ex = s_xyz[e][0], ey = s_xyz[e][1], ez = s_xyz[e][2];
+                const bool before = pke > pki;
+                const float d = kc.hipcc ? fps_dist<true>(cx, cy, cz, ex, ey, ez) : sqdist3(cx, cy, cz, ex, ey, ez);
+                rk += before ? 1 : 0;
+                bl = bl || (before && (d < cv));
+            }
+            if (rk) atomicAdd(&s_rank[i], rk);
+            if (bl) atomicOr(&s_blk[i], 1);
+        }
+        lds_barrier();                                                // A2
+        if (w == 0) {
+            const int rank = s_rank[i];
+            const bool blocked = s_blk[i] != 0;
+            const float gB = wave_max_f32(lane < 32 ? s_bound[lane] : -INFINITY);
+            const bool valid = !(ck == 0xffffffffu || !(cv > -1.0f));
+            const bool pass = rank == 0 ? true : ((cv > gB) && (cv > 0.f) && valid && !blocked);
+            const bool stop = !pass || (rank == 0 && !valid);
+            int r = (int)wave_min_u32((stop && !(rank == 0)) ? (uint32_t)rank : ((rank == 0 && !valid) ? 1u : 64u));
+            r = min(min(r, left), FS_RMAX);
+            if (r < 1) r = 1;
+            if (rank < r) {
+                const bool v0 = valid;
+                const float ox = v0 ? cx : cloud[0], oy = v0 ? cy : cloud[1], oz = v0 ? cz : cloud[2];
+                s_res[1 + 3 * rank] = ox; s_res[2 + 3 * rank] = oy; s_res[3 + 3 * rank] = oz;
+                if (half == 0) {
+                    sel[j + rank] = valid ? kc.decode(ck) : 0;
+                    if (nxyz) { nxyz[3 * (j + rank)] = ox; nxyz[3 * (j + rank) + 1] = oy; nxyz[3 * (j + rank) + 2] = oz; }
+                }
+            }
+            s_rank[i] = 0; s_blk[i] = 0;
+            if (lane == 0) s_res[0] = __int_as_float(r);
+        }
+        lds_barrier();                                                // B
+        const float rv = s_res[lane];
+        const int r = __builtin_amdgcn_readfirstlane(__float_as_int(rv));
+        j += r;
+        const int apply_n = j >= m ? r - 1 : r;
+        touched = 0ull;
+        for (int q0 = 0; q0 < apply_n; q0 += GP) {
+            const int qg = q0 + lane / PPT;
+            const int src = 1 + 3 * min(qg, FS_RMAX - 1);
+            const float gx = __shfl(rv, src, 64), gy = __shfl(rv, src + 1, 64), gz = __shfl(rv, src + 2, 64);
+            const unsigned long long masks = box_mask(gx, gy, gz, qg < apply_n);
+            if (masks == 0ull) continue;
+#pragma unroll
+            for (int g = 0; g < GP; ++g) {
+                const unsigned long long mk = (masks >> (g * PPT)) & ((1ull << PPT) - 1ull);
+                if (mk != 0ull) {
+                    const int q = q0 + g;
+                    const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 1 + 3 * q));
+                    const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 2 + 3 * q));
+                    const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 3 + 3 * q));
+                    update(ox, oy, oz, mk);
+                }
+            }
+        }
+        ++round;
+    }
+    if (mind) {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i)
+            if (pc[i] != 0xffffffffu) mind[kc.decode(pc[i] >> SB)] = pt[i];
+    }
+}
+
 // Any-n fallback: running minima stay in `temp` (global), one 1024-thread block per cloud.
 __global__ __launch_bounds__(1024) void fps_generic_kernel(
     int n, int m, KeyCodec kc, const float *__restrict__ xyz, float *__restrict__ temp,
@@ -854,7 +1122,9 @@ static int fps_any(int b, int n, int m, const float *xyz, float *temp, int *idx,
     // off when the sample count is large enough for the pruning radius to shrink.
     static const bool no_prune = getenv("PRCNN_FPS_NO_PRUNE") != nullptr;
     static const bool sequential = getenv("PRCNN_FPS_SEQUENTIAL") != nullptr;          // A/B: one pick per exchange (round 3)
-    const bool writes_xyz = !no_prune && !sequential && n > 2048 && n <= 16384 && m >= 256;
+    static const bool no_two = getenv("PRCNN_FPS_NO_PAIR") != nullptr;                 // A/B: 16384 < n <= 32768 on fps_generic_kernel (rounds 1-4)
+    const bool pair_ok = !no_prune && !sequential && !no_two && n > 16384 && n <= 32768 && m >= 256;
+    const bool writes_xyz = (!no_prune && !sequential && n > 2048 && n <= 16384 && m >= 256) || pair_ok;
     if (new_xyz && !writes_xyz) {
         if (!temp) {
             temp = (float *)scratch_for(st, (size_t)b * n * sizeof(float), 12);
@@ -865,6 +1135,26 @@ static int fps_any(int b, int n, int m, const float *xyz, float *temp, int *idx,
         if (rc != PRCNN_OK) return rc;
         hipLaunchKernelGGL(fps_gather_xyz_kernel, dim3((unsigned)((long)((m + 255) / 256) * b)), dim3(256), 0, st, n, m, xyz, idx, new_xyz);
         return check_launch("fps_new_xyz(gather)");
+    }
+    if (pair_ok) {
+        // two workgroups per cloud, blocks q and q + 8 (fps_spec2_kernel): the grid is padded to whole sets of 16 blocks
+        int *perm = (int *)scratch_for(st, (size_t)b * n * sizeof(int), 1);
+        Fps2Table *tables = (Fps2Table *)scratch_for(st, (size_t)b * sizeof(Fps2Table), 13);
+        if (!perm || !tables) { set_error("fps: cannot allocate the ordering / exchange scratch"); return PRCNN_ELAUNCH; }
+        hipLaunchKernelGGL(fps_order_kernel, dim3(b), dim3(1024), 0, st, n, xyz, perm);
+        if (hipMemsetAsync(tables, 0, (size_t)b * sizeof(Fps2Table), st) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("fps: cannot reset the exchange tables");
+            return PRCNN_ELAUNCH;
+        }
+        static const size_t pad2 = (size_t)(getenv("PRCNN_FPS_LDS_PAD") ? atoi(getenv("PRCNN_FPS_LDS_PAD")) : 84) * 1024;
+        // (the placement hint of the one-workgroup kernel is REQUIRED here: with more than half of a CU's LDS per workgroup no two of
+        //  these spinning workgroups share a CU, and every XCD dispatches a cloud's halves back to back)
+        const int rc2 = ensure_dynamic_lds((const void *)fps_spec2_kernel, pad2, "furthest_point_sampling(two workgroups)");
+        if (rc2 != PRCNN_OK) return rc2;
+        const unsigned grid = (unsigned)((b + 7) / 8) * 16u;
+        hipLaunchKernelGGL(fps_spec2_kernel, dim3(grid), dim3(1024), pad2, st, b, n, m, kc, xyz, perm, temp, idx, new_xyz, tables);
+        return check_launch("furthest_point_sampling(two workgroups)");
     }
     if (!no_prune && n > 2048 && n <= 16384 && m >= 256) {
         int *perm = (int *)scratch_for(st, (size_t)b * n * sizeof(int), 1);
@@ -979,7 +1269,7 @@ __global__ __launch_bounds__(256) void point_groups_kernel(int n, const float *_
 
 extern "C" int prcnn_point_groups(int b, int n, const float *xyz, float *pxyz, float *aabb, void *stream)
 {
-    PRCNN_REQUIRE(b >= 0 && n > 0 && n % 64 == 0 && n <= 16384 && b <= 65535, "point_groups: b=%d n=%d (n a multiple of 64, <= 16384)", b, n);
+    PRCNN_REQUIRE(b >= 0 && n > 0 && n % 64 == 0 && n <= 65536 && b <= 65535, "point_groups: b=%d n=%d (n a multiple of 64, <= 65536)", b, n);
     if (b == 0) return PRCNN_OK;
     PRCNN_REQUIRE(xyz && pxyz && aabb && (((uintptr_t)pxyz | (uintptr_t)aabb) & 15) == 0, "point_groups: null / misaligned pointer");
     hipStream_t st = (hipStream_t)stream;

@@ -578,7 +578,7 @@ static int rpn_proposals_any(int b, int n, const DecodeCfg *dc, int pre_nms_top_
 {
     int npad = 1;
     while (npad < n) npad <<= 1;
-    PRCNN_REQUIRE(npad <= 16384, "rpn_proposals: n=%d > 16384 points per scene unsupported by the fused path", n);
+    PRCNN_REQUIRE(npad <= 65536, "rpn_proposals: n=%d > 65536 points per scene unsupported by the fused path", n);   // (round 5: 32768 = tools/cfgs/double.yaml; the chunked sort and the band scan take any n)
     const int pre_near = (int)(pre_nms_top_n * 0.7), pre_far = pre_nms_top_n - pre_near;
     const int post_near = (int)(post_nms_top_n * 0.7), post_far = post_nms_top_n - post_near;
     PRCNN_REQUIRE(post_nms_top_n <= 128 && post_near >= post_far && pre_near >= pre_far, "rpn_proposals: unsupported quotas");
@@ -605,7 +605,7 @@ static int rpn_proposals_any(int b, int n, const DecodeCfg *dc, int pre_nms_top_
     if (!boxes_in)
         hipLaunchKernelGGL(rpn_decode_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, total, *dc, xyz, reg, (float *)(base + o_boxes));
     static const bool split_sort = !(getenv("PRCNN_SORT_SPLIT") && atoi(getenv("PRCNN_SORT_SPLIT")) == 0);   // A/B, same order
-    if (split_sort && npad > SS_CHUNK) {
+    if ((split_sort || npad > 16384) && npad > SS_CHUNK) {        // (the one-workgroup sort keeps all keys in LDS: 16384 at most)
         // chunks of 4096 keys sorted by a workgroup each, then pairwise merge-path rounds (ping-pong between two key buffers)
         unsigned long long *kbuf = (unsigned long long *)scratch_for(st, (size_t)2 * b * npad * sizeof(unsigned long long), 11);
         if (!kbuf) { set_error("rpn_proposals: cannot allocate the sort scratch"); return PRCNN_ELAUNCH; }

@@ -392,8 +392,8 @@ extern "C" int prcnn_roipool3d_canonical_xyz(int batch_size, int pts_num, int bo
                                              int *pooled_cnt, const float *pxyz, const float *aabb, float *xyz_out, void *stream)
 {
     PRCNN_REQUIRE((pxyz == nullptr) == (aabb == nullptr), "roipool3d_canonical: pxyz and aabb go together (prcnn_point_groups)");
-    PRCNN_REQUIRE(!pxyz || (pts_num % 64 == 0 && pts_num <= 16384 && (((uintptr_t)pxyz | (uintptr_t)aabb) & 15) == 0),
-                  "roipool3d_canonical: spatial groups need pts_num a multiple of 64, <= 16384");
+    PRCNN_REQUIRE(!pxyz || (pts_num % 64 == 0 && pts_num <= 65536 && (((uintptr_t)pxyz | (uintptr_t)aabb) & 15) == 0),
+                  "roipool3d_canonical: spatial groups need pts_num a multiple of 64, <= 65536");
     PRCNN_REQUIRE(batch_size >= 0 && pts_num >= 0 && boxes_num >= 0 && feature_len >= 0 && sampled_pts_num >= 0,
                   "roipool3d_canonical: bad sizes");
     PRCNN_REQUIRE(feature_len % 4 == 0, "roipool3d_canonical: feature length %d is not a multiple of 4", feature_len);

@@ -44,7 +44,7 @@ forward_slow = forward
 
 
 def point_groups(xyz):
-    """xyz (B,N,3), N % 64 == 0, N <= 16384 -> (pxyz (B,N,4), aabb (B,N/64,2,4)): the clouds in Morton order with the original
+    """xyz (B,N,3), N % 64 == 0, N <= 65536 -> (pxyz (B,N,4), aabb (B,N/64,2,4)): the clouds in Morton order with the original
     index in lane 3, and the bounding box of every 64-point group (csrc/fps.hip prcnn_point_groups) -- forward_canonical culls
     by group when handed these."""
     _chk(torch.float32, xyz)

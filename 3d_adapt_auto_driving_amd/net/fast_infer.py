@@ -523,7 +523,7 @@ class FastPointRCNN:
         """Spatial groups of the input clouds for the RCNN's RoI pooling (csrc/fps.hip prcnn_point_groups): xyz only, so they
         ride with the geometry chain on its side stream."""
         rp = roipool3d_utils.roipool3d_cuda
-        if not (USE_POOL_GROUPS and self.cfg.RCNN.ENABLED and has_entry(rp, "point_groups") and xyz.shape[1] % 64 == 0 and xyz.shape[1] <= 16384):
+        if not (USE_POOL_GROUPS and self.cfg.RCNN.ENABLED and has_entry(rp, "point_groups") and xyz.shape[1] % 64 == 0 and xyz.shape[1] <= 65536):
             return None
         return rp.point_groups(xyz)
 

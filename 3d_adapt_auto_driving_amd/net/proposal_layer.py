@@ -33,7 +33,7 @@ class ProposalLayer(nn.Module):
         ext = iou3d_utils.iou3d_cuda
         # (the reference reads the switch from cfg.TEST whatever the mode, proposal_layer.py:40)
         M = cfg[self.mode].RPN_POST_NMS_TOP_N
-        if (self.fused and cfg.TEST.RPN_DISTANCE_BASED_PROPOSE and N <= 16384 and M <= 128
+        if (self.fused and cfg.TEST.RPN_DISTANCE_BASED_PROPOSE and N <= 65536 and M <= 128
                 and cfg.RPN.NMS_TYPE in ("normal", "rotate") and has_entry(ext, "rpn_proposals")):
             # one extension call: decode, sort, band selection, NMS and assembly as HIP kernels
             rois = torch.empty((B, M, 7), dtype=torch.float32, device=xyz.device)

@@ -57,6 +57,7 @@ SWITCHES = {
     "PRCNN_NO_POINT_MLP": ("ab", "unset", "net/fast_infer.py", "RCNN entrance as separate layers"),
     "PRCNN_NO_ROI_GEOMETRY": ("ab", "unset", "net/fast_infer.py", "RCNN sampling / ball queries as six launches"),
     "PRCNN_NO_RPN_TAIL": ("ab", "unset", "net/fast_infer.py", "finest FP module and RPN heads layer by layer"),
+    "PRCNN_FPS_NO_PAIR": ("ab", "unset", "csrc/fps.hip", "set: sampling of 16384 < n <= 32768 points on fps_generic_kernel (rounds 1-4: 30.5 ms for 8 x 32768 -> 4096) instead of two workgroups per cloud (fps_spec2_kernel: 2.65 ms)"),
     "PRCNN_TAIL_DECODE": ("ab", "1", "net/fast_infer.py", "0: the fused RPN tail stores the (B, N, 76) regression rows and the proposal layer decodes them (rpn_decode_kernel) instead of decoding inside the tail kernel (round 5)"),
     "PRCNN_NO_SCALE_BATCH": ("ab", "unset", "net/fast_infer.py", "one launch per MSG scale"),
     "PRCNN_NO_WIDE_FUSED": ("ab", "unset", "net/fast_infer.py", "GroupAll level layer by layer"),

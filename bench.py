@@ -482,7 +482,7 @@ def main():
 
     shared_runner = {}
 
-    def timed_run(steps, warmup, batches=batches, fresh=False, keep_gc_off=False):
+    def timed_run(steps, warmup, batches=batches, fresh=False, keep_gc_off=False, key="runner", run_cfg=None):
         """W untimed + K timed steps of the pipelined runner; returns the elapsed time of the K steps and their detections"""
         # point-major engine + geometry chains on side streams; E.make_runner: the stages replayed as hipGraphs (captured once, at the
         # runner's first batch = during the set-up run below: graphs are part of the engine like the folded weights) unless PRCNN_GRAPHS=0.
@@ -490,8 +490,8 @@ def main():
         if fresh:
             runner = E.PipelinedRunner(model, cfg, dev)
         else:
-            runner = shared_runner.setdefault("runner", None) or E.make_runner(model, cfg, dev)
-            shared_runner["runner"] = runner
+            runner = shared_runner.setdefault(key, None) or E.make_runner(model, run_cfg or cfg, dev)
+            shared_runner[key] = runner
         assert runner.depth + 2 <= len(batches), "batch slots must outnumber the look-ahead"
         n_slots = len(batches)
         total = warmup + steps
@@ -686,6 +686,25 @@ def main():
                  "scene": "synth.lidar_scene: 64 beams x 0.1728 deg azimuth steps over +-40.5 deg, ground + cars + facades + poles, "
                           "~28 k raw points in PC_AREA_SCOPE -> reference near/far sampler -> 16384"}
 
+    double_leg = None
+    if world == 1 and not args.no_lidar and not args.no_roofline:
+        # ---- tools/cfgs/double.yaml (NUM_POINTS 32768, everything else default.yaml's): the same engine and runner, the same closed
+        # windows, on 32768-point scenes (round 5: sampling on two workgroups per cloud, fused proposal path up to 65536 points)
+        note('double.yaml')
+        cfg2 = C.default_eval_cfg()
+        C.merge_into({"RPN": {"NUM_POINTS": 32768}}, cfg2)
+        db = [torch.from_numpy(synth.scenes(BATCH, 32768, seed0=90000 + s * BATCH)).to(dev) for s in range(n_slots)]
+        timed_run(max(args.prewarm // 2, 4), 0, db, key="runner32k", run_cfg=cfg2)
+        d_windows = []
+        for _ in range(3):
+            t1, _ = timed_run(args.steps, args.warmup, db, key="runner32k", run_cfg=cfg2)
+            d_windows.append(args.steps * BATCH / (time.perf_counter() - t1))
+        double_leg = {"scenes_per_s": round(sorted(d_windows)[1], 1), "windows": [round(v, 1) for v in d_windows], "steps": args.steps,
+                      "points_per_scene": 32768, "what": "tools/cfgs/double.yaml:39 through make_runner(): median of 3 closed windows"}
+        shared_runner.pop("runner32k", None)
+        del db
+        torch.cuda.empty_cache()
+
     scenes_total = world * args.steps * BATCH
     line = {
         "metric": "KITTI scenes/s end-to-end eval_rcnn (joint RPN+RCNN, synthetic 16384-pt scenes)",
@@ -699,7 +718,7 @@ def main():
                    "parallelism": "scene-sharded x%d, one final all_gather of detections" % world,
                    "detections_gathered": int(counts.sum()) if rank == 0 else None,
                    "distinct_rows": distinct, "scenes_per_s_all_rows": all_rows, "scenes_per_s_k100": steady,
-                   "lidar_like": lidar,
+                   "lidar_like": lidar, "double_yaml_scenes_per_s": double_leg,
                    # every closed window of this run (W + K steps each), in run order; `value` is the median one
                    "windows": {"n": len(window_s), "reported": "median", "scenes_per_s": [round(world * args.steps * BATCH / w, 1) for w in window_s],
                                "min": round(world * args.steps * BATCH / max(window_s), 1), "max": round(world * args.steps * BATCH / min(window_s), 1)},

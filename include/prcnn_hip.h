@@ -98,7 +98,7 @@ int prcnn_set_fps_arithmetic(int mode);
 
 /* FPS with the selected points' coordinates written beside their indices: the result of furthest_point_sample + gather_operation
  * (pointnet2_modules.py:40-46) in one launch (no scratch fill, index cast or gather by the caller).  Served shapes: n <= 1024 (many small
- * clouds, a wave or four per cloud) and, since round 4, 2048 < n <= 16384 with m >= 256 (the speculative kernel).  Same selection, same
+ * clouds, a wave or four per cloud) and, since round 4, 2048 < n <= 16384 with m >= 256 (the speculative kernel; round 5: 16384 < n <= 32768 on two workgroups per cloud, and every other shape through an internal distance scratch + gather).  Same selection, same
  * tie rule as prcnn_furthest_point_sampling. */
 int prcnn_fps_new_xyz(int b, int n, int m, const float *xyz, int *idx, float *new_xyz, void *stream);
 
@@ -412,7 +412,7 @@ int prcnn_point_aux(long rows, float thresh, const float *scores, const float *x
  * decode -> per-scene score sort -> (0,40] / (40,80] m band selection (top 70 % / 30 % of pre_nms_top_n,
  * with the "no far points" fallback) -> batched NMS -> rois (b, post_nms_top_n, 7) + raw scores, zero padded.
  * xyz (b,n,3), scores (b,n), reg (b,n,channels); anchor_size_host = 3 floats in HOST memory (h,w,l).
- * n <= 16384 per scene. */
+ * n <= 65536 per scene (round 5: the chunked sort and the band scan take any n; tools/cfgs/double.yaml has 32768). */
 int prcnn_rpn_proposals(int b, int n, int channels, float loc_scope, float loc_bin_size, int num_head_bin,
                         int xz_fine, const float *anchor_size_host, int pre_nms_top_n, int post_nms_top_n,
                         float nms_thresh, int rotated_nms, const float *xyz, const float *scores,
@@ -453,7 +453,7 @@ int prcnn_roipool3d(int batch_size, int pts_num, int boxes_num, int feature_in_l
  * columns are written only for rows < round_up(cnt, 64): the coordinate / mask / depth columns of all rows are. */
 /* pxyz / aabb (optional, both or neither): the cloud's spatial groups from prcnn_point_groups -- the selection then tests
  * pts_num / 64 group boxes and reads the few groups that can hold a point of the box instead of sweeping all points; same
- * points, same order (the hits are sorted by original index).  pts_num % 64 == 0, <= 16384. */
+ * points, same order (the hits are sorted by original index).  pts_num % 64 == 0, <= 65536. */
 int prcnn_roipool3d_canonical(int batch_size, int pts_num, int boxes_num, int feature_len, int sampled_pts_num,
                               float pool_extra_width, const float *xyz, const float *rois, const float *feats,
                               const float *seg_mask, const float *depth, float *pooled, int *pooled_empty_flag,
@@ -464,7 +464,7 @@ int prcnn_roipool3d_canonical_xyz(int batch_size, int pts_num, int boxes_num, in
                                   float pool_extra_width, const float *xyz, const float *rois, const float *feats,
                                   const float *seg_mask, const float *depth, float *pooled, int *pooled_empty_flag,
                                   int *pooled_cnt, const float *pxyz, const float *aabb, float *xyz_out, void *stream);
-/* Spatial groups of clouds xyz (b,n,3), n % 64 == 0, n <= 16384: pxyz (b,n,4) = the points in Morton order over (x,z) with the
+/* Spatial groups of clouds xyz (b,n,3), n % 64 == 0, n <= 65536: pxyz (b,n,4) = the points in Morton order over (x,z) with the
  * original index in the 4th lane (int bits), aabb (b, n/64, 2, 4) = min / max corner of every 64-point group.  Any box-vs-cloud
  * sweep (RoI pooling here) can cull by group.  Not part of the reference ABI. */
 int prcnn_point_groups(int b, int n, const float *xyz, float *pxyz, float *aabb, void *stream);

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import pkg
 from helpers import scene, scenes, bev_boxes, boxes3d
 
 pytestmark = pytest.mark.gpu
@@ -44,6 +45,33 @@ def test_fps_tie_rule_lattice_and_duplicates(ext, oracle):
     dup = np.repeat(scene(3, 256), 4, axis=0)[None]                     # every point 4 times
     dup = dup[:, rng.permutation(dup.shape[1])]
     for xyz, m in ((lat, 512), (dup, 300), (lat[:, :700], 128)):
+        got, _ = fps_gpu(ext, xyz, m)
+        assert np.array_equal(got, oracle.furthest_point_sample(xyz, m))
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 32768, 4096), (1, 16385, 4096), (9, 20000, 300), (3, 32768, 8192), (17, 24576, 256)])
+def test_fps_two_workgroups_per_cloud(ext, oracle, b, n, m):
+    """16384 < n <= 32768 (tools/cfgs/double.yaml: NUM_POINTS 32768): fps_spec2_kernel -- the cloud's halves in the registers of TWO
+    workgroups that run the speculative rounds in lockstep over a table in global memory (round 5) -- gives the oracle's picks and
+    running minima bit for bit: uniform scenes, a cloud count that does not fill the last set of 16 blocks, a ragged second half
+    (n = 16385: the second workgroup holds ONE point), LiDAR-shaped density."""
+    S = pkg("synth")
+    xyz = scenes(b, n, seed0=n + m) if b != 3 else np.stack([S.lidar_scene(40 + i, n) for i in range(b)], 0)
+    got, gtemp = fps_gpu(ext, xyz, m)
+    want, wtemp = oracle.furthest_point_sample(xyz, m, return_temp=True)
+    assert np.array_equal(got, want)
+    assert np.array_equal(gtemp, wtemp)
+
+
+def test_fps_two_workgroups_tie_rule_lattice_and_duplicates(ext, oracle):
+    """the same kernel on clouds full of EXACT ties: a 32 x 16 x 48 integer lattice (24576 points) and a cloud whose every point occurs
+    four times -- the (bitrev(k mod bs), k div bs) tie rule decides thousands of picks, across the two workgroups' tables"""
+    g = np.stack(np.meshgrid(np.arange(32), np.arange(16), np.arange(48), indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(6)
+    lat = g[rng.permutation(len(g))].astype(np.float32)[None]            # (1, 24576, 3)
+    dup = np.repeat(scene(4, 8192), 4, axis=0)[None]                    # every point 4 times: 32768
+    dup = dup[:, rng.permutation(dup.shape[1])]
+    for xyz, m in ((lat, 2048), (dup, 1000), (np.concatenate([lat, lat[:, ::-1]], 0), 600)):
         got, _ = fps_gpu(ext, xyz, m)
         assert np.array_equal(got, oracle.furthest_point_sample(xyz, m))
 

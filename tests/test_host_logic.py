@@ -175,13 +175,18 @@ def full_model(device="cpu", kind="u"):
     C, S = pkg("config"), pkg("synth")
     cfg = C.default_eval_cfg()
     model = pkg("eval_rcnn").build_model(cfg, "cpu")
-    g = load("g12%s_e2e_full_ref.npz" % kind)
+    if kind == "d":       # tools/cfgs/double.yaml:39: NUM_POINTS 32768, everything else default.yaml's (fixture g13, B = 1)
+        C.merge_into({"RPN": {"NUM_POINTS": 32768}}, cfg)
+        model = pkg("eval_rcnn").build_model(cfg, "cpu")
+    g = load("g13_e2e_double_ref.npz" if kind == "d" else "g12%s_e2e_full_ref.npz" % kind)
     sd, checksum = helpers.seeded_state_dict(model.state_dict(), int(g["seed"]))
     assert abs(checksum - float(g["weights_checksum"])) < 1e-6 * checksum, "seeded weights differ from the ones the fixture was made with"
     sd["rpn.rpn_cls_layer.2.conv.bias"] = torch.from_numpy(g["rpn_cls_bias"])
     model.load_state_dict(sd)          # strict: the key tree must equal the reference's
     seed0 = int(g["scene_seed0"])
-    if kind == "p":       # configs[2]'s literal batch, one pair of the graphed runner: 8 uniform scenes, then 8 LiDAR-shaped sweeps
+    if kind == "d":
+        pts = np.stack([S.scene(seed0, 32768)], 0)
+    elif kind == "p":       # configs[2]'s literal batch, one pair of the graphed runner: 8 uniform scenes, then 8 LiDAR-shaped sweeps
         pts = [np.stack([S.scene(seed0 + i, 16384) for i in range(8)], 0), np.stack([S.lidar_scene(seed0 + 8 + i, 16384) for i in range(8)], 0)]
     else:
         pts = np.stack([(S.scene if kind == "u" else S.lidar_scene)(seed0 + i, 16384) for i in range(2)], 0)
