@@ -55,6 +55,8 @@ SIGNATURES = {
     "prcnn_gather_affine_relu_pm": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_sa_mlp_fused": [_I] * 7 + [_P] * 10 + [_I, _I, _P],
     "prcnn_ball_pack": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "prcnn_ball_pack_ex": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "prcnn_rcnn_postprocess_blobs": [_I, _I, _I, _F, _F, _I, _I, _F, _F, _P, _F, _F, _P, _P, _P, _P, _P, _I, _P],
     "prcnn_ball_pack_groups": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_ball_pack_rep": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_dup_rep": [_I, _I, _I, _P, _P, _P, _P, _P],

@@ -429,8 +429,18 @@ constexpr int RF_THREADS = 256, RF_MAX = 128;
 __global__ __launch_bounds__(RF_THREADS) void rcnn_final_kernel(
     int m, RcnnCfg c, float nms_thresh, const float *__restrict__ rois, const float *__restrict__ reg, const float *__restrict__ cls,
     float *__restrict__ pred /* (b,m,7) decoded, RoI order */, float *__restrict__ boxes /* (b,m,7) */, float *__restrict__ scores /* (b,m) */,
-    int *__restrict__ num /* (b) */)
+    int *__restrict__ num /* (b) */, int spb /* > 0: boxes = a sequence of BLOBS of spb scenes each, [spb m 7 boxes | spb m scores | spb num] */)
 {
+    if (spb > 0) {
+        // (round 5) one blob per batch of spb scenes inside a launch over several batches: each batch's detections leave the device
+        // with ONE copy (a pair of batches per launch used to cost three copies per batch)
+        const int bl = blockIdx.x / spb, si = blockIdx.x - bl * spb;
+        float *base = boxes + (long)bl * spb * (m * 8 + 1);
+        // re-based so that the scene indexing below (b = blockIdx.x) lands on this scene's slices
+        boxes = base + ((long)si - blockIdx.x) * m * 7;
+        scores = base + (long)spb * m * 7 + ((long)si - blockIdx.x) * m;
+        num = reinterpret_cast<int *>(base + (long)spb * m * 8) + (si - (int)blockIdx.x);
+    }
     __shared__ unsigned long long keys[RF_MAX];
     __shared__ unsigned long long s_mask[RF_MAX][2];
     __shared__ float s_box[RF_MAX * 8];                  // decoded box + raw score, RoI order
@@ -674,11 +684,11 @@ extern "C" int prcnn_rpn_proposals_boxes(int b, int n, int pre_nms_top_n, int po
 // rois (b,m,7), rcnn_reg (b,m,channels), rcnn_cls (b,m) raw -> pred_boxes3d (b,m,7) decoded in RoI order,
 // boxes (b,m,7) / scores (b,m) = survivors of score threshold + rotated NMS in descending score order, zero
 // padded, num (b) i32.  get_xz_fine = get_ry_fine = True (eval_rcnn.py:516-523).  m <= 128.
-extern "C" int prcnn_rcnn_postprocess(int b, int m, int channels, float loc_scope, float loc_bin_size,
-                                      int num_head_bin, int y_by_bin, float loc_y_scope, float loc_y_bin_size,
-                                      const float *anchor_size_host, float score_thresh, float nms_thresh,
-                                      const float *rois, const float *rcnn_reg, const float *rcnn_cls,
-                                      float *pred_boxes3d, float *boxes, float *scores, int *num, void *stream)
+static int rcnn_postprocess_any(int b, int m, int channels, float loc_scope, float loc_bin_size,
+                                int num_head_bin, int y_by_bin, float loc_y_scope, float loc_y_bin_size,
+                                const float *anchor_size_host, float score_thresh, float nms_thresh,
+                                const float *rois, const float *rcnn_reg, const float *rcnn_cls,
+                                float *pred_boxes3d, float *boxes, float *scores, int *num, int scenes_per_blob, void *stream)
 {
     PRCNN_REQUIRE(b >= 0 && m > 0 && m <= 128 && channels > 0 && num_head_bin > 0, "rcnn_postprocess: bad sizes (m <= 128)");
     PRCNN_REQUIRE(anchor_size_host, "rcnn_postprocess: anchor size missing");
@@ -695,9 +705,10 @@ extern "C" int prcnn_rcnn_postprocess(int b, int m, int channels, float loc_scop
     PRCNN_REQUIRE(rois && rcnn_reg && rcnn_cls && pred_boxes3d && boxes && scores && num, "rcnn_postprocess: null pointer");
     hipStream_t st = (hipStream_t)stream;
     static const bool fused = !(getenv("PRCNN_FINAL_FUSED") && atoi(getenv("PRCNN_FINAL_FUSED")) == 0);     // A/B switch, same results
+    PRCNN_REQUIRE(scenes_per_blob == 0 || (fused && nms_thresh >= 0.f), "rcnn_postprocess_blobs: needs the one-workgroup final stage (PRCNN_FINAL_FUSED)");
     if (fused && nms_thresh >= 0.f) {
         hipLaunchKernelGGL(rcnn_final_kernel, dim3(b), dim3(RF_THREADS), 0, st, m, c, nms_thresh, rois, rcnn_reg, rcnn_cls, pred_boxes3d,
-                           boxes, scores, num);
+                           boxes, scores, num, scenes_per_blob);
         return check_launch("rcnn_postprocess");
     }
     const size_t o_sorted = 0;
@@ -717,4 +728,32 @@ extern "C" int prcnn_rcnn_postprocess(int b, int m, int channels, float loc_scop
     if (rc != PRCNN_OK) return rc;
     hipLaunchKernelGGL(rcnn_final_gather_kernel, dim3(b), dim3(128), 0, st, m, sorted, keep, num, boxes, scores);
     return check_launch("rcnn_postprocess");
+}
+
+extern "C" int prcnn_rcnn_postprocess(int b, int m, int channels, float loc_scope, float loc_bin_size,
+                                      int num_head_bin, int y_by_bin, float loc_y_scope, float loc_y_bin_size,
+                                      const float *anchor_size_host, float score_thresh, float nms_thresh,
+                                      const float *rois, const float *rcnn_reg, const float *rcnn_cls,
+                                      float *pred_boxes3d, float *boxes, float *scores, int *num, void *stream)
+{
+    return rcnn_postprocess_any(b, m, channels, loc_scope, loc_bin_size, num_head_bin, y_by_bin, loc_y_scope, loc_y_bin_size,
+                                anchor_size_host, score_thresh, nms_thresh, rois, rcnn_reg, rcnn_cls, pred_boxes3d, boxes, scores, num, 0,
+                                stream);
+}
+
+// The same with the results as one BLOB per batch of scenes_per_blob scenes (b % scenes_per_blob == 0): blobs (b / spb, spb (8 m + 1))
+// f32, each [spb m 7 boxes | spb m scores | spb num (i32 bits)] -- eval_rcnn.split_detections' layout per batch, so that a launch over a
+// PAIR of batches still hands every batch's detections to the host with one copy.  Needs the one-workgroup final kernel (nms_thresh >= 0).
+extern "C" int prcnn_rcnn_postprocess_blobs(int b, int m, int channels, float loc_scope, float loc_bin_size,
+                                            int num_head_bin, int y_by_bin, float loc_y_scope, float loc_y_bin_size,
+                                            const float *anchor_size_host, float score_thresh, float nms_thresh,
+                                            const float *rois, const float *rcnn_reg, const float *rcnn_cls,
+                                            float *pred_boxes3d, float *blobs, int scenes_per_blob, void *stream)
+{
+    PRCNN_REQUIRE(scenes_per_blob > 0 && b % scenes_per_blob == 0 && nms_thresh >= 0.f, "rcnn_postprocess_blobs: %d scenes in blobs of %d",
+                  b, scenes_per_blob);
+    PRCNN_REQUIRE(blobs || b == 0, "rcnn_postprocess_blobs: null pointer");
+    return rcnn_postprocess_any(b, m, channels, loc_scope, loc_bin_size, num_head_bin, y_by_bin, loc_y_scope, loc_y_bin_size,
+                                anchor_size_host, score_thresh, nms_thresh, rois, rcnn_reg, rcnn_cls, pred_boxes3d, blobs, blobs,
+                                reinterpret_cast<int *>(blobs), scenes_per_blob, stream);
 }

@@ -483,7 +483,7 @@ using namespace prcnn;
 // limit (b) i32, optional: points k >= limit[cloud] are copies of point k % limit[cloud] (see ball_pack_kernel).
 static int ball_pack_launch(int b, int group, int n, int m, int nsample, const int *idx, const int *limit, const float *xyz,
                             const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr, void *stream,
-                            const int *rep = nullptr, const int *crep = nullptr)
+                            const int *rep = nullptr, const int *crep = nullptr, int hdr_is_zero = 0)
 {
     PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 1, "ball_pack: bad sizes");
     PRCNN_REQUIRE(group >= 1 && b % group == 0, "ball_pack: %d clouds do not split into lists of %d", b, group);
@@ -494,7 +494,9 @@ static int ball_pack_launch(int b, int group, int n, int m, int nsample, const i
     const int lists = b > 0 ? b / group : 1;
     // (round 4 tried counting in a self-resetting ticket record instead of this memset: 6323 / 6337 scenes/s against 6362 / 6402 at K = 96,
     //  6103 / 6120 with agent-scope fences around the arrival count -- the five fills per step are on nobody's critical path.  Not kept.)
-    if (hipMemsetAsync(hdr, 0, (size_t)lists * 4 * sizeof(unsigned int), st) != hipSuccess) { set_error("ball_pack: memset failed"); return PRCNN_ELAUNCH; }
+    //  Round 5: the caller may hand over headers that ARE zero -- slices of an arena it zeroes once per chain of launches
+    //  (prcnn_ball_pack_ex: 3.65 header fills per step -> 0.75 arena fills that also cover the levels' pooled outputs).)
+    if (!hdr_is_zero && hipMemsetAsync(hdr, 0, (size_t)lists * 4 * sizeof(unsigned int), st) != hipSuccess) { set_error("ball_pack: memset failed"); return PRCNN_ELAUNCH; }
     if (b == 0 || m == 0) return PRCNN_OK;
     PRCNN_REQUIRE(idx && rowinfo && tilecloud && xyz && new_xyz && rowdxyz, "ball_pack: null pointer");
     PRCNN_REQUIRE(((uintptr_t)rowdxyz & 15) == 0, "ball_pack: rowdxyz must be 16-byte aligned");
@@ -577,6 +579,16 @@ extern "C" int prcnn_ball_pack_groups(int b, int group, int n, int m, int nsampl
                                       void *stream)
 {
     return ball_pack_launch(b, group, n, m, nsample, idx, limit, xyz, new_xyz, rowinfo, rowdxyz, tilecloud, hdr, stream);
+}
+
+// Every form of the above behind one entry (round 5): group (1 list = all b clouds: pass b), limit / rep / crep optional, and
+// hdr_is_zero != 0: hdr [lists][4] holds zeros already (the caller zeroes an arena of headers with ONE fill): no memset here.
+extern "C" int prcnn_ball_pack_ex(int b, int group, int n, int m, int nsample, const int *idx, const int *limit, const int *rep,
+                                  const int *crep, const float *xyz, const float *new_xyz, unsigned int *rowinfo, float *rowdxyz,
+                                  int *tilecloud, unsigned int *hdr, int hdr_is_zero, void *stream)
+{
+    return ball_pack_launch(b, group > 0 ? group : (b > 0 ? b : 1), n, m, nsample, idx, limit, xyz, new_xyz, rowinfo, rowdxyz, tilecloud, hdr,
+                            stream, rep, crep, hdr_is_zero);
 }
 
 // The fused set-abstraction MLP over packed rows (prcnn_ball_pack): P (b,n,128) = features @ W1f^T + b1, wxyz (3,128),

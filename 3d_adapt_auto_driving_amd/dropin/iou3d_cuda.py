@@ -92,6 +92,23 @@ def rpn_proposals_boxes(scores, boxes, pre_nms_top_n, post_nms_top_n, nms_thresh
     return rois, roi_scores
 
 
+def rcnn_postprocess_blobs(rois, rcnn_reg, rcnn_cls, anchor_size, loc_scope, loc_bin_size, num_head_bin, y_by_bin,
+                           loc_y_scope, loc_y_bin_size, score_thresh, nms_thresh, pred_boxes3d, blobs, scenes_per_blob):
+    """rcnn_postprocess with the results as one blob per batch of scenes_per_blob scenes: blobs (B / spb, spb (8 M + 1)) f32, each
+    [boxes | scores | num] of its scenes (eval_rcnn.split_detections' layout) -- one D2H copy per batch out of a launch over several."""
+    import ctypes
+    _chk(rois, rcnn_reg, rcnn_cls, pred_boxes3d, blobs)
+    B, M = rois.size(0), rois.size(1)
+    if B % scenes_per_blob or blobs.numel() != B * (8 * M + 1):
+        raise RuntimeError("iou3d_cuda: %d scenes do not fill blobs of %d (or blobs has the wrong size)" % (B, scenes_per_blob))
+    anchor = (ctypes.c_float * 3)(*[float(v) for v in anchor_size])
+    _lib.call("prcnn_rcnn_postprocess_blobs", B, M, rcnn_reg.size(2), float(loc_scope), float(loc_bin_size), int(num_head_bin),
+              int(bool(y_by_bin)), float(loc_y_scope), float(loc_y_bin_size), ctypes.cast(anchor, ctypes.c_void_p), float(score_thresh),
+              float(nms_thresh), rois.data_ptr(), rcnn_reg.data_ptr(), rcnn_cls.data_ptr(), pred_boxes3d.data_ptr(), blobs.data_ptr(),
+              int(scenes_per_blob), _lib.current_stream(rois))
+    return blobs
+
+
 def rcnn_postprocess(rois, rcnn_reg, rcnn_cls, anchor_size, loc_scope, loc_bin_size, num_head_bin, y_by_bin,
                      loc_y_scope, loc_y_bin_size, score_thresh, nms_thresh, pred_boxes3d, boxes, scores, num):
     """Fused final stage (csrc/proposal.hip): decode against the RoIs, score threshold, rotated NMS.

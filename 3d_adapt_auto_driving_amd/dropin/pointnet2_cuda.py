@@ -251,12 +251,13 @@ class BallPack:
             t.record_stream(stream)
 
 
-def ball_pack_wrapper(idx, xyz, new_xyz, limit=None, rep=None, crep=None):
+def ball_pack_wrapper(idx, xyz, new_xyz, limit=None, rep=None, crep=None, hdr=None):
     """idx (b,m,nsample) i32 from a ball query of new_xyz (b,m,3) in xyz (b,n,3) -> BallPack for sa_packed_mlp_wrapper.
     limit (b) i32, optional: the points k >= limit[cloud] of a cloud are copies of point k % limit[cloud] (RoI pooling's
     wrap-around fill): dropped as well.  rep (b,n) i32, optional: rep[cloud][k] = the lowest-indexed exact copy of point k
     (dup_rep_wrapper): the slots whose point is not its own representative are dropped too (prcnn_ball_pack_rep).  crep (b,m) i32,
-    optional: the same map over the centres -- a centre that copies an earlier one gets no rows (its output row is never written)."""
+    optional: the same map over the centres -- a centre that copies an earlier one gets no rows (its output row is never written).
+    hdr (4) i32, optional: a header that IS ZERO already (a slice of an arena the caller zeroed: no memset launch per row list)."""
     _chk(torch.int32, idx); _chk(torch.float32, xyz, new_xyz)
     if limit is not None:
         _chk(torch.int32, limit)
@@ -275,8 +276,17 @@ def ball_pack_wrapper(idx, xyz, new_xyz, limit=None, rep=None, crep=None):
     pk.rowinfo = torch.empty((b * cap * 64,), dtype=torch.int32, device=idx.device)
     pk.rowdxyz = torch.empty((b * cap * 64, 4), dtype=torch.float32, device=idx.device)
     pk.tilecloud = torch.empty((b * cap,), dtype=torch.int32, device=idx.device)
-    pk.hdr = torch.empty((4,), dtype=torch.int32, device=idx.device)
     pk.max_tiles = b * cap
+    if hdr is not None:
+        _chk(torch.int32, hdr)
+        if hdr.numel() != 4:
+            raise ValueError("ball_pack: hdr must hold 4 int32")
+        pk.hdr = hdr
+        _lib.call("prcnn_ball_pack_ex", b, b, xyz.size(1), m, ns, idx.data_ptr(), _lib.ptr(limit), _lib.ptr(rep), _lib.ptr(crep),
+                  xyz.data_ptr(), new_xyz.data_ptr(), pk.rowinfo.data_ptr(), pk.rowdxyz.data_ptr(), pk.tilecloud.data_ptr(),
+                  pk.hdr.data_ptr(), 1, _lib.current_stream(idx))
+        return pk
+    pk.hdr = torch.empty((4,), dtype=torch.int32, device=idx.device)
     if rep is not None or crep is not None:
         _lib.call("prcnn_ball_pack_rep", b, xyz.size(1), m, ns, idx.data_ptr(), _lib.ptr(limit), _lib.ptr(rep), _lib.ptr(crep),
                   xyz.data_ptr(), new_xyz.data_ptr(), pk.rowinfo.data_ptr(), pk.rowdxyz.data_ptr(), pk.tilecloud.data_ptr(),
@@ -325,7 +335,7 @@ def dup_rep_wrapper(sel, n, limit=None, prev=None):
     return rep
 
 
-def ball_pack_groups_wrapper(idx, xyz, new_xyz, group):
+def ball_pack_groups_wrapper(idx, xyz, new_xyz, group, hdr=None):
     """ball_pack_wrapper for b = lists x group clouds in ONE launch -> a list of BallPack, one per `group` consecutive clouds
     (views into shared buffers), each exactly what ball_pack_wrapper returns for idx[l*group:(l+1)*group]."""
     _chk(torch.int32, idx); _chk(torch.float32, xyz, new_xyz)
@@ -337,9 +347,16 @@ def ball_pack_groups_wrapper(idx, xyz, new_xyz, group):
     rowinfo = torch.empty((lists, L * 64), dtype=torch.int32, device=idx.device)
     rowdxyz = torch.empty((lists, L * 64, 4), dtype=torch.float32, device=idx.device)
     tilecloud = torch.empty((lists, L), dtype=torch.int32, device=idx.device)
-    hdr = torch.empty((lists, 4), dtype=torch.int32, device=idx.device)
-    _lib.call("prcnn_ball_pack_groups", b, group, xyz.size(1), m, ns, idx.data_ptr(), None, xyz.data_ptr(), new_xyz.data_ptr(),
-              rowinfo.data_ptr(), rowdxyz.data_ptr(), tilecloud.data_ptr(), hdr.data_ptr(), _lib.current_stream(idx))
+    if hdr is not None:                    # (lists, 4) i32 that IS ZERO already: see ball_pack_wrapper
+        _chk(torch.int32, hdr)
+        if tuple(hdr.shape) != (lists, 4):
+            raise ValueError("ball_pack_groups: hdr must be (lists, 4)")
+        _lib.call("prcnn_ball_pack_ex", b, group, xyz.size(1), m, ns, idx.data_ptr(), None, None, None, xyz.data_ptr(), new_xyz.data_ptr(),
+                  rowinfo.data_ptr(), rowdxyz.data_ptr(), tilecloud.data_ptr(), hdr.data_ptr(), 1, _lib.current_stream(idx))
+    else:
+        hdr = torch.empty((lists, 4), dtype=torch.int32, device=idx.device)
+        _lib.call("prcnn_ball_pack_groups", b, group, xyz.size(1), m, ns, idx.data_ptr(), None, xyz.data_ptr(), new_xyz.data_ptr(),
+                  rowinfo.data_ptr(), rowdxyz.data_ptr(), tilecloud.data_ptr(), hdr.data_ptr(), _lib.current_stream(idx))
     out = []
     for l in range(lists):
         pk = BallPack()

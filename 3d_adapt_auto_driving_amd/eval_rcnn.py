@@ -89,9 +89,11 @@ def split_detections(blob, batch_size, M):
 
 
 @torch.no_grad()
-def postprocess(cfg, ret_dict, batch_size):
+def postprocess(cfg, ret_dict, batch_size, blob_scenes=None):
     """Final box decoding + score threshold + rotated NMS, batched (eval_rcnn.py:506-530,611-629).
-    Returns boxes (B,M,7), raw scores (B,M) and num (B) i32 on the device; rows >= num are zero."""
+    Returns boxes (B,M,7), raw scores (B,M) and num (B) i32 on the device; rows >= num are zero.
+    blob_scenes (the graphed runner's launches over several batches): the results as one blob per `blob_scenes` scenes --
+    "blobs" (B / blob_scenes, blob_scenes (8 M + 1)); boxes / scores / num are then LISTS of per-blob views."""
     R = cfg.RCNN
     rois = ret_dict["rois"]
     M = rois.shape[1]
@@ -107,9 +109,18 @@ def postprocess(cfg, ret_dict, batch_size):
         pred = torch.empty((batch_size, M, 7), dtype=torch.float32, device=dev)
         # the three results in ONE allocation ("blob": boxes | scores | num, see split_detections): the consumer brings them to the host
         # with one copy instead of three
+        raw = raw.contiguous()
+        if blob_scenes and blob_scenes < batch_size and batch_size % blob_scenes == 0 and has_entry(ext, "rcnn_postprocess_blobs") and R.NMS_THRESH >= 0:
+            nb = batch_size // blob_scenes
+            blobs = torch.empty((nb, blob_scenes * (M * 8 + 1)), dtype=torch.float32, device=dev)
+            ext.rcnn_postprocess_blobs(rois.contiguous(), rcnn_reg.contiguous(), raw, _anchor_host(cfg), R.LOC_SCOPE, R.LOC_BIN_SIZE,
+                                       R.NUM_HEAD_BIN, R.LOC_Y_BY_BIN, R.LOC_Y_SCOPE, R.LOC_Y_BIN_SIZE, R.SCORE_THRESH, R.NMS_THRESH,
+                                       pred, blobs, blob_scenes)
+            parts = [split_detections(blobs[i], blob_scenes, M) for i in range(nb)]
+            return {"boxes": [p[0] for p in parts], "scores": [p[1] for p in parts], "num": [p[2] for p in parts], "pred_boxes3d": pred,
+                    "raw_scores": raw, "blobs": blobs}
         blob = torch.empty((batch_size * (M * 8 + 1),), dtype=torch.float32, device=dev)
         boxes, scores, num = split_detections(blob, batch_size, M)
-        raw = raw.contiguous()
         ext.rcnn_postprocess(rois.contiguous(), rcnn_reg.contiguous(), raw, _anchor_host(cfg), R.LOC_SCOPE,
                              R.LOC_BIN_SIZE, R.NUM_HEAD_BIN, R.LOC_Y_BY_BIN, R.LOC_Y_SCOPE, R.LOC_Y_BIN_SIZE,
                              R.SCORE_THRESH, R.NMS_THRESH, pred, boxes, scores, num)
@@ -713,7 +724,7 @@ class GraphedRunner:
 
         def final_stage(tl, out):
             ret = {"rois": tl["rois"], "rcnn_cls": out["rcnn_cls"], "rcnn_reg": out["rcnn_reg"]}
-            det = postprocess(cfg, ret, Bm)
+            det = postprocess(cfg, ret, Bm, blob_scenes=B if P > 1 else None)
             det.update(ret)
             return det
 
@@ -940,12 +951,17 @@ class GraphedRunner:
         B = self.shape[0]
         for h in halves:                                    # one detections dict per batch: views of the member's tensors
             det = {}
+            blobs = m["det"].get("blobs")
             for key, v in m["det"].items():
-                if key == "blob" or not torch.is_tensor(v):
+                if key in ("blob", "blobs"):
                     continue
-                per = v.shape[0] // self.pair               # rows of this tensor per batch (B scenes, or B x rois)
-                det[key] = v[h * per:(h + 1) * per]
-            det["blob"] = None                              # (the member's single allocation holds both batches: three copies per batch)
+                if isinstance(v, list):                     # per-batch views of the batch's own blob (boxes, scores, num)
+                    det[key] = v[h]
+                elif torch.is_tensor(v):
+                    per = v.shape[0] // self.pair           # rows of this tensor per batch (B scenes, or B x rois)
+                    det[key] = v[h * per:(h + 1) * per]
+            # round 5: the final stage writes one blob per BATCH of the member (prcnn_rcnn_postprocess_blobs): one copy per batch
+            det["blob"] = blobs[h] if blobs is not None else None
             det["ready"], det["stream"] = m["ready"], post
             self._out.append(det)
 

@@ -86,6 +86,53 @@ USE_FP_LINEAR = os.environ.get("PRCNN_NO_FP_LINEAR") is None
 USE_TAIL_DECODE = os.environ.get("PRCNN_TAIL_DECODE", "1") != "0"
 
 
+class ZeroArena:
+    """ONE zero-filled allocation handed out in slices: the pooled outputs that the packed kernels fill through atomicMax and the
+    headers of the packed row lists of a whole chain of launches (a geometry group; the RCNN geometry of a pair of batches) -- one
+    fill launch per chain instead of one per tensor (round 5: 5.2 fills per step -> 0.75).  Sized by a dry run of the chain's
+    requests: the first pass of a shape allocates per request and records the total, later passes carve one arena."""
+    SIZES = {}
+
+    def __init__(self, key, device):
+        self.key, self.device = key, device
+        self.used = 0
+        self.parts = []
+        total = ZeroArena.SIZES.get(key)
+        self.buf = torch.zeros((total,), dtype=torch.float32, device=device) if total else None
+
+    def take(self, shape, dtype=torch.float32):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n4 = (n + 3) // 4 * 4                                        # 16-byte slices
+        if self.buf is None:
+            self.used += n4
+            part = torch.zeros(tuple(shape), dtype=dtype, device=self.device)
+            self.parts.append(part)
+            return part
+        if self.used + n4 > self.buf.numel():
+            # the chain asks for more than its dry run did (an engine switch changed in between): a fill of its own, and a larger
+            # arena from the next pass on
+            self.used += n4
+            part = torch.zeros(tuple(shape), dtype=dtype, device=self.device)
+            self.parts.append(part)
+            return part
+        out = self.buf[self.used:self.used + n].view(dtype).view(tuple(shape))
+        self.used += n4
+        return out
+
+    def done(self):
+        if self.buf is None or self.used > self.buf.numel():
+            ZeroArena.SIZES[self.key] = self.used
+
+    def rezero(self):
+        """zero everything handed out so far again (a second pass over the same slices)"""
+        if self.buf is not None:
+            self.buf.zero_()
+        for part in self.parts:
+            part.zero_()
+
+
 def pl_ext():
     """the iou3d operator backend in force (looked up per call: the test suite swaps it)"""
     return iou3d_utils.iou3d_cuda
@@ -449,9 +496,12 @@ class FastPointRCNN:
         state["sa"].append(lev)
         state["l_xyz"].append(new_xyz)
 
-    def _pack_level(self, k, cur, lev):
-        """the distinct-row lists of the scales that run on the packed MFMA kernels (they depend on the indices only)"""
-        lev["pack"] = [pu.pointnet2.ball_pack_wrapper(ix, cur, lev["new_xyz"])
+    def _pack_level(self, k, cur, lev, arena=None):
+        """the distinct-row lists of the scales that run on the packed MFMA kernels (they depend on the indices only);
+        arena: a ZeroArena the headers come from (zero already: no memset per list)"""
+        # (positional: test proxies around the extension module forward *args only)
+        hdr = (lambda: (None, None, None, arena.take((4,), torch.int32))) if (arena is not None and getattr(pu.pointnet2, "IS_HIP_EXTENSION", False)) else (lambda: ())
+        lev["pack"] = [pu.pointnet2.ball_pack_wrapper(ix, cur, lev["new_xyz"], *hdr())
                        if (USE_PACKED and (sc[2].packed is not None or sc[2].wide is not None or sc[3] == 0)) else None
                        for ix, sc in zip(lev["idx"], self.sa[k][1])]
 
@@ -466,7 +516,16 @@ class FastPointRCNN:
             if on_batch_done is not None:
                 on_batch_done(0)
             return geo1
-        state = {"l_xyz": [torch.cat(list(xyz_list), dim=0)], "sa": [], "defer_packs": True}
+        # the batches of a group slot of the graphed runner lie side by side in ONE tensor: take the view, not a copy
+        x0, whole = xyz_list[0], None
+        if (x0.is_contiguous() and all(x.is_contiguous() and x.shape[1:] == x0.shape[1:] and x.dtype == x0.dtype for x in xyz_list)
+                and all(xyz_list[i + 1].data_ptr() == xyz_list[i].data_ptr() + xyz_list[i].numel() * 4 for i in range(len(xyz_list) - 1))
+                and x0._base is not None and x0._base.is_contiguous() and x0._base.dim() == 3 and x0._base.shape[1:] == x0.shape[1:]):
+            lo_ = (x0.data_ptr() - x0._base.data_ptr()) // (x0[0].numel() * 4)
+            if 0 <= lo_ and lo_ + sum(sizes) <= x0._base.shape[0] and x0._base[lo_].data_ptr() == x0.data_ptr():
+                whole = x0._base[lo_:lo_ + sum(sizes)]
+        state = {"l_xyz": [whole if whole is not None else torch.cat(list(xyz_list), dim=0)], "sa": [], "defer_packs": True}
+        arena = ZeroArena(("geo", tuple(sizes), tuple(x0.shape[1:]), str(x0.device)), x0.device)
         self._geometry_level(state, 0)
         geo = self.geometry_finish(state)
         groups = self._point_groups(geo["l_xyz"][0])
@@ -482,10 +541,11 @@ class FastPointRCNN:
         n_early = 0
         if GROUP_SA if group_sa is None else group_sa:
             for k in range(min(EARLY_LEVELS, len(self.sa))):
-                self._pack_level(k, geo["l_xyz"][k], geo["sa"][k])
-            self._xyz_level(geo)
+                self._pack_level(k, geo["l_xyz"][k], geo["sa"][k], arena)
+            self._xyz_level(geo, arena)
             while n_early < len(geo["sa"]) and geo["sa"][n_early].get("out") is not None:
                 n_early += 1
+        arena.done()
         if same and n_early < len(geo["sa"]):
             gpacks = [[ext.ball_pack_groups_wrapper(ix, geo["l_xyz"][k], lev["new_xyz"], sizes[0])
                        if (USE_PACKED and (sc[2].packed is not None or sc[2].wide is not None or sc[3] == 0)) else None
@@ -535,7 +595,7 @@ class FastPointRCNN:
         self._xyz_level(geo)
         return geo
 
-    def _xyz_level(self, geo):
+    def _xyz_level(self, geo, arena=None):
         """The first EARLY_LEVELS SA levels of a coordinates-only backbone (USE_INTENSITY False: no input features) depend on xyz
         and the model's weights only -- so does the whole backbone -- and are computed WITH the geometry, on the geometry's stream
         (the pipelined runner: a side stream that has slack, off the feature stream's critical path).  Stored as
@@ -553,7 +613,8 @@ class FastPointRCNN:
             if not pre or any(pk is None for pk in packs):
                 return                                          # a level off the packed kernels: it (and what follows) stays in _backbone
             width = sum(sc[2].layers[-1][0].shape[1] for sc in scales)
-            out = torch.zeros((B, npoint, _round128(width) if PAD128 else width), dtype=torch.float32, device=l_xyz[0].device)
+            oshape = (B, npoint, _round128(width) if PAD128 else width)
+            out = arena.take(oshape) if arena is not None else torch.zeros(oshape, dtype=torch.float32, device=l_xyz[0].device)
             self._sa_level(scales, lev, l_xyz[k], prev, out, True)
             lev["out"] = prev = out
         # ... and, with every SA level done, the coarsest EARLY_FP feature-propagation modules (a few thousand rows each: launches
@@ -991,6 +1052,9 @@ class FastPointRCNN:
         tiles = ext.pooled_tiles_wrapper(pooled_cnt.view(-1), P) if (point_mlp and pooled_cnt is not None) else None
         cur_xyz = xyz_dense.view(B * M, P, 3) if xyz_dense is not None else flat[:, :, 0:3].contiguous()
         levels = []
+        # one zero fill for this stage: the headers of its three row lists and the pooled outputs of its levels (see ZeroArena)
+        zarena = ZeroArena(("rcnn", B, M, P, str(rows.device)), rows.device)
+        zhdr = (lambda: (zarena.take((4,), torch.int32),)) if getattr(ext, "IS_HIP_EXTENSION", False) else (lambda: ())   # positional (7th) argument
         # representative map of the CURRENT level's points (None: every point counts as distinct): which of them are exact copies
         # of one another.  Level 0: pooled point k >= count is a copy of k % count (`limit`); deeper: the centres the sampling
         # picked from copies of one source are copies of one another -- coordinates, ball and therefore features (dup_rep).
@@ -1010,9 +1074,9 @@ class FastPointRCNN:
             if npoint is not None and fused_geo is not None and k < 2:
                 new_xyz, idx, rep_out = fused_geo[3 * k:3 * k + 3]
                 if k == 0:
-                    lev["pack"] = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, pooled_cnt.view(-1), None, rep_out)
+                    lev["pack"] = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, pooled_cnt.view(-1), None, rep_out, *zhdr())
                 else:
-                    lev["pack"] = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, None, rep, rep_out)
+                    lev["pack"] = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, None, rep, rep_out, *zhdr())
                 rep = rep_out
                 lev["new_xyz"], lev["idx"] = new_xyz, idx
                 cur_xyz = new_xyz
@@ -1069,7 +1133,7 @@ class FastPointRCNN:
                 if rep is not None and n <= 64:          # the f clouds' maps side by side, shifted to the merged cloud's numbering
                     rep_v = (rep.view(Bc // f, f, n) + shift).view(Bc // f, f * n)
                 lev.update({"xyz": xyz_v, "new_xyz": origin, "idx": ga_idx,
-                            "pack": ext.ball_pack_wrapper(ga_idx, xyz_v, origin, None, rep_v) if rep_v is not None else ext.ball_pack_wrapper(ga_idx, xyz_v, origin),
+                            "pack": ext.ball_pack_wrapper(ga_idx, xyz_v, origin, None, rep_v, None, *zhdr()) if rep_v is not None else ext.ball_pack_wrapper(ga_idx, xyz_v, origin, None, None, None, *zhdr()),
                             "f": f})
                 cur_xyz = None
             levels.append(lev)
@@ -1081,7 +1145,11 @@ class FastPointRCNN:
                 shapes.append(rows_out * cout)
             else:
                 shapes.append(0)
-        arena = torch.zeros((sum(shapes),), dtype=torch.float32, device=rows.device) if sum(shapes) else None
+        arena = None
+        if sum(shapes):
+            parts = [zarena.take((n_,)) if n_ else None for n_ in shapes]
+            arena = {"zero": zarena, "parts": parts}
+        zarena.done()
         return {"B": B, "M": M, "P": P, "W": W, "rows": rows, "a": a, "rpn_part": rpn_part, "pooled": pooled, "pooled_cnt": pooled_cnt,
                 "point_mlp": point_mlp, "tiles": tiles, "levels": levels, "arena": arena, "arena_shapes": shapes}
 
@@ -1110,9 +1178,10 @@ class FastPointRCNN:
         shapes, arena = rg["arena_shapes"], rg["arena"]
         if arena is not None:
             if rg.get("arena_used"):           # a second pass over the same geometry (another set of weights, a probe): the atomicMax pools
-                arena.zero_()                  # must not start from the first pass's maxima -- the first pass stays fill-free
+                for part in arena["parts"]:    # must not start from the first pass's maxima -- the first pass stays fill-free
+                    if part is not None:
+                        part.zero_()
             rg["arena_used"] = True
-        offs = [sum(shapes[:k]) for k in range(len(shapes))]
         for k, ((npoint, radius, ns, mlp, cin), lev) in enumerate(zip(self.rcnn_sa, rg["levels"])):
             cur_xyz, cur_feat = lev["xyz"], l_feat[-1]
             cout = mlp.layers[-1][0].shape[1]
@@ -1120,7 +1189,7 @@ class FastPointRCNN:
             pre = shapes[k] > 0
             if npoint is not None:
                 Bc = cur_xyz.shape[0]
-                out = (arena[offs[k]:offs[k] + shapes[k]].view(Bc, npoint, cout) if pre
+                out = (arena["parts"][k].view(Bc, npoint, cout) if pre
                        else torch.empty((Bc, npoint, cout), dtype=torch.float32, device=cur_xyz.device))
                 self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, lev["idx"], mlp, cin, out, 0, P_pre=P_pre if first else None, pack=lev["pack"],
                                zeroed=pre)
@@ -1128,7 +1197,7 @@ class FastPointRCNN:
                 f = lev["f"]
                 Bc = cur_xyz.shape[0] * f
                 feat_v = cur_feat.view(Bc // f, cur_xyz.shape[1], cur_feat.shape[2])
-                out = (arena[offs[k]:offs[k] + shapes[k]].view(Bc, 1, cout) if pre
+                out = (arena["parts"][k].view(Bc, 1, cout) if pre
                        else torch.empty((Bc, 1, cout), dtype=torch.float32, device=cur_xyz.device))
                 self._sa_scale(cur_xyz, lev["new_xyz"], feat_v, lev["idx"], mlp, cin, out.view(Bc // f, f, cout), 0, pack=lev["pack"], dense=True,
                                zeroed=pre)

@@ -192,6 +192,13 @@ int prcnn_ball_pack_groups(int b, int group, int n, int m, int nsample, const in
                            const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr,
                            void *stream);
 
+/* Every form of prcnn_ball_pack behind one entry (round 5): group = clouds per list (b: one list), limit / rep / crep optional (NULL),
+ * hdr_is_zero != 0: hdr [lists][4] already holds zeros -- a slice of an arena the caller zeroes once per chain of launches instead of
+ * one memset per row list. */
+int prcnn_ball_pack_ex(int b, int group, int n, int m, int nsample, const int *idx, const int *limit, const int *rep, const int *crep,
+                       const float *xyz, const float *new_xyz, unsigned int *rowinfo, float *rowdxyz, int *tilecloud, unsigned int *hdr,
+                       int hdr_is_zero, void *stream);
+
 /* prcnn_ball_pack with a representative map (round 3): rep (b,n) i32, rep[cloud][k] = the lowest-indexed point of the cloud
  * that is an exact copy of point k (coordinates and features; k when it is the first of its kind).  A copy lies in a ball
  * iff its representative does and the representative is listed earlier in the same row, so the slots whose point is not
@@ -431,6 +438,13 @@ int prcnn_rcnn_postprocess(int b, int m, int channels, float loc_scope, float lo
                            float score_thresh, float nms_thresh, const float *rois, const float *rcnn_reg,
                            const float *rcnn_cls, float *pred_boxes3d, float *boxes, float *scores, int *num,
                            void *stream);
+/* The same with the results as one BLOB per batch of scenes_per_blob scenes (b a multiple of it): blobs (b / spb, spb (8 m + 1)) f32,
+ * each [spb m 7 boxes | spb m scores | spb num as i32 bits]: a launch over several batches hands every batch's detections to the
+ * host with one copy (round 5). */
+int prcnn_rcnn_postprocess_blobs(int b, int m, int channels, float loc_scope, float loc_bin_size, int num_head_bin,
+                                 int y_by_bin, float loc_y_scope, float loc_y_bin_size, const float *anchor_size_host,
+                                 float score_thresh, float nms_thresh, const float *rois, const float *rcnn_reg,
+                                 const float *rcnn_cls, float *pred_boxes3d, float *blobs, int scenes_per_blob, void *stream);
 
 /* ---- roipool3d_cuda ------------------------------------------------------------------ */
 

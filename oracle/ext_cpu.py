@@ -199,7 +199,7 @@ class pointnet2_cpu:
         return out
 
     @staticmethod
-    def ball_pack_wrapper(idx, xyz=None, new_xyz=None, limit=None, rep=None, crep=None):
+    def ball_pack_wrapper(idx, xyz=None, new_xyz=None, limit=None, rep=None, crep=None, hdr=None):
         """The CPU stand-in keeps the index tensor: the oracle evaluates ALL nsample rows (the reference's semantics)."""
         return _CpuPack(idx, limit, rep, crep)
 
@@ -237,7 +237,7 @@ class pointnet2_cpu:
         return rep
 
     @staticmethod
-    def ball_pack_groups_wrapper(idx, xyz, new_xyz, group):
+    def ball_pack_groups_wrapper(idx, xyz, new_xyz, group, hdr=None):
         return [_CpuPack(idx[l:l + group], None) for l in range(0, idx.shape[0], group)]
 
     @staticmethod
