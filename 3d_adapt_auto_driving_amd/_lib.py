@@ -28,6 +28,13 @@ class LayerProblem(C.Structure):
                 ("out_col", _I), ("out_is_zero", _I)]
 
 
+class SaProblem(C.Structure):
+    """prcnn_sa_problem (include/prcnn_hip.h)"""
+    _fields_ = [("b", _I), ("n", _I), ("m", _I), ("c3", _I), ("max_tiles", C.c_long), ("P", _P), ("wxyz", _P), ("rowinfo", _P), ("rowdxyz", _P),
+                ("tilecloud", _P), ("hdr", _P), ("w2t", _P), ("b2", _P), ("w3t", _P), ("b3", _P), ("out", _P), ("out_stride", _I),
+                ("out_col", _I), ("out_is_zero", _I)]
+
+
 # name -> argument types (return type is always int except where noted)
 SIGNATURES = {
     "prcnn_version": [],
@@ -71,6 +78,7 @@ SIGNATURES = {
     "prcnn_sa_wide_fused": [_I, _I, _I, _I, _I, _I, C.c_long] + [_P] * 11 + [_I, _I, _I, _P],
     "prcnn_sa_wide_fused3_supported": [_I, _I, _I, _I],
     "prcnn_sa_wide_fused3": [_I, _I, _I, _I, _I, _I, _I, C.c_long] + [_P] * 11 + [_I, _I, _I, _P],
+    "prcnn_sa_packed_mlp_batch": [_I, C.POINTER(SaProblem), _P],
     "prcnn_packed_gather_affine_batch": [_I, C.POINTER(GatherProblem), _P],
     "prcnn_packed_layer_batch": [_I, C.POINTER(LayerProblem), _I, _P],
     "prcnn_rpn_tail": [_I, _I, _I] + [_P] * 7 + [_I] + [_P] * 4,

@@ -182,12 +182,35 @@ __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, cons
 
 // ------------------------------------------------------------------------------------------------ C3 = 128
 // Two workgroups per CU (see sa_mlp_fused.hip for the MFMA mapping; identical here).
-__global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
-    int n, int m, const unsigned int *__restrict__ hdr, const float4 *__restrict__ rowdxyz,
-    const float4 *__restrict__ P /* (b,n,128) */, const float4 *__restrict__ wxyz /* (3,128) */,
-    const unsigned int *__restrict__ rowinfo, const int *__restrict__ tilecloud,
-    const float *__restrict__ w2t, const float *__restrict__ b2, const float *__restrict__ w3t, const float *__restrict__ b3,
-    float *__restrict__ out, int out_stride, int out_col, unsigned int *__restrict__ ticket, int tiles_per_wg, int lds_pool)
+// Round 5: ONE launch serves up to two PROBLEMS (the two scales of an MSG level: their own row lists, weights and output slices):
+// workgroup x works on problem x % nprob and draws its tiles from that problem's counter (words 0 and 2 of the launch's ticket record).
+// On the sparse launches of the real step (1-2 tiles per CU) a launch is mostly ramp: two of them side by side cost one ramp.
+struct SaPkProblem {
+    int n, m;
+    const unsigned int *hdr;
+    const float4 *rowdxyz, *P, *wxyz;
+    const unsigned int *rowinfo;
+    const int *tilecloud;
+    const float *w2t, *b2, *w3t, *b3;
+    float *out;
+    int out_stride, out_col, lds_pool;
+};
+struct SaPkBatch {
+    int nprob;
+    SaPkProblem p[2];
+};
+// thread 0 of every workgroup, once, after its last draw: the launch's last workgroup zeroes the record's draw counters and arrival count
+__device__ __forceinline__ void ticket_release3(unsigned int *rec)
+{
+    if (atomicAdd(rec + 1, 1u) == gridDim.x * gridDim.y * gridDim.z - 1u) {
+        atomicExch(rec, 0u);
+        atomicExch(rec + 2, 0u);
+        atomicExch(rec + 1, 0u);
+    }
+}
+
+template <int NPROB>
+__global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(const SaPkBatch batch, unsigned int *__restrict__ rec, int tiles_per_wg)
 {
     __shared__ float lds[2 * PK_ROWS * PK_LD];
     __shared__ unsigned int slot[2];
@@ -200,14 +223,34 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
+    // a workgroup starts on problem x % nprob and, when that problem's tiles have run out, moves on to the other one (it reloads the
+    // weights once): the tile counts live on the device, so the split of the launch's workgroups between the problems cannot be
+    // chosen on the host -- LiDAR-shaped scenes give the two scales of RPN SA2 27 % and 73 % of the rows
+    // (NPROB = 1, every single-problem launch: no loop, the kernel of rounds 2-4 register for register)
+    const int pi0 = NPROB > 1 ? (int)(blockIdx.x % (unsigned)NPROB) : 0;
+#pragma unroll 1
+    for (int attempt = 0; attempt < NPROB; ++attempt) {
+    const int pi = NPROB > 1 ? __builtin_amdgcn_readfirstlane(pi0 + attempt < NPROB ? pi0 + attempt : pi0 + attempt - NPROB) : 0;   // provably uniform: the problem's fields stay in SGPRs
+    const SaPkProblem &q = batch.p[pi];
+    const int n = q.n, m = q.m;
+    const unsigned int *__restrict__ hdr = q.hdr;
+    const float4 *__restrict__ rowdxyz = q.rowdxyz;
+    const float4 *__restrict__ P = q.P /* (b,n,128) */, *__restrict__ wxyz = q.wxyz /* (3,128) */;
+    const unsigned int *__restrict__ rowinfo = q.rowinfo;
+    const int *__restrict__ tilecloud = q.tilecloud;
+    const float *__restrict__ w2t = q.w2t, *__restrict__ b2 = q.b2, *__restrict__ w3t = q.w3t, *__restrict__ b3 = q.b3;
+    float *__restrict__ out = q.out;
+    const int out_stride = q.out_stride, out_col = q.out_col, lds_pool = q.lds_pool;
+    unsigned int *__restrict__ ticket = rec + 2 * pi;                 // this problem's draw counter
     const long tiles = hdr[0];
 
     // first ticket BEFORE the weights are fetched: the grid is sized for the worst case (every ball full) and most
     // workgroups of a sparse launch leave right here
+    __syncthreads();                                                  // (a second attempt reuses the slots and the tile buffers)
     if (tid == 0) slot[0] = atomicAdd(ticket, 1u);
     __syncthreads();
     long t = slot[0];
-    if (t >= tiles) { if (tid == 0) ticket_release(ticket); return; }
+    if (t >= tiles) continue;
 
     float wf2[64], wf3[64];
 #pragma unroll
@@ -327,7 +370,8 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(
         // already write the next one.
         t = t_next;
     }
-    if (tid == 0) ticket_release(ticket);          // the launch's last workgroup zeroes the counter for the word's next user
+    }   // attempt
+    if (tid == 0) ticket_release3(rec);          // the launch's last workgroup zeroes the counters for the record's next user
 }
 
 // ------------------------------------------------------------------------------------------------ C3 = 256
@@ -633,11 +677,58 @@ extern "C" int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, 
     // row-major pooling through LDS needs 16-byte aligned output rows; PRCNN_SEGMAX_LDS=0 keeps every tile on the register form
     static const bool env_lds = !(getenv("PRCNN_SEGMAX_LDS") && atoi(getenv("PRCNN_SEGMAX_LDS")) == 0);
     const int lds_pool = env_lds && (((uintptr_t)out | (uintptr_t)b3) & 15) == 0 && out_stride % 4 == 0 && out_col % 4 == 0;
-    if (c3 == 128)
-        hipLaunchKernelGGL(sa_packed_mlp128_kernel, dim3(grid), dim3(256), 0, st, n, m, hdr, (const float4 *)rowdxyz, (const float4 *)P,
-                           (const float4 *)wxyz, rowinfo, tilecloud, w2t, b2, w3t, b3, out, out_stride, out_col, ticket, per_wg, lds_pool);
-    else
+    if (c3 == 128) {
+        SaPkBatch batch;
+        batch.nprob = 1;
+        batch.p[0] = SaPkProblem{n, m, hdr, (const float4 *)rowdxyz, (const float4 *)P, (const float4 *)wxyz, rowinfo, tilecloud, w2t, b2, w3t, b3,
+                                 out, out_stride, out_col, lds_pool};
+        batch.p[1] = batch.p[0];
+        hipLaunchKernelGGL(sa_packed_mlp128_kernel<1>, dim3(grid), dim3(256), 0, st, batch, ticket, per_wg);
+    } else
         hipLaunchKernelGGL(sa_packed_mlp256_kernel, dim3(grid), dim3(512), 0, st, n, m, hdr, (const float4 *)rowdxyz, (const float4 *)P,
                            (const float4 *)wxyz, rowinfo, tilecloud, w2t, b2, w3t, b3, out, out_stride, out_col, ticket, per_wg, lds_pool);
     return check_launch("sa_packed_mlp");
+}
+
+// Up to two 128-wide problems (the scales of one MSG level) in ONE launch of sa_packed_mlp128_kernel: see the kernel.  Same arguments
+// per problem as prcnn_sa_packed_mlp (c3 = 128), every output slice zero already or zeroed here.
+extern "C" int prcnn_sa_packed_mlp_batch(int nprob, const prcnn_sa_problem *pr, void *stream)
+{
+    PRCNN_REQUIRE(nprob >= 1 && nprob <= 2 && pr, "sa_packed_mlp_batch: 1 or 2 problems");
+    hipStream_t st = (hipStream_t)stream;
+    static const int env_grid = getenv("PRCNN_SA_GRID") ? atoi(getenv("PRCNN_SA_GRID")) : 512;
+    static const bool env_lds = !(getenv("PRCNN_SEGMAX_LDS") && atoi(getenv("PRCNN_SEGMAX_LDS")) == 0);
+    SaPkBatch batch;
+    batch.nprob = nprob;
+    long most = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const prcnn_sa_problem &q = pr[i];
+        PRCNN_REQUIRE(q.b >= 0 && q.n >= 0 && q.m >= 0 && q.max_tiles >= 0 && q.c3 == 128, "sa_packed_mlp_batch: bad sizes (c3 = 128 only)");
+        PRCNN_REQUIRE(q.n <= 65536 && q.m <= 65536, "sa_packed_mlp_batch: cloud too large for the 16-bit row descriptors");
+        PRCNN_REQUIRE(q.out_stride >= q.out_col + 128 && q.out_col >= 0, "sa_packed_mlp_batch: bad output slice");
+        PRCNN_REQUIRE((long)q.b * q.m > 0 && q.max_tiles > 0, "sa_packed_mlp_batch: empty problem (use prcnn_sa_packed_mlp)");
+        PRCNN_REQUIRE(q.P && q.wxyz && q.rowinfo && q.rowdxyz && q.tilecloud && q.hdr && q.w2t && q.b2 && q.w3t && q.b3 && q.out, "sa_packed_mlp_batch: null pointer");
+        PRCNN_REQUIRE((((uintptr_t)q.P | (uintptr_t)q.wxyz) & 15) == 0, "sa_packed_mlp_batch: 16-byte alignment required");
+        if (!q.out_is_zero && hipMemset2DAsync(q.out + q.out_col, (size_t)q.out_stride * sizeof(float), 0, (size_t)128 * sizeof(float), (size_t)q.b * q.m, st) != hipSuccess) {
+            set_error("sa_packed_mlp_batch: cannot zero the output slice");
+            return PRCNN_ELAUNCH;
+        }
+        const int lds_pool = env_lds && (((uintptr_t)q.out | (uintptr_t)q.b3) & 15) == 0 && q.out_stride % 4 == 0 && q.out_col % 4 == 0;
+        batch.p[i] = SaPkProblem{q.n, q.m, q.hdr, (const float4 *)q.rowdxyz, (const float4 *)q.P, (const float4 *)q.wxyz, q.rowinfo, q.tilecloud,
+                                 q.w2t, q.b2, q.w3t, q.b3, q.out, q.out_stride, q.out_col, lds_pool};
+        most = q.max_tiles > most ? q.max_tiles : most;
+    }
+    if (nprob == 1) batch.p[1] = batch.p[0];
+    int per_wg = PK_TILES_PER_WG;
+    long grid1 = (most + per_wg - 1) / per_wg;
+    if (env_grid > 0) {
+        const long cap = (env_grid + nprob - 1) / nprob;           // the launch's workgroups together: as many as one problem's launch had
+        if (grid1 > cap) grid1 = cap;
+        per_wg = 1 << 30;
+    }
+    unsigned int *ticket = next_ticket(st);
+    if (!ticket) { set_error("sa_packed_mlp_batch: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
+    if (nprob == 1) hipLaunchKernelGGL(sa_packed_mlp128_kernel<1>, dim3((unsigned)grid1), dim3(256), 0, st, batch, ticket, per_wg);
+    else hipLaunchKernelGGL(sa_packed_mlp128_kernel<2>, dim3((unsigned)(grid1 * nprob)), dim3(256), 0, st, batch, ticket, per_wg);
+    return check_launch("sa_packed_mlp_batch");
 }

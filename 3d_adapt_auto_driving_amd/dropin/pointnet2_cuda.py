@@ -380,6 +380,24 @@ def sa_packed_mlp_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, ou
     return out
 
 
+def sa_packed_mlp_batch_wrapper(problems):
+    """sa_packed_mlp_wrapper for the (up to two) 128-wide scales of one MSG level in ONE launch (round 5):
+    [(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col, zeroed), ...]; same results as one call per problem."""
+    arr = (_lib.SaProblem * len(problems))()
+    for q, (new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col, zeroed) in zip(arr, problems):
+        _chk(torch.float32, new_xyz, xyz, P, wxyz, w2t, b2, w3t, b3, out)
+        b, n, c1 = P.shape
+        if c1 != 128 or w2t.shape != (128, 128) or tuple(w3t.shape) != (128, 128):
+            raise RuntimeError("pointnet2_cuda: sa_packed_mlp_batch takes 128-128-128 (zero-padded) problems")
+        q.b, q.n, q.m, q.c3, q.max_tiles = b, n, new_xyz.size(1), 128, pack.max_tiles
+        q.P, q.wxyz, q.rowinfo, q.rowdxyz = P.data_ptr(), wxyz.data_ptr(), pack.rowinfo.data_ptr(), pack.rowdxyz.data_ptr()
+        q.tilecloud, q.hdr = pack.tilecloud.data_ptr(), pack.hdr.data_ptr()
+        q.w2t, q.b2, q.w3t, q.b3 = w2t.data_ptr(), b2.data_ptr(), w3t.data_ptr(), b3.data_ptr()
+        q.out, q.out_stride, q.out_col, q.out_is_zero = out.data_ptr(), out.size(-1), int(out_col), int(bool(zeroed))
+    _lib.call("prcnn_sa_packed_mlp_batch", len(problems), arr, _lib.current_stream(problems[0][1]))
+    return [p[9] for p in problems]
+
+
 def packed_gather_affine_wrapper(new_xyz, xyz, P, wxyz, pack, out):
     """Layer 1 over a packed row list: out (pack.max_tiles*64, c1) = relu(P[point] + wxyz.(xyz[point] - centre))."""
     _chk(torch.float32, new_xyz, xyz, P, wxyz, out)

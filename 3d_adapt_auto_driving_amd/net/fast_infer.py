@@ -56,6 +56,7 @@ USE_RPN_TAIL = os.environ.get("PRCNN_NO_RPN_TAIL") is None
 # the scales of a wide MSG level (RPN SA3 / SA4) stage by stage, side by side in one launch per stage; PRCNN_NO_SCALE_BATCH=1: A/B
 USE_SCALE_BATCH = os.environ.get("PRCNN_NO_SCALE_BATCH") is None
 # layers 1-3 + pool of a wide scale in one kernel (csrc/sa_wide.hip); PRCNN_NO_WIDE_FUSED=1: gather / layer / layer+pool launches
+USE_SA2_BATCH = os.environ.get("PRCNN_NO_SA2_BATCH") is None        # the two 128-wide scales of an MSG level (RPN SA2) in one launch per stage (round 5)
 USE_WIDE_FUSED = os.environ.get("PRCNN_NO_WIDE_FUSED") is None
 # ... and layer 1 inside as well where a level groups every point once (the RCNN's GroupAll level; csrc/sa_wide3.hip);
 # PRCNN_NO_WIDE_FUSED3=1: the per-point layer as a launch of its own in front of csrc/sa_wide.hip (A/B, same bits)
@@ -759,6 +760,23 @@ class FastPointRCNN:
         if (USE_SCALE_BATCH and USE_PACKED and 2 <= len(scales) <= 4 and all(sc[2].wide is not None for sc in scales) and
                 has_entry(pu.pointnet2, "packed_layer_batch_wrapper")):
             self._sa_level_wide(cur_xyz, lev["new_xyz"], cur_feat, scales, lev["idx"], packs, out, pre)
+        elif (USE_SCALE_BATCH and USE_SA2_BATCH and USE_PACKED and len(scales) == 2 and cur_feat is not None and cur_feat.shape[2] % 128 == 0 and
+              all(sc[2].packed is not None and sc[2].packed[5].shape[1] == 128 and sc[2].packed[0].shape[0] == cur_feat.shape[2] for sc in scales) and
+              all(pk is not None for pk in packs) and has_entry(pu.pointnet2, "sa_packed_mlp_batch_wrapper")
+              and has_entry(pu.pointnet2, "packed_layer_batch_wrapper")):
+            # both 128-wide scales of the level side by side (round 5): their per-point parts in one layer launch, their fused
+            # gather -> layer 2 -> layer 3 -> pool kernels in one launch -- 2 launches for the level instead of 4; same kernels, same bits
+            ext = pu.pointnet2
+            B, N, _ = cur_xyz.shape
+            flat = cur_feat.view(B * N, cur_feat.shape[2])
+            Ps = [torch.empty((B * N, 128), dtype=torch.float32, device=cur_xyz.device) for _ in scales]
+            ext.packed_layer_batch_wrapper([(flat, sc[2].packed[0], sc[2].packed[2], False, P, None) for sc, P in zip(scales, Ps)])
+            probs, col = [], 0
+            for (radius, ns, mlp, cin), pack, P in zip(scales, packs, Ps):
+                wf, wx, b1, w2, b2, w3, b3 = mlp.packed
+                probs.append((lev["new_xyz"], cur_xyz, P.view(B, N, 128), wx, pack, w2, b2, w3, b3, out, col, pre))
+                col += mlp.layers[-1][0].shape[1]
+            ext.sa_packed_mlp_batch_wrapper(probs)
         else:
             col = 0
             for (radius, ns, mlp, cin), idx, pack in zip(scales, lev["idx"], packs):

@@ -59,6 +59,7 @@ SWITCHES = {
     "PRCNN_NO_RPN_TAIL": ("ab", "unset", "net/fast_infer.py", "finest FP module and RPN heads layer by layer"),
     "PRCNN_FPS_NO_PAIR": ("ab", "unset", "csrc/fps.hip", "set: sampling of 16384 < n <= 32768 points on fps_generic_kernel (rounds 1-4: 30.5 ms for 8 x 32768 -> 4096) instead of two workgroups per cloud (fps_spec2_kernel: 2.65 ms)"),
     "PRCNN_TAIL_DECODE": ("ab", "1", "net/fast_infer.py", "0: the fused RPN tail stores the (B, N, 76) regression rows and the proposal layer decodes them (rpn_decode_kernel) instead of decoding inside the tail kernel (round 5)"),
+    "PRCNN_NO_SA2_BATCH": ("ab", "unset", "net/fast_infer.py", "set: the two 128-wide scales of an MSG level (RPN SA2) as two launches per stage instead of one (prcnn_sa_packed_mlp_batch, round 5)"),
     "PRCNN_NO_SCALE_BATCH": ("ab", "unset", "net/fast_infer.py", "one launch per MSG scale"),
     "PRCNN_NO_WIDE_FUSED": ("ab", "unset", "net/fast_infer.py", "GroupAll level layer by layer"),
     "PRCNN_NO_WIDE_FUSED3": ("ab", "unset", "net/fast_infer.py", "1: the GroupAll level's layer 1 as a per-point launch in front of csrc/sa_wide.hip instead of inside csrc/sa_wide3.hip"),

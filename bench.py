@@ -68,11 +68,11 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32 MFMA peak (MI355X_MICROARCH.md)
 # HBM traffic per launch from the rocprofv3 PMC passes over the product step (FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950
 # + WRITE_SIZE), kept with the profile it came from; a kernel that has no entry reports null
-PMC_SOURCE = "profiles/r04_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the product step)"
+PMC_SOURCE = "profiles/r05_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the product step)"
 # keyed by the scenes per launch the passes ran at (profiles/pmc_step_probe.py: 16 = a pair of batches, the product's launch since the
 # second session of round 4; 8: the passes of rounds 2-4 over single batches)
 PMC_TRAFFIC = {8: {"rpn_tail_lin_kernel": 148.96e6, "rpn_tail_kernel": 325.87e6, "roipool3d_canonical_kernel": 87.06e6},
-               16: {"rpn_tail_lin_kernel": 297.60e6, "roipool3d_canonical_kernel": 172.60e6}}
+               16: {"rpn_tail_lin_kernel": 297.60e6, "rpn_tail_lin_kernel<decode>": 210.58e6, "roipool3d_canonical_kernel": 172.63e6}}
 # scenes per launch of the stages behind the geometry in the product runner (eval_rcnn.GraphedRunner pairs batches: PRCNN_PAIR = 2): the
 # roofline legs of those kernels run at THIS size, and their PMC traffic comes from passes at this size
 def launch_scenes():
@@ -206,12 +206,20 @@ def roofline_rpn_tail(dev, cfg, model, reps=20):
     B, N = idx.shape[0], idx.shape[1]
     feats = torch.empty((B, N, 128), device=dev); cls = torch.empty((B, N, 1), device=dev); reg = torch.empty((B, N, tw["n_reg"]), device=dev)
     lin = bool(F.USE_FP_LINEAR and hasattr(pu.pointnet2, "rpn_tail_lin_wrapper"))
+    dec = None
     if lin:
         # the engine's form since round 3: FP layer 1 applied over the coarse points (its own small launch, not timed here), the fused
         # kernel interpolates the 128-wide product and starts at layer 2
         m = known.shape[1]
         G = F.point_layer(known.view(B * m, known.shape[2]), tw["w1"], tw["zero128"], False).view(B, m, 128)
-        run = lambda: pu.pointnet2.rpn_tail_lin_wrapper(G, idx, weight, tw["wcat_lin"], tw["bcat"], tw["wc2"], tw["bc2"], feats, cls, reg)
+        dec = eng._tail_decode_cfg()
+        if dec is not None:
+            # the product's form since round 5: the proposal layer's decode inside -- the 7-float box leaves instead of the 76-float row
+            boxes = torch.empty((B, N, 7), device=dev)
+            run = lambda: pu.pointnet2.rpn_tail_lin_boxes_wrapper(G, idx, weight, tw["wcat_lin"], tw["bcat"], tw["wc2"], tw["bc2"], tw["n_reg"],
+                                                                  dec[0], dec[1], dec[2], dec[3], dec[4], pts, feats, cls, boxes)
+        else:
+            run = lambda: pu.pointnet2.rpn_tail_lin_wrapper(G, idx, weight, tw["wcat_lin"], tw["bcat"], tw["wc2"], tw["bc2"], feats, cls, reg)
     else:
         run = lambda: pu.pointnet2.rpn_tail_wrapper(known, idx, weight, tw["wcat"], tw["bcat"], tw["wc2"], tw["bc2"], feats, cls, reg)
     for _ in range(3):
@@ -228,20 +236,25 @@ def roofline_rpn_tail(dev, cfg, model, reps=20):
     # tile (`padded_flops`): those columns multiply zeros and are NOT counted in `achieved`.
     l1 = 0 if lin else 256 * 128
     flops = 2.0 * rows * (l1 + 3 * 128 * 128 + 128 + 128 * tw["n_reg"])
-    padded_flops = 2.0 * rows * (l1 + 3 * 128 * 128 + 128 + 128 * 128)
+    narrow = lin and 64 < tw["n_reg"] <= 80 and os.environ.get("PRCNN_TAIL_NARROW", "1") != "0"     # round 5: 80 computed columns, not 128
+    padded_flops = 2.0 * rows * (l1 + 3 * 128 * 128 + 128 + 128 * (80 if narrow else 128))
     achieved = flops / (ms * 1e-3) / 1e12
     table = (G if lin else known).numel() * 4
-    alg_bytes = table + rows * 24 + rows * (128 + 1 + tw["n_reg"]) * 4
+    # read the interpolated table once, indices + weights (+ the coordinates when the boxes are decoded here); write features, score and
+    # the regression row -- or, decoded, the 7-float box
+    alg_bytes = table + rows * 24 + (rows * 12 if dec is not None else 0) + rows * (128 + 1 + (7 if dec is not None else tw["n_reg"])) * 4
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": PMC_TRAFFIC.get(B, {}).get("rpn_tail_lin_kernel" if lin else "rpn_tail_kernel"),
+            "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": PMC_TRAFFIC.get(B, {}).get(("rpn_tail_lin_kernel<decode>" if dec is not None else "rpn_tail_lin_kernel") if lin else "rpn_tail_kernel"),
             "traffic_source": PMC_SOURCE,
             "kernel": "%s (prcnn_rpn_tail%s): the largest single launch on the FEATURE stream (the longest launch of "
                       "the step overall is the sampling kernel on a side stream: see roofline_longest)" % (
-                          "rpn_tail_lin_kernel" if lin else "rpn_tail_kernel", "_lin" if lin else ""),
+                          ("rpn_tail_lin_kernel<decode, narrow>" if dec is not None else "rpn_tail_lin_kernel") if lin else "rpn_tail_kernel",
+                          ("_lin_boxes" if dec is not None else "_lin") if lin else ""),
             "launch_ms": round(ms, 4), "algorithmic_flops_per_launch": flops, "padded_flops_per_launch": padded_flops,
             "algorithmic_bytes_per_launch": alg_bytes,
             "shape": {"scenes_per_launch": B, "points": rows, "coarse_points": known.shape[0] * known.shape[1],
-                      "layers": ("interp(128) | 128-128 | 128-128-1 | 128-128-%d" if lin else "256-128-128 | 128-128-1 | 128-128-%d") % tw["n_reg"]}}
+                      "layers": (("interp(128) | 128-128 | 128-128-1 | 128-128-%d" + (" | box decode" if dec is not None else "")) if lin
+                                 else "256-128-128 | 128-128-1 | 128-128-%d") % tw["n_reg"]}}
 
 
 def roofline_roipool(dev, cfg, model, reps=20):
@@ -566,6 +579,7 @@ def main():
             gc.enable()
             raise
         allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+        timed_run.slot_phase = getattr(runner, "_next_slot", 0) % max(1, getattr(runner, "n_slots", 1))   # diagnostic: which group slot / side stream the window's first chain takes
         try:
             t0 = time.perf_counter()
             for i in range(warmup, total):
@@ -592,10 +606,11 @@ def main():
     # window's rate is in config.windows: a single 26-ms window is at the mercy of the clock ramp of an idle GPU).
     ids = list(range(rank * args.steps * BATCH, (rank + 1) * args.steps * BATCH))
     import gc
-    window_s, allocs_w = [], []
+    window_s, allocs_w, phases_w = [], [], []
     for _ in range(max(1, args.windows)):
         t0, dets = timed_run(args.steps, args.warmup, keep_gc_off=True)
         allocs_w.append(getattr(timed_run, "device_allocs", None))     # hipMalloc calls inside the timed region (each one stalls the device)
+        phases_w.append(getattr(timed_run, "slot_phase", None))
         # the one exchange of the job: padded detection tables of this rank's scenes
         table, counts = E.pack_detections(ids, dets, M)
         table, counts = E.all_gather_detections(table, counts, comm_dev)
@@ -721,7 +736,8 @@ def main():
                    "lidar_like": lidar, "double_yaml_scenes_per_s": double_leg,
                    # every closed window of this run (W + K steps each), in run order; `value` is the median one
                    "windows": {"n": len(window_s), "reported": "median", "scenes_per_s": [round(world * args.steps * BATCH / w, 1) for w in window_s],
-                               "min": round(world * args.steps * BATCH / max(window_s), 1), "max": round(world * args.steps * BATCH / min(window_s), 1)},
+                               "min": round(world * args.steps * BATCH / max(window_s), 1), "max": round(world * args.steps * BATCH / min(window_s), 1),
+                               "first_group_slot": phases_w},
                    "device_allocs_in_timed_region": allocs_main,
                    # every PRCNN_* switch this process saw (22 of them select kernels at import time): a line
                    # measured with a non-default engine says so

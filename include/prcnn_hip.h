@@ -280,6 +280,13 @@ typedef struct prcnn_layer_problem {
     const float *bias; int relu; float *out; long ldo;
     int b, m; const unsigned int *rowinfo; const int *tilecloud; int out_col, out_is_zero;
 } prcnn_layer_problem;
+/* one 128-wide problem of prcnn_sa_packed_mlp (c3 = 128): the two scales of an MSG level go into ONE launch (round 5) */
+typedef struct prcnn_sa_problem {
+    int b, n, m, c3; long max_tiles; const float *P; const float *wxyz; const unsigned int *rowinfo; const float *rowdxyz;
+    const int *tilecloud; const unsigned int *hdr; const float *w2t; const float *b2; const float *w3t; const float *b3;
+    float *out; int out_stride, out_col, out_is_zero;
+} prcnn_sa_problem;
+int prcnn_sa_packed_mlp_batch(int nprob, const prcnn_sa_problem *problems, void *stream);
 int prcnn_packed_gather_affine_batch(int nprob, const prcnn_gather_problem *problems, void *stream);
 int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *problems, int segmax, void *stream);
 int prcnn_packed_gather_affine(int b, int n, int c1, long max_tiles, const float *P, const float *wxyz,

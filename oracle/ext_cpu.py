@@ -309,6 +309,10 @@ class pointnet2_cpu:
         return pointnet2_cpu.sa_wide_fused_wrapper(new_xyz, xyz, P.view(b, n, c1), wxyz, pack, w2, b2, w3, b3, out, out_col, zeroed)
 
     @staticmethod
+    def sa_packed_mlp_batch_wrapper(problems):
+        return [pointnet2_cpu.sa_packed_mlp_wrapper(*p) for p in problems]
+
+    @staticmethod
     def packed_gather_affine_batch_wrapper(problems):
         return [pointnet2_cpu.packed_gather_affine_wrapper(*p) for p in problems]
 
