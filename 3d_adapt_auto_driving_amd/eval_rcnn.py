@@ -1145,10 +1145,13 @@ def host_budget(world=None, local_rank=None, cores=None):
     per = max(1, len(cores) // world_slices)
     k = local_rank % world_slices
     mine = cores[k * per:k * per + per] or cores
-    # one core for the thread that feeds the GPU, a quarter of the rest for the writers (text formatting), the rest for the loaders
+    # one core for the thread that feeds the GPU, a quarter of the rest for the writers (text formatting), the rest for the loaders --
+    # at most 6 + 2 (round 5, profiles/r05_driver_shares.md: the whole driver runs 5260-5400 scenes/s with 6 loaders + 2 writers,
+    # 4550-5110 with 8 + 2, 3800-3900 with 8-10 + 3 and 3200-3600 with the 16 + 6 of rounds 2-4 on the same 256-core box: beyond what
+    # the engine consumes, more producer processes only add wake-ups and pinned-memory traffic around the one thread that feeds the GPU)
     spare = max(1, len(mine) - 1)
-    writers = max(1, min(6, spare // 4))
-    loaders = max(1, min(16, spare - writers))
+    writers = max(1, min(2, spare // 4))
+    loaders = max(1, min(6, spare - writers))
     return {"cores": mine, "loaders": int(os.environ.get("PRCNN_LOADER_WORKERS", loaders)),
             "writers": int(os.environ.get("PRCNN_WRITER_PROCS", writers)), "world": world, "local_rank": local_rank}
 
