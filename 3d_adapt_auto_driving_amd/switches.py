@@ -36,6 +36,7 @@ SWITCHES = {
     "PRCNN_LIB_GEMM": ("numerics", "unset", "net/fast_infer.py", "per-point layers through torch (library GEMM) instead of csrc/packed_layer.hip"),
     "PRCNN_ALLOW_LIB_GEMM": ("numerics", "unset", "net/fast_infer.py", "1: permit a library GEMM for a shape the layer kernels do not cover (else: error)"),
     "PRCNN_TAIL_NARROW": ("numerics", "1", "csrc/rpn_tail.hip", "0: the RPN regression head's last layer as a zero-padded 128-column stage (rounds 2-4) instead of 64 columns on 32x32x2 + 16 on v_mfma_f32_16x16x4_f32 (another k order in columns 64..75, ~1e-7 relative; the oracle stand-in reads the same switch)"),
+    "PRCNN_NO_PACK": ("numerics", "unset", "net/fast_infer.py", "all grouped rows instead of the distinct rows (prcnn_ball_pack) -- and, without the packed row lists, the per-point layers through the GEMM library (needs PRCNN_ALLOW_LIB_GEMM=1 on a covered network): the all-rows leg of bench.py"),
     "PRCNN_ROWS_GEMM": ("numerics", "unset", "net/fast_infer.py", "128-wide row layers through rows_gemm128 (round-1 form)"),
     # ---- scheduling A/B (same results)
     "PRCNN_EARLY_LEVELS": ("ab", "4", "net/fast_infer.py", "leading SA levels computed with the geometry"),
@@ -49,14 +50,13 @@ SWITCHES = {
     "PRCNN_SIDE_PRIORITY": ("ab", "0", "eval_rcnn.py", "HIP priority of the side streams"),
     "PRCNN_TAIL_PRIORITY": ("ab", "0", "eval_rcnn.py", "HIP priority of the proposal stream"),
     # ---- engine formulations A/B (same results)
-    "PRCNN_NO_PACK": ("ab", "unset", "net/fast_infer.py", "all grouped rows instead of the distinct rows (prcnn_ball_pack)"),
     "PRCNN_NO_POOL_DEDUP": ("ab", "unset", "net/fast_infer.py", "RCNN point MLP over all 512 pooled rows"),
     "PRCNN_NO_CENTRE_DEDUP": ("ab", "unset", "net/fast_infer.py", "no representative map over sampled centres"),
     "PRCNN_NO_CENTRE_SKIP": ("ab", "unset", "net/fast_infer.py", "copies of a centre keep rows of their own"),
     "PRCNN_NO_POOL_GROUPS": ("ab", "unset", "net/fast_infer.py", "RoI pooling sweeps all points (no spatial groups)"),
     "PRCNN_NO_POINT_MLP": ("ab", "unset", "net/fast_infer.py", "RCNN entrance as separate layers"),
     "PRCNN_NO_ROI_GEOMETRY": ("ab", "unset", "net/fast_infer.py", "RCNN sampling / ball queries as six launches"),
-    "PRCNN_NO_RPN_TAIL": ("ab", "unset", "net/fast_infer.py", "finest FP module and RPN heads layer by layer"),
+    "PRCNN_NO_RPN_TAIL": ("ab", "unset", "net/fast_infer.py", "finest FP module and RPN heads layer by layer (the bits of the fused tail under PRCNN_NO_FP_LINEAR=1: the layer-by-layer form keeps the reference's association)"),
     "PRCNN_FPS_NO_PAIR": ("ab", "unset", "csrc/fps.hip", "set: sampling of 16384 < n <= 32768 points on fps_generic_kernel (rounds 1-4: 30.5 ms for 8 x 32768 -> 4096) instead of two workgroups per cloud (fps_spec2_kernel: 2.65 ms)"),
     "PRCNN_TAIL_DECODE": ("ab", "1", "net/fast_infer.py", "0: the fused RPN tail stores the (B, N, 76) regression rows and the proposal layer decodes them (rpn_decode_kernel) instead of decoding inside the tail kernel (round 5)"),
     "PRCNN_NO_SA2_BATCH": ("ab", "unset", "net/fast_infer.py", "set: the two 128-wide scales of an MSG level (RPN SA2) as two launches per stage instead of one (prcnn_sa_packed_mlp_batch, round 5)"),
