@@ -609,3 +609,23 @@ def test_every_switch_is_registered():
             assert SW.check_environment() == ["PRCNN_NO_SUCH_SWITCH"] and len(w) == 1
     finally:
         del os.environ["PRCNN_NO_SUCH_SWITCH"]
+
+
+def test_rcnn_use_intensity_in_the_joint_path_fails_as_the_reference_does(oracle):
+    """cfg.RCNN.USE_INTENSITY = True has NO behaviour on the hot path: the reference's joint forward builds the RCNN's input without
+    the reflectance (point_rcnn.py:53-57) and rcnn_net.py:131 then reads `rpn_intensity` -- KeyError('rpn_intensity'), verified by
+    running the reference under the shims (tests/golden/ref_harness.py; the flag only works in the reference's offline RCNN mode,
+    outside SURVEY section 8).  This build's model keeps that: the same exception from the same place, nothing silently different;
+    `engine_covers` sends the configuration to the nn.Module graph so that it surfaces."""
+    from oracle import ext_cpu
+    C, E = pkg("config"), pkg("eval_rcnn")
+    cfg = C.default_eval_cfg()
+    C.merge_into(TINY, cfg)
+    C.merge_into({"RCNN": {"USE_INTENSITY": True}}, cfg)
+    assert not E.engine_covers(cfg)
+    model = E.build_model(cfg, "cpu")
+    assert model.rcnn_net.rcnn_input_channel == 6                       # rcnn_net.py:22: 3 + intensity + mask + depth
+    pts = torch.from_numpy(pkg("synth").scenes(1, cfg.RPN.NUM_POINTS, seed0=5))
+    with ext_cpu.patch_package(), pytest.raises(KeyError, match="rpn_intensity"):
+        with torch.no_grad():
+            model({"pts_input": pts})
