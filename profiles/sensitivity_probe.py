@@ -1,0 +1,62 @@
+"""How much of a kernel's time is on the step's critical resource?  The closed loop of the product runner (K batches of 8 scenes) with ONE
+extension entry launched TWICE per call (the second launch recomputes the same outputs: every entry listed is idempotent), against the
+unmodified loop: d(ms per step) / (the entry's solo time per step) ~ 1 means the chip has nothing to hide it behind, ~ 0 means it is free.
+usage: python profiles/sensitivity_probe.py [uniform|lidar] [K]"""
+import importlib, os, subprocess, sys, time
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TARGETS = [("none", None, None), ("fps_new_xyz (sampling, 32 CUs)", "pointnet2", "fps_new_xyz_wrapper"),
+           ("rpn_tail_lin_boxes (MFMA, whole chip)", "pointnet2", "rpn_tail_lin_boxes_wrapper"),
+           ("forward_canonical (RoI pooling, HBM)", "roipool3d", "forward_canonical"),
+           ("rcnn_roi_geometry (a wave per RoI)", "pointnet2", "rcnn_roi_geometry_wrapper"),
+           ("rpn_proposals_boxes (sort, bands, NMS)", "iou3d", "rpn_proposals_boxes"),
+           ("rcnn_point_mlp (entrance, MFMA)", "pointnet2", "rcnn_point_mlp_wrapper"),
+           ("sa_wide_fused3 (MFMA)", "pointnet2", "sa_wide_fused3_wrapper"),
+           ("ball_query_full (grid build + query)", "pointnet2", "ball_query_full_wrapper"),
+           ("three_nn_weights", "pointnet2", "three_nn_weights_wrapper"),
+           ("rcnn_postprocess_blobs (final stage)", "iou3d", "rcnn_postprocess_blobs"),
+           ("fps_new_xyz, level 4096 -> 1024 only (+0.41 ms per group)", "pointnet2", "fps_new_xyz_wrapper:4096"),
+           ("fps_new_xyz, level 1024 -> 256 only (+0.15 ms per group)", "pointnet2", "fps_new_xyz_wrapper:1024")]
+if len(sys.argv) > 3:
+    sys.path.insert(0, ROOT)
+    import torch
+    PKG = "3d_adapt_auto_driving_amd"
+    C, E, S = (importlib.import_module(PKG + "." + m) for m in ("config", "eval_rcnn", "synth"))
+    kind, K, which = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    name, modname, fn = TARGETS[which]
+    only_n = None
+    if fn and ":" in fn:
+        fn, only_n = fn.split(":")[0], int(fn.split(":")[1])
+    if fn:
+        mod = {"pointnet2": importlib.import_module(PKG + ".pointnet2.pointnet2_utils").pointnet2,
+               "roipool3d": importlib.import_module(PKG + ".roipool3d_utils").roipool3d_cuda,
+               "iou3d": importlib.import_module(PKG + ".iou3d_utils").iou3d_cuda}[modname]
+        real = getattr(mod, fn)
+        def twice(*a, **k):
+            if only_n is None or a[0].shape[1] == only_n:
+                real(*a, **k)
+            return real(*a, **k)
+        setattr(mod, fn, twice)
+    dev = "cuda:0"
+    cfg = C.default_eval_cfg()
+    model = E.build_model(cfg, dev, seed=0)
+    make = S.lidar_scenes if kind == "lidar" else S.scenes
+    batches = [torch.from_numpy(make(8, 16384, seed0=1000 + 8 * s)).to(dev) for s in range(16)]
+    runner = E.make_runner(model, cfg, dev)
+    def loop(k):
+        for i in range(k):
+            runner.submit(batches[i % 16], [batches[(i + d) % 16] for d in range(1, runner.depth + 1) if i + d < k])
+        runner.drain()
+        torch.cuda.synchronize()
+    loop(16)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter(); loop(K); best = min(best, (time.perf_counter() - t0) / K * 1e3)
+    print("%-44s %.4f ms per step" % (name, best), flush=True)
+else:
+    kind = sys.argv[1] if len(sys.argv) > 1 else "uniform"
+    K = sys.argv[2] if len(sys.argv) > 2 else "100"
+    for w in ([int(v) for v in sys.argv[3:]] if False else range(len(TARGETS))):
+        if os.environ.get("SENS_ONLY") and str(w) not in os.environ["SENS_ONLY"].split(","):
+            continue
+        subprocess.run([sys.executable, os.path.abspath(__file__), kind, K, str(w)])
