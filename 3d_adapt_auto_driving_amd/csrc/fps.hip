@@ -1311,14 +1311,10 @@ __device__ __forceinline__ void roi_fps(int n, int m, KeyCodec kc, const float (
     if (lane == 0) s_sel[0] = 0;
     for (int j = 1; j < m; ++j) {
         const int pl = old & 63, pi = old >> 6;
+        // the pivot's coordinates: three v_readlane behind a scalar compare ladder on its (uniform) slot -- reading all PPT slots and
+        // selecting (the first form) was 3 PPT v_readlane in front of every pick of a chain that is latency-bound from end to end
         float ox = 0.f, oy = 0.f, oz = 0.f;
-#pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const float vx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[i]), pl));
-            const float vy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[i]), pl));
-            const float vz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[i]), pl));
-            if (i == pi) { ox = vx; oy = vy; oz = vz; }
-        }
+        fs_pick3<PPT>(px, py, pz, pi, pl, ox, oy, oz);
         float lv = -INFINITY;
         if (kc.hipcc) {
 #pragma unroll
@@ -1359,7 +1355,7 @@ __device__ __forceinline__ void roi_fps(int n, int m, KeyCodec kc, const float (
 template <int PPT, int CPL>
 __device__ __forceinline__ void roi_ball_query(int n_scan, int ns, float r2, const float (&px)[PPT], const float (&py)[PPT],
                                                const float (&pz)[PPT], const float (&cx)[CPL], const float (&cy)[CPL], const float (&cz)[CPL],
-                                               const bool (&live)[CPL], int *__restrict__ s_hits, int stride, int *__restrict__ s_cnt, const int lane)
+                                               const bool (&live)[CPL], unsigned short *__restrict__ s_hits, int stride, int *__restrict__ s_cnt, const int lane)
 {
     int cnt[CPL];
 #pragma unroll
@@ -1381,7 +1377,7 @@ __device__ __forceinline__ void roi_ball_query(int n_scan, int ns, float r2, con
             for (int q = 0; q < CPL; ++q) {
                 const float d2 = sqdist3(cx[q], cy[q], cz[q], x, y, z);
                 if (d2 < r2 && cnt[q] < ns) {
-                    s_hits[cnt[q] * stride + lane + 64 * q] = base + l;
+                    s_hits[cnt[q] * stride + lane + 64 * q] = (unsigned short)(base + l);
                     ++cnt[q];
                 }
             }
@@ -1398,7 +1394,10 @@ __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
     int *__restrict__ rep1 /* (b,128) */, float *__restrict__ new_xyz2 /* (b,32,3) */, int *__restrict__ idx2 /* (b,32,ns2) */,
     int *__restrict__ rep2 /* (b,32) */)
 {
-    __shared__ int s_hits[RG_NS * RG_M1];            // 32 KB: hit lists of the running ball query, [slot][centre]
+    // hit lists of the running ball query, [slot][centre], as 16-bit point numbers (< 512): 16 KB.  With 32-bit entries the workgroup
+    // held 36 KB of LDS -- FOUR single-wave workgroups per CU, one per SIMD, and 1600 RoI clouds took two rounds of a chain that is
+    // latency-bound from end to end (250 us per 1600 clouds); at 20 KB eight fit and every cloud of a launch is resident at once
+    __shared__ unsigned short s_hits[RG_NS * RG_M1];
     __shared__ int s_cnt[RG_M1];
     __shared__ int s_sel1[RG_M1], s_sel2[RG_M2];
     __shared__ int s_first[RG_N];
