@@ -1293,71 +1293,126 @@ extern "C" int prcnn_point_groups(int b, int n, const float *xyz, float *pxyz, f
 namespace prcnn {
 
 constexpr int RG_N = 512, RG_M1 = 128, RG_M2 = 32, RG_NS = 64;
+constexpr int RG_LD1 = RG_M1 + 1, RG_LD2 = RG_M2 + 1;   // row strides of the staged hit lists (16-bit entries): odd, see the rows-out loops
 
-// FPS of the PPT * 64 points held in registers (point k = lane + 64 i) -> sel[0..m) in LDS; returns nothing, all lanes in step
-template <int PPT>
-__device__ __forceinline__ void roi_fps(int n, int m, KeyCodec kc, const float (&px)[PPT], const float (&py)[PPT], const float (&pz)[PPT],
-                                        int *__restrict__ s_sel, const int lane)
+// coordinates of point (lane l, slot) -- both wave-uniform, slot < D -- of the D first register slots: a scalar compare ladder in front
+// of three v_readlane (fs_pick3 over a prefix of the arrays)
+template <int PPT, int D, int I = 0>
+__device__ __forceinline__ void roi_pick3(const float (&px)[PPT], const float (&py)[PPT], const float (&pz)[PPT], int slot, int l,
+                                          float &x, float &y, float &z)
 {
-    float pt[PPT];
-    uint32_t pk[PPT];
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        const int k = lane + 64 * i;
-        pt[i] = k < n ? 1e10f : -INFINITY;
-        pk[i] = k < n ? kc.encode(k) : 0xffffffffu;
-    }
-    int old = 0;
-    if (lane == 0) s_sel[0] = 0;
-    for (int j = 1; j < m; ++j) {
-        const int pl = old & 63, pi = old >> 6;
-        // the pivot's coordinates: three v_readlane behind a scalar compare ladder on its (uniform) slot -- reading all PPT slots and
-        // selecting (the first form) was 3 PPT v_readlane in front of every pick of a chain that is latency-bound from end to end
-        float ox = 0.f, oy = 0.f, oz = 0.f;
-        fs_pick3<PPT>(px, py, pz, pi, pl, ox, oy, oz);
-        float lv = -INFINITY;
-        if (kc.hipcc) {
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) {
-                const float d2 = fminf(fps_dist<true>(px[i], py[i], pz[i], ox, oy, oz), pt[i]);
-                pt[i] = d2;
-                lv = fmaxf(lv, d2);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) {
-                const float d = sqdist3(px[i], py[i], pz[i], ox, oy, oz);
-                const float d2 = fminf(d, pt[i]);
-                pt[i] = d2;
-                lv = fmaxf(lv, d2);
-            }
-        }
-        const float bv = wave_max_f32(lv);
-        uint32_t lk = 0xffffffffu;
-#pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const uint32_t c = pt[i] == bv ? pk[i] : 0xffffffffu;
-            lk = c < lk ? c : lk;
-        }
-        const uint32_t bkey = wave_min_u32(lk);
-        old = (bkey == 0xffffffffu || !(bv > -1.0f)) ? 0 : kc.decode(bkey);
-        old = __builtin_amdgcn_readfirstlane(old);
-        if (lane == 0) s_sel[j] = old;
-        if (bv == 0.f) {                     // only copies are left: every later pick is point 0 (see fps_reg_kernel)
-            for (int jj = j + 1 + lane; jj < m; jj += 64) s_sel[jj] = 0;
-            break;
-        }
+    if (I + 1 == D || slot == I) {
+        x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[I]), l));
+        y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[I]), l));
+        z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[I]), l));
+    } else if constexpr (I + 1 < D) {
+        roi_pick3<PPT, D, I + 1>(px, py, pz, slot, l, x, y, z);
     }
 }
 
+// FPS of a cloud of n <= 64 PPT points held in registers (point k = lane + 64 i) -> sel[0..m) in LDS; all lanes in step.  Returns the
+// number of picks made before only copies of picked points were left (m if that never happened): sel[that ..] = 0.
+//
+// Only the first `lim` points are distinct: D = ceil(lim / 64) register slots take part instead of PPT (round 5; a pooled RoI cloud has
+// 20-80 distinct points of its 512 on the synthetic scenes, and a pick was ~130 VALU instructions of a single-wave dependent chain).
+//   MOD = true:  point k >= lim is a copy of point k % lim (the pooled rows).  A copy has its source's coordinates, hence its source's
+//     running minimum at every step, and the scan's pick is the arg-max with the smallest tie key: it is decided among the SOURCES when
+//     each carries the smallest key of its copies; the index handed back is that copy's, as in the scan over all n.
+//   MOD = false: the points k >= lim are all copies of point 0 (the sampled centres behind an exhausted level-1 scan).  Point 0 is the
+//     first pivot: its minimum is 0 from the first step on and its key never decides a pick before the exit below.
+// The exit: a best value of exactly 0 means only copies of picked points are left -- every later pick is point 0 (fps_reg_kernel).
+template <int PPT, int D, bool MOD>
+__device__ __forceinline__ int roi_fps(int n, int lim, int m, KeyCodec kc, const float (&px)[PPT], const float (&py)[PPT],
+                                       const float (&pz)[PPT], int *__restrict__ s_sel, const int lane)
+{
+    float pt[D];
+    uint32_t pk[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const int k = lane + 64 * i;
+        pt[i] = k < lim ? 1e10f : -INFINITY;
+        uint32_t key = 0xffffffffu;
+        if (k < lim) {
+            key = kc.encode(k);
+            if (MOD)
+                for (int c = k + lim; c < n; c += lim) {
+                    const uint32_t kc2 = kc.encode(c);
+                    key = kc2 < key ? kc2 : key;
+                }
+        }
+        pk[i] = key;
+    }
+    if (lane == 0) s_sel[0] = 0;
+    float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px[0]), 0));
+    float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py[0]), 0));
+    float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[0]), 0));
+    for (int j = 1; j < m; ++j) {
+        float lv = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const float d = kc.hipcc ? fps_dist<true>(px[i], py[i], pz[i], ox, oy, oz) : sqdist3(px[i], py[i], pz[i], ox, oy, oz);
+            const float d2 = fminf(d, pt[i]);
+            pt[i] = d2;
+            lv = fmaxf(lv, d2);
+        }
+        const float bv = wave_max_f32(lv);
+        uint32_t lk = 0xffffffffu;                               // this lane's smallest key among its slots at the best value, and its slot
+        int ls = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const bool take = pt[i] == bv && pk[i] < lk;
+            lk = take ? pk[i] : lk;
+            ls = take ? i : ls;
+        }
+        // one lane at the best value (the rule once the points are distinct): its key is the answer, no second reduction
+        const unsigned long long at = __ballot(lv == bv);
+        uint32_t bkey;
+        int wl;
+        if (__builtin_popcountll(at) == 1) {
+            wl = (int)__builtin_ctzll(at);
+            bkey = (uint32_t)__builtin_amdgcn_readlane((int)lk, wl);
+        } else {
+            bkey = wave_min_u32(lk);
+            const unsigned long long wm = __ballot(lk == bkey);
+            wl = wm ? (int)__builtin_ctzll(wm) : 0;
+        }
+        const bool valid = !(bkey == 0xffffffffu || !(bv > -1.0f));
+        int old = valid ? kc.decode(bkey) : 0;
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (lane == 0) s_sel[j] = old;
+        if (bv == 0.f) {
+            for (int jj = j + 1 + lane; jj < m; jj += 64) s_sel[jj] = 0;
+            return j;
+        }
+        // the next pivot: the winner's source sits in slot `ls` of lane `wl` (point 0 behind an invalid best)
+        wl = valid ? wl : 0;
+        const int slot = valid ? __builtin_amdgcn_readlane(ls, wl) : 0;
+        roi_pick3<PPT, D>(px, py, pz, slot, wl, ox, oy, oz);
+    }
+    return m;
+}
+
+template <int PPT, bool MOD>
+__device__ __forceinline__ int roi_fps_any(int n, int lim, int m, KeyCodec kc, const float (&px)[PPT], const float (&py)[PPT],
+                                           const float (&pz)[PPT], int *__restrict__ s_sel, const int lane)
+{
+    static_assert(PPT == 8 || PPT == 2, "the two shapes of the RoI chain");
+    if constexpr (PPT == 8) {
+        if (lim > 256) return roi_fps<PPT, 8, MOD>(n, lim, m, kc, px, py, pz, s_sel, lane);
+        if (lim > 128) return roi_fps<PPT, 4, MOD>(n, lim, m, kc, px, py, pz, s_sel, lane);
+    }
+    if (lim > 64) return roi_fps<PPT, 2, MOD>(n, lim, m, kc, px, py, pz, s_sel, lane);
+    return roi_fps<PPT, 1, MOD>(n, lim, m, kc, px, py, pz, s_sel, lane);
+}
+
 // first `ns` in-range points (k < n_scan, index order) of CPL centres per lane among the PPT * 64 points in registers -> hit lists in
-// LDS, s_hits[slot * stride + centre], counts in s_cnt[centre]; lanes whose centres are all full stop the scan early together
+// LDS, s_hits[slot * stride + centre], counts in cnt[] (returned in registers); lanes whose centres are all full stop the scan early together
 template <int PPT, int CPL>
 __device__ __forceinline__ void roi_ball_query(int n_scan, int ns, float r2, const float (&px)[PPT], const float (&py)[PPT],
                                                const float (&pz)[PPT], const float (&cx)[CPL], const float (&cy)[CPL], const float (&cz)[CPL],
-                                               const bool (&live)[CPL], unsigned short *__restrict__ s_hits, int stride, int *__restrict__ s_cnt, const int lane)
+                                               const bool (&live)[CPL], unsigned short *__restrict__ s_hits, int stride, int (&cnt)[CPL],
+                                               const int lane)
 {
-    int cnt[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) cnt[q] = live[q] ? 0 : ns;
 #pragma unroll
@@ -1383,9 +1438,31 @@ __device__ __forceinline__ void roi_ball_query(int n_scan, int ns, float r2, con
             }
         }
     }
-#pragma unroll
-    for (int q = 0; q < CPL; ++q)
-        if (live[q]) s_cnt[lane + 64 * q] = cnt[q];
+}
+
+// rows of an index tensor out of the staged hit lists: slot s of centre c; slots past the hit count repeat the first hit, an empty ball is
+// a row of zeros.  The lists sit in LDS as [slot][centre] with an ODD row stride: the ball query writes a slot of 64 centres side by
+// side, this loop reads the 64 slots of one centre -- 64 consecutive rows -- and with an even stride (128 entries = 256 bytes) those
+// were 64 addresses in ONE bank: 300 cycles per row, a fifth of the kernel.  cnt_lo / cnt_hi: the hit counts of centres lane / lane + 64.
+template <int M>
+__device__ __forceinline__ void roi_rows_out(int ns, const unsigned short *__restrict__ s_hits, int stride, int cnt_lo, int cnt_hi,
+                                             int *__restrict__ out, const int lane)
+{
+    if (ns == 64) {                                               // a row per wave store: centre c = the iteration, slot = the lane
+#pragma unroll 8
+        for (int c = 0; c < M; ++c) {
+            const int tot = __builtin_amdgcn_readlane(c < 64 ? cnt_lo : cnt_hi, c & 63);
+            const int v = s_hits[(lane < tot ? lane : 0) * stride + c];
+            out[c * 64 + lane] = tot == 0 ? 0 : v;
+        }
+    } else {
+        for (int e = lane; e < M * ns; e += 64) {
+            const int c = e / ns, s = e - c * ns;
+            const int t_lo = __shfl(cnt_lo, c & 63, 64), t_hi = __shfl(cnt_hi, c & 63, 64);
+            const int tot = c < 64 ? t_lo : t_hi;
+            out[e] = tot == 0 ? 0 : (int)s_hits[(s < tot ? s : 0) * stride + c];
+        }
+    }
 }
 
 __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
@@ -1394,17 +1471,16 @@ __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
     int *__restrict__ rep1 /* (b,128) */, float *__restrict__ new_xyz2 /* (b,32,3) */, int *__restrict__ idx2 /* (b,32,ns2) */,
     int *__restrict__ rep2 /* (b,32) */)
 {
-    // hit lists of the running ball query, [slot][centre], as 16-bit point numbers (< 512): 16 KB.  With 32-bit entries the workgroup
+    // hit lists of the running ball query, [slot][centre], as 16-bit point numbers (< 512): 16.5 KB.  With 32-bit entries the workgroup
     // held 36 KB of LDS -- FOUR single-wave workgroups per CU, one per SIMD, and 1600 RoI clouds took two rounds of a chain that is
-    // latency-bound from end to end (250 us per 1600 clouds); at 20 KB eight fit and every cloud of a launch is resident at once
-    __shared__ unsigned short s_hits[RG_NS * RG_M1];
-    __shared__ int s_cnt[RG_M1];
+    // latency-bound from end to end (250 us per 1600 clouds); at 21 KB seven fit and every cloud of a launch is resident at once
+    __shared__ unsigned short s_hits[RG_NS * RG_LD1];
     __shared__ int s_sel1[RG_M1], s_sel2[RG_M2];
     __shared__ int s_first[RG_N];
     __shared__ int s_rep1[RG_M1];
     const int b = blockIdx.x, lane = threadIdx.x;
     const float *__restrict__ cloud = xyz + (long)b * RG_N * 3;
-    const int lim = limit ? max(limit[b], 1) : RG_N;
+    const int lim = limit ? min(max(limit[b], 1), RG_N) : RG_N;
     __builtin_amdgcn_s_setprio(3);
 
     // ---- level 1: sample 128 of the 512 pooled points
@@ -1414,7 +1490,7 @@ __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
         const int k = lane + 64 * i;
         px[i] = cloud[3 * k]; py[i] = cloud[3 * k + 1]; pz[i] = cloud[3 * k + 2];
     }
-    roi_fps<8>(RG_N, RG_M1, kc1, px, py, pz, s_sel1, lane);
+    const int nd1 = roi_fps_any<8, true>(RG_N, lim, RG_M1, kc1, px, py, pz, s_sel1, lane);
     __syncthreads();
     // the sampled centres: coordinates into registers (centre c = lane + 64 q) and out to new_xyz1
     float qx[2], qy[2], qz[2];
@@ -1428,9 +1504,10 @@ __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
         src1[q] = k >= lim ? k % lim : k;                        // the distinct pooled point behind this centre
     }
     // ---- ball query of level 1 over the DISTINCT pooled points only (prcnn_ball_query_limit)
+    int cnt1[2];
     {
         const bool live[2] = {true, true};
-        roi_ball_query<8, 2>(min(RG_N, lim), ns1, r1sq, px, py, pz, qx, qy, qz, live, s_hits, RG_M1, s_cnt, lane);
+        roi_ball_query<8, 2>(lim, ns1, r1sq, px, py, pz, qx, qy, qz, live, s_hits, RG_LD1, cnt1, lane);
     }
     // representative map of the centres: the first centre sampled from the same source (prcnn_dup_rep)
 #pragma unroll
@@ -1445,18 +1522,12 @@ __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
         s_rep1[lane + 64 * q] = r;
         rep1[(long)b * RG_M1 + lane + 64 * q] = r;
     }
-    {   // rows out: slot s of centre c; slots past the hit count repeat the first hit, an empty ball is a row of zeros
-        int *out = idx1 + (long)b * RG_M1 * ns1;
-        for (int e = lane; e < RG_M1 * ns1; e += 64) {
-            const int c = e / ns1, s = e - c * ns1;
-            const int tot = s_cnt[c];
-            out[e] = tot == 0 ? 0 : s_hits[(s < tot ? s : 0) * RG_M1 + c];
-        }
-    }
-    __syncthreads();                                              // s_hits / s_cnt are reused below
+    roi_rows_out<RG_M1>(ns1, s_hits, RG_LD1, cnt1[0], cnt1[1], idx1 + (long)b * RG_M1 * ns1, lane);
+    __syncthreads();                                              // s_hits is reused below
 
-    // ---- level 2: sample 32 of the 128 centres (held in registers as points k = lane + 64 q), ball query over all 128
-    roi_fps<2>(RG_M1, RG_M2, kc2, qx, qy, qz, s_sel2, lane);
+    // ---- level 2: sample 32 of the 128 centres (held in registers as points k = lane + 64 q), ball query over all 128.
+    // Behind an exhausted level-1 scan (nd1 < 128 picks, then copies of point 0) only the first nd1 centres are distinct.
+    roi_fps_any<2, false>(RG_M1, nd1, RG_M2, kc2, qx, qy, qz, s_sel2, lane);
     __syncthreads();
     float cx[1] = {0.f}, cy[1] = {0.f}, cz[1] = {0.f};
     const bool has = lane < RG_M2;
@@ -1474,9 +1545,20 @@ __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
             o[0] = cx[0]; o[1] = cy[0]; o[2] = cz[0];
         }
     }
+    int cnt2[1];
     {
+        // the scan runs over the nd1 distinct centres; the centres behind them are copies of centre 0: in range together with it, and
+        // then the next hits in index order
         const bool live[1] = {has};
-        roi_ball_query<2, 1>(RG_M1, ns2, r2sq, qx, qy, qz, cx, cy, cz, live, s_hits, RG_M2, s_cnt, lane);
+        roi_ball_query<2, 1>(nd1, ns2, r2sq, qx, qy, qz, cx, cy, cz, live, s_hits, RG_LD2, cnt2, lane);
+        const float x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx[0]), 0));
+        const float y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy[0]), 0));
+        const float z0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz[0]), 0));
+        if (has && sqdist3(cx[0], cy[0], cz[0], x0, y0, z0) < r2sq)
+            for (int k = nd1; k < RG_M1 && cnt2[0] < ns2; ++k) {
+                s_hits[cnt2[0] * RG_LD2 + lane] = (unsigned short)k;
+                ++cnt2[0];
+            }
     }
     // representative map of level 2's centres through the map of level 1
     for (int i = lane; i < RG_M1; i += 64) s_first[i] = 0x7fffffff;
@@ -1484,14 +1566,7 @@ __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
     if (has) atomicMin(&s_first[src2], lane);
     __syncthreads();
     if (has) rep2[(long)b * RG_M2 + lane] = s_first[src2];
-    {
-        int *out = idx2 + (long)b * RG_M2 * ns2;
-        for (int e = lane; e < RG_M2 * ns2; e += 64) {
-            const int c = e / ns2, s = e - c * ns2;
-            const int tot = s_cnt[c];
-            out[e] = tot == 0 ? 0 : s_hits[(s < tot ? s : 0) * RG_M2 + c];
-        }
-    }
+    roi_rows_out<RG_M2>(ns2, s_hits, RG_LD2, has ? cnt2[0] : 0, 0, idx2 + (long)b * RG_M2 * ns2, lane);
 }
 
 }  // namespace prcnn

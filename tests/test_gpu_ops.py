@@ -593,6 +593,38 @@ def test_rcnn_roi_geometry_equals_the_separate_entry_points(ext, ns1, ns2):
     assert int((got[2] != torch.arange(128, device=DEV).view(1, -1)).sum()) > 500        # many centres are copies of earlier ones
 
 
+def test_rcnn_roi_geometry_ties_and_every_count(ext):
+    """The same chain on clouds that make the tie rule decide: coordinates on a coarse lattice (many equal running minima between
+    DIFFERENT points, so the smallest key among the copies of each point matters), every count of distinct points from 1 to 512 in steps
+    that cross the 64 / 128 / 256 register-slot boundaries of the kernel, the distinct part itself holding repeats."""
+    rng = np.random.default_rng(77)
+    counts = list(range(1, 20)) + [31, 32, 33, 63, 64, 65, 66, 96, 127, 128, 129, 130, 191, 192, 193, 255, 256, 257, 258, 384, 510, 511, 512]
+    counts += [int(c) for c in rng.integers(1, 513, size=40)]
+    b = len(counts)
+    xyz = np.zeros((b, 512, 3), np.float32)
+    for i, c in enumerate(counts):
+        step = [0.25, 0.1, 0.05][i % 3]
+        base = (rng.integers(-6, 7, size=(c, 3)) * step).astype(np.float32)
+        if i % 4 == 0:
+            base = (base + rng.standard_normal((c, 3)).astype(np.float32) * 0.3).astype(np.float32)
+        xyz[i] = base[np.arange(512) % c]
+    limit = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    P = ext.pointnet2
+    X = T(xyz)
+    got = P.rcnn_roi_geometry_wrapper(X, limit, 128, 0.2, 64, 32, 0.4, 64)
+    sel1, new1 = P.fps_new_xyz_wrapper(X, 128)
+    idx1 = torch.full((b, 128, 64), -1, dtype=torch.int32, device=DEV)
+    P.ball_query_limit_wrapper(b, 512, 128, 0.2, 64, new1, X, limit, idx1)
+    rep1 = P.dup_rep_wrapper(sel1, 512, limit, None)
+    sel2, new2 = P.fps_new_xyz_wrapper(new1, 32)
+    idx2 = torch.zeros((b, 32, 64), dtype=torch.int32, device=DEV)
+    P.ball_query_wrapper(b, 128, 32, 0.4, 64, new2, new1, idx2)
+    rep2 = P.dup_rep_wrapper(sel2, 128, None, rep1)
+    for k, (g, w) in enumerate(zip(got, (new1, idx1, rep1, new2, idx2, rep2))):
+        bad = (g != w).reshape(b, -1).any(1).nonzero().flatten().tolist()
+        assert not bad, (k, [counts[i] for i in bad][:10])
+
+
 def test_point_major_kernels(ext, oracle):
     """group_cat_pm / maxpool_pm / three_interpolate_pm against the oracle's channel-major results
     rearranged to the point-major row layout [features | pad | dx dy dz | 0] (pure data movement and
