@@ -2,7 +2,7 @@
 each publishing its best point, the best point of its other lanes and a bound; entries accepted in order while they beat the global bound
 and are not changed by the entries before them): rounds, picks per round and why rounds end, for the blocked Morton layout the kernel uses,
 for tiles interleaved across the waves, and for more published entries per wave.  CPU only.
-usage: python profiles/fps_round_sim.py uniform|lidar [m]
+usage: python profiles/fps_round_sim.py uniform|lidar [m] [greedy|lazy]
 (round 4: uniform 480 rounds = 8.5 picks per round, LiDAR-shaped 742 = 5.5; interleaved tiles 467 / 595 -- but every wave then rebuilds
 its entries every round, four waves per SIMD; 3 / 4 entries per wave 395 / 383 and 587 / 522 -- at the price of a 64-entry merge.)"""
 import os, sys, importlib, numpy as np
@@ -100,10 +100,74 @@ def simulate(p, m, layout, PPT=16, top=2, rmax=16, stats=None, W=16, greedy=Fals
         j += len(acc); rounds += 1
     return rounds, hist, why
 
+def simulate_lazy(p, m, mode, PPT=16, W=16, rmax=16):
+    """Which waves have to rebuild their published entries after a round?  mode 'touched': every wave one of whose tile boxes passed a
+    pivot's box test (the kernel until round 5); 'E': only a wave whose published points E1 / E2 changed; 'Etile': a wave one of whose
+    tiles HOLDING E1 / E2 was updated (what fps_spec_kernel does since round 5: no per-update cost).  The other waves keep their entries
+    and their (stale, still valid) bound.  -> rounds, rebuilds per round, box-touched waves per round."""
+    order = morton_order(p)
+    w_, i_, l_ = np.meshgrid(np.arange(W), np.arange(PPT), np.arange(64), indexing='ij')
+    idx = order[w_ * 64 * PPT + i_ * 64 + l_]
+    P = p[idx].astype(np.float32)
+    lo, hi = P.min(2), P.max(2)                                 # tile boxes [W][PPT][3]
+    pt = np.full((W, PPT, 64), 1e10, np.float32)
+    np.minimum(pt, ((P - p[0].astype(np.float32)) ** 2).sum(-1).astype(np.float32), out=pt)
+    cache = [None] * W
+    bound = np.full(W, np.inf, np.float32)                      # v1 at the last rebuild (what the box tests prune against)
+    j = 1; rounds = 0; rebuilds = 0; touched_tot = 0
+    def build(w):
+        lane_best = pt[w].max(0); lane_arg = pt[w].argmax(0)
+        lane_second = np.sort(pt[w], axis=0)[-2]
+        ordl = np.argsort(-lane_best, kind='stable')
+        ls = ordl[:2]
+        wB = max(lane_best[ordl[2]], lane_second[ls].max())
+        return [(lane_best[l], idx[w, lane_arg[l], l], w, (lane_arg[l], l)) for l in ls], wB, lane_best[ordl[0]]
+    need = np.ones(W, bool)
+    while j < m:
+        for w in range(W):
+            if need[w]:
+                cache[w] = build(w); rebuilds += 1; bound[w] = cache[w][2]
+        ents = sorted((e for w in range(W) for e in cache[w][0]), key=lambda e: (-e[0], e[1]))
+        gB = max(c[1] for c in cache)
+        acc = [ents[0]]
+        for e in ents[1:]:
+            if len(acc) >= min(rmax, m - j) or not (e[0] > gB): break
+            pe = p[e[1]].astype(np.float32)
+            blk = False
+            for a in ents:
+                if a is e: break
+                if ((p[a[1]].astype(np.float32) - pe) ** 2).sum() < e[0]: blk = True; break
+            if blk: break
+            acc.append(e)
+        old = pt.copy()
+        touched = np.zeros(W, bool); tt = np.zeros((W, PPT), bool)
+        for a in acc:
+            o = p[a[1]].astype(np.float32)
+            d = np.maximum(np.maximum(lo - o, o - hi), 0)
+            tmask = (d * d).sum(-1) * 0.99999 < bound[:, None]
+            touched |= tmask.any(1); tt |= tmask
+            dd = ((P - o) ** 2).sum(-1).astype(np.float32)
+            np.minimum(pt, np.where(tmask[:, :, None], dd, pt), out=pt)
+        touched_tot += touched.sum()
+        if mode == 'E':
+            need = np.array([any(pt[w][e[3]] < old[w][e[3]] for e in cache[w][0]) for w in range(W)])
+        elif mode == 'Etile':
+            need = np.array([any(tt[w, e[3][0]] for e in cache[w][0]) for w in range(W)])
+        else:
+            need = touched
+        j += len(acc); rounds += 1
+    return rounds, rebuilds / rounds, touched_tot / rounds
+
+
 if __name__ == '__main__':
     kind = sys.argv[1]; m = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     make = S.lidar_scenes if kind == 'lidar' else S.scenes
     pts = make(2, 16384, seed0=0)
+    if len(sys.argv) > 3 and sys.argv[3] == 'lazy':        # which waves rebuild their entries (round 5)
+        for mode in ('touched', 'E', 'Etile'):
+            r, rb, tc = simulate_lazy(pts[0][:, :3], m, mode)
+            print(kind, mode, 'rounds', r, 'rebuilds per round %.2f' % rb, 'box-touched waves per round %.2f' % tc, flush=True)
+        sys.exit(0)
     if len(sys.argv) > 3 and sys.argv[3] == 'greedy':      # the merge as an exact greedy selection over the published entries (not built)
         for g in (False, True):
             r, h, why = simulate(pts[0][:, :3], m, 'blocked', top=2, greedy=g)

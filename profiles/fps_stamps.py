@@ -4,7 +4,8 @@ into profiles/_exp/libprcnn_hip_fps_stamps.so; the product library is not touche
 
   python profiles/fps_stamps.py build               (build container: hipcc)
   python profiles/fps_stamps.py run [uniform|lidar] (GPU box): 16384 -> 4096, B = 8; per wave: rounds, and cycles per round spent in
-      rebuild + publish | waiting at barrier A | merge (wave 0) | waiting at barrier B | distance updates"""
+      rebuild + publish | waiting at barrier A | the pair tests of the merge | waiting at barrier A2 | the verdict (wave 0) | waiting at
+      barrier B | distance updates"""
 import ctypes, importlib, os, subprocess, sys
 import numpy as np
 
@@ -13,28 +14,29 @@ CSRC = os.path.join(ROOT, "3d_adapt_auto_driving_amd", "csrc")
 EXP = os.path.join(ROOT, "profiles", "_exp")
 LIB = os.path.join(EXP, "libprcnn_hip_fps_stamps.so")
 FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math".split()
-NPH = 6
+NPH = 8
 
 
 def instrument():
     s = open(os.path.join(CSRC, "fps.hip")).read()
     s = s.replace('#include "common.hpp"', '#include "%s/common.hpp"' % CSRC).replace('#include "../../include/prcnn_hip.h"', '#include "%s/include/prcnn_hip.h"' % ROOT)
     a = s.index("template <int PPT>\n__global__ __launch_bounds__(1024) void fps_spec_kernel(")
-    b = s.index("// Any-n fallback: running minima stay in `temp` (global)")
+    b = s.index("// The speculative kernel for 16384 < n <= 32768")
     k = s[a:b]
 
     def put(old, new):
         nonlocal k
         assert k.count(old) == 1, old[:70]
         k = k.replace(old, new)
-    put("    while (j < m) {\n", "    unsigned long long acc_[%d] = {0}, t_prev_ = __builtin_amdgcn_s_memtime();\n#define PH(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_[i] += n_ - t_prev_; t_prev_ = n_; }\n    while (j < m) {\n        acc_[5] += 1;\n" % NPH)
+    put("    while (j < m) {\n", "    unsigned long long acc_[%d] = {0}, t_prev_ = __builtin_amdgcn_s_memtime();\n#define PH(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_[i] += n_ - t_prev_; t_prev_ = n_; }\n    while (j < m) {\n        acc_[7] += 1;\n" % NPH)
     put("        lds_barrier();                                                // A: the table is complete\n", "        PH(0)\n        lds_barrier();                                                // A: the table is complete\n        PH(1)\n")
-    put("        lds_barrier();                                                // B: the verdict is in\n", "        PH(2)\n        lds_barrier();                                                // B: the verdict is in\n        PH(3)\n")
+    put("        lds_barrier();                                                // A2: every pair has been looked at\n", "        PH(2)\n        lds_barrier();                                                // A2: every pair has been looked at\n        PH(3)\n")
+    put("        lds_barrier();                                                // B: the verdict is in\n", "        PH(4)\n        lds_barrier();                                                // B: the verdict is in\n        PH(5)\n")
     put("    if (mind) {\n#pragma unroll\n        for (int i = 0; i < PPT; ++i)\n            if (pc[i] != 0xffffffffu) mind[kc.decode(pc[i] >> SB)] = pt[i];\n    }\n}",
         "    if (mind) {\n#pragma unroll\n        for (int i = 0; i < PPT; ++i)\n            if (pc[i] != 0xffffffffu) mind[kc.decode(pc[i] >> SB)] = pt[i];\n    }\n"
         "    if (blockIdx.x == 0 && lane == 0) for (int i = 0; i < %d; ++i) g_fps_acc[w * %d + i] = acc_[i];\n}" % (NPH, NPH))
     # the update phase ends at the bottom of the while loop: stamp right before its closing brace = before 'if (mind)'
-    put("                    update(ox, oy, oz, mk);\n                }\n            }\n        }\n    }\n", "                    update(ox, oy, oz, mk);\n                }\n            }\n        }\n        PH(4)\n    }\n")
+    put("                    update(ox, oy, oz, mk);\n                }\n            }\n        }\n    }\n", "                    update(ox, oy, oz, mk);\n                }\n            }\n        }\n        PH(6)\n    }\n")
     k = "__device__ unsigned long long g_fps_acc[16 * %d];\n" % NPH + k
     s = s[:a] + k + s[b:]
     s += ('\nextern "C" int prcnn_debug_fps_acc(unsigned long long *dst)\n{\n    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(prcnn::g_fps_acc), '
@@ -73,14 +75,14 @@ def run(kind):
     lib = ctypes.CDLL(LIB)
     assert lib.prcnn_debug_fps_acc(buf) == 0
     a = np.array(buf, dtype=np.float64).reshape(16, NPH)
-    rounds = a[:, 5]
+    rounds = a[:, 7]
     print("%s scenes, cloud 0, 16384 -> 4096: %d rounds; s_memtime cycles per round by wave" % (kind, int(rounds[0])))
-    print("wave | rebuild+publish | wait A | merge | wait B | updates | sum")
+    print("wave | rebuild+publish | wait A | pairs | wait A2 | verdict (wave 0) | wait B | updates | sum")
     for w in range(16):
-        v = a[w, :5] / rounds[w]
-        print("%4d | %7.1f | %7.1f | %7.1f | %7.1f | %7.1f | %7.1f" % (w, v[0], v[1], v[2], v[3], v[4], v.sum()))
-    v = (a[:, :5] / rounds[:, None]).mean(0)
-    print("mean | %7.1f | %7.1f | %7.1f | %7.1f | %7.1f | %7.1f" % (v[0], v[1], v[2], v[3], v[4], v.sum()))
+        v = a[w, :7] / rounds[w]
+        print("%4d | " % w + " | ".join("%7.1f" % x for x in v) + " | %7.1f" % v.sum())
+    v = (a[:, :7] / rounds[:, None]).mean(0)
+    print("mean | " + " | ".join("%7.1f" % x for x in v) + " | %7.1f" % v.sum())
 
 
 if __name__ == "__main__":
