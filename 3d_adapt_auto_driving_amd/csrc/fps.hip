@@ -1472,11 +1472,80 @@ __device__ __forceinline__ void roi_rows_out(int ns, const unsigned short *__res
     }
 }
 
+// The row lists of the two sampled levels (prcnn_rcnn_roi_geometry_packs): what prcnn_ball_pack_ex makes of idx1 (limit, crep = rep1)
+// and of idx2 (rep = rep1, crep = rep2), written by the wave that has the hit lists in LDS anyway -- as separate launches the two
+// packs re-derived them from 10240 index entries per cloud (1024-thread workgroups, a block scan, a binary search per row) and cost
+// the step 26 us (uniform scene) / 57 us (LiDAR-shaped) of 1060 / 1540 (profiles/sensitivity_probe.py).  hdr: zero on entry.
+struct RgPacks {
+    unsigned int *rowinfo1; float4 *rowdxyz1; int *tilecloud1; unsigned int *hdr1;
+    unsigned int *rowinfo2; float4 *rowdxyz2; int *tilecloud2; unsigned int *hdr2;
+};
+
+__device__ __forceinline__ int wave_incl_scan(int v, const int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// One cloud's list: centre c (c = lane: keep_lo / tot_lo, c = lane + 64: keep_hi / tot_hi; M centres) lists keep[c] rows -- 0 for a
+// centre that copies an earlier one, else max(hits, 1) -- row p of it = hit p of its staged list (point 0 of an empty ball), in centre
+// order, cut into 64-row tiles drawn from the list's counter; the last tile is filled with copies of centre M - 1's first row (as
+// ball_pack_kernel fills it).  pmap: staged hit -> point of the cloud (null: itself); cmap_*: centre -> point of the cloud.
+template <int M>
+__device__ __forceinline__ void roi_pack_out(int b, int keep_lo, int keep_hi, int tot_lo, int tot_hi, const unsigned short *__restrict__ s_hits,
+                                             int stride, int *__restrict__ s_off, const float *__restrict__ cloud,
+                                             const int *__restrict__ pmap, const int *__restrict__ cmap, const int *__restrict__ cmap2,
+                                             unsigned int *__restrict__ rowinfo, float4 *__restrict__ rowdxyz, int *__restrict__ tilecloud,
+                                             unsigned int *__restrict__ hdr, const int lane)
+{
+    const int in_lo = wave_incl_scan(keep_lo, lane);
+    const int sum_lo = __builtin_amdgcn_readlane(in_lo, 63);
+    const int in_hi = wave_incl_scan(M > 64 ? keep_hi : 0, lane) + sum_lo;
+    const int total = __builtin_amdgcn_readlane(in_hi, 63);
+    if (lane < M) s_off[lane] = in_lo - keep_lo;
+    if (M > 64) s_off[lane + 64] = in_hi - keep_hi;
+    const int nt = (total + 63) >> 6;
+    int base = 0;
+    if (lane == 0) {
+        base = (int)atomicAdd(&hdr[0], (unsigned int)nt);
+        atomicAdd(&hdr[1], (unsigned int)total);
+    }
+    base = __builtin_amdgcn_readfirstlane(base);
+    __syncthreads();                                              // (one wave: orders the LDS writes above before the searches below)
+    for (int t = lane; t < nt; t += 64) tilecloud[base + t] = b;
+    unsigned int *__restrict__ dst = rowinfo + (long)base * 64;
+    float4 *__restrict__ dx = rowdxyz + (long)base * 64;
+    for (int r0 = 0; r0 < nt * 64; r0 += 64) {
+        const int r = r0 + lane;
+        int c = M - 1, p = 0;
+        if (r < total) {
+            int lo = 0, hi = M - 1;                               // the last centre whose offset is <= r
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_off[mid] <= r) lo = mid; else hi = mid - 1;
+            }
+            c = lo; p = r - s_off[lo];
+        }
+        const int t_lo = __shfl(tot_lo, c & 63, 64), t_hi = __shfl(tot_hi, c & 63, 64);
+        const int tot = (M > 64 && c >= 64) ? t_hi : t_lo;
+        const int k = tot == 0 ? 0 : (int)s_hits[p * stride + c];
+        const int pi = pmap ? pmap[k] : k;
+        const int ci = cmap2 ? cmap[cmap2[c]] : cmap[c];
+        const float *__restrict__ pt = cloud + 3 * pi, *__restrict__ ct = cloud + 3 * ci;
+        dst[r] = ((unsigned int)c << 16) | (unsigned int)k;
+        dx[r] = make_float4(pt[0] - ct[0], pt[1] - ct[1], pt[2] - ct[2], 0.f);
+    }
+}
+
 __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
     KeyCodec kc1, KeyCodec kc2, float r1sq, float r2sq, int ns1, int ns2, const float *__restrict__ xyz /* (b, 512, 3) */,
     const int *__restrict__ limit /* (b) */, float *__restrict__ new_xyz1 /* (b,128,3) */, int *__restrict__ idx1 /* (b,128,ns1) */,
     int *__restrict__ rep1 /* (b,128) */, float *__restrict__ new_xyz2 /* (b,32,3) */, int *__restrict__ idx2 /* (b,32,ns2) */,
-    int *__restrict__ rep2 /* (b,32) */)
+    int *__restrict__ rep2 /* (b,32) */, const RgPacks pk /* .rowinfo1 == NULL: no row lists */)
 {
     // hit lists of the running ball query, [slot][centre], as 16-bit point numbers (< 512): 16.5 KB.  With 32-bit entries the workgroup
     // held 36 KB of LDS -- FOUR single-wave workgroups per CU, one per SIMD, and 1600 RoI clouds took two rounds of a chain that is
@@ -1523,13 +1592,20 @@ __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
 #pragma unroll
     for (int q = 0; q < 2; ++q) atomicMin(&s_first[src1[q]], lane + 64 * q);
     __syncthreads();
+    int own1[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int r = s_first[src1[q]];
         s_rep1[lane + 64 * q] = r;
         rep1[(long)b * RG_M1 + lane + 64 * q] = r;
+        own1[q] = r == lane + 64 * q;
     }
     roi_rows_out<RG_M1>(ns1, s_hits, RG_LD1, cnt1[0], cnt1[1], idx1 + (long)b * RG_M1 * ns1, lane);
+    if (pk.rowinfo1) {
+        __syncthreads();                                          // s_first is free: the list's offsets
+        roi_pack_out<RG_M1>(b, own1[0] ? max(cnt1[0], 1) : 0, own1[1] ? max(cnt1[1], 1) : 0, cnt1[0], cnt1[1], s_hits, RG_LD1, s_first, cloud,
+                            nullptr, s_sel1, nullptr, pk.rowinfo1, pk.rowdxyz1, pk.tilecloud1, pk.hdr1, lane);
+    }
     __syncthreads();                                              // s_hits is reused below
 
     // ---- level 2: sample 32 of the 128 centres (held in registers as points k = lane + 64 q), ball query over all 128.
@@ -1552,12 +1628,13 @@ __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
             o[0] = cx[0]; o[1] = cy[0]; o[2] = cz[0];
         }
     }
-    int cnt2[1];
+    int cnt2[1], cntd2 = 0;
     {
         // the scan runs over the nd1 distinct centres; the centres behind them are copies of centre 0: in range together with it, and
         // then the next hits in index order
         const bool live[1] = {has};
         roi_ball_query<2, 1>(nd1, ns2, r2sq, qx, qy, qz, cx, cy, cz, live, s_hits, RG_LD2, cnt2, lane);
+        cntd2 = has ? cnt2[0] : 0;                                // hits among the distinct centres: the rows the level's list keeps
         const float x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx[0]), 0));
         const float y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy[0]), 0));
         const float z0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz[0]), 0));
@@ -1572,8 +1649,14 @@ __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
     __syncthreads();
     if (has) atomicMin(&s_first[src2], lane);
     __syncthreads();
-    if (has) rep2[(long)b * RG_M2 + lane] = s_first[src2];
+    const int r2own = has ? s_first[src2] : -1;
+    if (has) rep2[(long)b * RG_M2 + lane] = r2own;
     roi_rows_out<RG_M2>(ns2, s_hits, RG_LD2, has ? cnt2[0] : 0, 0, idx2 + (long)b * RG_M2 * ns2, lane);
+    if (pk.rowinfo1) {
+        __syncthreads();
+        roi_pack_out<RG_M2>(b, r2own == lane ? max(cntd2, 1) : 0, 0, cntd2, 0, s_hits, RG_LD2, s_first, cloud, s_sel1, s_sel1, s_sel2,
+                            pk.rowinfo2, pk.rowdxyz2, pk.tilecloud2, pk.hdr2, lane);
+    }
 }
 
 }  // namespace prcnn
@@ -1584,9 +1667,9 @@ __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
  *   new_xyz2 (b,32,3), idx2 (b,32,ns2), rep2 (b,32): the same one level up over the 128 centres (prcnn_fps_new_xyz, prcnn_ball_query
  *                                                      with empty balls written as zeros, prcnn_dup_rep with prev = rep1).
  * ns1, ns2 <= 64.  The shape of rcnn_net.py:165-175 under default.yaml (RCNN.NUM_POINTS 512, SA_CONFIG NPOINTS [128, 32, -1]). */
-extern "C" int prcnn_rcnn_roi_geometry(int b, int n, int m1, float r1, int ns1, int m2, float r2, int ns2, const float *xyz,
-                                       const int *limit, float *new_xyz1, int *idx1, int *rep1, float *new_xyz2, int *idx2, int *rep2,
-                                       void *stream)
+static int roi_geometry_any(int b, int n, int m1, float r1, int ns1, int m2, float r2, int ns2, const float *xyz,
+                            const int *limit, float *new_xyz1, int *idx1, int *rep1, float *new_xyz2, int *idx2, int *rep2,
+                            const prcnn::RgPacks *packs, void *stream)
 {
     PRCNN_REQUIRE(b >= 0 && n == RG_N && m1 == RG_M1 && m2 == RG_M2, "rcnn_roi_geometry: written for 512 -> 128 -> 32 points (got %d -> %d -> %d)", n, m1, m2);
     PRCNN_REQUIRE(ns1 >= 1 && ns1 <= RG_NS && ns2 >= 1 && ns2 <= RG_NS && r1 > 0.f && r2 > 0.f, "rcnn_roi_geometry: nsample must be 1..64, radii positive");
@@ -1604,6 +1687,39 @@ extern "C" int prcnn_rcnn_roi_geometry(int b, int n, int m1, float r1, int ns1, 
         return kc;
     };
     hipLaunchKernelGGL(rcnn_roi_geometry_kernel, dim3(b), dim3(64), 0, (hipStream_t)stream, codec(RG_N), codec(RG_M1), r1 * r1, r2 * r2,
-                       ns1, ns2, xyz, limit, new_xyz1, idx1, rep1, new_xyz2, idx2, rep2);
+                       ns1, ns2, xyz, limit, new_xyz1, idx1, rep1, new_xyz2, idx2, rep2, *packs);
     return check_launch("rcnn_roi_geometry");
+}
+
+extern "C" int prcnn_rcnn_roi_geometry(int b, int n, int m1, float r1, int ns1, int m2, float r2, int ns2, const float *xyz,
+                                       const int *limit, float *new_xyz1, int *idx1, int *rep1, float *new_xyz2, int *idx2, int *rep2,
+                                       void *stream)
+{
+    const prcnn::RgPacks none = {};
+    return roi_geometry_any(b, n, m1, r1, ns1, m2, r2, ns2, xyz, limit, new_xyz1, idx1, rep1, new_xyz2, idx2, rep2, &none, stream);
+}
+
+/* prcnn_rcnn_roi_geometry + the distinct-row lists of both levels in the same launch (round 5):
+ *   list 1 = prcnn_ball_pack_ex(b, b, 512, 128, ns1, idx1, limit, NULL, rep1, xyz, new_xyz1, ...),
+ *   list 2 = prcnn_ball_pack_ex(b, b, 128, 32, ns2, idx2, NULL, rep1, rep2, new_xyz1, new_xyz2, ...)
+ * -- the same rows per cloud in the same order, cut into the same tiles (the order of the CLOUDS' tiles in a list is whatever the
+ * counter hands out, as it is for prcnn_ball_pack).  rowinfo* / rowdxyz* / tilecloud*: sized as for prcnn_ball_pack
+ * (b * ceil(m * ns / 64) tiles); hdr1 / hdr2 (4 u32 each): zeroed here unless hdr_is_zero. */
+extern "C" int prcnn_rcnn_roi_geometry_packs(int b, int n, int m1, float r1, int ns1, int m2, float r2, int ns2, const float *xyz,
+                                             const int *limit, float *new_xyz1, int *idx1, int *rep1, float *new_xyz2, int *idx2, int *rep2,
+                                             unsigned int *rowinfo1, float *rowdxyz1, int *tilecloud1, unsigned int *hdr1,
+                                             unsigned int *rowinfo2, float *rowdxyz2, int *tilecloud2, unsigned int *hdr2, int hdr_is_zero,
+                                             void *stream)
+{
+    PRCNN_REQUIRE(hdr1 && hdr2, "rcnn_roi_geometry_packs: null header");
+    if (!hdr_is_zero && (hipMemsetAsync(hdr1, 0, 4 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess ||
+                         hipMemsetAsync(hdr2, 0, 4 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess)) {
+        set_error("rcnn_roi_geometry_packs: memset failed");
+        return PRCNN_ELAUNCH;
+    }
+    if (b == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(rowinfo1 && rowdxyz1 && tilecloud1 && rowinfo2 && rowdxyz2 && tilecloud2, "rcnn_roi_geometry_packs: null pointer");
+    PRCNN_REQUIRE((((uintptr_t)rowdxyz1 | (uintptr_t)rowdxyz2) & 15) == 0, "rcnn_roi_geometry_packs: rowdxyz must be 16-byte aligned");
+    const prcnn::RgPacks pk = {rowinfo1, (float4 *)rowdxyz1, tilecloud1, hdr1, rowinfo2, (float4 *)rowdxyz2, tilecloud2, hdr2};
+    return roi_geometry_any(b, n, m1, r1, ns1, m2, r2, ns2, xyz, limit, new_xyz1, idx1, rep1, new_xyz2, idx2, rep2, &pk, stream);
 }

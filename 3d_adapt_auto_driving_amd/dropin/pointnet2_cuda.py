@@ -321,6 +321,47 @@ def rcnn_roi_geometry_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2):
     return new1, idx1, rep1, new2, idx2, rep2
 
 
+def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=None, hdr2=None):
+    """rcnn_roi_geometry_wrapper + the two levels' distinct-row lists out of the same launch (prcnn_rcnn_roi_geometry_packs) ->
+    (new_xyz1, idx1, rep1, new_xyz2, idx2, rep2, pack1, pack2): pack1 == ball_pack_wrapper(idx1, xyz, new_xyz1, limit, None, rep1),
+    pack2 == ball_pack_wrapper(idx2, new_xyz1, new_xyz2, None, rep1, rep2) -- the same rows per cloud, the same tiles.
+    hdr1 / hdr2 (4) i32, optional: headers that ARE ZERO already (slices of an arena the caller zeroed)."""
+    _chk(torch.float32, xyz); _chk(torch.int32, limit)
+    b, n, _ = xyz.shape
+    dev = xyz.device
+    new1 = torch.empty((b, m1, 3), dtype=torch.float32, device=dev)
+    idx1 = torch.empty((b, m1, ns1), dtype=torch.int32, device=dev)
+    rep1 = torch.empty((b, m1), dtype=torch.int32, device=dev)
+    new2 = torch.empty((b, m2, 3), dtype=torch.float32, device=dev)
+    idx2 = torch.empty((b, m2, ns2), dtype=torch.int32, device=dev)
+    rep2 = torch.empty((b, m2), dtype=torch.int32, device=dev)
+    if (hdr1 is None) != (hdr2 is None):
+        raise ValueError("rcnn_roi_geometry_packs: both headers or none")
+    packs = []
+    for idx, lim_, rep_, crep_, hdr in ((idx1, limit, None, rep1, hdr1), (idx2, None, rep1, rep2, hdr2)):
+        m, ns = idx.shape[1], idx.shape[2]
+        cap = (m * ns + 63) // 64
+        pk = BallPack()
+        pk.idx, pk.limit, pk.rep, pk.crep = idx, lim_, rep_, crep_
+        pk.rowinfo = torch.empty((b * cap * 64,), dtype=torch.int32, device=dev)
+        pk.rowdxyz = torch.empty((b * cap * 64, 4), dtype=torch.float32, device=dev)
+        pk.tilecloud = torch.empty((b * cap,), dtype=torch.int32, device=dev)
+        pk.max_tiles = b * cap
+        if hdr is not None:
+            _chk(torch.int32, hdr)
+            if hdr.numel() != 4:
+                raise ValueError("rcnn_roi_geometry_packs: a header must hold 4 int32")
+        pk.hdr = hdr if hdr is not None else torch.empty((4,), dtype=torch.int32, device=dev)
+        packs.append(pk)
+    p1, p2 = packs
+    _lib.call("prcnn_rcnn_roi_geometry_packs", b, n, m1, float(r1), ns1, m2, float(r2), ns2, xyz.data_ptr(), limit.data_ptr(), new1.data_ptr(),
+              idx1.data_ptr(), rep1.data_ptr(), new2.data_ptr(), idx2.data_ptr(), rep2.data_ptr(),
+              p1.rowinfo.data_ptr(), p1.rowdxyz.data_ptr(), p1.tilecloud.data_ptr(), p1.hdr.data_ptr(),
+              p2.rowinfo.data_ptr(), p2.rowdxyz.data_ptr(), p2.tilecloud.data_ptr(), p2.hdr.data_ptr(), 1 if hdr1 is not None else 0,
+              _lib.current_stream(xyz))
+    return new1, idx1, rep1, new2, idx2, rep2, p1, p2
+
+
 def dup_rep_wrapper(sel, n, limit=None, prev=None):
     """sel (b,m) i32 = an FPS answer over clouds of n points whose copies are described by limit (b) i32 (points k >= limit are
     copies of k % limit) and / or prev (b,n) i32 (their representative map) -> rep (b,m) i32: for every sampled point the

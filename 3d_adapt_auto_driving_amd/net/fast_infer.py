@@ -47,6 +47,7 @@ USE_CENTRE_SKIP = os.environ.get("PRCNN_NO_CENTRE_SKIP") is None       # ... and
 # sampling, ball query and representative map of both sampled RCNN levels for every RoI cloud in one launch; PRCNN_NO_ROI_GEOMETRY=1:
 # the six separate launches (A/B, same results)
 USE_ROI_GEOMETRY = os.environ.get("PRCNN_NO_ROI_GEOMETRY") is None
+USE_ROI_PACKS = os.environ.get("PRCNN_NO_ROI_PACKS") is None      # ... and their distinct-row lists out of the same launch (round 5)
 USE_POINT_LAYER = os.environ.get("PRCNN_LIB_GEMM") is None     # per-point layers (FP modules, heads) on the own MFMA layer kernel
 # every per-point width zero-padded to a multiple of 128 (SA level outputs, FP inputs, narrow head outputs), so that NO layer
 # of the engine is left to a GEMM library: fixed summation order everywhere, reproduced bit for bit by the oracle
@@ -1086,12 +1087,19 @@ class FastPointRCNN:
                 and has_entry(ext, "rcnn_roi_geometry_wrapper") and USE_PACKED
                 and all(m_[3].packed is not None or m_[3].wide is not None for m_ in sa[:2])
                 and ext.rcnn_roi_geometry_supported(cur_xyz.shape[1], sa[0][0], sa[0][2], sa[1][0], sa[1][2])):
-            fused_geo = ext.rcnn_roi_geometry_wrapper(cur_xyz, pooled_cnt.view(-1), sa[0][0], sa[0][1], sa[0][2], sa[1][0], sa[1][1], sa[1][2])
+            if USE_ROI_PACKS and has_entry(ext, "rcnn_roi_geometry_packs_wrapper"):
+                # ... and both levels' row lists written by the wave that holds the hit lists (no pack launches for these levels)
+                fused_geo = ext.rcnn_roi_geometry_packs_wrapper(cur_xyz, pooled_cnt.view(-1), sa[0][0], sa[0][1], sa[0][2], sa[1][0], sa[1][1],
+                                                                sa[1][2], *(zhdr() + zhdr()))
+            else:
+                fused_geo = ext.rcnn_roi_geometry_wrapper(cur_xyz, pooled_cnt.view(-1), sa[0][0], sa[0][1], sa[0][2], sa[1][0], sa[1][1], sa[1][2])
         for k, (npoint, radius, ns, mlp, cin) in enumerate(self.rcnn_sa):
             lev = {"xyz": cur_xyz, "new_xyz": None, "idx": None, "pack": None}
             if npoint is not None and fused_geo is not None and k < 2:
                 new_xyz, idx, rep_out = fused_geo[3 * k:3 * k + 3]
-                if k == 0:
+                if len(fused_geo) == 8:
+                    lev["pack"] = fused_geo[6 + k]
+                elif k == 0:
                     lev["pack"] = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, pooled_cnt.view(-1), None, rep_out, *zhdr())
                 else:
                     lev["pack"] = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, None, rep, rep_out, *zhdr())

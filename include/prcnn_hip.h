@@ -227,6 +227,18 @@ int prcnn_dup_rep(int b, int n, int m, const int *sel, const int *limit, const i
 int prcnn_rcnn_roi_geometry(int b, int n, int m1, float r1, int ns1, int m2, float r2, int ns2, const float *xyz,
                             const int *limit, float *new_xyz1, int *idx1, int *rep1, float *new_xyz2, int *idx2, int *rep2,
                             void *stream);
+/* ... and the distinct-row lists of both levels out of the same launch (round 5; csrc/fps.hip roi_pack_out): what
+ *   prcnn_ball_pack_ex(b, b, 512, 128, ns1, idx1, limit, NULL, rep1, xyz, new_xyz1, rowinfo1, rowdxyz1, tilecloud1, hdr1, ...) and
+ *   prcnn_ball_pack_ex(b, b, 128, 32, ns2, idx2, NULL, rep1, rep2, new_xyz1, new_xyz2, rowinfo2, rowdxyz2, tilecloud2, hdr2, ...)
+ * write -- every cloud's rows in the same order, cut into the same tiles; the order of the clouds' tiles inside a list is whatever
+ * the list's counter hands out (as for prcnn_ball_pack).  Buffers sized as for prcnn_ball_pack: b * ceil(m * ns / 64) tiles per list;
+ * hdr1 / hdr2 (4 u32 each) are zeroed by this call unless hdr_is_zero != 0 (the caller zeroed them: see prcnn_ball_pack_ex).
+ * The reference has no counterpart: it groups all nsample rows (pointnet2_utils.py:241-264); see prcnn_ball_pack. */
+int prcnn_rcnn_roi_geometry_packs(int b, int n, int m1, float r1, int ns1, int m2, float r2, int ns2, const float *xyz,
+                                  const int *limit, float *new_xyz1, int *idx1, int *rep1, float *new_xyz2, int *idx2, int *rep2,
+                                  unsigned int *rowinfo1, float *rowdxyz1, int *tilecloud1, unsigned int *hdr1,
+                                  unsigned int *rowinfo2, float *rowdxyz2, int *tilecloud2, unsigned int *hdr2, int hdr_is_zero,
+                                  void *stream);
 /* out_is_zero (this entry, prcnn_sa_xyz_mlp_packed, prcnn_packed_layer_segmax): the results arrive through atomicMax into a
  * zeroed slice; 0 = the entry zeroes out[..., out_col : out_col + width) itself, 1 = the caller has zeroed it (one fill for all
  * the scales of a level instead of one strided fill per scale). */

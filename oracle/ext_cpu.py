@@ -223,6 +223,14 @@ class pointnet2_cpu:
         return new1, idx1, rep1, new2, idx2, rep2
 
     @staticmethod
+    def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=None, hdr2=None):
+        """prcnn_rcnn_roi_geometry_packs as the chain of stand-ins it fuses: the geometry, then the two row lists"""
+        P = pointnet2_cpu
+        new1, idx1, rep1, new2, idx2, rep2 = P.rcnn_roi_geometry_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2)
+        return (new1, idx1, rep1, new2, idx2, rep2, P.ball_pack_wrapper(idx1, xyz, new1, limit, None, rep1),
+                P.ball_pack_wrapper(idx2, new1, new2, None, rep1, rep2))
+
+    @staticmethod
     def dup_rep_wrapper(sel, n, limit=None, prev=None):
         """for every sampled point the first sampled point with the same source (plain loops; see prcnn_dup_rep)"""
         b, m = sel.shape

@@ -625,6 +625,56 @@ def test_rcnn_roi_geometry_ties_and_every_count(ext):
         assert not bad, (k, [counts[i] for i in bad][:10])
 
 
+def _pack_rows_by_cloud(pk, b):
+    """a BallPack's tiles grouped by cloud (the order of the clouds' tiles in the list is the counter's): per cloud the rowinfo words and
+    relative coordinates of its tiles, in tile order"""
+    ntiles, nrows = int(pk.hdr[0]), int(pk.hdr[1])
+    tc = pk.tilecloud[:ntiles].cpu().numpy()
+    info = pk.rowinfo[:ntiles * 64].cpu().numpy().reshape(ntiles, 64)
+    dxyz = pk.rowdxyz[:ntiles * 64].cpu().numpy().reshape(ntiles, 64, 4)
+    out = []
+    for c in range(b):
+        t = np.nonzero(tc == c)[0]
+        assert len(t) == 0 or (np.diff(t) == 1).all(), "a cloud's tiles are consecutive"
+        out.append((info[t].copy(), dxyz[t].copy()))
+    return ntiles, nrows, out
+
+
+@pytest.mark.parametrize("ns1,ns2", [(64, 64), (16, 48)])
+def test_rcnn_roi_geometry_packs_equal_ball_pack(ext, ns1, ns2):
+    """prcnn_rcnn_roi_geometry_packs: the six geometry outputs of prcnn_rcnn_roi_geometry and, out of the same launch, the two row lists
+    exactly as prcnn_ball_pack_ex writes them from idx1 (limit, crep = rep1) and idx2 (rep = rep1, crep = rep2): per cloud the same rows
+    in the same order in the same tiles, relative coordinates bit for bit, the padding rows of a cloud's last tile included."""
+    rng = np.random.default_rng(5 + ns1)
+    counts = [1, 2, 7, 33, 60, 64, 65, 100, 127, 128, 129, 200, 300, 511, 512, 512, 50, 90] + [int(c) for c in rng.integers(1, 513, size=30)]
+    b = len(counts)
+    xyz = np.zeros((b, 512, 3), np.float32)
+    for i, c in enumerate(counts):
+        base = (rng.standard_normal((c, 3)) * [1.2, 0.5, 0.6]).astype(np.float32)
+        if i % 5 == 0:
+            base = (rng.integers(-6, 7, size=(c, 3)) * 0.1).astype(np.float32)      # lattice: ties, coinciding points
+        if i == 16:
+            base[:] = base[0]
+        xyz[i] = base[np.arange(512) % c]
+    limit = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    P = ext.pointnet2
+    X = T(xyz)
+    want = P.rcnn_roi_geometry_wrapper(X, limit, 128, 0.2, ns1, 32, 0.4, ns2)
+    for zeroed in (False, True):
+        hdrs = (torch.zeros(4, dtype=torch.int32, device=DEV), torch.zeros(4, dtype=torch.int32, device=DEV)) if zeroed else ()
+        got = P.rcnn_roi_geometry_packs_wrapper(X, limit, 128, 0.2, ns1, 32, 0.4, ns2, *hdrs)
+        for k, (g, w) in enumerate(zip(got[:6], want)):
+            assert torch.equal(g, w), k
+        new1, idx1, rep1, new2, idx2, rep2 = want
+        for lvl, (pk, ref) in enumerate(((got[6], P.ball_pack_wrapper(idx1, X, new1, limit, None, rep1)),
+                                         (got[7], P.ball_pack_wrapper(idx2, new1, new2, None, rep1, rep2)))):
+            a, r = _pack_rows_by_cloud(pk, b), _pack_rows_by_cloud(ref, b)
+            assert a[0] == r[0] and a[1] == r[1], (lvl, a[:2], r[:2])
+            for c in range(b):
+                assert np.array_equal(a[2][c][0], r[2][c][0]), (lvl, counts[c])
+                assert np.array_equal(a[2][c][1].view(np.uint32), r[2][c][1].view(np.uint32)), (lvl, counts[c])
+
+
 def test_point_major_kernels(ext, oracle):
     """group_cat_pm / maxpool_pm / three_interpolate_pm against the oracle's channel-major results
     rearranged to the point-major row layout [features | pad | dx dy dz | 0] (pure data movement and

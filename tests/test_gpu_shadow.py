@@ -150,6 +150,17 @@ def check_roi_geometry(self, name, args, host, ret):
         assert torch.equal(g.cpu(), w), (name, k)
 
 
+def check_roi_geometry_packs(self, name, args, host, ret):
+    """... with both levels' row lists out of the same launch: the six geometry outputs as above, and each list's header against the
+    definition of ball_pack (the rows themselves are checked through the MLP kernels that consume them: check_sa_packed)"""
+    want = self._cpu.rcnn_roi_geometry_wrapper(*host[:8])
+    for k, (g, w) in enumerate(zip(ret[:6], want)):
+        assert torch.equal(g.cpu(), w), (name, k)
+    new1, idx1, rep1, new2, idx2, rep2 = want
+    check_ball_pack(self, name, None, [idx1, host[0], new1, host[1], None, rep1], ret[6])
+    check_ball_pack(self, name, None, [idx2, new1, new2, None, rep1, rep2], ret[7])
+
+
 def check_dup_rep(self, name, args, host, ret):
     want = self._cpu.dup_rep_wrapper(*host)
     assert torch.equal(ret.cpu(), want), name
@@ -326,6 +337,7 @@ def check_point_aux(self, name, args, host, ret):
 POINTNET2["point_aux_wrapper"] = check_point_aux
 POINTNET2["dup_rep_wrapper"] = check_dup_rep
 POINTNET2["rcnn_roi_geometry_wrapper"] = check_roi_geometry
+POINTNET2["rcnn_roi_geometry_packs_wrapper"] = check_roi_geometry_packs
 POINTNET2["sa_packed_mlp_wrapper"] = check_sa_packed
 POINTNET2["sa_wide_fused_wrapper"] = {9: "exact"}          # one scale of a wide level in one kernel: output slice vs the oracle chain
 POINTNET2["sa_wide_fused3_wrapper"] = {10: "exact"}        # ... with the per-point layer inside (the RCNN's GroupAll level)
@@ -406,8 +418,9 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
     assert (det["num"] > 0).all()
     # coverage: every kernel family of the step was exercised at the batch-8 shapes
     fg = F.USE_ROI_GEOMETRY          # the RoI clouds' FPS / ball query / representative maps of both sampled levels in one launch
+    fp = fg and F.USE_ROI_PACKS      # ... and their two row lists out of that launch
     want_calls = {"furthest_point_sampling_wrapper": 0, "fps_new_xyz_wrapper": 4 if fg else 6, "dup_rep_wrapper": 0 if fg else 2, "point_aux_wrapper": 1,
-                  "ball_query_full_wrapper": 8, "ball_query_wrapper": 0 if fg else 1, "ball_query_limit_wrapper": 0 if fg else 1, "rcnn_roi_geometry_wrapper": 1 if fg else 0, "three_nn_wrapper": 0, "three_nn_weights_wrapper": 4, "ball_pack_wrapper": 11,
+                  "ball_query_full_wrapper": 8, "ball_query_wrapper": 0 if fg else 1, "ball_query_limit_wrapper": 0 if fg else 1, "rcnn_roi_geometry_wrapper": 1 if (fg and not fp) else 0, "rcnn_roi_geometry_packs_wrapper": 1 if fp else 0, "three_nn_wrapper": 0, "three_nn_weights_wrapper": 4, "ball_pack_wrapper": 9 if fp else 11,
                   "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 2 if (F.USE_SCALE_BATCH and F.USE_SA2_BATCH) else 4, "sa_packed_mlp_batch_wrapper": 1 if (F.USE_SCALE_BATCH and F.USE_SA2_BATCH) else 0,
                   "three_interpolate_cat_pm_wrapper": 0 if F.USE_FP_LINEAR else 3, "packed_layer_interp_wrapper": 3 if F.USE_FP_LINEAR else 0,
                   "rpn_tail_wrapper": 0 if F.USE_FP_LINEAR else 1, "rpn_tail_lin_wrapper": 1 if F.USE_FP_LINEAR and not F.USE_TAIL_DECODE else 0,
