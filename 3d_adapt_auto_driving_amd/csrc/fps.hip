@@ -1600,7 +1600,7 @@ __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
         rep1[(long)b * RG_M1 + lane + 64 * q] = r;
         own1[q] = r == lane + 64 * q;
     }
-    roi_rows_out<RG_M1>(ns1, s_hits, RG_LD1, cnt1[0], cnt1[1], idx1 + (long)b * RG_M1 * ns1, lane);
+    if (idx1) roi_rows_out<RG_M1>(ns1, s_hits, RG_LD1, cnt1[0], cnt1[1], idx1 + (long)b * RG_M1 * ns1, lane);
     if (pk.rowinfo1) {
         __syncthreads();                                          // s_first is free: the list's offsets
         roi_pack_out<RG_M1>(b, own1[0] ? max(cnt1[0], 1) : 0, own1[1] ? max(cnt1[1], 1) : 0, cnt1[0], cnt1[1], s_hits, RG_LD1, s_first, cloud,
@@ -1651,7 +1651,7 @@ __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
     __syncthreads();
     const int r2own = has ? s_first[src2] : -1;
     if (has) rep2[(long)b * RG_M2 + lane] = r2own;
-    roi_rows_out<RG_M2>(ns2, s_hits, RG_LD2, has ? cnt2[0] : 0, 0, idx2 + (long)b * RG_M2 * ns2, lane);
+    if (idx2) roi_rows_out<RG_M2>(ns2, s_hits, RG_LD2, has ? cnt2[0] : 0, 0, idx2 + (long)b * RG_M2 * ns2, lane);
     if (pk.rowinfo1) {
         __syncthreads();
         roi_pack_out<RG_M2>(b, r2own == lane ? max(cntd2, 1) : 0, 0, cntd2, 0, s_hits, RG_LD2, s_first, cloud, s_sel1, s_sel1, s_sel2,
@@ -1674,7 +1674,8 @@ static int roi_geometry_any(int b, int n, int m1, float r1, int ns1, int m2, flo
     PRCNN_REQUIRE(b >= 0 && n == RG_N && m1 == RG_M1 && m2 == RG_M2, "rcnn_roi_geometry: written for 512 -> 128 -> 32 points (got %d -> %d -> %d)", n, m1, m2);
     PRCNN_REQUIRE(ns1 >= 1 && ns1 <= RG_NS && ns2 >= 1 && ns2 <= RG_NS && r1 > 0.f && r2 > 0.f, "rcnn_roi_geometry: nsample must be 1..64, radii positive");
     if (b == 0) return PRCNN_OK;
-    PRCNN_REQUIRE(xyz && new_xyz1 && idx1 && rep1 && new_xyz2 && idx2 && rep2, "rcnn_roi_geometry: null pointer");
+    PRCNN_REQUIRE(xyz && new_xyz1 && rep1 && new_xyz2 && rep2, "rcnn_roi_geometry: null pointer");
+    PRCNN_REQUIRE((idx1 && idx2) || (!idx1 && !idx2 && packs->rowinfo1), "rcnn_roi_geometry: the index tensors may only be left out (both) when the row lists are asked for");
     auto codec = [](int npts) {
         const int bs = host_opt_n_threads(npts);
         KeyCodec kc;
@@ -1704,7 +1705,8 @@ extern "C" int prcnn_rcnn_roi_geometry(int b, int n, int m1, float r1, int ns1, 
  *   list 2 = prcnn_ball_pack_ex(b, b, 128, 32, ns2, idx2, NULL, rep1, rep2, new_xyz1, new_xyz2, ...)
  * -- the same rows per cloud in the same order, cut into the same tiles (the order of the CLOUDS' tiles in a list is whatever the
  * counter hands out, as it is for prcnn_ball_pack).  rowinfo* / rowdxyz* / tilecloud*: sized as for prcnn_ball_pack
- * (b * ceil(m * ns / 64) tiles); hdr1 / hdr2 (4 u32 each): zeroed here unless hdr_is_zero. */
+ * (b * ceil(m * ns / 64) tiles); hdr1 / hdr2 (4 u32 each): zeroed here unless hdr_is_zero.  idx1 == idx2 == NULL: the index tensors
+ * are not written (a caller that feeds the row lists to the packed MLP kernels has no use for them: 10240 words per cloud). */
 extern "C" int prcnn_rcnn_roi_geometry_packs(int b, int n, int m1, float r1, int ns1, int m2, float r2, int ns2, const float *xyz,
                                              const int *limit, float *new_xyz1, int *idx1, int *rep1, float *new_xyz2, int *idx2, int *rep2,
                                              unsigned int *rowinfo1, float *rowdxyz1, int *tilecloud1, unsigned int *hdr1,

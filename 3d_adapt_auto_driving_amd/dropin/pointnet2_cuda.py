@@ -321,19 +321,25 @@ def rcnn_roi_geometry_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2):
     return new1, idx1, rep1, new2, idx2, rep2
 
 
-def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=None, hdr2=None):
+def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=None, hdr2=None, want_idx=True):
     """rcnn_roi_geometry_wrapper + the two levels' distinct-row lists out of the same launch (prcnn_rcnn_roi_geometry_packs) ->
     (new_xyz1, idx1, rep1, new_xyz2, idx2, rep2, pack1, pack2): pack1 == ball_pack_wrapper(idx1, xyz, new_xyz1, limit, None, rep1),
     pack2 == ball_pack_wrapper(idx2, new_xyz1, new_xyz2, None, rep1, rep2) -- the same rows per cloud, the same tiles.
-    hdr1 / hdr2 (4) i32, optional: headers that ARE ZERO already (slices of an arena the caller zeroed)."""
+    hdr1 / hdr2 (4) i32, optional: headers that ARE ZERO already (slices of an arena the caller zeroed).  want_idx=False: idx1 / idx2 are
+    not written -- what comes back in their place (and in the packs' .idx) are tensors of the right SHAPE without storage behind it
+    (stride 0): the packed MLP wrappers only ask them for their shape."""
     _chk(torch.float32, xyz); _chk(torch.int32, limit)
     b, n, _ = xyz.shape
     dev = xyz.device
     new1 = torch.empty((b, m1, 3), dtype=torch.float32, device=dev)
-    idx1 = torch.empty((b, m1, ns1), dtype=torch.int32, device=dev)
+    if want_idx:
+        idx1 = torch.empty((b, m1, ns1), dtype=torch.int32, device=dev)
+        idx2 = torch.empty((b, m2, ns2), dtype=torch.int32, device=dev)
+    else:
+        idx1 = torch.empty((1,), dtype=torch.int32, device=dev).expand(b, m1, ns1)
+        idx2 = torch.empty((1,), dtype=torch.int32, device=dev).expand(b, m2, ns2)
     rep1 = torch.empty((b, m1), dtype=torch.int32, device=dev)
     new2 = torch.empty((b, m2, 3), dtype=torch.float32, device=dev)
-    idx2 = torch.empty((b, m2, ns2), dtype=torch.int32, device=dev)
     rep2 = torch.empty((b, m2), dtype=torch.int32, device=dev)
     if (hdr1 is None) != (hdr2 is None):
         raise ValueError("rcnn_roi_geometry_packs: both headers or none")
@@ -355,7 +361,7 @@ def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=N
         packs.append(pk)
     p1, p2 = packs
     _lib.call("prcnn_rcnn_roi_geometry_packs", b, n, m1, float(r1), ns1, m2, float(r2), ns2, xyz.data_ptr(), limit.data_ptr(), new1.data_ptr(),
-              idx1.data_ptr(), rep1.data_ptr(), new2.data_ptr(), idx2.data_ptr(), rep2.data_ptr(),
+              idx1.data_ptr() if want_idx else None, rep1.data_ptr(), new2.data_ptr(), idx2.data_ptr() if want_idx else None, rep2.data_ptr(),
               p1.rowinfo.data_ptr(), p1.rowdxyz.data_ptr(), p1.tilecloud.data_ptr(), p1.hdr.data_ptr(),
               p2.rowinfo.data_ptr(), p2.rowdxyz.data_ptr(), p2.tilecloud.data_ptr(), p2.hdr.data_ptr(), 1 if hdr1 is not None else 0,
               _lib.current_stream(xyz))

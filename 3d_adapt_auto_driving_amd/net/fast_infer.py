@@ -1089,8 +1089,10 @@ class FastPointRCNN:
                 and ext.rcnn_roi_geometry_supported(cur_xyz.shape[1], sa[0][0], sa[0][2], sa[1][0], sa[1][2])):
             if USE_ROI_PACKS and has_entry(ext, "rcnn_roi_geometry_packs_wrapper"):
                 # ... and both levels' row lists written by the wave that holds the hit lists (no pack launches for these levels)
+                # (the index tensors themselves are not written on the HIP path: the packed kernels read the lists, `idx` is asked for its shape)
+                hd = zhdr() + zhdr()
                 fused_geo = ext.rcnn_roi_geometry_packs_wrapper(cur_xyz, pooled_cnt.view(-1), sa[0][0], sa[0][1], sa[0][2], sa[1][0], sa[1][1],
-                                                                sa[1][2], *(zhdr() + zhdr()))
+                                                                sa[1][2], *(hd + (False,) if hd else ()))
             else:
                 fused_geo = ext.rcnn_roi_geometry_wrapper(cur_xyz, pooled_cnt.view(-1), sa[0][0], sa[0][1], sa[0][2], sa[1][0], sa[1][1], sa[1][2])
         for k, (npoint, radius, ns, mlp, cin) in enumerate(self.rcnn_sa):

@@ -233,6 +233,7 @@ int prcnn_rcnn_roi_geometry(int b, int n, int m1, float r1, int ns1, int m2, flo
  * write -- every cloud's rows in the same order, cut into the same tiles; the order of the clouds' tiles inside a list is whatever
  * the list's counter hands out (as for prcnn_ball_pack).  Buffers sized as for prcnn_ball_pack: b * ceil(m * ns / 64) tiles per list;
  * hdr1 / hdr2 (4 u32 each) are zeroed by this call unless hdr_is_zero != 0 (the caller zeroed them: see prcnn_ball_pack_ex).
+ * idx1 and idx2 may both be NULL: the index tensors are then not written (the packed MLP kernels read the row lists only).
  * The reference has no counterpart: it groups all nsample rows (pointnet2_utils.py:241-264); see prcnn_ball_pack. */
 int prcnn_rcnn_roi_geometry_packs(int b, int n, int m1, float r1, int ns1, int m2, float r2, int ns2, const float *xyz,
                                   const int *limit, float *new_xyz1, int *idx1, int *rep1, float *new_xyz2, int *idx2, int *rep2,

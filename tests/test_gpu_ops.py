@@ -660,10 +660,13 @@ def test_rcnn_roi_geometry_packs_equal_ball_pack(ext, ns1, ns2):
     P = ext.pointnet2
     X = T(xyz)
     want = P.rcnn_roi_geometry_wrapper(X, limit, 128, 0.2, ns1, 32, 0.4, ns2)
-    for zeroed in (False, True):
-        hdrs = (torch.zeros(4, dtype=torch.int32, device=DEV), torch.zeros(4, dtype=torch.int32, device=DEV)) if zeroed else ()
-        got = P.rcnn_roi_geometry_packs_wrapper(X, limit, 128, 0.2, ns1, 32, 0.4, ns2, *hdrs)
+    for zeroed, with_idx in ((False, True), (True, True), (True, False)):
+        hdrs = (torch.zeros(4, dtype=torch.int32, device=DEV), torch.zeros(4, dtype=torch.int32, device=DEV)) if zeroed else (None, None)
+        got = P.rcnn_roi_geometry_packs_wrapper(X, limit, 128, 0.2, ns1, 32, 0.4, ns2, *hdrs, with_idx)
         for k, (g, w) in enumerate(zip(got[:6], want)):
+            if not with_idx and k in (1, 4):                 # not written: a shape without storage
+                assert tuple(g.shape) == tuple(w.shape) and g.stride() == (0, 0, 0)
+                continue
             assert torch.equal(g, w), k
         new1, idx1, rep1, new2, idx2, rep2 = want
         for lvl, (pk, ref) in enumerate(((got[6], P.ball_pack_wrapper(idx1, X, new1, limit, None, rep1)),

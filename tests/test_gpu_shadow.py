@@ -154,9 +154,16 @@ def check_roi_geometry_packs(self, name, args, host, ret):
     """... with both levels' row lists out of the same launch: the six geometry outputs as above, and each list's header against the
     definition of ball_pack (the rows themselves are checked through the MLP kernels that consume them: check_sa_packed)"""
     want = self._cpu.rcnn_roi_geometry_wrapper(*host[:8])
+    no_idx = len(host) > 10 and host[10] is False           # the product's call: the index tensors are not written (shape-only stand-ins)
     for k, (g, w) in enumerate(zip(ret[:6], want)):
+        if no_idx and k in (1, 4):
+            assert tuple(g.shape) == tuple(w.shape) and g.stride() == (0, 0, 0), (name, k)
+            continue
         assert torch.equal(g.cpu(), w), (name, k)
     new1, idx1, rep1, new2, idx2, rep2 = want
+    if no_idx:      # the oracle's stand-ins of the MLP kernels restate the levels from the index tensors: hand them the oracle's own
+        ret[6].idx, ret[7].idx = idx1.to(ret[0].device), idx2.to(ret[0].device)
+        self._log["roi_idx_not_written"] += 1
     check_ball_pack(self, name, None, [idx1, host[0], new1, host[1], None, rep1], ret[6])
     check_ball_pack(self, name, None, [idx2, new1, new2, None, rep1, rep2], ret[7])
 
@@ -434,6 +441,7 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
     for name, n in want_calls.items():
         assert log[name] == n, (name, log[name], n)
     assert log["packed_layer_wrapper"] >= 3 and log["rows_dot_wrapper"] == 1
+    assert log["roi_idx_not_written"] == (1 if fp else 0)
     assert log["rep_rows_dropped"] > 1000            # the deeper RCNN levels really dropped rows of copied centres
     assert log["centres_skipped"] > 1000             # ... and skipped the centres that copy an earlier one
     print("shadowed calls:", {k: v for k, v in log.items() if not k.startswith("elements:")})
