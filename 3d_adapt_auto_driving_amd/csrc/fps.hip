@@ -1479,6 +1479,9 @@ __device__ __forceinline__ void roi_rows_out(int ns, const unsigned short *__res
 struct RgPacks {
     unsigned int *rowinfo1; float4 *rowdxyz1; int *tilecloud1; unsigned int *hdr1;
     unsigned int *rowinfo2; float4 *rowdxyz2; int *tilecloud2; unsigned int *hdr2;
+    // tilecloud* == NULL: the lists' rows carry their cloud -- descriptor (cloud << 16) | (centre << 9) | point -- and are drawn from the
+    // list's ROW counter hdr[1], so that tiles are cut wherever the rows fall (csrc/sa_packed.hip reads such a list when it is given no
+    // tilecloud): no padded last tile per cloud
 };
 
 __device__ __forceinline__ int wave_incl_scan(int v, const int lane)
@@ -1508,19 +1511,26 @@ __device__ __forceinline__ void roi_pack_out(int b, int keep_lo, int keep_hi, in
     const int total = __builtin_amdgcn_readlane(in_hi, 63);
     if (lane < M) s_off[lane] = in_lo - keep_lo;
     if (M > 64) s_off[lane + 64] = in_hi - keep_hi;
+    const bool rowcloud = tilecloud == nullptr;
     const int nt = (total + 63) >> 6;
     int base = 0;
     if (lane == 0) {
-        base = (int)atomicAdd(&hdr[0], (unsigned int)nt);
-        atomicAdd(&hdr[1], (unsigned int)total);
+        if (rowcloud) {
+            base = (int)atomicAdd(&hdr[1], (unsigned int)total);  // the cloud's first ROW of the list
+        } else {
+            base = (int)atomicAdd(&hdr[0], (unsigned int)nt);     // the cloud's first TILE
+            atomicAdd(&hdr[1], (unsigned int)total);
+        }
     }
     base = __builtin_amdgcn_readfirstlane(base);
     __syncthreads();                                              // (one wave: orders the LDS writes above before the searches below)
-    for (int t = lane; t < nt; t += 64) tilecloud[base + t] = b;
-    unsigned int *__restrict__ dst = rowinfo + (long)base * 64;
-    float4 *__restrict__ dx = rowdxyz + (long)base * 64;
-    for (int r0 = 0; r0 < nt * 64; r0 += 64) {
-        const int r = r0 + lane;
+    if (!rowcloud)
+        for (int t = lane; t < nt; t += 64) tilecloud[base + t] = b;
+    unsigned int *__restrict__ dst = rowinfo + (rowcloud ? (long)base : (long)base * 64);
+    float4 *__restrict__ dx = rowdxyz + (rowcloud ? (long)base : (long)base * 64);
+    const int rows_out = rowcloud ? total : nt * 64;
+    for (int r0 = 0; r0 < rows_out; r0 += 64) {
+        const int r = r0 + lane;                                  // (every lane stays in the loop: the shuffles below read all of them)
         int c = M - 1, p = 0;
         if (r < total) {
             int lo = 0, hi = M - 1;                               // the last centre whose offset is <= r
@@ -1536,8 +1546,10 @@ __device__ __forceinline__ void roi_pack_out(int b, int keep_lo, int keep_hi, in
         const int pi = pmap ? pmap[k] : k;
         const int ci = cmap2 ? cmap[cmap2[c]] : cmap[c];
         const float *__restrict__ pt = cloud + 3 * pi, *__restrict__ ct = cloud + 3 * ci;
-        dst[r] = ((unsigned int)c << 16) | (unsigned int)k;
-        dx[r] = make_float4(pt[0] - ct[0], pt[1] - ct[1], pt[2] - ct[2], 0.f);
+        if (r < rows_out) {
+            dst[r] = rowcloud ? (((unsigned int)b << 16) | ((unsigned int)c << 9) | (unsigned int)k) : (((unsigned int)c << 16) | (unsigned int)k);
+            dx[r] = make_float4(pt[0] - ct[0], pt[1] - ct[1], pt[2] - ct[2], 0.f);
+        }
     }
 }
 
@@ -1705,7 +1717,8 @@ extern "C" int prcnn_rcnn_roi_geometry(int b, int n, int m1, float r1, int ns1, 
  *   list 2 = prcnn_ball_pack_ex(b, b, 128, 32, ns2, idx2, NULL, rep1, rep2, new_xyz1, new_xyz2, ...)
  * -- the same rows per cloud in the same order, cut into the same tiles (the order of the CLOUDS' tiles in a list is whatever the
  * counter hands out, as it is for prcnn_ball_pack).  rowinfo* / rowdxyz* / tilecloud*: sized as for prcnn_ball_pack
- * (b * ceil(m * ns / 64) tiles); hdr1 / hdr2 (4 u32 each): zeroed here unless hdr_is_zero.  idx1 == idx2 == NULL: the index tensors
+ * (b * ceil(m * ns / 64) tiles); hdr1 / hdr2 (4 u32 each): zeroed here unless hdr_is_zero.  tilecloud1 == tilecloud2 == NULL: lists
+ * whose rows carry their cloud (see RgPacks; the form the engine uses: prcnn_sa_packed_mlp reads it).  idx1 == idx2 == NULL: the index tensors
  * are not written (a caller that feeds the row lists to the packed MLP kernels has no use for them: 10240 words per cloud). */
 extern "C" int prcnn_rcnn_roi_geometry_packs(int b, int n, int m1, float r1, int ns1, int m2, float r2, int ns2, const float *xyz,
                                              const int *limit, float *new_xyz1, int *idx1, int *rep1, float *new_xyz2, int *idx2, int *rep2,
@@ -1720,7 +1733,8 @@ extern "C" int prcnn_rcnn_roi_geometry_packs(int b, int n, int m1, float r1, int
         return PRCNN_ELAUNCH;
     }
     if (b == 0) return PRCNN_OK;
-    PRCNN_REQUIRE(rowinfo1 && rowdxyz1 && tilecloud1 && rowinfo2 && rowdxyz2 && tilecloud2, "rcnn_roi_geometry_packs: null pointer");
+    PRCNN_REQUIRE(rowinfo1 && rowdxyz1 && rowinfo2 && rowdxyz2, "rcnn_roi_geometry_packs: null pointer");
+    PRCNN_REQUIRE((tilecloud1 && tilecloud2) || (!tilecloud1 && !tilecloud2 && b <= 65536), "rcnn_roi_geometry_packs: both lists with a tilecloud or none");
     PRCNN_REQUIRE((((uintptr_t)rowdxyz1 | (uintptr_t)rowdxyz2) & 15) == 0, "rcnn_roi_geometry_packs: rowdxyz must be 16-byte aligned");
     const prcnn::RgPacks pk = {rowinfo1, (float4 *)rowdxyz1, tilecloud1, hdr1, rowinfo2, (float4 *)rowdxyz2, tilecloud2, hdr2};
     return roi_geometry_any(b, n, m1, r1, ns1, m2, r2, ns2, xyz, limit, new_xyz1, idx1, rep1, new_xyz2, idx2, rep2, &pk, stream);

@@ -242,7 +242,17 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(const SaPkBatc
     float *__restrict__ out = q.out;
     const int out_stride = q.out_stride, out_col = q.out_col, lds_pool = q.lds_pool;
     unsigned int *__restrict__ ticket = rec + 2 * pi;                 // this problem's draw counter
-    const long tiles = hdr[0];
+    // tilecloud == NULL (round 5): a list whose ROWS carry their cloud -- descriptor (cloud << 16) | (centre << 9) | point, written by
+    // prcnn_rcnn_roi_geometry_packs for the RoI clouds (512 points, 128 centres at most) -- and whose hdr[1] rows are cut into tiles
+    // wherever they fall: a tile holds the rows of several clouds, only the list's last tile is partly filled (its missing rows
+    // read as copies of the list's last row: copies do not change a max).  With a tile per cloud the 1600 RoI clouds of a launch
+    // padded 39 rows to 64 on the second level of the uniform scene, 102 to 128 on LiDAR-shaped ones.
+    const bool rowcloud = tilecloud == nullptr;
+    const long nrows = hdr[1];
+    const long tiles = rowcloud ? (nrows + PK_ROWS - 1) / PK_ROWS : (long)hdr[0];
+    const long last_row = rowcloud ? nrows - 1 : 0x7fffffffffffL;
+    const unsigned int kmask = rowcloud ? 0x1ffu : 0xffffu, cmask = rowcloud ? 0x7fu : 0xffffu;
+    const int cshift = rowcloud ? 9 : 16;
 
     // first ticket BEFORE the weights are fetched: the grid is sized for the worst case (every ball full) and most
     // workgroups of a sparse launch leave right here
@@ -264,15 +274,16 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(const SaPkBatc
 
     unsigned int info[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) info[i] = rowinfo[t * PK_ROWS + r0 + 8 * i];
-    int cloud = tilecloud[t];
-    if (tid < PK_ROWS) dxyz_s[0][tid] = rowdxyz[t * PK_ROWS + tid];
+    for (int i = 0; i < 8; ++i) info[i] = rowinfo[min(t * PK_ROWS + r0 + 8 * i, last_row)];
+    int cloud = rowcloud ? 0 : tilecloud[t];
+    if (tid < PK_ROWS) dxyz_s[0][tid] = rowdxyz[min(t * PK_ROWS + tid, last_row)];
     // half of the tile's 8 rows of P per thread are gathered ONE TILE AHEAD (behind layer 3's MFMAs; all 8 do not fit the
     // register budget next to the 128 resident weights: 164 bytes of spills, slower on sparse tiles): the builder's wait for its
     // gathers was 12-15k of a tile's 50k cycles (s_memtime stamps, profiles/r02_stage_stamps.md)
     float4 pb[PK_PF];
 #pragma unroll
-    for (int i = 0; i < PK_PF; ++i) pb[i] = P[((long)cloud * n + (long)(info[i] & 0xffffu)) * (PK_C / 4) + chunk];
+    for (int i = 0; i < PK_PF; ++i)
+        pb[i] = P[((long)(rowcloud ? (int)(info[i] >> 16) : cloud) * n + (long)(info[i] & kmask)) * (PK_C / 4) + chunk];
     __syncthreads();
 
     for (int served = 0; served < tiles_per_wg && t < tiles; ++served) {
@@ -280,26 +291,26 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(const SaPkBatc
         if (tid == 0) slot[(served + 1) & 1] = more ? atomicAdd(ticket, 1u) : 0xffffffffu;
         int *cc = ctr[served & 1];
         const float4 *dcur = dxyz_s[served & 1];
-        const long pbase = (long)cloud * n, cbase = (long)cloud * m;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = r0 + 8 * i;
-            const int k = (int)(info[i] & 0xffffu), cl = (int)(info[i] >> 16);
+            const int k = (int)(info[i] & kmask), cl = (int)((info[i] >> cshift) & cmask);
+            const long cl_ = rowcloud ? (long)(info[i] >> 16) : (long)cloud;
             const float4 d = dcur[row];
             const float dx = d.x, dy = d.y, dz = d.z;
-            const float4 base = i < PK_PF ? pb[i] : P[(pbase + k) * (PK_C / 4) + chunk];
+            const float4 base = i < PK_PF ? pb[i] : P[(cl_ * n + k) * (PK_C / 4) + chunk];
             const float4 v = affine_relu4(base, wx, wy, wz, dx, dy, dz);
             *reinterpret_cast<float4 *>(A1 + row * PK_LD + 4 * chunk) = v;
-            if (chunk == 0) cc[row] = (int)(cbase + cl);
+            if (chunk == 0) cc[row] = (int)(cl_ * m + cl);
         }
         __syncthreads();
         const long t_next = slot[(served + 1) & 1];
         float4 dnext = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t_next < tiles) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) info[i] = rowinfo[t_next * PK_ROWS + r0 + 8 * i];
-            cloud = tilecloud[t_next];
-            if (tid < PK_ROWS) dnext = rowdxyz[t_next * PK_ROWS + tid];     // in flight during layer 2
+            for (int i = 0; i < 8; ++i) info[i] = rowinfo[min(t_next * PK_ROWS + r0 + 8 * i, last_row)];
+            if (!rowcloud) cloud = tilecloud[t_next];
+            if (tid < PK_ROWS) dnext = rowdxyz[min(t_next * PK_ROWS + tid, last_row)];     // in flight during layer 2
         }
 
         // ---- layer 2
@@ -330,7 +341,8 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(const SaPkBatc
         if (tid < PK_ROWS && t_next < tiles) dxyz_s[(served + 1) & 1][tid] = dnext;   // ordered before the next builder by the barrier below
         if (t_next < tiles) {
 #pragma unroll
-            for (int i = 0; i < PK_PF; ++i) pb[i] = P[((long)cloud * n + (long)(info[i] & 0xffffu)) * (PK_C / 4) + chunk];   // in flight during layer 3
+            for (int i = 0; i < PK_PF; ++i)      // in flight during layer 3
+                pb[i] = P[((long)(rowcloud ? (int)(info[i] >> 16) : cloud) * n + (long)(info[i] & kmask)) * (PK_C / 4) + chunk];
         }
         __syncthreads();
 
@@ -392,7 +404,12 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6, wp = w & 3, wg = w >> 2;
     const int j = lane & 31, h = lane >> 5;
-    const long tiles = hdr[0];
+    const bool rowcloud = tilecloud == nullptr;                       // the rows carry their cloud: see sa_packed_mlp128_kernel
+    const long nrows = hdr[1];
+    const long tiles = rowcloud ? (nrows + PK_ROWS - 1) / PK_ROWS : (long)hdr[0];
+    const long last_row = rowcloud ? nrows - 1 : 0x7fffffffffffL;
+    const unsigned int kmask = rowcloud ? 0x1ffu : 0xffffu, cmask = rowcloud ? 0x7fu : 0xffffu;
+    const int cshift = rowcloud ? 9 : 16;
 
     if (tid == 0) slot[0] = atomicAdd(ticket, 1u);
     __syncthreads();
@@ -411,14 +428,14 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
 
     unsigned int info[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) info[i] = rowinfo[t * PK_ROWS + r0 + 16 * i];
-    int cloud = tilecloud[t];
-    if (tid < PK_ROWS) dxyz_s[0][tid] = rowdxyz[t * PK_ROWS + tid];
+    for (int i = 0; i < 4; ++i) info[i] = rowinfo[min(t * PK_ROWS + r0 + 16 * i, last_row)];
+    int cloud = rowcloud ? 0 : tilecloud[t];
+    if (tid < PK_ROWS) dxyz_s[0][tid] = rowdxyz[min(t * PK_ROWS + tid, last_row)];
     // the tile's 4 rows of P per thread are gathered ONE TILE AHEAD (behind layer 3's MFMAs): the builder used to wait for them,
     // a quarter of a tile's cycles (s_memtime stamps of the 128-wide kernel, profiles/r02_stage_stamps.md)
     float4 pb[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pb[i] = P[((long)cloud * n + (long)(info[i] & 0xffffu)) * (PK_C / 4) + chunk];
+    for (int i = 0; i < 4; ++i) pb[i] = P[((long)(rowcloud ? (int)(info[i] >> 16) : cloud) * n + (long)(info[i] & kmask)) * (PK_C / 4) + chunk];
     __syncthreads();
 
     for (int served = 0; served < tiles_per_wg && t < tiles; ++served) {
@@ -426,11 +443,11 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
         if (tid == 0) slot[(served + 1) & 1] = more ? atomicAdd(ticket, 1u) : 0xffffffffu;
         int *cc = ctr[served & 1];
         const float4 *dcur = dxyz_s[served & 1];
-        const long cbase = (long)cloud * m;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = r0 + 16 * i;
-            const int cl = (int)(info[i] >> 16);
+            const int cl = (int)((info[i] >> cshift) & cmask);
+            const long cbase = (rowcloud ? (long)(info[i] >> 16) : (long)cloud) * m;
             const float4 d = dcur[row];
             const float dx = d.x, dy = d.y, dz = d.z;
             const float4 base = pb[i];
@@ -443,9 +460,9 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
         float4 dnext = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t_next < tiles) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) info[i] = rowinfo[t_next * PK_ROWS + r0 + 16 * i];
-            cloud = tilecloud[t_next];
-            if (tid < PK_ROWS) dnext = rowdxyz[t_next * PK_ROWS + tid];
+            for (int i = 0; i < 4; ++i) info[i] = rowinfo[min(t_next * PK_ROWS + r0 + 16 * i, last_row)];
+            if (!rowcloud) cloud = tilecloud[t_next];
+            if (tid < PK_ROWS) dnext = rowdxyz[min(t_next * PK_ROWS + tid, last_row)];
         }
 
         // ---- layer 2: rows [32 wg, 32 wg + 32) x columns [32 wp, 32 wp + 32)
@@ -469,7 +486,8 @@ __global__ __launch_bounds__(512, 1) void sa_packed_mlp256_kernel(
         if (tid < PK_ROWS && t_next < tiles) dxyz_s[(served + 1) & 1][tid] = dnext;
         if (t_next < tiles) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pb[i] = P[((long)cloud * n + (long)(info[i] & 0xffffu)) * (PK_C / 4) + chunk];   // in flight during layer 3
+            for (int i = 0; i < 4; ++i)          // in flight during layer 3
+                pb[i] = P[((long)(rowcloud ? (int)(info[i] >> 16) : cloud) * n + (long)(info[i] & kmask)) * (PK_C / 4) + chunk];
         }
         __syncthreads();
 
@@ -649,7 +667,9 @@ extern "C" int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, 
     PRCNN_REQUIRE(n <= 65536 && m <= 65536, "sa_packed_mlp: cloud too large for the 16-bit row descriptors");
     PRCNN_REQUIRE(out_stride >= out_col + c3 && out_col >= 0, "sa_packed_mlp: bad output slice");
     if ((long)b * m == 0) return PRCNN_OK;
-    PRCNN_REQUIRE(P && wxyz && rowinfo && rowdxyz && tilecloud && hdr && w2t && b2 && w3t && b3 && out, "sa_packed_mlp: null pointer");
+    PRCNN_REQUIRE(P && wxyz && rowinfo && rowdxyz && hdr && w2t && b2 && w3t && b3 && out, "sa_packed_mlp: null pointer");
+    // tilecloud == NULL: the rows carry their cloud (descriptor (cloud << 16) | (centre << 9) | point; prcnn_rcnn_roi_geometry_packs)
+    PRCNN_REQUIRE(tilecloud || (n <= 512 && m <= 128 && b <= 65536), "sa_packed_mlp: a list without tilecloud holds clouds of <= 512 points, <= 128 centres");
     PRCNN_REQUIRE((((uintptr_t)P | (uintptr_t)wxyz) & 15) == 0, "sa_packed_mlp: 16-byte alignment required");
     hipStream_t st = (hipStream_t)stream;
     if (!out_is_zero && hipMemset2DAsync(out + out_col, (size_t)out_stride * sizeof(float), 0, (size_t)c3 * sizeof(float), (size_t)b * m, st) != hipSuccess) {

@@ -244,7 +244,7 @@ class BallPack:
     __slots__ = ("idx", "limit", "rep", "crep", "rowinfo", "rowdxyz", "tilecloud", "hdr", "max_tiles")
 
     def tensors(self):
-        return (self.idx, self.rowinfo, self.rowdxyz, self.tilecloud, self.hdr)
+        return tuple(t for t in (self.idx, self.rowinfo, self.rowdxyz, self.tilecloud, self.hdr) if t is not None)
 
     def record_stream(self, stream):
         for t in self.tensors():
@@ -321,13 +321,15 @@ def rcnn_roi_geometry_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2):
     return new1, idx1, rep1, new2, idx2, rep2
 
 
-def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=None, hdr2=None, want_idx=True):
+def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=None, hdr2=None, want_idx=True, row_clouds=False):
     """rcnn_roi_geometry_wrapper + the two levels' distinct-row lists out of the same launch (prcnn_rcnn_roi_geometry_packs) ->
     (new_xyz1, idx1, rep1, new_xyz2, idx2, rep2, pack1, pack2): pack1 == ball_pack_wrapper(idx1, xyz, new_xyz1, limit, None, rep1),
     pack2 == ball_pack_wrapper(idx2, new_xyz1, new_xyz2, None, rep1, rep2) -- the same rows per cloud, the same tiles.
     hdr1 / hdr2 (4) i32, optional: headers that ARE ZERO already (slices of an arena the caller zeroed).  want_idx=False: idx1 / idx2 are
     not written -- what comes back in their place (and in the packs' .idx) are tensors of the right SHAPE without storage behind it
-    (stride 0): the packed MLP wrappers only ask them for their shape."""
+    (stride 0): the packed MLP wrappers only ask them for their shape.  row_clouds=True: the lists in the form whose ROWS carry their
+    cloud (packs with .tilecloud None: rows of all clouds back to back, no padded last tile per cloud) -- sa_packed_mlp_wrapper takes
+    them, the other consumers of a BallPack do not."""
     _chk(torch.float32, xyz); _chk(torch.int32, limit)
     b, n, _ = xyz.shape
     dev = xyz.device
@@ -351,7 +353,7 @@ def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=N
         pk.idx, pk.limit, pk.rep, pk.crep = idx, lim_, rep_, crep_
         pk.rowinfo = torch.empty((b * cap * 64,), dtype=torch.int32, device=dev)
         pk.rowdxyz = torch.empty((b * cap * 64, 4), dtype=torch.float32, device=dev)
-        pk.tilecloud = torch.empty((b * cap,), dtype=torch.int32, device=dev)
+        pk.tilecloud = None if row_clouds else torch.empty((b * cap,), dtype=torch.int32, device=dev)
         pk.max_tiles = b * cap
         if hdr is not None:
             _chk(torch.int32, hdr)
@@ -362,8 +364,8 @@ def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=N
     p1, p2 = packs
     _lib.call("prcnn_rcnn_roi_geometry_packs", b, n, m1, float(r1), ns1, m2, float(r2), ns2, xyz.data_ptr(), limit.data_ptr(), new1.data_ptr(),
               idx1.data_ptr() if want_idx else None, rep1.data_ptr(), new2.data_ptr(), idx2.data_ptr() if want_idx else None, rep2.data_ptr(),
-              p1.rowinfo.data_ptr(), p1.rowdxyz.data_ptr(), p1.tilecloud.data_ptr(), p1.hdr.data_ptr(),
-              p2.rowinfo.data_ptr(), p2.rowdxyz.data_ptr(), p2.tilecloud.data_ptr(), p2.hdr.data_ptr(), 1 if hdr1 is not None else 0,
+              p1.rowinfo.data_ptr(), p1.rowdxyz.data_ptr(), _lib.ptr(p1.tilecloud), p1.hdr.data_ptr(),
+              p2.rowinfo.data_ptr(), p2.rowdxyz.data_ptr(), _lib.ptr(p2.tilecloud), p2.hdr.data_ptr(), 1 if hdr1 is not None else 0,
               _lib.current_stream(xyz))
     return new1, idx1, rep1, new2, idx2, rep2, p1, p2
 
@@ -421,7 +423,7 @@ def sa_packed_mlp_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, ou
     if c1 != 128 or w2t.shape != (128, 128) or w3t.size(0) != 128:
         raise RuntimeError("pointnet2_cuda: sa_packed_mlp needs 128-wide (zero-padded) layers 1 and 2")
     _lib.call("prcnn_sa_packed_mlp", b, n, new_xyz.size(1), w3t.size(1), pack.max_tiles,
-              P.data_ptr(), wxyz.data_ptr(), pack.rowinfo.data_ptr(), pack.rowdxyz.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr(),
+              P.data_ptr(), wxyz.data_ptr(), pack.rowinfo.data_ptr(), pack.rowdxyz.data_ptr(), _lib.ptr(pack.tilecloud), pack.hdr.data_ptr(),
               w2t.data_ptr(), b2.data_ptr(), w3t.data_ptr(), b3.data_ptr(), out.data_ptr(), out.size(-1), out_col, int(zeroed),
               _lib.current_stream(xyz))
     return out

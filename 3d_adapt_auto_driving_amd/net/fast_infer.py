@@ -1089,10 +1089,11 @@ class FastPointRCNN:
                 and ext.rcnn_roi_geometry_supported(cur_xyz.shape[1], sa[0][0], sa[0][2], sa[1][0], sa[1][2])):
             if USE_ROI_PACKS and has_entry(ext, "rcnn_roi_geometry_packs_wrapper"):
                 # ... and both levels' row lists written by the wave that holds the hit lists (no pack launches for these levels)
-                # (the index tensors themselves are not written on the HIP path: the packed kernels read the lists, `idx` is asked for its shape)
+                # (the index tensors themselves are not written on the HIP path: the packed kernels read the lists, `idx` is asked for its shape;
+                #  the lists' rows carry their cloud: no padded last tile per RoI cloud)
                 hd = zhdr() + zhdr()
                 fused_geo = ext.rcnn_roi_geometry_packs_wrapper(cur_xyz, pooled_cnt.view(-1), sa[0][0], sa[0][1], sa[0][2], sa[1][0], sa[1][1],
-                                                                sa[1][2], *(hd + (False,) if hd else ()))
+                                                                sa[1][2], *(hd + (False, all(m_[3].packed is not None for m_ in sa[:2])) if hd else ()))
             else:
                 fused_geo = ext.rcnn_roi_geometry_wrapper(cur_xyz, pooled_cnt.view(-1), sa[0][0], sa[0][1], sa[0][2], sa[1][0], sa[1][1], sa[1][2])
         for k, (npoint, radius, ns, mlp, cin) in enumerate(self.rcnn_sa):

@@ -234,6 +234,9 @@ int prcnn_rcnn_roi_geometry(int b, int n, int m1, float r1, int ns1, int m2, flo
  * the list's counter hands out (as for prcnn_ball_pack).  Buffers sized as for prcnn_ball_pack: b * ceil(m * ns / 64) tiles per list;
  * hdr1 / hdr2 (4 u32 each) are zeroed by this call unless hdr_is_zero != 0 (the caller zeroed them: see prcnn_ball_pack_ex).
  * idx1 and idx2 may both be NULL: the index tensors are then not written (the packed MLP kernels read the row lists only).
+ * tilecloud1 and tilecloud2 may both be NULL: the lists are then written in the form whose ROWS carry their cloud -- descriptor
+ * (cloud << 16) | (centre << 9) | point, hdr[1] = rows, hdr[0] unused -- with every cloud's rows right behind another cloud's: tiles are
+ * cut wherever the rows fall, no padded last tile per cloud.  prcnn_sa_packed_mlp takes such a list when IT is given tilecloud == NULL.
  * The reference has no counterpart: it groups all nsample rows (pointnet2_utils.py:241-264); see prcnn_ball_pack. */
 int prcnn_rcnn_roi_geometry_packs(int b, int n, int m1, float r1, int ns1, int m2, float r2, int ns2, const float *xyz,
                                   const int *limit, float *new_xyz1, int *idx1, int *rep1, float *new_xyz2, int *idx2, int *rep2,
@@ -243,6 +246,9 @@ int prcnn_rcnn_roi_geometry_packs(int b, int n, int m1, float r1, int ns1, int m
 /* out_is_zero (this entry, prcnn_sa_xyz_mlp_packed, prcnn_packed_layer_segmax): the results arrive through atomicMax into a
  * zeroed slice; 0 = the entry zeroes out[..., out_col : out_col + width) itself, 1 = the caller has zeroed it (one fill for all
  * the scales of a level instead of one strided fill per scale). */
+/* tilecloud == NULL (this entry only, round 5): a list whose rows carry their cloud, as prcnn_rcnn_roi_geometry_packs writes it when it
+ * is given no tilecloud either (n <= 512, m <= 128, b <= 65536): hdr[1] rows, tiles cut wherever they fall, the last tile's missing rows
+ * read as copies of the list's last row.  Same per-row arithmetic: same bits as over the list with a tile per cloud. */
 int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, const float *P, const float *wxyz,
                         const unsigned int *rowinfo, const float *rowdxyz, const int *tilecloud,
                         const unsigned int *hdr, const float *w2t, const float *b2, const float *w3t,

@@ -223,7 +223,7 @@ class pointnet2_cpu:
         return new1, idx1, rep1, new2, idx2, rep2
 
     @staticmethod
-    def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=None, hdr2=None, want_idx=True):
+    def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=None, hdr2=None, want_idx=True, row_clouds=False):
         """prcnn_rcnn_roi_geometry_packs as the chain of stand-ins it fuses: the geometry, then the two row lists"""
         P = pointnet2_cpu
         new1, idx1, rep1, new2, idx2, rep2 = P.rcnn_roi_geometry_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2)

@@ -676,6 +676,24 @@ def test_rcnn_roi_geometry_packs_equal_ball_pack(ext, ns1, ns2):
             for c in range(b):
                 assert np.array_equal(a[2][c][0], r[2][c][0]), (lvl, counts[c])
                 assert np.array_equal(a[2][c][1].view(np.uint32), r[2][c][1].view(np.uint32)), (lvl, counts[c])
+    # ... and in the form whose rows carry their cloud: every cloud's rows in one block (no padding), the same rows in the same order
+    got = P.rcnn_roi_geometry_packs_wrapper(X, limit, 128, 0.2, ns1, 32, 0.4, ns2, None, None, False, True)
+    for lvl, (pk, ref) in enumerate(((got[6], P.ball_pack_wrapper(idx1, X, new1, limit, None, rep1)),
+                                     (got[7], P.ball_pack_wrapper(idx2, new1, new2, None, rep1, rep2)))):
+        assert pk.tilecloud is None and int(pk.hdr[1]) == int(ref.hdr[1])
+        n = int(pk.hdr[1])
+        info = pk.rowinfo[:n].cpu().numpy().astype(np.int64)
+        dx = pk.rowdxyz[:n].cpu().numpy()
+        cl = info >> 16
+        r = _pack_rows_by_cloud(ref, b)[2]
+        for c in range(b):
+            sel = np.nonzero(cl == c)[0]
+            assert len(sel) > 0 and (np.diff(sel) == 1).all(), (lvl, counts[c])
+            want_info = r[c][0].reshape(-1)[:len(sel)].astype(np.int64)
+            assert np.array_equal((info[sel] >> 9) & 0x7f, want_info >> 16) and np.array_equal(info[sel] & 0x1ff, want_info & 0xffff), (lvl, counts[c])
+            assert np.array_equal(dx[sel].view(np.uint32), r[c][1].reshape(-1, 4)[:len(sel)].view(np.uint32)), (lvl, counts[c])
+            # what the per-cloud list holds beyond these rows is the padding of the cloud's last tile
+            assert len(sel) > 64 * (r[c][0].shape[0] - 1), (lvl, counts[c])
 
 
 def test_point_major_kernels(ext, oracle):

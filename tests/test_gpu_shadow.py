@@ -116,6 +116,13 @@ def check_ball_pack(self, name, args, host, pack):
         self._log["centres_skipped"] += int((crep != np.arange(crep.shape[1])[None]).sum())
         cnt = np.where(crep == np.arange(crep.shape[1])[None], cnt, 0)
     assert hdr[1] == cnt.sum(), (name, int(hdr[1]), int(cnt.sum()))
+    if pack.tilecloud is None:                     # a list whose rows carry their cloud (prcnn_rcnn_roi_geometry_packs): no tile count, and
+        info = pack.rowinfo[:int(hdr[1])].cpu().numpy().astype(np.int64)      # every cloud's rows in one block, as many as the definition says
+        clouds = info >> 16
+        assert np.array_equal(np.bincount(clouds, minlength=cnt.shape[0]), cnt.sum(-1)), name
+        assert (np.diff(np.nonzero(np.diff(clouds))[0]).size == 0) or len(set(clouds[np.r_[True, np.diff(clouds) != 0]])) == len(np.unique(clouds)), name
+        self._log["row_cloud_lists"] += 1
+        return
     assert hdr[0] == sum((int(c.sum()) + 63) // 64 for c in cnt)
 
 
@@ -441,7 +448,7 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
     for name, n in want_calls.items():
         assert log[name] == n, (name, log[name], n)
     assert log["packed_layer_wrapper"] >= 3 and log["rows_dot_wrapper"] == 1
-    assert log["roi_idx_not_written"] == (1 if fp else 0)
+    assert log["roi_idx_not_written"] == (1 if fp else 0) and log["row_cloud_lists"] == (2 if fp else 0)
     assert log["rep_rows_dropped"] > 1000            # the deeper RCNN levels really dropped rows of copied centres
     assert log["centres_skipped"] > 1000             # ... and skipped the centres that copy an earlier one
     print("shadowed calls:", {k: v for k, v in log.items() if not k.startswith("elements:")})
