@@ -100,6 +100,8 @@ SIGNATURES = {
     "prcnn_rows_gemm128": [_L, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P],
     "prcnn_rcnn_point_mlp": [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_pooled_tiles": [_I, _I, _P, _P, _P, _P],
+    "prcnn_pooled_rows": [_I, _I, _P, _P, _P, _I, _P],
+    "prcnn_rcnn_point_mlp_rows": [_L, _I, _I] + [_P] * 13,
     "prcnn_sa_xyz_mlp_supported": [_I, _I, _I, _I],
     "prcnn_sa_xyz_mlp": [_I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "prcnn_rpn_proposals": [_I, _I, _I, _F, _F, _I, _I, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],

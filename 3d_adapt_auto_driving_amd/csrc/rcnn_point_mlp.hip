@@ -174,9 +174,15 @@ __global__ __launch_bounds__(256, 2) void rcnn_entrance_kernel(
     long tiles, const float *__restrict__ rows, int ld, int fcol, const float4 *__restrict__ wu1, const float4 *__restrict__ bu1,
     const float *__restrict__ wu2, const float *__restrict__ bu2, const float *__restrict__ wm, const float *__restrict__ bm,
     const float *__restrict__ wp, const float *__restrict__ bp, float *__restrict__ p_out, unsigned int *__restrict__ ticket,
-    const int *__restrict__ tilemap, const unsigned int *__restrict__ ntiles_dev)
+    const int *__restrict__ tilemap, const unsigned int *__restrict__ ntiles_dev, const int *__restrict__ rowmap)
 {
-    if (ntiles_dev) tiles = (long)*ntiles_dev;
+    // rowmap != NULL (round 5, prcnn_rcnn_point_mlp_rows): tile t = the rows rowmap[64 t .. 64 t + 63] of `rows` / `p_out` -- the
+    // DISTINCT pooled rows of all RoIs back to back (prcnn_pooled_rows), ntiles_dev[1] of them; the last tile's missing entries repeat
+    // the list's last row (computed and stored again: the same values to the same place).  With whole 64-row tiles per RoI
+    // (tilemap) a RoI's 47 distinct rows of 512 filled a tile of 64; per row the arithmetic does not depend on the tile: same bits.
+    long nrows = 0;
+    if (rowmap) { nrows = (long)ntiles_dev[1]; tiles = (nrows + PM_ROWS - 1) / PM_ROWS; }
+    else if (ntiles_dev) tiles = (long)*ntiles_dev;
     __shared__ float T0[PM_ROWS * PM_LD];
     __shared__ float T1[PM_ROWS * PM_LD];
     __shared__ unsigned int slot[2];
@@ -199,15 +205,22 @@ __global__ __launch_bounds__(256, 2) void rcnn_entrance_kernel(
     float wa[64], wb[64];
     f32x16 acc0, acc1;
     RT_LOAD_W(wa, rs_u2, 0)
+    int ridx[8], nidx[8];                                      // this thread's 8 rows of the running tile / of the next one
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ridx[i] = (rowmap && t < tiles) ? rowmap[min(t * PM_ROWS + r0 + 8 * i, nrows - 1)] : 0;
     for (unsigned int served = 0; t < tiles; ++served) {
-        const long tt = tilemap ? (long)tilemap[t] : t;
+        if (!rowmap) {
+            const long tt = tilemap ? (long)tilemap[t] : t;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ridx[i] = (int)(tt * PM_ROWS + r0 + 8 * i);
+        }
         // ---- builder: layer 1 of xyz_up from the 5 input columns -> T0, the row's RPN features -> T1
         {
             float4 q[8], f[8];
             float d[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float *row = rows + (tt * PM_ROWS + r0 + 8 * i) * (long)ld;
+                const float *row = rows + (long)ridx[i] * (long)ld;
                 q[i] = *reinterpret_cast<const float4 *>(row);
                 d[i] = row[4];
                 f[i] = *reinterpret_cast<const float4 *>(row + fcol + 4 * chunk);
@@ -223,6 +236,11 @@ __global__ __launch_bounds__(256, 2) void rcnn_entrance_kernel(
         }
         RT_VM_DRAIN                                            // (also: this tile's first panel, fetched during the last stage)
         lds_barrier();
+        if (rowmap) {                                          // the next tile's row numbers: in flight behind the first stage
+            const long tq = (long)__builtin_amdgcn_readfirstlane((int)slot[(served + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) nidx[i] = tq < tiles ? rowmap[min(tq * PM_ROWS + r0 + 8 * i, nrows - 1)] : 0;
+        }
         // ---- xyz_up layer 2 (wa) while merge panel a (wb) comes in
         RT_STAGE(T0, wa, wb, rs_m, 0, true)
         lds_barrier();                                         // every wave has read the layer-1 rows
@@ -244,11 +262,15 @@ __global__ __launch_bounds__(256, 2) void rcnn_entrance_kernel(
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = r0 + 8 * i;
-            *reinterpret_cast<f32x4 *>(p_out + (tt * PM_ROWS + row) * PM_C + 4 * chunk) = *reinterpret_cast<const f32x4 *>(T1 + row * PM_LD + 4 * chunk);
+            *reinterpret_cast<f32x4 *>(p_out + (long)ridx[i] * PM_C + 4 * chunk) = *reinterpret_cast<const f32x4 *>(T1 + row * PM_LD + 4 * chunk);
         }
         const long tn = __builtin_amdgcn_readfirstlane((int)slot[(served + 1) & 1]);
         lds_barrier();                                         // T1 is free for the next builder
         t = tn;
+        if (rowmap) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ridx[i] = nidx[i];
+        }
     }
     if (tid == 0) ticket_release(ticket);          // the launch's last workgroup zeroes the counter for the word's next user
 }
@@ -281,6 +303,21 @@ __global__ __launch_bounds__(1024) void pooled_tiles_kernel(int clouds, int rows
         __syncthreads();
     }
     if (tid == 0) hdr[0] = (unsigned int)s_run;
+}
+
+// cnt[c] distinct rows of cloud c -> the list of those rows (row c * rows_per_cloud + j, j < max(cnt[c], 1)) of ALL clouds back to back:
+// rowmap[0 .. hdr[1]).  A wave per cloud draws its block from the list's row counter hdr[1] (zero on entry): the order of the clouds in
+// the list is the counter's, every row of the input is computed on its own.
+__global__ __launch_bounds__(256) void pooled_rows_kernel(int clouds, int rows_per_cloud, const int *__restrict__ cnt, int *__restrict__ rowmap,
+                                                          unsigned int *__restrict__ hdr)
+{
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= clouds) return;
+    const int n = min(max(cnt[c], 1), rows_per_cloud);
+    int base = 0;
+    if (lane == 0) base = (int)atomicAdd(&hdr[1], (unsigned int)n);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (int j = lane; j < n; j += 64) rowmap[base + j] = c * rows_per_cloud + j;
 }
 
 }  // namespace prcnn
@@ -316,7 +353,7 @@ extern "C" int prcnn_rcnn_point_mlp(long r, int ld, int fcol, const float *rows,
         if (!tk) { set_error("rcnn_point_mlp: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
         const long grid = tiles < mfma_grid_cap() ? tiles : mfma_grid_cap();
         hipLaunchKernelGGL(rcnn_entrance_kernel, dim3((unsigned)grid), dim3(256), 0, st, tiles, rows, ld, fcol, (const float4 *)wu1,
-                           (const float4 *)bu1, wu2, bu2, wm, bm, wp, bp, p, tk, tilemap, ntiles);
+                           (const float4 *)bu1, wu2, bu2, wm, bm, wp, bp, p, tk, tilemap, ntiles, nullptr);
         return check_launch("rcnn_point_mlp(fused)");
     }
     // one generation of workgroups when the launch is short (tiles / slots per workgroup, tickets balance the rest);
@@ -371,6 +408,42 @@ extern "C" int prcnn_rows_gemm128(long r, int npanel, const float *src0, int ld0
     return check_launch("rows_gemm128");
 }
 
+
+// The fused entrance chain (only p) over a LIST of rows: rowmap[0 .. hdr[1]) from prcnn_pooled_rows -- tiles of 64 list entries, whichever
+// RoIs they belong to.  p rows that are not listed are left as they are.
+extern "C" int prcnn_rcnn_point_mlp_rows(long r, int ld, int fcol, const float *rows, const float *wu1, const float *bu1,
+                                         const float *wu2, const float *bu2, const float *wm, const float *bm, const float *wp,
+                                         const float *bp, float *p, const int *rowmap, const unsigned int *hdr, void *stream)
+{
+    PRCNN_REQUIRE(r >= 0 && r % PM_ROWS == 0 && r <= 0x7fffffffL, "rcnn_point_mlp_rows: %ld rows is not a multiple of %d", r, PM_ROWS);
+    PRCNN_REQUIRE(ld >= 8 && ld % 4 == 0 && fcol >= 8 && fcol % 4 == 0 && fcol + PM_C <= ld,
+                  "rcnn_point_mlp_rows: bad row layout ld=%d fcol=%d", ld, fcol);
+    if (r == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(rows && wu1 && bu1 && wu2 && bu2 && wm && bm && wp && bp && p && rowmap && hdr, "rcnn_point_mlp_rows: null pointer");
+    PRCNN_REQUIRE((((uintptr_t)rows | (uintptr_t)wu1 | (uintptr_t)bu1 | (uintptr_t)p | (uintptr_t)wu2 | (uintptr_t)wm | (uintptr_t)wp) & 15) == 0,
+                  "rcnn_point_mlp_rows: 16-byte alignment required");
+    hipStream_t st = (hipStream_t)stream;
+    const long tiles = r / PM_ROWS;                            // at most: the list is on the device
+    unsigned int *tk = next_ticket(st);
+    if (!tk) { set_error("rcnn_point_mlp_rows: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
+    const long grid = tiles < mfma_grid_cap() ? tiles : mfma_grid_cap();
+    hipLaunchKernelGGL(rcnn_entrance_kernel, dim3((unsigned)grid), dim3(256), 0, st, tiles, rows, ld, fcol, (const float4 *)wu1,
+                       (const float4 *)bu1, wu2, bu2, wm, bm, wp, bp, p, tk, nullptr, hdr, rowmap);
+    return check_launch("rcnn_point_mlp_rows");
+}
+
+// cnt (clouds) i32 -> rowmap (clouds * rows_per_cloud entries at most), hdr[1] = number of listed rows (hdr (4 u32) zeroed here unless
+// hdr_is_zero): the distinct pooled rows of all clouds back to back, for prcnn_rcnn_point_mlp_rows.
+extern "C" int prcnn_pooled_rows(int clouds, int rows_per_cloud, const int *cnt, int *rowmap, unsigned int *hdr, int hdr_is_zero, void *stream)
+{
+    PRCNN_REQUIRE(clouds >= 0 && rows_per_cloud > 0 && (long)clouds * rows_per_cloud <= 0x7fffffffL, "pooled_rows: bad sizes");
+    PRCNN_REQUIRE(hdr && (clouds == 0 || (cnt && rowmap)), "pooled_rows: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (!hdr_is_zero && hipMemsetAsync(hdr, 0, 4 * sizeof(unsigned int), st) != hipSuccess) { set_error("pooled_rows: memset failed"); return PRCNN_ELAUNCH; }
+    if (clouds == 0) return PRCNN_OK;
+    hipLaunchKernelGGL(pooled_rows_kernel, dim3((clouds + 3) / 4), dim3(256), 0, st, clouds, rows_per_cloud, cnt, rowmap, hdr);
+    return check_launch("pooled_rows");
+}
 
 // cnt (clouds) i32 distinct rows per cloud of rows_per_cloud rows (prcnn_roipool3d_canonical's pooled_cnt) -> tilemap
 // (clouds * rows_per_cloud / 64 entries at most) and hdr[0] = number of live 64-row tiles, for prcnn_rcnn_point_mlp.

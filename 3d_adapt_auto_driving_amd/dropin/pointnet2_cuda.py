@@ -684,6 +684,35 @@ def pooled_tiles_wrapper(cnt, rows_per_cloud):
     return tilemap, hdr
 
 
+def pooled_rows_wrapper(cnt, rows_per_cloud, hdr=None):
+    """cnt (clouds) i32 distinct rows per pooled cloud -> (rowmap i32, hdr i32[4]): those rows of ALL clouds back to back, hdr[1] of
+    them (prcnn_pooled_rows), for rcnn_point_mlp_rows_wrapper.  hdr (4) i32, optional: a header that IS ZERO already."""
+    _chk(torch.int32, cnt)
+    clouds = cnt.numel()
+    rowmap = torch.empty((max(1, clouds * rows_per_cloud),), dtype=torch.int32, device=cnt.device)
+    zero = hdr is not None
+    if zero:
+        _chk(torch.int32, hdr)
+        if hdr.numel() != 4:
+            raise ValueError("pooled_rows: hdr must hold 4 int32")
+    else:
+        hdr = torch.empty((4,), dtype=torch.int32, device=cnt.device)
+    _lib.call("prcnn_pooled_rows", clouds, rows_per_cloud, cnt.data_ptr(), rowmap.data_ptr(), hdr.data_ptr(), int(zero), _lib.current_stream(cnt))
+    return rowmap, hdr
+
+
+def rcnn_point_mlp_rows_wrapper(rows, fcol, wu1, bu1, wu2, bu2, wm, bm, wp, bp, p, rowlist):
+    """rcnn_point_mlp_wrapper's fused form (only p) over the row list of pooled_rows_wrapper: p[r] for the listed rows r, the others are
+    left as they are (prcnn_rcnn_point_mlp_rows)."""
+    _chk(torch.float32, rows, wu1, bu1, wu2, bu2, wm, bm, wp, bp, p)
+    rowmap, hdr = rowlist
+    _chk(torch.int32, rowmap, hdr)
+    _lib.call("prcnn_rcnn_point_mlp_rows", rows.size(0), rows.size(1), int(fcol), rows.data_ptr(), wu1.data_ptr(), bu1.data_ptr(),
+              wu2.data_ptr(), bu2.data_ptr(), wm.data_ptr(), bm.data_ptr(), wp.data_ptr(), bp.data_ptr(), p.data_ptr(),
+              rowmap.data_ptr(), hdr.data_ptr(), _lib.current_stream(rows))
+    return p
+
+
 def sa_xyz_mlp_packed_wrapper(new_xyz, xyz, pack, w1, b1, w2, b2, w3, b3, out, out_col, zeroed=False):
     """sa_xyz_mlp_wrapper over the distinct rows of the level's index tensor (BallPack) -- bit-identical results."""
     _chk(torch.float32, w1, b1, w2, b2, w3, b3, out)

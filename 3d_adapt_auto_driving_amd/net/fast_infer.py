@@ -48,6 +48,7 @@ USE_CENTRE_SKIP = os.environ.get("PRCNN_NO_CENTRE_SKIP") is None       # ... and
 # the six separate launches (A/B, same results)
 USE_ROI_GEOMETRY = os.environ.get("PRCNN_NO_ROI_GEOMETRY") is None
 USE_ROI_PACKS = os.environ.get("PRCNN_NO_ROI_PACKS") is None      # ... and their distinct-row lists out of the same launch (round 5)
+USE_POOLED_ROWS = os.environ.get("PRCNN_NO_POOLED_ROWS") is None  # the RCNN entrance over the list of distinct pooled rows, not whole tiles per RoI (round 5)
 USE_POINT_LAYER = os.environ.get("PRCNN_LIB_GEMM") is None     # per-point layers (FP modules, heads) on the own MFMA layer kernel
 # every per-point width zero-padded to a multiple of 128 (SA level outputs, FP inputs, narrow head outputs), so that NO layer
 # of the engine is left to a GEMM library: fixed summation order everywhere, reproduced bit for bit by the oracle
@@ -1068,12 +1069,14 @@ class FastPointRCNN:
             a[:, :nin] = rows[:, :nin]
             rpn_part = rows[:, nin:]
         point_mlp = bool(USE_RCNN_POINT_MLP and W == 136 and rows.shape[0] % 64 == 0 and self._point_mlp_ok())
-        tiles = ext.pooled_tiles_wrapper(pooled_cnt.view(-1), P) if (point_mlp and pooled_cnt is not None) else None
+        use_rows = bool(point_mlp and pooled_cnt is not None and USE_POOLED_ROWS and has_entry(ext, "pooled_rows_wrapper"))
+        tiles = ext.pooled_tiles_wrapper(pooled_cnt.view(-1), P) if (point_mlp and pooled_cnt is not None and not use_rows) else None
         cur_xyz = xyz_dense.view(B * M, P, 3) if xyz_dense is not None else flat[:, :, 0:3].contiguous()
         levels = []
         # one zero fill for this stage: the headers of its three row lists and the pooled outputs of its levels (see ZeroArena)
         zarena = ZeroArena(("rcnn", B, M, P, str(rows.device)), rows.device)
         zhdr = (lambda: (zarena.take((4,), torch.int32),)) if getattr(ext, "IS_HIP_EXTENSION", False) else (lambda: ())   # positional (7th) argument
+        rowlist = ext.pooled_rows_wrapper(pooled_cnt.view(-1), P, *zhdr()) if use_rows else None       # the distinct pooled rows of all RoIs, back to back
         # representative map of the CURRENT level's points (None: every point counts as distinct): which of them are exact copies
         # of one another.  Level 0: pooled point k >= count is a copy of k % count (`limit`); deeper: the centres the sampling
         # picked from copies of one source are copies of one another -- coordinates, ball and therefore features (dup_rep).
@@ -1180,7 +1183,7 @@ class FastPointRCNN:
             arena = {"zero": zarena, "parts": parts}
         zarena.done()
         return {"B": B, "M": M, "P": P, "W": W, "rows": rows, "a": a, "rpn_part": rpn_part, "pooled": pooled, "pooled_cnt": pooled_cnt,
-                "point_mlp": point_mlp, "tiles": tiles, "levels": levels, "arena": arena, "arena_shapes": shapes}
+                "point_mlp": point_mlp, "tiles": tiles, "rowlist": rowlist, "levels": levels, "arena": arena, "arena_shapes": shapes}
 
     def _rcnn_features(self, rg):
         """The MLPs of the RCNN stage over the rows and row lists of `_rcnn_geometry`: xyz_up + merge_down + SA levels + heads."""
@@ -1195,7 +1198,10 @@ class FastPointRCNN:
             (wm, bm, _), = self.merge_down.layers
             wf, _, b1 = sa1[3].split
             P_pre = torch.empty((rows.shape[0], 128), dtype=torch.float32, device=rows.device)
-            ext.rcnn_point_mlp_wrapper(rows, 8, wu1, bu1, wu2, bu2, wm, bm, wf, b1, None, None, P_pre, rg["tiles"])   # only P is needed
+            if rg.get("rowlist") is not None:
+                ext.rcnn_point_mlp_rows_wrapper(rows, 8, wu1, bu1, wu2, bu2, wm, bm, wf, b1, P_pre, rg["rowlist"])     # only P, only the distinct rows
+            else:
+                ext.rcnn_point_mlp_wrapper(rows, 8, wu1, bu1, wu2, bu2, wm, bm, wf, b1, None, None, P_pre, rg["tiles"])   # only P is needed
             P_pre = P_pre.view(B * M, P, 128)
             l_feat = [None]
         else:

@@ -377,6 +377,15 @@ int prcnn_rcnn_point_mlp(long r, int ld, int fcol, const float *rows, const floa
                          const float *bp, float *xfeat, float *merged, float *p, const int *tilemap,
                          const unsigned int *ntiles, void *stream);
 int prcnn_pooled_tiles(int clouds, int rows_per_cloud, const int *cnt, int *tilemap, unsigned int *hdr, void *stream);
+/* The same chain (only p) over a LIST of rows instead of whole tiles (round 5): prcnn_pooled_rows lists the distinct pooled rows of all
+ * clouds back to back -- rowmap[0 .. hdr[1]), row c * rows_per_cloud + j for j < max(cnt[c], 1), the clouds in the order a device counter
+ * hands out; hdr (4 u32) is zeroed by the call unless hdr_is_zero -- and prcnn_rcnn_point_mlp_rows computes p for exactly those rows,
+ * 64 list entries per tile whichever RoIs they belong to (a RoI's 47 distinct rows no longer fill a tile of 64).  p rows that are not
+ * listed are left as they are.  Per row the arithmetic is prcnn_rcnn_point_mlp's: same bits. */
+int prcnn_pooled_rows(int clouds, int rows_per_cloud, const int *cnt, int *rowmap, unsigned int *hdr, int hdr_is_zero, void *stream);
+int prcnn_rcnn_point_mlp_rows(long r, int ld, int fcol, const float *rows, const float *wu1, const float *bu1,
+                              const float *wu2, const float *bu2, const float *wm, const float *bm, const float *wp,
+                              const float *bp, float *p, const int *rowmap, const unsigned int *hdr, void *stream);
 
 /* One 128-wide shared-MLP / Conv1d layer (pytorch_utils.py:35-101 with BN folded) on the same tiled MFMA kernel:
  * out (r,128) = act(A0 w[0:128] [+ A1 w[128:256]] + bias), r % 64 == 0; A0 = src0 rows (128 floats at column col0, row

@@ -422,6 +422,14 @@ class pointnet2_cpu:
         return None                                  # the CPU stand-in evaluates every row
 
     @staticmethod
+    def pooled_rows_wrapper(cnt, rows_per_cloud, hdr=None):
+        return None                                  # the CPU stand-in evaluates every row
+
+    @staticmethod
+    def rcnn_point_mlp_rows_wrapper(rows, fcol, wu1, bu1, wu2, bu2, wm, bm, wp, bp, p, rowlist):
+        return pointnet2_cpu.rcnn_point_mlp_wrapper(rows, fcol, wu1, bu1, wu2, bu2, wm, bm, wp, bp, None, None, p)
+
+    @staticmethod
     def sa_xyz_mlp_packed_wrapper(new_xyz, xyz, pack, w1, b1, w2, b2, w3, b3, out, out_col, zeroed=False):
         return pointnet2_cpu.sa_xyz_mlp_wrapper(new_xyz, xyz, pack.idx, w1, b1, w2, b2, w3, b3, out, out_col)
 

@@ -1031,6 +1031,18 @@ def test_rcnn_point_mlp_kernels(ext):
     live[tiles[0][:int(tiles[1][0])].long()] = True
     rows_live = live.repeat_interleave(64)
     assert torch.equal(p2[rows_live], outs[0][1][rows_live]) and torch.isnan(p2[~rows_live]).all() and 0 < int(live.sum()) < R // 64
+    # ... and over the LIST of distinct rows (prcnn_pooled_rows / prcnn_rcnn_point_mlp_rows): exactly the first max(cnt, 1) rows of every
+    # cloud are computed, the same bits, whichever tile of the list a row falls into; with a header zeroed by the caller as well
+    for hdr in (None, torch.zeros(4, dtype=torch.int32, device=DEV)):
+        rowlist = ext.pointnet2.pooled_rows_wrapper(cnt, 512, *(() if hdr is None else (hdr,)))
+        n = int(rowlist[1][1])
+        want_rows = torch.cat([torch.arange(max(int(c), 1)) + 512 * i for i, c in enumerate(cnt.cpu())])
+        assert n == len(want_rows) and torch.equal(torch.sort(rowlist[0][:n].cpu().long())[0], want_rows)
+        p3 = torch.full((R, 128), float("nan"), device=DEV)
+        ext.pointnet2.rcnn_point_mlp_rows_wrapper(trow, 8, wu1, bu1, wu2, bu2, wm, bm, wp, bp, p3, rowlist)
+        listed = torch.zeros(R, dtype=torch.bool, device=DEV)
+        listed[want_rows.to(DEV)] = True
+        assert torch.equal(p3[listed], outs[0][1][listed]) and torch.isnan(p3[~listed]).all()
 
 
 @pytest.mark.parametrize("K,relu", [(128, True), (128, False), (256, True), (256, False)])

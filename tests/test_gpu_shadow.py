@@ -308,6 +308,22 @@ def check_rcnn_point_mlp(self, name, args, host, ret):
 POINTNET2["rcnn_point_mlp_wrapper"] = check_rcnn_point_mlp
 
 
+def check_rcnn_point_mlp_rows(self, name, args, host, ret):
+    """the entrance chain over the list of distinct pooled rows: the listed rows == the oracle's rows, bit for bit; the list holds the
+    first max(count, 1) rows of every RoI exactly once (the counts are what the RoI pooling handed over: checked there)"""
+    self._cpu.rcnn_point_mlp_rows_wrapper(*host[:11], None)
+    rowmap, hdr = args[11]
+    n = int(hdr[1])
+    listed = rowmap[:n].cpu().long()
+    assert len(torch.unique(listed)) == n
+    got, want = args[10].detach().cpu(), host[10]
+    assert torch.equal(got[listed], want[listed]), name
+    self._log["live_rows_fraction_x1000"] = int(1000 * n / host[0].shape[0])
+
+
+POINTNET2["rcnn_point_mlp_rows_wrapper"] = check_rcnn_point_mlp_rows
+
+
 def check_packed_segmax(self, name, args, host, ret):
     """last layer + pool: the oracle evaluates the layer on the GPU's packed rows and pools them by centre"""
     a, wt, bias, _, b, m, _, out_col = host[:8]
@@ -438,7 +454,7 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
                   "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 2 if (F.USE_SCALE_BATCH and F.USE_SA2_BATCH) else 4, "sa_packed_mlp_batch_wrapper": 1 if (F.USE_SCALE_BATCH and F.USE_SA2_BATCH) else 0,
                   "three_interpolate_cat_pm_wrapper": 0 if F.USE_FP_LINEAR else 3, "packed_layer_interp_wrapper": 3 if F.USE_FP_LINEAR else 0,
                   "rpn_tail_wrapper": 0 if F.USE_FP_LINEAR else 1, "rpn_tail_lin_wrapper": 1 if F.USE_FP_LINEAR and not F.USE_TAIL_DECODE else 0,
-                  "rpn_tail_lin_boxes_wrapper": 1 if F.USE_FP_LINEAR and F.USE_TAIL_DECODE else 0, "rcnn_point_mlp_wrapper": 1, "forward_canonical": 1}
+                  "rpn_tail_lin_boxes_wrapper": 1 if F.USE_FP_LINEAR and F.USE_TAIL_DECODE else 0, "rcnn_point_mlp_wrapper": 0 if F.USE_POOLED_ROWS else 1, "rcnn_point_mlp_rows_wrapper": 1 if F.USE_POOLED_ROWS else 0, "forward_canonical": 1}
     want_calls.update({"packed_layer_segmax_batch_wrapper": 2, "packed_gather_affine_batch_wrapper": 2, "packed_layer_batch_wrapper": 6 if (F.USE_SCALE_BATCH and F.USE_SA2_BATCH) else 5})   # RPN SA3, SA4; the two branches of the RCNN head (round 4); RPN SA2's per-point parts (round 5)
     if wide_fused:       # the RCNN's GroupAll level (every row distinct: 800 units of work) in one kernel
         f3 = 1 if F.USE_WIDE_FUSED3 else 0   # ... and its per-point layer inside that kernel (csrc/sa_wide3.hip)
