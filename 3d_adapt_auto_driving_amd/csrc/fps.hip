@@ -1479,6 +1479,7 @@ __device__ __forceinline__ void roi_rows_out(int ns, const unsigned short *__res
 struct RgPacks {
     unsigned int *rowinfo1; float4 *rowdxyz1; int *tilecloud1; unsigned int *hdr1;
     unsigned int *rowinfo2; float4 *rowdxyz2; int *tilecloud2; unsigned int *hdr2;
+    unsigned int *rowinfo3; float4 *rowdxyz3; unsigned int *hdr3;    // optional third list (rows carry their cloud): see the kernel's end
     // tilecloud* == NULL: the lists' rows carry their cloud -- descriptor (cloud << 16) | (centre << 9) | point -- and are drawn from the
     // list's ROW counter hdr[1], so that tiles are cut wherever the rows fall (csrc/sa_packed.hip reads such a list when it is given no
     // tilecloud): no padded last tile per cloud
@@ -1669,6 +1670,21 @@ __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
         roi_pack_out<RG_M2>(b, r2own == lane ? max(cntd2, 1) : 0, 0, cntd2, 0, s_hits, RG_LD2, s_first, cloud, s_sel1, s_sel1, s_sel2,
                             pk.rowinfo2, pk.rowdxyz2, pk.tilecloud2, pk.hdr2, lane);
     }
+    // the list of the level ABOVE (rcnn_net.py's GroupAll module: one group of all 32 centres, no centre subtraction): a row per centre of
+    // level 2 that is its own representative -- what prcnn_ball_pack_ex makes of the index rows 0 .. 31 around the origin with rep = rep2,
+    // every cloud a list of its own centre 0
+    if (pk.rowinfo3) {
+        const unsigned long long own = __ballot(has && r2own == lane);
+        const int n3 = __builtin_popcountll(own);
+        int base = 0;
+        if (lane == 0) base = (int)atomicAdd(&pk.hdr3[1], (unsigned int)n3);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (has && r2own == lane) {
+            const int r = base + (int)__builtin_popcountll(own & ((1ull << lane) - 1ull));
+            pk.rowinfo3[r] = ((unsigned int)b << 16) | (unsigned int)lane;
+            pk.rowdxyz3[r] = make_float4(cx[0] - 0.f, cy[0] - 0.f, cz[0] - 0.f, 0.f);
+        }
+    }
 }
 
 }  // namespace prcnn
@@ -1719,23 +1735,30 @@ extern "C" int prcnn_rcnn_roi_geometry(int b, int n, int m1, float r1, int ns1, 
  * counter hands out, as it is for prcnn_ball_pack).  rowinfo* / rowdxyz* / tilecloud*: sized as for prcnn_ball_pack
  * (b * ceil(m * ns / 64) tiles); hdr1 / hdr2 (4 u32 each): zeroed here unless hdr_is_zero.  tilecloud1 == tilecloud2 == NULL: lists
  * whose rows carry their cloud (see RgPacks; the form the engine uses: prcnn_sa_packed_mlp reads it).  idx1 == idx2 == NULL: the index tensors
- * are not written (a caller that feeds the row lists to the packed MLP kernels has no use for them: 10240 words per cloud). */
+ * are not written (a caller that feeds the row lists to the packed MLP kernels has no use for them: 10240 words per cloud).
+ * rowinfo3 / rowdxyz3 / hdr3 (optional, b * m2 rows at most): the list of the GroupAll level above -- every cloud one group (centre 0) of
+ * its m2 level-2 centres, the centres that copy an earlier one dropped: prcnn_ball_pack_ex(b, b, m2, 1, m2, {0..m2-1}, NULL, rep2, NULL,
+ * new_xyz2, origin, ...) in the row-carried form. */
 extern "C" int prcnn_rcnn_roi_geometry_packs(int b, int n, int m1, float r1, int ns1, int m2, float r2, int ns2, const float *xyz,
                                              const int *limit, float *new_xyz1, int *idx1, int *rep1, float *new_xyz2, int *idx2, int *rep2,
                                              unsigned int *rowinfo1, float *rowdxyz1, int *tilecloud1, unsigned int *hdr1,
-                                             unsigned int *rowinfo2, float *rowdxyz2, int *tilecloud2, unsigned int *hdr2, int hdr_is_zero,
-                                             void *stream)
+                                             unsigned int *rowinfo2, float *rowdxyz2, int *tilecloud2, unsigned int *hdr2,
+                                             unsigned int *rowinfo3, float *rowdxyz3, unsigned int *hdr3, int hdr_is_zero, void *stream)
 {
     PRCNN_REQUIRE(hdr1 && hdr2, "rcnn_roi_geometry_packs: null header");
+    PRCNN_REQUIRE((rowinfo3 != nullptr) == (rowdxyz3 != nullptr) && (rowinfo3 != nullptr) == (hdr3 != nullptr) && (!rowinfo3 || !tilecloud1),
+                  "rcnn_roi_geometry_packs: the third list comes whole, and only with lists whose rows carry their cloud");
     if (!hdr_is_zero && (hipMemsetAsync(hdr1, 0, 4 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess ||
-                         hipMemsetAsync(hdr2, 0, 4 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess)) {
+                         hipMemsetAsync(hdr2, 0, 4 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess ||
+                         (hdr3 && hipMemsetAsync(hdr3, 0, 4 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess))) {
         set_error("rcnn_roi_geometry_packs: memset failed");
         return PRCNN_ELAUNCH;
     }
     if (b == 0) return PRCNN_OK;
     PRCNN_REQUIRE(rowinfo1 && rowdxyz1 && rowinfo2 && rowdxyz2, "rcnn_roi_geometry_packs: null pointer");
     PRCNN_REQUIRE((tilecloud1 && tilecloud2) || (!tilecloud1 && !tilecloud2 && b <= 65536), "rcnn_roi_geometry_packs: both lists with a tilecloud or none");
-    PRCNN_REQUIRE((((uintptr_t)rowdxyz1 | (uintptr_t)rowdxyz2) & 15) == 0, "rcnn_roi_geometry_packs: rowdxyz must be 16-byte aligned");
-    const prcnn::RgPacks pk = {rowinfo1, (float4 *)rowdxyz1, tilecloud1, hdr1, rowinfo2, (float4 *)rowdxyz2, tilecloud2, hdr2};
+    PRCNN_REQUIRE((((uintptr_t)rowdxyz1 | (uintptr_t)rowdxyz2 | (uintptr_t)rowdxyz3) & 15) == 0, "rcnn_roi_geometry_packs: rowdxyz must be 16-byte aligned");
+    const prcnn::RgPacks pk = {rowinfo1, (float4 *)rowdxyz1, tilecloud1, hdr1, rowinfo2, (float4 *)rowdxyz2, tilecloud2, hdr2,
+                               rowinfo3, (float4 *)rowdxyz3, hdr3};
     return roi_geometry_any(b, n, m1, r1, ns1, m2, r2, ns2, xyz, limit, new_xyz1, idx1, rep1, new_xyz2, idx2, rep2, &pk, stream);
 }

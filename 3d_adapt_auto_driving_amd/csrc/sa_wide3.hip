@@ -60,7 +60,12 @@ __global__ __launch_bounds__(256, 2) void sa_wide3_kernel(const SaWide3Args a)
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chunk = tid & 31, r0 = tid >> 5;
-    const long units = 2L * (long)a.hdr[0];
+    // tilecloud == NULL (round 5): the rows carry their cloud -- descriptor (cloud << 16) | (centre << 9) | point, hdr[1] rows back to back
+    // (prcnn_rcnn_roi_geometry_packs' third list; see sa_packed_mlp128_kernel) -- and a unit is 32 consecutive rows of the list
+    const bool rowcloud = a.tilecloud == nullptr;
+    const long nrows = (long)a.hdr[1];
+    const long units = rowcloud ? (nrows + 31) >> 5 : 2L * (long)a.hdr[0];
+    const long last_row = rowcloud ? nrows - 1 : 0x7fffffffffffL;
     const int ns1 = kp0 * kp1, ns2 = kp1 * kp2, ns = ns1 + ns2 + kp2 * nb3;                       // (even)
     const unsigned int o2 = (unsigned int)(a.c0 * a.c1) * 4u, o3 = o2 + (unsigned int)(a.c1 * a.c2) * 4u;
     const unsigned int total = o3 + (unsigned int)(a.c2 * a.c3) * 4u;
@@ -100,23 +105,27 @@ __global__ __launch_bounds__(256, 2) void sa_wide3_kernel(const SaWide3Args a)
 
     for (unsigned int served = 0; u < units; ++served) {
         const long t = u >> 1;
-        const long row0 = t * 64 + 32 * (u & 1);
+        const long row0 = rowcloud ? u * 32 : t * 64 + 32 * (u & 1);
         // ---- builder: the unit's 32 feature rows, panel by panel (a copy: 4 rows x one 16-byte chunk per thread and panel)
         {
-            const int cloud = a.tilecloud[t];
-            const long pbase = (long)cloud * a.n;
+            const int cloud = rowcloud ? 0 : a.tilecloud[t];
             unsigned int info[4];
+            long prow[4];                                                 // the rows' points as rows of F
 #pragma unroll
-            for (int i = 0; i < 4; ++i) info[i] = a.rowinfo[row0 + r0 + 8 * i];
+            for (int i = 0; i < 4; ++i) {
+                info[i] = a.rowinfo[min(row0 + r0 + 8 * i, last_row)];
+                prow[i] = rowcloud ? (long)(info[i] >> 16) * a.n + (long)(info[i] & 0x1ffu) : (long)cloud * a.n + (long)(info[i] & 0xffffu);
+            }
             if (tid == 0) slot[(served + 1) & 1] = atomicAdd(a.ticket, 1u);
             if (tid < SW_R) {
-                ctr[tid] = cloud * a.m + (int)(a.rowinfo[row0 + tid] >> 16);
-                s_d[tid] = a.rowdxyz[row0 + tid];
+                const unsigned int wd = a.rowinfo[min(row0 + tid, last_row)];
+                ctr[tid] = rowcloud ? (int)(wd >> 16) * a.m + (int)((wd >> 9) & 0x7fu) : cloud * a.m + (int)(wd >> 16);
+                s_d[tid] = a.rowdxyz[min(row0 + tid, last_row)];
             }
             for (int pc = 0; pc < kp0; ++pc) {
                 float4 v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = F4[(pbase + (long)(info[i] & 0xffffu)) * q0 + pc * 32 + chunk];
+                for (int i = 0; i < 4; ++i) v[i] = F4[prow[i] * q0 + pc * 32 + chunk];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(X + pc * SW_PANEL + (r0 + 8 * i) * SW_LD + 4 * chunk) = v[i];
             }
@@ -207,7 +216,9 @@ extern "C" int prcnn_sa_wide_fused3(int b, int n, int m, int c0, int c1, int c2,
     PRCNN_REQUIRE(n <= 65536 && m <= 65536, "sa_wide_fused3: cloud too large for the 16-bit row descriptors");
     PRCNN_REQUIRE(out_stride >= out_col + c3 && out_col >= 0, "sa_wide_fused3: bad output slice");
     if ((long)b * m == 0) return PRCNN_OK;
-    PRCNN_REQUIRE(F && wxyz && rowinfo && rowdxyz && tilecloud && hdr && wcat && b1 && b2 && b3 && out, "sa_wide_fused3: null pointer");
+    PRCNN_REQUIRE(F && wxyz && rowinfo && rowdxyz && hdr && wcat && b1 && b2 && b3 && out, "sa_wide_fused3: null pointer");
+    // tilecloud == NULL: the rows carry their cloud (descriptor (cloud << 16) | (centre << 9) | point; prcnn_rcnn_roi_geometry_packs)
+    PRCNN_REQUIRE(tilecloud || (n <= 512 && m <= 128 && b <= 65536), "sa_wide_fused3: a list without tilecloud holds clouds of <= 512 points, <= 128 centres");
     PRCNN_REQUIRE((((uintptr_t)F | (uintptr_t)wcat | (uintptr_t)rowdxyz) & 15) == 0, "sa_wide_fused3: 16-byte alignment required");
     hipStream_t st = (hipStream_t)stream;
     if (!out_is_zero && hipMemset2DAsync(out + out_col, (size_t)out_stride * sizeof(float), 0, (size_t)c3 * sizeof(float), (size_t)b * m, st) != hipSuccess) {

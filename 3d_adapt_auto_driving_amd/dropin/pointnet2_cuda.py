@@ -321,7 +321,8 @@ def rcnn_roi_geometry_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2):
     return new1, idx1, rep1, new2, idx2, rep2
 
 
-def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=None, hdr2=None, want_idx=True, row_clouds=False):
+def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=None, hdr2=None, want_idx=True, row_clouds=False, hdr3=None,
+                                    group_all=False):
     """rcnn_roi_geometry_wrapper + the two levels' distinct-row lists out of the same launch (prcnn_rcnn_roi_geometry_packs) ->
     (new_xyz1, idx1, rep1, new_xyz2, idx2, rep2, pack1, pack2): pack1 == ball_pack_wrapper(idx1, xyz, new_xyz1, limit, None, rep1),
     pack2 == ball_pack_wrapper(idx2, new_xyz1, new_xyz2, None, rep1, rep2) -- the same rows per cloud, the same tiles.
@@ -329,7 +330,9 @@ def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=N
     not written -- what comes back in their place (and in the packs' .idx) are tensors of the right SHAPE without storage behind it
     (stride 0): the packed MLP wrappers only ask them for their shape.  row_clouds=True: the lists in the form whose ROWS carry their
     cloud (packs with .tilecloud None: rows of all clouds back to back, no padded last tile per cloud) -- sa_packed_mlp_wrapper takes
-    them, the other consumers of a BallPack do not."""
+    them, the other consumers of a BallPack do not.  group_all=True (with row_clouds; hdr3 as hdr1 / hdr2): a ninth value, the list of the
+    GroupAll level above -- every cloud ONE group of its m2 level-2 centres, the copies among them dropped: the BallPack of the index
+    tensor (b, 1, m2) = 0 .. m2-1 around the origin with rep = rep2 (sa_wide_fused3_wrapper takes it, with new_xyz = zeros (b, 1, 3))."""
     _chk(torch.float32, xyz); _chk(torch.int32, limit)
     b, n, _ = xyz.shape
     dev = xyz.device
@@ -362,12 +365,27 @@ def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=N
         pk.hdr = hdr if hdr is not None else torch.empty((4,), dtype=torch.int32, device=dev)
         packs.append(pk)
     p1, p2 = packs
+    p3 = None
+    if group_all:
+        if not row_clouds or (hdr3 is None) != (hdr1 is None):
+            raise ValueError("rcnn_roi_geometry_packs: the GroupAll list comes in the row-carried form, its header like the others")
+        p3 = BallPack()
+        p3.idx = torch.arange(m2, dtype=torch.int32, device=dev).view(1, 1, m2).expand(b, 1, m2)
+        p3.limit, p3.rep, p3.crep = None, rep2, None
+        p3.rowinfo = torch.empty((b * m2,), dtype=torch.int32, device=dev)
+        p3.rowdxyz = torch.empty((b * m2, 4), dtype=torch.float32, device=dev)
+        p3.tilecloud = None
+        p3.max_tiles = (b * m2 + 63) // 64
+        if hdr3 is not None:
+            _chk(torch.int32, hdr3)
+        p3.hdr = hdr3 if hdr3 is not None else torch.empty((4,), dtype=torch.int32, device=dev)
     _lib.call("prcnn_rcnn_roi_geometry_packs", b, n, m1, float(r1), ns1, m2, float(r2), ns2, xyz.data_ptr(), limit.data_ptr(), new1.data_ptr(),
               idx1.data_ptr() if want_idx else None, rep1.data_ptr(), new2.data_ptr(), idx2.data_ptr() if want_idx else None, rep2.data_ptr(),
               p1.rowinfo.data_ptr(), p1.rowdxyz.data_ptr(), _lib.ptr(p1.tilecloud), p1.hdr.data_ptr(),
-              p2.rowinfo.data_ptr(), p2.rowdxyz.data_ptr(), _lib.ptr(p2.tilecloud), p2.hdr.data_ptr(), 1 if hdr1 is not None else 0,
-              _lib.current_stream(xyz))
-    return new1, idx1, rep1, new2, idx2, rep2, p1, p2
+              p2.rowinfo.data_ptr(), p2.rowdxyz.data_ptr(), _lib.ptr(p2.tilecloud), p2.hdr.data_ptr(),
+              None if p3 is None else p3.rowinfo.data_ptr(), None if p3 is None else p3.rowdxyz.data_ptr(),
+              None if p3 is None else p3.hdr.data_ptr(), 1 if hdr1 is not None else 0, _lib.current_stream(xyz))
+    return (new1, idx1, rep1, new2, idx2, rep2, p1, p2) + ((p3,) if p3 is not None else ())
 
 
 def dup_rep_wrapper(sel, n, limit=None, prev=None):
@@ -527,7 +545,7 @@ def sa_wide_fused3_wrapper(new_xyz, xyz, feats, wcat, b1, wxyz, pack, b2, b3, wi
     if c0 != c0w or wcat.numel() != c0 * c1 + c1 * c2 + c2 * c3 or wxyz.size(1) != c1 or b1.numel() != c1 or b2.numel() != c2 or b3.numel() != c3:
         raise RuntimeError("pointnet2_cuda: sa_wide_fused3 shape mismatch")
     _lib.call("prcnn_sa_wide_fused3", b, n, new_xyz.size(1), c0, c1, c2, c3, pack.max_tiles, feats.data_ptr(), wxyz.data_ptr(),
-              pack.rowinfo.data_ptr(), pack.rowdxyz.data_ptr(), pack.tilecloud.data_ptr(), pack.hdr.data_ptr(), wcat.data_ptr(),
+              pack.rowinfo.data_ptr(), pack.rowdxyz.data_ptr(), _lib.ptr(pack.tilecloud), pack.hdr.data_ptr(), wcat.data_ptr(),
               b1.data_ptr(), b2.data_ptr(), b3.data_ptr(), out.data_ptr(), out.size(-1), out_col, int(bool(zeroed)),
               _lib.current_stream(xyz))
     return out

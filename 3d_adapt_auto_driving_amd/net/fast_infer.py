@@ -1022,6 +1022,18 @@ class FastPointRCNN:
     def _rcnn(self, xyz, feats, seg_mask, pts_depth, rois, depth_norm=None, groups=None):
         return self._rcnn_features(self._rcnn_geometry(xyz, feats, seg_mask, pts_depth, rois, depth_norm=depth_norm, groups=groups))
 
+    @staticmethod
+    def _groupall_fused3_ok(mlp, below):
+        """the GroupAll level runs on csrc/sa_wide3.hip (the only consumer of a list whose rows carry their cloud at that level):
+        `_sa_scale`'s condition for that branch, known before the level's features exist (they are the level below's output)"""
+        ext = pu.pointnet2
+        if not (USE_PACKED and mlp.packed is None and mlp.wide is not None and USE_WIDE_FUSED and USE_WIDE_FUSED3
+                and has_entry(ext, "sa_wide_fused3_wrapper") and getattr(mlp, "wide_cat", None) is not None):
+            return False
+        wf, wx, b1, w2, b2, w3, b3 = mlp.wide
+        c_below = below.layers[-1][0].shape[1]
+        return bool(c_below == wf.shape[0] and ext.sa_wide_fused3_supported(wf.shape[0], wf.shape[1], w2.shape[1], w3.shape[1]))
+
     def _rcnn_geometry(self, xyz, feats, seg_mask, pts_depth, rois, depth_norm=None, groups=None):
         """Everything of the RCNN stage (rcnn_net.py:127-185) that needs no MLP result: RoI pooling into the canonical row layout,
         then per SA level sampling, ball query and the distinct-row lists.  All of it hangs on the RoIs and on coordinates only
@@ -1095,15 +1107,18 @@ class FastPointRCNN:
                 # (the index tensors themselves are not written on the HIP path: the packed kernels read the lists, `idx` is asked for its shape;
                 #  the lists' rows carry their cloud: no padded last tile per RoI cloud)
                 hd = zhdr() + zhdr()
+                rc = all(m_[3].packed is not None for m_ in sa[:2])        # the consumers that read lists whose rows carry their cloud
+                # ... and, in that form, the list of the GroupAll level above them (one group per RoI: no clouds merged to fill tiles)
+                ga = bool(rc and hd and len(sa) == 3 and sa[2][0] is None and self._groupall_fused3_ok(sa[2][3], sa[1][3]))
                 fused_geo = ext.rcnn_roi_geometry_packs_wrapper(cur_xyz, pooled_cnt.view(-1), sa[0][0], sa[0][1], sa[0][2], sa[1][0], sa[1][1],
-                                                                sa[1][2], *(hd + (False, all(m_[3].packed is not None for m_ in sa[:2])) if hd else ()))
+                                                                sa[1][2], *(hd + (False, rc) + ((zhdr()[0], True) if ga else ()) if hd else ()))
             else:
                 fused_geo = ext.rcnn_roi_geometry_wrapper(cur_xyz, pooled_cnt.view(-1), sa[0][0], sa[0][1], sa[0][2], sa[1][0], sa[1][1], sa[1][2])
         for k, (npoint, radius, ns, mlp, cin) in enumerate(self.rcnn_sa):
             lev = {"xyz": cur_xyz, "new_xyz": None, "idx": None, "pack": None}
             if npoint is not None and fused_geo is not None and k < 2:
                 new_xyz, idx, rep_out = fused_geo[3 * k:3 * k + 3]
-                if len(fused_geo) == 8:
+                if len(fused_geo) >= 8:
                     lev["pack"] = fused_geo[6 + k]
                 elif k == 0:
                     lev["pack"] = ext.ball_pack_wrapper(idx, cur_xyz, new_xyz, pooled_cnt.view(-1), None, rep_out, *zhdr())
@@ -1142,6 +1157,15 @@ class FastPointRCNN:
                                    else ext.ball_pack_wrapper(idx, cur_xyz, new_xyz))
                 lev["new_xyz"], lev["idx"] = new_xyz, idx
                 cur_xyz = new_xyz
+            elif fused_geo is not None and len(fused_geo) == 9:
+                # GroupAll over the list the fused launch wrote: every RoI one group (centre 0) of its own 32 centres
+                Bc, n = cur_xyz.shape[0], cur_xyz.shape[1]
+                cache = self.__dict__.setdefault("_groupall", {})
+                key = ("origin", Bc, str(cur_xyz.device))
+                if key not in cache:
+                    cache[key] = torch.zeros((Bc, 1, 3), dtype=torch.float32, device=cur_xyz.device)
+                lev.update({"new_xyz": cache[key], "idx": fused_geo[8].idx, "pack": fused_geo[8], "f": 1})
+                cur_xyz = None
             elif USE_PACKED and (mlp.packed is not None or mlp.wide is not None):
                 # GroupAll (pointnet2_utils.py:267-288): ONE group holding all n points, no centre subtraction == a ball
                 # query answer 0..n-1 around the origin; same packed kernels as the other levels

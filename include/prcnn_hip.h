@@ -237,12 +237,16 @@ int prcnn_rcnn_roi_geometry(int b, int n, int m1, float r1, int ns1, int m2, flo
  * tilecloud1 and tilecloud2 may both be NULL: the lists are then written in the form whose ROWS carry their cloud -- descriptor
  * (cloud << 16) | (centre << 9) | point, hdr[1] = rows, hdr[0] unused -- with every cloud's rows right behind another cloud's: tiles are
  * cut wherever the rows fall, no padded last tile per cloud.  prcnn_sa_packed_mlp takes such a list when IT is given tilecloud == NULL.
+ * rowinfo3 / rowdxyz3 / hdr3 (all three or none; only with the row-carried form): the list of the GroupAll level above the two sampled ones
+ * (rcnn_net.py:64-92, SA_CONFIG.NPOINTS[2] = -1: one group of all m2 centres, no centre subtraction) -- per cloud a row (centre 0, point j)
+ * for every level-2 centre j that is its own representative, relative coordinates = new_xyz2[j]: what
+ * prcnn_ball_pack_ex(b, b, m2, 1, m2, {0 .. m2-1}, NULL, rep2, NULL, new_xyz2, zeros, ...) lists; prcnn_sa_wide_fused3 reads it (tilecloud NULL).
  * The reference has no counterpart: it groups all nsample rows (pointnet2_utils.py:241-264); see prcnn_ball_pack. */
 int prcnn_rcnn_roi_geometry_packs(int b, int n, int m1, float r1, int ns1, int m2, float r2, int ns2, const float *xyz,
                                   const int *limit, float *new_xyz1, int *idx1, int *rep1, float *new_xyz2, int *idx2, int *rep2,
                                   unsigned int *rowinfo1, float *rowdxyz1, int *tilecloud1, unsigned int *hdr1,
-                                  unsigned int *rowinfo2, float *rowdxyz2, int *tilecloud2, unsigned int *hdr2, int hdr_is_zero,
-                                  void *stream);
+                                  unsigned int *rowinfo2, float *rowdxyz2, int *tilecloud2, unsigned int *hdr2,
+                                  unsigned int *rowinfo3, float *rowdxyz3, unsigned int *hdr3, int hdr_is_zero, void *stream);
 /* out_is_zero (this entry, prcnn_sa_xyz_mlp_packed, prcnn_packed_layer_segmax): the results arrive through atomicMax into a
  * zeroed slice; 0 = the entry zeroes out[..., out_col : out_col + width) itself, 1 = the caller has zeroed it (one fill for all
  * the scales of a level instead of one strided fill per scale). */

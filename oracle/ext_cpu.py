@@ -223,12 +223,18 @@ class pointnet2_cpu:
         return new1, idx1, rep1, new2, idx2, rep2
 
     @staticmethod
-    def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=None, hdr2=None, want_idx=True, row_clouds=False):
+    def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=None, hdr2=None, want_idx=True, row_clouds=False, hdr3=None,
+                                        group_all=False):
         """prcnn_rcnn_roi_geometry_packs as the chain of stand-ins it fuses: the geometry, then the two row lists"""
         P = pointnet2_cpu
         new1, idx1, rep1, new2, idx2, rep2 = P.rcnn_roi_geometry_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2)
-        return (new1, idx1, rep1, new2, idx2, rep2, P.ball_pack_wrapper(idx1, xyz, new1, limit, None, rep1),
-                P.ball_pack_wrapper(idx2, new1, new2, None, rep1, rep2))
+        out = (new1, idx1, rep1, new2, idx2, rep2, P.ball_pack_wrapper(idx1, xyz, new1, limit, None, rep1),
+               P.ball_pack_wrapper(idx2, new1, new2, None, rep1, rep2))
+        if group_all:       # every cloud one group of its m2 centres around the origin, the copies among them marked by rep2
+            b = xyz.shape[0]
+            ga = torch.arange(m2, dtype=torch.int32).view(1, 1, m2).expand(b, 1, m2).contiguous()
+            out += (P.ball_pack_wrapper(ga, new2, torch.zeros((b, 1, 3)), None, rep2, None),)
+        return out
 
     @staticmethod
     def dup_rep_wrapper(sel, n, limit=None, prev=None):

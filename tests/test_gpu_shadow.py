@@ -173,6 +173,12 @@ def check_roi_geometry_packs(self, name, args, host, ret):
         self._log["roi_idx_not_written"] += 1
     check_ball_pack(self, name, None, [idx1, host[0], new1, host[1], None, rep1], ret[6])
     check_ball_pack(self, name, None, [idx2, new1, new2, None, rep1, rep2], ret[7])
+    if len(ret) == 9:      # the GroupAll level's list: one group per RoI (all its level-2 centres around the origin), copies marked by rep2
+        b, m2 = rep2.shape
+        ga = torch.arange(m2, dtype=torch.int32).view(1, 1, m2).expand(b, 1, m2).contiguous()
+        assert torch.equal(ret[8].idx.cpu(), ga) and torch.equal(ret[8].rep.cpu(), rep2)
+        check_ball_pack(self, name, None, [ga, new2, torch.zeros((b, 1, 3)), None, rep2, None], ret[8])
+        self._log["group_all_list_fused"] += 1
 
 
 def check_dup_rep(self, name, args, host, ret):
@@ -450,7 +456,7 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
     fg = F.USE_ROI_GEOMETRY          # the RoI clouds' FPS / ball query / representative maps of both sampled levels in one launch
     fp = fg and F.USE_ROI_PACKS      # ... and their two row lists out of that launch
     want_calls = {"furthest_point_sampling_wrapper": 0, "fps_new_xyz_wrapper": 4 if fg else 6, "dup_rep_wrapper": 0 if fg else 2, "point_aux_wrapper": 1,
-                  "ball_query_full_wrapper": 8, "ball_query_wrapper": 0 if fg else 1, "ball_query_limit_wrapper": 0 if fg else 1, "rcnn_roi_geometry_wrapper": 1 if (fg and not fp) else 0, "rcnn_roi_geometry_packs_wrapper": 1 if fp else 0, "three_nn_wrapper": 0, "three_nn_weights_wrapper": 4, "ball_pack_wrapper": 9 if fp else 11,
+                  "ball_query_full_wrapper": 8, "ball_query_wrapper": 0 if fg else 1, "ball_query_limit_wrapper": 0 if fg else 1, "rcnn_roi_geometry_wrapper": 1 if (fg and not fp) else 0, "rcnn_roi_geometry_packs_wrapper": 1 if fp else 0, "three_nn_wrapper": 0, "three_nn_weights_wrapper": 4, "ball_pack_wrapper": (8 if log["group_all_list_fused"] else 9) if fp else 11,
                   "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 2 if (F.USE_SCALE_BATCH and F.USE_SA2_BATCH) else 4, "sa_packed_mlp_batch_wrapper": 1 if (F.USE_SCALE_BATCH and F.USE_SA2_BATCH) else 0,
                   "three_interpolate_cat_pm_wrapper": 0 if F.USE_FP_LINEAR else 3, "packed_layer_interp_wrapper": 3 if F.USE_FP_LINEAR else 0,
                   "rpn_tail_wrapper": 0 if F.USE_FP_LINEAR else 1, "rpn_tail_lin_wrapper": 1 if F.USE_FP_LINEAR and not F.USE_TAIL_DECODE else 0,
@@ -464,7 +470,7 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
     for name, n in want_calls.items():
         assert log[name] == n, (name, log[name], n)
     assert log["packed_layer_wrapper"] >= 3 and log["rows_dot_wrapper"] == 1
-    assert log["roi_idx_not_written"] == (1 if fp else 0) and log["row_cloud_lists"] == (2 if fp else 0)
+    assert log["roi_idx_not_written"] == (1 if fp else 0) and log["row_cloud_lists"] == ((3 if wide_fused and F.USE_WIDE_FUSED3 else 2) if fp else 0)
     assert log["rep_rows_dropped"] > 1000            # the deeper RCNN levels really dropped rows of copied centres
     assert log["centres_skipped"] > 1000             # ... and skipped the centres that copy an earlier one
     print("shadowed calls:", {k: v for k, v in log.items() if not k.startswith("elements:")})
