@@ -66,7 +66,7 @@ USE_WIDE_FUSED3 = os.environ.get("PRCNN_NO_WIDE_FUSED3") is None
 # RoI pooling culls by 64-point spatial groups of the scene (built with the geometry chain); PRCNN_NO_POOL_GROUPS=1: full sweep
 USE_XYZ_LEVEL_EARLY = os.environ.get("PRCNN_NO_XYZ_EARLY") != "1"    # leading SA levels of a coordinates-only backbone computed with the geometry (side stream)
 EARLY_LEVELS = int(os.environ.get("PRCNN_EARLY_LEVELS", "4"))
-EARLY_FP = int(os.environ.get("PRCNN_EARLY_FP", "3"))                 # ... plus this many of the coarsest FP modules, over the 32 clouds of a group in one launch each (round 3: 1 -- the geometry chains were the longer side then; round 4: 3, see EARLY_TAIL)
+EARLY_FP = int(os.environ.get("PRCNN_EARLY_FP", "2"))                 # ... plus this many of the coarsest FP modules, over the 32 clouds of a group in one launch each (round 3: 1 -- the geometry chains were the longer side then; round 4: 3, see EARLY_TAIL; round 5: 2 -- with the RCNN's padded tiles gone the feature stream has room again and the geometry chains bind: profiles/sensitivity_probe.py, 7860 -> 7980 / LiDAR-shaped 5500 -> 5570 at K = 100)
 # ... and the finest FP module + both RPN heads as well (round 4 experiment, needs EARLY_FP >= number of FP modules - 1): the RPN backbone has
 # no input features, so the WHOLE RPN stage is a function of xyz and the weights.  With the geometry chains twice as fast as in round 3 the
 # feature stream binds (1.10 ms of kernels per step against 0.6 on each geometry stream): EARLY_FP = 3 (all FP modules but the finest over

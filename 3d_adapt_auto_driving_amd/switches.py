@@ -40,7 +40,7 @@ SWITCHES = {
     "PRCNN_ROWS_GEMM": ("numerics", "unset", "net/fast_infer.py", "128-wide row layers through rows_gemm128 (round-1 form)"),
     # ---- scheduling A/B (same results)
     "PRCNN_EARLY_LEVELS": ("ab", "4", "net/fast_infer.py", "leading SA levels computed with the geometry"),
-    "PRCNN_EARLY_FP": ("ab", "3", "net/fast_infer.py", "coarsest FP modules computed with the geometry"),
+    "PRCNN_EARLY_FP": ("ab", "2", "net/fast_infer.py", "coarsest FP modules computed with the geometry (round 5: 2; 3 until then)"),
     "PRCNN_EARLY_G0": ("ab", "1", "net/fast_infer.py", "the finest FP module's coarse product computed with the geometry (round 4: +1.2 %)"),
     "PRCNN_EARLY_TAIL": ("ab", "0", "net/fast_infer.py", "1: the whole RPN tail with the geometry (round 4: slower, 6042 vs 6382)"),
     "PRCNN_NO_XYZ_EARLY": ("ab", "unset", "net/fast_infer.py", "1: no SA level rides with the geometry"),
