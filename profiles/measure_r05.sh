@@ -27,4 +27,13 @@ rm -rf $O/pmc_mfma
 python profiles/qg_sweep.py uniform 10 2>/dev/null > $O/qg_sweep_uniform.md
 # double.yaml (32768 points) and the fused tail alone
 ( echo '## profiles/double_probe.py 24 8'; python profiles/double_probe.py 24 8; echo; echo '## PRCNN_FPS_NO_PAIR=1 profiles/double_probe.py 24 8'; PRCNN_FPS_NO_PAIR=1 python profiles/double_probe.py 24 8; echo; echo '## profiles/tail_probe.py'; python profiles/tail_probe.py; echo '## PRCNN_TAIL_NARROW=0 profiles/tail_probe.py'; PRCNN_TAIL_NARROW=0 python profiles/tail_probe.py; echo '## profiles/nms_probe.py'; python profiles/nms_probe.py ) 2>&1 | grep -v amdgpu.ids > $O/kernel_probes.txt
+# second session of the round: what a kernel's microsecond costs the step, the RoI chain and the FPS rounds by phase, occupancy, the pack calls alone
+for sc in uniform lidar; do echo "## $sc"; timeout 1100 python -W ignore profiles/sensitivity_probe.py $sc 100 2>&1 | grep -v amdgpu.ids; done > $O/sensitivity.txt
+python profiles/roi_geometry_stamps.py build > /dev/null 2>&1; python profiles/fps_stamps.py build > /dev/null 2>&1
+for sc in uniform lidar; do timeout 300 python -W ignore profiles/roi_geometry_stamps.py run $sc 2>&1 | grep -v amdgpu.ids; done > $O/roi_geometry_stamps.md
+for sc in uniform lidar; do timeout 300 python -W ignore profiles/fps_stamps.py run $sc 2>&1 | grep -v amdgpu.ids; done > $O/fps_stamps.txt
+rm -rf /tmp/kt_occ; timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_occ -- python profiles/pmc_step_probe.py 3 > /dev/null 2>&1
+python profiles/occupancy_table.py /tmp/kt_occ/*/*kernel_trace.csv > $O/occupancy.md; python profiles/solo_kernel_times.py /tmp/kt_occ/*/*kernel_trace.csv 40 > $O/solo_kernel_times.md
+for sc in uniform lidar; do timeout 250 python -W ignore profiles/ball_pack_probe.py $sc 2>&1 | grep -v amdgpu.ids; done > $O/ball_pack_probe.md
+timeout 900 python bench.py --steps 100 --warmup 8 --windows 3 --no-cpu-baseline --no-roofline --no-driver > $O/bench_k100.json 2> $O/bench_k100.err
 cut -c1-300 $O/bench_k20.json; head -12 $O/pmc_product_kernels.md

@@ -16,6 +16,7 @@ print("| kernel | threads | LDS B | VGPR + AGPR | workgroups per CU by LDS / reg
 print("|---|---|---|---|---|---|---|---|---|")
 for (n, wg, lds, v, a), d in sorted(by.items(), key=lambda kv: -kv[1]["us"]):
     waves = (wg + 63) // 64
+    v, a = 2 * v, 2 * a                         # (rocprofv3 reports the counts of this wave64 target halved: 144 for rpn_tail_lin_kernel's 288)
     regs = max(((v + a + 7) // 8) * 8, 8)
     by_lds = 163840 // max(lds, 1) if lds else 99
     per_simd = 512 // regs                       # waves per SIMD by registers

@@ -8,9 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TARGETS = [("none", None, None), ("fps_new_xyz (sampling, 32 CUs)", "pointnet2", "fps_new_xyz_wrapper"),
            ("rpn_tail_lin_boxes (MFMA, whole chip)", "pointnet2", "rpn_tail_lin_boxes_wrapper"),
            ("forward_canonical (RoI pooling, HBM)", "roipool3d", "forward_canonical"),
-           ("rcnn_roi_geometry (a wave per RoI)", "pointnet2", "rcnn_roi_geometry_wrapper"),
+           ("rcnn_roi_geometry_packs (a wave per RoI: sampling, ball queries, the three row lists)", "pointnet2", "rcnn_roi_geometry_packs_wrapper"),
            ("rpn_proposals_boxes (sort, bands, NMS)", "iou3d", "rpn_proposals_boxes"),
-           ("rcnn_point_mlp (entrance, MFMA)", "pointnet2", "rcnn_point_mlp_wrapper"),
+           ("rcnn_point_mlp_rows (entrance, MFMA)", "pointnet2", "rcnn_point_mlp_rows_wrapper"),
            ("sa_wide_fused3 (MFMA)", "pointnet2", "sa_wide_fused3_wrapper"),
            ("ball_query_full (grid build + query)", "pointnet2", "ball_query_full_wrapper"),
            ("three_nn_weights", "pointnet2", "three_nn_weights_wrapper"),
@@ -26,7 +26,7 @@ TARGETS = [("none", None, None), ("fps_new_xyz (sampling, 32 CUs)", "pointnet2",
            ("sa_xyz_mlp_packed (RPN SA1)", "pointnet2", "sa_xyz_mlp_packed_wrapper"),
            ("point_aux", "pointnet2", "point_aux_wrapper"),
            ("pooled_tiles", "pointnet2", "pooled_tiles_wrapper"),
-           ("ball_pack (RCNN row lists; the extra launch with a header of its own)", "pointnet2", "ball_pack_wrapper"),
+           ("ball_pack (single lists; the extra launch with a header of its own)", "pointnet2", "ball_pack_wrapper"),
            ("ball_pack_groups (RPN row lists)", "pointnet2", "ball_pack_groups_wrapper")]
 if len(sys.argv) > 3:
     sys.path.insert(0, ROOT)
@@ -44,7 +44,10 @@ if len(sys.argv) > 3:
                "iou3d": importlib.import_module(PKG + ".iou3d_utils").iou3d_cuda}[modname]
         real = getattr(mod, fn)
         def twice(*a, **k):
-            if fn == "ball_pack_wrapper":                 # not idempotent on a shared header: the extra launch counts into one of its own
+            if fn == "rcnn_roi_geometry_packs_wrapper" and len(a) >= 14:     # the extra launch lists into headers of its own
+                z = lambda: torch.zeros(4, dtype=torch.int32, device=a[0].device)
+                real(*a[:8], z(), z(), a[10], a[11], z(), a[13])
+            elif fn == "ball_pack_wrapper":               # not idempotent on a shared header: the extra launch counts into one of its own
                 real(*a[:6])
             elif fn == "ball_pack_groups_wrapper":
                 real(*a[:4])
