@@ -13,8 +13,8 @@ CSRC = os.path.join(ROOT, "3d_adapt_auto_driving_amd", "csrc")
 EXP = os.path.join(ROOT, "profiles", "_exp")
 LIB = os.path.join(EXP, "libprcnn_hip_rg_stamps.so")
 FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math".split()
-PHASES = ["load 512 points", "FPS 512 -> 128", "centres out + ball query 1", "rep map 1", "rows of idx1 out", "FPS 128 -> 32", "centres 2 + ball query 2",
-          "rep map 2 + rows of idx2 out"]
+PHASES = ["load 512 points", "FPS 512 -> 128", "centres out + ball query 1", "rep map 1", "rows of idx1 out (skipped by the engine)", "row list 1", "FPS 128 -> 32",
+          "centres 2 + ball query 2", "rep map 2", "rows of idx2 out (skipped by the engine)", "row lists 2 and 3"]
 NPH = len(PHASES)
 MAXB = 4096
 
@@ -34,11 +34,14 @@ def instrument():
         "#define PH { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (lane == 0 && b < %d) g_rg_acc[b * %d + ph_] = n_ - t_prev_; t_prev_ = n_; ++ph_; }\n" % (MAXB, NPH))
     put("    const int nd1 = roi_fps_any<8, true>(RG_N, lim, RG_M1, kc1, px, py, pz, s_sel1, lane);\n", "    PH\n    const int nd1 = roi_fps_any<8, true>(RG_N, lim, RG_M1, kc1, px, py, pz, s_sel1, lane);\n    PH\n")
     put("    // representative map of the centres: the first centre sampled from the same source (prcnn_dup_rep)\n", "    PH\n")
-    put("    roi_rows_out<RG_M1>(", "    PH\n    roi_rows_out<RG_M1>(")
+    put("    if (idx1) roi_rows_out<RG_M1>(", "    PH\n    if (idx1) roi_rows_out<RG_M1>(")
+    put("    if (pk.rowinfo1) {\n        __syncthreads();                                          // s_first is free: the list's offsets\n", "    PH\n    if (pk.rowinfo1) {\n        __syncthreads();\n")
     put("    roi_fps_any<2, false>(RG_M1, nd1, RG_M2, kc2, qx, qy, qz, s_sel2, lane);\n", "    PH\n    roi_fps_any<2, false>(RG_M1, nd1, RG_M2, kc2, qx, qy, qz, s_sel2, lane);\n    PH\n")
     put("    // representative map of level 2's centres through the map of level 1\n", "    PH\n")
-    # the end of the kernel
-    tail = "idx2 + (long)b * RG_M2 * ns2, lane);\n}\n"
+    put("    if (idx2) roi_rows_out<RG_M2>(", "    PH\n    if (idx2) roi_rows_out<RG_M2>(")
+    # the lists of level 2 and of the GroupAll level, the end of the kernel
+    put("    if (pk.rowinfo1) {\n        __syncthreads();\n        roi_pack_out<RG_M2>(", "    PH\n    if (pk.rowinfo1) {\n        __syncthreads();\n        roi_pack_out<RG_M2>(")
+    tail = "            pk.rowdxyz3[r] = make_float4(cx[0] - 0.f, cy[0] - 0.f, cz[0] - 0.f, 0.f);\n        }\n    }\n}\n"
     put(tail, tail[:-2] + "    PH\n}\n")
     k = "}\n__device__ unsigned long long g_rg_acc[%d * %d];\nnamespace prcnn {\n" % (MAXB, NPH) + k
     # the kernel sits inside namespace prcnn: close and reopen it around the symbol so that HIP_SYMBOL finds it at file scope
@@ -75,24 +78,29 @@ def run(kind):
     make = S.lidar_scenes if kind == "lidar" else S.scenes
     pts = torch.from_numpy(make(16, 16384, seed0=1000)).to(dev)
     seen = []
-    real = P.rcnn_roi_geometry_wrapper
+    real = P.rcnn_roi_geometry_packs_wrapper
 
     def spy(xyz, limit, *a):
         seen.append((xyz.clone(), limit.clone(), a))
         return real(xyz, limit, *a)
-    P.rcnn_roi_geometry_wrapper = spy
+    P.rcnn_roi_geometry_packs_wrapper = spy
     eng = F.FastPointRCNN(model, cfg)
     with torch.no_grad():
         eng.forward(pts)
     torch.cuda.synchronize()
-    P.rcnn_roi_geometry_wrapper = real
+    P.rcnn_roi_geometry_packs_wrapper = real
     xyz, limit, a = seen[0]
     b = xyz.shape[0]
+
+    def again():                                   # the product's call with fresh (zero) list headers
+        z = lambda: torch.zeros(4, dtype=torch.int32, device=xyz.device)
+        return real(xyz, limit, *a[:6], z(), z(), a[8], a[9], z(), a[11])
     for _ in range(3):
-        real(xyz, limit, *a)
+        again()
     torch.cuda.synchronize()
+    z3 = [torch.zeros(4, dtype=torch.int32, device=xyz.device) for _ in range(3)]
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record(); real(xyz, limit, *a); ev1.record(); torch.cuda.synchronize()
+    ev0.record(); real(xyz, limit, *a[:6], z3[0], z3[1], a[8], a[9], z3[2], a[11]); ev1.record(); torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * (MAXB * NPH))()
     lib = ctypes.CDLL(LIB)
     assert lib.prcnn_debug_rg_acc(buf) == 0
