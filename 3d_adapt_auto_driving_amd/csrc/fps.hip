@@ -18,6 +18,23 @@ namespace prcnn {
 
 // (v, key) beats (bv, bkey): larger value, ties -> smaller key.  Branchless on purpose: the
 // short-circuit form compiles to exec-mask branches inside the hot loop.
+// v_min_f32 / v_max_f32 as ONE instruction each.  fminf / fmaxf are llvm.minnum / maxnum, and for an operand that is not provably the
+// result of an arithmetic instruction (a register-resident running minimum, a v_readlane, a bitcast) the backend puts a canonicalising
+// `v_max_f32 x, x, x` in front -- sNaN quieting the hardware instruction does by itself in the IEEE mode compute kernels run in: 944 of the
+// 6435 instructions of fps_spec_kernel<16> were that.  Same results for every input including quiet NaNs (the non-NaN operand is returned).
+__device__ __forceinline__ float fmin_raw(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float fmax_raw(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ bool better(float v, uint32_t key, float bv, uint32_t bkey)
 {
     return (v > bv) | ((v == bv) & (key < bkey));
@@ -86,7 +103,7 @@ __device__ __forceinline__ float dpp_max(float v)
     else if constexpr (CTRL == 0x4E) PRCNN_DPP_OP("v_max_f32_dpp", float, "quad_perm:[2,3,0,1]");
     else if constexpr (CTRL == 0x141) PRCNN_DPP_OP("v_max_f32_dpp", float, "row_half_mirror");
     else if constexpr (CTRL == 0x140) PRCNN_DPP_OP("v_max_f32_dpp", float, "row_mirror");
-    else r = fmaxf(v, __int_as_float(dpp_mov<CTRL>(__float_as_int(v))));
+    else r = fmax_raw(v, __int_as_float(dpp_mov<CTRL>(__float_as_int(v))));
     return r;
 }
 template <int CTRL>
@@ -555,9 +572,9 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
-            x0 = fminf(x0, __shfl_xor(x0, d, 64)); x1 = fmaxf(x1, __shfl_xor(x1, d, 64));
-            y0 = fminf(y0, __shfl_xor(y0, d, 64)); y1 = fmaxf(y1, __shfl_xor(y1, d, 64));
-            z0 = fminf(z0, __shfl_xor(z0, d, 64)); z1 = fmaxf(z1, __shfl_xor(z1, d, 64));
+            x0 = fmin_raw(x0, __shfl_xor(x0, d, 64)); x1 = fmax_raw(x1, __shfl_xor(x1, d, 64));
+            y0 = fmin_raw(y0, __shfl_xor(y0, d, 64)); y1 = fmax_raw(y1, __shfl_xor(y1, d, 64));
+            z0 = fmin_raw(z0, __shfl_xor(z0, d, 64)); z1 = fmax_raw(z1, __shfl_xor(z1, d, 64));
         }
         if (lane == i) { bx0 = x0; bx1 = x1; by0 = y0; by1 = y1; bz0 = z0; bz1 = z1; }
     }
@@ -578,23 +595,38 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
     float bound = INFINITY;
     // which tiles can a pivot (per lane group: ox, oy, oz differ by group) change?  bit g * PPT + i: tile i, the group's pivot
     auto box_mask = [&](float ox, float oy, float oz, bool live) __attribute__((always_inline)) {
-        const float dx = fmaxf(fmaxf(bx0 - ox, ox - bx1), 0.f);
-        const float dy = fmaxf(fmaxf(by0 - oy, oy - by1), 0.f);
-        const float dz = fmaxf(fmaxf(bz0 - oz, oz - bz1), 0.f);
+        const float dx = fmax_raw(fmax_raw(bx0 - ox, ox - bx1), 0.f);
+        const float dy = fmax_raw(fmax_raw(by0 - oy, oy - by1), 0.f);
+        const float dz = fmax_raw(fmax_raw(bz0 - oz, oz - bz1), 0.f);
         const float lb = dx * dx + dy * dy + dz * dz;
         return __ballot(live && !(lb * 0.99999f >= bound));           // empty boxes give lb = +inf
     };
     auto update = [&](float ox, float oy, float oz, unsigned long long mask) __attribute__((always_inline)) {
         if (mask != 0ull) {
             touched |= mask & etiles;
+            // Tiles in PAIRS on packed f32 arithmetic (round 5): v_pk_add / v_pk_mul / v_pk_fma apply to each half exactly the operation
+            // of the scalar form (one rounding each), so a tile's new minima are the same bits; a pair is updated when EITHER tile passed
+            // the box test -- for the other one the update is the identity (no point of a pruned tile can come closer than its minimum:
+            // that is what the pruning rests on).  8 packed + 2 min instructions per pair instead of 9 per tile.
+            const pk_f32x2 o_x = {ox, ox}, o_y = {oy, oy}, o_z = {oz, oz};
             if (kc.hipcc) {
 #pragma unroll
-                for (int i = 0; i < PPT; ++i)
-                    if ((mask >> i) & 1ull) pt[i] = fminf(fps_dist<true>(px[i], py[i], pz[i], ox, oy, oz), pt[i]);
+                for (int i = 0; i < PPT; i += 2)
+                    if ((mask >> i) & 3ull) {
+                        const pk_f32x2 dx = (pk_f32x2){px[i], px[i + 1]} - o_x, dy = (pk_f32x2){py[i], py[i + 1]} - o_y,
+                                       dz = (pk_f32x2){pz[i], pz[i + 1]} - o_z;
+                        const pk_f32x2 d = __builtin_elementwise_fma(dy, dy, dx * dx) + dz * dz;
+                        pt[i] = fmin_raw(d.x, pt[i]); pt[i + 1] = fmin_raw(d.y, pt[i + 1]);
+                    }
             } else {
 #pragma unroll
-                for (int i = 0; i < PPT; ++i)
-                    if ((mask >> i) & 1ull) pt[i] = fminf(sqdist3(px[i], py[i], pz[i], ox, oy, oz), pt[i]);
+                for (int i = 0; i < PPT; i += 2)
+                    if ((mask >> i) & 3ull) {
+                        const pk_f32x2 dx = (pk_f32x2){px[i], px[i + 1]} - o_x, dy = (pk_f32x2){py[i], py[i + 1]} - o_y,
+                                       dz = (pk_f32x2){pz[i], pz[i + 1]} - o_z;
+                        const pk_f32x2 d = (dx * dx + dy * dy) + dz * dz;
+                        pt[i] = fmin_raw(d.x, pt[i]); pt[i + 1] = fmin_raw(d.y, pt[i + 1]);
+                    }
             }
         }
     };
@@ -615,8 +647,8 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
             float bv = -INFINITY, sv = -INFINITY;                     // best and second-best VALUE of this lane
 #pragma unroll
             for (int i = 0; i < PPT; ++i) {
-                sv = fmaxf(sv, fminf(bv, pt[i]));
-                bv = fmaxf(bv, pt[i]);
+                sv = __builtin_amdgcn_fmed3f(bv, sv, pt[i]);          // = max(sv, min(bv, pt)) while sv <= bv: one v_med3_f32
+                bv = fmax_raw(bv, pt[i]);
             }
             uint32_t lk = 0xffffffffu;                                // (key, slot) of this lane's best
 #pragma unroll
@@ -637,7 +669,7 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
             const float v3 = wave_max_f32((lane == l1 || lane == l2) ? -INFINITY : bv);
             const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), l1));
             const float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), l2));
-            const float wB = fmaxf(v3, fmaxf(s1, s2));
+            const float wB = fmax_raw(v3, fmax_raw(s1, s2));
             bound = v1;
             const int sl1 = (int)(c1 & ((1u << SB) - 1u)), sl2 = (int)(c2 & ((1u << SB) - 1u));
             const bool has2 = m2 != 0ull && c2 != 0xffffffffu;
@@ -1358,9 +1390,9 @@ __device__ __forceinline__ int roi_fps(int n, int lim, int m, KeyCodec kc, const
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             const float d = kc.hipcc ? fps_dist<true>(px[i], py[i], pz[i], ox, oy, oz) : sqdist3(px[i], py[i], pz[i], ox, oy, oz);
-            const float d2 = fminf(d, pt[i]);
+            const float d2 = fmin_raw(d, pt[i]);
             pt[i] = d2;
-            lv = fmaxf(lv, d2);
+            lv = fmax_raw(lv, d2);
         }
         const float bv = wave_max_f32(lv);
         uint32_t lk = 0xffffffffu;                               // this lane's smallest key among its slots at the best value, and its slot
