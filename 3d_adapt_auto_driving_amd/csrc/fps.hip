@@ -866,23 +866,35 @@ __global__ __launch_bounds__(1024) void fps_spec2_kernel(
     unsigned long long touched = 0ull;
     float bound = INFINITY;
     auto box_mask = [&](float ox, float oy, float oz, bool live) __attribute__((always_inline)) {
-        const float dx = fmaxf(fmaxf(bx0 - ox, ox - bx1), 0.f);
-        const float dy = fmaxf(fmaxf(by0 - oy, oy - by1), 0.f);
-        const float dz = fmaxf(fmaxf(bz0 - oz, oz - bz1), 0.f);
+        const float dx = fmax_raw(fmax_raw(bx0 - ox, ox - bx1), 0.f);
+        const float dy = fmax_raw(fmax_raw(by0 - oy, oy - by1), 0.f);
+        const float dz = fmax_raw(fmax_raw(bz0 - oz, oz - bz1), 0.f);
         const float lb = dx * dx + dy * dy + dz * dz;
         return __ballot(live && !(lb * 0.99999f >= bound));
     };
     auto update = [&](float ox, float oy, float oz, unsigned long long mask) __attribute__((always_inline)) {
         if (mask != 0ull) {
             touched |= mask;
+            // tile pairs on packed f32 arithmetic, as in fps_spec_kernel
+            const pk_f32x2 o_x = {ox, ox}, o_y = {oy, oy}, o_z = {oz, oz};
             if (kc.hipcc) {
 #pragma unroll
-                for (int i = 0; i < PPT; ++i)
-                    if ((mask >> i) & 1ull) pt[i] = fminf(fps_dist<true>(px[i], py[i], pz[i], ox, oy, oz), pt[i]);
+                for (int i = 0; i < PPT; i += 2)
+                    if ((mask >> i) & 3ull) {
+                        const pk_f32x2 dx = (pk_f32x2){px[i], px[i + 1]} - o_x, dy = (pk_f32x2){py[i], py[i + 1]} - o_y,
+                                       dz = (pk_f32x2){pz[i], pz[i + 1]} - o_z;
+                        const pk_f32x2 d = __builtin_elementwise_fma(dy, dy, dx * dx) + dz * dz;
+                        pt[i] = fmin_raw(d.x, pt[i]); pt[i + 1] = fmin_raw(d.y, pt[i + 1]);
+                    }
             } else {
 #pragma unroll
-                for (int i = 0; i < PPT; ++i)
-                    if ((mask >> i) & 1ull) pt[i] = fminf(sqdist3(px[i], py[i], pz[i], ox, oy, oz), pt[i]);
+                for (int i = 0; i < PPT; i += 2)
+                    if ((mask >> i) & 3ull) {
+                        const pk_f32x2 dx = (pk_f32x2){px[i], px[i + 1]} - o_x, dy = (pk_f32x2){py[i], py[i + 1]} - o_y,
+                                       dz = (pk_f32x2){pz[i], pz[i + 1]} - o_z;
+                        const pk_f32x2 d = (dx * dx + dy * dy) + dz * dz;
+                        pt[i] = fmin_raw(d.x, pt[i]); pt[i + 1] = fmin_raw(d.y, pt[i + 1]);
+                    }
             }
         }
     };
@@ -904,8 +916,8 @@ __global__ __launch_bounds__(1024) void fps_spec2_kernel(
             float bv = -INFINITY, sv = -INFINITY;
 #pragma unroll
             for (int i = 0; i < PPT; ++i) {
-                sv = fmaxf(sv, fminf(bv, pt[i]));
-                bv = fmaxf(bv, pt[i]);
+                sv = __builtin_amdgcn_fmed3f(bv, sv, pt[i]);
+                bv = fmax_raw(bv, pt[i]);
             }
             uint32_t lk = 0xffffffffu;
 #pragma unroll
