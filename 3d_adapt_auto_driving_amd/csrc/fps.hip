@@ -18,23 +18,6 @@ namespace prcnn {
 
 // (v, key) beats (bv, bkey): larger value, ties -> smaller key.  Branchless on purpose: the
 // short-circuit form compiles to exec-mask branches inside the hot loop.
-// v_min_f32 / v_max_f32 as ONE instruction each.  fminf / fmaxf are llvm.minnum / maxnum, and for an operand that is not provably the
-// result of an arithmetic instruction (a register-resident running minimum, a v_readlane, a bitcast) the backend puts a canonicalising
-// `v_max_f32 x, x, x` in front -- sNaN quieting the hardware instruction does by itself in the IEEE mode compute kernels run in: 944 of the
-// 6435 instructions of fps_spec_kernel<16> were that.  Same results for every input including quiet NaNs (the non-NaN operand is returned).
-__device__ __forceinline__ float fmin_raw(float a, float b)
-{
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float fmax_raw(float a, float b)
-{
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 __device__ __forceinline__ bool better(float v, uint32_t key, float bv, uint32_t bkey)
 {
     return (v > bv) | ((v == bv) & (key < bkey));

@@ -35,10 +35,10 @@ __device__ __forceinline__ void sw_segmented_max(const f32x16 &acc, const int *c
                 flush(prev + 4 * h, cur);
                 cur = v;
             } else {
-                cur = fmaxf(cur, v);
+                cur = fmax_raw(cur, v);
             }
         } else {
-            cur = fmaxf(cur, v);
+            cur = fmax_raw(cur, v);
         }
     }
     flush(rowof(15) + 4 * h, cur);

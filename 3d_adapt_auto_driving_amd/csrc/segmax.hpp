@@ -24,9 +24,9 @@ __device__ __forceinline__ void pk_segmented_max(const f32x16 &acc0, const f32x1
 {
     if (start == 1ULL) {
         // the whole tile belongs to ONE centre (a full ball): plain max over the 64 rows, one store per column
-        float mx = fmaxf(acc0[0], acc1[0]);
+        float mx = fmax_raw(acc0[0], acc1[0]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(acc0[r], acc1[r]));
+        for (int r = 1; r < 16; ++r) mx = fmax_raw(mx, fmax_raw(acc0[r], acc1[r]));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         if (h == 0) pk_flush(out, ctr[0], out_stride, col, mx, bias);
         return;
@@ -50,10 +50,10 @@ __device__ __forceinline__ void pk_segmented_max(const f32x16 &acc0, const f32x1
                 pk_flush(out, ctr[prev + 4 * h], out_stride, col, cur, bias);
                 cur = v;
             } else {
-                cur = fmaxf(cur, v);
+                cur = fmax_raw(cur, v);
             }
         } else {
-            cur = fmaxf(cur, v);
+            cur = fmax_raw(cur, v);
         }
     }
     pk_flush(out, ctr[pk_row(31) + 4 * h], out_stride, col, cur, bias);
@@ -118,7 +118,7 @@ __device__ __forceinline__ void pk_segmented_max_lds(const float *Z, int ld, con
             pk_flush4(out, c_cur, out_stride, col0 + 4 * chunk, cur, bias4, first && (row0 == 0 || before == c_cur));
             c_cur = c; cur = v; first = false;
         } else {
-            cur.x = fmaxf(cur.x, v.x); cur.y = fmaxf(cur.y, v.y); cur.z = fmaxf(cur.z, v.z); cur.w = fmaxf(cur.w, v.w);
+            cur.x = fmax_raw(cur.x, v.x); cur.y = fmax_raw(cur.y, v.y); cur.z = fmax_raw(cur.z, v.z); cur.w = fmax_raw(cur.w, v.w);
         }
     }
     pk_flush4(out, c_cur, out_stride, col0 + 4 * chunk, cur, bias4,
