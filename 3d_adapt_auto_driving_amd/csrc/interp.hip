@@ -32,16 +32,13 @@ __global__ __launch_bounds__(256) void three_nn_kernel(
 #pragma unroll 4
     for (int k = 0; k < m; ++k) {
         const float d = sqdist3(ux, uy, uz, kn[3 * k], kn[3 * k + 1], kn[3 * k + 2]);
-        if (d < b1) {
-            b3 = b2; i3 = i2;
-            b2 = b1; i2 = i1;
-            b1 = d; i1 = k;
-        } else if (d < b2) {
-            b3 = b2; i3 = i2;
-            b2 = d; i2 = k;
-        } else if (d < b3) {
-            b3 = d; i3 = k;
-        }
+        // the reference's insertion (interpolate_gpu.cu:36-44: `if (d < best1) ... else if (d < best2) ... else if (d < best3)`) as selects:
+        // the same strict comparisons, the same (distance, index) triples -- as branches the three arms diverge inside a wave and every
+        // known point cost the sum of all three
+        const bool c1 = d < b1, c2 = d < b2, c3 = d < b3;
+        b3 = c2 ? b2 : (c3 ? d : b3); i3 = c2 ? i2 : (c3 ? k : i3);
+        b2 = c1 ? b1 : (c2 ? d : b2); i2 = c1 ? i1 : (c2 ? k : i2);
+        b1 = c1 ? d : b1;             i1 = c1 ? k : i1;
     }
     if (valid) {
         int *oi = idx + ((long)b * n + p) * 3;
