@@ -136,15 +136,137 @@ __global__ __launch_bounds__(256) void sa_xyz_mlp_packed_kernel(
     constexpr int ROWS_PER = C3 == 64 ? 64 : 32;
     const int ch = lane & (C3 - 1), hh = C3 == 64 ? 0 : (lane >> 5);
     const int *cc = ctr[wv];
+    // where a new centre begins, as ONE word (round 5): the row values are independent loads of an unrolled loop and a boundary is a bit
+    // test on a constant position (C3 = 64: a scalar branch; C3 = 32: the two lane halves walk their own 32 rows, the test is per lane).
+    // (The loop used to read the row's value, then two entries of the centre list, compare and branch, row after row, not unrolled.)
+    const int myc = cc[lane], prevc = cc[lane ? lane - 1 : 0];
+    const unsigned long long start = __ballot(lane == 0 || myc != prevc);
+    const unsigned long long sh = C3 == 64 ? start : (start >> (hh * ROWS_PER));
     float cur = 0.f;
+#pragma unroll
     for (int i = 0; i < ROWS_PER; ++i) {
         const int r = hh * ROWS_PER + i;
-        cur = fmaxf(cur, zw[r * (C3 + 1) + ch]);
-        const bool last = (i == ROWS_PER - 1) || (cc[r + 1] != cc[r]);
+        cur = fmax_raw(cur, zw[r * (C3 + 1) + ch]);
+        const bool last = (i == ROWS_PER - 1) || ((sh >> (i + 1)) & 1ull) != 0;
         if (last) {
             atomicMax(reinterpret_cast<int *>(out + (long)cc[r] * out_stride + out_col + ch), __float_as_int(cur));
             cur = 0.f;
         }
+    }
+}
+
+
+// ---- the wider scale (3 -> 32 -> 32 -> 64) with layers 2 and 3 on the matrix cores (round 5) -------------------------------------
+// The VALU form above streams every weight through a scalar register: 213 s_load_dwordx16 per 64-row tile, 13.6 KB that each of
+// a CU's waves asks the scalar cache for again -- at the packed-f32 rate that is most of the cache's bandwidth, and on LiDAR-shaped
+// scenes (1.2 M rows in this scale) the kernel ran at 0.37 of that rate (150 us for 16 clouds; more resident waves made it SLOWER).
+// Here the weights sit in registers as the MFMA's A operand and the product is taken transposed, out^T = W^T act^T:
+//   A: lane (c = lane & 31, h = lane >> 5) holds W[2 s + h][32 cb + c]            (a channel block's weights of k-step s)
+//   B: lane (j = lane & 31, h) holds act[row j of the 32-row block][2 s + h]
+//   D: lane (j, h), register r holds out[row j][32 cb + (r & 3) + 8 (r >> 2) + 4 h] -- the ROW stays in its lane.
+// B operands: layer 2's input has all 32 channels of the lane's own row (the VALU layer 1): X = act[2 s], Y = act[2 s + 1], and ONE
+// v_permlane32_swap (X's upper lanes <-> Y's lower lanes) turns them into the operand of rows 0-31 and that of rows 32-63.  Layer 3's
+// input is layer 2's D: channels 2 s and 2 s + 1 sit in the same lane half; swapping registers r(2 s), r(2 s + 1) gives the operand of
+// step s in one result and that of step s + 2 (channels 2 s + 4, 2 s + 5, held by the other half) in the other: 8 swaps per block.
+// v_mfma_f32_32x32x2_f32 is bitwise fma(A[i][0], B[0][j], .) then fma(A[i][1], B[1][j], .) (oracle/mlp_oracle.c), the accumulators
+// start from the bias: the chain of xyz_layer, k ascending -- same bits as the VALU form (tests/test_gpu_packed.py, the shadow run).
+// Persistent waves (the weights are loaded once), one 64-row tile at a time; pooling as above through a 64 x 68 LDS tile per wave.
+typedef float xm_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256, 2) void sa_xyz_mlp_packed_mfma_kernel(
+    int m, const unsigned int *__restrict__ hdr, const unsigned int *__restrict__ rowinfo, const float4 *__restrict__ rowdxyz,
+    const int *__restrict__ tilecloud, const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w2,
+    const float *__restrict__ b2, const float *__restrict__ w3, const float *__restrict__ b3, float *__restrict__ out,
+    int out_stride, int out_col)
+{
+    constexpr int C1 = 32, C2 = 32, C3 = 64, LD = 68;
+    __shared__ __align__(16) float z[4][64 * LD];
+    __shared__ int ctr[4][64];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const long tiles = (long)hdr[0];
+    const long nw = (long)gridDim.x * 4;
+    long t = (long)blockIdx.x * 4 + wv;
+    if (t >= tiles) return;                                    // wave-uniform: no workgroup barrier below, LDS is private per wave
+    float wa2[16], wa3[2][16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        wa2[s] = w2[(2 * s + h) * C2 + c];
+        wa3[0][s] = w3[(2 * s + h) * C3 + c];
+        wa3[1][s] = w3[(2 * s + h) * C3 + 32 + c];
+    }
+    xm_f32x16 bias2, bias3[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch_r = (r & 3) + 8 * (r >> 2) + 4 * h;
+        bias2[r] = b2[ch_r]; bias3[0][r] = b3[ch_r]; bias3[1][r] = b3[32 + ch_r];
+    }
+    float *zw = z[wv];
+    int *cc = ctr[wv];
+    for (; t < tiles; t += nw) {
+        const long row = t * 64 + lane;
+        const float4 d = rowdxyz[row];
+        cc[lane] = tilecloud[t] * m + (int)(rowinfo[row] >> 16);
+        float a1[C1];
+        {
+            const float d3[3] = {d.x, d.y, d.z};
+            xyz_layer<3, C1>(w1, b1, d3, a1);
+        }
+#pragma unroll
+        for (int j = 0; j < C1; ++j) a1[j] = fmaxf(a1[j], 0.f);
+        // ---- layer 2: D2[rb] (32 channels x 32 rows) for the row blocks rb = 0 (lanes 0-31's rows), 1 (lanes 32-63's rows)
+        xm_f32x16 d2[2] = {bias2, bias2};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(a1[2 * s]), __float_as_int(a1[2 * s + 1]), false, false);
+            d2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa2[s], __int_as_float(sw[0]), d2[0], 0, 0, 0);
+            d2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa2[s], __int_as_float(sw[1]), d2[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { d2[0][r] = fmaxf(d2[0][r], 0.f); d2[1][r] = fmaxf(d2[1][r], 0.f); }
+        // ---- layer 3: D3[rb][cb]
+        xm_f32x16 d3[2][2] = {{bias3[0], bias3[1]}, {bias3[0], bias3[1]}};
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            float bop[16];                                     // the B operand of every k-step of this row block
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                if (((s >> 1) & 1) == 0) {                     // channels 2 s, 2 s + 1 live in the lower lanes; the swap also yields step s + 2
+                    const int r0 = ((2 * s) & 3) + 4 * ((2 * s) >> 3), r1 = ((2 * s + 1) & 3) + 4 * ((2 * s + 1) >> 3);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(d2[rb][r0]), __float_as_int(d2[rb][r1]), false, false);
+                    bop[s] = __int_as_float(sw[0]);
+                    bop[s + 2] = __int_as_float(sw[1]);
+                }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                d3[rb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa3[0][s], bop[s], d3[rb][0], 0, 0, 0);
+                d3[rb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa3[1][s], bop[s], d3[rb][1], 0, 0, 0);
+            }
+        }
+        // ---- ReLU, rows to LDS ([row][channel], four consecutive channels per store), pool with lane = channel
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = make_float4(fmaxf(d3[rb][cb][4 * q], 0.f), fmaxf(d3[rb][cb][4 * q + 1], 0.f),
+                                                 fmaxf(d3[rb][cb][4 * q + 2], 0.f), fmaxf(d3[rb][cb][4 * q + 3], 0.f));
+                    *reinterpret_cast<float4 *>(zw + (32 * rb + c) * LD + 32 * cb + 8 * q + 4 * h) = v;
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int myc = cc[lane], prevc = cc[lane ? lane - 1 : 0];
+        const unsigned long long start = __ballot(lane == 0 || myc != prevc);
+        float cur = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            cur = fmax_raw(cur, zw[i * LD + lane]);
+            const bool last = (i == 63) || ((start >> (i + 1)) & 1ull) != 0;
+            if (last) {
+                atomicMax(reinterpret_cast<int *>(out + (long)cc[i] * out_stride + out_col + lane), __float_as_int(cur));
+                cur = 0.f;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                       // the next tile overwrites the LDS tile and the centre list
     }
 }
 
@@ -176,9 +298,17 @@ extern "C" int prcnn_sa_xyz_mlp_packed(int b, int m, int c1, int c2, int c3, lon
     if (c3 == 32)
         hipLaunchKernelGGL((sa_xyz_mlp_packed_kernel<16, 16, 32>), dim3((unsigned)grid), dim3(256), 0, st, m, hdr, rowinfo,
                            (const float4 *)rowdxyz, tilecloud, w1, b1, w2, b2, w3, b3, out, out_stride, out_col);
-    else
-        hipLaunchKernelGGL((sa_xyz_mlp_packed_kernel<32, 32, 64>), dim3((unsigned)grid), dim3(256), 0, st, m, hdr, rowinfo,
-                           (const float4 *)rowdxyz, tilecloud, w1, b1, w2, b2, w3, b3, out, out_stride, out_col);
+    else {
+        // PRCNN_XYZ_MFMA=0: the VALU form of this scale (A/B: same bits)
+        static const bool mfma = !(getenv("PRCNN_XYZ_MFMA") && atoi(getenv("PRCNN_XYZ_MFMA")) == 0);
+        if (mfma) {
+            const long cap = 2L * mfma_grid_cap();             // persistent waves: the weights are loaded once per wave
+            hipLaunchKernelGGL(sa_xyz_mlp_packed_mfma_kernel, dim3((unsigned)(grid < cap ? grid : cap)), dim3(256), 0, st, m, hdr, rowinfo,
+                               (const float4 *)rowdxyz, tilecloud, w1, b1, w2, b2, w3, b3, out, out_stride, out_col);
+        } else
+            hipLaunchKernelGGL((sa_xyz_mlp_packed_kernel<32, 32, 64>), dim3((unsigned)grid), dim3(256), 0, st, m, hdr, rowinfo,
+                               (const float4 *)rowdxyz, tilecloud, w1, b1, w2, b2, w3, b3, out, out_stride, out_col);
+    }
     return check_launch("sa_xyz_mlp_packed");
 }
 

@@ -14,7 +14,7 @@ cfg = C.default_eval_cfg()
 model = E.build_model(cfg, dev, seed=0)
 eng = F.FastPointRCNN(model, cfg)
 NSC = int(sys.argv[2]) if len(sys.argv) > 2 else 8 * max(1, E.RCNN_PAIR)
-pts = torch.from_numpy(S.scenes(NSC, 16384, seed0=0)).to(dev)
+pts = torch.from_numpy((S.lidar_scenes if (len(sys.argv) > 3 and sys.argv[3] == "lidar") else S.scenes)(NSC, 16384, seed0=0)).to(dev)   # argv[3] = lidar: LiDAR-shaped scenes
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     det = E.infer_batch(model, cfg, pts, engine=eng)
 torch.cuda.synchronize()
