@@ -1382,12 +1382,20 @@ __device__ __forceinline__ int roi_fps(int n, int lim, int m, KeyCodec kc, const
     float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz[0]), 0));
     for (int j = 1; j < m; ++j) {
         float lv = -INFINITY;
+        if constexpr (D >= 2) {
+            // slot PAIRS on packed f32 arithmetic (each half the scalar form's operations, one rounding each: same bits; see fps_spec_kernel)
+            const pk_f32x2 o_x = {ox, ox}, o_y = {oy, oy}, o_z = {oz, oz};
 #pragma unroll
-        for (int i = 0; i < D; ++i) {
-            const float d = kc.hipcc ? fps_dist<true>(px[i], py[i], pz[i], ox, oy, oz) : sqdist3(px[i], py[i], pz[i], ox, oy, oz);
-            const float d2 = fmin_raw(d, pt[i]);
-            pt[i] = d2;
-            lv = fmax_raw(lv, d2);
+            for (int i = 0; i < D; i += 2) {
+                const pk_f32x2 dx = (pk_f32x2){px[i], px[i + 1]} - o_x, dy = (pk_f32x2){py[i], py[i + 1]} - o_y, dz = (pk_f32x2){pz[i], pz[i + 1]} - o_z;
+                const pk_f32x2 d = kc.hipcc ? (pk_f32x2)(__builtin_elementwise_fma(dy, dy, dx * dx) + dz * dz) : (pk_f32x2)((dx * dx + dy * dy) + dz * dz);
+                pt[i] = fmin_raw(d.x, pt[i]); pt[i + 1] = fmin_raw(d.y, pt[i + 1]);
+                lv = fmax_raw(lv, fmax_raw(pt[i], pt[i + 1]));
+            }
+        } else {
+            const float d = kc.hipcc ? fps_dist<true>(px[0], py[0], pz[0], ox, oy, oz) : sqdist3(px[0], py[0], pz[0], ox, oy, oz);
+            pt[0] = fmin_raw(d, pt[0]);
+            lv = pt[0];
         }
         const float bv = wave_max_f32(lv);
         uint32_t lk = 0xffffffffu;                               // this lane's smallest key among its slots at the best value, and its slot
