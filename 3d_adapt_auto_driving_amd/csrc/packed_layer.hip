@@ -374,6 +374,26 @@ __global__ __launch_bounds__(256, 2) void packed_layer_pipe_kernel(
             PL_STAGE(T, wa)
         }
     }
+    if constexpr (!SEGMAX) {
+        if (n0 + 128 <= n_store && !pb.addG) {
+            // whole 128-column blocks, no addend: straight from the accumulators as buffer stores into the tile's own rows of `out`
+            // (packed_layer_persist_kernel's epilogue: no LDS staging, no barrier; rows past the end are outside the buffer) -- round 5:
+            // the staged epilogue was 4.5-14 k of a workgroup's 95-120 k cycles in the launches of at most 512 items this kernel keeps
+            const float bcol = bias[n0 + 32 * w + j];
+            const unsigned int o_row_bytes = (unsigned int)ldo * 4u;
+            const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(out + t * PL_ROWS * ldo), 0, (int)((left < PL_ROWS ? left : PL_ROWS) * (long)o_row_bytes), 0x00020000);
+            const unsigned int o_lane = (unsigned int)(4 * h) * o_row_bytes + (unsigned int)(n0 + 32 * w + j) * 4u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned int so = (unsigned int)((r & 3) + 8 * (r >> 2)) * o_row_bytes;
+                const float v0 = acc0[r] + bcol, v1 = acc1[r] + bcol;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(do_relu ? fmaxf(v0, 0.f) : v0), ors, o_lane, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(do_relu ? fmaxf(v1, 0.f) : v1), ors, o_lane, so + 32u * o_row_bytes, 0);
+            }
+            return;
+        }
+    }
     pl_epilogue<SEGMAX>(acc0, acc1, tiles, ctr, t, rows, n0, bias, do_relu, out, ldo, rowinfo, tilecloud, m, out_col, n_store, pb.lds_pool, &pb);
 }
 
