@@ -68,7 +68,8 @@ SIGNATURES = {
     "prcnn_ball_pack_rep": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "prcnn_dup_rep": [_I, _I, _I, _P, _P, _P, _P, _P],
     "prcnn_rcnn_roi_geometry": [_I, _I, _I, _F, _I, _I, _F, _I] + [_P] * 9,
-    "prcnn_rcnn_roi_geometry_packs": [_I, _I, _I, _F, _I, _I, _F, _I] + [_P] * 19 + [_I, _P],
+    "prcnn_rcnn_roi_geometry_packs": [_I, _I, _I, _F, _I, _I, _F, _I] + [_P] * 21 + [_I, _P],
+    "prcnn_rows_gemm128_rows": [_L, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P],
     "prcnn_sa_packed_mlp": [_I, _I, _I, _I, C.c_long] + [_P] * 11 + [_I, _I, _I, _P],
     "prcnn_packed_gather_affine": [_I, _I, _I, C.c_long] + [_P] * 7 + [_P],
     "prcnn_packed_layer": [_P, C.c_long, C.c_long, _I, _I, _I, _P, C.c_long, _P, _P, _I, _P, C.c_long, _P],

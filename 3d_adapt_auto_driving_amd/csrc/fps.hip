@@ -1515,6 +1515,7 @@ struct RgPacks {
     unsigned int *rowinfo1; float4 *rowdxyz1; int *tilecloud1; unsigned int *hdr1;
     unsigned int *rowinfo2; float4 *rowdxyz2; int *tilecloud2; unsigned int *hdr2;
     unsigned int *rowinfo3; float4 *rowdxyz3; unsigned int *hdr3;    // optional third list (rows carry their cloud): see the kernel's end
+    int *crows1; unsigned int *hdr_c1;                               // optional: the level-1 centres that are their own representatives, as rows
     // tilecloud* == NULL: the lists' rows carry their cloud -- descriptor (cloud << 16) | (centre << 9) | point -- and are drawn from the
     // list's ROW counter hdr[1], so that tiles are cut wherever the rows fall (csrc/sa_packed.hip reads such a list when it is given no
     // tilecloud): no padded last tile per cloud
@@ -1616,6 +1617,14 @@ __global__ __launch_bounds__(64) void rcnn_roi_geometry_kernel(
     }
     const int nd1 = roi_fps_any<8, true>(RG_N, lim, RG_M1, kc1, px, py, pz, s_sel1, lane);
     __syncthreads();
+    // the centres that are their own representatives are the first nd1 (distinct picks; what follows are copies of centre 0): listed as
+    // rows b * 128 + c for the per-point layer of the level above (prcnn_rows_gemm128_rows), which nobody asks for the other rows
+    if (pk.crows1) {
+        int base = 0;
+        if (lane == 0) base = (int)atomicAdd(&pk.hdr_c1[1], (unsigned int)nd1);
+        base = __builtin_amdgcn_readfirstlane(base);
+        for (int c = lane; c < nd1; c += 64) pk.crows1[base + c] = b * RG_M1 + c;
+    }
     // the sampled centres: coordinates into registers (centre c = lane + 64 q) and out to new_xyz1
     float qx[2], qy[2], qz[2];
     int src1[2];
@@ -1773,14 +1782,22 @@ extern "C" int prcnn_rcnn_roi_geometry(int b, int n, int m1, float r1, int ns1, 
  * are not written (a caller that feeds the row lists to the packed MLP kernels has no use for them: 10240 words per cloud).
  * rowinfo3 / rowdxyz3 / hdr3 (optional, b * m2 rows at most): the list of the GroupAll level above -- every cloud one group (centre 0) of
  * its m2 level-2 centres, the centres that copy an earlier one dropped: prcnn_ball_pack_ex(b, b, m2, 1, m2, {0..m2-1}, NULL, rep2, NULL,
- * new_xyz2, origin, ...) in the row-carried form. */
+ * new_xyz2, origin, ...) in the row-carried form.
+ * crows1 / hdr_c1 (optional, b * m1 entries at most): the level-1 centres that are their own representatives as rows cloud * m1 + centre,
+ * hdr_c1[1] of them -- for prcnn_rows_gemm128_rows (the per-point layer of level 2 over exactly the rows its lists name). */
 extern "C" int prcnn_rcnn_roi_geometry_packs(int b, int n, int m1, float r1, int ns1, int m2, float r2, int ns2, const float *xyz,
                                              const int *limit, float *new_xyz1, int *idx1, int *rep1, float *new_xyz2, int *idx2, int *rep2,
                                              unsigned int *rowinfo1, float *rowdxyz1, int *tilecloud1, unsigned int *hdr1,
                                              unsigned int *rowinfo2, float *rowdxyz2, int *tilecloud2, unsigned int *hdr2,
-                                             unsigned int *rowinfo3, float *rowdxyz3, unsigned int *hdr3, int hdr_is_zero, void *stream)
+                                             unsigned int *rowinfo3, float *rowdxyz3, unsigned int *hdr3, int *crows1, unsigned int *hdr_c1,
+                                             int hdr_is_zero, void *stream)
 {
     PRCNN_REQUIRE(hdr1 && hdr2, "rcnn_roi_geometry_packs: null header");
+    PRCNN_REQUIRE((crows1 != nullptr) == (hdr_c1 != nullptr), "rcnn_roi_geometry_packs: the centre rows come with their header");
+    if (hdr_c1 && !hdr_is_zero && hipMemsetAsync(hdr_c1, 0, 4 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess) {
+        set_error("rcnn_roi_geometry_packs: memset failed");
+        return PRCNN_ELAUNCH;
+    }
     PRCNN_REQUIRE((rowinfo3 != nullptr) == (rowdxyz3 != nullptr) && (rowinfo3 != nullptr) == (hdr3 != nullptr) && (!rowinfo3 || !tilecloud1),
                   "rcnn_roi_geometry_packs: the third list comes whole, and only with lists whose rows carry their cloud");
     if (!hdr_is_zero && (hipMemsetAsync(hdr1, 0, 4 * sizeof(unsigned int), (hipStream_t)stream) != hipSuccess ||
@@ -1794,6 +1811,6 @@ extern "C" int prcnn_rcnn_roi_geometry_packs(int b, int n, int m1, float r1, int
     PRCNN_REQUIRE((tilecloud1 && tilecloud2) || (!tilecloud1 && !tilecloud2 && b <= 65536), "rcnn_roi_geometry_packs: both lists with a tilecloud or none");
     PRCNN_REQUIRE((((uintptr_t)rowdxyz1 | (uintptr_t)rowdxyz2 | (uintptr_t)rowdxyz3) & 15) == 0, "rcnn_roi_geometry_packs: rowdxyz must be 16-byte aligned");
     const prcnn::RgPacks pk = {rowinfo1, (float4 *)rowdxyz1, tilecloud1, hdr1, rowinfo2, (float4 *)rowdxyz2, tilecloud2, hdr2,
-                               rowinfo3, (float4 *)rowdxyz3, hdr3};
+                               rowinfo3, (float4 *)rowdxyz3, hdr3, crows1, hdr_c1};
     return roi_geometry_any(b, n, m1, r1, ns1, m2, r2, ns2, xyz, limit, new_xyz1, idx1, rep1, new_xyz2, idx2, rep2, &pk, stream);
 }

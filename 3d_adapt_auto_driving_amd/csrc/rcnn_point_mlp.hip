@@ -156,6 +156,69 @@ __global__ __launch_bounds__(256, 2) void rows_layer_kernel(
     if (tid == 0) ticket_release(ticket);          // the launch's last workgroup zeroes the counter for the word's next user
 }
 
+// ---- one 128 -> 128 layer over a LIST of rows (round 5): out[r] = act(src[r] @ W + bias) for r = rowmap[0 .. hdr[1]), 64 list entries
+// per tile whichever rows they are; rows that are not listed are neither read nor written.  The per-point part of the RCNN's second SA
+// level runs over the level-1 centres that are their own representatives only (47 of 128 per RoI on the uniform scene: the others
+// copy an earlier centre and no row list names them).  Tiles strided over the workgroups; the NEXT tile's rows (their numbers were
+// fetched one tile earlier still) arrive behind the MFMAs.  Per row the arithmetic of rows_layer_kernel / packed_layer_stream_kernel.
+template <bool RELU>
+__global__ __launch_bounds__(256, 2) void rows_layer_list_kernel(const float *__restrict__ src, int ld, int col, const float *__restrict__ w0,
+                                                                 const float *__restrict__ bias, float *__restrict__ out,
+                                                                 const int *__restrict__ rowmap, const unsigned int *__restrict__ hdr)
+{
+    __shared__ float T0[PM_ROWS * PM_LD];
+    const long nrows = (long)hdr[1];
+    const long tiles = (nrows + PM_ROWS - 1) / PM_ROWS;
+    long t = blockIdx.x;
+    if (t >= tiles) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int chunk = tid & 31, r0 = tid >> 5;
+    float wa[64];
+    load_panel(wa, w0, w, j, h);
+    const float bcol = bias[32 * w + j];
+    const long step = gridDim.x;
+    int cur[8], nxt[8];
+    float4 p0[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        cur[i] = rowmap[min(t * PM_ROWS + r0 + 8 * i, nrows - 1)];
+        nxt[i] = t + step < tiles ? rowmap[min((t + step) * PM_ROWS + r0 + 8 * i, nrows - 1)] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p0[i] = *reinterpret_cast<const float4 *>(src + (long)cur[i] * ld + col + 4 * chunk);
+    for (; t < tiles; t += step) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4 *>(T0 + (r0 + 8 * i) * PM_LD + 4 * chunk) = p0[i];
+        lds_barrier();
+        int nn[8];
+        if (t + step < tiles) {                                     // the next tile's rows, the numbers of the one after it: behind the MFMAs
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p0[i] = *reinterpret_cast<const float4 *>(src + (long)nxt[i] * ld + col + 4 * chunk);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) nn[i] = t + 2 * step < tiles ? rowmap[min((t + 2 * step) * PM_ROWS + r0 + 8 * i, nrows - 1)] : 0;
+        }
+        f32x16 acc0 = {0}, acc1 = {0};
+        mfma_panel(T0, wa, acc0, acc1, j, h);
+        lds_barrier();                                              // every wave has finished reading the tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, h);
+            const float v0 = acc0[r] + bcol, v1 = acc1[r] + bcol;
+            T0[row * PM_LD + 32 * w + j] = RELU ? fmaxf(v0, 0.f) : v0;
+            T0[(32 + row) * PM_LD + 32 * w + j] = RELU ? fmaxf(v1, 0.f) : v1;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<float4 *>(out + (long)cur[i] * PM_C + 4 * chunk) = *reinterpret_cast<const float4 *>(T0 + (r0 + 8 * i) * PM_LD + 4 * chunk);
+        lds_barrier();                                              // the next builder overwrites T0
+        if (t + step < tiles) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { cur[i] = nxt[i]; nxt[i] = nn[i]; }
+        }
+    }
+}
+
 unsigned int *next_ticket(hipStream_t st);    // sa_mlp_fused.hip
 
 // ---- the whole entrance chain over a tile that stays in LDS (round 2, after the stage stamps of csrc/rpn_tail.hip) -----------
@@ -430,6 +493,22 @@ extern "C" int prcnn_rcnn_point_mlp_rows(long r, int ld, int fcol, const float *
     hipLaunchKernelGGL(rcnn_entrance_kernel, dim3((unsigned)grid), dim3(256), 0, st, tiles, rows, ld, fcol, (const float4 *)wu1,
                        (const float4 *)bu1, wu2, bu2, wm, bm, wp, bp, p, tk, nullptr, hdr, rowmap);
     return check_launch("rcnn_point_mlp_rows");
+}
+
+// out (r, 128) rows rowmap[0 .. hdr[1]) = act(src rows (128 floats at column col, row stride ld) @ w (128, 128) k-major + bias): the
+// 128-wide layer of prcnn_rows_gemm128 (npanel = 1) over a LIST of rows; rows that are not listed are left as they are.
+extern "C" int prcnn_rows_gemm128_rows(long r, const float *src, int ld, int col, const float *w, const float *bias, int relu, float *out,
+                                       const int *rowmap, const unsigned int *hdr, void *stream)
+{
+    PRCNN_REQUIRE(r >= 0 && r <= 0x7fffffffL && ld % 4 == 0 && col % 4 == 0 && col >= 0 && col + PM_C <= ld, "rows_gemm128_rows: bad layout");
+    if (r == 0) return PRCNN_OK;
+    PRCNN_REQUIRE(src && w && bias && out && rowmap && hdr, "rows_gemm128_rows: null pointer");
+    PRCNN_REQUIRE((((uintptr_t)src | (uintptr_t)out) & 15) == 0, "rows_gemm128_rows: 16-byte alignment required");
+    const long tiles = (r + PM_ROWS - 1) / PM_ROWS;              // at most: the list is on the device
+    const long grid = tiles < mfma_grid_cap() ? tiles : mfma_grid_cap();
+    if (relu) hipLaunchKernelGGL(rows_layer_list_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, src, ld, col, w, bias, out, rowmap, hdr);
+    else hipLaunchKernelGGL(rows_layer_list_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, src, ld, col, w, bias, out, rowmap, hdr);
+    return check_launch("rows_gemm128_rows");
 }
 
 // cnt (clouds) i32 -> rowmap (clouds * rows_per_cloud entries at most), hdr[1] = number of listed rows (hdr (4 u32) zeroed here unless

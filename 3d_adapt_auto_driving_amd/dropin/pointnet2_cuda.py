@@ -322,7 +322,7 @@ def rcnn_roi_geometry_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2):
 
 
 def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=None, hdr2=None, want_idx=True, row_clouds=False, hdr3=None,
-                                    group_all=False):
+                                    group_all=False, hdr_c1=None, centre_rows=False):
     """rcnn_roi_geometry_wrapper + the two levels' distinct-row lists out of the same launch (prcnn_rcnn_roi_geometry_packs) ->
     (new_xyz1, idx1, rep1, new_xyz2, idx2, rep2, pack1, pack2): pack1 == ball_pack_wrapper(idx1, xyz, new_xyz1, limit, None, rep1),
     pack2 == ball_pack_wrapper(idx2, new_xyz1, new_xyz2, None, rep1, rep2) -- the same rows per cloud, the same tiles.
@@ -332,7 +332,9 @@ def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=N
     cloud (packs with .tilecloud None: rows of all clouds back to back, no padded last tile per cloud) -- sa_packed_mlp_wrapper takes
     them, the other consumers of a BallPack do not.  group_all=True (with row_clouds; hdr3 as hdr1 / hdr2): a ninth value, the list of the
     GroupAll level above -- every cloud ONE group of its m2 level-2 centres, the copies among them dropped: the BallPack of the index
-    tensor (b, 1, m2) = 0 .. m2-1 around the origin with rep = rep2 (sa_wide_fused3_wrapper takes it, with new_xyz = zeros (b, 1, 3))."""
+    tensor (b, 1, m2) = 0 .. m2-1 around the origin with rep = rep2 (sa_wide_fused3_wrapper takes it, with new_xyz = zeros (b, 1, 3)).
+    centre_rows=True (hdr_c1 as the other headers): one more value at the end, (rowmap i32, hdr i32[4]) = the level-1 centres that are their
+    own representatives as rows cloud * m1 + centre, hdr[1] of them -- the list rows_gemm128_rows_wrapper takes."""
     _chk(torch.float32, xyz); _chk(torch.int32, limit)
     b, n, _ = xyz.shape
     dev = xyz.device
@@ -379,13 +381,21 @@ def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=N
         if hdr3 is not None:
             _chk(torch.int32, hdr3)
         p3.hdr = hdr3 if hdr3 is not None else torch.empty((4,), dtype=torch.int32, device=dev)
+    crows = None
+    if centre_rows:
+        if (hdr_c1 is None) != (hdr1 is None):
+            raise ValueError("rcnn_roi_geometry_packs: the centre rows' header comes like the others")
+        if hdr_c1 is not None:
+            _chk(torch.int32, hdr_c1)
+        crows = (torch.empty((b * m1,), dtype=torch.int32, device=dev), hdr_c1 if hdr_c1 is not None else torch.empty((4,), dtype=torch.int32, device=dev))
     _lib.call("prcnn_rcnn_roi_geometry_packs", b, n, m1, float(r1), ns1, m2, float(r2), ns2, xyz.data_ptr(), limit.data_ptr(), new1.data_ptr(),
               idx1.data_ptr() if want_idx else None, rep1.data_ptr(), new2.data_ptr(), idx2.data_ptr() if want_idx else None, rep2.data_ptr(),
               p1.rowinfo.data_ptr(), p1.rowdxyz.data_ptr(), _lib.ptr(p1.tilecloud), p1.hdr.data_ptr(),
               p2.rowinfo.data_ptr(), p2.rowdxyz.data_ptr(), _lib.ptr(p2.tilecloud), p2.hdr.data_ptr(),
               None if p3 is None else p3.rowinfo.data_ptr(), None if p3 is None else p3.rowdxyz.data_ptr(),
-              None if p3 is None else p3.hdr.data_ptr(), 1 if hdr1 is not None else 0, _lib.current_stream(xyz))
-    return (new1, idx1, rep1, new2, idx2, rep2, p1, p2) + ((p3,) if p3 is not None else ())
+              None if p3 is None else p3.hdr.data_ptr(), None if crows is None else crows[0].data_ptr(),
+              None if crows is None else crows[1].data_ptr(), 1 if hdr1 is not None else 0, _lib.current_stream(xyz))
+    return (new1, idx1, rep1, new2, idx2, rep2, p1, p2) + ((p3,) if p3 is not None else ()) + ((crows,) if crows is not None else ())
 
 
 def dup_rep_wrapper(sel, n, limit=None, prev=None):
@@ -756,6 +766,19 @@ def rcnn_point_mlp_wrapper(rows, fcol, wu1, bu1, wu2, bu2, wm, bm, wp, bp, xfeat
               _lib.ptr(merged), p.data_ptr(), None if tiles is None else tiles[0].data_ptr(),
               None if tiles is None else tiles[1].data_ptr(), _lib.current_stream(rows))
     return p
+
+
+def rows_gemm128_rows_wrapper(a, wt, bias, relu, out, rowlist):
+    """rows_gemm128_wrapper (K = 128) over a LIST of rows: out[r] = act(a[r] @ wt + bias) for r = rowmap[0 .. hdr[1]); the other rows of
+    `out` are left as they are (prcnn_rows_gemm128_rows)."""
+    if a.dim() != 2 or a.stride(1) != 1 or not a.is_cuda or a.dtype != torch.float32 or a.shape[1] != 128:
+        raise RuntimeError("pointnet2_cuda: rows_gemm128_rows expects a 2-D float32 CUDA matrix of 128 columns with unit column stride")
+    _chk(torch.float32, wt, bias, out)
+    rowmap, hdr = rowlist
+    _chk(torch.int32, rowmap, hdr)
+    _lib.call("prcnn_rows_gemm128_rows", a.shape[0], a.data_ptr(), a.stride(0), 0, wt.data_ptr(), bias.data_ptr(), int(bool(relu)), out.data_ptr(),
+              rowmap.data_ptr(), hdr.data_ptr(), _lib.current_stream(a))
+    return out
 
 
 def rows_gemm128_wrapper(a, wt, bias, relu, out=None):

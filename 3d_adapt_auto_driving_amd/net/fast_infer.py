@@ -48,6 +48,7 @@ USE_CENTRE_SKIP = os.environ.get("PRCNN_NO_CENTRE_SKIP") is None       # ... and
 # the six separate launches (A/B, same results)
 USE_ROI_GEOMETRY = os.environ.get("PRCNN_NO_ROI_GEOMETRY") is None
 USE_ROI_PACKS = os.environ.get("PRCNN_NO_ROI_PACKS") is None      # ... and their distinct-row lists out of the same launch (round 5)
+USE_CENTRE_ROWS = os.environ.get("PRCNN_NO_CENTRE_ROWS") is None  # the RCNN's second level: per-point layer over the representative level-1 centres only (round 5)
 USE_POOLED_ROWS = os.environ.get("PRCNN_NO_POOLED_ROWS") is None  # the RCNN entrance over the list of distinct pooled rows, not whole tiles per RoI (round 5)
 USE_POINT_LAYER = os.environ.get("PRCNN_LIB_GEMM") is None     # per-point layers (FP modules, heads) on the own MFMA layer kernel
 # every per-point width zero-padded to a multiple of 128 (SA level outputs, FP inputs, narrow head outputs), so that NO layer
@@ -1110,12 +1111,22 @@ class FastPointRCNN:
                 rc = all(m_[3].packed is not None for m_ in sa[:2])        # the consumers that read lists whose rows carry their cloud
                 # ... and, in that form, the list of the GroupAll level above them (one group per RoI: no clouds merged to fill tiles)
                 ga = bool(rc and hd and len(sa) == 3 and sa[2][0] is None and self._groupall_fused3_ok(sa[2][3], sa[1][3]))
+                # ... and the level-1 centres that are their own representatives as a row list: level 2's per-point layer over those rows only
+                cr = bool(rc and hd and USE_CENTRE_ROWS and has_entry(ext, "rows_gemm128_rows_wrapper") and sa[1][3].packed is not None
+                          and tuple(sa[1][3].packed[0].shape) == (128, 128))
+                extra = ()
+                if hd:
+                    extra = hd + (False, rc) + ((zhdr()[0], True) if ga else (None, False)) + ((zhdr()[0], True) if cr else ())
                 fused_geo = ext.rcnn_roi_geometry_packs_wrapper(cur_xyz, pooled_cnt.view(-1), sa[0][0], sa[0][1], sa[0][2], sa[1][0], sa[1][1],
-                                                                sa[1][2], *(hd + (False, rc) + ((zhdr()[0], True) if ga else ()) if hd else ()))
+                                                                sa[1][2], *extra)
             else:
                 fused_geo = ext.rcnn_roi_geometry_wrapper(cur_xyz, pooled_cnt.view(-1), sa[0][0], sa[0][1], sa[0][2], sa[1][0], sa[1][1], sa[1][2])
+        fused_p3 = next((x for x in (fused_geo or ())[8:] if hasattr(x, "rowinfo")), None)
+        fused_crows = next((x for x in (fused_geo or ())[8:] if isinstance(x, tuple)), None)
         for k, (npoint, radius, ns, mlp, cin) in enumerate(self.rcnn_sa):
             lev = {"xyz": cur_xyz, "new_xyz": None, "idx": None, "pack": None}
+            if k == 1 and fused_crows is not None:
+                lev["crows"] = fused_crows
             if npoint is not None and fused_geo is not None and k < 2:
                 new_xyz, idx, rep_out = fused_geo[3 * k:3 * k + 3]
                 if len(fused_geo) >= 8:
@@ -1157,14 +1168,14 @@ class FastPointRCNN:
                                    else ext.ball_pack_wrapper(idx, cur_xyz, new_xyz))
                 lev["new_xyz"], lev["idx"] = new_xyz, idx
                 cur_xyz = new_xyz
-            elif fused_geo is not None and len(fused_geo) == 9:
+            elif fused_p3 is not None:
                 # GroupAll over the list the fused launch wrote: every RoI one group (centre 0) of its own 32 centres
                 Bc, n = cur_xyz.shape[0], cur_xyz.shape[1]
                 cache = self.__dict__.setdefault("_groupall", {})
                 key = ("origin", Bc, str(cur_xyz.device))
                 if key not in cache:
                     cache[key] = torch.zeros((Bc, 1, 3), dtype=torch.float32, device=cur_xyz.device)
-                lev.update({"new_xyz": cache[key], "idx": fused_geo[8].idx, "pack": fused_geo[8], "f": 1})
+                lev.update({"new_xyz": cache[key], "idx": fused_p3.idx, "pack": fused_p3, "f": 1})
                 cur_xyz = None
             elif USE_PACKED and (mlp.packed is not None or mlp.wide is not None):
                 # GroupAll (pointnet2_utils.py:267-288): ONE group holding all n points, no centre subtraction == a ball
@@ -1250,7 +1261,13 @@ class FastPointRCNN:
                 Bc = cur_xyz.shape[0]
                 out = (arena["parts"][k].view(Bc, npoint, cout) if pre
                        else torch.empty((Bc, npoint, cout), dtype=torch.float32, device=cur_xyz.device))
-                self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, lev["idx"], mlp, cin, out, 0, P_pre=P_pre if first else None, pack=lev["pack"],
+                P_lev = P_pre if first else None
+                if lev.get("crows") is not None and not first and mlp.packed is not None and cur_feat.shape[2] == 128:
+                    # the level's per-point part P = f W1 + b1 over the rows its lists name (the centres that are their own representatives)
+                    P_lev = torch.empty((Bc * cur_xyz.shape[1], 128), dtype=torch.float32, device=cur_xyz.device)
+                    ext.rows_gemm128_rows_wrapper(cur_feat.view(-1, 128), mlp.packed[0], mlp.packed[2], False, P_lev, lev["crows"])
+                    P_lev = P_lev.view(Bc, cur_xyz.shape[1], 128)
+                self._sa_scale(cur_xyz, lev["new_xyz"], cur_feat, lev["idx"], mlp, cin, out, 0, P_pre=P_lev, pack=lev["pack"],
                                zeroed=pre)
             elif lev["pack"] is not None:                                       # GroupAll over f RoIs per "cloud" (see _rcnn_geometry)
                 f = lev["f"]

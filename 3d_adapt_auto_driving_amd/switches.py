@@ -57,6 +57,7 @@ SWITCHES = {
     "PRCNN_NO_POINT_MLP": ("ab", "unset", "net/fast_infer.py", "RCNN entrance as separate layers"),
     "PRCNN_NO_ROI_GEOMETRY": ("ab", "unset", "net/fast_infer.py", "RCNN sampling / ball queries as six launches"),
     "PRCNN_XYZ_MFMA": ("ab", "1", "csrc/sa_xyz_mlp.hip", "0: the wider scale of the coordinates-only RPN level on the VALU form (weights through scalar registers) instead of the matrix cores"),
+    "PRCNN_NO_CENTRE_ROWS": ("ab", "unset", "net/fast_infer.py", "the RCNN second level's per-point layer over all 128 level-1 centres of every RoI instead of the listed representatives"),
     "PRCNN_NO_POOLED_ROWS": ("ab", "unset", "net/fast_infer.py", "the RCNN entrance over whole 64-row tiles per RoI (prcnn_pooled_tiles) instead of the list of distinct pooled rows"),
     "PRCNN_NO_ROI_PACKS": ("ab", "unset", "net/fast_infer.py", "the RoI clouds' two row lists by prcnn_ball_pack_ex launches instead of inside prcnn_rcnn_roi_geometry_packs"),
     "PRCNN_NO_RPN_TAIL": ("ab", "unset", "net/fast_infer.py", "finest FP module and RPN heads layer by layer (the bits of the fused tail under PRCNN_NO_FP_LINEAR=1: the layer-by-layer form keeps the reference's association)"),

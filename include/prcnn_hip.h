@@ -241,12 +241,16 @@ int prcnn_rcnn_roi_geometry(int b, int n, int m1, float r1, int ns1, int m2, flo
  * (rcnn_net.py:64-92, SA_CONFIG.NPOINTS[2] = -1: one group of all m2 centres, no centre subtraction) -- per cloud a row (centre 0, point j)
  * for every level-2 centre j that is its own representative, relative coordinates = new_xyz2[j]: what
  * prcnn_ball_pack_ex(b, b, m2, 1, m2, {0 .. m2-1}, NULL, rep2, NULL, new_xyz2, zeros, ...) lists; prcnn_sa_wide_fused3 reads it (tilecloud NULL).
+ * crows1 / hdr_c1 (both or none): the level-1 centres that are their own representatives, as rows cloud * m1 + centre of a (b * m1)-row
+ * matrix, hdr_c1[1] of them: the list prcnn_rows_gemm128_rows takes for level 2's per-point layer (the other centres copy an earlier one:
+ * no row list names them, nobody reads their rows).
  * The reference has no counterpart: it groups all nsample rows (pointnet2_utils.py:241-264); see prcnn_ball_pack. */
 int prcnn_rcnn_roi_geometry_packs(int b, int n, int m1, float r1, int ns1, int m2, float r2, int ns2, const float *xyz,
                                   const int *limit, float *new_xyz1, int *idx1, int *rep1, float *new_xyz2, int *idx2, int *rep2,
                                   unsigned int *rowinfo1, float *rowdxyz1, int *tilecloud1, unsigned int *hdr1,
                                   unsigned int *rowinfo2, float *rowdxyz2, int *tilecloud2, unsigned int *hdr2,
-                                  unsigned int *rowinfo3, float *rowdxyz3, unsigned int *hdr3, int hdr_is_zero, void *stream);
+                                  unsigned int *rowinfo3, float *rowdxyz3, unsigned int *hdr3, int *crows1, unsigned int *hdr_c1,
+                                  int hdr_is_zero, void *stream);
 /* out_is_zero (this entry, prcnn_sa_xyz_mlp_packed, prcnn_packed_layer_segmax): the results arrive through atomicMax into a
  * zeroed slice; 0 = the entry zeroes out[..., out_col : out_col + width) itself, 1 = the caller has zeroed it (one fill for all
  * the scales of a level instead of one strided fill per scale). */
@@ -394,6 +398,10 @@ int prcnn_rcnn_point_mlp_rows(long r, int ld, int fcol, const float *rows, const
 /* One 128-wide shared-MLP / Conv1d layer (pytorch_utils.py:35-101 with BN folded) on the same tiled MFMA kernel:
  * out (r,128) = act(A0 w[0:128] [+ A1 w[128:256]] + bias), r % 64 == 0; A0 = src0 rows (128 floats at column col0, row
  * stride ld0), npanel = 2 adds A1 = src1 rows (col1, ld1): a K = 256 layer over two 128-wide halves. w k-major. */
+/* the same 128 -> 128 layer (npanel = 1) over a LIST of rows: out[r] = act(src[r] @ w + bias) for r = rowmap[0 .. hdr[1]), rows that are not
+ * listed are neither read nor written (round 5; per row the arithmetic of prcnn_rows_gemm128 / prcnn_packed_layer: same bits) */
+int prcnn_rows_gemm128_rows(long r, const float *src, int ld, int col, const float *w, const float *bias, int relu, float *out,
+                            const int *rowmap, const unsigned int *hdr, void *stream);
 int prcnn_rows_gemm128(long r, int npanel, const float *src0, int ld0, int col0, const float *src1, int ld1, int col1,
                        const float *w, const float *bias, int relu, float *out, void *stream);
 

@@ -224,7 +224,7 @@ class pointnet2_cpu:
 
     @staticmethod
     def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=None, hdr2=None, want_idx=True, row_clouds=False, hdr3=None,
-                                        group_all=False):
+                                        group_all=False, hdr_c1=None, centre_rows=False):
         """prcnn_rcnn_roi_geometry_packs as the chain of stand-ins it fuses: the geometry, then the two row lists"""
         P = pointnet2_cpu
         new1, idx1, rep1, new2, idx2, rep2 = P.rcnn_roi_geometry_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2)
@@ -234,6 +234,8 @@ class pointnet2_cpu:
             b = xyz.shape[0]
             ga = torch.arange(m2, dtype=torch.int32).view(1, 1, m2).expand(b, 1, m2).contiguous()
             out += (P.ball_pack_wrapper(ga, new2, torch.zeros((b, 1, 3)), None, rep2, None),)
+        if centre_rows:     # the CPU stand-in of the layer evaluates every row
+            out += (None,)
         return out
 
     @staticmethod
@@ -447,6 +449,10 @@ class pointnet2_cpu:
                                    _p(wu2, _f), _p(bu2, _f), _p(wm, _f), _p(bm, _f), _p(wp, _f), _p(bp, _f),
                                    _p(xfeat, _f), _p(merged, _f), _p(p, _f))
         return p
+
+    @staticmethod
+    def rows_gemm128_rows_wrapper(a, wt, bias, relu, out, rowlist):
+        return pointnet2_cpu.rows_gemm128_wrapper(a, wt, bias, relu, out)
 
     @staticmethod
     def rows_gemm128_wrapper(a, wt, bias, relu, out=None):

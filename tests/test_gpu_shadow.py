@@ -173,12 +173,19 @@ def check_roi_geometry_packs(self, name, args, host, ret):
         self._log["roi_idx_not_written"] += 1
     check_ball_pack(self, name, None, [idx1, host[0], new1, host[1], None, rep1], ret[6])
     check_ball_pack(self, name, None, [idx2, new1, new2, None, rep1, rep2], ret[7])
-    if len(ret) == 9:      # the GroupAll level's list: one group per RoI (all its level-2 centres around the origin), copies marked by rep2
+    if len(ret) > 8 and hasattr(ret[8], "rowinfo"):      # the GroupAll level's list: one group per RoI (all its level-2 centres around the origin), copies marked by rep2
         b, m2 = rep2.shape
         ga = torch.arange(m2, dtype=torch.int32).view(1, 1, m2).expand(b, 1, m2).contiguous()
         assert torch.equal(ret[8].idx.cpu(), ga) and torch.equal(ret[8].rep.cpu(), rep2)
         check_ball_pack(self, name, None, [ga, new2, torch.zeros((b, 1, 3)), None, rep2, None], ret[8])
         self._log["group_all_list_fused"] += 1
+    crows = next((x for x in ret[8:] if isinstance(x, tuple)), None)
+    if crows is not None:   # the level-1 centres that are their own representatives, as rows: exactly those with rep1[c] == c, each once
+        n = int(crows[1][1])
+        got_rows = torch.sort(crows[0][:n].cpu().long())[0]
+        own = (rep1 == torch.arange(rep1.shape[1]).view(1, -1)).nonzero()
+        assert torch.equal(got_rows, own[:, 0] * rep1.shape[1] + own[:, 1]), name
+        self._log["centre_rows_listed"] += 1
 
 
 def check_dup_rep(self, name, args, host, ret):
@@ -330,6 +337,25 @@ def check_rcnn_point_mlp_rows(self, name, args, host, ret):
 POINTNET2["rcnn_point_mlp_rows_wrapper"] = check_rcnn_point_mlp_rows
 
 
+def check_rows_gemm128_rows(self, name, args, host, ret):
+    """a 128-wide layer over a list of rows: the listed rows == the oracle's, bit for bit; the others untouched (the poisoned torch.empty
+    of this run: NaN)"""
+    a, wt, bias, relu = host[:4]
+    want = self._cpu.rows_gemm128_wrapper(a, wt, bias, relu)
+    rowmap, hdr = args[5]
+    n = int(hdr[1])
+    listed = rowmap[:n].cpu().long()
+    assert len(torch.unique(listed)) == n
+    got = args[4].detach().cpu()
+    assert torch.equal(got[listed], want[listed]), name
+    rest = torch.ones(got.shape[0], dtype=torch.bool); rest[listed] = False
+    assert torch.isnan(got[rest]).all(), name
+    self._log["rows_gemm_listed_x1000"] = int(1000 * n / got.shape[0])
+
+
+POINTNET2["rows_gemm128_rows_wrapper"] = check_rows_gemm128_rows
+
+
 def check_packed_segmax(self, name, args, host, ret):
     """last layer + pool: the oracle evaluates the layer on the GPU's packed rows and pools them by centre"""
     a, wt, bias, _, b, m, _, out_col = host[:8]
@@ -460,7 +486,8 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
                   "sa_xyz_mlp_packed_wrapper": 2, "sa_packed_mlp_wrapper": 2 if (F.USE_SCALE_BATCH and F.USE_SA2_BATCH) else 4, "sa_packed_mlp_batch_wrapper": 1 if (F.USE_SCALE_BATCH and F.USE_SA2_BATCH) else 0,
                   "three_interpolate_cat_pm_wrapper": 0 if F.USE_FP_LINEAR else 3, "packed_layer_interp_wrapper": 3 if F.USE_FP_LINEAR else 0,
                   "rpn_tail_wrapper": 0 if F.USE_FP_LINEAR else 1, "rpn_tail_lin_wrapper": 1 if F.USE_FP_LINEAR and not F.USE_TAIL_DECODE else 0,
-                  "rpn_tail_lin_boxes_wrapper": 1 if F.USE_FP_LINEAR and F.USE_TAIL_DECODE else 0, "rcnn_point_mlp_wrapper": 0 if F.USE_POOLED_ROWS else 1, "rcnn_point_mlp_rows_wrapper": 1 if F.USE_POOLED_ROWS else 0, "forward_canonical": 1}
+                  "rpn_tail_lin_boxes_wrapper": 1 if F.USE_FP_LINEAR and F.USE_TAIL_DECODE else 0, "rcnn_point_mlp_wrapper": 0 if F.USE_POOLED_ROWS else 1, "rcnn_point_mlp_rows_wrapper": 1 if F.USE_POOLED_ROWS else 0, "forward_canonical": 1,
+                  "rows_gemm128_rows_wrapper": 1 if (fp and F.USE_CENTRE_ROWS) else 0}
     want_calls.update({"packed_layer_segmax_batch_wrapper": 2, "packed_gather_affine_batch_wrapper": 2, "packed_layer_batch_wrapper": 6 if (F.USE_SCALE_BATCH and F.USE_SA2_BATCH) else 5})   # RPN SA3, SA4; the two branches of the RCNN head (round 4); RPN SA2's per-point parts (round 5)
     if wide_fused:       # the RCNN's GroupAll level (every row distinct: 800 units of work) in one kernel
         f3 = 1 if F.USE_WIDE_FUSED3 else 0   # ... and its per-point layer inside that kernel (csrc/sa_wide3.hip)
