@@ -321,6 +321,9 @@ def rcnn_roi_geometry_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2):
     return new1, idx1, rep1, new2, idx2, rep2
 
 
+_ARANGE = {}
+
+
 def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=None, hdr2=None, want_idx=True, row_clouds=False, hdr3=None,
                                     group_all=False, hdr_c1=None, centre_rows=False):
     """rcnn_roi_geometry_wrapper + the two levels' distinct-row lists out of the same launch (prcnn_rcnn_roi_geometry_packs) ->
@@ -372,7 +375,10 @@ def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=N
         if not row_clouds or (hdr3 is None) != (hdr1 is None):
             raise ValueError("rcnn_roi_geometry_packs: the GroupAll list comes in the row-carried form, its header like the others")
         p3 = BallPack()
-        p3.idx = torch.arange(m2, dtype=torch.int32, device=dev).view(1, 1, m2).expand(b, 1, m2)
+        key = (m2, str(dev))
+        if key not in _ARANGE:                               # (a constant of the shape: not a launch per call)
+            _ARANGE[key] = torch.arange(m2, dtype=torch.int32, device=dev)
+        p3.idx = _ARANGE[key].view(1, 1, m2).expand(b, 1, m2)
         p3.limit, p3.rep, p3.crep = None, rep2, None
         p3.rowinfo = torch.empty((b * m2,), dtype=torch.int32, device=dev)
         p3.rowdxyz = torch.empty((b * m2, 4), dtype=torch.float32, device=dev)
