@@ -503,6 +503,8 @@ def packed_layer_wrapper(a, wt, bias, relu, out, pack=None):
     n_store = out.size(1)                     # <= N: a narrow last layer whose weights were zero-padded to N
     if wt.size(0) != K or out.size(0) != R or n_store > N:
         raise RuntimeError("pointnet2_cuda: packed_layer shape mismatch")
+    if pack is not None and pack.tilecloud is None:
+        raise RuntimeError("pointnet2_cuda: packed_layer does not take a list whose rows carry their cloud (its tile count is not in hdr[0])")
     _lib.call("prcnn_packed_layer", None if pack is None else pack.hdr.data_ptr(), R, 0 if pack is None else pack.max_tiles,
               K, N, n_store, a.data_ptr(), a.stride(0), wt.data_ptr(), bias.data_ptr(), int(bool(relu)), out.data_ptr(), out.stride(0),
               _lib.current_stream(a))
