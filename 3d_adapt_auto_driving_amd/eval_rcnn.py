@@ -60,8 +60,11 @@ FUSED_POSTPROCESS = True     # final stage through the fused HIP entry when the 
 # Round 4: the final stage (decode + threshold + rotated NMS, 0.2 ms) runs BEHIND the RCNN features on the feature stream instead of
 # on the proposal stream: with the FP modules on the geometry streams (fast_infer.EARLY_FP = 3) the proposal stream -- proposal layer,
 # RoI pooling, the RoI clouds' geometry, final stage -- was the longest of the four, and the hop feature -> proposal -> host costs two
-# event waits.  PRCNN_FINAL_ON_FEATURE=0: as in round 3.
-FINAL_ON_FEATURE = os.environ.get("PRCNN_FINAL_ON_FEATURE", "1") != "0"
+# event waits.  Round 5, second session: back on the proposal stream by default -- with the pack launches, half of the RoI geometry and the
+# padded tiles gone that stream is busy 0.35-0.40 ms of a 0.97-ms step and the feature stream is the fullest (0.78): K = 20 7253 / 7238 /
+# 7226 -> 7323 / 7261 / 7256 scenes/s, LiDAR-shaped 5109 / 5134 / 5143 -> 5183 / 5175 / 5180 (three alternating runs of five windows each);
+# K = 100 unchanged.  PRCNN_FINAL_ON_FEATURE=1: behind the RCNN features on the feature stream (round 4).
+FINAL_ON_FEATURE = os.environ.get("PRCNN_FINAL_ON_FEATURE", "0") != "0"
 # batches of a geometry group that share the launches of the stages behind the geometry in the graphed runner (GraphedRunner.pair):
 # 2 (measured: 6040-6150 / 6980-7050 scenes/s at K = 20 / 100 against 5800-5860 / 6730-6750 with 1, LiDAR-shaped 4270-4350 / 4930-4970
 # against 4140-4160 / 4830; 4: 6060 / 6780 and 4330 / 4750); 1: every batch its own launches

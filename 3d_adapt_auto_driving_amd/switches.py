@@ -45,7 +45,7 @@ SWITCHES = {
     "PRCNN_EARLY_TAIL": ("ab", "0", "net/fast_infer.py", "1: the whole RPN tail with the geometry (round 4: slower, 6042 vs 6382)"),
     "PRCNN_NO_XYZ_EARLY": ("ab", "unset", "net/fast_infer.py", "1: no SA level rides with the geometry"),
     "PRCNN_NO_GROUP_SA": ("ab", "unset", "net/fast_infer.py", "1: early SA levels per batch instead of per geometry group"),
-    "PRCNN_FINAL_ON_FEATURE": ("ab", "1", "eval_rcnn.py", "0: final stage on the proposal stream (round 3)"),
+    "PRCNN_FINAL_ON_FEATURE": ("ab", "0", "eval_rcnn.py", "1: final stage behind the RCNN features on the feature stream (round 4's default); 0: on the proposal stream"),
     "PRCNN_NO_RCNN_SPLIT": ("ab", "unset", "eval_rcnn.py", "1: RCNN geometry on the feature stream"),
     "PRCNN_SIDE_PRIORITY": ("ab", "0", "eval_rcnn.py", "HIP priority of the side streams"),
     "PRCNN_TAIL_PRIORITY": ("ab", "0", "eval_rcnn.py", "HIP priority of the proposal stream"),
