@@ -32,7 +32,7 @@ class SaProblem(C.Structure):
     """prcnn_sa_problem (include/prcnn_hip.h)"""
     _fields_ = [("b", _I), ("n", _I), ("m", _I), ("c3", _I), ("max_tiles", C.c_long), ("P", _P), ("wxyz", _P), ("rowinfo", _P), ("rowdxyz", _P),
                 ("tilecloud", _P), ("hdr", _P), ("w2t", _P), ("b2", _P), ("w3t", _P), ("b3", _P), ("out", _P), ("out_stride", _I),
-                ("out_col", _I), ("out_is_zero", _I)]
+                ("out_col", _I), ("out_is_zero", _I), ("c1", _I), ("c2", _I)]
 
 
 # name -> argument types (return type is always int except where noted)

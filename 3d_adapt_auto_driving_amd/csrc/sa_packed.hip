@@ -194,6 +194,7 @@ struct SaPkProblem {
     const float *w2t, *b2, *w3t, *b3;
     float *out;
     int out_stride, out_col, lds_pool;
+    int c1, c2;                       // the real widths of layers 1 and 2 (the arrays are zero-padded to 128 whatever they are)
 };
 struct SaPkBatch {
     int nprob;
@@ -209,7 +210,178 @@ __device__ __forceinline__ void ticket_release3(unsigned int *rec)
     }
 }
 
-template <int NPROB>
+// Round 5, third session: the two scales of RPN SA2 (64-64-128 and 64-96-128 after the per-point layer; tools/cfgs/default.yaml's
+// SA_CONFIG.MLPS[1]) arrive zero-padded to 128-128-128, and the padded kernel spends 256 MFMAs per wave and tile where 96 / 160 carry
+// non-zero operands.  A padded chain is  acc = fma(a[s], w[s], acc); acc = fma(a[s + 64], w[s + 64], acc)  for s = 0..63 (the
+// instruction's two k values in that order); with zeros at k >= K a second step is  fma(0, 0, acc) = acc,  so the chain IS the
+// chain over the real k in this order:  K = 64: k = 0, 1, 2, ... 63;  K = 96: k = 0, 64, 1, 65, ... 31, 95, then 32, 33, ... 63.
+// Fed to the instruction as pairs -- K = 64: step s takes k = 2s (lanes 0-31) and 2s + 1 (lanes 32-63), 32 steps;  K = 96:
+// steps 0-31 as before (s, s + 64), then 16 steps (32 + 2u, 33 + 2u) -- the result is the padded chain's, bit for bit (an
+// accumulator of -0 would come out of fma(0, 0, -0) as +0: no chain that starts from +0 gets there short of products below
+// 1e-45).  Layer 2 of the 64-wide scale has 2 x 2 blocks of 32 x 32: one per wave; the 96-wide one leaves wave 3 idle.  The tile
+// builder works on 64 channels: 16 float4 chunks x 16 row slots, four rows per thread, ALL of them gathered one tile ahead.
+template <int C2>
+__device__ __forceinline__ void sa_pk128_narrow(const SaPkProblem &q, unsigned int *__restrict__ ticket, int tiles_per_wg, float *lds,
+                                                unsigned int *slot, int (*ctr)[PK_ROWS], float4 (*dxyz_s)[PK_ROWS])
+{
+    static_assert(C2 == 64 || C2 == 96, "layer 2 of RPN SA2");
+    float *A1 = lds, *Y1 = lds + PK_ROWS * PK_LD;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int n = q.n, m = q.m;
+    const unsigned int *__restrict__ hdr = q.hdr;
+    const float4 *__restrict__ rowdxyz = q.rowdxyz;
+    const float4 *__restrict__ P = q.P, *__restrict__ wxyz = q.wxyz;
+    const unsigned int *__restrict__ rowinfo = q.rowinfo;
+    const int *__restrict__ tilecloud = q.tilecloud;
+    const float *__restrict__ w2t = q.w2t, *__restrict__ b2 = q.b2, *__restrict__ w3t = q.w3t, *__restrict__ b3 = q.b3;
+    float *__restrict__ out = q.out;
+    const int out_stride = q.out_stride, out_col = q.out_col, lds_pool = q.lds_pool;
+    const long tiles = hdr[0];
+
+    __syncthreads();                                                  // (a second attempt reuses the slots and the tile buffers)
+    if (tid == 0) slot[0] = atomicAdd(ticket, 1u);
+    __syncthreads();
+    long t = slot[0];
+    if (t >= tiles) return;
+
+    constexpr int S3 = C2 / 2;                                        // MFMA steps of layer 3
+    const int cb2 = C2 == 64 ? (w & 1) : w, rb2 = w >> 1;             // layer 2: column block; C2 == 64: row block as well
+    float wf2[32], wf3[S3];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) wf2[s] = w2t[(long)(2 * s + h) * PK_C + 32 * cb2 + j];
+#pragma unroll
+    for (int s = 0; s < S3; ++s) {
+        const int k = C2 == 64 ? 2 * s + h : (s < 32 ? s + 64 * h : 32 + 2 * (s - 32) + h);
+        wf3[s] = w3t[(long)k * 128 + 32 * w + j];
+    }
+    const float bias2 = b2[32 * cb2 + j], bias3 = b3[32 * w + j];
+
+    const int chunk = tid & 15, r0 = tid >> 4;
+    const float4 wx = wxyz[chunk], wy = wxyz[32 + chunk], wz = wxyz[64 + chunk];
+    unsigned int info[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) info[i] = rowinfo[t * PK_ROWS + r0 + 16 * i];
+    int cloud = tilecloud[t];
+    if (tid < PK_ROWS) dxyz_s[0][tid] = rowdxyz[t * PK_ROWS + tid];
+    float4 pb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pb[i] = P[((long)cloud * n + (long)(info[i] & 0xffffu)) * (PK_C / 4) + chunk];
+    __syncthreads();
+
+    for (int served = 0; served < tiles_per_wg && t < tiles; ++served) {
+        const bool more = served + 1 < tiles_per_wg;
+        if (tid == 0) slot[(served + 1) & 1] = more ? atomicAdd(ticket, 1u) : 0xffffffffu;
+        int *cc = ctr[served & 1];
+        const float4 *dcur = dxyz_s[served & 1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 16 * i;
+            const float4 d = dcur[row];
+            const float4 v = affine_relu4(pb[i], wx, wy, wz, d.x, d.y, d.z);
+            *reinterpret_cast<float4 *>(A1 + row * PK_LD + 4 * chunk) = v;
+            if (chunk == 0) cc[row] = (int)((long)cloud * m + (long)(info[i] >> 16));
+        }
+        __syncthreads();
+        const long t_next = slot[(served + 1) & 1];
+        float4 dnext = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t_next < tiles) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) info[i] = rowinfo[t_next * PK_ROWS + r0 + 16 * i];
+            cloud = tilecloud[t_next];
+            if (tid < PK_ROWS) dnext = rowdxyz[t_next * PK_ROWS + tid];                    // in flight during layer 2
+        }
+
+        // ---- layer 2: K = 64 as 32 steps of (2s, 2s + 1)
+        if (C2 == 64) {
+            f32x16 acc = {0};
+            const float *ap = A1 + (32 * rb2 + j) * PK_LD + h;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[4 * g], wf2[2 * g], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[4 * g + 2], wf2[2 * g + 1], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                Y1[(32 * rb2 + row) * PK_LD + 32 * cb2 + j] = fmaxf(acc[r] + bias2, 0.f);
+            }
+        } else if (w < 3) {
+            f32x16 acc0 = {0}, acc1 = {0};
+            const float *a0p = A1 + j * PK_LD + h;
+            const float *a1p = A1 + (32 + j) * PK_LD + h;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0p[4 * g], wf2[2 * g], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1p[4 * g], wf2[2 * g], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0p[4 * g + 2], wf2[2 * g + 1], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1p[4 * g + 2], wf2[2 * g + 1], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                Y1[row * PK_LD + 32 * w + j] = fmaxf(acc0[r] + bias2, 0.f);
+                Y1[(32 + row) * PK_LD + 32 * w + j] = fmaxf(acc1[r] + bias2, 0.f);
+            }
+        }
+        if (tid < PK_ROWS && t_next < tiles) dxyz_s[(served + 1) & 1][tid] = dnext;   // ordered before the next builder by the barrier below
+        if (t_next < tiles) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)          // in flight during layer 3
+                pb[i] = P[((long)cloud * n + (long)(info[i] & 0xffffu)) * (PK_C / 4) + chunk];
+        }
+        __syncthreads();
+
+        // ---- layer 3 (K = C2) + segmented max over the tile's rows
+        {
+            f32x16 acc0 = {0}, acc1 = {0};
+            if (C2 == 96) {
+                const float *a0p = Y1 + j * PK_LD + 64 * h;
+                const float *a1p = Y1 + (32 + j) * PK_LD + 64 * h;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float4 a0 = *reinterpret_cast<const float4 *>(a0p + 4 * g);
+                    const float4 a1 = *reinterpret_cast<const float4 *>(a1p + 4 * g);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, wf3[4 * g + 0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, wf3[4 * g + 0], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, wf3[4 * g + 1], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, wf3[4 * g + 1], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, wf3[4 * g + 2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, wf3[4 * g + 2], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, wf3[4 * g + 3], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, wf3[4 * g + 3], acc1, 0, 0, 0);
+                }
+            }
+            {
+                constexpr int K0 = C2 == 96 ? 32 : 0, S0 = C2 == 96 ? 32 : 0;       // the (2u, 2u + 1) steps: k from K0, weights from S0
+                const float *a0p = Y1 + j * PK_LD + K0 + h;
+                const float *a1p = Y1 + (32 + j) * PK_LD + K0 + h;
+#pragma unroll
+                for (int g = 0; g < (S3 - S0) / 2; ++g) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0p[4 * g], wf3[S0 + 2 * g], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1p[4 * g], wf3[S0 + 2 * g], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0p[4 * g + 2], wf3[S0 + 2 * g + 1], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1p[4 * g + 2], wf3[S0 + 2 * g + 1], acc1, 0, 0, 0);
+                }
+            }
+            const int myc = cc[lane], prevc = cc[lane ? lane - 1 : 0];
+            const unsigned long long start = __ballot(lane == 0 || myc != prevc);       // the same word in every wave
+            if (!lds_pool || __popcll(start) <= PK_LDS_MIN) {
+                pk_segmented_max(acc0, acc1, cc, start, h, out, out_stride, out_col + 32 * w + j, bias3);
+            } else {
+                const float4 bias4 = *reinterpret_cast<const float4 *>(b3 + 4 * (tid & 31));
+                pk_park(acc0, acc1, A1, PK_LD, 32 * w + j, h);
+                lds_barrier();
+                pk_segmented_max_lds(A1, PK_LD, cc, tid, out, out_stride, out_col, bias4);
+                lds_barrier();                                 // the next builder rewrites A1
+            }
+        }
+        t = t_next;
+    }
+}
+
+template <int NPROB, bool NARROW = false>
 __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(const SaPkBatch batch, unsigned int *__restrict__ rec, int tiles_per_wg)
 {
     __shared__ float lds[2 * PK_ROWS * PK_LD];
@@ -232,6 +404,11 @@ __global__ __launch_bounds__(256, 2) void sa_packed_mlp128_kernel(const SaPkBatc
     for (int attempt = 0; attempt < NPROB; ++attempt) {
     const int pi = NPROB > 1 ? __builtin_amdgcn_readfirstlane(pi0 + attempt < NPROB ? pi0 + attempt : pi0 + attempt - NPROB) : 0;   // provably uniform: the problem's fields stay in SGPRs
     const SaPkProblem &q = batch.p[pi];
+    if (NARROW) {                                                     // the scales of RPN SA2: every problem of the launch has c1 = 64, c2 in {64, 96}
+        if (q.c2 == 64) sa_pk128_narrow<64>(q, rec + 2 * pi, tiles_per_wg, lds, slot, ctr, dxyz_s);
+        else sa_pk128_narrow<96>(q, rec + 2 * pi, tiles_per_wg, lds, slot, ctr, dxyz_s);
+        continue;
+    }
     const int n = q.n, m = q.m;
     const unsigned int *__restrict__ hdr = q.hdr;
     const float4 *__restrict__ rowdxyz = q.rowdxyz;
@@ -701,7 +878,7 @@ extern "C" int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, 
         SaPkBatch batch;
         batch.nprob = 1;
         batch.p[0] = SaPkProblem{n, m, hdr, (const float4 *)rowdxyz, (const float4 *)P, (const float4 *)wxyz, rowinfo, tilecloud, w2t, b2, w3t, b3,
-                                 out, out_stride, out_col, lds_pool};
+                                 out, out_stride, out_col, lds_pool, 128, 128};
         batch.p[1] = batch.p[0];
         hipLaunchKernelGGL(sa_packed_mlp128_kernel<1>, dim3(grid), dim3(256), 0, st, batch, ticket, per_wg);
     } else
@@ -718,9 +895,11 @@ extern "C" int prcnn_sa_packed_mlp_batch(int nprob, const prcnn_sa_problem *pr, 
     hipStream_t st = (hipStream_t)stream;
     static const int env_grid = getenv("PRCNN_SA_GRID") ? atoi(getenv("PRCNN_SA_GRID")) : 512;
     static const bool env_lds = !(getenv("PRCNN_SEGMAX_LDS") && atoi(getenv("PRCNN_SEGMAX_LDS")) == 0);
+    static const bool env_narrow = !(getenv("PRCNN_SA_NARROW") && atoi(getenv("PRCNN_SA_NARROW")) == 0);
     SaPkBatch batch;
     batch.nprob = nprob;
     long most = 0;
+    int narrow = 0;
     for (int i = 0; i < nprob; ++i) {
         const prcnn_sa_problem &q = pr[i];
         PRCNN_REQUIRE(q.b >= 0 && q.n >= 0 && q.m >= 0 && q.max_tiles >= 0 && q.c3 == 128, "sa_packed_mlp_batch: bad sizes (c3 = 128 only)");
@@ -735,7 +914,10 @@ extern "C" int prcnn_sa_packed_mlp_batch(int nprob, const prcnn_sa_problem *pr, 
         }
         const int lds_pool = env_lds && (((uintptr_t)q.out | (uintptr_t)q.b3) & 15) == 0 && q.out_stride % 4 == 0 && q.out_col % 4 == 0;
         batch.p[i] = SaPkProblem{q.n, q.m, q.hdr, (const float4 *)q.rowdxyz, (const float4 *)q.P, (const float4 *)q.wxyz, q.rowinfo, q.tilecloud,
-                                 q.w2t, q.b2, q.w3t, q.b3, q.out, q.out_stride, q.out_col, lds_pool};
+                                 q.w2t, q.b2, q.w3t, q.b3, q.out, q.out_stride, q.out_col, lds_pool, 128, 128};
+        // the real widths of a zero-padded problem (0 = 128): 64-64 and 64-96 have kernels of their own (PRCNN_SA_NARROW=0: the padded one)
+        PRCNN_REQUIRE((q.c1 == 0 || (q.c1 >= 1 && q.c1 <= 128)) && (q.c2 == 0 || (q.c2 >= 1 && q.c2 <= 128)), "sa_packed_mlp_batch: bad widths c1=%d c2=%d", q.c1, q.c2);
+        if (env_narrow && nprob == 2 && q.c1 == 64 && (q.c2 == 64 || q.c2 == 96)) { batch.p[i].c1 = 64; batch.p[i].c2 = q.c2; ++narrow; }
         most = q.max_tiles > most ? q.max_tiles : most;
     }
     if (nprob == 1) batch.p[1] = batch.p[0];
@@ -749,6 +931,7 @@ extern "C" int prcnn_sa_packed_mlp_batch(int nprob, const prcnn_sa_problem *pr, 
     unsigned int *ticket = next_ticket(st);
     if (!ticket) { set_error("sa_packed_mlp_batch: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
     if (nprob == 1) hipLaunchKernelGGL(sa_packed_mlp128_kernel<1>, dim3((unsigned)grid1), dim3(256), 0, st, batch, ticket, per_wg);
+    else if (narrow == 2) hipLaunchKernelGGL((sa_packed_mlp128_kernel<2, true>), dim3((unsigned)(grid1 * nprob)), dim3(256), 0, st, batch, ticket, per_wg);
     else hipLaunchKernelGGL(sa_packed_mlp128_kernel<2>, dim3((unsigned)(grid1 * nprob)), dim3(256), 0, st, batch, ticket, per_wg);
     return check_launch("sa_packed_mlp_batch");
 }

@@ -465,9 +465,12 @@ def sa_packed_mlp_wrapper(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, ou
 
 def sa_packed_mlp_batch_wrapper(problems):
     """sa_packed_mlp_wrapper for the (up to two) 128-wide scales of one MSG level in ONE launch (round 5):
-    [(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col, zeroed), ...]; same results as one call per problem."""
+    [(new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col, zeroed[, (c1, c2)]), ...]; same results as one call per problem.
+    (c1, c2): the real widths of layers 1 and 2 under the zero padding -- 64-64 and 64-96 (RPN SA2) skip the padding's MFMAs, same bits."""
     arr = (_lib.SaProblem * len(problems))()
-    for q, (new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col, zeroed) in zip(arr, problems):
+    for q, prob in zip(arr, problems):
+        new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col, zeroed = prob[:12]
+        q.c1, q.c2 = (int(v) for v in prob[12]) if len(prob) > 12 and prob[12] is not None else (0, 0)
         _chk(torch.float32, new_xyz, xyz, P, wxyz, w2t, b2, w3t, b3, out)
         b, n, c1 = P.shape
         if c1 != 128 or w2t.shape != (128, 128) or tuple(w3t.shape) != (128, 128):

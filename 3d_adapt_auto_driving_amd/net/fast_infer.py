@@ -277,6 +277,7 @@ class _Mlp:
             if c1 <= 128 and c2 <= 128 and c3 in (128, 256) and w2.shape[0] == c1 and w3.shape[0] == c2:
                 self.packed = (_pad2(wf, kin, 128), _pad2(wx, 3, 128), _pad1(b1, 128),
                                _pad2(w2, 128, 128), _pad1(b2, 128), _pad2(w3, 128, c3), b3)
+                self.packed_widths = (c1, c2)                          # what the padding hides (the batched kernel skips it)
             elif c3 % 128 == 0 and w2.shape[0] == c1 and w3.shape[0] == c2:
                 # wider levels: layer by layer over the packed rows (csrc/packed_layer.hip), widths padded to 128s
                 c1p, c2p = _round128(c1), _round128(c2)
@@ -777,7 +778,7 @@ class FastPointRCNN:
             probs, col = [], 0
             for (radius, ns, mlp, cin), pack, P in zip(scales, packs, Ps):
                 wf, wx, b1, w2, b2, w3, b3 = mlp.packed
-                probs.append((lev["new_xyz"], cur_xyz, P.view(B, N, 128), wx, pack, w2, b2, w3, b3, out, col, pre))
+                probs.append((lev["new_xyz"], cur_xyz, P.view(B, N, 128), wx, pack, w2, b2, w3, b3, out, col, pre, mlp.packed_widths))
                 col += mlp.layers[-1][0].shape[1]
             ext.sa_packed_mlp_batch_wrapper(probs)
         else:

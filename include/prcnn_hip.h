@@ -312,6 +312,8 @@ typedef struct prcnn_sa_problem {
     int b, n, m, c3; long max_tiles; const float *P; const float *wxyz; const unsigned int *rowinfo; const float *rowdxyz;
     const int *tilecloud; const unsigned int *hdr; const float *w2t; const float *b2; const float *w3t; const float *b3;
     float *out; int out_stride, out_col, out_is_zero;
+    int c1, c2;     /* the REAL widths of layers 1 and 2 when the 128-wide arrays are zero-padded (0 = 128): 64-64 and 64-96, the scales of
+                     * RPN SA2 (tools/cfgs/default.yaml SA_CONFIG.MLPS[1]), skip the padding's MFMAs -- same bits as the padded chain */
 } prcnn_sa_problem;
 int prcnn_sa_packed_mlp_batch(int nprob, const prcnn_sa_problem *problems, void *stream);
 int prcnn_packed_gather_affine_batch(int nprob, const prcnn_gather_problem *problems, void *stream);

@@ -326,7 +326,7 @@ class pointnet2_cpu:
 
     @staticmethod
     def sa_packed_mlp_batch_wrapper(problems):
-        return [pointnet2_cpu.sa_packed_mlp_wrapper(*p) for p in problems]
+        return [pointnet2_cpu.sa_packed_mlp_wrapper(*p[:12]) for p in problems]     # p[12] = the widths under the padding: the padded chain is the definition
 
     @staticmethod
     def packed_gather_affine_batch_wrapper(problems):

@@ -74,6 +74,52 @@ def test_fused_mfma_kernel_is_bit_exact_vs_the_fma_chain_oracle(ext, c3):
     assert not torch.equal(other, want)
 
 
+@pytest.mark.parametrize("mean_cnt", [1.5, 9, 40])
+@pytest.mark.parametrize("col", [0, 5])
+def test_narrow_scales_skip_the_padding_and_keep_its_bits(ext, mean_cnt, col):
+    """RPN SA2's scales (64-64-128, 64-96-128; cfgs/default.yaml SA_CONFIG.MLPS[1]) arrive zero-padded to 128-128-128; told the real
+    widths, the batched launch feeds only the real k to the MFMAs (csrc/sa_packed.hip sa_pk128_narrow) -- the same bits as the padded
+    kernel one problem at a time, and as the oracle's padded chain over all nsample rows"""
+    rng = np.random.default_rng(int(77 + 10 * mean_cnt + col))
+    b, n, m = 5, 700, 61
+    xyz = T(rng.uniform(-2, 2, (b, n, 3)).astype(np.float32))
+    new_xyz = T(rng.uniform(-2, 2, (b, m, 3)).astype(np.float32))
+    width = col + 256
+    probs, idxs = [], []
+    for c2, ns, c0 in ((64, 16, col), (96, 32, col + 128)):
+        def padded(a, shape):
+            o = np.zeros(shape, np.float32)
+            o[tuple(slice(0, d) for d in a.shape)] = a
+            return T(o)
+        P = padded(rng.standard_normal((b, n, 64)).astype(np.float32), (b, n, 128))
+        wx = padded((rng.standard_normal((3, 64)) * 0.5).astype(np.float32), (3, 128))
+        w2 = padded((rng.standard_normal((64, c2)) / 8).astype(np.float32), (128, 128))
+        b2 = padded(rng.standard_normal(c2).astype(np.float32) * 0.1, (128,))
+        w3 = padded((rng.standard_normal((c2, 128)) / 8).astype(np.float32), (128, 128))
+        b3 = T(rng.standard_normal(128).astype(np.float32) * 0.1)
+        idx = T(ball_like_idx(rng, b, m, n, ns, min(mean_cnt, ns / 2))[0])
+        pk = ext.pointnet2.ball_pack_wrapper(idx, xyz, new_xyz)
+        probs.append([new_xyz, xyz, P, wx, pk, w2, b2, w3, b3, None, c0, True, (64, c2)])
+        idxs.append(idx)
+    outs = {}
+    for name in ("narrow", "padded_batch", "single"):
+        out = torch.zeros((b, m, width), device=DEV)
+        for q in probs:
+            q[9] = out
+        if name == "single":
+            for q in probs:
+                ext.pointnet2.sa_packed_mlp_wrapper(*q[:12])
+        else:
+            ext.pointnet2.sa_packed_mlp_batch_wrapper([tuple(q) if name == "narrow" else tuple(q[:12]) for q in probs])
+        outs[name] = out.cpu()
+    assert torch.equal(outs["padded_batch"], outs["single"])
+    assert torch.equal(outs["narrow"], outs["single"]), float((outs["narrow"] - outs["single"]).abs().max())
+    for q, idx in zip(probs, idxs):
+        want = oracle_fused(new_xyz, xyz, q[2], q[3], idx, q[5], q[6], q[7], q[8], width, q[10])
+        assert torch.equal(outs["narrow"][..., q[10]:q[10] + 128], want[..., q[10]:q[10] + 128])
+    assert float(outs["narrow"].abs().max()) > 0
+
+
 @pytest.mark.parametrize("c3", [128, 256])
 @pytest.mark.parametrize("mean_cnt", [1.5, 9, 40])
 @pytest.mark.parametrize("col", [4, 5])
