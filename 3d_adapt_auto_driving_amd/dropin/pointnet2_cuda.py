@@ -471,9 +471,19 @@ def sa_packed_mlp_batch_wrapper(problems):
     for q, prob in zip(arr, problems):
         new_xyz, xyz, P, wxyz, pack, w2t, b2, w3t, b3, out, out_col, zeroed = prob[:12]
         q.c1, q.c2 = (int(v) for v in prob[12]) if len(prob) > 12 and prob[12] is not None else (0, 0)
-        _chk(torch.float32, new_xyz, xyz, P, wxyz, w2t, b2, w3t, b3, out)
+        _chk(torch.float32, new_xyz, xyz, wxyz, w2t, b2, w3t, b3, out)
         b, n, c1 = P.shape
-        if c1 != 128 or w2t.shape != (128, 128) or tuple(w3t.shape) != (128, 128):
+        if c1 == 64:
+            # a 64-column slice of a (b, n, 128) tensor that holds the per-point parts of BOTH scales side by side: the narrow
+            # kernel reads 64 columns of a 128-float row, the padded one would read its neighbour's
+            if not (P.is_cuda and P.dtype == torch.float32 and P.stride() == (n * 128, 128, 1) and P.data_ptr() % 16 == 0):
+                raise RuntimeError("pointnet2_cuda: sa_packed_mlp_batch: a 64-wide P must be a column slice of a contiguous (b, n, 128) tensor")
+            if not (len(problems) == 2 and all(len(pp) > 12 and pp[12] is not None and pp[12][0] == 64 and pp[12][1] in (64, 96) for pp in problems)
+                    and os.environ.get("PRCNN_SA_NARROW", "1") != "0"):
+                raise RuntimeError("pointnet2_cuda: sa_packed_mlp_batch: a 64-wide P needs two problems of real widths 64-64 / 64-96 (and PRCNN_SA_NARROW != 0)")
+        else:
+            _chk(torch.float32, P)
+        if c1 not in (64, 128) or w2t.shape != (128, 128) or tuple(w3t.shape) != (128, 128):
             raise RuntimeError("pointnet2_cuda: sa_packed_mlp_batch takes 128-128-128 (zero-padded) problems")
         q.b, q.n, q.m, q.c3, q.max_tiles = b, n, new_xyz.size(1), 128, pack.max_tiles
         q.P, q.wxyz, q.rowinfo, q.rowdxyz = P.data_ptr(), wxyz.data_ptr(), pack.rowinfo.data_ptr(), pack.rowdxyz.data_ptr()

@@ -59,6 +59,7 @@ USE_RPN_TAIL = os.environ.get("PRCNN_NO_RPN_TAIL") is None
 # the scales of a wide MSG level (RPN SA3 / SA4) stage by stage, side by side in one launch per stage; PRCNN_NO_SCALE_BATCH=1: A/B
 USE_SCALE_BATCH = os.environ.get("PRCNN_NO_SCALE_BATCH") is None
 # layers 1-3 + pool of a wide scale in one kernel (csrc/sa_wide.hip); PRCNN_NO_WIDE_FUSED=1: gather / layer / layer+pool launches
+USE_SA_NARROW = os.environ.get("PRCNN_SA_NARROW", "1") != "0"        # RPN SA2's scales without their zero padding (csrc/sa_packed.hip), their per-point parts in one product
 USE_SA2_BATCH = os.environ.get("PRCNN_NO_SA2_BATCH") is None        # the two 128-wide scales of an MSG level (RPN SA2) in one launch per stage (round 5)
 USE_WIDE_FUSED = os.environ.get("PRCNN_NO_WIDE_FUSED") is None
 # ... and layer 1 inside as well where a level groups every point once (the RCNN's GroupAll level; csrc/sa_wide3.hip);
@@ -773,12 +774,26 @@ class FastPointRCNN:
             ext = pu.pointnet2
             B, N, _ = cur_xyz.shape
             flat = cur_feat.view(B * N, cur_feat.shape[2])
-            Ps = [torch.empty((B * N, 128), dtype=torch.float32, device=cur_xyz.device) for _ in scales]
-            ext.packed_layer_batch_wrapper([(flat, sc[2].packed[0], sc[2].packed[2], False, P, None) for sc, P in zip(scales, Ps)])
+            if (USE_SA_NARROW and all(sc[2].packed_widths[0] == 64 and sc[2].packed_widths[1] in (64, 96) for sc in scales)
+                    and getattr(ext, "IS_HIP_EXTENSION", False)):
+                # both scales' first layers are 64 wide under their padding to 128 (RPN SA2): their per-point parts side by side in ONE
+                # 128-wide product (a column's chain does not depend on its neighbours: same bits), half the flops and bytes of two
+                # padded ones; the narrow kernel reads its 64 columns out of the shared rows
+                m0 = scales[0][2]
+                if getattr(m0, "_pcat", None) is None or m0._pcat[2] is not scales[1][2].packed[0]:
+                    m0._pcat = (torch.cat([sc[2].packed[0][:, :64] for sc in scales], 1).contiguous(),
+                                torch.cat([sc[2].packed[2][:64] for sc in scales]).contiguous(), scales[1][2].packed[0])
+                Pcat = torch.empty((B * N, 128), dtype=torch.float32, device=cur_xyz.device)
+                ext.packed_layer_wrapper(flat, m0._pcat[0], m0._pcat[1], False, Pcat)
+                Ps = [Pcat.view(B, N, 128)[:, :, 64 * k:64 * k + 64] for k in range(2)]
+            else:
+                Ps = [torch.empty((B * N, 128), dtype=torch.float32, device=cur_xyz.device) for _ in scales]
+                ext.packed_layer_batch_wrapper([(flat, sc[2].packed[0], sc[2].packed[2], False, P, None) for sc, P in zip(scales, Ps)])
+                Ps = [P.view(B, N, 128) for P in Ps]
             probs, col = [], 0
             for (radius, ns, mlp, cin), pack, P in zip(scales, packs, Ps):
                 wf, wx, b1, w2, b2, w3, b3 = mlp.packed
-                probs.append((lev["new_xyz"], cur_xyz, P.view(B, N, 128), wx, pack, w2, b2, w3, b3, out, col, pre, mlp.packed_widths))
+                probs.append((lev["new_xyz"], cur_xyz, P, wx, pack, w2, b2, w3, b3, out, col, pre, mlp.packed_widths))
                 col += mlp.layers[-1][0].shape[1]
             ext.sa_packed_mlp_batch_wrapper(probs)
         else:

@@ -56,7 +56,7 @@ SWITCHES = {
     "PRCNN_NO_POOL_GROUPS": ("ab", "unset", "net/fast_infer.py", "RoI pooling sweeps all points (no spatial groups)"),
     "PRCNN_NO_POINT_MLP": ("ab", "unset", "net/fast_infer.py", "RCNN entrance as separate layers"),
     "PRCNN_NO_ROI_GEOMETRY": ("ab", "unset", "net/fast_infer.py", "RCNN sampling / ball queries as six launches"),
-    "PRCNN_SA_NARROW": ("ab", "1", "csrc/sa_packed.hip", "0: the two scales of RPN SA2 (64-64-128, 64-96-128) through the kernel that multiplies their zero padding up to 128-128-128 as well"),
+    "PRCNN_SA_NARROW": ("ab", "1", "csrc/sa_packed.hip", "0: the two scales of RPN SA2 (64-64-128, 64-96-128) through the kernel that multiplies their zero padding up to 128-128-128 as well, their per-point parts as two padded 128-wide products instead of one (also read by net/fast_infer.py, dropin/pointnet2_cuda.py)"),
     "PRCNN_XYZ_MFMA": ("ab", "1", "csrc/sa_xyz_mlp.hip", "0: the wider scale of the coordinates-only RPN level on the VALU form (weights through scalar registers) instead of the matrix cores"),
     "PRCNN_NO_CENTRE_ROWS": ("ab", "unset", "net/fast_infer.py", "the RCNN second level's per-point layer over all 128 level-1 centres of every RoI instead of the listed representatives"),
     "PRCNN_NO_POOLED_ROWS": ("ab", "unset", "net/fast_infer.py", "the RCNN entrance over whole 64-row tiles per RoI (prcnn_pooled_tiles) instead of the list of distinct pooled rows"),

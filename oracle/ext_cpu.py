@@ -326,7 +326,11 @@ class pointnet2_cpu:
 
     @staticmethod
     def sa_packed_mlp_batch_wrapper(problems):
-        return [pointnet2_cpu.sa_packed_mlp_wrapper(*p[:12]) for p in problems]     # p[12] = the widths under the padding: the padded chain is the definition
+        # p[12] = the widths under the padding: the padded chain is the definition; a 64-wide P (a column slice of the tensor that holds
+        # both scales' per-point parts) is that chain's P without its zero columns
+        def pad(P):
+            return P.contiguous() if P.shape[2] == 128 else torch.cat([P, torch.zeros_like(P)], 2).contiguous()
+        return [pointnet2_cpu.sa_packed_mlp_wrapper(*(tuple(p[:2]) + (pad(p[2]),) + tuple(p[3:12]))) for p in problems]
 
     @staticmethod
     def packed_gather_affine_batch_wrapper(problems):

@@ -114,6 +114,13 @@ def test_narrow_scales_skip_the_padding_and_keep_its_bits(ext, mean_cnt, col):
         outs[name] = out.cpu()
     assert torch.equal(outs["padded_batch"], outs["single"])
     assert torch.equal(outs["narrow"], outs["single"]), float((outs["narrow"] - outs["single"]).abs().max())
+    # the engine's form: both scales' per-point parts side by side in ONE (b, n, 128) tensor, each problem reading its 64 columns
+    pcat = torch.cat([q[2][:, :, :64] for q in probs], 2).contiguous()
+    out = torch.zeros((b, m, width), device=DEV)
+    ext.pointnet2.sa_packed_mlp_batch_wrapper([tuple(q[:2]) + (pcat[:, :, 64 * k:64 * k + 64],) + tuple(q[3:9]) + (out,) + tuple(q[10:]) for k, q in enumerate(probs)])
+    assert torch.equal(out.cpu(), outs["single"])
+    with pytest.raises(RuntimeError):          # a 64-wide P without the widths would be read as 128 columns
+        ext.pointnet2.sa_packed_mlp_batch_wrapper([tuple(q[:2]) + (pcat[:, :, 64 * k:64 * k + 64],) + tuple(q[3:9]) + (out,) + tuple(q[10:12]) for k, q in enumerate(probs)])
     for q, idx in zip(probs, idxs):
         want = oracle_fused(new_xyz, xyz, q[2], q[3], idx, q[5], q[6], q[7], q[8], width, q[10])
         assert torch.equal(outs["narrow"][..., q[10]:q[10] + 128], want[..., q[10]:q[10] + 128])

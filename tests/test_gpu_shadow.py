@@ -418,7 +418,7 @@ POINTNET2["packed_layer_batch_wrapper"] = batched(check_packed_layer)
 def check_sa_packed_slice(self, name, args, host, ret):
     """one problem of sa_packed_mlp_batch_wrapper (both scales of RPN SA2 in one launch, round 5): the problems share the output
     tensor, each owns a column slice -- the oracle over all nsample rows fills its slice of a host copy, compared bit for bit"""
-    self._cpu.sa_packed_mlp_wrapper(*host[:12])             # host[12]: the real widths under the padding (the padded chain is the definition)
+    self._cpu.sa_packed_mlp_batch_wrapper([tuple(host)])   # host[12]: the real widths under the padding (the padded chain is the definition; a 64-wide P is padded back)
     c0, width = host[10], host[7].shape[1]
     got, want = args[9].detach().cpu()[..., c0:c0 + width], host[9][..., c0:c0 + width]
     assert getattr(args[4], "crep", None) is None
@@ -488,7 +488,7 @@ def test_batch8_step_every_kernel_call_equals_the_oracle(wide_fused, scene_kind,
                   "rpn_tail_wrapper": 0 if F.USE_FP_LINEAR else 1, "rpn_tail_lin_wrapper": 1 if F.USE_FP_LINEAR and not F.USE_TAIL_DECODE else 0,
                   "rpn_tail_lin_boxes_wrapper": 1 if F.USE_FP_LINEAR and F.USE_TAIL_DECODE else 0, "rcnn_point_mlp_wrapper": 0 if F.USE_POOLED_ROWS else 1, "rcnn_point_mlp_rows_wrapper": 1 if F.USE_POOLED_ROWS else 0, "forward_canonical": 1,
                   "rows_gemm128_rows_wrapper": 1 if (fp and F.USE_CENTRE_ROWS) else 0}
-    want_calls.update({"packed_layer_segmax_batch_wrapper": 2, "packed_gather_affine_batch_wrapper": 2, "packed_layer_batch_wrapper": 6 if (F.USE_SCALE_BATCH and F.USE_SA2_BATCH) else 5})   # RPN SA3, SA4; the two branches of the RCNN head (round 4); RPN SA2's per-point parts (round 5)
+    want_calls.update({"packed_layer_segmax_batch_wrapper": 2, "packed_gather_affine_batch_wrapper": 2, "packed_layer_batch_wrapper": 6 if (F.USE_SCALE_BATCH and F.USE_SA2_BATCH and not F.USE_SA_NARROW) else 5})   # RPN SA3, SA4; the two branches of the RCNN head (round 4); RPN SA2's per-point parts (round 5; one plain product for both scales with the narrow kernel)
     if wide_fused:       # the RCNN's GroupAll level (every row distinct: 800 units of work) in one kernel
         f3 = 1 if F.USE_WIDE_FUSED3 else 0   # ... and its per-point layer inside that kernel (csrc/sa_wide3.hip)
         want_calls.update({"sa_wide_fused3_wrapper": f3, "sa_wide_fused_wrapper": 1 - f3, "packed_layer_segmax_wrapper": 0, "packed_gather_affine_wrapper": 0})
