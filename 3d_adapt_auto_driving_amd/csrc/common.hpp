@@ -126,6 +126,15 @@ __device__ __forceinline__ float atan2_f32(float y, float x) { return (float)ata
 // result of an arithmetic instruction (a register-resident running minimum, a v_readlane, a bitcast) the backend puts a canonicalising
 // `v_max_f32 x, x, x` in front -- sNaN quieting the hardware instruction does by itself in the IEEE mode compute kernels run in: 944 of the
 // 6435 instructions of fps_spec_kernel<16> were that, 164 of the 2500 of sa_packed_mlp128_kernel (the pooling epilogues' maxima over MFMA results).  Same results for every input including quiet NaNs (the non-NaN operand is returned).
+// PRECONDITIONS: (1) the kernel runs in IEEE mode (the default of every HIP compute kernel; `amdgpu-ieee=false` is not used
+// anywhere in this build): that is what quiets a signalling NaN inside v_min / v_max -- for an sNaN operand the instruction then returns
+// the QUIETED NaN where canonicalize + minnum would return the other operand, the one input class on which the two forms differ; no caller
+// feeds one (operands are distances, running minima initialised to 1e10 / +-inf, MFMA results); (2) gfx9 encodings: this library is built
+// for gfx950 only (csrc/Makefile), the #error below keeps it that way.  The asm is not volatile on purpose (pure function of its inputs:
+// the compiler may CSE and schedule it); it hides the operation from constant folding, which no call site needs.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "fmin_raw / fmax_raw are written for the gfx9 VOP2 encodings (this library targets gfx950)"
+#endif
 __device__ __forceinline__ float fmin_raw(float a, float b)
 {
     float r;

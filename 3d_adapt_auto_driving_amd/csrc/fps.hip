@@ -13,6 +13,8 @@
 #include "common.hpp"
 #include <math.h>
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 
 namespace prcnn {
 
@@ -791,6 +793,15 @@ __device__ __forceinline__ float ld_agent_f32(const float *p)
     return __int_as_float(__hip_atomic_load(reinterpret_cast<const int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+__device__ __forceinline__ void st_agent_u64(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent_f32(float *p, float v)
+{
+    __hip_atomic_store(reinterpret_cast<int *>(p), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(1024) void fps_spec2_kernel(
     int nclouds, int n, int m, KeyCodec kc, const float *__restrict__ xyz, const int *__restrict__ perm,
     float *__restrict__ temp, int *__restrict__ idx, float *__restrict__ new_xyz, Fps2Table *__restrict__ tables)
@@ -938,16 +949,28 @@ __global__ __launch_bounds__(1024) void fps_spec2_kernel(
         const int par = (int)(round & 1u);
         if (lane < 2) {                                               // (the same lanes wrote the LDS copy: program order)
             const int e = 2 * gw + lane, le = 2 * w + lane;
-            tb->vk[par][e] = s_evk[le];
-            tb->xyz[par][e][0] = s_exyz[le][0]; tb->xyz[par][e][1] = s_exyz[le][1]; tb->xyz[par][e][2] = s_exyz[le][2];
-            if (lane == 0) tb->bound[par][gw] = s_eb[w];
+            st_agent_u64(&tb->vk[par][e], s_evk[le]);
+            st_agent_f32(&tb->xyz[par][e][0], s_exyz[le][0]); st_agent_f32(&tb->xyz[par][e][1], s_exyz[le][1]);
+            st_agent_f32(&tb->xyz[par][e][2], s_exyz[le][2]);
+            if (lane == 0) st_agent_f32(&tb->bound[par][gw], s_eb[w]);
         }
-        // ---- the round's cross-workgroup barrier: both halves have published
+        // ---- the round's cross-workgroup barrier: both halves have published.  EVERY wave releases its own table stores at agent
+        // scope before the workgroup barrier (a workgroup barrier orders nothing beyond the workgroup, and thread 0's release
+        // covers only what has reached the L2 by then) -- what OCKL's grid sync does; the stores themselves are agent-scope
+        // write-throughs, so the fence finds nothing dirty to write back
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         if (t == 0) {
             __hip_atomic_fetch_add(&tb->sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned int want = 2u * (round + 1u);
-            while (__hip_atomic_load(&tb->sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+            // bounded: the host side only launches grids that fit the chip twice over (fps2_capacity), so the partner IS resident or
+            // becomes resident as other work retires; should it never arrive (a CU mask narrower than the one the capacity was
+            // computed under, a partition change) the launch dies loudly after ~4 s of the 100-MHz clock instead of hanging the GPU
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(&tb->sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 400000000ll) __builtin_trap();
+            }
         }
         __syncthreads();
         if (t < NE) {
@@ -1134,6 +1157,28 @@ __global__ __launch_bounds__(256) void fps_gather_xyz_kernel(int n, int m, const
 // coordinates itself; every other route (PRCNN_FPS_SEQUENTIAL / PRCNN_FPS_NO_PRUNE, few samples, n > 16384) runs its kernel over an
 // internal distance scratch filled with the reference caller's 1e10 and gathers the coordinates behind it -- same indices, same
 // coordinates, two small launches more (round 5; ADVICE r4: those routes used to refuse)
+// how many fps_spec2_kernel workgroups the current device holds at once (0: it refuses the dynamic LDS); cached per device
+static int fps2_capacity(size_t pad)
+{
+    static std::mutex mu;
+    static std::map<int, int> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(dev);
+    if (it != cache.end()) return it->second;
+    int cap = 0, per_cu = 0, cus = 0;
+    if (ensure_dynamic_lds((const void *)prcnn::fps_spec2_kernel, pad, "furthest_point_sampling(two workgroups)") == PRCNN_OK &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)prcnn::fps_spec2_kernel, 1024, pad) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+        cap = per_cu * cus;
+    else
+        (void)hipGetLastError();
+    if (const char *e = getenv("PRCNN_FPS2_CAPACITY")) cap = atoi(e);    // tests: force the chunked launches / the fallback
+    cache[dev] = cap;
+    return cap;
+}
+
 static int fps_any(int b, int n, int m, const float *xyz, float *temp, int *idx, float *new_xyz, void *stream)
 {
     PRCNN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "fps: bad sizes b=%d n=%d m=%d", b, n, m);
@@ -1157,7 +1202,15 @@ static int fps_any(int b, int n, int m, const float *xyz, float *temp, int *idx,
     static const bool no_prune = getenv("PRCNN_FPS_NO_PRUNE") != nullptr;
     static const bool sequential = getenv("PRCNN_FPS_SEQUENTIAL") != nullptr;          // A/B: one pick per exchange (round 3)
     static const bool no_two = getenv("PRCNN_FPS_NO_PAIR") != nullptr;                 // A/B: 16384 < n <= 32768 on fps_generic_kernel (rounds 1-4)
-    const bool pair_ok = !no_prune && !sequential && !no_two && n > 16384 && n <= 32768 && m >= 256;
+    // the two-workgroup kernel spins on its partner: only where BOTH halves of every cloud of a launch are resident at once.  One such
+    // workgroup holds a CU (84 KB of LDS); a launch takes at most HALF of what the device can hold (the other geometry stream may be
+    // running the same kernel: per XCD at most one unpaired block per launch is resident, every other resident block has its partner
+    // and makes progress), larger batches go as several launches.  A device that refuses the LDS (64 KB parts) or has fewer than 32
+    // such slots keeps fps_generic_kernel
+    static const size_t pad2 = (size_t)(getenv("PRCNN_FPS_LDS_PAD") ? atoi(getenv("PRCNN_FPS_LDS_PAD")) : 84) * 1024;
+    const bool pair_shape = !no_prune && !sequential && !no_two && n > 16384 && n <= 32768 && m >= 256;
+    const int cap2 = pair_shape ? fps2_capacity(pad2) : 0;
+    const bool pair_ok = pair_shape && cap2 >= 32;
     const bool writes_xyz = (!no_prune && !sequential && n > 2048 && n <= 16384 && m >= 256) || pair_ok;
     if (new_xyz && !writes_xyz) {
         if (!temp) {
@@ -1181,13 +1234,16 @@ static int fps_any(int b, int n, int m, const float *xyz, float *temp, int *idx,
             set_error("fps: cannot reset the exchange tables");
             return PRCNN_ELAUNCH;
         }
-        static const size_t pad2 = (size_t)(getenv("PRCNN_FPS_LDS_PAD") ? atoi(getenv("PRCNN_FPS_LDS_PAD")) : 84) * 1024;
         // (the placement hint of the one-workgroup kernel is REQUIRED here: with more than half of a CU's LDS per workgroup no two of
         //  these spinning workgroups share a CU, and every XCD dispatches a cloud's halves back to back)
-        const int rc2 = ensure_dynamic_lds((const void *)fps_spec2_kernel, pad2, "furthest_point_sampling(two workgroups)");
-        if (rc2 != PRCNN_OK) return rc2;
-        const unsigned grid = (unsigned)((b + 7) / 8) * 16u;
-        hipLaunchKernelGGL(fps_spec2_kernel, dim3(grid), dim3(1024), pad2, st, b, n, m, kc, xyz, perm, temp, idx, new_xyz, tables);
+        const int per = (cap2 / 2 / 16) * 8;                          // clouds per launch: whole sets of 16 blocks, half the capacity
+        for (int off = 0; off < b; off += per) {
+            const int nb = b - off < per ? b - off : per;
+            const unsigned grid = (unsigned)((nb + 7) / 8) * 16u;
+            hipLaunchKernelGGL(fps_spec2_kernel, dim3(grid), dim3(1024), pad2, st, nb, n, m, kc, xyz + (size_t)off * n * 3, perm + (size_t)off * n,
+                               temp ? temp + (size_t)off * n : nullptr, idx + (size_t)off * m, new_xyz ? new_xyz + (size_t)off * m * 3 : nullptr,
+                               tables + off);
+        }
         return check_launch("furthest_point_sampling(two workgroups)");
     }
     if (!no_prune && n > 2048 && n <= 16384 && m >= 256) {

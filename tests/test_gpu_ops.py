@@ -76,6 +76,33 @@ def test_fps_two_workgroups_tie_rule_lattice_and_duplicates(ext, oracle):
         assert np.array_equal(got, oracle.furthest_point_sample(xyz, m))
 
 
+@pytest.mark.parametrize("capacity,what", [("64", "two launches of 16 + 4 clouds"), ("0", "fps_generic_kernel")])
+def test_fps_two_workgroups_respects_the_co_resident_capacity(tmp_path, oracle, capacity, what):
+    """the two-workgroup kernel spins on its partner, so the host side launches at most HALF of what the device holds at
+    once (PRCNN_FPS2_CAPACITY overrides the occupancy query: 64 slots -> 16 clouds per launch, a batch of 20 goes as two launches over
+    offset pointers) and falls back to fps_generic_kernel where the kernel cannot be co-resident at all (capacity 0 = a part that
+    refuses 84 KB of LDS); picks and running minima stay the oracle's.  A child process: the capacity is read once per device."""
+    import subprocess, sys
+    xyz = scenes(20, 17000, seed0=3)
+    np.save(tmp_path / "xyz.npy", xyz)
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from conftest import pkg\nimport importlib\n"
+            "p = pkg(); sys.path.insert(0, p.DROPIN_DIR); import pointnet2_cuda\n"
+            "xyz = np.load(%r); t = torch.from_numpy(xyz).cuda()\n"
+            "temp = torch.full(xyz.shape[:2], 1e10, device='cuda'); idx = torch.empty((xyz.shape[0], 300), dtype=torch.int32, device='cuda')\n"
+            "pointnet2_cuda.furthest_point_sampling_wrapper(xyz.shape[0], xyz.shape[1], 300, t, temp, idx); torch.cuda.synchronize()\n"
+            "np.savez(%r, idx=idx.cpu().numpy(), temp=temp.cpu().numpy())\n"
+            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+               str(tmp_path / "xyz.npy"), str(tmp_path / "out.npz")))
+    env = dict(os.environ, PRCNN_FPS2_CAPACITY=capacity)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (what, r.stdout[-1500:], r.stderr[-1500:])
+    got = np.load(tmp_path / "out.npz")
+    want, wtemp = oracle.furthest_point_sample(xyz, 300, return_temp=True)
+    assert np.array_equal(got["idx"], want), what
+    assert np.array_equal(got["temp"], wtemp), what
+
+
 def test_fps_many_small_clouds(ext, oracle):
     xyz = np.random.default_rng(1).uniform(-1, 1, (300, 512, 3)).astype(np.float32)
     got, _ = fps_gpu(ext, xyz, 128)
