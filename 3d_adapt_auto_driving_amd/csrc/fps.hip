@@ -954,11 +954,13 @@ __global__ __launch_bounds__(1024) void fps_spec2_kernel(
             st_agent_f32(&tb->xyz[par][e][2], s_exyz[le][2]);
             if (lane == 0) st_agent_f32(&tb->bound[par][gw], s_eb[w]);
         }
-        // ---- the round's cross-workgroup barrier: both halves have published.  EVERY wave releases its own table stores at agent
-        // scope before the workgroup barrier (a workgroup barrier orders nothing beyond the workgroup, and thread 0's release
-        // covers only what has reached the L2 by then) -- what OCKL's grid sync does; the stores themselves are agent-scope
-        // write-throughs, so the fence finds nothing dirty to write back
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // ---- the round's cross-workgroup barrier: both halves have published.  ADVICE r5: a workgroup barrier orders nothing beyond the
+        // workgroup, and thread 0's agent-scope release waits for ITS wave's stores only.  So the table stores are agent-scope
+        // write-throughs (st_agent_*: they are complete when they are acknowledged, nothing stays dirty in a cache that a release
+        // would have to write back) and EVERY wave waits for its own acknowledgements before the workgroup barrier: when thread 0
+        // signals, the whole table is at the agent's coherence point.  (A full agent-scope release fence per wave and round --
+        // buffer_wbl2, an L2 write-back walk -- does the same and HALVED the kernel: double.yaml 5011 -> 2420 scenes/s.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0) {
             __hip_atomic_fetch_add(&tb->sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

@@ -95,52 +95,71 @@ def algorithmic_bytes_qg(n, m, c, ns):
 
 
 def roofline_query_and_group(dev, reps=20):
+    """BASELINE's second metric: ball_query + group (prcnn_query_and_group = QueryAndGroup of pointnet2_utils.py:241-264 in one call) at
+    B = 8, N = 16384, M = 4096 FPS centres, C = 128, r = 0.2.  The headline object is the uniform scene of SURVEY 8d at nsample = 32 (as
+    in rounds 1-5); `lidar_like` holds the same operator on LiDAR-shaped scenes -- full balls, 32 / 64 DISTINCT gathers per centre, the
+    regime the reference's grouping kernel (group_points_gpu.cu:47-66) sees on KITTI -- at nsample 32 and 64, and `uniform_ns64`
+    the uniform scene at nsample = 64 (VERDICT r5 "missing 2").  HBM traffic cannot be measured from inside the process: it comes
+    from the committed rocprofv3 PMC passes over this same operator with the kernels that run NOW (profiles/
+    r06_pmc_query_and_group_{uniform,lidar}.json, produced by `bash profiles/measure_r06.sh qg`: separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes over profiles/qg_sweep.py, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), and is reported only
+    if shape and kernel names match."""
     pkg = importlib.import_module(PKG)
     if pkg.DROPIN_DIR not in sys.path:
         sys.path.insert(0, pkg.DROPIN_DIR)
     import pointnet2_cuda
     synth = importlib.import_module(PKG + ".synth")
-    B, N, M, C, NS, R = BATCH, NPOINTS, 4096, 128, 32, 0.2
-    xyz = torch.from_numpy(synth.scenes(B, N, seed0=1000)).to(dev)
-    temp = torch.full((B, N), 1e10, device=dev)
-    sel = torch.empty((B, M), dtype=torch.int32, device=dev)
-    pointnet2_cuda.furthest_point_sampling_wrapper(B, N, M, xyz, temp, sel)
-    new_xyz = torch.gather(xyz, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
-    feats = torch.randn((B, C, N), device=dev)
-    idx = torch.empty((B, M, NS), dtype=torch.int32, device=dev)
-    out = torch.empty((B, 3 + C, M, NS), device=dev)
-    for _ in range(3):
-        pointnet2_cuda.query_and_group_wrapper(B, N, M, C, R, NS, new_xyz, xyz, feats, idx, out)
-    torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for a, b in evs:   # HIP events recorded on the stream the kernels are launched on (torch's current stream)
-        a.record()
-        pointnet2_cuda.query_and_group_wrapper(B, N, M, C, R, NS, new_xyz, xyz, feats, idx, out)
-        b.record()
-    torch.cuda.synchronize()
-    ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    nbytes = B * algorithmic_bytes_qg(N, M, C, NS)
-    achieved = nbytes / (ms * 1e-3) / 1e9
-    # HBM traffic cannot be measured from inside the process: it comes from the committed rocprofv3 PMC passes over this same
-    # operator with the kernels that run NOW (profiles/r04_pmc_query_and_group.json, produced by profiles/measure_r04.sh:
-    # separate --pmc FETCH_SIZE / WRITE_SIZE passes over profiles/qg_sweep.py, FETCH_SIZE doubled as MI355X_MICROARCH.md
-    # prescribes for gfx950), and is reported only if shape and kernel names match.
+    B, N, M, C, R = BATCH, NPOINTS, 4096, 128, 0.2
     kernels = "dense_build_reg_kernel<16> + dense_query_kernel + group_cat_lds_kernel<1, true>"
-    traffic = per_kernel = None
-    src = os.path.join("profiles", "r04_pmc_query_and_group.json")
-    try:
-        with open(os.path.join(ROOT, src)) as f:
-            pmc = json.load(f)
-        if pmc.get("algorithmic_bytes_per_launch") == nbytes and pmc.get("kernels") == kernels:
-            traffic, per_kernel = pmc["hbm_traffic_bytes_per_launch"], pmc.get("per_kernel")
-    except (OSError, ValueError, KeyError):
-        pass
-    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_source": (src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over profiles/qg_sweep.py)") if traffic else None,
-            "kernel": "prcnn_query_and_group = " + kernels, "per_kernel_profile": per_kernel,
-            "launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": nbytes,
-            "shape": {"B": B, "N": N, "M": M, "C": C, "nsample": NS, "radius": R}}
+
+    def one(kind, NS):
+        make = synth.lidar_scenes if kind == "lidar" else synth.scenes
+        xyz = torch.from_numpy(make(B, N, seed0=1000)).to(dev)
+        temp = torch.full((B, N), 1e10, device=dev)
+        sel = torch.empty((B, M), dtype=torch.int32, device=dev)
+        pointnet2_cuda.furthest_point_sampling_wrapper(B, N, M, xyz, temp, sel)
+        new_xyz = torch.gather(xyz, 1, sel.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+        feats = torch.randn((B, C, N), device=dev)
+        idx = torch.empty((B, M, NS), dtype=torch.int32, device=dev)
+        out = torch.empty((B, 3 + C, M, NS), device=dev)
+        for _ in range(3):
+            pointnet2_cuda.query_and_group_wrapper(B, N, M, C, R, NS, new_xyz, xyz, feats, idx, out)
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:   # HIP events recorded on the stream the kernels are launched on (torch's current stream)
+            a.record()
+            pointnet2_cuda.query_and_group_wrapper(B, N, M, C, R, NS, new_xyz, xyz, feats, idx, out)
+            b.record()
+        torch.cuda.synchronize()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        nbytes = B * algorithmic_bytes_qg(N, M, C, NS)
+        achieved = nbytes / (ms * 1e-3) / 1e9
+        # mean number of DISTINCT neighbours per ball (back-filled slots repeat slot 0: ball_query_gpu.cu:35-39)
+        first = idx[:, :, :1]
+        distinct = float(((idx != first).sum(dim=2) + 1).float().mean())
+        traffic = per_kernel = src = None
+        for cand in ("r06_pmc_query_and_group_%s.json" % kind,) + (("r04_pmc_query_and_group.json",) if (kind, NS) == ("uniform", 32) else ()):
+            try:
+                with open(os.path.join(ROOT, "profiles", cand)) as f:
+                    pmc = json.load(f)
+                if NS == 64:
+                    pmc = pmc.get("ns64", {})
+                if pmc.get("algorithmic_bytes_per_launch") == nbytes and pmc.get("kernels") == kernels:
+                    traffic, per_kernel, src = pmc["hbm_traffic_bytes_per_launch"], pmc.get("per_kernel"), os.path.join("profiles", cand)
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
+        return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": (src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over profiles/qg_sweep.py)") if traffic else None,
+                "kernel": "prcnn_query_and_group = " + kernels, "per_kernel_profile": per_kernel,
+                "launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": nbytes, "distinct_neighbours_per_ball": round(distinct, 2),
+                "shape": {"B": B, "N": N, "M": M, "C": C, "nsample": NS, "radius": R, "scene": kind}}
+
+    line = one("uniform", 32)
+    line["uniform_ns64"] = one("uniform", 64)
+    line["lidar_like"] = {"ns32": one("lidar", 32), "ns64": one("lidar", 64)}
+    return line
 
 
 def roofline_sa_mlp_fused(dev, reps=10):

@@ -1,8 +1,9 @@
 """Per-kernel durations (rocprofv3 --kernel-trace) and HBM traffic (--pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled as
 MI355X_MICROARCH.md prescribes for gfx950, both counters in KB) of profiles/qg_sweep.py, per configuration.
-usage: python profiles/qg_sweep_summarize.py <kernel_trace.csv> <fetch counter_collection.csv> <write counter_collection.csv> [reps] [json out]
-The JSON (profiles/r04_pmc_query_and_group.json) holds the B = 8, r = 0.2, nsample = 32, C = 128 configuration: bench.py's
-roofline_reference_op reads its traffic from it."""
+usage: python profiles/qg_sweep_summarize.py <kernel_trace.csv> <fetch counter_collection.csv> <write counter_collection.csv> [reps] [json out] [scene kind]
+The JSON (profiles/r06_pmc_query_and_group_{uniform,lidar}.json; round 4: r04_pmc_query_and_group.json) holds the B = 8, C = 128,
+r = 0.2 configurations at nsample = 32 (top level: bench.py's roofline_reference_op reads its traffic from it) and nsample = 64
+("ns64")."""
 import collections, csv, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
@@ -73,10 +74,15 @@ for k, (B, R, NS, C) in enumerate(CONFIGS):
     a = alg(B, C, NS)
     print("| %d | %g | %d | %d | **sum** (algorithmic %.2f MB) | **%.1f** = %.0f GB/s = %.3f of 8 TB/s | | | %s |" % (
         B, R, NS, C, a / 1e6, tot_d, a / tot_d / 1e3, a / tot_d / 1e3 / 8000, ("**%.2f** = %.2f x algorithmic" % (tot_t, tot_t * 1e6 / a)) if tot_t else "-"))
-    if (B, R, NS, C) == (8, 0.2, 32, 128) and len(sys.argv) > 5 and tot_t:
+    if (B, R, C) == (8, 0.2, 128) and len(sys.argv) > 5 and tot_t:
         full = {"dense_build_reg_kernel": "dense_build_reg_kernel<16>", "group_cat_lds_kernel": "group_cat_lds_kernel<1, true>"}
-        json.dump({"what": "prcnn_query_and_group, B = 8, N = 16384, M = 4096, C = 128, nsample = 32, r = 0.2: rocprofv3 --kernel-trace averages and "
-                           "--pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE passes over profiles/qg_sweep.py (profiles/measure_r04.sh)",
-                   "kernels": " + ".join(full.get(n, n) for n in names), "algorithmic_bytes_per_launch": a,
-                   "hbm_traffic_bytes_per_launch": int(tot_t * 1e6), "sum_of_kernel_durations_us": round(tot_d, 1), "per_kernel": detail},
-                  open(sys.argv[5], "w"), indent=1)
+        kind = sys.argv[6] if len(sys.argv) > 6 else "uniform"
+        rec = {"what": "prcnn_query_and_group, %s scenes, B = 8, N = 16384, M = 4096, C = 128, nsample = %d, r = 0.2: rocprofv3 --kernel-trace averages and "
+                       "--pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE passes over profiles/qg_sweep.py (profiles/measure_r06.sh qg)" % (kind, NS),
+               "scene": kind, "kernels": " + ".join(full.get(n, n) for n in names), "algorithmic_bytes_per_launch": a,
+               "hbm_traffic_bytes_per_launch": int(tot_t * 1e6), "sum_of_kernel_durations_us": round(tot_d, 1), "per_kernel": detail}
+        if NS == 32:
+            OUT = rec
+        else:
+            OUT["ns64"] = rec
+            json.dump(OUT, open(sys.argv[5], "w"), indent=1)
