@@ -31,7 +31,7 @@ DEV = "cuda:0"
 
 def to_cpu(a):
     if torch.is_tensor(a):
-        return a.detach().cpu().clone()
+        return a if a.device.type == "meta" else a.detach().cpu().clone()      # (meta: a shape-only index tensor, never read)
     if hasattr(a, "rowinfo"):                      # BallPack -> the oracle's stand-in keeps the index tensor
         cp = lambda t: None if t is None else t.detach().cpu().clone()
         return ext_cpu._CpuPack(a.idx.detach().cpu().clone(), cp(a.limit), cp(getattr(a, "rep", None)), cp(getattr(a, "crep", None)))
@@ -164,7 +164,7 @@ def check_roi_geometry_packs(self, name, args, host, ret):
     no_idx = len(host) > 10 and host[10] is False           # the product's call: the index tensors are not written (shape-only stand-ins)
     for k, (g, w) in enumerate(zip(ret[:6], want)):
         if no_idx and k in (1, 4):
-            assert tuple(g.shape) == tuple(w.shape) and g.stride() == (0, 0, 0), (name, k)
+            assert tuple(g.shape) == tuple(w.shape) and g.device.type == "meta", (name, k)   # a shape on the "meta" device
             continue
         assert torch.equal(g.cpu(), w), (name, k)
     new1, idx1, rep1, new2, idx2, rep2 = want
