@@ -5,6 +5,8 @@ A scene is N points in rect-camera coordinates: uniform clutter inside PC_AREA_S
 car-sized dense boxes standing on it, so that proposals and RoI pooling see non-empty boxes.
 Deterministic in the seed (seed = scene id).  Also a KITTI-like synthetic calibration used by the
 result writer."""
+import os
+
 import numpy as np
 
 
@@ -179,3 +181,63 @@ class SyntheticCalib:
         boxes = np.stack((x1, y1, x2, y2), axis=1)
         boxes_corner = np.stack((x, y), axis=2)
         return boxes, boxes_corner
+
+
+def _write_tree_scene(args):
+    """one pool scene of write_kitti_tree (a module-level function: it runs in worker processes)"""
+    base, k, seed0, extra = args
+    rng = np.random.default_rng(seed0 + k)
+    rect = lidar_raw_with_labels(seed0 + k)[0].astype(np.float64)
+    # what a real sweep has besides the in-scope returns: points outside the image / behind the camera / outside PC_AREA_SCOPE
+    outside = np.stack([rng.uniform(-60, 60, extra), rng.uniform(-3, 5, extra), rng.uniform(-20, 90, extra)], 1)
+    rect = np.concatenate([rect, outside], 0)[rng.permutation(len(rect) + extra)]
+    velo = rect @ _VELO_AXES                                   # rect = axes . velo (R0 = I, no translation) -> velo = axes^T . rect
+    np.concatenate([velo, rng.random((len(velo), 1))], 1).astype(np.float32).tofile(os.path.join(base, "velodyne", "%06d.bin" % k))
+    P2 = SyntheticCalib().P2.astype(np.float64)
+    rows = {"P0": P2, "P1": P2, "P2": P2, "P3": P2, "R0_rect": np.eye(3), "Tr_velo_to_cam": np.concatenate([_VELO_AXES, np.zeros((3, 1))], 1),
+            "Tr_imu_to_velo": np.concatenate([np.eye(3), np.zeros((3, 1))], 1)}
+    with open(os.path.join(base, "calib", "%06d.txt" % k), "w") as f:
+        for key in ("P0", "P1", "P2", "P3", "R0_rect", "Tr_velo_to_cam", "Tr_imu_to_velo"):
+            f.write("%s: %s\n" % (key, " ".join("%.12e" % v for v in rows[key].reshape(-1))))
+    return len(rect)
+
+
+_VELO_AXES = np.array([[0.0, -1.0, 0.0], [0.0, 0.0, -1.0], [1.0, 0.0, 0.0]])      # velodyne (x forward, y left, z up) -> camera (x right, y down, z forward)
+
+
+def write_kitti_tree(root, scenes, pool=64, seed0=50000, extra=6000, processes=None):
+    """A KITTI-format tree of LiDAR-shaped scenes for the whole-driver measurements (bench.py driver_leg; VERDICT r5 "missing 4"):
+    <root>/KITTI/{ImageSets/val.txt, object/training/{velodyne,calib}/%06d.*} with ``scenes`` sample ids 0 .. scenes-1.  ``pool``
+    DISTINCT sweeps are generated (lidar_raw_with_labels: a ray-cast 64-beam sweep, ~28 k in-scope returns, + ``extra`` points outside
+    the image / behind the camera / out of scope, shuffled, moved into the velodyne frame, a reflectance column: what a .bin file holds);
+    the ids beyond the pool are hard links onto them -- the loaders read, rectify, filter and sample REAL files per scene
+    (kitti_io.KittiSource: the reference's get_rpn_sample), the generator's 50-80 ms per sweep stays out of the measured loop.
+    -> the list of sample ids."""
+    import multiprocessing
+    base = os.path.join(root, "KITTI", "object", "training")
+    for sub in ("velodyne", "calib"):
+        os.makedirs(os.path.join(base, sub), exist_ok=True)
+    os.makedirs(os.path.join(root, "KITTI", "ImageSets"), exist_ok=True)
+    pool = min(pool, scenes)
+    jobs = [(base, k, seed0, extra) for k in range(pool)]
+    procs = processes or 1                                     # (serial by default: ~75 ms per sweep; a pool only pays for hundreds of sweeps)
+    if procs > 1:
+        with multiprocessing.get_context("fork" if not _hip_started() else "forkserver").Pool(procs) as mp:
+            mp.map(_write_tree_scene, jobs)
+    else:
+        for j in jobs:
+            _write_tree_scene(j)
+    for k in range(pool, scenes):
+        for sub, ext in (("velodyne", "bin"), ("calib", "txt")):
+            os.link(os.path.join(base, sub, "%06d.%s" % (k % pool, ext)), os.path.join(base, sub, "%06d.%s" % (k, ext)))
+    with open(os.path.join(root, "KITTI", "ImageSets", "val.txt"), "w") as f:
+        f.write("\n".join("%06d" % k for k in range(scenes)) + "\n")
+    return list(range(scenes))
+
+
+def _hip_started():
+    try:
+        import torch
+        return torch.cuda.is_available() and torch.cuda.is_initialized()
+    except Exception:                                           # noqa: BLE001
+        return False

@@ -326,25 +326,47 @@ def roofline_roipool(dev, cfg, model, reps=20):
 
 
 def driver_leg(cfg, model, dev, scenes=4096):
-    """eval_rcnn.eval_scenes over synthetic scenes with everything the reference's loop has around the model
-    (eval_rcnn.py:493-649): loader processes produce the 16384-point clouds, pinned H2D, pipelined engine, one D2H per
-    batch, KITTI result files.  Steady-state rate (loader / writer process start-up excluded)."""
+    """eval_rcnn.eval_scenes with everything the reference's loop has around the model (eval_rcnn.py:493-649): loader processes
+    produce the 16384-point clouds, pinned H2D, pipelined engine, one D2H per batch, KITTI result files by writer processes.
+    Steady-state rates (loader / writer process start-up excluded) of three drivers:
+      * `value`: the uniform synthetic scene source, host-side generator in the loaders (rounds 2-5's figure);
+      * `lidar_kitti_tree`: a KITTI-format tree of LiDAR-shaped sweeps on disk (synth.write_kitti_tree: velodyne .bin + calib files,
+        64 distinct sweeps hard-linked to `scenes` ids) through kitti_io.KittiSource -- the reference's get_rpn_sample per scene in the
+        loaders (read, lidar_to_rect, rect_to_img, validity filter, near / far sampler: kitti_rcnn_dataset.py:249-324);
+      * `lidar_kitti_tree_device_input`: the same files with --device_input: the loaders only read the raw clouds, rectification, filter
+        and sampler run on the device (csrc/input_stage.hip)."""
     import shutil
     import tempfile
     E = importlib.import_module(PKG + ".eval_rcnn")
     K = importlib.import_module(PKG + ".kitti_io")
-    src = K.SyntheticSource(cfg, scenes)
-    out = tempfile.mkdtemp(prefix="prcnn_bench_")
-    stats = {}
+    synth = importlib.import_module(PKG + ".synth")
+
+    def run(src, device_input=False):
+        out = tempfile.mkdtemp(prefix="prcnn_bench_")
+        stats = {}
+        try:
+            table, counts = E.eval_scenes(model, cfg, dev, src, src.ids, BATCH, out, device_input=device_input, stats=stats)
+            files = len(os.listdir(out))
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+        return {"value": round(E.steady_state_rate(stats, BATCH), 1), "unit": "scenes/s", "scenes": len(src.ids), "result_files": files,
+                "detections": int(counts.sum()), "host_budget": stats.get("host_budget")}
+
+    line = run(K.SyntheticSource(cfg, scenes))
+    line["what"] = ("eval_scenes: synthetic scene source + host 16384-point stage in loader processes, pinned upload, engine, "
+                    "D2H, KITTI text files by writer processes; steady state between the first and the last batch")
+    tree = tempfile.mkdtemp(prefix="prcnn_tree_")
     try:
-        table, counts = E.eval_scenes(model, cfg, dev, src, src.ids, BATCH, out, stats=stats)
-        files = len(os.listdir(out))
+        synth.write_kitti_tree(tree, scenes, pool=64)
+        line["lidar_kitti_tree"] = run(K.KittiSource(tree, cfg))
+        line["lidar_kitti_tree_device_input"] = run(K.KittiSource(tree, cfg), device_input=True)
+        line["lidar_kitti_tree"]["what"] = ("the same loop over a KITTI-format tree of LiDAR-shaped sweeps (64 distinct .bin files, ~34 k raw points, "
+                                            "hard-linked to %d ids): kitti_io.KittiSource = the reference's get_rpn_sample in the loaders" % scenes)
+    except Exception as e:                                          # noqa: BLE001 -- report legs, never the headline
+        line["lidar_kitti_tree_error"] = repr(e)[:300]
     finally:
-        shutil.rmtree(out, ignore_errors=True)
-    return {"value": round(E.steady_state_rate(stats, BATCH), 1), "unit": "scenes/s", "scenes": scenes, "result_files": files,
-            "detections": int(counts.sum()), "host_budget": stats.get("host_budget"),
-            "what": "eval_scenes: synthetic scene source + host 16384-point stage in loader processes, pinned upload, engine, "
-                    "D2H, KITTI text files by writer processes; steady state between the first and the last batch"}
+        shutil.rmtree(tree, ignore_errors=True)
+    return line
 
 
 def dropin_module_leg(cfg, model, dev, steps=6):
@@ -447,6 +469,37 @@ def roofline_fps(dev, reps=3):
             "workgroups": B, "cus_held": B, "shape": {"clouds": B, "N": N, "M": M}}
 
 
+def in_step(kernel_prefix, peak_time_field=None):
+    """The same kernel's average duration INSIDE the pipelined step (other streams' kernels beside it), read from the committed rocprofv3
+    step tables (profiles/r06_bench_step_kernel_stats_{uniform,lidar}.md, produced by `bash profiles/measure_r06.sh step`): the
+    rooflines below time their kernel ALONE on the chip with HIP events; VERDICT r5 W5 / W6 asked for the in-step figure beside it.
+    -> {"uniform": avg ms per launch, "lidar": ...} (None where the table or the row is missing)."""
+    out = {}
+    for kind in ("uniform", "lidar"):
+        v = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r06_bench_step_kernel_stats_%s.md" % kind)) as f:
+                for ln in f:
+                    if ln.startswith("| `") and kernel_prefix in ln.split("`")[1]:
+                        v = round(float(ln.rstrip().rstrip("|").split("|")[-1]) / 1e3, 4)
+                        break
+        except (OSError, ValueError, IndexError):
+            pass
+        out[kind] = v
+    return out
+
+
+def with_in_step(line, kernel_prefix, work_per_launch, peak, scale=1.0):
+    """adds launch_ms_in_step / frac_in_step (work per launch / in-step duration / peak) to a roofline object"""
+    if line is None:
+        return line
+    ms = in_step(kernel_prefix)
+    line["launch_ms_in_step"] = ms
+    line["frac_in_step"] = {k: (None if not v else round(work_per_launch * scale / (v * 1e-3) / peak, 4)) for k, v in ms.items()}
+    line["in_step_source"] = "profiles/r06_bench_step_kernel_stats_{uniform,lidar}.md (rocprofv3 --kernel-trace of the pipelined bench)"
+    return line
+
+
 def rccl_world1_leg():
     """RCCL on this box (untimed, a child process so that a collective-library failure cannot take the headline with it):
     torch.distributed "nccl" as a world of one rank, the job's one exchange forced through it on rank 0's shard of the 3769-scene
@@ -480,6 +533,8 @@ def main():
                     help="scene generator of the HEADLINE loop: SURVEY 8d's uniform synthetic scene (default, the contract) or "
                          "synth.lidar_scene (for profiling that regime; the default run reports it under config.lidar_like)")
     ap.add_argument("--windows", type=int, default=5, help="closed timed windows of W + K steps each; `value` is the MEDIAN window, config.windows lists them all (VERDICT r4 W9: one K = 20 window in six came out 8 % low)")
+    ap.add_argument("--points", type=int, default=16384, help="points per scene of the HEADLINE loop: 16384 = default.yaml (the contract); 32768 = tools/cfgs/double.yaml, "
+                                                              "for profiling that configuration (the default run reports it under config.double_yaml_scenes_per_s)")
     ap.add_argument("--prewarm", type=int, default=24, help="untimed set-up steps before the W warm-up steps (allocator pool, code objects)")
     args = ap.parse_args()
 
@@ -519,6 +574,10 @@ def main():
     E = importlib.import_module(PKG + ".eval_rcnn")
     synth = importlib.import_module(PKG + ".synth")
     cfg = C.default_eval_cfg()
+    if args.points != 16384:
+        global NPOINTS
+        NPOINTS = args.points
+        C.merge_into({"RPN": {"NUM_POINTS": NPOINTS}}, cfg)
     model = E.build_model(cfg, dev, seed=0)
     M = cfg.TEST.RPN_POST_NMS_TOP_N
 
@@ -792,9 +851,14 @@ def main():
         if not args.no_roofline:
             note("rooflines")
             line["roofline"] = roofline_rpn_tail(dev, cfg, model) or roofline_sa_mlp_fused(dev)
+            if "rpn_tail" in line["roofline"].get("kernel", ""):
+                with_in_step(line["roofline"], "rpn_tail_lin_kernel", line["roofline"]["algorithmic_flops_per_launch"], MFMA_F32_PEAK_TFLOPS * 1e12)
             line["roofline_longest"] = roofline_fps(dev)
+            line["roofline_longest"]["launch_ms_in_step"] = in_step("fps_spec_kernel<16>")
             line["roofline_mfma"] = roofline_sa_mlp_fused(dev)
-            line["roofline_product"] = roofline_roipool(dev, cfg, model)
+            rp = line["roofline_product"] = roofline_roipool(dev, cfg, model)
+            if rp:
+                with_in_step(rp, "roipool3d_canonical_kernel", rp.get("algorithmic_bytes_per_launch", 0), HBM_PEAK_GBS * 1e9)
             line["roofline_reference_op"] = roofline_query_and_group(dev)
         if world == 1 and not args.no_driver:
             line["config"]["driver_scenes_per_s"] = driver_leg(cfg, model, dev)

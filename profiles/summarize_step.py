@@ -8,7 +8,8 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "fps_pruned_kernel<16" in r["Kernel_Name"] or "fps_spec_kernel<16" in r["Kernel_Name"]]   # one per geometry group (SA1 FPS)
+marks = [i for i, r in enumerate(rows) if "fps_pruned_kernel<16" in r["Kernel_Name"] or "fps_spec_kernel<16" in r["Kernel_Name"]
+         or "fps_spec2_kernel" in r["Kernel_Name"]]            # (fps_spec2_kernel: double.yaml's 32768-point clouds)   # one per geometry group (SA1 FPS)
 # steady-state window: from the second sampling launch after the middle of the trace to the last one; a STEP = one launch of
 # the fused RPN tail (one per batch).  (Round 2 counted sa_xyz_mlp<32> launches, which moved into the group chain -- one per
 # group -- at the end of that round: the window search found nothing and the committed table was empty.)
