@@ -518,7 +518,7 @@ __device__ __forceinline__ void fs_pick3(const float (&px)[PPT], const float (&p
 template <int PPT>
 __global__ __launch_bounds__(1024) void fps_spec_kernel(
     int n, int m, KeyCodec kc, const float *__restrict__ xyz, const int *__restrict__ perm,
-    float *__restrict__ temp, int *__restrict__ idx, float *__restrict__ new_xyz, int layout)
+    float *__restrict__ temp, int *__restrict__ idx, float *__restrict__ new_xyz)
 {
     // temp == NULL: the running minima start at the reference caller's fill value (1e10, pointnet2_utils.py:26) and are not handed back;
     // new_xyz != NULL: the coordinates of the picks are written as well (prcnn_fps_new_xyz: the caller's gather launch folded in)
@@ -542,11 +542,10 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
     float bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY, bz0 = INFINITY, bz1 = -INFINITY;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        // position in Morton order.  layout 0: a wave = 1024 consecutive positions; 1: PAIRS of 64-point tiles dealt round-robin to the
-        // waves (a pivot's neighbourhood is spread over the waves, the packed-f32 tile pairs stay spatial neighbours); 2: single tiles
-        const int s = layout == 0 ? w * (64 * PPT) + i * 64 + lane
-                    : layout == 1 ? (((i >> 1) * 16 + w) * 2 + (i & 1)) * 64 + lane
-                                  : (i * 16 + w) * 64 + lane;
+        // position in Morton order: a wave = 1024 consecutive positions.  (Round 6, measured and not kept: tiles or tile PAIRS dealt
+        // round-robin to the waves so that a pivot's neighbourhood is spread over them -- with the lazy rebuild of round 5 in place:
+        // pairs 1.91 / 2.32 ms, single tiles 2.04 / 2.41 ms against 1.69 / 2.46 ms, uniform / LiDAR-shaped, same picks.)
+        const int s = w * (64 * PPT) + i * 64 + lane;
         float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY, z0 = INFINITY, z1 = -INFINITY;
         if (s < n) {
             const int k = order[s];
@@ -1278,10 +1277,9 @@ static int fps_any(int b, int n, int m, const float *xyz, float *temp, int *idx,
                     const int rc = ensure_dynamic_lds(k, pad, "furthest_point_sampling(speculative)");
                     if (rc != PRCNN_OK) return rc;
                 }
-            static const int layout = getenv("PRCNN_FPS_LAYOUT") ? atoi(getenv("PRCNN_FPS_LAYOUT")) : 0;
-            if (n <= 4096) hipLaunchKernelGGL((fps_spec_kernel<4>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx, new_xyz, layout);
-            else if (n <= 8192) hipLaunchKernelGGL((fps_spec_kernel<8>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx, new_xyz, layout);
-            else hipLaunchKernelGGL((fps_spec_kernel<16>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx, new_xyz, layout);
+            if (n <= 4096) hipLaunchKernelGGL((fps_spec_kernel<4>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx, new_xyz);
+            else if (n <= 8192) hipLaunchKernelGGL((fps_spec_kernel<8>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx, new_xyz);
+            else hipLaunchKernelGGL((fps_spec_kernel<16>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx, new_xyz);
             return check_launch("furthest_point_sampling(speculative)");
         }
         if (n <= 4096) hipLaunchKernelGGL((fps_pruned_kernel<4, 1024>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);

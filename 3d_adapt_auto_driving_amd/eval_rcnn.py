@@ -1275,7 +1275,7 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
         ctx = os.environ.get("PRCNN_LOADER_CONTEXT", ctx)
         feed = iter(torch.utils.data.DataLoader(_SceneDataset(source, scene_ids, stage is not None), batch_size=batch_size,
                                                 shuffle=False, num_workers=workers, pin_memory=on_gpu and stage is None,
-                                                prefetch_factor=2, multiprocessing_context=ctx,
+                                                prefetch_factor=2, multiprocessing_context=ctx, worker_init_fn=_limit_worker_threads,
                                                 collate_fn=_identity if stage is not None else None))
 
     def load(s):
@@ -1312,7 +1312,7 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
     writers = None
     if output_dir:
         wctx = "forkserver" if (on_gpu and torch.cuda.is_initialized()) else "fork"
-        writers = ProcessPoolExecutor(max_workers=budget["writers"],
+        writers = ProcessPoolExecutor(max_workers=budget["writers"], initializer=_limit_worker_threads,
                                       mp_context=multiprocessing.get_context(os.environ.get("PRCNN_LOADER_CONTEXT", wctx)))
     jobs = []
     results = {}
@@ -1414,6 +1414,29 @@ class _SceneDataset(torch.utils.data.Dataset):
 
 def _identity(items):
     return items
+
+
+def _limit_worker_threads(_worker_id=None):
+    """Start-up hook of every loader / writer process: ONE thread for the numeric libraries.  A loader's numpy work is a few small
+    products per scene (Calibration.lidar_to_rect: (n, 4) x (4, 3)); left alone, each of them fans out over the BLAS / OpenMP pool of
+    the whole host (256 threads on the MI355X boxes) -- processes x cores runnable threads around the one thread that feeds the GPU.
+    PRCNN_LOADER_THREADS (default 1; 0: leave the libraries alone)."""
+    n = int(os.environ.get("PRCNN_LOADER_THREADS", "1"))
+    if n <= 0:
+        return
+    try:
+        torch.set_num_threads(n)
+    except RuntimeError:
+        pass
+    try:
+        import threadpoolctl
+        global _THREAD_LIMIT
+        _THREAD_LIMIT = threadpoolctl.threadpool_limits(limits=n)      # kept alive: the limit lasts as long as the object
+    except Exception:                                                   # noqa: BLE001 -- no threadpoolctl: the environment variables below
+        pass
+
+
+_THREAD_LIMIT = None
 
 
 def eval_synthetic(model, cfg, device, scene_ids, batch_size=8, npoints=16384, output_dir=None, raw_points=None):

@@ -24,6 +24,7 @@ SWITCHES = {
     "PRCNN_PAIR": ("operational", "2", "eval_rcnn.py", "batches of a geometry group that share the launches of the RPN / proposal / RCNN / final stages in the graphed runner (must divide the group; detections come back up to 2 x pair - 1 submits late)"),
     "PRCNN_GEO_DEPTH": ("operational", "3*group", "eval_rcnn.py", "batches the geometry runs ahead"),
     "PRCNN_SIDE_STREAMS": ("operational", "2", "eval_rcnn.py", "geometry side streams (with feature + proposal stream: the 4 hardware queues)"),
+    "PRCNN_LOADER_THREADS": ("operational", "1", "eval_rcnn.py", "threads of the numeric libraries (BLAS / OpenMP) in every loader and writer process; 0: leave them alone (round 6: a loader's small numpy products fanned out over the whole host's thread pool)"),
     "PRCNN_LOADER_WORKERS": ("operational", "budget", "eval_rcnn.py", "loader processes of eval_scenes (default: host_budget)"),
     "PRCNN_WRITER_PROCS": ("operational", "budget", "eval_rcnn.py", "KITTI result writer processes"),
     "PRCNN_LOADER_CONTEXT": ("operational", "forkserver/fork", "eval_rcnn.py", "multiprocessing start method of loaders and writers"),
@@ -91,6 +92,7 @@ SWITCHES = {
     "PRCNN_PL_STREAM_CAP": ("tuning", "512", "csrc/packed_layer.hip", "workgroups of the persistent layer kernels"),
     "PRCNN_PL_STREAM_MIN": ("tuning", "512", "csrc/packed_layer.hip", "items from which a K = 128 layer runs persistently"),
     "PRCNN_PL_PERSIST_MIN": ("tuning", "256", "csrc/packed_layer.hip", "items from which a K >= 256 layer runs persistently (and more than the cap)"),
+    "PRCNN_FPS2_CAPACITY": ("tuning", "auto", "csrc/fps.hip", "co-resident fps_spec2_kernel workgroups the device is assumed to hold (default: occupancy query x CUs); a launch takes half of it, below 32 the sampling of 16384 < n <= 32768 points falls back to fps_generic_kernel (tests: 64 / 0)"),
     "PRCNN_FPS_LDS_PAD": ("tuning", "84", "csrc/fps.hip", "KB of dynamic LDS an FPS workgroup claims (keeps its CU to itself)"),
     "PRCNN_TNN_CELLS": ("tuning", "2", "csrc/three_nn_grid.hip", "grid cells per known point"),
     "PRCNN_GROUP_CHUNKS": ("tuning", "auto", "csrc/ball_group.hip", "channel chunks of the grouping kernels"),
