@@ -1229,6 +1229,144 @@ def all_gather_detections(table, counts, device, force=False):
     return out_t[order].contiguous(), out_c[order].contiguous()
 
 
+
+LOADER_TARGET = 9000.0          # scenes/s the loader processes are sized for (above the engine's rate on any scene kind)
+
+
+def _calib_row(calib):
+    """P2 | R0 | V2C of a calibration object as 33 floats (what a loader process sends back instead of the object)"""
+    row = np.zeros(33, dtype=np.float32)
+    row[0:12] = np.asarray(calib.P2, np.float32).reshape(-1)
+    r0, v2c = getattr(calib, "R0", None), getattr(calib, "V2C", None)
+    row[12:21] = (np.eye(3, dtype=np.float32) if r0 is None else np.asarray(r0, np.float32)).reshape(-1)
+    row[21:33] = (np.eye(3, 4, dtype=np.float32) if v2c is None else np.asarray(v2c, np.float32)).reshape(-1)
+    return row
+
+
+class _RowCalib:
+    """the parent's side of _calib_row: projection for the result writer + the arrays DeviceInputStage.pack_calib reads"""
+
+    def __init__(self, row):
+        self.P2, self.R0, self.V2C = row[0:12].reshape(3, 4), row[12:21].reshape(3, 3), row[21:33].reshape(3, 4)
+
+    def corners3d_to_img_boxes(self, corners3d):
+        n = corners3d.shape[0]
+        hom = np.concatenate((corners3d, np.ones((n, 8, 1))), axis=2)
+        img = np.matmul(hom, self.P2.T)
+        x, y = img[:, :, 0] / img[:, :, 2], img[:, :, 1] / img[:, :, 2]
+        boxes = np.stack((np.min(x, axis=1), np.min(y, axis=1), np.max(x, axis=1), np.max(y, axis=1)), axis=1)
+        return boxes, np.stack((x, y), axis=2)
+
+
+def _shm_worker(source, scene_ids, batch_size, raw, buf, tasks, results):
+    """A loader process of _ShmFeed: takes (batch index, slot), produces the batch's scenes STRAIGHT INTO the slot of the shared,
+    pinned buffer -- sampled clouds (B, npoints, c) or, for the device input stage, raw clouds packed (B, n_max, stride) -- and sends
+    back only the small things: per-scene counts, calibration rows, image shapes."""
+    _limit_worker_threads()
+    flat = buf.numpy()
+    try:
+        while True:
+            t = tasks.get()
+            if t is None:
+                return
+            b, slot = t
+            ids = scene_ids[b * batch_size:(b + 1) * batch_size]
+            loaded = [source.load_raw(i) if raw else source.load(i) for i in ids]
+            arrs = [np.ascontiguousarray(l[0], dtype=np.float32) for l in loaded]
+            n_max, c = max(1, max(a.shape[0] for a in arrs)), arrs[0].shape[1]
+            if len(ids) * n_max * c > flat.shape[1]:
+                raise RuntimeError("a batch of %d clouds x %d points x %d floats does not fit a loader slot of %d floats "
+                                   "(PRCNN_RAW_SLOT_POINTS)" % (len(ids), n_max, c, flat.shape[1]))
+            dst = flat[slot, :len(ids) * n_max * c].reshape(len(ids), n_max, c)
+            for k, a in enumerate(arrs):
+                dst[k, :a.shape[0]] = a                           # (rows beyond a raw cloud's length are never read: counts)
+            results.put((b, slot, n_max, c, [a.shape[0] for a in arrs], np.stack([_calib_row(l[1]) for l in loaded], 0),
+                         [tuple(l[2]) for l in loaded]))
+    except BaseException as e:                                      # noqa: BLE001 -- the parent re-raises it
+        import traceback
+        results.put((-1, -1, 0, 0, "loader process failed: %r\n%s" % (e, traceback.format_exc()), None, None))
+
+
+class _ShmFeed:
+    """Loader processes that write into ONE shared, page-locked buffer (round 6).  torch's DataLoader hands every
+    batch (device input stage: every raw cloud) over as a tensor in a shared-memory file of its own -- a file descriptor through a unix
+    socket per tensor, a copy into pinned memory by a thread of the parent, then the upload: 2.4 ms of the feeding thread per batch of raw
+    clouds (profiles/r06_driver.md), the whole driver at 2400 scenes/s beside an engine that does 6500.  Here the buffer is allocated once
+    (torch shared memory), registered with the HIP runtime (hipHostRegister: uploads from it are asynchronous DMA), cut into slots, and a
+    loader fills the slot its task names; the parent receives a dozen integers and 33 floats per scene, views the slot and enqueues the
+    upload.  A slot returns to the free list when its upload has completed (an event).  Batches come back in order."""
+
+    def __init__(self, source, scene_ids, batch_size, raw, workers, ctx, pin, slot_floats):
+        import torch.multiprocessing as tmp
+        self.batch_size, self.raw = batch_size, raw
+        self.n_batches = -(-len(scene_ids) // batch_size)
+        n_slots = min(self.n_batches, 2 * workers + 4)
+        self.buf = torch.empty((n_slots, slot_floats), dtype=torch.float32).share_memory_()
+        self.registered = False
+        if pin:
+            rc = torch.cuda.cudart().cudaHostRegister(self.buf.data_ptr(), self.buf.numel() * 4, 0)
+            self.registered = int(rc) == 0
+        mp = tmp.get_context(ctx)
+        self.tasks, self.results = mp.Queue(), mp.Queue()
+        self.procs = [mp.Process(target=_shm_worker, args=(source, list(scene_ids), batch_size, raw, self.buf, self.tasks, self.results), daemon=True)
+                      for _ in range(workers)]
+        for p in self.procs:
+            p.start()
+        self.free, self.busy, self.ready = collections.deque(range(n_slots)), collections.deque(), {}
+        self.next_task = self.next_out = 0
+        self._feed()
+
+    def _feed(self):
+        while self.busy and self.busy[0][1].query():
+            self.free.append(self.busy.popleft()[0])
+        while self.free and self.next_task < self.n_batches:
+            self.tasks.put((self.next_task, self.free.popleft()))
+            self.next_task += 1
+
+    def next(self):
+        """-> (host tensor (B, n_max, c): a view of the slot, slot, counts, calibs, shapes) of the next batch, or None at the end"""
+        if self.next_out >= self.n_batches:
+            return None
+        while self.next_out not in self.ready:
+            if not self.free and self.next_task < self.n_batches and self.busy and len(self.ready) == 0 and self.results.empty():
+                self.busy[0][1].synchronize()                     # every slot is waiting for its upload: wait for the oldest one
+                self._feed()
+            try:
+                r = self.results.get(timeout=1.0)
+            except Exception:                                      # noqa: BLE001 (queue.Empty): keep the workers fed, notice dead ones
+                self._feed()
+                if not any(p.is_alive() for p in self.procs):
+                    raise RuntimeError("eval_scenes: every loader process has exited")
+                continue
+            if r[0] < 0:
+                raise RuntimeError(r[4])
+            self.ready[r[0]] = r[1:]
+        slot, n_max, c, counts, rows, shapes = self.ready.pop(self.next_out)
+        self.next_out += 1
+        host = self.buf[slot, :len(counts) * n_max * c].view(len(counts), n_max, c)
+        return host, slot, counts, [_RowCalib(rows[k]) for k in range(len(counts))], shapes
+
+    def release(self, slot, event):
+        """the slot's upload has been enqueued behind `event` (None: the data has been consumed already)"""
+        if event is None:
+            self.free.append(slot)
+        else:
+            self.busy.append((slot, event))
+        self._feed()
+
+    def close(self):
+        for _ in self.procs:
+            self.tasks.put(None)
+        for p in self.procs:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.terminate()
+        if self.registered:
+            torch.cuda.synchronize()
+            torch.cuda.cudart().cudaHostUnregister(self.buf.data_ptr())
+            self.registered = False
+
+
 @torch.no_grad()
 def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=None, workers=None, device_input=False,
                 recall=None, stats=None):
@@ -1255,9 +1393,21 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
                                 "pinned": pin_to_budget(budget)}
     else:
         pin_to_budget(budget)
+    starts = list(range(0, len(scene_ids), batch_size))
     if workers is None:
         workers = budget["loaders"]
-    starts = list(range(0, len(scene_ids), batch_size))
+        if "PRCNN_LOADER_WORKERS" not in os.environ and len(starts) > 2:
+            # as many loaders as THIS source needs to feed the engine: one scene is timed here, in the parent (the uniform generator
+            # costs ~0.8 ms, the KITTI reader + sampler of kitti_io.KittiSource 1.6-4 ms, a raw .bin read 0.3 ms), and the count covers
+            # LOADER_TARGET scenes/s with a third to spare -- inside the rank's share of the host (round 6: 6 loaders, the budget of
+            # round 5, fed the KITTI reader's clouds at 3450 scenes/s to an engine that takes 6500; 18 loaders: 5000)
+            t0 = time.perf_counter()
+            (source.load_raw if device_input else source.load)(scene_ids[0])
+            t_load = time.perf_counter() - t0
+            spare = max(1, len(budget["cores"]) - 1 - budget["writers"])
+            workers = int(max(min(workers, spare), min(np.ceil(t_load * LOADER_TARGET * 1.33), 24, spare)))
+            if stats is not None:
+                stats["loader_calibration"] = {"ms_per_scene": round(t_load * 1e3, 2), "loaders": workers}
     stage = None
     if device_input:
         if not on_gpu:
@@ -1267,35 +1417,54 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
                                           seed=getattr(source, "seed", 1024))
     feed = None
     if workers > 0 and len(starts) > 2:
-        # loader PROCESSES (the scene generator / KITTI reader is Python + numpy: threads would serialise on the GIL);
-        # they only produce host arrays, the parent uploads.  prefetch_factor batches per worker stay in flight.
+        # loader PROCESSES (the scene generator / KITTI reader is Python + numpy: threads would serialise on the GIL) that write into
+        # one shared page-locked buffer (_ShmFeed); the parent views a slot and enqueues its upload.
         # Forking a process whose HIP runtime is already initialised is unsupported (sporadic hangs at worker start or
         # exit): once the GPU has been touched the workers come from a fork SERVER (clean interpreters, picklable dataset).
         ctx = "forkserver" if (on_gpu and torch.cuda.is_initialized()) else "fork"
         ctx = os.environ.get("PRCNN_LOADER_CONTEXT", ctx)
-        feed = iter(torch.utils.data.DataLoader(_SceneDataset(source, scene_ids, stage is not None), batch_size=batch_size,
-                                                shuffle=False, num_workers=workers, pin_memory=on_gpu and stage is None,
-                                                prefetch_factor=2, multiprocessing_context=ctx, worker_init_fn=_limit_worker_threads,
-                                                collate_fn=_identity if stage is not None else None))
+        if stage is not None:
+            slot_floats = batch_size * int(os.environ.get("PRCNN_RAW_SLOT_POINTS", "200000")) * 4
+        else:
+            slot_floats = batch_size * cfg.RPN.NUM_POINTS * (4 if cfg.RPN.USE_INTENSITY else 3)
+        feed = _ShmFeed(source, scene_ids, batch_size, stage is not None, workers, ctx, on_gpu, slot_floats)
+        if stats is not None:
+            stats["loader_buffer"] = {"slots": int(feed.buf.shape[0]), "MB": round(feed.buf.numel() * 4 / 1e6, 1), "page_locked": feed.registered}
 
     def load(s):
         ids = scene_ids[s:s + batch_size]
         if not ids:
             return None, ids, None
+        if feed is not None:
+            host, slot, counts, calibs, shapes = feed.next()
+            meta = list(zip(calibs, shapes))
+            if stage is not None:
+                pts, _ = stage.from_packed(host, counts, calibs, shapes, ids, lidar_frame=source.raw_in_lidar_frame,
+                                           image_filter=source.raw_needs_image_filter)
+                feed.release(slot, stage.last_done)
+                return pts, ids, meta
+            if not on_gpu:
+                pts = host.clone()
+                feed.release(slot, None)
+                return pts, ids, meta
+            if feed.registered:
+                pts = host.to(device, non_blocking=True)
+            else:                                                   # registration refused: through a pinned staging copy
+                pts = host.pin_memory().to(device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            feed.release(slot, ev)
+            return pts, ids, meta
         if stage is not None:
-            raws = [t.numpy() for t in next(feed)] if feed is not None else [source.load_raw(i)[0] for i in ids]
+            raws = [source.load_raw(i)[0] for i in ids]
             meta = [source.calib_and_shape(i) for i in ids]
             pts, _ = stage(raws, [m[0] for m in meta], [m[1] for m in meta], ids,
                            lidar_frame=source.raw_in_lidar_frame, image_filter=source.raw_needs_image_filter)
             return pts, ids, meta
-        if feed is not None:
-            host = next(feed)
-            meta = [source.calib_and_shape(i) for i in ids]
-        else:
-            loaded = [source.load(i) for i in ids]
-            host = torch.from_numpy(np.stack([l[0] for l in loaded], 0))
-            host = host.pin_memory() if on_gpu else host
-            meta = [(l[1], l[2]) for l in loaded]
+        loaded = [source.load(i) for i in ids]
+        host = torch.from_numpy(np.stack([l[0] for l in loaded], 0))
+        host = host.pin_memory() if on_gpu else host
+        meta = [(l[1], l[2]) for l in loaded]
         return host.to(device, non_blocking=True), ids, meta
 
     # Results are consumed LATE: the D2H copy of a batch is queued (on the stream that produced it) the moment the batch
@@ -1380,7 +1549,8 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
         j.result()
     if writers is not None:
         writers.shutdown()
-    del feed
+    if feed is not None:
+        feed.close()
     return pack_detections(scene_ids, [results[k] for k in sorted(results)], M)
 
 

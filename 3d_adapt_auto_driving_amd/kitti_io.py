@@ -196,7 +196,7 @@ class DeviceInputStage:
         if bufs[k] is not None and bufs[k][2] is not None:
             bufs[k][2].synchronize()               # the upload that last used this buffer has completed
         raw, small = (None, None) if bufs[k] is None else bufs[k][:2]
-        if raw is None or raw.numel() < need:      # the two buffers grow INDEPENDENTLY (a later call with more,
+        if need and (raw is None or raw.numel() < need):      # the two buffers grow INDEPENDENTLY (a later call with more,
             raw = torch.empty((need,), dtype=torch.float32).pin_memory()     # smaller clouds overran the small one)
         if small is None or small.numel() < B * 40 + 64:
             small = torch.empty((B * 40 + 64,), dtype=torch.float32).pin_memory()
@@ -204,25 +204,39 @@ class DeviceInputStage:
         return k, raw, small
 
     def __call__(self, raws, calibs, shapes, scene_ids, lidar_frame=True, image_filter=True, return_choice=False):
+        return self._run(raws, None, calibs, shapes, scene_ids, lidar_frame, image_filter, return_choice)
+
+    def from_packed(self, host, counts, calibs, shapes, scene_ids, lidar_frame=True, image_filter=True, return_choice=False):
+        """The same stage over raw clouds that already lie packed in page-locked memory: ``host`` (B, n_max, stride) f32 -- a slot of the
+        loaders' shared buffer (eval_rcnn._ShmFeed), rows beyond ``counts[i]`` unused -- is uploaded as it is, no staging copy."""
+        return self._run(None, (host, [int(c) for c in counts]), calibs, shapes, scene_ids, lidar_frame, image_filter, return_choice)
+
+    def _run(self, raws, packed, calibs, shapes, scene_ids, lidar_frame, image_filter, return_choice):
         import ctypes
         import torch
         from . import _lib
         cfg = self.cfg
-        B = len(raws)
-        stride = raws[0].shape[1]
-        n_max = max(1, max(r.shape[0] for r in raws))
         dev = self.device
-        k, pin_raw, pin_small = self._staging(B, n_max, stride)
-        host = pin_raw[:B * n_max * stride].view(B, n_max, stride)
-        hnp = host.numpy()
-        for i, r in enumerate(raws):               # rows beyond a cloud's length are never read (counts)
-            hnp[i, :r.shape[0]] = r
+        if packed is None:
+            B = len(raws)
+            stride = raws[0].shape[1]
+            n_max = max(1, max(r.shape[0] for r in raws))
+            lengths = [r.shape[0] for r in raws]
+            k, pin_raw, pin_small = self._staging(B, n_max, stride)
+            host = pin_raw[:B * n_max * stride].view(B, n_max, stride)
+            hnp = host.numpy()
+            for i, r in enumerate(raws):               # rows beyond a cloud's length are never read (counts)
+                hnp[i, :r.shape[0]] = r
+        else:
+            host, lengths = packed
+            B, n_max, stride = host.shape
+            k, pin_raw, pin_small = self._staging(B, 0, 0)
         raw = host.to(dev, non_blocking=True)
         # the per-scene calibration rows travel as one pinned block; counts and seeds are two tiny uploads
         meta = np.zeros((B, 38), dtype=np.float32)
         meta[:, 0:35] = np.stack([self.pack_calib(c, s) for c, s in zip(calibs, shapes)], 0)
         ints = np.zeros((B, 3), dtype=np.int64)
-        ints[:, 0] = [r.shape[0] for r in raws]
+        ints[:, 0] = lengths
         ints[:, 1] = [self.seed + int(i) for i in scene_ids]
         small = pin_small[:B * 38].view(B, 38)
         small.copy_(torch.from_numpy(meta))
@@ -233,6 +247,7 @@ class DeviceInputStage:
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(dev))
         self._pinned[k] = (pin_raw, pin_small, done)
+        self.last_done = done                         # (the uploads of this call have completed behind it: eval_rcnn._ShmFeed recycles the slot)
         npoints = cfg.RPN.NUM_POINTS
         out = torch.empty((B, npoints, 3), dtype=torch.float32, device=dev)
         stats = torch.empty((B, 3), dtype=torch.int32, device=dev)

@@ -25,6 +25,7 @@ SWITCHES = {
     "PRCNN_GEO_DEPTH": ("operational", "3*group", "eval_rcnn.py", "batches the geometry runs ahead"),
     "PRCNN_SIDE_STREAMS": ("operational", "2", "eval_rcnn.py", "geometry side streams (with feature + proposal stream: the 4 hardware queues)"),
     "PRCNN_LOADER_THREADS": ("operational", "1", "eval_rcnn.py", "threads of the numeric libraries (BLAS / OpenMP) in every loader and writer process; 0: leave them alone (round 6: a loader's small numpy products fanned out over the whole host's thread pool)"),
+    "PRCNN_RAW_SLOT_POINTS": ("operational", "200000", "eval_rcnn.py", "points per raw cloud a slot of the loaders' shared page-locked buffer holds with --device_input (slot = batch x points x 16 bytes; a larger cloud raises)"),
     "PRCNN_LOADER_WORKERS": ("operational", "budget", "eval_rcnn.py", "loader processes of eval_scenes (default: host_budget)"),
     "PRCNN_WRITER_PROCS": ("operational", "budget", "eval_rcnn.py", "KITTI result writer processes"),
     "PRCNN_LOADER_CONTEXT": ("operational", "forkserver/fork", "eval_rcnn.py", "multiprocessing start method of loaders and writers"),
