@@ -1230,7 +1230,7 @@ def all_gather_detections(table, counts, device, force=False):
 
 
 
-LOADER_TARGET = 9000.0          # scenes/s the loader processes are sized for (above the engine's rate on any scene kind)
+LOADER_TARGET = 6500.0          # scenes/s the loader processes are sized for
 
 
 def _calib_row(calib):
@@ -1397,15 +1397,19 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
     if workers is None:
         workers = budget["loaders"]
         if "PRCNN_LOADER_WORKERS" not in os.environ and len(starts) > 2:
-            # as many loaders as THIS source needs to feed the engine: one scene is timed here, in the parent (the uniform generator
-            # costs ~0.8 ms, the KITTI reader + sampler of kitti_io.KittiSource 1.6-4 ms, a raw .bin read 0.3 ms), and the count covers
-            # LOADER_TARGET scenes/s with a third to spare -- inside the rank's share of the host (round 6: 6 loaders, the budget of
-            # round 5, fed the KITTI reader's clouds at 3450 scenes/s to an engine that takes 6500; 18 loaders: 5000)
+            # as many loaders as THIS source needs to feed the engine: a scene is timed here, in the parent (the uniform generator costs
+            # ~0.8 ms, the KITTI reader + sampler of kitti_io.KittiSource ~2 ms, a raw .bin read 0.3 ms), and the count covers
+            # LOADER_TARGET scenes/s with a third to spare -- at least the budget's 6, at most 12, inside the rank's share of the host.  More is NOT better
+            # (profiles/r06_driver_sweep.md, KITTI tree + host sampler: 6 loaders 4060, 12: 5200-5650, 18: 4900, 24: 4700 scenes/s, and
+            # 4 writers instead of 2 cost another 15 %; round 5 found the same for the uniform source): every runnable process
+            # beyond what the engine consumes takes clock and memory bandwidth from the one thread that feeds the GPU
+            load_one = source.load_raw if device_input else source.load
+            load_one(scene_ids[0])                                  # (first touch: imports, page cache)
             t0 = time.perf_counter()
-            (source.load_raw if device_input else source.load)(scene_ids[0])
+            load_one(scene_ids[min(1, len(scene_ids) - 1)])
             t_load = time.perf_counter() - t0
             spare = max(1, len(budget["cores"]) - 1 - budget["writers"])
-            workers = int(max(min(workers, spare), min(np.ceil(t_load * LOADER_TARGET * 1.33), 24, spare)))
+            workers = int(max(min(workers, spare), min(np.ceil(t_load * LOADER_TARGET * 1.33), 12, spare)))
             if stats is not None:
                 stats["loader_calibration"] = {"ms_per_scene": round(t_load * 1e3, 2), "loaders": workers}
     stage = None
@@ -1525,19 +1529,31 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
     order = 0
     depth = runner.depth if runner is not None else 1
     ahead = [load(k * batch_size) for k in range(depth)]   # `depth` batches ahead: the runner starts their geometry chains early
+    phase = {"load": 0.0, "submit": 0.0, "copy": 0.0, "consume": 0.0} if stats is not None else None     # host seconds of the feeding thread by phase
+    clock = time.perf_counter
     for s in range(0, len(scene_ids), batch_size):
         pts, ids, meta = ahead.pop(0)
+        t0 = clock()
         ahead.append(load(s + depth * batch_size))
+        t1 = clock()
         if runner is not None:
             det = runner.submit(pts, [a[0] for a in ahead])        # an earlier batch's detections (in submit order), or None
             submitted.append((ids, meta, order))
+            t2 = clock()
             if det is not None:
                 start_copy(det, *submitted.popleft())
         else:
+            t2 = clock()
             start_copy(infer_batch(model, cfg, pts), ids, meta, order)
+        t3 = clock()
         order += 1
         while len(inflight) > lag:
             consume()
+        if phase is not None and order > depth:                    # (steady state: behind the first look-ahead's worth of batches)
+            phase["load"] += t1 - t0; phase["submit"] += t2 - t1; phase["copy"] += t3 - t2; phase["consume"] += clock() - t3
+            phase["batches"] = phase.get("batches", 0) + 1
+    if phase is not None:
+        stats["host_phases_ms_per_batch"] = {k: round(v / max(1, phase.get("batches", 1)) * 1e3, 3) for k, v in phase.items() if k != "batches"}
     while runner is not None and submitted:
         det = runner.flush()                                        # one batch per call, oldest first
         if det is None:

@@ -350,7 +350,8 @@ def driver_leg(cfg, model, dev, scenes=4096):
         finally:
             shutil.rmtree(out, ignore_errors=True)
         return {"value": round(E.steady_state_rate(stats, BATCH), 1), "unit": "scenes/s", "scenes": len(src.ids), "result_files": files,
-                "detections": int(counts.sum()), "host_budget": stats.get("host_budget")}
+                "detections": int(counts.sum()), "host_budget": stats.get("host_budget"), "loaders": (stats.get("loader_calibration") or {}).get("loaders"),
+                "host_phases_ms_per_batch": stats.get("host_phases_ms_per_batch")}
 
     line = run(K.SyntheticSource(cfg, scenes))
     line["what"] = ("eval_scenes: synthetic scene source + host 16384-point stage in loader processes, pinned upload, engine, "

@@ -14,11 +14,11 @@ if __name__ == "__main__":
     cfg = C.default_eval_cfg(); dev = torch.device("cuda", 0); model = E.build_model(cfg, dev, seed=0)
     scenes = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4096
     r = bench.driver_leg(cfg, model, dev, scenes=scenes)
-    print("| driver | scenes/s (steady state) | host budget |\n|---|---|---|")
-    print("| uniform synthetic source, host sampler | %.0f | %s |" % (r["value"], r["host_budget"]))
+    print("| driver | scenes/s (steady state) | loaders | feeding thread, ms per batch by phase |\n|---|---|---|---|")
+    print("| uniform synthetic source, host sampler | %.0f | %s | %s |" % (r["value"], r["loaders"], r["host_phases_ms_per_batch"]))
     for k in ("lidar_kitti_tree", "lidar_kitti_tree_device_input"):
         if k in r:
-            print("| %s | %.0f | %s |" % (k, r[k]["value"], r[k]["host_budget"]))
+            print("| %s | %.0f | %s | %s |" % (k, r[k]["value"], r[k]["loaders"], r[k]["host_phases_ms_per_batch"]))
     if "lidar_kitti_tree_error" in r:
         print("error:", r["lidar_kitti_tree_error"])
     # the engine alone on the clouds the KITTI tree's loader produces (closed loop, inputs resident)
