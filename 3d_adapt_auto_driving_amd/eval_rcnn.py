@@ -1126,6 +1126,59 @@ def _node_affinity():
     return _NODE_AFFINITY
 
 
+def _cpu_topology(allowed):
+    """-> [[(physical cpu, sibling, ...), ...] per NUMA node], restricted to ``allowed``, from sysfs; None when it cannot be read.
+    (EPYC hosts number the first hardware threads 0 .. P-1 across the sockets and the SMT siblings P .. 2P-1: a CONTIGUOUS range of CPU
+    ids is not a set of neighbouring cores -- on the 2 x 64-core MI355X boxes ids 64-127 are the OTHER socket, 128-191 the siblings of 0-63.)"""
+    import glob
+
+    def parse(text):
+        out = []
+        for part in text.strip().split(","):
+            if part:
+                lo, _, hi = part.partition("-")
+                out += range(int(lo), int(hi or lo) + 1)
+        return out
+    try:
+        allowed = set(allowed)
+        nodes = []
+        for path in sorted(glob.glob("/sys/devices/system/node/node[0-9]*/cpulist"), key=lambda q: int(q.split("node")[-1].split("/")[0])):
+            with open(path) as f:
+                cpus = [c for c in parse(f.read()) if c in allowed]
+            groups, seen = [], set()
+            for c in cpus:
+                if c in seen:
+                    continue
+                with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
+                    sib = [x for x in parse(f.read()) if x in allowed]
+                seen.update(sib)
+                groups.append(tuple(sorted(sib)))
+            if groups:
+                nodes.append(groups)
+        if {c for n in nodes for t in n for c in t} != allowed:     # sysfs does not describe the CPUs we were given: no topology
+            return None
+        return nodes or None
+    except (OSError, ValueError):
+        return None
+
+
+def slice_topology(topo, world, k):
+    """rank k of ``world`` local ranks on a host of ``topo`` (= _cpu_topology): the ranks are dealt to the NUMA nodes in order (GPUs
+    0 .. W/2-1 hang off node 0, the rest off node 1 on the 2-socket MI355X hosts), a node's PHYSICAL cores are cut into equal runs, and
+    a rank gets its run's first hardware threads followed by their SMT siblings -> list of CPU ids, physical cores first."""
+    rpn = -(-world // len(topo))                                       # ranks per node
+    node = min(k // rpn, len(topo) - 1)
+    groups = topo[node]
+    on_node = max(1, min(rpn, world - node * rpn))
+    gper = max(1, len(groups) // on_node)
+    g = groups[(k % rpn) * gper:(k % rpn) * gper + gper] or groups
+    return [t[0] for t in g] + [c for t in g for c in t[1:]]
+
+
+PIN_CORES = 32      # CPUs a rank's processes are confined to (profiles/r06_driver_sweep.md: the whole driver on 32 cores of the GPU's socket
+#                     runs 5800-6200 scenes/s on the KITTI tree, on 64 cores 5000-5400, unconfined on 256 CPUs 4500-5600)
+
+
 def host_budget(world=None, local_rank=None, cores=None):
     """The share of the host one rank may use when W ranks of a node each drive a GPU with loader and writer processes
     (at 16 loaders + 6 writers per rank, 8 ranks are 176 processes on 128-256 cores with no placement).
@@ -1135,6 +1188,7 @@ def host_budget(world=None, local_rank=None, cores=None):
     world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) if world is None else int(world)
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else int(local_rank)
     world = max(1, world)
+    topo_ok = cores is None
     if cores is None:
         # always sliced from the affinity the process started with, never from a slice an earlier call pinned it to (ADVICE r3:
         # 128 cores became 16, then 2, then 1 over repeated eval_scenes calls); a rank its launcher already confined to a 1/W share
@@ -1149,6 +1203,14 @@ def host_budget(world=None, local_rank=None, cores=None):
     per = max(1, len(cores) // world_slices)
     k = local_rank % world_slices
     mine = cores[k * per:k * per + per] or cores
+    pin = None
+    if topo_ok:
+        # the real machine: a rank's share = a run of PHYSICAL cores of one NUMA node (GPUs 0 .. W/2-1 hang off node 0, the rest off
+        # node 1) plus their SMT siblings, physical cores first; the processes are pinned to the first PIN_CORES of it
+        topo = _cpu_topology(cores)
+        if topo:
+            mine = slice_topology(topo, world_slices, k)
+            pin = mine[:PIN_CORES]
     # one core for the thread that feeds the GPU, a quarter of the rest for the writers (text formatting), the rest for the loaders --
     # at most 6 + 2 (round 5, profiles/r05_driver_shares.md: the whole driver runs 5260-5400 scenes/s with 6 loaders + 2 writers,
     # 4550-5110 with 8 + 2, 3800-3900 with 8-10 + 3 and 3200-3600 with the 16 + 6 of rounds 2-4 on the same 256-core box: beyond what
@@ -1156,16 +1218,21 @@ def host_budget(world=None, local_rank=None, cores=None):
     spare = max(1, len(mine) - 1)
     writers = max(1, min(2, spare // 4))
     loaders = max(1, min(6, spare - writers))
-    return {"cores": mine, "loaders": int(os.environ.get("PRCNN_LOADER_WORKERS", loaders)),
+    if pin is None:                                     # no topology (or an explicit core list): a single rank takes the head of its cores
+        pin = mine[:PIN_CORES] if world_slices == 1 else mine
+    return {"cores": mine, "pin": pin,
+            "loaders": int(os.environ.get("PRCNN_LOADER_WORKERS", loaders)),
             "writers": int(os.environ.get("PRCNN_WRITER_PROCS", writers)), "world": world, "local_rank": local_rank}
 
 
 def pin_to_budget(budget):
-    """Restrict this process (and the loader / writer processes it starts: affinity is inherited) to the rank's cores."""
-    if os.environ.get("PRCNN_NO_AFFINITY") == "1" or budget["world"] <= 1:
+    """Restrict this process (and the loader / writer processes it starts: affinity is inherited) to the rank's cores -- since round 6
+    also a single rank, to budget["pin"]: PIN_CORES neighbouring cores next to its GPU.  eval_scenes restores the previous affinity
+    when it returns.  PRCNN_NO_AFFINITY=1: leave the affinity alone."""
+    if os.environ.get("PRCNN_NO_AFFINITY") == "1":
         return False
     try:
-        os.sched_setaffinity(0, budget["cores"])
+        os.sched_setaffinity(0, budget.get("pin") or budget["cores"])
         return True
     except (AttributeError, OSError):
         return False
@@ -1367,9 +1434,27 @@ class _ShmFeed:
             self.registered = False
 
 
+def eval_scenes(*args, **kwargs):
+    """eval_scenes_pinned with the process's CPU affinity put back afterwards (the driver confines itself and its loader / writer
+    processes to the rank's cores: host_budget / pin_to_budget; a caller that goes on to other work -- bench.py's CPU baseline --
+    gets the whole host back)."""
+    try:
+        before = os.sched_getaffinity(0)
+    except (AttributeError, OSError):
+        before = None
+    try:
+        return eval_scenes_pinned(*args, **kwargs)
+    finally:
+        if before is not None:
+            try:
+                os.sched_setaffinity(0, before)
+            except OSError:
+                pass
+
+
 @torch.no_grad()
-def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=None, workers=None, device_input=False,
-                recall=None, stats=None):
+def eval_scenes_pinned(model, cfg, device, source, scene_ids, batch_size=8, output_dir=None, workers=None, device_input=False,
+                       recall=None, stats=None):
     """Evaluate ``scene_ids`` of a scene source (kitti_io.KittiSource / SyntheticSource) on this rank:
     the counterpart of the batch loop of eval_one_epoch_joint (eval_rcnn.py:493-649) incl. the KITTI
     result files.  Returns (table, counts) as pack_detections.
@@ -1389,7 +1474,7 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
     runner = make_runner(model, cfg, device) if on_gpu else None
     budget = host_budget()
     if stats is not None:
-        stats["host_budget"] = {"loaders": budget["loaders"], "writers": budget["writers"], "cores": len(budget["cores"]),
+        stats["host_budget"] = {"loaders": budget["loaders"], "writers": budget["writers"], "cores": len(budget["cores"]), "pin": len(budget["pin"]),
                                 "pinned": pin_to_budget(budget)}
     else:
         pin_to_budget(budget)
@@ -1408,7 +1493,7 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
             t0 = time.perf_counter()
             load_one(scene_ids[min(1, len(scene_ids) - 1)])
             t_load = time.perf_counter() - t0
-            spare = max(1, len(budget["cores"]) - 1 - budget["writers"])
+            spare = max(1, len(budget.get("pin") or budget["cores"]) - 1 - budget["writers"])
             workers = int(max(min(workers, spare), min(np.ceil(t_load * LOADER_TARGET * 1.33), 12, spare)))
             if stats is not None:
                 stats["loader_calibration"] = {"ms_per_scene": round(t_load * 1e3, 2), "loaders": workers}
@@ -1435,12 +1520,16 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
         if stats is not None:
             stats["loader_buffer"] = {"slots": int(feed.buf.shape[0]), "MB": round(feed.buf.numel() * 4 / 1e6, 1), "page_locked": feed.registered}
 
+    feed_wait = [0.0]                      # seconds the feeding thread spent inside feed.next() (waiting for a loader + unpacking its message)
+
     def load(s):
         ids = scene_ids[s:s + batch_size]
         if not ids:
             return None, ids, None
         if feed is not None:
+            tw = time.perf_counter()
             host, slot, counts, calibs, shapes = feed.next()
+            feed_wait[0] += time.perf_counter() - tw
             meta = list(zip(calibs, shapes))
             if stage is not None:
                 pts, _ = stage.from_packed(host, counts, calibs, shapes, ids, lidar_frame=source.raw_in_lidar_frame,
@@ -1533,7 +1622,7 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
     clock = time.perf_counter
     for s in range(0, len(scene_ids), batch_size):
         pts, ids, meta = ahead.pop(0)
-        t0 = clock()
+        t0, w0 = clock(), feed_wait[0]
         ahead.append(load(s + depth * batch_size))
         t1 = clock()
         if runner is not None:
@@ -1550,7 +1639,8 @@ def eval_scenes(model, cfg, device, source, scene_ids, batch_size=8, output_dir=
         while len(inflight) > lag:
             consume()
         if phase is not None and order > depth:                    # (steady state: behind the first look-ahead's worth of batches)
-            phase["load"] += t1 - t0; phase["submit"] += t2 - t1; phase["copy"] += t3 - t2; phase["consume"] += clock() - t3
+            phase["feed_next"] = phase.get("feed_next", 0.0) + feed_wait[0] - w0
+            phase["load"] += t1 - t0 - (feed_wait[0] - w0); phase["submit"] += t2 - t1; phase["copy"] += t3 - t2; phase["consume"] += clock() - t3
             phase["batches"] = phase.get("batches", 0) + 1
     if phase is not None:
         stats["host_phases_ms_per_batch"] = {k: round(v / max(1, phase.get("batches", 1)) * 1e3, 3) for k, v in phase.items() if k != "batches"}

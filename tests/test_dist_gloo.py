@@ -149,6 +149,27 @@ def test_host_budget_world8_slices(ncores):
     assert (b["loaders"], b["writers"]) == want
 
 
+def test_slice_topology_of_a_two_socket_smt_host():
+    """round 6: a rank's share of the REAL machine is a run of physical cores of the NUMA node its GPU hangs off plus their SMT siblings
+    (EPYC numbering: first hardware threads 0 .. 127 across both sockets, siblings 128 .. 255 -- a contiguous id range is neither), the
+    shares of 8 ranks are disjoint and cover the host, and a single rank's pin set is 32 neighbouring physical cores of node 0."""
+    from conftest import pkg
+    E = pkg("eval_rcnn")
+    topo = [[(c, c + 128) for c in range(0, 64)], [(c, c + 128) for c in range(64, 128)]]
+    seen = []
+    for r in range(8):
+        mine = E.slice_topology(topo, 8, r)
+        node = 0 if r < 4 else 1
+        lo = 64 * node + 16 * (r % 4)
+        assert mine == list(range(lo, lo + 16)) + list(range(lo + 128, lo + 144))
+        seen += mine
+    assert sorted(seen) == list(range(256))
+    one = E.slice_topology(topo, 1, 0)
+    assert one[:E.PIN_CORES] == list(range(32)) and len(one) == 128          # node 0: physical cores first
+    two = [E.slice_topology(topo, 2, r) for r in range(2)]
+    assert two[0][:64] == list(range(64)) and two[1][:64] == list(range(64, 128))
+
+
 def test_all_gather_is_identity_without_process_group():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import pkg
