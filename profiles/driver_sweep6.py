@@ -29,7 +29,7 @@ else:
     tree = tempfile.mkdtemp(prefix="prcnn_tree_")
     S.write_kitti_tree(tree, scenes, pool=64)
     print("| source | loaders + writers | library threads per loader | scenes/s (two runs) |\n|---|---|---|---|", flush=True)
-    settings = [("host", 12, 2, "1"), ("host", 18, 2, "1"), ("host", 24, 2, "1"), ("device", 6, 2, "1"), ("device", 12, 2, "1")]
+    settings = [("host", None, None, "1"), ("host", 12, 2, "1"), ("host", 18, 2, "1"), ("device", None, None, "1"), ("device", 12, 2, "1"), ("uniform", None, None, "1")]
     for kind, lw, wp, th in settings:
         env = dict(os.environ, PRCNN_LOADER_THREADS=th)
         if lw is not None:
