@@ -73,6 +73,8 @@ SIGNATURES = {
     "prcnn_sa_packed_mlp": [_I, _I, _I, _I, C.c_long] + [_P] * 11 + [_I, _I, _I, _P],
     "prcnn_packed_gather_affine": [_I, _I, _I, C.c_long] + [_P] * 7 + [_P],
     "prcnn_packed_layer": [_P, C.c_long, C.c_long, _I, _I, _I, _P, C.c_long, _P, _P, _I, _P, C.c_long, _P],
+    "prcnn_split_weights_bf16x3": [_I, _I, _P, _P, _P],
+    "prcnn_rows_layer_bf16x3": [C.c_long, _I, _I, _I, _P, C.c_long, _P, _P, _I, _P, C.c_long, _P],
     "prcnn_packed_layer_interp": [C.c_long, _I, _I, _P, C.c_long, _P, _P, _I, _P, C.c_long, _I, _I, _P, C.c_long, _P, _P, _P],
     "prcnn_sa_xyz_mlp_packed": [_I, _I, _I, _I, _I, C.c_long] + [_P] * 11 + [_I, _I, _I, _P],
     "prcnn_rows_dot": [C.c_long, _I, _I, _P, C.c_long, _P, _P, _P, C.c_long, _P],

@@ -527,6 +527,27 @@ def packed_layer_wrapper(a, wt, bias, relu, out, pack=None):
     return out
 
 
+_SPLIT_W = {}
+
+
+def rows_layer_bf16x3_wrapper(a, wt, bias, relu, out):
+    """EXPERIMENT (numerics switch PRCNN_SPLIT_BF16, csrc/split_bf16.hip): out = act(a @ wt + bias)[:, :out.size(1)] on the bf16 matrix
+    cores with every operand split into three bf16 pieces (six products per k-step, f32 accumulation): ~1e-7 relative to the f32 fma
+    chain of packed_layer_wrapper, NOT its bits.  The split weights are cached per weight tensor."""
+    _chk(torch.float32, wt, bias)
+    R, K = a.shape
+    N = wt.size(1)
+    key = (wt.data_ptr(), wt._version, K, N, str(wt.device))
+    ws = _SPLIT_W.get(key)
+    if ws is None:
+        ws = torch.empty(((K // 16) * (N // 32) * 3 * 64 * 16,), dtype=torch.uint8, device=wt.device)     # three 16-byte pieces per lane, k-step and column block
+        _lib.call("prcnn_split_weights_bf16x3", K, N, wt.data_ptr(), ws.data_ptr(), _lib.current_stream(wt))
+        _SPLIT_W[key] = ws
+    _lib.call("prcnn_rows_layer_bf16x3", R, K, N, out.size(1), a.data_ptr(), a.stride(0), ws.data_ptr(), bias.data_ptr(), int(bool(relu)),
+              out.data_ptr(), out.stride(0), _lib.current_stream(a))
+    return out
+
+
 def packed_layer_interp_wrapper(a, wt, bias, relu, out, G, idx, weight):
     """out = act((a @ wt + bias) + interp3(G)): the first layer of a feature-propagation module with the interpolation behind the
     layer's linear part (prcnn_packed_layer_interp).  a (B*n, K) skip features, wt (K, N), G (B, m, N) = coarse features @ the

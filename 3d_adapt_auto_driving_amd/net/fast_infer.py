@@ -200,6 +200,9 @@ def gemm_bias_act(a, wt, bias, relu):
     return torch.addmm(bias, a, wt)
 
 
+SPLIT_BF16 = os.environ.get("PRCNN_SPLIT_BF16") == "1"      # numerics experiment (profiles/r06_split_bf16.md): plain per-point layers as three-way bf16 splits
+
+
 def point_layer(a, wt, bias, relu, n_out=None):
     """act(a @ wt + bias)[:, :n_out] for a per-point (row-major) matrix: the tiled MFMA layer kernel of
     csrc/packed_layer.hip when K and N are multiples of 128 (fixed summation order, reproduced bit for bit by the oracle),
@@ -209,6 +212,9 @@ def point_layer(a, wt, bias, relu, n_out=None):
     if (USE_PACKED and K % 128 == 0 and N % 128 == 0 and a.dim() == 2 and a.shape[1] == K and a.stride(1) == 1
             and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0):
         out = torch.empty((a.shape[0], n_out), dtype=torch.float32, device=a.device)
+        if SPLIT_BF16 and getattr(pu.pointnet2, "IS_HIP_EXTENSION", False):
+            # EXPERIMENT (numerics switch, default off): the layer on the bf16 matrix cores, operands split in three (csrc/split_bf16.hip)
+            return pu.pointnet2.rows_layer_bf16x3_wrapper(a, wt, bias, relu, out)
         return pu.pointnet2.packed_layer_wrapper(a, wt, bias, relu, out)
     y = gemm_bias_act(a, wt, bias, relu)
     return y if n_out == N else y[:, :n_out].contiguous()

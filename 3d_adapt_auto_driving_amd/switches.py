@@ -34,6 +34,7 @@ SWITCHES = {
     "PRCNN_GRAPHS_FORCE": ("debug", "unset", "__init__.py", "1: replay graphs although DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was not in place (profiles/graph_fault_probe.py)"),
     "PRCNN_GRAPH_DEBUG": ("debug", "0", "eval_rcnn.py", "bit mask: device syncs + prints around the graph replays"),
     # ---- numerics
+    "PRCNN_SPLIT_BF16": ("numerics", "unset", "net/fast_infer.py", "1: EXPERIMENT -- the plain per-point layers (point_layer: FP modules' second layers, coarse products, RCNN heads) on the bf16 matrix cores with every operand split exactly into three bf16 pieces (csrc/split_bf16.hip): ~1e-7 relative to the f32 fma chain, not its bits; measured in profiles/r06_split_bf16.md, never the headline"),
     "PRCNN_NO_FP_LINEAR": ("numerics", "unset", "net/fast_infer.py", "FP layer 1 over the interpolated tensor (reference association) instead of interp(W f)"),
     "PRCNN_LIB_GEMM": ("numerics", "unset", "net/fast_infer.py", "per-point layers through torch (library GEMM) instead of csrc/packed_layer.hip"),
     "PRCNN_ALLOW_LIB_GEMM": ("numerics", "unset", "net/fast_infer.py", "1: permit a library GEMM for a shape the layer kernels do not cover (else: error)"),

@@ -323,6 +323,15 @@ int prcnn_packed_gather_affine(int b, int n, int c1, long max_tiles, const float
                                const unsigned int *hdr, float *out, void *stream);
 int prcnn_packed_layer(const unsigned int *hdr, long rows, long max_tiles, int K, int N, int n_store, const float *A,
                        long lda, const float *W, const float *bias, int relu, float *out, long ldo, void *stream);
+/* EXPERIMENT (round 6, numerics switch PRCNN_SPLIT_BF16, default off; csrc/split_bf16.hip): the plain per-point layer of prcnn_packed_layer
+ * (hdr == NULL form) on the bf16 matrix cores, every operand split exactly into three bf16 pieces, six products per k-step of 16,
+ * f32 accumulation: ~1e-7 relative to the f32 fma chain, not its bits.  prcnn_split_weights_bf16x3: W (K, N) f32 -> `out`
+ * ((K / 16) * (N / 32) * 3 * 64 * 16 bytes: the B operands of v_mfma_f32_32x32x16_bf16 in issue order), once per weight matrix;
+ * prcnn_rows_layer_bf16x3: out[:, 0..n_store) = act(A @ W + bias).  K % 16 == 0, N % 128 == 0, lda % 4 == 0, A 16-byte aligned.
+ * Replaces nothing of the reference's (its convolutions are a GEMM library's: pytorch_utils.py:35-101); measured in profiles/r06_split_bf16.md. */
+int prcnn_split_weights_bf16x3(int K, int N, const float *W, void *out, void *stream);
+int prcnn_rows_layer_bf16x3(long rows, int K, int N, int n_store, const float *A, long lda, const void *wsplit, const float *bias,
+                            int relu, float *out, long ldo, void *stream);
 /* First layer of a feature-propagation module (pointnet2_modules.py:139-156) with the interpolation moved behind the layer's
  * linear part: out[r] = act((A[r] @ W + bias) + ((w0 G[i0] + w1 G[i1]) + w2 G[i2])), A (rows,K) = the skip features, W (K,N) = the
  * skip columns of the layer, G = coarse features @ the interpolated columns of the layer (clouds * m_known rows, N wide),
