@@ -569,3 +569,31 @@ def test_rpn_tail_kernel_equals_the_separate_kernels_at_the_batch8_shape(ext):
     hr = lay(f2, 512, 640, 3, True, 128)
     r2 = lay(hr, 640, 768, 4, False, n_reg)
     assert torch.equal(feats.view(-1, 128), f2) and torch.equal(cls.view(-1, 1), c2) and torch.equal(reg.view(-1, n_reg), r2)
+
+
+@pytest.mark.parametrize("rows,K,N,n_store", [(1000, 128, 128, 128), (70, 256, 256, 256), (513, 512, 128, 77), (256, 128, 384, 384)])
+def test_split_bf16_layer_is_an_f32_class_product(ext, rows, K, N, n_store):
+    """EXPERIMENT (numerics switch PRCNN_SPLIT_BF16, default off; csrc/split_bf16.hip): act(A @ W + b) as six bf16 MFMAs per k-step
+    over operands split exactly into three bf16 pieces.  Not the f32 kernels' bits (those are pinned by the oracle above): held to a
+    float64 product of the same f32 operands within 1e-6 of each row's sum of |terms| -- the f32 fma chain's own error level --, on
+    ragged row counts (the last 256-row tile partly filled), a narrow store (n_store < N) and several column blocks; and A = I hands
+    an asymmetric W back exactly (the operand layouts of v_mfma_f32_32x32x16_bf16)."""
+    g = torch.Generator().manual_seed(rows + K)
+    a = torch.randn((rows, K), generator=g).relu_().to(DEV)
+    w = (torch.randn((K, N), generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn((N,), generator=g).to(DEV)
+    out = torch.full((rows + 3, n_store), -7.0, device=DEV)
+    ext.pointnet2.rows_layer_bf16x3_wrapper(a, w, b, True, out[:rows])
+    ref = torch.relu(a.double() @ w.double() + b.double())[:, :n_store]
+    scale = (a.double().abs() @ w.double().abs() + b.double().abs())[:, :n_store]
+    assert float(((out[:rows].double() - ref).abs() / scale).max()) < 1e-6
+    assert (out[rows:] == -7.0).all()                                   # nothing stored past the ragged end
+    f32 = torch.empty((rows, n_store), device=DEV)
+    ext.pointnet2.packed_layer_wrapper(a, w, b, True, f32)
+    assert float((out[:rows] - f32).abs().max()) < 2e-5
+    if K == N == 128:
+        eye = torch.eye(K, device=DEV)
+        w2 = (torch.arange(K * N, dtype=torch.float32, device=DEV).view(K, N) / 7.0).contiguous()
+        o2 = torch.empty((K, N), device=DEV)
+        ext.pointnet2.rows_layer_bf16x3_wrapper(eye, w2, torch.zeros(N, device=DEV), False, o2)
+        assert torch.equal(o2, w2)
