@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64 * WAVES) void fps_reg_kernel(
     int *__restrict__ sel = idx + (long)b * m;
     float *__restrict__ nxyz = new_xyz ? new_xyz + (long)b * m * 3 : nullptr;
     const int t = threadIdx.x;
-    __builtin_amdgcn_s_setprio(3);   // latency-bound dependent chain: win issue arbitration (see fps_pruned_kernel)
+    __builtin_amdgcn_s_setprio(3);   // latency-bound dependent chain: win issue arbitration (see fps_spec_kernel)
 
     float px[PPT], py[PPT], pz[PPT], pt[PPT];
     uint32_t pk[PPT];
@@ -370,114 +370,13 @@ __global__ __launch_bounds__(1024) void fps_order_kernel(int n, const float *__r
     for (int k = t; k < n; k += 1024) perm[(long)b * n + atomicAdd(&cnt[code_of(k)], 1)] = k;
 }
 
-template <int PPT, int THREADS>
-__global__ __launch_bounds__(THREADS) void fps_pruned_kernel(
-    int n, int m, KeyCodec kc, const float *__restrict__ xyz, const int *__restrict__ perm,
-    float *__restrict__ temp, int *__restrict__ idx)
-{
-    __shared__ unsigned long long s_best[3];
-    const int b = blockIdx.x;
-    const float *__restrict__ cloud = xyz + (long)b * n * 3;
-    const int *__restrict__ order = perm + (long)b * n;
-    float *__restrict__ mind = temp + (long)b * n;
-    int *__restrict__ sel = idx + (long)b * m;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    // FPS is a chain of ~m dependent iterations: when it shares a CU with another stream's waves (the
-    // pipelined runner overlaps it with the feature pass) every lost issue slot is pure latency, so its
-    // waves take the highest arbitration priority; they are few (<= 16 per CU) and mostly wait on barriers.
-    __builtin_amdgcn_s_setprio(3);
-
-    float px[PPT], py[PPT], pz[PPT], pt[PPT];
-    uint32_t pk[PPT];
-    // lane i < PPT keeps the bounding box of tile i of this wave
-    float bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY, bz0 = INFINITY, bz1 = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        const int s = w * (64 * PPT) + i * 64 + lane;      // position in Morton order
-        float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY, z0 = INFINITY, z1 = -INFINITY;
-        if (s < n) {
-            const int k = order[s];
-            px[i] = cloud[3 * k]; py[i] = cloud[3 * k + 1]; pz[i] = cloud[3 * k + 2];
-            pt[i] = mind[k];
-            pk[i] = kc.encode(k);
-            x0 = x1 = px[i]; y0 = y1 = py[i]; z0 = z1 = pz[i];
-        } else {
-            px[i] = py[i] = pz[i] = 0.f;
-            pt[i] = -INFINITY;
-            pk[i] = 0xffffffffu;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            x0 = fminf(x0, __shfl_xor(x0, d, 64)); x1 = fmaxf(x1, __shfl_xor(x1, d, 64));
-            y0 = fminf(y0, __shfl_xor(y0, d, 64)); y1 = fmaxf(y1, __shfl_xor(y1, d, 64));
-            z0 = fminf(z0, __shfl_xor(z0, d, 64)); z1 = fmaxf(z1, __shfl_xor(z1, d, 64));
-        }
-        if (lane == i) { bx0 = x0; bx1 = x1; by0 = y0; by1 = y1; bz0 = z0; bz1 = z1; }
-    }
-    if (t < 3) s_best[t] = 0ull;
-    __syncthreads();
-
-    int old = 0;
-    float vmax = INFINITY;                 // value of the pivot just selected: bounds every running minimum
-    float wbv = -1.0f;                     // this wave's cached best
-    uint32_t wkey = 0xffffffffu;
-    if (t == 0) sel[0] = 0;
-    for (int j = 1; j < m; ++j) {
-        const float ox = cloud[3 * old], oy = cloud[3 * old + 1], oz = cloud[3 * old + 2];
-        // distance from the pivot to tile `lane`'s box: a lower bound for every point of the tile
-        const float dx = fmaxf(fmaxf(bx0 - ox, ox - bx1), 0.f);
-        const float dy = fmaxf(fmaxf(by0 - oy, oy - by1), 0.f);
-        const float dz = fmaxf(fmaxf(bz0 - oz, oz - bz1), 0.f);
-        const float lb = dx * dx + dy * dy + dz * dz;
-        const bool touch = (lane < PPT) && !(lb * 0.99999f >= vmax);   // empty boxes give lb = +inf
-        const unsigned long long mask = __ballot(touch);
-        if (mask != 0ull) {                                              // wave-uniform
-            if (kc.hipcc) {
-#pragma unroll
-                for (int i = 0; i < PPT; ++i)
-                    if ((mask >> i) & 1ull) pt[i] = fminf(fps_dist<true>(px[i], py[i], pz[i], ox, oy, oz), pt[i]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < PPT; ++i)
-                    if ((mask >> i) & 1ull) {
-                        const float d = sqdist3(px[i], py[i], pz[i], ox, oy, oz);
-                        pt[i] = fminf(d, pt[i]);
-                    }
-            }
-            float lv = pt[0];
-#pragma unroll
-            for (int i = 1; i < PPT; ++i) lv = fmaxf(lv, pt[i]);
-            wbv = wave_max_f32(lv);
-            uint32_t lk = 0xffffffffu;
-#pragma unroll
-            for (int i = 0; i < PPT; ++i) {
-                const uint32_t c = pt[i] == wbv ? pk[i] : 0xffffffffu;
-                lk = c < lk ? c : lk;
-            }
-            wkey = wave_min_u32(lk);
-        }
-        const int buf = j % 3;
-        if (lane == 0) atomicMax(&s_best[buf], pack_candidate(wbv, wkey));
-        lds_barrier();         // orders LDS only: __syncthreads() would also drain wave 0's store of sel[j-1] every iteration
-        const unsigned long long best = s_best[buf];
-        if (t == 0) s_best[(j + 2) % 3] = 0ull;        // the slot of iteration j-1: read by every wave before barrier j, next used at j+2
-        float bv;
-        uint32_t bkey;
-        unpack_candidate(best, bv, bkey);
-        vmax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bv)));
-        old = (bkey == 0xffffffffu || !(bv > -1.0f)) ? 0 : kc.decode(bkey);
-        old = __builtin_amdgcn_readfirstlane(old);
-        if (t == 0) sel[j] = old;
-    }
-#pragma unroll
-    for (int i = 0; i < PPT; ++i)
-        if (pk[i] != 0xffffffffu) mind[kc.decode(pk[i])] = pt[i];
-}
+// (fps_pruned_kernel, the one-pick-per-exchange kernel of round 3 -- 4.07 ms for 32 x (16384 -> 4096) against the speculative kernel's
+// 1.69 -- was removed in round 6 together with its switch PRCNN_FPS_SEQUENTIAL; the pruning above lives on in fps_spec_kernel.)
 
 // ---------------------------------------------------------------------------------------------
 // SPECULATIVE multi-pick FPS (round 4) -- the same picks as the sequential scan, several per exchange.
 //
-// fps_pruned_kernel pays one workgroup-wide exchange (LDS atomic, barrier, LDS read, scalar load of the pivot) per PICK:
+// Round 3's fps_pruned_kernel paid one workgroup-wide exchange (LDS atomic, barrier, LDS read, scalar load of the pivot) per PICK:
 // 0.99 us x 4095 picks = 4.07 ms for 16384 -> 4096, the longest launch of the step and the limiter on LiDAR-shaped scenes.
 // An exchange can decide MORE than one pick.  Let the points be ordered by (running minimum desc, tie key asc) and let
 // g0, g1, ... be the head of that order.  g0 is the next pick.  If adding g0 leaves g1's minimum unchanged
@@ -1159,7 +1058,7 @@ __global__ __launch_bounds__(256) void fps_gather_xyz_kernel(int n, int m, const
 }  // namespace prcnn
 
 // new_xyz != NULL (prcnn_fps_new_xyz; temp may then be NULL): the speculative kernel (2048 < n <= 16384, m >= 256) writes the
-// coordinates itself; every other route (PRCNN_FPS_SEQUENTIAL / PRCNN_FPS_NO_PRUNE, few samples, n > 16384) runs its kernel over an
+// coordinates itself; every other route (few samples, small clouds, n > 32768 or a device that cannot hold the two-workgroup kernel) runs its kernel over an
 // internal distance scratch filled with the reference caller's 1e10 and gathers the coordinates behind it -- same indices, same
 // coordinates, two small launches more (round 5; ADVICE r4: those routes used to refuse)
 // how many fps_spec2_kernel workgroups the current device holds at once (0: it refuses the dynamic LDS); cached per device
@@ -1204,19 +1103,16 @@ static int fps_any(int b, int n, int m, const float *xyz, float *temp, int *idx,
 
     // large clouds: Morton ordering + pruned scan (exact).  It needs (n ints) of scratch per scene and pays
     // off when the sample count is large enough for the pruning radius to shrink.
-    static const bool no_prune = getenv("PRCNN_FPS_NO_PRUNE") != nullptr;
-    static const bool sequential = getenv("PRCNN_FPS_SEQUENTIAL") != nullptr;          // A/B: one pick per exchange (round 3)
-    static const bool no_two = getenv("PRCNN_FPS_NO_PAIR") != nullptr;                 // A/B: 16384 < n <= 32768 on fps_generic_kernel (rounds 1-4)
     // the two-workgroup kernel spins on its partner: only where BOTH halves of every cloud of a launch are resident at once.  One such
     // workgroup holds a CU (84 KB of LDS); a launch takes at most HALF of what the device can hold (the other geometry stream may be
     // running the same kernel: per XCD at most one unpaired block per launch is resident, every other resident block has its partner
     // and makes progress), larger batches go as several launches.  A device that refuses the LDS (64 KB parts) or has fewer than 32
     // such slots keeps fps_generic_kernel
     static const size_t pad2 = (size_t)(getenv("PRCNN_FPS_LDS_PAD") ? atoi(getenv("PRCNN_FPS_LDS_PAD")) : 84) * 1024;
-    const bool pair_shape = !no_prune && !sequential && !no_two && n > 16384 && n <= 32768 && m >= 256;
+    const bool pair_shape = n > 16384 && n <= 32768 && m >= 256;
     const int cap2 = pair_shape ? fps2_capacity(pad2) : 0;
     const bool pair_ok = pair_shape && cap2 >= 32;
-    const bool writes_xyz = (!no_prune && !sequential && n > 2048 && n <= 16384 && m >= 256) || pair_ok;
+    const bool writes_xyz = (n > 2048 && n <= 16384 && m >= 256) || pair_ok;
     if (new_xyz && !writes_xyz) {
         if (!temp) {
             temp = (float *)scratch_for(st, (size_t)b * n * sizeof(float), 12);
@@ -1251,7 +1147,7 @@ static int fps_any(int b, int n, int m, const float *xyz, float *temp, int *idx,
         }
         return check_launch("furthest_point_sampling(two workgroups)");
     }
-    if (!no_prune && n > 2048 && n <= 16384 && m >= 256) {
+    if (n > 2048 && n <= 16384 && m >= 256) {
         int *perm = (int *)scratch_for(st, (size_t)b * n * sizeof(int), 1);
         if (!perm) { set_error("fps: cannot allocate ordering scratch"); return PRCNN_ELAUNCH; }
         hipLaunchKernelGGL(fps_order_kernel, dim3(b), dim3(1024), 0, st, n, xyz, perm);
@@ -1260,32 +1156,18 @@ static int fps_any(int b, int n, int m, const float *xyz, float *temp, int *idx,
         // (+1.2 % end to end; only when the batch is small enough that one workgroup per CU costs no concurrency)
         static const size_t pad_cfg = (size_t)(getenv("PRCNN_FPS_LDS_PAD") ? atoi(getenv("PRCNN_FPS_LDS_PAD")) : 84) * 1024;
         const size_t pad = b <= 128 ? pad_cfg : 0;
-        if (pad) {
-            const void *ks[3] = {(const void *)fps_pruned_kernel<4, 1024>, (const void *)fps_pruned_kernel<8, 1024>,
-                                 (const void *)fps_pruned_kernel<16, 1024>};
-            for (const void *k : ks) {
-                const int rc = ensure_dynamic_lds(k, pad, "furthest_point_sampling(pruned)");
-                if (rc != PRCNN_OK) return rc;
-            }
-        }
         // 16 waves per cloud: 8 waves x 32 points per lane runs 4.98 ms, 4 waves x 64 points 7.7 ms (16384 -> 4096, 4.2-4.3 ms here):
         // the per-iteration update of the touched tiles parallelises over waves, the exchange does not get cheaper with fewer
-        if (!sequential) {
-            const void *ss[3] = {(const void *)fps_spec_kernel<4>, (const void *)fps_spec_kernel<8>, (const void *)fps_spec_kernel<16>};
-            if (pad)
-                for (const void *k : ss) {
-                    const int rc = ensure_dynamic_lds(k, pad, "furthest_point_sampling(speculative)");
-                    if (rc != PRCNN_OK) return rc;
-                }
-            if (n <= 4096) hipLaunchKernelGGL((fps_spec_kernel<4>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx, new_xyz);
-            else if (n <= 8192) hipLaunchKernelGGL((fps_spec_kernel<8>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx, new_xyz);
-            else hipLaunchKernelGGL((fps_spec_kernel<16>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx, new_xyz);
-            return check_launch("furthest_point_sampling(speculative)");
-        }
-        if (n <= 4096) hipLaunchKernelGGL((fps_pruned_kernel<4, 1024>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
-        else if (n <= 8192) hipLaunchKernelGGL((fps_pruned_kernel<8, 1024>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
-        else hipLaunchKernelGGL((fps_pruned_kernel<16, 1024>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx);
-        return check_launch("furthest_point_sampling(pruned)");
+        const void *ss[3] = {(const void *)fps_spec_kernel<4>, (const void *)fps_spec_kernel<8>, (const void *)fps_spec_kernel<16>};
+        if (pad)
+            for (const void *k : ss) {
+                const int rc = ensure_dynamic_lds(k, pad, "furthest_point_sampling(speculative)");
+                if (rc != PRCNN_OK) return rc;
+            }
+        if (n <= 4096) hipLaunchKernelGGL((fps_spec_kernel<4>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx, new_xyz);
+        else if (n <= 8192) hipLaunchKernelGGL((fps_spec_kernel<8>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx, new_xyz);
+        else hipLaunchKernelGGL((fps_spec_kernel<16>), dim3(b), dim3(1024), pad, st, n, m, kc, xyz, perm, temp, idx, new_xyz);
+        return check_launch("furthest_point_sampling(speculative)");
     }
     if (n <= 128) launch_reg<1, 2>(b, n, m, kc, xyz, temp, idx, st);
     else if (n <= 256) launch_reg<1, 4>(b, n, m, kc, xyz, temp, idx, st);

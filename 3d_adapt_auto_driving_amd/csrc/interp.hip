@@ -165,7 +165,7 @@ static int three_nn_any(int b, int n, int m, const float *unknown, const float *
     PRCNN_REQUIRE(b <= 65535, "three_nn: batch > 65535");
     if (b == 0 || n == 0) return PRCNN_OK;
     PRCNN_REQUIRE(unknown && (dist2 || weight) && idx && (known || m == 0), "three_nn: null pointer");
-    static const bool brute_only = getenv("PRCNN_THREE_NN_BRUTE") != nullptr;
+    const bool brute_only = false;       // (round 6: switch PRCNN_THREE_NN_BRUTE removed; small levels take the scan by shape)
     if (!brute_only) {
         int used = 0;
         const int rc = three_nn_grid(b, n, m, unknown, known, dist2, idx, (hipStream_t)stream, &used, weight);

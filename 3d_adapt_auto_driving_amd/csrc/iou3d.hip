@@ -302,8 +302,7 @@ int nms_device(int nprob, int n_max, const int *counts, const float *boxes, floa
     PRCNN_REQUIRE(n_max <= NMS_MAX_N, "nms: %d boxes > %d unsupported", n_max, NMS_MAX_N);
     if (nprob == 0) return PRCNN_OK;
     PRCNN_REQUIRE(num_keep && (keep || max_keep == 0) && (boxes || n_max == 0), "nms: null pointer");
-    static const bool quota_form = !(getenv("PRCNN_NMS_QUOTA") && atoi(getenv("PRCNN_NMS_QUOTA")) == 0);   // A/B switch, same results
-    static const bool dense_form = !(getenv("PRCNN_NMS_DENSE") && atoi(getenv("PRCNN_NMS_DENSE")) == 0);   // A/B switch, same results
+    const bool quota_form = true, dense_form = true;      // (round 6: the switches PRCNN_NMS_QUOTA / _DENSE / _FULL are gone; the forms are chosen by shape)
     if (dense_form && n_max >= 1 && n_max <= ND_MAX) {
         // small problems (the final stage: <= 100 boxes per scene): all pairs at once + a one-wave resolve
         unsigned long long *mask = (unsigned long long *)scratch_for(st, (size_t)nprob * ND_MAX * 2 * sizeof(unsigned long long), 10);
@@ -542,7 +541,7 @@ static int nms_blocking(int n, const float *boxes, long long *keep_host, float t
     PRCNN_REQUIRE(boxes && keep_host, "nms: null pointer");
     int *g_scratch = (int *)scratch_for(st, ((size_t)n + 1) * sizeof(int), 7);
     if (!g_scratch) { set_error("nms: cannot allocate %zu bytes of scratch", ((size_t)n + 1) * sizeof(int)); return PRCNN_ELAUNCH; }
-    static const bool full_form = !(getenv("PRCNN_NMS_FULL") && atoi(getenv("PRCNN_NMS_FULL")) == 0);   // A/B switch, same results
+    const bool full_form = true;
     PRCNN_REQUIRE(n <= NMS_MAX_N, "nms: %d boxes > %d unsupported", n, NMS_MAX_N);
     int rc = full_form && n > ND_MAX ? nms_full(n, boxes, thresh, rotated, g_scratch + 1, g_scratch, st)
                                      : nms_device(1, n, nullptr, boxes, thresh, rotated, n, g_scratch + 1, g_scratch, st);

@@ -745,29 +745,15 @@ __global__ __launch_bounds__(256) void rows_dot_kernel(long rows, int K, int n, 
 
 using namespace prcnn;
 
-// PRCNN_PL_PIPE=0: the one-panel-at-a-time loop for every K (A/B runs of profiles/layer_probe.py; same results either way)
-static bool pipe_enabled()
-{
-    static const bool on = [] { const char *e = getenv("PRCNN_PL_PIPE"); return !(e && e[0] == '0'); }();
-    return on;
-}
+// (round 6: the A/B switches PRCNN_PL_PIPE / PRCNN_PL_STREAM / PRCNN_PL_PERSIST / PRCNN_SEGMAX_LDS are gone -- the forms they selected are
+// chosen by shape below, each still reached by the shapes it serves: tests/test_gpu_packed.py)
+static bool pipe_enabled() { return true; }
 
 static long stream_min() { static const long v = getenv("PRCNN_PL_STREAM_MIN") ? atol(getenv("PRCNN_PL_STREAM_MIN")) : 512; return v; }
 static long persist_min() { static const long v = getenv("PRCNN_PL_PERSIST_MIN") ? atol(getenv("PRCNN_PL_PERSIST_MIN")) : 256; return v; }
 static long stream_cap() { static const long v = getenv("PRCNN_PL_STREAM_CAP") ? atol(getenv("PRCNN_PL_STREAM_CAP")) : 512; return v; }
-// PRCNN_PL_STREAM=0: K = 128 layers with one row tile per workgroup (A/B switch, same results)
-static bool stream_enabled()
-{
-    static const bool on = [] { const char *e = getenv("PRCNN_PL_STREAM"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
-// PRCNN_SEGMAX_LDS=0: every tile's segmented max in registers (A/B switch, same results)
-static bool segmax_lds_enabled()
-{
-    static const bool on = [] { const char *e = getenv("PRCNN_SEGMAX_LDS"); return !(e && e[0] == '0'); }();
-    return on;
-}
+static bool stream_enabled() { return true; }
+static bool segmax_lds_enabled() { return true; }
 
 extern "C" int prcnn_rows_dot(long rows, int K, int n, const float *A, long lda, const float *W, const float *bias, float *out,
                               long ldo, void *stream)
@@ -862,7 +848,7 @@ extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr
         const int col_blocks = (n_store + 127) / 128;      // column blocks that hold nothing to store are not launched
         const bool pipe = q.K >= 256 && pipe_enabled();
         cls[k] = (!segmax && !q.hdr && pipe && tiles * col_blocks < 256) ? PL_PIPE32 : (pipe ? PL_PIPE : PL_ONE);
-        // one panel, many row tiles, rows counted on the host: persistent workgroups (PRCNN_PL_STREAM=0: one tile per workgroup)
+        // one panel, many row tiles, rows counted on the host: persistent workgroups (few items: one tile per workgroup)
         if (cls[k] == PL_ONE && !segmax && !q.hdr && q.K == 128 && tiles * col_blocks >= stream_min() && stream_enabled() &&
             q.rows * q.lda * 4 < (1L << 31))
             cls[k] = PL_STREAM;
@@ -876,8 +862,8 @@ extern "C" int prcnn_packed_layer_batch(int nprob, const prcnn_layer_problem *pr
     }
     if (k == 0) return PRCNN_OK;
     // one plain K >= 256 layer over rows counted on the host, whole 128-column blocks stored: the persistent pipeline (round 4;
-    // PRCNN_PL_PERSIST=0: one tile per workgroup as in round 3, same bits)
-    static const bool persist = !(getenv("PRCNN_PL_PERSIST") && atoi(getenv("PRCNN_PL_PERSIST")) == 0);
+    // few items: one tile per workgroup as in round 3, same bits)
+    const bool persist = true;
     if (persist && k == 1 && cls[0] == PL_PIPE && !segmax && !bt.p[0].hdr && bt.p[0].n_store == bt.p[0].N && !pr[src[0]].hdr &&
         tiles_of[0] * blocks_of[0] > stream_cap() && tiles_of[0] * blocks_of[0] >= persist_min()) {   // (items <= workgroups: nothing to pipeline)
         const PLProblem &q = bt.p[0];
@@ -980,7 +966,7 @@ extern "C" int prcnn_packed_layer_interp(long rows, int K, int N, const float *A
                         G, idx, weight, n_per_cloud, m_known, ldg};
     // round 4: the persistent forms (weights resident / next tile fetched behind the running one) when there is more than one round of
     // workgroups to run; same epilogue, same bits
-    static const bool persist = !(getenv("PRCNN_PL_PERSIST") && atoi(getenv("PRCNN_PL_PERSIST")) == 0);
+    const bool persist = true;
     const long items = tiles * (N / 128);
     hipStream_t st = (hipStream_t)stream;
     if (persist && K == 128 && stream_enabled() && items >= stream_min() && rows * lda * 4 < (1L << 31)) {

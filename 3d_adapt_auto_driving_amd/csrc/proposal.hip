@@ -614,8 +614,7 @@ static int rpn_proposals_any(int b, int n, const DecodeCfg *dc, int pre_nms_top_
     const long total = (long)b * n;
     if (!boxes_in)
         hipLaunchKernelGGL(rpn_decode_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, total, *dc, xyz, reg, (float *)(base + o_boxes));
-    static const bool split_sort = !(getenv("PRCNN_SORT_SPLIT") && atoi(getenv("PRCNN_SORT_SPLIT")) == 0);   // A/B, same order
-    if ((split_sort || npad > 16384) && npad > SS_CHUNK) {        // (the one-workgroup sort keeps all keys in LDS: 16384 at most)
+    if (npad > SS_CHUNK) {        // (small problems: one workgroup sorts a scene with all keys in LDS; round 6: switch PRCNN_SORT_SPLIT removed)
         // chunks of 4096 keys sorted by a workgroup each, then pairwise merge-path rounds (ping-pong between two key buffers)
         unsigned long long *kbuf = (unsigned long long *)scratch_for(st, (size_t)2 * b * npad * sizeof(unsigned long long), 11);
         if (!kbuf) { set_error("rpn_proposals: cannot allocate the sort scratch"); return PRCNN_ELAUNCH; }
@@ -704,8 +703,8 @@ static int rcnn_postprocess_any(int b, int m, int channels, float loc_scope, flo
     if (b == 0) return PRCNN_OK;
     PRCNN_REQUIRE(rois && rcnn_reg && rcnn_cls && pred_boxes3d && boxes && scores && num, "rcnn_postprocess: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    static const bool fused = !(getenv("PRCNN_FINAL_FUSED") && atoi(getenv("PRCNN_FINAL_FUSED")) == 0);     // A/B switch, same results
-    PRCNN_REQUIRE(scenes_per_blob == 0 || (fused && nms_thresh >= 0.f), "rcnn_postprocess_blobs: needs the one-workgroup final stage (PRCNN_FINAL_FUSED)");
+    const bool fused = true;                               // (round 6: switch PRCNN_FINAL_FUSED removed; the four-launch form serves nms_thresh < 0)
+    PRCNN_REQUIRE(scenes_per_blob == 0 || nms_thresh >= 0.f, "rcnn_postprocess_blobs: needs the one-workgroup final stage (nms_thresh >= 0)");
     if (fused && nms_thresh >= 0.f) {
         hipLaunchKernelGGL(rcnn_final_kernel, dim3(b), dim3(RF_THREADS), 0, st, m, c, nms_thresh, rois, rcnn_reg, rcnn_cls, pred_boxes3d,
                            boxes, scores, num, scenes_per_blob);

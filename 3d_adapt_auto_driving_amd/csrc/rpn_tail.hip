@@ -49,7 +49,7 @@ struct RpnTailArgs {
     float *feats, *cls, *reg;       // (rows,128), (rows,1), (rows,n_reg)
     int n_reg;
     unsigned int *ticket;           // tile counter record of this launch (zero on entry)
-    int xcd_split;                  // rpn_tail_lin: tiles drawn per XCD partition (1) or from one counter (0: A/B switch PRCNN_TAIL_XCD=0)
+    int xcd_split;                  // rpn_tail_lin: tiles drawn per XCD partition (1) or from one counter (0: fewer than 8 workgroups; round 6: no switch PRCNN_TAIL_XCD=0)
     // rpn_tail_lin_kernel<true> (round 5): the regression rows are DECODED where they stand in LDS and only the 7-float box leaves
     const float *xyz;               // (rows, 3)
     float *boxes;                   // (rows, 7)
@@ -600,7 +600,7 @@ static int rpn_tail_lin_any(int b, int n, int m, const float *G, const int *idx,
     for (int i = 0; i < 3; ++i) a.anchor[i] = anchor ? anchor[i] : 0.f;
     a.ticket = next_ticket((hipStream_t)stream);
     if (!a.ticket) { set_error("%s: cannot set up the tile ticket", who); return PRCNN_ELAUNCH; }
-    static const int xcd_split = !(getenv("PRCNN_TAIL_XCD") && atoi(getenv("PRCNN_TAIL_XCD")) == 0);
+    const int xcd_split = 1;                               // (round 6: A/B switch PRCNN_TAIL_XCD removed)
     const long tiles = (rows + RT_ROWS - 1) / RT_ROWS;
     const long cap = mfma_grid_cap() < 256 ? mfma_grid_cap() : 256;
     const long grid = tiles < cap ? tiles : cap;

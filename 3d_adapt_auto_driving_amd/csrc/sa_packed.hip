@@ -871,8 +871,8 @@ extern "C" int prcnn_sa_packed_mlp(int b, int n, int m, int c3, long max_tiles, 
     }
     unsigned int *ticket = next_ticket(st);
     if (!ticket) { set_error("sa_packed_mlp: cannot set up the tile ticket"); return PRCNN_ELAUNCH; }
-    // row-major pooling through LDS needs 16-byte aligned output rows; PRCNN_SEGMAX_LDS=0 keeps every tile on the register form
-    static const bool env_lds = !(getenv("PRCNN_SEGMAX_LDS") && atoi(getenv("PRCNN_SEGMAX_LDS")) == 0);
+    // row-major pooling through LDS needs 16-byte aligned output rows (else every tile stays on the register form)
+    const bool env_lds = true;
     const int lds_pool = env_lds && (((uintptr_t)out | (uintptr_t)b3) & 15) == 0 && out_stride % 4 == 0 && out_col % 4 == 0;
     if (c3 == 128) {
         SaPkBatch batch;
@@ -894,8 +894,7 @@ extern "C" int prcnn_sa_packed_mlp_batch(int nprob, const prcnn_sa_problem *pr, 
     PRCNN_REQUIRE(nprob >= 1 && nprob <= 2 && pr, "sa_packed_mlp_batch: 1 or 2 problems");
     hipStream_t st = (hipStream_t)stream;
     static const int env_grid = getenv("PRCNN_SA_GRID") ? atoi(getenv("PRCNN_SA_GRID")) : 512;
-    static const bool env_lds = !(getenv("PRCNN_SEGMAX_LDS") && atoi(getenv("PRCNN_SEGMAX_LDS")) == 0);
-    static const bool env_narrow = !(getenv("PRCNN_SA_NARROW") && atoi(getenv("PRCNN_SA_NARROW")) == 0);
+    const bool env_lds = true, env_narrow = true;          // (round 6: A/B switches PRCNN_SEGMAX_LDS / PRCNN_SA_NARROW removed)
     SaPkBatch batch;
     batch.nprob = nprob;
     long most = 0;
@@ -915,7 +914,7 @@ extern "C" int prcnn_sa_packed_mlp_batch(int nprob, const prcnn_sa_problem *pr, 
         const int lds_pool = env_lds && (((uintptr_t)q.out | (uintptr_t)q.b3) & 15) == 0 && q.out_stride % 4 == 0 && q.out_col % 4 == 0;
         batch.p[i] = SaPkProblem{q.n, q.m, q.hdr, (const float4 *)q.rowdxyz, (const float4 *)q.P, (const float4 *)q.wxyz, q.rowinfo, q.tilecloud,
                                  q.w2t, q.b2, q.w3t, q.b3, q.out, q.out_stride, q.out_col, lds_pool, 128, 128};
-        // the real widths of a zero-padded problem (0 = 128): 64-64 and 64-96 have kernels of their own (PRCNN_SA_NARROW=0: the padded one)
+        // the real widths of a zero-padded problem (0 = 128): 64-64 and 64-96 have kernels of their own (round 5)
         PRCNN_REQUIRE((q.c1 == 0 || (q.c1 >= 1 && q.c1 <= 128)) && (q.c2 == 0 || (q.c2 >= 1 && q.c2 <= 128)), "sa_packed_mlp_batch: bad widths c1=%d c2=%d", q.c1, q.c2);
         if (env_narrow && nprob == 2 && q.c1 == 64 && (q.c2 == 64 || q.c2 == 96)) { batch.p[i].c1 = 64; batch.p[i].c2 = q.c2; ++narrow; }
         most = q.max_tiles > most ? q.max_tiles : most;

@@ -299,15 +299,11 @@ extern "C" int prcnn_sa_xyz_mlp_packed(int b, int m, int c1, int c2, int c3, lon
         hipLaunchKernelGGL((sa_xyz_mlp_packed_kernel<16, 16, 32>), dim3((unsigned)grid), dim3(256), 0, st, m, hdr, rowinfo,
                            (const float4 *)rowdxyz, tilecloud, w1, b1, w2, b2, w3, b3, out, out_stride, out_col);
     else {
-        // PRCNN_XYZ_MFMA=0: the VALU form of this scale (A/B: same bits)
-        static const bool mfma = !(getenv("PRCNN_XYZ_MFMA") && atoi(getenv("PRCNN_XYZ_MFMA")) == 0);
-        if (mfma) {
-            const long cap = 2L * mfma_grid_cap();             // persistent waves: the weights are loaded once per wave
-            hipLaunchKernelGGL(sa_xyz_mlp_packed_mfma_kernel, dim3((unsigned)(grid < cap ? grid : cap)), dim3(256), 0, st, m, hdr, rowinfo,
-                               (const float4 *)rowdxyz, tilecloud, w1, b1, w2, b2, w3, b3, out, out_stride, out_col);
-        } else
-            hipLaunchKernelGGL((sa_xyz_mlp_packed_kernel<32, 32, 64>), dim3((unsigned)grid), dim3(256), 0, st, m, hdr, rowinfo,
-                               (const float4 *)rowdxyz, tilecloud, w1, b1, w2, b2, w3, b3, out, out_stride, out_col);
+        // (round 6: the VALU form of this scale, sa_xyz_mlp_packed_kernel<32, 32, 64>, and its switch PRCNN_XYZ_MFMA are gone:
+        //  0.37 of the packed-f32 rate on LiDAR-shaped scenes against the matrix-core form below, same bits)
+        const long cap = 2L * mfma_grid_cap();                 // persistent waves: the weights are loaded once per wave
+        hipLaunchKernelGGL(sa_xyz_mlp_packed_mfma_kernel, dim3((unsigned)(grid < cap ? grid : cap)), dim3(256), 0, st, m, hdr, rowinfo,
+                           (const float4 *)rowdxyz, tilecloud, w1, b1, w2, b2, w3, b3, out, out_stride, out_col);
     }
     return check_launch("sa_xyz_mlp_packed");
 }

@@ -426,7 +426,7 @@ int three_nn_grid(int b, int n, int m, const float *unknown, const float *known,
     static const double cells_per_point = [] { const char *e = getenv("PRCNN_TNN_CELLS"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 2.0; }();
     int g = (int)ceil(sqrt((double)m * cells_per_point));          // round 2: sqrt(m / 2) (PRCNN_TNN_CELLS=0.5)
     if (g > TG_MAX) g = TG_MAX;
-    static const bool ordered = [] { const char *e = getenv("PRCNN_TNN_UNORDERED"); return !(e && atoi(e)); }();
+    const bool ordered = true;           // queries served in cell order (round 6: switches PRCNN_TNN_UNORDERED / PRCNN_TNN_NO_LDS removed)
     const size_t o_par = 0;
     const size_t o_cs = align_up256((size_t)b * sizeof(GridParams));
     const size_t o_sorted = o_cs + align_up256((size_t)b * (TG_MAX * TG_MAX + 1) * sizeof(int));
@@ -445,7 +445,7 @@ int three_nn_grid(int b, int n, int m, const float *unknown, const float *known,
         hipLaunchKernelGGL(tnn_build_kernel, dim3(b), dim3(TB), (size_t)g * g * sizeof(int), st, m, g, known, params, cs, sorted,
                            n, unknown, order);
     const size_t qlds = (size_t)m * sizeof(float4) + ((size_t)g * g + 1) * sizeof(int);
-    static const bool no_lds = getenv("PRCNN_TNN_NO_LDS") != nullptr;                  // A/B switch
+    const bool no_lds = false;
     if (!no_lds && qlds <= 128 * 1024 && n >= 2 * m) {
         const int rc = ensure_dynamic_lds((const void *)tnn_query_lds_kernel, qlds, "three_nn(query)");
         if (rc != PRCNN_OK) return rc;

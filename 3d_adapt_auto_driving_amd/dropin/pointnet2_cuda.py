@@ -40,7 +40,7 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
 
 def fps_new_xyz_supported(n, m):
     """prcnn_fps_new_xyz serves every shape since round 5 (one launch for n <= 1024 and in the speculative kernel's range
-    2048 < n <= 16384, m >= 256; elsewhere -- and under PRCNN_FPS_SEQUENTIAL / PRCNN_FPS_NO_PRUNE -- FPS over an internal
+    2048 < n <= 16384, m >= 256; elsewhere FPS over an internal
     distance scratch + a gather launch inside the library)."""
     return True
 
@@ -481,9 +481,8 @@ def sa_packed_mlp_batch_wrapper(problems):
             # kernel reads 64 columns of a 128-float row, the padded one would read its neighbour's
             if not (P.is_cuda and P.dtype == torch.float32 and P.stride() == (n * 128, 128, 1) and P.data_ptr() % 16 == 0):
                 raise RuntimeError("pointnet2_cuda: sa_packed_mlp_batch: a 64-wide P must be a column slice of a contiguous (b, n, 128) tensor")
-            if not (len(problems) == 2 and all(len(pp) > 12 and pp[12] is not None and pp[12][0] == 64 and pp[12][1] in (64, 96) for pp in problems)
-                    and os.environ.get("PRCNN_SA_NARROW", "1") != "0"):
-                raise RuntimeError("pointnet2_cuda: sa_packed_mlp_batch: a 64-wide P needs two problems of real widths 64-64 / 64-96 (and PRCNN_SA_NARROW != 0)")
+            if not (len(problems) == 2 and all(len(pp) > 12 and pp[12] is not None and pp[12][0] == 64 and pp[12][1] in (64, 96) for pp in problems)):
+                raise RuntimeError("pointnet2_cuda: sa_packed_mlp_batch: a 64-wide P needs two problems of real widths 64-64 / 64-96")
         else:
             _chk(torch.float32, P)
         if c1 not in (64, 128) or w2t.shape != (128, 128) or tuple(w3t.shape) != (128, 128):

@@ -188,7 +188,7 @@ def _runner_streams(device, n_sides, prio):
     key = (str(device), prio)
     have = _RUNNER_STREAMS.setdefault(key, {"tail": None, "sides": [], "feat": None})
     if have["tail"] is None:
-        have["tail"] = torch.cuda.Stream(device, priority=int(os.environ.get("PRCNN_TAIL_PRIORITY", "0")))
+        have["tail"] = torch.cuda.Stream(device)
     while len(have["sides"]) < n_sides:
         have["sides"].append(torch.cuda.Stream(device, priority=prio))
     return have["tail"], have["sides"][:n_sides]
@@ -217,7 +217,7 @@ class PipelinedRunner:
         # when CU slots free up they should be placed before the feature pass's next workgroups
         # default priority: with the SA levels on the packed MFMA kernels the feature pass is short, and high-priority side
         # streams (three of them at depth 3) starve it -- measured 971 vs 1375 scenes/s
-        prio = int(os.environ.get("PRCNN_SIDE_PRIORITY", "0"))
+        prio = 0           # (default priority: high-priority side streams starve the feature pass; the switch PRCNN_SIDE_PRIORITY is gone, round 6)
         self._shared_tail, self.sides = _runner_streams(self.device, int(os.environ.get("PRCNN_SIDE_STREAMS", "2")) if self.group > 1 else max(1, self.depth), prio)
         self._next_side = 0
         self._pending = []        # [(batch tensor, geometry dict, ready event)] in launch order
@@ -658,7 +658,7 @@ class GraphedRunner:
         self.device = torch.device(device)
         self.group = max(1, int(os.environ.get("PRCNN_GEO_GROUP", "4")))
         self.depth = PipelinedRunner.default_depth() if depth is None else depth
-        prio = int(os.environ.get("PRCNN_SIDE_PRIORITY", "0"))
+        prio = 0           # (default priority: high-priority side streams starve the feature pass; the switch PRCNN_SIDE_PRIORITY is gone, round 6)
         self.tail, self.sides = _runner_streams(self.device, int(os.environ.get("PRCNN_SIDE_STREAMS", "2")), prio)
         have = _RUNNER_STREAMS[(str(self.device), prio)]
         # the feature-stream graphs are CAPTURED on a stream of their own (a capture cannot run on the default stream) and REPLAYED on

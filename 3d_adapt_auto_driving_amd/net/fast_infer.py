@@ -56,12 +56,12 @@ USE_POINT_LAYER = os.environ.get("PRCNN_LIB_GEMM") is None     # per-point layer
 PAD128 = USE_PACKED and USE_POINT_LAYER
 # the finest FP module and both RPN heads in one kernel (csrc/rpn_tail.hip); PRCNN_NO_RPN_TAIL=1: layer by layer (A/B, same bits)
 USE_RPN_TAIL = os.environ.get("PRCNN_NO_RPN_TAIL") is None
-# the scales of a wide MSG level (RPN SA3 / SA4) stage by stage, side by side in one launch per stage; PRCNN_NO_SCALE_BATCH=1: A/B
-USE_SCALE_BATCH = os.environ.get("PRCNN_NO_SCALE_BATCH") is None
-# layers 1-3 + pool of a wide scale in one kernel (csrc/sa_wide.hip); PRCNN_NO_WIDE_FUSED=1: gather / layer / layer+pool launches
-USE_SA_NARROW = os.environ.get("PRCNN_SA_NARROW", "1") != "0"        # RPN SA2's scales without their zero padding (csrc/sa_packed.hip), their per-point parts in one product
+# the scales of a wide MSG level (RPN SA3 / SA4) stage by stage, side by side in one launch per stage
+USE_SCALE_BATCH = True      # (a module constant since round 6; tests patch it)
+# layers 1-3 + pool of a wide scale in one kernel (csrc/sa_wide.hip); False: gather / layer / layer+pool launches
+USE_SA_NARROW = True        # RPN SA2's scales without their zero padding (csrc/sa_packed.hip), their per-point parts in one product
 USE_SA2_BATCH = os.environ.get("PRCNN_NO_SA2_BATCH") is None        # the two 128-wide scales of an MSG level (RPN SA2) in one launch per stage (round 5)
-USE_WIDE_FUSED = os.environ.get("PRCNN_NO_WIDE_FUSED") is None
+USE_WIDE_FUSED = True       # (a module constant since round 6; tests/test_gpu_shadow.py patches it for the layer-by-layer variant)
 # ... and layer 1 inside as well where a level groups every point once (the RCNN's GroupAll level; csrc/sa_wide3.hip);
 # PRCNN_NO_WIDE_FUSED3=1: the per-point layer as a launch of its own in front of csrc/sa_wide.hip (A/B, same bits)
 USE_WIDE_FUSED3 = os.environ.get("PRCNN_NO_WIDE_FUSED3") is None
@@ -74,7 +74,7 @@ EARLY_FP = int(os.environ.get("PRCNN_EARLY_FP", "2"))                 # ... plus
 # feature stream binds (1.10 ms of kernels per step against 0.6 on each geometry stream): EARLY_FP = 3 (all FP modules but the finest over
 # the 32 clouds of a group) buys +4.6 % at K = 100 (6382 against 6103 scenes/s; K = 20: level).  The fused tail on top of it -- a 256-workgroup
 # MFMA kernel of 0.7 ms per group on a geometry stream -- costs it again: 6042 at K = 100, 5158 against 5314 at K = 20.  Off.
-EARLY_TAIL = os.environ.get("PRCNN_EARLY_TAIL", "0") == "1"
+# (round 6: the switch PRCNN_EARLY_TAIL and its branch are gone.)
 # ... in between: only the coarse-level product G of the finest FP module (4096 rows per cloud, K = 256) goes with the geometry; the fused
 # tail kernel, which reads it, stays on the feature stream
 EARLY_G0 = os.environ.get("PRCNN_EARLY_G0", "1") == "1"
@@ -569,8 +569,6 @@ class FastPointRCNN:
                  "groups": None if groups is None else (groups[0][lo:hi], groups[1][lo:hi])}
             if geo.get("fp_out"):
                 g["fp_out"] = {kk: v[lo:hi] for kk, v in geo["fp_out"].items()}
-            if geo.get("tail_out") is not None:
-                g["tail_out"] = tuple(v[lo:hi] for v in geo["tail_out"])
             if geo.get("tail_G") is not None:
                 g["tail_G"] = geo["tail_G"][lo:hi]
             for k, lev in enumerate(geo["sa"]):
@@ -638,28 +636,10 @@ class FastPointRCNN:
                 kk = len(self.fp) + i
                 idx, weight = geo["fp"][kk]
                 l_feat[kk] = geo["fp_out"][kk] = self._fp_module(kk, l_feat[kk + 1], l_feat[kk], idx, weight)
-            if (EARLY_TAIL and EARLY_FP >= len(self.fp) - 1 and self.rpn_tail is not None and self.in_feat == 0
-                    and l_feat[1].shape[2] == 256 and USE_FP_LINEAR and has_entry(pu.pointnet2, "rpn_tail_lin_wrapper")):
-                idx, weight = geo["fp"][0]
-                geo["tail_out"] = self._fused_tail(l_feat[1], idx, weight)
-            elif (EARLY_G0 and EARLY_FP >= len(self.fp) - 1 and self.rpn_tail is not None and self.in_feat == 0
+            if (EARLY_G0 and EARLY_FP >= len(self.fp) - 1 and self.rpn_tail is not None and self.in_feat == 0
                     and l_feat[1].shape[2] == 256 and USE_FP_LINEAR and has_entry(pu.pointnet2, "rpn_tail_lin_wrapper")):
                 kf = l_feat[1]
                 geo["tail_G"] = point_layer(kf.view(-1, kf.shape[2]), self.rpn_tail["w1"], self.rpn_tail["zero128"], False).view(kf.shape[0], kf.shape[1], 128)
-
-    def _fused_tail(self, known_feat, idx, weight):
-        """interpolation + FP module 0 + both heads: one kernel, a 64-point tile never leaves LDS (csrc/rpn_tail.hip);
-        FP layer 1 over the coarse points (a quarter of the rows), interpolated inside the fused kernel -> (feats, rpn_cls, rpn_reg)"""
-        tw = self.rpn_tail
-        B, N = idx.shape[0], idx.shape[1]
-        dev = known_feat.device
-        feats = torch.empty((B, N, 128), dtype=torch.float32, device=dev)
-        rpn_cls = torch.empty((B, N, 1), dtype=torch.float32, device=dev)
-        rpn_reg = torch.empty((B, N, tw["n_reg"]), dtype=torch.float32, device=dev)
-        m = known_feat.shape[1]
-        G = point_layer(known_feat.view(B * m, known_feat.shape[2]), tw["w1"], tw["zero128"], False).view(B, m, 128)
-        pu.pointnet2.rpn_tail_lin_wrapper(G, idx, weight, tw["wcat_lin"], tw["bcat"], tw["wc2"], tw["bc2"], feats, rpn_cls, rpn_reg)
-        return feats, rpn_cls, rpn_reg
 
     # ------------------------------------------------------------------ building blocks
     @staticmethod
@@ -918,13 +898,6 @@ class FastPointRCNN:
         if geo is None:
             geo = self.geometry(xyz)
         B, N, _ = xyz.shape
-        if geo.get("tail_out") is not None:
-            # the whole RPN stage came with the geometry (EARLY_TAIL): nothing left to compute here
-            feats, rpn_cls, rpn_reg = geo["tail_out"]
-            out = {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": xyz, "rpn_features": feats, "groups": geo.get("groups")}
-            if cfg.RCNN.ENABLED:
-                out["rpn_scores_raw"] = rpn_cls[:, :, 0].contiguous()
-            return out
         with self._strictly():
             feats, tail = self._backbone(xyz, geo, fuse_tail=True, feats0=feats0)
         if tail is not None:

@@ -45,13 +45,10 @@ SWITCHES = {
     "PRCNN_EARLY_LEVELS": ("ab", "4", "net/fast_infer.py", "leading SA levels computed with the geometry"),
     "PRCNN_EARLY_FP": ("ab", "2", "net/fast_infer.py", "coarsest FP modules computed with the geometry (round 5: 2; 3 until then)"),
     "PRCNN_EARLY_G0": ("ab", "1", "net/fast_infer.py", "the finest FP module's coarse product computed with the geometry (round 4: +1.2 %)"),
-    "PRCNN_EARLY_TAIL": ("ab", "0", "net/fast_infer.py", "1: the whole RPN tail with the geometry (round 4: slower, 6042 vs 6382)"),
     "PRCNN_NO_XYZ_EARLY": ("ab", "unset", "net/fast_infer.py", "1: no SA level rides with the geometry"),
     "PRCNN_NO_GROUP_SA": ("ab", "unset", "net/fast_infer.py", "1: early SA levels per batch instead of per geometry group"),
     "PRCNN_FINAL_ON_FEATURE": ("ab", "0", "eval_rcnn.py", "1: final stage behind the RCNN features on the feature stream (round 4's default); 0: on the proposal stream"),
     "PRCNN_NO_RCNN_SPLIT": ("ab", "unset", "eval_rcnn.py", "1: RCNN geometry on the feature stream"),
-    "PRCNN_SIDE_PRIORITY": ("ab", "0", "eval_rcnn.py", "HIP priority of the side streams"),
-    "PRCNN_TAIL_PRIORITY": ("ab", "0", "eval_rcnn.py", "HIP priority of the proposal stream"),
     # ---- engine formulations A/B (same results)
     "PRCNN_NO_POOL_DEDUP": ("ab", "unset", "net/fast_infer.py", "RCNN point MLP over all 512 pooled rows"),
     "PRCNN_NO_CENTRE_DEDUP": ("ab", "unset", "net/fast_infer.py", "no representative map over sampled centres"),
@@ -59,34 +56,14 @@ SWITCHES = {
     "PRCNN_NO_POOL_GROUPS": ("ab", "unset", "net/fast_infer.py", "RoI pooling sweeps all points (no spatial groups)"),
     "PRCNN_NO_POINT_MLP": ("ab", "unset", "net/fast_infer.py", "RCNN entrance as separate layers"),
     "PRCNN_NO_ROI_GEOMETRY": ("ab", "unset", "net/fast_infer.py", "RCNN sampling / ball queries as six launches"),
-    "PRCNN_SA_NARROW": ("ab", "1", "csrc/sa_packed.hip", "0: the two scales of RPN SA2 (64-64-128, 64-96-128) through the kernel that multiplies their zero padding up to 128-128-128 as well, their per-point parts as two padded 128-wide products instead of one (also read by net/fast_infer.py, dropin/pointnet2_cuda.py)"),
-    "PRCNN_XYZ_MFMA": ("ab", "1", "csrc/sa_xyz_mlp.hip", "0: the wider scale of the coordinates-only RPN level on the VALU form (weights through scalar registers) instead of the matrix cores"),
     "PRCNN_NO_CENTRE_ROWS": ("ab", "unset", "net/fast_infer.py", "the RCNN second level's per-point layer over all 128 level-1 centres of every RoI instead of the listed representatives"),
     "PRCNN_NO_POOLED_ROWS": ("ab", "unset", "net/fast_infer.py", "the RCNN entrance over whole 64-row tiles per RoI (prcnn_pooled_tiles) instead of the list of distinct pooled rows"),
     "PRCNN_NO_ROI_PACKS": ("ab", "unset", "net/fast_infer.py", "the RoI clouds' two row lists by prcnn_ball_pack_ex launches instead of inside prcnn_rcnn_roi_geometry_packs"),
     "PRCNN_NO_RPN_TAIL": ("ab", "unset", "net/fast_infer.py", "finest FP module and RPN heads layer by layer (the bits of the fused tail under PRCNN_NO_FP_LINEAR=1: the layer-by-layer form keeps the reference's association)"),
-    "PRCNN_FPS_NO_PAIR": ("ab", "unset", "csrc/fps.hip", "set: sampling of 16384 < n <= 32768 points on fps_generic_kernel (rounds 1-4: 30.5 ms for 8 x 32768 -> 4096) instead of two workgroups per cloud (fps_spec2_kernel: 2.65 ms)"),
     "PRCNN_TAIL_DECODE": ("ab", "1", "net/fast_infer.py", "0: the fused RPN tail stores the (B, N, 76) regression rows and the proposal layer decodes them (rpn_decode_kernel) instead of decoding inside the tail kernel (round 5)"),
     "PRCNN_NO_SA2_BATCH": ("ab", "unset", "net/fast_infer.py", "set: the two 128-wide scales of an MSG level (RPN SA2) as two launches per stage instead of one (prcnn_sa_packed_mlp_batch, round 5)"),
-    "PRCNN_NO_SCALE_BATCH": ("ab", "unset", "net/fast_infer.py", "one launch per MSG scale"),
-    "PRCNN_NO_WIDE_FUSED": ("ab", "unset", "net/fast_infer.py", "GroupAll level layer by layer"),
     "PRCNN_NO_WIDE_FUSED3": ("ab", "unset", "net/fast_infer.py", "1: the GroupAll level's layer 1 as a per-point launch in front of csrc/sa_wide.hip instead of inside csrc/sa_wide3.hip"),
     # ---- kernel forms A/B (C library; same results)
-    "PRCNN_FPS_SEQUENTIAL": ("ab", "unset", "csrc/fps.hip", "one pick per exchange (round 3 kernel)"),
-    "PRCNN_FPS_NO_PRUNE": ("ab", "unset", "csrc/fps.hip", "full scan per pick"),
-    "PRCNN_THREE_NN_BRUTE": ("ab", "unset", "csrc/interp.hip", "three_nn without the grid"),
-    "PRCNN_TNN_NO_LDS": ("ab", "unset", "csrc/three_nn_grid.hip", "ring search from global memory"),
-    "PRCNN_TNN_UNORDERED": ("ab", "unset", "csrc/three_nn_grid.hip", "queries in input order"),
-    "PRCNN_NMS_DENSE": ("ab", "1", "csrc/iou3d.hip", "0: lazy kernel for small problems"),
-    "PRCNN_NMS_FULL": ("ab", "1", "csrc/iou3d.hip", "0: no full-mask form of the blocking NMS"),
-    "PRCNN_NMS_QUOTA": ("ab", "1", "csrc/iou3d.hip", "0: lazy kernel for the proposal NMS"),
-    "PRCNN_SORT_SPLIT": ("ab", "1", "csrc/proposal.hip", "0: one workgroup sorts a scene's scores"),
-    "PRCNN_FINAL_FUSED": ("ab", "1", "csrc/proposal.hip", "0: final stage as four launches (round 3)"),
-    "PRCNN_PL_PIPE": ("ab", "1", "csrc/packed_layer.hip", "0: K >= 256 layers without the panel pipeline"),
-    "PRCNN_PL_STREAM": ("ab", "1", "csrc/packed_layer.hip", "0: K = 128 layers one tile per workgroup"),
-    "PRCNN_PL_PERSIST": ("ab", "1", "csrc/packed_layer.hip", "0: K >= 256 layers one tile per workgroup (round 3)"),
-    "PRCNN_SEGMAX_LDS": ("ab", "1", "csrc/packed_layer.hip", "0: segmented max from registers only"),
-    "PRCNN_TAIL_XCD": ("ab", "1", "csrc/rpn_tail.hip", "0: one tile counter instead of one per XCD"),
     # ---- tuning
     "PRCNN_MFMA_GRID": ("tuning", "512", "csrc/capi.hip", "workgroups of a persistent MFMA launch"),
     "PRCNN_SA_GRID": ("tuning", "512", "csrc/sa_packed.hip", "workgroups of the packed SA kernels"),

@@ -459,10 +459,8 @@ def roofline_fps(dev, reps=3):
     ms = float(np.mean([a.elapsed_time(e) for a, e in evs]))
     nbytes = B * (12 * N + 4 * M)
     achieved = nbytes / (ms * 1e-3) / 1e9
-    seq = os.environ.get("PRCNN_FPS_SEQUENTIAL") is not None
-    return {"bound": "latency", "kernel": "%s (+ fps_order_kernel), %d clouds per launch" % (
-                "fps_pruned_kernel<16,1024>: one pick per workgroup exchange" if seq else
-                "fps_spec_kernel<16>: speculative multi-pick (round 4), several exact picks per workgroup exchange", B),
+    return {"bound": "latency", "kernel": "fps_spec_kernel<16>: speculative multi-pick (round 4), several exact picks per workgroup exchange "
+                                          "(+ fps_order_kernel), %d clouds per launch" % B,
             "launch_ms": round(ms, 4), "us_per_pick": round(ms * 1e3 / (M - 1), 4),
             "sequential_exchange_floor_us": 0.69,      # what ONE pick per exchange cannot go below (round 3's kernel: 0.99 us per pick)
             "algorithmic_bytes_per_launch": nbytes,

@@ -191,30 +191,6 @@ def test_fps_with_coordinates_output_every_shape(ext, oracle, b, n, m):
     assert np.array_equal(new_xyz.cpu().numpy(), np.take_along_axis(xyz, want[:, :, None].astype(np.int64), axis=1))
 
 
-@pytest.mark.parametrize("switch", ["PRCNN_FPS_SEQUENTIAL", "PRCNN_FPS_NO_PRUNE"])
-def test_fps_with_coordinates_output_under_the_ab_switches(switch):
-    """with either A/B switch set the engine's SA levels (fps_new_xyz on 16384 -> 4096 and 4096 -> 1024) raised
-    'shape not served'.  The switches are read once per process, hence the child process."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, importlib, numpy as np, torch\n"
-        "sys.path.insert(0, %r)\n"
-        "from oracle import oracle as O\n"
-        "pkg = importlib.import_module('3d_adapt_auto_driving_amd'); sys.path.insert(0, pkg.DROPIN_DIR)\n"
-        "import pointnet2_cuda as P\n"
-        "for n, m in ((16384, 4096), (4096, 1024), (16384, 128)):\n"
-        "    xyz = np.random.default_rng(n).uniform(-20, 20, (2, n, 3)).astype(np.float32)\n"
-        "    idx, new = P.fps_new_xyz_wrapper(torch.from_numpy(xyz).cuda(), m)\n"
-        "    want = O.furthest_point_sample(xyz, m)\n"
-        "    assert np.array_equal(idx.cpu().numpy(), want)\n"
-        "    assert np.array_equal(new.cpu().numpy(), np.take_along_axis(xyz, want[:, :, None].astype(np.int64), axis=1))\n"
-        "print('ok')\n") % root
-    env = dict(os.environ); env[switch] = "1"
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
-
-
 def test_ball_query_with_scan_limit_on_wrapped_clouds(ext, oracle):
     """Clouds filled the way RoI pooling fills a box holding fewer than 512 points (row k >= count is a copy of row
     k % count, roipool3d_kernel.cu:152-159; an empty box is all one point).  prcnn_ball_query_limit scans the first count

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = os.path.join(ROOT, "tests", "ab_switch_child.py")
 
 # the non-default value of a switch: "unset" -> "1", "1" -> "0", "0" -> "1"; the few numeric ones by hand
-ALT = {"PRCNN_EARLY_LEVELS": "2", "PRCNN_EARLY_FP": "1", "PRCNN_SIDE_PRIORITY": "-1", "PRCNN_TAIL_PRIORITY": "-1"}
+ALT = {"PRCNN_EARLY_LEVELS": "2", "PRCNN_EARLY_FP": "1"}
 
 
 def alternatives():
@@ -48,7 +48,7 @@ UNDER = {"PRCNN_NO_RPN_TAIL": {"PRCNN_NO_FP_LINEAR": "1"}}
 
 def test_every_ab_switch_gives_the_same_detections(tmp_path):
     alts = alternatives()
-    assert len(alts) >= 35
+    assert len(alts) == 20                                        # round 6: 43 -> 20 A/B switches
     wants = {}
     for tag, extra in [("default", {})] + [(n, e) for n, e in UNDER.items()]:
         base = str(tmp_path / ("base_%s.npz" % tag))
