@@ -1325,11 +1325,16 @@ class _RowCalib:
         return boxes, np.stack((x, y), axis=2)
 
 
-def _shm_worker(source, scene_ids, batch_size, raw, buf, tasks, results):
+def _shm_worker(source, scene_ids, batch_size, raw, buf, tasks, results, pin=None):
     """A loader process of _ShmFeed: takes (batch index, slot), produces the batch's scenes STRAIGHT INTO the slot of the shared,
     pinned buffer -- sampled clouds (B, npoints, c) or, for the device input stage, raw clouds packed (B, n_max, stride) -- and sends
     back only the small things: per-scene counts, calibration rows, image shapes."""
     _limit_worker_threads()
+    if pin:                     # (a fork server that was started before the parent confined itself hands out its own, wider affinity)
+        try:
+            os.sched_setaffinity(0, pin)
+        except (AttributeError, OSError):
+            pass
     flat = buf.numpy()
     try:
         while True:
@@ -1363,7 +1368,7 @@ class _ShmFeed:
     loader fills the slot its task names; the parent receives a dozen integers and 33 floats per scene, views the slot and enqueues the
     upload.  A slot returns to the free list when its upload has completed (an event).  Batches come back in order."""
 
-    def __init__(self, source, scene_ids, batch_size, raw, workers, ctx, pin, slot_floats):
+    def __init__(self, source, scene_ids, batch_size, raw, workers, ctx, pin, slot_floats, cpus=None):
         import torch.multiprocessing as tmp
         self.batch_size, self.raw = batch_size, raw
         self.n_batches = -(-len(scene_ids) // batch_size)
@@ -1375,7 +1380,7 @@ class _ShmFeed:
             self.registered = int(rc) == 0
         mp = tmp.get_context(ctx)
         self.tasks, self.results = mp.Queue(), mp.Queue()
-        self.procs = [mp.Process(target=_shm_worker, args=(source, list(scene_ids), batch_size, raw, self.buf, self.tasks, self.results), daemon=True)
+        self.procs = [mp.Process(target=_shm_worker, args=(source, list(scene_ids), batch_size, raw, self.buf, self.tasks, self.results, cpus), daemon=True)
                       for _ in range(workers)]
         for p in self.procs:
             p.start()
@@ -1446,10 +1451,18 @@ def eval_scenes(*args, **kwargs):
         return eval_scenes_pinned(*args, **kwargs)
     finally:
         if before is not None:
+            # EVERY thread of the process: sched_setaffinity(0) moves the calling thread only, and pool threads (OpenMP, BLAS) that
+            # were created while the driver was confined inherited its 32 cores -- bench.py's CPU baseline, which runs afterwards
+            # on 128 threads, took 138 s instead of 27 behind a driver leg that had restored the main thread alone
             try:
-                os.sched_setaffinity(0, before)
+                tids = [int(t) for t in os.listdir("/proc/self/task")]
             except OSError:
-                pass
+                tids = [0]
+            for tid in tids:
+                try:
+                    os.sched_setaffinity(tid, before)
+                except OSError:
+                    pass
 
 
 @torch.no_grad()
@@ -1516,7 +1529,8 @@ def eval_scenes_pinned(model, cfg, device, source, scene_ids, batch_size=8, outp
             slot_floats = batch_size * int(os.environ.get("PRCNN_RAW_SLOT_POINTS", "200000")) * 4
         else:
             slot_floats = batch_size * cfg.RPN.NUM_POINTS * (4 if cfg.RPN.USE_INTENSITY else 3)
-        feed = _ShmFeed(source, scene_ids, batch_size, stage is not None, workers, ctx, on_gpu, slot_floats)
+        feed = _ShmFeed(source, scene_ids, batch_size, stage is not None, workers, ctx, on_gpu, slot_floats,
+                        cpus=None if os.environ.get("PRCNN_NO_AFFINITY") == "1" else list(budget.get("pin") or budget["cores"]))
         if stats is not None:
             stats["loader_buffer"] = {"slots": int(feed.buf.shape[0]), "MB": round(feed.buf.numel() * 4 / 1e6, 1), "page_locked": feed.registered}
 

@@ -698,6 +698,14 @@ def main():
     # steady state needs (every hipMalloc inside a step stalls the device) and HIP has loaded every code object
     if args.prewarm > 0:
         timed_run(args.prewarm, 0)
+        # ... and one UNTIMED rehearsal of a whole window -- W warm-up + K steps, the detection tables packed and exchanged -- so that
+        # the first timed window is not the first time this exact sequence runs (the first of five windows came out
+        # 26 % low on the driver's box: 5477 against 7366-7396 scenes/s; the median hid it, config.windows showed it)
+        _, dets0 = timed_run(args.steps, args.warmup)
+        E.all_gather_detections(*E.pack_detections(list(range(rank * args.steps * BATCH, (rank + 1) * args.steps * BATCH)), dets0, M), comm_dev)
+        barrier()
+        torch.cuda.synchronize()
+        del dets0
     # The headline: `--windows` CLOSED windows, each W warm-up steps + exactly K timed steps + the job's one exchange, bracketed by
     # barrier + synchronize on both sides, the pipeline empty at both ends -- and the MEDIAN window is what `value` reports (each
     # window's rate is in config.windows: a single 26-ms window is at the mercy of the clock ramp of an idle GPU).
