@@ -480,6 +480,14 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
     // themselves 481 / 742 against 480 / 742.
     unsigned long long touched = 0ull, etiles = ~0ull;
     float bound = INFINITY;
+    // the box of ALL this wave's points (round 6): a pivot that cannot change a point of the wave box cannot pass a tile box inside it
+    // (the lower bound of a larger box is the smaller one, in f32 as in the reals: subtraction, max, product and sum are monotone under
+    // round-to-nearest), so one test per pivot -- lane q tests pivot q, all of a round's pivots at once -- stands in front of the
+    // PPT tile tests: until then every wave ran ceil(r / GP) passes of tile tests in every round, 16 waves on 4 SIMDs, beside the
+    // few waves whose points the pivots actually change.  Measured (same box, alternating): 1.823 -> 1.798 ms uniform, 2.688 -> 2.69 ms
+    // LiDAR-shaped for 32 x (16384 -> 4096), same picks: almost every wave IS reached by a pivot of a round of 8; kept, it costs nothing
+    const float wx0 = -wave_max_f32(-bx0), wx1 = wave_max_f32(bx1), wy0 = -wave_max_f32(-by0), wy1 = wave_max_f32(by1),
+                wz0 = -wave_max_f32(-bz0), wz1 = wave_max_f32(bz1);
     // which tiles can a pivot (per lane group: ox, oy, oz differ by group) change?  bit g * PPT + i: tile i, the group's pivot
     auto box_mask = [&](float ox, float oy, float oz, bool live) __attribute__((always_inline)) {
         const float dx = fmax_raw(fmax_raw(bx0 - ox, ox - bx1), 0.f);
@@ -634,7 +642,19 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
         j += r;
         const int apply_n = j >= m ? r - 1 : r;
         touched = 0ull;
+        unsigned hits;
+        {
+            const int ql = lane & (FS_RMAX - 1);
+            const float qx = s_res[1 + 3 * ql], qy = s_res[2 + 3 * ql], qz = s_res[3 + 3 * ql];
+            const float dx = fmax_raw(fmax_raw(wx0 - qx, qx - wx1), 0.f);
+            const float dy = fmax_raw(fmax_raw(wy0 - qy, qy - wy1), 0.f);
+            const float dz = fmax_raw(fmax_raw(wz0 - qz, qz - wz1), 0.f);
+            const float lb = dx * dx + dy * dy + dz * dz;
+            hits = (unsigned)__ballot(lane < apply_n && !(lb * 0.99999f >= bound));
+        }
+        if (hits == 0u) continue;                                       // no pivot of the round reaches this wave
         for (int q0 = 0; q0 < apply_n; q0 += GP) {
+            if (((hits >> q0) & ((GP >= 32) ? ~0u : ((1u << GP) - 1u))) == 0u) continue;
             // lane group g tests pivot q0 + g against the PPT tile boxes
             const int qg = q0 + lane / PPT;
             const int src = 1 + 3 * min(qg, FS_RMAX - 1);

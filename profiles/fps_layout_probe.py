@@ -31,7 +31,7 @@ for kind in ("uniform", "lidar"):
         cur = torch.gather(cur, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
 os.makedirs(os.path.join(ROOT, "gpurun_out", "r06"), exist_ok=True)
 np.savez(os.path.join(ROOT, "gpurun_out", "r06", "fps_picks_%s.npz" % tag), **out)
-if len(sys.argv) > 2:
+if len(sys.argv) > 2 and os.path.exists(os.path.join(ROOT, "gpurun_out", "r06", "fps_picks_%s.npz" % sys.argv[2])):
     ref = np.load(os.path.join(ROOT, "gpurun_out", "r06", "fps_picks_%s.npz" % sys.argv[2]))
     bad = [k for k in out if not np.array_equal(out[k], ref[k])]
     print("%s vs %s: %s" % (tag, sys.argv[2], "IDENTICAL picks and running minima" if not bad else "DIFFERS in %s" % bad))
