@@ -602,7 +602,11 @@ static int rpn_tail_lin_any(int b, int n, int m, const float *G, const int *idx,
     if (!a.ticket) { set_error("%s: cannot set up the tile ticket", who); return PRCNN_ELAUNCH; }
     const int xcd_split = 1;                               // (round 6: A/B switch PRCNN_TAIL_XCD removed)
     const long tiles = (rows + RT_ROWS - 1) / RT_ROWS;
-    const long cap = mfma_grid_cap() < 256 ? mfma_grid_cap() : 256;
+    // PRCNN_TAIL_GRID (tuning): workgroups of the fused tail.  Its waves hold a SIMD's whole register file, so while it runs on all 256 CUs no
+    // other stream's kernel makes progress; measured in round 6 (bench.py, alternating): 224 / 192 workgroups 8412 / 8443 scenes/s at K = 100
+    // against 8347-8361 with 256 (the tail itself a third longer at 192), 160: 8273; at K = 20 level within the windows' spread -- default kept
+    static const long tail_cap = getenv("PRCNN_TAIL_GRID") && atol(getenv("PRCNN_TAIL_GRID")) > 0 ? atol(getenv("PRCNN_TAIL_GRID")) : 256;
+    const long cap = mfma_grid_cap() < tail_cap ? mfma_grid_cap() : tail_cap;
     const long grid = tiles < cap ? tiles : cap;
     // a workgroup draws only from partition blockIdx.x & 7 (no stealing): every non-empty partition needs a workgroup of its own --
     // with fewer than 8 workgroups for 8 or more tiles (PRCNN_MFMA_GRID < 8) the tiles come from one counter instead

@@ -72,6 +72,7 @@ SWITCHES = {
     "PRCNN_PL_STREAM_MIN": ("tuning", "512", "csrc/packed_layer.hip", "items from which a K = 128 layer runs persistently"),
     "PRCNN_PL_PERSIST_MIN": ("tuning", "256", "csrc/packed_layer.hip", "items from which a K >= 256 layer runs persistently (and more than the cap)"),
     "PRCNN_FPS2_CAPACITY": ("tuning", "auto", "csrc/fps.hip", "co-resident fps_spec2_kernel workgroups the device is assumed to hold (default: occupancy query x CUs); a launch takes half of it, below 32 the sampling of 16384 < n <= 32768 points falls back to fps_generic_kernel (tests: 64 / 0)"),
+    "PRCNN_TAIL_GRID": ("tuning", "256", "csrc/rpn_tail.hip", "workgroups of the fused RPN tail (one per CU: its waves hold a SIMD's whole register file, no other kernel shares a CU with it); 192-224 leave CUs to the other streams: +0.8-1.0 % at K = 100, level at K = 20 (round 6)"),
     "PRCNN_FPS_LDS_PAD": ("tuning", "84", "csrc/fps.hip", "KB of dynamic LDS an FPS workgroup claims (keeps its CU to itself)"),
     "PRCNN_TNN_CELLS": ("tuning", "2", "csrc/three_nn_grid.hip", "grid cells per known point"),
     "PRCNN_GROUP_CHUNKS": ("tuning", "auto", "csrc/ball_group.hip", "channel chunks of the grouping kernels"),

@@ -661,8 +661,20 @@ def main():
         # falls back to its idle clocks meanwhile, and the ramp back up landed inside the timed region -- one K = 20 run in eight came out
         # 5-25 % low while the K = 100 loop of the same process did not move (second session of round 4)
         import gc
+        tg = time.perf_counter()
         gc.collect()
         gc.disable()                           # a generational collection inside a 70 ms timed region costs several percent
+        timed_run.gc_ms = round((time.perf_counter() - tg) * 1e3, 1)
+        # ... and the device is WOKEN before the W warm-up steps (round 6): a collection of the heap the graph captures leave behind
+        # takes 100+ ms, the idle GPU drops its clocks, and W = 5 steps (5 ms) do not bring them all the way back -- the first of five
+        # windows came out 10-26 % low in half of the runs (`config.windows.gc_ms` shows the pause).  ~20 ms of dense
+        # f32 work on the current stream, untimed like the warm-up steps it precedes, none of it the workload's.
+        if warmup and steps > 1:
+            wake = shared_runner.setdefault("wake", None)
+            if wake is None:
+                wake = shared_runner["wake"] = (torch.randn((4096, 4096), device=dev), torch.empty((4096, 4096), device=dev))
+            for _ in range(24):
+                torch.mm(wake[0], wake[0], out=wake[1])
         try:
             for i in range(warmup):
                 step(i, warmup)
@@ -711,10 +723,11 @@ def main():
     # window's rate is in config.windows: a single 26-ms window is at the mercy of the clock ramp of an idle GPU).
     ids = list(range(rank * args.steps * BATCH, (rank + 1) * args.steps * BATCH))
     import gc
-    window_s, allocs_w, phases_w = [], [], []
+    window_s, allocs_w, phases_w, gc_w = [], [], [], []
     for _ in range(max(1, args.windows)):
         t0, dets = timed_run(args.steps, args.warmup, keep_gc_off=True)
         allocs_w.append(getattr(timed_run, "device_allocs", None))     # hipMalloc calls inside the timed region (each one stalls the device)
+        gc_w.append(getattr(timed_run, "gc_ms", None))
         phases_w.append(getattr(timed_run, "slot_phase", None))
         # the one exchange of the job: padded detection tables of this rank's scenes
         table, counts = E.pack_detections(ids, dets, M)
@@ -842,7 +855,7 @@ def main():
                    # every closed window of this run (W + K steps each), in run order; `value` is the median one
                    "windows": {"n": len(window_s), "reported": "median", "scenes_per_s": [round(world * args.steps * BATCH / w, 1) for w in window_s],
                                "min": round(world * args.steps * BATCH / max(window_s), 1), "max": round(world * args.steps * BATCH / min(window_s), 1),
-                               "first_group_slot": phases_w},
+                               "first_group_slot": phases_w, "gc_ms": gc_w, "device_allocs": allocs_w},
                    "device_allocs_in_timed_region": allocs_main,
                    # every PRCNN_* switch this process saw (22 of them select kernels at import time): a line
                    # measured with a non-default engine says so
