@@ -1407,8 +1407,9 @@ class _ShmFeed:
                 r = self.results.get(timeout=1.0)
             except Exception:                                      # noqa: BLE001 (queue.Empty): keep the workers fed, notice dead ones
                 self._feed()
-                if not any(p.is_alive() for p in self.procs):
-                    raise RuntimeError("eval_scenes: every loader process has exited")
+                dead = [p.exitcode for p in self.procs if p.exitcode not in (None, 0)]
+                if dead or not any(p.is_alive() for p in self.procs):
+                    raise RuntimeError("eval_scenes: a loader process has exited (exit codes %s): its batch will never arrive" % (dead or "0"))
                 continue
             if r[0] < 0:
                 raise RuntimeError(r[4])
@@ -1534,143 +1535,146 @@ def eval_scenes_pinned(model, cfg, device, source, scene_ids, batch_size=8, outp
         if stats is not None:
             stats["loader_buffer"] = {"slots": int(feed.buf.shape[0]), "MB": round(feed.buf.numel() * 4 / 1e6, 1), "page_locked": feed.registered}
 
-    feed_wait = [0.0]                      # seconds the feeding thread spent inside feed.next() (waiting for a loader + unpacking its message)
-
-    def load(s):
-        ids = scene_ids[s:s + batch_size]
-        if not ids:
-            return None, ids, None
-        if feed is not None:
-            tw = time.perf_counter()
-            host, slot, counts, calibs, shapes = feed.next()
-            feed_wait[0] += time.perf_counter() - tw
-            meta = list(zip(calibs, shapes))
-            if stage is not None:
-                pts, _ = stage.from_packed(host, counts, calibs, shapes, ids, lidar_frame=source.raw_in_lidar_frame,
-                                           image_filter=source.raw_needs_image_filter)
-                feed.release(slot, stage.last_done)
-                return pts, ids, meta
-            if not on_gpu:
-                pts = host.clone()
-                feed.release(slot, None)
-                return pts, ids, meta
-            if feed.registered:
-                pts = host.to(device, non_blocking=True)
-            else:                                                   # registration refused: through a pinned staging copy
-                pts = host.pin_memory().to(device, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(device))
-            feed.release(slot, ev)
-            return pts, ids, meta
-        if stage is not None:
-            raws = [source.load_raw(i)[0] for i in ids]
-            meta = [source.calib_and_shape(i) for i in ids]
-            pts, _ = stage(raws, [m[0] for m in meta], [m[1] for m in meta], ids,
-                           lidar_frame=source.raw_in_lidar_frame, image_filter=source.raw_needs_image_filter)
-            return pts, ids, meta
-        loaded = [source.load(i) for i in ids]
-        host = torch.from_numpy(np.stack([l[0] for l in loaded], 0))
-        host = host.pin_memory() if on_gpu else host
-        meta = [(l[1], l[2]) for l in loaded]
-        return host.to(device, non_blocking=True), ids, meta
-
-    # Results are consumed LATE: the D2H copy of a batch is queued (on the stream that produced it) the moment the batch
-    # is submitted, but the host only waits for it `lag` batches later, when it has long completed -- the host thread
-    # never stalls on the GPU inside the loop and keeps enqueueing ahead of it.  The KITTI text files are written by a
-    # small thread pool (numpy projection + formatting + file I/O per scene; the reference does this inline, :635).
-    import collections
-    from concurrent.futures import ProcessPoolExecutor
-    import multiprocessing
-    lag = int(os.environ.get("PRCNN_RESULT_LAG", "3")) if runner is not None else 0
-    inflight = collections.deque()
-    # writer PROCESSES: the formatting of ~40 text lines per scene is pure Python and would hold the GIL of the thread
-    # that feeds the GPU; one job per batch
     writers = None
-    if output_dir:
-        wctx = "forkserver" if (on_gpu and torch.cuda.is_initialized()) else "fork"
-        writers = ProcessPoolExecutor(max_workers=budget["writers"], initializer=_limit_worker_threads,
-                                      mp_context=multiprocessing.get_context(os.environ.get("PRCNN_LOADER_CONTEXT", wctx)))
-    jobs = []
-    results = {}
+    try:                                   # (the loader processes, their page-locked buffer and the writer pool are released on every way out)
+        feed_wait = [0.0]                      # seconds the feeding thread spent inside feed.next() (waiting for a loader + unpacking its message)
 
-    def start_copy(det, ids, meta, order):
-        with torch.cuda.stream(det["stream"]) if "stream" in det else contextlib.nullcontext():
-            if on_gpu and det.get("blob") is not None:
-                hb = torch.empty(det["blob"].shape, dtype=torch.float32, pin_memory=True)
-                hb.copy_(det["blob"], non_blocking=True)            # boxes | scores | num in one transfer
-                host = list(split_detections(hb, det["boxes"].shape[0], det["boxes"].shape[1]))
-                done = torch.cuda.Event()
-                done.record()
-            elif on_gpu:
-                host = [torch.empty(det[k].shape, dtype=det[k].dtype, pin_memory=True) for k in ("boxes", "scores", "num")]
-                for h, k in zip(host, ("boxes", "scores", "num")):
-                    h.copy_(det[k], non_blocking=True)
-                done = torch.cuda.Event()
-                done.record()
-            else:
-                host, done = [det[k] for k in ("boxes", "scores", "num")], None
-            if recall is not None:
-                recall.update(det["pred_boxes3d"], det["rois"], [source.gt_boxes3d(i) for i in ids])
-        inflight.append((host, done, ids, meta, order))
+        def load(s):
+            ids = scene_ids[s:s + batch_size]
+            if not ids:
+                return None, ids, None
+            if feed is not None:
+                tw = time.perf_counter()
+                host, slot, counts, calibs, shapes = feed.next()
+                feed_wait[0] += time.perf_counter() - tw
+                meta = list(zip(calibs, shapes))
+                if stage is not None:
+                    pts, _ = stage.from_packed(host, counts, calibs, shapes, ids, lidar_frame=source.raw_in_lidar_frame,
+                                               image_filter=source.raw_needs_image_filter)
+                    feed.release(slot, stage.last_done)
+                    return pts, ids, meta
+                if not on_gpu:
+                    pts = host.clone()
+                    feed.release(slot, None)
+                    return pts, ids, meta
+                if feed.registered:
+                    pts = host.to(device, non_blocking=True)
+                else:                                                   # registration refused: through a pinned staging copy
+                    pts = host.pin_memory().to(device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(device))
+                feed.release(slot, ev)
+                return pts, ids, meta
+            if stage is not None:
+                raws = [source.load_raw(i)[0] for i in ids]
+                meta = [source.calib_and_shape(i) for i in ids]
+                pts, _ = stage(raws, [m[0] for m in meta], [m[1] for m in meta], ids,
+                               lidar_frame=source.raw_in_lidar_frame, image_filter=source.raw_needs_image_filter)
+                return pts, ids, meta
+            loaded = [source.load(i) for i in ids]
+            host = torch.from_numpy(np.stack([l[0] for l in loaded], 0))
+            host = host.pin_memory() if on_gpu else host
+            meta = [(l[1], l[2]) for l in loaded]
+            return host.to(device, non_blocking=True), ids, meta
 
-    def consume():
-        (boxes, scores, num), done, ids, meta, order = inflight.popleft()
-        if done is not None:
-            done.synchronize()
-        results[order] = (boxes, scores, num)
-        if stats is not None:
-            stats.setdefault("batch_done", []).append(time.perf_counter())
+        # Results are consumed LATE: the D2H copy of a batch is queued (on the stream that produced it) the moment the batch
+        # is submitted, but the host only waits for it `lag` batches later, when it has long completed -- the host thread
+        # never stalls on the GPU inside the loop and keeps enqueueing ahead of it.  The KITTI text files are written by a
+        # small thread pool (numpy projection + formatting + file I/O per scene; the reference does this inline, :635).
+        import collections
+        from concurrent.futures import ProcessPoolExecutor
+        import multiprocessing
+        lag = int(os.environ.get("PRCNN_RESULT_LAG", "3")) if runner is not None else 0
+        inflight = collections.deque()
+        # writer PROCESSES: the formatting of ~40 text lines per scene is pure Python and would hold the GIL of the thread
+        # that feeds the GPU; one job per batch
+        writers = None
         if output_dir:
-            nn = num.tolist()
-            jobs.append(writers.submit(_write_batch, ids, [m[0] for m in meta], [m[1] for m in meta],
-                                       [boxes[k, :nn[k]].numpy() for k in range(len(ids))],
-                                       [scores[k, :nn[k]].numpy() for k in range(len(ids))], output_dir, cfg.CLASSES))
+            wctx = "forkserver" if (on_gpu and torch.cuda.is_initialized()) else "fork"
+            writers = ProcessPoolExecutor(max_workers=budget["writers"], initializer=_limit_worker_threads,
+                                          mp_context=multiprocessing.get_context(os.environ.get("PRCNN_LOADER_CONTEXT", wctx)))
+        jobs = []
+        results = {}
 
-    # software pipeline: while batch i is on the device, batch i+1 is loaded and (three-stream runner) the RCNN +
-    # final stage of batch i-1 complete; results are consumed `lag` batches late
-    submitted = collections.deque()        # (ids, meta, order) of the batches whose detections have not come back yet, oldest first
-    order = 0
-    depth = runner.depth if runner is not None else 1
-    ahead = [load(k * batch_size) for k in range(depth)]   # `depth` batches ahead: the runner starts their geometry chains early
-    phase = {"load": 0.0, "submit": 0.0, "copy": 0.0, "consume": 0.0} if stats is not None else None     # host seconds of the feeding thread by phase
-    clock = time.perf_counter
-    for s in range(0, len(scene_ids), batch_size):
-        pts, ids, meta = ahead.pop(0)
-        t0, w0 = clock(), feed_wait[0]
-        ahead.append(load(s + depth * batch_size))
-        t1 = clock()
-        if runner is not None:
-            det = runner.submit(pts, [a[0] for a in ahead])        # an earlier batch's detections (in submit order), or None
-            submitted.append((ids, meta, order))
-            t2 = clock()
-            if det is not None:
-                start_copy(det, *submitted.popleft())
-        else:
-            t2 = clock()
-            start_copy(infer_batch(model, cfg, pts), ids, meta, order)
-        t3 = clock()
-        order += 1
-        while len(inflight) > lag:
+        def start_copy(det, ids, meta, order):
+            with torch.cuda.stream(det["stream"]) if "stream" in det else contextlib.nullcontext():
+                if on_gpu and det.get("blob") is not None:
+                    hb = torch.empty(det["blob"].shape, dtype=torch.float32, pin_memory=True)
+                    hb.copy_(det["blob"], non_blocking=True)            # boxes | scores | num in one transfer
+                    host = list(split_detections(hb, det["boxes"].shape[0], det["boxes"].shape[1]))
+                    done = torch.cuda.Event()
+                    done.record()
+                elif on_gpu:
+                    host = [torch.empty(det[k].shape, dtype=det[k].dtype, pin_memory=True) for k in ("boxes", "scores", "num")]
+                    for h, k in zip(host, ("boxes", "scores", "num")):
+                        h.copy_(det[k], non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record()
+                else:
+                    host, done = [det[k] for k in ("boxes", "scores", "num")], None
+                if recall is not None:
+                    recall.update(det["pred_boxes3d"], det["rois"], [source.gt_boxes3d(i) for i in ids])
+            inflight.append((host, done, ids, meta, order))
+
+        def consume():
+            (boxes, scores, num), done, ids, meta, order = inflight.popleft()
+            if done is not None:
+                done.synchronize()
+            results[order] = (boxes, scores, num)
+            if stats is not None:
+                stats.setdefault("batch_done", []).append(time.perf_counter())
+            if output_dir:
+                nn = num.tolist()
+                jobs.append(writers.submit(_write_batch, ids, [m[0] for m in meta], [m[1] for m in meta],
+                                           [boxes[k, :nn[k]].numpy() for k in range(len(ids))],
+                                           [scores[k, :nn[k]].numpy() for k in range(len(ids))], output_dir, cfg.CLASSES))
+
+        # software pipeline: while batch i is on the device, batch i+1 is loaded and (three-stream runner) the RCNN +
+        # final stage of batch i-1 complete; results are consumed `lag` batches late
+        submitted = collections.deque()        # (ids, meta, order) of the batches whose detections have not come back yet, oldest first
+        order = 0
+        depth = runner.depth if runner is not None else 1
+        ahead = [load(k * batch_size) for k in range(depth)]   # `depth` batches ahead: the runner starts their geometry chains early
+        phase = {"load": 0.0, "submit": 0.0, "copy": 0.0, "consume": 0.0} if stats is not None else None     # host seconds of the feeding thread by phase
+        clock = time.perf_counter
+        for s in range(0, len(scene_ids), batch_size):
+            pts, ids, meta = ahead.pop(0)
+            t0, w0 = clock(), feed_wait[0]
+            ahead.append(load(s + depth * batch_size))
+            t1 = clock()
+            if runner is not None:
+                det = runner.submit(pts, [a[0] for a in ahead])        # an earlier batch's detections (in submit order), or None
+                submitted.append((ids, meta, order))
+                t2 = clock()
+                if det is not None:
+                    start_copy(det, *submitted.popleft())
+            else:
+                t2 = clock()
+                start_copy(infer_batch(model, cfg, pts), ids, meta, order)
+            t3 = clock()
+            order += 1
+            while len(inflight) > lag:
+                consume()
+            if phase is not None and order > depth:                    # (steady state: behind the first look-ahead's worth of batches)
+                phase["feed_next"] = phase.get("feed_next", 0.0) + feed_wait[0] - w0
+                phase["load"] += t1 - t0 - (feed_wait[0] - w0); phase["submit"] += t2 - t1; phase["copy"] += t3 - t2; phase["consume"] += clock() - t3
+                phase["batches"] = phase.get("batches", 0) + 1
+        if phase is not None:
+            stats["host_phases_ms_per_batch"] = {k: round(v / max(1, phase.get("batches", 1)) * 1e3, 3) for k, v in phase.items() if k != "batches"}
+        while runner is not None and submitted:
+            det = runner.flush()                                        # one batch per call, oldest first
+            if det is None:
+                raise RuntimeError("eval_scenes: the runner returned no detections for %d submitted batches" % len(submitted))
+            start_copy(det, *submitted.popleft())
+        while inflight:
             consume()
-        if phase is not None and order > depth:                    # (steady state: behind the first look-ahead's worth of batches)
-            phase["feed_next"] = phase.get("feed_next", 0.0) + feed_wait[0] - w0
-            phase["load"] += t1 - t0 - (feed_wait[0] - w0); phase["submit"] += t2 - t1; phase["copy"] += t3 - t2; phase["consume"] += clock() - t3
-            phase["batches"] = phase.get("batches", 0) + 1
-    if phase is not None:
-        stats["host_phases_ms_per_batch"] = {k: round(v / max(1, phase.get("batches", 1)) * 1e3, 3) for k, v in phase.items() if k != "batches"}
-    while runner is not None and submitted:
-        det = runner.flush()                                        # one batch per call, oldest first
-        if det is None:
-            raise RuntimeError("eval_scenes: the runner returned no detections for %d submitted batches" % len(submitted))
-        start_copy(det, *submitted.popleft())
-    while inflight:
-        consume()
-    for j in jobs:
-        j.result()
-    if writers is not None:
-        writers.shutdown()
-    if feed is not None:
-        feed.close()
+        for j in jobs:
+            j.result()
+    finally:
+        if writers is not None:
+            writers.shutdown(wait=True, cancel_futures=True)
+        if feed is not None:
+            feed.close()
     return pack_detections(scene_ids, [results[k] for k in sorted(results)], M)
 
 

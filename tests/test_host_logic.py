@@ -629,3 +629,61 @@ def test_rcnn_use_intensity_in_the_joint_path_fails_as_the_reference_does(oracle
     with ext_cpu.patch_package(), pytest.raises(KeyError, match="rpn_intensity"):
         with torch.no_grad():
             model({"pts_input": pts})
+
+
+class _FailingSource:
+    """a scene source whose third scene cannot be loaded (picklable: module level)"""
+    ids = list(range(16))
+
+    def load(self, i):
+        if i == 10:
+            raise ValueError("scene %d is broken" % i)
+        return np.full((64, 3), float(i), np.float32), pkg("synth").SyntheticCalib(), (375, 1242)
+
+
+def test_shared_loader_feed_hands_over_the_loaders_bits_in_order(tmp_path):
+    """round 6: eval_scenes' loader processes write into ONE shared buffer (eval_rcnn._ShmFeed; page-locked on a GPU box) instead of
+    handing tensors over one by one.  On CPU: the batches come back in order with exactly the arrays source.load / load_raw produce
+    (sampled clouds; raw clouds of different lengths packed (B, n_max, 4) with their counts), calibration rows and image shapes
+    survive the trip, a ragged last batch works, a loader's exception reaches the parent, and a cloud that does not fit a slot says so."""
+    E, K, S, C = pkg("eval_rcnn"), pkg("kitti_io"), pkg("synth"), pkg("config")
+    cfg = C.default_eval_cfg()
+    src = K.SyntheticSource(cfg, 21)                                     # 21 scenes in batches of 8: the last batch holds 5
+    feed = E._ShmFeed(src, src.ids, 8, False, 3, "fork", False, 8 * cfg.RPN.NUM_POINTS * 3)
+    try:
+        for b in range(3):
+            host, slot, counts, calibs, shapes = feed.next()
+            want = np.stack([src.load(i)[0] for i in src.ids[8 * b:8 * b + 8]], 0)
+            assert np.array_equal(host.numpy(), want) and counts == [cfg.RPN.NUM_POINTS] * len(want)
+            assert np.allclose(calibs[0].P2, src.calib.P2) and tuple(shapes[0]) == tuple(src.calib.image_shape)
+            feed.release(slot, None)
+        assert feed.next() is None
+    finally:
+        feed.close()
+    root = str(tmp_path / "tree")
+    S.write_kitti_tree(root, 12, pool=4)
+    ks = K.KittiSource(root, cfg)
+    feed = E._ShmFeed(ks, ks.ids, 8, True, 2, "fork", False, 8 * 60000 * 4)
+    try:
+        for b in range(2):
+            host, slot, counts, calibs, shapes = feed.next()
+            for k, i in enumerate(ks.ids[8 * b:8 * b + 8]):
+                raw, cal, shape = ks.load_raw(i)
+                assert counts[k] == len(raw) and np.array_equal(host[k, :counts[k]].numpy(), raw)
+                assert np.allclose(calibs[k].V2C, cal.V2C) and np.allclose(calibs[k].R0, cal.R0) and tuple(shapes[k]) == tuple(shape)
+            feed.release(slot, None)
+    finally:
+        feed.close()
+    small = E._ShmFeed(ks, ks.ids, 8, True, 1, "fork", False, 8 * 1000 * 4)    # a slot of 1000 points per raw cloud: too small
+    try:
+        with pytest.raises(RuntimeError, match="does not fit a loader slot"):
+            small.next()
+    finally:
+        small.close()
+    bad = E._ShmFeed(_FailingSource(), _FailingSource.ids, 8, False, 2, "fork", False, 8 * 64 * 3)
+    try:
+        bad.next()
+        with pytest.raises(RuntimeError, match="scene 10 is broken"):
+            bad.next()
+    finally:
+        bad.close()
