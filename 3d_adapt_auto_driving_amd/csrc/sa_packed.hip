@@ -180,6 +180,160 @@ __global__ void ball_pack_kernel(int n, int m, int ns, int tiles_cap_cloud, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------ packing, many workgroups per cloud
+// Round 6.  ball_pack_kernel is ONE workgroup per cloud: 32 workgroups for a geometry group, 142 us for the 1.2 M rows of SA1's wider
+// scale on LiDAR-shaped scenes, 2.5 launches and 178 us per step there on geometry streams that are 90 % busy (profiles/
+// r06_bench_step_kernel_stats_lidar.md).  The plain form (no representative map over the points) as TWO launches whose workgroups own
+// PK_CH centres each: (1) counts per centre + their sum per chunk; (2) every workgroup finds its place from the chunk sums -- the
+// clouds of a list in INDEX order (no atomic: the tile list is deterministic now), its chunk behind the chunks before it -- and writes
+// its rows.  Same rows per cloud in the same order as ball_pack_kernel, same padding of a cloud's last tile, same header.
+constexpr int PK_CH = 64;           // centres per workgroup
+
+__global__ __launch_bounds__(256) void ball_pack_count_kernel(int m, int ns, int nchunk, const int *__restrict__ idx, const int *__restrict__ limit,
+                                                              const int *__restrict__ crep, int *__restrict__ cnts, int *__restrict__ csum)
+{
+    __shared__ int s_cnt[PK_CH];
+    __shared__ int s_part[4];
+    const int chunk = blockIdx.x, gb = blockIdx.y, tid = threadIdx.x;
+    const int c0 = chunk * PK_CH, nc = min(PK_CH, m - c0);
+    const int *rows = idx + ((long)gb * m + c0) * ns;
+    const int lim = limit ? max(limit[gb], 1) : 0x7fffffff;
+    if (tid < PK_CH) s_cnt[tid] = 1;
+    __syncthreads();
+    if ((ns & 3) == 0) {
+        const int q4 = ns >> 2;
+        for (int e = tid; e < nc * q4; e += 256) {
+            const int c = e / q4, p = (e - c * q4) * 4;
+            const int first = rows[(long)c * ns];
+            const int4 v = *reinterpret_cast<const int4 *>(rows + (long)c * ns + p);
+            int last = -1;
+            if (v.x != first && v.x < lim) last = p;
+            if (v.y != first && v.y < lim) last = p + 1;
+            if (v.z != first && v.z < lim) last = p + 2;
+            if (v.w != first && v.w < lim) last = p + 3;
+            if (last > 0) atomicMax(&s_cnt[c], last + 1);
+        }
+    } else {
+        for (int e = tid; e < nc * ns; e += 256) {
+            const int c = e / ns, p = e - c * ns;
+            const int v = rows[e];
+            if (p > 0 && v != rows[(long)c * ns] && v < lim) atomicMax(&s_cnt[c], p + 1);
+        }
+    }
+    __syncthreads();
+    int v = 0;
+    if (tid < nc) {
+        v = s_cnt[tid];
+        if (crep && crep[(long)gb * m + c0 + tid] != c0 + tid) v = 0;          // a centre that copies an earlier one gets no rows
+        cnts[(long)gb * m + c0 + tid] = v;
+    }
+    if (tid < 64) {                                                            // PK_CH = 64: one wave holds the chunk
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (tid == 0) csum[(long)gb * nchunk + chunk] = v;
+    }
+    (void)s_part;
+}
+
+__global__ __launch_bounds__(256) void ball_pack_write_kernel(int n, int m, int ns, int nchunk, int tiles_cap_cloud, const int *__restrict__ idx,
+                                                              const int *__restrict__ limit, const float *__restrict__ xyz,
+                                                              const float *__restrict__ new_xyz, const int *__restrict__ cnts,
+                                                              const int *__restrict__ csum, unsigned int *__restrict__ rowinfo,
+                                                              float4 *__restrict__ rowdxyz, int *__restrict__ tilecloud,
+                                                              unsigned int *__restrict__ hdr, int group)
+{
+    __shared__ int s_off[PK_CH + 1];
+    __shared__ int s_red[256];
+    __shared__ int s_red2[256];
+    const int chunk = blockIdx.x, gb = blockIdx.y, tid = threadIdx.x;
+    const int list = gb / group, b = gb - list * group;
+    rowinfo += (long)list * group * tiles_cap_cloud * PK_ROWS;
+    rowdxyz += (long)list * group * tiles_cap_cloud * PK_ROWS;
+    tilecloud += (long)list * group * tiles_cap_cloud;
+    hdr += 4 * list;
+    const int c0 = chunk * PK_CH, nc = min(PK_CH, m - c0);
+    // tiles of the list's clouds before this one (index order), rows of this cloud's chunks before this one, rows of the cloud
+    const int *lsum = csum + (long)list * group * nchunk;
+    int tiles_before = 0, tiles_all = 0, rows_all = 0;
+    for (int j = tid; j < group; j += 256) {
+        int tot = 0;
+        for (int k = 0; k < nchunk; ++k) tot += lsum[(long)j * nchunk + k];
+        const int tl = (tot + PK_ROWS - 1) / PK_ROWS;
+        if (j < b) tiles_before += tl;
+        tiles_all += tl; rows_all += tot;
+    }
+    int before = 0, total = 0;
+    for (int k = tid; k < nchunk; k += 256) {
+        const int v = lsum[(long)b * nchunk + k];
+        if (k < chunk) before += v;
+        total += v;
+    }
+    auto block_sum = [&](int v, int *buf) {
+        buf[tid] = v;
+        __syncthreads();
+        for (int d = 128; d >= 1; d >>= 1) {
+            if (tid < d) buf[tid] += buf[tid + d];
+            __syncthreads();
+        }
+        const int r = buf[0];
+        __syncthreads();
+        return r;
+    };
+    tiles_before = block_sum(tiles_before, s_red);
+    before = block_sum(before, s_red2);
+    total = block_sum(total, s_red);
+    if (chunk == 0 && b == 0) {                                                 // the list's header (block-uniform condition)
+        tiles_all = block_sum(tiles_all, s_red2);
+        rows_all = block_sum(rows_all, s_red);
+        if (tid == 0) { hdr[0] = (unsigned int)tiles_all; hdr[1] = (unsigned int)rows_all; }
+    }
+    // exclusive offsets of this chunk's centres (one wave)
+    if (tid < 64) {
+        const int v = tid < nc ? cnts[(long)gb * m + c0 + tid] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (tid >= d) incl += o;
+        }
+        s_off[tid] = incl - v;
+        if (tid == 63) s_off[PK_CH] = incl;
+    }
+    __syncthreads();
+    const int mine = s_off[PK_CH];                                              // rows of this chunk
+    const int ntiles = (total + PK_ROWS - 1) / PK_ROWS;
+    const int lim = limit ? max(limit[gb], 1) : 0x7fffffff;
+    const int *rows = idx + (long)gb * m * ns;
+    const float *cloud = xyz + (long)gb * n * 3;
+    unsigned int *dst = rowinfo + (long)tiles_before * PK_ROWS;
+    float4 *dxyz = rowdxyz + (long)tiles_before * PK_ROWS;
+    // the cloud's tiles that START inside this chunk's rows are recorded by this workgroup (tile 0 by the first chunk that has rows)
+    for (int t = (before + PK_ROWS - 1) / PK_ROWS + tid; (long)t * PK_ROWS < (long)before + mine; t += 256) tilecloud[tiles_before + t] = b;
+    // rows beyond `total` fill the cloud's last tile with copies of its LAST CENTRE's first row (as ball_pack_kernel): by the last chunk
+    const int extra = (chunk == nchunk - 1) ? ntiles * PK_ROWS - total : 0;
+    for (int r = tid; r < mine + extra; r += 256) {
+        int c, p;
+        if (r < mine) {
+            int lo = 0, hi = nc - 1;                                            // the last centre of the chunk whose offset is <= r
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_off[mid] <= r) lo = mid; else hi = mid - 1;
+            }
+            c = c0 + lo; p = r - s_off[lo];
+        } else {
+            c = m - 1; p = 0;
+        }
+        const int *row = rows + (long)c * ns;
+        const int v = row[p];
+        const int k = v < lim ? v : row[0];
+        const float *ct = new_xyz + ((long)gb * m + c) * 3;
+        const float *pt = cloud + 3 * (long)k;
+        const long o = r < mine ? (long)before + r : (long)total + (r - mine);
+        dst[o] = ((unsigned int)c << 16) | (unsigned int)k;
+        dxyz[o] = make_float4(pt[0] - ct[0], pt[1] - ct[1], pt[2] - ct[2], 0.f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ C3 = 128
 // Two workgroups per CU (see sa_mlp_fused.hip for the MFMA mapping; identical here).
 // Round 5: ONE launch serves up to two PROBLEMS (the two scales of an MSG level: their own row lists, weights and output slices):
@@ -740,6 +894,18 @@ static int ball_pack_launch(int b, int group, int n, int m, int nsample, const i
     PRCNN_REQUIRE(idx && rowinfo && tilecloud && xyz && new_xyz && rowdxyz, "ball_pack: null pointer");
     PRCNN_REQUIRE(((uintptr_t)rowdxyz & 15) == 0, "ball_pack: rowdxyz must be 16-byte aligned");
     PRCNN_REQUIRE(((uintptr_t)idx & 15) == 0 || (nsample & 3) != 0, "ball_pack: 16-byte alignment required");
+    if (!rep && m >= 512) {
+        // many workgroups per cloud (round 6): counts, then rows -- see ball_pack_count_kernel
+        const int nchunk = (m + PK_CH - 1) / PK_CH;
+        int *scr = (int *)scratch_for(st, ((size_t)b * m + (size_t)b * nchunk) * sizeof(int), 14);
+        if (!scr) { set_error("ball_pack: cannot allocate the count scratch"); return PRCNN_ELAUNCH; }
+        int *cnts = scr, *csum = scr + (size_t)b * m;
+        const int cap = (int)(((long)m * nsample + PK_ROWS - 1) / PK_ROWS);
+        hipLaunchKernelGGL(ball_pack_count_kernel, dim3(nchunk, b), dim3(256), 0, st, m, nsample, nchunk, idx, limit, crep, cnts, csum);
+        hipLaunchKernelGGL(ball_pack_write_kernel, dim3(nchunk, b), dim3(256), 0, st, n, m, nsample, nchunk, cap, idx, limit, xyz, new_xyz, cnts, csum,
+                           rowinfo, (float4 *)rowdxyz, tilecloud, hdr, group);
+        return check_launch("ball_pack");
+    }
     int threads = 64;                              // enough threads for the cloud's index elements, 16 bytes each
     while (threads < (int)(((long)m * nsample + 3) / 4) && threads < 1024) threads *= 2;
     PRCNN_REQUIRE(!rep || nsample <= 64, "ball_pack: a representative map needs nsample <= 64 (got %d)", nsample);
