@@ -425,7 +425,6 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
     __shared__ unsigned long long s_vk[32];                          // packed (value, key) of the published entries
     __shared__ float s_xyz[32][3];
     __shared__ float s_bound[16];
-    __shared__ float s_res[64];                                      // the round's verdict: [0] = number of picks, [1 + 3 q ..] = pivot q
     __shared__ int s_rank[32], s_blk[32];                            // per entry: entries that precede it / one of them blocks it
     const int b = blockIdx.x;
     const float *__restrict__ cloud = xyz + (long)b * n * 3;
@@ -480,14 +479,6 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
     // themselves 481 / 742 against 480 / 742.
     unsigned long long touched = 0ull, etiles = ~0ull;
     float bound = INFINITY;
-    // the box of ALL this wave's points (round 6): a pivot that cannot change a point of the wave box cannot pass a tile box inside it
-    // (the lower bound of a larger box is the smaller one, in f32 as in the reals: subtraction, max, product and sum are monotone under
-    // round-to-nearest), so one test per pivot -- lane q tests pivot q, all of a round's pivots at once -- stands in front of the
-    // PPT tile tests: until then every wave ran ceil(r / GP) passes of tile tests in every round, 16 waves on 4 SIMDs, beside the
-    // few waves whose points the pivots actually change.  Measured (same box, alternating): 1.823 -> 1.798 ms uniform, 2.688 -> 2.69 ms
-    // LiDAR-shaped for 32 x (16384 -> 4096), same picks: almost every wave IS reached by a pivot of a round of 8; kept, it costs nothing
-    const float wx0 = -wave_max_f32(-bx0), wx1 = wave_max_f32(bx1), wy0 = -wave_max_f32(-by0), wy1 = wave_max_f32(by1),
-                wz0 = -wave_max_f32(-bz0), wz1 = wave_max_f32(bz1);
     // which tiles can a pivot (per lane group: ox, oy, oz differ by group) change?  bit g * PPT + i: tile i, the group's pivot
     auto box_mask = [&](float ox, float oy, float oz, bool live) __attribute__((always_inline)) {
         const float dx = fmax_raw(fmax_raw(bx0 - ox, ox - bx1), 0.f);
@@ -584,80 +575,68 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
             }
         }
         lds_barrier();                                                // A: the table is complete
-        // ---- 3. merge.  All 32 x 32 pairs at once, over ALL 16 waves: lane = (entry i = lane & 31, half h = lane >> 5) of wave w
-        // compares entry i with entry e = 2 w + h; entry i's RANK = how many entries precede it in the order (value desc, key asc);
-        // it is BLOCKED if an entry that precedes it lies closer than its running minimum.  The per-pair bits are summed / or-ed
-        // per entry through LDS atomics (s_rank / s_blk, zero between rounds), and one wave reads the verdict off: the picks of the
-        // round are the ranks 0 .. r-1 up to the first rank that fails.  (History: every wave merging the whole table redundantly --
-        // the first version -- made the kernel issue-bound, 5.2 ms against the sequential kernel's 4.2; ONE wave walking its
-        // half of the table, 16 dependent LDS round trips, was 2.6 k of a round's 10.2 k cycles with 15 waves waiting.)
+        // ---- 3. merge (round 6 form: two barriers per round, no LDS atomic, no verdict broadcast).  All 32 x 32 pairs at once over the
+        // 16 waves: wave w OWNS entries 2 w and 2 w + 1 -- lane (e = lane & 31, h = lane >> 5) compares entry i = 2 w + h with entry e:
+        // does e precede i in the order (value desc, key asc), and does it lie closer to i than i's running minimum?  Entry i's RANK
+        // (how many precede it) and its BLOCKED bit are a population count / a test of one half of a ballot: wave-uniform, written by
+        // one lane.  Behind the second barrier EVERY wave reads the 32 ranks and derives the verdict itself -- the picks of the round
+        // are the ranks 0 .. r-1 up to the first rank that fails -- so nobody waits for wave 0 and a third barrier; a forward
+        // permute (ds_permute: lane e sends to lane rank(e)) puts pivot q's coordinates into lane q of every wave.
+        // (Rounds 4-5: lane = entry i, wave = entry e, ranks summed through LDS atomics, the verdict by wave 0 into s_res, barrier B:
+        // pairs 540 + verdict 760 + the barrier ~ 1500 of a round's 8200 cycles, profiles/r05_fps_round_stamps.txt.  History before that:
+        // every wave merging the whole table by sequential extraction -- issue-bound, 5.2 ms; one wave walking its half of the table,
+        // 16 dependent LDS round trips: 2.6 k of 10.2 k cycles.)
         const int left = m - j;
-        const int i = lane & 31, h = lane >> 5;
-        const unsigned long long pki = s_vk[i];
-        float cv; uint32_t ck;
-        unpack_candidate(pki, cv, ck);
-        const float cx = s_xyz[i][0], cy = s_xyz[i][1], cz = s_xyz[i][2];
+        const int e = lane & 31, h = lane >> 5;
+        const unsigned long long pke = s_vk[e];
+        float cv; uint32_t ck;                                        // entry e: what this lane is responsible for in the verdict
+        unpack_candidate(pke, cv, ck);
+        const float cx = s_xyz[e][0], cy = s_xyz[e][1], cz = s_xyz[e][2];
+        const float gB = wave_max_f32(lane < 16 ? s_bound[lane] : -INFINITY);     // (read in front of A2: the next publish rewrites it behind A2)
         {
-            const int e = 2 * w + h;
-            const unsigned long long pke = s_vk[e];
-            const float ex = s_xyz[e][0], ey = s_xyz[e][1], ez = s_xyz[e][2];
+            const int i = 2 * w + h;
+            const unsigned long long pki = s_vk[i];
+            float iv; uint32_t ik;
+            unpack_candidate(pki, iv, ik);
+            const float ix = s_xyz[i][0], iy = s_xyz[i][1], iz = s_xyz[i][2];
             const bool before = pke > pki;
-            const float d = kc.hipcc ? fps_dist<true>(cx, cy, cz, ex, ey, ez) : sqdist3(cx, cy, cz, ex, ey, ez);
-            const bool blk = before && (d < cv);
-            // both bits of the pair in ONE exchange with the other half's lane (and never behind a short-circuit: a shuffle that only
-            // the lanes with a false left operand execute reads inactive lanes)
-            const int mine = (before ? 1 : 0) | (blk ? 2 : 0);
-            const int other = __shfl_xor(mine, 32, 64);
-            const int rk = (mine & 1) + (other & 1);
-            const bool bl = ((mine | other) & 2) != 0;
-            if (h == 0 && rk) atomicAdd(&s_rank[i], rk);
-            if (h == 0 && bl) atomicOr(&s_blk[i], 1);
-        }
-        lds_barrier();                                                // A2: every pair has been looked at
-        if (w == 0) {
-            const int rank = s_rank[i];
-            const bool blocked = s_blk[i] != 0;
-            const float gB = wave_max_f32(lane < 16 ? s_bound[lane] : -INFINITY);
-            const bool valid = !(ck == 0xffffffffu || !(cv > -1.0f));      // (reference: best starts at -1, besti at 0)
-            const bool pass = rank == 0 ? true : ((cv > gB) && (cv > 0.f) && valid && !blocked);
-            // a round ends behind an invalid first entry (the reference then picks index 0: every running minimum is below -1 / NaN)
-            const bool stop = !pass || (rank == 0 && !valid);
-            int r = (int)wave_min_u32((stop && !(rank == 0)) ? (uint32_t)rank : ((rank == 0 && !valid) ? 1u : 32u));
-            r = min(min(r, left), FS_RMAX);
-            if (r < 1) r = 1;
-            if (h == 0 && rank < r) {
-                sel[j + rank] = valid ? kc.decode(ck) : 0;
-                const bool v0 = valid;
-                const float ox = v0 ? cx : cloud[0], oy = v0 ? cy : cloud[1], oz = v0 ? cz : cloud[2];
-                s_res[1 + 3 * rank] = ox; s_res[2 + 3 * rank] = oy; s_res[3 + 3 * rank] = oz;
-                if (nxyz) { nxyz[3 * (j + rank)] = ox; nxyz[3 * (j + rank) + 1] = oy; nxyz[3 * (j + rank) + 2] = oz; }
+            const float d = kc.hipcc ? fps_dist<true>(ix, iy, iz, cx, cy, cz) : sqdist3(ix, iy, iz, cx, cy, cz);
+            const unsigned long long bb = __ballot(before), kb = __ballot(before && (d < iv));
+            if (e == 0) {
+                s_rank[i] = __popc((unsigned)(h ? (bb >> 32) : bb));
+                s_blk[i] = (unsigned)(h ? (kb >> 32) : kb) != 0u;
             }
-            if (h == 0) { s_rank[i] = 0; s_blk[i] = 0; }              // for the next round (read above, program order)
-            if (lane == 0) s_res[0] = __int_as_float(r);
         }
-        lds_barrier();                                                // B: the verdict is in
+        lds_barrier();                                                // A2: every entry has its rank
+        const int rank = s_rank[e];
+        const bool blocked = s_blk[e] != 0;
+        const bool valid = !(ck == 0xffffffffu || !(cv > -1.0f));      // (reference: best starts at -1, besti at 0)
+        const bool pass = rank == 0 ? true : ((cv > gB) && (cv > 0.f) && valid && !blocked);
+        // a round ends behind an invalid first entry (the reference then picks index 0: every running minimum is below -1 / NaN)
+        const bool stop = !pass || (rank == 0 && !valid);
+        int r = (int)wave_min_u32((stop && !(rank == 0)) ? (uint32_t)rank : ((rank == 0 && !valid) ? 1u : 32u));
+        r = min(min(r, left), FS_RMAX);
+        if (r < 1) r = 1;
+        const float ox_ = valid ? cx : cloud[0], oy_ = valid ? cy : cloud[1], oz_ = valid ? cz : cloud[2];
+        if (w == 0 && h == 0 && rank < r) {                           // the outputs: one wave writes them
+            sel[j + rank] = valid ? kc.decode(ck) : 0;
+            if (nxyz) { nxyz[3 * (j + rank)] = ox_; nxyz[3 * (j + rank) + 1] = oy_; nxyz[3 * (j + rank) + 2] = oz_; }
+        }
+        // pivot q -> lanes 3 q, 3 q + 1, 3 q + 2 of ONE register (x, y, z): lane e (first half) sends its three coordinates to the lanes
+        // of its rank; whatever is no pivot goes to lane 63, which nobody reads; lanes nobody writes read 0, so the three answers OR
+        // together.  (Three registers, lane q = pivot q, spilled fps_spec_kernel<16> at its 128-register limit.)
+        const int dst = (h == 0 && rank < FS_RMAX) ? 3 * rank : 63;
+        const float rv = __int_as_float(__builtin_amdgcn_ds_permute(dst << 2, __float_as_int(ox_)) |
+                                        __builtin_amdgcn_ds_permute(min(dst + 1, 63) << 2, __float_as_int(oy_)) |
+                                        __builtin_amdgcn_ds_permute(min(dst + 2, 63) << 2, __float_as_int(oz_)));
         // ---- 4. running minima against this round's pivots (the last pick of the whole run does not update them: sampling_gpu.cu)
-        const float rv = s_res[lane];
-        const int r = __builtin_amdgcn_readfirstlane(__float_as_int(rv));
         j += r;
         const int apply_n = j >= m ? r - 1 : r;
         touched = 0ull;
-        unsigned hits;
-        {
-            const int ql = lane & (FS_RMAX - 1);
-            const float qx = s_res[1 + 3 * ql], qy = s_res[2 + 3 * ql], qz = s_res[3 + 3 * ql];
-            const float dx = fmax_raw(fmax_raw(wx0 - qx, qx - wx1), 0.f);
-            const float dy = fmax_raw(fmax_raw(wy0 - qy, qy - wy1), 0.f);
-            const float dz = fmax_raw(fmax_raw(wz0 - qz, qz - wz1), 0.f);
-            const float lb = dx * dx + dy * dy + dz * dz;
-            hits = (unsigned)__ballot(lane < apply_n && !(lb * 0.99999f >= bound));
-        }
-        if (hits == 0u) continue;                                       // no pivot of the round reaches this wave
         for (int q0 = 0; q0 < apply_n; q0 += GP) {
-            if (((hits >> q0) & ((GP >= 32) ? ~0u : ((1u << GP) - 1u))) == 0u) continue;
             // lane group g tests pivot q0 + g against the PPT tile boxes
             const int qg = q0 + lane / PPT;
-            const int src = 1 + 3 * min(qg, FS_RMAX - 1);
+            const int src = 3 * min(qg, FS_RMAX - 1);
             const float gx = __shfl(rv, src, 64), gy = __shfl(rv, src + 1, 64), gz = __shfl(rv, src + 2, 64);
             const unsigned long long masks = box_mask(gx, gy, gz, qg < apply_n);
             if (masks == 0ull) continue;
@@ -666,9 +645,9 @@ __global__ __launch_bounds__(1024) void fps_spec_kernel(
                 const unsigned long long mk = (masks >> (g * PPT)) & ((PPT == 64) ? ~0ull : ((1ull << PPT) - 1ull));
                 if (mk != 0ull) {
                     const int q = q0 + g;
-                    const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 1 + 3 * q));
-                    const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 2 + 3 * q));
-                    const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 3 + 3 * q));
+                    const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 3 * q));
+                    const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 3 * q + 1));
+                    const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rv), 3 * q + 2));
                     update(ox, oy, oz, mk);
                 }
             }

@@ -6,6 +6,8 @@ import importlib, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 pkg = importlib.import_module("3d_adapt_auto_driving_amd"); sys.path.insert(0, pkg.DROPIN_DIR)
+if os.environ.get("FPS_PROBE_LIB"):                 # A/B against another build of the library on the same box (experiments only)
+    L = importlib.import_module("3d_adapt_auto_driving_amd._lib"); L.LIB_PATH = os.environ["FPS_PROBE_LIB"]
 import pointnet2_cuda as P
 synth = importlib.import_module("3d_adapt_auto_driving_amd.synth")
 dev = torch.device("cuda", 0)
