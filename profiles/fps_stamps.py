@@ -4,8 +4,8 @@ into profiles/_exp/libprcnn_hip_fps_stamps.so; the product library is not touche
 
   python profiles/fps_stamps.py build               (build container: hipcc)
   python profiles/fps_stamps.py run [uniform|lidar] (GPU box): 16384 -> 4096, B = 8; per wave: rounds, and cycles per round spent in
-      rebuild + publish | waiting at barrier A | the pair tests of the merge | waiting at barrier A2 | the verdict (wave 0) | waiting at
-      barrier B | distance updates"""
+      rebuild + publish | waiting at barrier A | the pair tests of the merge | waiting at barrier A2 | the verdict + the pivot permute
+      (every wave since round 6: no barrier B) | - | distance updates"""
 import ctypes, importlib, os, subprocess, sys
 import numpy as np
 
@@ -30,8 +30,8 @@ def instrument():
         k = k.replace(old, new)
     put("    while (j < m) {\n", "    unsigned long long acc_[%d] = {0}, t_prev_ = __builtin_amdgcn_s_memtime();\n#define PH(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_[i] += n_ - t_prev_; t_prev_ = n_; }\n    while (j < m) {\n        acc_[7] += 1;\n" % NPH)
     put("        lds_barrier();                                                // A: the table is complete\n", "        PH(0)\n        lds_barrier();                                                // A: the table is complete\n        PH(1)\n")
-    put("        lds_barrier();                                                // A2: every pair has been looked at\n", "        PH(2)\n        lds_barrier();                                                // A2: every pair has been looked at\n        PH(3)\n")
-    put("        lds_barrier();                                                // B: the verdict is in\n", "        PH(4)\n        lds_barrier();                                                // B: the verdict is in\n        PH(5)\n")
+    put("        lds_barrier();                                                // A2: every entry has its rank\n", "        PH(2)\n        lds_barrier();                                                // A2: every entry has its rank\n        PH(3)\n")
+    put("        // ---- 4. running minima against this round's pivots (the last pick of the whole run does not update them: sampling_gpu.cu)\n", "        PH(4)\n        PH(5)\n        // ---- 4. running minima against this round's pivots (the last pick of the whole run does not update them: sampling_gpu.cu)\n")
     put("    if (mind) {\n#pragma unroll\n        for (int i = 0; i < PPT; ++i)\n            if (pc[i] != 0xffffffffu) mind[kc.decode(pc[i] >> SB)] = pt[i];\n    }\n}",
         "    if (mind) {\n#pragma unroll\n        for (int i = 0; i < PPT; ++i)\n            if (pc[i] != 0xffffffffu) mind[kc.decode(pc[i] >> SB)] = pt[i];\n    }\n"
         "    if (blockIdx.x == 0 && lane == 0) for (int i = 0; i < %d; ++i) g_fps_acc[w * %d + i] = acc_[i];\n}" % (NPH, NPH))
@@ -77,7 +77,7 @@ def run(kind):
     a = np.array(buf, dtype=np.float64).reshape(16, NPH)
     rounds = a[:, 7]
     print("%s scenes, cloud 0, 16384 -> 4096: %d rounds; s_memtime cycles per round by wave" % (kind, int(rounds[0])))
-    print("wave | rebuild+publish | wait A | pairs | wait A2 | verdict (wave 0) | wait B | updates | sum")
+    print("wave | rebuild+publish | wait A | pairs | wait A2 | verdict + permute (every wave, round 6) | - | updates | sum")
     for w in range(16):
         v = a[w, :7] / rounds[w]
         print("%4d | " % w + " | ".join("%7.1f" % x for x in v) + " | %7.1f" % v.sum())

@@ -1,8 +1,8 @@
 # The command set behind the r06_* artefacts of profiles/ (run on the GPU box from the repo root: bash profiles/measure_r06.sh [part ...])
-# parts: qg (BASELINE's second metric, both scene kinds, with PMC traffic) | double (double.yaml step tables) | step (per-step kernel
+# parts: fps (a sampling round by phase) | qg (BASELINE's second metric, both scene kinds, with PMC traffic) | double (double.yaml step tables) | step (per-step kernel
 # tables + MFMA counters of the bench, both scene kinds) | driver (whole-driver rates) | bench (the driver's own command)
 O=gpurun_out/r06; mkdir -p $O; export TMPDIR=/tmp
-PARTS="${@:-qg double step driver bench}"
+PARTS="${@:-qg double step driver bench fps}"
 has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
 
 if has qg; then
@@ -71,4 +71,9 @@ if has bench; then
 timeout 1200 python bench.py --steps 20 --warmup 5 > $O/bench_k20.json 2> $O/bench_k20.err
 timeout 900 python bench.py --steps 100 --warmup 8 --windows 3 --no-cpu-baseline --no-roofline --no-driver > $O/bench_k100.json 2> $O/bench_k100.err
 cut -c1-300 $O/bench_k20.json
+fi
+
+if has fps; then
+# a round of fps_spec_kernel by phase (s_memtime stamps in an instrumented copy: `python profiles/fps_stamps.py build` in the build container first)
+for sc in uniform lidar; do timeout 300 python -W ignore profiles/fps_stamps.py run $sc 2>&1 | grep -v amdgpu.ids; done > $O/fps_stamps.txt
 fi

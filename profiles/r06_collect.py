@@ -16,7 +16,7 @@ COPY = {"bench_k20.json": "r06_bench_line.json", "bench_k100.json": "r06_bench_l
         "pmc_query_and_group_uniform.json": "r06_pmc_query_and_group_uniform.json", "pmc_query_and_group_lidar.json": "r06_pmc_query_and_group_lidar.json",
         "double_step_uniform.md": "r06_double_yaml_step_uniform.md", "double_step_lidar.md": "r06_double_yaml_step_lidar.md",
         "double_bench_uniform.json": "r06_double_yaml_bench_uniform.json", "double_bench_lidar.json": "r06_double_yaml_bench_lidar.json",
-        "double_probe.txt": "r06_double_yaml_probe.txt"}
+        "double_probe.txt": "r06_double_yaml_probe.txt", "fps_stamps.txt": "r06_fps_round_stamps.txt"}
 n = 0
 for a, b in COPY.items():
     if os.path.exists(os.path.join(SRC, a)) and os.path.getsize(os.path.join(SRC, a)) > 0:
