@@ -100,9 +100,16 @@ def check_environment():
 
 
 def table():
-    rows = ["| switch | kind | default | read by | meaning |", "|---|---|---|---|---|"]
+    # the last column names the test that RUNS the switch in its non-default form
+    held = {"ab": "`tests/test_gpu_switches.py::test_every_ab_switch_gives_the_same_detections` (bit for bit)",
+            "numerics": "`tests/test_gpu_switches.py::test_numerics_switches_stay_inside_the_box_tolerance` (boxes within 1e-4)"}
+    special = {"PRCNN_ALLOW_LIB_GEMM": "set together with the GEMM-library switches in the numerics test",
+               "PRCNN_FPS2_CAPACITY": "`tests/test_gpu_ops.py::test_fps_two_workgroups_respects_the_co_resident_capacity`",
+               "PRCNN_BENCH_SHARE_GPU": "`tests/test_gpu_configs.py::test_bench_two_ranks_on_one_gpu_...`, `::test_bench_eight_ranks_on_one_gpu`",
+               "PRCNN_GRAPHS": "`tests/test_gpu_graphs.py` (replay == eager enqueue, bit for bit); every child of the switch tests runs with 0"}
+    rows = ["| switch | kind | default | read by | meaning | run in its other form by |", "|---|---|---|---|---|---|"]
     for name, (kind, default, where, what) in sorted(SWITCHES.items(), key=lambda kv: (kv[1][0], kv[0])):
-        rows.append("| `%s` | %s | %s | `%s` | %s |" % (name, kind, default, where, what))
+        rows.append("| `%s` | %s | %s | `%s` | %s | %s |" % (name, kind, default, where, what, special.get(name, held.get(kind, "-"))))
     return "\n".join(rows)
 
 
