@@ -68,11 +68,11 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32 MFMA peak (MI355X_MICROARCH.md)
 # HBM traffic per launch from the rocprofv3 PMC passes over the product step (FETCH_SIZE x2 as MI355X_MICROARCH.md prescribes for gfx950
 # + WRITE_SIZE), kept with the profile it came from; a kernel that has no entry reports null
-PMC_SOURCE = "profiles/r05_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the product step)"
+PMC_SOURCE = "profiles/r06_pmc_product_kernels.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the product step, bash profiles/measure_r06.sh step)"
 # keyed by the scenes per launch the passes ran at (profiles/pmc_step_probe.py: 16 = a pair of batches, the product's launch since the
 # second session of round 4; 8: the passes of rounds 2-4 over single batches)
 PMC_TRAFFIC = {8: {"rpn_tail_lin_kernel": 148.96e6, "rpn_tail_kernel": 325.87e6, "roipool3d_canonical_kernel": 87.06e6},
-               16: {"rpn_tail_lin_kernel": 297.60e6, "rpn_tail_lin_kernel<decode>": 210.58e6, "roipool3d_canonical_kernel": 172.63e6}}
+               16: {"rpn_tail_lin_kernel": 297.60e6, "rpn_tail_lin_kernel<decode>": 210.66e6, "roipool3d_canonical_kernel": 172.71e6}}      # (round 6 passes: 210.66 / 172.71 MB; round 5: 210.58 / 172.63)
 # scenes per launch of the stages behind the geometry in the product runner (eval_rcnn.GraphedRunner pairs batches: PRCNN_PAIR = 2): the
 # roofline legs of those kernels run at THIS size, and their PMC traffic comes from passes at this size
 def launch_scenes():
